@@ -1,0 +1,735 @@
+"""NumPy restatement of the TC-VIML back-end hot path -- TEST INFRASTRUCTURE ONLY.
+
+**Parity unpinned**: the reference ships no tests / golden vectors for this path and neither
+Ceres nor Eigen exist in the authoring container; this file is one of two
+independent restatements (the other is oracle/tcv_oracle.c) that must agree with each other.
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it.
+
+Every function cites the reference lines it follows (paths relative to
+/root/reference/vins_estimator/src/).  Quaternions are stored x,y,z,w (memory order of
+Eigen::Map<Quaterniond>, factor/pose_local_parameterization.cpp:6).
+
+The trust-region / dogleg loop restates upstream Ceres 2.x defaults (TrustRegionMinimizer,
+DoglegStrategy, SchurComplementSolver) -- *not in /root/reference*, unverified here
+(SURVEY.md Appendix C).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+O_P, O_R, O_V, O_BA, O_BG = 0, 3, 6, 9, 12          # parameters.h:66-73
+
+
+# --------------------------------------------------------------------------------------
+# utility/utility.h:15-68 and the Eigen behaviours listed in SURVEY.md Appendix A
+# --------------------------------------------------------------------------------------
+def qmul(a, b):
+    ax, ay, az, aw = a
+    bx, by, bz, bw = b
+    return np.array([aw * bx + ax * bw + ay * bz - az * by,
+                     aw * by - ax * bz + ay * bw + az * bx,
+                     aw * bz + ax * by - ay * bx + az * bw,
+                     aw * bw - ax * bx - ay * by - az * bz])
+
+
+def qinv(q):                     # Eigen inverse(): conjugate / squaredNorm
+    n2 = float(np.dot(q, q))
+    return np.array([-q[0], -q[1], -q[2], q[3]]) / n2
+
+
+def qrot(q, v):                  # Eigen _transformVector: v + 2w(u x v) + 2u x (u x v)
+    u = q[:3]
+    uv = np.cross(u, v)
+    uv = uv + uv
+    return v + q[3] * uv + np.cross(u, uv)
+
+
+def qnormalized(q):
+    return q / np.sqrt(np.dot(q, q))
+
+
+def q2R(q):                      # Eigen toRotationMatrix (no normalisation)
+    x, y, z, w = q
+    tx, ty, tz = 2 * x, 2 * y, 2 * z
+    twx, twy, twz = tx * w, ty * w, tz * w
+    txx, txy, txz = tx * x, ty * x, tz * x
+    tyy, tyz, tzz = ty * y, tz * y, tz * z
+    return np.array([[1 - (tyy + tzz), txy - twz, txz + twy],
+                     [txy + twz, 1 - (txx + tzz), tyz - twx],
+                     [txz - twy, tyz + twx, 1 - (txx + tyy)]])
+
+
+def deltaQ(theta):               # utility.h:15-28 (NOT normalised)
+    return np.array([theta[0] / 2, theta[1] / 2, theta[2] / 2, 1.0])
+
+
+def skew(v):                     # utility.h:30-38
+    return np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])
+
+
+def Qleft33(q):                  # utility.h:50-58, bottomRightCorner<3,3>; positify == identity (:40-48)
+    return q[3] * np.eye(3) + skew(q[:3])
+
+
+def Qright33(p):                 # utility.h:60-68
+    return p[3] * np.eye(3) - skew(p[:3])
+
+
+# --------------------------------------------------------------------------------------
+# S2: PoseLocalParameterization::Plus   factor/pose_local_parameterization.cpp:3-19
+# --------------------------------------------------------------------------------------
+def pose_plus(x, delta):
+    out = np.empty(7)
+    out[0:3] = x[0:3] + delta[0:3]
+    out[3:7] = qnormalized(qmul(x[3:7], deltaQ(delta[3:6])))
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# I0: IntegrationBase   factor/integration_base.h:13-158
+# --------------------------------------------------------------------------------------
+def preintegrate(acc, gyr, dt, lin_ba, lin_bg, acc_n, gyr_n, acc_w, gyr_w):
+    """acc/gyr: (S+1,3); sample 0 is (acc_0, gyr_0) of the constructor, 1..S are push_back()s."""
+    noise = np.zeros((18, 18))                      # :21-27 (ACC_N/GYR_N used for both k and k+1)
+    noise[0:3, 0:3] = acc_n * acc_n * np.eye(3)
+    noise[3:6, 3:6] = gyr_n * gyr_n * np.eye(3)
+    noise[6:9, 6:9] = acc_n * acc_n * np.eye(3)
+    noise[9:12, 9:12] = gyr_n * gyr_n * np.eye(3)
+    noise[12:15, 12:15] = acc_w * acc_w * np.eye(3)
+    noise[15:18, 15:18] = gyr_w * gyr_w * np.eye(3)
+    delta_p = np.zeros(3); delta_v = np.zeros(3); delta_q = np.array([0.0, 0, 0, 1])
+    jacobian = np.eye(15); covariance = np.zeros((15, 15)); sum_dt = 0.0
+    I3 = np.eye(3)
+    for k in range(acc.shape[0] - 1):
+        a0, g0, a1, g1 = acc[k], gyr[k], acc[k + 1], gyr[k + 1]
+        # midPointIntegration :54-128
+        un_acc_0 = qrot(delta_q, a0 - lin_ba)
+        un_gyr = 0.5 * (g0 + g1) - lin_bg
+        rq = qmul(delta_q, np.array([un_gyr[0] * dt / 2, un_gyr[1] * dt / 2, un_gyr[2] * dt / 2, 1.0]))
+        un_acc_1 = qrot(rq, a1 - lin_ba)
+        un_acc = 0.5 * (un_acc_0 + un_acc_1)
+        rp = delta_p + delta_v * dt + 0.5 * un_acc * dt * dt
+        rv = delta_v + un_acc * dt
+        w_x = 0.5 * (g0 + g1) - lin_bg
+        R_w_x = skew(w_x); R_a_0_x = skew(a0 - lin_ba); R_a_1_x = skew(a1 - lin_ba)
+        R0 = q2R(delta_q); R1 = q2R(rq)
+        F = np.zeros((15, 15))
+        F[0:3, 0:3] = I3
+        F[0:3, 3:6] = -0.25 * R0 @ R_a_0_x * dt * dt + -0.25 * R1 @ R_a_1_x @ (I3 - R_w_x * dt) * dt * dt
+        F[0:3, 6:9] = I3 * dt
+        F[0:3, 9:12] = -0.25 * (R0 + R1) * dt * dt
+        F[0:3, 12:15] = -0.25 * R1 @ R_a_1_x * dt * dt * -dt
+        F[3:6, 3:6] = I3 - R_w_x * dt
+        F[3:6, 12:15] = -1.0 * I3 * dt
+        F[6:9, 3:6] = -0.5 * R0 @ R_a_0_x * dt + -0.5 * R1 @ R_a_1_x @ (I3 - R_w_x * dt) * dt
+        F[6:9, 6:9] = I3
+        F[6:9, 9:12] = -0.5 * (R0 + R1) * dt
+        F[6:9, 12:15] = -0.5 * R1 @ R_a_1_x * dt * -dt
+        F[9:12, 9:12] = I3
+        F[12:15, 12:15] = I3
+        V = np.zeros((15, 18))
+        V[0:3, 0:3] = 0.25 * R0 * dt * dt
+        V[0:3, 3:6] = 0.25 * -R1 @ R_a_1_x * dt * dt * 0.5 * dt
+        V[0:3, 6:9] = 0.25 * R1 * dt * dt
+        V[0:3, 9:12] = V[0:3, 3:6]
+        V[3:6, 3:6] = 0.5 * I3 * dt
+        V[3:6, 9:12] = 0.5 * I3 * dt
+        V[6:9, 0:3] = 0.5 * R0 * dt
+        V[6:9, 3:6] = 0.5 * -R1 @ R_a_1_x * dt * 0.5 * dt
+        V[6:9, 6:9] = 0.5 * R1 * dt
+        V[6:9, 9:12] = V[6:9, 3:6]
+        V[9:12, 12:15] = I3 * dt
+        V[12:15, 15:18] = I3 * dt
+        jacobian = F @ jacobian
+        covariance = F @ covariance @ F.T + V @ noise @ V.T
+        # propagate :148-156
+        delta_p, delta_v = rp, rv
+        delta_q = qnormalized(rq)
+        sum_dt += dt
+    return dict(delta_p=delta_p, delta_q=delta_q, delta_v=delta_v, jacobian=jacobian,
+                covariance=covariance, sum_dt=sum_dt)
+
+
+# --------------------------------------------------------------------------------------
+# I1: IMUFactor::Evaluate   factor/imu_factor.h:19-181 + integration_base.h:160-186
+# --------------------------------------------------------------------------------------
+def imu_sqrt_info(cov):
+    """imu_factor.h:64  LLT(cov.inverse()).matrixL().transpose()  (upper triangular)."""
+    return np.linalg.cholesky(np.linalg.inv(cov)).T
+
+
+def imu_evaluate(pose_i, sb_i, pose_j, sb_j, pre, G, sqrt_info=None, want_jac=True):
+    Pi, Qi = pose_i[0:3], pose_i[3:7]
+    Vi, Bai, Bgi = sb_i[0:3], sb_i[3:6], sb_i[6:9]
+    Pj, Qj = pose_j[0:3], pose_j[3:7]
+    Vj, Baj, Bgj = sb_j[0:3], sb_j[3:6], sb_j[6:9]
+    jac = pre["jacobian"]
+    dp_dba = jac[O_P:O_P + 3, O_BA:O_BA + 3]; dp_dbg = jac[O_P:O_P + 3, O_BG:O_BG + 3]
+    dq_dbg = jac[O_R:O_R + 3, O_BG:O_BG + 3]
+    dv_dba = jac[O_V:O_V + 3, O_BA:O_BA + 3]; dv_dbg = jac[O_V:O_V + 3, O_BG:O_BG + 3]
+    sum_dt = pre["sum_dt"]
+    delta_q = pre["delta_q"]
+    # integration_base.h:173-184
+    dba = Bai - pre["lin_ba"]; dbg = Bgi - pre["lin_bg"]
+    corrected_delta_q = qmul(delta_q, deltaQ(dq_dbg @ dbg))
+    corrected_delta_v = pre["delta_v"] + dv_dba @ dba + dv_dbg @ dbg
+    corrected_delta_p = pre["delta_p"] + dp_dba @ dba + dp_dbg @ dbg
+    Qi_inv = qinv(Qi)
+    r = np.empty(15)
+    r[O_P:O_P + 3] = qrot(Qi_inv, 0.5 * G * sum_dt * sum_dt + Pj - Pi - Vi * sum_dt) - corrected_delta_p
+    r[O_R:O_R + 3] = 2 * qmul(qinv(corrected_delta_q), qmul(Qi_inv, Qj))[:3]
+    r[O_V:O_V + 3] = qrot(Qi_inv, G * sum_dt + Vj - Vi) - corrected_delta_v
+    r[O_BA:O_BA + 3] = Baj - Bai
+    r[O_BG:O_BG + 3] = Bgj - Bgi
+    if sqrt_info is None:
+        sqrt_info = imu_sqrt_info(pre["covariance"])
+    r = sqrt_info @ r
+    if not want_jac:
+        return r, None
+    Ri_inv = q2R(Qi_inv)
+    J0 = np.zeros((15, 7))                                          # imu_factor.h:88-113
+    J0[O_P:O_P + 3, O_P:O_P + 3] = -Ri_inv
+    J0[O_P:O_P + 3, O_R:O_R + 3] = skew(qrot(Qi_inv, 0.5 * G * sum_dt * sum_dt + Pj - Pi - Vi * sum_dt))
+    cdq = qmul(delta_q, deltaQ(dq_dbg @ (Bgi - pre["lin_bg"])))
+    J0[O_R:O_R + 3, O_R:O_R + 3] = -(_Qleft4(qmul(qinv(Qj), Qi)) @ _Qright4(cdq))[1:4, 1:4]
+    J0[O_V:O_V + 3, O_R:O_R + 3] = skew(qrot(Qi_inv, G * sum_dt + Vj - Vi))
+    J0 = sqrt_info @ J0
+    J1 = np.zeros((15, 9))                                          # :114-142
+    J1[O_P:O_P + 3, 0:3] = -Ri_inv * sum_dt
+    J1[O_P:O_P + 3, 3:6] = -dp_dba
+    J1[O_P:O_P + 3, 6:9] = -dp_dbg
+    J1[O_R:O_R + 3, 6:9] = -Qleft33(qmul(qmul(qinv(Qj), Qi), delta_q)) @ dq_dbg     # :127 (un-corrected delta_q)
+    J1[O_V:O_V + 3, 0:3] = -Ri_inv
+    J1[O_V:O_V + 3, 3:6] = -dv_dba
+    J1[O_V:O_V + 3, 6:9] = -dv_dbg
+    J1[O_BA:O_BA + 3, 3:6] = -np.eye(3)
+    J1[O_BG:O_BG + 3, 6:9] = -np.eye(3)
+    J1 = sqrt_info @ J1
+    J2 = np.zeros((15, 7))                                          # :143-161
+    J2[O_P:O_P + 3, O_P:O_P + 3] = Ri_inv
+    J2[O_R:O_R + 3, O_R:O_R + 3] = Qleft33(qmul(qmul(qinv(cdq), Qi_inv), Qj))
+    J2 = sqrt_info @ J2
+    J3 = np.zeros((15, 9))                                          # :162-177
+    J3[O_V:O_V + 3, 0:3] = Ri_inv
+    J3[O_BA:O_BA + 3, 3:6] = np.eye(3)
+    J3[O_BG:O_BG + 3, 6:9] = np.eye(3)
+    J3 = sqrt_info @ J3
+    return r, [J0, J1, J2, J3]
+
+
+def _Qleft4(q):
+    M = np.empty((4, 4))
+    M[0, 0] = q[3]; M[0, 1:4] = -q[:3]; M[1:4, 0] = q[:3]; M[1:4, 1:4] = q[3] * np.eye(3) + skew(q[:3])
+    return M
+
+
+def _Qright4(p):
+    M = np.empty((4, 4))
+    M[0, 0] = p[3]; M[0, 1:4] = -p[:3]; M[1:4, 0] = p[:3]; M[1:4, 1:4] = p[3] * np.eye(3) - skew(p[:3])
+    return M
+
+
+# --------------------------------------------------------------------------------------
+# P1: ProjectionFactor::Evaluate   factor/projection_factor.cpp:21-124
+# --------------------------------------------------------------------------------------
+def proj_evaluate(pose_i, pose_j, ex, lam, pts_i, pts_j, sqrt_info_scalar, want_jac=True):
+    Pi, Qi = pose_i[0:3], pose_i[3:7]
+    Pj, Qj = pose_j[0:3], pose_j[3:7]
+    tic, qic = ex[0:3], ex[3:7]
+    inv_dep_i = lam
+    pts_camera_i = pts_i / inv_dep_i
+    pts_imu_i = qrot(qic, pts_camera_i) + tic
+    pts_w = qrot(Qi, pts_imu_i) + Pi
+    pts_imu_j = qrot(qinv(Qj), pts_w - Pj)
+    pts_camera_j = qrot(qinv(qic), pts_imu_j - tic)
+    dep_j = pts_camera_j[2]
+    r = sqrt_info_scalar * ((pts_camera_j / dep_j)[:2] - pts_j[:2])
+    if not want_jac:
+        return r, None
+    Ri, Rj, ric = q2R(Qi), q2R(Qj), q2R(qic)
+    reduce = np.array([[1. / dep_j, 0, -pts_camera_j[0] / (dep_j * dep_j)],
+                       [0, 1. / dep_j, -pts_camera_j[1] / (dep_j * dep_j)]])
+    reduce = sqrt_info_scalar * reduce
+    J0 = np.zeros((2, 7)); J1 = np.zeros((2, 7)); J2 = np.zeros((2, 7))
+    jaco_i = np.hstack([ric.T @ Rj.T, ric.T @ Rj.T @ Ri @ -skew(pts_imu_i)])
+    J0[:, :6] = reduce @ jaco_i
+    jaco_j = np.hstack([ric.T @ -Rj.T, ric.T @ skew(pts_imu_j)])
+    J1[:, :6] = reduce @ jaco_j
+    tmp_r = ric.T @ Rj.T @ Ri @ ric
+    jaco_ex = np.hstack([ric.T @ (Rj.T @ Ri - np.eye(3)),
+                         -tmp_r @ skew(pts_camera_i) + skew(tmp_r @ pts_camera_i)
+                         + skew(ric.T @ (Rj.T @ (Ri @ tic + Pi - Pj) - tic))])
+    J2[:, :6] = reduce @ jaco_ex
+    J3 = (reduce @ ric.T @ Rj.T @ Ri @ ric @ pts_i * -1.0 / (inv_dep_i * inv_dep_i)).reshape(2, 1)
+    return r, [J0, J1, J2, J3]
+
+
+# --------------------------------------------------------------------------------------
+# L1: LineProjectionFactor::Evaluate   factor/line_projection_factor.cpp:19-120
+# (Jacobian is "as written", NOT the derivative of the residual -- SURVEY.md §8(a) L1)
+# --------------------------------------------------------------------------------------
+def line_evaluate(pose, pts_start, pts_end, abc, K, b_c_R, b_c_T, want_jac=True):
+    T_w = pose[0:3]
+    R_w = q2R(qnormalized(pose[3:7]))
+    R = b_c_R.T @ R_w.T
+    t = -R @ T_w - (b_c_R.T @ b_c_T)
+    pcs = R @ pts_start + t
+    pce = R @ pts_end + t
+    si = K @ pcs; ei = K @ pce
+    u_s, v_s = si[0] / si[2], si[1] / si[2]
+    u_e, v_e = ei[0] / ei[2], ei[1] / ei[2]
+    a, b, c = abc
+    d = a * a + b * b
+    mus = (b * b * u_s - a * b * v_s - a * c) / d
+    mvs = (a * a * v_s - a * b * u_s - b * c) / d
+    mue = (b * b * u_e - a * b * v_e - a * c) / d
+    mve = (a * a * v_e - a * b * u_e - b * c) / d
+    r = np.array([np.sqrt((mus - u_s) ** 2 + (mvs - v_s) ** 2),
+                  np.sqrt((mue - u_e) ** 2 + (mve - v_e) ** 2)])
+    if not want_jac:
+        return r, None
+    ep = np.array([[-2 / d * ((mus - u_s) * a * a + a * b * (mvs - v_s)),
+                    -2 / d * ((mus - u_s) * a * b + b * b * (mvs - v_s))]])
+    ep_ = np.array([[-2 / d * ((mue - u_e) * a * a + a * b * (mve - v_e)),
+                     -2 / d * ((mue - u_e) * a * b + b * b * (mve - v_e))]])
+    fx, fy = K[0, 0], K[1, 1]
+    pps = np.array([[fx / pcs[2], 0, -fx * pcs[0] / (pcs[2] * pcs[2])],
+                    [0, fy / pcs[2], -fy * pcs[1] / (pcs[2] * pcs[2])]])
+    ppe = np.array([[fx / pce[2], 0, -fx * pce[0] / (pce[2] * pce[2])],
+                    [0, fy / pce[2], -fy * pce[1] / (pce[2] * pce[2])]])
+    jaco_s = np.hstack([np.eye(3), skew(pcs)])
+    jaco_e = np.hstack([np.eye(3), skew(pce)])
+    J = np.zeros((2, 7))
+    J[0, :6] = (ep @ pps @ jaco_s)[0]
+    J[1, :6] = (ep_ @ ppe @ jaco_e)[0]
+    return r, [J]
+
+
+# --------------------------------------------------------------------------------------
+# C1: loss + corrector   marginalization_factor.cpp:37-68 ; CauchyLoss per upstream Ceres
+# --------------------------------------------------------------------------------------
+def cauchy_rho(s, a):
+    b = a * a
+    c = 1.0 / b
+    ssum = 1.0 + s * c
+    inv = 1.0 / ssum
+    return np.array([b * np.log(ssum), max(np.finfo(float).tiny, inv), -c * (inv * inv)])
+
+
+def loss_correct(r, Js, loss_a):
+    """returns corrected r, corrected Js, block cost (0.5*rho0)."""
+    s = float(np.dot(r, r))
+    if loss_a is None or loss_a <= 0:
+        return r, Js, 0.5 * s
+    rho = cauchy_rho(s, loss_a)
+    sqrt_rho1 = np.sqrt(rho[1])
+    if s == 0.0 or rho[2] <= 0.0:
+        residual_scaling, alpha_sq_norm = sqrt_rho1, 0.0
+    else:
+        D = 1.0 + 2.0 * s * rho[2] / rho[1]
+        alpha = 1.0 - np.sqrt(D)
+        residual_scaling = sqrt_rho1 / (1 - alpha)
+        alpha_sq_norm = alpha / s
+    if Js is not None:
+        Js = [sqrt_rho1 * (J - alpha_sq_norm * np.outer(r, r @ J)) for J in Js]
+    return r * residual_scaling, Js, 0.5 * rho[0]
+
+
+# --------------------------------------------------------------------------------------
+# M0: MarginalizationFactor::Evaluate   marginalization_factor.cpp:335-384
+# --------------------------------------------------------------------------------------
+def prior_evaluate(prior, blocks_x, want_jac=True):
+    n = prior["n"]
+    dx = np.zeros(n)
+    for k, x in enumerate(blocks_x):
+        size = prior["sizes"][k]; idx = prior["idx"][k]; x0 = prior["x0"][k]
+        if size != 7:
+            dx[idx:idx + size] = x - x0
+        else:
+            dx[idx:idx + 3] = x[0:3] - x0[0:3]
+            dq = qmul(qinv(x0[3:7]), x[3:7])
+            dx[idx + 3:idx + 6] = 2.0 * dq[:3]
+            if not (dq[3] >= 0):
+                dx[idx + 3:idx + 6] = 2.0 * -dq[:3]
+    r = prior["r0"] + prior["J0"] @ dx
+    if not want_jac:
+        return r, None
+    Js = []
+    for k in range(len(blocks_x)):
+        size = prior["sizes"][k]; idx = prior["idx"][k]
+        local = 6 if size == 7 else size
+        J = np.zeros((n, size))
+        J[:, :local] = prior["J0"][:, idx:idx + local]
+        Js.append(J)
+    return r, Js
+
+
+# --------------------------------------------------------------------------------------
+# G1: problem structure (estimator.cpp:1679-1886).  Camera-side parameter blocks are ordered
+# pose0, sb0, pose1, sb1, ..., ex ; landmarks follow.
+# --------------------------------------------------------------------------------------
+class Problem:
+    def __init__(self, win, ex_constant=False, const_blocks=()):
+        self.win = win
+        F = win["pose"].shape[0]
+        L = win["lam"].shape[0]
+        self.F, self.L = F, L
+        self.blocks = []                       # (name, idx, gsize)
+        for i in range(F):
+            self.blocks.append(("pose", i, 7)); self.blocks.append(("sb", i, 9))
+        self.blocks.append(("ex", 0, 7))
+        for l in range(L):
+            self.blocks.append(("lam", l, 1))
+        self.const = set(const_blocks)
+        if ex_constant:
+            self.const.add(("ex", 0))
+        self.loff = {}
+        off = 0
+        for (nm, i, g) in self.blocks:
+            if (nm, i) in self.const:
+                self.loff[(nm, i)] = -1
+                continue
+            self.loff[(nm, i)] = off
+            off += 6 if g == 7 else g
+        self.nlocal = off
+        self.nc = off - sum(1 for l in range(L) if ("lam", l) not in self.const)
+
+    def x0(self):
+        w = self.win
+        return dict(pose=w["pose"].copy(), sb=w["speedbias"].copy(), ex=w["ex_pose"].copy(), lam=w["lam"].copy())
+
+    @staticmethod
+    def get(x, nm, i):
+        if nm == "pose": return x["pose"][i]
+        if nm == "sb": return x["sb"][i]
+        if nm == "ex": return x["ex"]
+        return x["lam"][i:i + 1]
+
+    def factors(self):
+        """list of (kind, index, [(name, idx)...])  in estimator.cpp order: prior, imu, points, lines."""
+        w = self.win
+        out = []
+        if w.get("prior") is not None:
+            out.append(("prior", 0, list(w["prior"]["blocks"])))
+        im = w["imu"]
+        for k in range(len(im["frame_i"])):
+            if im["sum_dt"][k] > 10.0:              # estimator.cpp:1726
+                continue
+            i, j = int(im["frame_i"][k]), int(im["frame_j"][k])
+            out.append(("imu", k, [("pose", i), ("sb", i), ("pose", j), ("sb", j)]))
+        pr = w["proj"]
+        for k in range(len(pr["frame_i"])):
+            out.append(("proj", k, [("pose", int(pr["frame_i"][k])), ("pose", int(pr["frame_j"][k])),
+                                    ("ex", 0), ("lam", int(pr["landmark"][k]))]))
+        ln = w["line"]
+        for k in range(len(ln["frame"])):
+            out.append(("line", k, [("pose", int(ln["frame"][k]))]))
+        return out
+
+    def eval_factor(self, fac, x, want_jac=True, imu_sqrt=None):
+        kind, k, blks = fac
+        w = self.win
+        xs = [self.get(x, nm, i) for (nm, i) in blks]
+        if kind == "imu":
+            im = w["imu"]
+            pre = dict(delta_p=im["delta_p"][k], delta_q=im["delta_q"][k], delta_v=im["delta_v"][k],
+                       lin_ba=im["lin_ba"][k], lin_bg=im["lin_bg"][k], sum_dt=float(im["sum_dt"][k]),
+                       jacobian=im["jacobian"][k], covariance=im["covariance"][k])
+            si = None if imu_sqrt is None else imu_sqrt[k]
+            r, Js = imu_evaluate(xs[0], xs[1], xs[2], xs[3], pre, w["G"], sqrt_info=si, want_jac=want_jac)
+            return loss_correct(r, Js, None)
+        if kind == "proj":
+            pr = w["proj"]
+            r, Js = proj_evaluate(xs[0], xs[1], xs[2], float(xs[3][0]), pr["pts_i"][k], pr["pts_j"][k],
+                                  pr["sqrt_info"], want_jac)
+            return loss_correct(r, Js, pr["loss_a"])
+        if kind == "line":
+            ln = w["line"]
+            r, Js = line_evaluate(xs[0], ln["pts_start"][k], ln["pts_end"][k], ln["abc"][k], ln["K"], ln["Ric"],
+                                  ln["Tic"], want_jac)
+            return loss_correct(r, Js, ln["loss_a"])
+        if kind == "prior":
+            r, Js = prior_evaluate(w["prior"], xs, want_jac)
+            return loss_correct(r, Js, None)
+        raise ValueError(kind)
+
+    def linearize(self, x, imu_sqrt=None, want_jac=True):
+        """dense local Jacobian (rows x nlocal), residual vector, cost."""
+        facs = self.factors()
+        rows = []
+        cost = 0.0
+        rs = []
+        for fac in facs:
+            r, Js, c = self.eval_factor(fac, x, want_jac, imu_sqrt)
+            cost += c
+            rs.append(r)
+            if want_jac:
+                Jrow = np.zeros((len(r), self.nlocal))
+                for (nm, i), J in zip(fac[2], Js):
+                    lo = self.loff[(nm, i)]
+                    if lo < 0:
+                        continue
+                    ls = 6 if J.shape[1] == 7 else J.shape[1]
+                    Jrow[:, lo:lo + ls] += J[:, :ls]      # local J = global J * [I;0]  (S2 ComputeJacobian)
+                rows.append(Jrow)
+        r = np.concatenate(rs)
+        J = np.vstack(rows) if want_jac else None
+        return J, r, cost
+
+    def plus(self, x, delta):
+        out = dict(pose=x["pose"].copy(), sb=x["sb"].copy(), ex=x["ex"].copy(), lam=x["lam"].copy())
+        for (nm, i, g) in self.blocks:
+            lo = self.loff[(nm, i)]
+            if lo < 0:
+                continue
+            if nm == "pose":
+                out["pose"][i] = pose_plus(x["pose"][i], delta[lo:lo + 6])
+            elif nm == "ex":
+                out["ex"] = pose_plus(x["ex"], delta[lo:lo + 6])
+            elif nm == "sb":
+                out["sb"][i] = x["sb"][i] + delta[lo:lo + 9]
+            else:
+                out["lam"][i] = x["lam"][i] + delta[lo]
+        return out
+
+    def ambient(self, x):
+        parts = []
+        for (nm, i, g) in self.blocks:
+            if self.loff[(nm, i)] < 0:
+                continue
+            parts.append(np.atleast_1d(self.get(x, nm, i)))
+        return np.concatenate(parts)
+
+
+# --------------------------------------------------------------------------------------
+# Linear solve: (J'J + mu D^2) y = J'r with landmark Schur elimination + dense Cholesky
+# (SPARSE_SCHUR restated densely; any exact elimination order is equivalent)
+# --------------------------------------------------------------------------------------
+def schur_solve(H, g, nc):
+    """H (n x n) SPD-ish with diagonal landmark block H[nc:,nc:]; returns y or None on failure."""
+    n = H.shape[0]
+    Hcc = H[:nc, :nc]; Hcl = H[:nc, nc:]; hll = np.diag(H)[nc:]
+    if np.any(hll <= 0) or not np.all(np.isfinite(hll)):
+        return None
+    W = Hcl / hll
+    S = Hcc - W @ Hcl.T
+    rhs = g[:nc] - W @ g[nc:]
+    try:
+        Lc = np.linalg.cholesky(S)
+    except np.linalg.LinAlgError:
+        return None
+    z = np.linalg.solve(Lc, rhs)
+    yc = np.linalg.solve(Lc.T, z)
+    yl = (g[nc:] - Hcl.T @ yc) / hll
+    y = np.concatenate([yc, yl])
+    if not np.all(np.isfinite(y)):
+        return None
+    return y
+
+
+# --------------------------------------------------------------------------------------
+# Trust-region minimiser with traditional dogleg -- upstream Ceres 2.x defaults, unverified
+# here; options set by the reference: estimator.cpp:1888-1897.
+# --------------------------------------------------------------------------------------
+def solve(prob: Problem, max_num_iterations=8, fixed_iterations=False, imu_sqrt=None, trace=None):
+    x = prob.x0()
+    nc = prob.nc
+    J, r, cost = prob.linearize(x, imu_sqrt)
+    # jacobi scaling, computed once at iteration 0
+    scale = 1.0 / (1.0 + np.sqrt((J * J).sum(0)))
+    J = J * scale
+    grad_unscaled = (J / scale).T @ r
+    summary = dict(initial_cost=cost, iterations=[dict(it=0, cost=cost, step_ok=True)], termination="NO_CONVERGENCE")
+    if not fixed_iterations and np.max(np.abs(grad_unscaled)) <= 1e-10:
+        summary["termination"] = "CONVERGENCE_GRADIENT"; summary["final_cost"] = cost
+        return x, summary
+    radius, mu, reuse, invalid = 1e4, 1e-8, False, 0
+    min_mu, max_mu, mu_inc = 1e-8, 1.0, 10.0
+    x_norm = np.linalg.norm(prob.ambient(x))
+    it = 0
+    diag = grad = gn = None
+    alpha = 0.0
+    while True:
+        if it >= max_num_iterations:
+            break
+        it += 1
+        rec = dict(it=it)
+        # ---- DoglegStrategy::ComputeStep
+        step_valid_ls = True
+        if not reuse:
+            reuse = True
+            diag = np.sqrt(np.clip((J * J).sum(0), 1e-6, 1e32))
+            grad = (J.T @ r) / diag
+            Jg = J @ (grad / diag)
+            alpha = float(grad @ grad) / float(Jg @ Jg)
+            H = J.T @ J
+            g = J.T @ r
+            y = None
+            while mu < max_mu:
+                y = schur_solve(H + np.diag(mu * diag * diag), g, nc)
+                if y is None:
+                    mu *= mu_inc
+                    continue
+                break
+            if y is None:
+                step_valid_ls = False
+            else:
+                gn = -diag * y
+        rec["mu"] = mu
+        if step_valid_ls:
+            gnorm = np.linalg.norm(grad); gn_norm = np.linalg.norm(gn)
+            if gn_norm <= radius:
+                step = gn.copy(); step_norm = gn_norm; case = 1
+            elif gnorm * alpha >= radius:
+                step = -(radius / gnorm) * grad; step_norm = radius; case = 2
+            else:
+                b_dot_a = -alpha * float(grad @ gn)
+                a_sq = (alpha * gnorm) ** 2
+                bma_sq = a_sq - 2 * b_dot_a + gn_norm ** 2
+                c = b_dot_a - a_sq
+                d = np.sqrt(c * c + bma_sq * (radius ** 2 - a_sq))
+                beta = (d - c) / bma_sq if c <= 0 else (radius * radius - a_sq) / (d + c)
+                step = (-alpha * (1.0 - beta)) * grad + beta * gn
+                step_norm = np.linalg.norm(step); case = 3
+            step = step / diag
+            rec["case"] = case
+            Jstep = J @ step
+            model_cost_change = -float(Jstep @ (r + Jstep / 2.0))
+            step_valid = model_cost_change > 0.0
+        else:
+            step_valid = False
+        if not step_valid:
+            invalid += 1
+            rec["step_ok"] = False; rec["invalid"] = True; rec["cost"] = cost
+            summary["iterations"].append(rec)
+            if invalid >= 5:
+                summary["termination"] = "FAILURE"
+                break
+            mu *= mu_inc; reuse = False       # DoglegStrategy::StepIsInvalid
+            continue
+        invalid = 0
+        delta = step * scale
+        x_c = prob.plus(x, delta)
+        _, r_c, cost_c = prob.linearize(x_c, imu_sqrt, want_jac=False)
+        rec.update(model_cost_change=model_cost_change, cost_candidate=cost_c, radius=radius,
+                   step_norm_dogleg=step_norm, delta=delta.copy())
+        dxn = np.linalg.norm(prob.ambient(x) - prob.ambient(x_c))
+        if not fixed_iterations and dxn <= 1e-8 * (x_norm + 1e-8):
+            rec["cost"] = cost; summary["iterations"].append(rec)
+            summary["termination"] = "CONVERGENCE_PARAMETER"
+            break
+        cost_change = cost - cost_c
+        if not fixed_iterations and abs(cost_change) <= 1e-6 * cost:
+            rec["cost"] = cost; summary["iterations"].append(rec)
+            summary["termination"] = "CONVERGENCE_FUNCTION"
+            break
+        rho = cost_change / model_cost_change
+        rec["rho"] = rho
+        if rho > 1e-3:
+            x = x_c
+            x_norm = np.linalg.norm(prob.ambient(x))
+            J, r, cost = prob.linearize(x, imu_sqrt)
+            grad_unscaled = J.T @ r
+            J = J * scale
+            rec["step_ok"] = True
+            if rho < 0.25:
+                radius *= 0.5
+            if rho > 0.75:
+                radius = max(radius, 3.0 * step_norm)
+            mu = max(min_mu, 2.0 * mu / mu_inc)
+            reuse = False
+            rec["cost"] = cost
+            summary["iterations"].append(rec)
+            if not fixed_iterations and np.max(np.abs(grad_unscaled)) <= 1e-10:
+                summary["termination"] = "CONVERGENCE_GRADIENT"
+                break
+        else:
+            rec["step_ok"] = False
+            radius *= 0.5
+            reuse = True
+            rec["cost"] = cost
+            summary["iterations"].append(rec)
+        if radius < 1e-32:
+            summary["termination"] = "CONVERGENCE_RADIUS"
+            break
+    summary["final_cost"] = cost
+    summary["scale"] = scale
+    return x, summary
+
+
+# --------------------------------------------------------------------------------------
+# M1-M4: marginalisation   marginalization_factor.cpp:89-321 ; estimator.cpp:1907-2046 (MARGIN_OLD)
+# Deterministic block order: dropped camera blocks, dropped landmarks, then kept blocks, each
+# in problem order (the reference's order is unordered_map/address dependent).
+# --------------------------------------------------------------------------------------
+def marginalize_old(prob: Problem, x, imu_sqrt=None, eps=1e-8):
+    w = prob.win
+    facs = []
+    for fac in prob.factors():
+        kind, k, blks = fac
+        if kind == "prior":
+            drop = [bi for bi, b in enumerate(blks) if b in (("pose", 0), ("sb", 0))]     # estimator.cpp:1918-1924
+            facs.append((fac, drop))
+        elif kind == "imu" and blks[0] == ("pose", 0):
+            if float(w["imu"]["sum_dt"][k]) < 10.0:                                      # :1936
+                facs.append((fac, [0, 1]))
+        elif kind == "proj" and blks[0] == ("pose", 0):                                   # :1957-1986
+            facs.append((fac, [0, 3]))
+    order = {nm_i: n for n, nm_i in enumerate((nm, i) for (nm, i, g) in prob.blocks)}
+    gsize = {(nm, i): g for (nm, i, g) in prob.blocks}
+    touched, dropped = set(), set()
+    for fac, drop in facs:
+        for b in fac[2]:
+            touched.add(b)
+        for d in drop:
+            dropped.add(fac[2][d])
+    drop_list = sorted(dropped, key=lambda b: order[b])
+    keep_list = sorted(touched - dropped, key=lambda b: order[b])
+    idx = {}
+    pos = 0
+    for b in drop_list + keep_list:
+        idx[b] = pos
+        pos += 6 if gsize[b] == 7 else gsize[b]
+        if b == drop_list[-1]:
+            m = pos
+    n = pos - m
+    A = np.zeros((pos, pos)); bvec = np.zeros(pos)
+    for fac, drop in facs:
+        r, Js, _ = prob.eval_factor(fac, x, True, imu_sqrt)           # ResidualBlockInfo::Evaluate (:3-69)
+        blks = fac[2]
+        for i in range(len(blks)):
+            si = 6 if gsize[blks[i]] == 7 else gsize[blks[i]]
+            Ji = Js[i][:, :si]
+            for j in range(i, len(blks)):
+                sj = 6 if gsize[blks[j]] == 7 else gsize[blks[j]]
+                Jj = Js[j][:, :sj]
+                ii, jj = idx[blks[i]], idx[blks[j]]
+                if i == j:
+                    A[ii:ii + si, jj:jj + sj] += Ji.T @ Jj
+                else:
+                    A[ii:ii + si, jj:jj + sj] += Ji.T @ Jj
+                    A[jj:jj + sj, ii:ii + si] = A[ii:ii + si, jj:jj + sj].T
+            bvec[idx[blks[i]]:idx[blks[i]] + si] += Ji.T @ r
+    A_full = A.copy(); b_full = bvec.copy()
+    Amm = 0.5 * (A[:m, :m] + A[:m, :m].T)
+    lam_m, V_m = np.linalg.eigh(Amm)
+    inv_m = np.where(lam_m > eps, 1.0 / np.where(lam_m > eps, lam_m, 1.0), 0.0)
+    Amm_inv = V_m @ np.diag(inv_m) @ V_m.T
+    bmm = bvec[:m]; Amr = A[:m, m:]; Arm = A[m:, :m]; Arr = A[m:, m:]; brr = bvec[m:]
+    A2 = Arr - Arm @ Amm_inv @ Amr
+    b2 = brr - Arm @ Amm_inv @ bmm
+    lam2, V2 = np.linalg.eigh(A2)
+    S = np.where(lam2 > eps, lam2, 0.0)
+    S_inv = np.where(lam2 > eps, 1.0 / np.where(lam2 > eps, lam2, 1.0), 0.0)
+    J0 = np.diag(np.sqrt(S)) @ V2.T
+    r0 = np.diag(np.sqrt(S_inv)) @ V2.T @ b2
+    # getParameterBlocks with addr_shift pose i -> i-1, sb i -> i-1, ex -> ex (estimator.cpp:2027-2039)
+    blocks, sizes, kidx, x0 = [], [], [], []
+    for b in keep_list:
+        nm, i = b
+        blocks.append((nm, i - 1) if nm in ("pose", "sb") else b)
+        sizes.append(gsize[b]); kidx.append(idx[b] - m)
+        x0.append(np.atleast_1d(Problem.get(x, nm, i)).copy())
+    prior = dict(n=n, m=m, blocks=blocks, sizes=sizes, idx=kidx, x0=x0, J0=J0, r0=r0)
+    dbg = dict(A=A_full, b=b_full, A_schur=A2, b_schur=b2, drop=drop_list, keep=keep_list, m=m, n=n)
+    return prior, dbg
