@@ -1,0 +1,208 @@
+/* tcv.h -- C-ABI of the MI355X-native sliding-window factor-graph solver that replaces the
+ * Ceres-based back end of TC-VIML's vins_estimator (Estimator::OptimizationWithLine,
+ * reference vins_estimator/src/estimator.cpp:1677-2119).
+ *
+ * The reference has no FFI; its hot path talks to Ceres through C++ virtual classes.  Every
+ * entry point below names the reference call it stands in for (paths relative to
+ * /root/reference/vins_estimator/src/).  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Conventions (identical to the reference):
+ *   pose block      double[7] = px py pz qx qy qz qw      (estimator.h:166, estimator.cpp:1496-1503)
+ *   speed-bias      double[9] = v(3) ba(3) bg(3)          (estimator.h:167)
+ *   inverse depth   double[1]                             (estimator.h:168)
+ *   Jacobians       row-major num_residuals x global_size (ceres::CostFunction::Evaluate)
+ *   all arithmetic  FP64
+ *
+ * Error convention: every function returns 0 (TCV_OK) or a negative tcv_status; nothing aborts.
+ * The reference ignores Ceres failures (estimator.cpp:1900-1903); here they are reported.
+ * A handle is single-threaded; distinct handles are independent.
+ */
+#ifndef TCV_H
+#define TCV_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    TCV_OK = 0,
+    TCV_ERR_INVALID = -1,     /* bad argument / unknown parameter block / inconsistent sizes     */
+    TCV_ERR_NO_DEVICE = -2,   /* no HIP device: the product never falls back to a CPU path        */
+    TCV_ERR_TOO_LARGE = -3,   /* window exceeds the on-chip (LDS) budget of the fused solver       */
+    TCV_ERR_HIP = -4,         /* HIP runtime error, see tcv_last_error()                           */
+    TCV_ERR_UNSUPPORTED = -5, /* structure the fused kernels do not implement                      */
+    TCV_ERR_NUMERIC = -6      /* NaN/Inf in inputs or solver failure; caller state left untouched  */
+} tcv_status;
+
+typedef enum { TCV_PARAM_EUCLIDEAN = 0, TCV_PARAM_POSE = 1 } tcv_parameterization; /* pose_local_parameterization.h:7-13 */
+typedef enum { TCV_LOSS_NONE = 0, TCV_LOSS_CAUCHY = 1 } tcv_loss;                  /* estimator.cpp:1682 CauchyLoss(1.0) */
+
+typedef struct tcv_problem tcv_problem; /* ceres::Problem           estimator.cpp:1679 */
+typedef struct tcv_prior tcv_prior;     /* MarginalizationInfo      marginalization_factor.h:46-72 */
+typedef struct tcv_batch tcv_batch;     /* device-resident batch of independent windows (throughput mode) */
+
+/* IntegrationBase fields read by IMUFactor (imu_factor.h:16,61-79; integration_base.h:188-203). */
+typedef struct {
+    double delta_p[3];
+    double delta_q[4]; /* x y z w */
+    double delta_v[3];
+    double linearized_ba[3];
+    double linearized_bg[3];
+    double sum_dt;
+    double jacobian[225];   /* 15x15 row-major, state order P,R,V,BA,BG (parameters.h:66-73) */
+    double covariance[225]; /* 15x15 row-major */
+} tcv_imu_preintegration;
+
+/* ceres::Solver::Options fields the reference sets (estimator.cpp:1888-1897) + determinism switch. */
+typedef struct {
+    int max_num_iterations;            /* NUM_ITERATIONS                                             */
+    double max_solver_time_in_seconds; /* <= 0: ignore wall clock (deterministic)                    */
+    int fixed_iterations;              /* 1: run exactly max_num_iterations, convergence tests off   */
+    int compute_sqrt_info_on_device;   /* 1 (default): imu_factor.h:64 evaluated in the kernel        */
+    int use_mfma;                      /* 1 (default): trailing Cholesky update on v_mfma_f64_16x16x4_f64; 0: FP64 VALU (debug) */
+    int threads_per_window;            /* 256 (default) or 512 threads per workgroup / window          */
+    int record_first_step;             /* 1: keep the tangent step of iteration 1 (parity tests)      */
+} tcv_solver_options;
+
+#define TCV_MAX_TRACE 64
+/* ceres::Solver::Summary subset (estimator.cpp:1899-1902 reads iterations.size()) + parity trace. */
+typedef struct {
+    int num_iterations;   /* = summary.iterations.size(): iteration 0 + accepted + rejected steps   */
+    int termination;      /* 0 NO_CONVERGENCE 1 gradient 2 parameter 3 function 4 radius 5 FAILURE */
+    double initial_cost, final_cost;
+    double cost[TCV_MAX_TRACE], cost_candidate[TCV_MAX_TRACE], model_cost_change[TCV_MAX_TRACE];
+    double radius[TCV_MAX_TRACE], mu[TCV_MAX_TRACE], rho[TCV_MAX_TRACE], step_norm[TCV_MAX_TRACE];
+    int step_ok[TCV_MAX_TRACE], dogleg_case[TCV_MAX_TRACE];
+} tcv_solver_summary;
+
+/* Frame-indexed description of one window: the arrays Estimator owns (estimator.h:166-172) plus
+ * the factor lists OptimizationWithLine walks.  tcv_problem_from_window() performs the graph
+ * construction of estimator.cpp:1683-1846 on it. */
+typedef struct {
+    int n_frames, n_landmarks, n_imu, n_proj, n_line;
+    int estimate_extrinsic;    /* 0: SetParameterBlockConstant(para_Ex_Pose) estimator.cpp:1694-1698 */
+    double *para_pose;         /* n_frames x 7, updated in place by solve */
+    double *para_speedbias;    /* n_frames x 9 */
+    double *para_ex_pose;      /* 7 */
+    double *para_feature;      /* n_landmarks */
+    const int *imu_frame_i, *imu_frame_j;
+    const tcv_imu_preintegration *imu; /* n_imu */
+    const int *proj_frame_i, *proj_frame_j, *proj_feature;
+    const double *proj_pts;    /* n_proj x 6: pts_i xyz, pts_j xyz */
+    double proj_sqrt_info;     /* ProjectionFactor::sqrt_info(0,0) = FOCAL_LENGTH/1.5, estimator.cpp:48 */
+    double proj_loss_a;        /* CauchyLoss scale, <= 0: no loss */
+    const int *line_frame;
+    const double *line_data;   /* n_line x 9: pts_start xyz, pts_end xyz, A B C (line_projection_factor.cpp:6-17) */
+    double line_K[9], line_Ric[9], line_Tic[3]; /* row-major; captured constants estimator.cpp:1777-1781,1834 */
+    double line_loss_a;
+    double gravity[3];         /* global G, parameters.cpp:11,91 */
+    const tcv_prior *prior;    /* last_marginalization_info or NULL, estimator.cpp:1714-1720 */
+    /* which blocks the prior is attached to, in the prior's keep-block order: kind 0 pose,1 speedbias,2 ex */
+    const int *prior_block_kind, *prior_block_index;
+} tcv_window_desc;
+
+/* ---- library ------------------------------------------------------------------------------ */
+const char *tcv_version(void);
+const char *tcv_last_error(void);
+int tcv_device_count(void);            /* 0 when no HIP device is visible */
+int tcv_set_device(int device);
+
+/* ---- ceres::Problem surface (estimator.cpp:1679-1886) ---------------------------------------- */
+int tcv_problem_create(tcv_problem **out);
+void tcv_problem_destroy(tcv_problem *p);
+/* Problem::AddParameterBlock(double*, int[, LocalParameterization*])   estimator.cpp:1686-1687,1693,1838 */
+int tcv_problem_add_parameter_block(tcv_problem *p, double *values, int size, int parameterization);
+/* Problem::SetParameterBlockConstant   estimator.cpp:1697 */
+int tcv_problem_set_parameter_block_constant(tcv_problem *p, double *values);
+int tcv_problem_set_gravity(tcv_problem *p, const double G[3]);
+/* AddResidualBlock(new IMUFactor(pre), NULL, P_i, SB_i, P_j, SB_j)   estimator.cpp:1728-1731 */
+int tcv_problem_add_imu_factor(tcv_problem *p, const tcv_imu_preintegration *pre, double *pose_i,
+                               double *speedbias_i, double *pose_j, double *speedbias_j);
+/* AddResidualBlock(new ProjectionFactor(pts_i, pts_j), loss, P_i, P_j, Ex, Feature)   estimator.cpp:1766-1767 */
+int tcv_problem_add_projection_factor(tcv_problem *p, const double pts_i[3], const double pts_j[3],
+                                      double sqrt_info, double loss_a, double *pose_i, double *pose_j,
+                                      double *ex_pose, double *inv_depth);
+/* AddResidualBlock(new LineProjectionFactor(ps, pe, abc, K, Ric, Tic), loss, P_f)   estimator.cpp:1834-1840 */
+int tcv_problem_add_line_factor(tcv_problem *p, const double pts_start[3], const double pts_end[3],
+                                const double line_abc[3], const double K[9], const double b_c_R[9],
+                                const double b_c_T[3], double loss_a, double *pose);
+/* AddResidualBlock(new MarginalizationFactor(info), NULL, last_marginalization_parameter_blocks)  :1717-1719 */
+int tcv_problem_add_marginalization_factor(tcv_problem *p, const tcv_prior *prior, double *const *blocks,
+                                           int num_blocks);
+/* graph construction of estimator.cpp:1683-1846 from frame-indexed arrays */
+int tcv_problem_from_window(const tcv_window_desc *w, tcv_problem **out);
+int tcv_problem_num_parameter_blocks(const tcv_problem *p);
+int tcv_problem_num_residual_blocks(const tcv_problem *p);
+int tcv_problem_num_residuals(const tcv_problem *p);
+/* host-only (no device needed): packs the problem into the device plan/data layout and reports
+ * out[16] = nc, nx, npp, nland, tile rows, visual chunks, imu chunks, visual units/items, Schur units/items,
+ * imu units/items, plan ints, window doubles, LDS bytes.  Error codes as tcv_batch_create. */
+int tcv_problem_plan_stats(const tcv_problem *p, int *out16);
+
+/* ceres::Solve(options, &problem, &summary)   estimator.cpp:1900.  Updates the caller's blocks in place. */
+void tcv_solver_options_default(tcv_solver_options *o);
+int tcv_solve(const tcv_solver_options *o, tcv_problem *p, tcv_solver_summary *summary);
+
+/* ---- MarginalizationInfo surface (marginalization_factor.cpp:89-321, estimator.cpp:1913-2044) -- */
+/* `p` holds exactly the factors the reference would wrap in ResidualBlockInfo; `drop` lists the
+ * parameter blocks of the drop_sets.  Equivalent to addResidualBlockInfo* + preMarginalize +
+ * marginalize.  The new prior keeps the current values of the kept blocks as linearisation point. */
+int tcv_marginalize(tcv_problem *p, double *const *drop, int num_drop, tcv_prior **out);
+/* MarginalizationInfo fields: m, n, keep_block_size/idx/data, linearized_jacobians (n x n,
+ * column-major like Eigen::MatrixXd), linearized_residuals (marginalization_factor.h:57-70). */
+int tcv_prior_create(tcv_prior **out, int m, int n, int num_blocks, const int *keep_block_size,
+                     const int *keep_block_idx, const double *keep_block_data_concat,
+                     const double *linearized_jacobians, const double *linearized_residuals);
+int tcv_prior_dims(const tcv_prior *pr, int *m, int *n, int *num_blocks, int *sum_block_size);
+int tcv_prior_export(const tcv_prior *pr, int *keep_block_size, int *keep_block_idx,
+                     double *keep_block_data_concat, double *linearized_jacobians, double *linearized_residuals);
+/* getParameterBlocks(): addresses (un-shifted) of the kept blocks, caller applies addr_shift  :301-321 */
+int tcv_prior_keep_block_addresses(const tcv_prior *pr, double **addresses);
+void tcv_prior_destroy(tcv_prior *pr);
+
+/* ---- throughput mode: many independent windows resident in HBM ------------------------------ */
+/* marg_problems[i] (optional, may be NULL array) shares parameter-block addresses with problems[i]
+ * and holds the marginalisation factor set; drop lists as in tcv_marginalize. */
+int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, tcv_problem *const *marg_problems,
+                     double *const *const *marg_drop, const int *marg_num_drop, int n);
+void tcv_batch_destroy(tcv_batch *b);
+/* one pass of the hot path over the batch: solve every window from its uploaded initial state
+ * (and, if marg problems were given, marginalise at the solution).  Asynchronous on `hip_stream`
+ * (a hipStream_t cast to void*, NULL = default stream); inputs and outputs stay in HBM. */
+int tcv_batch_solve(tcv_batch *b, const tcv_solver_options *o, void *hip_stream);
+int tcv_batch_marginalize(tcv_batch *b, void *hip_stream);
+int tcv_batch_synchronize(tcv_batch *b);
+/* copy results back: states into the callers' parameter blocks, summaries, priors */
+int tcv_batch_download_states(tcv_batch *b);
+int tcv_batch_get_summaries(tcv_batch *b, tcv_solver_summary *out, int n);
+int tcv_batch_get_prior(tcv_batch *b, int window, tcv_prior **out);
+/* tangent step of iteration 1 (needs record_first_step): free camera blocks in the order they were
+ * added (local size each), then the inverse depths in order of first use.  Parity/debug surface. */
+int tcv_batch_get_first_step(tcv_batch *b, int window, double *out, int cap, int *len);
+/* number of distinct graph structures (plans) in the batch, their bytes, launch grid and LDS bytes */
+int tcv_batch_plan_stats(tcv_batch *b, int *num_plans, double *plan_bytes, int *grid, int *lds_bytes);
+/* bytes of window input resident in HBM and elapsed milliseconds of the last solve / marginalise
+ * kernels measured with HIP events on the launch stream */
+int tcv_batch_stats(tcv_batch *b, double *input_bytes, double *solve_ms, double *marg_ms);
+int tcv_batch_size(const tcv_batch *b);
+
+/* ---- batched factor evaluation (parity / debug surface; CostFunction::Evaluate layout) ------- */
+/* All pointers are HOST pointers; the call uploads, evaluates on the GPU, downloads.
+ * jacobians may be NULL.  Layouts follow the reference: row-major, global block width. */
+/* IMUFactor::Evaluate imu_factor.h:19-181: params n x (7+9+7+9), residuals n x 15, jacobians n x (15*7+15*9+15*7+15*9).
+ * sqrt_info_io: n x 225; if use_given_sqrt_info == 0 it is computed on the device and written back. */
+int tcv_eval_imu_factors(int n, const tcv_imu_preintegration *pre, const double *params, const double G[3],
+                         int use_given_sqrt_info, double *sqrt_info_io, double *residuals, double *jacobians);
+/* ProjectionFactor::Evaluate projection_factor.cpp:21-124: params n x (7+7+7+1), pts n x 6, residuals n x 2, jacobians n x (14+14+14+2) */
+int tcv_eval_projection_factors(int n, const double *pts, const double *params, double sqrt_info,
+                                double *residuals, double *jacobians);
+/* LineProjectionFactor::Evaluate line_projection_factor.cpp:19-120: params n x 7, line n x 9, residuals n x 2, jacobians n x 14 */
+int tcv_eval_line_factors(int n, const double *line_data, const double K[9], const double b_c_R[9],
+                          const double b_c_T[3], const double *params, double *residuals, double *jacobians);
+/* PoseLocalParameterization::Plus pose_local_parameterization.cpp:3-19: x n x 7, delta n x 6 */
+int tcv_pose_plus(int n, const double *x, const double *delta, double *x_plus_delta);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TCV_H */

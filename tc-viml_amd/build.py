@@ -1,0 +1,47 @@
+"""Builds the in-tree HIP library `tc-viml_amd/libtcv_hip.so` for gfx950 (MI355X).
+
+    python tc-viml_amd/build.py [--force]
+
+hipcc cross-compiles without a GPU; the .so is git-ignored but travels to the GPU box."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libtcv_hip.so")
+SOURCES = ["tcv_capi.hip", "tcv_solve.hip", "tcv_marg.hip", "tcv_pack.cpp"]
+HEADERS = ["tcv_math.h", "tcv_factors.h", "tcv_packed.h", "tcv_host.h", os.path.join("..", "..", "include", "tcv.h")]
+
+
+def _stale() -> bool:
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    for f in SOURCES + HEADERS:
+        p = os.path.join(CSRC, f)
+        if os.path.exists(p) and os.path.getmtime(p) > t:
+            return True
+    return False
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not _stale():
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    srcs = [os.path.join(CSRC, f) for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=on",
+           "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-value", "-Wno-unused-result", "-x", "hip"]
+    if any(s.endswith("tcv_marg.hip") for s in srcs):
+        cmd.append("-DTCV_HAVE_MARG=1")
+    if verbose:
+        cmd.append("-Rpass-analysis=kernel-resource-usage")
+    cmd += srcs + ["-o", OUT]
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))

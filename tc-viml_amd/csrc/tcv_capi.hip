@@ -1,0 +1,716 @@
+// C-ABI of include/tcv.h: ceres::Problem-shaped graph building, ceres::Solve, MarginalizationInfo,
+// the device-resident batch mode and the batched factor-evaluation (parity) surface.
+// There is no CPU fallback anywhere in this file: without a HIP device every compute entry point
+// returns TCV_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+
+#include "tcv_factors.h"
+#include "tcv_host.h"
+
+extern "C" int tcv_launch_solve(const tcv::SolveArgs *args, int grid, int nthreads, size_t lds_bytes, void *stream);
+extern "C" int tcv_solve_scratch_doubles(void);
+extern "C" int tcv_launch_marg(const void *args, int grid, size_t lds_bytes, void *stream);
+
+namespace tcv {
+static thread_local std::string g_err;
+void set_error(const std::string &s) { g_err = s; }
+static int hip_fail(hipError_t e, const char *what) {
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return TCV_ERR_HIP;
+}
+#define HIPCHK(x)                                         \
+    do {                                                  \
+        hipError_t e_ = (x);                              \
+        if (e_ != hipSuccess) return hip_fail(e_, #x);    \
+    } while (0)
+
+static int device_ready() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        g_err = "no HIP device visible: libtcv_hip has no CPU fallback";
+        return TCV_ERR_NO_DEVICE;
+    }
+    return TCV_OK;
+}
+}  // namespace tcv
+using namespace tcv;
+
+// =====================================================================================================
+// library
+// =====================================================================================================
+extern "C" const char *tcv_version(void) { return "tcv-hip 0.1 (gfx950)"; }
+extern "C" const char *tcv_last_error(void) { return g_err.c_str(); }
+extern "C" int tcv_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+extern "C" int tcv_set_device(int device) {
+    if (int rc = device_ready()) return rc;
+    HIPCHK(hipSetDevice(device));
+    return TCV_OK;
+}
+
+// =====================================================================================================
+// ceres::Problem surface
+// =====================================================================================================
+extern "C" int tcv_problem_create(tcv_problem **out) {
+    if (!out) return TCV_ERR_INVALID;
+    *out = new tcv_problem();
+    return TCV_OK;
+}
+extern "C" void tcv_problem_destroy(tcv_problem *p) { delete p; }
+
+static int block_of(tcv_problem *p, double *addr) {
+    auto it = p->index.find(addr);
+    return it == p->index.end() ? -1 : it->second;
+}
+
+extern "C" int tcv_problem_add_parameter_block(tcv_problem *p, double *values, int size, int parameterization) {
+    if (!p || !values || size <= 0) { set_error("add_parameter_block: bad argument"); return TCV_ERR_INVALID; }
+    if (parameterization == TCV_PARAM_POSE && size != 7) { set_error("pose parameterisation needs a size-7 block"); return TCV_ERR_INVALID; }
+    const int b = block_of(p, values);
+    if (b >= 0) {  // Ceres 2.x accepts re-adding a block (estimator.cpp:1837-1838); size must agree
+        if (p->blocks[b].size != size) { set_error("parameter block re-added with a different size"); return TCV_ERR_INVALID; }
+        p->blocks[b].kind = parameterization == TCV_PARAM_POSE ? KIND_POSE : p->blocks[b].kind;
+        return TCV_OK;
+    }
+    p->index[values] = (int)p->blocks.size();
+    p->blocks.push_back(ParamBlock{values, size, parameterization == TCV_PARAM_POSE ? KIND_POSE : KIND_EUCLID, false});
+    return TCV_OK;
+}
+extern "C" int tcv_problem_set_parameter_block_constant(tcv_problem *p, double *values) {
+    const int b = p ? block_of(p, values) : -1;
+    if (b < 0) { set_error("set_parameter_block_constant: unknown block"); return TCV_ERR_INVALID; }
+    p->blocks[b].constant = true;
+    return TCV_OK;
+}
+extern "C" int tcv_problem_set_gravity(tcv_problem *p, const double G[3]) {
+    if (!p || !G) return TCV_ERR_INVALID;
+    for (int i = 0; i < 3; i++) p->G[i] = G[i];
+    return TCV_OK;
+}
+// implicit AddParameterBlock like ceres::Problem::AddResidualBlock does for unknown pointers
+static int ensure_block(tcv_problem *p, double *addr, int size) {
+    int b = block_of(p, addr);
+    if (b >= 0) return p->blocks[b].size == size ? b : -1;
+    if (tcv_problem_add_parameter_block(p, addr, size, TCV_PARAM_EUCLIDEAN) != TCV_OK) return -1;
+    return block_of(p, addr);
+}
+extern "C" int tcv_problem_add_imu_factor(tcv_problem *p, const tcv_imu_preintegration *pre, double *pose_i, double *sb_i,
+                                          double *pose_j, double *sb_j) {
+    if (!p || !pre) return TCV_ERR_INVALID;
+    ImuFac f;
+    f.pre = *pre;
+    double *a[4] = {pose_i, sb_i, pose_j, sb_j};
+    const int sz[4] = {7, 9, 7, 9};
+    for (int k = 0; k < 4; k++) {
+        f.b[k] = a[k] ? ensure_block(p, a[k], sz[k]) : -1;
+        if (f.b[k] < 0) { set_error("add_imu_factor: bad parameter block"); return TCV_ERR_INVALID; }
+    }
+    p->imu.push_back(f);
+    return TCV_OK;
+}
+extern "C" int tcv_problem_add_projection_factor(tcv_problem *p, const double pts_i[3], const double pts_j[3], double sqrt_info,
+                                                 double loss_a, double *pose_i, double *pose_j, double *ex_pose,
+                                                 double *inv_depth) {
+    if (!p || !pts_i || !pts_j) return TCV_ERR_INVALID;
+    ProjFac f;
+    for (int i = 0; i < 3; i++) { f.pts[i] = pts_i[i]; f.pts[3 + i] = pts_j[i]; }
+    f.sqrt_info = sqrt_info; f.loss_a = loss_a;
+    double *a[4] = {pose_i, pose_j, ex_pose, inv_depth};
+    const int sz[4] = {7, 7, 7, 1};
+    for (int k = 0; k < 4; k++) {
+        f.b[k] = a[k] ? ensure_block(p, a[k], sz[k]) : -1;
+        if (f.b[k] < 0) { set_error("add_projection_factor: bad parameter block"); return TCV_ERR_INVALID; }
+    }
+    p->proj.push_back(f);
+    return TCV_OK;
+}
+extern "C" int tcv_problem_add_line_factor(tcv_problem *p, const double ps[3], const double pe[3], const double abc[3],
+                                           const double K[9], const double R[9], const double T[3], double loss_a, double *pose) {
+    if (!p || !ps || !pe || !abc || !K || !R || !T || !pose) return TCV_ERR_INVALID;
+    LineFac f;
+    for (int i = 0; i < 3; i++) { f.d[i] = ps[i]; f.d[3 + i] = pe[i]; f.d[6 + i] = abc[i]; f.T[i] = T[i]; }
+    for (int i = 0; i < 9; i++) { f.K[i] = K[i]; f.R[i] = R[i]; }
+    f.loss_a = loss_a;
+    f.b = ensure_block(p, pose, 7);
+    if (f.b < 0) { set_error("add_line_factor: bad parameter block"); return TCV_ERR_INVALID; }
+    p->line.push_back(f);
+    return TCV_OK;
+}
+extern "C" int tcv_problem_add_marginalization_factor(tcv_problem *p, const tcv_prior *prior, double *const *blocks, int n) {
+    if (!p || !prior || !blocks || n != (int)prior->size.size()) { set_error("add_marginalization_factor: block count mismatch"); return TCV_ERR_INVALID; }
+    PriorFac f;
+    f.prior = prior;
+    for (int k = 0; k < n; k++) {
+        const int b = ensure_block(p, blocks[k], prior->size[k]);
+        if (b < 0) { set_error("add_marginalization_factor: bad parameter block"); return TCV_ERR_INVALID; }
+        f.b.push_back(b);
+    }
+    p->prior.push_back(f);
+    return TCV_OK;
+}
+extern "C" int tcv_problem_num_parameter_blocks(const tcv_problem *p) { return p ? (int)p->blocks.size() : 0; }
+extern "C" int tcv_problem_num_residual_blocks(const tcv_problem *p) {
+    return p ? (int)(p->imu.size() + p->proj.size() + p->line.size() + p->prior.size()) : 0;
+}
+extern "C" int tcv_problem_num_residuals(const tcv_problem *p) {
+    if (!p) return 0;
+    int n = 15 * (int)p->imu.size() + 2 * (int)p->proj.size() + 2 * (int)p->line.size();
+    for (auto &f : p->prior) n += f.prior->n;
+    return n;
+}
+
+// host-only: packs the problem (no device needed) and reports the sizes of its plan and data.
+// out[0..15] = nc, nx, npp, nland, nt, n_vis_chunk, n_imu_chunk, n_vunit, n_vitem, n_sunit, n_sitem, n_iunit, n_iitem,
+//              plan ints, window doubles, LDS bytes
+extern "C" int tcv_problem_plan_stats(const tcv_problem *p, int *out) {
+    if (!p || !out) return TCV_ERR_INVALID;
+    Packed pk;
+    const int rc = pack_problem(*p, pk, nullptr);
+    if (rc != TCV_OK) return rc;
+    const PlanHdr &H = pk.hdr;
+    const int v[16] = {H.nc, H.nx, H.npp, H.nland, H.nt, H.n_vis_chunk, H.n_imu_chunk, H.n_vunit, H.n_vitem, H.n_sunit, H.n_sitem,
+                       H.n_iunit, H.n_iitem, H.plan_ints, pk.win.n_doubles,
+                       (H.nt * (H.nt + 1) / 2 * 256 + 2 * ((H.nx + H.nland + 1) & ~1) + 4 * 176 + 64 + H.lds_area) * 8};
+    std::memcpy(out, v, sizeof v);
+    return TCV_OK;
+}
+
+// graph construction of estimator.cpp:1683-1846 from frame-indexed arrays
+extern "C" int tcv_problem_from_window(const tcv_window_desc *w, tcv_problem **out) {
+    if (!w || !out || w->n_frames <= 0) return TCV_ERR_INVALID;
+    tcv_problem *p = new tcv_problem();
+    int rc = TCV_OK;
+    auto chk = [&](int r) { if (rc == TCV_OK && r != TCV_OK) rc = r; };
+    for (int i = 0; i < w->n_frames; i++) {   // :1683-1688
+        chk(tcv_problem_add_parameter_block(p, w->para_pose + 7 * i, 7, TCV_PARAM_POSE));
+        chk(tcv_problem_add_parameter_block(p, w->para_speedbias + 9 * i, 9, TCV_PARAM_EUCLIDEAN));
+    }
+    chk(tcv_problem_add_parameter_block(p, w->para_ex_pose, 7, TCV_PARAM_POSE));   // :1689-1701
+    if (!w->estimate_extrinsic) chk(tcv_problem_set_parameter_block_constant(p, w->para_ex_pose));
+    chk(tcv_problem_set_gravity(p, w->gravity));
+    if (w->prior) {   // :1714-1720
+        int m, n, nb, xs;
+        tcv_prior_dims(w->prior, &m, &n, &nb, &xs);
+        std::vector<double *> blocks(nb);
+        for (int k = 0; k < nb; k++) {
+            const int kind = w->prior_block_kind[k], idx = w->prior_block_index[k];
+            blocks[k] = kind == 0 ? w->para_pose + 7 * idx : (kind == 1 ? w->para_speedbias + 9 * idx : w->para_ex_pose);
+        }
+        chk(tcv_problem_add_marginalization_factor(p, w->prior, blocks.data(), nb));
+    }
+    for (int k = 0; k < w->n_imu; k++) {   // :1723-1732
+        if (w->imu[k].sum_dt > 10.0) continue;
+        const int i = w->imu_frame_i[k], j = w->imu_frame_j[k];
+        chk(tcv_problem_add_imu_factor(p, w->imu + k, w->para_pose + 7 * i, w->para_speedbias + 9 * i, w->para_pose + 7 * j,
+                                       w->para_speedbias + 9 * j));
+    }
+    for (int k = 0; k < w->n_proj; k++)   // :1737-1771
+        chk(tcv_problem_add_projection_factor(p, w->proj_pts + 6 * k, w->proj_pts + 6 * k + 3, w->proj_sqrt_info, w->proj_loss_a,
+                                              w->para_pose + 7 * w->proj_frame_i[k], w->para_pose + 7 * w->proj_frame_j[k],
+                                              w->para_ex_pose, w->para_feature + w->proj_feature[k]));
+    for (int k = 0; k < w->n_line; k++)   // :1786-1846
+        chk(tcv_problem_add_line_factor(p, w->line_data + 9 * k, w->line_data + 9 * k + 3, w->line_data + 9 * k + 6, w->line_K,
+                                        w->line_Ric, w->line_Tic, w->line_loss_a, w->para_pose + 7 * w->line_frame[k]));
+    if (rc != TCV_OK) { delete p; return rc; }
+    *out = p;
+    return TCV_OK;
+}
+
+// =====================================================================================================
+// prior (MarginalizationInfo layout, marginalization_factor.h:57-70)
+// =====================================================================================================
+extern "C" int tcv_prior_create(tcv_prior **out, int m, int n, int nb, const int *size, const int *idx, const double *x0,
+                                const double *J0, const double *r0) {
+    if (!out || n <= 0 || nb <= 0 || !size || !idx || !x0 || !J0 || !r0) return TCV_ERR_INVALID;
+    tcv_prior *pr = new tcv_prior();
+    pr->m = m; pr->n = n;
+    int xs = 0;
+    for (int k = 0; k < nb; k++) { pr->size.push_back(size[k]); pr->idx.push_back(idx[k]); pr->xoff.push_back(xs); xs += size[k]; }
+    pr->x0.assign(x0, x0 + xs);
+    pr->J0.assign(J0, J0 + (size_t)n * n);
+    pr->r0.assign(r0, r0 + n);
+    pr->addr.assign(nb, nullptr);
+    *out = pr;
+    return TCV_OK;
+}
+extern "C" int tcv_prior_dims(const tcv_prior *pr, int *m, int *n, int *nb, int *xs) {
+    if (!pr) return TCV_ERR_INVALID;
+    if (m) *m = pr->m;
+    if (n) *n = pr->n;
+    if (nb) *nb = (int)pr->size.size();
+    if (xs) *xs = (int)pr->x0.size();
+    return TCV_OK;
+}
+extern "C" int tcv_prior_export(const tcv_prior *pr, int *size, int *idx, double *x0, double *J0, double *r0) {
+    if (!pr) return TCV_ERR_INVALID;
+    if (size) std::copy(pr->size.begin(), pr->size.end(), size);
+    if (idx) std::copy(pr->idx.begin(), pr->idx.end(), idx);
+    if (x0) std::copy(pr->x0.begin(), pr->x0.end(), x0);
+    if (J0) std::copy(pr->J0.begin(), pr->J0.end(), J0);
+    if (r0) std::copy(pr->r0.begin(), pr->r0.end(), r0);
+    return TCV_OK;
+}
+extern "C" int tcv_prior_keep_block_addresses(const tcv_prior *pr, double **addresses) {
+    if (!pr || !addresses) return TCV_ERR_INVALID;
+    std::copy(pr->addr.begin(), pr->addr.end(), addresses);
+    return TCV_OK;
+}
+extern "C" void tcv_prior_destroy(tcv_prior *pr) { delete pr; }
+
+// =====================================================================================================
+// batch: many independent windows resident in HBM
+// =====================================================================================================
+struct MargPlan;   // tcv_marg.hip
+struct tcv_batch {
+    int n = 0;
+    std::vector<tcv_problem *> problems;
+    std::vector<Packed> packed;         // host copies of per-window maps (ints/doubles released after upload)
+    std::vector<PlanHdr> plans;
+    std::vector<long long> plan_base;
+    std::vector<WinHdr> wins;
+    int state_stride = 0, delta_stride = 0;
+    double input_bytes = 0, plan_bytes = 0;
+    // device
+    WinHdr *d_win = nullptr;
+    PlanHdr *d_plans = nullptr;
+    long long *d_plan_base = nullptr;
+    int *d_ipool = nullptr;
+    double *d_dpool = nullptr, *d_state = nullptr, *d_delta = nullptr, *d_scratch = nullptr;
+    DevSummary *d_summary = nullptr;
+    int grid = 0, nthreads = 256;
+    size_t lds_bytes = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float solve_ms = 0, marg_ms = 0;
+    bool solved = false;
+    std::vector<double> h_state;
+    // marginalisation
+    std::shared_ptr<void> marg;
+};
+
+static void batch_free(tcv_batch *b) {
+    if (!b) return;
+    hipFree(b->d_win); hipFree(b->d_plans); hipFree(b->d_plan_base); hipFree(b->d_ipool); hipFree(b->d_dpool);
+    hipFree(b->d_state); hipFree(b->d_delta); hipFree(b->d_scratch); hipFree(b->d_summary);
+    if (b->ev0) hipEventDestroy(b->ev0);
+    if (b->ev1) hipEventDestroy(b->ev1);
+    delete b;
+}
+
+int tcv_marg_attach(tcv_batch *b, tcv_problem *const *marg_problems, double *const *const *marg_drop, const int *marg_num_drop);
+int tcv_marg_run(tcv_batch *b, void *stream);
+int tcv_marg_get_prior(tcv_batch *b, int window, tcv_prior **out);
+
+extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, tcv_problem *const *marg_problems,
+                                double *const *const *marg_drop, const int *marg_num_drop, int n) {
+    if (!out || !problems || n <= 0) return TCV_ERR_INVALID;
+    if (int rc = device_ready()) return rc;
+    tcv_batch *b = new tcv_batch();
+    b->n = n;
+    b->problems.assign(problems, problems + n);
+    b->packed.resize(n);
+    std::map<std::vector<int>, int> plan_index;   // structure de-duplication
+    std::vector<int> ipool;
+    std::vector<double> dpool;
+    int max_state = 0, max_nl = 0;
+    size_t max_lds = 0;
+    for (int w = 0; w < n; w++) {
+        Packed &pk = b->packed[w];
+        const int rc = pack_problem(*problems[w], pk, nullptr);
+        if (rc != TCV_OK) { batch_free(b); return rc; }
+        std::vector<int> key(pk.ints);
+        const int *hp = reinterpret_cast<const int *>(&pk.hdr);
+        key.insert(key.end(), hp, hp + sizeof(PlanHdr) / sizeof(int));
+        auto it = plan_index.find(key);
+        int pid;
+        if (it == plan_index.end()) {
+            pid = (int)b->plans.size();
+            plan_index[key] = pid;
+            b->plans.push_back(pk.hdr);
+            b->plan_base.push_back((long long)ipool.size());
+            ipool.insert(ipool.end(), pk.ints.begin(), pk.ints.end());
+        } else pid = it->second;
+        pk.win.plan = pid;
+        pk.win.dbase = (long long)dpool.size();
+        dpool.insert(dpool.end(), pk.doubles.begin(), pk.doubles.end());
+        b->wins.push_back(pk.win);
+        max_state = std::max(max_state, pk.hdr.nx + pk.hdr.nland);
+        max_nl = std::max(max_nl, pk.hdr.nc + pk.hdr.nland);
+        const int nt = pk.hdr.nt;
+        const size_t lds = (size_t)(nt * (nt + 1) / 2 * 256 + 2 * ((pk.hdr.nx + pk.hdr.nland + 1) & ~1) + 4 * 176 + 64 + pk.hdr.lds_area) * 8;
+        max_lds = std::max(max_lds, lds);
+        pk.ints.clear(); pk.ints.shrink_to_fit();
+        b->input_bytes += 8.0 * pk.doubles.size();
+        pk.doubles.clear(); pk.doubles.shrink_to_fit();
+    }
+    b->plan_bytes = 4.0 * ipool.size();
+    b->state_stride = (max_state + 1) & ~1;
+    b->delta_stride = (max_nl + 1) & ~1;
+    b->lds_bytes = max_lds;
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, 0));
+    int dev = 0;
+    hipGetDevice(&dev);
+    hipGetDeviceProperties(&prop, dev);
+    b->grid = std::min(n, prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
+    const int scr = tcv_solve_scratch_doubles();
+#define UP(dst, src, T, cnt)                                                                          \
+    do {                                                                                              \
+        hipError_t e_ = hipMalloc((void **)&dst, sizeof(T) * std::max<size_t>(1, (cnt)));             \
+        if (e_ != hipSuccess) { batch_free(b); return hip_fail(e_, "hipMalloc"); }                    \
+        if (src) {                                                                                    \
+            e_ = hipMemcpy(dst, src, sizeof(T) * (cnt), hipMemcpyHostToDevice);                       \
+            if (e_ != hipSuccess) { batch_free(b); return hip_fail(e_, "hipMemcpy H2D"); }            \
+        }                                                                                             \
+    } while (0)
+    UP(b->d_win, b->wins.data(), WinHdr, (size_t)n);
+    UP(b->d_plans, b->plans.data(), PlanHdr, b->plans.size());
+    UP(b->d_plan_base, b->plan_base.data(), long long, b->plan_base.size());
+    UP(b->d_ipool, ipool.data(), int, ipool.size());
+    UP(b->d_dpool, dpool.data(), double, dpool.size());
+    UP(b->d_state, (double *)nullptr, double, (size_t)n * b->state_stride);
+    UP(b->d_delta, (double *)nullptr, double, (size_t)n * b->delta_stride);
+    UP(b->d_scratch, (double *)nullptr, double, (size_t)b->grid * scr);
+    UP(b->d_summary, (DevSummary *)nullptr, DevSummary, (size_t)n);
+#undef UP
+    hipMemset(b->d_scratch, 0, sizeof(double) * (size_t)b->grid * scr);
+    hipMemset(b->d_summary, 0, sizeof(DevSummary) * (size_t)n);
+    hipMemset(b->d_delta, 0, sizeof(double) * (size_t)n * b->delta_stride);
+    HIPCHK(hipEventCreate(&b->ev0));
+    HIPCHK(hipEventCreate(&b->ev1));
+    if (marg_problems) {
+        const int rc = tcv_marg_attach(b, marg_problems, marg_drop, marg_num_drop);
+        if (rc != TCV_OK) { batch_free(b); return rc; }
+    }
+    *out = b;
+    return TCV_OK;
+}
+extern "C" void tcv_batch_destroy(tcv_batch *b) { batch_free(b); }
+extern "C" int tcv_batch_size(const tcv_batch *b) { return b ? b->n : 0; }
+
+extern "C" void tcv_solver_options_default(tcv_solver_options *o) {
+    if (!o) return;
+    o->max_num_iterations = 8;
+    o->max_solver_time_in_seconds = 0.0;
+    o->fixed_iterations = 0;
+    o->compute_sqrt_info_on_device = 1;
+    o->use_mfma = 1;
+    o->threads_per_window = 256;
+    o->record_first_step = 0;
+}
+
+extern "C" int tcv_batch_solve(tcv_batch *b, const tcv_solver_options *o, void *hip_stream) {
+    if (!b || !o) return TCV_ERR_INVALID;
+    SolveArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.win = b->d_win; a.plans = b->d_plans; a.plan_base = b->d_plan_base; a.ipool = b->d_ipool; a.dpool = b->d_dpool;
+    a.state_out = b->d_state; a.summary = b->d_summary; a.first_delta = o->record_first_step ? b->d_delta : nullptr;
+    a.scratch = b->d_scratch;
+    a.nwin = b->n; a.state_stride = b->state_stride; a.delta_stride = b->delta_stride; a.scratch_stride = tcv_solve_scratch_doubles();
+    a.max_iterations = o->max_num_iterations; a.fixed_iterations = o->fixed_iterations; a.use_mfma = o->use_mfma;
+    hipStream_t st = (hipStream_t)hip_stream;
+    HIPCHK(hipEventRecord(b->ev0, st));
+    const int rc = tcv_launch_solve(&a, b->grid, o->threads_per_window == 512 ? 512 : 256, b->lds_bytes, hip_stream);
+    if (rc != 0) return hip_fail((hipError_t)rc, "solve kernel launch");
+    HIPCHK(hipEventRecord(b->ev1, st));
+    b->solved = true;
+    return TCV_OK;
+}
+extern "C" int tcv_batch_marginalize(tcv_batch *b, void *hip_stream) {
+    if (!b) return TCV_ERR_INVALID;
+    return tcv_marg_run(b, hip_stream);
+}
+extern "C" int tcv_batch_synchronize(tcv_batch *b) {
+    if (!b) return TCV_ERR_INVALID;
+    HIPCHK(hipDeviceSynchronize());
+    if (b->solved) hipEventElapsedTime(&b->solve_ms, b->ev0, b->ev1);
+    return TCV_OK;
+}
+extern "C" int tcv_batch_download_states(tcv_batch *b) {
+    if (!b || !b->solved) return TCV_ERR_INVALID;
+    b->h_state.resize((size_t)b->n * b->state_stride);
+    HIPCHK(hipMemcpy(b->h_state.data(), b->d_state, sizeof(double) * b->h_state.size(), hipMemcpyDeviceToHost));
+    for (int w = 0; w < b->n; w++) {
+        const Packed &pk = b->packed[w];
+        const tcv_problem &p = *b->problems[w];
+        const double *x = b->h_state.data() + (size_t)w * b->state_stride;
+        int off = 0;
+        for (int blk : pk.cam_block) { std::memcpy(p.blocks[blk].addr, x + off, sizeof(double) * p.blocks[blk].size); off += p.blocks[blk].size; }
+        for (int blk : pk.lm_block) p.blocks[blk].addr[0] = x[off++];
+    }
+    return TCV_OK;
+}
+static void summary_to_public(const DevSummary &s, tcv_solver_summary *o) {
+    std::memset(o, 0, sizeof *o);
+    o->num_iterations = s.num_iterations; o->termination = s.termination;
+    o->initial_cost = s.initial_cost; o->final_cost = s.final_cost;
+    for (int i = 0; i < TCV_MAX_TRACE; i++) {
+        o->cost[i] = s.cost[i]; o->cost_candidate[i] = s.cost_candidate[i]; o->model_cost_change[i] = s.model_cost_change[i];
+        o->radius[i] = s.radius[i]; o->mu[i] = s.mu[i]; o->rho[i] = s.rho[i]; o->step_norm[i] = s.step_norm[i];
+        o->step_ok[i] = s.step_ok[i]; o->dogleg_case[i] = s.dogleg_case[i];
+    }
+}
+extern "C" int tcv_batch_get_summaries(tcv_batch *b, tcv_solver_summary *out, int n) {
+    if (!b || !out || n > b->n) return TCV_ERR_INVALID;
+    std::vector<DevSummary> h(n);
+    HIPCHK(hipMemcpy(h.data(), b->d_summary, sizeof(DevSummary) * n, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++) summary_to_public(h[i], out + i);
+    return TCV_OK;
+}
+// tangent step of iteration 1 in problem order: free camera blocks in the order they were added
+// (local size each), then the inverse depths in landmark order.  Returns the length in *len.
+extern "C" int tcv_batch_get_first_step(tcv_batch *b, int window, double *out, int cap, int *len) {
+    if (!b || window < 0 || window >= b->n || !out) return TCV_ERR_INVALID;
+    const PlanHdr &H = b->plans[b->wins[window].plan];
+    std::vector<double> d(b->delta_stride);
+    HIPCHK(hipMemcpy(d.data(), b->d_delta + (size_t)window * b->delta_stride, sizeof(double) * b->delta_stride, hipMemcpyDeviceToHost));
+    const tcv_problem &p = *b->problems[window];
+    const Packed &pk = b->packed[window];
+    // recompute loff exactly as the packer does
+    int nc = 0, k = 0;
+    std::vector<int> loff(pk.cam_block.size(), -1);
+    for (size_t c = 0; c < pk.cam_block.size(); c++) { const ParamBlock &pb = p.blocks[pk.cam_block[c]]; if (pb.kind == KIND_POSE && !pb.constant) { loff[c] = nc; nc += 6; } }
+    for (size_t c = 0; c < pk.cam_block.size(); c++) { const ParamBlock &pb = p.blocks[pk.cam_block[c]]; if (pb.kind != KIND_POSE && !pb.constant) { loff[c] = nc; nc += pb.size; } }
+    for (size_t c = 0; c < pk.cam_block.size(); c++) {
+        if (loff[c] < 0) continue;
+        const ParamBlock &pb = p.blocks[pk.cam_block[c]];
+        const int ls = pb.kind == KIND_POSE ? 6 : pb.size;
+        for (int j = 0; j < ls; j++) { if (k >= cap) return TCV_ERR_INVALID; out[k++] = d[loff[c] + j]; }
+    }
+    for (int l = 0; l < H.nland; l++) { if (k >= cap) return TCV_ERR_INVALID; out[k++] = d[H.nc + l]; }
+    if (len) *len = k;
+    return TCV_OK;
+}
+extern "C" int tcv_batch_get_prior(tcv_batch *b, int window, tcv_prior **out) {
+    if (!b || !out) return TCV_ERR_INVALID;
+    return tcv_marg_get_prior(b, window, out);
+}
+extern "C" int tcv_batch_stats(tcv_batch *b, double *input_bytes, double *solve_ms, double *marg_ms) {
+    if (!b) return TCV_ERR_INVALID;
+    if (input_bytes) *input_bytes = b->input_bytes;
+    if (solve_ms) *solve_ms = b->solve_ms;
+    if (marg_ms) *marg_ms = b->marg_ms;
+    return TCV_OK;
+}
+extern "C" int tcv_batch_plan_stats(tcv_batch *b, int *num_plans, double *plan_bytes, int *grid, int *lds_bytes) {
+    if (!b) return TCV_ERR_INVALID;
+    if (num_plans) *num_plans = (int)b->plans.size();
+    if (plan_bytes) *plan_bytes = b->plan_bytes;
+    if (grid) *grid = b->grid;
+    if (lds_bytes) *lds_bytes = (int)b->lds_bytes;
+    return TCV_OK;
+}
+
+// ceres::Solve(options, &problem, &summary)   estimator.cpp:1900
+extern "C" int tcv_solve(const tcv_solver_options *o, tcv_problem *p, tcv_solver_summary *summary) {
+    if (!o || !p) return TCV_ERR_INVALID;
+    tcv_batch *b = nullptr;
+    tcv_problem *arr[1] = {p};
+    int rc = tcv_batch_create(&b, arr, nullptr, nullptr, nullptr, 1);
+    if (rc != TCV_OK) return rc;
+    rc = tcv_batch_solve(b, o, nullptr);
+    if (rc == TCV_OK) rc = tcv_batch_synchronize(b);
+    tcv_solver_summary s;
+    if (rc == TCV_OK) rc = tcv_batch_get_summaries(b, &s, 1);
+    if (rc == TCV_OK) {
+        if (summary) *summary = s;
+        if (!(s.final_cost == s.final_cost) || s.termination == 5) {
+            set_error("solver failure (NaN cost or no valid step); parameter blocks left untouched");
+            rc = TCV_ERR_NUMERIC;
+        } else rc = tcv_batch_download_states(b);
+    }
+    tcv_batch_destroy(b);
+    return rc;
+}
+
+// single-window MarginalizationInfo path (marginalization_factor.cpp:89-321): a batch of one
+extern "C" int tcv_marginalize(tcv_problem *p, double *const *drop, int num_drop, tcv_prior **out) {
+    if (!p || !drop || num_drop <= 0 || !out) return TCV_ERR_INVALID;
+    tcv_batch *b = nullptr;
+    tcv_problem *arr[1] = {p};
+    double *const *dr[1] = {drop};
+    int nd[1] = {num_drop};
+    // the marginalisation problem doubles as the (unused) solve problem of the batch
+    int rc = tcv_batch_create(&b, arr, arr, dr, nd, 1);
+    if (rc != TCV_OK) return rc;
+    rc = tcv_batch_marginalize(b, nullptr);
+    if (rc == TCV_OK) rc = tcv_batch_synchronize(b);
+    if (rc == TCV_OK) rc = tcv_batch_get_prior(b, 0, out);
+    tcv_batch_destroy(b);
+    return rc;
+}
+
+// =====================================================================================================
+// batched factor evaluation (CostFunction::Evaluate layout: row-major, global block width, 7th column zero)
+// =====================================================================================================
+namespace tcv {
+__global__ void eval_imu_kernel(int n, const double *consts, const double *params, double G0, double G1, double G2, int use_given,
+                                double *sqrt_io, double *res, double *jac, double *work) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double G[3] = {G0, G1, G2};
+    const double *pm = params + (size_t)i * 32, *c = consts + (size_t)i * IMU_CONST;
+    double *S = sqrt_io + (size_t)i * 225;
+    if (!use_given) imu_sqrt_info(c + IMU_COV, S, work + (size_t)i * 450);
+    double *w = work + (size_t)i * 450;   // reuse as raw J (15 x 30)
+    double rr[15];
+    imu_raw(pm, pm + 7, pm + 16, pm + 23, c, G, rr, 1, jac ? w : nullptr, 30);
+    for (int r = 0; r < 15; r++) {
+        double a = 0;
+        for (int s = r; s < 15; s++) a += S[r * 15 + s] * rr[s];
+        res[(size_t)i * 15 + r] = a;
+    }
+    if (!jac) return;
+    double *J = jac + (size_t)i * 480;
+    const int gofs[4] = {0, 105, 240, 345}, gw[4] = {7, 9, 7, 9}, lc[4] = {0, 6, 15, 21}, lw[4] = {6, 9, 6, 9};
+    for (int b = 0; b < 4; b++)
+        for (int r = 0; r < 15; r++) {
+            for (int cc = 0; cc < lw[b]; cc++) {
+                double a = 0;
+                for (int s = r; s < 15; s++) a += S[r * 15 + s] * w[s * 30 + lc[b] + cc];
+                J[gofs[b] + r * gw[b] + cc] = a;
+            }
+            if (gw[b] == 7) J[gofs[b] + r * 7 + 6] = 0.0;
+        }
+}
+__global__ void eval_proj_kernel(int n, const double *pts, const double *params, double sqrt_info, double *res, double *jac) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double *pm = params + (size_t)i * 22;
+    double r[2], J[38];
+    proj_eval(pm, pm + 7, pm + 14, pm[21], pts + (size_t)i * 6, sqrt_info, r, jac ? J : nullptr, 19);
+    res[2 * i] = r[0]; res[2 * i + 1] = r[1];
+    if (!jac) return;
+    double *o = jac + (size_t)i * 44;   // 2x7 | 2x7 | 2x7 | 2x1
+    for (int b = 0; b < 3; b++)
+        for (int row = 0; row < 2; row++) {
+            for (int c = 0; c < 6; c++) o[b * 14 + row * 7 + c] = J[row * 19 + 6 * b + c];
+            o[b * 14 + row * 7 + 6] = 0.0;
+        }
+    o[42] = J[18]; o[43] = J[19 + 18];
+}
+__global__ void eval_line_kernel(int n, const double *line, const double *consts21, const double *params, double *res, double *jac) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double r[2], J[12];
+    line_eval(params + (size_t)i * 7, line + (size_t)i * 9, consts21, consts21 + 9, consts21 + 18, r, jac ? J : nullptr, 6);
+    res[2 * i] = r[0]; res[2 * i + 1] = r[1];
+    if (!jac) return;
+    double *o = jac + (size_t)i * 14;
+    for (int row = 0; row < 2; row++) { for (int c = 0; c < 6; c++) o[row * 7 + c] = J[row * 6 + c]; o[row * 7 + 6] = 0.0; }
+}
+__global__ void pose_plus_kernel(int n, const double *x, const double *d, double *o) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    pose_plus(x + (size_t)i * 7, d + (size_t)i * 6, o + (size_t)i * 7);
+}
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+    int alloc(size_t bytes) { return hipMalloc(&p, std::max<size_t>(bytes, 8)) == hipSuccess ? 0 : -1; }
+    template <class T> T *as() { return (T *)p; }
+};
+}  // namespace tcv
+
+#define EVAL_ALLOC(buf, bytes)                                                         \
+    if (buf.alloc(bytes)) { set_error("hipMalloc failed in eval"); return TCV_ERR_HIP; }
+
+extern "C" int tcv_eval_imu_factors(int n, const tcv_imu_preintegration *pre, const double *params, const double G[3],
+                                    int use_given, double *sqrt_io, double *res, double *jac) {
+    if (n <= 0 || !pre || !params || !G || !sqrt_io || !res) return TCV_ERR_INVALID;
+    if (int rc = device_ready()) return rc;
+    tcv_problem tmp;   // reuse the packer's constant layout
+    std::vector<double> consts((size_t)n * IMU_CONST);
+    for (int i = 0; i < n; i++) {
+        double *D = consts.data() + (size_t)i * IMU_CONST;
+        const tcv_imu_preintegration &q = pre[i];
+        std::memcpy(D, q.delta_p, 24); std::memcpy(D + 3, q.delta_q, 32); std::memcpy(D + 7, q.delta_v, 24);
+        std::memcpy(D + 10, q.linearized_ba, 24); std::memcpy(D + 13, q.linearized_bg, 24); D[16] = q.sum_dt;
+        const int rc[5][2] = {{0, 9}, {0, 12}, {3, 12}, {6, 9}, {6, 12}};
+        int o = 17;
+        for (auto &b : rc) for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) D[o++] = q.jacobian[(b[0] + r) * 15 + b[1] + c];
+        std::memcpy(D + 62, q.covariance, 225 * 8);
+    }
+    DevBuf dc, dp, ds, dr, dj, dw;
+    EVAL_ALLOC(dc, consts.size() * 8); EVAL_ALLOC(dp, (size_t)n * 32 * 8); EVAL_ALLOC(ds, (size_t)n * 225 * 8);
+    EVAL_ALLOC(dr, (size_t)n * 15 * 8); EVAL_ALLOC(dj, (size_t)n * 480 * 8); EVAL_ALLOC(dw, (size_t)n * 450 * 8);
+    HIPCHK(hipMemcpy(dc.p, consts.data(), consts.size() * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dp.p, params, (size_t)n * 32 * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ds.p, sqrt_io, (size_t)n * 225 * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(eval_imu_kernel, dim3((n + 63) / 64), dim3(64), 0, 0, n, dc.as<double>(), dp.as<double>(), G[0], G[1], G[2],
+                       use_given, ds.as<double>(), dr.as<double>(), jac ? dj.as<double>() : nullptr, dw.as<double>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(sqrt_io, ds.p, (size_t)n * 225 * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(res, dr.p, (size_t)n * 15 * 8, hipMemcpyDeviceToHost));
+    if (jac) HIPCHK(hipMemcpy(jac, dj.p, (size_t)n * 480 * 8, hipMemcpyDeviceToHost));
+    return TCV_OK;
+}
+extern "C" int tcv_eval_projection_factors(int n, const double *pts, const double *params, double sqrt_info, double *res, double *jac) {
+    if (n <= 0 || !pts || !params || !res) return TCV_ERR_INVALID;
+    if (int rc = device_ready()) return rc;
+    DevBuf d1, d2, dr, dj;
+    EVAL_ALLOC(d1, (size_t)n * 6 * 8); EVAL_ALLOC(d2, (size_t)n * 22 * 8); EVAL_ALLOC(dr, (size_t)n * 2 * 8); EVAL_ALLOC(dj, (size_t)n * 44 * 8);
+    HIPCHK(hipMemcpy(d1.p, pts, (size_t)n * 6 * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d2.p, params, (size_t)n * 22 * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(eval_proj_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, n, d1.as<double>(), d2.as<double>(), sqrt_info,
+                       dr.as<double>(), jac ? dj.as<double>() : nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(res, dr.p, (size_t)n * 2 * 8, hipMemcpyDeviceToHost));
+    if (jac) HIPCHK(hipMemcpy(jac, dj.p, (size_t)n * 44 * 8, hipMemcpyDeviceToHost));
+    return TCV_OK;
+}
+extern "C" int tcv_eval_line_factors(int n, const double *line, const double K[9], const double R[9], const double T[3],
+                                     const double *params, double *res, double *jac) {
+    if (n <= 0 || !line || !K || !R || !T || !params || !res) return TCV_ERR_INVALID;
+    if (int rc = device_ready()) return rc;
+    double c21[21];
+    std::memcpy(c21, K, 72); std::memcpy(c21 + 9, R, 72); std::memcpy(c21 + 18, T, 24);
+    DevBuf d1, dc, d2, dr, dj;
+    EVAL_ALLOC(d1, (size_t)n * 9 * 8); EVAL_ALLOC(dc, 21 * 8); EVAL_ALLOC(d2, (size_t)n * 7 * 8); EVAL_ALLOC(dr, (size_t)n * 2 * 8); EVAL_ALLOC(dj, (size_t)n * 14 * 8);
+    HIPCHK(hipMemcpy(d1.p, line, (size_t)n * 9 * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dc.p, c21, 21 * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d2.p, params, (size_t)n * 7 * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(eval_line_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, n, d1.as<double>(), dc.as<double>(), d2.as<double>(),
+                       dr.as<double>(), jac ? dj.as<double>() : nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(res, dr.p, (size_t)n * 2 * 8, hipMemcpyDeviceToHost));
+    if (jac) HIPCHK(hipMemcpy(jac, dj.p, (size_t)n * 14 * 8, hipMemcpyDeviceToHost));
+    return TCV_OK;
+}
+extern "C" int tcv_pose_plus(int n, const double *x, const double *delta, double *out) {
+    if (n <= 0 || !x || !delta || !out) return TCV_ERR_INVALID;
+    if (int rc = device_ready()) return rc;
+    DevBuf d1, d2, d3;
+    EVAL_ALLOC(d1, (size_t)n * 7 * 8); EVAL_ALLOC(d2, (size_t)n * 6 * 8); EVAL_ALLOC(d3, (size_t)n * 7 * 8);
+    HIPCHK(hipMemcpy(d1.p, x, (size_t)n * 7 * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d2.p, delta, (size_t)n * 6 * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(pose_plus_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, n, d1.as<double>(), d2.as<double>(), d3.as<double>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, d3.p, (size_t)n * 7 * 8, hipMemcpyDeviceToHost));
+    return TCV_OK;
+}
+
+// ---- temporary marginalisation stubs until tcv_marg.hip lands (replaced below when TCV_HAVE_MARG) ----
+#ifndef TCV_HAVE_MARG
+int tcv_marg_attach(tcv_batch *, tcv_problem *const *, double *const *const *, const int *) {
+    set_error("marginalisation kernel not built");
+    return TCV_ERR_UNSUPPORTED;
+}
+int tcv_marg_run(tcv_batch *, void *) { set_error("marginalisation kernel not built"); return TCV_ERR_UNSUPPORTED; }
+int tcv_marg_get_prior(tcv_batch *, int, tcv_prior **) { set_error("marginalisation kernel not built"); return TCV_ERR_UNSUPPORTED; }
+#endif

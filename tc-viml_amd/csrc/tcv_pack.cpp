@@ -1,0 +1,386 @@
+// Packer: ceres::Problem-shaped graph (estimator.cpp:1679-1886) -> device plan + window data
+// (tcv_packed.h).  Everything structural that the reference redoes per frame through
+// AddParameterBlock / AddResidualBlock pointer chasing is resolved here, once, into flat gather lists.
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <tuple>
+
+#include "tcv_host.h"
+
+namespace tcv {
+
+namespace {
+
+struct DestKey {
+    int kind, o0, o1;
+    bool operator<(const DestKey &o) const { return std::tie(kind, o0, o1) < std::tie(o.kind, o.o0, o.o1); }
+};
+struct DestList {
+    std::vector<DestKey> keys;                 // insertion order (deterministic)
+    std::map<DestKey, int> index;
+    std::vector<std::vector<int>> items;
+    std::vector<std::pair<int, int>> shape;    // (la, lb); lb = 0: triangle of la
+    void add(int kind, int o0, int o1, int la, int lb, int item) {
+        DestKey k{kind, o0, o1};
+        auto it = index.find(k);
+        int id;
+        if (it == index.end()) {
+            id = (int)keys.size();
+            index[k] = id;
+            keys.push_back(k);
+            items.emplace_back();
+            shape.emplace_back(la, lb);
+        } else id = it->second;
+        items[id].push_back(item);
+    }
+};
+
+// append the dests of `dl` (sorted by descending item count for load balance) to the global tables
+void emit(const DestList &dl, std::vector<int> &dest, std::vector<int> &unit, std::vector<int> &item) {
+    std::vector<int> order(dl.keys.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = (int)i;
+    std::stable_sort(order.begin(), order.end(),
+                     [&](int a, int b) { return dl.items[a].size() > dl.items[b].size(); });
+    for (int id : order) {
+        const DestKey &k = dl.keys[id];
+        const int did = (int)dest.size() / 4;
+        dest.push_back(k.o0);
+        dest.push_back((int)(((unsigned)k.o1 & 0x0fffffffu) | ((unsigned)k.kind << 28)));
+        dest.push_back((int)item.size());
+        dest.push_back((int)dl.items[id].size());
+        for (int it : dl.items[id]) item.push_back(it);
+        const int la = dl.shape[id].first, lb = dl.shape[id].second;
+        if (lb == 0) {
+            for (int ea = 0; ea < la; ea++)
+                for (int eb = 0; eb <= ea; eb++) unit.push_back((int)pack_unit(did, ea, eb));
+        } else {
+            for (int ea = 0; ea < la; ea++)
+                for (int eb = 0; eb < lb; eb++) unit.push_back((int)pack_unit(did, ea, eb));
+        }
+    }
+}
+
+// add all pairwise products of one factor's column groups.
+// cols: (tangent offset or -1 if constant, column in the record, width)
+struct Col { int t, c, w; };
+template <class MakeItem>
+void add_pairs(DestList &dl, const std::vector<Col> &cols, MakeItem mk, int rcol) {
+    for (size_t a = 0; a < cols.size(); a++) {
+        if (cols[a].t < 0) continue;
+        dl.add(DK_TILE, cols[a].t, cols[a].t, cols[a].w, 0, mk(cols[a].c, cols[a].c));
+        dl.add(DK_G, cols[a].t, 0, cols[a].w, 1, mk(cols[a].c, rcol));
+        for (size_t b = 0; b < a; b++) {
+            if (cols[b].t < 0) continue;
+            if (cols[a].t > cols[b].t) dl.add(DK_TILE, cols[a].t, cols[b].t, cols[a].w, cols[b].w, mk(cols[a].c, cols[b].c));
+            else dl.add(DK_TILE, cols[b].t, cols[a].t, cols[b].w, cols[a].w, mk(cols[b].c, cols[a].c));
+        }
+    }
+}
+
+}  // namespace
+
+int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt) {
+    const int nb = (int)p.blocks.size();
+    // ---- classify blocks: landmarks = size-1 Euclidean blocks used only as 4th block of projection factors
+    std::vector<int> use_lm(nb, 0), use_other(nb, 0);
+    for (auto &f : p.proj) { use_lm[f.b[3]]++; for (int k = 0; k < 3; k++) use_other[f.b[k]]++; }
+    for (auto &f : p.imu) for (int k = 0; k < 4; k++) use_other[f.b[k]]++;
+    for (auto &f : p.line) use_other[f.b]++;
+    for (auto &f : p.prior) for (int b : f.b) use_other[b]++;
+    std::vector<int> lm_of(nb, -1), cam_of(nb, -1);
+    out.cam_block.clear(); out.lm_block.clear();
+    // landmark numbering = order of first appearance in the projection factors (feature_index, estimator.cpp:1743)
+    for (auto &f : p.proj) {
+        const int b = f.b[3];
+        const ParamBlock &pb = p.blocks[b];
+        if (pb.size != 1 || pb.kind != KIND_EUCLID || use_other[b] || pb.constant) {
+            set_error("projection factor: 4th block must be a free size-1 inverse-depth block used by projection factors only");
+            return TCV_ERR_UNSUPPORTED;
+        }
+        if (lm_of[b] < 0) { lm_of[b] = (int)out.lm_block.size(); out.lm_block.push_back(b); }
+    }
+    for (int b = 0; b < nb; b++)
+        if (lm_of[b] < 0) { cam_of[b] = (int)out.cam_block.size(); out.cam_block.push_back(b); }
+    const int nblk = (int)out.cam_block.size(), L = (int)out.lm_block.size();
+    for (auto &f : p.proj)
+        for (int k = 0; k < 3; k++)
+            if (p.blocks[f.b[k]].kind != KIND_POSE || p.blocks[f.b[k]].size != 7) {
+                set_error("projection factor: first three blocks must be pose blocks");
+                return TCV_ERR_UNSUPPORTED;
+            }
+    for (auto &f : p.imu)
+        for (int k = 0; k < 4; k++) {
+            const ParamBlock &pb = p.blocks[f.b[k]];
+            const bool ok = (k % 2 == 0) ? (pb.kind == KIND_POSE && pb.size == 7) : (pb.kind == KIND_EUCLID && pb.size == 9);
+            if (!ok) { set_error("IMU factor: blocks must be pose(7), speed-bias(9), pose(7), speed-bias(9)"); return TCV_ERR_UNSUPPORTED; }
+        }
+    for (auto &f : p.line)
+        if (p.blocks[f.b].kind != KIND_POSE) { set_error("line factor: block must be a pose"); return TCV_ERR_UNSUPPORTED; }
+
+    // ---- ambient / tangent offsets: pose-kind blocks first in tangent space
+    std::vector<int> gsize(nblk), goff(nblk), loff(nblk, -1), kind(nblk);
+    int nx = 0, nc = 0;
+    for (int c = 0; c < nblk; c++) {
+        const ParamBlock &pb = p.blocks[out.cam_block[c]];
+        gsize[c] = pb.size; kind[c] = pb.kind; goff[c] = nx; nx += pb.size;
+        if (pb.kind == KIND_EUCLID && pb.size > 15) { set_error("Euclidean block wider than 15"); return TCV_ERR_UNSUPPORTED; }
+    }
+    for (int c = 0; c < nblk; c++)
+        if (kind[c] == KIND_POSE && !p.blocks[out.cam_block[c]].constant) { loff[c] = nc; nc += 6; }
+    const int npp = nc;
+    for (int c = 0; c < nblk; c++)
+        if (kind[c] != KIND_POSE && !p.blocks[out.cam_block[c]].constant) { loff[c] = nc; nc += gsize[c]; }
+    if (nc < 1) { set_error("no free camera-side parameter block"); return TCV_ERR_INVALID; }
+    const int nt = (nc + 1 + 15) / 16, ntp = (npp + 15) / 16;
+    const int ntiles = nt * (nt + 1) / 2, pp_tiles = ntp * (ntp + 1) / 2;
+    if (nc > 175 || nc + L > SCR_NL || L > 1024) { set_error("window too large for the fused solver (camera tangent dim > 175)"); return TCV_ERR_TOO_LARGE; }
+    const int nxl = (nx + L + 1) & ~1;
+    const int area_cap = LDS_DOUBLES - ntiles * 256 - 2 * nxl - 4 * 176 - 64;
+    const int stage_cap = (ntiles - pp_tiles) * 256;
+    if (area_cap < 512) { set_error("window too large for the fused solver (LDS)"); return TCV_ERR_TOO_LARGE; }
+
+    PlanHdr &H = out.hdr;
+    std::memset(&H, 0, sizeof(H));
+    H.nblk = nblk; H.nland = L; H.nc = nc; H.nx = nx; H.npp = npp; H.nt = nt; H.ntp = ntp;
+    H.n_imu = (int)p.imu.size(); H.n_proj = (int)p.proj.size(); H.n_line = (int)p.line.size();
+    H.lds_area = area_cap;
+    std::vector<int> &I = out.ints;
+    I.clear();
+    auto mark = [&]() { return (int)I.size(); };
+
+    H.o_blk = mark();
+    for (int c = 0; c < nblk; c++) { I.push_back(gsize[c]); I.push_back(goff[c]); I.push_back(loff[c]); I.push_back(kind[c]); }
+    H.o_imu = mark();
+    for (auto &f : p.imu) for (int k = 0; k < 4; k++) I.push_back(cam_of[f.b[k]]);
+
+    // ---- projection factors sorted by landmark (stable), landmark slots
+    std::vector<int> &order = out.proj_order;
+    order.resize(p.proj.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = (int)i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lm_of[p.proj[a].b[3]] < lm_of[p.proj[b].b[3]]; });
+    std::vector<int> lmptr(L + 1, 0);
+    for (auto &f : p.proj) lmptr[lm_of[f.b[3]] + 1]++;
+    for (int l = 0; l < L; l++) lmptr[l + 1] += lmptr[l];
+    std::vector<std::vector<int>> lm_slots(L);   // tangent offsets of the distinct free pose blocks
+    std::vector<int> e_off(L + 1, 0);
+    for (int l = 0; l < L; l++) {
+        for (int k = lmptr[l]; k < lmptr[l + 1]; k++) {
+            const ProjFac &f = p.proj[order[k]];
+            for (int s = 0; s < 3; s++) {
+                const int t = loff[cam_of[f.b[s]]];
+                if (t < 0) continue;
+                if (std::find(lm_slots[l].begin(), lm_slots[l].end(), t) == lm_slots[l].end()) lm_slots[l].push_back(t);
+            }
+        }
+        if (lm_slots[l].size() > 40) { set_error("landmark observed from more than 40 blocks"); return TCV_ERR_TOO_LARGE; }
+        e_off[l + 1] = e_off[l] + 6 * (int)lm_slots[l].size();
+    }
+    H.hcl_total = e_off[L];
+    if (H.hcl_total > 8192) { set_error("landmark coupling store too large"); return TCV_ERR_TOO_LARGE; }
+    H.o_proj = mark();
+    for (size_t k = 0; k < order.size(); k++) {
+        const ProjFac &f = p.proj[order[k]];
+        for (int s = 0; s < 3; s++) I.push_back(cam_of[f.b[s]]);
+        I.push_back(lm_of[f.b[3]]);
+    }
+    H.o_line = mark();
+    for (auto &f : p.line) I.push_back(cam_of[f.b]);
+
+    // ---- prior
+    if (p.prior.size() > 1) { set_error("more than one marginalisation factor"); return TCV_ERR_UNSUPPORTED; }
+    const tcv_prior *pr = p.prior.empty() ? nullptr : p.prior[0].prior;
+    H.o_prior = mark();
+    std::vector<int> pcol;
+    if (pr) {
+        if (pr->n > 128) { set_error("prior with more than 128 rows"); return TCV_ERR_TOO_LARGE; }
+        H.prior_n = pr->n; H.prior_nblk = (int)pr->size.size(); H.prior_xsize = (int)pr->x0.size();
+        pcol.assign(pr->n, -1);
+        for (int k = 0; k < H.prior_nblk; k++) {
+            const int b = p.prior[0].b[k];
+            if (cam_of[b] < 0) { set_error("prior attached to a landmark block"); return TCV_ERR_UNSUPPORTED; }
+            const ParamBlock &pb = p.blocks[b];
+            if (pb.size != pr->size[k]) { set_error("prior block size mismatch"); return TCV_ERR_INVALID; }
+            I.push_back(cam_of[b]); I.push_back(pr->idx[k]); I.push_back(pr->size[k]); I.push_back(pr->xoff[k]);
+            const int local = pr->size[k] == 7 ? 6 : pr->size[k];
+            const int t = loff[cam_of[b]];
+            for (int j = 0; j < local; j++)
+                if (pr->idx[k] + j < pr->n) pcol[pr->idx[k] + j] = t < 0 ? -1 : t + j;
+        }
+    }
+    H.o_pcol = mark();
+    for (int v : pcol) I.push_back(v);
+
+    H.o_lm = mark();
+    for (int l = 0; l < L; l++) { I.push_back(e_off[l]); I.push_back((int)lm_slots[l].size()); }
+    H.o_lmslotptr = mark();
+    { int acc = 0; for (int l = 0; l < L; l++) { I.push_back(acc); acc += (int)lm_slots[l].size(); } I.push_back(acc); }
+    H.o_lmslot = mark();
+    for (int l = 0; l < L; l++) for (int t : lm_slots[l]) I.push_back(t);
+
+    // ---- visual chunks (whole landmarks; lines ride in chunk 0)
+    struct VChunk { int pb, pn, lb, ln, lmb, lmn; };
+    std::vector<VChunk> vch;
+    {
+        const int nline = (int)p.line.size();
+        if (nline * LINE_REC > stage_cap) { set_error("too many line factors for LDS staging"); return TCV_ERR_TOO_LARGE; }
+        VChunk cur{0, 0, 0, nline, 0, 0};
+        int recs = nline * LINE_REC, hcl = 0;
+        for (int l = 0; l < L; l++) {
+            const int nf = lmptr[l + 1] - lmptr[l], nh = 6 * (int)lm_slots[l].size();
+            if (nf * PROJ_REC > stage_cap || nh + 3 > area_cap) { set_error("landmark track too long for LDS staging"); return TCV_ERR_TOO_LARGE; }
+            if (recs + nf * PROJ_REC > stage_cap || hcl + nh + 3 * (cur.lmn + 1) > area_cap) {
+                vch.push_back(cur);
+                cur = VChunk{lmptr[l], 0, 0, 0, l, 0};
+                recs = 0; hcl = 0;
+            }
+            cur.pn += nf; cur.lmn += 1; recs += nf * PROJ_REC; hcl += nh;
+        }
+        vch.push_back(cur);
+    }
+    H.n_vis_chunk = (int)vch.size();
+    std::vector<int> vdest, vunit, vitem, sdest, sunit, sitem, vchunk_tab;
+    for (auto &c : vch) {
+        DestList dl, sl;
+        for (int k = 0; k < c.pn; k++) {
+            const ProjFac &f = p.proj[order[c.pb + k]];
+            const int l = lm_of[f.b[3]];
+            const int base = k * PROJ_REC;
+            auto mk = [&](int ca, int cb) { return (int)(((unsigned)base << 11) | ((unsigned)ca << 6) | ((unsigned)cb << 1)); };
+            std::vector<Col> cols;
+            for (int s = 0; s < 3; s++) cols.push_back(Col{loff[cam_of[f.b[s]]], 6 * s, 6});
+            for (size_t a = 0; a < cols.size(); a++)
+                for (size_t b = 0; b < a; b++)
+                    if (cols[a].t >= 0 && cols[a].t == cols[b].t) { set_error("projection factor uses one block twice"); return TCV_ERR_UNSUPPORTED; }
+            add_pairs(dl, cols, mk, 19);
+            for (auto &cc : cols) {
+                if (cc.t < 0) continue;
+                const int slot = (int)(std::find(lm_slots[l].begin(), lm_slots[l].end(), cc.t) - lm_slots[l].begin());
+                dl.add(DK_HCL, e_off[l] + 6 * slot, 0, 6, 1, mk(cc.c, 18));
+            }
+            dl.add(DK_HLL, l, 0, 1, 1, mk(18, 18));
+            dl.add(DK_GL, l, 0, 1, 1, mk(18, 19));
+        }
+        for (int k = 0; k < c.ln; k++) {
+            const LineFac &f = p.line[c.lb + k];
+            const int base = c.pn * PROJ_REC + k * LINE_REC;
+            if (base >= (1 << 21)) { set_error("staging offset overflow"); return TCV_ERR_TOO_LARGE; }
+            auto mk = [&](int ca, int cb) { return (int)(((unsigned)base << 11) | ((unsigned)ca << 6) | ((unsigned)cb << 1) | 1u); };
+            std::vector<Col> cols{Col{loff[cam_of[f.b]], 0, 6}};
+            add_pairs(dl, cols, mk, 6);
+        }
+        for (int l = c.lmb; l < c.lmb + c.lmn; l++) {
+            const auto &sl_t = lm_slots[l];
+            for (size_t a = 0; a < sl_t.size(); a++) {
+                auto mk = [&](int oa, int ob) { return (int)(((unsigned)l << 16) | ((unsigned)oa << 8) | (unsigned)ob); };
+                sl.add(DK_TILE, sl_t[a], sl_t[a], 6, 0, mk(6 * (int)a, 6 * (int)a));
+                sl.add(DK_RC, sl_t[a], 0, 6, 1, mk(6 * (int)a, 255));
+                for (size_t b = 0; b < a; b++) {
+                    if (sl_t[a] > sl_t[b]) sl.add(DK_TILE, sl_t[a], sl_t[b], 6, 6, mk(6 * (int)a, 6 * (int)b));
+                    else sl.add(DK_TILE, sl_t[b], sl_t[a], 6, 6, mk(6 * (int)b, 6 * (int)a));
+                }
+            }
+        }
+        const int ub = (int)vunit.size(), sub = (int)sunit.size();
+        emit(dl, vdest, vunit, vitem);
+        emit(sl, sdest, sunit, sitem);
+        const int tab[12] = {c.pb, c.pn, c.lb, c.ln, ub, (int)vunit.size() - ub, c.lmb, c.lmn,
+                             e_off[c.lmb], e_off[c.lmb + c.lmn] - e_off[c.lmb], sub, (int)sunit.size() - sub};
+        vchunk_tab.insert(vchunk_tab.end(), tab, tab + 12);
+    }
+    if (vdest.size() / 4 >= (1u << 24) || sdest.size() / 4 >= (1u << 24)) { set_error("plan too large"); return TCV_ERR_TOO_LARGE; }
+    H.o_vchunk = mark(); I.insert(I.end(), vchunk_tab.begin(), vchunk_tab.end());
+    H.o_vdest = mark(); I.insert(I.end(), vdest.begin(), vdest.end()); H.n_vdest = (int)vdest.size() / 4;
+    H.o_vunit = mark(); I.insert(I.end(), vunit.begin(), vunit.end()); H.n_vunit = (int)vunit.size();
+    H.o_vitem = mark(); I.insert(I.end(), vitem.begin(), vitem.end()); H.n_vitem = (int)vitem.size();
+    H.o_sdest = mark(); I.insert(I.end(), sdest.begin(), sdest.end()); H.n_sdest = (int)sdest.size() / 4;
+    H.o_sunit = mark(); I.insert(I.end(), sunit.begin(), sunit.end()); H.n_sunit = (int)sunit.size();
+    H.o_sitem = mark(); I.insert(I.end(), sitem.begin(), sitem.end()); H.n_sitem = (int)sitem.size();
+
+    // ---- IMU chunks
+    {
+        const int per = std::max(1, std::min(H.n_imu, area_cap / IMU_REC));
+        if (H.n_imu > 0 && area_cap < IMU_REC) { set_error("no LDS room for IMU staging"); return TCV_ERR_TOO_LARGE; }
+        if (H.n_imu > 16) { set_error("more than 16 IMU factors"); return TCV_ERR_TOO_LARGE; }
+        std::vector<int> idest, iunit, iitem, ichunk;
+        for (int fb = 0; fb < H.n_imu; fb += per) {
+            const int fn = std::min(per, H.n_imu - fb);
+            DestList dl;
+            for (int k = 0; k < fn; k++) {
+                const ImuFac &f = p.imu[fb + k];
+                auto mk = [&](int ca, int cb) { return (int)(((unsigned)k << 10) | ((unsigned)ca << 5) | (unsigned)cb); };
+                const int colc[4] = {0, 6, 15, 21}, colw[4] = {6, 9, 6, 9};
+                std::vector<Col> cols;
+                for (int s = 0; s < 4; s++) cols.push_back(Col{loff[cam_of[f.b[s]]], colc[s], colw[s]});
+                for (size_t a = 0; a < cols.size(); a++)
+                    for (size_t b = 0; b < a; b++)
+                        if (cols[a].t >= 0 && cols[a].t == cols[b].t) { set_error("IMU factor uses one block twice"); return TCV_ERR_UNSUPPORTED; }
+                add_pairs(dl, cols, mk, 30);
+            }
+            const int ub = (int)iunit.size();
+            emit(dl, idest, iunit, iitem);
+            ichunk.push_back(fb); ichunk.push_back(fn); ichunk.push_back(ub); ichunk.push_back((int)iunit.size() - ub);
+        }
+        H.n_imu_chunk = (int)ichunk.size() / 4;
+        H.o_ichunk = mark(); I.insert(I.end(), ichunk.begin(), ichunk.end());
+        H.o_idest = mark(); I.insert(I.end(), idest.begin(), idest.end()); H.n_idest = (int)idest.size() / 4;
+        H.o_iunit = mark(); I.insert(I.end(), iunit.begin(), iunit.end()); H.n_iunit = (int)iunit.size();
+        H.o_iitem = mark(); I.insert(I.end(), iitem.begin(), iitem.end()); H.n_iitem = (int)iitem.size();
+    }
+    H.plan_ints = (int)I.size();
+
+    // ---- data
+    std::vector<double> &D = out.doubles;
+    D.clear();
+    WinHdr &W = out.win;
+    std::memset(&W, 0, sizeof(W));
+    W.d_x = (int)D.size();
+    for (int c = 0; c < nblk; c++) { const ParamBlock &pb = p.blocks[out.cam_block[c]]; D.insert(D.end(), pb.addr, pb.addr + pb.size); }
+    for (int l = 0; l < L; l++) D.push_back(p.blocks[out.lm_block[l]].addr[0]);
+    W.d_imu = (int)D.size();
+    for (auto &f : p.imu) {
+        const tcv_imu_preintegration &q = f.pre;
+        D.insert(D.end(), q.delta_p, q.delta_p + 3); D.insert(D.end(), q.delta_q, q.delta_q + 4);
+        D.insert(D.end(), q.delta_v, q.delta_v + 3); D.insert(D.end(), q.linearized_ba, q.linearized_ba + 3);
+        D.insert(D.end(), q.linearized_bg, q.linearized_bg + 3); D.push_back(q.sum_dt);
+        const int rc[5][2] = {{0, 9}, {0, 12}, {3, 12}, {6, 9}, {6, 12}};   // dp_dba dp_dbg dq_dbg dv_dba dv_dbg (imu_factor.h:61-79)
+        for (auto &b : rc) for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) D.push_back(q.jacobian[(b[0] + i) * 15 + b[1] + j]);
+        D.insert(D.end(), q.covariance, q.covariance + 225);
+    }
+    W.d_proj = (int)D.size();
+    double psi = 0, pla = 0;
+    for (size_t k = 0; k < order.size(); k++) {
+        const ProjFac &f = p.proj[order[k]];
+        if (k == 0) { psi = f.sqrt_info; pla = f.loss_a; }
+        else if (f.sqrt_info != psi || f.loss_a != pla) { set_error("projection factors must share sqrt_info and loss"); return TCV_ERR_UNSUPPORTED; }
+        D.insert(D.end(), f.pts, f.pts + 6);
+    }
+    W.d_line = (int)D.size();
+    double lla = 0;
+    for (size_t k = 0; k < p.line.size(); k++) {
+        const LineFac &f = p.line[k];
+        if (k == 0) lla = f.loss_a;
+        else {
+            const LineFac &g = p.line[0];
+            if (f.loss_a != lla || std::memcmp(f.K, g.K, sizeof f.K) || std::memcmp(f.R, g.R, sizeof f.R) || std::memcmp(f.T, g.T, sizeof f.T)) {
+                set_error("line factors must share K, b_c_R, b_c_T and loss"); return TCV_ERR_UNSUPPORTED;
+            }
+        }
+        D.insert(D.end(), f.d, f.d + 9);
+    }
+    W.d_linec = (int)D.size();
+    if (!p.line.empty()) { const LineFac &g = p.line[0]; D.insert(D.end(), g.K, g.K + 9); D.insert(D.end(), g.R, g.R + 9); D.insert(D.end(), g.T, g.T + 3); }
+    else D.insert(D.end(), 21, 0.0);
+    W.d_prior = (int)D.size();
+    if (pr) { D.insert(D.end(), pr->J0.begin(), pr->J0.end()); D.insert(D.end(), pr->r0.begin(), pr->r0.end()); D.insert(D.end(), pr->x0.begin(), pr->x0.end()); }
+    W.d_misc = (int)D.size();
+    D.insert(D.end(), p.G, p.G + 3); D.push_back(psi); D.push_back(pla); D.push_back(lla);
+    W.d_sqrt = -1;
+    if (imu_sqrt && H.n_imu) { W.d_sqrt = (int)D.size(); D.insert(D.end(), imu_sqrt, imu_sqrt + 225 * H.n_imu); }
+    if (D.size() & 1) D.push_back(0.0);
+    W.n_doubles = (int)D.size();
+    for (double v : D) if (!(v == v) || v > 1e300 || v < -1e300) { set_error("NaN/Inf in window data"); return TCV_ERR_NUMERIC; }
+    return TCV_OK;
+}
+
+}  // namespace tcv

@@ -1,0 +1,130 @@
+// Device-resident layout of one packed sliding window ("what OptimizationWithLine hands to the
+// solver", reference vins_estimator/src/estimator.cpp:1677-1900) and of the static assembly plan
+// that goes with its graph structure.
+//
+// A window is split into
+//   * DATA  (doubles, one copy per window):  initial states, IMU pre-integration constants,
+//     point / line observations, the marginalisation prior.  These are the "algorithmic bytes".
+//   * PLAN  (ints, one copy per distinct graph STRUCTURE, shared by every window with the same
+//     structure):  block tables and the destination-driven gather lists that turn per-factor
+//     Jacobian blocks into the block-sparse normal equations without atomics, in a fixed order.
+//
+// Unknown ordering inside the fused solver (tangent space):
+//   [ pose-kind camera blocks (6 each: the 11 poses + the extrinsic) | Euclidean camera blocks
+//   (speed-bias 9 each) ] followed, outside the dense system, by the landmarks (inverse depths,
+//   eliminated by the Schur complement: they only ever meet {pose_i, pose_j, ex}, estimator.cpp:1767).
+#pragma once
+
+namespace tcv {
+
+enum { KIND_EUCLID = 0, KIND_POSE = 1 };
+enum { TILE = 16, TILE_ELEMS = 256 };
+enum { LDS_DOUBLES = 20480 };  // 160 KiB per workgroup on gfx950
+enum { MAX_TRACE = 64 };
+
+// staging record strides (doubles per residual row): Jacobian columns followed by the residual
+enum {
+    PROJ_STRIDE = 20,  // [pose_i 6 | pose_j 6 | ex 6 | inv depth 1 | r]
+    PROJ_REC = 40,
+    LINE_STRIDE = 7,   // [pose 6 | r]
+    LINE_REC = 14,
+    IMU_STRIDE_J = 31, // [pose_i 6 | sb_i 9 | pose_j 6 | sb_j 9 | r]
+    IMU_REC = 465,
+    IMU_CONST = 287    // doubles of pre-integration constants per IMU factor
+};
+
+// gather destination kinds
+enum { DK_TILE = 0, DK_G = 1, DK_HCL = 2, DK_HLL = 3, DK_GL = 4, DK_RC = 5 };
+
+// dest record: 4 ints {o0, o1 | kind << 28, item_begin, item_count}
+//   DK_TILE: o0 = first tangent row, o1 = first tangent col (row >= col for every entry)
+//   DK_G   : o0 = first tangent index
+//   DK_HCL : o0 = offset in the Hcl store
+//   DK_HLL / DK_GL : o0 = landmark
+//   DK_RC  : o0 = first tangent index (Schur plan only)
+// unit: dest << 8 | ea << 4 | eb        (ea/eb: entry inside the block pair)
+// visual item: rec_base << 11 | colA << 6 | colB << 1 | type   (type 0: proj stride 20, 1: line stride 7)
+// imu item   : fac_local << 10 | colA << 5 | colB
+// schur item : landmark << 16 | offA << 8 | offB      (offsets inside the landmark's Hcl slice; offB = 255: gl)
+inline unsigned pack_unit(int dest, int ea, int eb) { return ((unsigned)dest << 8) | ((unsigned)ea << 4) | (unsigned)eb; }
+
+struct PlanHdr {
+    // sizes
+    int nblk, nland;    // camera blocks (constant ones included), landmarks
+    int nc, nx;         // camera tangent dim (variable blocks), camera ambient dim
+    int npp;            // tangent dims of the pose-kind blocks (they come first)
+    int nt, ntp;        // 16x16 tile rows of the augmented system (nc + 1 rhs row), tile rows covering npp
+    int n_imu, n_proj, n_line;
+    int prior_n, prior_nblk, prior_xsize;
+    int hcl_total;      // doubles of the landmark/camera coupling store
+    int n_imu_chunk;    // IMU factors are staged through LDS in chunks
+    int n_vis_chunk;    // point/line factors likewise (1 for the BASELINE configs)
+    int lds_area;       // doubles of the time-shared LDS area
+    int flags;
+    // int-pool offsets (relative to the plan base)
+    int o_blk;      // nblk x 4 : gsize, goff (ambient), loff (tangent, -1 constant), kind
+    int o_imu;      // n_imu x 4 block ids
+    int o_proj;     // n_proj x 4 : blk_i, blk_j, blk_ex, landmark
+    int o_line;     // n_line
+    int o_prior;    // prior_nblk x 4 : blk id, idx (first J0 column), gsize, x0 offset
+    int o_pcol;     // prior_n : tangent index of each J0 column (-1 constant)
+    int o_lm;       // nland x 2 : e_off (offset of the landmark's slice in the Hcl store), nslot
+    int o_lmslot;   // sum nslot : tangent offset of every slot's block (ordered by landmark)
+    int o_lmslotptr;// nland + 1
+    int o_vchunk;   // n_vis_chunk x 12: proj_begin, proj_count, line_begin, line_count, unit_begin, unit_count,
+                    //                   lm_begin, lm_count, hcl_begin, hcl_size, schur_unit_begin, schur_unit_count
+    int o_vdest, o_vunit, o_vitem;
+    int n_vdest, n_vunit, n_vitem;
+    int o_sdest, o_sunit, o_sitem;   // Schur plan
+    int n_sdest, n_sunit, n_sitem;
+    int o_ichunk;   // n_imu_chunk x 4 : fac_begin, fac_count, unit_begin, unit_count
+    int o_idest, o_iunit, o_iitem;
+    int n_idest, n_iunit, n_iitem;
+    int plan_ints;  // total ints of this plan (header excluded)
+};
+
+struct WinHdr {
+    int plan;           // index of the plan
+    int pad;
+    long long dbase;    // element offset of this window's doubles in the batch data pool
+    // double-pool offsets (relative to dbase)
+    int d_x;        // nx + nland initial state (camera blocks in block order, then landmarks)
+    int d_imu;      // n_imu x 287
+    int d_proj;     // n_proj x 6
+    int d_line;     // n_line x 9
+    int d_linec;    // 21 : K, Ric, Tic (row-major)
+    int d_prior;    // J0 (n x n column-major), r0 (n), x0 (prior_xsize)
+    int d_misc;     // G(3), proj sqrt_info, proj loss a, line loss a
+    int d_sqrt;     // optional host-provided sqrt_info, n_imu x 225 (-1: computed on device)
+    int n_doubles;  // doubles of this window
+    int pad1;
+};
+
+// per-window result block written by the solver
+struct DevSummary {
+    int num_iterations, termination;
+    int status, pad;
+    double initial_cost, final_cost;
+    double cost[MAX_TRACE], cost_candidate[MAX_TRACE], model_cost_change[MAX_TRACE];
+    double radius[MAX_TRACE], mu[MAX_TRACE], rho[MAX_TRACE], step_norm[MAX_TRACE];
+    int step_ok[MAX_TRACE], dogleg_case[MAX_TRACE];
+};
+
+struct SolveArgs {
+    const WinHdr *win;
+    const PlanHdr *plans;
+    const long long *plan_base;   // element offset of every plan in the int pool
+    const int *ipool;
+    const double *dpool;
+    double *state_out;            // per window: nx + nland (stride state_stride)
+    DevSummary *summary;
+    double *first_delta;          // optional, per window: nc + nland tangent step of iteration 1 (stride delta_stride)
+    double *scratch;              // per workgroup
+    int nwin, state_stride, delta_stride, scratch_stride;
+    int max_iterations, fixed_iterations, use_mfma, pad;
+};
+
+// per-workgroup global scratch layout (doubles)
+enum { SCR_NL = 1280 };  // capacity of an nl-sized vector (nc + nland)
+
+}  // namespace tcv

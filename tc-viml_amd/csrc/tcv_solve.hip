@@ -1,0 +1,875 @@
+// Fused sliding-window solve for gfx950 (MI355X): one workgroup owns one window at a time and
+// runs the whole trust-region (dogleg) loop of ceres::Solve as the reference configures it
+// (vins_estimator/src/estimator.cpp:1888-1900: SPARSE_SCHUR + DOGLEG, Ceres defaults otherwise)
+// without ever writing a Jacobian or the normal equations to HBM:
+//
+//   linearise   residual blocks are evaluated one lane per block into LDS staging records
+//               (imu_factor.h:19-181, projection_factor.cpp:21-124, line_projection_factor.cpp:19-120,
+//               marginalization_factor.cpp:335-384 with the CauchyLoss corrector of :37-68) and
+//               gathered, destination-driven and in a fixed order, into the reduced camera
+//               system that lives in LDS as 16x16 FP64 tiles (lower triangle, XOR-swizzled);
+//   Schur       the inverse-depth blocks are 1x1, so their elimination is a scaled rank-1 update
+//               per landmark, again gathered per destination entry;
+//   factorise   right-looking tiled Cholesky in LDS; the trailing update runs on the matrix cores
+//               (v_mfma_f64_16x16x4_f64); the right-hand side rides along as an extra matrix row;
+//   step        dogleg step selection, PoseLocalParameterization::Plus
+//               (pose_local_parameterization.cpp:3-19), candidate evaluation fused with the next
+//               linearisation.
+//
+// Trust-region semantics restate upstream Ceres 2.x (not in the reference tree; SURVEY.md
+// Appendix C).  All arithmetic is FP64.
+#include <hip/hip_runtime.h>
+#include "tcv_factors.h"
+#include "tcv_packed.h"
+
+namespace tcv {
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+// ---- LDS tile addressing -------------------------------------------------------------------------
+// element (r, c) of a 16x16 tile sits at r*16 + (c ^ (r & 14)): conflict-free for the MFMA operand
+// reads (lane -> row l&15, column 4kk + (l>>4)), for the C-layout loads/stores and for row-per-lane
+// column walks.
+__device__ __forceinline__ int sw(int r, int c) { return (r << 4) + (c ^ (r & 14)); }
+__device__ __forceinline__ int tbase(int I, int J) { return ((I * (I + 1) / 2) + J) << 8; }
+__device__ __forceinline__ int tix(int a, int b) { return tbase(a >> 4, b >> 4) + sw(a & 15, b & 15); }
+
+template <int NT>
+struct Ctx {
+    // plan / data
+    const PlanHdr *P;
+    const int *ip;       // plan ints
+    const double *dp;    // window doubles
+    const WinHdr *W;
+    // LDS
+    double *tiles, *stage, *xs, *xc, *sc, *dd, *ycam, *invdiag, *red, *area;
+    int *flag;
+    // global scratch (per workgroup)
+    double *v_s, *v_g, *v_D, *v_ghat, *v_y, *v_p, *v_rc, *v_sd, *l_hll, *l_gl, *l_invk, *g_hcl, *g_hp, *g_pr, *g_pdx,
+        *g_sqrt;
+    int ntiles, stage_cap;
+    int tid;
+};
+
+enum { SCR_HCL = 8192, SCR_HP = 8256, SCR_SQ = 16 * 225, SCR_LM = 1024 };
+enum {
+    SCR_TOTAL = 8 * SCR_NL + 3 * SCR_LM + SCR_HCL + SCR_HP + 2 * 128 + SCR_SQ
+};
+
+template <int NT>
+__device__ __forceinline__ double block_sum(double v, double *red, int tid) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    double t = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; w++) t += red[w];
+    return t;
+}
+
+template <int NT, int N>
+__device__ __forceinline__ void block_sum_n(double (&v)[N], double *red, int tid) {
+#pragma unroll
+    for (int k = 0; k < N; k++)
+        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_down(v[k], o);
+    __syncthreads();
+    if ((tid & 63) == 0)
+#pragma unroll
+        for (int k = 0; k < N; k++) red[(tid >> 6) * N + k] = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        double t = 0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; w++) t += red[w * N + k];
+        v[k] = t;
+    }
+}
+
+// ---- gather: sum over the items of a destination -------------------------------------------------
+__device__ __forceinline__ double gather_visual(const double *stage, const int *items, int n, int ea, int eb) {
+    double s = 0;
+    for (int k = 0; k < n; k++) {
+        const unsigned it = (unsigned)items[k];
+        const int type = it & 1, cb = (it >> 1) & 31, ca = (it >> 6) & 31, base = it >> 11;
+        const int ld = type ? LINE_STRIDE : PROJ_STRIDE;
+        const double *rec = stage + base;
+        s += rec[ca + ea] * rec[cb + eb];
+        s += rec[ld + ca + ea] * rec[ld + cb + eb];
+    }
+    return s;
+}
+
+__device__ __forceinline__ double gather_imu(const double *recs, const int *items, int n, int ea, int eb) {
+    double s = 0;
+    for (int k = 0; k < n; k++) {
+        const unsigned it = (unsigned)items[k];
+        const int cb = it & 31, ca = (it >> 5) & 31, f = it >> 10;
+        const double *rec = recs + f * IMU_REC;
+#pragma unroll
+        for (int row = 0; row < 15; row++) s += rec[row * IMU_STRIDE_J + ca + ea] * rec[row * IMU_STRIDE_J + cb + eb];
+    }
+    return s;
+}
+
+// ---- linearise at x: cost, and (if assemble) S~ = Hcc - sum_l Hcl Hcl'/kappa_l in the tiles --------
+// kappa_l = hll + mu * clamp(s_l^2 hll) / s_l^2 is the landmark pivot of the Jacobi-scaled,
+// mu-regularised system expressed in unscaled units (DoglegStrategy + SchurEliminator restated).
+template <int NT>
+__device__ double linearize(Ctx<NT> &C, const double *x, bool first, bool assemble, double mu) {
+    const PlanHdr &P = *C.P;
+    const int tid = C.tid;
+    const int *ip = C.ip;
+    const double *dp = C.dp;
+    const int nc = P.nc, L = P.nland, nx = P.nx;
+    const double *misc = dp + C.W->d_misc;
+    const double G3[3] = {misc[0], misc[1], misc[2]};
+    const double proj_sqrt = misc[3], proj_loss = misc[4], line_loss = misc[5];
+    const int pp_elems = (P.ntp * (P.ntp + 1) / 2) << 8;
+    double cost_acc = 0.0;
+
+    if (assemble) {
+        for (int i = tid; i < pp_elems; i += NT) C.tiles[i] = 0.0;
+        for (int i = tid; i < nc + L; i += NT) C.v_g[i] = 0.0;
+        for (int i = tid; i < nc; i += NT) { C.v_rc[i] = 0.0; C.v_sd[i] = 0.0; }
+    }
+    const int *blk = ip + P.o_blk;
+    // ---------------- point + line factors, chunk by chunk -------------------------------------------
+    for (int ch = 0; ch < P.n_vis_chunk; ch++) {
+        const int *vc = ip + P.o_vchunk + ch * 12;
+        const int pb = vc[0], pn = vc[1], lb = vc[2], ln = vc[3], ub = vc[4], un = vc[5];
+        const int lmb = vc[6], lmn = vc[7], ebase = vc[8], esize = vc[9], sub = vc[10], sun = vc[11];
+        double *hcl = C.area, *hll = C.area + esize, *gl = hll + lmn, *invk = gl + lmn;
+        if (assemble)
+            for (int i = tid; i < esize + 2 * lmn; i += NT) C.area[i] = 0.0;
+        __syncthreads();
+        for (int f = tid; f < pn; f += NT) {
+            const int *pf = ip + P.o_proj + (pb + f) * 4;
+            const double *xi = x + blk[pf[0] * 4 + 1], *xj = x + blk[pf[1] * 4 + 1], *xe = x + blk[pf[2] * 4 + 1];
+            const double lam = x[nx + pf[3]];
+            double *rec = C.stage + f * PROJ_REC;
+            double r[2];
+            if (assemble) {
+                proj_eval(xi, xj, xe, lam, dp + C.W->d_proj + (pb + f) * 6, proj_sqrt, r, rec, PROJ_STRIDE);
+                cost_acc += loss_correct2(r, rec, 19, PROJ_STRIDE, proj_loss);
+                rec[19] = r[0];
+                rec[PROJ_STRIDE + 19] = r[1];
+            } else {
+                proj_eval(xi, xj, xe, lam, dp + C.W->d_proj + (pb + f) * 6, proj_sqrt, r, nullptr, PROJ_STRIDE);
+                cost_acc += loss_correct2(r, nullptr, 19, PROJ_STRIDE, proj_loss);
+            }
+        }
+        for (int f = tid; f < ln; f += NT) {
+            const int b = ip[P.o_line + lb + f];
+            const double *xp = x + blk[b * 4 + 1];
+            const double *lc = dp + C.W->d_linec;
+            double *rec = C.stage + pn * PROJ_REC + f * LINE_REC;
+            double r[2];
+            if (assemble) {
+                line_eval(xp, dp + C.W->d_line + (lb + f) * 9, lc, lc + 9, lc + 18, r, rec, LINE_STRIDE);
+                cost_acc += loss_correct2(r, rec, 6, LINE_STRIDE, line_loss);
+                rec[6] = r[0];
+                rec[LINE_STRIDE + 6] = r[1];
+            } else {
+                line_eval(xp, dp + C.W->d_line + (lb + f) * 9, lc, lc + 9, lc + 18, r, nullptr, LINE_STRIDE);
+                cost_acc += loss_correct2(r, nullptr, 6, LINE_STRIDE, line_loss);
+            }
+        }
+        if (!assemble) continue;
+        __syncthreads();
+        // gather J'J / J'r contributions, one destination entry per unit
+        {
+            const int *dest = ip + P.o_vdest, *unit = ip + P.o_vunit + ub, *item = ip + P.o_vitem;
+            for (int u = tid; u < un; u += NT) {
+                const unsigned uu = (unsigned)unit[u];
+                const int eb = uu & 15, ea = (uu >> 4) & 15;
+                const int *d = dest + (uu >> 8) * 4;
+                const int kind = ((unsigned)d[1]) >> 28, o0 = d[0], o1 = d[1] & 0x0fffffff;
+                const double s = gather_visual(C.stage, item + d[2], d[3], ea, eb);
+                if (kind == DK_TILE) C.tiles[tix(o0 + ea, o1 + eb)] += s;
+                else if (kind == DK_G) C.v_g[o0 + ea] += s;
+                else if (kind == DK_HCL) hcl[o0 - ebase + ea] += s;
+                else if (kind == DK_HLL) hll[o0 - lmb] += s;
+                else gl[o0 - lmb] += s;
+            }
+        }
+        __syncthreads();
+        // landmark pivots of this chunk; keep copies for the Cauchy point and the back-substitution
+        for (int l = tid; l < lmn; l += NT) {
+            const double h = hll[l];
+            double sl;
+            if (first) { sl = 1.0 / (1.0 + sqrt(h)); C.v_s[nc + lmb + l] = sl; }
+            else sl = C.v_s[nc + lmb + l];
+            const double d2 = fmin(fmax(sl * sl * h, 1e-6), 1e32);
+            const double kappa = h + mu * d2 / (sl * sl);
+            const double ik = 1.0 / kappa;
+            invk[l] = ik;
+            C.l_hll[lmb + l] = h; C.l_gl[lmb + l] = gl[l]; C.l_invk[lmb + l] = ik;
+            C.v_g[nc + lmb + l] = gl[l];
+        }
+        for (int i = tid; i < esize; i += NT) C.g_hcl[ebase + i] = hcl[i];
+        __syncthreads();
+        // Schur complement of the chunk's landmarks
+        {
+            const int *dest = ip + P.o_sdest, *unit = ip + P.o_sunit + sub, *item = ip + P.o_sitem;
+            const int *lm = ip + P.o_lm;
+            for (int u = tid; u < sun; u += NT) {
+                const unsigned uu = (unsigned)unit[u];
+                const int eb = uu & 15, ea = (uu >> 4) & 15;
+                const int *d = dest + (uu >> 8) * 4;
+                const int kind = ((unsigned)d[1]) >> 28, o0 = d[0], o1 = d[1] & 0x0fffffff;
+                const int *it = item + d[2];
+                double s = 0;
+                for (int k = 0; k < d[3]; k++) {
+                    const unsigned v = (unsigned)it[k];
+                    const int l = v >> 16, oa = (v >> 8) & 255, ob = v & 255;
+                    const double *h = hcl + (lm[l * 2] - ebase);
+                    const double rhs = (ob == 255) ? gl[l - lmb] : h[ob + eb];
+                    s += h[oa + ea] * rhs * invk[l - lmb];
+                }
+                if (kind == DK_TILE) {
+                    C.tiles[tix(o0 + ea, o1 + eb)] -= s;
+                    if (o0 + ea == o1 + eb) C.v_sd[o0 + ea] += s;
+                } else {
+                    C.v_rc[o0 + ea] += s;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (assemble) {
+        const int all_elems = C.ntiles << 8;
+        for (int i = pp_elems + tid; i < all_elems; i += NT) C.tiles[i] = 0.0;
+    }
+    __syncthreads();
+    // ---------------- IMU factors, chunk by chunk ---------------------------------------------------
+    for (int ch = 0; ch < P.n_imu_chunk; ch++) {
+        const int *ic = ip + P.o_ichunk + ch * 4;
+        const int fb = ic[0], fn = ic[1], ub = ic[2], un = ic[3];
+        double *recs = C.area;
+        if (tid < fn) {
+            const int *b = ip + P.o_imu + (fb + tid) * 4;
+            double *rec = recs + tid * IMU_REC;
+            imu_raw(x + blk[b[0] * 4 + 1], x + blk[b[1] * 4 + 1], x + blk[b[2] * 4 + 1], x + blk[b[3] * 4 + 1],
+                    dp + C.W->d_imu + (fb + tid) * IMU_CONST, G3, rec + 30, IMU_STRIDE_J, assemble ? rec : nullptr,
+                    IMU_STRIDE_J);
+        }
+        __syncthreads();
+        // whiten in place with the upper-triangular sqrt_info: column-parallel, rows ascending
+        {
+            const int ncol = assemble ? 31 : 1;
+            for (int w = tid; w < fn * ncol; w += NT) {
+                const int f = w / ncol, col = assemble ? (w - f * ncol) : 30;
+                double *rec = recs + f * IMU_REC + col;
+                const double *S = C.g_sqrt + (fb + f) * 225;
+                double v[15];
+#pragma unroll
+                for (int r = 0; r < 15; r++) v[r] = rec[r * IMU_STRIDE_J];
+#pragma unroll
+                for (int r = 0; r < 15; r++) {
+                    double a = 0;
+#pragma unroll
+                    for (int s2 = r; s2 < 15; s2++) a += S[r * 15 + s2] * v[s2];
+                    rec[r * IMU_STRIDE_J] = a;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < fn) {
+            const double *rec = recs + tid * IMU_REC + 30;
+            double s = 0;
+#pragma unroll
+            for (int r = 0; r < 15; r++) s += rec[r * IMU_STRIDE_J] * rec[r * IMU_STRIDE_J];
+            cost_acc += 0.5 * s;
+        }
+        if (assemble) {
+            const int *dest = ip + P.o_idest, *unit = ip + P.o_iunit + ub, *item = ip + P.o_iitem;
+            for (int u = tid; u < un; u += NT) {
+                const unsigned uu = (unsigned)unit[u];
+                const int eb = uu & 15, ea = (uu >> 4) & 15;
+                const int *d = dest + (uu >> 8) * 4;
+                const int kind = ((unsigned)d[1]) >> 28, o0 = d[0], o1 = d[1] & 0x0fffffff;
+                const double s = gather_imu(recs, item + d[2], d[3], ea, eb);
+                if (kind == DK_TILE) C.tiles[tix(o0 + ea, o1 + eb)] += s;
+                else C.v_g[o0 + ea] += s;
+            }
+        }
+        __syncthreads();
+    }
+    // ---------------- marginalisation prior (marginalization_factor.cpp:335-384) ---------------------
+    if (P.prior_n > 0) {
+        const int n = P.prior_n;
+        const double *J0 = dp + C.W->d_prior, *r0 = J0 + n * n, *x0 = r0 + n;
+        if (tid < P.prior_nblk) {
+            const int *pb = ip + P.o_prior + tid * 4;
+            prior_block_dx(x + blk[pb[0] * 4 + 1], x0 + pb[3], pb[2], C.g_pdx + pb[1]);
+        }
+        __syncthreads();
+        if (tid < n) {
+            double r = r0[tid];
+            for (int j = 0; j < n; j++) r += J0[tid + n * j] * C.g_pdx[j];
+            C.g_pr[tid] = r;
+            cost_acc += 0.5 * r * r;
+        }
+        if (assemble) {
+            __syncthreads();
+            const int *pcol = ip + P.o_pcol;
+            if (tid < n && pcol[tid] >= 0) {
+                double s = 0;
+                for (int i = 0; i < n; i++) s += J0[i + n * tid] * C.g_pr[i];
+                C.v_g[pcol[tid]] += s;
+            }
+            for (int e = tid; e < n * n; e += NT) {
+                const int a = e / n, b = e - a * n;
+                if (b > a) continue;
+                const int ta = pcol[a], tb = pcol[b];
+                if (ta < 0 || tb < 0) continue;
+                const double h = C.g_hp[a * (a + 1) / 2 + b];
+                C.tiles[ta >= tb ? tix(ta, tb) : tix(tb, ta)] += h;
+            }
+        }
+    }
+    const double cost = block_sum<NT>(cost_acc, C.red, tid);
+    __syncthreads();
+    return cost;
+}
+
+// ---- tiled Cholesky of the augmented system in LDS -----------------------------------------------
+template <int NT, bool MFMA>
+__device__ bool chol_tiles(Ctx<NT> &C, int nt, int nc) {
+    const int tid = C.tid, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = NT / 64, NG = NT / 16;
+    double *tiles = C.tiles;
+    for (int K = 0; K < nt; K++) {
+        const int cmax = min(16, nc - 16 * K);
+        if (cmax <= 0) break;
+        double *TK = tiles + tbase(K, K);
+        if (wave == 0) {
+            const int r = lane & 15, cq = lane >> 4;
+            for (int c = 0; c < cmax; c++) {
+                const double d = TK[sw(c, c)];
+                if (!(d > 0.0) || !(d < 1e300)) { if (lane == 0) *C.flag = 1; break; }
+                const double l = sqrt(d), inv = 1.0 / l;
+                const double colr = TK[sw(r, c)] * inv;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int c2 = cq + 4 * k;
+                    if (c2 > c && c2 <= r) TK[sw(r, c2)] -= colr * (TK[sw(c2, c)] * inv);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                if (cq == 0 && r > c) TK[sw(r, c)] = colr;
+                if (lane == 0) { TK[sw(c, c)] = l; C.invdiag[16 * K + c] = inv; }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+        }
+        __syncthreads();
+        if (*C.flag) return false;
+        if (K + 1 >= nt) break;
+        // panel: X * L_KK^T = A_IK, one matrix row per lane
+        {
+            const int g = tid >> 4, r = tid & 15;
+            for (int I = K + 1 + g; I < nt; I += NG) {
+                double *T = tiles + tbase(I, K);
+                double xr[16];
+#pragma unroll
+                for (int c = 0; c < 16; c++) xr[c] = T[sw(r, c)];
+#pragma unroll
+                for (int c = 0; c < 16; c++) {
+                    double a = xr[c];
+#pragma unroll
+                    for (int c1 = 0; c1 < c; c1++) a -= xr[c1] * TK[sw(c, c1)];
+                    xr[c] = a * C.invdiag[16 * K + c];
+                }
+#pragma unroll
+                for (int c = 0; c < 16; c++) T[sw(r, c)] = xr[c];
+            }
+        }
+        __syncthreads();
+        // trailing update A_IJ -= L_IK L_JK^T
+        {
+            int cnt = 0;
+            const int row0 = lane >> 4, col = lane & 15;
+            for (int I = K + 1; I < nt; I++)
+                for (int J = K + 1; J <= I; J++) {
+                    if ((cnt++ % NW) != wave) continue;
+                    double *Ct = tiles + tbase(I, J);
+                    const double *A = tiles + tbase(I, K), *B = tiles + tbase(J, K);
+                    if (MFMA) {
+                        v4f64 acc;
+#pragma unroll
+                        for (int i = 0; i < 4; i++) acc[i] = Ct[sw(row0 + 4 * i, col)];
+#pragma unroll
+                        for (int kk = 0; kk < 4; kk++) {
+                            const double a = -A[sw(col, 4 * kk + row0)];
+                            const double b = B[sw(col, 4 * kk + row0)];
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; i++) Ct[sw(row0 + 4 * i, col)] = acc[i];
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const int row = row0 + 4 * i;
+                            double a = Ct[sw(row, col)];
+#pragma unroll
+                            for (int k = 0; k < 16; k++) a -= A[sw(row, k)] * B[sw(col, k)];
+                            Ct[sw(row, col)] = a;
+                        }
+                    }
+                }
+        }
+        __syncthreads();
+    }
+    return true;
+}
+
+// ---- back substitution L^T y = z (z = the factored rhs row) ----------------------------------------
+template <int NT>
+__device__ void back_subst(Ctx<NT> &C, int nc) {
+    const int tid = C.tid;
+    constexpr int NP = NT / 16;
+    double *tiles = C.tiles, *y = C.ycam, *part = C.area;
+    for (int c = tid; c < nc; c += NT) y[c] = tiles[tix(nc, c)];
+    __syncthreads();
+    for (int K = (nc - 1) >> 4; K >= 0; K--) {
+        const int cmax = min(16, nc - 16 * K);
+        {
+            const int c = tid & 15, p = tid >> 4;
+            double s = 0;
+            if (c < cmax)
+                for (int r = 16 * (K + 1) + p; r < nc; r += NP) s += tiles[tix(r, 16 * K + c)] * y[r];
+            part[p * 16 + c] = s;
+        }
+        __syncthreads();
+        if (tid < 16) {
+            const int c = tid;
+            double t = (c < cmax) ? y[16 * K + c] : 0.0;
+#pragma unroll
+            for (int p = 0; p < NP; p++) t -= part[p * 16 + c];
+            const double *TK = tiles + tbase(K, K);
+            double lrow[16];
+#pragma unroll
+            for (int cc = 0; cc < 16; cc++) lrow[cc] = (c <= cc) ? TK[sw(cc, c)] : 0.0;
+#pragma unroll
+            for (int cc = 15; cc >= 0; cc--) {
+                if (cc < cmax) {
+                    const double ycc = __shfl(t, cc, 16) * C.invdiag[16 * K + cc];
+                    if (c == cc) t = ycc;
+                    else if (c < cc) t -= lrow[cc] * ycc;
+                }
+            }
+            if (c < cmax) y[16 * K + c] = t;
+        }
+        __syncthreads();
+    }
+}
+
+// ---- scale, regularise, factorise and solve (J'J + mu D^2) y = J'r ---------------------------------
+// On return (true): v_y = y (scaled space, camera then landmarks), v_D, v_ghat set, scal = {gg, q}.
+template <int NT, bool MFMA>
+__device__ bool finalize_and_solve(Ctx<NT> &C, bool first, double mu, double &gg_out, double &q_out) {
+    const PlanHdr &P = *C.P;
+    const int tid = C.tid, nc = P.nc, L = P.nland;
+    const int *ip = C.ip;
+    for (int a = tid; a < nc; a += NT) {
+        const double dH = C.tiles[tix(a, a)] + C.v_sd[a];
+        double s;
+        if (first) { s = 1.0 / (1.0 + sqrt(dH)); C.v_s[a] = s; }
+        else s = C.v_s[a];
+        C.sc[a] = s;
+        const double d2 = fmin(fmax(s * s * dH, 1e-6), 1e32);
+        const double D = sqrt(d2);
+        C.dd[a] = d2;
+        C.v_D[a] = D;
+        const double gh = s * C.v_g[a] / D;
+        C.v_ghat[a] = gh;
+        C.ycam[a] = s * gh / D;  // u = s * (ghat / D): Cauchy direction in unscaled tangent units
+    }
+    for (int l = tid; l < L; l += NT) {
+        const double s = C.v_s[nc + l], h = C.l_hll[l];
+        const double d2 = fmin(fmax(s * s * h, 1e-6), 1e32), D = sqrt(d2);
+        C.v_D[nc + l] = D;
+        C.v_ghat[nc + l] = s * C.l_gl[l] / D;
+    }
+    __syncthreads();
+    // Cauchy point: gg = |ghat|^2, q = |J (ghat / D)|^2 = u' H u with H = [S~ + sum Hcl Hcl'/kappa, Hcl; Hcl', hll]
+    double acc[2] = {0.0, 0.0};
+    for (int a = tid; a < nc; a += NT) {
+        double w = 0;
+        for (int b = 0; b < a; b++) w += C.tiles[tix(a, b)] * C.ycam[b];
+        for (int b = a; b < nc; b++) w += C.tiles[tix(b, a)] * C.ycam[b];
+        acc[1] += C.ycam[a] * w;
+        const double gh = C.v_ghat[a];
+        acc[0] += gh * gh;
+    }
+    {
+        const int *lm = ip + P.o_lm, *sp = ip + P.o_lmslotptr, *so = ip + P.o_lmslot;
+        for (int l = tid; l < L; l += NT) {
+            const double *h = C.g_hcl + lm[2 * l];
+            double t = 0;
+            const int s0 = sp[l], s1 = sp[l + 1];
+            for (int s = s0; s < s1; s++) {
+                const int off = so[s];
+#pragma unroll
+                for (int e = 0; e < 6; e++) t += h[(s - s0) * 6 + e] * C.ycam[off + e];
+            }
+            const double gh = C.v_ghat[nc + l];
+            const double ul = C.v_s[nc + l] * gh / C.v_D[nc + l];
+            acc[1] += t * t * C.l_invk[l] + 2.0 * t * ul + C.l_hll[l] * ul * ul;
+            acc[0] += gh * gh;
+        }
+    }
+    block_sum_n<NT, 2>(acc, C.red, tid);
+    gg_out = acc[0];
+    q_out = acc[1];
+    __syncthreads();
+    // scaled + regularised system, rhs row, identity padding
+    {
+        const int all = C.ntiles << 8;
+        for (int idx = tid; idx < all; idx += NT) {
+            const int t = idx >> 8, r = (idx >> 4) & 15, c = (idx & 15) ^ (r & 14);
+            int I = 0;
+            while (((I + 1) * (I + 2) / 2) <= t) I++;
+            const int J = t - I * (I + 1) / 2;
+            const int a = 16 * I + r, b = 16 * J + c;
+            double v;
+            if (b > a) v = 0.0;
+            else if (a < nc) {
+                v = C.sc[a] * C.sc[b] * C.tiles[idx];
+                if (a == b) v += mu * C.dd[a];
+            } else if (a == nc) v = (b < nc) ? C.sc[b] * (C.v_g[b] - C.v_rc[b]) : 1.0;
+            else v = (a == b) ? 1.0 : 0.0;
+            C.tiles[idx] = v;
+        }
+    }
+    if (tid == 0) *C.flag = 0;
+    __syncthreads();
+    if (!chol_tiles<NT, MFMA>(C, P.nt, nc)) return false;
+    back_subst<NT>(C, nc);
+    // landmarks: y_l = (gl - Hcl' (s o y_c)) / (s_l kappa_l)
+    bool bad = false;
+    for (int a = tid; a < nc; a += NT) {
+        const double y = C.ycam[a];
+        C.v_y[a] = y;
+        if (!(fabs(y) < 1e300)) bad = true;
+    }
+    {
+        const int *lm = ip + P.o_lm, *sp = ip + P.o_lmslotptr, *so = ip + P.o_lmslot;
+        for (int l = tid; l < L; l += NT) {
+            const double *h = C.g_hcl + lm[2 * l];
+            double t = 0;
+            const int s0 = sp[l], s1 = sp[l + 1];
+            for (int s = s0; s < s1; s++) {
+                const int off = so[s];
+#pragma unroll
+                for (int e = 0; e < 6; e++) t += h[(s - s0) * 6 + e] * (C.sc[off + e] * C.ycam[off + e]);
+            }
+            const double y = (C.l_gl[l] - t) * C.l_invk[l] / C.v_s[nc + l];
+            C.v_y[nc + l] = y;
+            if (!(fabs(y) < 1e300)) bad = true;
+        }
+    }
+    const int anybad = __syncthreads_or(bad ? 1 : 0);
+    return anybad == 0;
+}
+
+// ---- ambient-space helpers ---------------------------------------------------------------------------
+template <int NT>
+__device__ void apply_plus(Ctx<NT> &C, const double *x, const double *delta_scaled, const double *s, double *xo) {
+    // delta = step o scale; per block Plus (pose_local_parameterization.cpp:3-19) or x + delta
+    const PlanHdr &P = *C.P;
+    const int *blk = C.ip + P.o_blk;
+    for (int b = C.tid; b < P.nblk; b += NT) {
+        const int gs = blk[b * 4], go = blk[b * 4 + 1], lo = blk[b * 4 + 2], kind = blk[b * 4 + 3];
+        if (lo < 0) {
+            for (int i = 0; i < gs; i++) xo[go + i] = x[go + i];
+        } else if (kind == KIND_POSE) {
+            double d[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) d[i] = delta_scaled[lo + i] * s[lo + i];
+            pose_plus(x + go, d, xo + go);
+        } else {
+            for (int i = 0; i < gs; i++) xo[go + i] = x[go + i] + delta_scaled[lo + i] * s[lo + i];
+        }
+    }
+    for (int l = C.tid; l < P.nland; l += NT) xo[P.nx + l] = x[P.nx + l] + delta_scaled[P.nc + l] * s[P.nc + l];
+}
+
+template <int NT>
+__device__ void ambient_norms(Ctx<NT> &C, const double *x, const double *xo, double &xn2, double &dn2) {
+    const PlanHdr &P = *C.P;
+    const int *blk = C.ip + P.o_blk;
+    double acc[2] = {0.0, 0.0};
+    for (int b = C.tid; b < P.nblk; b += NT) {
+        const int gs = blk[b * 4], go = blk[b * 4 + 1], lo = blk[b * 4 + 2];
+        if (lo < 0) continue;
+        for (int i = 0; i < gs; i++) {
+            const double a = x[go + i], d = a - xo[go + i];
+            acc[0] += a * a;
+            acc[1] += d * d;
+        }
+    }
+    for (int l = C.tid; l < P.nland; l += NT) {
+        const double a = x[P.nx + l], d = a - xo[P.nx + l];
+        acc[0] += a * a;
+        acc[1] += d * d;
+    }
+    block_sum_n<NT, 2>(acc, C.red, C.tid);
+    xn2 = acc[0];
+    dn2 = acc[1];
+}
+
+template <int NT>
+__device__ double grad_max(Ctx<NT> &C) {
+    double m = 0;
+    for (int i = C.tid; i < C.P->nc + C.P->nland; i += NT) m = fmax(m, fabs(C.v_g[i]));
+    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_down(m, o));
+    __syncthreads();
+    if ((C.tid & 63) == 0) C.red[C.tid >> 6] = m;
+    __syncthreads();
+    double t = 0;
+    for (int w = 0; w < NT / 64; w++) t = fmax(t, C.red[w]);
+    __syncthreads();
+    return t;
+}
+
+// ---- the kernel ---------------------------------------------------------------------------------------
+template <int NT, bool MFMA>
+__global__ void __launch_bounds__(NT) solve_kernel(SolveArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ int s_flag;
+    const int tid = threadIdx.x;
+    Ctx<NT> C;
+    C.tid = tid;
+    C.flag = &s_flag;
+    double *scr = A.scratch + (size_t)blockIdx.x * A.scratch_stride;
+    C.v_s = scr; C.v_g = scr + SCR_NL; C.v_D = scr + 2 * SCR_NL; C.v_ghat = scr + 3 * SCR_NL; C.v_y = scr + 4 * SCR_NL;
+    C.v_p = scr + 5 * SCR_NL; C.v_rc = scr + 6 * SCR_NL; C.v_sd = scr + 7 * SCR_NL;
+    C.l_hll = scr + 8 * SCR_NL; C.l_gl = C.l_hll + SCR_LM; C.l_invk = C.l_gl + SCR_LM;
+    C.g_hcl = C.l_invk + SCR_LM; C.g_hp = C.g_hcl + SCR_HCL; C.g_pr = C.g_hp + SCR_HP; C.g_pdx = C.g_pr + 128;
+    C.g_sqrt = C.g_pdx + 128;
+
+    for (int win = blockIdx.x; win < A.nwin; win += gridDim.x) {
+        const WinHdr *W = A.win + win;
+        const PlanHdr &P = A.plans[W->plan];
+        C.P = &P; C.W = W;
+        C.ip = A.ipool + A.plan_base[W->plan];
+        C.dp = A.dpool + W->dbase;
+        const int nc = P.nc, L = P.nland, nxl = (P.nx + L + 1) & ~1, nl = nc + L;
+        C.ntiles = P.nt * (P.nt + 1) / 2;
+        const int pp_tiles = P.ntp * (P.ntp + 1) / 2;
+        C.tiles = lds;
+        C.stage = lds + (pp_tiles << 8);
+        C.stage_cap = (C.ntiles - pp_tiles) << 8;
+        double *p = lds + (C.ntiles << 8);
+        C.xs = p; p += nxl;
+        C.xc = p; p += nxl;
+        C.sc = p; p += 176;
+        C.dd = p; p += 176;
+        C.ycam = p; p += 176;
+        C.invdiag = p; p += 176;
+        C.red = p; p += 64;
+        C.area = p;
+        DevSummary *S = A.summary + win;
+
+        for (int i = tid; i < P.nx + L; i += NT) C.xs[i] = C.dp[W->d_x + i];
+        // sqrt_info = LLT(cov^-1).matrixL()^T once per solve (imu_factor.h:64 recomputes it per Evaluate)
+        if (W->d_sqrt >= 0) {
+            for (int i = tid; i < P.n_imu * 225; i += NT) C.g_sqrt[i] = C.dp[W->d_sqrt + i];
+        } else {
+            int bad = 0;
+            if (tid < P.n_imu)
+                bad = imu_sqrt_info(C.dp + W->d_imu + tid * IMU_CONST + IMU_COV, C.g_sqrt + tid * 225, lds + tid * 450);
+            (void)bad;
+        }
+        // constant part of the prior: Hp = J0' J0 (packed lower), marginalization_factor.cpp:366,371-380
+        if (P.prior_n > 0) {
+            const int n = P.prior_n;
+            const double *J0 = C.dp + W->d_prior;
+            for (int e = tid; e < n * n; e += NT) {
+                const int a = e / n, b = e - a * n;
+                if (b > a) continue;
+                double s = 0;
+                for (int i = 0; i < n; i++) s += J0[i + n * a] * J0[i + n * b];
+                C.g_hp[a * (a + 1) / 2 + b] = s;
+            }
+        }
+        __syncthreads();
+
+        const int max_it = A.max_iterations < MAX_TRACE - 1 ? A.max_iterations : MAX_TRACE - 1;
+        const bool fixed = A.fixed_iterations != 0;
+        double radius = 1e4, mu = 1e-8, lin_mu = 1e-8;
+        bool reuse = false, tiles_valid = true;
+        int invalid = 0, termination = 0, nrec = 1, status = 0;
+        double cost = linearize<NT>(C, C.xs, true, true, mu);
+        bool first = true;
+        const double initial_cost = cost;
+        if (tid == 0) { S->cost[0] = cost; S->step_ok[0] = 1; S->dogleg_case[0] = 0; S->radius[0] = radius; S->mu[0] = mu; }
+        double gg = 0, q = 0, alpha = 0, yg = 0, gdy = 0, dy2 = 0;
+        double xn2, dn2;
+        ambient_norms<NT>(C, C.xs, C.xs, xn2, dn2);
+        double x_norm = sqrt(xn2);
+        bool done = false;
+        if (!fixed) {
+            const double gm = grad_max<NT>(C);
+            if (gm <= 1e-10) { termination = 1; done = true; }
+        }
+        int it = 0;
+        while (!done) {
+            if (it >= max_it) break;
+            it++;
+            bool ls_ok = true;
+            if (!reuse) {
+                reuse = true;
+                ls_ok = false;
+                while (mu < 1.0) {
+                    if (!tiles_valid || lin_mu != mu) {
+                        (void)linearize<NT>(C, C.xs, false, true, mu);
+                        lin_mu = mu;
+                    }
+                    const bool ok = finalize_and_solve<NT, MFMA>(C, first, mu, gg, q);
+                    first = false;
+                    tiles_valid = false;
+                    if (ok) { ls_ok = true; break; }
+                    mu *= 10.0;
+                }
+                if (ls_ok) {
+                    alpha = gg / q;
+                    // dot products for the dogleg interpolation and the model decrease
+                    double acc[3] = {0.0, 0.0, 0.0};
+                    for (int i = tid; i < nl; i += NT) {
+                        const double y = C.v_y[i], D = C.v_D[i], gh = C.v_ghat[i];
+                        acc[0] += y * (gh * D);   // y' g_s
+                        acc[1] += gh * D * y;     // ghat . (D y) = -ghat . gn
+                        acc[2] += (D * y) * (D * y);
+                    }
+                    block_sum_n<NT, 3>(acc, C.red, tid);
+                    yg = acc[0]; gdy = acc[1]; dy2 = acc[2];
+                }
+            }
+            double model_cost_change = 0, step_norm = 0, ca = 0, cb = 0;
+            int dcase = 0;
+            bool step_valid = false;
+            if (ls_ok) {
+                // traditional dogleg in D-space: gn = -D y, Cauchy = -alpha ghat
+                const double gnorm = sqrt(gg), gn_norm = sqrt(dy2);
+                if (gn_norm <= radius) { ca = 0.0; cb = -1.0; step_norm = gn_norm; dcase = 1; }
+                else if (gnorm * alpha >= radius) { ca = -(radius / gnorm); cb = 0.0; step_norm = radius; dcase = 2; }
+                else {
+                    const double b_dot_a = alpha * gdy;          // (-alpha ghat) . (-D y)
+                    const double a_sq = (alpha * gnorm) * (alpha * gnorm);
+                    const double bma_sq = a_sq - 2.0 * b_dot_a + gn_norm * gn_norm;
+                    const double c = b_dot_a - a_sq;
+                    const double d = sqrt(c * c + bma_sq * (radius * radius - a_sq));
+                    const double beta = (c <= 0) ? (d - c) / bma_sq : (radius * radius - a_sq) / (d + c);
+                    ca = -alpha * (1.0 - beta); cb = -beta; dcase = 3;
+                    // |ca ghat - cb' gn|: step = ca*ghat + beta*gn with gn = -D y
+                    step_norm = sqrt(ca * ca * gg + 2.0 * ca * cb * gdy + cb * cb * dy2);
+                }
+                // step (scaled-J space) p = ca * (ghat / D) + cb * y ; model decrease via H_s y = g_s - mu D^2 y
+                const double pg = ca * gg + cb * yg;
+                const double vHy = gg - mu * gdy, yHy = yg - mu * dy2;
+                const double pHp = ca * ca * q + 2.0 * ca * cb * vHy + cb * cb * yHy;
+                model_cost_change = -pg - 0.5 * pHp;
+                // sign convention of the minimiser: step = -(...) so that model_cost_change > 0 for descent
+                step_valid = model_cost_change > 0.0;
+            }
+            if (!step_valid) {
+                invalid++;
+                if (tid == 0 && nrec < MAX_TRACE) {
+                    S->cost[nrec] = cost; S->step_ok[nrec] = 0; S->dogleg_case[nrec] = -1; S->mu[nrec] = mu;
+                    S->radius[nrec] = radius; S->rho[nrec] = 0; S->model_cost_change[nrec] = model_cost_change;
+                    S->cost_candidate[nrec] = 0; S->step_norm[nrec] = 0;
+                }
+                nrec++;
+                if (invalid >= 5) { termination = 5; break; }
+                mu *= 10.0;
+                reuse = false;
+                continue;
+            }
+            invalid = 0;
+            for (int i = tid; i < nl; i += NT) C.v_p[i] = ca * (C.v_ghat[i] / C.v_D[i]) + cb * C.v_y[i];
+            __syncthreads();
+            apply_plus<NT>(C, C.xs, C.v_p, C.v_s, C.xc);
+            if (A.first_delta && it == 1)
+                for (int i = tid; i < nl; i += NT) A.first_delta[(size_t)win * A.delta_stride + i] = C.v_p[i] * C.v_s[i];
+            __syncthreads();
+            const double mu_next = fmax(1e-8, 2.0 * mu / 10.0);
+            const bool want_asm = (it < max_it) || !fixed;
+            const double cost_c = linearize<NT>(C, C.xc, false, want_asm, mu_next);
+            tiles_valid = want_asm;
+            lin_mu = mu_next;
+            ambient_norms<NT>(C, C.xs, C.xc, xn2, dn2);
+            const double rho = (cost - cost_c) / model_cost_change;
+            if (tid == 0 && nrec < MAX_TRACE) {
+                S->model_cost_change[nrec] = model_cost_change; S->cost_candidate[nrec] = cost_c;
+                S->radius[nrec] = radius; S->mu[nrec] = mu; S->rho[nrec] = rho; S->step_norm[nrec] = step_norm;
+                S->dogleg_case[nrec] = dcase;
+            }
+            if (!fixed && sqrt(dn2) <= 1e-8 * (x_norm + 1e-8)) {
+                if (tid == 0 && nrec < MAX_TRACE) { S->cost[nrec] = cost; S->step_ok[nrec] = 0; }
+                nrec++; termination = 2; break;
+            }
+            const double cost_change = cost - cost_c;
+            if (!fixed && fabs(cost_change) <= 1e-6 * cost) {
+                if (tid == 0 && nrec < MAX_TRACE) { S->cost[nrec] = cost; S->step_ok[nrec] = 0; }
+                nrec++; termination = 3; break;
+            }
+            if (rho > 1e-3) {
+                for (int i = tid; i < P.nx + L; i += NT) C.xs[i] = C.xc[i];
+                ambient_norms<NT>(C, C.xc, C.xc, xn2, dn2);
+                x_norm = sqrt(xn2);
+                cost = cost_c;
+                if (rho < 0.25) radius *= 0.5;
+                if (rho > 0.75) radius = fmax(radius, 3.0 * step_norm);
+                mu = mu_next;
+                reuse = false;
+                if (tid == 0 && nrec < MAX_TRACE) { S->cost[nrec] = cost; S->step_ok[nrec] = 1; }
+                nrec++;
+                if (!fixed) {
+                    const double gm = grad_max<NT>(C);
+                    if (gm <= 1e-10) { termination = 1; break; }
+                }
+            } else {
+                radius *= 0.5;
+                reuse = true;
+                tiles_valid = false;
+                if (tid == 0 && nrec < MAX_TRACE) { S->cost[nrec] = cost; S->step_ok[nrec] = 0; }
+                nrec++;
+            }
+            if (radius < 1e-32) { termination = 4; break; }
+        }
+        __syncthreads();
+        for (int i = tid; i < P.nx + L; i += NT) A.state_out[(size_t)win * A.state_stride + i] = C.xs[i];
+        if (tid == 0) {
+            S->num_iterations = nrec < MAX_TRACE ? nrec : MAX_TRACE;
+            S->termination = termination;
+            S->status = status;
+            S->initial_cost = initial_cost;
+            S->final_cost = cost;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace tcv
+
+extern "C" int tcv_launch_solve(const tcv::SolveArgs *args, int grid, int nthreads, size_t lds_bytes, void *stream) {
+    using namespace tcv;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e;
+#define TCV_LAUNCH(NTV, MF)                                                                                         \
+    do {                                                                                                            \
+        e = hipFuncSetAttribute((const void *)solve_kernel<NTV, MF>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                (int)lds_bytes);                                                                    \
+        if (e != hipSuccess) return (int)e;                                                                         \
+        hipLaunchKernelGGL((solve_kernel<NTV, MF>), dim3(grid), dim3(NTV), lds_bytes, st, *args);                   \
+    } while (0)
+    if (nthreads == 512) { if (args->use_mfma) TCV_LAUNCH(512, true); else TCV_LAUNCH(512, false); }
+    else { if (args->use_mfma) TCV_LAUNCH(256, true); else TCV_LAUNCH(256, false); }
+#undef TCV_LAUNCH
+    return (int)hipGetLastError();
+}
+
+extern "C" int tcv_solve_scratch_doubles(void) { return tcv::SCR_TOTAL; }

@@ -1,0 +1,399 @@
+"""ctypes binding of the C-ABI in include/tcv.h (libtcv_hip.so) plus helpers that turn the
+synthetic-window dicts of synth.py into `tcv_window_desc` structs.
+
+This is host plumbing only: every compute entry point runs HIP kernels on the GPU and returns
+TCV_ERR_NO_DEVICE (-2) when no device is visible -- there is no CPU fallback, and nothing here
+imports `oracle/`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtcv_hip.so")
+
+TCV_OK, TCV_ERR_INVALID, TCV_ERR_NO_DEVICE, TCV_ERR_TOO_LARGE, TCV_ERR_HIP, TCV_ERR_UNSUPPORTED, TCV_ERR_NUMERIC = 0, -1, -2, -3, -4, -5, -6
+TCV_PARAM_EUCLIDEAN, TCV_PARAM_POSE = 0, 1
+TCV_MAX_TRACE = 64
+TERMINATION = ["NO_CONVERGENCE", "CONVERGENCE_GRADIENT", "CONVERGENCE_PARAMETER", "CONVERGENCE_FUNCTION",
+               "CONVERGENCE_RADIUS", "FAILURE"]
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+# every symbol include/tcv.h declares (checked by tests/test_abi.py against the header text)
+EXPORTS = [
+    "tcv_version", "tcv_last_error", "tcv_device_count", "tcv_set_device",
+    "tcv_problem_create", "tcv_problem_destroy", "tcv_problem_add_parameter_block",
+    "tcv_problem_set_parameter_block_constant", "tcv_problem_set_gravity", "tcv_problem_add_imu_factor",
+    "tcv_problem_add_projection_factor", "tcv_problem_add_line_factor", "tcv_problem_add_marginalization_factor",
+    "tcv_problem_from_window", "tcv_problem_num_parameter_blocks", "tcv_problem_num_residual_blocks",
+    "tcv_problem_num_residuals", "tcv_problem_plan_stats", "tcv_solver_options_default", "tcv_solve", "tcv_marginalize",
+    "tcv_prior_create", "tcv_prior_dims", "tcv_prior_export", "tcv_prior_keep_block_addresses", "tcv_prior_destroy",
+    "tcv_batch_create", "tcv_batch_destroy", "tcv_batch_solve", "tcv_batch_marginalize", "tcv_batch_synchronize",
+    "tcv_batch_download_states", "tcv_batch_get_summaries", "tcv_batch_get_prior", "tcv_batch_get_first_step",
+    "tcv_batch_plan_stats", "tcv_batch_stats", "tcv_batch_size",
+    "tcv_eval_imu_factors", "tcv_eval_projection_factors", "tcv_eval_line_factors", "tcv_pose_plus",
+]
+
+
+class ImuPreintegration(C.Structure):
+    _fields_ = [("delta_p", C.c_double * 3), ("delta_q", C.c_double * 4), ("delta_v", C.c_double * 3),
+                ("linearized_ba", C.c_double * 3), ("linearized_bg", C.c_double * 3), ("sum_dt", C.c_double),
+                ("jacobian", C.c_double * 225), ("covariance", C.c_double * 225)]
+
+
+class SolverOptions(C.Structure):
+    _fields_ = [("max_num_iterations", C.c_int), ("max_solver_time_in_seconds", C.c_double),
+                ("fixed_iterations", C.c_int), ("compute_sqrt_info_on_device", C.c_int), ("use_mfma", C.c_int),
+                ("threads_per_window", C.c_int), ("record_first_step", C.c_int)]
+
+
+class SolverSummary(C.Structure):
+    _fields_ = [("num_iterations", C.c_int), ("termination", C.c_int),
+                ("initial_cost", C.c_double), ("final_cost", C.c_double),
+                ("cost", C.c_double * TCV_MAX_TRACE), ("cost_candidate", C.c_double * TCV_MAX_TRACE),
+                ("model_cost_change", C.c_double * TCV_MAX_TRACE), ("radius", C.c_double * TCV_MAX_TRACE),
+                ("mu", C.c_double * TCV_MAX_TRACE), ("rho", C.c_double * TCV_MAX_TRACE),
+                ("step_norm", C.c_double * TCV_MAX_TRACE),
+                ("step_ok", C.c_int * TCV_MAX_TRACE), ("dogleg_case", C.c_int * TCV_MAX_TRACE)]
+
+
+class WindowDesc(C.Structure):
+    _fields_ = [("n_frames", C.c_int), ("n_landmarks", C.c_int), ("n_imu", C.c_int), ("n_proj", C.c_int),
+                ("n_line", C.c_int), ("estimate_extrinsic", C.c_int),
+                ("para_pose", _dp), ("para_speedbias", _dp), ("para_ex_pose", _dp), ("para_feature", _dp),
+                ("imu_frame_i", _ip), ("imu_frame_j", _ip), ("imu", C.POINTER(ImuPreintegration)),
+                ("proj_frame_i", _ip), ("proj_frame_j", _ip), ("proj_feature", _ip), ("proj_pts", _dp),
+                ("proj_sqrt_info", C.c_double), ("proj_loss_a", C.c_double),
+                ("line_frame", _ip), ("line_data", _dp),
+                ("line_K", C.c_double * 9), ("line_Ric", C.c_double * 9), ("line_Tic", C.c_double * 3),
+                ("line_loss_a", C.c_double), ("gravity", C.c_double * 3),
+                ("prior", C.c_void_p), ("prior_block_kind", _ip), ("prior_block_index", _ip)]
+
+
+_lib = None
+
+
+class TcvError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"tcv status {status}: {msg}")
+        self.status = status
+
+
+def lib():
+    """Loads libtcv_hip.so; raises if it has not been built (no fallback of any kind)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(f"{LIB_PATH} missing: run `python tc-viml_amd/build.py` (HIP extension is mandatory)")
+        L = C.CDLL(LIB_PATH)
+        L.tcv_version.restype = C.c_char_p
+        L.tcv_last_error.restype = C.c_char_p
+        vp = C.c_void_p
+        L.tcv_problem_create.argtypes = [C.POINTER(vp)]
+        L.tcv_problem_destroy.argtypes = [vp]
+        L.tcv_problem_destroy.restype = None
+        L.tcv_problem_add_parameter_block.argtypes = [vp, _dp, C.c_int, C.c_int]
+        L.tcv_problem_set_parameter_block_constant.argtypes = [vp, _dp]
+        L.tcv_problem_set_gravity.argtypes = [vp, _dp]
+        L.tcv_problem_add_imu_factor.argtypes = [vp, C.POINTER(ImuPreintegration), _dp, _dp, _dp, _dp]
+        L.tcv_problem_add_projection_factor.argtypes = [vp, _dp, _dp, C.c_double, C.c_double, _dp, _dp, _dp, _dp]
+        L.tcv_problem_add_line_factor.argtypes = [vp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_double, _dp]
+        L.tcv_problem_add_marginalization_factor.argtypes = [vp, vp, C.POINTER(_dp), C.c_int]
+        L.tcv_problem_from_window.argtypes = [C.POINTER(WindowDesc), C.POINTER(vp)]
+        for f in ("tcv_problem_num_parameter_blocks", "tcv_problem_num_residual_blocks", "tcv_problem_num_residuals"):
+            getattr(L, f).argtypes = [vp]
+        L.tcv_problem_plan_stats.argtypes = [vp, _ip]
+        L.tcv_solver_options_default.argtypes = [C.POINTER(SolverOptions)]
+        L.tcv_solver_options_default.restype = None
+        L.tcv_solve.argtypes = [C.POINTER(SolverOptions), vp, C.POINTER(SolverSummary)]
+        L.tcv_marginalize.argtypes = [vp, C.POINTER(_dp), C.c_int, C.POINTER(vp)]
+        L.tcv_prior_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, _ip, _ip, _dp, _dp, _dp]
+        L.tcv_prior_dims.argtypes = [vp, _ip, _ip, _ip, _ip]
+        L.tcv_prior_export.argtypes = [vp, _ip, _ip, _dp, _dp, _dp]
+        L.tcv_prior_keep_block_addresses.argtypes = [vp, C.POINTER(_dp)]
+        L.tcv_prior_destroy.argtypes = [vp]
+        L.tcv_prior_destroy.restype = None
+        L.tcv_batch_create.argtypes = [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.POINTER(_dp)), _ip, C.c_int]
+        L.tcv_batch_destroy.argtypes = [vp]
+        L.tcv_batch_destroy.restype = None
+        L.tcv_batch_solve.argtypes = [vp, C.POINTER(SolverOptions), vp]
+        L.tcv_batch_marginalize.argtypes = [vp, vp]
+        L.tcv_batch_synchronize.argtypes = [vp]
+        L.tcv_batch_download_states.argtypes = [vp]
+        L.tcv_batch_get_summaries.argtypes = [vp, C.POINTER(SolverSummary), C.c_int]
+        L.tcv_batch_get_prior.argtypes = [vp, C.c_int, C.POINTER(vp)]
+        L.tcv_batch_get_first_step.argtypes = [vp, C.c_int, _dp, C.c_int, _ip]
+        L.tcv_batch_plan_stats.argtypes = [vp, _ip, _dp, _ip, _ip]
+        L.tcv_batch_stats.argtypes = [vp, _dp, _dp, _dp]
+        L.tcv_batch_size.argtypes = [vp]
+        L.tcv_eval_imu_factors.argtypes = [C.c_int, C.POINTER(ImuPreintegration), _dp, _dp, C.c_int, _dp, _dp, _dp]
+        L.tcv_eval_projection_factors.argtypes = [C.c_int, _dp, _dp, C.c_double, _dp, _dp]
+        L.tcv_eval_line_factors.argtypes = [C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
+        L.tcv_pose_plus.argtypes = [C.c_int, _dp, _dp, _dp]
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != TCV_OK:
+        raise TcvError(rc, lib().tcv_last_error().decode())
+
+
+def dptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+def iptr(a):
+    return a.ctypes.data_as(_ip)
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def default_options(max_num_iterations=8, fixed_iterations=True, use_mfma=True, threads=256, record_first_step=False):
+    o = SolverOptions()
+    lib().tcv_solver_options_default(C.byref(o))
+    o.max_num_iterations = max_num_iterations
+    o.fixed_iterations = int(fixed_iterations)
+    o.use_mfma = int(use_mfma)
+    o.threads_per_window = threads
+    o.record_first_step = int(record_first_step)
+    return o
+
+
+def pack_imu(imu) -> C.Array:
+    """synth 'imu' dict (arrays over n_imu) -> array of tcv_imu_preintegration."""
+    n = len(imu["frame_i"])
+    arr = (ImuPreintegration * n)()
+    for k in range(n):
+        p = arr[k]
+        p.delta_p[:] = list(imu["delta_p"][k]); p.delta_q[:] = list(imu["delta_q"][k]); p.delta_v[:] = list(imu["delta_v"][k])
+        p.linearized_ba[:] = list(imu["lin_ba"][k]); p.linearized_bg[:] = list(imu["lin_bg"][k])
+        p.sum_dt = float(imu["sum_dt"][k])
+        p.jacobian[:] = list(np.asarray(imu["jacobian"][k]).reshape(225))
+        p.covariance[:] = list(np.asarray(imu["covariance"][k]).reshape(225))
+    return arr
+
+
+class Prior:
+    """Owns a tcv_prior handle (MarginalizationInfo layout)."""
+
+    def __init__(self, handle=None):
+        self.h = handle
+
+    @classmethod
+    def from_dict(cls, p):
+        sizes = i32(p["sizes"]); idx = i32(p["idx"])
+        x0 = f64(np.concatenate([np.atleast_1d(x) for x in p["x0"]]))
+        J0 = np.asfortranarray(p["J0"], dtype=np.float64)     # column-major like Eigen::MatrixXd
+        r0 = f64(p["r0"])
+        h = C.c_void_p()
+        check(lib().tcv_prior_create(C.byref(h), int(p.get("m", 0)), int(p["n"]), len(sizes), iptr(sizes), iptr(idx), dptr(x0),
+                                     J0.ctypes.data_as(_dp), dptr(r0)))
+        return cls(h)
+
+    def dims(self):
+        m, n, nb, xs = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        check(lib().tcv_prior_dims(self.h, C.byref(m), C.byref(n), C.byref(nb), C.byref(xs)))
+        return m.value, n.value, nb.value, xs.value
+
+    def export(self):
+        m, n, nb, xs = self.dims()
+        size = np.zeros(nb, np.int32); idx = np.zeros(nb, np.int32)
+        x0 = np.zeros(xs); J0 = np.zeros(n * n); r0 = np.zeros(n)
+        check(lib().tcv_prior_export(self.h, iptr(size), iptr(idx), dptr(x0), dptr(J0), dptr(r0)))
+        xs_l, o = [], 0
+        for s in size:
+            xs_l.append(x0[o:o + s].copy()); o += int(s)
+        return dict(m=m, n=n, sizes=[int(s) for s in size], idx=[int(i) for i in idx], x0=xs_l,
+                    J0=J0.reshape(n, n).T.copy(), r0=r0)
+
+    def __del__(self):
+        if self.h is not None and _lib is not None:
+            _lib.tcv_prior_destroy(self.h)
+            self.h = None
+
+
+_KIND = {"pose": 0, "sb": 1, "ex": 2}
+
+
+class Window:
+    """Caller-side state arrays of one sliding window (what Estimator owns, estimator.h:166-172)
+    plus the problem handle built from them with tcv_problem_from_window."""
+
+    def __init__(self, win: dict, estimate_extrinsic=True, prior: Prior | None = None):
+        self.win = win
+        self.pose = f64(win["pose"]).copy(); self.sb = f64(win["speedbias"]).copy()
+        self.ex = f64(win["ex_pose"]).copy(); self.lam = f64(win["lam"]).copy()
+        im, pr, ln = win["imu"], win["proj"], win["line"]
+        self._imu = pack_imu(im)
+        self._imu_i = i32(im["frame_i"]); self._imu_j = i32(im["frame_j"])
+        self._pi = i32(pr["frame_i"]); self._pj = i32(pr["frame_j"]); self._pl = i32(pr["landmark"])
+        self._pts = f64(np.concatenate([pr["pts_i"], pr["pts_j"]], -1)) if len(self._pi) else np.zeros((0, 6))
+        self._lf = i32(ln["frame"])
+        self._ld = f64(np.concatenate([ln["pts_start"], ln["pts_end"], ln["abc"]], -1)) if len(self._lf) else np.zeros((0, 9))
+        d = WindowDesc()
+        d.n_frames = self.pose.shape[0]; d.n_landmarks = self.lam.shape[0]
+        d.n_imu = len(self._imu_i); d.n_proj = len(self._pi); d.n_line = len(self._lf)
+        d.estimate_extrinsic = int(estimate_extrinsic)
+        d.para_pose = dptr(self.pose); d.para_speedbias = dptr(self.sb); d.para_ex_pose = dptr(self.ex); d.para_feature = dptr(self.lam)
+        d.imu_frame_i = iptr(self._imu_i); d.imu_frame_j = iptr(self._imu_j); d.imu = self._imu
+        d.proj_frame_i = iptr(self._pi); d.proj_frame_j = iptr(self._pj); d.proj_feature = iptr(self._pl); d.proj_pts = dptr(self._pts)
+        d.proj_sqrt_info = float(pr["sqrt_info"]); d.proj_loss_a = float(pr["loss_a"] or 0.0)
+        d.line_frame = iptr(self._lf); d.line_data = dptr(self._ld)
+        d.line_K[:] = list(np.asarray(ln["K"]).reshape(9)); d.line_Ric[:] = list(np.asarray(ln["Ric"]).reshape(9))
+        d.line_Tic[:] = list(np.asarray(ln["Tic"]).reshape(3)); d.line_loss_a = float(ln["loss_a"] or 0.0)
+        d.gravity[:] = list(np.asarray(win["G"]).reshape(3))
+        self.prior = prior
+        if prior is None and win.get("prior") is not None:
+            self.prior = Prior.from_dict(win["prior"])
+        if self.prior is not None:
+            blocks = win["prior"]["blocks"] if win.get("prior") is not None else self.prior_blocks
+            self._pk = i32([_KIND[b[0]] for b in blocks]); self._pidx = i32([b[1] for b in blocks])
+            d.prior = self.prior.h; d.prior_block_kind = iptr(self._pk); d.prior_block_index = iptr(self._pidx)
+        self.desc = d
+        self.h = C.c_void_p()
+        check(lib().tcv_problem_from_window(C.byref(d), C.byref(self.h)))
+
+    def states(self):
+        return dict(pose=self.pose.copy(), sb=self.sb.copy(), ex=self.ex.copy(), lam=self.lam.copy())
+
+    def plan_stats(self):
+        out = np.zeros(16, np.int32)
+        check(lib().tcv_problem_plan_stats(self.h, iptr(out)))
+        keys = ["nc", "nx", "npp", "nland", "nt", "n_vis_chunk", "n_imu_chunk", "n_vunit", "n_vitem", "n_sunit", "n_sitem",
+                "n_iunit", "n_iitem", "plan_ints", "window_doubles", "lds_bytes"]
+        return dict(zip(keys, [int(v) for v in out]))
+
+    def block_ptr(self, name, i):
+        if name == "pose":
+            return C.cast(C.addressof(self.pose.ctypes.data_as(_dp).contents) + 56 * i, _dp)
+        if name == "sb":
+            return C.cast(C.addressof(self.sb.ctypes.data_as(_dp).contents) + 72 * i, _dp)
+        if name == "ex":
+            return dptr(self.ex)
+        return C.cast(C.addressof(self.lam.ctypes.data_as(_dp).contents) + 8 * i, _dp)
+
+    def __del__(self):
+        if getattr(self, "h", None) is not None and _lib is not None:
+            _lib.tcv_problem_destroy(self.h)
+            self.h = None
+
+
+class Batch:
+    """Device-resident batch of independent windows (throughput mode)."""
+
+    def __init__(self, windows, marg_windows=None, marg_drops=None):
+        self.windows = list(windows)
+        n = len(self.windows)
+        arr = (C.c_void_p * n)(*[w.h for w in self.windows])
+        self.h = C.c_void_p()
+        if marg_windows is None:
+            check(lib().tcv_batch_create(C.byref(self.h), arr, None, None, None, n))
+        else:
+            self.marg_windows = list(marg_windows)
+            marr = (C.c_void_p * n)(*[w.h for w in self.marg_windows])
+            self._drop_arrays = []
+            dd = (C.POINTER(_dp) * n)()
+            nd = (C.c_int * n)()
+            for k, drops in enumerate(marg_drops):
+                a = (_dp * len(drops))(*drops)
+                self._drop_arrays.append(a)
+                dd[k] = C.cast(a, C.POINTER(_dp))
+                nd[k] = len(drops)
+            check(lib().tcv_batch_create(C.byref(self.h), arr, marr, dd, nd, n))
+
+    def solve(self, opts, stream=None):
+        check(lib().tcv_batch_solve(self.h, C.byref(opts), stream))
+
+    def marginalize(self, stream=None):
+        check(lib().tcv_batch_marginalize(self.h, stream))
+
+    def synchronize(self):
+        check(lib().tcv_batch_synchronize(self.h))
+
+    def download_states(self):
+        check(lib().tcv_batch_download_states(self.h))
+
+    def summaries(self, n=None):
+        n = len(self.windows) if n is None else n
+        arr = (SolverSummary * n)()
+        check(lib().tcv_batch_get_summaries(self.h, arr, n))
+        return arr
+
+    def first_step(self, window):
+        out = np.zeros(2048)
+        ln = C.c_int()
+        check(lib().tcv_batch_get_first_step(self.h, window, dptr(out), 2048, C.byref(ln)))
+        return out[:ln.value].copy()
+
+    def prior(self, window):
+        h = C.c_void_p()
+        check(lib().tcv_batch_get_prior(self.h, window, C.byref(h)))
+        return Prior(h)
+
+    def stats(self):
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        check(lib().tcv_batch_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(input_bytes=a.value, solve_ms=b.value, marg_ms=c.value)
+
+    def plan_stats(self):
+        a, b, c, d = C.c_int(), C.c_double(), C.c_int(), C.c_int()
+        check(lib().tcv_batch_plan_stats(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return dict(num_plans=a.value, plan_bytes=b.value, grid=c.value, lds_bytes=d.value)
+
+    def __del__(self):
+        if getattr(self, "h", None) is not None and _lib is not None:
+            _lib.tcv_batch_destroy(self.h)
+            self.h = None
+
+
+# ---- batched factor evaluation (CostFunction::Evaluate layout) ---------------------------------------
+def eval_imu(imu, params, G, sqrt_info=None, want_jac=True):
+    n = len(imu["frame_i"])
+    pre = pack_imu(imu)
+    params = f64(params).reshape(n, 32)
+    S = np.zeros((n, 225)) if sqrt_info is None else f64(sqrt_info).reshape(n, 225).copy()
+    res = np.zeros((n, 15)); jac = np.zeros((n, 480))
+    Gv = f64(G)
+    check(lib().tcv_eval_imu_factors(n, pre, dptr(params), dptr(Gv), int(sqrt_info is not None), dptr(S), dptr(res),
+                                     dptr(jac) if want_jac else None))
+    Js = [jac[:, 0:105].reshape(n, 15, 7), jac[:, 105:240].reshape(n, 15, 9), jac[:, 240:345].reshape(n, 15, 7),
+          jac[:, 345:480].reshape(n, 15, 9)]
+    return res, Js, S.reshape(n, 15, 15)
+
+
+def eval_proj(pts, params, sqrt_info, want_jac=True):
+    pts = f64(pts); params = f64(params)
+    n = pts.shape[0]
+    res = np.zeros((n, 2)); jac = np.zeros((n, 44))
+    check(lib().tcv_eval_projection_factors(n, dptr(pts), dptr(params), float(sqrt_info), dptr(res), dptr(jac) if want_jac else None))
+    return res, [jac[:, 0:14].reshape(n, 2, 7), jac[:, 14:28].reshape(n, 2, 7), jac[:, 28:42].reshape(n, 2, 7),
+                 jac[:, 42:44].reshape(n, 2, 1)]
+
+
+def eval_line(line, K, R, T, params, want_jac=True):
+    line = f64(line); params = f64(params)
+    n = line.shape[0]
+    res = np.zeros((n, 2)); jac = np.zeros((n, 14))
+    K = f64(K).reshape(9); R = f64(R).reshape(9); T = f64(T).reshape(3)
+    check(lib().tcv_eval_line_factors(n, dptr(line), dptr(K), dptr(R), dptr(T), dptr(params), dptr(res), dptr(jac) if want_jac else None))
+    return res, jac.reshape(n, 2, 7)
+
+
+def pose_plus(x, delta):
+    x = f64(x); delta = f64(delta)
+    n = x.shape[0]
+    out = np.zeros((n, 7))
+    check(lib().tcv_pose_plus(n, dptr(x), dptr(delta), dptr(out)))
+    return out
