@@ -570,7 +570,10 @@ __device__ bool finalize_and_solve(Ctx<NT> &C, bool first, double mu, double &gg
             if (!(fabs(y) < 1e300)) bad = true;
         }
     }
-    const int anybad = __syncthreads_or(bad ? 1 : 0);
+    if (bad) *C.flag = 2;
+    __syncthreads();
+    const int anybad = *C.flag;
+    __syncthreads();
     return anybad == 0;
 }
 
@@ -638,11 +641,9 @@ __device__ double grad_max(Ctx<NT> &C) {
 template <int NT, bool MFMA>
 __global__ void __launch_bounds__(NT) solve_kernel(SolveArgs A) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    __shared__ int s_flag;
     const int tid = threadIdx.x;
     Ctx<NT> C;
     C.tid = tid;
-    C.flag = &s_flag;
     double *scr = A.scratch + (size_t)blockIdx.x * A.scratch_stride;
     C.v_s = scr; C.v_g = scr + SCR_NL; C.v_D = scr + 2 * SCR_NL; C.v_ghat = scr + 3 * SCR_NL; C.v_y = scr + 4 * SCR_NL;
     C.v_p = scr + 5 * SCR_NL; C.v_rc = scr + 6 * SCR_NL; C.v_sd = scr + 7 * SCR_NL;
@@ -670,6 +671,7 @@ __global__ void __launch_bounds__(NT) solve_kernel(SolveArgs A) {
         C.ycam = p; p += 176;
         C.invdiag = p; p += 176;
         C.red = p; p += 64;
+        C.flag = reinterpret_cast<int *>(C.red + 62);   // red[] uses at most 5 * NT/64 = 40 doubles
         C.area = p;
         DevSummary *S = A.summary + win;
 
