@@ -149,13 +149,16 @@ int tcv_solve(const tcv_solver_options *o, tcv_problem *p, tcv_solver_summary *s
  * marginalize.  The new prior keeps the current values of the kept blocks as linearisation point. */
 int tcv_marginalize(tcv_problem *p, double *const *drop, int num_drop, tcv_prior **out);
 /* MarginalizationInfo fields: m, n, keep_block_size/idx/data, linearized_jacobians (n x n,
- * column-major like Eigen::MatrixXd), linearized_residuals (marginalization_factor.h:57-70). */
+ * column-major like Eigen::MatrixXd), linearized_residuals (marginalization_factor.h:57-70).
+ * keep_block_idx counts from the start of the [m | n] ordering exactly as in the reference (>= m). */
 int tcv_prior_create(tcv_prior **out, int m, int n, int num_blocks, const int *keep_block_size,
                      const int *keep_block_idx, const double *keep_block_data_concat,
                      const double *linearized_jacobians, const double *linearized_residuals);
 int tcv_prior_dims(const tcv_prior *pr, int *m, int *n, int *num_blocks, int *sum_block_size);
 int tcv_prior_export(const tcv_prior *pr, int *keep_block_size, int *keep_block_idx,
                      double *keep_block_data_concat, double *linearized_jacobians, double *linearized_residuals);
+/* parity/debug: Schur system A' (n x n row-major), b' the factors were taken from (marginalization_factor.cpp:281-282) */
+int tcv_prior_export_schur(const tcv_prior *pr, double *A_schur, double *b_schur);
 /* getParameterBlocks(): addresses (un-shifted) of the kept blocks, caller applies addr_shift  :301-321 */
 int tcv_prior_keep_block_addresses(const tcv_prior *pr, double **addresses);
 void tcv_prior_destroy(tcv_prior *pr);

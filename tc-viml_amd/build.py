@@ -27,9 +27,16 @@ def _stale() -> bool:
     return False
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, profile: bool = False) -> str:
+    """profile=True builds libtcv_hip_prof.so with per-phase cycle accounting (developer tool)."""
+    if profile:
+        return _compile(os.path.join(HERE, "libtcv_hip_prof.so"), verbose, ["-DTCV_PROFILE=1"])
     if not force and not _stale():
         return OUT
+    return _compile(OUT, verbose, [])
+
+
+def _compile(out: str, verbose: bool, extra) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     srcs = [os.path.join(CSRC, f) for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=on",
@@ -38,10 +45,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
         cmd.append("-DTCV_HAVE_MARG=1")
     if verbose:
         cmd.append("-Rpass-analysis=kernel-resource-usage")
-    cmd += srcs + ["-o", OUT]
+    cmd += list(extra) + srcs + ["-o", out]
     subprocess.check_call(cmd)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv, profile="--profile" in sys.argv))

@@ -22,7 +22,7 @@ extern "C" int tcv_launch_marg(const void *args, int grid, size_t lds_bytes, voi
 namespace tcv {
 static thread_local std::string g_err;
 void set_error(const std::string &s) { g_err = s; }
-static int hip_fail(hipError_t e, const char *what) {
+int hip_fail(hipError_t e, const char *what) {
     g_err = std::string(what) + ": " + hipGetErrorString(e);
     return TCV_ERR_HIP;
 }
@@ -32,7 +32,7 @@ static int hip_fail(hipError_t e, const char *what) {
         if (e_ != hipSuccess) return hip_fail(e_, #x);    \
     } while (0)
 
-static int device_ready() {
+int device_ready() {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
         g_err = "no HIP device visible: libtcv_hip has no CPU fallback";
@@ -236,7 +236,10 @@ extern "C" int tcv_prior_create(tcv_prior **out, int m, int n, int nb, const int
     tcv_prior *pr = new tcv_prior();
     pr->m = m; pr->n = n;
     int xs = 0;
-    for (int k = 0; k < nb; k++) { pr->size.push_back(size[k]); pr->idx.push_back(idx[k]); pr->xoff.push_back(xs); xs += size[k]; }
+    for (int k = 0; k < nb; k++) {   // keep_block_idx counts from the start of the [m | n] ordering (marginalization_factor.cpp:312, :347)
+        if (idx[k] < m) { delete pr; set_error("prior_create: keep_block_idx must be >= m"); return TCV_ERR_INVALID; }
+        pr->size.push_back(size[k]); pr->idx.push_back(idx[k] - m); pr->xoff.push_back(xs); xs += size[k];
+    }
     pr->x0.assign(x0, x0 + xs);
     pr->J0.assign(J0, J0 + (size_t)n * n);
     pr->r0.assign(r0, r0 + n);
@@ -255,10 +258,17 @@ extern "C" int tcv_prior_dims(const tcv_prior *pr, int *m, int *n, int *nb, int 
 extern "C" int tcv_prior_export(const tcv_prior *pr, int *size, int *idx, double *x0, double *J0, double *r0) {
     if (!pr) return TCV_ERR_INVALID;
     if (size) std::copy(pr->size.begin(), pr->size.end(), size);
-    if (idx) std::copy(pr->idx.begin(), pr->idx.end(), idx);
+    if (idx) for (size_t k = 0; k < pr->idx.size(); k++) idx[k] = pr->idx[k] + pr->m;
     if (x0) std::copy(pr->x0.begin(), pr->x0.end(), x0);
     if (J0) std::copy(pr->J0.begin(), pr->J0.end(), J0);
     if (r0) std::copy(pr->r0.begin(), pr->r0.end(), r0);
+    return TCV_OK;
+}
+// parity/debug: the Schur system (A' n x n row-major, b') the prior was factored from; TCV_ERR_INVALID if not recorded
+extern "C" int tcv_prior_export_schur(const tcv_prior *pr, double *As, double *bs) {
+    if (!pr || pr->As.empty()) { set_error("prior carries no Schur system"); return TCV_ERR_INVALID; }
+    if (As) std::copy(pr->As.begin(), pr->As.end(), As);
+    if (bs) std::copy(pr->bs.begin(), pr->bs.end(), bs);
     return TCV_OK;
 }
 extern "C" int tcv_prior_keep_block_addresses(const tcv_prior *pr, double **addresses) {
@@ -271,45 +281,16 @@ extern "C" void tcv_prior_destroy(tcv_prior *pr) { delete pr; }
 // =====================================================================================================
 // batch: many independent windows resident in HBM
 // =====================================================================================================
-struct MargPlan;   // tcv_marg.hip
-struct tcv_batch {
-    int n = 0;
-    std::vector<tcv_problem *> problems;
-    std::vector<Packed> packed;         // host copies of per-window maps (ints/doubles released after upload)
-    std::vector<PlanHdr> plans;
-    std::vector<long long> plan_base;
-    std::vector<WinHdr> wins;
-    int state_stride = 0, delta_stride = 0;
-    double input_bytes = 0, plan_bytes = 0;
-    // device
-    WinHdr *d_win = nullptr;
-    PlanHdr *d_plans = nullptr;
-    long long *d_plan_base = nullptr;
-    int *d_ipool = nullptr;
-    double *d_dpool = nullptr, *d_state = nullptr, *d_delta = nullptr, *d_scratch = nullptr;
-    DevSummary *d_summary = nullptr;
-    int grid = 0, nthreads = 256;
-    size_t lds_bytes = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    float solve_ms = 0, marg_ms = 0;
-    bool solved = false;
-    std::vector<double> h_state;
-    // marginalisation
-    std::shared_ptr<void> marg;
-};
-
 static void batch_free(tcv_batch *b) {
     if (!b) return;
     hipFree(b->d_win); hipFree(b->d_plans); hipFree(b->d_plan_base); hipFree(b->d_ipool); hipFree(b->d_dpool);
-    hipFree(b->d_state); hipFree(b->d_delta); hipFree(b->d_scratch); hipFree(b->d_summary);
+    hipFree(b->d_prof); hipFree(b->d_state); hipFree(b->d_delta); hipFree(b->d_scratch); hipFree(b->d_summary);
     if (b->ev0) hipEventDestroy(b->ev0);
     if (b->ev1) hipEventDestroy(b->ev1);
+    if (b->marg_free) b->marg_free(b);
     delete b;
 }
 
-int tcv_marg_attach(tcv_batch *b, tcv_problem *const *marg_problems, double *const *const *marg_drop, const int *marg_num_drop);
-int tcv_marg_run(tcv_batch *b, void *stream);
-int tcv_marg_get_prior(tcv_batch *b, int window, tcv_prior **out);
 
 extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, tcv_problem *const *marg_problems,
                                 double *const *const *marg_drop, const int *marg_num_drop, int n) {
@@ -382,6 +363,8 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
     UP(b->d_delta, (double *)nullptr, double, (size_t)n * b->delta_stride);
     UP(b->d_scratch, (double *)nullptr, double, (size_t)b->grid * scr);
     UP(b->d_summary, (DevSummary *)nullptr, DevSummary, (size_t)n);
+    UP(b->d_prof, (double *)nullptr, double, (size_t)32 * b->grid);
+    hipMemset(b->d_prof, 0, sizeof(double) * 32 * b->grid);
 #undef UP
     hipMemset(b->d_scratch, 0, sizeof(double) * (size_t)b->grid * scr);
     hipMemset(b->d_summary, 0, sizeof(DevSummary) * (size_t)n);
@@ -416,6 +399,7 @@ extern "C" int tcv_batch_solve(tcv_batch *b, const tcv_solver_options *o, void *
     a.win = b->d_win; a.plans = b->d_plans; a.plan_base = b->d_plan_base; a.ipool = b->d_ipool; a.dpool = b->d_dpool;
     a.state_out = b->d_state; a.summary = b->d_summary; a.first_delta = o->record_first_step ? b->d_delta : nullptr;
     a.scratch = b->d_scratch;
+    a.prof = b->d_prof;
     a.nwin = b->n; a.state_stride = b->state_stride; a.delta_stride = b->delta_stride; a.scratch_stride = tcv_solve_scratch_doubles();
     a.max_iterations = o->max_num_iterations; a.fixed_iterations = o->fixed_iterations; a.use_mfma = o->use_mfma;
     hipStream_t st = (hipStream_t)hip_stream;
@@ -434,6 +418,7 @@ extern "C" int tcv_batch_synchronize(tcv_batch *b) {
     if (!b) return TCV_ERR_INVALID;
     HIPCHK(hipDeviceSynchronize());
     if (b->solved) hipEventElapsedTime(&b->solve_ms, b->ev0, b->ev1);
+    tcv_marg_elapsed(b);
     return TCV_OK;
 }
 extern "C" int tcv_batch_download_states(tcv_batch *b) {
@@ -500,6 +485,15 @@ extern "C" int tcv_batch_stats(tcv_batch *b, double *input_bytes, double *solve_
     if (input_bytes) *input_bytes = b->input_bytes;
     if (solve_ms) *solve_ms = b->solve_ms;
     if (marg_ms) *marg_ms = b->marg_ms;
+    return TCV_OK;
+}
+// TCV_PROFILE builds only: copies (and clears) the 32 per-phase cycle accumulators of the solve kernel
+extern "C" int tcv_batch_profile(tcv_batch *b, double *out32) {
+    if (!b || !out32) return TCV_ERR_INVALID;
+    std::vector<double> h((size_t)32 * b->grid);
+    HIPCHK(hipMemcpy(h.data(), b->d_prof, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 32; i++) { out32[i] = 0; for (int g = 0; g < b->grid; g++) out32[i] += h[(size_t)g * 32 + i]; }
+    HIPCHK(hipMemset(b->d_prof, 0, sizeof(double) * h.size()));
     return TCV_OK;
 }
 extern "C" int tcv_batch_plan_stats(tcv_batch *b, int *num_plans, double *plan_bytes, int *grid, int *lds_bytes) {
@@ -705,12 +699,3 @@ extern "C" int tcv_pose_plus(int n, const double *x, const double *delta, double
     return TCV_OK;
 }
 
-// ---- temporary marginalisation stubs until tcv_marg.hip lands (replaced below when TCV_HAVE_MARG) ----
-#ifndef TCV_HAVE_MARG
-int tcv_marg_attach(tcv_batch *, tcv_problem *const *, double *const *const *, const int *) {
-    set_error("marginalisation kernel not built");
-    return TCV_ERR_UNSUPPORTED;
-}
-int tcv_marg_run(tcv_batch *, void *) { set_error("marginalisation kernel not built"); return TCV_ERR_UNSUPPORTED; }
-int tcv_marg_get_prior(tcv_batch *, int, tcv_prior **) { set_error("marginalisation kernel not built"); return TCV_ERR_UNSUPPORTED; }
-#endif

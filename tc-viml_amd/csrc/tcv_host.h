@@ -3,7 +3,10 @@
 // (factor/marginalization_factor.h:46-72) and the packer that turns a problem into the
 // device-resident plan + data of tcv_packed.h.
 #pragma once
+#include <hip/hip_runtime.h>
+
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -18,6 +21,7 @@ struct tcv_prior {
     std::vector<double> x0;           // keep_block_data, concatenated
     std::vector<double> J0, r0;       // linearized_jacobians (n x n column-major), linearized_residuals
     std::vector<double *> addr;       // addresses of the kept blocks at marginalisation time (un-shifted)
+    std::vector<double> As, bs;       // Schur system A', b' the factors were taken from (parity/debug, may be empty)
 };
 
 namespace tcv {
@@ -55,7 +59,43 @@ struct tcv_problem {
     double G[3] = {0, 0, 9.8};
 };
 
+struct tcv_batch {
+    int n = 0;
+    std::vector<tcv_problem *> problems;
+    std::vector<tcv::Packed> packed;         // host copies of per-window maps (ints/doubles released after upload)
+    std::vector<tcv::PlanHdr> plans;
+    std::vector<long long> plan_base;
+    std::vector<tcv::WinHdr> wins;
+    int state_stride = 0, delta_stride = 0;
+    double input_bytes = 0, plan_bytes = 0;
+    // device
+    tcv::WinHdr *d_win = nullptr;
+    tcv::PlanHdr *d_plans = nullptr;
+    long long *d_plan_base = nullptr;
+    int *d_ipool = nullptr;
+    double *d_dpool = nullptr, *d_state = nullptr, *d_delta = nullptr, *d_scratch = nullptr;
+    tcv::DevSummary *d_summary = nullptr;
+    double *d_prof = nullptr;
+    int grid = 0, nthreads = 256;
+    size_t lds_bytes = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float solve_ms = 0, marg_ms = 0;
+    bool solved = false;
+    std::vector<double> h_state;
+    // marginalisation
+    void *marg = nullptr;                 // tcv_marg.hip state
+    void (*marg_free)(tcv_batch *) = nullptr;
+};
+
+
+int tcv_marg_attach(tcv_batch *b, tcv_problem *const *marg_problems, double *const *const *marg_drop, const int *marg_num_drop);
+int tcv_marg_run(tcv_batch *b, void *stream);
+int tcv_marg_get_prior(tcv_batch *b, int window, tcv_prior **out);
+void tcv_marg_elapsed(tcv_batch *b);
+
 namespace tcv {
+int hip_fail(hipError_t e, const char *what);
+int device_ready();
 void set_error(const std::string &s);
 // returns TCV_OK or a negative status; fills out.  imu_sqrt: optional host-provided sqrt_info (n_imu x 225).
 int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt);

@@ -120,6 +120,7 @@ struct SolveArgs {
     DevSummary *summary;
     double *first_delta;          // optional, per window: nc + nland tangent step of iteration 1 (stride delta_stride)
     double *scratch;              // per workgroup
+    double *prof;                 // TCV_PROFILE builds: 32 cycle accumulators (lane 0 of every workgroup adds), else unused
     int nwin, state_stride, delta_stride, scratch_stride;
     int max_iterations, fixed_iterations, use_mfma, pad;
 };

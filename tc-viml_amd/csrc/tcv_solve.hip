@@ -34,8 +34,25 @@ __device__ __forceinline__ int sw(int r, int c) { return (r << 4) + (c ^ (r & 14
 __device__ __forceinline__ int tbase(int I, int J) { return ((I * (I + 1) / 2) + J) << 8; }
 __device__ __forceinline__ int tix(int a, int b) { return tbase(a >> 4, b >> 4) + sw(a & 15, b & 15); }
 
+// optional per-phase cycle accounting (build with -DTCV_PROFILE): lane 0 adds s_memtime deltas to a global table
+#ifdef TCV_PROFILE
+#define TCV_MARK(C, id)                                                        \
+    do {                                                                       \
+        const long long t_ = clock64();                                        \
+        if ((C).tid == 0) (C).prof[id] += (double)(t_ - (C).t_last);           \
+        (C).t_last = t_;                                                       \
+    } while (0)
+#else
+#define TCV_MARK(C, id) do { } while (0)
+#endif
+enum { PH_SETUP = 0, PH_VIS_EVAL, PH_VIS_GATHER, PH_LM, PH_SCHUR, PH_ZERO, PH_IMU_RAW, PH_IMU_WHITEN, PH_IMU_GATHER, PH_PRIOR,
+       PH_COST_RED, PH_FIN_SCALE, PH_FIN_CAUCHY, PH_FIN_PASS, PH_CHOL_DIAG, PH_CHOL_TRSM, PH_CHOL_UPD, PH_BACK, PH_LM_BACK,
+       PH_DOGLEG, PH_PLUS, PH_NORMS, PH_OTHER, PH_COUNT = 32 };
+
 template <int NT>
 struct Ctx {
+    double *prof;
+    long long t_last;
     // plan / data
     const PlanHdr *P;
     const int *ip;       // plan ints
@@ -135,6 +152,7 @@ __device__ double linearize(Ctx<NT> &C, const double *x, bool first, bool assemb
         for (int i = tid; i < nc; i += NT) { C.v_rc[i] = 0.0; C.v_sd[i] = 0.0; }
     }
     const int *blk = ip + P.o_blk;
+    TCV_MARK(C, PH_ZERO);
     // ---------------- point + line factors, chunk by chunk -------------------------------------------
     for (int ch = 0; ch < P.n_vis_chunk; ch++) {
         const int *vc = ip + P.o_vchunk + ch * 12;
@@ -176,8 +194,9 @@ __device__ double linearize(Ctx<NT> &C, const double *x, bool first, bool assemb
                 cost_acc += loss_correct2(r, nullptr, 6, LINE_STRIDE, line_loss);
             }
         }
-        if (!assemble) continue;
+        if (!assemble) { TCV_MARK(C, PH_VIS_EVAL); continue; }
         __syncthreads();
+        TCV_MARK(C, PH_VIS_EVAL);
         // gather J'J / J'r contributions, one destination entry per unit
         {
             const int *dest = ip + P.o_vdest, *unit = ip + P.o_vunit + ub, *item = ip + P.o_vitem;
@@ -195,6 +214,7 @@ __device__ double linearize(Ctx<NT> &C, const double *x, bool first, bool assemb
             }
         }
         __syncthreads();
+        TCV_MARK(C, PH_VIS_GATHER);
         // landmark pivots of this chunk; keep copies for the Cauchy point and the back-substitution
         for (int l = tid; l < lmn; l += NT) {
             const double h = hll[l];
@@ -210,6 +230,7 @@ __device__ double linearize(Ctx<NT> &C, const double *x, bool first, bool assemb
         }
         for (int i = tid; i < esize; i += NT) C.g_hcl[ebase + i] = hcl[i];
         __syncthreads();
+        TCV_MARK(C, PH_LM);
         // Schur complement of the chunk's landmarks
         {
             const int *dest = ip + P.o_sdest, *unit = ip + P.o_sunit + sub, *item = ip + P.o_sitem;
@@ -237,12 +258,14 @@ __device__ double linearize(Ctx<NT> &C, const double *x, bool first, bool assemb
             }
         }
         __syncthreads();
+        TCV_MARK(C, PH_SCHUR);
     }
     if (assemble) {
         const int all_elems = C.ntiles << 8;
         for (int i = pp_elems + tid; i < all_elems; i += NT) C.tiles[i] = 0.0;
     }
     __syncthreads();
+    TCV_MARK(C, PH_ZERO);
     // ---------------- IMU factors, chunk by chunk ---------------------------------------------------
     for (int ch = 0; ch < P.n_imu_chunk; ch++) {
         const int *ic = ip + P.o_ichunk + ch * 4;
@@ -256,6 +279,7 @@ __device__ double linearize(Ctx<NT> &C, const double *x, bool first, bool assemb
                     IMU_STRIDE_J);
         }
         __syncthreads();
+        TCV_MARK(C, PH_IMU_RAW);
         // whiten in place with the upper-triangular sqrt_info: column-parallel, rows ascending
         {
             const int ncol = assemble ? 31 : 1;
@@ -276,6 +300,7 @@ __device__ double linearize(Ctx<NT> &C, const double *x, bool first, bool assemb
             }
         }
         __syncthreads();
+        TCV_MARK(C, PH_IMU_WHITEN);
         if (tid < fn) {
             const double *rec = recs + tid * IMU_REC + 30;
             double s = 0;
@@ -296,6 +321,7 @@ __device__ double linearize(Ctx<NT> &C, const double *x, bool first, bool assemb
             }
         }
         __syncthreads();
+        TCV_MARK(C, PH_IMU_GATHER);
     }
     // ---------------- marginalisation prior (marginalization_factor.cpp:335-384) ---------------------
     if (P.prior_n > 0) {
@@ -330,8 +356,10 @@ __device__ double linearize(Ctx<NT> &C, const double *x, bool first, bool assemb
             }
         }
     }
+    TCV_MARK(C, PH_PRIOR);
     const double cost = block_sum<NT>(cost_acc, C.red, tid);
     __syncthreads();
+    TCV_MARK(C, PH_COST_RED);
     return cost;
 }
 
@@ -364,6 +392,7 @@ __device__ bool chol_tiles(Ctx<NT> &C, int nt, int nc) {
             }
         }
         __syncthreads();
+        TCV_MARK(C, PH_CHOL_DIAG);
         if (*C.flag) return false;
         if (K + 1 >= nt) break;
         // panel: X * L_KK^T = A_IK, one matrix row per lane
@@ -386,6 +415,7 @@ __device__ bool chol_tiles(Ctx<NT> &C, int nt, int nc) {
             }
         }
         __syncthreads();
+        TCV_MARK(C, PH_CHOL_TRSM);
         // trailing update A_IJ -= L_IK L_JK^T
         {
             int cnt = 0;
@@ -420,6 +450,7 @@ __device__ bool chol_tiles(Ctx<NT> &C, int nt, int nc) {
                 }
         }
         __syncthreads();
+        TCV_MARK(C, PH_CHOL_UPD);
     }
     return true;
 }
@@ -493,6 +524,7 @@ __device__ bool finalize_and_solve(Ctx<NT> &C, bool first, double mu, double &gg
         C.v_ghat[nc + l] = s * C.l_gl[l] / D;
     }
     __syncthreads();
+    TCV_MARK(C, PH_FIN_SCALE);
     // Cauchy point: gg = |ghat|^2, q = |J (ghat / D)|^2 = u' H u with H = [S~ + sum Hcl Hcl'/kappa, Hcl; Hcl', hll]
     double acc[2] = {0.0, 0.0};
     for (int a = tid; a < nc; a += NT) {
@@ -524,6 +556,7 @@ __device__ bool finalize_and_solve(Ctx<NT> &C, bool first, double mu, double &gg
     gg_out = acc[0];
     q_out = acc[1];
     __syncthreads();
+    TCV_MARK(C, PH_FIN_CAUCHY);
     // scaled + regularised system, rhs row, identity padding
     {
         const int all = C.ntiles << 8;
@@ -545,8 +578,10 @@ __device__ bool finalize_and_solve(Ctx<NT> &C, bool first, double mu, double &gg
     }
     if (tid == 0) *C.flag = 0;
     __syncthreads();
+    TCV_MARK(C, PH_FIN_PASS);
     if (!chol_tiles<NT, MFMA>(C, P.nt, nc)) return false;
     back_subst<NT>(C, nc);
+    TCV_MARK(C, PH_BACK);
     // landmarks: y_l = (gl - Hcl' (s o y_c)) / (s_l kappa_l)
     bool bad = false;
     for (int a = tid; a < nc; a += NT) {
@@ -574,6 +609,7 @@ __device__ bool finalize_and_solve(Ctx<NT> &C, bool first, double mu, double &gg
     __syncthreads();
     const int anybad = *C.flag;
     __syncthreads();
+    TCV_MARK(C, PH_LM_BACK);
     return anybad == 0;
 }
 
@@ -650,6 +686,11 @@ __global__ void __launch_bounds__(NT) solve_kernel(SolveArgs A) {
     C.l_hll = scr + 8 * SCR_NL; C.l_gl = C.l_hll + SCR_LM; C.l_invk = C.l_gl + SCR_LM;
     C.g_hcl = C.l_invk + SCR_LM; C.g_hp = C.g_hcl + SCR_HCL; C.g_pr = C.g_hp + SCR_HP; C.g_pdx = C.g_pr + 128;
     C.g_sqrt = C.g_pdx + 128;
+    C.prof = A.prof ? A.prof + (size_t)blockIdx.x * 32 : nullptr;
+    C.t_last = 0;
+#ifdef TCV_PROFILE
+    C.t_last = clock64();
+#endif
 
     for (int win = blockIdx.x; win < A.nwin; win += gridDim.x) {
         const WinHdr *W = A.win + win;
@@ -698,6 +739,7 @@ __global__ void __launch_bounds__(NT) solve_kernel(SolveArgs A) {
             }
         }
         __syncthreads();
+        TCV_MARK(C, PH_SETUP);
 
         const int max_it = A.max_iterations < MAX_TRACE - 1 ? A.max_iterations : MAX_TRACE - 1;
         const bool fixed = A.fixed_iterations != 0;
@@ -750,6 +792,7 @@ __global__ void __launch_bounds__(NT) solve_kernel(SolveArgs A) {
                     yg = acc[0]; gdy = acc[1]; dy2 = acc[2];
                 }
             }
+            TCV_MARK(C, PH_OTHER);
             double model_cost_change = 0, step_norm = 0, ca = 0, cb = 0;
             int dcase = 0;
             bool step_valid = false;
@@ -791,18 +834,21 @@ __global__ void __launch_bounds__(NT) solve_kernel(SolveArgs A) {
                 continue;
             }
             invalid = 0;
+            TCV_MARK(C, PH_DOGLEG);
             for (int i = tid; i < nl; i += NT) C.v_p[i] = ca * (C.v_ghat[i] / C.v_D[i]) + cb * C.v_y[i];
             __syncthreads();
             apply_plus<NT>(C, C.xs, C.v_p, C.v_s, C.xc);
             if (A.first_delta && it == 1)
                 for (int i = tid; i < nl; i += NT) A.first_delta[(size_t)win * A.delta_stride + i] = C.v_p[i] * C.v_s[i];
             __syncthreads();
+            TCV_MARK(C, PH_PLUS);
             const double mu_next = fmax(1e-8, 2.0 * mu / 10.0);
             const bool want_asm = (it < max_it) || !fixed;
             const double cost_c = linearize<NT>(C, C.xc, false, want_asm, mu_next);
             tiles_valid = want_asm;
             lin_mu = mu_next;
             ambient_norms<NT>(C, C.xs, C.xc, xn2, dn2);
+            TCV_MARK(C, PH_NORMS);
             const double rho = (cost - cost_c) / model_cost_change;
             if (tid == 0 && nrec < MAX_TRACE) {
                 S->model_cost_change[nrec] = model_cost_change; S->cost_candidate[nrec] = cost_c;
@@ -852,6 +898,7 @@ __global__ void __launch_bounds__(NT) solve_kernel(SolveArgs A) {
             S->final_cost = cost;
         }
         __syncthreads();
+        TCV_MARK(C, PH_OTHER);
     }
 }
 

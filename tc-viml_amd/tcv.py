@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtcv_hip.so")
+LIB_PATH = os.environ.get("TCV_LIB", os.path.join(_HERE, "libtcv_hip.so"))
 
 TCV_OK, TCV_ERR_INVALID, TCV_ERR_NO_DEVICE, TCV_ERR_TOO_LARGE, TCV_ERR_HIP, TCV_ERR_UNSUPPORTED, TCV_ERR_NUMERIC = 0, -1, -2, -3, -4, -5, -6
 TCV_PARAM_EUCLIDEAN, TCV_PARAM_POSE = 0, 1
@@ -32,7 +32,7 @@ EXPORTS = [
     "tcv_problem_add_projection_factor", "tcv_problem_add_line_factor", "tcv_problem_add_marginalization_factor",
     "tcv_problem_from_window", "tcv_problem_num_parameter_blocks", "tcv_problem_num_residual_blocks",
     "tcv_problem_num_residuals", "tcv_problem_plan_stats", "tcv_solver_options_default", "tcv_solve", "tcv_marginalize",
-    "tcv_prior_create", "tcv_prior_dims", "tcv_prior_export", "tcv_prior_keep_block_addresses", "tcv_prior_destroy",
+    "tcv_prior_create", "tcv_prior_dims", "tcv_prior_export", "tcv_prior_export_schur", "tcv_prior_keep_block_addresses", "tcv_prior_destroy",
     "tcv_batch_create", "tcv_batch_destroy", "tcv_batch_solve", "tcv_batch_marginalize", "tcv_batch_synchronize",
     "tcv_batch_download_states", "tcv_batch_get_summaries", "tcv_batch_get_prior", "tcv_batch_get_first_step",
     "tcv_batch_plan_stats", "tcv_batch_stats", "tcv_batch_size",
@@ -115,6 +115,7 @@ def lib():
         L.tcv_prior_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, _ip, _ip, _dp, _dp, _dp]
         L.tcv_prior_dims.argtypes = [vp, _ip, _ip, _ip, _ip]
         L.tcv_prior_export.argtypes = [vp, _ip, _ip, _dp, _dp, _dp]
+        L.tcv_prior_export_schur.argtypes = [vp, _dp, _dp]
         L.tcv_prior_keep_block_addresses.argtypes = [vp, C.POINTER(_dp)]
         L.tcv_prior_destroy.argtypes = [vp]
         L.tcv_prior_destroy.restype = None
@@ -193,7 +194,7 @@ class Prior:
 
     @classmethod
     def from_dict(cls, p):
-        sizes = i32(p["sizes"]); idx = i32(p["idx"])
+        sizes = i32(p["sizes"]); idx = i32(np.asarray(p["idx"]) + int(p.get("m", 0)))   # reference convention: idx includes m
         x0 = f64(np.concatenate([np.atleast_1d(x) for x in p["x0"]]))
         J0 = np.asfortranarray(p["J0"], dtype=np.float64)     # column-major like Eigen::MatrixXd
         r0 = f64(p["r0"])
@@ -215,8 +216,14 @@ class Prior:
         xs_l, o = [], 0
         for s in size:
             xs_l.append(x0[o:o + s].copy()); o += int(s)
-        return dict(m=m, n=n, sizes=[int(s) for s in size], idx=[int(i) for i in idx], x0=xs_l,
+        return dict(m=m, n=n, sizes=[int(s) for s in size], idx=[int(i) - m for i in idx], x0=xs_l,
                     J0=J0.reshape(n, n).T.copy(), r0=r0)
+
+    def schur(self):
+        m, n, nb, xs = self.dims()
+        As = np.zeros(n * n); bs = np.zeros(n)
+        check(lib().tcv_prior_export_schur(self.h, dptr(As), dptr(bs)))
+        return As.reshape(n, n), bs
 
     def __del__(self):
         if self.h is not None and _lib is not None:
@@ -231,10 +238,13 @@ class Window:
     """Caller-side state arrays of one sliding window (what Estimator owns, estimator.h:166-172)
     plus the problem handle built from them with tcv_problem_from_window."""
 
-    def __init__(self, win: dict, estimate_extrinsic=True, prior: Prior | None = None):
+    def __init__(self, win: dict, estimate_extrinsic=True, prior: Prior | None = None, share: "Window | None" = None):
         self.win = win
-        self.pose = f64(win["pose"]).copy(); self.sb = f64(win["speedbias"]).copy()
-        self.ex = f64(win["ex_pose"]).copy(); self.lam = f64(win["lam"]).copy()
+        if share is not None:      # same caller-owned state arrays (parameter blocks are identified by address)
+            self.pose, self.sb, self.ex, self.lam = share.pose, share.sb, share.ex, share.lam
+        else:
+            self.pose = f64(win["pose"]).copy(); self.sb = f64(win["speedbias"]).copy()
+            self.ex = f64(win["ex_pose"]).copy(); self.lam = f64(win["lam"]).copy()
         im, pr, ln = win["imu"], win["proj"], win["line"]
         self._imu = pack_imu(im)
         self._imu_i = i32(im["frame_i"]); self._imu_j = i32(im["frame_j"])
@@ -288,6 +298,48 @@ class Window:
         if getattr(self, "h", None) is not None and _lib is not None:
             _lib.tcv_problem_destroy(self.h)
             self.h = None
+
+
+def margin_old_window(win: dict) -> dict:
+    """Factor set Estimator::OptimizationWithLine hands to MarginalizationInfo when the oldest frame is
+    marginalised (estimator.cpp:1911-1986): the prior, the IMU factor (0,1) and every projection factor
+    anchored in frame 0.  Line factors are not added (`if (0)`, :1992)."""
+    im, pr, ln = win["imu"], win["proj"], win["line"]
+    ki = [k for k in range(len(im["frame_i"])) if int(im["frame_i"][k]) == 0 and float(im["sum_dt"][k]) < 10.0]
+    kp = [k for k in range(len(pr["frame_i"])) if int(pr["frame_i"][k]) == 0]
+    out = dict(win)
+    out["imu"] = {k: (np.asarray(v)[ki] if isinstance(v, np.ndarray) and v.shape[:1] == (len(im["frame_i"]),) else v) for k, v in im.items()}
+    out["proj"] = {k: (np.asarray(v)[kp] if isinstance(v, np.ndarray) and v.shape[:1] == (len(pr["frame_i"]),) else v) for k, v in pr.items()}
+    out["line"] = dict(ln, frame=np.zeros(0, int), pts_start=np.zeros((0, 3)), pts_end=np.zeros((0, 3)), abc=np.zeros((0, 3)))
+    return out
+
+
+def margin_old_drops(w: "Window", mwin: dict):
+    """drop sets of estimator.cpp:1918-1924 (prior), :1939-1941 (IMU) and :1983-1985 (points): pose 0, speed-bias 0
+    and the inverse depths of the landmarks anchored in frame 0."""
+    drops = [w.block_ptr("pose", 0), w.block_ptr("sb", 0)]
+    for l in sorted(set(int(v) for v in mwin["proj"]["landmark"])):
+        drops.append(w.block_ptr("lam", l))
+    return drops
+
+
+def shifted_prior_blocks(prior: "Prior", w: "Window"):
+    """getParameterBlocks(addr_shift) for MARGIN_OLD (estimator.cpp:2027-2039): pose i -> i-1, speed-bias i -> i-1."""
+    m, n, nb, xs = prior.dims()
+    addrs = (_dp * nb)()
+    check(lib().tcv_prior_keep_block_addresses(prior.h, addrs))
+    base = {"pose": (w.pose.ctypes.data, 56, w.pose.shape[0]), "sb": (w.sb.ctypes.data, 72, w.sb.shape[0]), "ex": (w.ex.ctypes.data, 56, 1)}
+    out = []
+    for k in range(nb):
+        a = C.cast(addrs[k], C.c_void_p).value
+        for name, (b0, stride, cnt) in base.items():
+            if b0 <= a < b0 + stride * cnt and (a - b0) % stride == 0:
+                i = (a - b0) // stride
+                out.append((name, i - 1) if name in ("pose", "sb") else (name, 0))
+                break
+        else:
+            raise ValueError("kept block is not a pose / speed-bias / extrinsic block")
+    return out
 
 
 class Batch:

@@ -1,0 +1,141 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports every symbol include/tcv.h declares,
+the ceres::Problem-shaped host logic works without a device, and every compute entry point fails loudly
+(TCV_ERR_NO_DEVICE) instead of falling back to a CPU path."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import synth
+from util import golden_windows
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def tcv(built):
+    import tcv
+    return tcv
+
+
+def test_library_exports_every_declared_symbol(tcv):
+    hdr = open(os.path.join(ROOT, "include", "tcv.h")).read()
+    declared = set(re.findall(r"\b(tcv_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 40
+    L = tcv.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), f"libtcv_hip.so does not export {name}"
+    assert declared == set(tcv.EXPORTS)
+    assert b"gfx950" in L.tcv_version()
+
+
+def test_product_does_not_link_or_import_the_oracle(tcv):
+    import subprocess
+    out = subprocess.check_output(["ldd", tcv.LIB_PATH]).decode()
+    assert "liborc" not in out
+    src = open(os.path.join(ROOT, "tc-viml_amd", "tcv.py")).read() + open(os.path.join(ROOT, "tc-viml_amd", "synth.py")).read()
+    assert "import orc" not in src and "np_oracle" not in src and "from oracle" not in src
+
+
+def test_window_graph_counts(tcv):
+    b = synth.make_windows(5, 1)
+    w = tcv.Window(synth.window_at(b, 0))
+    L = tcv.lib()
+    # estimator.cpp:1683-1846: 11 poses + 11 speed-biases + extrinsic + 50 inverse depths; 10 IMU + 200 point + 40 line blocks
+    assert L.tcv_problem_num_parameter_blocks(w.h) == 11 + 11 + 1 + 50
+    assert L.tcv_problem_num_residual_blocks(w.h) == 10 + 200 + 40
+    assert L.tcv_problem_num_residuals(w.h) == 150 + 400 + 80
+    st = w.plan_stats()
+    assert st["nc"] == 171 and st["nx"] == 183 and st["npp"] == 72 and st["nland"] == 50 and st["nt"] == 11
+    assert st["lds_bytes"] <= 160 * 1024
+    # algorithmic window data of cfg 2 (no prior): SURVEY.md 8(d) counts 39 728 B incl. indices; the data pool holds the doubles
+    assert 4500 <= st["window_doubles"] <= 5000
+
+
+def test_prior_and_constant_extrinsic_change_the_plan(tcv):
+    pre, main, z = golden_windows()
+    w = tcv.Window(main)
+    st = w.plan_stats()
+    assert st["window_doubles"] > 10000          # + n^2 + n + x0 of the prior
+    w2 = tcv.Window(main, estimate_extrinsic=False)
+    st2 = w2.plan_stats()
+    assert st2["nc"] == 165 and st2["npp"] == 66
+    m, n, nb, xs = w.prior.dims()
+    assert (m, n, nb) == (int(z["marg_m"]), int(z["marg_n"]), len(z["marg_sizes"]))
+    d = w.prior.export()
+    assert np.array_equal(d["J0"], z["marg_J0"]) and d["idx"] == [int(i) for i in z["marg_idx"]]
+
+
+def test_large_landmark_count_is_chunked_not_rejected(tcv):
+    b = synth.make_windows(9, 1, n_landmarks=200)
+    w = tcv.Window(synth.window_at(b, 0))
+    st = w.plan_stats()
+    assert st["nland"] == 200 and st["n_vis_chunk"] >= 2
+
+
+def test_error_paths(tcv):
+    L = tcv.lib()
+    p = C.c_void_p()
+    assert L.tcv_problem_create(C.byref(p)) == 0
+    x = np.zeros(7); x[6] = 1
+    assert L.tcv_problem_add_parameter_block(p, tcv.dptr(x), 6, tcv.TCV_PARAM_POSE) == tcv.TCV_ERR_INVALID     # pose blocks are size 7
+    assert L.tcv_problem_add_parameter_block(p, tcv.dptr(x), 7, tcv.TCV_PARAM_POSE) == 0
+    assert L.tcv_problem_add_parameter_block(p, tcv.dptr(x), 9, tcv.TCV_PARAM_EUCLIDEAN) == tcv.TCV_ERR_INVALID  # re-add with another size
+    y = np.zeros(3)
+    assert L.tcv_problem_set_parameter_block_constant(p, tcv.dptr(y)) == tcv.TCV_ERR_INVALID                  # unknown block
+    assert b"unknown block" in L.tcv_last_error()
+    out = np.zeros(16, np.int32)
+    assert L.tcv_problem_plan_stats(p, tcv.iptr(out)) == 0
+    L.tcv_problem_destroy(p)
+    # NaN in the window data is reported, not propagated
+    b = synth.make_windows(3, 1)
+    w0 = synth.window_at(b, 0)
+    w0["pose"] = w0["pose"].copy(); w0["pose"][2, 1] = np.nan
+    w = tcv.Window(w0)
+    assert L.tcv_problem_plan_stats(w.h, tcv.iptr(out)) == tcv.TCV_ERR_NUMERIC
+
+
+def test_too_many_frames_is_rejected(tcv):
+    # 13 frames -> camera tangent dim 201 > 175: the LDS-resident solver refuses instead of truncating
+    L = tcv.lib()
+    p = C.c_void_p(); L.tcv_problem_create(C.byref(p))
+    poses = np.zeros((13, 7)); poses[:, 6] = 1; sbs = np.zeros((13, 9))
+    for i in range(13):
+        L.tcv_problem_add_parameter_block(p, tcv.dptr(poses[i]), 7, tcv.TCV_PARAM_POSE)
+        L.tcv_problem_add_parameter_block(p, tcv.dptr(sbs[i]), 9, tcv.TCV_PARAM_EUCLIDEAN)
+    out = np.zeros(16, np.int32)
+    assert L.tcv_problem_plan_stats(p, tcv.iptr(out)) == tcv.TCV_ERR_TOO_LARGE
+    L.tcv_problem_destroy(p)
+
+
+def test_compute_entry_points_fail_loudly_without_a_device(tcv):
+    L = tcv.lib()
+    if L.tcv_device_count() > 0:
+        pytest.skip("a HIP device is visible")
+    b = synth.make_windows(0, 1)
+    w = tcv.Window(synth.window_at(b, 0))
+    with pytest.raises(tcv.TcvError) as e:
+        tcv.Batch([w])
+    assert e.value.status == tcv.TCV_ERR_NO_DEVICE
+    with pytest.raises(tcv.TcvError) as e:
+        tcv.pose_plus(np.zeros((1, 7)), np.zeros((1, 6)))
+    assert e.value.status == tcv.TCV_ERR_NO_DEVICE
+    s = tcv.SolverSummary()
+    o = tcv.default_options()
+    assert L.tcv_solve(C.byref(o), w.h, C.byref(s)) == tcv.TCV_ERR_NO_DEVICE
+    assert np.array_equal(w.pose, synth.window_at(b, 0)["pose"])      # caller state untouched
+
+
+def test_synthetic_generator_is_deterministic_and_batch_independent():
+    a = synth.make_windows(40, 3)
+    b = synth.make_windows(41, 1)
+    w1 = synth.window_at(a, 1); w2 = synth.window_at(b, 0)
+    for k in ("pose", "speedbias", "lam"):
+        assert np.array_equal(w1[k], w2[k])
+    assert np.array_equal(w1["imu"]["covariance"], w2["imu"]["covariance"])
+    assert np.array_equal(w1["line"]["abc"], w2["line"]["abc"])
+    assert len(w1["proj"]["frame_i"]) == 200 and len(w1["line"]["frame"]) == 40 and len(w1["imu"]["frame_i"]) == 10
+    # consecutive tracks starting at the anchor (estimator.cpp:1745-1770), anchors < WINDOW_SIZE - 2 (:1740)
+    assert np.all(w1["proj"]["frame_j"] > w1["proj"]["frame_i"]) and w1["proj"]["frame_i"].max() < 8

@@ -1,0 +1,108 @@
+"""GPU parity of the marginalisation (MarginalizationInfo::marginalize, marginalization_factor.cpp:174-299)
+against the golden vectors and the C oracle.  Gates follow SURVEY.md Appendix B.2: A' is a small difference
+of ~1e14 terms, so ~1e-7 relative is the FP64 reproducibility floor between any two implementations; the
+factors J0, r0 are only defined up to eigenvector sign / rotation, so parity is gated on J0'J0 and J0'r0."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import orc
+import synth
+from util import fro, golden_windows, rel
+
+pytestmark = pytest.mark.gpu
+
+
+def marg_batch(tcv, wins, solve=True):
+    W = [tcv.Window(w) for w in wins]
+    MW = [tcv.margin_old_window(w) for w in wins]
+    M = [tcv.Window(mw, share=W[k]) for k, mw in enumerate(MW)]
+    drops = [tcv.margin_old_drops(W[k], MW[k]) for k in range(len(wins))]
+    b = tcv.Batch(W, M, drops)
+    if solve:
+        b.solve(tcv.default_options(8, True))
+    b.marginalize()
+    b.synchronize()
+    return W, b
+
+
+def test_golden_marginalisation_after_solve(gpu):
+    pre, main, z = golden_windows()
+    W, b = marg_batch(gpu, [pre])
+    P = b.prior(0); d = P.export(); As, bs = P.schur()
+    assert (d["m"], d["n"]) == (int(z["marg_m"]), int(z["marg_n"]))
+    assert d["sizes"] == [int(s) for s in z["marg_sizes"]] and d["idx"] == [int(i) for i in z["marg_idx"]]
+    kinds = {0: "pose", 1: "sb", 2: "ex"}
+    want = [(kinds[int(k)], int(i)) for k, i in zip(z["marg_block_kind"], z["marg_block_index"])]
+    assert gpu.shifted_prior_blocks(P, W[0]) == want                 # addr_shift of estimator.cpp:2027-2039
+    assert fro(As, z["marg_A_schur"]) < 1e-5 and fro(bs, z["marg_b_schur"]) < 1e-6
+    JtJ = d["J0"].T @ d["J0"]
+    assert fro(JtJ, z["marg_J0"].T @ z["marg_J0"]) < 1e-5
+    assert fro(d["J0"].T @ d["r0"], z["marg_J0"].T @ z["marg_r0"]) < 1e-3
+    assert rel(np.concatenate(d["x0"]), z["marg_x0"]) < 1e-6          # linearisation point = solved states (preMarginalize :110-129)
+    # reference invariants (marginalization_factor.cpp:297-298) up to the eps = 1e-8 thresholded null space
+    assert fro(JtJ, As) < 1e-5 and fro(d["J0"].T @ d["r0"], bs) < 1e-3
+    # thresholded factor is positive semi-definite and ordered like SelfAdjointEigenSolver (ascending)
+    rn = np.linalg.norm(d["J0"], axis=1)
+    assert np.all(np.diff(rn) >= -1e-9 * rn.max())
+
+
+def test_standalone_marginalise_at_given_state_vs_oracle(gpu):
+    """tcv_marginalize on host-resident states: both sides linearise at bit-identical states."""
+    batch = synth.make_windows(900, 2, frame_shift=-1)
+    for k in range(2):
+        w = synth.window_at(batch, k)
+        O = orc.Window(w); O.solve(8, True); st = O.states(); po, dbg = O.marginalize_old()
+        w2 = dict(w, pose=st["pose"], speedbias=st["sb"], ex_pose=st["ex"], lam=st["lam"])
+        mw = gpu.margin_old_window(w2)
+        Wm = gpu.Window(mw)
+        dr = gpu.margin_old_drops(Wm, mw)
+        arr = (gpu._dp * len(dr))(*dr)
+        h = C.c_void_p()
+        gpu.check(gpu.lib().tcv_marginalize(Wm.h, arr, len(dr), C.byref(h)))
+        P = gpu.Prior(h); d = P.export(); As, bs = P.schur()
+        assert (d["m"], d["n"]) == (po["m"], po["n"])
+        assert fro(As, dbg["A_schur"]) < 1e-5 and fro(bs, dbg["b_schur"]) < 1e-6
+        assert fro(d["J0"].T @ d["J0"], dbg["A_schur"]) < 1e-5
+        assert rel(np.concatenate(d["x0"]), np.concatenate([np.atleast_1d(v) for v in po["x0"]])) == 0.0
+
+
+def test_marginalisation_with_an_incoming_prior(gpu):
+    """second window of a chain: the prior itself is one of the marginalised factors (estimator.cpp:1913-1931)."""
+    pre, main, z = golden_windows()
+    W, b = marg_batch(gpu, [main])
+    P = b.prior(0); d = P.export(); As, bs = P.schur()
+    O = orc.Window(main); O.solve(8, True); po, dbg = O.marginalize_old()
+    assert (d["m"], d["n"]) == (po["m"], po["n"]) and d["sizes"] == po["sizes"] and d["idx"] == po["idx"]
+    assert fro(As, dbg["A_schur"]) < 1e-4 and fro(bs, dbg["b_schur"]) < 1e-4
+    assert fro(d["J0"].T @ d["J0"], po["J0"].T @ po["J0"]) < 1e-4
+
+
+def test_prior_round_trip_and_chained_solve(gpu):
+    """the prior exported by the GPU marginalisation is importable (checkpoint) and drives the next solve to the
+    same optimum as the oracle chain, within the reproducibility floor of the prior."""
+    pre, main, z = golden_windows()
+    W, b = marg_batch(gpu, [pre])
+    P = b.prior(0); d = P.export()
+    d["blocks"] = gpu.shifted_prior_blocks(P, W[0])
+    P2 = gpu.Prior.from_dict(d)
+    d2 = P2.export()
+    assert np.array_equal(d2["J0"], d["J0"]) and np.array_equal(d2["r0"], d["r0"]) and d2["idx"] == d["idx"]
+    w = dict(main); w["prior"] = d
+    Wn = gpu.Window(w)
+    bn = gpu.Batch([Wn]); bn.solve(gpu.default_options(8, True)); bn.synchronize(); bn.download_states()
+    s = bn.summaries()[0]
+    O = orc.Window(main); so = O.solve(8, True)
+    assert abs(s.final_cost - so.final_cost) < 1e-4 * so.final_cost
+    assert rel(Wn.pose, O.states()["pose"]) < 1e-5
+
+
+def test_marginalise_error_paths(gpu):
+    batch = synth.make_windows(901, 1)
+    w = synth.window_at(batch, 0)
+    W = gpu.Window(w)
+    h = C.c_void_p()
+    bogus = np.zeros(7)
+    arr = (gpu._dp * 1)(gpu.dptr(bogus))
+    assert gpu.lib().tcv_marginalize(W.h, arr, 1, C.byref(h)) in (gpu.TCV_ERR_INVALID, gpu.TCV_ERR_UNSUPPORTED)

@@ -1,0 +1,161 @@
+"""GPU parity of the fused sliding-window solve (through the C-ABI batch surface) against the golden trace
+and the C oracle on the same seeded windows.  Tolerance: 1e-6 relative on dx and final cost (north_star)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import orc
+import synth
+from util import fro, golden_windows, rel
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+
+
+def gpu_solve(tcv, wins, iters=8, fixed=True, mfma=True, threads=256, **kw):
+    W = [tcv.Window(w, **kw) for w in wins]
+    b = tcv.Batch(W)
+    b.solve(tcv.default_options(iters, fixed, mfma, threads, True))
+    b.synchronize()
+    b.download_states()
+    return W, b, b.summaries()
+
+
+def check_against_oracle(tcv, w, W, b, s, k, iters, fixed, ex_constant=False):
+    O = orc.Window(w, ex_constant=ex_constant)
+    so = O.solve(iters, fixed)
+    assert s.num_iterations == so.num_iterations and s.termination == so.termination
+    n = so.num_iterations
+    assert [s.dogleg_case[i] for i in range(1, n)] == [so.dogleg_case[i] for i in range(1, n)]
+    assert [s.step_ok[i] for i in range(1, n)] == [so.step_ok[i] for i in range(1, n)]
+    assert rel([s.cost[i] for i in range(n)], [so.cost[i] for i in range(n)]) < TOL
+    assert abs(s.final_cost - so.final_cost) < TOL * so.final_cost
+    st, sg = O.states(), W.states()
+    for key in ("pose", "sb", "ex", "lam"):
+        assert rel(sg[key], st[key]) < TOL, key
+    fo = np.array(so.first_delta[:so.n_local]); fg = b.first_step(k)
+    assert len(fg) == len(fo) and fro(fg, fo) < TOL
+    mg = np.array([s.model_cost_change[i] for i in range(1, n)]); mo = np.array([so.model_cost_change[i] for i in range(1, n)])
+    ok = np.array([so.dogleg_case[i] > 0 for i in range(1, n)])
+    assert rel(mg[ok], mo[ok]) < 1e-5
+
+
+def test_golden_window_trace(gpu):
+    pre, main, z = golden_windows()
+    for w, p in ((pre, "pre_"), (main, "main_")):
+        W, b, s = gpu_solve(gpu, [w])
+        n = s[0].num_iterations
+        assert n == len(z[p + "cost"])
+        assert rel([s[0].cost[i] for i in range(n)], z[p + "cost"]) < TOL
+        sg = W[0].states()
+        assert rel(sg["pose"], z[p + "final_pose"]) < TOL and rel(sg["sb"], z[p + "final_sb"]) < TOL
+        assert rel(sg["ex"], z[p + "final_ex"]) < TOL and rel(sg["lam"], z[p + "final_lam"]) < TOL
+        assert fro(b.first_step(0), z[p + "first_delta"]) < TOL
+        assert [s[0].dogleg_case[i] for i in range(1, n)] == [int(c) for c in z[p + "case"][1:]]
+
+
+@pytest.mark.parametrize("mfma,threads", [(True, 256), (False, 256), (True, 512)])
+def test_cfg2_points_only_vs_oracle(gpu, mfma, threads):
+    """BASELINE config 2: 10-kf window, 200 point residual blocks, no lines, no prior (gauge handled by the mu D^2 path)."""
+    batch = synth.make_windows(100, 3, with_lines=False)
+    wins = [synth.window_at(batch, k) for k in range(3)]
+    W, b, s = gpu_solve(gpu, wins, mfma=mfma, threads=threads)
+    for k in range(3):
+        check_against_oracle(gpu, wins[k], W[k], b, s[k], k, 8, True)
+
+
+def test_cfg3_points_lines_prior_vs_oracle(gpu):
+    """BASELINE config 3: 200 point + 40 line residual blocks + marginalisation prior."""
+    pre, main, z = golden_windows()
+    batch = synth.make_windows(200, 2)
+    wins = [main] + [dict(synth.window_at(batch, k), prior=None) for k in range(2)]
+    W, b, s = gpu_solve(gpu, wins)
+    for k in range(3):
+        check_against_oracle(gpu, wins[k], W[k], b, s[k], k, 8, True)
+    assert b.plan_stats()["num_plans"] == 2          # windows with the same graph structure share one plan
+
+
+def test_run_to_convergence_with_ceres_tolerances(gpu):
+    pre, main, z = golden_windows()
+    W, b, s = gpu_solve(gpu, [main], iters=50, fixed=False)
+    assert s[0].num_iterations == int(z["conv_num_iterations"]) and s[0].termination == int(z["conv_termination"])
+    assert abs(s[0].final_cost - float(z["conv_final_cost"])) < TOL * float(z["conv_final_cost"])
+    check_against_oracle(gpu, main, W[0], b, s[0], 0, 50, False)
+
+
+def test_constant_extrinsic(gpu):
+    """ESTIMATE_EXTRINSIC == 0: SetParameterBlockConstant(para_Ex_Pose) (estimator.cpp:1694-1698)."""
+    batch = synth.make_windows(300, 1)
+    w = synth.window_at(batch, 0)
+    W, b, s = gpu_solve(gpu, [w], estimate_extrinsic=False)
+    assert np.array_equal(W[0].ex, w["ex_pose"])
+    check_against_oracle(gpu, w, W[0], b, s[0], 0, 8, True, ex_constant=True)
+
+
+def _sub_window(w, frames, keep_lines=True):
+    """first `frames` frames of a window (ragged case: factors that touch later frames are dropped)."""
+    out = dict(w)
+    out["pose"] = w["pose"][:frames]; out["speedbias"] = w["speedbias"][:frames]
+    im = w["imu"]; ki = [k for k in range(len(im["frame_i"])) if im["frame_j"][k] < frames]
+    out["imu"] = {k: (np.asarray(v)[ki] if isinstance(v, np.ndarray) and v.shape[:1] == (len(im["frame_i"]),) else v) for k, v in im.items()}
+    pr = w["proj"]; kp = [k for k in range(len(pr["frame_i"])) if pr["frame_j"][k] < frames]
+    out["proj"] = {k: (np.asarray(v)[kp] if isinstance(v, np.ndarray) and v.shape[:1] == (len(pr["frame_i"]),) else v) for k, v in pr.items()}
+    used = sorted(set(int(l) for l in out["proj"]["landmark"]))
+    remap = {l: i for i, l in enumerate(used)}
+    out["proj"]["landmark"] = np.array([remap[int(l)] for l in out["proj"]["landmark"]], int)
+    out["lam"] = w["lam"][used]
+    ln = w["line"]; kl = [k for k in range(len(ln["frame"])) if ln["frame"][k] < frames and keep_lines]
+    out["line"] = {k: (np.asarray(v)[kl] if isinstance(v, np.ndarray) and v.shape[:1] == (len(ln["frame"]),) else v) for k, v in ln.items()}
+    out["prior"] = None
+    return out
+
+
+@pytest.mark.parametrize("frames", [3, 6, 9])
+def test_short_and_ragged_windows(gpu, frames):
+    batch = synth.make_windows(400, 1)
+    w = _sub_window(synth.window_at(batch, 0), frames)
+    W, b, s = gpu_solve(gpu, [w])
+    check_against_oracle(gpu, w, W[0], b, s[0], 0, 8, True)
+
+
+def test_no_points_imu_and_lines_only(gpu):
+    batch = synth.make_windows(500, 1)
+    w = dict(synth.window_at(batch, 0))
+    pr = w["proj"]
+    w["proj"] = {k: (np.asarray(v)[:0] if isinstance(v, np.ndarray) and v.shape[:1] == (200,) else v) for k, v in pr.items()}
+    w["lam"] = np.zeros(0)
+    W, b, s = gpu_solve(gpu, [w])
+    check_against_oracle(gpu, w, W[0], b, s[0], 0, 8, True)
+
+
+def test_many_landmarks_are_chunked_through_lds(gpu):
+    """alternative reading of the config (200 landmarks x 4 observations = 800 blocks): several staging chunks."""
+    batch = synth.make_windows(600, 1, n_landmarks=200)
+    w = synth.window_at(batch, 0)
+    W, b, s = gpu_solve(gpu, [w])
+    assert W[0].plan_stats()["n_vis_chunk"] >= 2
+    check_against_oracle(gpu, w, W[0], b, s[0], 0, 8, True)
+
+
+def test_single_problem_ceres_style_entry_point(gpu):
+    """tcv_solve(options, problem, summary) updates the caller's parameter blocks in place like ceres::Solve."""
+    batch = synth.make_windows(700, 1)
+    w = synth.window_at(batch, 0)
+    W = gpu.Window(w)
+    s = gpu.SolverSummary()
+    o = gpu.default_options(8, True)
+    gpu.check(gpu.lib().tcv_solve(C.byref(o), W.h, C.byref(s)))
+    O = orc.Window(w); so = O.solve(8, True)
+    assert abs(s.final_cost - so.final_cost) < TOL * so.final_cost
+    assert rel(W.pose, O.states()["pose"]) < TOL and not np.array_equal(W.pose, w["pose"])
+
+
+def test_max_iterations_zero_and_one(gpu):
+    batch = synth.make_windows(800, 1)
+    w = synth.window_at(batch, 0)
+    W, b, s = gpu_solve(gpu, [w], iters=0)
+    assert s[0].num_iterations == 1 and s[0].initial_cost == s[0].final_cost
+    assert np.array_equal(W[0].pose, w["pose"])
+    W, b, s = gpu_solve(gpu, [w], iters=1)
+    check_against_oracle(gpu, w, W[0], b, s[0], 0, 1, True)
