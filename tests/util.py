@@ -11,6 +11,8 @@ sys.path.insert(0, GOLDEN)
 
 def rel(a, b):
     a = np.asarray(a, dtype=float); b = np.asarray(b, dtype=float)
+    if a.size == 0 and b.size == 0:
+        return 0.0
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
 
 
