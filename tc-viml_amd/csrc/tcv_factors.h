@@ -144,6 +144,71 @@ TCV_HD int imu_sqrt_info(const double *cov, double *S /*225 row-major*/, double 
     return 0;
 }
 
+#if defined(__HIPCC__)
+// Same computation as imu_sqrt_info, cooperatively by the 16 lanes of one lane group (lane = 0..15 of a
+// 16-aligned group inside one wavefront; every element goes through the identical sequence of IEEE
+// operations, so the result is bit-identical to the serial routine and to the CPU oracle).
+// a, inv: 225 doubles each in LDS, private to the group.  Returns 0, or -1 if cov^-1 is not positive definite.
+__device__ __forceinline__ int imu_sqrt_info_group(const double *cov, double *S, double *a, double *inv, int lane) {
+    TCV_NO_CONTRACT
+#define TCV_GFENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
+    int perm = lane;   // lane i holds perm[i]
+    for (int i = lane; i < 225; i += 16) a[i] = cov[i];
+    TCV_GFENCE();
+    for (int k = 0; k < 15; k++) {
+        int p = k;
+        double mv = fabs(a[k * 15 + k]);
+        for (int i = k + 1; i < 15; i++) { const double v = fabs(a[i * 15 + k]); if (v > mv) { mv = v; p = i; } }
+        if (p != k) {
+            if (lane < 15) { const double t = a[k * 15 + lane]; a[k * 15 + lane] = a[p * 15 + lane]; a[p * 15 + lane] = t; }
+            const int pk = __shfl(perm, k, 16), pp = __shfl(perm, p, 16);
+            if (lane == k) perm = pp; else if (lane == p) perm = pk;
+        }
+        TCV_GFENCE();
+        if (lane > k && lane < 15) a[lane * 15 + k] = a[lane * 15 + k] / a[k * 15 + k];
+        TCV_GFENCE();
+        if (lane > k && lane < 15) {
+            const double m = a[lane * 15 + k];
+            for (int j = k + 1; j < 15; j++) a[lane * 15 + j] = a[lane * 15 + j] - m * a[k * 15 + j];
+        }
+        TCV_GFENCE();
+    }
+    {   // column `lane` of the inverse
+        double y[15], x[15];
+        for (int i = 0; i < 15; i++) {
+            const int pi = __shfl(perm, i, 16);
+            double s = (pi == lane) ? 1.0 : 0.0;
+            for (int k = 0; k < i; k++) s = s - a[i * 15 + k] * y[k];
+            y[i] = s;
+        }
+        for (int i = 14; i >= 0; i--) {
+            double s = y[i];
+            for (int k = i + 1; k < 15; k++) s = s - a[i * 15 + k] * x[k];
+            x[i] = s / a[i * 15 + i];
+        }
+        if (lane < 15) for (int i = 0; i < 15; i++) inv[i * 15 + lane] = x[i];
+    }
+    TCV_GFENCE();
+    int bad = 0;
+    for (int j = 0; j < 15; j++) {   // Cholesky of the lower triangle of inv, L over a, column by column
+        double s = 0;
+        if (lane >= j && lane < 15) {
+            s = inv[lane * 15 + j];
+            for (int k = 0; k < j; k++) s = s - a[lane * 15 + k] * a[j * 15 + k];
+        }
+        const double dj = __shfl(s, j, 16);
+        if (!(dj > 0)) bad = 1;
+        const double ljj = sqrt(dj);
+        if (lane == j) a[j * 15 + j] = ljj;
+        else if (lane > j && lane < 15) a[lane * 15 + j] = s / ljj;
+        TCV_GFENCE();
+    }
+    if (lane < 15) for (int c = 0; c < 15; c++) S[lane * 15 + c] = (c >= lane) ? a[c * 15 + lane] : 0.0;
+#undef TCV_GFENCE
+    return bad ? -1 : 0;
+}
+#endif
+
 // ---- point re-projection factor --------------------------------------------------------------------
 // pts: pts_i xyz, pts_j xyz.  r[2]; J 2 x 19 row-major (leading dimension ld) local [pose_i 6 | pose_j 6 | ex 6 | inv depth 1]
 TCV_HD void proj_eval(const double *pose_i, const double *pose_j, const double *ex, double inv_dep,

@@ -194,9 +194,9 @@ __global__ void __launch_bounds__(MARG_NT) marg_kernel(MargArgs Aarg) {
         // ---- IMU factors, one at a time (only the factor touching the marginalised frame is passed in)
         for (int f = 0; f < H.n_imu; f++) {
             const int *b = ip + H.o_imu + f * 4;
-            double *S = scr + MARG_SCR_SQ + f * 225;
-            if (tid == 0) {
-                imu_sqrt_info(dp + H.d_imu + f * IMU_CONST + IMU_COV, S, scr + MARG_SCR_SQ + 16 * 225 + f * 450);
+            double *S = stage + 1500;
+            if (tid < 16) (void)imu_sqrt_info_group(dp + H.d_imu + f * IMU_CONST + IMU_COV, S, stage + 512, stage + 512 + 225, tid);
+            if (tid == 64) {
                 imu_raw(x + blk[b[0] * 5 + 1], x + blk[b[1] * 5 + 1], x + blk[b[2] * 5 + 1], x + blk[b[3] * 5 + 1],
                         dp + H.d_imu + f * IMU_CONST, G3, stage + 30, IMU_STRIDE_J, stage, IMU_STRIDE_J);
             }

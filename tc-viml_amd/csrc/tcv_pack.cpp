@@ -36,29 +36,51 @@ struct DestList {
     }
 };
 
-// append the dests of `dl` (sorted by descending item count for load balance) to the global tables
-void emit(const DestList &dl, std::vector<int> &dest, std::vector<int> &unit, std::vector<int> &item) {
-    std::vector<int> order(dl.keys.size());
-    for (size_t i = 0; i < order.size(); i++) order[i] = (int)i;
-    std::stable_sort(order.begin(), order.end(),
-                     [&](int a, int b) { return dl.items[a].size() > dl.items[b].size(); });
-    for (int id : order) {
+// A ROW UNIT is one row of a destination block: up to `ncols` register accumulators
+//   acc[e] += sum_rows rec[row][colA + ea] * rec[row][colB + e]      over the destination's items.
+// unit record (UNIT_INTS ints): u0 = kind << 28 | ncols << 24 | ea << 20 | nitems,  u1 = o0 << 16 | o1,  u2 = item_begin
+// (IMU units carry their <= 2 items inline instead: u2 = item0, u3 = item1).  Units are sorted by descending item
+// count; those with more than WAVE_UNIT_ITEMS items come first and are processed by a whole wavefront each.
+enum { WAVE_UNIT_ITEMS = 48 };
+struct RowProg {
+    std::vector<int> units, items;
+    int n_units = 0, n_wave_units = 0;
+};
+static bool emit_rows(const DestList &dl, RowProg &out, bool inline_items) {
+    struct U { int u0, u1, u2, u3, n; };
+    std::vector<U> us;
+    for (size_t id = 0; id < dl.keys.size(); id++) {
         const DestKey &k = dl.keys[id];
-        const int did = (int)dest.size() / 4;
-        dest.push_back(k.o0);
-        dest.push_back((int)(((unsigned)k.o1 & 0x0fffffffu) | ((unsigned)k.kind << 28)));
-        dest.push_back((int)item.size());
-        dest.push_back((int)dl.items[id].size());
-        for (int it : dl.items[id]) item.push_back(it);
+        const int n = (int)dl.items[id].size();
         const int la = dl.shape[id].first, lb = dl.shape[id].second;
-        if (lb == 0) {
-            for (int ea = 0; ea < la; ea++)
-                for (int eb = 0; eb <= ea; eb++) unit.push_back((int)pack_unit(did, ea, eb));
+        int ib = 0, i0 = 0, i1 = 0;
+        if (inline_items) {
+            if (n > 2) return false;
+            i0 = dl.items[id][0]; i1 = n > 1 ? dl.items[id][1] : 0;
         } else {
-            for (int ea = 0; ea < la; ea++)
-                for (int eb = 0; eb < lb; eb++) unit.push_back((int)pack_unit(did, ea, eb));
+            ib = (int)out.items.size();
+            for (int it : dl.items[id]) out.items.push_back(it);
+            if (ib + n >= (1 << 16) * 16) return false;
+        }
+        if (k.o0 >= (1 << 16) || k.o1 >= (1 << 16) || n >= (1 << 20)) return false;
+        const int nrow = (k.kind == DK_TILE) ? la : 1;
+        for (int ea = 0; ea < nrow; ea++) {
+            const int ncols = (k.kind == DK_TILE) ? (lb == 0 ? ea + 1 : lb) : la;   // non-tile dests: `la` accumulators
+            U u;
+            u.u0 = (int)(((unsigned)k.kind << 28) | ((unsigned)ncols << 24) | ((unsigned)ea << 20) | (unsigned)n);
+            u.u1 = (int)(((unsigned)k.o0 << 16) | (unsigned)k.o1);
+            u.u2 = inline_items ? i0 : ib; u.u3 = i1; u.n = n;
+            us.push_back(u);
         }
     }
+    std::stable_sort(us.begin(), us.end(), [](const U &a, const U &b) { return a.n > b.n; });
+    for (auto &u : us) {
+        out.units.push_back(u.u0); out.units.push_back(u.u1); out.units.push_back(u.u2);
+        if (inline_items) out.units.push_back(u.u3);
+        if (!inline_items && u.n > WAVE_UNIT_ITEMS) out.n_wave_units++;
+    }
+    out.n_units = (int)us.size();
+    return true;
 }
 
 // add all pairwise products of one factor's column groups.
@@ -69,7 +91,7 @@ void add_pairs(DestList &dl, const std::vector<Col> &cols, MakeItem mk, int rcol
     for (size_t a = 0; a < cols.size(); a++) {
         if (cols[a].t < 0) continue;
         dl.add(DK_TILE, cols[a].t, cols[a].t, cols[a].w, 0, mk(cols[a].c, cols[a].c));
-        dl.add(DK_G, cols[a].t, 0, cols[a].w, 1, mk(cols[a].c, rcol));
+        dl.add(DK_G, cols[a].t, 0, cols[a].w, 1, mk(rcol, cols[a].c));          // g[t + e] += sum r * J[:, c + e]
         for (size_t b = 0; b < a; b++) {
             if (cols[b].t < 0) continue;
             if (cols[a].t > cols[b].t) dl.add(DK_TILE, cols[a].t, cols[b].t, cols[a].w, cols[b].w, mk(cols[a].c, cols[b].c));
@@ -174,7 +196,8 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt) {
             }
         }
         if (lm_slots[l].size() > 40) { set_error("landmark observed from more than 40 blocks"); return TCV_ERR_TOO_LARGE; }
-        e_off[l + 1] = e_off[l] + 6 * (int)lm_slots[l].size();
+        if (e_off[l] >= (1 << 13)) { set_error("landmark coupling store too large"); return TCV_ERR_TOO_LARGE; }
+        e_off[l + 1] = e_off[l] + 6 * (int)lm_slots[l].size() + 2;   // + 1/kappa and gl/kappa behind the slice
     }
     H.hcl_total = e_off[L];
     if (H.hcl_total > 8192) { set_error("landmark coupling store too large"); return TCV_ERR_TOO_LARGE; }
@@ -218,28 +241,35 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt) {
     H.o_lmslot = mark();
     for (int l = 0; l < L; l++) for (int t : lm_slots[l]) I.push_back(t);
 
-    // ---- visual chunks (whole landmarks; lines ride in chunk 0)
+    // ---- visual chunks (whole landmarks; lines ride in chunk 0).  Staging holds the factor records AND the chunk's
+    // gather program (units + items), so both count against the capacity.
     struct VChunk { int pb, pn, lb, ln, lmb, lmn; };
     std::vector<VChunk> vch;
     {
         const int nline = (int)p.line.size();
-        if (nline * LINE_REC > stage_cap) { set_error("too many line factors for LDS staging"); return TCV_ERR_TOO_LARGE; }
+        const int npose = npp / 6;
+        const int base_prog = 3 * (npose * (npose + 1) / 2 * 6 + npose) ;      // upper bound on tile + gradient units
+        auto need = [&](int recs, int nf, int nl_, int slots, int nln) {
+            const int ints = base_prog + 3 * (slots + nl_) + 13 * nf + 2 * nln;
+            return ((recs + 1) & ~1) + (ints + 1) / 2 + 8;
+        };
+        if (need(nline * LINE_REC, 0, 0, 0, nline) > stage_cap) { set_error("too many line factors for LDS staging"); return TCV_ERR_TOO_LARGE; }
         VChunk cur{0, 0, 0, nline, 0, 0};
-        int recs = nline * LINE_REC, hcl = 0;
+        int recs = nline * LINE_REC, hcl = 0, nf_c = 0, slots_c = 0, nln_c = nline;
         for (int l = 0; l < L; l++) {
-            const int nf = lmptr[l + 1] - lmptr[l], nh = 6 * (int)lm_slots[l].size();
-            if (nf * PROJ_REC > stage_cap || nh + 3 > area_cap) { set_error("landmark track too long for LDS staging"); return TCV_ERR_TOO_LARGE; }
-            if (recs + nf * PROJ_REC > stage_cap || hcl + nh + 3 * (cur.lmn + 1) > area_cap) {
+            const int nf = lmptr[l + 1] - lmptr[l], ns = (int)lm_slots[l].size(), nh = 6 * ns + 2;
+            if (need(nf * PROJ_REC, nf, 1, ns, 0) > stage_cap || nh + 3 > area_cap) { set_error("landmark track too long for LDS staging"); return TCV_ERR_TOO_LARGE; }
+            if (need(recs + nf * PROJ_REC, nf_c + nf, cur.lmn + 1, slots_c + ns, nln_c) > stage_cap || hcl + nh + 3 * (cur.lmn + 1) > area_cap) {
                 vch.push_back(cur);
                 cur = VChunk{lmptr[l], 0, 0, 0, l, 0};
-                recs = 0; hcl = 0;
+                recs = 0; hcl = 0; nf_c = 0; slots_c = 0; nln_c = 0;
             }
-            cur.pn += nf; cur.lmn += 1; recs += nf * PROJ_REC; hcl += nh;
+            cur.pn += nf; cur.lmn += 1; recs += nf * PROJ_REC; hcl += nh; nf_c += nf; slots_c += ns;
         }
         vch.push_back(cur);
     }
     H.n_vis_chunk = (int)vch.size();
-    std::vector<int> vdest, vunit, vitem, sdest, sunit, sitem, vchunk_tab;
+    std::vector<int> vprog, sprog, vchunk_tab;
     for (auto &c : vch) {
         DestList dl, sl;
         for (int k = 0; k < c.pn; k++) {
@@ -248,18 +278,17 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt) {
             const int base = k * PROJ_REC;
             auto mk = [&](int ca, int cb) { return (int)(((unsigned)base << 11) | ((unsigned)ca << 6) | ((unsigned)cb << 1)); };
             std::vector<Col> cols;
-            for (int s = 0; s < 3; s++) cols.push_back(Col{loff[cam_of[f.b[s]]], 6 * s, 6});
-            for (size_t a = 0; a < cols.size(); a++)
-                for (size_t b = 0; b < a; b++)
-                    if (cols[a].t >= 0 && cols[a].t == cols[b].t) { set_error("projection factor uses one block twice"); return TCV_ERR_UNSUPPORTED; }
+            for (int s2 = 0; s2 < 3; s2++) cols.push_back(Col{loff[cam_of[f.b[s2]]], 6 * s2, 6});
+            for (size_t a2 = 0; a2 < cols.size(); a2++)
+                for (size_t b2 = 0; b2 < a2; b2++)
+                    if (cols[a2].t >= 0 && cols[a2].t == cols[b2].t) { set_error("projection factor uses one block twice"); return TCV_ERR_UNSUPPORTED; }
             add_pairs(dl, cols, mk, 19);
             for (auto &cc : cols) {
                 if (cc.t < 0) continue;
                 const int slot = (int)(std::find(lm_slots[l].begin(), lm_slots[l].end(), cc.t) - lm_slots[l].begin());
-                dl.add(DK_HCL, e_off[l] + 6 * slot, 0, 6, 1, mk(cc.c, 18));
+                dl.add(DK_HCL, e_off[l] + 6 * slot, 0, 6, 1, mk(18, cc.c));      // Hcl[e] += sum J[:,18] * J[:, c + e]
             }
-            dl.add(DK_HLL, l, 0, 1, 1, mk(18, 18));
-            dl.add(DK_GL, l, 0, 1, 1, mk(18, 19));
+            dl.add(DK_HLL, l, 0, 2, 1, mk(18, 18));                              // acc[0] = hll, acc[1] = gl (columns 18, 19)
         }
         for (int k = 0; k < c.ln; k++) {
             const LineFac &f = p.line[c.lb + k];
@@ -271,38 +300,48 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt) {
         }
         for (int l = c.lmb; l < c.lmb + c.lmn; l++) {
             const auto &sl_t = lm_slots[l];
-            for (size_t a = 0; a < sl_t.size(); a++) {
-                auto mk = [&](int oa, int ob) { return (int)(((unsigned)l << 16) | ((unsigned)oa << 8) | (unsigned)ob); };
-                sl.add(DK_TILE, sl_t[a], sl_t[a], 6, 0, mk(6 * (int)a, 6 * (int)a));
-                sl.add(DK_RC, sl_t[a], 0, 6, 1, mk(6 * (int)a, 255));
-                for (size_t b = 0; b < a; b++) {
-                    if (sl_t[a] > sl_t[b]) sl.add(DK_TILE, sl_t[a], sl_t[b], 6, 6, mk(6 * (int)a, 6 * (int)b));
-                    else sl.add(DK_TILE, sl_t[b], sl_t[a], 6, 6, mk(6 * (int)b, 6 * (int)a));
+            for (size_t a2 = 0; a2 < sl_t.size(); a2++) {
+                const unsigned hoff = (unsigned)(e_off[l] - e_off[c.lmb]), ns = (unsigned)sl_t.size();
+                auto mk = [&](int sa, int sb) { return (int)((hoff << 18) | (ns << 12) | ((unsigned)sa << 6) | (unsigned)sb); };
+                sl.add(DK_TILE, sl_t[a2], sl_t[a2], 6, 0, mk((int)a2, (int)a2));
+                sl.add(DK_RC, sl_t[a2], 0, 6, 1, mk(63, (int)a2));                // rc[t + e] += gl/kappa * Hcl[slot][e]
+                for (size_t b2 = 0; b2 < a2; b2++) {
+                    if (sl_t[a2] > sl_t[b2]) sl.add(DK_TILE, sl_t[a2], sl_t[b2], 6, 6, mk((int)a2, (int)b2));
+                    else sl.add(DK_TILE, sl_t[b2], sl_t[a2], 6, 6, mk((int)b2, (int)a2));
                 }
             }
         }
-        const int ub = (int)vunit.size(), sub = (int)sunit.size();
-        emit(dl, vdest, vunit, vitem);
-        emit(sl, sdest, sunit, sitem);
-        const int tab[12] = {c.pb, c.pn, c.lb, c.ln, ub, (int)vunit.size() - ub, c.lmb, c.lmn,
-                             e_off[c.lmb], e_off[c.lmb + c.lmn] - e_off[c.lmb], sub, (int)sunit.size() - sub};
-        vchunk_tab.insert(vchunk_tab.end(), tab, tab + 12);
+        RowProg vp, sp;
+        if (!emit_rows(dl, vp, false) || !emit_rows(sl, sp, false)) { set_error("gather program field overflow"); return TCV_ERR_TOO_LARGE; }
+        const int recs = (c.pn * PROJ_REC + c.ln * LINE_REC + 1) & ~1;
+        if (recs + ((int)(vp.units.size() + vp.items.size()) + 1) / 2 + 2 > stage_cap || ((int)(sp.units.size() + sp.items.size()) + 1) / 2 + 2 > stage_cap) {
+            set_error("gather program does not fit the LDS staging area"); return TCV_ERR_TOO_LARGE;
+        }
+        while (vprog.size() & 3) vprog.push_back(0);        // every program starts 16-byte aligned (vector loads on the device)
+        while (sprog.size() & 3) sprog.push_back(0);
+        const int voff = (int)vprog.size(), soff = (int)sprog.size();
+        vprog.insert(vprog.end(), vp.units.begin(), vp.units.end()); vprog.insert(vprog.end(), vp.items.begin(), vp.items.end());
+        sprog.insert(sprog.end(), sp.units.begin(), sp.units.end()); sprog.insert(sprog.end(), sp.items.begin(), sp.items.end());
+        const int tab[16] = {c.pb, c.pn, c.lb, c.ln, voff, vp.n_units, vp.n_wave_units, (int)vp.items.size(),
+                             c.lmb, c.lmn, e_off[c.lmb], e_off[c.lmb + c.lmn] - e_off[c.lmb],
+                             soff, sp.n_units, sp.n_wave_units, (int)sp.items.size()};
+        vchunk_tab.insert(vchunk_tab.end(), tab, tab + 16);
     }
-    if (vdest.size() / 4 >= (1u << 24) || sdest.size() / 4 >= (1u << 24)) { set_error("plan too large"); return TCV_ERR_TOO_LARGE; }
     H.o_vchunk = mark(); I.insert(I.end(), vchunk_tab.begin(), vchunk_tab.end());
-    H.o_vdest = mark(); I.insert(I.end(), vdest.begin(), vdest.end()); H.n_vdest = (int)vdest.size() / 4;
-    H.o_vunit = mark(); I.insert(I.end(), vunit.begin(), vunit.end()); H.n_vunit = (int)vunit.size();
-    H.o_vitem = mark(); I.insert(I.end(), vitem.begin(), vitem.end()); H.n_vitem = (int)vitem.size();
-    H.o_sdest = mark(); I.insert(I.end(), sdest.begin(), sdest.end()); H.n_sdest = (int)sdest.size() / 4;
-    H.o_sunit = mark(); I.insert(I.end(), sunit.begin(), sunit.end()); H.n_sunit = (int)sunit.size();
-    H.o_sitem = mark(); I.insert(I.end(), sitem.begin(), sitem.end()); H.n_sitem = (int)sitem.size();
+    while ((I.size() & 3) != 0) I.push_back(0);
+    H.o_vdest = mark(); I.insert(I.end(), vprog.begin(), vprog.end()); H.n_vdest = 0;
+    H.o_vunit = H.o_vdest; H.n_vunit = (int)vprog.size(); H.o_vitem = H.o_vdest; H.n_vitem = 0;
+    while ((I.size() & 3) != 0) I.push_back(0);
+    H.o_sdest = mark(); I.insert(I.end(), sprog.begin(), sprog.end()); H.n_sdest = 0;
+    H.o_sunit = H.o_sdest; H.n_sunit = (int)sprog.size(); H.o_sitem = H.o_sdest; H.n_sitem = 0;
 
-    // ---- IMU chunks
+    // ---- IMU chunks: row units with their <= 2 items inline (4 ints, one 16-byte load per unit)
     {
         const int per = std::max(1, std::min(H.n_imu, area_cap / IMU_REC));
         if (H.n_imu > 0 && area_cap < IMU_REC) { set_error("no LDS room for IMU staging"); return TCV_ERR_TOO_LARGE; }
         if (H.n_imu > 16) { set_error("more than 16 IMU factors"); return TCV_ERR_TOO_LARGE; }
-        std::vector<int> idest, iunit, iitem, ichunk;
+        std::vector<int> iprog, ichunk;
+        while ((I.size() & 3) != 0) I.push_back(0);      // 16-byte alignment of the unit records inside the plan
         for (int fb = 0; fb < H.n_imu; fb += per) {
             const int fn = std::min(per, H.n_imu - fb);
             DestList dl;
@@ -311,22 +350,23 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt) {
                 auto mk = [&](int ca, int cb) { return (int)(((unsigned)k << 10) | ((unsigned)ca << 5) | (unsigned)cb); };
                 const int colc[4] = {0, 6, 15, 21}, colw[4] = {6, 9, 6, 9};
                 std::vector<Col> cols;
-                for (int s = 0; s < 4; s++) cols.push_back(Col{loff[cam_of[f.b[s]]], colc[s], colw[s]});
-                for (size_t a = 0; a < cols.size(); a++)
-                    for (size_t b = 0; b < a; b++)
-                        if (cols[a].t >= 0 && cols[a].t == cols[b].t) { set_error("IMU factor uses one block twice"); return TCV_ERR_UNSUPPORTED; }
+                for (int s2 = 0; s2 < 4; s2++) cols.push_back(Col{loff[cam_of[f.b[s2]]], colc[s2], colw[s2]});
+                for (size_t a2 = 0; a2 < cols.size(); a2++)
+                    for (size_t b2 = 0; b2 < a2; b2++)
+                        if (cols[a2].t >= 0 && cols[a2].t == cols[b2].t) { set_error("IMU factor uses one block twice"); return TCV_ERR_UNSUPPORTED; }
                 add_pairs(dl, cols, mk, 30);
             }
-            const int ub = (int)iunit.size();
-            emit(dl, idest, iunit, iitem);
-            ichunk.push_back(fb); ichunk.push_back(fn); ichunk.push_back(ub); ichunk.push_back((int)iunit.size() - ub);
+            RowProg ip2;
+            if (!emit_rows(dl, ip2, true)) { set_error("an IMU destination collects more than two factors"); return TCV_ERR_UNSUPPORTED; }
+            ichunk.push_back(fb); ichunk.push_back(fn); ichunk.push_back((int)iprog.size()); ichunk.push_back(ip2.n_units);
+            iprog.insert(iprog.end(), ip2.units.begin(), ip2.units.end());
         }
         H.n_imu_chunk = (int)ichunk.size() / 4;
+        H.o_idest = mark(); I.insert(I.end(), iprog.begin(), iprog.end()); H.n_idest = 0;
+        H.o_iunit = H.o_idest; H.n_iunit = (int)iprog.size() / 4; H.o_iitem = H.o_idest; H.n_iitem = 0;
         H.o_ichunk = mark(); I.insert(I.end(), ichunk.begin(), ichunk.end());
-        H.o_idest = mark(); I.insert(I.end(), idest.begin(), idest.end()); H.n_idest = (int)idest.size() / 4;
-        H.o_iunit = mark(); I.insert(I.end(), iunit.begin(), iunit.end()); H.n_iunit = (int)iunit.size();
-        H.o_iitem = mark(); I.insert(I.end(), iitem.begin(), iitem.end()); H.n_iitem = (int)iitem.size();
     }
+    while ((I.size() & 3) != 0) I.push_back(0);          // plans are concatenated: keep every plan 16-byte aligned
     H.plan_ints = (int)I.size();
 
     // ---- data

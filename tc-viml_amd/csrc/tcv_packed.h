@@ -25,7 +25,7 @@ enum { MAX_TRACE = 64 };
 // staging record strides (doubles per residual row): Jacobian columns followed by the residual
 enum {
     PROJ_STRIDE = 20,  // [pose_i 6 | pose_j 6 | ex 6 | inv depth 1 | r]
-    PROJ_REC = 40,
+    PROJ_REC = 41,     // 2 rows x 20 + 1 pad: an odd record stride spreads same-column accesses of different factors over all LDS banks
     LINE_STRIDE = 7,   // [pose 6 | r]
     LINE_REC = 14,
     IMU_STRIDE_J = 31, // [pose_i 6 | sb_i 9 | pose_j 6 | sb_j 9 | r]
@@ -36,16 +36,16 @@ enum {
 // gather destination kinds
 enum { DK_TILE = 0, DK_G = 1, DK_HCL = 2, DK_HLL = 3, DK_GL = 4, DK_RC = 5 };
 
-// dest record: 4 ints {o0, o1 | kind << 28, item_begin, item_count}
-//   DK_TILE: o0 = first tangent row, o1 = first tangent col (row >= col for every entry)
-//   DK_G   : o0 = first tangent index
-//   DK_HCL : o0 = offset in the Hcl store
-//   DK_HLL / DK_GL : o0 = landmark
-//   DK_RC  : o0 = first tangent index (Schur plan only)
-// unit: dest << 8 | ea << 4 | eb        (ea/eb: entry inside the block pair)
-// visual item: rec_base << 11 | colA << 6 | colB << 1 | type   (type 0: proj stride 20, 1: line stride 7)
-// imu item   : fac_local << 10 | colA << 5 | colB
-// schur item : landmark << 16 | offA << 8 | offB      (offsets inside the landmark's Hcl slice; offB = 255: gl)
+// The gathers are destination driven: the host turns the graph into ROW UNITS, one per row of a destination block,
+//   acc[e] += sum_rows rec[row][colA + ea] * rec[row][colB + e]   (e < ncols <= 6, IMU: <= 9)   over the unit's items,
+// so every staged Jacobian value is read once per row and the summation order is fixed (bit-wise deterministic).
+//   unit : u0 = kind << 28 | ncols << 24 | ea << 20 | nitems ; u1 = o0 << 16 | o1 ; u2 = item_begin  (IMU: u2, u3 = items)
+//     DK_TILE o0/o1 = first tangent row/col of the block pair (row >= col); DK_G o0 = first tangent index;
+//     DK_HCL  o0 = offset in the landmark/camera coupling store; DK_HLL o0 = landmark (acc[0] = hll, acc[1] = gl);
+//     DK_RC   o0 = first tangent index (Schur program: rhs correction)
+//   visual item: rec_base << 11 | colA << 6 | colB << 1 | type   (type 0: point record stride 20, 1: line stride 7)
+//   imu item   : fac_local << 10 | colA << 5 | colB
+//   schur item : landmark << 16 | offA << 8 | offB   (offsets in the landmark's Hcl slice; offA = 255: gl instead)
 inline unsigned pack_unit(int dest, int ea, int eb) { return ((unsigned)dest << 8) | ((unsigned)ea << 4) | (unsigned)eb; }
 
 struct PlanHdr {
@@ -71,13 +71,13 @@ struct PlanHdr {
     int o_lm;       // nland x 2 : e_off (offset of the landmark's slice in the Hcl store), nslot
     int o_lmslot;   // sum nslot : tangent offset of every slot's block (ordered by landmark)
     int o_lmslotptr;// nland + 1
-    int o_vchunk;   // n_vis_chunk x 12: proj_begin, proj_count, line_begin, line_count, unit_begin, unit_count,
-                    //                   lm_begin, lm_count, hcl_begin, hcl_size, schur_unit_begin, schur_unit_count
-    int o_vdest, o_vunit, o_vitem;
+    int o_vchunk;   // n_vis_chunk x 16: proj_begin, proj_count, line_begin, line_count, vprog offset (rel. o_vdest), units,
+                    //   wave units, items, lm_begin, lm_count, hcl_begin, hcl_size, sprog offset (rel. o_sdest), units, wave units, items
+    int o_vdest, o_vunit, o_vitem;   // o_vdest: visual gather programs of all chunks (units then items per chunk)
     int n_vdest, n_vunit, n_vitem;
     int o_sdest, o_sunit, o_sitem;   // Schur plan
     int n_sdest, n_sunit, n_sitem;
-    int o_ichunk;   // n_imu_chunk x 4 : fac_begin, fac_count, unit_begin, unit_count
+    int o_ichunk;   // n_imu_chunk x 4 : fac_begin, fac_count, first int of the chunk's units (rel. o_idest), unit_count
     int o_idest, o_iunit, o_iitem;
     int n_idest, n_iunit, n_iitem;
     int plan_ints;  // total ints of this plan (header excluded)

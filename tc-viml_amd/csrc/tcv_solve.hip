@@ -26,6 +26,21 @@ namespace tcv {
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
+// Every pointer carries its address space, so that LDS accesses compile to ds_read/ds_write, read-only inputs to
+// scalar / global loads and nothing to FLAT instructions (generic pointers stored in a struct defeat the inference).
+typedef __attribute__((address_space(3))) double lds_d;        // LDS
+typedef __attribute__((address_space(3))) int lds_i;
+typedef __attribute__((address_space(1))) double gbl_d;        // per-workgroup scratch / outputs in HBM
+typedef const __attribute__((address_space(4))) double cst_d;  // read-only inputs: window data
+typedef const __attribute__((address_space(4))) int cst_i;     // read-only inputs: plan
+typedef const __attribute__((address_space(4))) PlanHdr cst_plan;
+typedef const __attribute__((address_space(4))) WinHdr cst_win;
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) v4i cst_v4i;
+typedef __attribute__((address_space(3))) v4i lds_v4i;
+#define GEN(p) ((double *)(p))           // explicit address-space cast to generic for the shared factor code (inlined)
+#define CGEN(p) ((const double *)(p))
+
 // ---- LDS tile addressing -------------------------------------------------------------------------
 // element (r, c) of a 16x16 tile sits at r*16 + (c ^ (r & 14)): conflict-free for the MFMA operand
 // reads (lane -> row l&15, column 4kk + (l>>4)), for the C-layout loads/stores and for row-per-lane
@@ -51,19 +66,18 @@ enum { PH_SETUP = 0, PH_VIS_EVAL, PH_VIS_GATHER, PH_LM, PH_SCHUR, PH_ZERO, PH_IM
 
 template <int NT>
 struct Ctx {
-    double *prof;
+    gbl_d *prof;
     long long t_last;
     // plan / data
-    const PlanHdr *P;
-    const int *ip;       // plan ints
-    const double *dp;    // window doubles
-    const WinHdr *W;
+    cst_plan *P;
+    cst_i *ip;       // plan ints
+    cst_d *dp;       // window doubles
+    cst_win *W;
     // LDS
-    double *tiles, *stage, *xs, *xc, *sc, *dd, *ycam, *invdiag, *red, *area;
-    int *flag;
+    lds_d *tiles, *stage, *xs, *xc, *sc, *dd, *ycam, *invdiag, *red, *area;
+    lds_i *flag;
     // global scratch (per workgroup)
-    double *v_s, *v_g, *v_D, *v_ghat, *v_y, *v_p, *v_rc, *v_sd, *l_hll, *l_gl, *l_invk, *g_hcl, *g_hp, *g_pr, *g_pdx,
-        *g_sqrt;
+    gbl_d *v_s, *v_g, *v_D, *v_ghat, *v_y, *v_p, *v_rc, *v_sd, *l_hll, *l_gl, *l_invk, *g_hcl, *g_hp, *g_pr, *g_pdx, *g_sqrt;
     int ntiles, stage_cap;
     int tid;
 };
@@ -74,7 +88,7 @@ enum {
 };
 
 template <int NT>
-__device__ __forceinline__ double block_sum(double v, double *red, int tid) {
+__device__ __forceinline__ double block_sum(double v, lds_d *red, int tid) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
     __syncthreads();
     if ((tid & 63) == 0) red[tid >> 6] = v;
@@ -86,7 +100,7 @@ __device__ __forceinline__ double block_sum(double v, double *red, int tid) {
 }
 
 template <int NT, int N>
-__device__ __forceinline__ void block_sum_n(double (&v)[N], double *red, int tid) {
+__device__ __forceinline__ void block_sum_n(double (&v)[N], lds_d *red, int tid) {
 #pragma unroll
     for (int k = 0; k < N; k++)
         for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_down(v[k], o);
@@ -104,43 +118,68 @@ __device__ __forceinline__ void block_sum_n(double (&v)[N], double *red, int tid
     }
 }
 
-// ---- gather: sum over the items of a destination -------------------------------------------------
-__device__ __forceinline__ double gather_visual(const double *stage, const int *items, int n, int ea, int eb) {
-    double s = 0;
-    for (int k = 0; k < n; k++) {
+// ---- row-unit gathers (tcv_packed.h): acc[e] += sum_rows rec[row][colA + ea] * rec[row][colB + e] ------------------
+__device__ __forceinline__ void vis_items(const lds_d *stage, const lds_i *items, int k0, int k1, int kstep, int ea, double (&acc)[6]) {
+    for (int k = k0; k < k1; k += kstep) {
         const unsigned it = (unsigned)items[k];
         const int type = it & 1, cb = (it >> 1) & 31, ca = (it >> 6) & 31, base = it >> 11;
         const int ld = type ? LINE_STRIDE : PROJ_STRIDE;
-        const double *rec = stage + base;
-        s += rec[ca + ea] * rec[cb + eb];
-        s += rec[ld + ca + ea] * rec[ld + cb + eb];
+        const lds_d *rec = stage + base;
+        const double a0 = rec[ca + ea], a1 = rec[ld + ca + ea];
+        double b0[6], b1[6];
+#pragma unroll
+        for (int e = 0; e < 6; e++) { b0[e] = rec[cb + e]; b1[e] = rec[ld + cb + e]; }
+#pragma unroll
+        for (int e = 0; e < 6; e++) acc[e] += a0 * b0[e] + a1 * b1[e];
     }
-    return s;
 }
 
-__device__ __forceinline__ double gather_imu(const double *recs, const int *items, int n, int ea, int eb) {
-    double s = 0;
-    for (int k = 0; k < n; k++) {
-        const unsigned it = (unsigned)items[k];
-        const int cb = it & 31, ca = (it >> 5) & 31, f = it >> 10;
-        const double *rec = recs + f * IMU_REC;
+// Schur item: hoff << 18 | nslot << 12 | slotA << 6 | slotB   (slotA = 63: the landmark's gl / kappa instead of Hcl[slotA])
+__device__ __forceinline__ void schur_items(const lds_d *hcl, const lds_i *items, int k0, int k1, int kstep, int ea, double (&acc)[6]) {
+    for (int k = k0; k < k1; k += kstep) {
+        const unsigned v = (unsigned)items[k];
+        const int sb = v & 63, sa = (v >> 6) & 63, ns = (v >> 12) & 63, hoff = v >> 18;
+        const lds_d *h = hcl + hoff;
+        const double w = (sa == 63) ? h[6 * ns + 1] : h[6 * sa + ea] * h[6 * ns];
 #pragma unroll
-        for (int row = 0; row < 15; row++) s += rec[row * IMU_STRIDE_J + ca + ea] * rec[row * IMU_STRIDE_J + cb + eb];
+        for (int e = 0; e < 6; e++) acc[e] += w * h[6 * sb + e];
     }
-    return s;
+}
+
+// global (plan, L2-resident) -> LDS copy of a gather program: 16-byte loads, four in flight per thread
+template <int NT>
+__device__ __forceinline__ void copy_prog(lds_i *dst, cst_i *src, int n, int tid) {
+    const int n4 = n >> 2;
+    cst_v4i *s4 = (cst_v4i *)src;      // plans and every program inside them start 16-byte aligned (tcv_pack.cpp)
+    lds_v4i *d4 = (lds_v4i *)dst;
+    for (int i = tid; i < n4; i += 4 * NT) {
+        v4i v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (i + k * NT < n4) v[k] = s4[i + k * NT];
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (i + k * NT < n4) d4[i + k * NT] = v[k];
+    }
+    for (int i = (n4 << 2) + tid; i < n; i += NT) dst[i] = src[i];
+}
+
+template <int N>
+__device__ __forceinline__ void wave_sum(double (&acc)[N]) {
+#pragma unroll
+    for (int e = 0; e < N; e++)
+        for (int o = 32; o > 0; o >>= 1) acc[e] += __shfl_down(acc[e], o);
 }
 
 // ---- linearise at x: cost, and (if assemble) S~ = Hcc - sum_l Hcl Hcl'/kappa_l in the tiles --------
 // kappa_l = hll + mu * clamp(s_l^2 hll) / s_l^2 is the landmark pivot of the Jacobi-scaled,
 // mu-regularised system expressed in unscaled units (DoglegStrategy + SchurEliminator restated).
 template <int NT>
-__device__ double linearize(Ctx<NT> &C, const double *x, bool first, bool assemble, double mu) {
-    const PlanHdr &P = *C.P;
+__device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first, bool assemble, double mu) {
+    cst_plan &P = *C.P;
     const int tid = C.tid;
-    const int *ip = C.ip;
-    const double *dp = C.dp;
+    cst_i *ip = C.ip;
+    cst_d *dp = C.dp;
     const int nc = P.nc, L = P.nland, nx = P.nx;
-    const double *misc = dp + C.W->d_misc;
+    cst_d *misc = dp + C.W->d_misc;
     const double G3[3] = {misc[0], misc[1], misc[2]};
     const double proj_sqrt = misc[3], proj_loss = misc[4], line_loss = misc[5];
     const int pp_elems = (P.ntp * (P.ntp + 1) / 2) << 8;
@@ -151,109 +190,132 @@ __device__ double linearize(Ctx<NT> &C, const double *x, bool first, bool assemb
         for (int i = tid; i < nc + L; i += NT) C.v_g[i] = 0.0;
         for (int i = tid; i < nc; i += NT) { C.v_rc[i] = 0.0; C.v_sd[i] = 0.0; }
     }
-    const int *blk = ip + P.o_blk;
+    cst_i *blk = ip + P.o_blk;
     TCV_MARK(C, PH_ZERO);
     // ---------------- point + line factors, chunk by chunk -------------------------------------------
     for (int ch = 0; ch < P.n_vis_chunk; ch++) {
-        const int *vc = ip + P.o_vchunk + ch * 12;
-        const int pb = vc[0], pn = vc[1], lb = vc[2], ln = vc[3], ub = vc[4], un = vc[5];
-        const int lmb = vc[6], lmn = vc[7], ebase = vc[8], esize = vc[9], sub = vc[10], sun = vc[11];
-        double *hcl = C.area, *hll = C.area + esize, *gl = hll + lmn, *invk = gl + lmn;
-        if (assemble)
+        cst_i *vc = ip + P.o_vchunk + ch * 16;
+        const int pb = vc[0], pn = vc[1], lb = vc[2], ln = vc[3], voff = vc[4], vnu = vc[5], vnw = vc[6], vni = vc[7];
+        const int lmb = vc[8], lmn = vc[9], ebase = vc[10], esize = vc[11], soff = vc[12], snu = vc[13], snw = vc[14], sni = vc[15];
+        lds_d *hcl = C.area, *hll = C.area + esize, *gl = hll + lmn;
+        lds_i *lprog = (lds_i *)(C.stage + ((pn * PROJ_REC + ln * LINE_REC + 1) & ~1));   // gather program behind the records
+        if (assemble) {
             for (int i = tid; i < esize + 2 * lmn; i += NT) C.area[i] = 0.0;
+            copy_prog<NT>(lprog, ip + P.o_vdest + voff, 3 * vnu + vni, tid);
+        }
         __syncthreads();
         for (int f = tid; f < pn; f += NT) {
-            const int *pf = ip + P.o_proj + (pb + f) * 4;
-            const double *xi = x + blk[pf[0] * 4 + 1], *xj = x + blk[pf[1] * 4 + 1], *xe = x + blk[pf[2] * 4 + 1];
+            cst_i *pf = ip + P.o_proj + (pb + f) * 4;
+            const lds_d *xi = x + blk[pf[0] * 4 + 1], *xj = x + blk[pf[1] * 4 + 1], *xe = x + blk[pf[2] * 4 + 1];
             const double lam = x[nx + pf[3]];
-            double *rec = C.stage + f * PROJ_REC;
+            lds_d *rec = C.stage + f * PROJ_REC;
             double r[2];
-            if (assemble) {
-                proj_eval(xi, xj, xe, lam, dp + C.W->d_proj + (pb + f) * 6, proj_sqrt, r, rec, PROJ_STRIDE);
-                cost_acc += loss_correct2(r, rec, 19, PROJ_STRIDE, proj_loss);
-                rec[19] = r[0];
-                rec[PROJ_STRIDE + 19] = r[1];
-            } else {
-                proj_eval(xi, xj, xe, lam, dp + C.W->d_proj + (pb + f) * 6, proj_sqrt, r, nullptr, PROJ_STRIDE);
-                cost_acc += loss_correct2(r, nullptr, 19, PROJ_STRIDE, proj_loss);
-            }
+            double *J = assemble ? GEN(rec) : nullptr;
+            double pts[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) pts[i] = dp[C.W->d_proj + (pb + f) * 6 + i];
+            proj_eval(CGEN(xi), CGEN(xj), CGEN(xe), lam, pts, proj_sqrt, r, J, PROJ_STRIDE);
+            cost_acc += loss_correct2(r, J, 19, PROJ_STRIDE, proj_loss);
+            if (assemble) { rec[19] = r[0]; rec[PROJ_STRIDE + 19] = r[1]; }
         }
         for (int f = tid; f < ln; f += NT) {
             const int b = ip[P.o_line + lb + f];
-            const double *xp = x + blk[b * 4 + 1];
-            const double *lc = dp + C.W->d_linec;
-            double *rec = C.stage + pn * PROJ_REC + f * LINE_REC;
+            const lds_d *xp = x + blk[b * 4 + 1];
+            lds_d *rec = C.stage + pn * PROJ_REC + f * LINE_REC;
             double r[2];
-            if (assemble) {
-                line_eval(xp, dp + C.W->d_line + (lb + f) * 9, lc, lc + 9, lc + 18, r, rec, LINE_STRIDE);
-                cost_acc += loss_correct2(r, rec, 6, LINE_STRIDE, line_loss);
-                rec[6] = r[0];
-                rec[LINE_STRIDE + 6] = r[1];
-            } else {
-                line_eval(xp, dp + C.W->d_line + (lb + f) * 9, lc, lc + 9, lc + 18, r, nullptr, LINE_STRIDE);
-                cost_acc += loss_correct2(r, nullptr, 6, LINE_STRIDE, line_loss);
-            }
+            double *J = assemble ? GEN(rec) : nullptr;
+            double ld9[9], lc[21];
+#pragma unroll
+            for (int i = 0; i < 9; i++) ld9[i] = dp[C.W->d_line + (lb + f) * 9 + i];
+#pragma unroll
+            for (int i = 0; i < 21; i++) lc[i] = dp[C.W->d_linec + i];
+            line_eval(CGEN(xp), ld9, lc, lc + 9, lc + 18, r, J, LINE_STRIDE);
+            cost_acc += loss_correct2(r, J, 6, LINE_STRIDE, line_loss);
+            if (assemble) { rec[6] = r[0]; rec[LINE_STRIDE + 6] = r[1]; }
         }
         if (!assemble) { TCV_MARK(C, PH_VIS_EVAL); continue; }
         __syncthreads();
         TCV_MARK(C, PH_VIS_EVAL);
-        // gather J'J / J'r contributions, one destination entry per unit
+        // gather J'J / J'r / landmark couplings: wave units (long item lists) first, then one unit per thread
         {
-            const int *dest = ip + P.o_vdest, *unit = ip + P.o_vunit + ub, *item = ip + P.o_vitem;
-            for (int u = tid; u < un; u += NT) {
-                const unsigned uu = (unsigned)unit[u];
-                const int eb = uu & 15, ea = (uu >> 4) & 15;
-                const int *d = dest + (uu >> 8) * 4;
-                const int kind = ((unsigned)d[1]) >> 28, o0 = d[0], o1 = d[1] & 0x0fffffff;
-                const double s = gather_visual(C.stage, item + d[2], d[3], ea, eb);
-                if (kind == DK_TILE) C.tiles[tix(o0 + ea, o1 + eb)] += s;
-                else if (kind == DK_G) C.v_g[o0 + ea] += s;
-                else if (kind == DK_HCL) hcl[o0 - ebase + ea] += s;
-                else if (kind == DK_HLL) hll[o0 - lmb] += s;
-                else gl[o0 - lmb] += s;
+            const lds_i *items = lprog + 3 * vnu;
+            const int lane = tid & 63, wave = tid >> 6;
+            const int nloop = vnw + ((vnu - vnw + NT - 1) / NT) * 1;   // (only for clarity; loops below are separate)
+            (void)nloop;
+            for (int uu = 0; uu < 2; uu++) {
+                const bool wv = (uu == 0);
+                for (int u = wv ? wave : vnw + tid; u < (wv ? vnw : vnu); u += (wv ? NT / 64 : NT)) {
+                    const unsigned u0 = (unsigned)lprog[3 * u], u1 = (unsigned)lprog[3 * u + 1];
+                    const int ib = lprog[3 * u + 2];
+                    const int kind = u0 >> 28, ncols = (u0 >> 24) & 15, ea = (u0 >> 20) & 15, n = u0 & 0xfffff;
+                    const int o0 = u1 >> 16, o1 = u1 & 0xffff;
+                    double acc[6] = {0, 0, 0, 0, 0, 0};
+                    if (wv) { vis_items(C.stage, items, ib + lane, ib + n, 64, ea, acc); wave_sum<6>(acc); if (lane != 0) continue; }
+                    else vis_items(C.stage, items, ib, ib + n, 1, ea, acc);
+                    if (kind == DK_TILE) {
+#pragma unroll
+                        for (int e = 0; e < 6; e++) if (e < ncols) C.tiles[tix(o0 + ea, o1 + e)] += acc[e];
+                    } else if (kind == DK_G) {
+#pragma unroll
+                        for (int e = 0; e < 6; e++) if (e < ncols) C.v_g[o0 + e] += acc[e];
+                    } else if (kind == DK_HCL) {
+#pragma unroll
+                        for (int e = 0; e < 6; e++) hcl[o0 - ebase + e] += acc[e];
+                    } else { hll[o0 - lmb] += acc[0]; gl[o0 - lmb] += acc[1]; }
+                }
             }
         }
         __syncthreads();
         TCV_MARK(C, PH_VIS_GATHER);
-        // landmark pivots of this chunk; keep copies for the Cauchy point and the back-substitution
-        for (int l = tid; l < lmn; l += NT) {
-            const double h = hll[l];
-            double sl;
-            if (first) { sl = 1.0 / (1.0 + sqrt(h)); C.v_s[nc + lmb + l] = sl; }
-            else sl = C.v_s[nc + lmb + l];
-            const double d2 = fmin(fmax(sl * sl * h, 1e-6), 1e32);
-            const double kappa = h + mu * d2 / (sl * sl);
-            const double ik = 1.0 / kappa;
-            invk[l] = ik;
-            C.l_hll[lmb + l] = h; C.l_gl[lmb + l] = gl[l]; C.l_invk[lmb + l] = ik;
-            C.v_g[nc + lmb + l] = gl[l];
+        // landmark pivots of this chunk; keep copies for the Cauchy point and the back-substitution.  The staging area
+        // is dead now: the Schur program moves in.
+        {
+            cst_i *lm = ip + P.o_lm;
+            for (int l = tid; l < lmn; l += NT) {
+                const double h = hll[l];
+                double sl;
+                if (first) { sl = 1.0 / (1.0 + sqrt(h)); C.v_s[nc + lmb + l] = sl; }
+                else sl = C.v_s[nc + lmb + l];
+                const double d2 = fmin(fmax(sl * sl * h, 1e-6), 1e32);
+                const double kappa = h + mu * d2 / (sl * sl);
+                const double ik = 1.0 / kappa;
+                const int eo = lm[2 * (lmb + l)] - ebase, ns = lm[2 * (lmb + l) + 1];
+                hcl[eo + 6 * ns] = ik;
+                hcl[eo + 6 * ns + 1] = gl[l] * ik;
+                C.l_hll[lmb + l] = h; C.l_gl[lmb + l] = gl[l]; C.l_invk[lmb + l] = ik;
+                C.v_g[nc + lmb + l] = gl[l];
+            }
+            copy_prog<NT>((lds_i *)C.stage, ip + P.o_sdest + soff, 3 * snu + sni, tid);
         }
-        for (int i = tid; i < esize; i += NT) C.g_hcl[ebase + i] = hcl[i];
         __syncthreads();
+        for (int i = tid; i < esize; i += NT) C.g_hcl[ebase + i] = hcl[i];
         TCV_MARK(C, PH_LM);
         // Schur complement of the chunk's landmarks
         {
-            const int *dest = ip + P.o_sdest, *unit = ip + P.o_sunit + sub, *item = ip + P.o_sitem;
-            const int *lm = ip + P.o_lm;
-            for (int u = tid; u < sun; u += NT) {
-                const unsigned uu = (unsigned)unit[u];
-                const int eb = uu & 15, ea = (uu >> 4) & 15;
-                const int *d = dest + (uu >> 8) * 4;
-                const int kind = ((unsigned)d[1]) >> 28, o0 = d[0], o1 = d[1] & 0x0fffffff;
-                const int *it = item + d[2];
-                double s = 0;
-                for (int k = 0; k < d[3]; k++) {
-                    const unsigned v = (unsigned)it[k];
-                    const int l = v >> 16, oa = (v >> 8) & 255, ob = v & 255;
-                    const double *h = hcl + (lm[l * 2] - ebase);
-                    const double rhs = (ob == 255) ? gl[l - lmb] : h[ob + eb];
-                    s += h[oa + ea] * rhs * invk[l - lmb];
-                }
-                if (kind == DK_TILE) {
-                    C.tiles[tix(o0 + ea, o1 + eb)] -= s;
-                    if (o0 + ea == o1 + eb) C.v_sd[o0 + ea] += s;
-                } else {
-                    C.v_rc[o0 + ea] += s;
+            const lds_i *sprog = (const lds_i *)C.stage;
+            const lds_i *items = sprog + 3 * snu;
+            const int lane = tid & 63, wave = tid >> 6;
+            for (int uu = 0; uu < 2; uu++) {
+                const bool wv = (uu == 0);
+                for (int u = wv ? wave : snw + tid; u < (wv ? snw : snu); u += (wv ? NT / 64 : NT)) {
+                    const unsigned u0 = (unsigned)sprog[3 * u], u1 = (unsigned)sprog[3 * u + 1];
+                    const int ib = sprog[3 * u + 2];
+                    const int kind = u0 >> 28, ncols = (u0 >> 24) & 15, ea = (u0 >> 20) & 15, n = u0 & 0xfffff;
+                    const int o0 = u1 >> 16, o1 = u1 & 0xffff;
+                    double acc[6] = {0, 0, 0, 0, 0, 0};
+                    if (wv) { schur_items(hcl, items, ib + lane, ib + n, 64, ea, acc); wave_sum<6>(acc); if (lane != 0) continue; }
+                    else schur_items(hcl, items, ib, ib + n, 1, ea, acc);
+                    if (kind == DK_TILE) {
+#pragma unroll
+                        for (int e = 0; e < 6; e++)
+                            if (e < ncols) {
+                                C.tiles[tix(o0 + ea, o1 + e)] -= acc[e];
+                                if (o0 + ea == o1 + e) C.v_sd[o0 + ea] += acc[e];
+                            }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 6; e++) C.v_rc[o0 + e] += acc[e];
+                    }
                 }
             }
         }
@@ -268,15 +330,17 @@ __device__ double linearize(Ctx<NT> &C, const double *x, bool first, bool assemb
     TCV_MARK(C, PH_ZERO);
     // ---------------- IMU factors, chunk by chunk ---------------------------------------------------
     for (int ch = 0; ch < P.n_imu_chunk; ch++) {
-        const int *ic = ip + P.o_ichunk + ch * 4;
+        cst_i *ic = ip + P.o_ichunk + ch * 4;
         const int fb = ic[0], fn = ic[1], ub = ic[2], un = ic[3];
-        double *recs = C.area;
+        lds_d *recs = C.area;
         if (tid < fn) {
-            const int *b = ip + P.o_imu + (fb + tid) * 4;
-            double *rec = recs + tid * IMU_REC;
-            imu_raw(x + blk[b[0] * 4 + 1], x + blk[b[1] * 4 + 1], x + blk[b[2] * 4 + 1], x + blk[b[3] * 4 + 1],
-                    dp + C.W->d_imu + (fb + tid) * IMU_CONST, G3, rec + 30, IMU_STRIDE_J, assemble ? rec : nullptr,
-                    IMU_STRIDE_J);
+            cst_i *b = ip + P.o_imu + (fb + tid) * 4;
+            lds_d *rec = recs + tid * IMU_REC;
+            double cst[62];
+#pragma unroll
+            for (int i = 0; i < 62; i++) cst[i] = dp[C.W->d_imu + (fb + tid) * IMU_CONST + i];
+            imu_raw(CGEN(x + blk[b[0] * 4 + 1]), CGEN(x + blk[b[1] * 4 + 1]), CGEN(x + blk[b[2] * 4 + 1]), CGEN(x + blk[b[3] * 4 + 1]),
+                    cst, G3, GEN(rec + 30), IMU_STRIDE_J, assemble ? GEN(rec) : nullptr, IMU_STRIDE_J);
         }
         __syncthreads();
         TCV_MARK(C, PH_IMU_RAW);
@@ -285,8 +349,8 @@ __device__ double linearize(Ctx<NT> &C, const double *x, bool first, bool assemb
             const int ncol = assemble ? 31 : 1;
             for (int w = tid; w < fn * ncol; w += NT) {
                 const int f = w / ncol, col = assemble ? (w - f * ncol) : 30;
-                double *rec = recs + f * IMU_REC + col;
-                const double *S = C.g_sqrt + (fb + f) * 225;
+                lds_d *rec = recs + f * IMU_REC + col;
+                const gbl_d *S = C.g_sqrt + (fb + f) * 225;
                 double v[15];
 #pragma unroll
                 for (int r = 0; r < 15; r++) v[r] = rec[r * IMU_STRIDE_J];
@@ -302,22 +366,41 @@ __device__ double linearize(Ctx<NT> &C, const double *x, bool first, bool assemb
         __syncthreads();
         TCV_MARK(C, PH_IMU_WHITEN);
         if (tid < fn) {
-            const double *rec = recs + tid * IMU_REC + 30;
+            const lds_d *rec = recs + tid * IMU_REC + 30;
             double s = 0;
 #pragma unroll
             for (int r = 0; r < 15; r++) s += rec[r * IMU_STRIDE_J] * rec[r * IMU_STRIDE_J];
             cost_acc += 0.5 * s;
         }
         if (assemble) {
-            const int *dest = ip + P.o_idest, *unit = ip + P.o_iunit + ub, *item = ip + P.o_iitem;
+            cst_v4i *units = (cst_v4i *)(ip + P.o_idest + ub);
+            v4i q = {0, 0, 0, 0};
+            if (tid < un) q = units[tid];
             for (int u = tid; u < un; u += NT) {
-                const unsigned uu = (unsigned)unit[u];
-                const int eb = uu & 15, ea = (uu >> 4) & 15;
-                const int *d = dest + (uu >> 8) * 4;
-                const int kind = ((unsigned)d[1]) >> 28, o0 = d[0], o1 = d[1] & 0x0fffffff;
-                const double s = gather_imu(recs, item + d[2], d[3], ea, eb);
-                if (kind == DK_TILE) C.tiles[tix(o0 + ea, o1 + eb)] += s;
-                else C.v_g[o0 + ea] += s;
+                const v4i cur = q;
+                if (u + NT < un) q = units[u + NT];      // prefetch the next record (L2-resident plan)
+                const unsigned u0 = (unsigned)cur.x, u1 = (unsigned)cur.y;
+                const int kind = u0 >> 28, ncols = (u0 >> 24) & 15, ea = (u0 >> 20) & 15, n = u0 & 0xfffff;
+                const int o0 = u1 >> 16, o1 = u1 & 0xffff;
+                double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                for (int k = 0; k < n; k++) {
+                    const unsigned it = (unsigned)(k ? cur.w : cur.z);
+                    const int cb = it & 31, ca = (it >> 5) & 31, f = it >> 10;
+                    const lds_d *rec = recs + f * IMU_REC;
+#pragma unroll 3
+                    for (int row = 0; row < 15; row++) {
+                        const double av = rec[row * IMU_STRIDE_J + ca + ea];
+#pragma unroll
+                        for (int e = 0; e < 9; e++) acc[e] += av * rec[row * IMU_STRIDE_J + cb + e];
+                    }
+                }
+                if (kind == DK_TILE) {
+#pragma unroll
+                    for (int e = 0; e < 9; e++) if (e < ncols) C.tiles[tix(o0 + ea, o1 + e)] += acc[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 9; e++) if (e < ncols) C.v_g[o0 + e] += acc[e];
+                }
             }
         }
         __syncthreads();
@@ -326,10 +409,17 @@ __device__ double linearize(Ctx<NT> &C, const double *x, bool first, bool assemb
     // ---------------- marginalisation prior (marginalization_factor.cpp:335-384) ---------------------
     if (P.prior_n > 0) {
         const int n = P.prior_n;
-        const double *J0 = dp + C.W->d_prior, *r0 = J0 + n * n, *x0 = r0 + n;
+        cst_d *J0 = dp + C.W->d_prior, *r0 = J0 + n * n, *x0 = r0 + n;
         if (tid < P.prior_nblk) {
-            const int *pb = ip + P.o_prior + tid * 4;
-            prior_block_dx(x + blk[pb[0] * 4 + 1], x0 + pb[3], pb[2], C.g_pdx + pb[1]);
+            cst_i *pb = ip + P.o_prior + tid * 4;
+            double x0v[16], dxv[16];
+            const int gs = pb[2];
+            for (int i = 0; i < 16; i++) x0v[i] = (i < gs) ? x0[pb[3] + i] : 0.0;
+            double xv[16];
+            for (int i = 0; i < 16; i++) xv[i] = (i < gs) ? x[blk[pb[0] * 4 + 1] + i] : 0.0;
+            prior_block_dx(xv, x0v, gs, dxv);
+            const int ls = gs == 7 ? 6 : gs;
+            for (int i = 0; i < 16; i++) if (i < ls) C.g_pdx[pb[1] + i] = dxv[i];
         }
         __syncthreads();
         if (tid < n) {
@@ -340,7 +430,7 @@ __device__ double linearize(Ctx<NT> &C, const double *x, bool first, bool assemb
         }
         if (assemble) {
             __syncthreads();
-            const int *pcol = ip + P.o_pcol;
+            cst_i *pcol = ip + P.o_pcol;
             if (tid < n && pcol[tid] >= 0) {
                 double s = 0;
                 for (int i = 0; i < n; i++) s += J0[i + n * tid] * C.g_pr[i];
@@ -364,42 +454,112 @@ __device__ double linearize(Ctx<NT> &C, const double *x, bool first, bool assemb
 }
 
 // ---- tiled Cholesky of the augmented system in LDS -----------------------------------------------
-template <int NT, bool MFMA>
-__device__ bool chol_tiles(Ctx<NT> &C, int nt, int nc) {
-    const int tid = C.tid, lane = tid & 63, wave = tid >> 6;
-    constexpr int NW = NT / 64, NG = NT / 16;
-    double *tiles = C.tiles;
-    for (int K = 0; K < nt; K++) {
-        const int cmax = min(16, nc - 16 * K);
-        if (cmax <= 0) break;
-        double *TK = tiles + tbase(K, K);
-        if (wave == 0) {
-            const int r = lane & 15, cq = lane >> 4;
-            for (int c = 0; c < cmax; c++) {
-                const double d = TK[sw(c, c)];
-                if (!(d > 0.0) || !(d < 1e300)) { if (lane == 0) *C.flag = 1; break; }
-                const double l = sqrt(d), inv = 1.0 / l;
-                const double colr = TK[sw(r, c)] * inv;
+// sqrt(d) and 1/sqrt(d) from v_rsq_f64 + Goldschmidt/Newton refinement (same scheme LLVM uses for f64 sqrt)
+__device__ __forceinline__ void sqrt_rsqrt(double d, double &l, double &inv) {
+    const double y = __builtin_amdgcn_rsq(d);
+    double g = d * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    double e = fma(-g, g, d);
+    g = fma(e, h, g);
+    e = fma(-g, g, d);
+    g = fma(e, h, g);
+    r = fma(-h, g, 0.5);
+    h = fma(h, r, h);
+    l = g; inv = h + h;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int srclane) {
+    const unsigned long long u = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, srclane), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), srclane);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
+// Cholesky of one 16x16 diagonal tile by ONE wavefront, one matrix row per lane held in registers
+// (lane & 15 = row; the four 16-lane groups compute redundantly, so there is no divergence).  The pivot and the
+// pivot column are broadcast with v_readlane (SGPR operands of the FMAs): nothing on the pivot chain touches LDS.
+// Only the first cmax columns are pivots (the rest: rhs row / padding).
+__device__ __forceinline__ bool diag_tile_wave(lds_d *TK, int cmax, lds_d *invd, int lane) {
+    const int r = lane & 15;
+    double t[16];
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int c2 = cq + 4 * k;
-                    if (c2 > c && c2 <= r) TK[sw(r, c2)] -= colr * (TK[sw(c2, c)] * inv);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                if (cq == 0 && r > c) TK[sw(r, c)] = colr;
-                if (lane == 0) { TK[sw(c, c)] = l; C.invdiag[16 * K + c] = inv; }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int c = 0; c < 16; c++) t[c] = TK[sw(r, c)];
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        if (k < cmax && ok) {
+            const double d = readlane_f64(t[k], k);
+            if (!(d > 0.0) || !(d < 1e300)) ok = false;
+            else {
+                double l, y;
+                sqrt_rsqrt(d, l, y);
+                const double lk = (r == k) ? l : t[k] * y;
+                t[k] = lk;
+#pragma unroll
+                for (int c = k + 1; c < 16; c++) t[c] -= lk * readlane_f64(lk, c);
+                if (lane == 0) invd[k] = y;
             }
         }
-        __syncthreads();
-        TCV_MARK(C, PH_CHOL_DIAG);
-        if (*C.flag) return false;
-        if (K + 1 >= nt) break;
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; c++) TK[sw(r, c)] = t[c];
+    }
+    return ok;
+}
+
+template <bool MFMA>
+__device__ __forceinline__ void update_tile(lds_d *tiles, int I, int J, int K, int lane) {
+    const int row0 = lane >> 4, col = lane & 15;
+    lds_d *Ct = tiles + tbase(I, J);
+    const lds_d *A = tiles + tbase(I, K), *B = tiles + tbase(J, K);
+    if (MFMA) {
+        v4f64 acc;
+        double av[4], bv[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) { av[kk] = -A[sw(col, 4 * kk + row0)]; bv[kk] = B[sw(col, 4 * kk + row0)]; }
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc[i] = Ct[sw(row0 + 4 * i, col)];
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], acc, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; i++) Ct[sw(row0 + 4 * i, col)] = acc[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int row = row0 + 4 * i;
+            double a = Ct[sw(row, col)];
+#pragma unroll
+            for (int k = 0; k < 16; k++) a -= A[sw(row, k)] * B[sw(col, k)];
+            Ct[sw(row, col)] = a;
+        }
+    }
+}
+
+// Right-looking tiled Cholesky with look-ahead: while the other waves run the trailing update of step K,
+// wave 0 updates tile (K+1, K+1) first and factorises it, so the serial pivot chain of the next diagonal
+// tile hides behind the matrix-core work.  Two barriers per tile column.
+template <int NT, bool MFMA>
+__device__ __noinline__ bool chol_tiles(Ctx<NT> &C, int nt, int nc) {
+    const int tid = C.tid, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = NT / 64, NG = NT / 16;
+    lds_d *tiles = C.tiles;
+    if (wave == 0) {
+        const int cmax0 = min(16, nc);
+        if (!diag_tile_wave(tiles + tbase(0, 0), cmax0, C.invdiag, lane) && lane == 0) *C.flag = 1;
+    }
+    __syncthreads();
+    TCV_MARK(C, PH_CHOL_DIAG);
+    if (*C.flag) return false;
+    for (int K = 0; K + 1 < nt; K++) {
+        const int cmax = min(16, nc - 16 * K);
+        if (cmax < 16) break;   // partial pivot tile is the last tile row: nothing below / right of it
+        const lds_d *TK = tiles + tbase(K, K);
         // panel: X * L_KK^T = A_IK, one matrix row per lane
         {
             const int g = tid >> 4, r = tid & 15;
             for (int I = K + 1 + g; I < nt; I += NG) {
-                double *T = tiles + tbase(I, K);
+                lds_d *T = tiles + tbase(I, K);
                 double xr[16];
 #pragma unroll
                 for (int c = 0; c < 16; c++) xr[c] = T[sw(r, c)];
@@ -416,51 +576,42 @@ __device__ bool chol_tiles(Ctx<NT> &C, int nt, int nc) {
         }
         __syncthreads();
         TCV_MARK(C, PH_CHOL_TRSM);
-        // trailing update A_IJ -= L_IK L_JK^T
+        // trailing update A_IJ -= L_IK L_JK^T; wave 0 takes (K+1, K+1) + the next diagonal factorisation, which is
+        // priced at DIAG_COST tile updates when the remaining tiles are dealt to the least-loaded wave
         {
-            int cnt = 0;
-            const int row0 = lane >> 4, col = lane & 15;
+            constexpr int DIAG_COST = 8;
+            const int cnext = min(16, nc - 16 * (K + 1));
+            if (wave == 0) {
+                update_tile<MFMA>(tiles, K + 1, K + 1, K, lane);
+                if (cnext > 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    if (!diag_tile_wave(tiles + tbase(K + 1, K + 1), cnext, C.invdiag + 16 * (K + 1), lane) && lane == 0) *C.flag = 1;
+                }
+            }
+            // the other tiles: the first DIAG_COST * (NW - 1) go round-robin to waves 1.., the rest to all waves
+            constexpr int HEAD = (NW > 1) ? DIAG_COST * (NW - 1) : 0;
+            int idx = 0;
             for (int I = K + 1; I < nt; I++)
                 for (int J = K + 1; J <= I; J++) {
-                    if ((cnt++ % NW) != wave) continue;
-                    double *Ct = tiles + tbase(I, J);
-                    const double *A = tiles + tbase(I, K), *B = tiles + tbase(J, K);
-                    if (MFMA) {
-                        v4f64 acc;
-#pragma unroll
-                        for (int i = 0; i < 4; i++) acc[i] = Ct[sw(row0 + 4 * i, col)];
-#pragma unroll
-                        for (int kk = 0; kk < 4; kk++) {
-                            const double a = -A[sw(col, 4 * kk + row0)];
-                            const double b = B[sw(col, 4 * kk + row0)];
-                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-                        }
-#pragma unroll
-                        for (int i = 0; i < 4; i++) Ct[sw(row0 + 4 * i, col)] = acc[i];
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 4; i++) {
-                            const int row = row0 + 4 * i;
-                            double a = Ct[sw(row, col)];
-#pragma unroll
-                            for (int k = 0; k < 16; k++) a -= A[sw(row, k)] * B[sw(col, k)];
-                            Ct[sw(row, col)] = a;
-                        }
-                    }
+                    if (I == K + 1 && J == K + 1) continue;
+                    const int owner = (idx < HEAD && cnext > 0) ? 1 + idx % (NW - 1) : (idx - ((cnext > 0) ? HEAD : 0)) % NW;
+                    idx++;
+                    if (owner == wave) update_tile<MFMA>(tiles, I, J, K, lane);
                 }
         }
         __syncthreads();
         TCV_MARK(C, PH_CHOL_UPD);
+        if (*C.flag) return false;
     }
     return true;
 }
 
 // ---- back substitution L^T y = z (z = the factored rhs row) ----------------------------------------
 template <int NT>
-__device__ void back_subst(Ctx<NT> &C, int nc) {
+__device__ __noinline__ void back_subst(Ctx<NT> &C, int nc) {
     const int tid = C.tid;
     constexpr int NP = NT / 16;
-    double *tiles = C.tiles, *y = C.ycam, *part = C.area;
+    lds_d *tiles = C.tiles, *y = C.ycam, *part = C.area;
     for (int c = tid; c < nc; c += NT) y[c] = tiles[tix(nc, c)];
     __syncthreads();
     for (int K = (nc - 1) >> 4; K >= 0; K--) {
@@ -478,7 +629,7 @@ __device__ void back_subst(Ctx<NT> &C, int nc) {
             double t = (c < cmax) ? y[16 * K + c] : 0.0;
 #pragma unroll
             for (int p = 0; p < NP; p++) t -= part[p * 16 + c];
-            const double *TK = tiles + tbase(K, K);
+            const lds_d *TK = tiles + tbase(K, K);
             double lrow[16];
 #pragma unroll
             for (int cc = 0; cc < 16; cc++) lrow[cc] = (c <= cc) ? TK[sw(cc, c)] : 0.0;
@@ -499,10 +650,10 @@ __device__ void back_subst(Ctx<NT> &C, int nc) {
 // ---- scale, regularise, factorise and solve (J'J + mu D^2) y = J'r ---------------------------------
 // On return (true): v_y = y (scaled space, camera then landmarks), v_D, v_ghat set, scal = {gg, q}.
 template <int NT, bool MFMA>
-__device__ bool finalize_and_solve(Ctx<NT> &C, bool first, double mu, double &gg_out, double &q_out) {
-    const PlanHdr &P = *C.P;
+__device__ __noinline__ bool finalize_and_solve(Ctx<NT> &C, bool first, double mu, double &gg_out, double &q_out) {
+    cst_plan &P = *C.P;
     const int tid = C.tid, nc = P.nc, L = P.nland;
-    const int *ip = C.ip;
+    cst_i *ip = C.ip;
     for (int a = tid; a < nc; a += NT) {
         const double dH = C.tiles[tix(a, a)] + C.v_sd[a];
         double s;
@@ -517,6 +668,7 @@ __device__ bool finalize_and_solve(Ctx<NT> &C, bool first, double mu, double &gg
         C.v_ghat[a] = gh;
         C.ycam[a] = s * gh / D;  // u = s * (ghat / D): Cauchy direction in unscaled tangent units
     }
+    for (int a = nc + tid; a < 176; a += NT) { C.ycam[a] = 0.0; C.sc[a] = 0.0; }
     for (int l = tid; l < L; l += NT) {
         const double s = C.v_s[nc + l], h = C.l_hll[l];
         const double d2 = fmin(fmax(s * s * h, 1e-6), 1e32), D = sqrt(d2);
@@ -525,20 +677,15 @@ __device__ bool finalize_and_solve(Ctx<NT> &C, bool first, double mu, double &gg
     }
     __syncthreads();
     TCV_MARK(C, PH_FIN_SCALE);
-    // Cauchy point: gg = |ghat|^2, q = |J (ghat / D)|^2 = u' H u with H = [S~ + sum Hcl Hcl'/kappa, Hcl; Hcl', hll]
+    // Cauchy point: gg = |ghat|^2, q = |J (ghat / D)|^2 = u' H u with H = [S~ + sum Hcl Hcl'/kappa, Hcl; Hcl', hll].
+    // The camera part u_c' S~ u_c is accumulated in the same sweep over the tiles that applies the Jacobi scaling,
+    // adds mu D^2, writes the rhs row and the identity padding.
     double acc[2] = {0.0, 0.0};
-    for (int a = tid; a < nc; a += NT) {
-        double w = 0;
-        for (int b = 0; b < a; b++) w += C.tiles[tix(a, b)] * C.ycam[b];
-        for (int b = a; b < nc; b++) w += C.tiles[tix(b, a)] * C.ycam[b];
-        acc[1] += C.ycam[a] * w;
-        const double gh = C.v_ghat[a];
-        acc[0] += gh * gh;
-    }
+    for (int a = tid; a < nc; a += NT) { const double gh = C.v_ghat[a]; acc[0] += gh * gh; }
     {
-        const int *lm = ip + P.o_lm, *sp = ip + P.o_lmslotptr, *so = ip + P.o_lmslot;
+        cst_i *lm = ip + P.o_lm, *sp = ip + P.o_lmslotptr, *so = ip + P.o_lmslot;
         for (int l = tid; l < L; l += NT) {
-            const double *h = C.g_hcl + lm[2 * l];
+            const gbl_d *h = C.g_hcl + lm[2 * l];
             double t = 0;
             const int s0 = sp[l], s1 = sp[l + 1];
             for (int s = s0; s < s1; s++) {
@@ -552,30 +699,51 @@ __device__ bool finalize_and_solve(Ctx<NT> &C, bool first, double mu, double &gg
             acc[0] += gh * gh;
         }
     }
+    TCV_MARK(C, PH_FIN_CAUCHY);
+    {
+        constexpr int NW = NT / 64;
+        const int lane = tid & 63, wave = tid >> 6;
+        const int r = lane >> 2, c0 = (lane & 3) << 2;
+        int t = 0;
+        for (int I = 0; I < P.nt; I++)
+            for (int J = 0; J <= I; J++, t++) {
+                if ((t % NW) != wave) continue;
+                lds_d *T = C.tiles + (t << 8);
+                const int a = 16 * I + r;
+                double tv[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) tv[i] = T[sw(r, c0 + i)];
+                if (a < nc) {
+                    const double sa = C.sc[a], ua = C.ycam[a];
+                    double sb[4], ub[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { sb[i] = C.sc[16 * J + c0 + i]; ub[i] = C.ycam[16 * J + c0 + i]; }
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int b = 16 * J + c0 + i;
+                        double v = 0.0;
+                        if (b <= a) {
+                            acc[1] += ((a == b) ? 1.0 : 2.0) * tv[i] * ua * ub[i];
+                            v = sa * sb[i] * tv[i];
+                            if (a == b) v += mu * C.dd[a];
+                        }
+                        T[sw(r, c0 + i)] = v;
+                    }
+                } else if (a == nc) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int b = 16 * J + c0 + i;
+                        T[sw(r, c0 + i)] = (b < nc) ? C.sc[b] * (C.v_g[b] - C.v_rc[b]) : ((b == nc) ? 1.0 : 0.0);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) T[sw(r, c0 + i)] = (16 * J + c0 + i == a) ? 1.0 : 0.0;
+                }
+            }
+    }
     block_sum_n<NT, 2>(acc, C.red, tid);
     gg_out = acc[0];
     q_out = acc[1];
-    __syncthreads();
-    TCV_MARK(C, PH_FIN_CAUCHY);
-    // scaled + regularised system, rhs row, identity padding
-    {
-        const int all = C.ntiles << 8;
-        for (int idx = tid; idx < all; idx += NT) {
-            const int t = idx >> 8, r = (idx >> 4) & 15, c = (idx & 15) ^ (r & 14);
-            int I = 0;
-            while (((I + 1) * (I + 2) / 2) <= t) I++;
-            const int J = t - I * (I + 1) / 2;
-            const int a = 16 * I + r, b = 16 * J + c;
-            double v;
-            if (b > a) v = 0.0;
-            else if (a < nc) {
-                v = C.sc[a] * C.sc[b] * C.tiles[idx];
-                if (a == b) v += mu * C.dd[a];
-            } else if (a == nc) v = (b < nc) ? C.sc[b] * (C.v_g[b] - C.v_rc[b]) : 1.0;
-            else v = (a == b) ? 1.0 : 0.0;
-            C.tiles[idx] = v;
-        }
-    }
     if (tid == 0) *C.flag = 0;
     __syncthreads();
     TCV_MARK(C, PH_FIN_PASS);
@@ -590,9 +758,9 @@ __device__ bool finalize_and_solve(Ctx<NT> &C, bool first, double mu, double &gg
         if (!(fabs(y) < 1e300)) bad = true;
     }
     {
-        const int *lm = ip + P.o_lm, *sp = ip + P.o_lmslotptr, *so = ip + P.o_lmslot;
+        cst_i *lm = ip + P.o_lm, *sp = ip + P.o_lmslotptr, *so = ip + P.o_lmslot;
         for (int l = tid; l < L; l += NT) {
-            const double *h = C.g_hcl + lm[2 * l];
+            const gbl_d *h = C.g_hcl + lm[2 * l];
             double t = 0;
             const int s0 = sp[l], s1 = sp[l + 1];
             for (int s = s0; s < s1; s++) {
@@ -615,19 +783,23 @@ __device__ bool finalize_and_solve(Ctx<NT> &C, bool first, double mu, double &gg
 
 // ---- ambient-space helpers ---------------------------------------------------------------------------
 template <int NT>
-__device__ void apply_plus(Ctx<NT> &C, const double *x, const double *delta_scaled, const double *s, double *xo) {
+__device__ __noinline__ void apply_plus(Ctx<NT> &C, const lds_d *x, const gbl_d *delta_scaled, const gbl_d *s, lds_d *xo) {
     // delta = step o scale; per block Plus (pose_local_parameterization.cpp:3-19) or x + delta
-    const PlanHdr &P = *C.P;
-    const int *blk = C.ip + P.o_blk;
+    cst_plan &P = *C.P;
+    cst_i *blk = C.ip + P.o_blk;
     for (int b = C.tid; b < P.nblk; b += NT) {
         const int gs = blk[b * 4], go = blk[b * 4 + 1], lo = blk[b * 4 + 2], kind = blk[b * 4 + 3];
         if (lo < 0) {
             for (int i = 0; i < gs; i++) xo[go + i] = x[go + i];
         } else if (kind == KIND_POSE) {
-            double d[6];
+            double d[6], xv[7], ov[7];
 #pragma unroll
             for (int i = 0; i < 6; i++) d[i] = delta_scaled[lo + i] * s[lo + i];
-            pose_plus(x + go, d, xo + go);
+#pragma unroll
+            for (int i = 0; i < 7; i++) xv[i] = x[go + i];
+            pose_plus(xv, d, ov);
+#pragma unroll
+            for (int i = 0; i < 7; i++) xo[go + i] = ov[i];
         } else {
             for (int i = 0; i < gs; i++) xo[go + i] = x[go + i] + delta_scaled[lo + i] * s[lo + i];
         }
@@ -636,9 +808,9 @@ __device__ void apply_plus(Ctx<NT> &C, const double *x, const double *delta_scal
 }
 
 template <int NT>
-__device__ void ambient_norms(Ctx<NT> &C, const double *x, const double *xo, double &xn2, double &dn2) {
-    const PlanHdr &P = *C.P;
-    const int *blk = C.ip + P.o_blk;
+__device__ __noinline__ void ambient_norms(Ctx<NT> &C, const lds_d *x, const lds_d *xo, double &xn2, double &dn2) {
+    cst_plan &P = *C.P;
+    cst_i *blk = C.ip + P.o_blk;
     double acc[2] = {0.0, 0.0};
     for (int b = C.tid; b < P.nblk; b += NT) {
         const int gs = blk[b * 4], go = blk[b * 4 + 1], lo = blk[b * 4 + 2];
@@ -660,7 +832,7 @@ __device__ void ambient_norms(Ctx<NT> &C, const double *x, const double *xo, dou
 }
 
 template <int NT>
-__device__ double grad_max(Ctx<NT> &C) {
+__device__ __noinline__ double grad_max(Ctx<NT> &C) {
     double m = 0;
     for (int i = C.tid; i < C.P->nc + C.P->nland; i += NT) m = fmax(m, fabs(C.v_g[i]));
     for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_down(m, o));
@@ -676,35 +848,36 @@ __device__ double grad_max(Ctx<NT> &C) {
 // ---- the kernel ---------------------------------------------------------------------------------------
 template <int NT, bool MFMA>
 __global__ void __launch_bounds__(NT) solve_kernel(SolveArgs A) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+    lds_d *lds = (lds_d *)lds_raw;
     const int tid = threadIdx.x;
     Ctx<NT> C;
     C.tid = tid;
-    double *scr = A.scratch + (size_t)blockIdx.x * A.scratch_stride;
+    gbl_d *scr = (gbl_d *)A.scratch + (size_t)blockIdx.x * A.scratch_stride;
     C.v_s = scr; C.v_g = scr + SCR_NL; C.v_D = scr + 2 * SCR_NL; C.v_ghat = scr + 3 * SCR_NL; C.v_y = scr + 4 * SCR_NL;
     C.v_p = scr + 5 * SCR_NL; C.v_rc = scr + 6 * SCR_NL; C.v_sd = scr + 7 * SCR_NL;
     C.l_hll = scr + 8 * SCR_NL; C.l_gl = C.l_hll + SCR_LM; C.l_invk = C.l_gl + SCR_LM;
     C.g_hcl = C.l_invk + SCR_LM; C.g_hp = C.g_hcl + SCR_HCL; C.g_pr = C.g_hp + SCR_HP; C.g_pdx = C.g_pr + 128;
     C.g_sqrt = C.g_pdx + 128;
-    C.prof = A.prof ? A.prof + (size_t)blockIdx.x * 32 : nullptr;
+    C.prof = A.prof ? (gbl_d *)A.prof + (size_t)blockIdx.x * 32 : nullptr;
     C.t_last = 0;
 #ifdef TCV_PROFILE
     C.t_last = clock64();
 #endif
 
     for (int win = blockIdx.x; win < A.nwin; win += gridDim.x) {
-        const WinHdr *W = A.win + win;
-        const PlanHdr &P = A.plans[W->plan];
+        cst_win *W = (cst_win *)A.win + win;
+        cst_plan &P = ((cst_plan *)A.plans)[W->plan];
         C.P = &P; C.W = W;
-        C.ip = A.ipool + A.plan_base[W->plan];
-        C.dp = A.dpool + W->dbase;
+        C.ip = (cst_i *)A.ipool + A.plan_base[W->plan];
+        C.dp = (cst_d *)A.dpool + W->dbase;
         const int nc = P.nc, L = P.nland, nxl = (P.nx + L + 1) & ~1, nl = nc + L;
         C.ntiles = P.nt * (P.nt + 1) / 2;
         const int pp_tiles = P.ntp * (P.ntp + 1) / 2;
         C.tiles = lds;
         C.stage = lds + (pp_tiles << 8);
         C.stage_cap = (C.ntiles - pp_tiles) << 8;
-        double *p = lds + (C.ntiles << 8);
+        lds_d *p = lds + (C.ntiles << 8);
         C.xs = p; p += nxl;
         C.xc = p; p += nxl;
         C.sc = p; p += 176;
@@ -712,24 +885,25 @@ __global__ void __launch_bounds__(NT) solve_kernel(SolveArgs A) {
         C.ycam = p; p += 176;
         C.invdiag = p; p += 176;
         C.red = p; p += 64;
-        C.flag = reinterpret_cast<int *>(C.red + 62);   // red[] uses at most 5 * NT/64 = 40 doubles
+        C.flag = (lds_i *)(C.red + 62);   // red[] uses at most 5 * NT/64 = 40 doubles
         C.area = p;
-        DevSummary *S = A.summary + win;
+        typedef __attribute__((address_space(1))) DevSummary gbl_sum;
+        gbl_sum *S = (gbl_sum *)A.summary + win;
 
         for (int i = tid; i < P.nx + L; i += NT) C.xs[i] = C.dp[W->d_x + i];
         // sqrt_info = LLT(cov^-1).matrixL()^T once per solve (imu_factor.h:64 recomputes it per Evaluate)
         if (W->d_sqrt >= 0) {
             for (int i = tid; i < P.n_imu * 225; i += NT) C.g_sqrt[i] = C.dp[W->d_sqrt + i];
         } else {
-            int bad = 0;
-            if (tid < P.n_imu)
-                bad = imu_sqrt_info(C.dp + W->d_imu + tid * IMU_CONST + IMU_COV, C.g_sqrt + tid * 225, lds + tid * 450);
-            (void)bad;
+            // one 16-lane group per factor, workspace in the (still unused) tile region
+            for (int f = tid >> 4; f < P.n_imu; f += NT / 16)
+                (void)imu_sqrt_info_group((const double *)(C.dp + W->d_imu + f * IMU_CONST + IMU_COV), GEN(C.g_sqrt + f * 225), GEN(lds + f * 450),
+                                          GEN(lds + f * 450 + 225), tid & 15);
         }
         // constant part of the prior: Hp = J0' J0 (packed lower), marginalization_factor.cpp:366,371-380
         if (P.prior_n > 0) {
             const int n = P.prior_n;
-            const double *J0 = C.dp + W->d_prior;
+            cst_d *J0 = C.dp + W->d_prior;
             for (int e = tid; e < n * n; e += NT) {
                 const int a = e / n, b = e - a * n;
                 if (b > a) continue;
