@@ -19,14 +19,17 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "tcv_factors.h"
 #include "tcv_host.h"
+#include "tcv_dev.h"
 
 namespace tcv {
 
-enum { MARG_MAX_M = 64, MARG_MAX_N = 80, MARG_MAX_POS = MARG_MAX_M + MARG_MAX_N, MARG_MAX_X = 320, MARG_NT = 256 };
+enum { MARG_MAX_M = 64, MARG_MAX_N = 80, MARG_MAX_POS = MARG_MAX_M + MARG_MAX_N, MARG_MAX_X = 320, MARG_NT = 512 };
 enum { MARG_OUT_J0 = 0, MARG_OUT_R0 = 6400, MARG_OUT_AS = 6480, MARG_OUT_BS = 12880, MARG_OUT_X = 12960, MARG_OUT_STRIDE = 13312 };
 enum { MARG_SCR_Z = 0, MARG_SCR_PR = MARG_MAX_M * MARG_MAX_N, MARG_SCR_SQ = MARG_SCR_PR + 256, MARG_SCR_STRIDE = MARG_SCR_SQ + 16 * 225 + 450 * 16 };
 
@@ -56,19 +59,42 @@ struct MargArgs {
 
 __device__ __forceinline__ int pidx(int a, int b) { return a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a; }
 
-// Parallel cyclic Jacobi eigen-decomposition of the symmetric matrix M (row-major, leading dimension ld,
-// padded to the even size de with a zero row/column), V = eigenvectors.  A round-robin pairing splits M
-// into (de/2)^2 independent 2x2 blocks B_kl <- J_k' B_kl J_l, so one round is: angles | barrier | every
-// block and the V columns in place | barrier.  Returns the number of sweeps used.
-__device__ int jacobi_eig(double *M, double *V, int d, int ld, double *rot, int *cnt, int tid) {
+// Parallel cyclic Jacobi eigen-decomposition of the symmetric matrix M (row-major, leading dimension ld, padded to
+// the even size de with a zero row/column), V = eigenvectors.  Round-robin pairing: every round rotates de/2 disjoint
+// index pairs.  Thread (k, part) keeps pair k's (c, s, p, q) in registers and sweeps its share of the rows (column
+// rotation of M and V), then of the columns (row rotation of M) with four independent element pairs in flight; a third
+// short phase computes the next round's angles.  Returns the number of sweeps used.
+__device__ __forceinline__ void jacobi_angle(double app, double aqq, double apq, double tiny, double &c, double &s, bool &rot) {
+    c = 1.0; s = 0.0; rot = false;
+    if (fabs(apq) > tiny && fabs(apq) > 1e-15 * sqrt(fabs(app) * fabs(aqq))) {
+        const double tau = (aqq - app) / (2.0 * apq);
+        const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+        c = 1.0 / sqrt(1.0 + t * t);
+        s = t * c;
+        rot = true;
+    }
+}
+__device__ int jacobi_eig(lds_d *M, lds_d *V, int d, int ld, lds_d *rot, lds_i *cnt, int tid, double floor_rel, gbl_d *prof = nullptr) {
+    long long t_last = clock64();
+#ifdef TCV_PROFILE
+#define JMARK(id) do { const long long t_ = clock64(); if (tid == 0 && prof) prof[id] += (double)(t_ - t_last); t_last = t_; } while (0)
+#else
+#define JMARK(id) do { } while (0)
+#endif
     const int de = d + (d & 1), half = de / 2;
-    int *rp = reinterpret_cast<int *>(rot);          // [0..half) p, [half..2half) q
-    double *rc = rot + 64, *rs = rot + 64 + 48;      // half <= 40
+    lds_i *rp = (lds_i *)rot;          // [0..half) p, [half..2half) q
+    lds_d *rc = rot + 64, *rs = rot + 64 + 48;      // half <= 40
     double md = 0;
     for (int i = 0; i < d; i++) md = fmax(md, fabs(M[i * ld + i]));
-    const double tiny = 1e-19 * md;
+    // floor_rel > 0: entries below floor_rel * |A| are treated as rounding noise (the accuracy class of Eigen's
+    // tridiagonal QR, which the reference uses); without it the near-null (gauge) directions of A' rotate forever.
+    // floor_rel = 0 keeps the purely relative criterion, which the graded, positive definite Amm needs.
+    const double tiny = floor_rel * md;
     for (int i = tid; i < de * de; i += MARG_NT) { const int r = i / de, c = i - r * de; V[r * ld + c] = (r == c) ? 1.0 : 0.0; }
     if (de > d) for (int i = tid; i < de; i += MARG_NT) { M[i * ld + d] = 0.0; M[d * ld + i] = 0.0; }
+    const int nparts = MARG_NT / half;              // threads per pair
+    const int k = tid / nparts, part = tid - k * nparts;
+    const bool active = k < half;
     __syncthreads();
     int sweep = 0;
     for (; sweep < 24; sweep++) {
@@ -79,39 +105,61 @@ __device__ int jacobi_eig(double *M, double *V, int d, int ld, double *rot, int 
                 int a = (r + tid) % (de - 1), b = (r - tid + de - 1) % (de - 1);
                 if (tid == 0) b = de - 1;
                 const int p = min(a, b), q = max(a, b);
-                double c = 1.0, s = 0.0;
-                const double apq = M[p * ld + q], app = M[p * ld + p], aqq = M[q * ld + q];
-                if (fabs(apq) > tiny && fabs(apq) > 1e-15 * sqrt(fabs(app) * fabs(aqq))) {
-                    const double tau = (aqq - app) / (2.0 * apq);
-                    const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                    c = 1.0 / sqrt(1.0 + t * t);
-                    s = t * c;
-                    atomicAdd(cnt, 1);
+                double c, s2;
+                bool rt;
+                jacobi_angle(M[p * ld + p], M[q * ld + q], M[p * ld + q], tiny, c, s2, rt);
+                if (rt) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                rp[tid] = p; rp[half + tid] = q; rc[tid] = c; rs[tid] = s2;
+            }
+            __syncthreads();
+            JMARK(0);
+            const int p = active ? rp[k] : 0, q = active ? rp[half + k] : 0;
+            const double c = active ? rc[k] : 1.0, s2 = active ? rs[k] : 0.0;
+            const bool doit = active && s2 != 0.0;
+            // columns p, q of M and V
+            if (doit) {
+                for (int i0 = part; i0 < de; i0 += 4 * nparts) {
+                    double mp[4], mq[4], vp[4], vq[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int i = i0 + u * nparts;
+                        if (i < de) { mp[u] = M[i * ld + p]; mq[u] = M[i * ld + q]; vp[u] = V[i * ld + p]; vq[u] = V[i * ld + q]; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int i = i0 + u * nparts;
+                        if (i < de) {
+                            M[i * ld + p] = c * mp[u] - s2 * mq[u]; M[i * ld + q] = s2 * mp[u] + c * mq[u];
+                            V[i * ld + p] = c * vp[u] - s2 * vq[u]; V[i * ld + q] = s2 * vp[u] + c * vq[u];
+                        }
+                    }
                 }
-                rp[tid] = p; rp[half + tid] = q; rc[tid] = c; rs[tid] = s;
             }
             __syncthreads();
-            for (int w = tid; w < half * half; w += MARG_NT) {
-                const int k = w / half, l = w - k * half;
-                const double ck = rc[k], sk = rs[k], cl = rc[l], sl = rs[l];
-                if (sk == 0.0 && sl == 0.0) continue;
-                const int pk = rp[k], qk = rp[half + k], pl = rp[l], ql = rp[half + l];
-                const double b00 = M[pk * ld + pl], b01 = M[pk * ld + ql], b10 = M[qk * ld + pl], b11 = M[qk * ld + ql];
-                const double t00 = cl * b00 - sl * b01, t01 = sl * b00 + cl * b01;
-                const double t10 = cl * b10 - sl * b11, t11 = sl * b10 + cl * b11;
-                double n00 = ck * t00 - sk * t10, n01 = ck * t01 - sk * t11, n10 = sk * t00 + ck * t10, n11 = sk * t01 + ck * t11;
-                if (k == l) { n01 = 0.0; n10 = 0.0; }
-                M[pk * ld + pl] = n00; M[pk * ld + ql] = n01; M[qk * ld + pl] = n10; M[qk * ld + ql] = n11;
-            }
-            for (int w = tid; w < d * half; w += MARG_NT) {
-                const int k = w / d, i = w - k * d;
-                const double c = rc[k], s = rs[k];
-                if (s == 0.0) continue;
-                const int p = rp[k], q = rp[half + k];
-                const double vp = V[i * ld + p], vq = V[i * ld + q];
-                V[i * ld + p] = c * vp - s * vq; V[i * ld + q] = s * vp + c * vq;
+            JMARK(1);
+            // rows p, q of M
+            if (doit) {
+                for (int j0 = part; j0 < de; j0 += 4 * nparts) {
+                    double mp[4], mq[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int j = j0 + u * nparts;
+                        if (j < de) { mp[u] = M[p * ld + j]; mq[u] = M[q * ld + j]; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int j = j0 + u * nparts;
+                        if (j < de) {
+                            double np2 = c * mp[u] - s2 * mq[u], nq2 = s2 * mp[u] + c * mq[u];
+                            if (j == q) np2 = 0.0;      // the annihilated pair, exactly
+                            if (j == p) nq2 = 0.0;
+                            M[p * ld + j] = np2; M[q * ld + j] = nq2;
+                        }
+                    }
+                }
             }
             __syncthreads();
+            JMARK(2);
         }
         if (*cnt == 0) break;
         __syncthreads();
@@ -120,52 +168,302 @@ __device__ int jacobi_eig(double *M, double *V, int d, int ld, double *rot, int 
     return sweep;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Symmetric eigen-decomposition for the n x n Schur matrix A' (n <= 80), all in LDS, built for one 512-thread
+// workgroup:  (1) Householder tridiagonalisation A = Q T Q' (LAPACK dsytd2 recurrences, the matrix kept full and
+// symmetric so rows are contiguous);  (2) every eigenvalue of T by multisection on Sturm counts, four lanes per
+// eigenvalue (absolute accuracy eps |T|, the class of the tridiagonal QR inside Eigen::SelfAdjointEigenSolver that
+// the reference calls);  (3) every eigenvector of T from the twisted factorisation of T - lambda I (Fernando /
+// Parlett), one lane per eigenvector;  (4) modified Gram-Schmidt inside clusters of close eigenvalues (the
+// near-null gauge directions);  (5) back-transformation by the reflectors, four lanes per column, no barriers.
+// Returns false (caller falls back to the Jacobi sweep) if the result fails the orthogonality / trace checks.
+// A is destroyed (reflectors end up below the sub-diagonal), Z gets the eigenvectors (columns, ascending
+// eigenvalues in lam), W is n*ld doubles of workspace, sm 512 doubles.
+__device__ __forceinline__ double fast_rcp(double q) {
+    double r = __builtin_amdgcn_rcp(q);
+    r = fma(fma(-q, r, 1.0), r, r);
+    r = fma(fma(-q, r, 1.0), r, r);
+    return r;
+}
+__device__ bool sym_eig_tridiag(lds_d *A, lds_d *Z, lds_d *W, lds_d *sm, lds_d *lam, int n, int ld, int tid, gbl_d *dbg) {
+    constexpr int NT = MARG_NT, NW = MARG_NT / 64;
+    lds_d *dv = sm, *ev = sm + 80, *tauv = sm + 160, *vbuf = sm + 240, *pbuf = sm + 320, *red = sm + 400, *e2 = sm + 416;
+    const int lane = tid & 63, wave = tid >> 6;
+    double trace = 0;
+    for (int i = 0; i < n; i++) trace += A[i * ld + i];
+    // ---- (1) tridiagonalisation
+    for (int i = 0; i + 1 < n; i++) {
+        const int m = n - i - 1;
+        const double alpha = A[(i + 1) * ld + i];
+        double xn2 = 0;
+        for (int r = 1; r < m; r++) { const double t = A[(i + 1 + r) * ld + i]; xn2 += t * t; }
+        double tau = 0.0, beta = alpha, scale = 0.0;
+        if (xn2 > 0.0) {
+            beta = -copysign(sqrt(alpha * alpha + xn2), alpha);
+            tau = (beta - alpha) / beta;
+            scale = 1.0 / (alpha - beta);
+        }
+        __syncthreads();      // every thread has read the pivot column before it is overwritten with the reflector
+        for (int r = tid; r < m; r += NT) {
+            const double v = (r == 0) ? 1.0 : A[(i + 1 + r) * ld + i] * scale;
+            vbuf[r] = v;
+            if (r > 0) A[(i + 1 + r) * ld + i] = v;
+        }
+        if (tid == 0) { dv[i] = A[i * ld + i]; ev[i] = beta; tauv[i] = tau; }
+        __syncthreads();
+        if (tau != 0.0) {
+            {   // p = tau * A22 v, four lanes per row; partial sums of p'v per wave
+                const int r = tid >> 2, part = tid & 3;
+                double sum = 0;
+                if (r < m) {
+                    const lds_d *row = A + (i + 1 + r) * ld + (i + 1);
+                    for (int c = part; c < m; c += 4) sum += row[c] * vbuf[c];
+                }
+                sum += __shfl_xor(sum, 1);
+                sum += __shfl_xor(sum, 2);
+                double pv = 0;
+                if (r < m && part == 0) { const double pr = tau * sum; pbuf[r] = pr; pv = pr * vbuf[r]; }
+                for (int o = 32; o > 0; o >>= 1) pv += __shfl_down(pv, o);
+                if (lane == 0) red[wave] = pv;
+            }
+            __syncthreads();
+            double K = 0;
+#pragma unroll
+            for (int w = 0; w < NW; w++) K += red[w];
+            K *= -0.5 * tau;
+            {   // A22 -= v w' + w v',  w = p + K v ; eight lanes per row
+                const int part = tid & 7;
+                for (int r = tid >> 3; r < m; r += NT / 8) {
+                    const double vr = vbuf[r], wr = pbuf[r] + K * vr;
+                    lds_d *row = A + (i + 1 + r) * ld + (i + 1);
+                    for (int c = part; c < m; c += 8) {
+                        const double vc = vbuf[c];
+                        row[c] -= vr * (pbuf[c] + K * vc) + wr * vc;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) { dv[n - 1] = A[(n - 1) * ld + n - 1]; ev[n - 1] = 0.0; }
+    __syncthreads();
+    for (int i = tid; i < n; i += NT) e2[i] = ev[i] * ev[i];
+    // Gershgorin interval, |T| and the pivot floor (every thread, redundantly)
+    double gl = dv[0], gu = dv[0], emax2 = 0;
+    for (int i = 0; i < n; i++) {
+        const double rad = (i > 0 ? fabs(ev[i - 1]) : 0.0) + (i + 1 < n ? fabs(ev[i]) : 0.0);
+        gl = fmin(gl, dv[i] - rad); gu = fmax(gu, dv[i] + rad);
+        if (i + 1 < n) emax2 = fmax(emax2, ev[i] * ev[i]);
+    }
+    const double tnorm = fmax(fabs(gl), fabs(gu));
+    const double pivmin = 1e-290 * fmax(1.0, emax2);
+    gl -= 2.2e-16 * tnorm * n + pivmin; gu += 2.2e-16 * tnorm * n + pivmin;
+    __syncthreads();
+    // ---- (2) eigenvalues by multisection, four lanes per eigenvalue
+    {
+        const int k = tid >> 2, sub = tid & 3;
+        double lo = gl, hi = gu;
+        for (int it = 0; it < 30; it++) {
+            const double w4 = (hi - lo) * 0.25;
+            const double x = lo + w4 * (double)(sub + 1);
+            int cnt = 0;
+            double q = dv[0] - x;
+            if (fabs(q) < pivmin) q = -pivmin;
+            cnt += (q < 0.0);
+            for (int i = 1; i < n; i++) {
+                q = fma(-e2[i - 1], fast_rcp(q), dv[i] - x);
+                if (fabs(q) < pivmin) q = -pivmin;
+                cnt += (q < 0.0);
+            }
+            const int below = (cnt > k) ? 1 : 0;       // eigenvalue k lies below x
+            const int b0 = __shfl(below, (lane & ~3) + 0), b1 = __shfl(below, (lane & ~3) + 1), b2 = __shfl(below, (lane & ~3) + 2);
+            const double x0 = lo + w4, x1 = lo + 2.0 * w4, x2 = lo + 3.0 * w4;
+            if (b0) hi = x0;
+            else if (b1) { lo = x0; hi = x1; }
+            else if (b2) { lo = x1; hi = x2; }
+            else lo = x2;
+        }
+        if (k < n && sub == 0) lam[k] = 0.5 * (lo + hi);
+    }
+    __syncthreads();
+    // ---- (3) eigenvectors of T: twisted factorisation, one lane per eigenvector (column k of Z / W as workspace)
+    // eigenvalues <= eps are zeroed by the thresholding of marginalization_factor.cpp:284-293: their vectors are never
+    // used, and inside that (possibly large, rank-deficient) null cluster they are not even defined -> zero columns
+    if (tid < n && !(lam[tid] > 1e-8)) {
+        for (int i = 0; i < n; i++) Z[i * ld + tid] = 0.0;
+    } else if (tid < n) {
+        const int k = tid;
+        const double l = lam[k];
+        double dp = dv[0] - l;
+        if (fabs(dp) < pivmin) dp = -pivmin;
+        Z[k] = dp;
+        for (int i = 0; i + 1 < n; i++) {
+            dp = fma(-e2[i], fast_rcp(dp), dv[i + 1] - l);
+            if (fabs(dp) < pivmin) dp = -pivmin;
+            Z[(i + 1) * ld + k] = dp;
+        }
+        double dm = dv[n - 1] - l;
+        if (fabs(dm) < pivmin) dm = -pivmin;
+        W[(n - 1) * ld + k] = dm;
+        double gbest = fabs(Z[(n - 1) * ld + k] + dm - (dv[n - 1] - l));
+        int rbest = n - 1;
+        for (int i = n - 2; i >= 0; i--) {
+            dm = fma(-e2[i], fast_rcp(dm), dv[i] - l);
+            if (fabs(dm) < pivmin) dm = -pivmin;
+            W[i * ld + k] = dm;
+            const double g = fabs(Z[i * ld + k] + dm - (dv[i] - l));
+            if (g < gbest) { gbest = g; rbest = i; }
+        }
+        double z = 1.0, nrm2 = 1.0;
+        for (int i = rbest - 1; i >= 0; i--) {          // z_i = -(e_i / D+_i) z_{i+1}
+            z = -ev[i] * fast_rcp(Z[i * ld + k]) * z;
+            Z[i * ld + k] = z;
+            nrm2 += z * z;
+        }
+        z = 1.0;
+        for (int i = rbest; i + 1 < n; i++) {           // z_{i+1} = -(e_i / D-_{i+1}) z_i
+            z = -ev[i] * fast_rcp(W[(i + 1) * ld + k]) * z;
+            Z[(i + 1) * ld + k] = z;
+            nrm2 += z * z;
+        }
+        Z[rbest * ld + k] = 1.0;
+        const double sc = 1.0 / sqrt(nrm2);
+        for (int i = 0; i < n; i++) Z[i * ld + k] *= sc;
+    }
+    __syncthreads();
+    // ---- (4) modified Gram-Schmidt among RETAINED eigenvectors whose eigenvalues are closer than 1e-10 |T| (the
+    // twisted vectors of such neighbours lose orthogonality like eps |T| / gap); wave 0, lanes over the entries
+    if (wave == 0) {
+        const double ctol = 1e-10 * tnorm;
+        int start = -1;
+        for (int k = 0; k < n; k++) {
+            if (!(lam[k] > 1e-8)) continue;
+            if (start < 0 || lam[k] - lam[k - 1] > ctol || !(lam[k - 1] > 1e-8)) { start = k; continue; }
+            for (int pass = 0; pass < 2; pass++)
+                for (int j = start; j < k; j++) {
+                    double dot = 0;
+                    for (int r = lane; r < n; r += 64) dot += Z[r * ld + j] * Z[r * ld + k];
+                    for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+                    for (int r = lane; r < n; r += 64) Z[r * ld + k] -= dot * Z[r * ld + j];
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                }
+            double nn = 0;
+            for (int r = lane; r < n; r += 64) { const double t = Z[r * ld + k]; nn += t * t; }
+            for (int o = 32; o > 0; o >>= 1) nn += __shfl_xor(nn, o);
+            const double sc = 1.0 / sqrt(nn);
+            for (int r = lane; r < n; r += 64) Z[r * ld + k] *= sc;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+    }
+    __syncthreads();
+    // ---- (5) back-transformation Z <- Q Z, Q = H_0 ... H_{n-2}: four lanes own a column for all reflectors
+    {
+        const int c = tid >> 2, sub = tid & 3;
+        for (int i = n - 2; i >= 0; i--) {
+            const double tau = tauv[i];
+            if (tau == 0.0) continue;
+            const int m = n - i - 1;
+            double sum = 0;
+            if (c < n)
+                for (int r = sub; r < m; r += 4) {
+                    const double v = (r == 0) ? 1.0 : A[(i + 1 + r) * ld + i];
+                    sum += v * Z[(i + 1 + r) * ld + c];
+                }
+            sum += __shfl_xor(sum, 1);
+            sum += __shfl_xor(sum, 2);
+            const double w = tau * sum;
+            if (c < n)
+                for (int r = sub; r < m; r += 4) {
+                    const double v = (r == 0) ? 1.0 : A[(i + 1 + r) * ld + i];
+                    Z[(i + 1 + r) * ld + c] -= v * w;
+                }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+    }
+    __syncthreads();
+    // ---- checks: Z'Z = I and sum lambda = trace
+    double dev = 0;
+    for (int e = tid; e < n * n; e += NT) {
+        const int a = e / n, b = e - a * n;
+        if (b > a || !(lam[a] > 1e-8) || !(lam[b] > 1e-8)) continue;
+        double g = 0;
+        for (int r = 0; r < n; r++) g += Z[r * ld + a] * Z[r * ld + b];
+        dev = fmax(dev, fabs(g - (a == b ? 1.0 : 0.0)));
+    }
+    for (int o = 32; o > 0; o >>= 1) dev = fmax(dev, __shfl_xor(dev, o));
+    __syncthreads();
+    if (lane == 0) red[wave] = dev;
+    __syncthreads();
+    dev = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) dev = fmax(dev, red[w]);
+    double sl = 0;
+    for (int i = 0; i < n; i++) sl += lam[i];
+    __syncthreads();
+    if (tid == 0 && dbg) { dbg[0] = dev; dbg[1] = sl; dbg[2] = trace; dbg[3] = tnorm; dbg[4] = lam[0]; dbg[5] = lam[n - 1]; }
+    return (dev < 1e-8) && (fabs(sl - trace) <= 1e-9 * fmax(tnorm, 1e-300) * n) && (dev == dev);
+}
+
+#ifdef TCV_PROFILE
+#define MARG_MARK(id) do { const long long t_ = clock64(); if (tid == 0) out[MARG_OUT_X + MARG_MAX_X + 2 + (id)] += (double)(t_ - t_last); t_last = t_; } while (0)
+#else
+#define MARG_MARK(id) do { } while (0)
+#endif
 __global__ void __launch_bounds__(MARG_NT) marg_kernel(MargArgs Aarg) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+    lds_d *lds = (lds_d *)lds_raw;
     const int tid = threadIdx.x;
-    double *scr = Aarg.scratch + (size_t)blockIdx.x * MARG_SCR_STRIDE;
+    gbl_d *scr = (gbl_d *)Aarg.scratch + (size_t)blockIdx.x * MARG_SCR_STRIDE;
     for (int win = blockIdx.x; win < Aarg.nwin; win += gridDim.x) {
-        const MargHdr &H = Aarg.hdr[win];
-        const int *ip = Aarg.ipool + H.ibase;
-        const double *dp = Aarg.dpool + H.dbase;
+        typedef const __attribute__((address_space(4))) MargHdr cst_mh;
+        cst_mh &H = ((cst_mh *)Aarg.hdr)[win];
+        cst_i *ip = (cst_i *)Aarg.ipool + H.ibase;
+        cst_d *dp = (cst_d *)Aarg.dpool + H.dbase;
         const int pos = H.pos, m = H.m, n = H.n;
         const int npk = pos * (pos + 1) / 2;
         // LDS carve
-        double *Apk = lds;                                   // packed lower triangle of A (later: V2)
+        lds_d *Apk = lds;                                   // packed lower triangle of A (later: V2)
         const int me = m + (m & 1), ne = n + (n & 1);
         const int r1 = max(npk, ne * (ne + 1));
-        double *R2 = lds + ((r1 + 1) & ~1);                  // Amm + V (later A')
+        lds_d *R2 = lds + ((r1 + 1) & ~1);                  // Amm + V (later A')
         const int r2 = max(2 * me * (me + 1), ne * (ne + 1));
-        double *bv = R2 + ((r2 + 1) & ~1);                   // pos
-        double *x = bv + MARG_MAX_POS;                       // nx
-        double *rot = x + MARG_MAX_X;                        // 160
-        double *lam = rot + 160;                             // MARG_MAX_N
-        double *stage = lam + MARG_MAX_N;                    // 64 proj records or 1 imu record
-        int *cnt = reinterpret_cast<int *>(rot + 158);
-        double *out = Aarg.out + (size_t)win * MARG_OUT_STRIDE;
+        lds_d *bv = R2 + ((r2 + 1) & ~1);                   // pos
+        lds_d *x = bv + MARG_MAX_POS;                       // nx
+        lds_d *rot = x + MARG_MAX_X;                        // 160
+        lds_d *lam = rot + 160;                             // MARG_MAX_N
+        lds_d *stage = lam + MARG_MAX_N;                    // 64 proj records or 1 imu record
+        lds_i *cnt = (lds_i *)(rot + 158);
+        gbl_d *out = (gbl_d *)Aarg.out + (size_t)win * MARG_OUT_STRIDE;
+        long long t_last = clock64();
+        if (tid == 0) for (int i = 0; i < 12; i++) out[MARG_OUT_X + MARG_MAX_X + 2 + i] = 0.0;
 
-        const int *blk = ip + H.o_blk;
+        cst_i *blk = ip + H.o_blk;
         for (int b = tid; b < H.nblk; b += MARG_NT) {
             const int gs = blk[b * 5], go = blk[b * 5 + 1], xs = blk[b * 5 + 4];
             for (int i = 0; i < gs; i++)
                 x[go + i] = (Aarg.use_solved_state && xs >= 0 && Aarg.solve_state)
-                                ? Aarg.solve_state[(size_t)H.solve_window * Aarg.state_stride + xs + i]
+                                ? ((const gbl_d *)Aarg.solve_state)[(size_t)H.solve_window * Aarg.state_stride + xs + i]
                                 : dp[H.d_x + go + i];
         }
         for (int i = tid; i < npk; i += MARG_NT) Apk[i] = 0.0;
         for (int i = tid; i < pos; i += MARG_NT) bv[i] = 0.0;
-        const double *misc = dp + H.d_misc;
+        cst_d *misc = dp + H.d_misc;
         const double G3[3] = {misc[0], misc[1], misc[2]};
         __syncthreads();
 
+        MARG_MARK(0);
         // ---- prior factor (MarginalizationFactor::Evaluate, :335-384)
         if (H.prior_n > 0) {
             const int np = H.prior_n;
-            const double *J0 = dp + H.d_prior, *r0 = J0 + np * np, *x0 = r0 + np;
-            double *pdx = scr + MARG_SCR_PR, *pr = pdx + 128;
+            cst_d *J0 = dp + H.d_prior, *r0 = J0 + np * np, *x0 = r0 + np;
+            gbl_d *pdx = scr + MARG_SCR_PR, *pr = pdx + 128;
             if (tid < H.prior_nblk) {
-                const int *pb = ip + H.o_prior + tid * 4;
-                prior_block_dx(x + blk[pb[0] * 5 + 1], x0 + pb[3], pb[2], pdx + pb[1]);
+                cst_i *pb = ip + H.o_prior + tid * 4;
+                const int gs = pb[2], ls = gs == 7 ? 6 : gs;
+                double x0v[16], xv[16], dxv[16];
+                for (int i = 0; i < 16; i++) { x0v[i] = (i < gs) ? x0[pb[3] + i] : 0.0; xv[i] = (i < gs) ? x[blk[pb[0] * 5 + 1] + i] : 0.0; }
+                prior_block_dx(xv, x0v, gs, dxv);
+                for (int i = 0; i < 16; i++) if (i < ls) pdx[pb[1] + i] = dxv[i];
             }
             __syncthreads();
             if (tid < np) {
@@ -174,7 +472,7 @@ __global__ void __launch_bounds__(MARG_NT) marg_kernel(MargArgs Aarg) {
                 pr[tid] = r;
             }
             __syncthreads();
-            const int *pcol = ip + H.o_pcol;
+            cst_i *pcol = ip + H.o_pcol;
             for (int e = tid; e < np * np; e += MARG_NT) {
                 const int a = e / np, b = e - a * np;
                 if (b > a) continue;
@@ -191,18 +489,22 @@ __global__ void __launch_bounds__(MARG_NT) marg_kernel(MargArgs Aarg) {
             }
             __syncthreads();
         }
+        MARG_MARK(1);
         // ---- IMU factors, one at a time (only the factor touching the marginalised frame is passed in)
         for (int f = 0; f < H.n_imu; f++) {
-            const int *b = ip + H.o_imu + f * 4;
-            double *S = stage + 1500;
-            if (tid < 16) (void)imu_sqrt_info_group(dp + H.d_imu + f * IMU_CONST + IMU_COV, S, stage + 512, stage + 512 + 225, tid);
+            cst_i *b = ip + H.o_imu + f * 4;
+            lds_d *S = stage + 1500;
+            if (tid < 16) (void)imu_sqrt_info_group((const double *)(dp + H.d_imu + f * IMU_CONST + IMU_COV), GEN(S), GEN(stage + 512), GEN(stage + 512 + 225), tid);
             if (tid == 64) {
-                imu_raw(x + blk[b[0] * 5 + 1], x + blk[b[1] * 5 + 1], x + blk[b[2] * 5 + 1], x + blk[b[3] * 5 + 1],
-                        dp + H.d_imu + f * IMU_CONST, G3, stage + 30, IMU_STRIDE_J, stage, IMU_STRIDE_J);
+                double cst[62];
+#pragma unroll
+                for (int i = 0; i < 62; i++) cst[i] = dp[H.d_imu + f * IMU_CONST + i];
+                imu_raw(CGEN(x + blk[b[0] * 5 + 1]), CGEN(x + blk[b[1] * 5 + 1]), CGEN(x + blk[b[2] * 5 + 1]), CGEN(x + blk[b[3] * 5 + 1]),
+                        cst, G3, GEN(stage + 30), IMU_STRIDE_J, GEN(stage), IMU_STRIDE_J);
             }
             __syncthreads();
             if (tid < 31) {
-                double *rec = stage + tid;
+                lds_d *rec = stage + tid;
                 double v[15];
                 for (int r = 0; r < 15; r++) v[r] = rec[r * IMU_STRIDE_J];
                 for (int r = 0; r < 15; r++) {
@@ -232,22 +534,25 @@ __global__ void __launch_bounds__(MARG_NT) marg_kernel(MargArgs Aarg) {
             (void)colw;
             __syncthreads();
         }
+        MARG_MARK(2);
         // ---- projection factors in chunks of 64: evaluate in parallel, accumulate one factor at a time
         for (int f0 = 0; f0 < H.n_proj; f0 += 64) {
             const int fn = min(64, H.n_proj - f0);
             if (tid < fn) {
-                const int *pf = ip + H.o_proj + (f0 + tid) * 4;
-                double *rec = stage + tid * PROJ_REC;
-                double r[2];
-                proj_eval(x + blk[pf[0] * 5 + 1], x + blk[pf[1] * 5 + 1], x + blk[pf[2] * 5 + 1], x[blk[pf[3] * 5 + 1]],
-                          dp + H.d_proj + (f0 + tid) * 6, misc[3], r, rec, PROJ_STRIDE);
-                (void)loss_correct2(r, rec, 19, PROJ_STRIDE, misc[4]);
+                cst_i *pf = ip + H.o_proj + (f0 + tid) * 4;
+                lds_d *rec = stage + tid * PROJ_REC;
+                double r[2], pts[6];
+#pragma unroll
+                for (int i = 0; i < 6; i++) pts[i] = dp[H.d_proj + (f0 + tid) * 6 + i];
+                proj_eval(CGEN(x + blk[pf[0] * 5 + 1]), CGEN(x + blk[pf[1] * 5 + 1]), CGEN(x + blk[pf[2] * 5 + 1]), x[blk[pf[3] * 5 + 1]],
+                          pts, misc[3], r, GEN(rec), PROJ_STRIDE);
+                (void)loss_correct2(r, GEN(rec), 19, PROJ_STRIDE, misc[4]);
                 rec[19] = r[0]; rec[PROJ_STRIDE + 19] = r[1];
             }
             __syncthreads();
             for (int f = 0; f < fn; f++) {
-                const int *pf = ip + H.o_proj + (f0 + f) * 4;
-                const double *rec = stage + f * PROJ_REC;
+                cst_i *pf = ip + H.o_proj + (f0 + f) * 4;
+                const lds_d *rec = stage + f * PROJ_REC;
                 for (int e = tid; e < 19 * 20; e += MARG_NT) {
                     const int ca = e / 20, cb = e - ca * 20;   // cb == 19: residual column
                     if (cb < 19 && cb > ca) continue;
@@ -265,16 +570,18 @@ __global__ void __launch_bounds__(MARG_NT) marg_kernel(MargArgs Aarg) {
                 __syncthreads();
             }
         }
+        MARG_MARK(3);
         // ---- Amm = V diag(lam) V'
         const int ldm = me + 1;
-        double *Mm = R2, *Vm = R2 + me * ldm;
+        lds_d *Mm = R2, *Vm = R2 + me * ldm;
         for (int i = tid; i < m * m; i += MARG_NT) { const int r = i / m, c = i - r * m; Mm[r * ldm + c] = Apk[pidx(r, c)]; }
         __syncthreads();
-        const int sweeps1 = jacobi_eig(Mm, Vm, m, ldm, rot, cnt, tid);
+        const int sweeps1 = jacobi_eig(Mm, Vm, m, ldm, rot, cnt, tid, 0.0);
+        MARG_MARK(4);
         if (tid < m) { const double l = Mm[tid * ldm + tid]; lam[tid] = l > 1e-8 ? sqrt(1.0 / l) : 0.0; }
         __syncthreads();
         // Z = diag(sqrt(lam^+)) V' Amr  (m x n) and zb = diag(sqrt(lam^+)) V' bmm, kept in global scratch
-        double *Z = scr + MARG_SCR_Z, *zb = scr + MARG_SCR_PR;
+        gbl_d *Z = scr + MARG_SCR_Z, *zb = scr + MARG_SCR_PR;
         for (int e = tid; e < m * n; e += MARG_NT) {
             const int k = e / n, j = e - k * n;
             double s = 0;
@@ -287,9 +594,10 @@ __global__ void __launch_bounds__(MARG_NT) marg_kernel(MargArgs Aarg) {
             zb[tid] = lam[tid] * s;
         }
         __syncthreads();
+        MARG_MARK(5);
         // A' = Arr - Z'Z, b' = brr - Z' zb
         const int ldn = ne + 1;
-        double *As = R2, *V2 = Apk;
+        lds_d *As = R2, *V2 = Apk;
         double keepA[ (MARG_MAX_N * MARG_MAX_N + MARG_NT - 1) / MARG_NT ];
         {
             int q = 0;
@@ -316,9 +624,23 @@ __global__ void __launch_bounds__(MARG_NT) marg_kernel(MargArgs Aarg) {
         }
         if (tid < n) { bv[tid] = bprime; out[MARG_OUT_BS + tid] = bprime; }
         __syncthreads();
-        const int sweeps2 = jacobi_eig(As, V2, n, ldn, rot, cnt, tid);
-        // ascending order like SelfAdjointEigenSolver, eps thresholding, outputs (J0 column-major n x n)
-        if (tid < n) lam[tid] = As[tid * ldn + tid];
+        MARG_MARK(6);
+        // A' = V2 diag(lam) V2': tridiagonal path first, Jacobi sweep as the safety net
+        lds_d *evals = lam;
+        int sweeps2 = 0;
+        {
+            lds_d *sm = stage, *Wk = stage + 512;
+            const bool ok = sym_eig_tridiag(As, V2, Wk, sm, rot, n, ldn, tid, out + MARG_OUT_X + MARG_MAX_X + 14);    // rot: 160 doubles >= n eigenvalues
+            if (ok) {
+                if (tid < n) lam[tid] = rot[tid];
+            } else {
+                for (int e = tid; e < n * n; e += MARG_NT) { const int i2 = e / n, j2 = e - i2 * n; As[i2 * ldn + j2] = out[MARG_OUT_AS + i2 * n + j2]; }
+                __syncthreads();
+                sweeps2 = 100 + jacobi_eig(As, V2, n, ldn, rot, cnt, tid, 2.3e-16, out + MARG_OUT_X + MARG_MAX_X + 2 + 9);
+                if (tid < n) lam[tid] = As[tid * ldn + tid];
+            }
+        }
+        MARG_MARK(7);
         __syncthreads();
         if (tid < n) {
             const double l = lam[tid];
@@ -335,7 +657,8 @@ __global__ void __launch_bounds__(MARG_NT) marg_kernel(MargArgs Aarg) {
             out[MARG_OUT_R0 + rank] = si * rb;
         }
         for (int i = tid; i < H.nx; i += MARG_NT) out[MARG_OUT_X + i] = x[i];
-        if (tid == 0) Aarg.out_status[win] = (sweeps1 >= 24 || sweeps2 >= 24) ? 1 : 0;   // 1: Jacobi hit the sweep cap
+        MARG_MARK(8);
+        if (tid == 0) ((gbl_i *)Aarg.out_status)[win] = (sweeps1 >= 24 || sweeps2 == 124) ? 1 : (sweeps2 >= 100 ? 2 : 0);   // 1: Jacobi hit the sweep cap, 2: fell back to Jacobi   // 1: Jacobi hit the sweep cap
         if (tid == 0) { out[MARG_OUT_X + MARG_MAX_X] = sweeps1; out[MARG_OUT_X + MARG_MAX_X + 1] = sweeps2; }
         __syncthreads();
     }
@@ -512,6 +835,7 @@ int tcv_marg_attach(tcv_batch *b, tcv_problem *const *marg_problems, double *con
         const size_t need = (size_t)(((r1 + 1) & ~1) + ((r2 + 1) & ~1) + MARG_MAX_POS + MARG_MAX_X + 160 + MARG_MAX_N + 64 * PROJ_REC) * 8;
         if (need > (size_t)LDS_DOUBLES * 8) { set_error("marginalisation does not fit LDS"); return TCV_ERR_TOO_LARGE; }
         lds = std::max(lds, need);
+        lds = (size_t)LDS_DOUBLES * 8;      // the eigen-solver's workspace uses everything behind the staging area
     }
     s->lds_bytes = lds;
     hipDeviceProp_t prop;
@@ -593,6 +917,12 @@ int tcv_marg_get_prior(tcv_batch *b, int window, tcv_prior **out) {
     pr->r0.assign(o.begin() + MARG_OUT_R0, o.begin() + MARG_OUT_R0 + n);
     pr->As.assign(o.begin() + MARG_OUT_AS, o.begin() + MARG_OUT_AS + (size_t)n * n);
     pr->bs.assign(o.begin() + MARG_OUT_BS, o.begin() + MARG_OUT_BS + n);
+    if (getenv("TCV_DEBUG")) {
+        fprintf(stderr, "[tcv] marg window %d: m=%d n=%d jacobi sweeps %g / %g status %d\n", window, m, n, o[MARG_OUT_X + MARG_MAX_X], o[MARG_OUT_X + MARG_MAX_X + 1], status);
+        const char *nm[12] = {"load", "prior", "imu", "proj", "eig_mm", "Z", "schur", "eig_rr", "out", "j_angle", "j_cols", "j_rows"};
+        for (int i = 0; i < 12; i++) fprintf(stderr, "[tcv]   %-7s %12.0f cycles\n", nm[i], o[MARG_OUT_X + MARG_MAX_X + 2 + i]);
+        fprintf(stderr, "[tcv]   tridiag check: dev %.3e sum(lam) %.10e trace %.10e |T| %.3e lam_min %.3e lam_max %.3e\n", o[MARG_OUT_X + MARG_MAX_X + 14], o[MARG_OUT_X + MARG_MAX_X + 15], o[MARG_OUT_X + MARG_MAX_X + 16], o[MARG_OUT_X + MARG_MAX_X + 17], o[MARG_OUT_X + MARG_MAX_X + 18], o[MARG_OUT_X + MARG_MAX_X + 19]);
+    }
     for (double v : pr->J0) if (!(v == v)) { delete pr; set_error("NaN in marginalisation result"); return TCV_ERR_NUMERIC; }
     *out = pr;
     return TCV_OK;

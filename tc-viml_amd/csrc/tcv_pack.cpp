@@ -41,7 +41,7 @@ struct DestList {
 // unit record (UNIT_INTS ints): u0 = kind << 28 | ncols << 24 | ea << 20 | nitems,  u1 = o0 << 16 | o1,  u2 = item_begin
 // (IMU units carry their <= 2 items inline instead: u2 = item0, u3 = item1).  Units are sorted by descending item
 // count; those with more than WAVE_UNIT_ITEMS items come first and are processed by a whole wavefront each.
-enum { WAVE_UNIT_ITEMS = 48 };
+enum { WAVE_UNIT_ITEMS = 128 };
 struct RowProg {
     std::vector<int> units, items;
     int n_units = 0, n_wave_units = 0;

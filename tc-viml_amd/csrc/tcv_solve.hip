@@ -21,25 +21,11 @@
 #include <hip/hip_runtime.h>
 #include "tcv_factors.h"
 #include "tcv_packed.h"
+#include "tcv_dev.h"
 
 namespace tcv {
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
-
-// Every pointer carries its address space, so that LDS accesses compile to ds_read/ds_write, read-only inputs to
-// scalar / global loads and nothing to FLAT instructions (generic pointers stored in a struct defeat the inference).
-typedef __attribute__((address_space(3))) double lds_d;        // LDS
-typedef __attribute__((address_space(3))) int lds_i;
-typedef __attribute__((address_space(1))) double gbl_d;        // per-workgroup scratch / outputs in HBM
-typedef const __attribute__((address_space(4))) double cst_d;  // read-only inputs: window data
-typedef const __attribute__((address_space(4))) int cst_i;     // read-only inputs: plan
-typedef const __attribute__((address_space(4))) PlanHdr cst_plan;
-typedef const __attribute__((address_space(4))) WinHdr cst_win;
-typedef int v4i __attribute__((ext_vector_type(4)));
-typedef const __attribute__((address_space(4))) v4i cst_v4i;
-typedef __attribute__((address_space(3))) v4i lds_v4i;
-#define GEN(p) ((double *)(p))           // explicit address-space cast to generic for the shared factor code (inlined)
-#define CGEN(p) ((const double *)(p))
 
 // ---- LDS tile addressing -------------------------------------------------------------------------
 // element (r, c) of a 16x16 tile sits at r*16 + (c ^ (r & 14)): conflict-free for the MFMA operand
@@ -119,31 +105,82 @@ __device__ __forceinline__ void block_sum_n(double (&v)[N], lds_d *red, int tid)
 }
 
 // ---- row-unit gathers (tcv_packed.h): acc[e] += sum_rows rec[row][colA + ea] * rec[row][colB + e] ------------------
+__device__ __forceinline__ void vis_item1(const lds_d *stage, unsigned it, int ea, double (&acc)[6]) {
+    const int type = it & 1, cb = (it >> 1) & 31, ca = (it >> 6) & 31, base = it >> 11;
+    const int ld = type ? LINE_STRIDE : PROJ_STRIDE;
+    const lds_d *rec = stage + base;
+    const double a0 = rec[ca + ea], a1 = rec[ld + ca + ea];
+    double b0[6], b1[6];
+#pragma unroll
+    for (int e = 0; e < 6; e++) { b0[e] = rec[cb + e]; b1[e] = rec[ld + cb + e]; }
+#pragma unroll
+    for (int e = 0; e < 6; e++) acc[e] += a0 * b0[e] + a1 * b1[e];
+}
+// Four items per trip: all item words, then all operands, are in flight before the first FMA (one wave per SIMD
+// cannot hide LDS latency by switching waves, so the loads are batched by hand).
 __device__ __forceinline__ void vis_items(const lds_d *stage, const lds_i *items, int k0, int k1, int kstep, int ea, double (&acc)[6]) {
-    for (int k = k0; k < k1; k += kstep) {
-        const unsigned it = (unsigned)items[k];
-        const int type = it & 1, cb = (it >> 1) & 31, ca = (it >> 6) & 31, base = it >> 11;
-        const int ld = type ? LINE_STRIDE : PROJ_STRIDE;
-        const lds_d *rec = stage + base;
-        const double a0 = rec[ca + ea], a1 = rec[ld + ca + ea];
-        double b0[6], b1[6];
+    int k = k0;
+    for (; k + 3 * kstep < k1; k += 4 * kstep) {
+        unsigned it[4];
 #pragma unroll
-        for (int e = 0; e < 6; e++) { b0[e] = rec[cb + e]; b1[e] = rec[ld + cb + e]; }
+        for (int j = 0; j < 4; j++) it[j] = (unsigned)items[k + j * kstep];
+        double a0[4], a1[4], b0[4][6], b1[4][6];
 #pragma unroll
-        for (int e = 0; e < 6; e++) acc[e] += a0 * b0[e] + a1 * b1[e];
+        for (int j = 0; j < 4; j++) {
+            const int type = it[j] & 1, cb = (it[j] >> 1) & 31, ca = (it[j] >> 6) & 31, base = it[j] >> 11;
+            const int ld = type ? LINE_STRIDE : PROJ_STRIDE;
+            const lds_d *rec = stage + base;
+            a0[j] = rec[ca + ea]; a1[j] = rec[ld + ca + ea];
+#pragma unroll
+            for (int e = 0; e < 6; e++) { b0[j][e] = rec[cb + e]; b1[j][e] = rec[ld + cb + e]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int e = 0; e < 6; e++) acc[e] += a0[j] * b0[j][e] + a1[j] * b1[j][e];
     }
+    for (; k < k1; k += kstep) vis_item1(stage, (unsigned)items[k], ea, acc);
 }
 
 // Schur item: hoff << 18 | nslot << 12 | slotA << 6 | slotB   (slotA = 63: the landmark's gl / kappa instead of Hcl[slotA])
 __device__ __forceinline__ void schur_items(const lds_d *hcl, const lds_i *items, int k0, int k1, int kstep, int ea, double (&acc)[6]) {
-    for (int k = k0; k < k1; k += kstep) {
+    int k = k0;
+    for (; k + 3 * kstep < k1; k += 4 * kstep) {
+        unsigned v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] = (unsigned)items[k + j * kstep];
+        double w0[4], w1[4], hb[4][6];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int sb = v[j] & 63, sa = (v[j] >> 6) & 63, ns = (v[j] >> 12) & 63, hoff = v[j] >> 18;
+            const lds_d *h = hcl + hoff;
+            w0[j] = (sa == 63) ? 1.0 : h[6 * sa + ea];
+            w1[j] = (sa == 63) ? h[6 * ns + 1] : h[6 * ns];
+#pragma unroll
+            for (int e = 0; e < 6; e++) hb[j][e] = h[6 * sb + e];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const double w = w0[j] * w1[j];
+#pragma unroll
+            for (int e = 0; e < 6; e++) acc[e] += w * hb[j][e];
+        }
+    }
+    for (; k < k1; k += kstep) {
         const unsigned v = (unsigned)items[k];
         const int sb = v & 63, sa = (v >> 6) & 63, ns = (v >> 12) & 63, hoff = v >> 18;
         const lds_d *h = hcl + hoff;
-        const double w = (sa == 63) ? h[6 * ns + 1] : h[6 * sa + ea] * h[6 * ns];
+        const double w = ((sa == 63) ? 1.0 : h[6 * sa + ea]) * ((sa == 63) ? h[6 * ns + 1] : h[6 * ns]);
 #pragma unroll
         for (int e = 0; e < 6; e++) acc[e] += w * h[6 * sb + e];
     }
+}
+
+template <int N>
+__device__ __forceinline__ void wave_sum(double (&acc)[N]) {
+#pragma unroll
+    for (int e = 0; e < N; e++)
+        for (int o = 32; o > 0; o >>= 1) acc[e] += __shfl_down(acc[e], o);
 }
 
 // global (plan, L2-resident) -> LDS copy of a gather program: 16-byte loads, four in flight per thread
@@ -162,12 +199,6 @@ __device__ __forceinline__ void copy_prog(lds_i *dst, cst_i *src, int n, int tid
     for (int i = (n4 << 2) + tid; i < n; i += NT) dst[i] = src[i];
 }
 
-template <int N>
-__device__ __forceinline__ void wave_sum(double (&acc)[N]) {
-#pragma unroll
-    for (int e = 0; e < N; e++)
-        for (int o = 32; o > 0; o >>= 1) acc[e] += __shfl_down(acc[e], o);
-}
 
 // ---- linearise at x: cost, and (if assemble) S~ = Hcc - sum_l Hcl Hcl'/kappa_l in the tiles --------
 // kappa_l = hll + mu * clamp(s_l^2 hll) / s_l^2 is the landmark pivot of the Jacobi-scaled,
