@@ -87,6 +87,75 @@ TCV_HD void imu_raw(const double *pose_i, const double *sb_i, const double *pose
     for (int i = 0; i < 3; i++) { Jraw[(9 + i) * ld + 24 + i] = 1.0; Jraw[(12 + i) * ld + 27 + i] = 1.0; }
 }
 
+// Same Jacobian / residual as imu_raw, split into four parts so that four wavefronts can work on the same factors
+// (the branch on `part` is wave-uniform).  Every part fills (and zero-fills) only its own entries of the 15 x 31 record
+// [J_raw | r_raw]:  0: residual + pose_j + speedbias_j columns,  1: pose_i columns,  2: speedbias_i columns, rows
+// p and theta,  3: speedbias_i columns, rows v, ba, bg.
+TCV_HD void imu_raw_part(int part, const double *pose_i, const double *sb_i, const double *pose_j, const double *sb_j,
+                         const double *c, const double *G3, double *rec, int ld, bool want_jac) {
+    const V3 Pi(pose_i), Vi(sb_i), Bai(sb_i + 3), Bgi(sb_i + 6);
+    const V3 Pj(pose_j), Vj(sb_j), Baj(sb_j + 3), Bgj(sb_j + 6);
+    const Quat Qi(pose_i + 3), Qj(pose_j + 3), dq0(c + IMU_DQ);
+    const V3 G(G3);
+    const double dt = c[IMU_DT];
+    const M3 dq_dbg = m3_load(c + IMU_DQ_DBG);
+    const V3 dba = Bai - V3(c + IMU_BA), dbg = Bgi - V3(c + IMU_BG);
+    const Quat cdq = dq0 * delta_q(dq_dbg * dbg);
+    const Quat Qi_inv = inverse(Qi);
+    if (part == 0) {
+        const M3 dp_dba = m3_load(c + IMU_DP_DBA), dp_dbg = m3_load(c + IMU_DP_DBG);
+        const M3 dv_dba = m3_load(c + IMU_DV_DBA), dv_dbg = m3_load(c + IMU_DV_DBG);
+        const V3 cdv = V3(c + IMU_DV) + dv_dba * dba + dv_dbg * dbg;
+        const V3 cdp = V3(c + IMU_DP) + dp_dba * dba + dp_dbg * dbg;
+        const V3 rp = rotate(Qi_inv, 0.5 * G * dt * dt + Pj - Pi - Vi * dt);
+        const V3 rv = rotate(Qi_inv, G * dt + Vj - Vi);
+        const Quat cdq_inv = inverse(cdq);
+        const Quat qe = cdq_inv * (Qi_inv * Qj);
+        double *r = rec + 30;
+        r[0] = rp.x - cdp.x; r[ld] = rp.y - cdp.y; r[2 * ld] = rp.z - cdp.z;
+        r[3 * ld] = 2 * qe.x; r[4 * ld] = 2 * qe.y; r[5 * ld] = 2 * qe.z;
+        r[6 * ld] = rv.x - cdv.x; r[7 * ld] = rv.y - cdv.y; r[8 * ld] = rv.z - cdv.z;
+        r[9 * ld] = Baj.x - Bai.x; r[10 * ld] = Baj.y - Bai.y; r[11 * ld] = Baj.z - Bai.z;
+        r[12 * ld] = Bgj.x - Bgi.x; r[13 * ld] = Bgj.y - Bgi.y; r[14 * ld] = Bgj.z - Bgi.z;
+        if (!want_jac) return;
+        for (int i = 0; i < 15; i++) for (int j = 15; j < 30; j++) rec[i * ld + j] = 0.0;
+        const M3 Ri_inv = to_matrix(Qi_inv);
+        put33(rec, ld, 0, 15, Ri_inv);                                  // pose_j  imu_factor.h:148-154
+        put33(rec, ld, 3, 18, qleft33((cdq_inv * Qi_inv) * Qj));
+        put33(rec, ld, 6, 21, Ri_inv);                                  // speedbias_j  :167-171
+        for (int i = 0; i < 3; i++) { rec[(9 + i) * ld + 24 + i] = 1.0; rec[(12 + i) * ld + 27 + i] = 1.0; }
+    } else if (part == 1) {
+        if (!want_jac) return;
+        for (int i = 0; i < 15; i++) for (int j = 0; j < 6; j++) rec[i * ld + j] = 0.0;
+        const V3 rp = rotate(Qi_inv, 0.5 * G * dt * dt + Pj - Pi - Vi * dt);
+        const V3 rv = rotate(Qi_inv, G * dt + Vj - Vi);
+        const M3 Ri_inv = to_matrix(Qi_inv);
+        put33(rec, ld, 0, 0, -Ri_inv);                                  // pose_i  :93-103
+        put33(rec, ld, 0, 3, skew(rp));
+        const Quat ql = inverse(Qj) * Qi;
+        M3 M = qleft33(ql) * qright33(cdq);
+        const V3 a = ql.vec(), b = cdq.vec();
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) M.m[3 * i + j] -= a[i] * b[j];
+        put33(rec, ld, 3, 3, -M);
+        put33(rec, ld, 6, 3, skew(rv));
+    } else if (part == 2) {
+        if (!want_jac) return;
+        for (int i = 0; i < 6; i++) for (int j = 6; j < 15; j++) rec[i * ld + j] = 0.0;
+        const M3 nRi = -to_matrix(Qi_inv);
+        put33(rec, ld, 0, 6, dt * nRi);                                 // speedbias_i  :118-136
+        put33(rec, ld, 0, 9, -m3_load(c + IMU_DP_DBA));
+        put33(rec, ld, 0, 12, -m3_load(c + IMU_DP_DBG));
+        put33(rec, ld, 3, 12, -(qleft33((inverse(Qj) * Qi) * dq0) * dq_dbg));   // :127, un-corrected delta_q
+    } else {
+        if (!want_jac) return;
+        for (int i = 6; i < 15; i++) for (int j = 6; j < 15; j++) rec[i * ld + j] = 0.0;
+        put33(rec, ld, 6, 6, -to_matrix(Qi_inv));
+        put33(rec, ld, 6, 9, -m3_load(c + IMU_DV_DBA));
+        put33(rec, ld, 6, 12, -m3_load(c + IMU_DV_DBG));
+        for (int i = 0; i < 3; i++) { rec[(9 + i) * ld + 9 + i] = -1.0; rec[(12 + i) * ld + 12 + i] = -1.0; }
+    }
+}
+
 // ---- imu_factor.h:64  sqrt_info = LLT(cov^-1).matrixL()^T ----------------------------------------
 // Partial-pivot LU inverse followed by a lower Cholesky, one IEEE operation at a time with FMA
 // contraction disabled so that the result is reproducible against the CPU oracle.

@@ -156,7 +156,7 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt) {
     if (nc < 1) { set_error("no free camera-side parameter block"); return TCV_ERR_INVALID; }
     const int nt = (nc + 1 + 15) / 16, ntp = (npp + 15) / 16;
     const int ntiles = nt * (nt + 1) / 2, pp_tiles = ntp * (ntp + 1) / 2;
-    if (nc > 175 || nc + L > SCR_NL || L > 1024) { set_error("window too large for the fused solver (camera tangent dim > 175)"); return TCV_ERR_TOO_LARGE; }
+    if (nc > 175 || npp > 88 || nc + L > SCR_NL || L > 1024) { set_error("window too large for the fused solver (camera tangent dim > 175)"); return TCV_ERR_TOO_LARGE; }
     const int nxl = (nx + L + 1) & ~1;
     const int area_cap = LDS_DOUBLES - ntiles * 256 - 2 * nxl - 4 * 176 - 64;
     const int stage_cap = (ntiles - pp_tiles) * 256;
@@ -335,35 +335,53 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt) {
     H.o_sdest = mark(); I.insert(I.end(), sprog.begin(), sprog.end()); H.n_sdest = 0;
     H.o_sunit = H.o_sdest; H.n_sunit = (int)sprog.size(); H.o_sitem = H.o_sdest; H.n_sitem = 0;
 
-    // ---- IMU chunks: row units with their <= 2 items inline (4 ints, one 16-byte load per unit)
+    // ---- IMU chunks.  Per factor: the tangent index of each of its 30 local Jacobian columns (-1 for a constant
+    // block) and a colour; factors of one colour share no parameter block, so their J'J tiles can be scattered into the
+    // reduced camera system concurrently (the frame chain needs two colours).
     {
         const int per = std::max(1, std::min(H.n_imu, area_cap / IMU_REC));
         if (H.n_imu > 0 && area_cap < IMU_REC) { set_error("no LDS room for IMU staging"); return TCV_ERR_TOO_LARGE; }
         if (H.n_imu > 16) { set_error("more than 16 IMU factors"); return TCV_ERR_TOO_LARGE; }
-        std::vector<int> iprog, ichunk;
-        while ((I.size() & 3) != 0) I.push_back(0);      // 16-byte alignment of the unit records inside the plan
+        std::vector<int> imap, icolor(H.n_imu, 0), ichunk;
         for (int fb = 0; fb < H.n_imu; fb += per) {
             const int fn = std::min(per, H.n_imu - fb);
-            DestList dl;
-            for (int k = 0; k < fn; k++) {
+            int ncol = 0;
+            for (int k = 0; k < fn; k++) {       // greedy colouring inside the chunk
                 const ImuFac &f = p.imu[fb + k];
-                auto mk = [&](int ca, int cb) { return (int)(((unsigned)k << 10) | ((unsigned)ca << 5) | (unsigned)cb); };
-                const int colc[4] = {0, 6, 15, 21}, colw[4] = {6, 9, 6, 9};
-                std::vector<Col> cols;
-                for (int s2 = 0; s2 < 4; s2++) cols.push_back(Col{loff[cam_of[f.b[s2]]], colc[s2], colw[s2]});
-                for (size_t a2 = 0; a2 < cols.size(); a2++)
-                    for (size_t b2 = 0; b2 < a2; b2++)
-                        if (cols[a2].t >= 0 && cols[a2].t == cols[b2].t) { set_error("IMU factor uses one block twice"); return TCV_ERR_UNSUPPORTED; }
-                add_pairs(dl, cols, mk, 30);
+                for (int a2 = 0; a2 < 4; a2++)
+                    for (int b2 = 0; b2 < a2; b2++)
+                        if (f.b[a2] == f.b[b2]) { set_error("IMU factor uses one block twice"); return TCV_ERR_UNSUPPORTED; }
+                int col = 0;
+                for (;; col++) {
+                    bool clash = false;
+                    for (int j = 0; j < k && !clash; j++) {
+                        if (icolor[fb + j] != col) continue;
+                        for (int a2 = 0; a2 < 4; a2++) for (int b2 = 0; b2 < 4; b2++) if (p.imu[fb + j].b[a2] == f.b[b2]) clash = true;
+                    }
+                    if (!clash) break;
+                }
+                icolor[fb + k] = col;
+                ncol = std::max(ncol, col + 1);
             }
-            RowProg ip2;
-            if (!emit_rows(dl, ip2, true)) { set_error("an IMU destination collects more than two factors"); return TCV_ERR_UNSUPPORTED; }
-            ichunk.push_back(fb); ichunk.push_back(fn); ichunk.push_back((int)iprog.size()); ichunk.push_back(ip2.n_units);
-            iprog.insert(iprog.end(), ip2.units.begin(), ip2.units.end());
+            if (ncol > 4) { set_error("IMU factors of one chunk need more than 4 colours"); return TCV_ERR_UNSUPPORTED; }
+            unsigned bits = 0;
+            for (int k = 0; k < fn; k++) bits |= (unsigned)icolor[fb + k] << (2 * k);      // 2 bits per factor
+            ichunk.push_back(fb); ichunk.push_back(fn); ichunk.push_back(ncol); ichunk.push_back((int)bits);
+        }
+        for (auto &f : p.imu) {
+            const int colc[4] = {0, 6, 15, 21}, colw[4] = {6, 9, 6, 9};
+            int m[32];
+            for (int i = 0; i < 32; i++) m[i] = -1;
+            for (int s2 = 0; s2 < 4; s2++) {
+                const int t = loff[cam_of[f.b[s2]]];
+                for (int j = 0; j < colw[s2]; j++) m[colc[s2] + j] = t < 0 ? -1 : t + j;
+            }
+            imap.insert(imap.end(), m, m + 32);
         }
         H.n_imu_chunk = (int)ichunk.size() / 4;
-        H.o_idest = mark(); I.insert(I.end(), iprog.begin(), iprog.end()); H.n_idest = 0;
-        H.o_iunit = H.o_idest; H.n_iunit = (int)iprog.size() / 4; H.o_iitem = H.o_idest; H.n_iitem = 0;
+        H.o_idest = mark(); I.insert(I.end(), imap.begin(), imap.end()); H.n_idest = (int)imap.size();
+        H.o_iunit = mark(); I.insert(I.end(), icolor.begin(), icolor.end()); H.n_iunit = (int)icolor.size();
+        H.o_iitem = H.o_iunit; H.n_iitem = 0;
         H.o_ichunk = mark(); I.insert(I.end(), ichunk.begin(), ichunk.end());
     }
     while ((I.size() & 3) != 0) I.push_back(0);          // plans are concatenated: keep every plan 16-byte aligned

@@ -77,8 +77,8 @@ struct PlanHdr {
     int n_vdest, n_vunit, n_vitem;
     int o_sdest, o_sunit, o_sitem;   // Schur plan
     int n_sdest, n_sunit, n_sitem;
-    int o_ichunk;   // n_imu_chunk x 4 : fac_begin, fac_count, first int of the chunk's units (rel. o_idest), unit_count
-    int o_idest, o_iunit, o_iitem;
+    int o_ichunk;   // n_imu_chunk x 4 : fac_begin, fac_count, number of colours, 0
+    int o_idest, o_iunit, o_iitem;   // o_idest: n_imu x 32 tangent index of each local column (-1 constant); o_iunit: n_imu colours
     int n_idest, n_iunit, n_iitem;
     int plan_ints;  // total ints of this plan (header excluded)
 };

@@ -60,7 +60,9 @@ struct Ctx {
     cst_d *dp;       // window doubles
     cst_win *W;
     // LDS
-    lds_d *tiles, *stage, *xs, *xc, *sc, *dd, *ycam, *invdiag, *red, *area;
+    lds_d *tiles, *stage, *xs, *xc, *sc, *ycam, *invdiag, *red, *area;
+    lds_d *gcam;     // camera part of the gradient J'r; shares the slot of invdiag (g is dead once the rhs row is written)
+    lds_d *rc, *sd;  // Schur corrections of the rhs and of the diagonal (pose part only, < 88 entries each)
     lds_i *flag;
     // global scratch (per workgroup)
     gbl_d *v_s, *v_g, *v_D, *v_ghat, *v_y, *v_p, *v_rc, *v_sd, *l_hll, *l_gl, *l_invk, *g_hcl, *g_hp, *g_pr, *g_pdx, *g_sqrt;
@@ -218,8 +220,8 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
 
     if (assemble) {
         for (int i = tid; i < pp_elems; i += NT) C.tiles[i] = 0.0;
-        for (int i = tid; i < nc + L; i += NT) C.v_g[i] = 0.0;
-        for (int i = tid; i < nc; i += NT) { C.v_rc[i] = 0.0; C.v_sd[i] = 0.0; }
+        for (int i = tid; i < nc; i += NT) C.gcam[i] = 0.0;
+        for (int i = tid; i < 176; i += NT) C.rc[i] = 0.0;      // rc | sd
     }
     cst_i *blk = ip + P.o_blk;
     TCV_MARK(C, PH_ZERO);
@@ -288,7 +290,7 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
                         for (int e = 0; e < 6; e++) if (e < ncols) C.tiles[tix(o0 + ea, o1 + e)] += acc[e];
                     } else if (kind == DK_G) {
 #pragma unroll
-                        for (int e = 0; e < 6; e++) if (e < ncols) C.v_g[o0 + e] += acc[e];
+                        for (int e = 0; e < 6; e++) if (e < ncols) C.gcam[o0 + e] += acc[e];
                     } else if (kind == DK_HCL) {
 #pragma unroll
                         for (int e = 0; e < 6; e++) hcl[o0 - ebase + e] += acc[e];
@@ -341,11 +343,11 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
                         for (int e = 0; e < 6; e++)
                             if (e < ncols) {
                                 C.tiles[tix(o0 + ea, o1 + e)] -= acc[e];
-                                if (o0 + ea == o1 + e) C.v_sd[o0 + ea] += acc[e];
+                                if (o0 + ea == o1 + e) C.sd[o0 + ea] += acc[e];
                             }
                     } else {
 #pragma unroll
-                        for (int e = 0; e < 6; e++) C.v_rc[o0 + e] += acc[e];
+                        for (int e = 0; e < 6; e++) C.rc[o0 + e] += acc[e];
                     }
                 }
             }
@@ -360,37 +362,45 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
     __syncthreads();
     TCV_MARK(C, PH_ZERO);
     // ---------------- IMU factors, chunk by chunk ---------------------------------------------------
+    // raw residual/Jacobian: lanes = factors, waves 0..3 = the four parts of imu_raw_part; whitening J = sqrt_info * J_raw
+    // and J'J / J'r per factor on the matrix cores (one wavefront per factor); the 30 x 31 result is scattered into the
+    // reduced camera system colour by colour (factors of one colour share no block).
     for (int ch = 0; ch < P.n_imu_chunk; ch++) {
         cst_i *ic = ip + P.o_ichunk + ch * 4;
-        const int fb = ic[0], fn = ic[1], ub = ic[2], un = ic[3];
+        const int fb = ic[0], fn = ic[1], ncolor = ic[2];
+        const unsigned colorbits = (unsigned)ic[3];
         lds_d *recs = C.area;
-        if (tid < fn) {
-            cst_i *b = ip + P.o_imu + (fb + tid) * 4;
-            lds_d *rec = recs + tid * IMU_REC;
+        const int lane = tid & 63, wave = tid >> 6;
+        constexpr int NW = NT / 64;
+        if (wave < 4 && lane < fn) {
+            cst_i *b = ip + P.o_imu + (fb + lane) * 4;
+            lds_d *rec = recs + lane * IMU_REC;
             double cst[62];
 #pragma unroll
-            for (int i = 0; i < 62; i++) cst[i] = dp[C.W->d_imu + (fb + tid) * IMU_CONST + i];
-            imu_raw(CGEN(x + blk[b[0] * 4 + 1]), CGEN(x + blk[b[1] * 4 + 1]), CGEN(x + blk[b[2] * 4 + 1]), CGEN(x + blk[b[3] * 4 + 1]),
-                    cst, G3, GEN(rec + 30), IMU_STRIDE_J, assemble ? GEN(rec) : nullptr, IMU_STRIDE_J);
+            for (int i = 0; i < 62; i++) cst[i] = dp[C.W->d_imu + (fb + lane) * IMU_CONST + i];
+            imu_raw_part(wave, CGEN(x + blk[b[0] * 4 + 1]), CGEN(x + blk[b[1] * 4 + 1]), CGEN(x + blk[b[2] * 4 + 1]),
+                         CGEN(x + blk[b[3] * 4 + 1]), cst, G3, GEN(rec), IMU_STRIDE_J, assemble);
         }
         __syncthreads();
         TCV_MARK(C, PH_IMU_RAW);
-        // whiten in place with the upper-triangular sqrt_info: column-parallel, rows ascending
-        {
-            const int ncol = assemble ? 31 : 1;
-            for (int w = tid; w < fn * ncol; w += NT) {
-                const int f = w / ncol, col = assemble ? (w - f * ncol) : 30;
-                lds_d *rec = recs + f * IMU_REC + col;
+        {   // whiten: T = S * [J_raw | r_raw]  (S upper triangular 15 x 15, zero padded to 16 x 16)
+            const int i16 = lane & 15, k4 = lane >> 4;
+            for (int f = wave; f < fn; f += NW) {
+                lds_d *rec = recs + f * IMU_REC;
                 const gbl_d *S = C.g_sqrt + (fb + f) * 225;
-                double v[15];
+                double sa[4];
 #pragma unroll
-                for (int r = 0; r < 15; r++) v[r] = rec[r * IMU_STRIDE_J];
+                for (int kk = 0; kk < 4; kk++) { const int k = 4 * kk + k4; sa[kk] = (i16 < 15 && k < 15) ? S[i16 * 15 + k] : 0.0; }
+                for (int ct = assemble ? 0 : 1; ct < 2; ct++) {
+                    const int col = 16 * ct + i16;
+                    double bb[4];
 #pragma unroll
-                for (int r = 0; r < 15; r++) {
-                    double a = 0;
+                    for (int kk = 0; kk < 4; kk++) { const int k = 4 * kk + k4; bb[kk] = (k < 15 && col < 31) ? rec[k * IMU_STRIDE_J + col] : 0.0; }
+                    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                    for (int s2 = r; s2 < 15; s2++) a += S[r * 15 + s2] * v[s2];
-                    rec[r * IMU_STRIDE_J] = a;
+                    for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[kk], bb[kk], acc, 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { const int row = k4 + 4 * i; if (row < 15 && col < 31) rec[row * IMU_STRIDE_J + col] = acc[i]; }
                 }
             }
         }
@@ -404,34 +414,67 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
             cost_acc += 0.5 * s;
         }
         if (assemble) {
-            cst_v4i *units = (cst_v4i *)(ip + P.o_idest + ub);
-            v4i q = {0, 0, 0, 0};
-            if (tid < un) q = units[tid];
-            for (int u = tid; u < un; u += NT) {
-                const v4i cur = q;
-                if (u + NT < un) q = units[u + NT];      // prefetch the next record (L2-resident plan)
-                const unsigned u0 = (unsigned)cur.x, u1 = (unsigned)cur.y;
-                const int kind = u0 >> 28, ncols = (u0 >> 24) & 15, ea = (u0 >> 20) & 15, n = u0 & 0xfffff;
-                const int o0 = u1 >> 16, o1 = u1 & 0xffff;
-                double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-                for (int k = 0; k < n; k++) {
-                    const unsigned it = (unsigned)(k ? cur.w : cur.z);
-                    const int cb = it & 31, ca = (it >> 5) & 31, f = it >> 10;
+            cst_i *imap = ip + P.o_idest;
+            const int i16 = lane & 15, k4 = lane >> 4;
+            for (int color = 0; color < ncolor; color++) {
+                int slot = 0;
+                for (int f = 0; f < fn; f++) {
+                    if ((int)((colorbits >> (2 * f)) & 3u) != color) continue;
+                    if ((slot++ % NW) != wave) continue;
                     const lds_d *rec = recs + f * IMU_REC;
-#pragma unroll 3
-                    for (int row = 0; row < 15; row++) {
-                        const double av = rec[row * IMU_STRIDE_J + ca + ea];
+                    cst_i *tm = imap + (fb + f) * 32;
+                    // tangent indices of this lane's C rows (two row tiles x four registers) and C columns, all loads up front
+                    int trow[2][4], tcol[2];
 #pragma unroll
-                        for (int e = 0; e < 9; e++) acc[e] += av * rec[row * IMU_STRIDE_J + cb + e];
+                    for (int I = 0; I < 2; I++)
+#pragma unroll
+                        for (int i = 0; i < 4; i++) trow[I][i] = tm[16 * I + k4 + 4 * i];     // entries 30, 31 are -1
+                    tcol[0] = tm[i16]; tcol[1] = tm[16 + i16];
+                    double op[2][4];      // operand values of column tiles 0 and 1 (A and B operands coincide: J' J)
+#pragma unroll
+                    for (int t = 0; t < 2; t++)
+#pragma unroll
+                        for (int kk = 0; kk < 4; kk++) {
+                            const int k = 4 * kk + k4, col = 16 * t + i16;
+                            op[t][kk] = (k < 15 && col < 31) ? rec[k * IMU_STRIDE_J + col] : 0.0;
+                        }
+                    v4f64 acc[4];
+#pragma unroll
+                    for (int tile = 0; tile < 4; tile++) {     // (I, J): (0,0) (1,0) (1,1) (0,1)
+                        const int I = (tile == 1 || tile == 2) ? 1 : 0, J = (tile >= 2) ? 1 : 0;
+                        acc[tile] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int kk = 0; kk < 4; kk++) acc[tile] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[I][kk], op[J][kk], acc[tile], 0, 0, 0);
+                    }
+                    // scatter: all destination reads in flight, then the adds, then the writes (distinct addresses per lane)
+                    int didx[16];
+                    double dval[16];
+#pragma unroll
+                    for (int tile = 0; tile < 4; tile++) {
+                        const int I = (tile == 1 || tile == 2) ? 1 : 0, J = (tile >= 2) ? 1 : 0;
+                        const int bl = 16 * J + i16;            // local column of C held by this lane
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const int al = 16 * I + k4 + 4 * i;  // local row
+                            const int ta = trow[I][i], tb = tcol[J];
+                            int d = -1;                          // >= 0: tile element, -2 - ta: gradient entry, -1: nothing
+                            if (ta >= 0) {
+                                if (bl == 30) d = -2 - ta;
+                                else if (tile != 3 && bl < 30 && al >= bl && tb >= 0) d = ta >= tb ? tix(ta, tb) : tix(tb, ta);
+                            }
+                            didx[tile * 4 + i] = d;
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 16; q++) dval[q] = didx[q] >= 0 ? C.tiles[didx[q]] : (didx[q] <= -2 ? C.gcam[-2 - didx[q]] : 0.0);
+#pragma unroll
+                    for (int q = 0; q < 16; q++) {
+                        const double v = dval[q] + acc[q >> 2][q & 3];
+                        if (didx[q] >= 0) C.tiles[didx[q]] = v;
+                        else if (didx[q] <= -2) C.gcam[-2 - didx[q]] = v;
                     }
                 }
-                if (kind == DK_TILE) {
-#pragma unroll
-                    for (int e = 0; e < 9; e++) if (e < ncols) C.tiles[tix(o0 + ea, o1 + e)] += acc[e];
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 9; e++) if (e < ncols) C.v_g[o0 + e] += acc[e];
-                }
+                __syncthreads();
             }
         }
         __syncthreads();
@@ -465,7 +508,7 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
             if (tid < n && pcol[tid] >= 0) {
                 double s = 0;
                 for (int i = 0; i < n; i++) s += J0[i + n * tid] * C.g_pr[i];
-                C.v_g[pcol[tid]] += s;
+                C.gcam[pcol[tid]] += s;
             }
             for (int e = tid; e < n * n; e += NT) {
                 const int a = e / n, b = e - a * n;
@@ -487,17 +530,14 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
 // ---- tiled Cholesky of the augmented system in LDS -----------------------------------------------
 // sqrt(d) and 1/sqrt(d) from v_rsq_f64 + Goldschmidt/Newton refinement (same scheme LLVM uses for f64 sqrt)
 __device__ __forceinline__ void sqrt_rsqrt(double d, double &l, double &inv) {
+    // v_rsq_f64 carries ~26 bits; one Goldschmidt step squares the error, one Newton step polishes sqrt(d).
     const double y = __builtin_amdgcn_rsq(d);
     double g = d * y, h = 0.5 * y;
-    double r = fma(-h, g, 0.5);
+    const double r = fma(-h, g, 0.5);
     g = fma(g, r, g); h = fma(h, r, h);
-    double e = fma(-g, g, d);
-    g = fma(e, h, g);
-    e = fma(-g, g, d);
-    g = fma(e, h, g);
-    r = fma(-h, g, 0.5);
-    h = fma(h, r, h);
-    l = g; inv = h + h;
+    const double e = fma(-g, g, d);
+    l = fma(e, h, g);
+    inv = h + h;
 }
 
 __device__ __forceinline__ double readlane_f64(double v, int srclane) {
@@ -516,18 +556,22 @@ __device__ __forceinline__ bool diag_tile_wave(lds_d *TK, int cmax, lds_d *invd,
 #pragma unroll
     for (int c = 0; c < 16; c++) t[c] = TK[sw(r, c)];
     bool ok = true;
+    double d = readlane_f64(t[0], 0);
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         if (k < cmax && ok) {
-            const double d = readlane_f64(t[k], k);
             if (!(d > 0.0) || !(d < 1e300)) ok = false;
             else {
                 double l, y;
                 sqrt_rsqrt(d, l, y);
                 const double lk = (r == k) ? l : t[k] * y;
                 t[k] = lk;
+                if (k + 1 < 16) {       // next pivot first: its rsqrt chain overlaps the rest of this column's updates
+                    t[k + 1] -= lk * readlane_f64(lk, k + 1);
+                    d = readlane_f64(t[k + 1], k + 1);
+                }
 #pragma unroll
-                for (int c = k + 1; c < 16; c++) t[c] -= lk * readlane_f64(lk, c);
+                for (int c = k + 2; c < 16; c++) t[c] -= lk * readlane_f64(lk, c);
                 if (lane == 0) invd[k] = y;
             }
         }
@@ -566,6 +610,31 @@ __device__ __forceinline__ void update_tile(lds_d *tiles, int I, int J, int K, i
         }
     }
 }
+// two independent tiles at once: their dependent MFMA chains interleave on the matrix core and all LDS operands of
+// both are in flight before the first MFMA issues
+template <bool MFMA>
+__device__ __forceinline__ void update_tile2(lds_d *tiles, int I0, int J0, int I1, int J1, int K, int lane) {
+    if (!MFMA) { update_tile<false>(tiles, I0, J0, K, lane); update_tile<false>(tiles, I1, J1, K, lane); return; }
+    const int row0 = lane >> 4, col = lane & 15;
+    lds_d *C0 = tiles + tbase(I0, J0), *C1 = tiles + tbase(I1, J1);
+    const lds_d *A0 = tiles + tbase(I0, K), *B0 = tiles + tbase(J0, K), *A1 = tiles + tbase(I1, K), *B1 = tiles + tbase(J1, K);
+    v4f64 acc0, acc1;
+    double a0[4], b0[4], a1[4], b1[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+        a0[kk] = -A0[sw(col, 4 * kk + row0)]; b0[kk] = B0[sw(col, 4 * kk + row0)];
+        a1[kk] = -A1[sw(col, 4 * kk + row0)]; b1[kk] = B1[sw(col, 4 * kk + row0)];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) { acc0[i] = C0[sw(row0 + 4 * i, col)]; acc1[i] = C1[sw(row0 + 4 * i, col)]; }
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[kk], b0[kk], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], b1[kk], acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) { C0[sw(row0 + 4 * i, col)] = acc0[i]; C1[sw(row0 + 4 * i, col)] = acc1[i]; }
+}
 
 // Right-looking tiled Cholesky with look-ahead: while the other waves run the trailing update of step K,
 // wave 0 updates tile (K+1, K+1) first and factorises it, so the serial pivot chain of the next diagonal
@@ -595,11 +664,12 @@ __device__ __noinline__ bool chol_tiles(Ctx<NT> &C, int nt, int nc) {
 #pragma unroll
                 for (int c = 0; c < 16; c++) xr[c] = T[sw(r, c)];
 #pragma unroll
-                for (int c = 0; c < 16; c++) {
-                    double a = xr[c];
+                for (int c = 0; c < 16; c++) {      // two partial sums halve the dependent FMA chain
+                    double a = xr[c], a2 = 0.0;
 #pragma unroll
-                    for (int c1 = 0; c1 < c; c1++) a -= xr[c1] * TK[sw(c, c1)];
-                    xr[c] = a * C.invdiag[16 * K + c];
+                    for (int c1 = 0; c1 + 1 < c; c1 += 2) { a -= xr[c1] * TK[sw(c, c1)]; a2 -= xr[c1 + 1] * TK[sw(c, c1 + 1)]; }
+                    if (c & 1) a -= xr[c - 1] * TK[sw(c, c - 1)];
+                    xr[c] = (a + a2) * C.invdiag[16 * K + c];
                 }
 #pragma unroll
                 for (int c = 0; c < 16; c++) T[sw(r, c)] = xr[c];
@@ -610,7 +680,7 @@ __device__ __noinline__ bool chol_tiles(Ctx<NT> &C, int nt, int nc) {
         // trailing update A_IJ -= L_IK L_JK^T; wave 0 takes (K+1, K+1) + the next diagonal factorisation, which is
         // priced at DIAG_COST tile updates when the remaining tiles are dealt to the least-loaded wave
         {
-            constexpr int DIAG_COST = 8;
+            constexpr int DIAG_COST = 12;
             const int cnext = min(16, nc - 16 * (K + 1));
             if (wave == 0) {
                 update_tile<MFMA>(tiles, K + 1, K + 1, K, lane);
@@ -619,16 +689,20 @@ __device__ __noinline__ bool chol_tiles(Ctx<NT> &C, int nt, int nc) {
                     if (!diag_tile_wave(tiles + tbase(K + 1, K + 1), cnext, C.invdiag + 16 * (K + 1), lane) && lane == 0) *C.flag = 1;
                 }
             }
-            // the other tiles: the first DIAG_COST * (NW - 1) go round-robin to waves 1.., the rest to all waves
+            // the other tiles: the first DIAG_COST * (NW - 1) go round-robin to waves 1.., the rest to all waves; every
+            // wave runs its tiles two at a time
             constexpr int HEAD = (NW > 1) ? DIAG_COST * (NW - 1) : 0;
-            int idx = 0;
+            int idx = 0, pI = -1, pJ = -1;
             for (int I = K + 1; I < nt; I++)
                 for (int J = K + 1; J <= I; J++) {
                     if (I == K + 1 && J == K + 1) continue;
                     const int owner = (idx < HEAD && cnext > 0) ? 1 + idx % (NW - 1) : (idx - ((cnext > 0) ? HEAD : 0)) % NW;
                     idx++;
-                    if (owner == wave) update_tile<MFMA>(tiles, I, J, K, lane);
+                    if (owner != wave) continue;
+                    if (pI < 0) { pI = I; pJ = J; }
+                    else { update_tile2<MFMA>(tiles, pI, pJ, I, J, K, lane); pI = -1; }
                 }
+            if (pI >= 0) update_tile<MFMA>(tiles, pI, pJ, K, lane);
         }
         __syncthreads();
         TCV_MARK(C, PH_CHOL_UPD);
@@ -637,45 +711,48 @@ __device__ __noinline__ bool chol_tiles(Ctx<NT> &C, int nt, int nc) {
     return true;
 }
 
-// ---- back substitution L^T y = z (z = the factored rhs row) ----------------------------------------
+// ---- back substitution L^T y = z (z = the factored rhs row) -----------------------------------------
+// Column sweep: thread c keeps t_c = z_c - sum_{r > tile} L[r][c] y_r in a register.  Per tile row K (descending): the
+// 16 lanes that own its columns solve the 16 x 16 triangular system among themselves (v_readlane broadcasts), publish
+// y_K, and after ONE barrier every thread folds tile row K into its own t_c.
 template <int NT>
 __device__ __noinline__ void back_subst(Ctx<NT> &C, int nc) {
-    const int tid = C.tid;
-    constexpr int NP = NT / 16;
-    lds_d *tiles = C.tiles, *y = C.ycam, *part = C.area;
-    for (int c = tid; c < nc; c += NT) y[c] = tiles[tix(nc, c)];
-    __syncthreads();
+    const int tid = C.tid, lane = tid & 63;
+    lds_d *tiles = C.tiles, *y = C.ycam;
+    const int c = tid, Kc = c >> 4, cc = c & 15;
+    double t = (c < nc) ? tiles[tix(nc, c)] : 0.0;
     for (int K = (nc - 1) >> 4; K >= 0; K--) {
         const int cmax = min(16, nc - 16 * K);
-        {
-            const int c = tid & 15, p = tid >> 4;
-            double s = 0;
-            if (c < cmax)
-                for (int r = 16 * (K + 1) + p; r < nc; r += NP) s += tiles[tix(r, 16 * K + c)] * y[r];
-            part[p * 16 + c] = s;
-        }
-        __syncthreads();
-        if (tid < 16) {
-            const int c = tid;
-            double t = (c < cmax) ? y[16 * K + c] : 0.0;
-#pragma unroll
-            for (int p = 0; p < NP; p++) t -= part[p * 16 + c];
+        if (Kc == K) {     // the 16 lanes holding columns 16K .. 16K+15 (one aligned 16-lane group of one wave)
             const lds_d *TK = tiles + tbase(K, K);
+            const int g0 = lane & ~15;
             double lrow[16];
 #pragma unroll
-            for (int cc = 0; cc < 16; cc++) lrow[cc] = (c <= cc) ? TK[sw(cc, c)] : 0.0;
+            for (int j = 0; j < 16; j++) lrow[j] = (cc <= j) ? TK[sw(j, cc)] : 0.0;      // L[j][cc]
+            const double inv = C.invdiag[c < nc ? c : 0];
 #pragma unroll
-            for (int cc = 15; cc >= 0; cc--) {
-                if (cc < cmax) {
-                    const double ycc = __shfl(t, cc, 16) * C.invdiag[16 * K + cc];
-                    if (c == cc) t = ycc;
-                    else if (c < cc) t -= lrow[cc] * ycc;
+            for (int j = 15; j >= 0; j--) {
+                if (j < cmax) {
+                    const double yj = readlane_f64(t * inv, g0 + j);     // lane j of the group: its t is final
+                    if (cc == j) t = yj;
+                    else if (cc < j) t -= lrow[j] * yj;
                 }
             }
-            if (c < cmax) y[16 * K + c] = t;
+            if (cc < cmax) y[c] = t;
         }
         __syncthreads();
+        if (Kc < K && c < nc) {
+            const lds_d *T = tiles + tbase(K, Kc);
+            double lv[16], yv[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) { lv[i] = T[sw(i, cc)]; yv[i] = y[16 * K + i]; }
+            double s0 = 0, s1 = 0;
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) { if (i < cmax) s0 += lv[i] * yv[i]; if (i + 1 < cmax) s1 += lv[i + 1] * yv[i + 1]; }
+            t -= s0 + s1;
+        }
     }
+    __syncthreads();
 }
 
 // ---- scale, regularise, factorise and solve (J'J + mu D^2) y = J'r ---------------------------------
@@ -686,16 +763,15 @@ __device__ __noinline__ bool finalize_and_solve(Ctx<NT> &C, bool first, double m
     const int tid = C.tid, nc = P.nc, L = P.nland;
     cst_i *ip = C.ip;
     for (int a = tid; a < nc; a += NT) {
-        const double dH = C.tiles[tix(a, a)] + C.v_sd[a];
+        const double dH = C.tiles[tix(a, a)] + (a < P.npp ? C.sd[a] : 0.0);
         double s;
         if (first) { s = 1.0 / (1.0 + sqrt(dH)); C.v_s[a] = s; }
         else s = C.v_s[a];
         C.sc[a] = s;
         const double d2 = fmin(fmax(s * s * dH, 1e-6), 1e32);
         const double D = sqrt(d2);
-        C.dd[a] = d2;
         C.v_D[a] = D;
-        const double gh = s * C.v_g[a] / D;
+        const double gh = s * C.gcam[a] / D;
         C.v_ghat[a] = gh;
         C.ycam[a] = s * gh / D;  // u = s * (ghat / D): Cauchy direction in unscaled tangent units
     }
@@ -756,7 +832,7 @@ __device__ __noinline__ bool finalize_and_solve(Ctx<NT> &C, bool first, double m
                         if (b <= a) {
                             acc[1] += ((a == b) ? 1.0 : 2.0) * tv[i] * ua * ub[i];
                             v = sa * sb[i] * tv[i];
-                            if (a == b) v += mu * C.dd[a];
+                            if (a == b) v += mu * fmin(fmax(sa * sa * (tv[i] + (a < P.npp ? C.sd[a] : 0.0)), 1e-6), 1e32);   // mu D_a^2
                         }
                         T[sw(r, c0 + i)] = v;
                     }
@@ -764,7 +840,7 @@ __device__ __noinline__ bool finalize_and_solve(Ctx<NT> &C, bool first, double m
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         const int b = 16 * J + c0 + i;
-                        T[sw(r, c0 + i)] = (b < nc) ? C.sc[b] * (C.v_g[b] - C.v_rc[b]) : ((b == nc) ? 1.0 : 0.0);
+                        T[sw(r, c0 + i)] = (b < nc) ? C.sc[b] * (C.gcam[b] - (b < P.npp ? C.rc[b] : 0.0)) : ((b == nc) ? 1.0 : 0.0);
                     }
                 } else {
 #pragma unroll
@@ -865,7 +941,8 @@ __device__ __noinline__ void ambient_norms(Ctx<NT> &C, const lds_d *x, const lds
 template <int NT>
 __device__ __noinline__ double grad_max(Ctx<NT> &C) {
     double m = 0;
-    for (int i = C.tid; i < C.P->nc + C.P->nland; i += NT) m = fmax(m, fabs(C.v_g[i]));
+    for (int i = C.tid; i < C.P->nc; i += NT) m = fmax(m, fabs(C.gcam[i]));
+    for (int i = C.tid; i < C.P->nland; i += NT) m = fmax(m, fabs(C.v_g[C.P->nc + i]));
     for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_down(m, o));
     __syncthreads();
     if ((C.tid & 63) == 0) C.red[C.tid >> 6] = m;
@@ -912,9 +989,9 @@ __global__ void __launch_bounds__(NT) solve_kernel(SolveArgs A) {
         C.xs = p; p += nxl;
         C.xc = p; p += nxl;
         C.sc = p; p += 176;
-        C.dd = p; p += 176;
+        C.rc = p; C.sd = p + 88; p += 176;
         C.ycam = p; p += 176;
-        C.invdiag = p; p += 176;
+        C.invdiag = p; C.gcam = p; p += 176;
         C.red = p; p += 64;
         C.flag = (lds_i *)(C.red + 62);   // red[] uses at most 5 * NT/64 = 40 doubles
         C.area = p;

@@ -9,9 +9,14 @@ NAMES = ["setup", "vis_eval", "vis_gather", "lm", "schur", "zero", "imu_raw", "i
          "fin_scale", "fin_cauchy", "fin_pass", "chol_diag", "chol_trsm", "chol_upd", "back", "lm_back", "dogleg", "plus", "norms", "other"]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 th = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-big = synth.make_windows(0, B)
-W = [tcv.Window(synth.window_at(big, k)) for k in range(B)]
-b = tcv.Batch(W)
+if "--prior" in sys.argv:       # the bench workload: windows with the n = 75 prior produced by the GPU marginalisation
+    sys.path.insert(0, ROOT)
+    import bench
+    b, wins, keep = bench.build_batches(tcv, synth, 100000, B)
+else:
+    big = synth.make_windows(0, B)
+    W = [tcv.Window(synth.window_at(big, k)) for k in range(B)]
+    b = tcv.Batch(W)
 o = tcv.default_options(8, True, True, th)
 L = tcv.lib(); L.tcv_batch_profile.argtypes = [C.c_void_p, tcv._dp]
 b.solve(o); b.synchronize()
