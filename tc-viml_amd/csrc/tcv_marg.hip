@@ -74,7 +74,7 @@ __device__ __forceinline__ void jacobi_angle(double app, double aqq, double apq,
         rot = true;
     }
 }
-__device__ int jacobi_eig(lds_d *M, lds_d *V, int d, int ld, lds_d *rot, lds_i *cnt, int tid, double floor_rel, gbl_d *prof = nullptr) {
+__device__ __noinline__ int jacobi_eig(lds_d *M, lds_d *V, int d, int ld, lds_d *rot, lds_i *cnt, int tid, double floor_rel, gbl_d *prof = nullptr) {
     long long t_last = clock64();
 #ifdef TCV_PROFILE
 #define JMARK(id) do { const long long t_ = clock64(); if (tid == 0 && prof) prof[id] += (double)(t_ - t_last); t_last = t_; } while (0)
@@ -185,65 +185,167 @@ __device__ __forceinline__ double fast_rcp(double q) {
     r = fma(fma(-q, r, 1.0), r, r);
     return r;
 }
-__device__ bool sym_eig_tridiag(lds_d *A, lds_d *Z, lds_d *W, lds_d *sm, lds_d *lam, int n, int ld, int tid, gbl_d *dbg) {
+// eigenvalue k of the symmetric tridiagonal (dv, e2 = squared off-diagonal) by 4-section on Sturm counts: four lanes per
+// eigenvalue test three interior points per trip (30 trips: 4^-30 of the Gershgorin interval).  Sturm count from the
+// scaled determinant recurrence p_i = (d_i - x) p_{i-1} - e_{i-1}^2 p_{i-2}: a sign change between consecutive p's is a
+// negative pivot; no division on the chain, rescaled every fourth step.
+__device__ __noinline__ void eig_multisection(const lds_d *dv, const lds_d *e2, lds_d *lam, int n, double gl, double gu, double pivmin, int tid) {
+    const int k = tid >> 2, sub = tid & 3, lane = tid & 63;
+    if (((tid & ~63) >> 2) >= n) return;          // whole wavefront beyond the last eigenvalue
+    double lo = gl, hi = gu;
+    for (int it = 0; it < 30; it++) {      // 4^-30: eigenvalues to ~1e-12 abs, close pairs need it for orthogonal twisted vectors
+        const double w4 = (hi - lo) * 0.25;
+        const double x = lo + w4 * (double)(sub + 1);
+        double pp = 1.0, pc = dv[0] - x;
+        if (pc == 0.0) pc = -pivmin;
+        int cnt = (pc < 0.0);
+        int i = 1;
+        for (; i + 3 < n; i += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                double pn = fma(dv[i + u] - x, pc, -e2[i + u - 1] * pp);
+                if (pn == 0.0) pn = -copysign(pivmin, pc);
+                cnt += (int)(((unsigned)(__double2hiint(pn) ^ __double2hiint(pc))) >> 31);
+                pp = pc; pc = pn;
+            }
+            const double ap = fabs(pc);
+            const double sc = (ap > 1e100) ? 1e-100 : ((ap < 1e-100) ? 1e100 : 1.0);
+            pp *= sc; pc *= sc;
+        }
+        for (; i < n; i++) {
+            double pn = fma(dv[i] - x, pc, -e2[i - 1] * pp);
+            if (pn == 0.0) pn = -copysign(pivmin, pc);
+            cnt += (int)(((unsigned)(__double2hiint(pn) ^ __double2hiint(pc))) >> 31);
+            pp = pc; pc = pn;
+        }
+        const int below = (cnt > k) ? 1 : 0;       // eigenvalue k lies below x
+        const int b0 = __shfl(below, (lane & ~3) + 0), b1 = __shfl(below, (lane & ~3) + 1), b2 = __shfl(below, (lane & ~3) + 2);
+        const double x0 = lo + w4, x1 = lo + 2.0 * w4, x2 = lo + 3.0 * w4;
+        if (b0) hi = x0;
+        else if (b1) { lo = x0; hi = x1; }
+        else if (b2) { lo = x1; hi = x2; }
+        else lo = x2;
+    }
+    if (k < n && sub == 0) lam[k] = 0.5 * (lo + hi);
+}
+
+// Z <- Q Z, Q = H_0 ... H_{n-2} (reflectors below the sub-diagonal of A): four lanes own a column and keep it in
+// registers (rows R = sub + 4 q) for all reflectors, so successive reflectors do not wait on LDS write -> read trips
+__device__ __noinline__ void eig_backtransform(const lds_d *A, lds_d *Z, const lds_d *tauv, int n, int ld, int tid) {
+    const int c = tid >> 2, sub = tid & 3;
+    if (((tid & ~63) >> 2) >= n) return;
+    const int cs = c < n ? c : 0;
+    double z[20];
+#pragma unroll
+    // all LDS loads are unconditional (clamped row) and masked afterwards: a conditional load becomes an exec-mask
+    // branch with its own wait, which serialises the loads at full LDS latency
+    for (int q = 0; q < 20; q++) { const int R = sub + 4 * q; const double t = Z[min(R, n - 1) * ld + cs]; z[q] = (R < n) ? t : 0.0; }
+    for (int i = n - 2; i >= 0; i--) {
+        const double tau = tauv[i];
+        if (tau == 0.0) continue;
+        double v[20], sum = 0;
+#pragma unroll
+        for (int q = 0; q < 20; q++) v[q] = A[min(sub + 4 * q, n - 1) * ld + i];
+#pragma unroll
+        for (int q = 0; q < 20; q++) {
+            const int R = sub + 4 * q;
+            v[q] = (R > i + 1 && R < n) ? v[q] : ((R == i + 1) ? 1.0 : 0.0);
+            sum += v[q] * z[q];
+        }
+        sum += __shfl_xor(sum, 1);
+        sum += __shfl_xor(sum, 2);
+        const double w = tau * sum;
+#pragma unroll
+        for (int q = 0; q < 20; q++) z[q] -= v[q] * w;
+    }
+    if (c < n) {
+#pragma unroll
+        for (int q = 0; q < 20; q++) { const int R = sub + 4 * q; if (R < n) Z[R * ld + c] = z[q]; }
+    }
+}
+
+__device__ __noinline__ bool sym_eig_tridiag(lds_d *A, lds_d *Z, lds_d *W, lds_d *sm, lds_d *lam, int n, int ld, int tid, gbl_d *dbg) {
     constexpr int NT = MARG_NT, NW = MARG_NT / 64;
     lds_d *dv = sm, *ev = sm + 80, *tauv = sm + 160, *vbuf = sm + 240, *pbuf = sm + 320, *red = sm + 400, *e2 = sm + 416;
     const int lane = tid & 63, wave = tid >> 6;
     double trace = 0;
     for (int i = 0; i < n; i++) trace += A[i * ld + i];
-    // ---- (1) tridiagonalisation
+    long long t_last = clock64();
+#ifdef TCV_PROFILE
+#define EMARK(id) do { const long long t_ = clock64(); if (tid == 0 && dbg) dbg[8 + (id)] += (double)(t_ - t_last); t_last = t_; } while (0)
+#else
+#define EMARK(id) do { } while (0)
+#endif
+    if (tid == 0 && dbg) for (int i = 0; i < 6; i++) dbg[8 + i] = 0.0;
+    // ---- (1) tridiagonalisation.  Step i: x = A[i+1:, i] (read as row i: the matrix is kept fully symmetric).  Every
+    // 4-lane group owns one row r of A22 and forms u_r = A22[r,:] x together with |x[1:]|^2 in the same sweep, so that
+    // beta, tau and v = (x - beta e1) / (alpha - beta) need no extra pass: A22 v = (u - beta A22[:,0]) / (alpha - beta).
     for (int i = 0; i + 1 < n; i++) {
         const int m = n - i - 1;
-        const double alpha = A[(i + 1) * ld + i];
-        double xn2 = 0;
-        for (int r = 1; r < m; r++) { const double t = A[(i + 1 + r) * ld + i]; xn2 += t * t; }
+        const int r = tid >> 2, part = tid & 3;
+        const lds_d *xrow = A + i * ld + (i + 1);
+        double u = 0, xn2 = 0;
+        {   // m <= 79: at most 20 columns per lane; loads batched five at a time, clamped and masked
+            const lds_d *row = A + (i + 1 + (r < m ? r : 0)) * ld + (i + 1);
+#pragma unroll
+            for (int j0 = 0; j0 < 20; j0 += 5) {
+                if (part + 4 * j0 >= m) break;
+                double rv[5], xv[5];
+#pragma unroll
+                for (int j = 0; j < 5; j++) { const int c = min(part + 4 * (j0 + j), m - 1); rv[j] = row[c]; xv[j] = xrow[c]; }
+#pragma unroll
+                for (int j = 0; j < 5; j++) {
+                    const int c = part + 4 * (j0 + j);
+                    if (c < m) { u += rv[j] * xv[j]; if (c > 0) xn2 += xv[j] * xv[j]; }
+                }
+            }
+        }
+        u += __shfl_xor(u, 1); u += __shfl_xor(u, 2);
+        xn2 += __shfl_xor(xn2, 1); xn2 += __shfl_xor(xn2, 2);
+        const double alpha = xrow[0];
         double tau = 0.0, beta = alpha, scale = 0.0;
         if (xn2 > 0.0) {
-            beta = -copysign(sqrt(alpha * alpha + xn2), alpha);
-            tau = (beta - alpha) / beta;
-            scale = 1.0 / (alpha - beta);
+            const double nn = alpha * alpha + xn2;
+            double y = __builtin_amdgcn_rsq(nn);                 // |x| = nn * rsqrt(nn), two Newton steps
+            y = y * fma(-0.5 * nn * y, y, 1.5);
+            y = y * fma(-0.5 * nn * y, y, 1.5);
+            beta = -copysign(nn * y, alpha);
+            tau = (beta - alpha) * fast_rcp(beta);
+            scale = fast_rcp(alpha - beta);
         }
-        __syncthreads();      // every thread has read the pivot column before it is overwritten with the reflector
-        for (int r = tid; r < m; r += NT) {
-            const double v = (r == 0) ? 1.0 : A[(i + 1 + r) * ld + i] * scale;
-            vbuf[r] = v;
-            if (r > 0) A[(i + 1 + r) * ld + i] = v;
+        double pv = 0;
+        if (r < m && part == 0) {
+            const double vr = (r == 0) ? 1.0 : xrow[r] * scale;
+            const double pr = tau * scale * (u - beta * A[(i + 1 + r) * ld + (i + 1)]);
+            vbuf[r] = vr; pbuf[r] = pr;
+            pv = pr * vr;
         }
+        for (int o = 32; o > 0; o >>= 1) pv += __shfl_down(pv, o);
+        if (lane == 0) red[wave] = pv;
         if (tid == 0) { dv[i] = A[i * ld + i]; ev[i] = beta; tauv[i] = tau; }
         __syncthreads();
         if (tau != 0.0) {
-            {   // p = tau * A22 v, four lanes per row; partial sums of p'v per wave
-                const int r = tid >> 2, part = tid & 3;
-                double sum = 0;
-                if (r < m) {
-                    const lds_d *row = A + (i + 1 + r) * ld + (i + 1);
-                    for (int c = part; c < m; c += 4) sum += row[c] * vbuf[c];
-                }
-                sum += __shfl_xor(sum, 1);
-                sum += __shfl_xor(sum, 2);
-                double pv = 0;
-                if (r < m && part == 0) { const double pr = tau * sum; pbuf[r] = pr; pv = pr * vbuf[r]; }
-                for (int o = 32; o > 0; o >>= 1) pv += __shfl_down(pv, o);
-                if (lane == 0) red[wave] = pv;
-            }
-            __syncthreads();
             double K = 0;
 #pragma unroll
             for (int w = 0; w < NW; w++) K += red[w];
             K *= -0.5 * tau;
-            {   // A22 -= v w' + w v',  w = p + K v ; eight lanes per row
-                const int part = tid & 7;
-                for (int r = tid >> 3; r < m; r += NT / 8) {
-                    const double vr = vbuf[r], wr = pbuf[r] + K * vr;
-                    lds_d *row = A + (i + 1 + r) * ld + (i + 1);
-                    for (int c = part; c < m; c += 8) {
-                        const double vc = vbuf[c];
-                        row[c] -= vr * (pbuf[c] + K * vc) + wr * vc;
-                    }
+            // A22 -= v w' + w v',  w = p + K v ; eight lanes per row.  Column i keeps the reflector for the back-transform.
+            const int part8 = tid & 7;
+            for (int rr = tid >> 3; rr < m; rr += NT / 8) {
+                const double vr = vbuf[rr], wr = pbuf[rr] + K * vr;
+                lds_d *row = A + (i + 1 + rr) * ld + (i + 1);
+                double vc[10], pc[10], av[10];      // m <= 79: at most 10 columns per lane, every load in flight at once
+#pragma unroll
+                for (int j = 0; j < 10; j++) { const int c = min(part8 + 8 * j, m - 1); vc[j] = vbuf[c]; pc[j] = pbuf[c]; av[j] = row[c]; }
+#pragma unroll
+                for (int j = 0; j < 10; j++) {
+                    const int c = part8 + 8 * j;
+                    if (c < m) row[c] = av[j] - (vr * (pc[j] + K * vc[j]) + wr * vc[j]);
                 }
+                if (part8 == 0 && rr > 0) A[(i + 1 + rr) * ld + i] = vr;
             }
-            __syncthreads();
         }
+        __syncthreads();
     }
     if (tid == 0) { dv[n - 1] = A[(n - 1) * ld + n - 1]; ev[n - 1] = 0.0; }
     __syncthreads();
@@ -259,33 +361,11 @@ __device__ bool sym_eig_tridiag(lds_d *A, lds_d *Z, lds_d *W, lds_d *sm, lds_d *
     const double pivmin = 1e-290 * fmax(1.0, emax2);
     gl -= 2.2e-16 * tnorm * n + pivmin; gu += 2.2e-16 * tnorm * n + pivmin;
     __syncthreads();
+    EMARK(0);
     // ---- (2) eigenvalues by multisection, four lanes per eigenvalue
-    {
-        const int k = tid >> 2, sub = tid & 3;
-        double lo = gl, hi = gu;
-        for (int it = 0; it < 30; it++) {
-            const double w4 = (hi - lo) * 0.25;
-            const double x = lo + w4 * (double)(sub + 1);
-            int cnt = 0;
-            double q = dv[0] - x;
-            if (fabs(q) < pivmin) q = -pivmin;
-            cnt += (q < 0.0);
-            for (int i = 1; i < n; i++) {
-                q = fma(-e2[i - 1], fast_rcp(q), dv[i] - x);
-                if (fabs(q) < pivmin) q = -pivmin;
-                cnt += (q < 0.0);
-            }
-            const int below = (cnt > k) ? 1 : 0;       // eigenvalue k lies below x
-            const int b0 = __shfl(below, (lane & ~3) + 0), b1 = __shfl(below, (lane & ~3) + 1), b2 = __shfl(below, (lane & ~3) + 2);
-            const double x0 = lo + w4, x1 = lo + 2.0 * w4, x2 = lo + 3.0 * w4;
-            if (b0) hi = x0;
-            else if (b1) { lo = x0; hi = x1; }
-            else if (b2) { lo = x1; hi = x2; }
-            else lo = x2;
-        }
-        if (k < n && sub == 0) lam[k] = 0.5 * (lo + hi);
-    }
+    eig_multisection(dv, e2, lam, n, gl, gu, pivmin, tid);
     __syncthreads();
+    EMARK(1);
     // ---- (3) eigenvectors of T: twisted factorisation, one lane per eigenvector (column k of Z / W as workspace)
     // eigenvalues <= eps are zeroed by the thresholding of marginalization_factor.cpp:284-293: their vectors are never
     // used, and inside that (possibly large, rank-deficient) null cluster they are not even defined -> zero columns
@@ -331,6 +411,7 @@ __device__ bool sym_eig_tridiag(lds_d *A, lds_d *Z, lds_d *W, lds_d *sm, lds_d *
         for (int i = 0; i < n; i++) Z[i * ld + k] *= sc;
     }
     __syncthreads();
+    EMARK(2);
     // ---- (4) modified Gram-Schmidt among RETAINED eigenvectors whose eigenvalues are closer than 1e-10 |T| (the
     // twisted vectors of such neighbours lose orthogonality like eps |T| / gap); wave 0, lanes over the entries
     if (wave == 0) {
@@ -356,39 +437,27 @@ __device__ bool sym_eig_tridiag(lds_d *A, lds_d *Z, lds_d *W, lds_d *sm, lds_d *
         }
     }
     __syncthreads();
-    // ---- (5) back-transformation Z <- Q Z, Q = H_0 ... H_{n-2}: four lanes own a column for all reflectors
-    {
-        const int c = tid >> 2, sub = tid & 3;
-        for (int i = n - 2; i >= 0; i--) {
-            const double tau = tauv[i];
-            if (tau == 0.0) continue;
-            const int m = n - i - 1;
-            double sum = 0;
-            if (c < n)
-                for (int r = sub; r < m; r += 4) {
-                    const double v = (r == 0) ? 1.0 : A[(i + 1 + r) * ld + i];
-                    sum += v * Z[(i + 1 + r) * ld + c];
-                }
-            sum += __shfl_xor(sum, 1);
-            sum += __shfl_xor(sum, 2);
-            const double w = tau * sum;
-            if (c < n)
-                for (int r = sub; r < m; r += 4) {
-                    const double v = (r == 0) ? 1.0 : A[(i + 1 + r) * ld + i];
-                    Z[(i + 1 + r) * ld + c] -= v * w;
-                }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        }
-    }
+    EMARK(3);
+    // ---- (5) back-transformation Z <- Q Z
+    eig_backtransform(A, Z, tauv, n, ld, tid);
     __syncthreads();
-    // ---- checks: Z'Z = I and sum lambda = trace
+    EMARK(4);
+    // ---- checks: sum lambda = trace, and (Z_R' Z_R) w = w for two probe vectors w over the retained columns R
+    // (a defect delta between two retained vectors shows up as 1 +- delta)
     double dev = 0;
-    for (int e = tid; e < n * n; e += NT) {
-        const int a = e / n, b = e - a * n;
-        if (b > a || !(lam[a] > 1e-8) || !(lam[b] > 1e-8)) continue;
-        double g = 0;
-        for (int r = 0; r < n; r++) g += Z[r * ld + a] * Z[r * ld + b];
-        dev = fmax(dev, fabs(g - (a == b ? 1.0 : 0.0)));
+    {
+        lds_d *u1 = vbuf, *u2 = pbuf;          // n-vectors (n <= 80)
+        if (tid < n) {
+            double a1 = 0, a2 = 0;
+            for (int k = 0; k < n; k++) if (lam[k] > 1e-8) { const double zz = Z[tid * ld + k]; a1 += zz; a2 += (k & 1) ? -zz : zz; }
+            u1[tid] = a1; u2[tid] = a2;
+        }
+        __syncthreads();
+        if (tid < n && lam[tid] > 1e-8) {
+            double t1 = 0, t2 = 0;
+            for (int r2 = 0; r2 < n; r2++) { const double zz = Z[r2 * ld + tid]; t1 += zz * u1[r2]; t2 += zz * u2[r2]; }
+            dev = fmax(fabs(t1 - 1.0), fabs(t2 - ((tid & 1) ? -1.0 : 1.0)));
+        }
     }
     for (int o = 32; o > 0; o >>= 1) dev = fmax(dev, __shfl_xor(dev, o));
     __syncthreads();
@@ -400,6 +469,7 @@ __device__ bool sym_eig_tridiag(lds_d *A, lds_d *Z, lds_d *W, lds_d *sm, lds_d *
     double sl = 0;
     for (int i = 0; i < n; i++) sl += lam[i];
     __syncthreads();
+    EMARK(5);
     if (tid == 0 && dbg) { dbg[0] = dev; dbg[1] = sl; dbg[2] = trace; dbg[3] = tnorm; dbg[4] = lam[0]; dbg[5] = lam[n - 1]; }
     return (dev < 1e-8) && (fabs(sl - trace) <= 1e-9 * fmax(tnorm, 1e-300) * n) && (dev == dev);
 }
@@ -473,19 +543,38 @@ __global__ void __launch_bounds__(MARG_NT) marg_kernel(MargArgs Aarg) {
             }
             __syncthreads();
             cst_i *pcol = ip + H.o_pcol;
+            // J0 (np x np, column-major) staged in R2 (free until Amm is formed): J0' J0 and J0' r run out of LDS
+            const bool in_lds = np * np <= r2;
+            if (in_lds) {
+                for (int e = tid; e < np * np; e += 4 * MARG_NT) {
+                    double v4[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) if (e + k * MARG_NT < np * np) v4[k] = J0[e + k * MARG_NT];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) if (e + k * MARG_NT < np * np) R2[e + k * MARG_NT] = v4[k];
+                }
+                __syncthreads();
+            }
             for (int e = tid; e < np * np; e += MARG_NT) {
                 const int a = e / np, b = e - a * np;
                 if (b > a) continue;
                 const int ia = pcol[a], ib = pcol[b];
                 if (ia < 0 || ib < 0) continue;
-                double s = 0;
-                for (int i = 0; i < np; i++) s += J0[i + np * a] * J0[i + np * b];
-                Apk[pidx(ia, ib)] += s;
+                double s0 = 0, s1 = 0;
+                if (in_lds) {
+                    const lds_d *ca = R2 + np * a, *cb = R2 + np * b;
+                    for (int i = 0; i + 1 < np; i += 2) { s0 += ca[i] * cb[i]; s1 += ca[i + 1] * cb[i + 1]; }
+                    if (np & 1) s0 += ca[np - 1] * cb[np - 1];
+                } else {
+                    for (int i = 0; i < np; i++) s0 += J0[i + np * a] * J0[i + np * b];
+                }
+                Apk[pidx(ia, ib)] += s0 + s1;
             }
             if (tid < np && pcol[tid] >= 0) {
-                double s = 0;
-                for (int i = 0; i < np; i++) s += J0[i + np * tid] * pr[i];
-                bv[pcol[tid]] += s;
+                double s2 = 0;
+                if (in_lds) for (int i = 0; i < np; i++) s2 += R2[i + np * tid] * pr[i];
+                else for (int i = 0; i < np; i++) s2 += J0[i + np * tid] * pr[i];
+                bv[pcol[tid]] += s2;
             }
             __syncthreads();
         }
@@ -921,6 +1010,8 @@ int tcv_marg_get_prior(tcv_batch *b, int window, tcv_prior **out) {
         fprintf(stderr, "[tcv] marg window %d: m=%d n=%d jacobi sweeps %g / %g status %d\n", window, m, n, o[MARG_OUT_X + MARG_MAX_X], o[MARG_OUT_X + MARG_MAX_X + 1], status);
         const char *nm[12] = {"load", "prior", "imu", "proj", "eig_mm", "Z", "schur", "eig_rr", "out", "j_angle", "j_cols", "j_rows"};
         for (int i = 0; i < 12; i++) fprintf(stderr, "[tcv]   %-7s %12.0f cycles\n", nm[i], o[MARG_OUT_X + MARG_MAX_X + 2 + i]);
+        const char *en[6] = {"tridiag", "bisect", "vectors", "mgs", "backtr", "check"};
+        for (int i = 0; i < 6; i++) fprintf(stderr, "[tcv]     eig_rr.%-8s %10.0f cycles\n", en[i], o[MARG_OUT_X + MARG_MAX_X + 14 + 8 + i]);
         fprintf(stderr, "[tcv]   tridiag check: dev %.3e sum(lam) %.10e trace %.10e |T| %.3e lam_min %.3e lam_max %.3e\n", o[MARG_OUT_X + MARG_MAX_X + 14], o[MARG_OUT_X + MARG_MAX_X + 15], o[MARG_OUT_X + MARG_MAX_X + 16], o[MARG_OUT_X + MARG_MAX_X + 17], o[MARG_OUT_X + MARG_MAX_X + 18], o[MARG_OUT_X + MARG_MAX_X + 19]);
     }
     for (double v : pr->J0) if (!(v == v)) { delete pr; set_error("NaN in marginalisation result"); return TCV_ERR_NUMERIC; }

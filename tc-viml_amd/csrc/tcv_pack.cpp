@@ -429,6 +429,7 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt) {
     W.d_linec = (int)D.size();
     if (!p.line.empty()) { const LineFac &g = p.line[0]; D.insert(D.end(), g.K, g.K + 9); D.insert(D.end(), g.R, g.R + 9); D.insert(D.end(), g.T, g.T + 3); }
     else D.insert(D.end(), 21, 0.0);
+    if (D.size() & 1) D.push_back(0.0);        // J0 is copied with 16-byte loads
     W.d_prior = (int)D.size();
     if (pr) { D.insert(D.end(), pr->J0.begin(), pr->J0.end()); D.insert(D.end(), pr->r0.begin(), pr->r0.end()); D.insert(D.end(), pr->x0.begin(), pr->x0.end()); }
     W.d_misc = (int)D.size();

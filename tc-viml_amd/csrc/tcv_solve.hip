@@ -178,6 +178,25 @@ __device__ __forceinline__ void schur_items(const lds_d *hcl, const lds_i *items
     }
 }
 
+// window data (read-only, HBM/L2) -> LDS, four independent 8-byte loads per thread in flight
+template <int NT>
+__device__ __forceinline__ void copy_doubles(lds_d *dst, cst_d *src, int n, int tid) {
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    typedef const __attribute__((address_space(4))) v2d cst_v2d;
+    typedef __attribute__((address_space(3))) v2d lds_v2d;
+    const int n2 = n >> 1;                      // src and dst are 16-byte aligned (even double offsets, tcv_pack.cpp)
+    cst_v2d *s2 = (cst_v2d *)src;
+    lds_v2d *d2 = (lds_v2d *)dst;
+    for (int i = tid; i < n2; i += 4 * NT) {
+        v2d v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (i + k * NT < n2) v[k] = s2[i + k * NT];
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (i + k * NT < n2) d2[i + k * NT] = v[k];
+    }
+    if ((n & 1) && tid == 0) dst[n - 1] = src[n - 1];
+}
+
 template <int N>
 __device__ __forceinline__ void wave_sum(double (&acc)[N]) {
 #pragma unroll
@@ -355,6 +374,76 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
         __syncthreads();
         TCV_MARK(C, PH_SCHUR);
     }
+    // ---------------- marginalisation prior, part A (marginalization_factor.cpp:335-384): r = r0 + J0 dx, J0' r ------
+    // The staging area is free between the Schur phase and the IMU chunks: J0 (n x n, column-major) is staged there
+    // once per linearisation so that both products run out of LDS.
+    if (P.prior_n > 0) {
+        const int n = P.prior_n;
+        cst_d *J0g = dp + C.W->d_prior, *r0 = J0g + n * n, *x0 = r0 + n;
+        const bool in_lds = n * n + 2 * n <= C.stage_cap;
+        lds_d *J0 = C.stage, *pdx = C.stage + n * n, *pr = pdx + n;
+        if (tid < P.prior_nblk) {      // dx of one kept block (marginalization_factor.cpp:348-364); fixed-size, fully unrolled
+            cst_i *pb = ip + P.o_prior + tid * 4;
+            const int gs = pb[2], xo = blk[pb[0] * 4 + 1], x0o = pb[3], ls = gs == 7 ? 6 : gs;
+            double d15[15];
+#pragma unroll
+            for (int i = 0; i < 15; i++) d15[i] = (i < gs) ? x[xo + (i < gs ? i : 0)] - x0[x0o + (i < gs ? i : 0)] : 0.0;
+            if (gs == 7) {
+                const Quat q0(x0[x0o + 3], x0[x0o + 4], x0[x0o + 5], x0[x0o + 6]), q(x[xo + 3], x[xo + 4], x[xo + 5], x[xo + 6]);
+                const Quat dq = inverse(q0) * q;
+                const double sg = (dq.w >= 0) ? 2.0 : -2.0;
+                d15[3] = sg * dq.x; d15[4] = sg * dq.y; d15[5] = sg * dq.z;
+            }
+#pragma unroll
+            for (int i = 0; i < 15; i++) if (i < ls) { if (in_lds) pdx[pb[1] + i] = d15[i]; else C.g_pdx[pb[1] + i] = d15[i]; }
+        }
+        if (in_lds) {
+            copy_doubles<NT>(J0, J0g, n * n, tid);
+            __syncthreads();
+            if (tid < n) {      // row tid of J0: stride-n walk, conflict-free across the threads of a wave
+                double r = r0[tid], r2 = 0.0;
+                for (int j = 0; j + 1 < n; j += 2) { r += J0[tid + n * j] * pdx[j]; r2 += J0[tid + n * (j + 1)] * pdx[j + 1]; }
+                if (n & 1) r += J0[tid + n * (n - 1)] * pdx[n - 1];
+                r += r2;
+                pr[tid] = r;
+                cost_acc += 0.5 * r * r;
+            }
+            __syncthreads();
+            if (assemble) {
+                cst_i *pcol = ip + P.o_pcol;
+                if (tid < n) {
+                    const int t = pcol[tid];
+                    if (t >= 0) {
+                        const lds_d *col = J0 + n * tid;
+                        double s0 = 0, s1 = 0;
+                        for (int i = 0; i + 1 < n; i += 2) { s0 += col[i] * pr[i]; s1 += col[i + 1] * pr[i + 1]; }
+                        if (n & 1) s0 += col[n - 1] * pr[n - 1];
+                        C.gcam[t] += s0 + s1;
+                    }
+                }
+            }
+            __syncthreads();
+        } else {
+            __syncthreads();
+            if (tid < n) {
+                double r = r0[tid];
+                for (int j = 0; j < n; j++) r += J0g[tid + n * j] * C.g_pdx[j];
+                C.g_pr[tid] = r;
+                cost_acc += 0.5 * r * r;
+            }
+            __syncthreads();
+            if (assemble) {
+                cst_i *pcol = ip + P.o_pcol;
+                if (tid < n && pcol[tid] >= 0) {
+                    double s2 = 0;
+                    for (int i = 0; i < n; i++) s2 += J0g[i + n * tid] * C.g_pr[i];
+                    C.gcam[pcol[tid]] += s2;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    TCV_MARK(C, PH_PRIOR);
     if (assemble) {
         const int all_elems = C.ntiles << 8;
         for (int i = pp_elems + tid; i < all_elems; i += NT) C.tiles[i] = 0.0;
@@ -390,12 +479,12 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
                 const gbl_d *S = C.g_sqrt + (fb + f) * 225;
                 double sa[4];
 #pragma unroll
-                for (int kk = 0; kk < 4; kk++) { const int k = 4 * kk + k4; sa[kk] = (i16 < 15 && k < 15) ? S[i16 * 15 + k] : 0.0; }
+                for (int kk = 0; kk < 4; kk++) { const int k = 4 * kk + k4; const double t = S[min(i16, 14) * 15 + min(k, 14)]; sa[kk] = (i16 < 15 && k < 15) ? t : 0.0; }
                 for (int ct = assemble ? 0 : 1; ct < 2; ct++) {
                     const int col = 16 * ct + i16;
                     double bb[4];
 #pragma unroll
-                    for (int kk = 0; kk < 4; kk++) { const int k = 4 * kk + k4; bb[kk] = (k < 15 && col < 31) ? rec[k * IMU_STRIDE_J + col] : 0.0; }
+                    for (int kk = 0; kk < 4; kk++) { const int k = 4 * kk + k4; const double t = rec[min(k, 14) * IMU_STRIDE_J + min(col, 30)]; bb[kk] = (k < 15 && col < 31) ? t : 0.0; }
                     v4f64 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                     for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[kk], bb[kk], acc, 0, 0, 0);
@@ -436,7 +525,8 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
 #pragma unroll
                         for (int kk = 0; kk < 4; kk++) {
                             const int k = 4 * kk + k4, col = 16 * t + i16;
-                            op[t][kk] = (k < 15 && col < 31) ? rec[k * IMU_STRIDE_J + col] : 0.0;
+                            const double tv = rec[min(k, 14) * IMU_STRIDE_J + min(col, 30)];      // unconditional load, masked after
+                            op[t][kk] = (k < 15 && col < 31) ? tv : 0.0;
                         }
                     v4f64 acc[4];
 #pragma unroll
@@ -466,7 +556,10 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
                         }
                     }
 #pragma unroll
-                    for (int q = 0; q < 16; q++) dval[q] = didx[q] >= 0 ? C.tiles[didx[q]] : (didx[q] <= -2 ? C.gcam[-2 - didx[q]] : 0.0);
+                    for (int q = 0; q < 16; q++) {      // both candidate loads unconditional, selected afterwards
+                        const double tv = C.tiles[max(didx[q], 0)], gv = C.gcam[max(-2 - didx[q], 0)];
+                        dval[q] = didx[q] >= 0 ? tv : gv;
+                    }
 #pragma unroll
                     for (int q = 0; q < 16; q++) {
                         const double v = dval[q] + acc[q >> 2][q & 3];
@@ -480,44 +573,32 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
         __syncthreads();
         TCV_MARK(C, PH_IMU_GATHER);
     }
-    // ---------------- marginalisation prior (marginalization_factor.cpp:335-384) ---------------------
-    if (P.prior_n > 0) {
-        const int n = P.prior_n;
-        cst_d *J0 = dp + C.W->d_prior, *r0 = J0 + n * n, *x0 = r0 + n;
-        if (tid < P.prior_nblk) {
-            cst_i *pb = ip + P.o_prior + tid * 4;
-            double x0v[16], dxv[16];
-            const int gs = pb[2];
-            for (int i = 0; i < 16; i++) x0v[i] = (i < gs) ? x0[pb[3] + i] : 0.0;
-            double xv[16];
-            for (int i = 0; i < 16; i++) xv[i] = (i < gs) ? x[blk[pb[0] * 4 + 1] + i] : 0.0;
-            prior_block_dx(xv, x0v, gs, dxv);
-            const int ls = gs == 7 ? 6 : gs;
-            for (int i = 0; i < 16; i++) if (i < ls) C.g_pdx[pb[1] + i] = dxv[i];
-        }
-        __syncthreads();
-        if (tid < n) {
-            double r = r0[tid];
-            for (int j = 0; j < n; j++) r += J0[tid + n * j] * C.g_pdx[j];
-            C.g_pr[tid] = r;
-            cost_acc += 0.5 * r * r;
-        }
-        if (assemble) {
-            __syncthreads();
-            cst_i *pcol = ip + P.o_pcol;
-            if (tid < n && pcol[tid] >= 0) {
-                double s = 0;
-                for (int i = 0; i < n; i++) s += J0[i + n * tid] * C.g_pr[i];
-                C.gcam[pcol[tid]] += s;
+    // ---------------- marginalisation prior, part B: the constant J0' J0 (cached per solve) joins the tiles --------------
+    if (P.prior_n > 0 && assemble) {
+        const int n = P.prior_n, npk = n * (n + 1) / 2;
+        cst_i *pcol = ip + P.o_pcol;
+        for (int e0 = tid; e0 < npk; e0 += 4 * NT) {
+            double hv[4];
+            int di[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int e = e0 + k * NT;
+                di[k] = -1;
+                if (e < npk) {
+                    hv[k] = C.g_hp[e];
+                    int a2 = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);      // e = a (a + 1) / 2 + b, b <= a
+                    while ((a2 + 1) * (a2 + 2) / 2 <= e) a2++;
+                    while (a2 * (a2 + 1) / 2 > e) a2--;
+                    const int b2 = e - a2 * (a2 + 1) / 2;
+                    const int ta = pcol[a2], tb = pcol[b2];
+                    if (ta >= 0 && tb >= 0) di[k] = ta >= tb ? tix(ta, tb) : tix(tb, ta);
+                }
             }
-            for (int e = tid; e < n * n; e += NT) {
-                const int a = e / n, b = e - a * n;
-                if (b > a) continue;
-                const int ta = pcol[a], tb = pcol[b];
-                if (ta < 0 || tb < 0) continue;
-                const double h = C.g_hp[a * (a + 1) / 2 + b];
-                C.tiles[ta >= tb ? tix(ta, tb) : tix(tb, ta)] += h;
-            }
+            double tv[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) tv[k] = C.tiles[max(di[k], 0)];
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (di[k] >= 0) C.tiles[di[k]] = tv[k] + hv[k];
         }
     }
     TCV_MARK(C, PH_PRIOR);
@@ -720,7 +801,8 @@ __device__ __noinline__ void back_subst(Ctx<NT> &C, int nc) {
     const int tid = C.tid, lane = tid & 63;
     lds_d *tiles = C.tiles, *y = C.ycam;
     const int c = tid, Kc = c >> 4, cc = c & 15;
-    double t = (c < nc) ? tiles[tix(nc, c)] : 0.0;
+    double t = tiles[tix(nc, min(c, nc - 1))];
+    if (c >= nc) t = 0.0;
     for (int K = (nc - 1) >> 4; K >= 0; K--) {
         const int cmax = min(16, nc - 16 * K);
         if (Kc == K) {     // the 16 lanes holding columns 16K .. 16K+15 (one aligned 16-lane group of one wave)
@@ -728,7 +810,7 @@ __device__ __noinline__ void back_subst(Ctx<NT> &C, int nc) {
             const int g0 = lane & ~15;
             double lrow[16];
 #pragma unroll
-            for (int j = 0; j < 16; j++) lrow[j] = (cc <= j) ? TK[sw(j, cc)] : 0.0;      // L[j][cc]
+            for (int j = 0; j < 16; j++) { const double tv = TK[sw(j, cc)]; lrow[j] = (cc <= j) ? tv : 0.0; }      // L[j][cc]
             const double inv = C.invdiag[c < nc ? c : 0];
 #pragma unroll
             for (int j = 15; j >= 0; j--) {
@@ -763,7 +845,8 @@ __device__ __noinline__ bool finalize_and_solve(Ctx<NT> &C, bool first, double m
     const int tid = C.tid, nc = P.nc, L = P.nland;
     cst_i *ip = C.ip;
     for (int a = tid; a < nc; a += NT) {
-        const double dH = C.tiles[tix(a, a)] + (a < P.npp ? C.sd[a] : 0.0);
+        const double sdv = C.sd[min(a, 87)];
+        const double dH = C.tiles[tix(a, a)] + (a < P.npp ? sdv : 0.0);
         double s;
         if (first) { s = 1.0 / (1.0 + sqrt(dH)); C.v_s[a] = s; }
         else s = C.v_s[a];
@@ -821,7 +904,7 @@ __device__ __noinline__ bool finalize_and_solve(Ctx<NT> &C, bool first, double m
 #pragma unroll
                 for (int i = 0; i < 4; i++) tv[i] = T[sw(r, c0 + i)];
                 if (a < nc) {
-                    const double sa = C.sc[a], ua = C.ycam[a];
+                    const double sa = C.sc[a], ua = C.ycam[a], sda = C.sd[min(a, 87)];
                     double sb[4], ub[4];
 #pragma unroll
                     for (int i = 0; i < 4; i++) { sb[i] = C.sc[16 * J + c0 + i]; ub[i] = C.ycam[16 * J + c0 + i]; }
@@ -832,7 +915,7 @@ __device__ __noinline__ bool finalize_and_solve(Ctx<NT> &C, bool first, double m
                         if (b <= a) {
                             acc[1] += ((a == b) ? 1.0 : 2.0) * tv[i] * ua * ub[i];
                             v = sa * sb[i] * tv[i];
-                            if (a == b) v += mu * fmin(fmax(sa * sa * (tv[i] + (a < P.npp ? C.sd[a] : 0.0)), 1e-6), 1e32);   // mu D_a^2
+                            if (a == b) v += mu * fmin(fmax(sa * sa * (tv[i] + (a < P.npp ? sda : 0.0)), 1e-6), 1e32);   // mu D_a^2
                         }
                         T[sw(r, c0 + i)] = v;
                     }
@@ -840,7 +923,8 @@ __device__ __noinline__ bool finalize_and_solve(Ctx<NT> &C, bool first, double m
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         const int b = 16 * J + c0 + i;
-                        T[sw(r, c0 + i)] = (b < nc) ? C.sc[b] * (C.gcam[b] - (b < P.npp ? C.rc[b] : 0.0)) : ((b == nc) ? 1.0 : 0.0);
+                        const double scb = C.sc[b], gb = C.gcam[b], rcb = C.rc[min(b, 87)];      // sc/gcam hold 176 entries
+                        T[sw(r, c0 + i)] = (b < nc) ? scb * (gb - (b < P.npp ? rcb : 0.0)) : ((b == nc) ? 1.0 : 0.0);
                     }
                 } else {
 #pragma unroll
@@ -1008,16 +1092,27 @@ __global__ void __launch_bounds__(NT) solve_kernel(SolveArgs A) {
                 (void)imu_sqrt_info_group((const double *)(C.dp + W->d_imu + f * IMU_CONST + IMU_COV), GEN(C.g_sqrt + f * 225), GEN(lds + f * 450),
                                           GEN(lds + f * 450 + 225), tid & 15);
         }
-        // constant part of the prior: Hp = J0' J0 (packed lower), marginalization_factor.cpp:366,371-380
+        __syncthreads();
+        // constant part of the prior: Hp = J0' J0 (packed lower), marginalization_factor.cpp:366,371-380.  The tile
+        // region is still unused: J0 is staged there (columns contiguous) and every thread forms 1 x 2 entry pairs.
         if (P.prior_n > 0) {
             const int n = P.prior_n;
-            cst_d *J0 = C.dp + W->d_prior;
+            cst_d *J0g = C.dp + W->d_prior;
+            const bool in_lds = n * n <= (C.ntiles << 8);
+            if (in_lds) copy_doubles<NT>(lds, J0g, n * n, tid);
+            __syncthreads();
             for (int e = tid; e < n * n; e += NT) {
                 const int a = e / n, b = e - a * n;
                 if (b > a) continue;
-                double s = 0;
-                for (int i = 0; i < n; i++) s += J0[i + n * a] * J0[i + n * b];
-                C.g_hp[a * (a + 1) / 2 + b] = s;
+                double s0 = 0, s1 = 0;
+                if (in_lds) {
+                    const lds_d *ca = lds + n * a, *cb = lds + n * b;
+                    for (int i = 0; i + 1 < n; i += 2) { s0 += ca[i] * cb[i]; s1 += ca[i + 1] * cb[i + 1]; }
+                    if (n & 1) s0 += ca[n - 1] * cb[n - 1];
+                } else {
+                    for (int i = 0; i < n; i++) s0 += J0g[i + n * a] * J0g[i + n * b];
+                }
+                C.g_hp[a * (a + 1) / 2 + b] = s0 + s1;
             }
         }
         __syncthreads();
