@@ -189,6 +189,17 @@ int tcv_batch_plan_stats(tcv_batch *b, int *num_plans, double *plan_bytes, int *
 int tcv_batch_stats(tcv_batch *b, double *input_bytes, double *solve_ms, double *marg_ms);
 int tcv_batch_size(const tcv_batch *b);
 
+/* ---- IMU pre-integration (the producer of the IMU factor's constants) ------- */
+/* Batched `IntegrationBase(acc_0, gyr_0, linearized_ba, linearized_bg)` followed by `push_back(dt, acc, gyr)` for every
+ * buffered sample (integration_base.h:13-36, propagate :130-158, midPointIntegration :54-128).  `repropagate(ba, bg)`
+ * (:38-52) is the same call with the new linearisation biases.  Host pointers.
+ *   first/count[i]   : sample rows of pre-integration i in `samples7`
+ *   samples7         : num_samples x 7 = dt, acc xyz, gyr xyz   (dt_buf / acc_buf / gyr_buf)
+ *   acc0_gyr0_ba_bg  : n x 12
+ *   noise            : ACC_N, GYR_N, ACC_W, GYR_W (parameters.h; noise matrix integration_base.h:21-27) */
+int tcv_preintegrate(int n, const int *first, const int *count, const double *samples7, int num_samples,
+                     const double *acc0_gyr0_ba_bg, const double noise[4], tcv_imu_preintegration *out);
+
 /* ---- batched factor evaluation (parity / debug surface; CostFunction::Evaluate layout) ------- */
 /* All pointers are HOST pointers; the call uploads, evaluates on the GPU, downloads.
  * jacobians may be NULL.  Layouts follow the reference: row-major, global block width. */

@@ -1,0 +1,206 @@
+// Batched IMU pre-integration on the GPU: IntegrationBase(acc_0, gyr_0, ba, bg) followed by push_back(dt, acc, gyr)
+// for every buffered sample (reference vins_estimator/src/factor/integration_base.h:13-158: constructor :13-28,
+// push_back :30-36, propagate :130-158, midPointIntegration :54-128).  repropagate (:38-52) is the same computation
+// with new linearisation biases, so it maps onto the same entry point.
+//
+// One 256-thread workgroup per pre-integration.  Per sample: lanes 0..44 build the five 3x3 base matrices every block
+// of F (15x15) and V (15x18) is a multiple of (R0 = R(delta_q), R1 = R(result_delta_q), M0 = R0 [a0]x, M1 = R1 [a1]x,
+// M1B = M1 (I - [w]x dt)); lane 64 advances delta_p / delta_q / delta_v (mid-point rule); then 225 lanes own one entry
+// each of jacobian <- F jacobian and covariance <- F covariance F' + V noise V' (noise is diagonal, :21-27).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "tcv_factors.h"
+#include "tcv_host.h"
+#include "tcv_dev.h"
+
+namespace tcv {
+
+struct PreintArgs {
+    const int *first, *count;
+    const double *samples;   // rows of 7: dt, acc xyz, gyr xyz
+    const double *init;      // n x 12: acc_0, gyr_0, linearized_ba, linearized_bg
+    double noise[4];         // ACC_N, GYR_N, ACC_W, GYR_W
+    double *out;             // n x 466: delta_p 3, delta_q 4 (xyzw), delta_v 3, ba 3, bg 3, sum_dt, jacobian 225, covariance 225 (row-major)
+    int n;
+};
+enum { PREINT_OUT = 467 };
+
+// entry (r, c) of F from the base matrices B[5][9] = R0, R1, M0, M1, M1B  (integration_base.h:90-103)
+__device__ __forceinline__ double F_entry(const lds_d *B, int r, int c, double dt) {
+    const int br = r / 3, bc = c / 3, i = r - 3 * br, j = c - 3 * bc, e = 3 * i + j;
+    const double id = (i == j) ? 1.0 : 0.0;
+    if (br == 0) {
+        if (bc == 0) return id;
+        if (bc == 1) return -0.25 * B[18 + e] * dt * dt + -0.25 * B[36 + e] * dt * dt;
+        if (bc == 2) return id * dt;
+        if (bc == 3) return -0.25 * (B[e] + B[9 + e]) * dt * dt;
+        return -0.25 * B[27 + e] * dt * dt * -dt;
+    }
+    if (br == 1) {
+        if (bc == 1) return B[45 + e];                 // I - [w]x dt
+        if (bc == 4) return -1.0 * id * dt;
+        return 0.0;
+    }
+    if (br == 2) {
+        if (bc == 1) return -0.5 * B[18 + e] * dt + -0.5 * B[36 + e] * dt;
+        if (bc == 2) return id;
+        if (bc == 3) return -0.5 * (B[e] + B[9 + e]) * dt;
+        if (bc == 4) return -0.5 * B[27 + e] * dt * -dt;
+        return 0.0;
+    }
+    return (br == bc) ? id : 0.0;
+}
+// entry (r, k) of V, k < 18  (integration_base.h:106-118)
+__device__ __forceinline__ double V_entry(const lds_d *B, int r, int k, double dt) {
+    const int br = r / 3, bk = k / 3, i = r - 3 * br, j = k - 3 * bk, e = 3 * i + j;
+    const double id = (i == j) ? 1.0 : 0.0;
+    if (br == 0) {
+        if (bk == 0) return 0.25 * B[e] * dt * dt;
+        if (bk == 1 || bk == 3) return 0.25 * -B[27 + e] * dt * dt * 0.5 * dt;
+        if (bk == 2) return 0.25 * B[9 + e] * dt * dt;
+        return 0.0;
+    }
+    if (br == 1) return (bk == 1 || bk == 3) ? 0.5 * id * dt : 0.0;
+    if (br == 2) {
+        if (bk == 0) return 0.5 * B[e] * dt;
+        if (bk == 1 || bk == 3) return 0.5 * -B[27 + e] * dt * 0.5 * dt;
+        if (bk == 2) return 0.5 * B[9 + e] * dt;
+        return 0.0;
+    }
+    if (br == 3) return (bk == 4) ? id * dt : 0.0;
+    return (bk == 5) ? id * dt : 0.0;
+}
+
+__global__ void __launch_bounds__(256) preint_kernel(PreintArgs A) {
+    __shared__ double sh[15 * 15 * 4 + 15 * 18 + 64 + 32];
+    lds_d *S = (lds_d *)sh;
+    lds_d *J = S, *P = S + 225, *T = S + 450, *F = S + 675, *V = S + 900, *B = S + 1170, *st = S + 1234;
+    // st: delta_p 0..2, delta_q 3..6, delta_v 7..9, acc_0 10..12, gyr_0 13..15, ba 16..18, bg 19..21, sum_dt 22
+    const int tid = threadIdx.x;
+    for (int it = blockIdx.x; it < A.n; it += gridDim.x) {
+        const double *init = A.init + (size_t)it * 12;
+        if (tid < 225) { J[tid] = (tid / 15 == tid % 15) ? 1.0 : 0.0; P[tid] = 0.0; }
+        if (tid == 0) {
+            for (int i = 0; i < 10; i++) st[i] = 0.0;
+            st[6] = 1.0;
+            for (int i = 0; i < 12; i++) st[10 + i] = init[i];
+            st[22] = 0.0;
+        }
+        __syncthreads();
+        const int s0 = A.first[it], ns = A.count[it];
+        for (int k = 0; k < ns; k++) {
+            const double *smp = A.samples + (size_t)(s0 + k) * 7;
+            const double dt = smp[0];
+            const V3 a1(smp + 1), g1(smp + 4);
+            const V3 a0(st[10], st[11], st[12]), g0(st[13], st[14], st[15]), ba(st[16], st[17], st[18]), bg(st[19], st[20], st[21]);
+            const Quat dq(st[3], st[4], st[5], st[6]);
+            const V3 un_gyr = 0.5 * (g0 + g1) - bg;                                             // :65
+            const Quat rq = dq * Quat(un_gyr.x * dt / 2, un_gyr.y * dt / 2, un_gyr.z * dt / 2, 1.0);   // :66 (not normalised here)
+            if (tid < 45) {           // base matrices
+                const int which = tid / 9, e = tid - 9 * which, i = e / 3, j = e - 3 * i;
+                const M3 R0 = to_matrix(dq), R1 = to_matrix(rq);
+                const M3 A0 = skew(a0 - ba), A1 = skew(a1 - ba), Rw = skew(un_gyr);
+                double v;
+                if (which == 0) v = R0(i, j);
+                else if (which == 1) v = R1(i, j);
+                else if (which == 2) v = (R0 * A0)(i, j);
+                else if (which == 3) v = (R1 * A1)(i, j);
+                else { const M3 Bm = m3_identity() - dt * Rw; v = ((R1 * A1) * Bm)(i, j); }
+                B[tid] = v;
+                if (which == 4) { const M3 Bm = m3_identity() - dt * Rw; B[45 + e] = Bm(i, j); }
+            }
+            __syncthreads();
+            if (tid < 225) F[tid] = F_entry(B, tid / 15, tid % 15, dt);
+            for (int e = tid; e < 270; e += 256) V[e] = V_entry(B, e / 18, e % 18, dt);
+            __syncthreads();
+            double jn = 0, tn = 0;
+            if (tid < 225) {
+                const int r = tid / 15, c = tid - 15 * r;
+#pragma unroll
+                for (int q = 0; q < 15; q++) { jn += F[r * 15 + q] * J[q * 15 + c]; tn += F[r * 15 + q] * P[q * 15 + c]; }
+            }
+            __syncthreads();
+            if (tid < 225) { J[tid] = jn; T[tid] = tn; }
+            if (tid == 255) {         // state: mid-point rule :63-71, propagate :148-156 (st is next read after two more barriers)
+                const V3 un_acc_0 = rotate(dq, a0 - ba);
+                const V3 un_acc_1 = rotate(rq, a1 - ba);
+                const V3 un_acc = 0.5 * (un_acc_0 + un_acc_1);
+                const V3 dp(st[0], st[1], st[2]), dv(st[7], st[8], st[9]);
+                const V3 rp = dp + dv * dt + 0.5 * un_acc * dt * dt;
+                const V3 rv = dv + un_acc * dt;
+                const Quat qn = normalized(rq);                                                      // :153
+                st[0] = rp.x; st[1] = rp.y; st[2] = rp.z; st[3] = qn.x; st[4] = qn.y; st[5] = qn.z; st[6] = qn.w;
+                st[7] = rv.x; st[8] = rv.y; st[9] = rv.z;
+                st[10] = a1.x; st[11] = a1.y; st[12] = a1.z; st[13] = g1.x; st[14] = g1.y; st[15] = g1.z;
+                st[22] += dt;
+            }
+            __syncthreads();
+            if (tid < 225) {
+                const int r = tid / 15, c = tid - 15 * r;
+                double pn = 0;
+#pragma unroll
+                for (int q = 0; q < 15; q++) pn += T[r * 15 + q] * F[c * 15 + q];
+                const double n2[6] = {A.noise[0] * A.noise[0], A.noise[1] * A.noise[1], A.noise[0] * A.noise[0], A.noise[1] * A.noise[1],
+                                      A.noise[2] * A.noise[2], A.noise[3] * A.noise[3]};      // :21-27 (ACC_N / GYR_N for k and k+1)
+                double vn = 0;
+#pragma unroll
+                for (int q = 0; q < 18; q++) vn += V[r * 18 + q] * n2[q / 3] * V[c * 18 + q];
+                P[tid] = pn + vn;
+            }
+            __syncthreads();
+        }
+        double *o = A.out + (size_t)it * PREINT_OUT;
+        if (tid < 10) o[tid] = st[tid];
+        if (tid < 6) o[10 + tid] = st[16 + tid];
+        if (tid == 0) o[16] = st[22];
+        if (tid < 225) { o[17 + tid] = J[tid]; o[242 + tid] = P[tid]; }
+        __syncthreads();
+    }
+}
+
+}  // namespace tcv
+using namespace tcv;
+
+// IntegrationBase ctor + push_back x count[i] (integration_base.h:13-36, :130-158); repropagate (:38-52) = same call with new biases
+extern "C" int tcv_preintegrate(int n, const int *first, const int *count, const double *samples7, int num_samples,
+                                const double *acc0_gyr0_ba_bg, const double noise[4], tcv_imu_preintegration *out) {
+    if (n <= 0 || !first || !count || !samples7 || num_samples < 0 || !acc0_gyr0_ba_bg || !noise || !out) return TCV_ERR_INVALID;
+    for (int i = 0; i < n; i++)
+        if (first[i] < 0 || count[i] < 0 || first[i] + count[i] > num_samples) { set_error("preintegrate: sample range out of bounds"); return TCV_ERR_INVALID; }
+    if (int rc = device_ready()) return rc;
+    PreintArgs a;
+    a.n = n;
+    for (int i = 0; i < 4; i++) a.noise[i] = noise[i];
+    int *d_first = nullptr, *d_count = nullptr;
+    double *d_s = nullptr, *d_i = nullptr, *d_o = nullptr;
+    hipError_t e = hipSuccess;
+    auto fail = [&](const char *w) { (void)hipFree(d_first); (void)hipFree(d_count); (void)hipFree(d_s); (void)hipFree(d_i); (void)hipFree(d_o); return hip_fail(e, w); };
+    if ((e = hipMalloc((void **)&d_first, sizeof(int) * n)) != hipSuccess) return fail("hipMalloc");
+    if ((e = hipMalloc((void **)&d_count, sizeof(int) * n)) != hipSuccess) return fail("hipMalloc");
+    if ((e = hipMalloc((void **)&d_s, sizeof(double) * 7 * (size_t)std::max(1, num_samples))) != hipSuccess) return fail("hipMalloc");
+    if ((e = hipMalloc((void **)&d_i, sizeof(double) * 12 * (size_t)n)) != hipSuccess) return fail("hipMalloc");
+    if ((e = hipMalloc((void **)&d_o, sizeof(double) * PREINT_OUT * (size_t)n)) != hipSuccess) return fail("hipMalloc");
+    if ((e = hipMemcpy(d_first, first, sizeof(int) * n, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy");
+    if ((e = hipMemcpy(d_count, count, sizeof(int) * n, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy");
+    if (num_samples && (e = hipMemcpy(d_s, samples7, sizeof(double) * 7 * (size_t)num_samples, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy");
+    if ((e = hipMemcpy(d_i, acc0_gyr0_ba_bg, sizeof(double) * 12 * (size_t)n, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy");
+    a.first = d_first; a.count = d_count; a.samples = d_s; a.init = d_i; a.out = d_o;
+    hipLaunchKernelGGL(preint_kernel, dim3(std::min(n, 4096)), dim3(256), 0, 0, a);
+    if ((e = hipGetLastError()) != hipSuccess) return fail("preint kernel launch");
+    if ((e = hipDeviceSynchronize()) != hipSuccess) return fail("hipDeviceSynchronize");
+    std::vector<double> h((size_t)n * PREINT_OUT);
+    if ((e = hipMemcpy(h.data(), d_o, sizeof(double) * h.size(), hipMemcpyDeviceToHost)) != hipSuccess) return fail("hipMemcpy");
+    for (int i = 0; i < n; i++) {
+        const double *o = h.data() + (size_t)i * PREINT_OUT;
+        tcv_imu_preintegration &p = out[i];
+        std::memcpy(p.delta_p, o, 24); std::memcpy(p.delta_q, o + 3, 32); std::memcpy(p.delta_v, o + 7, 24);
+        std::memcpy(p.linearized_ba, o + 10, 24); std::memcpy(p.linearized_bg, o + 13, 24); p.sum_dt = o[16];
+        std::memcpy(p.jacobian, o + 17, 225 * 8); std::memcpy(p.covariance, o + 242, 225 * 8);
+    }
+    (void)hipFree(d_first); (void)hipFree(d_count); (void)hipFree(d_s); (void)hipFree(d_i); (void)hipFree(d_o);
+    return TCV_OK;
+}

@@ -197,6 +197,16 @@ __device__ __forceinline__ void copy_doubles(lds_d *dst, cst_d *src, int n, int 
     if ((n & 1) && tid == 0) dst[n - 1] = src[n - 1];
 }
 
+// zero n doubles (n even, 16-byte aligned) with 16-byte LDS stores
+template <int NT>
+__device__ __forceinline__ void zero_lds(lds_d *dst, int n, int tid) {
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) v2d lds_v2d;
+    lds_v2d *d2 = (lds_v2d *)dst;
+    const v2d z = {0.0, 0.0};
+    for (int i = tid; i < (n >> 1); i += NT) d2[i] = z;
+}
+
 template <int N>
 __device__ __forceinline__ void wave_sum(double (&acc)[N]) {
 #pragma unroll
@@ -238,7 +248,7 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
     double cost_acc = 0.0;
 
     if (assemble) {
-        for (int i = tid; i < pp_elems; i += NT) C.tiles[i] = 0.0;
+        zero_lds<NT>(C.tiles, pp_elems, tid);
         for (int i = tid; i < nc; i += NT) C.gcam[i] = 0.0;
         for (int i = tid; i < 176; i += NT) C.rc[i] = 0.0;      // rc | sd
     }
@@ -446,7 +456,7 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
     TCV_MARK(C, PH_PRIOR);
     if (assemble) {
         const int all_elems = C.ntiles << 8;
-        for (int i = pp_elems + tid; i < all_elems; i += NT) C.tiles[i] = 0.0;
+        zero_lds<NT>(C.tiles + pp_elems, all_elems - pp_elems, tid);
     }
     __syncthreads();
     TCV_MARK(C, PH_ZERO);

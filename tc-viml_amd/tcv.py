@@ -36,7 +36,7 @@ EXPORTS = [
     "tcv_batch_create", "tcv_batch_destroy", "tcv_batch_solve", "tcv_batch_marginalize", "tcv_batch_synchronize",
     "tcv_batch_download_states", "tcv_batch_get_summaries", "tcv_batch_get_prior", "tcv_batch_get_first_step",
     "tcv_batch_plan_stats", "tcv_batch_stats", "tcv_batch_size",
-    "tcv_eval_imu_factors", "tcv_eval_projection_factors", "tcv_eval_line_factors", "tcv_pose_plus",
+    "tcv_eval_imu_factors", "tcv_eval_projection_factors", "tcv_eval_line_factors", "tcv_pose_plus", "tcv_preintegrate",
 ]
 
 
@@ -136,6 +136,7 @@ def lib():
         L.tcv_eval_projection_factors.argtypes = [C.c_int, _dp, _dp, C.c_double, _dp, _dp]
         L.tcv_eval_line_factors.argtypes = [C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
         L.tcv_pose_plus.argtypes = [C.c_int, _dp, _dp, _dp]
+        L.tcv_preintegrate.argtypes = [C.c_int, _ip, _ip, _dp, C.c_int, _dp, _dp, C.POINTER(ImuPreintegration)]
         _lib = L
     return _lib
 
@@ -449,3 +450,21 @@ def pose_plus(x, delta):
     out = np.zeros((n, 7))
     check(lib().tcv_pose_plus(n, dptr(x), dptr(delta), dptr(out)))
     return out
+
+
+def preintegrate(acc, gyr, dt, lin_ba, lin_bg, noise):
+    """Batched IntegrationBase: acc/gyr (n, S+1, 3) with sample 0 = constructor's (acc_0, gyr_0), samples 1..S pushed with
+    step dt; lin_ba/lin_bg (n, 3); noise = (ACC_N, GYR_N, ACC_W, GYR_W).  Returns the dict layout of synth's 'imu'."""
+    acc = f64(acc); gyr = f64(gyr)
+    n, S = acc.shape[0], acc.shape[1] - 1
+    samples = np.concatenate([np.full((n, S, 1), float(dt)), acc[:, 1:], gyr[:, 1:]], -1).reshape(n * S, 7).copy()
+    first = i32(np.arange(n) * S); count = i32(np.full(n, S))
+    init = f64(np.concatenate([acc[:, 0], gyr[:, 0], f64(lin_ba).reshape(n, 3), f64(lin_bg).reshape(n, 3)], -1))
+    nz = f64(noise)
+    out = (ImuPreintegration * n)()
+    check(lib().tcv_preintegrate(n, iptr(first), iptr(count), dptr(samples), n * S, dptr(init), dptr(nz), out))
+    return dict(delta_p=np.array([list(o.delta_p) for o in out]), delta_q=np.array([list(o.delta_q) for o in out]),
+                delta_v=np.array([list(o.delta_v) for o in out]), lin_ba=np.array([list(o.linearized_ba) for o in out]),
+                lin_bg=np.array([list(o.linearized_bg) for o in out]), sum_dt=np.array([o.sum_dt for o in out]),
+                jacobian=np.array([list(o.jacobian) for o in out]).reshape(n, 15, 15),
+                covariance=np.array([list(o.covariance) for o in out]).reshape(n, 15, 15))
