@@ -4,7 +4,7 @@
 
 One STEP = one pass of the hot path over one batch of B independent synthetic windows per GPU, already
 resident in HBM: the fused solve kernel (8 fixed trust-region iterations, the per-frame budget regime of
-estimator.cpp:1888-1897 made deterministic) followed by the MARGIN_OLD marginalisation kernel
+estimator.cpp:1888-1897 made deterministic), the double2vector gauge fix (:1905) and the MARGIN_OLD marginalisation kernel
 (estimator.cpp:1911-2046) that produces the next prior.  value = windows solved per second over all GPUs.
 
 Multi-GPU: windows are independent (per-sequence replay shards one sequence per GPU), so every rank owns
@@ -158,6 +158,7 @@ def main():
 
     def step():
         batch.solve(opts)
+        batch.gauge_fix()          # double2vector(), estimator.cpp:1905: the marginalisation linearises at the gauge-fixed states
         batch.marginalize()
 
     def sync():

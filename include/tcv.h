@@ -131,6 +131,9 @@ int tcv_problem_add_marginalization_factor(tcv_problem *p, const tcv_prior *prio
                                            int num_blocks);
 /* graph construction of estimator.cpp:1683-1846 from frame-indexed arrays */
 int tcv_problem_from_window(const tcv_window_desc *w, tcv_problem **out);
+/* Names the blocks that are the window's frames (para_Pose[i], para_SpeedBias[i], estimator.h:166-167); only
+ * tcv_batch_gauge_fix needs it.  tcv_problem_from_window() does this implicitly. */
+int tcv_problem_set_frames(tcv_problem *p, int n_frames, double *const *pose, double *const *speedbias);
 int tcv_problem_num_parameter_blocks(const tcv_problem *p);
 int tcv_problem_num_residual_blocks(const tcv_problem *p);
 int tcv_problem_num_residuals(const tcv_problem *p);
@@ -174,6 +177,11 @@ void tcv_batch_destroy(tcv_batch *b);
  * (a hipStream_t cast to void*, NULL = default stream); inputs and outputs stay in HBM. */
 int tcv_batch_solve(tcv_batch *b, const tcv_solver_options *o, void *hip_stream);
 int tcv_batch_marginalize(tcv_batch *b, void *hip_stream);
+/* Estimator::double2vector() gauge fix (estimator.cpp:1537-1581) followed by vector2double() (:1492-1512), in place
+ * on the solved states in HBM, so that the marginalisation linearises at the gauge-fixed states exactly as the
+ * reference does (double2vector :1905, vector2double :1915).  The origin (Rs[0], Ps[0]) is the uploaded initial
+ * pose of frame 0.  Needs the frame table (tcv_problem_set_frames / tcv_problem_from_window). */
+int tcv_batch_gauge_fix(tcv_batch *b, void *hip_stream);
 int tcv_batch_synchronize(tcv_batch *b);
 /* copy results back: states into the callers' parameter blocks, summaries, priors */
 int tcv_batch_download_states(tcv_batch *b);
@@ -188,6 +196,17 @@ int tcv_batch_plan_stats(tcv_batch *b, int *num_plans, double *plan_bytes, int *
  * kernels measured with HIP events on the launch stream */
 int tcv_batch_stats(tcv_batch *b, double *input_bytes, double *solve_ms, double *marg_ms);
 int tcv_batch_size(const tcv_batch *b);
+
+/* ---- Estimator::double2vector() gauge fix (estimator.cpp:1537-1581) ------------------------ */
+/* The yaw of frame 0 and its position are unobservable: after the solve the window is rotated back about the
+ * vertical by the yaw drift of frame 0 (Utility::R2ypr / ypr2R, utility.h:70-112; full rotation near the Euler
+ * singularity, :1556-1563) and re-anchored at the original Ps[0].  Host pointers; evaluated on the GPU.
+ *   origin_R0 (3x3 row-major) / origin_P0 : Rs[0], Ps[0] before the solve (or last_R0 / last_P0 after a failure, :1542-1547)
+ *   para_pose n x 7, para_speedbias n x 9  : the solved parameter blocks (inputs, untouched)
+ *   Rs n x 9 row-major, Ps n x 3, Vs n x 3 : outputs (:1565-1581);  pose_out n x 7 (optional) = what the next
+ *   vector2double() writes from them (:1494-1503, Eigen's matrix -> quaternion conversion) */
+int tcv_gauge_fix(int n_frames, const double origin_R0[9], const double origin_P0[3], const double *para_pose,
+                  const double *para_speedbias, double *Rs, double *Ps, double *Vs, double *pose_out);
 
 /* ---- IMU pre-integration (the producer of the IMU factor's constants) ------- */
 /* Batched `IntegrationBase(acc_0, gyr_0, linearized_ba, linearized_bg)` followed by `push_back(dt, acc, gyr)` for every

@@ -675,6 +675,28 @@ def marginalize_old(prob: Problem, x, imu_sqrt=None, eps=1e-8):
                 facs.append((fac, [0, 1]))
         elif kind == "proj" and blks[0] == ("pose", 0):                                   # :1957-1986
             facs.append((fac, [0, 3]))
+    # getParameterBlocks with addr_shift pose i -> i-1, sb i -> i-1, ex -> ex (estimator.cpp:2027-2039)
+    return _marginalize(prob, x, facs, lambda nm, i: (nm, i - 1) if nm in ("pose", "sb") else (nm, i), imu_sqrt, eps)
+
+
+def marginalize_second_new(prob: Problem, x, eps=1e-8):
+    """MARGIN_SECOND_NEW (estimator.cpp:2047-2113): only the old prior is re-marginalised, dropping para_Pose[WINDOW_SIZE-1];
+    addr_shift maps frame WINDOW_SIZE -> WINDOW_SIZE-1 and every other block to itself (:2084-2104)."""
+    W = prob.win["pose"].shape[0] - 1                                                     # WINDOW_SIZE
+    facs = []
+    for fac in prob.factors():
+        kind, k, blks = fac
+        if kind == "prior" and ("pose", W - 1) in blks:                                   # :2049-2050
+            assert ("sb", W - 1) not in blks                                              # ROS_ASSERT :2060
+            facs.append((fac, [bi for bi, b in enumerate(blks) if b == ("pose", W - 1)]))
+    if not facs:
+        return None, None
+    return _marginalize(prob, x, facs, lambda nm, i: (nm, i - 1) if (nm in ("pose", "sb") and i == W) else (nm, i), None, eps)
+
+
+def _marginalize(prob: Problem, x, facs, shift, imu_sqrt=None, eps=1e-8):
+    """MarginalizationInfo::addResidualBlockInfo / preMarginalize / marginalize / getParameterBlocks
+    (marginalization_factor.cpp:89-321) for the (factor, drop_set) list `facs`."""
     order = {nm_i: n for n, nm_i in enumerate((nm, i) for (nm, i, g) in prob.blocks)}
     gsize = {(nm, i): g for (nm, i, g) in prob.blocks}
     touched, dropped = set(), set()
@@ -723,13 +745,68 @@ def marginalize_old(prob: Problem, x, imu_sqrt=None, eps=1e-8):
     S_inv = np.where(lam2 > eps, 1.0 / np.where(lam2 > eps, lam2, 1.0), 0.0)
     J0 = np.diag(np.sqrt(S)) @ V2.T
     r0 = np.diag(np.sqrt(S_inv)) @ V2.T @ b2
-    # getParameterBlocks with addr_shift pose i -> i-1, sb i -> i-1, ex -> ex (estimator.cpp:2027-2039)
     blocks, sizes, kidx, x0 = [], [], [], []
     for b in keep_list:
         nm, i = b
-        blocks.append((nm, i - 1) if nm in ("pose", "sb") else b)
+        blocks.append(shift(nm, i))
         sizes.append(gsize[b]); kidx.append(idx[b] - m)
         x0.append(np.atleast_1d(Problem.get(x, nm, i)).copy())
     prior = dict(n=n, m=m, blocks=blocks, sizes=sizes, idx=kidx, x0=x0, J0=J0, r0=r0)
     dbg = dict(A=A_full, b=b_full, A_schur=A2, b_schur=b2, drop=drop_list, keep=keep_list, m=m, n=n)
     return prior, dbg
+
+
+# --------------------------------------------------------------------------------------
+# G3: Estimator::double2vector() gauge fix   estimator.cpp:1537-1581
+# --------------------------------------------------------------------------------------
+def R2ypr(R):                    # utility.h:70-85 (degrees)
+    n, o, a = R[:, 0], R[:, 1], R[:, 2]
+    y = np.arctan2(n[1], n[0])
+    p = np.arctan2(-n[2], n[0] * np.cos(y) + n[1] * np.sin(y))
+    r = np.arctan2(a[0] * np.sin(y) - a[1] * np.cos(y), -o[0] * np.sin(y) + o[1] * np.cos(y))
+    return np.array([y, p, r]) / np.pi * 180.0
+
+
+def ypr2R(ypr):                  # utility.h:87-112 (degrees)
+    y, p, r = np.asarray(ypr, dtype=float) / 180.0 * np.pi
+    Rz = np.array([[np.cos(y), -np.sin(y), 0], [np.sin(y), np.cos(y), 0], [0, 0, 1.0]])
+    Ry = np.array([[np.cos(p), 0, np.sin(p)], [0, 1.0, 0], [-np.sin(p), 0, np.cos(p)]])
+    Rx = np.array([[1.0, 0, 0], [0, np.cos(r), -np.sin(r)], [0, np.sin(r), np.cos(r)]])
+    return Rz @ Ry @ Rx
+
+
+def R2q(m):                      # Eigen `Quaterniond q{R}` (vector2double, estimator.cpp:1499), returns x y z w
+    q = np.zeros(4)
+    t = m[0, 0] + m[1, 1] + m[2, 2]
+    if t > 0:
+        t = np.sqrt(t + 1.0); q[3] = 0.5 * t; t = 0.5 / t
+        q[0] = (m[2, 1] - m[1, 2]) * t; q[1] = (m[0, 2] - m[2, 0]) * t; q[2] = (m[1, 0] - m[0, 1]) * t
+    else:
+        i = 0
+        if m[1, 1] > m[0, 0]:
+            i = 1
+        if m[2, 2] > m[i, i]:
+            i = 2
+        j = (i + 1) % 3; k = (j + 1) % 3
+        t = np.sqrt(m[i, i] - m[j, j] - m[k, k] + 1.0); q[i] = 0.5 * t; t = 0.5 / t
+        q[3] = (m[k, j] - m[j, k]) * t; q[j] = (m[j, i] + m[i, j]) * t; q[k] = (m[k, i] + m[i, k]) * t
+    return q
+
+
+def gauge_fix(R0, P0, pose, sb):
+    """double2vector: Rs, Ps, Vs (:1565-1581) and the para_Pose the next vector2double() writes (:1494-1503)."""
+    pose = np.asarray(pose, dtype=float); sb = np.asarray(sb, dtype=float)
+    a = R2ypr(np.asarray(R0, dtype=float))
+    R00 = q2R(pose[0, 3:7])
+    b = R2ypr(R00)
+    rot = ypr2R([a[0] - b[0], 0.0, 0.0])
+    if abs(abs(a[1]) - 90.0) < 1.0 or abs(abs(b[1]) - 90.0) < 1.0:      # :1555-1563
+        rot = np.asarray(R0, dtype=float) @ R00.T
+    n = pose.shape[0]
+    Rs = np.zeros((n, 3, 3)); Ps = np.zeros((n, 3)); Vs = np.zeros((n, 3)); po = np.zeros((n, 7))
+    for i in range(n):
+        Rs[i] = rot @ q2R(qnormalized(pose[i, 3:7]))
+        Ps[i] = rot @ (pose[i, :3] - pose[0, :3]) + np.asarray(P0, dtype=float)
+        Vs[i] = rot @ sb[i, :3]
+        po[i, :3] = Ps[i]; po[i, 3:] = R2q(Rs[i])
+    return Rs, Ps, Vs, po

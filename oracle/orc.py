@@ -64,6 +64,7 @@ def lib():
         _lib.orc_prior_residual.argtypes = [C.POINTER(OrcWindow), _dp]
         _lib.orc_linearize_dense.argtypes = [C.POINTER(OrcWindow), _dp, _dp, _dp, _ip, _ip]
         _lib.orc_marginalize_old.argtypes = [C.POINTER(OrcWindow), _ip, _ip, _ip, _ip, _ip, _ip, _ip, _dp, _dp, _dp, _dp, _dp]
+        _lib.orc_gauge_fix.argtypes = [C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
         _lib.orc_eig_sym.argtypes = [C.c_int, _dp, _dp, _dp]
         _lib.orc_loss_correct.restype = C.c_double
     return _lib
@@ -177,3 +178,13 @@ def imu_sqrt_info(cov):
     if rc != 0:
         raise FloatingPointError("covariance inverse not positive definite")
     return out.reshape(15, 15)
+
+
+def gauge_fix(R0, P0, pose, sb):
+    """C restatement of Estimator::double2vector() (estimator.cpp:1537-1581) + the next vector2double() quaternion."""
+    pose = np.ascontiguousarray(pose, dtype=np.float64); sb = np.ascontiguousarray(sb, dtype=np.float64)
+    R0 = np.ascontiguousarray(R0, dtype=np.float64).reshape(9); P0 = np.ascontiguousarray(P0, dtype=np.float64)
+    n = pose.shape[0]
+    Rs = np.zeros((n, 3, 3)); Ps = np.zeros((n, 3)); Vs = np.zeros((n, 3)); po = np.zeros((n, 7))
+    lib().orc_gauge_fix(n, dptr(R0), dptr(P0), dptr(pose), dptr(sb), dptr(Rs), dptr(Ps), dptr(Vs), dptr(po))
+    return Rs, Ps, Vs, po

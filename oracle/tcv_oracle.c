@@ -1045,3 +1045,77 @@ int orc_marginalize_old(const orc_window *w, int *m_out, int *n_out, int *nblk_o
     free(A); free(Amm); free(T); free(pose_t); free(pose_ix);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * G3: Estimator::double2vector() gauge fix, estimator.cpp:1537-1581
+ * ------------------------------------------------------------------------------------------------ */
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+static void r2ypr_deg(const double *R, double *ypr) { /* utility.h:70-85; R row-major, n/o/a = columns 0/1/2 */
+    const double y = atan2(R[3], R[0]);
+    const double p = atan2(-R[6], R[0] * cos(y) + R[3] * sin(y));
+    const double r = atan2(R[2] * sin(y) - R[5] * cos(y), -R[1] * sin(y) + R[4] * cos(y));
+    ypr[0] = y / M_PI * 180.0; ypr[1] = p / M_PI * 180.0; ypr[2] = r / M_PI * 180.0;
+}
+static void mat3_mul(const double *A, const double *B, double *Cm) {
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) Cm[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+static void ypr2R_deg(double yd, double pd, double rd, double *R) { /* utility.h:87-112 */
+    const double y = yd / 180.0 * M_PI, p = pd / 180.0 * M_PI, r = rd / 180.0 * M_PI;
+    const double Rz[9] = {cos(y), -sin(y), 0, sin(y), cos(y), 0, 0, 0, 1};
+    const double Ry[9] = {cos(p), 0, sin(p), 0, 1, 0, -sin(p), 0, cos(p)};
+    const double Rx[9] = {1, 0, 0, 0, cos(r), -sin(r), 0, sin(r), cos(r)};
+    double T[9];
+    mat3_mul(Rz, Ry, T);
+    mat3_mul(T, Rx, R);
+}
+static void mat3_to_quat(const double *m, double *q /* x y z w */) { /* Eigen Quaternion(Matrix3) */
+    double t = m[0] + m[4] + m[8];
+    if (t > 0.0) {
+        t = sqrt(t + 1.0);
+        q[3] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (m[7] - m[5]) * t; q[1] = (m[2] - m[6]) * t; q[2] = (m[3] - m[1]) * t;
+    } else {
+        int i = 0;
+        if (m[4] > m[0]) i = 1;
+        if (m[8] > m[4 * i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrt(m[4 * i] - m[4 * j] - m[4 * k] + 1.0);
+        q[i] = 0.5 * t;
+        t = 0.5 / t;
+        q[3] = (m[3 * k + j] - m[3 * j + k]) * t;
+        q[j] = (m[3 * j + i] + m[3 * i + j]) * t;
+        q[k] = (m[3 * k + i] + m[3 * i + k]) * t;
+    }
+}
+void orc_gauge_fix(int n, const double *R0, const double *P0, const double *pose, const double *sb, double *Rs,
+                   double *Ps, double *Vs, double *pose_out) {
+    double a[3], b[3], R00[9], rot[9];
+    r2ypr_deg(R0, a);                                   /* :1539 */
+    q_toR(pose + 3, R00);                               /* :1548-1551 */
+    r2ypr_deg(R00, b);
+    ypr2R_deg(a[0] - b[0], 0.0, 0.0, rot);              /* :1552-1554 */
+    if (fabs(fabs(a[1]) - 90.0) < 1.0 || fabs(fabs(b[1]) - 90.0) < 1.0) { /* :1555-1563 */
+        double R00t[9];
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R00t[3 * i + j] = R00[3 * j + i];
+        mat3_mul(R0, R00t, rot);
+    }
+    for (int i = 0; i < n; i++) {                       /* :1565-1581 */
+        double qn[4], Ri[9];
+        q_normalized(pose + 7 * i + 3, qn);
+        q_toR(qn, Ri);
+        mat3_mul(rot, Ri, Rs + 9 * i);
+        const double d[3] = {pose[7 * i] - pose[0], pose[7 * i + 1] - pose[1], pose[7 * i + 2] - pose[2]};
+        for (int r = 0; r < 3; r++) {
+            Ps[3 * i + r] = rot[3 * r] * d[0] + rot[3 * r + 1] * d[1] + rot[3 * r + 2] * d[2] + P0[r];
+            Vs[3 * i + r] = rot[3 * r] * sb[9 * i] + rot[3 * r + 1] * sb[9 * i + 1] + rot[3 * r + 2] * sb[9 * i + 2];
+        }
+        if (pose_out) {
+            for (int r = 0; r < 3; r++) pose_out[7 * i + r] = Ps[3 * i + r];
+            mat3_to_quat(Rs + 9 * i, pose_out + 7 * i + 3);
+        }
+    }
+}

@@ -92,6 +92,12 @@ int orc_linearize_dense(const orc_window *w, double *H, double *g, double *cost,
 int orc_marginalize_old(const orc_window *w, int *m_out, int *n_out, int *nblk_out, int *kind, int *index,
                         int *size, int *idx, double *x0, double *J0, double *r0, double *As_out, double *bs_out);
 
+/* G3 Estimator::double2vector() gauge fix, estimator.cpp:1537-1581 (Utility::R2ypr / ypr2R utility.h:70-112), followed by the
+ * matrix -> quaternion conversion of the next vector2double() (:1494-1503, Eigen `Quaterniond q{R}`).
+ * R0 3x3 row-major, pose n x 7, sb n x 9 -> Rs n x 9 row-major, Ps n x 3, Vs n x 3, pose_out n x 7 (may be NULL) */
+void orc_gauge_fix(int n, const double *R0, const double *P0, const double *pose, const double *sb, double *Rs,
+                   double *Ps, double *Vs, double *pose_out);
+
 /* symmetric eigen-decomposition (cyclic Jacobi), ascending eigenvalues; V column-major n x n */
 void orc_eig_sym(int n, double *A /* n x n, destroyed */, double *evals, double *V);
 

@@ -159,6 +159,20 @@ extern "C" int tcv_problem_add_marginalization_factor(tcv_problem *p, const tcv_
     p->prior.push_back(f);
     return TCV_OK;
 }
+extern "C" int tcv_problem_set_frames(tcv_problem *p, int n_frames, double *const *pose, double *const *speedbias) {
+    if (!p || n_frames <= 0 || !pose) { set_error("set_frames: bad argument"); return TCV_ERR_INVALID; }
+    std::vector<int> fp(n_frames, -1), fs(n_frames, -1);
+    for (int i = 0; i < n_frames; i++) {
+        fp[i] = block_of(p, pose[i]);
+        if (fp[i] < 0 || p->blocks[fp[i]].size != 7) { set_error("set_frames: unknown pose block"); return TCV_ERR_INVALID; }
+        if (speedbias && speedbias[i]) {
+            fs[i] = block_of(p, speedbias[i]);
+            if (fs[i] < 0 || p->blocks[fs[i]].size != 9) { set_error("set_frames: unknown speed-bias block"); return TCV_ERR_INVALID; }
+        }
+    }
+    p->frame_pose = fp; p->frame_sb = fs;
+    return TCV_OK;
+}
 extern "C" int tcv_problem_num_parameter_blocks(const tcv_problem *p) { return p ? (int)p->blocks.size() : 0; }
 extern "C" int tcv_problem_num_residual_blocks(const tcv_problem *p) {
     return p ? (int)(p->imu.size() + p->proj.size() + p->line.size() + p->prior.size()) : 0;
@@ -222,6 +236,11 @@ extern "C" int tcv_problem_from_window(const tcv_window_desc *w, tcv_problem **o
     for (int k = 0; k < w->n_line; k++)   // :1786-1846
         chk(tcv_problem_add_line_factor(p, w->line_data + 9 * k, w->line_data + 9 * k + 3, w->line_data + 9 * k + 6, w->line_K,
                                         w->line_Ric, w->line_Tic, w->line_loss_a, w->para_pose + 7 * w->line_frame[k]));
+    {
+        std::vector<double *> fp(w->n_frames), fs(w->n_frames);
+        for (int i = 0; i < w->n_frames; i++) { fp[i] = w->para_pose + 7 * i; fs[i] = w->para_speedbias + 9 * i; }
+        chk(tcv_problem_set_frames(p, w->n_frames, fp.data(), fs.data()));
+    }
     if (rc != TCV_OK) { delete p; return rc; }
     *out = p;
     return TCV_OK;

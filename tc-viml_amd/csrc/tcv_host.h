@@ -57,6 +57,7 @@ struct tcv_problem {
     std::vector<tcv::LineFac> line;
     std::vector<tcv::PriorFac> prior;
     double G[3] = {0, 0, 9.8};
+    std::vector<int> frame_pose, frame_sb;   // block ids of para_Pose[i] / para_SpeedBias[i] (gauge fix), may be empty
 };
 
 struct tcv_batch {
@@ -82,6 +83,7 @@ struct tcv_batch {
     float solve_ms = 0, marg_ms = 0;
     bool solved = false;
     std::vector<double> h_state;
+    bool gauge_fixed = false;
     // marginalisation
     void *marg = nullptr;                 // tcv_marg.hip state
     void (*marg_free)(tcv_batch *) = nullptr;

@@ -384,6 +384,14 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt) {
         H.o_iitem = H.o_iunit; H.n_iitem = 0;
         H.o_ichunk = mark(); I.insert(I.end(), ichunk.begin(), ichunk.end());
     }
+    // ---- frame table (gauge fix, estimator.cpp:1537-1581)
+    H.n_frames = (int)p.frame_pose.size();
+    H.o_frames = mark();
+    for (int i = 0; i < H.n_frames; i++) {
+        const int bp = p.frame_pose[i], bs = i < (int)p.frame_sb.size() ? p.frame_sb[i] : -1;
+        I.push_back(bp >= 0 && cam_of[bp] >= 0 ? goff[cam_of[bp]] : -1);
+        I.push_back(bs >= 0 && cam_of[bs] >= 0 ? goff[cam_of[bs]] : -1);
+    }
     while ((I.size() & 3) != 0) I.push_back(0);          // plans are concatenated: keep every plan 16-byte aligned
     H.plan_ints = (int)I.size();
 

@@ -80,6 +80,7 @@ struct PlanHdr {
     int o_ichunk;   // n_imu_chunk x 4 : fac_begin, fac_count, number of colours, 0
     int o_idest, o_iunit, o_iitem;   // o_idest: n_imu x 32 tangent index of each local column (-1 constant); o_iunit: n_imu colours
     int n_idest, n_iunit, n_iitem;
+    int n_frames, o_frames;   // n_frames x 2 : ambient offset of para_Pose[i], para_SpeedBias[i] (-1: not in the problem)
     int plan_ints;  // total ints of this plan (header excluded)
 };
 

@@ -37,6 +37,7 @@ EXPORTS = [
     "tcv_batch_download_states", "tcv_batch_get_summaries", "tcv_batch_get_prior", "tcv_batch_get_first_step",
     "tcv_batch_plan_stats", "tcv_batch_stats", "tcv_batch_size",
     "tcv_eval_imu_factors", "tcv_eval_projection_factors", "tcv_eval_line_factors", "tcv_pose_plus", "tcv_preintegrate",
+    "tcv_problem_set_frames", "tcv_gauge_fix", "tcv_batch_gauge_fix",
 ]
 
 
@@ -137,6 +138,9 @@ def lib():
         L.tcv_eval_line_factors.argtypes = [C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
         L.tcv_pose_plus.argtypes = [C.c_int, _dp, _dp, _dp]
         L.tcv_preintegrate.argtypes = [C.c_int, _ip, _ip, _dp, C.c_int, _dp, _dp, C.POINTER(ImuPreintegration)]
+        L.tcv_problem_set_frames.argtypes = [vp, C.c_int, C.POINTER(_dp), C.POINTER(_dp)]
+        L.tcv_gauge_fix.argtypes = [C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
+        L.tcv_batch_gauge_fix.argtypes = [vp, vp]
         _lib = L
     return _lib
 
@@ -315,6 +319,22 @@ def margin_old_window(win: dict) -> dict:
     return out
 
 
+def margin_second_new_window(win: dict) -> dict:
+    """MARGIN_SECOND_NEW (estimator.cpp:2047-2113): MarginalizationInfo receives only the old prior."""
+    im, pr, ln = win["imu"], win["proj"], win["line"]
+    none = np.zeros(0, int)
+    out = dict(win)
+    out["imu"] = {k: (np.asarray(v)[none] if isinstance(v, np.ndarray) and v.shape[:1] == (len(im["frame_i"]),) else v) for k, v in im.items()}
+    out["proj"] = {k: (np.asarray(v)[none] if isinstance(v, np.ndarray) and v.shape[:1] == (len(pr["frame_i"]),) else v) for k, v in pr.items()}
+    out["line"] = dict(ln, frame=np.zeros(0, int), pts_start=np.zeros((0, 3)), pts_end=np.zeros((0, 3)), abc=np.zeros((0, 3)))
+    return out
+
+
+def margin_second_new_drops(w: "Window"):
+    """drop set of estimator.cpp:2057-2063: para_Pose[WINDOW_SIZE - 1]."""
+    return [w.block_ptr("pose", w.pose.shape[0] - 2)]
+
+
 def margin_old_drops(w: "Window", mwin: dict):
     """drop sets of estimator.cpp:1918-1924 (prior), :1939-1941 (IMU) and :1983-1985 (points): pose 0, speed-bias 0
     and the inverse depths of the landmarks anchored in frame 0."""
@@ -371,6 +391,10 @@ class Batch:
 
     def marginalize(self, stream=None):
         check(lib().tcv_batch_marginalize(self.h, stream))
+
+    def gauge_fix(self, stream=None):
+        """Estimator::double2vector() + vector2double() in place on the solved states in HBM (estimator.cpp:1537-1581)."""
+        check(lib().tcv_batch_gauge_fix(self.h, stream))
 
     def synchronize(self):
         check(lib().tcv_batch_synchronize(self.h))
@@ -468,3 +492,13 @@ def preintegrate(acc, gyr, dt, lin_ba, lin_bg, noise):
                 lin_bg=np.array([list(o.linearized_bg) for o in out]), sum_dt=np.array([o.sum_dt for o in out]),
                 jacobian=np.array([list(o.jacobian) for o in out]).reshape(n, 15, 15),
                 covariance=np.array([list(o.covariance) for o in out]).reshape(n, 15, 15))
+
+
+def gauge_fix(R0, P0, pose, sb):
+    """Estimator::double2vector() (estimator.cpp:1537-1581) on the GPU: returns Rs (n,3,3), Ps, Vs and the para_Pose
+    the next vector2double() writes."""
+    pose = f64(pose); sb = f64(sb); R0 = f64(R0).reshape(9); P0 = f64(P0)
+    n = pose.shape[0]
+    Rs = np.zeros((n, 3, 3)); Ps = np.zeros((n, 3)); Vs = np.zeros((n, 3)); po = np.zeros((n, 7))
+    check(lib().tcv_gauge_fix(n, dptr(R0), dptr(P0), dptr(pose), dptr(sb), dptr(Rs), dptr(Ps), dptr(Vs), dptr(po)))
+    return Rs, Ps, Vs, po

@@ -98,6 +98,44 @@ def test_prior_round_trip_and_chained_solve(gpu):
     assert rel(Wn.pose, O.states()["pose"]) < 1e-5
 
 
+def test_margin_second_new_prior_only(gpu):
+    """MARGIN_SECOND_NEW (estimator.cpp:2047-2113): only the old prior is marginalised, dropping para_Pose[WINDOW_SIZE-1]
+    (m = 6); kept blocks keep their frame index (addr_shift :2084-2104)."""
+    import np_oracle as NO
+    pre, main, z = golden_windows()
+    Oc = orc.Window(main); Oc.solve(8, True); st = Oc.states()
+    w2 = dict(main, pose=st["pose"], speedbias=st["sb"], ex_pose=st["ex"], lam=st["lam"])
+    prob = NO.Problem(w2)
+    po, dbg = NO.marginalize_second_new(prob, prob.x0())
+    mw = gpu.margin_second_new_window(w2)
+    Wm = gpu.Window(mw)
+    assert gpu.lib().tcv_problem_num_residual_blocks(Wm.h) == 1
+    dr = gpu.margin_second_new_drops(Wm)
+    arr = (gpu._dp * len(dr))(*dr)
+    h = C.c_void_p()
+    gpu.check(gpu.lib().tcv_marginalize(Wm.h, arr, len(dr), C.byref(h)))
+    P = gpu.Prior(h); d = P.export(); As, bs = P.schur()
+    assert (d["m"], d["n"]) == (6, po["n"]) == (6, main["prior"]["n"] - 6)
+    assert d["sizes"] == po["sizes"] and d["idx"] == po["idx"]
+    assert fro(As, dbg["A_schur"]) < 1e-5 and fro(bs, dbg["b_schur"]) < 1e-6
+    assert fro(d["J0"].T @ d["J0"], po["J0"].T @ po["J0"]) < 1e-5
+    assert fro(d["J0"].T @ d["r0"], po["J0"].T @ po["r0"]) < 1e-3
+    assert rel(np.concatenate(d["x0"]), np.concatenate([np.atleast_1d(v) for v in po["x0"]])) == 0.0
+    # kept blocks: every prior block except pose WINDOW_SIZE-1, un-shifted
+    W = main["pose"].shape[0] - 1
+    assert po["blocks"] == [b for b in main["prior"]["blocks"] if tuple(b) != ("pose", W - 1)]
+    base = {"pose": (Wm.pose.ctypes.data, 56), "sb": (Wm.sb.ctypes.data, 72), "ex": (Wm.ex.ctypes.data, 56)}
+    addrs = (gpu._dp * len(d["sizes"]))()
+    gpu.check(gpu.lib().tcv_prior_keep_block_addresses(P.h, addrs))
+    got = []
+    for a in addrs:
+        a = C.cast(a, C.c_void_p).value
+        for nm, (b0, stride) in base.items():
+            if b0 <= a < b0 + stride * (11 if nm != "ex" else 1):
+                got.append((nm, (a - b0) // stride))
+    assert got == [tuple(b) for b in po["blocks"]]
+
+
 def test_marginalise_error_paths(gpu):
     batch = synth.make_windows(901, 1)
     w = synth.window_at(batch, 0)

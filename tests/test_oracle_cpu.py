@@ -189,3 +189,24 @@ def test_eig_sym_reconstructs(lib):
         Vm = V.reshape(n, n).T        # column-major
         assert np.all(np.diff(ev) >= 0)
         assert rel(Vm @ np.diag(ev) @ Vm.T, A) < 1e-12
+
+
+def test_margin_second_new_oracle_invariants(lib):
+    """MARGIN_SECOND_NEW (estimator.cpp:2047-2113): prior-only marginalisation of para_Pose[WINDOW_SIZE-1]; the reference's
+    documented invariants J0'J0 = A', J0'r0 = b' (marginalization_factor.cpp:297-298) and the Schur identity hold."""
+    import np_oracle as NO
+    import orc
+    from util import fro, golden_windows
+    pre, main, z = golden_windows()
+    Oc = orc.Window(main); Oc.solve(8, True); st = Oc.states()
+    w2 = dict(main, pose=st["pose"], speedbias=st["sb"], ex_pose=st["ex"], lam=st["lam"])
+    prob = NO.Problem(w2)
+    po, dbg = NO.marginalize_second_new(prob, prob.x0())
+    assert (po["m"], po["n"]) == (6, main["prior"]["n"] - 6)
+    assert ("pose", main["pose"].shape[0] - 2) not in [tuple(b) for b in po["blocks"]]
+    assert fro(po["J0"].T @ po["J0"], dbg["A_schur"]) < 1e-9 and fro(po["J0"].T @ po["r0"], dbg["b_schur"]) < 1e-9
+    # before the Schur complement the system is the old prior's own J0'J0 / J0'r at the current states
+    r, Js, _ = prob.eval_factor(prob.factors()[0], prob.x0(), True)
+    assert abs(np.trace(dbg["A"]) - sum(np.sum(J[:, :6 if J.shape[1] == 7 else J.shape[1]] ** 2) for J in Js)) < 1e-6 * np.trace(dbg["A"])
+    # a window without a prior on pose WINDOW_SIZE-1 marginalises nothing (:2049-2050)
+    assert NO.marginalize_second_new(NO.Problem(pre), NO.Problem(pre).x0()) == (None, None)
