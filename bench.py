@@ -139,6 +139,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--windows", type=int, default=1024, help="independent windows per GPU per step")
     ap.add_argument("--threads", type=int, default=256)
+    ap.add_argument("--variant", type=int, default=0, help="0: chain layout (default, two windows per CU), 1: dense 171-dim layout (cross-check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
@@ -150,6 +151,7 @@ def main():
     if tcv.lib().tcv_device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
     tcv.check(tcv.lib().tcv_set_device(local))
+    tcv.check(tcv.lib().tcv_set_solver_variant(args.variant))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     B = args.windows

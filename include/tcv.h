@@ -106,6 +106,10 @@ const char *tcv_version(void);
 const char *tcv_last_error(void);
 int tcv_device_count(void);            /* 0 when no HIP device is visible */
 int tcv_set_device(int device);
+/* 0 (default): batches whose speed-bias blocks form chains (every window OptimizationWithLine builds) use the chain layout
+ * of the fused solver (speed-biases eliminated block by block before the dense pose system, two windows per CU);
+ * 1: always the dense 171-dim layout (one window per CU; cross-check / arbitrary graphs).  Read at tcv_batch_create. */
+int tcv_set_solver_variant(int variant);
 
 /* ---- ceres::Problem surface (estimator.cpp:1679-1886) ---------------------------------------- */
 int tcv_problem_create(tcv_problem **out);
@@ -187,6 +191,9 @@ int tcv_batch_synchronize(tcv_batch *b);
 int tcv_batch_download_states(tcv_batch *b);
 int tcv_batch_get_summaries(tcv_batch *b, tcv_solver_summary *out, int n);
 int tcv_batch_get_prior(tcv_batch *b, int window, tcv_prior **out);
+/* per-window status of the last marginalisation: 0 ok, 1 an eigen-solver hit its sweep cap, 2 result produced by the
+ * cyclic-Jacobi safety net (the tridiagonal eigen-solver failed its orthogonality / trace self-check) */
+int tcv_batch_marg_status(tcv_batch *b, int *out, int n);
 /* tangent step of iteration 1 (needs record_first_step): free camera blocks in the order they were
  * added (local size each), then the inverse depths in order of first use.  Parity/debug surface. */
 int tcv_batch_get_first_step(tcv_batch *b, int window, double *out, int cap, int *len);

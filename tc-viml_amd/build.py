@@ -37,16 +37,31 @@ def build(force: bool = False, verbose: bool = False, profile: bool = False) -> 
 
 
 def _compile(out: str, verbose: bool, extra) -> str:
+    """One object per source (compiled in parallel), then one link.  tcv_solve.hip is compiled twice: the dense kernels, and
+    (-DTCV_SOLVE_CHAIN_TU) the chain kernel alone in its own translation unit so that its 2-waves-per-SIMD register budget
+    is not widened by the other instantiations' call trees."""
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    srcs = [os.path.join(CSRC, f) for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=on",
-           "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-value", "-Wno-unused-result", "-x", "hip"]
-    if any(s.endswith("tcv_marg.hip") for s in srcs):
-        cmd.append("-DTCV_HAVE_MARG=1")
+    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on",
+            "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-value", "-Wno-unused-result", "-x", "hip"]
+    if os.path.exists(os.path.join(CSRC, "tcv_marg.hip")):
+        base.append("-DTCV_HAVE_MARG=1")
     if verbose:
-        cmd.append("-Rpass-analysis=kernel-resource-usage")
-    cmd += list(extra) + srcs + ["-o", out]
-    subprocess.check_call(cmd)
+        base.append("-Rpass-analysis=kernel-resource-usage")
+    base += list(extra)
+    objdir = os.path.join(HERE, "build", os.path.basename(out).replace(".so", ""))
+    os.makedirs(objdir, exist_ok=True)
+    jobs = [(f, os.path.join(objdir, f + ".o"), []) for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
+    jobs.append(("tcv_solve.hip", os.path.join(objdir, "tcv_solve_chain.o"), ["-DTCV_SOLVE_CHAIN_TU=1"]))
+
+    def one(job):
+        src, obj, flags = job
+        subprocess.check_call(base + flags + ["-c", os.path.join(CSRC, src), "-o", obj])
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+        objs = list(ex.map(one, jobs))
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out])
     return out
 
 

@@ -17,6 +17,7 @@
 
 extern "C" int tcv_launch_solve(const tcv::SolveArgs *args, int grid, int nthreads, size_t lds_bytes, void *stream);
 extern "C" int tcv_solve_scratch_doubles(void);
+static int g_solver_variant = 0;   // 0: chain layout when the graph allows it, 1: always the dense 171-dim layout
 extern "C" int tcv_launch_marg(const void *args, int grid, size_t lds_bytes, void *stream);
 
 namespace tcv {
@@ -52,6 +53,11 @@ extern "C" int tcv_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+extern "C" int tcv_set_solver_variant(int variant) {
+    if (variant != 0 && variant != 1) return TCV_ERR_INVALID;
+    g_solver_variant = variant;
+    return TCV_OK;
 }
 extern "C" int tcv_set_device(int device) {
     if (int rc = device_ready()) return rc;
@@ -190,12 +196,13 @@ extern "C" int tcv_problem_num_residuals(const tcv_problem *p) {
 extern "C" int tcv_problem_plan_stats(const tcv_problem *p, int *out) {
     if (!p || !out) return TCV_ERR_INVALID;
     Packed pk;
-    const int rc = pack_problem(*p, pk, nullptr);
+    const int rc = pack_problem(*p, pk, nullptr, g_solver_variant);
     if (rc != TCV_OK) return rc;
     const PlanHdr &H = pk.hdr;
-    const int v[16] = {H.nc, H.nx, H.npp, H.nland, H.nt, H.n_vis_chunk, H.n_imu_chunk, H.n_vunit, H.n_vitem, H.n_sunit, H.n_sitem,
-                       H.n_iunit, H.n_iitem, H.plan_ints, pk.win.n_doubles,
-                       (H.nt * (H.nt + 1) / 2 * 256 + 2 * ((H.nx + H.nland + 1) & ~1) + 4 * 176 + 64 + H.lds_area) * 8};
+    const int v[16] = {H.nc, H.nx, H.npp, H.nland, H.chain ? H.nt_c : H.nt, H.n_vis_chunk, H.n_imu_chunk, H.n_vunit, H.n_vitem, H.n_sunit, H.n_sitem,
+                       H.chain ? H.n_e : H.n_iunit, H.n_iitem, H.plan_ints, pk.win.n_doubles,
+                       H.chain ? chain_lds_doubles() * 8
+                               : (H.nt * (H.nt + 1) / 2 * 256 + 2 * ((H.nx + H.nland + 1) & ~1) + 4 * 176 + 64 + H.lds_area) * 8};
     std::memcpy(out, v, sizeof v);
     return TCV_OK;
 }
@@ -303,6 +310,7 @@ extern "C" void tcv_prior_destroy(tcv_prior *pr) { delete pr; }
 static void batch_free(tcv_batch *b) {
     if (!b) return;
     hipFree(b->d_win); hipFree(b->d_plans); hipFree(b->d_plan_base); hipFree(b->d_ipool); hipFree(b->d_dpool);
+    hipFree(b->d_imublk); hipFree(b->d_spill);
     hipFree(b->d_prof); hipFree(b->d_state); hipFree(b->d_delta); hipFree(b->d_scratch); hipFree(b->d_summary);
     if (b->ev0) hipEventDestroy(b->ev0);
     if (b->ev1) hipEventDestroy(b->ev1);
@@ -324,10 +332,28 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
     std::vector<double> dpool;
     int max_state = 0, max_nl = 0;
     size_t max_lds = 0;
+    int mode = g_solver_variant;
+    if (mode == 0)      // the chain layout is used only if every window of the batch allows it (structure-only question)
+        for (int w = 0; w < n && mode == 0; w++) {
+            if (w > 0 && problems[w]->imu.size() == problems[0]->imu.size() && problems[w]->proj.size() == problems[0]->proj.size() &&
+                problems[w]->prior.size() == problems[0]->prior.size() && problems[w]->blocks.size() == problems[0]->blocks.size())
+                continue;      // same shape as window 0: verified by the packing pass below
+            Packed pk;
+            const int rc = pack_problem(*problems[w], pk, nullptr, 0);
+            if (rc != TCV_OK) { batch_free(b); return rc; }
+            if (!pk.hdr.chain) mode = 1;
+        }
+    b->chain = (mode == 0);
     for (int w = 0; w < n; w++) {
         Packed &pk = b->packed[w];
-        const int rc = pack_problem(*problems[w], pk, nullptr);
+        const int rc = pack_problem(*problems[w], pk, nullptr, mode);
         if (rc != TCV_OK) { batch_free(b); return rc; }
+        if (mode == 0 && !pk.hdr.chain) {      // a same-shaped window turned out not to be chain-eligible: start over with the dense layout
+            mode = 1; b->chain = false; w = -1;
+            b->plans.clear(); b->plan_base.clear(); b->wins.clear(); plan_index.clear(); ipool.clear(); dpool.clear();
+            max_state = max_nl = 0; max_lds = 0; b->input_bytes = 0; b->spill_stride = 0;
+            continue;
+        }
         std::vector<int> key(pk.ints);
         const int *hp = reinterpret_cast<const int *>(&pk.hdr);
         key.insert(key.end(), hp, hp + sizeof(PlanHdr) / sizeof(int));
@@ -347,8 +373,10 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
         max_state = std::max(max_state, pk.hdr.nx + pk.hdr.nland);
         max_nl = std::max(max_nl, pk.hdr.nc + pk.hdr.nland);
         const int nt = pk.hdr.nt;
-        const size_t lds = (size_t)(nt * (nt + 1) / 2 * 256 + 2 * ((pk.hdr.nx + pk.hdr.nland + 1) & ~1) + 4 * 176 + 64 + pk.hdr.lds_area) * 8;
+        const size_t lds = b->chain ? (size_t)chain_lds_doubles() * 8
+                                    : (size_t)(nt * (nt + 1) / 2 * 256 + 2 * ((pk.hdr.nx + pk.hdr.nland + 1) & ~1) + 4 * 176 + 64 + pk.hdr.lds_area) * 8;
         max_lds = std::max(max_lds, lds);
+        b->spill_stride = std::max(b->spill_stride, pk.hdr.c_spill);
         pk.ints.clear(); pk.ints.shrink_to_fit();
         b->input_bytes += 8.0 * pk.doubles.size();
         pk.doubles.clear(); pk.doubles.shrink_to_fit();
@@ -362,7 +390,7 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
     int dev = 0;
     hipGetDevice(&dev);
     hipGetDeviceProperties(&prop, dev);
-    b->grid = std::min(n, prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
+    b->grid = std::min(n, (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256) * (b->chain ? 2 : 1));
     const int scr = tcv_solve_scratch_doubles();
 #define UP(dst, src, T, cnt)                                                                          \
     do {                                                                                              \
@@ -383,6 +411,10 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
     UP(b->d_scratch, (double *)nullptr, double, (size_t)b->grid * scr);
     UP(b->d_summary, (DevSummary *)nullptr, DevSummary, (size_t)n);
     UP(b->d_prof, (double *)nullptr, double, (size_t)32 * b->grid);
+    if (b->chain) {
+        UP(b->d_imublk, (double *)nullptr, double, (size_t)b->grid * 16 * IMU_BLK);
+        UP(b->d_spill, (double *)nullptr, double, (size_t)b->grid * b->spill_stride);
+    }
     hipMemset(b->d_prof, 0, sizeof(double) * 32 * b->grid);
 #undef UP
     hipMemset(b->d_scratch, 0, sizeof(double) * (size_t)b->grid * scr);
@@ -421,9 +453,10 @@ extern "C" int tcv_batch_solve(tcv_batch *b, const tcv_solver_options *o, void *
     a.prof = b->d_prof;
     a.nwin = b->n; a.state_stride = b->state_stride; a.delta_stride = b->delta_stride; a.scratch_stride = tcv_solve_scratch_doubles();
     a.max_iterations = o->max_num_iterations; a.fixed_iterations = o->fixed_iterations; a.use_mfma = o->use_mfma;
+    a.chain = b->chain ? 1 : 0; a.imublk = b->d_imublk; a.spill = b->d_spill; a.spill_stride = b->spill_stride;
     hipStream_t st = (hipStream_t)hip_stream;
     HIPCHK(hipEventRecord(b->ev0, st));
-    const int rc = tcv_launch_solve(&a, b->grid, o->threads_per_window == 512 ? 512 : 256, b->lds_bytes, hip_stream);
+    const int rc = tcv_launch_solve(&a, b->grid, (!b->chain && o->threads_per_window == 512) ? 512 : 256, b->lds_bytes, hip_stream);
     if (rc != 0) return hip_fail((hipError_t)rc, "solve kernel launch");
     HIPCHK(hipEventRecord(b->ev1, st));
     b->solved = true;

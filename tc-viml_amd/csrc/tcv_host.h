@@ -84,6 +84,9 @@ struct tcv_batch {
     bool solved = false;
     std::vector<double> h_state;
     bool gauge_fixed = false;
+    bool chain = false;                   // all plans use the chain layout (2 workgroups per CU)
+    double *d_imublk = nullptr, *d_spill = nullptr;   // chain mode: per-workgroup IMU J'J blocks and factored fronts
+    int spill_stride = 0;
     // marginalisation
     void *marg = nullptr;                 // tcv_marg.hip state
     void (*marg_free)(tcv_batch *) = nullptr;
@@ -100,5 +103,6 @@ int hip_fail(hipError_t e, const char *what);
 int device_ready();
 void set_error(const std::string &s);
 // returns TCV_OK or a negative status; fills out.  imu_sqrt: optional host-provided sqrt_info (n_imu x 225).
-int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt);
+// mode: 0 = chain layout when the graph allows it (speed-bias blocks form chains), else dense; 1 = dense layout
+int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int mode = 0);
 }  // namespace tcv

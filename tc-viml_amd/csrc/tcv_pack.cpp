@@ -2,6 +2,7 @@
 // (tcv_packed.h).  Everything structural that the reference redoes per frame through
 // AddParameterBlock / AddResidualBlock pointer chasing is resolved here, once, into flat gather lists.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <tuple>
@@ -9,6 +10,18 @@
 #include "tcv_host.h"
 
 namespace tcv {
+
+// Two chain-mode workgroups share one CU's 160 KiB of LDS.  TCV_CHAIN_LDS_DOUBLES overrides the per-workgroup size (tuning).
+int chain_lds_doubles() {
+    static int v = 0;
+    if (v == 0) {
+        const char *e = getenv("TCV_CHAIN_LDS_DOUBLES");
+        v = e ? atoi(e) : LDS_DOUBLES / 2;
+        if (v < 6144 || v > LDS_DOUBLES) v = LDS_DOUBLES / 2;
+        v &= ~1;
+    }
+    return v;
+}
 
 namespace {
 
@@ -102,7 +115,7 @@ void add_pairs(DestList &dl, const std::vector<Col> &cols, MakeItem mk, int rcol
 
 }  // namespace
 
-int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt) {
+int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int mode) {
     const int nb = (int)p.blocks.size();
     // ---- classify blocks: landmarks = size-1 Euclidean blocks used only as 4th block of projection factors
     std::vector<int> use_lm(nb, 0), use_other(nb, 0);
@@ -158,9 +171,62 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt) {
     const int ntiles = nt * (nt + 1) / 2, pp_tiles = ntp * (ntp + 1) / 2;
     if (nc > 175 || npp > 88 || nc + L > SCR_NL || L > 1024) { set_error("window too large for the fused solver (camera tangent dim > 175)"); return TCV_ERR_TOO_LARGE; }
     const int nxl = (nx + L + 1) & ~1;
-    const int area_cap = LDS_DOUBLES - ntiles * 256 - 2 * nxl - 4 * 176 - 64;
-    const int stage_cap = (ntiles - pp_tiles) * 256;
+    int area_cap = LDS_DOUBLES - ntiles * 256 - 2 * nxl - 4 * 176 - 64;
+    int stage_cap = (ntiles - pp_tiles) * 256;
     if (area_cap < 512) { set_error("window too large for the fused solver (LDS)"); return TCV_ERR_TOO_LARGE; }
+
+    // ---- chain layout: the free Euclidean camera blocks (speed-biases, 9 wide) only meet their IMU neighbours and the
+    // prior, so they are eliminated one after the other BEFORE the dense pose system (block-sparse Cholesky with the poses
+    // ordered last, what SPARSE_SCHUR's reduced-camera factorisation exploits too).  Symbolic elimination at block level:
+    // eligible iff every Euclidean block has at most one later-eliminated Euclidean neighbour and that one is next in order.
+    struct ChainStep { int cam, t0; std::vector<int> prow_t; bool next; int nsrc, f[2], lc[2]; };
+    std::vector<ChainStep> chain;
+    bool use_chain = (mode == 0);
+    std::vector<int> eorder;
+    if (use_chain) {
+        std::vector<char> in_prior(nblk, 0);
+        if (!p.prior.empty()) for (int b : p.prior[0].b) if (cam_of[b] >= 0) in_prior[cam_of[b]] = 1;
+        for (int c = nblk - 1; c >= 0; c--) if (kind[c] != KIND_POSE && loff[c] >= 0 && !in_prior[c]) eorder.push_back(c);
+        for (int c = nblk - 1; c >= 0; c--) if (kind[c] != KIND_POSE && loff[c] >= 0 && in_prior[c]) eorder.push_back(c);
+        for (int c : eorder) if (gsize[c] != CH_W) use_chain = false;
+        if (eorder.empty() || eorder.size() > 16 || npp < 1) use_chain = false;
+    }
+    if (use_chain) {
+        const int ne = (int)eorder.size();
+        std::vector<int> pos(nblk, -1);
+        for (int s2 = 0; s2 < ne; s2++) pos[eorder[s2]] = s2;
+        std::vector<std::vector<char>> adj(nblk, std::vector<char>(nblk, 0));
+        auto link = [&](const std::vector<int> &bs) { for (int a2 : bs) for (int b2 : bs) if (a2 != b2 && loff[a2] >= 0 && loff[b2] >= 0) adj[a2][b2] = 1; };
+        for (auto &f : p.imu) link({cam_of[f.b[0]], cam_of[f.b[1]], cam_of[f.b[2]], cam_of[f.b[3]]});
+        if (!p.prior.empty()) { std::vector<int> bs; for (int b : p.prior[0].b) bs.push_back(cam_of[b]); link(bs); }
+        for (int s2 = 0; s2 < ne && use_chain; s2++) {
+            const int e = eorder[s2];
+            ChainStep st;
+            st.cam = e; st.t0 = loff[e]; st.next = false; st.nsrc = 0; st.f[0] = st.f[1] = 0; st.lc[0] = st.lc[1] = 0;
+            std::vector<int> later;
+            for (int x = 0; x < nblk; x++) if (adj[e][x] && pos[x] > s2) later.push_back(x);
+            if (later.size() > 1 || (later.size() == 1 && pos[later[0]] != s2 + 1)) { use_chain = false; break; }
+            st.next = !later.empty();
+            std::vector<int> prow;
+            for (int x = 0; x < nblk; x++) if (adj[e][x] && kind[x] == KIND_POSE) prow.push_back(x);
+            std::sort(prow.begin(), prow.end(), [&](int a2, int b2) { return loff[a2] < loff[b2]; });
+            for (int x : prow) for (int j = 0; j < 6; j++) st.prow_t.push_back(loff[x] + j);
+            // fill: the eliminated block's neighbours become a clique (pose-pose is dense anyway)
+            for (int x : later) for (int y : prow) { adj[x][y] = 1; adj[y][x] = 1; }
+            for (size_t k = 0; k < p.imu.size(); k++)
+                for (int sl = 1; sl < 4; sl += 2)
+                    if (cam_of[p.imu[k].b[sl]] == e) {
+                        if (st.nsrc >= 2) { use_chain = false; break; }
+                        st.f[st.nsrc] = (int)k; st.lc[st.nsrc] = sl == 1 ? 6 : 21; st.nsrc++;
+                    }
+            if (CH_W + (st.next ? CH_W : 0) + (int)st.prow_t.size() + 1 > CH_MAXROWS) use_chain = false;
+            chain.push_back(st);
+        }
+    }
+    const int nt_c = (npp + 1 + 15) / 16, ctiles = nt_c * (nt_c + 1) / 2;
+    const int c_vec = 2 * nxl + 4 * 176 + 64 + 112;
+    const int c_pool = chain_lds_doubles() - ctiles * 256 - c_vec;
+    if (use_chain && (c_pool < 2 * CH_MAXROWS * CH_W + 16 + 8 * CH_STRIDE + 64 || c_pool < IMU_REC)) use_chain = false;
 
     PlanHdr &H = out.hdr;
     std::memset(&H, 0, sizeof(H));
@@ -245,7 +311,8 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt) {
     // gather program (units + items), so both count against the capacity.
     struct VChunk { int pb, pn, lb, ln, lmb, lmn; };
     std::vector<VChunk> vch;
-    {
+    auto build_chunks = [&](int stage_cap, int area_cap, std::vector<VChunk> &vch) -> int {
+        vch.clear();
         const int nline = (int)p.line.size();
         const int npose = npp / 6;
         const int base_prog = 3 * (npose * (npose + 1) / 2 * 6 + npose) ;      // upper bound on tile + gradient units
@@ -254,20 +321,42 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt) {
             return ((recs + 1) & ~1) + (ints + 1) / 2 + 8;
         };
         if (need(nline * LINE_REC, 0, 0, 0, nline) > stage_cap) { set_error("too many line factors for LDS staging"); return TCV_ERR_TOO_LARGE; }
-        VChunk cur{0, 0, 0, nline, 0, 0};
-        int recs = nline * LINE_REC, hcl = 0, nf_c = 0, slots_c = 0, nln_c = nline;
+        // whole landmarks per chunk, greedily; the line factors ride in the LAST chunk (the least full one) if they fit
+        VChunk cur{0, 0, 0, 0, 0, 0};
+        int recs = 0, hcl = 0, nf_c = 0, slots_c = 0;
         for (int l = 0; l < L; l++) {
             const int nf = lmptr[l + 1] - lmptr[l], ns = (int)lm_slots[l].size(), nh = 6 * ns + 2;
             if (need(nf * PROJ_REC, nf, 1, ns, 0) > stage_cap || nh + 3 > area_cap) { set_error("landmark track too long for LDS staging"); return TCV_ERR_TOO_LARGE; }
-            if (need(recs + nf * PROJ_REC, nf_c + nf, cur.lmn + 1, slots_c + ns, nln_c) > stage_cap || hcl + nh + 3 * (cur.lmn + 1) > area_cap) {
+            if (need(recs + nf * PROJ_REC, nf_c + nf, cur.lmn + 1, slots_c + ns, 0) > stage_cap || hcl + nh + 3 * (cur.lmn + 1) > area_cap) {
                 vch.push_back(cur);
                 cur = VChunk{lmptr[l], 0, 0, 0, l, 0};
-                recs = 0; hcl = 0; nf_c = 0; slots_c = 0; nln_c = 0;
+                recs = 0; hcl = 0; nf_c = 0; slots_c = 0;
             }
             cur.pn += nf; cur.lmn += 1; recs += nf * PROJ_REC; hcl += nh; nf_c += nf; slots_c += ns;
         }
+        if (nline > 0 && need(recs + nline * LINE_REC, nf_c, cur.lmn, slots_c, nline) > stage_cap) {
+            vch.push_back(cur);
+            cur = VChunk{lmptr[L], 0, 0, 0, L, 0};
+        }
+        cur.ln = nline;
         vch.push_back(cur);
+        return TCV_OK;
+    };
+    if (use_chain) {      // split the LDS pool between staging and the landmark coupling area: fewest chunks wins
+        int best = -1, best_n = 1 << 30;
+        std::vector<VChunk> tmp;
+        for (int ac = 320; ac <= c_pool - 1024; ac += 160) {
+            if (build_chunks(c_pool - ac, ac, tmp) != TCV_OK) continue;
+            if ((int)tmp.size() < best_n) { best_n = (int)tmp.size(); best = ac; }
+        }
+        if (best < 0) use_chain = false;
+        else { area_cap = best; stage_cap = c_pool - best; }
     }
+    if (!use_chain) chain.clear();
+    { const int rc = build_chunks(stage_cap, area_cap, vch); if (rc != TCV_OK) return rc; }
+    set_error("");
+    H.chain = use_chain ? 1 : 0; H.n_e = (int)chain.size(); H.nt_c = nt_c; H.c_stage_cap = stage_cap; H.c_area_cap = area_cap; H.c_pool = c_pool;
+    if (use_chain) H.lds_area = area_cap;
     H.n_vis_chunk = (int)vch.size();
     std::vector<int> vprog, sprog, vchunk_tab;
     for (auto &c : vch) {
@@ -335,14 +424,17 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt) {
     H.o_sdest = mark(); I.insert(I.end(), sprog.begin(), sprog.end()); H.n_sdest = 0;
     H.o_sunit = H.o_sdest; H.n_sunit = (int)sprog.size(); H.o_sitem = H.o_sdest; H.n_sitem = 0;
 
+    std::vector<int> imap_all;
     // ---- IMU chunks.  Per factor: the tangent index of each of its 30 local Jacobian columns (-1 for a constant
     // block) and a colour; factors of one colour share no parameter block, so their J'J tiles can be scattered into the
     // reduced camera system concurrently (the frame chain needs two colours).
     {
-        const int per = std::max(1, std::min(H.n_imu, area_cap / IMU_REC));
-        if (H.n_imu > 0 && area_cap < IMU_REC) { set_error("no LDS room for IMU staging"); return TCV_ERR_TOO_LARGE; }
+        const int imu_cap = use_chain ? c_pool : area_cap;       // chain mode: the whole pool holds IMU records
+        const int per = std::max(1, std::min(H.n_imu, imu_cap / IMU_REC));
+        if (H.n_imu > 0 && imu_cap < IMU_REC) { set_error("no LDS room for IMU staging"); return TCV_ERR_TOO_LARGE; }
         if (H.n_imu > 16) { set_error("more than 16 IMU factors"); return TCV_ERR_TOO_LARGE; }
-        std::vector<int> imap, icolor(H.n_imu, 0), ichunk;
+        std::vector<int> &imap = imap_all;
+        std::vector<int> icolor(H.n_imu, 0), ichunk;
         for (int fb = 0; fb < H.n_imu; fb += per) {
             const int fn = std::min(per, H.n_imu - fb);
             int ncol = 0;
@@ -383,6 +475,53 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt) {
         H.o_iunit = mark(); I.insert(I.end(), icolor.begin(), icolor.end()); H.n_iunit = (int)icolor.size();
         H.o_iitem = H.o_iunit; H.n_iitem = 0;
         H.o_ichunk = mark(); I.insert(I.end(), ichunk.begin(), ichunk.end());
+    }
+    // ---- chain step tables
+    while ((I.size() & 3) != 0) I.push_back(0);
+    H.o_chain = mark();
+    if (use_chain) {
+        const int ne = (int)chain.size();
+        std::vector<int> tab((size_t)ne * CH_STRIDE, 0);
+        std::vector<int> pinv(nc + 1, -1);
+        for (size_t j = 0; j < pcol.size(); j++) if (pcol[j] >= 0) pinv[pcol[j]] = (int)j;
+        int spill = 0;
+        std::vector<std::vector<int>> rowt(ne);
+        for (int s2 = 0; s2 < ne; s2++) {
+            const ChainStep &st = chain[s2];
+            std::vector<int> &rt = rowt[s2];
+            for (int j = 0; j < CH_W; j++) rt.push_back(st.t0 + j);
+            if (st.next) for (int j = 0; j < CH_W; j++) rt.push_back(chain[s2 + 1].t0 + j);
+            for (int t : st.prow_t) rt.push_back(t);
+            rt.push_back(-2);
+        }
+        for (int s2 = 0; s2 < ne; s2++) {
+            const ChainStep &st = chain[s2];
+            const std::vector<int> &rt = rowt[s2];
+            const int nr = (int)rt.size();
+            int *h = tab.data() + (size_t)s2 * CH_STRIDE;
+            h[CH_T0] = st.t0; h[CH_R] = nr - CH_W - 1; h[CH_NEXT] = st.next ? 1 : 0; h[CH_NSRC] = st.nsrc;
+            h[CH_F0] = st.f[0]; h[CH_LC0] = st.lc[0]; h[CH_F1] = st.f[1]; h[CH_LC1] = st.lc[1];
+            h[CH_PC0] = pinv[st.t0]; h[CH_SPILL] = spill;
+            spill += nr * CH_W + 16;
+            for (int r = 0; r < nr; r++) {
+                int vn = 255;
+                if (st.next) {
+                    const std::vector<int> &nx2 = rowt[s2 + 1];
+                    for (size_t q = 0; q < nx2.size(); q++) if (nx2[q] == rt[r]) vn = (int)q;
+                    if (r >= CH_W && vn == 255) { set_error("chain: fill row missing in the next front"); return TCV_ERR_INVALID; }
+                }
+                int l01[2] = {255, 255};
+                for (int src = 0; src < st.nsrc; src++)
+                    if (rt[r] >= 0)
+                        for (int l = 0; l < 30; l++) if (imap_all[(size_t)st.f[src] * 32 + l] == rt[r]) l01[src] = l;
+                const int tr = rt[r] >= 0 ? rt[r] : 255;
+                if (tr > 254 && rt[r] >= 0) { set_error("chain: tangent index overflow"); return TCV_ERR_TOO_LARGE; }
+                h[CH_INTS + 2 * r] = tr | (vn << 8) | (l01[0] << 16) | (l01[1] << 24);
+                h[CH_INTS + 2 * r + 1] = rt[r] >= 0 ? pinv[rt[r]] : -1;
+            }
+        }
+        H.c_spill = (spill + 1) & ~1;
+        I.insert(I.end(), tab.begin(), tab.end());
     }
     // ---- frame table (gauge fix, estimator.cpp:1537-1581)
     H.n_frames = (int)p.frame_pose.size();

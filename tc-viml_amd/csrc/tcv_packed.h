@@ -20,6 +20,7 @@ namespace tcv {
 enum { KIND_EUCLID = 0, KIND_POSE = 1 };
 enum { TILE = 16, TILE_ELEMS = 256 };
 enum { LDS_DOUBLES = 20480 };  // 160 KiB per workgroup on gfx950
+int chain_lds_doubles();       // LDS doubles of a chain-mode workgroup (two per CU); tcv_pack.cpp
 enum { MAX_TRACE = 64 };
 
 // staging record strides (doubles per residual row): Jacobian columns followed by the residual
@@ -80,6 +81,15 @@ struct PlanHdr {
     int o_ichunk;   // n_imu_chunk x 4 : fac_begin, fac_count, number of colours, 0
     int o_idest, o_iunit, o_iitem;   // o_idest: n_imu x 32 tangent index of each local column (-1 constant); o_iunit: n_imu colours
     int n_idest, n_iunit, n_iitem;
+    // chain mode (tcv_solve.hip, CHAIN = true): the Euclidean camera blocks (speed-biases) are eliminated one by one in a
+    // fixed order BEFORE the dense pose system; only the pose part (npp + 1 rhs row) lives in LDS tiles
+    int chain;          // 1: this plan was laid out for the chain kernel
+    int n_e;            // number of chain steps (= free Euclidean camera blocks, all 9 wide)
+    int nt_c;           // tile rows of the pose system (npp + 1 rhs row)
+    int c_stage_cap, c_area_cap;   // split of the LDS pool in the visual phase (doubles)
+    int c_pool;         // doubles of the LDS pool (staging | area | IMU records | fronts)
+    int c_spill;        // doubles of the L-column spill per workgroup
+    int o_chain;        // n_e x CH_STRIDE ints (16-byte aligned)
     int n_frames, o_frames;   // n_frames x 2 : ambient offset of para_Pose[i], para_SpeedBias[i] (-1: not in the problem)
     int plan_ints;  // total ints of this plan (header excluded)
 };
@@ -123,8 +133,29 @@ struct SolveArgs {
     double *scratch;              // per workgroup
     double *prof;                 // TCV_PROFILE builds: 32 cycle accumulators (lane 0 of every workgroup adds), else unused
     int nwin, state_stride, delta_stride, scratch_stride;
-    int max_iterations, fixed_iterations, use_mfma, pad;
+    int max_iterations, fixed_iterations, use_mfma, chain;
+    double *imublk;               // chain mode, per workgroup: 16 x IMU_BLK doubles (per-factor J'J | J'r blocks, 32 x 32 row-major)
+    double *spill;                // chain mode, per workgroup: factored fronts (spill_stride doubles)
+    int spill_stride, pad2;
 };
+
+// chain step record (CH_STRIDE ints per step, copied into LDS by the kernel): a header followed by two ints per front row.
+// The front of Euclidean block e_s is a (9 + R + 1) x 9 row-major matrix: rows 0..8 the block itself, then the
+// later-eliminated Euclidean block (0 or 9 rows), the pose rows (ascending tangent index), last the rhs.
+enum {
+    CH_T0 = 0,      // tangent offset of the block
+    CH_R,           // rows between the diagonal block and the rhs row
+    CH_NEXT,        // 1: rows 9..17 are the next step's block (its front receives the Schur update)
+    CH_NSRC,        // number of IMU factors touching the block (<= 2)
+    CH_F0, CH_LC0,  // factor index and local column of the block in it (6 or 21)
+    CH_F1, CH_LC1,
+    CH_PC0,         // prior column of the block's first tangent column (-1: not in the prior)
+    CH_SPILL,       // offset of the factored front in the spill area
+    CH_INTS = 16,   // row r: int 2r   = tangent index (rhs: 255) | row in the next front << 8 (255 none)
+                    //                   | local index in factor 0 << 16 (255 none) | local index in factor 1 << 24
+                    //        int 2r+1 = prior column of the row (-1 none)
+};
+enum { CH_W = 9, CH_MAXROWS = 96, CH_STRIDE = CH_INTS + 2 * CH_MAXROWS, IMU_BLK = 1024 };   // front rows incl. diagonal block and rhs <= 96; per-factor J'J block 32 x 32
 
 // per-workgroup global scratch layout (doubles)
 enum { SCR_NL = 1280 };  // capacity of an nl-sized vector (nc + nland)

@@ -48,7 +48,7 @@ __device__ __forceinline__ int tix(int a, int b) { return tbase(a >> 4, b >> 4) 
 #endif
 enum { PH_SETUP = 0, PH_VIS_EVAL, PH_VIS_GATHER, PH_LM, PH_SCHUR, PH_ZERO, PH_IMU_RAW, PH_IMU_WHITEN, PH_IMU_GATHER, PH_PRIOR,
        PH_COST_RED, PH_FIN_SCALE, PH_FIN_CAUCHY, PH_FIN_PASS, PH_CHOL_DIAG, PH_CHOL_TRSM, PH_CHOL_UPD, PH_BACK, PH_LM_BACK,
-       PH_DOGLEG, PH_PLUS, PH_NORMS, PH_OTHER, PH_COUNT = 32 };
+       PH_DOGLEG, PH_PLUS, PH_NORMS, PH_OTHER, PH_CHAIN_FWD, PH_CHAIN_BWD, PH_CH_A, PH_CH_B, PH_CH_C, PH_CH_D, PH_COUNT = 32 };
 
 template <int NT>
 struct Ctx {
@@ -64,6 +64,9 @@ struct Ctx {
     lds_d *gcam;     // camera part of the gradient J'r; shares the slot of invdiag (g is dead once the rhs row is written)
     lds_d *rc, *sd;  // Schur corrections of the rhs and of the diagonal (pose part only, < 88 entries each)
     lds_i *flag;
+    lds_d *hd;       // chain mode: diagonal of J'J for the Euclidean camera blocks (index t - npp)
+    gbl_d *g_imublk, *g_spill;   // chain mode: per-factor J'J | J'r blocks (32 x 32) and the factored fronts
+    int nd, ntd;     // dimension and tile rows of the dense system held in the tiles (dense mode: nc / nt, chain mode: npp / nt_c)
     // global scratch (per workgroup)
     gbl_d *v_s, *v_g, *v_D, *v_ghat, *v_y, *v_p, *v_rc, *v_sd, *l_hll, *l_gl, *l_invk, *g_hcl, *g_hp, *g_pr, *g_pdx, *g_sqrt;
     int ntiles, stage_cap;
@@ -197,6 +200,18 @@ __device__ __forceinline__ void copy_doubles(lds_d *dst, cst_d *src, int n, int 
     if ((n & 1) && tid == 0) dst[n - 1] = src[n - 1];
 }
 
+// same without alignment assumptions (8-byte accesses), four loads per thread in flight
+template <int NT>
+__device__ __forceinline__ void copy_doubles1(lds_d *dst, cst_d *src, int n, int tid) {
+    for (int i = tid; i < n; i += 4 * NT) {
+        double v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = src[min(i + k * NT, n - 1)];
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (i + k * NT < n) dst[i + k * NT] = v[k];
+    }
+}
+
 // zero n doubles (n even, 16-byte aligned) with 16-byte LDS stores
 template <int NT>
 __device__ __forceinline__ void zero_lds(lds_d *dst, int n, int tid) {
@@ -234,7 +249,7 @@ __device__ __forceinline__ void copy_prog(lds_i *dst, cst_i *src, int n, int tid
 // ---- linearise at x: cost, and (if assemble) S~ = Hcc - sum_l Hcl Hcl'/kappa_l in the tiles --------
 // kappa_l = hll + mu * clamp(s_l^2 hll) / s_l^2 is the landmark pivot of the Jacobi-scaled,
 // mu-regularised system expressed in unscaled units (DoglegStrategy + SchurEliminator restated).
-template <int NT>
+template <int NT, bool CHAIN>
 __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first, bool assemble, double mu) {
     cst_plan &P = *C.P;
     const int tid = C.tid;
@@ -244,13 +259,14 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
     cst_d *misc = dp + C.W->d_misc;
     const double G3[3] = {misc[0], misc[1], misc[2]};
     const double proj_sqrt = misc[3], proj_loss = misc[4], line_loss = misc[5];
-    const int pp_elems = (P.ntp * (P.ntp + 1) / 2) << 8;
+    const int pp_elems = CHAIN ? (C.ntiles << 8) : ((P.ntp * (P.ntp + 1) / 2) << 8);
     double cost_acc = 0.0;
 
     if (assemble) {
         zero_lds<NT>(C.tiles, pp_elems, tid);
         for (int i = tid; i < nc; i += NT) C.gcam[i] = 0.0;
         for (int i = tid; i < 176; i += NT) C.rc[i] = 0.0;      // rc | sd
+        if (CHAIN) for (int i = tid; i < 112; i += NT) C.hd[i] = 0.0;
     }
     cst_i *blk = ip + P.o_blk;
     TCV_MARK(C, PH_ZERO);
@@ -391,7 +407,8 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
         const int n = P.prior_n;
         cst_d *J0g = dp + C.W->d_prior, *r0 = J0g + n * n, *x0 = r0 + n;
         const bool in_lds = n * n + 2 * n <= C.stage_cap;
-        lds_d *J0 = C.stage, *pdx = C.stage + n * n, *pr = pdx + n;
+        const bool staged = CHAIN && !in_lds;      // chain mode: J0 goes through the pool in two column pieces
+        lds_d *J0 = C.stage, *pdx = staged ? C.stage + ((P.c_pool - 2 * n) & ~1) : C.stage + n * n, *pr = pdx + n;
         if (tid < P.prior_nblk) {      // dx of one kept block (marginalization_factor.cpp:348-364); fixed-size, fully unrolled
             cst_i *pb = ip + P.o_prior + tid * 4;
             const int gs = pb[2], xo = blk[pb[0] * 4 + 1], x0o = pb[3], ls = gs == 7 ? 6 : gs;
@@ -405,9 +422,49 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
                 d15[3] = sg * dq.x; d15[4] = sg * dq.y; d15[5] = sg * dq.z;
             }
 #pragma unroll
-            for (int i = 0; i < 15; i++) if (i < ls) { if (in_lds) pdx[pb[1] + i] = d15[i]; else C.g_pdx[pb[1] + i] = d15[i]; }
+            for (int i = 0; i < 15; i++) if (i < ls) { if (in_lds || staged) pdx[pb[1] + i] = d15[i]; else C.g_pdx[pb[1] + i] = d15[i]; }
         }
-        if (in_lds) {
+        if (CHAIN && !in_lds) {
+            // J0 does not fit the pool in one piece: columns [0, ns) and [ns, n) are staged one after the other.  The big
+            // piece comes second and stays resident for the J0' r pass, so only the small one is read twice.
+            const int cap = (P.c_pool - 2 * n - 2) / n;
+            const int nb = min(n, cap), ns = n - nb;
+            lds_d *Jp = C.stage;
+            lds_d *pdx2 = pdx, *pr2 = pr;
+            double r = (tid < n) ? r0[tid] : 0.0, r2 = 0.0;
+            for (int piece = 0; piece < 2; piece++) {
+                const int c0 = piece == 0 ? 0 : ns, cn = piece == 0 ? ns : nb;
+                if (cn == 0) continue;
+                copy_doubles1<NT>(Jp, J0g + n * c0, n * cn, tid);
+                __syncthreads();
+                if (tid < n) {
+                    for (int j = 0; j + 1 < cn; j += 2) { r += Jp[tid + n * j] * pdx2[c0 + j]; r2 += Jp[tid + n * (j + 1)] * pdx2[c0 + j + 1]; }
+                    if (cn & 1) r += Jp[tid + n * (cn - 1)] * pdx2[c0 + cn - 1];
+                }
+                if (piece == 0) __syncthreads();
+            }
+            if (tid < n) { r += r2; pr2[tid] = r; cost_acc += 0.5 * r * r; }
+            __syncthreads();
+            if (assemble) {
+                cst_i *pcol = ip + P.o_pcol;
+                for (int piece = 1; piece >= 0; piece--) {
+                    const int c0 = piece == 0 ? 0 : ns, cn = piece == 0 ? ns : nb;
+                    if (cn == 0) continue;
+                    if (piece == 0) { __syncthreads(); copy_doubles1<NT>(Jp, J0g, n * cn, tid); __syncthreads(); }
+                    if (tid < cn) {
+                        const int t = pcol[c0 + tid];
+                        if (t >= 0) {
+                            const lds_d *col = Jp + n * tid;
+                            double s0 = 0, s1 = 0;
+                            for (int i = 0; i + 1 < n; i += 2) { s0 += col[i] * pr2[i]; s1 += col[i + 1] * pr2[i + 1]; }
+                            if (n & 1) s0 += col[n - 1] * pr2[n - 1];
+                            C.gcam[t] += s0 + s1;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        } else if (in_lds) {
             copy_doubles<NT>(J0, J0g, n * n, tid);
             __syncthreads();
             if (tid < n) {      // row tid of J0: stride-n walk, conflict-free across the threads of a wave
@@ -454,7 +511,7 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
         }
     }
     TCV_MARK(C, PH_PRIOR);
-    if (assemble) {
+    if (assemble && !CHAIN) {
         const int all_elems = C.ntiles << 8;
         zero_lds<NT>(C.tiles + pp_elems, all_elems - pp_elems, tid);
     }
@@ -468,7 +525,7 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
         cst_i *ic = ip + P.o_ichunk + ch * 4;
         const int fb = ic[0], fn = ic[1], ncolor = ic[2];
         const unsigned colorbits = (unsigned)ic[3];
-        lds_d *recs = C.area;
+        lds_d *recs = CHAIN ? C.stage : C.area;      // chain mode: the whole LDS pool holds the records
         const int lane = tid & 63, wave = tid >> 6;
         constexpr int NW = NT / 64;
         if (wave < 4 && lane < fn) {
@@ -560,20 +617,29 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
                             int d = -1;                          // >= 0: tile element, -2 - ta: gradient entry, -1: nothing
                             if (ta >= 0) {
                                 if (bl == 30) d = -2 - ta;
-                                else if (tile != 3 && bl < 30 && al >= bl && tb >= 0) d = ta >= tb ? tix(ta, tb) : tix(tb, ta);
+                                else if (tile != 3 && bl < 30 && al >= bl && tb >= 0) {
+                                    if (CHAIN && (ta >= P.npp || tb >= P.npp)) {
+                                        // an entry of a Euclidean block's row / column: parked per factor in HBM/L2 for the chain
+                                        // elimination (no other factor writes there); its diagonal also feeds the Jacobi scaling
+                                        C.g_imublk[(fb + f) * IMU_BLK + al * 32 + bl] = acc[tile][i];
+                                        d = (al == bl) ? -1000 - (ta - P.npp) : -1;
+                                    } else d = ta >= tb ? tix(ta, tb) : tix(tb, ta);
+                                }
                             }
                             didx[tile * 4 + i] = d;
                         }
                     }
 #pragma unroll
                     for (int q = 0; q < 16; q++) {      // both candidate loads unconditional, selected afterwards
-                        const double tv = C.tiles[max(didx[q], 0)], gv = C.gcam[max(-2 - didx[q], 0)];
+                        const double tv = C.tiles[max(didx[q], 0)], gv = C.gcam[min(max(-2 - didx[q], 0), 175)];
                         dval[q] = didx[q] >= 0 ? tv : gv;
+                        if (CHAIN && didx[q] <= -1000) dval[q] = C.hd[-1000 - didx[q]];
                     }
 #pragma unroll
                     for (int q = 0; q < 16; q++) {
                         const double v = dval[q] + acc[q >> 2][q & 3];
                         if (didx[q] >= 0) C.tiles[didx[q]] = v;
+                        else if (CHAIN && didx[q] <= -1000) C.hd[-1000 - didx[q]] = v;
                         else if (didx[q] <= -2) C.gcam[-2 - didx[q]] = v;
                     }
                 }
@@ -601,7 +667,11 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
                     while (a2 * (a2 + 1) / 2 > e) a2--;
                     const int b2 = e - a2 * (a2 + 1) / 2;
                     const int ta = pcol[a2], tb = pcol[b2];
-                    if (ta >= 0 && tb >= 0) di[k] = ta >= tb ? tix(ta, tb) : tix(tb, ta);
+                    if (ta >= 0 && tb >= 0) {
+                        if (CHAIN && (ta >= P.npp || tb >= P.npp)) {      // chain mode reads these straight from g_hp; only the diagonal is needed here
+                            if (ta == tb) C.hd[ta - P.npp] += hv[k];
+                        } else di[k] = ta >= tb ? tix(ta, tb) : tix(tb, ta);
+                    }
                 }
             }
             double tv[4];
@@ -847,16 +917,264 @@ __device__ __noinline__ void back_subst(Ctx<NT> &C, int nc) {
     __syncthreads();
 }
 
+// ---- chain mode: block elimination of the Euclidean camera blocks before the dense pose system ------------------------
+// Step s eliminates block e_s (9 wide).  Its front F is a (9 + R + 1) x 9 row-major matrix in LDS: the block's own rows, the
+// next step's block (if coupled), the coupled pose rows in ascending tangent order and the rhs row.  F = fill left by step
+// s - 1 + the original entries (per-factor IMU J'J blocks parked in HBM/L2 by the linearisation, the cached J0'J0 of the
+// prior), Jacobi-scaled, + mu D^2.  After the 9 x 9 Cholesky and the row solves, the rank-9 Schur update runs on the
+// matrix cores and is scattered into the next front (rows of the next block) and into the pose tiles.  The factored front is
+// spilled to HBM/L2 for the back-substitution.  q accumulates u' H u over the original entries (Cauchy point).
+__device__ __forceinline__ bool diag9_wave(lds_d *F, lds_d *invd, int lane) {
+    const int r = lane & 15, rr = min(r, CH_W - 1);
+    double t[CH_W];
+#pragma unroll
+    for (int c = 0; c < CH_W; c++) t[c] = F[rr * CH_W + c];
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < CH_W; k++) {
+        const double d = readlane_f64(t[k], k);
+        if (!(d > 0.0) || !(d < 1e300)) ok = false;
+        if (ok) {
+            double l, y;
+            sqrt_rsqrt(d, l, y);
+            const double lk = (rr == k) ? l : t[k] * y;
+            t[k] = lk;
+#pragma unroll
+            for (int c = k + 1; c < CH_W; c++) t[c] -= lk * readlane_f64(lk, c);
+            if (lane == 0) invd[k] = y;
+        }
+    }
+    if (lane < CH_W) {
+#pragma unroll
+        for (int c = 0; c < CH_W; c++) F[r * CH_W + c] = t[c];
+    }
+    return ok;
+}
+
+// LDS layout of the pool during the chain: [front 0 | front 1 | 1/diag (16) | step records (n_e x CH_STRIDE ints)]
+enum { CH_FSZ = CH_MAXROWS * CH_W, CH_TAB_OFF = 2 * CH_FSZ + 16 };
+
+// original (unscaled) entries of front `h` handled by this thread: up to 4 entries (idx = tid + 256 k), three sources each.
+// Issued one step ahead so that the HBM/L2 latency hides behind the previous step's factorisation.
+template <int NT>
+__device__ __forceinline__ void chain_fetch(const Ctx<NT> &C, const lds_i *h, double (&v)[4][3]) {
+    const int nr = CH_W + h[CH_R] + 1, nsrc = h[CH_NSRC];
+    const int f0 = h[CH_F0], lc0 = h[CH_LC0], f1 = h[CH_F1], lc1 = h[CH_LC1], pc0 = h[CH_PC0];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int idx = C.tid + k * NT;
+        v[k][0] = v[k][1] = v[k][2] = 0.0;
+        if (idx < (nr - 1) * CH_W) {
+            const int r = idx / CH_W, c = idx - r * CH_W;
+            const unsigned w0 = (unsigned)h[CH_INTS + 2 * r];
+            const int pr = h[CH_INTS + 2 * r + 1];
+            const int l0 = (w0 >> 16) & 255, l1 = w0 >> 24;
+            if (nsrc > 0 && l0 != 255) { const int lc = lc0 + c; v[k][0] = C.g_imublk[f0 * IMU_BLK + max(l0, lc) * 32 + min(l0, lc)]; }
+            if (nsrc > 1 && l1 != 255) { const int lc = lc1 + c; v[k][1] = C.g_imublk[f1 * IMU_BLK + max(l1, lc) * 32 + min(l1, lc)]; }
+            if (pc0 >= 0 && pr >= 0) { const int pa = max(pr, pc0 + c), pb = min(pr, pc0 + c); v[k][2] = C.g_hp[pa * (pa + 1) / 2 + pb]; }
+        }
+    }
+}
+
+template <int NT>
+__device__ __noinline__ bool chain_forward(Ctx<NT> &C, double mu, double &q_out) {
+    cst_plan &P = *C.P;
+    const int tid = C.tid, lane = tid & 63, wave = tid >> 6, npp = P.npp;
+    constexpr int NW = NT / 64;
+    lds_d *pool = C.stage;
+    lds_d *invd = pool + 2 * CH_FSZ;
+    lds_i *tab = (lds_i *)(pool + CH_TAB_OFF);
+    double q = 0.0;
+    copy_prog<NT>(tab, C.ip + P.o_chain, P.n_e * CH_STRIDE, tid);
+    for (int i = tid; i < CH_FSZ; i += NT) pool[i] = 0.0;
+    __syncthreads();
+    double v[4][3];
+    chain_fetch<NT>(C, tab, v);
+    for (int s = 0; s < P.n_e; s++) {
+        const lds_i *h = tab + s * CH_STRIDE;
+        const int t0 = h[CH_T0], nr = CH_W + h[CH_R] + 1, has_next = h[CH_NEXT];
+        lds_d *F = pool + (s & 1) * CH_FSZ, *Fn = pool + ((s + 1) & 1) * CH_FSZ;
+        gbl_d *sp = C.g_spill + h[CH_SPILL];
+        // (A) assemble: original entries, Jacobi-scaled, + mu D^2, on top of the fill left by the previous step
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int idx = tid + k * NT;
+            if (idx < nr * CH_W) {
+                const int r = idx / CH_W, c = idx - r * CH_W, tc = t0 + c;
+                const int tr = h[CH_INTS + 2 * r] & 255;
+                const double scc = C.sc[tc];
+                double add;
+                if (tr == 255) add = scc * C.gcam[tc];
+                else {
+                    const double vv = (v[k][0] + v[k][1]) + v[k][2];
+                    const double w = (r < CH_W) ? ((r == c) ? 1.0 : ((r > c) ? 2.0 : 0.0)) : 2.0;
+                    q += w * C.ycam[tr] * C.ycam[tc] * vv;
+                    add = C.sc[tr] * scc * vv;
+                    if (r == c) add += mu * fmin(fmax(scc * scc * C.hd[tc - npp], 1e-6), 1e32);      // mu D^2, D exactly as finalize computes it
+                }
+                F[idx] += add;
+            }
+        }
+        for (int i = tid; i < CH_FSZ; i += NT) Fn[i] = 0.0;
+        __syncthreads();
+        TCV_MARK(C, PH_CH_A);
+        if (s + 1 < P.n_e) chain_fetch<NT>(C, h + CH_STRIDE, v);      // next step's entries: in flight during (B)-(D)
+        // (B) Cholesky of the 9 x 9 diagonal block, one wavefront, rows in registers
+        if (wave == 0) { if (!diag9_wave(F, invd, lane) && lane == 0) *C.flag = 1; }
+        __syncthreads();
+        TCV_MARK(C, PH_CH_B);
+        if (*C.flag) return false;
+        // (C) row solves X L' = F[rows], one row per thread; spill the factored front
+        for (int r = CH_W + tid; r < nr; r += NT) {
+            double x[CH_W];
+#pragma unroll
+            for (int c = 0; c < CH_W; c++) x[c] = F[r * CH_W + c];
+#pragma unroll
+            for (int c = 0; c < CH_W; c++) {
+                double a = x[c];
+#pragma unroll
+                for (int c1 = 0; c1 < c; c1++) a -= x[c1] * F[c * CH_W + c1];
+                x[c] = a * invd[c];
+            }
+#pragma unroll
+            for (int c = 0; c < CH_W; c++) { F[r * CH_W + c] = x[c]; sp[r * CH_W + c] = x[c]; }
+        }
+        if (tid >= NT - 128) {
+            const int i = tid - (NT - 128);
+            if (i < CH_W * CH_W) sp[i] = F[i];
+            else if (i < CH_W * CH_W + CH_W) sp[nr * CH_W + i - CH_W * CH_W] = invd[i - CH_W * CH_W];
+        }
+        __syncthreads();
+        TCV_MARK(C, PH_CH_C);
+        // (D) rank-9 update of everything below: -X X' on the matrix cores, 16 x 16 output tiles over the sub-rows
+        {
+            const int m = nr - CH_W, mt = (m + 15) >> 4;
+            const int i16 = lane & 15, k4 = lane >> 4;
+            int pidx = 0;
+            for (int I = 0; I < mt; I++)
+                for (int J = 0; J <= I; J++, pidx++) {
+                    if ((pidx % NW) != wave) continue;
+                    double av[3], bv[3];
+                    const int ra = CH_W + 16 * I + i16, rb = CH_W + 16 * J + i16;
+#pragma unroll
+                    for (int kk = 0; kk < 3; kk++) {
+                        const int k = 4 * kk + k4;
+                        const double ta = F[min(ra, nr - 1) * CH_W + min(k, CH_W - 1)], tb = F[min(rb, nr - 1) * CH_W + min(k, CH_W - 1)];
+                        av[kk] = (ra < nr && k < CH_W) ? -ta : 0.0;
+                        bv[kk] = (rb < nr && k < CH_W) ? tb : 0.0;
+                    }
+                    const int R2 = CH_W + 16 * J + i16;
+                    const int t2 = h[CH_INTS + 2 * min(R2, nr - 1)] & 255;
+                    int dst[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {      // destinations first: their LDS reads overlap the MFMAs
+                        const int R1 = CH_W + 16 * I + k4 + 4 * i;
+                        dst[i] = -1;
+                        if (R1 < nr && R2 < nr - 1 && R1 >= R2) {      // lower triangle; the rhs row is never a column
+                            const unsigned w1 = (unsigned)h[CH_INTS + 2 * R1];
+                            if (has_next && R2 < 2 * CH_W) dst[i] = -2 - (int)(((w1 >> 8) & 255) * CH_W + (R2 - CH_W));
+                            else dst[i] = tix((R1 == nr - 1) ? npp : (int)(w1 & 255), t2);
+                        }
+                    }
+                    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int kk = 0; kk < 3; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], acc, 0, 0, 0);
+                    double old[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) old[i] = C.tiles[max(dst[i], 0)];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        if (dst[i] >= 0) C.tiles[dst[i]] = old[i] + acc[i];
+                        else if (dst[i] <= -2) Fn[-2 - dst[i]] = acc[i];
+                    }
+                }
+        }
+        __syncthreads();
+        TCV_MARK(C, PH_CH_D);
+    }
+    q_out = block_sum<NT>(q, C.red, tid);
+    __syncthreads();
+    return true;
+}
+
+// back-substitution through the chain by ONE wavefront: y_e = L_ee^-T (z_e - sum_rows X[row]' y_row), blocks in reverse
+// elimination order; the rows' solutions (pose part, later blocks) are already in ycam.  The step records are still in LDS
+// (nothing touches the pool between chain_forward and here); every step's loads are issued one step ahead.
+struct ChainCol { double x0[CH_W], x1[CH_W], m0, m1; };
+template <int NT>
+__device__ __forceinline__ void chain_col_fetch(const Ctx<NT> &C, const lds_i *h, int lane, ChainCol &o) {
+    const int nr = CH_W + h[CH_R] + 1;
+    const gbl_d *sp = C.g_spill + h[CH_SPILL];
+    const int r0 = CH_W + lane, r1 = CH_W + lane + 64;
+#pragma unroll
+    for (int c = 0; c < CH_W; c++) {
+        o.x0[c] = (r0 < nr - 1) ? sp[min(r0, nr - 1) * CH_W + c] : 0.0;
+        o.x1[c] = (r1 < nr - 1) ? sp[min(r1, nr - 1) * CH_W + c] : 0.0;
+    }
+    // mailbox slots 0..80: L_ee (row-major 9 x 9); 81..89: the rhs row z; 90..98: 1/diag -- two slots per lane
+    const int i1 = 64 + lane;
+    o.m0 = sp[lane];
+    o.m1 = (i1 < 81) ? sp[min(i1, 80)] : ((i1 < 90) ? sp[(nr - 1) * CH_W + min(max(i1 - 81, 0), 8)] : ((i1 < 99) ? sp[nr * CH_W + min(max(i1 - 90, 0), 8)] : 0.0));
+}
+template <int NT>
+__device__ __noinline__ bool chain_backward(Ctx<NT> &C) {
+    cst_plan &P = *C.P;
+    const int lane = C.tid & 63;
+    lds_d *pool = C.stage;
+    const lds_i *tab = (const lds_i *)(pool + CH_TAB_OFF);
+    lds_d *mb = pool;            // 128 doubles of mailbox for L_ee / z / 1/diag (the fronts are dead)
+    bool bad = false;
+    ChainCol cur, nxt;
+    chain_col_fetch<NT>(C, tab + (P.n_e - 1) * CH_STRIDE, lane, cur);
+    for (int s = P.n_e - 1; s >= 0; s--) {
+        const lds_i *h = tab + s * CH_STRIDE;
+        const int t0 = h[CH_T0], nr = CH_W + h[CH_R] + 1;
+        if (s > 0) chain_col_fetch<NT>(C, h - CH_STRIDE, lane, nxt);
+        const int r0 = CH_W + lane, r1 = CH_W + lane + 64;
+        const double y0 = (r0 < nr - 1) ? C.ycam[h[CH_INTS + 2 * min(r0, nr - 1)] & 255] : 0.0;
+        const double y1 = (r1 < nr - 1) ? C.ycam[h[CH_INTS + 2 * min(r1, nr - 1)] & 255] : 0.0;
+        double acc[CH_W];
+#pragma unroll
+        for (int c = 0; c < CH_W; c++) acc[c] = cur.x0[c] * y0 + cur.x1[c] * y1;
+        wave_sum<CH_W>(acc);
+        mb[lane] = cur.m0;
+        mb[64 + lane] = cur.m1;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (lane == 0) {
+            double y[CH_W];
+#pragma unroll
+            for (int c = CH_W - 1; c >= 0; c--) {
+                double a = mb[81 + c] - acc[c];
+#pragma unroll
+                for (int c2 = c + 1; c2 < CH_W; c2++) a -= mb[c2 * CH_W + c] * y[c2];
+                y[c] = a * mb[90 + c];
+            }
+#pragma unroll
+            for (int c = 0; c < CH_W; c++) {
+                C.ycam[t0 + c] = y[c];
+                C.v_y[t0 + c] = y[c];
+                if (!(fabs(y[c]) < 1e300)) bad = true;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        cur = nxt;
+    }
+    return !bad;
+}
+
 // ---- scale, regularise, factorise and solve (J'J + mu D^2) y = J'r ---------------------------------
 // On return (true): v_y = y (scaled space, camera then landmarks), v_D, v_ghat set, scal = {gg, q}.
-template <int NT, bool MFMA>
+template <int NT, bool MFMA, bool CHAIN>
 __device__ __noinline__ bool finalize_and_solve(Ctx<NT> &C, bool first, double mu, double &gg_out, double &q_out) {
     cst_plan &P = *C.P;
     const int tid = C.tid, nc = P.nc, L = P.nland;
+    const int nd = C.nd;      // dimension of the dense system in the tiles: nc, or npp in chain mode
     cst_i *ip = C.ip;
     for (int a = tid; a < nc; a += NT) {
         const double sdv = C.sd[min(a, 87)];
-        const double dH = C.tiles[tix(a, a)] + (a < P.npp ? sdv : 0.0);
+        const double hdv = CHAIN ? C.hd[min(max(a - P.npp, 0), 111)] : 0.0;
+        const double tdv = C.tiles[tix(min(a, nd - 1), min(a, nd - 1))];
+        const double dH = (CHAIN && a >= P.npp) ? hdv : tdv + (a < P.npp ? sdv : 0.0);
         double s;
         if (first) { s = 1.0 / (1.0 + sqrt(dH)); C.v_s[a] = s; }
         else s = C.v_s[a];
@@ -905,7 +1223,7 @@ __device__ __noinline__ bool finalize_and_solve(Ctx<NT> &C, bool first, double m
         const int lane = tid & 63, wave = tid >> 6;
         const int r = lane >> 2, c0 = (lane & 3) << 2;
         int t = 0;
-        for (int I = 0; I < P.nt; I++)
+        for (int I = 0; I < C.ntd; I++)
             for (int J = 0; J <= I; J++, t++) {
                 if ((t % NW) != wave) continue;
                 lds_d *T = C.tiles + (t << 8);
@@ -913,7 +1231,7 @@ __device__ __noinline__ bool finalize_and_solve(Ctx<NT> &C, bool first, double m
                 double tv[4];
 #pragma unroll
                 for (int i = 0; i < 4; i++) tv[i] = T[sw(r, c0 + i)];
-                if (a < nc) {
+                if (a < nd) {
                     const double sa = C.sc[a], ua = C.ycam[a], sda = C.sd[min(a, 87)];
                     double sb[4], ub[4];
 #pragma unroll
@@ -929,12 +1247,12 @@ __device__ __noinline__ bool finalize_and_solve(Ctx<NT> &C, bool first, double m
                         }
                         T[sw(r, c0 + i)] = v;
                     }
-                } else if (a == nc) {
+                } else if (a == nd) {
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         const int b = 16 * J + c0 + i;
                         const double scb = C.sc[b], gb = C.gcam[b], rcb = C.rc[min(b, 87)];      // sc/gcam hold 176 entries
-                        T[sw(r, c0 + i)] = (b < nc) ? scb * (gb - (b < P.npp ? rcb : 0.0)) : ((b == nc) ? 1.0 : 0.0);
+                        T[sw(r, c0 + i)] = (b < nd) ? scb * (gb - (b < P.npp ? rcb : 0.0)) : ((b == nd) ? 1.0 : 0.0);
                     }
                 } else {
 #pragma unroll
@@ -948,19 +1266,29 @@ __device__ __noinline__ bool finalize_and_solve(Ctx<NT> &C, bool first, double m
     if (tid == 0) *C.flag = 0;
     __syncthreads();
     TCV_MARK(C, PH_FIN_PASS);
-    if (!chol_tiles<NT, MFMA>(C, P.nt, nc)) return false;
-    back_subst<NT>(C, nc);
+    if (CHAIN) {
+        double qc = 0.0;
+        if (!chain_forward<NT>(C, mu, qc)) return false;
+        q_out += qc;
+        TCV_MARK(C, PH_CHAIN_FWD);
+    }
+    if (!chol_tiles<NT, MFMA>(C, C.ntd, nd)) return false;
+    back_subst<NT>(C, nd);
     TCV_MARK(C, PH_BACK);
     // landmarks: y_l = (gl - Hcl' (s o y_c)) / (s_l kappa_l)
     bool bad = false;
-    for (int a = tid; a < nc; a += NT) {
+    for (int a = tid; a < nd; a += NT) {
         const double y = C.ycam[a];
         C.v_y[a] = y;
         if (!(fabs(y) < 1e300)) bad = true;
     }
-    {
+    // chain mode: wave 0 walks the chain backwards (Euclidean blocks in reverse elimination order) while the other
+    // waves back-substitute the landmarks, which only meet pose-kind blocks
+    const int l_first = CHAIN ? tid - 64 : tid, l_step = CHAIN ? NT - 64 : NT;
+    if (CHAIN && tid < 64) { if (!chain_backward<NT>(C)) bad = true; }
+    if (!CHAIN || tid >= 64) {
         cst_i *lm = ip + P.o_lm, *sp = ip + P.o_lmslotptr, *so = ip + P.o_lmslot;
-        for (int l = tid; l < L; l += NT) {
+        for (int l = l_first; l < L; l += l_step) {
             const gbl_d *h = C.g_hcl + lm[2 * l];
             double t = 0;
             const int s0 = sp[l], s1 = sp[l + 1];
@@ -1048,8 +1376,8 @@ __device__ __noinline__ double grad_max(Ctx<NT> &C) {
 }
 
 // ---- the kernel ---------------------------------------------------------------------------------------
-template <int NT, bool MFMA>
-__global__ void __launch_bounds__(NT) solve_kernel(SolveArgs A) {
+template <int NT, bool MFMA, bool CHAIN>
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CHAIN ? 2 : 1, CHAIN ? 2 : 8))) solve_kernel(SolveArgs A) {
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
     lds_d *lds = (lds_d *)lds_raw;
     const int tid = threadIdx.x;
@@ -1074,12 +1402,23 @@ __global__ void __launch_bounds__(NT) solve_kernel(SolveArgs A) {
         C.ip = (cst_i *)A.ipool + A.plan_base[W->plan];
         C.dp = (cst_d *)A.dpool + W->dbase;
         const int nc = P.nc, L = P.nland, nxl = (P.nx + L + 1) & ~1, nl = nc + L;
-        C.ntiles = P.nt * (P.nt + 1) / 2;
+        C.ntd = CHAIN ? P.nt_c : P.nt;
+        C.nd = CHAIN ? P.npp : nc;
+        C.ntiles = C.ntd * (C.ntd + 1) / 2;
         const int pp_tiles = P.ntp * (P.ntp + 1) / 2;
         C.tiles = lds;
-        C.stage = lds + (pp_tiles << 8);
-        C.stage_cap = (C.ntiles - pp_tiles) << 8;
-        lds_d *p = lds + (C.ntiles << 8);
+        lds_d *p;
+        if (CHAIN) {      // [pose tiles | pool: staging + area, IMU records, fronts | vectors]
+            C.stage = lds + (C.ntiles << 8);
+            C.stage_cap = P.c_stage_cap;
+            p = C.stage + P.c_pool;
+            C.g_imublk = (gbl_d *)A.imublk + (size_t)blockIdx.x * 16 * IMU_BLK;
+            C.g_spill = (gbl_d *)A.spill + (size_t)blockIdx.x * A.spill_stride;
+        } else {
+            C.stage = lds + (pp_tiles << 8);
+            C.stage_cap = (C.ntiles - pp_tiles) << 8;
+            p = lds + (C.ntiles << 8);
+        }
         C.xs = p; p += nxl;
         C.xc = p; p += nxl;
         C.sc = p; p += 176;
@@ -1088,7 +1427,8 @@ __global__ void __launch_bounds__(NT) solve_kernel(SolveArgs A) {
         C.invdiag = p; C.gcam = p; p += 176;
         C.red = p; p += 64;
         C.flag = (lds_i *)(C.red + 62);   // red[] uses at most 5 * NT/64 = 40 doubles
-        C.area = p;
+        C.hd = p;                         // chain mode only (112 doubles)
+        C.area = CHAIN ? C.stage + P.c_stage_cap : p;
         typedef __attribute__((address_space(1))) DevSummary gbl_sum;
         gbl_sum *S = (gbl_sum *)A.summary + win;
 
@@ -1108,7 +1448,7 @@ __global__ void __launch_bounds__(NT) solve_kernel(SolveArgs A) {
         if (P.prior_n > 0) {
             const int n = P.prior_n;
             cst_d *J0g = C.dp + W->d_prior;
-            const bool in_lds = n * n <= (C.ntiles << 8);
+            const bool in_lds = n * n <= (C.ntiles << 8) + (CHAIN ? P.c_pool : 0);
             if (in_lds) copy_doubles<NT>(lds, J0g, n * n, tid);
             __syncthreads();
             for (int e = tid; e < n * n; e += NT) {
@@ -1133,7 +1473,7 @@ __global__ void __launch_bounds__(NT) solve_kernel(SolveArgs A) {
         double radius = 1e4, mu = 1e-8, lin_mu = 1e-8;
         bool reuse = false, tiles_valid = true;
         int invalid = 0, termination = 0, nrec = 1, status = 0;
-        double cost = linearize<NT>(C, C.xs, true, true, mu);
+        double cost = linearize<NT, CHAIN>(C, C.xs, true, true, mu);
         bool first = true;
         const double initial_cost = cost;
         if (tid == 0) { S->cost[0] = cost; S->step_ok[0] = 1; S->dogleg_case[0] = 0; S->radius[0] = radius; S->mu[0] = mu; }
@@ -1156,10 +1496,10 @@ __global__ void __launch_bounds__(NT) solve_kernel(SolveArgs A) {
                 ls_ok = false;
                 while (mu < 1.0) {
                     if (!tiles_valid || lin_mu != mu) {
-                        (void)linearize<NT>(C, C.xs, false, true, mu);
+                        (void)linearize<NT, CHAIN>(C, C.xs, false, true, mu);
                         lin_mu = mu;
                     }
-                    const bool ok = finalize_and_solve<NT, MFMA>(C, first, mu, gg, q);
+                    const bool ok = finalize_and_solve<NT, MFMA, CHAIN>(C, first, mu, gg, q);
                     first = false;
                     tiles_valid = false;
                     if (ok) { ls_ok = true; break; }
@@ -1231,7 +1571,7 @@ __global__ void __launch_bounds__(NT) solve_kernel(SolveArgs A) {
             TCV_MARK(C, PH_PLUS);
             const double mu_next = fmax(1e-8, 2.0 * mu / 10.0);
             const bool want_asm = (it < max_it) || !fixed;
-            const double cost_c = linearize<NT>(C, C.xc, false, want_asm, mu_next);
+            const double cost_c = linearize<NT, CHAIN>(C, C.xc, false, want_asm, mu_next);
             tiles_valid = want_asm;
             lin_mu = mu_next;
             ambient_norms<NT>(C, C.xs, C.xc, xn2, dn2);
@@ -1291,16 +1631,30 @@ __global__ void __launch_bounds__(NT) solve_kernel(SolveArgs A) {
 
 }  // namespace tcv
 
-extern "C" int tcv_launch_solve(const tcv::SolveArgs *args, int grid, int nthreads, size_t lds_bytes, void *stream) {
+// The chain kernel is built in its own translation unit (-DTCV_SOLVE_CHAIN_TU, every device function inlined so that the
+// 2-waves-per-SIMD register budget covers the whole call tree: the occupancy attribute does not reach non-inlined callees).
+#ifdef TCV_SOLVE_CHAIN_TU
+extern "C" int tcv_launch_solve_chain(const tcv::SolveArgs *args, int grid, size_t lds_bytes, void *stream) {
     using namespace tcv;
     hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipFuncSetAttribute((const void *)solve_kernel<256, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((solve_kernel<256, true, true>), dim3(grid), dim3(256), lds_bytes, st, *args);
+    return (int)hipGetLastError();
+}
+#else
+extern "C" int tcv_launch_solve_chain(const tcv::SolveArgs *args, int grid, size_t lds_bytes, void *stream);
+extern "C" int tcv_launch_solve(const tcv::SolveArgs *args, int grid, int nthreads, size_t lds_bytes, void *stream) {
+    using namespace tcv;
+    if (args->chain) return tcv_launch_solve_chain(args, grid, lds_bytes, stream);
+    hipStream_t st = (hipStream_t)stream;
     hipError_t e;
-#define TCV_LAUNCH(NTV, MF)                                                                                         \
-    do {                                                                                                            \
-        e = hipFuncSetAttribute((const void *)solve_kernel<NTV, MF>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
-                                (int)lds_bytes);                                                                    \
-        if (e != hipSuccess) return (int)e;                                                                         \
-        hipLaunchKernelGGL((solve_kernel<NTV, MF>), dim3(grid), dim3(NTV), lds_bytes, st, *args);                   \
+#define TCV_LAUNCH(NTV, MF)                                                                                                \
+    do {                                                                                                                   \
+        e = hipFuncSetAttribute((const void *)solve_kernel<NTV, MF, false>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                (int)lds_bytes);                                                                           \
+        if (e != hipSuccess) return (int)e;                                                                                \
+        hipLaunchKernelGGL((solve_kernel<NTV, MF, false>), dim3(grid), dim3(NTV), lds_bytes, st, *args);                   \
     } while (0)
     if (nthreads == 512) { if (args->use_mfma) TCV_LAUNCH(512, true); else TCV_LAUNCH(512, false); }
     else { if (args->use_mfma) TCV_LAUNCH(256, true); else TCV_LAUNCH(256, false); }
@@ -1309,3 +1663,4 @@ extern "C" int tcv_launch_solve(const tcv::SolveArgs *args, int grid, int nthrea
 }
 
 extern "C" int tcv_solve_scratch_doubles(void) { return tcv::SCR_TOTAL; }
+#endif

@@ -37,7 +37,7 @@ EXPORTS = [
     "tcv_batch_download_states", "tcv_batch_get_summaries", "tcv_batch_get_prior", "tcv_batch_get_first_step",
     "tcv_batch_plan_stats", "tcv_batch_stats", "tcv_batch_size",
     "tcv_eval_imu_factors", "tcv_eval_projection_factors", "tcv_eval_line_factors", "tcv_pose_plus", "tcv_preintegrate",
-    "tcv_problem_set_frames", "tcv_gauge_fix", "tcv_batch_gauge_fix",
+    "tcv_problem_set_frames", "tcv_gauge_fix", "tcv_batch_gauge_fix", "tcv_set_solver_variant", "tcv_batch_marg_status",
 ]
 
 
@@ -141,6 +141,7 @@ def lib():
         L.tcv_problem_set_frames.argtypes = [vp, C.c_int, C.POINTER(_dp), C.POINTER(_dp)]
         L.tcv_gauge_fix.argtypes = [C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
         L.tcv_batch_gauge_fix.argtypes = [vp, vp]
+        L.tcv_batch_marg_status.argtypes = [vp, _ip, C.c_int]
         _lib = L
     return _lib
 
@@ -391,6 +392,11 @@ class Batch:
 
     def marginalize(self, stream=None):
         check(lib().tcv_batch_marginalize(self.h, stream))
+
+    def marg_status(self):
+        out = np.zeros(len(self.windows), np.int32)
+        check(lib().tcv_batch_marg_status(self.h, iptr(out), len(out)))
+        return out
 
     def gauge_fix(self, stream=None):
         """Estimator::double2vector() + vector2double() in place on the solved states in HBM (estimator.cpp:1537-1581)."""

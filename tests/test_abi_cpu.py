@@ -48,8 +48,16 @@ def test_window_graph_counts(tcv):
     assert L.tcv_problem_num_residual_blocks(w.h) == 10 + 200 + 40
     assert L.tcv_problem_num_residuals(w.h) == 150 + 400 + 80
     st = w.plan_stats()
-    assert st["nc"] == 171 and st["nx"] == 183 and st["npp"] == 72 and st["nland"] == 50 and st["nt"] == 11
-    assert st["lds_bytes"] <= 160 * 1024
+    # default = chain layout: the 11 speed-bias blocks are eliminated one by one, the pose system (72 + rhs row) is 5 tile rows,
+    # and the whole window fits half a CU's LDS (two windows per CU)
+    assert st["nc"] == 171 and st["nx"] == 183 and st["npp"] == 72 and st["nland"] == 50 and st["nt"] == 5
+    assert st["n_iunit"] == 11 and st["lds_bytes"] == 80 * 1024
+    L.tcv_set_solver_variant(1)                   # dense layout: one 171 (+ rhs) system = 11 tile rows, the whole LDS
+    try:
+        sd = tcv.Window(synth.window_at(b, 0)).plan_stats()
+    finally:
+        L.tcv_set_solver_variant(0)
+    assert sd["nt"] == 11 and sd["lds_bytes"] <= 160 * 1024
     # algorithmic window data of cfg 2 (no prior): SURVEY.md 8(d) counts 39 728 B incl. indices; the data pool holds the doubles
     assert 4500 <= st["window_doubles"] <= 5000
 

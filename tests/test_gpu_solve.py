@@ -159,3 +159,32 @@ def test_max_iterations_zero_and_one(gpu):
     assert np.array_equal(W[0].pose, w["pose"])
     W, b, s = gpu_solve(gpu, [w], iters=1)
     check_against_oracle(gpu, w, W[0], b, s[0], 0, 1, True)
+
+
+def test_chain_layout_matches_dense_layout_and_oracle(gpu):
+    """The default chain layout (speed-bias blocks eliminated one by one before the dense pose system, two windows per CU)
+    and the dense 171-dim layout solve the same scaled, mu-regularised system: identical dogleg traces, first steps within
+    1e-6 of each other (measured 1e-9..1e-8), and both within the north-star tolerance of the C oracle."""
+    pre, main, z = golden_windows()
+    wins = [pre, main] + [synth.window_at(synth.make_windows(77, 2), k) for k in range(2)]
+    out = {}
+    try:
+        for variant in (0, 1):
+            gpu.check(gpu.lib().tcv_set_solver_variant(variant))
+            W = [gpu.Window(w) for w in wins]
+            b = gpu.Batch(W)
+            assert b.plan_stats()["lds_bytes"] == (80 * 1024 if variant == 0 else 160 * 1024)
+            b.solve(gpu.default_options(8, True, True, 256, True)); b.synchronize(); b.download_states()
+            s = b.summaries()
+            out[variant] = [(s[k].final_cost, [s[k].dogleg_case[i] for i in range(9)], [s[k].step_ok[i] for i in range(9)],
+                             W[k].pose.copy(), W[k].sb.copy(), b.first_step(k)) for k in range(len(wins))]
+    finally:
+        gpu.check(gpu.lib().tcv_set_solver_variant(0))
+    for k, w in enumerate(wins):
+        O = orc.Window(w); so = O.solve(8, True); st = O.states()
+        c, d = out[0][k], out[1][k]
+        assert c[1] == d[1] == [so.dogleg_case[i] for i in range(9)] and c[2] == d[2]
+        assert rel(c[5], d[5]) < 1e-6
+        for v in (c, d):
+            assert abs(v[0] - so.final_cost) < 1e-6 * so.final_cost
+            assert rel(v[3], st["pose"]) < 1e-6 and rel(v[4], st["sb"]) < 1e-6

@@ -6,9 +6,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tc-viml_amd"))
 import synth, tcv
 NAMES = ["setup", "vis_eval", "vis_gather", "lm", "schur", "zero", "imu_raw", "imu_whiten", "imu_gather", "prior", "cost_red",
-         "fin_scale", "fin_cauchy", "fin_pass", "chol_diag", "chol_trsm", "chol_upd", "back", "lm_back", "dogleg", "plus", "norms", "other"]
+         "fin_scale", "fin_cauchy", "fin_pass", "chol_diag", "chol_trsm", "chol_upd", "back", "lm_back", "dogleg", "plus", "norms", "other", "chain_fwd", "chain_bwd", "ch_A", "ch_B", "ch_C", "ch_D"]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 th = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+if "--dense" in sys.argv:
+    tcv.lib().tcv_set_solver_variant(1)
 if "--prior" in sys.argv:       # the bench workload: windows with the n = 75 prior produced by the GPU marginalisation
     sys.path.insert(0, ROOT)
     import bench
@@ -24,6 +26,7 @@ out = np.zeros(32); L.tcv_batch_profile(b.h, tcv.dptr(out))
 b.solve(o); b.synchronize()
 L.tcv_batch_profile(b.h, tcv.dptr(out))
 tot = out.sum()
+print(b.plan_stats())
 print(f"B={B} threads={th} solve_ms={b.stats()['solve_ms']:.3f}; cycles per window-solve (8 it): {tot/B:.0f}")
 for n, v in zip(NAMES, out):
     print(f"  {n:12s} {v/B:12.0f} cyc/solve  {100*v/tot:5.1f}%")
