@@ -391,6 +391,7 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
     hipGetDevice(&dev);
     hipGetDeviceProperties(&prop, dev);
     b->grid = std::min(n, (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256) * (b->chain ? 2 : 1));
+    if (const char *eg = getenv("TCV_GRID")) { const int g = atoi(eg); if (g > 0) b->grid = std::min(n, g); }      // tuning experiments
     const int scr = tcv_solve_scratch_doubles();
 #define UP(dst, src, T, cnt)                                                                          \
     do {                                                                                              \

@@ -342,24 +342,11 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int 
         vch.push_back(cur);
         return TCV_OK;
     };
-    if (use_chain) {      // split the LDS pool between staging and the landmark coupling area: fewest chunks wins
-        int best = -1, best_n = 1 << 30;
-        std::vector<VChunk> tmp;
-        for (int ac = 320; ac <= c_pool - 1024; ac += 160) {
-            if (build_chunks(c_pool - ac, ac, tmp) != TCV_OK) continue;
-            if ((int)tmp.size() < best_n) { best_n = (int)tmp.size(); best = ac; }
-        }
-        if (best < 0) use_chain = false;
-        else { area_cap = best; stage_cap = c_pool - best; }
-    }
-    if (!use_chain) chain.clear();
-    { const int rc = build_chunks(stage_cap, area_cap, vch); if (rc != TCV_OK) return rc; }
-    set_error("");
-    H.chain = use_chain ? 1 : 0; H.n_e = (int)chain.size(); H.nt_c = nt_c; H.c_stage_cap = stage_cap; H.c_area_cap = area_cap; H.c_pool = c_pool;
-    if (use_chain) H.lds_area = area_cap;
-    H.n_vis_chunk = (int)vch.size();
-    std::vector<int> vprog, sprog, vchunk_tab;
-    for (auto &c : vch) {
+    // gather programs of a chunk list; measures the staging / area doubles the largest chunk needs
+    auto emit_all = [&](const std::vector<VChunk> &vch, int stage_chk, int area_chk, std::vector<int> &vprog, std::vector<int> &sprog,
+                        std::vector<int> &vchunk_tab, int &max_stage, int &max_area) -> int {
+        vprog.clear(); sprog.clear(); vchunk_tab.clear(); max_stage = 0; max_area = 0;
+        for (auto &c : vch) {
         DestList dl, sl;
         for (int k = 0; k < c.pn; k++) {
             const ProjFac &f = p.proj[order[c.pb + k]];
@@ -403,7 +390,10 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int 
         RowProg vp, sp;
         if (!emit_rows(dl, vp, false) || !emit_rows(sl, sp, false)) { set_error("gather program field overflow"); return TCV_ERR_TOO_LARGE; }
         const int recs = (c.pn * PROJ_REC + c.ln * LINE_REC + 1) & ~1;
-        if (recs + ((int)(vp.units.size() + vp.items.size()) + 1) / 2 + 2 > stage_cap || ((int)(sp.units.size() + sp.items.size()) + 1) / 2 + 2 > stage_cap) {
+        const int st_need = std::max(recs + ((int)(vp.units.size() + vp.items.size()) + 1) / 2 + 2, ((int)(sp.units.size() + sp.items.size()) + 1) / 2 + 2);
+        const int ar_need = (e_off[c.lmb + c.lmn] - e_off[c.lmb]) + 3 * c.lmn + 8;
+        max_stage = std::max(max_stage, st_need); max_area = std::max(max_area, ar_need);
+        if (stage_chk >= 0 && (st_need > stage_chk || ar_need > area_chk)) {
             set_error("gather program does not fit the LDS staging area"); return TCV_ERR_TOO_LARGE;
         }
         while (vprog.size() & 3) vprog.push_back(0);        // every program starts 16-byte aligned (vector loads on the device)
@@ -415,7 +405,42 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int 
                              c.lmb, c.lmn, e_off[c.lmb], e_off[c.lmb + c.lmn] - e_off[c.lmb],
                              soff, sp.n_units, sp.n_wave_units, (int)sp.items.size()};
         vchunk_tab.insert(vchunk_tab.end(), tab, tab + 16);
+            }
+        return TCV_OK;
+    };
+    std::vector<int> vprog, sprog, vchunk_tab;
+    if (use_chain) {
+        // chain layout: the LDS pool (staging | landmark coupling area) is small, so the landmarks are dealt evenly to the
+        // smallest number k of chunks whose EXACT programs fit; the line factors are spread over the chunks
+        bool found = false;
+        const int nline = (int)p.line.size(), nproj = (int)p.proj.size();
+        for (int k = 1; k <= std::max(1, std::min(L, 48)) && !found; k++) {
+            std::vector<VChunk> cand;
+            int l = 0;
+            for (int c = 0; c < k; c++) {
+                VChunk cur{lmptr[l], 0, c * nline / k, (c + 1) * nline / k - c * nline / k, l, 0};
+                const int target = (int)((long long)(c + 1) * nproj / k);
+                while (l < L && (c == k - 1 || lmptr[l + 1] <= target || cur.lmn == 0)) { cur.pn += lmptr[l + 1] - lmptr[l]; cur.lmn++; l++; }
+                cand.push_back(cur);
+            }
+            int ms = 0, ma = 0;
+            if (emit_all(cand, -1, -1, vprog, sprog, vchunk_tab, ms, ma) != TCV_OK) continue;
+            ma = (ma + 1) & ~1;
+            if (ms + ma <= c_pool) { found = true; vch = cand; area_cap = ma; stage_cap = c_pool - ma; }
+        }
+        if (!found) { use_chain = false; chain.clear(); }
     }
+    if (!use_chain) {
+        chain.clear();
+        { const int rc = build_chunks(stage_cap, area_cap, vch); if (rc != TCV_OK) return rc; }
+        int ms = 0, ma = 0;
+        const int rc = emit_all(vch, stage_cap, area_cap, vprog, sprog, vchunk_tab, ms, ma);
+        if (rc != TCV_OK) return rc;
+    }
+    set_error("");
+    H.chain = use_chain ? 1 : 0; H.n_e = (int)chain.size(); H.nt_c = nt_c; H.c_stage_cap = stage_cap; H.c_area_cap = area_cap; H.c_pool = c_pool;
+    if (use_chain) H.lds_area = area_cap;
+    H.n_vis_chunk = (int)vch.size();
     H.o_vchunk = mark(); I.insert(I.end(), vchunk_tab.begin(), vchunk_tab.end());
     while ((I.size() & 3) != 0) I.push_back(0);
     H.o_vdest = mark(); I.insert(I.end(), vprog.begin(), vprog.end()); H.n_vdest = 0;

@@ -924,33 +924,6 @@ __device__ __noinline__ void back_subst(Ctx<NT> &C, int nc) {
 // prior), Jacobi-scaled, + mu D^2.  After the 9 x 9 Cholesky and the row solves, the rank-9 Schur update runs on the
 // matrix cores and is scattered into the next front (rows of the next block) and into the pose tiles.  The factored front is
 // spilled to HBM/L2 for the back-substitution.  q accumulates u' H u over the original entries (Cauchy point).
-__device__ __forceinline__ bool diag9_wave(lds_d *F, lds_d *invd, int lane) {
-    const int r = lane & 15, rr = min(r, CH_W - 1);
-    double t[CH_W];
-#pragma unroll
-    for (int c = 0; c < CH_W; c++) t[c] = F[rr * CH_W + c];
-    bool ok = true;
-#pragma unroll
-    for (int k = 0; k < CH_W; k++) {
-        const double d = readlane_f64(t[k], k);
-        if (!(d > 0.0) || !(d < 1e300)) ok = false;
-        if (ok) {
-            double l, y;
-            sqrt_rsqrt(d, l, y);
-            const double lk = (rr == k) ? l : t[k] * y;
-            t[k] = lk;
-#pragma unroll
-            for (int c = k + 1; c < CH_W; c++) t[c] -= lk * readlane_f64(lk, c);
-            if (lane == 0) invd[k] = y;
-        }
-    }
-    if (lane < CH_W) {
-#pragma unroll
-        for (int c = 0; c < CH_W; c++) F[r * CH_W + c] = t[c];
-    }
-    return ok;
-}
-
 // LDS layout of the pool during the chain: [front 0 | front 1 | 1/diag (16) | step records (n_e x CH_STRIDE ints)]
 enum { CH_FSZ = CH_MAXROWS * CH_W, CH_TAB_OFF = 2 * CH_FSZ + 16 };
 
@@ -1019,75 +992,116 @@ __device__ __noinline__ bool chain_forward(Ctx<NT> &C, double mu, double &q_out)
         __syncthreads();
         TCV_MARK(C, PH_CH_A);
         if (s + 1 < P.n_e) chain_fetch<NT>(C, h + CH_STRIDE, v);      // next step's entries: in flight during (B)-(D)
-        // (B) Cholesky of the 9 x 9 diagonal block, one wavefront, rows in registers
-        if (wave == 0) { if (!diag9_wave(F, invd, lane) && lane == 0) *C.flag = 1; }
-        __syncthreads();
-        TCV_MARK(C, PH_CH_B);
-        if (*C.flag) return false;
-        // (C) row solves X L' = F[rows], one row per thread; spill the factored front
-        for (int r = CH_W + tid; r < nr; r += NT) {
-            double x[CH_W];
+        // (B) Cholesky of the 9 x 9 diagonal block: every thread factors it redundantly in registers (no cross-lane traffic, no
+        // barrier before the row solves); (C) row solves X L' = F[rows], one row per thread; the factored front is spilled
+        {
+            double Ld[CH_W * (CH_W + 1) / 2], inv[CH_W];
 #pragma unroll
-            for (int c = 0; c < CH_W; c++) x[c] = F[r * CH_W + c];
+            for (int r = 0; r < CH_W; r++)
 #pragma unroll
-            for (int c = 0; c < CH_W; c++) {
-                double a = x[c];
+                for (int c = 0; c <= r; c++) Ld[r * (r + 1) / 2 + c] = F[r * CH_W + c];
+            bool ok = true;
 #pragma unroll
-                for (int c1 = 0; c1 < c; c1++) a -= x[c1] * F[c * CH_W + c1];
-                x[c] = a * invd[c];
+            for (int k = 0; k < CH_W; k++) {
+                const double d = Ld[k * (k + 1) / 2 + k];
+                if (!(d > 0.0) || !(d < 1e300)) ok = false;
+                double l, y;
+                sqrt_rsqrt(ok ? d : 1.0, l, y);
+                Ld[k * (k + 1) / 2 + k] = l; inv[k] = y;
+#pragma unroll
+                for (int r = k + 1; r < CH_W; r++) Ld[r * (r + 1) / 2 + k] *= y;
+#pragma unroll
+                for (int r = k + 1; r < CH_W; r++)
+#pragma unroll
+                    for (int c = k + 1; c <= r; c++) Ld[r * (r + 1) / 2 + c] -= Ld[r * (r + 1) / 2 + k] * Ld[c * (c + 1) / 2 + k];
             }
+            if (!ok) return false;      // uniform: every thread factored the same block
+            for (int r = CH_W + tid; r < nr; r += NT) {
+                double x[CH_W];
 #pragma unroll
-            for (int c = 0; c < CH_W; c++) { F[r * CH_W + c] = x[c]; sp[r * CH_W + c] = x[c]; }
-        }
-        if (tid >= NT - 128) {
-            const int i = tid - (NT - 128);
-            if (i < CH_W * CH_W) sp[i] = F[i];
-            else if (i < CH_W * CH_W + CH_W) sp[nr * CH_W + i - CH_W * CH_W] = invd[i - CH_W * CH_W];
+                for (int c = 0; c < CH_W; c++) x[c] = F[r * CH_W + c];
+#pragma unroll
+                for (int c = 0; c < CH_W; c++) {
+                    double a = x[c];
+#pragma unroll
+                    for (int c1 = 0; c1 < c; c1++) a -= x[c1] * Ld[c * (c + 1) / 2 + c1];
+                    x[c] = a * inv[c];
+                }
+#pragma unroll
+                for (int c = 0; c < CH_W; c++) { F[r * CH_W + c] = x[c]; sp[r * CH_W + c] = x[c]; }
+            }
+            if (tid == NT - 1) {      // an otherwise idle thread publishes L_ee and 1/diag for the back-substitution
+#pragma unroll
+                for (int r = 0; r < CH_W; r++)
+#pragma unroll
+                    for (int c = 0; c <= r; c++) sp[r * CH_W + c] = Ld[r * (r + 1) / 2 + c];
+#pragma unroll
+                for (int c = 0; c < CH_W; c++) sp[nr * CH_W + c] = inv[c];
+            }
         }
         __syncthreads();
         TCV_MARK(C, PH_CH_C);
-        // (D) rank-9 update of everything below: -X X' on the matrix cores, 16 x 16 output tiles over the sub-rows
+        // (D) rank-9 update of everything below: -X X' on the matrix cores, 16 x 16 output tiles over the sub-rows, two tiles
+        // per trip so that their operand loads, MFMA chains and read-modify-writes overlap
         {
-            const int m = nr - CH_W, mt = (m + 15) >> 4;
+            const int m = nr - CH_W, mt = (m + 15) >> 4, npair = mt * (mt + 1) / 2;
             const int i16 = lane & 15, k4 = lane >> 4;
-            int pidx = 0;
-            for (int I = 0; I < mt; I++)
-                for (int J = 0; J <= I; J++, pidx++) {
-                    if ((pidx % NW) != wave) continue;
-                    double av[3], bv[3];
-                    const int ra = CH_W + 16 * I + i16, rb = CH_W + 16 * J + i16;
+            for (int p0 = 2 * wave; p0 < npair; p0 += 2 * NW) {
+                int II[2], JJ[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {      // pair index -> (I, J), J <= I
+                    const int pq = min(p0 + u, npair - 1);
+                    int I = (int)((sqrtf(8.0f * (float)pq + 1.0f) - 1.0f) * 0.5f);
+                    while ((I + 1) * (I + 2) / 2 <= pq) I++;
+                    while (I * (I + 1) / 2 > pq) I--;
+                    II[u] = I; JJ[u] = pq - I * (I + 1) / 2;
+                }
+                const bool two = p0 + 1 < npair;
+                double av[2][3], bv[2][3];
+                int dst[2][4];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int ra = CH_W + 16 * II[u] + i16, rb = CH_W + 16 * JJ[u] + i16;
 #pragma unroll
                     for (int kk = 0; kk < 3; kk++) {
                         const int k = 4 * kk + k4;
                         const double ta = F[min(ra, nr - 1) * CH_W + min(k, CH_W - 1)], tb = F[min(rb, nr - 1) * CH_W + min(k, CH_W - 1)];
-                        av[kk] = (ra < nr && k < CH_W) ? -ta : 0.0;
-                        bv[kk] = (rb < nr && k < CH_W) ? tb : 0.0;
+                        av[u][kk] = (ra < nr && k < CH_W) ? -ta : 0.0;
+                        bv[u][kk] = (rb < nr && k < CH_W) ? tb : 0.0;
                     }
-                    const int R2 = CH_W + 16 * J + i16;
+                    const int R2 = rb;
                     const int t2 = h[CH_INTS + 2 * min(R2, nr - 1)] & 255;
-                    int dst[4];
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {      // destinations first: their LDS reads overlap the MFMAs
-                        const int R1 = CH_W + 16 * I + k4 + 4 * i;
-                        dst[i] = -1;
-                        if (R1 < nr && R2 < nr - 1 && R1 >= R2) {      // lower triangle; the rhs row is never a column
-                            const unsigned w1 = (unsigned)h[CH_INTS + 2 * R1];
-                            if (has_next && R2 < 2 * CH_W) dst[i] = -2 - (int)(((w1 >> 8) & 255) * CH_W + (R2 - CH_W));
-                            else dst[i] = tix((R1 == nr - 1) ? npp : (int)(w1 & 255), t2);
-                        }
-                    }
-                    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                    for (int kk = 0; kk < 3; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], acc, 0, 0, 0);
-                    double old[4];
-#pragma unroll
-                    for (int i = 0; i < 4; i++) old[i] = C.tiles[max(dst[i], 0)];
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
-                        if (dst[i] >= 0) C.tiles[dst[i]] = old[i] + acc[i];
-                        else if (dst[i] <= -2) Fn[-2 - dst[i]] = acc[i];
+                        const int R1 = CH_W + 16 * II[u] + k4 + 4 * i;
+                        dst[u][i] = -1;
+                        if ((u == 0 || two) && R1 < nr && R2 < nr - 1 && R1 >= R2) {      // lower triangle; the rhs row is never a column
+                            const unsigned w1 = (unsigned)h[CH_INTS + 2 * R1];
+                            if (has_next && R2 < 2 * CH_W) dst[u][i] = -2 - (int)(((w1 >> 8) & 255) * CH_W + (R2 - CH_W));
+                            else dst[u][i] = tix((R1 == nr - 1) ? npp : (int)(w1 & 255), t2);
+                        }
                     }
                 }
+                v4f64 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < 3; kk++) {
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0][kk], bv[0][kk], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1][kk], bv[1][kk], acc1, 0, 0, 0);
+                }
+                double old[2][4];
+#pragma unroll
+                for (int u = 0; u < 2; u++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) old[u][i] = C.tiles[max(dst[u][i], 0)];
+#pragma unroll
+                for (int u = 0; u < 2; u++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const double a = u == 0 ? acc0[i] : acc1[i];
+                        if (dst[u][i] >= 0) C.tiles[dst[u][i]] = old[u][i] + a;
+                        else if (dst[u][i] <= -2) Fn[-2 - dst[u][i]] = a;
+                    }
+            }
         }
         __syncthreads();
         TCV_MARK(C, PH_CH_D);
@@ -1133,18 +1147,29 @@ __device__ __noinline__ bool chain_backward(Ctx<NT> &C) {
         const int r0 = CH_W + lane, r1 = CH_W + lane + 64;
         const double y0 = (r0 < nr - 1) ? C.ycam[h[CH_INTS + 2 * min(r0, nr - 1)] & 255] : 0.0;
         const double y1 = (r1 < nr - 1) ? C.ycam[h[CH_INTS + 2 * min(r1, nr - 1)] & 255] : 0.0;
-        double acc[CH_W];
+        // column sums over the rows through LDS (a shuffle tree on 9 doubles costs 108 ds_bpermutes): lane l adds 16 of the 64
+        // per-lane partial products of column l & 15, two xor-shuffles finish the job
+        lds_d *pp = pool + 128;
 #pragma unroll
-        for (int c = 0; c < CH_W; c++) acc[c] = cur.x0[c] * y0 + cur.x1[c] * y1;
-        wave_sum<CH_W>(acc);
+        for (int c = 0; c < CH_W; c++) pp[c * 64 + lane] = cur.x0[c] * y0 + cur.x1[c] * y1;
         mb[lane] = cur.m0;
         mb[64 + lane] = cur.m1;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        {
+            const int c = min(lane & 15, CH_W - 1), g = lane >> 4;
+            double t = 0.0;
+#pragma unroll
+            for (int j = 0; j < 16; j++) t += pp[c * 64 + g * 16 + j];
+            t += __shfl_xor(t, 16);
+            t += __shfl_xor(t, 32);
+            if (lane < CH_W) mb[100 + lane] = t;
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (lane == 0) {
             double y[CH_W];
 #pragma unroll
             for (int c = CH_W - 1; c >= 0; c--) {
-                double a = mb[81 + c] - acc[c];
+                double a = mb[81 + c] - mb[100 + c];
 #pragma unroll
                 for (int c2 = c + 1; c2 < CH_W; c2++) a -= mb[c2 * CH_W + c] * y[c2];
                 y[c] = a * mb[90 + c];
