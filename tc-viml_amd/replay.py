@@ -1,0 +1,455 @@
+"""Front-end-free replay harness: the callers of the hot path.
+
+The reference's steady state is `estimator_node.cpp:process()` -> `Estimator::processIMU` (estimator.cpp:191-228) ->
+`processImagewithLine` (:230-383) -> `solveOdometry` (:1476-1490: triangulate + OptimizationWithLine) ->
+`failureDetection` (:1629-1675) -> `slideWindowWithLinesFoV` (:2121-2259) with `FeatureManager`
+(feature_manager.cpp: addFeaturesCheckParallax :260-334, triangulate :440-492, setDepth :379-397, removeFailures :399-408,
+removeBackShiftDepth :559-616, removeFront :655-696, compensatedParallax2 :698-734).  This module mirrors exactly that
+window management on the host (NumPy) and hands every window to a BACK END:
+
+    backend.preintegrate(bufs)            -> IntegrationBase results for a list of IMU buffers
+    backend.optimize(win, marg_flag)      -> solved + gauge-fixed states and the new marginalisation prior
+
+`HipBackend` is the product path (the C-ABI of include/tcv.h: device pre-integration, fused solve, gauge fix and
+marginalisation kernels).  The tests plug the CPU oracle in through the same interface and compare trajectories (ATE).
+
+The image/IMU front end (feature tracker, line detector, ROS) is out of scope; `simulate_stream` produces the per-frame
+streams it would deliver -- IMU samples, tracked point features, matched 2D-3D lines -- from an analytic trajectory with the
+sensor model of benchmark_publisher/config/V1_01_easy/sensor.yaml.  Initialisation (initialStructure, estimator.cpp:1221)
+is out of scope too: the first window starts from perturbed ground truth.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+import synth
+
+MARGIN_OLD, MARGIN_SECOND_NEW = 0, 1
+WINDOW_SIZE = synth.WINDOW_SIZE
+MIN_PARALLAX = 10.0 / synth.FOCAL_LENGTH        # keyframe_parallax: 10 px (sensor.yaml:87, parameters.cpp:73-74)
+INIT_DEPTH = 5.0                                # parameters.cpp:131
+G = np.array([0.0, 0.0, synth.G_NORM])
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# small rotation helpers (same conventions as the factors: quaternions x y z w)
+# ----------------------------------------------------------------------------------------------------------------
+def q2R(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def R2q(m):
+    """Eigen `Quaterniond q{R}` (vector2double, estimator.cpp:1499)."""
+    q = np.zeros(4)
+    t = m[0, 0] + m[1, 1] + m[2, 2]
+    if t > 0:
+        t = np.sqrt(t + 1.0); q[3] = 0.5 * t; t = 0.5 / t
+        q[0] = (m[2, 1] - m[1, 2]) * t; q[1] = (m[0, 2] - m[2, 0]) * t; q[2] = (m[1, 0] - m[0, 1]) * t
+    else:
+        i = 0
+        if m[1, 1] > m[0, 0]:
+            i = 1
+        if m[2, 2] > m[i, i]:
+            i = 2
+        j = (i + 1) % 3; k = (j + 1) % 3
+        t = np.sqrt(m[i, i] - m[j, j] - m[k, k] + 1.0); q[i] = 0.5 * t; t = 0.5 / t
+        q[3] = (m[k, j] - m[j, k]) * t; q[j] = (m[j, i] + m[i, j]) * t; q[k] = (m[k, i] + m[i, k]) * t
+    return q
+
+
+def deltaQ_R(theta):
+    """Utility::deltaQ(theta).toRotationMatrix() (utility.h:15-28; not normalised, like the reference)."""
+    return q2R(np.array([theta[0] / 2, theta[1] / 2, theta[2] / 2, 1.0]))
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# simulated front-end streams
+# ----------------------------------------------------------------------------------------------------------------
+def simulate_stream(seed: int, n_frames: int, max_features: int = 36, max_lines: int = 4, pixel_sigma: float = 1.0,
+                    t0: float = 0.0, imu_noise: bool = True, pace: float = 0.85):
+    """Per-frame streams of a front end following the analytic trajectory of synth.py at 10 Hz / 200 Hz IMU.
+    Returns dict(t, gt_p, gt_R, gt_v, imu=[(acc (S+1,3), gyr (S+1,3))] per frame (sample 0 = the previous frame's last
+    sample), points=[{id: (x, y, 1)}], lines=[[(pts_start, pts_end, abc)]], ba, bg)."""
+    rng = np.random.Generator(np.random.PCG64(0xFEED + seed))
+    S = synth.IMU_RATE_SUB
+    t = t0 + synth.DT_KF * np.arange(n_frames)
+    ba = rng.uniform(-0.05, 0.05, 3); bg = rng.uniform(-0.01, 0.01, 3)
+    ts = t0 + synth.DT_IMU * np.arange((n_frames - 1) * S + 1)
+    # smooth time warp tau(t): the platform alternates between fast and almost-hovering phases, so that both keyframe
+    # decisions of addFeaturesCheckParallax (MARGIN_OLD / MARGIN_SECOND_NEW) occur
+    wa, ww = pace, 2.0 * np.pi / 3.0
+    tau = lambda x: x + wa / ww * np.sin(ww * x)
+    dtau = lambda x: 1.0 + wa * np.cos(ww * x)
+    ddtau = lambda x: -wa * ww * np.sin(ww * x)
+    Rw = synth.traj_R(tau(ts))
+    a_w = synth.traj_a(tau(ts)) * dtau(ts)[:, None] ** 2 + synth.traj_v(tau(ts)) * ddtau(ts)[:, None]
+    acc = (np.swapaxes(Rw, -1, -2) @ (a_w + G)[..., None])[..., 0] + ba
+    gyr = synth.traj_w_body(tau(ts)) * dtau(ts)[:, None] + bg
+    if imu_noise:      # discrete-time white noise of a 200 Hz IMU with the continuous densities of sensor.yaml:90-91
+        acc = acc + rng.normal(size=acc.shape) * synth.ACC_N * 0.1
+        gyr = gyr + rng.normal(size=gyr.shape) * synth.GYR_N * 0.1
+    imu = [None] + [(acc[(k - 1) * S:k * S + 1].copy(), gyr[(k - 1) * S:k * S + 1].copy()) for k in range(1, n_frames)]
+    Rk = synth.traj_R(tau(t)); pk = synth.traj_p(tau(t)); vk = synth.traj_v(tau(t)) * dtau(t)[:, None]
+    Rwc, twc = synth._cam_pose(Rk, pk)
+    ps_pool, pe_pool = synth.line_pool()
+    land = []            # world points, spawned in front of the camera when the tracker runs short of features
+    alive = []
+    points, lines = [], []
+    for k in range(n_frames):
+        obs = {}
+        if land:
+            Pw = np.array(land)
+            pc = synth._project(Rwc[k], twc[k], Pw)
+            vis = synth._visible_norm(pc, 8.0) & (pc[:, 2] < 14.0)
+            for i in np.nonzero(vis & np.array(alive))[0]:
+                obs[int(i)] = pc[i]
+            for i in range(len(land)):
+                if alive[i] and not vis[i]:
+                    alive[i] = False          # a lost track is never re-acquired (feature_tracker behaviour)
+        while len(obs) < max_features:
+            d = rng.uniform(3.0, 8.0)
+            u = rng.uniform(30.0, synth.IMG_W - 30.0); v = rng.uniform(30.0, synth.IMG_H - 30.0)
+            pc = np.array([(u - synth.CX) / synth.FX * d, (v - synth.CY) / synth.FY * d, d])
+            land.append(Rwc[k] @ pc + twc[k]); alive.append(True)
+            obs[len(land) - 1] = pc
+        frame_pts = {}
+        for i in sorted(obs)[:max_features]:
+            pc = obs[i]
+            n = rng.normal(size=2) * pixel_sigma / synth.FOCAL_LENGTH
+            frame_pts[i] = np.array([pc[0] / pc[2] + n[0], pc[1] / pc[2] + n[1], 1.0])
+        points.append(frame_pts)
+        fl = []
+        pcs = synth._project(Rwc[k], twc[k], ps_pool); pce = synth._project(Rwc[k], twc[k], pe_pool)
+        ok = np.nonzero(synth._visible_norm(pcs, 5.0) & synth._visible_norm(pce, 5.0))[0]
+        for i in ok[:max_lines]:
+            uv = []
+            for pc in (pcs[i], pce[i]):
+                uv.append(np.array([synth.FX * pc[0] / pc[2] + synth.CX, synth.FY * pc[1] / pc[2] + synth.CY]) + rng.normal(size=2) * pixel_sigma)
+            (xs, ys), (xe, ye) = uv
+            abc = np.array([ye - ys, xs - xe, xe * ys - xs * ye])          # feature_manager.cpp:11-13
+            fl.append((ps_pool[i].copy(), pe_pool[i].copy(), abc))
+        lines.append(fl)
+    return dict(t=t, gt_p=pk, gt_R=Rk, gt_v=vk, imu=imu, points=points, lines=lines, ba=ba, bg=bg)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# window management (Estimator + FeatureManager mirror)
+# ----------------------------------------------------------------------------------------------------------------
+class Feature:
+    __slots__ = ("id", "start_frame", "obs", "depth", "solve_flag")
+
+    def __init__(self, fid, start_frame):
+        self.id, self.start_frame, self.obs, self.depth, self.solve_flag = fid, start_frame, [], -1.0, 0      # FeaturePerId ctor: estimated_depth(-1.0)
+
+    def end_frame(self):
+        return self.start_frame + len(self.obs) - 1
+
+
+class Replay:
+    def __init__(self, backend, num_iterations: int = 8, fixed_iterations: bool = False):
+        W = WINDOW_SIZE
+        self.backend = backend
+        self.num_iterations, self.fixed_iterations = num_iterations, fixed_iterations
+        self.Ps = np.zeros((W + 1, 3)); self.Rs = np.tile(np.eye(3), (W + 1, 1, 1)); self.Vs = np.zeros((W + 1, 3))
+        self.Bas = np.zeros((W + 1, 3)); self.Bgs = np.zeros((W + 1, 3))
+        self.tic = synth.TIC.copy(); self.ric = synth.RIC.copy()
+        self.bufs = [None] * (W + 1)       # per slot: dict(acc0, gyr0, ba, bg, acc [S,3], gyr [S,3]) = pre_integrations[j] + dt/acc/gyr_buf[j]
+        self.pre = [None] * (W + 1)        # cached pre-integration of every slot
+        self.features = []                 # f_manager.feature (insertion order matters: it is the landmark order)
+        self.line_obs = [[] for _ in range(W + 1)]
+        self.prior = None                  # last_marginalization_info + last_marginalization_parameter_blocks
+        self.frame_count = 0
+        self.marg_flag = MARGIN_OLD
+        self.acc_0 = None; self.gyr_0 = None
+        self.last_P = None; self.last_R = None
+        self.log = []
+
+    # ---- IMU ---------------------------------------------------------------------------------------------------
+    def process_imu(self, acc, gyr):
+        """Estimator::processIMU for all samples between two frames; acc/gyr (S+1, 3), row 0 = the previous frame's last sample."""
+        j = self.frame_count
+        if self.acc_0 is None:
+            self.acc_0, self.gyr_0 = acc[0].copy(), gyr[0].copy()
+        if self.bufs[j] is None:
+            self.bufs[j] = dict(acc0=self.acc_0.copy(), gyr0=self.gyr_0.copy(), ba=self.Bas[j].copy(), bg=self.Bgs[j].copy(), acc=[], gyr=[])
+        dt = synth.DT_IMU
+        for a, w in zip(acc[1:], gyr[1:]):
+            if j != 0:
+                self.bufs[j]["acc"].append(a.copy()); self.bufs[j]["gyr"].append(w.copy())
+                un_acc_0 = self.Rs[j] @ (self.acc_0 - self.Bas[j]) - G               # estimator.cpp:217-224
+                un_gyr = 0.5 * (self.gyr_0 + w) - self.Bgs[j]
+                self.Rs[j] = self.Rs[j] @ deltaQ_R(un_gyr * dt)
+                un_acc_1 = self.Rs[j] @ (a - self.Bas[j]) - G
+                un_acc = 0.5 * (un_acc_0 + un_acc_1)
+                self.Ps[j] = self.Ps[j] + dt * self.Vs[j] + 0.5 * dt * dt * un_acc
+                self.Vs[j] = self.Vs[j] + dt * un_acc
+            self.acc_0, self.gyr_0 = a.copy(), w.copy()
+        self.pre[j] = None
+
+    # ---- FeatureManager ------------------------------------------------------------------------------------------
+    def add_features_check_parallax(self, pts: dict, lines: list) -> bool:
+        fc = self.frame_count
+        by_id = {f.id: f for f in self.features}
+        last_track_num = 0
+        for fid, p in pts.items():
+            f = by_id.get(fid)
+            if f is None:
+                f = Feature(fid, fc); self.features.append(f)
+            else:
+                last_track_num += 1
+            f.obs.append(np.asarray(p, dtype=float))
+        self.line_obs[fc] = list(lines)
+        if fc < 2 or last_track_num < 20:
+            return True
+        s, n = 0.0, 0
+        for f in self.features:
+            if f.start_frame <= fc - 2 and f.end_frame() >= fc - 1:
+                pi, pj = f.obs[fc - 2 - f.start_frame], f.obs[fc - 1 - f.start_frame]      # compensatedParallax2 (:698-734)
+                du, dv = pi[0] / pi[2] - pj[0], pi[1] / pi[2] - pj[1]
+                s += np.sqrt(du * du + dv * dv); n += 1
+        return True if n == 0 else (s / n >= MIN_PARALLAX)
+
+    def _selected(self):
+        return [f for f in self.features if len(f.obs) >= 2 and f.start_frame < WINDOW_SIZE - 2]
+
+    def triangulate(self):
+        for f in self._selected():
+            if f.depth > 0:
+                continue
+            i = f.start_frame
+            t0 = self.Ps[i] + self.Rs[i] @ self.tic; R0 = self.Rs[i] @ self.ric
+            A = []
+            for k, p in enumerate(f.obs):
+                j = i + k
+                t1 = self.Ps[j] + self.Rs[j] @ self.tic; R1 = self.Rs[j] @ self.ric
+                t = R0.T @ (t1 - t0); R = R0.T @ R1
+                P = np.hstack([R.T, (-R.T @ t)[:, None]])
+                fn = p / np.linalg.norm(p)
+                A.append(fn[0] * P[2] - fn[2] * P[0]); A.append(fn[1] * P[2] - fn[2] * P[1])
+            V = np.linalg.svd(np.array(A))[2][-1]
+            f.depth = V[2] / V[3]
+            if f.depth < 0.1:
+                f.depth = INIT_DEPTH
+
+    # ---- window -> back end ----------------------------------------------------------------------------------------
+    def _preintegrations(self):
+        need = [j for j in range(1, WINDOW_SIZE + 1) if self.pre[j] is None]
+        if need:
+            res = self.backend.preintegrate([self.bufs[j] for j in need])
+            for j, r in zip(need, res):
+                self.pre[j] = r
+        return [self.pre[j] for j in range(1, WINDOW_SIZE + 1)]
+
+    def build_window(self):
+        W = WINDOW_SIZE
+        pose = np.zeros((W + 1, 7)); sb = np.zeros((W + 1, 9))
+        for i in range(W + 1):      # vector2double (estimator.cpp:1492-1535)
+            pose[i, :3] = self.Ps[i]; pose[i, 3:] = R2q(self.Rs[i])
+            sb[i, :3] = self.Vs[i]; sb[i, 3:6] = self.Bas[i]; sb[i, 6:] = self.Bgs[i]
+        ex = np.concatenate([self.tic, R2q(self.ric)])
+        sel = self._selected()
+        lam = np.array([1.0 / f.depth for f in sel])
+        pre = self._preintegrations()
+        keep = [k for k in range(W) if pre[k]["sum_dt"] <= 10.0]          # estimator.cpp:1726
+        imu = {key: np.array([pre[k][key] for k in keep]) for key in ("delta_p", "delta_q", "delta_v", "lin_ba", "lin_bg", "sum_dt", "jacobian", "covariance")}
+        imu["frame_i"] = np.array(keep, dtype=np.int64); imu["frame_j"] = np.array(keep, dtype=np.int64) + 1
+        fi, fj, fl, pi, pj = [], [], [], [], []
+        for l, f in enumerate(sel):      # estimator.cpp:1737-1771
+            for k in range(1, len(f.obs)):
+                fi.append(f.start_frame); fj.append(f.start_frame + k); fl.append(l); pi.append(f.obs[0]); pj.append(f.obs[k])
+        proj = dict(frame_i=np.array(fi, dtype=np.int64), frame_j=np.array(fj, dtype=np.int64), landmark=np.array(fl, dtype=np.int64),
+                    pts_i=np.array(pi).reshape(-1, 3), pts_j=np.array(pj).reshape(-1, 3), sqrt_info=synth.PROJ_SQRT_INFO, loss_a=1.0)
+        lf, lps, lpe, labc = [], [], [], []
+        for i in range(W + 1):           # estimator.cpp:1786-1846 (every stored match is a credible one here)
+            for (ps, pe, abc) in self.line_obs[i]:
+                lf.append(i); lps.append(ps); lpe.append(pe); labc.append(abc)
+        line = dict(frame=np.array(lf, dtype=np.int64), pts_start=np.array(lps).reshape(-1, 3), pts_end=np.array(lpe).reshape(-1, 3),
+                    abc=np.array(labc).reshape(-1, 3), K=synth.K_MAT.copy(), Ric=q2R(ex[3:] / np.linalg.norm(ex[3:])), Tic=self.tic.copy(), loss_a=1.0)
+        win = dict(pose=pose, speedbias=sb, ex_pose=ex, lam=lam, imu=imu, proj=proj, line=line, G=G.copy(), prior=self.prior)
+        return win, sel
+
+    def optimize(self):
+        """solveOdometry (:1476-1490) + double2vector + the marginalisation of OptimizationWithLine."""
+        self.triangulate()
+        win, sel = self.build_window()
+        out = self.backend.optimize(win, self.marg_flag, self.num_iterations, self.fixed_iterations)
+        W = WINDOW_SIZE
+        for i in range(W + 1):       # double2vector (:1565-1581) -- the gauge fix itself runs in the back end
+            self.Ps[i] = out["pose"][i, :3]; self.Rs[i] = q2R(out["pose"][i, 3:])
+            self.Vs[i] = out["sb"][i, :3]; self.Bas[i] = out["sb"][i, 3:6]; self.Bgs[i] = out["sb"][i, 6:]
+        self.tic = out["ex"][:3].copy(); self.ric = q2R(out["ex"][3:])
+        for f, lam in zip(sel, out["lam"]):      # setDepth (feature_manager.cpp:379-397)
+            f.depth = 1.0 / lam
+            f.solve_flag = 2 if f.depth < 0 else 1
+        if out.get("prior", "keep") != "keep":
+            self.prior = out["prior"]
+        self.log.append(dict(flag=self.marg_flag, n_landmarks=len(sel), n_proj=len(win["proj"]["frame_i"]), n_line=len(win["line"]["frame"]),
+                             iterations=out.get("iterations"), final_cost=out.get("final_cost"), prior_n=None if self.prior is None else self.prior["n"]))
+
+    def failure_detection(self) -> bool:
+        W = WINDOW_SIZE
+        if np.linalg.norm(self.Bas[W]) > 2.5 or np.linalg.norm(self.Bgs[W]) > 1.0:
+            return True
+        if self.last_P is not None:
+            if np.linalg.norm(self.Ps[W] - self.last_P) > 5 or abs(self.Ps[W][2] - self.last_P[2]) > 1:
+                return True
+        return False
+
+    # ---- sliding ---------------------------------------------------------------------------------------------------
+    def slide_window(self):
+        W = WINDOW_SIZE
+        if self.frame_count != W:
+            return
+        if self.marg_flag == MARGIN_OLD:
+            back_R0, back_P0 = self.Rs[0].copy(), self.Ps[0].copy()
+            for arr in (self.Ps, self.Rs, self.Vs, self.Bas, self.Bgs):
+                arr[:-1] = arr[1:].copy()            # the swaps of :2131-2153 followed by the copy of slot W-1 into W
+            self.bufs = self.bufs[1:] + [None]
+            self.pre = self.pre[1:] + [None]
+            self.line_obs = self.line_obs[1:] + [list(self.line_obs[W])]      # WorldLinesInFOV[W] = WorldLinesInFOV[W-1] (:2158)
+            self.bufs[W] = dict(acc0=self.acc_0.copy(), gyr0=self.gyr_0.copy(), ba=self.Bas[W].copy(), bg=self.Bgs[W].copy(), acc=[], gyr=[])
+            # slideWindowOld (:2242-2259) -> removeBackShiftDepth (feature_manager.cpp:559-616)
+            R0 = back_R0 @ self.ric; R1 = self.Rs[0] @ self.ric
+            P0 = back_P0 + back_R0 @ self.tic; P1 = self.Ps[0] + self.Rs[0] @ self.tic
+            kept = []
+            for f in self.features:
+                if f.start_frame != 0:
+                    f.start_frame -= 1; kept.append(f); continue
+                uv_i = f.obs.pop(0)
+                if len(f.obs) < 2:
+                    continue
+                pts_j = R1.T @ (R0 @ (uv_i * f.depth) + P0 - P1)
+                f.depth = pts_j[2] if pts_j[2] > 0 else INIT_DEPTH
+                kept.append(f)
+            self.features = kept
+        else:
+            # MARGIN_SECOND_NEW (:2189-2230): the newest frame replaces the second newest, their IMU buffers are concatenated
+            self.bufs[W - 1]["acc"] += self.bufs[W]["acc"]; self.bufs[W - 1]["gyr"] += self.bufs[W]["gyr"]
+            self.pre[W - 1] = None
+            for arr in (self.Ps, self.Rs, self.Vs, self.Bas, self.Bgs):
+                arr[W - 1] = arr[W].copy()
+            self.line_obs[W - 1] = list(self.line_obs[W])
+            self.bufs[W] = dict(acc0=self.acc_0.copy(), gyr0=self.gyr_0.copy(), ba=self.Bas[W].copy(), bg=self.Bgs[W].copy(), acc=[], gyr=[])
+            self.pre[W] = None
+            kept = []                                  # slideWindowNew -> removeFront(frame_count) (feature_manager.cpp:655-675)
+            for f in self.features:
+                if f.start_frame == W:
+                    f.start_frame -= 1; kept.append(f); continue
+                if f.end_frame() < W - 1:
+                    kept.append(f); continue
+                f.obs.pop(W - 1 - f.start_frame)
+                if len(f.obs) > 0:
+                    kept.append(f)
+            self.features = kept
+        self.features = [f for f in self.features if f.solve_flag != 2]          # removeFailures (:399-408)
+
+    # ---- one frame ---------------------------------------------------------------------------------------------------
+    def process_frame(self, imu, pts, lines, truth=None):
+        """processIMU for the interval + processImagewithLine.  While the window fills (solver_flag == INITIAL) the states come
+        from `truth` = (P, R, V): initialisation is out of scope."""
+        W = WINDOW_SIZE
+        if imu is not None:
+            self.process_imu(*imu)
+        self.marg_flag = MARGIN_OLD if self.add_features_check_parallax(pts, lines) else MARGIN_SECOND_NEW
+        if truth is not None:
+            self.Ps[self.frame_count], self.Rs[self.frame_count], self.Vs[self.frame_count] = truth
+        if self.frame_count < W:
+            self.frame_count += 1
+            j = self.frame_count
+            self.Bas[j] = self.Bas[j - 1]; self.Bgs[j] = self.Bgs[j - 1]
+            self.Ps[j] = self.Ps[j - 1]; self.Rs[j] = self.Rs[j - 1]; self.Vs[j] = self.Vs[j - 1]
+            return None
+        self.optimize()
+        if self.failure_detection():
+            raise RuntimeError("failure detection (estimator.cpp:1629-1675): the replay diverged")
+        res = (self.Ps[W].copy(), R2q(self.Rs[W]), self.Vs[W].copy())
+        self.slide_window()
+        self.last_P, self.last_R = self.Ps[W].copy(), self.Rs[W].copy()
+        return res
+
+
+def run(stream: dict, backend, num_iterations: int = 8, fixed_iterations: bool = False, init_sigma=(0.02, 0.005, 0.05), bias_sigma=(0.005, 0.0005)):
+    """replays a simulated stream; returns dict(t, p, q, v) of Ps/Rs/Vs[WINDOW_SIZE] after every optimisation (what pubOdometry
+    writes, visualization.cpp:210-226) plus the per-frame log."""
+    rng = np.random.Generator(np.random.PCG64(0xABCD))
+    rp = Replay(backend, num_iterations, fixed_iterations)
+    # the reference's initialisation calibrates the gyroscope bias (initial_aligment.cpp) before the first window; here the
+    # biases start near the truth like the other states
+    rp.Bas[:] = stream["ba"] + rng.normal(size=3) * bias_sigma[0]; rp.Bgs[:] = stream["bg"] + rng.normal(size=3) * bias_sigma[1]
+    out_t, out_p, out_q, out_v = [], [], [], []
+    for k in range(len(stream["t"])):
+        truth = None
+        if k <= WINDOW_SIZE:       # window fill: perturbed ground truth instead of initialStructure
+            dth = rng.normal(size=3) * init_sigma[1]
+            truth = (stream["gt_p"][k] + rng.normal(size=3) * init_sigma[0], stream["gt_R"][k] @ deltaQ_R(dth),
+                     stream["gt_v"][k] + rng.normal(size=3) * init_sigma[2])
+        r = rp.process_frame(stream["imu"][k], stream["points"][k], stream["lines"][k], truth)
+        if r is not None:
+            out_t.append(stream["t"][k]); out_p.append(r[0]); out_q.append(r[1]); out_v.append(r[2])
+    return dict(t=np.array(out_t), p=np.array(out_p), q=np.array(out_q), v=np.array(out_v), log=rp.log)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# the product back end: C-ABI of include/tcv.h
+# ----------------------------------------------------------------------------------------------------------------
+class HipBackend:
+    """pre-integration, solve, gauge fix and marginalisation on the MI355X through libtcv_hip.so."""
+
+    def __init__(self):
+        import tcv
+        self.tcv = tcv
+        if tcv.lib().tcv_device_count() < 1:
+            raise RuntimeError("HipBackend needs a HIP device: the product has no CPU path")
+
+    def preintegrate(self, bufs):
+        tcv = self.tcv
+        n = len(bufs)
+        first, count, rows = [], [], []
+        for b in bufs:
+            first.append(len(rows)); count.append(len(b["acc"]))
+            for a, w in zip(b["acc"], b["gyr"]):
+                rows.append([synth.DT_IMU, *a, *w])
+        samples = tcv.f64(np.array(rows).reshape(-1, 7))
+        init = tcv.f64(np.array([[*b["acc0"], *b["gyr0"], *b["ba"], *b["bg"]] for b in bufs]))
+        noise = tcv.f64([synth.ACC_N, synth.GYR_N, synth.ACC_W, synth.GYR_W])
+        fi, ci = tcv.i32(first), tcv.i32(count)
+        out = (tcv.ImuPreintegration * n)()
+        tcv.check(tcv.lib().tcv_preintegrate(n, tcv.iptr(fi), tcv.iptr(ci), tcv.dptr(samples), samples.shape[0], tcv.dptr(init), tcv.dptr(noise), out))
+        return [dict(delta_p=np.array(o.delta_p), delta_q=np.array(o.delta_q), delta_v=np.array(o.delta_v), lin_ba=np.array(o.linearized_ba),
+                     lin_bg=np.array(o.linearized_bg), sum_dt=float(o.sum_dt), jacobian=np.array(o.jacobian).reshape(15, 15),
+                     covariance=np.array(o.covariance).reshape(15, 15)) for o in out]
+
+    def optimize(self, win, marg_flag, num_iterations, fixed_iterations):
+        tcv = self.tcv
+        W = tcv.Window(win)
+        Wn = win["pose"].shape[0] - 1
+        prior_blocks = [tuple(b) for b in win["prior"]["blocks"]] if win.get("prior") is not None else []
+        do_marg = marg_flag == MARGIN_OLD or ("pose", Wn - 1) in prior_blocks
+        if do_marg:
+            if marg_flag == MARGIN_OLD:
+                mw = tcv.margin_old_window(win); M = tcv.Window(mw, share=W, prior=W.prior); drops = tcv.margin_old_drops(W, mw)
+            else:
+                mw = tcv.margin_second_new_window(win); M = tcv.Window(mw, share=W, prior=W.prior); drops = tcv.margin_second_new_drops(W)
+            b = tcv.Batch([W], [M], [drops])
+        else:
+            b = tcv.Batch([W])
+        b.solve(tcv.default_options(num_iterations, fixed_iterations))
+        b.gauge_fix()
+        if do_marg:
+            b.marginalize()
+        b.synchronize(); b.download_states()
+        s = b.summaries()[0]
+        out = dict(pose=W.pose.copy(), sb=W.sb.copy(), ex=W.ex.copy(), lam=W.lam.copy(), iterations=s.num_iterations, final_cost=s.final_cost, prior="keep")
+        if do_marg:
+            P = b.prior(0)
+            d = P.export()
+            shift = (lambda nm, i: (nm, i - 1) if nm in ("pose", "sb") else (nm, i)) if marg_flag == MARGIN_OLD else \
+                    (lambda nm, i: (nm, i - 1) if (nm in ("pose", "sb") and i == Wn) else (nm, i))
+            d["blocks"] = tcv.prior_blocks(P, W, shift)
+            out["prior"] = d
+        return out

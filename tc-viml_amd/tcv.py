@@ -345,8 +345,9 @@ def margin_old_drops(w: "Window", mwin: dict):
     return drops
 
 
-def shifted_prior_blocks(prior: "Prior", w: "Window"):
-    """getParameterBlocks(addr_shift) for MARGIN_OLD (estimator.cpp:2027-2039): pose i -> i-1, speed-bias i -> i-1."""
+def prior_blocks(prior: "Prior", w: "Window", shift):
+    """getParameterBlocks(addr_shift) (marginalization_factor.cpp:301-321): the kept blocks as (name, index) after applying
+    `shift(name, index)` -- the addr_shift map of estimator.cpp:2027-2039 (MARGIN_OLD) or :2084-2104 (MARGIN_SECOND_NEW)."""
     m, n, nb, xs = prior.dims()
     addrs = (_dp * nb)()
     check(lib().tcv_prior_keep_block_addresses(prior.h, addrs))
@@ -356,12 +357,16 @@ def shifted_prior_blocks(prior: "Prior", w: "Window"):
         a = C.cast(addrs[k], C.c_void_p).value
         for name, (b0, stride, cnt) in base.items():
             if b0 <= a < b0 + stride * cnt and (a - b0) % stride == 0:
-                i = (a - b0) // stride
-                out.append((name, i - 1) if name in ("pose", "sb") else (name, 0))
+                out.append(tuple(shift(name, (a - b0) // stride)))
                 break
         else:
             raise ValueError("kept block is not a pose / speed-bias / extrinsic block")
     return out
+
+
+def shifted_prior_blocks(prior: "Prior", w: "Window"):
+    """getParameterBlocks(addr_shift) for MARGIN_OLD (estimator.cpp:2027-2039): pose i -> i-1, speed-bias i -> i-1."""
+    return prior_blocks(prior, w, lambda name, i: (name, i - 1) if name in ("pose", "sb") else (name, 0))
 
 
 class Batch:

@@ -1,0 +1,26 @@
+"""N1 on the GPU (BASELINE configs[3] in spirit: full replay through the HIP back end, ATE parity vs the reference
+algorithm): the same simulated front-end streams are replayed through the C-ABI (device pre-integration, fused solve,
+gauge fix, marginalisation) and through the CPU oracle; the two trajectories must agree to 1 mm (north-star)."""
+import numpy as np
+import pytest
+
+import ate
+import replay
+from replay_oracle import OracleBackend
+
+pytestmark = pytest.mark.gpu
+
+
+def test_replay_hip_vs_oracle_ate(gpu):
+    stream = replay.simulate_stream(1, 36, max_features=30)
+    hip = replay.run(stream, replay.HipBackend(), num_iterations=8)
+    ref = replay.run(stream, OracleBackend(), num_iterations=8)
+    assert len(hip["t"]) == len(ref["t"]) == 36 - replay.WINDOW_SIZE
+    assert [l["flag"] for l in hip["log"]] == [l["flag"] for l in ref["log"]]
+    assert [l["iterations"] for l in hip["log"]] == [l["iterations"] for l in ref["log"]]
+    d = np.linalg.norm(hip["p"] - ref["p"], axis=1)
+    print("max |p_hip - p_oracle| per frame [m]:", np.array2string(d, precision=2))
+    assert ate.ate_rmse(hip["p"], ref["p"], align=False) < 1e-3            # ATE of the HIP replay w.r.t. the reference algorithm
+    assert d.max() < 1e-3
+    i, j = ate.associate(hip["t"], stream["t"])
+    assert abs(ate.ate_rmse(hip["p"][i], stream["gt_p"][j]) - ate.ate_rmse(ref["p"][i], stream["gt_p"][j])) < 1e-3
