@@ -236,6 +236,13 @@ int tcv_eval_imu_factors(int n, const tcv_imu_preintegration *pre, const double 
 /* ProjectionFactor::Evaluate projection_factor.cpp:21-124: params n x (7+7+7+1), pts n x 6, residuals n x 2, jacobians n x (14+14+14+2) */
 int tcv_eval_projection_factors(int n, const double *pts, const double *params, double sqrt_info,
                                 double *residuals, double *jacobians);
+/* ProjectionTdFactor::Evaluate projection_td_factor.cpp:34-140 (camera-IMU time offset + rolling shutter; selected by ESTIMATE_TD,
+ * estimator.cpp:1757, which is 0 in every shipped configuration -- the fused solver does not take this factor yet):
+ * params n x (7+7+7+1+1) = pose_i, pose_j, ex_pose, inverse depth, td; pts n x 6; aux n x 8 = velocity_i xy, velocity_j xy, td_i,
+ * td_j, row_i, row_j (constructor arguments, :6-18); TR / ROW = rolling-shutter read-out time / image height (parameters.cpp:92,145);
+ * residuals n x 2, jacobians n x (14+14+14+2+2) */
+int tcv_eval_projection_td_factors(int n, const double *pts, const double *aux, const double *params, double sqrt_info,
+                                   double TR, double ROW, double *residuals, double *jacobians);
 /* LineProjectionFactor::Evaluate line_projection_factor.cpp:19-120: params n x 7, line n x 9, residuals n x 2, jacobians n x 14 */
 int tcv_eval_line_factors(int n, const double *line_data, const double K[9], const double b_c_R[9],
                           const double b_c_T[3], const double *params, double *residuals, double *jacobians);

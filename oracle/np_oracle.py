@@ -810,3 +810,25 @@ def gauge_fix(R0, P0, pose, sb):
         Vs[i] = rot @ sb[i, :3]
         po[i, :3] = Ps[i]; po[i, 3:] = R2q(Rs[i])
     return Rs, Ps, Vs, po
+
+
+# --------------------------------------------------------------------------------------
+# T1: ProjectionTdFactor::Evaluate   factor/projection_td_factor.cpp:34-140  (<2,7,7,7,1,1>)
+# --------------------------------------------------------------------------------------
+def proj_td_evaluate(pose_i, pose_j, ex, lam, td, pts_i, pts_j, vel_i, vel_j, td_i, td_j, row_i, row_j, sqrt_info_scalar, TR, ROW,
+                     want_jac=True):
+    vi = np.array([vel_i[0], vel_i[1], 0.0]); vj = np.array([vel_j[0], vel_j[1], 0.0])            # :11-16
+    ri = row_i - ROW / 2; rj = row_j - ROW / 2                                                    # :17-18
+    pts_i_td = np.asarray(pts_i, dtype=float) - (td - td_i + TR / ROW * ri) * vi                  # :50-51
+    pts_j_td = np.asarray(pts_j, dtype=float) - (td - td_j + TR / ROW * rj) * vj
+    r, Js = proj_evaluate(pose_i, pose_j, ex, lam, pts_i_td, pts_j_td, sqrt_info_scalar, want_jac)   # :52-130 are ProjectionFactor's
+    if not want_jac:
+        return r, None
+    Pi, Qi = pose_i[:3], pose_i[3:7]; Pj, Qj = pose_j[:3], pose_j[3:7]; tic, qic = ex[:3], ex[3:7]
+    pc_i = pts_i_td / lam
+    pc_j = qrot(qinv(qic), qrot(qinv(Qj), qrot(Qi, qrot(qic, pc_i) + tic) + Pi - Pj) - tic)
+    dep_j = pc_j[2]
+    reduce = sqrt_info_scalar * np.array([[1.0 / dep_j, 0, -pc_j[0] / (dep_j * dep_j)], [0, 1.0 / dep_j, -pc_j[1] / (dep_j * dep_j)]])
+    Ri, Rj, ric = q2R(Qi), q2R(Qj), q2R(qic)
+    J_td = reduce @ ric.T @ Rj.T @ Ri @ ric @ vi / lam * -1.0 + sqrt_info_scalar * vj[:2]        # :131-136
+    return r, Js + [J_td.reshape(2, 1)]

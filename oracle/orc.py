@@ -64,6 +64,7 @@ def lib():
         _lib.orc_prior_residual.argtypes = [C.POINTER(OrcWindow), _dp]
         _lib.orc_linearize_dense.argtypes = [C.POINTER(OrcWindow), _dp, _dp, _dp, _ip, _ip]
         _lib.orc_marginalize_old.argtypes = [C.POINTER(OrcWindow), _ip, _ip, _ip, _ip, _ip, _ip, _ip, _dp, _dp, _dp, _dp, _dp]
+        _lib.orc_proj_td_evaluate.argtypes = [_dp, _dp, _dp, C.c_double, C.c_double, _dp, _dp, _dp, C.c_double, C.c_double, C.c_double, _dp, C.POINTER(_dp)]
         _lib.orc_gauge_fix.argtypes = [C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
         _lib.orc_eig_sym.argtypes = [C.c_int, _dp, _dp, _dp]
         _lib.orc_loss_correct.restype = C.c_double

@@ -391,6 +391,40 @@ void orc_proj_evaluate(const double *pose_i, const double *pose_j, const double 
 }
 
 /* ------------------------------------------------------------------------------------------
+ * T1  factor/projection_td_factor.cpp:34-140: P1 on time-offset / rolling-shutter corrected observations + d/dtd
+ * ---------------------------------------------------------------------------------------- */
+void orc_proj_td_evaluate(const double *pose_i, const double *pose_j, const double *ex, double lam, double td,
+                          const double *pts_i, const double *pts_j, const double *aux, double si, double TR, double ROW,
+                          double *r, double **jac) {
+    const double vi[3] = {aux[0], aux[1], 0.0}, vj[3] = {aux[2], aux[3], 0.0};       /* :11-16 */
+    const double row_i = aux[6] - ROW / 2, row_j = aux[7] - ROW / 2;                   /* :17-18 */
+    double pi_td[3], pj_td[3];
+    for (int i = 0; i < 3; i++) {                                                      /* :50-51 */
+        pi_td[i] = pts_i[i] - (td - aux[4] + TR / ROW * row_i) * vi[i];
+        pj_td[i] = pts_j[i] - (td - aux[5] + TR / ROW * row_j) * vj[i];
+    }
+    orc_proj_evaluate(pose_i, pose_j, ex, lam, pi_td, pj_td, si, r, jac);              /* :52-130 = ProjectionFactor on the corrected points */
+    if (!jac || !jac[4]) return;
+    const double *Pi = pose_i, *Qi = pose_i + 3, *Pj = pose_j, *Qj = pose_j + 3, *tic = ex, *qic = ex + 3;
+    double pci[3], pii[3], pw[3], pij[3], pcj[3], t[3], Qj_inv[4], qic_inv[4];
+    for (int i = 0; i < 3; i++) pci[i] = pi_td[i] / lam;
+    q_rot(qic, pci, t); for (int i = 0; i < 3; i++) pii[i] = t[i] + tic[i];
+    q_rot(Qi, pii, t); for (int i = 0; i < 3; i++) pw[i] = t[i] + Pi[i];
+    q_inv(Qj, Qj_inv); for (int i = 0; i < 3; i++) t[i] = pw[i] - Pj[i];
+    q_rot(Qj_inv, t, pij);
+    q_inv(qic, qic_inv); for (int i = 0; i < 3; i++) t[i] = pij[i] - tic[i];
+    q_rot(qic_inv, t, pcj);
+    const double dep_j = pcj[2];
+    const double red[6] = {si * (1. / dep_j), 0, si * (-pcj[0] / (dep_j * dep_j)), 0, si * (1. / dep_j), si * (-pcj[1] / (dep_j * dep_j))};
+    double Ri[9], Rj[9], ric[9], ricT[9], RjT[9], A[9], T2[9], tmp_r[9], v[3];
+    q_toR(Qi, Ri); q_toR(Qj, Rj); q_toR(qic, ric); m33_T(ric, ricT); m33_T(Rj, RjT);
+    m33_mul(ricT, RjT, A); m33_mul(A, Ri, T2); m33_mul(T2, ric, tmp_r);
+    m33_v(tmp_r, vi, v);
+    for (int i = 0; i < 2; i++)                                                        /* :131-136 */
+        jac[4][i] = (red[3 * i] * v[0] + red[3 * i + 1] * v[1] + red[3 * i + 2] * v[2]) / lam * -1.0 + si * vj[i];
+}
+
+/* ------------------------------------------------------------------------------------------
  * L1  factor/line_projection_factor.cpp:19-120  (Jacobian copied as written)
  * ---------------------------------------------------------------------------------------- */
 void orc_line_evaluate(const double *pose, const double *lc, const double *K, const double *bcR, const double *bcT,

@@ -69,6 +69,10 @@ void orc_imu_evaluate(const double *pose_i, const double *sb_i, const double *po
 /* P1 projection_factor.cpp:21-124.  row-major 2x7,2x7,2x7,2x1 */
 void orc_proj_evaluate(const double *pose_i, const double *pose_j, const double *ex, double lam,
                        const double *pts_i, const double *pts_j, double sqrt_info, double *r, double **jac);
+/* T1 projection_td_factor.cpp:34-140.  aux = velocity_i xy, velocity_j xy, td_i, td_j, row_i, row_j; jac[k] row-major 2x7,2x7,2x7,2x1,2x1 */
+void orc_proj_td_evaluate(const double *pose_i, const double *pose_j, const double *ex, double lam, double td,
+                          const double *pts_i, const double *pts_j, const double *aux, double sqrt_info, double TR, double ROW,
+                          double *r, double **jac);
 /* L1 line_projection_factor.cpp:19-120.  row-major 2x7 */
 void orc_line_evaluate(const double *pose, const double *line_c, const double *K, const double *Ric,
                        const double *Tic, double *r, double *jac);

@@ -646,6 +646,23 @@ __global__ void eval_proj_kernel(int n, const double *pts, const double *params,
         }
     o[42] = J[18]; o[43] = J[19 + 18];
 }
+__global__ void eval_proj_td_kernel(int n, const double *pts, const double *aux, const double *params, double sqrt_info, double TR, double ROW,
+                                    double *res, double *jac) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double *pm = params + (size_t)i * 23;
+    double r[2], J[40];
+    proj_td_eval(pm, pm + 7, pm + 14, pm[21], pm[22], pts + (size_t)i * 6, aux + (size_t)i * 8, sqrt_info, TR, ROW, r, jac ? J : nullptr, 20);
+    res[2 * i] = r[0]; res[2 * i + 1] = r[1];
+    if (!jac) return;
+    double *o = jac + (size_t)i * 46;   // 2x7 | 2x7 | 2x7 | 2x1 | 2x1
+    for (int b = 0; b < 3; b++)
+        for (int row = 0; row < 2; row++) {
+            for (int c = 0; c < 6; c++) o[b * 14 + row * 7 + c] = J[row * 20 + 6 * b + c];
+            o[b * 14 + row * 7 + 6] = 0.0;
+        }
+    o[42] = J[18]; o[43] = J[20 + 18]; o[44] = J[19]; o[45] = J[20 + 19];
+}
 __global__ void eval_line_kernel(int n, const double *line, const double *consts21, const double *params, double *res, double *jac) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -717,6 +734,24 @@ extern "C" int tcv_eval_projection_factors(int n, const double *pts, const doubl
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(res, dr.p, (size_t)n * 2 * 8, hipMemcpyDeviceToHost));
     if (jac) HIPCHK(hipMemcpy(jac, dj.p, (size_t)n * 44 * 8, hipMemcpyDeviceToHost));
+    return TCV_OK;
+}
+extern "C" int tcv_eval_projection_td_factors(int n, const double *pts, const double *aux, const double *params, double sqrt_info,
+                                              double TR, double ROW, double *res, double *jac) {
+    if (n <= 0 || !pts || !aux || !params || !res || !(ROW > 0)) return TCV_ERR_INVALID;
+    if (int rc = device_ready()) return rc;
+    DevBuf d1, da, d2, dr, dj;
+    EVAL_ALLOC(d1, (size_t)n * 6 * 8); EVAL_ALLOC(da, (size_t)n * 8 * 8); EVAL_ALLOC(d2, (size_t)n * 23 * 8); EVAL_ALLOC(dr, (size_t)n * 2 * 8);
+    EVAL_ALLOC(dj, (size_t)n * 46 * 8);
+    HIPCHK(hipMemcpy(d1.p, pts, (size_t)n * 6 * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(da.p, aux, (size_t)n * 8 * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d2.p, params, (size_t)n * 23 * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(eval_proj_td_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, n, d1.as<double>(), da.as<double>(), d2.as<double>(), sqrt_info,
+                       TR, ROW, dr.as<double>(), jac ? dj.as<double>() : nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(res, dr.p, (size_t)n * 2 * 8, hipMemcpyDeviceToHost));
+    if (jac) HIPCHK(hipMemcpy(jac, dj.p, (size_t)n * 46 * 8, hipMemcpyDeviceToHost));
     return TCV_OK;
 }
 extern "C" int tcv_eval_line_factors(int n, const double *line, const double K[9], const double R[9], const double T[3],

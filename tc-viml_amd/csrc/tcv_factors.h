@@ -317,6 +317,34 @@ TCV_HD void proj_eval(const double *pose_i, const double *pose_j, const double *
     }
 }
 
+// ---- point re-projection with time offset / rolling shutter (ProjectionTdFactor::Evaluate, projection_td_factor.cpp:34-140)
+// aux: velocity_i xy, velocity_j xy, td_i, td_j, row_i, row_j (rows as passed to the constructor; ROW / 2 is subtracted like
+// :17-18).  J: 2 x 20 row-major local [pose_i 6 | pose_j 6 | ex 6 | inverse depth 1 | td 1].
+TCV_HD void proj_td_eval(const double *pose_i, const double *pose_j, const double *ex, double inv_dep, double td, const double *pts,
+                         const double *aux, double sqrt_info, double TR, double ROW, double *r, double *J, int ld) {
+    const double row_i = aux[6] - ROW / 2, row_j = aux[7] - ROW / 2;
+    const double si = td - aux[4] + TR / ROW * row_i, sj = td - aux[5] + TR / ROW * row_j;     // :50-51
+    const double pts_td[6] = {pts[0] - si * aux[0], pts[1] - si * aux[1], pts[2] - si * 0.0,
+                              pts[3] - sj * aux[2], pts[4] - sj * aux[3], pts[5] - sj * 0.0};
+    double Jp[2 * 19];
+    proj_eval(pose_i, pose_j, ex, inv_dep, pts_td, sqrt_info, r, J ? Jp : nullptr, 19);
+    if (!J) return;
+    // jacobian_td = reduce * ric^T Rj^T Ri ric * velocity_i / inv_dep * -1 + sqrt_info * velocity_j.head(2)   (:131-136)
+    const V3 Pi(pose_i), Pj(pose_j), tic(ex);
+    const Quat Qi(pose_i + 3), Qj(pose_j + 3), qic(ex + 3);
+    const V3 pc_i = V3(pts_td) / inv_dep;
+    const V3 pc_j = rotate(inverse(qic), rotate(inverse(Qj), rotate(Qi, rotate(qic, pc_i) + tic) + Pi - Pj) - tic);
+    const double dep_j = pc_j.z;
+    const double red[6] = {sqrt_info * (1. / dep_j), 0.0, sqrt_info * (-pc_j.x / (dep_j * dep_j)),
+                           0.0, sqrt_info * (1. / dep_j), sqrt_info * (-pc_j.y / (dep_j * dep_j))};
+    const M3 tmp_r = ((transpose(to_matrix(qic)) * transpose(to_matrix(Qj))) * to_matrix(Qi)) * to_matrix(qic);
+    const V3 mv = (tmp_r * V3(aux[0], aux[1], 0.0)) * (-1.0 / inv_dep);
+    for (int row = 0; row < 2; row++) {
+        for (int c = 0; c < 19; c++) J[row * ld + c] = Jp[row * 19 + c];
+        J[row * ld + 19] = red[3 * row] * mv.x + red[3 * row + 1] * mv.y + red[3 * row + 2] * mv.z + sqrt_info * aux[2 + row];
+    }
+}
+
 // ---- 2D-3D line factor (prior 3D map line vs detected 2D line) ---------------------------------------
 // lc: pts_start xyz, pts_end xyz, A B C;  K / Ric / Tic row-major constants.  J 2 x 6 row-major local.
 TCV_HD void line_eval(const double *pose, const double *lc, const double *K9, const double *Ric9,

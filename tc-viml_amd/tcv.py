@@ -37,7 +37,7 @@ EXPORTS = [
     "tcv_batch_download_states", "tcv_batch_get_summaries", "tcv_batch_get_prior", "tcv_batch_get_first_step",
     "tcv_batch_plan_stats", "tcv_batch_stats", "tcv_batch_size",
     "tcv_eval_imu_factors", "tcv_eval_projection_factors", "tcv_eval_line_factors", "tcv_pose_plus", "tcv_preintegrate",
-    "tcv_problem_set_frames", "tcv_gauge_fix", "tcv_batch_gauge_fix", "tcv_set_solver_variant", "tcv_batch_marg_status",
+    "tcv_problem_set_frames", "tcv_gauge_fix", "tcv_batch_gauge_fix", "tcv_set_solver_variant", "tcv_batch_marg_status", "tcv_eval_projection_td_factors",
 ]
 
 
@@ -142,6 +142,7 @@ def lib():
         L.tcv_gauge_fix.argtypes = [C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
         L.tcv_batch_gauge_fix.argtypes = [vp, vp]
         L.tcv_batch_marg_status.argtypes = [vp, _ip, C.c_int]
+        L.tcv_eval_projection_td_factors.argtypes = [C.c_int, _dp, _dp, _dp, C.c_double, C.c_double, C.c_double, _dp, _dp]
         _lib = L
     return _lib
 
@@ -468,6 +469,16 @@ def eval_proj(pts, params, sqrt_info, want_jac=True):
     check(lib().tcv_eval_projection_factors(n, dptr(pts), dptr(params), float(sqrt_info), dptr(res), dptr(jac) if want_jac else None))
     return res, [jac[:, 0:14].reshape(n, 2, 7), jac[:, 14:28].reshape(n, 2, 7), jac[:, 28:42].reshape(n, 2, 7),
                  jac[:, 42:44].reshape(n, 2, 1)]
+
+
+def eval_proj_td(pts, aux, params, sqrt_info, TR, ROW, want_jac=True):
+    pts = f64(pts); aux = f64(aux); params = f64(params)
+    n = pts.shape[0]
+    res = np.zeros((n, 2)); jac = np.zeros((n, 46))
+    check(lib().tcv_eval_projection_td_factors(n, dptr(pts), dptr(aux), dptr(params), float(sqrt_info), float(TR), float(ROW), dptr(res),
+                                               dptr(jac) if want_jac else None))
+    return res, [jac[:, 0:14].reshape(n, 2, 7), jac[:, 14:28].reshape(n, 2, 7), jac[:, 28:42].reshape(n, 2, 7),
+                 jac[:, 42:44].reshape(n, 2, 1), jac[:, 44:46].reshape(n, 2, 1)]
 
 
 def eval_line(line, K, R, T, params, want_jac=True):

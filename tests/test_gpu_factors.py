@@ -80,3 +80,18 @@ def test_single_factor_and_large_batch(gpu):
     idx = np.arange(reps) % len(pts)
     r, Js = gpu.eval_proj(pts[idx], params[idx], float(z["p1_sqrt_info"]))
     assert rel(r, z["p1_r"][idx]) < TOL and rel(Js[2], z["p1_J2"][idx]) < TOL
+
+
+def test_projection_td_factor_golden(gpu):
+    """T1 ProjectionTdFactor::Evaluate (projection_td_factor.cpp:34-140) on the device vs the golden vectors."""
+    z = load("proj_td.npz")
+    for tr in (0.03, 0.0):
+        sel = np.nonzero(z["TR"] == tr)[0]
+        res, Js = gpu.eval_proj_td(z["pts"][sel], z["aux"][sel], z["params"][sel], float(z["sqrt_info"]), tr, float(z["ROW"]))
+        assert rel(res, z["res"][sel]) < 1e-10
+        for J, nm in zip(Js, ["J_pose_i", "J_pose_j", "J_ex", "J_lam", "J_td"]):
+            assert rel(J, z[nm][sel]) < 1e-10, nm
+            if J.shape[-1] == 7:
+                assert np.all(J[..., 6] == 0.0)
+    res2, _ = gpu.eval_proj_td(z["pts"][:3], z["aux"][:3], z["params"][:3], float(z["sqrt_info"]), 0.03, float(z["ROW"]), want_jac=False)
+    assert np.array_equal(res2, gpu.eval_proj_td(z["pts"][:3], z["aux"][:3], z["params"][:3], float(z["sqrt_info"]), 0.03, float(z["ROW"]))[0])

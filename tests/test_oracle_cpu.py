@@ -210,3 +210,32 @@ def test_margin_second_new_oracle_invariants(lib):
     assert abs(np.trace(dbg["A"]) - sum(np.sum(J[:, :6 if J.shape[1] == 7 else J.shape[1]] ** 2) for J in Js)) < 1e-6 * np.trace(dbg["A"])
     # a window without a prior on pose WINDOW_SIZE-1 marginalises nothing (:2049-2050)
     assert NO.marginalize_second_new(NO.Problem(pre), NO.Problem(pre).x0()) == (None, None)
+
+
+def test_c_oracle_projection_td_matches_golden_and_is_a_true_derivative(lib):
+    """T1 ProjectionTdFactor (projection_td_factor.cpp:34-140): C restatement vs the NumPy golden vectors, the td column by
+    central differences, and the degenerate case (zero feature velocity -> ProjectionFactor, zero td column)."""
+    import ctypes as C
+    import np_oracle as NO
+    from util import load, rel
+    z = load("proj_td.npz")
+    n = z["pts"].shape[0]
+    names = ["J_pose_i", "J_pose_j", "J_ex", "J_lam", "J_td"]
+    for k in range(n):
+        r = np.zeros(2); Js = [np.zeros(14), np.zeros(14), np.zeros(14), np.zeros(2), np.zeros(2)]
+        arr = (C.POINTER(C.c_double) * 5)(*[J.ctypes.data_as(C.POINTER(C.c_double)) for J in Js])
+        p = np.ascontiguousarray(z["params"][k]); pts = np.ascontiguousarray(z["pts"][k]); aux = np.ascontiguousarray(z["aux"][k])
+        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+        lib.orc_proj_td_evaluate(dp(p[0:7].copy()), dp(p[7:14].copy()), dp(p[14:21].copy()), float(p[21]), float(p[22]), dp(pts[:3].copy()),
+                                 dp(pts[3:].copy()), dp(aux), float(z["sqrt_info"]), float(z["TR"][k]), float(z["ROW"]), dp(r), arr)
+        assert rel(r, z["res"][k]) < 1e-10
+        for J, nm in zip(Js, names):
+            assert rel(J.reshape(z[nm][k].shape), z[nm][k]) < 1e-9, (k, nm)
+        # d r / d td by central differences
+        f = lambda td: NO.proj_td_evaluate(p[0:7], p[7:14], p[14:21], p[21], td, pts[:3], pts[3:], aux[0:2], aux[2:4], aux[4], aux[5], aux[6],
+                                           aux[7], float(z["sqrt_info"]), float(z["TR"][k]), float(z["ROW"]), False)[0]
+        fd = (f(p[22] + 1e-6) - f(p[22] - 1e-6)) / 2e-6
+        assert np.abs(fd - z["J_td"][k][:, 0]).max() < 1e-5 * max(1.0, np.abs(fd).max())
+        if k >= 36:
+            r0, J0 = NO.proj_evaluate(p[0:7], p[7:14], p[14:21], p[21], pts[:3], pts[3:], float(z["sqrt_info"]))
+            assert np.array_equal(r0, z["res"][k]) and np.abs(z["J_td"][k]).max() == 0.0
