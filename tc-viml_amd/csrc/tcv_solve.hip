@@ -618,12 +618,12 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
                             if (ta >= 0) {
                                 if (bl == 30) d = -2 - ta;
                                 else if (tile != 3 && bl < 30 && al >= bl && tb >= 0) {
-                                    if (CHAIN && (ta >= P.npp || tb >= P.npp)) {
-                                        // an entry of a Euclidean block's row / column: parked per factor in HBM/L2 for the chain
-                                        // elimination (no other factor writes there); its diagonal also feeds the Jacobi scaling
-                                        C.g_imublk[(fb + f) * IMU_BLK + al * 32 + bl] = acc[tile][i];
-                                        d = (al == bl) ? -1000 - (ta - P.npp) : -1;
-                                    } else d = ta >= tb ? tix(ta, tb) : tix(tb, ta);
+                                    // chain mode: the factor's lower triangle is parked in HBM/L2 for the chain elimination (whole
+                                    // rows, so that the stores fill their 64-byte granules; no other factor writes there).  Entries
+                                    // of a Euclidean block's row / column go nowhere else; their diagonal feeds the Jacobi scaling.
+                                    if (CHAIN) C.g_imublk[(fb + f) * IMU_BLK + al * 32 + bl] = acc[tile][i];
+                                    if (CHAIN && (ta >= P.npp || tb >= P.npp)) d = (al == bl) ? -1000 - (ta - P.npp) : -1;
+                                    else d = ta >= tb ? tix(ta, tb) : tix(tb, ta);
                                 }
                             }
                             didx[tile * 4 + i] = d;
@@ -1028,7 +1028,7 @@ __device__ __noinline__ bool chain_forward(Ctx<NT> &C, double mu, double &q_out)
                     x[c] = a * inv[c];
                 }
 #pragma unroll
-                for (int c = 0; c < CH_W; c++) { F[r * CH_W + c] = x[c]; sp[r * CH_W + c] = x[c]; }
+                for (int c = 0; c < CH_W; c++) F[r * CH_W + c] = x[c];
             }
             if (tid == NT - 1) {      // an otherwise idle thread publishes L_ee and 1/diag for the back-substitution
 #pragma unroll
@@ -1041,6 +1041,9 @@ __device__ __noinline__ bool chain_forward(Ctx<NT> &C, double mu, double &q_out)
         }
         __syncthreads();
         TCV_MARK(C, PH_CH_C);
+        // the solved rows go to the spill area in one coalesced sweep (row-wise stores from the solving threads would touch
+        // every 64-byte granule nine times)
+        for (int i = CH_W * CH_W + tid; i < nr * CH_W; i += NT) sp[i] = F[i];
         // (D) rank-9 update of everything below: -X X' on the matrix cores, 16 x 16 output tiles over the sub-rows, two tiles
         // per trip so that their operand loads, MFMA chains and read-modify-writes overlap
         {
