@@ -215,6 +215,23 @@ int tcv_batch_size(const tcv_batch *b);
 int tcv_gauge_fix(int n_frames, const double origin_R0[9], const double origin_P0[3], const double *para_pose,
                   const double *para_speedbias, double *Rs, double *Ps, double *Vs, double *pose_out);
 
+/* ---- 2D-3D line association (the step that feeds the line factors) --------------------------------- */
+/* Estimator::UpdateLinesInFoV (estimator.cpp:385-447) for every frame of the window and Estimator::LineCorrespondenceInFrame
+ * (:671-885, with CalAngleDist :602-613, CalEulerDist :615-669, Line2D feature_manager.cpp:4-73) for every detected 2D line.
+ * Host pointers; evaluated on the GPU.
+ *   poses n_frames x 7, ex_pose 7 (para_Pose / para_Ex_Pose); Rbw (3x3 row-major), Tbw: prior-map -> VIO world (sensor.yaml:40-57);
+ *   K 3x3 row-major; width / height in pixels; window_size = WINDOW_SIZE (FoV margin, :405-408);
+ *   lines3d n_map x 6: end points of the prior map lines (line_3d.txt rows);
+ *   det_frame / det_lines n_det x 4: frame index and pixel end points xs ys xe ye of each detected line;
+ *   angle_th [rad], overlap_th (sensor.yaml:119-122).
+ * Outputs (any may be NULL): in_fov n_frames x n_map (WorldLinesInFOV membership), match_index n_det (row of lines3d, -1: no
+ * credible line), err n_det x 3 = errA, errD, overlap as the reference's Eigen::Vector3f (-1 -1 -1: none), projected n_det x 4
+ * (pixel end points of the chosen projected line; the detected line itself when there is no match). */
+int tcv_match_lines(int n_frames, const double *poses, const double *ex_pose, const double *Rbw, const double *Tbw, const double *K,
+                    int width, int height, int window_size, int n_map, const double *lines3d, int n_det, const int *det_frame,
+                    const double *det_lines, double angle_th, double overlap_th, unsigned char *in_fov, int *match_index, float *err,
+                    double *projected);
+
 /* ---- IMU pre-integration (the producer of the IMU factor's constants) ------- */
 /* Batched `IntegrationBase(acc_0, gyr_0, linearized_ba, linearized_bg)` followed by `push_back(dt, acc, gyr)` for every
  * buffered sample (integration_base.h:13-36, propagate :130-158, midPointIntegration :54-128).  `repropagate(ba, bg)`

@@ -832,3 +832,140 @@ def proj_td_evaluate(pose_i, pose_j, ex, lam, td, pts_i, pts_j, vel_i, vel_j, td
     Ri, Rj, ric = q2R(Qi), q2R(Qj), q2R(qic)
     J_td = reduce @ ric.T @ Rj.T @ Ri @ ric @ vi / lam * -1.0 + sqrt_info_scalar * vj[:2]        # :131-136
     return r, Js + [J_td.reshape(2, 1)]
+
+
+# --------------------------------------------------------------------------------------
+# N4: 2D-3D line association   estimator.cpp:385-447 (UpdateLinesInFoV), :615-669 (CalEulerDist), :602-613 (CalAngleDist),
+#     :671-885 (LineCorrespondenceInFrame); Line2D feature_manager.cpp:4-73.  The reference mixes float and double here
+#     (`float xx, yy`, `float min_dist`, `Eigen::Vector3f error`): the float roundings are reproduced.
+# --------------------------------------------------------------------------------------
+class Line2D:
+    def __init__(self, v):                       # Line2D(const Eigen::Vector4d &Vec), feature_manager.cpp:4-16
+        v = np.asarray(v, dtype=float)
+        self.PtrStart = v[0:2].copy(); self.PtrEnd = v[2:4].copy()
+        self.LineVec = self.PtrEnd - self.PtrStart
+        self.Length = np.sqrt(self.LineVec[0] * self.LineVec[0] + self.LineVec[1] * self.LineVec[1])
+        self.Direction = self.LineVec / self.Length
+        self.A = self.PtrEnd[1] - self.PtrStart[1]
+        self.B = self.PtrStart[0] - self.PtrEnd[0]
+        self.C = self.PtrEnd[0] * self.PtrStart[1] - self.PtrStart[0] * self.PtrEnd[1]
+        self.A2B2 = np.sqrt(self.A * self.A + self.B * self.B)
+
+    def point2flined(self, P):                   # Line2D::Point2Flined, feature_manager.cpp:48-73
+        ts = P - self.PtrStart; d1 = np.sqrt(ts[0] * ts[0] + ts[1] * ts[1])
+        te = P - self.PtrEnd; d2 = np.sqrt(te[0] * te[0] + te[1] * te[1])
+        A_, B_ = self.B, -self.A
+        C_ = -1 * (A_ * P[0] + B_ * P[1])
+        det = self.A * B_ - self.B * A_          # Cof.inverse() * (-C, -C_): 2x2 adjugate * (1 / det)
+        invdet = 1.0 / det
+        ix = (B_ * invdet) * (-self.C) + (-self.B * invdet) * (-C_)
+        iy = (-A_ * invdet) * (-self.C) + (self.A * invdet) * (-C_)
+        if (ix - self.PtrStart[0]) * (ix - self.PtrEnd[0]) >= 0:
+            return self.PtrStart.copy() if d1 < d2 else self.PtrEnd.copy()
+        return np.array([ix, iy])
+
+
+def cal_angle_dist(proj: Line2D, det: Line2D):   # estimator.cpp:602-613
+    with np.errstate(invalid="ignore"):
+        beta = np.arccos(abs(det.Direction[0] * proj.Direction[0] + det.Direction[1] * proj.Direction[1]))
+    return np.pi if np.isnan(beta) else beta
+
+
+def cal_euler_dist(proj: Line2D, det: Line2D):   # estimator.cpp:615-669
+    sampleNum = 10
+    line1, line2 = (det, proj) if det.Length <= proj.Length else (proj, det)
+    d = line2.point2flined(line1.PtrStart) - line2.point2flined(line1.PtrEnd)
+    overlap = np.sqrt(d[0] * d[0] + d[1] * d[1]) / line2.Length
+    px, py = line1.PtrStart
+    step_x = (line1.PtrStart[0] - line1.PtrEnd[0]) / sampleNum; step_y = (line1.PtrStart[1] - line1.PtrEnd[1]) / sampleNum
+    dist = 0.0
+    for i in range(sampleNum):
+        x = px + i * step_x; y = py + i * step_y
+        dist = dist + abs(line2.A * x + line2.B * y + line2.C) / line2.A2B2
+    dist = dist + 1 * abs(line2.A * line1.PtrStart[0] + line2.B * line1.PtrStart[1] + line2.C) / line2.A2B2
+    dist = dist + 1 * abs(line2.A * line1.PtrEnd[0] + line2.B * line1.PtrEnd[1] + line2.C) / line2.A2B2
+    dist = dist / (sampleNum + 2)
+    if np.isnan(dist) or np.isnan(overlap):
+        return 10000.0, 0.0
+    return dist, overlap
+
+
+def _line_extrinsic(pose, ex, Rbw, Tbw):         # estimator.cpp:388-402 / :679-692
+    Ric = q2R(qnormalized(ex[3:7])); Tic = ex[:3]
+    Rbi = q2R(qnormalized(pose[3:7])); Tbi = pose[:3]
+    R = Ric.T @ Rbi.T @ Rbw
+    T = Ric.T @ (Rbi.T @ (Tbw - Tbi) - Tic)
+    return R, T
+
+
+def lines_in_fov(pose, ex, Rbw, Tbw, K, width, height, window_size, lines3d):
+    """UpdateLinesInFoV (estimator.cpp:385-447): mask of the map lines kept for this frame."""
+    R, T = _line_extrinsic(np.asarray(pose, float), np.asarray(ex, float), Rbw, Tbw)
+    hu, hd, wl, wr = -2 * window_size, 2 * window_size + height, -2 * window_size, 2 * window_size + width
+    out = np.zeros(len(lines3d), dtype=bool)
+    for j, l in enumerate(np.asarray(lines3d, float)):
+        ps = R @ l[0:3] + T; pe = R @ l[3:6] + T
+        if ps[2] > 0 and pe[2] > 0:
+            xx = K[0, 0] * ps[0] / ps[2] + K[0, 2]; yy = K[1, 1] * ps[1] / ps[2] + K[1, 2]
+            xx_ = K[0, 0] * pe[0] / pe[2] + K[0, 2]; yy_ = K[1, 1] * pe[1] / pe[2] + K[1, 2]
+            s = xx > wl and xx < (wr - 1) and yy > hu and yy < hd
+            e = xx_ > wl and xx_ < (wr - 1) and yy_ > hu and yy_ < hd
+            out[j] = s or e
+    return out
+
+
+def line_correspondence_in_frame(pose, ex, Rbw, Tbw, K, width, height, lines3d, in_fov, det_vec4, angle_th, overlap_th):
+    """LineCorrespondenceInFrame (estimator.cpp:671-885).  Returns (error float32[3] = angle, distance, overlap or -1s,
+    index into lines3d or -1, projected line as pixel end points)."""
+    f32 = np.float32
+    R, T = _line_extrinsic(np.asarray(pose, float), np.asarray(ex, float), Rbw, Tbw)
+    det = Line2D(det_vec4)
+    idxs = np.nonzero(in_fov)[0]
+    err = np.array([-1, -1, -1], dtype=np.float32)
+    if len(idxs) == 0:
+        return err, -1, np.asarray(det_vec4, float).copy()
+    min_dist = f32(10000.0); choose = -1; proj_vec = np.asarray(det_vec4, float).copy()
+    for j in idxs:
+        l = np.asarray(lines3d[j], float)
+        ps = R @ l[0:3] + T; pe = R @ l[3:6] + T
+        sflag = eflag = False
+        xx = yy = xx_ = yy_ = f32(0)
+        if ps[2] > 0 and pe[2] > 0:
+            xx = f32(K[0, 0] * ps[0] / ps[2] + K[0, 2]); yy = f32(K[1, 1] * ps[1] / ps[2] + K[1, 2])
+            xx_ = f32(K[0, 0] * pe[0] / pe[2] + K[0, 2]); yy_ = f32(K[1, 1] * pe[1] / pe[2] + K[1, 2])
+            sflag = bool(xx > 0 and xx < width - 1 and yy > 0 and yy < height - 1)
+            eflag = bool(xx_ > 0 and xx_ < width - 1 and yy_ > 0 and yy_ < height - 1)
+        cand = None
+        if sflag and eflag:
+            cand = [float(xx), float(yy), float(xx_), float(yy_)]
+        elif sflag or eflag:                     # walk the hidden end point back towards the visible one, t = 0.9, 0.8, ...
+            a, b = (ps, pe) if sflag else (pe, ps)
+            dirvec = b - a
+            t = 0.9
+            found = False
+            while t > 0:
+                q = a + t * dirvec
+                if q[2] > 0:
+                    x = K[0, 0] * q[0] / q[2] + K[0, 2]; y = K[1, 1] * q[1] / q[2] + K[1, 2]
+                    if x > 0 and x < (width - 1) and y > 0 and y < (height - 1):
+                        found = True
+                        break
+                t = t - 0.1
+            if found:
+                cand = [float(xx), float(yy), x, y] if sflag else [x, y, float(xx_), float(yy_)]
+        if cand is None:
+            continue
+        tl = Line2D(cand)
+        angle = cal_angle_dist(tl, det)
+        if angle > angle_th:
+            continue
+        dist, ov = cal_euler_dist(tl, det)
+        distance = f32(dist); overlap = f32(ov)
+        if float(overlap) < overlap_th:
+            continue
+        if distance < min_dist:
+            min_dist = distance; choose = int(j); proj_vec = np.array(cand)
+            err = np.array([f32(angle), min_dist, overlap], dtype=np.float32)
+    if choose == -1:
+        return np.array([-1, -1, -1], dtype=np.float32), -1, np.asarray(det_vec4, float).copy()
+    return err, choose, proj_vec

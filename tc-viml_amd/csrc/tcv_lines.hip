@@ -1,0 +1,239 @@
+// 2D-3D line association: the step that feeds the line factors.
+//   Estimator::UpdateLinesInFoV           estimator.cpp:385-447   which prior map lines can be seen from a frame
+//   Estimator::LineCorrespondenceInFrame  estimator.cpp:671-885   nearest projected map line for one detected 2D line
+//   Estimator::CalAngleDist / CalEulerDist  :602-669,  Line2D  feature_manager.cpp:4-73
+// One wavefront per detected line scans the map (an HBM/L2-bound read of 48 B per map line), every lane scoring a strided
+// subset exactly like the reference's loop body; the best (smallest distance, first index on ties, as the reference's
+// strict `<` in map order) is reduced across the lanes.  The reference mixes float and double here (`float xx, yy`,
+// `float min_dist`, `Eigen::Vector3f error`); the float roundings are reproduced.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <vector>
+
+#include "tcv_host.h"
+#include "tcv_math.h"
+
+namespace tcv {
+
+struct L2 {      // Line2D(const Eigen::Vector4d &), feature_manager.cpp:4-16
+    double sx, sy, ex, ey, len, dx, dy, A, B, C, A2B2;
+};
+TCV_HD L2 make_l2(double sx, double sy, double ex, double ey) {
+    L2 l;
+    l.sx = sx; l.sy = sy; l.ex = ex; l.ey = ey;
+    const double vx = ex - sx, vy = ey - sy;
+    l.len = sqrt(vx * vx + vy * vy);
+    l.dx = vx / l.len; l.dy = vy / l.len;
+    l.A = ey - sy; l.B = sx - ex; l.C = ex * sy - sx * ey;
+    l.A2B2 = sqrt(l.A * l.A + l.B * l.B);
+    return l;
+}
+// Line2D::Point2Flined, feature_manager.cpp:48-73
+TCV_HD void point2flined(const L2 &l, double px, double py, double &ox, double &oy) {
+    const double tsx = px - l.sx, tsy = py - l.sy, d1 = sqrt(tsx * tsx + tsy * tsy);
+    const double tex = px - l.ex, tey = py - l.ey, d2 = sqrt(tex * tex + tey * tey);
+    const double A_ = l.B, B_ = -l.A;
+    const double C_ = -1 * (A_ * px + B_ * py);
+    const double det = l.A * B_ - l.B * A_;
+    const double invdet = 1.0 / det;
+    const double ix = (B_ * invdet) * (-l.C) + (-l.B * invdet) * (-C_);
+    const double iy = (-A_ * invdet) * (-l.C) + (l.A * invdet) * (-C_);
+    if ((ix - l.sx) * (ix - l.ex) >= 0) {
+        if (d1 < d2) { ox = l.sx; oy = l.sy; } else { ox = l.ex; oy = l.ey; }
+    } else { ox = ix; oy = iy; }
+}
+// CalEulerDist, estimator.cpp:615-669
+TCV_HD void euler_dist(const L2 &proj, const L2 &det, double &dist, double &overlap) {
+    const int sampleNum = 10;
+    const bool det_short = det.len <= proj.len;
+    const L2 &l1 = det_short ? det : proj, &l2 = det_short ? proj : det;
+    double ax, ay, bx, by;
+    point2flined(l2, l1.sx, l1.sy, ax, ay);
+    point2flined(l2, l1.ex, l1.ey, bx, by);
+    overlap = sqrt((ax - bx) * (ax - bx) + (ay - by) * (ay - by)) / l2.len;
+    const double step_x = (l1.sx - l1.ex) / sampleNum, step_y = (l1.sy - l1.ey) / sampleNum;
+    double d = 0.0;
+    for (int i = 0; i < sampleNum; ++i) {
+        const double x = l1.sx + i * step_x, y = l1.sy + i * step_y;
+        d = d + fabs(l2.A * x + l2.B * y + l2.C) / l2.A2B2;
+    }
+    d = d + 1 * fabs(l2.A * l1.sx + l2.B * l1.sy + l2.C) / l2.A2B2;
+    d = d + 1 * fabs(l2.A * l1.ex + l2.B * l1.ey + l2.C) / l2.A2B2;
+    d = d / (sampleNum + 2);
+    if (d != d || overlap != overlap) { d = 10000.0; overlap = 0.0; }
+    dist = d;
+}
+
+struct LineCam { M3 R; V3 T; };
+// R = Ric^T Rbi^T Rbw, T = Ric^T (Rbi^T (Tbw - Tbi) - Tic)   (estimator.cpp:388-402, :679-692)
+TCV_HD LineCam line_cam(const double *pose, const double *ex, const double *Rbw, const double *Tbw) {
+    const M3 RicT = transpose(to_matrix(normalized(Quat(ex + 3)))), RbiT = transpose(to_matrix(normalized(Quat(pose + 3))));
+    LineCam c;
+    c.R = (RicT * RbiT) * m3_load(Rbw);
+    c.T = RicT * (RbiT * (V3(Tbw) - V3(pose)) - V3(ex));
+    return c;
+}
+
+struct LineArgs {
+    const double *poses, *ex, *Rbw, *Tbw, *K, *map, *det;
+    const int *det_frame;
+    int n_frames, n_map, n_det, width, height, window_size;
+    double angle_th, overlap_th;
+    unsigned char *in_fov;      // n_frames x n_map
+    int *match;                 // n_det
+    float *err;                 // n_det x 3
+    double *proj;               // n_det x 4
+};
+
+// UpdateLinesInFoV: one thread per (frame, map line)
+__global__ void lines_fov_kernel(LineArgs A) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.n_frames * A.n_map) return;
+    const int f = i / A.n_map, j = i - f * A.n_map;
+    const LineCam c = line_cam(A.poses + 7 * f, A.ex, A.Rbw, A.Tbw);
+    const double *l = A.map + 6 * (size_t)j;
+    const V3 ps = c.R * V3(l) + c.T, pe = c.R * V3(l + 3) + c.T;
+    const int hu = -2 * A.window_size, hd = 2 * A.window_size + A.height, wl = -2 * A.window_size, wr = 2 * A.window_size + A.width;
+    bool s = false, e = false;
+    if (ps.z > 0 && pe.z > 0) {
+        const double xx = A.K[0] * ps.x / ps.z + A.K[2], yy = A.K[4] * ps.y / ps.z + A.K[5];
+        const double xx_ = A.K[0] * pe.x / pe.z + A.K[2], yy_ = A.K[4] * pe.y / pe.z + A.K[5];
+        s = xx > wl && xx < (wr - 1) && yy > hu && yy < hd;
+        e = xx_ > wl && xx_ < (wr - 1) && yy_ > hu && yy_ < hd;
+    }
+    A.in_fov[i] = (s || e) ? 1 : 0;
+}
+
+// LineCorrespondenceInFrame: one wavefront per detected line
+__global__ void __launch_bounds__(64) lines_match_kernel(LineArgs A) {
+    const int q = blockIdx.x, lane = threadIdx.x;
+    const int f = A.det_frame[q];
+    const double *dv = A.det + 4 * (size_t)q;
+    const L2 det = make_l2(dv[0], dv[1], dv[2], dv[3]);
+    const LineCam c = line_cam(A.poses + 7 * f, A.ex, A.Rbw, A.Tbw);
+    const double fx = A.K[0], cx = A.K[2], fy = A.K[4], cy = A.K[5];
+    const int W = A.width, H = A.height;
+    float best = 10000.0f, b_angle = -1.0f, b_ov = -1.0f;
+    int best_j = 0x7fffffff;
+    double bp[4] = {dv[0], dv[1], dv[2], dv[3]};
+    int any_fov = 0;
+    for (int j = lane; j < A.n_map; j += 64) {
+        if (!A.in_fov[(size_t)f * A.n_map + j]) continue;
+        any_fov = 1;
+        const double *l = A.map + 6 * (size_t)j;
+        const V3 ps = c.R * V3(l) + c.T, pe = c.R * V3(l + 3) + c.T;
+        bool sflag = false, eflag = false;
+        float xx = 0, yy = 0, xx_ = 0, yy_ = 0;
+        if (ps.z > 0 && pe.z > 0) {
+            xx = (float)(fx * ps.x / ps.z + cx); yy = (float)(fy * ps.y / ps.z + cy);
+            xx_ = (float)(fx * pe.x / pe.z + cx); yy_ = (float)(fy * pe.y / pe.z + cy);
+            sflag = xx > 0 && xx < W - 1 && yy > 0 && yy < H - 1;
+            eflag = xx_ > 0 && xx_ < W - 1 && yy_ > 0 && yy_ < H - 1;
+        }
+        double cand[4];
+        bool have = false;
+        if (sflag && eflag) { cand[0] = xx; cand[1] = yy; cand[2] = xx_; cand[3] = yy_; have = true; }
+        else if (sflag || eflag) {      // walk the hidden end point back towards the visible one: t = 0.9, 0.8, ... (:765-791, :813-839)
+            const V3 a = sflag ? ps : pe, b = sflag ? pe : ps;
+            const V3 dir = b - a;
+            double t = 0.9, x = 0.0, y = 0.0;
+            bool found = false;
+            while (t > 0) {
+                const V3 p = a + t * dir;
+                if (p.z > 0) {
+                    x = fx * p.x / p.z + cx; y = fy * p.y / p.z + cy;
+                    if (x > 0 && x < (W - 1) && y > 0 && y < (H - 1)) { found = true; break; }
+                }
+                t = t - 0.1;
+            }
+            if (found) {
+                if (sflag) { cand[0] = xx; cand[1] = yy; cand[2] = x; cand[3] = y; }
+                else { cand[0] = x; cand[1] = y; cand[2] = xx_; cand[3] = yy_; }
+                have = true;
+            }
+        }
+        if (!have) continue;
+        const L2 tl = make_l2(cand[0], cand[1], cand[2], cand[3]);
+        double angle = acos(fabs(det.dx * tl.dx + det.dy * tl.dy));      // CalAngleDist
+        if (angle != angle) angle = 3.14159265358979323846;
+        if (angle > A.angle_th) continue;
+        double dist, ov;
+        euler_dist(tl, det, dist, ov);
+        const float distance = (float)dist, overlap = (float)ov;
+        if ((double)overlap < A.overlap_th) continue;
+        if (distance < best) {      // lanes walk their lines in ascending j, so the first minimum of the lane is kept
+            best = distance; best_j = j; b_angle = (float)angle; b_ov = overlap;
+            bp[0] = cand[0]; bp[1] = cand[1]; bp[2] = cand[2]; bp[3] = cand[3];
+        }
+    }
+    // wave reduction: smallest distance, then smallest map index (= first hit of the reference's sequential scan)
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o);
+        const int oj = __shfl_xor(best_j, o);
+        const float oa = __shfl_xor(b_angle, o), oo = __shfl_xor(b_ov, o);
+        double op[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) op[k] = __shfl_xor(bp[k], o);
+        any_fov |= __shfl_xor(any_fov, o);
+        if (oj != 0x7fffffff && (best_j == 0x7fffffff || ob < best || (ob == best && oj < best_j))) {
+            best = ob; best_j = oj; b_angle = oa; b_ov = oo;
+#pragma unroll
+            for (int k = 0; k < 4; k++) bp[k] = op[k];
+        }
+    }
+    if (lane == 0) {
+        const bool hit = best_j != 0x7fffffff;
+        A.match[q] = hit ? best_j : -1;
+        A.err[3 * q] = hit ? b_angle : -1.0f; A.err[3 * q + 1] = hit ? best : -1.0f; A.err[3 * q + 2] = hit ? b_ov : -1.0f;
+        for (int k = 0; k < 4; k++) A.proj[4 * (size_t)q + k] = hit ? bp[k] : dv[k];
+        (void)any_fov;
+    }
+}
+
+}  // namespace tcv
+using namespace tcv;
+
+extern "C" int tcv_match_lines(int n_frames, const double *poses, const double *ex_pose, const double *Rbw, const double *Tbw, const double *K,
+                               int width, int height, int window_size, int n_map, const double *lines3d, int n_det, const int *det_frame,
+                               const double *det_lines, double angle_th, double overlap_th, unsigned char *in_fov, int *match_index, float *err,
+                               double *projected) {
+    if (n_frames <= 0 || n_map <= 0 || n_det < 0 || !poses || !ex_pose || !Rbw || !Tbw || !K || !lines3d || (n_det > 0 && (!det_frame || !det_lines))) {
+        set_error("match_lines: bad argument"); return TCV_ERR_INVALID;
+    }
+    for (int i = 0; i < n_det; i++) if (det_frame[i] < 0 || det_frame[i] >= n_frames) { set_error("match_lines: frame index out of range"); return TCV_ERR_INVALID; }
+    if (int rc = device_ready()) return rc;
+    const size_t nd_in = (size_t)7 * n_frames + 7 + 9 + 3 + 9 + (size_t)6 * n_map + (size_t)4 * n_det;
+    const size_t nd_out = (size_t)4 * n_det;
+    std::vector<double> h(nd_in);
+    size_t o = 0;
+    auto put = [&](const double *p, size_t n) { std::memcpy(h.data() + o, p, sizeof(double) * n); o += n; return o - n; };
+    const size_t o_pose = put(poses, (size_t)7 * n_frames), o_ex = put(ex_pose, 7), o_R = put(Rbw, 9), o_T = put(Tbw, 3), o_K = put(K, 9);
+    const size_t o_map = put(lines3d, (size_t)6 * n_map), o_det = n_det ? put(det_lines, (size_t)4 * n_det) : o;
+    double *dd = nullptr; int *di = nullptr; float *df = nullptr; unsigned char *db = nullptr;
+    hipError_t e = hipMalloc((void **)&dd, sizeof(double) * (nd_in + nd_out + 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&di, sizeof(int) * (2 * (size_t)n_det + 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&df, sizeof(float) * (3 * (size_t)n_det + 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&db, (size_t)n_frames * n_map);
+    if (e == hipSuccess) e = hipMemcpy(dd, h.data(), sizeof(double) * nd_in, hipMemcpyHostToDevice);
+    if (e == hipSuccess && n_det) e = hipMemcpy(di, det_frame, sizeof(int) * n_det, hipMemcpyHostToDevice);
+    int rc = TCV_OK;
+    if (e == hipSuccess) {
+        LineArgs A;
+        A.poses = dd + o_pose; A.ex = dd + o_ex; A.Rbw = dd + o_R; A.Tbw = dd + o_T; A.K = dd + o_K; A.map = dd + o_map; A.det = dd + o_det;
+        A.det_frame = di; A.n_frames = n_frames; A.n_map = n_map; A.n_det = n_det; A.width = width; A.height = height; A.window_size = window_size;
+        A.angle_th = angle_th; A.overlap_th = overlap_th; A.in_fov = db; A.match = di + n_det; A.err = df; A.proj = dd + nd_in;
+        const int tot = n_frames * n_map;
+        hipLaunchKernelGGL(lines_fov_kernel, dim3((tot + 255) / 256), dim3(256), 0, 0, A);
+        if (n_det) hipLaunchKernelGGL(lines_match_kernel, dim3(n_det), dim3(64), 0, 0, A);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e == hipSuccess && in_fov) e = hipMemcpy(in_fov, db, (size_t)tot, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && n_det && match_index) e = hipMemcpy(match_index, di + n_det, sizeof(int) * n_det, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && n_det && err) e = hipMemcpy(err, df, sizeof(float) * 3 * n_det, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && n_det && projected) e = hipMemcpy(projected, dd + nd_in, sizeof(double) * 4 * n_det, hipMemcpyDeviceToHost);
+    }
+    if (e != hipSuccess) rc = hip_fail(e, "match_lines");
+    hipFree(dd); hipFree(di); hipFree(df); hipFree(db);
+    return rc;
+}

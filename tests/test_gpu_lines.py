@@ -1,0 +1,38 @@
+"""N4 on the GPU: tcv_match_lines (UpdateLinesInFoV + LineCorrespondenceInFrame, estimator.cpp:385-447 / :671-885) against
+the golden vectors.  Indices and FoV masks must be identical; the float-typed errors equal to a float ulp (device acos /
+sqrt vs libm), the projected end points to 1e-9 px."""
+import numpy as np
+import pytest
+
+from util import load
+
+pytestmark = pytest.mark.gpu
+
+
+def test_match_lines_golden(gpu):
+    z = load("lines.npz")
+    fov, match, err, proj = gpu.match_lines(z["poses"], z["ex"], z["Rbw"], z["Tbw"], z["K"], int(z["width"]), int(z["height"]), int(z["window_size"]),
+                                            z["lines3d"], z["det_frame"], z["det"], float(z["angle_th"]), float(z["overlap_th"]))
+    assert np.array_equal(fov, z["in_fov"])
+    assert np.array_equal(match, z["match"])
+    assert np.abs(err - z["err"]).max() <= 4e-6 * max(1.0, np.abs(z["err"]).max())
+    assert np.abs(proj - z["proj"]).max() < 1e-9
+    assert (match >= 0).sum() > 100 and (match < 0).sum() > 100
+
+
+def test_match_lines_edge_cases(gpu):
+    z = load("lines.npz")
+    args = (z["ex"], z["Rbw"], z["Tbw"], z["K"], int(z["width"]), int(z["height"]), int(z["window_size"]))
+    # no detections: only the FoV masks
+    fov, match, err, proj = gpu.match_lines(z["poses"], *args, z["lines3d"], np.zeros(0, np.int32), np.zeros((0, 4)), 0.1745, 0.45)
+    assert np.array_equal(fov, z["in_fov"]) and len(match) == 0
+    # a map far behind the camera: nothing in the FoV, every detection comes back unmatched with the -1 error triple (:703-712)
+    far = z["lines3d"] + 1e4
+    fov, match, err, proj = gpu.match_lines(z["poses"][:1], *args, far, z["det_frame"][:5] * 0, z["det"][:5], 0.1745, 0.45)
+    assert not fov.any() and np.all(match == -1) and np.all(err == -1) and np.array_equal(proj, z["det"][:5])
+    # a single map line, a single frame
+    j = int(z["match"][0]); f = int(z["det_frame"][0])
+    fov, match, err, proj = gpu.match_lines(z["poses"][f:f + 1], *args, z["lines3d"][j:j + 1], [0], z["det"][:1], 0.1745, 0.45)
+    assert match[0] == 0 and abs(err[0, 1] - z["err"][0, 1]) < 1e-5
+    with pytest.raises(gpu.TcvError):
+        gpu.match_lines(z["poses"], *args, z["lines3d"], [99], z["det"][:1], 0.1745, 0.45)
