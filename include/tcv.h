@@ -224,13 +224,15 @@ int tcv_gauge_fix(int n_frames, const double origin_R0[9], const double origin_P
  *   lines3d n_map x 6: end points of the prior map lines (line_3d.txt rows);
  *   det_frame / det_lines n_det x 4: frame index and pixel end points xs ys xe ye of each detected line;
  *   angle_th [rad], overlap_th (sensor.yaml:119-122).
+ * fov_given != 0: in_fov is an INPUT (the reference freezes WorldLinesInFOV[i] when frame i enters the window, :328, and re-matches
+ * against it with the current poses, updateLinePairInWindow :449-481).
  * Outputs (any may be NULL): in_fov n_frames x n_map (WorldLinesInFOV membership), match_index n_det (row of lines3d, -1: no
  * credible line), err n_det x 3 = errA, errD, overlap as the reference's Eigen::Vector3f (-1 -1 -1: none), projected n_det x 4
  * (pixel end points of the chosen projected line; the detected line itself when there is no match). */
 int tcv_match_lines(int n_frames, const double *poses, const double *ex_pose, const double *Rbw, const double *Tbw, const double *K,
                     int width, int height, int window_size, int n_map, const double *lines3d, int n_det, const int *det_frame,
-                    const double *det_lines, double angle_th, double overlap_th, unsigned char *in_fov, int *match_index, float *err,
-                    double *projected);
+                    const double *det_lines, double angle_th, double overlap_th, int fov_given, unsigned char *in_fov, int *match_index,
+                    float *err, double *projected);
 
 /* ---- IMU pre-integration (the producer of the IMU factor's constants) ------- */
 /* Batched `IntegrationBase(acc_0, gyr_0, linearized_ba, linearized_bg)` followed by `push_back(dt, acc, gyr)` for every

@@ -196,11 +196,12 @@ using namespace tcv;
 
 extern "C" int tcv_match_lines(int n_frames, const double *poses, const double *ex_pose, const double *Rbw, const double *Tbw, const double *K,
                                int width, int height, int window_size, int n_map, const double *lines3d, int n_det, const int *det_frame,
-                               const double *det_lines, double angle_th, double overlap_th, unsigned char *in_fov, int *match_index, float *err,
-                               double *projected) {
+                               const double *det_lines, double angle_th, double overlap_th, int fov_given, unsigned char *in_fov, int *match_index,
+                               float *err, double *projected) {
     if (n_frames <= 0 || n_map <= 0 || n_det < 0 || !poses || !ex_pose || !Rbw || !Tbw || !K || !lines3d || (n_det > 0 && (!det_frame || !det_lines))) {
         set_error("match_lines: bad argument"); return TCV_ERR_INVALID;
     }
+    if (fov_given && !in_fov) { set_error("match_lines: fov_given needs in_fov"); return TCV_ERR_INVALID; }
     for (int i = 0; i < n_det; i++) if (det_frame[i] < 0 || det_frame[i] >= n_frames) { set_error("match_lines: frame index out of range"); return TCV_ERR_INVALID; }
     if (int rc = device_ready()) return rc;
     const size_t nd_in = (size_t)7 * n_frames + 7 + 9 + 3 + 9 + (size_t)6 * n_map + (size_t)4 * n_det;
@@ -217,6 +218,7 @@ extern "C" int tcv_match_lines(int n_frames, const double *poses, const double *
     if (e == hipSuccess) e = hipMalloc((void **)&db, (size_t)n_frames * n_map);
     if (e == hipSuccess) e = hipMemcpy(dd, h.data(), sizeof(double) * nd_in, hipMemcpyHostToDevice);
     if (e == hipSuccess && n_det) e = hipMemcpy(di, det_frame, sizeof(int) * n_det, hipMemcpyHostToDevice);
+    if (e == hipSuccess && fov_given) e = hipMemcpy(db, in_fov, (size_t)n_frames * n_map, hipMemcpyHostToDevice);
     int rc = TCV_OK;
     if (e == hipSuccess) {
         LineArgs A;
@@ -224,11 +226,11 @@ extern "C" int tcv_match_lines(int n_frames, const double *poses, const double *
         A.det_frame = di; A.n_frames = n_frames; A.n_map = n_map; A.n_det = n_det; A.width = width; A.height = height; A.window_size = window_size;
         A.angle_th = angle_th; A.overlap_th = overlap_th; A.in_fov = db; A.match = di + n_det; A.err = df; A.proj = dd + nd_in;
         const int tot = n_frames * n_map;
-        hipLaunchKernelGGL(lines_fov_kernel, dim3((tot + 255) / 256), dim3(256), 0, 0, A);
+        if (!fov_given) hipLaunchKernelGGL(lines_fov_kernel, dim3((tot + 255) / 256), dim3(256), 0, 0, A);
         if (n_det) hipLaunchKernelGGL(lines_match_kernel, dim3(n_det), dim3(64), 0, 0, A);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipDeviceSynchronize();
-        if (e == hipSuccess && in_fov) e = hipMemcpy(in_fov, db, (size_t)tot, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && in_fov && !fov_given) e = hipMemcpy(in_fov, db, (size_t)tot, hipMemcpyDeviceToHost);
         if (e == hipSuccess && n_det && match_index) e = hipMemcpy(match_index, di + n_det, sizeof(int) * n_det, hipMemcpyDeviceToHost);
         if (e == hipSuccess && n_det && err) e = hipMemcpy(err, df, sizeof(float) * 3 * n_det, hipMemcpyDeviceToHost);
         if (e == hipSuccess && n_det && projected) e = hipMemcpy(projected, dd + nd_in, sizeof(double) * 4 * n_det, hipMemcpyDeviceToHost);

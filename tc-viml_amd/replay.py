@@ -71,10 +71,13 @@ def deltaQ_R(theta):
 # simulated front-end streams
 # ----------------------------------------------------------------------------------------------------------------
 def simulate_stream(seed: int, n_frames: int, max_features: int = 36, max_lines: int = 4, pixel_sigma: float = 1.0,
-                    t0: float = 0.0, imu_noise: bool = True, pace: float = 0.85):
+                    t0: float = 0.0, imu_noise: bool = True, pace: float = 0.85, associate: bool = False):
     """Per-frame streams of a front end following the analytic trajectory of synth.py at 10 Hz / 200 Hz IMU.
     Returns dict(t, gt_p, gt_R, gt_v, imu=[(acc (S+1,3), gyr (S+1,3))] per frame (sample 0 = the previous frame's last
-    sample), points=[{id: (x, y, 1)}], lines=[[(pts_start, pts_end, abc)]], ba, bg)."""
+    sample), points=[{id: (x, y, 1)}], lines=[[(pts_start, pts_end, abc)]], ba, bg).
+    associate=True: the lines come as the line tracker delivers them -- [(track id, pixel end points xs ys xe ye)] without their
+    3D partner -- together with the prior map (`map_lines` n x 6 in the map frame, `Rbw`, `Tbw`); the replay then runs the
+    reference's 2D-3D association (UpdateLinesInFoV / LineCorrespondenceInFrame / removeLineOutlier) every frame."""
     rng = np.random.Generator(np.random.PCG64(0xFEED + seed))
     S = synth.IMU_RATE_SUB
     t = t0 + synth.DT_KF * np.arange(n_frames)
@@ -132,9 +135,12 @@ def simulate_stream(seed: int, n_frames: int, max_features: int = 36, max_lines:
                 uv.append(np.array([synth.FX * pc[0] / pc[2] + synth.CX, synth.FY * pc[1] / pc[2] + synth.CY]) + rng.normal(size=2) * pixel_sigma)
             (xs, ys), (xe, ye) = uv
             abc = np.array([ye - ys, xs - xe, xe * ys - xs * ye])          # feature_manager.cpp:11-13
-            fl.append((ps_pool[i].copy(), pe_pool[i].copy(), abc))
+            fl.append((int(i), np.array([xs, ys, xe, ye])) if associate else (ps_pool[i].copy(), pe_pool[i].copy(), abc))
         lines.append(fl)
-    return dict(t=t, gt_p=pk, gt_R=Rk, gt_v=vk, imu=imu, points=points, lines=lines, ba=ba, bg=bg)
+    out = dict(t=t, gt_p=pk, gt_R=Rk, gt_v=vk, imu=imu, points=points, lines=lines, ba=ba, bg=bg)
+    if associate:
+        out.update(map_lines=np.hstack([(ps_pool - synth.TBW) @ synth.RBW, (pe_pool - synth.TBW) @ synth.RBW]), Rbw=synth.RBW.copy(), Tbw=synth.TBW.copy())
+    return out
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -162,6 +168,10 @@ class Replay:
         self.pre = [None] * (W + 1)        # cached pre-integration of every slot
         self.features = []                 # f_manager.feature (insertion order matters: it is the landmark order)
         self.line_obs = [[] for _ in range(W + 1)]
+        self.map_lines = None              # prior 3D line map (association mode): lines3d_map, Rbw, Tbw
+        self.linefeatures = []             # f_manager.linefeature: dict(id, start_frame, obs=[...], credible_matching)
+        self.fov = [None] * (W + 1)        # WorldLinesInFOV[i] as a mask over the map
+        self.fov_ready = False
         self.prior = None                  # last_marginalization_info + last_marginalization_parameter_blocks
         self.frame_count = 0
         self.marg_flag = MARGIN_OLD
@@ -203,7 +213,17 @@ class Replay:
             else:
                 last_track_num += 1
             f.obs.append(np.asarray(p, dtype=float))
-        self.line_obs[fc] = list(lines)
+        if self.map_lines is not None:       # the line tracker's (id, end points): addFeaturesCheckParallax :291-311
+            by_lid = {lf["id"]: lf for lf in self.linefeatures}
+            for lid, v in lines:
+                lf = by_lid.get(lid)
+                if lf is None:
+                    lf = dict(id=lid, start_frame=fc, obs=[], credible_matching=True); self.linefeatures.append(lf)
+                v = np.asarray(v, dtype=float)
+                lf["obs"].append(dict(vec=v, abc=np.array([v[3] - v[1], v[0] - v[2], v[2] * v[1] - v[0] * v[3]]), world=np.zeros(6), errA=-1.0, errD=-1.0,
+                                      overlap=-1.0, credible_line=True, use_flag=False))
+        else:
+            self.line_obs[fc] = list(lines)
         if fc < 2 or last_track_num < 20:
             return True
         s, n = 0.0, 0
@@ -245,6 +265,75 @@ class Replay:
                 self.pre[j] = r
         return [self.pre[j] for j in range(1, WINDOW_SIZE + 1)]
 
+    def _poses(self):
+        W = WINDOW_SIZE
+        pose = np.zeros((W + 1, 7))
+        for i in range(W + 1):
+            pose[i, :3] = self.Ps[i]; pose[i, 3:] = R2q(self.Rs[i])
+        return pose, np.concatenate([self.tic, R2q(self.ric)])
+
+    def associate_lines(self):
+        """UpdateLinesInFoV(frame_count) (or initialLineFoVWindow the first time), updateLinePairInWindow (estimator.cpp:449-481)
+        and f_manager.removeLineOutlier (feature_manager.cpp:494-534), as processImagewithLine runs them before solveOdometry."""
+        W = WINDOW_SIZE
+        pose, ex = self._poses()
+        det_frame, det, where = [], [], []
+        for lf in self.linefeatures:
+            for k, ob in enumerate(lf["obs"]):
+                det_frame.append(lf["start_frame"] + k); det.append(ob["vec"]); where.append(ob)
+        given = None
+        if self.fov_ready:
+            given = np.array([self.fov[i] if self.fov[i] is not None else np.zeros(len(self.map_lines), bool) for i in range(W + 1)])
+        fov_now, _, _, _ = self.backend.match_lines(pose, ex, None, np.zeros(0, np.int32), np.zeros((0, 4)))
+        if not self.fov_ready:
+            for i in range(W + 1):
+                self.fov[i] = fov_now[i].copy()          # initialLineFoVWindow (:483-497)
+            self.fov_ready = True
+        else:
+            self.fov[W] = fov_now[W].copy()              # UpdateLinesInFoV(frame_count) (:385-447)
+        given = np.array(self.fov)
+        if det:
+            _, match, err, _ = self.backend.match_lines(pose, ex, given, np.array(det_frame, dtype=np.int32), np.array(det))
+            for ob, f, m, e in zip(where, det_frame, match, err):
+                ob["errA"], ob["errD"], ob["overlap"] = float(e[0]), float(e[1]), float(e[2])
+                idx = np.nonzero(given[f])[0]
+                if m >= 0:
+                    ob["world"] = self.map_lines[m].copy()
+                elif len(idx):
+                    ob["world"] = self.map_lines[idx[0]].copy()           # `linesInThisFov[0]` (:871-877)
+                else:
+                    ob["world"] = np.concatenate([[ob["vec"][0], ob["vec"][1], 1.0]] * 2)       # fake_line (:707-709)
+                ob["use_flag"] = True
+                ob["credible_line"] = e[0] != -1
+        for lf in self.linefeatures:                      # removeLineOutlier
+            if len(lf["obs"]) < 1:
+                continue
+            first = lf["obs"][0]["world"]; count = 0
+            for ob in lf["obs"]:
+                d = (ob["world"][3:] - ob["world"][:3]) - (first[3:] - first[:3])
+                ob["credible_line"] = not (np.float32(np.linalg.norm(d)) > 0.1)
+                count += 0 if ob["credible_line"] else 1
+            lf["credible_matching"] = not ((count // len(lf["obs"])) >= 0.5)
+
+    def _line_factors(self):
+        """estimator.cpp:1786-1846: which line observations become LineProjectionFactors."""
+        lf_, lps, lpe, labc = [], [], [], []
+        if self.map_lines is None:
+            for i in range(WINDOW_SIZE + 1):
+                for (ps, pe, abc) in self.line_obs[i]:
+                    lf_.append(i); lps.append(ps); lpe.append(pe); labc.append(abc)
+            return lf_, lps, lpe, labc
+        dist_th = 50.0                                    # sensor.yaml:120
+        for lf in self.linefeatures:
+            if not (len(lf["obs"]) >= 2 and lf["start_frame"] < WINDOW_SIZE - 2) or not lf["credible_matching"]:
+                continue
+            for k, ob in enumerate(lf["obs"]):
+                if not ob["credible_line"] or not ob["use_flag"] or ob["errD"] > dist_th:
+                    continue
+                lf_.append(lf["start_frame"] + k)
+                lps.append(self.Rbw @ ob["world"][:3] + self.Tbw); lpe.append(self.Rbw @ ob["world"][3:] + self.Tbw); labc.append(ob["abc"])
+        return lf_, lps, lpe, labc
+
     def build_window(self):
         W = WINDOW_SIZE
         pose = np.zeros((W + 1, 7)); sb = np.zeros((W + 1, 9))
@@ -264,10 +353,7 @@ class Replay:
                 fi.append(f.start_frame); fj.append(f.start_frame + k); fl.append(l); pi.append(f.obs[0]); pj.append(f.obs[k])
         proj = dict(frame_i=np.array(fi, dtype=np.int64), frame_j=np.array(fj, dtype=np.int64), landmark=np.array(fl, dtype=np.int64),
                     pts_i=np.array(pi).reshape(-1, 3), pts_j=np.array(pj).reshape(-1, 3), sqrt_info=synth.PROJ_SQRT_INFO, loss_a=1.0)
-        lf, lps, lpe, labc = [], [], [], []
-        for i in range(W + 1):           # estimator.cpp:1786-1846 (every stored match is a credible one here)
-            for (ps, pe, abc) in self.line_obs[i]:
-                lf.append(i); lps.append(ps); lpe.append(pe); labc.append(abc)
+        lf, lps, lpe, labc = self._line_factors()
         line = dict(frame=np.array(lf, dtype=np.int64), pts_start=np.array(lps).reshape(-1, 3), pts_end=np.array(lpe).reshape(-1, 3),
                     abc=np.array(labc).reshape(-1, 3), K=synth.K_MAT.copy(), Ric=q2R(ex[3:] / np.linalg.norm(ex[3:])), Tic=self.tic.copy(), loss_a=1.0)
         win = dict(pose=pose, speedbias=sb, ex_pose=ex, lam=lam, imu=imu, proj=proj, line=line, G=G.copy(), prior=self.prior)
@@ -275,6 +361,8 @@ class Replay:
 
     def optimize(self):
         """solveOdometry (:1476-1490) + double2vector + the marginalisation of OptimizationWithLine."""
+        if self.map_lines is not None:
+            self.associate_lines()
         self.triangulate()
         win, sel = self.build_window()
         out = self.backend.optimize(win, self.marg_flag, self.num_iterations, self.fixed_iterations)
@@ -288,7 +376,7 @@ class Replay:
             f.solve_flag = 2 if f.depth < 0 else 1
         if out.get("prior", "keep") != "keep":
             self.prior = out["prior"]
-        self.log.append(dict(flag=self.marg_flag, n_landmarks=len(sel), n_proj=len(win["proj"]["frame_i"]), n_line=len(win["line"]["frame"]),
+        self.log.append(dict(flag=self.marg_flag, n_landmarks=len(sel), n_proj=len(win["proj"]["frame_i"]), n_line=len(win["line"]["frame"]), n_line_obs=sum(len(lf["obs"]) for lf in self.linefeatures),
                              iterations=out.get("iterations"), final_cost=out.get("final_cost"), prior_n=None if self.prior is None else self.prior["n"]))
 
     def failure_detection(self) -> bool:
@@ -327,6 +415,15 @@ class Replay:
                 f.depth = pts_j[2] if pts_j[2] > 0 else INIT_DEPTH
                 kept.append(f)
             self.features = kept
+            keptl = []                                # line features: feature_manager.cpp:598-614
+            for lf in self.linefeatures:
+                if lf["start_frame"] != 0:
+                    lf["start_frame"] -= 1; keptl.append(lf); continue
+                lf["obs"].pop(0)
+                if len(lf["obs"]) > 0:
+                    keptl.append(lf)
+            self.linefeatures = keptl
+            self.fov = self.fov[1:] + [self.fov[W]]
         else:
             # MARGIN_SECOND_NEW (:2189-2230): the newest frame replaces the second newest, their IMU buffers are concatenated
             self.bufs[W - 1]["acc"] += self.bufs[W]["acc"]; self.bufs[W - 1]["gyr"] += self.bufs[W]["gyr"]
@@ -346,6 +443,17 @@ class Replay:
                 if len(f.obs) > 0:
                     kept.append(f)
             self.features = kept
+            keptl = []                                # feature_manager.cpp:677-695
+            for lf in self.linefeatures:
+                if lf["start_frame"] == W:
+                    lf["start_frame"] -= 1; keptl.append(lf); continue
+                if lf["start_frame"] + len(lf["obs"]) - 1 < W - 1:
+                    keptl.append(lf); continue
+                lf["obs"].pop(W - 1 - lf["start_frame"])
+                if len(lf["obs"]) > 0:
+                    keptl.append(lf)
+            self.linefeatures = keptl
+            self.fov[W - 1] = self.fov[W]
         self.features = [f for f in self.features if f.solve_flag != 2]          # removeFailures (:399-408)
 
     # ---- one frame ---------------------------------------------------------------------------------------------------
@@ -378,6 +486,9 @@ def run(stream: dict, backend, num_iterations: int = 8, fixed_iterations: bool =
     writes, visualization.cpp:210-226) plus the per-frame log."""
     rng = np.random.Generator(np.random.PCG64(0xABCD))
     rp = Replay(backend, num_iterations, fixed_iterations)
+    if "map_lines" in stream:
+        rp.map_lines, rp.Rbw, rp.Tbw = stream["map_lines"], stream["Rbw"], stream["Tbw"]
+        backend.set_map(stream["map_lines"], stream["Rbw"], stream["Tbw"])
     # the reference's initialisation calibrates the gyroscope bias (initial_aligment.cpp) before the first window; here the
     # biases start near the truth like the other states
     rp.Bas[:] = stream["ba"] + rng.normal(size=3) * bias_sigma[0]; rp.Bgs[:] = stream["bg"] + rng.normal(size=3) * bias_sigma[1]
@@ -423,6 +534,14 @@ class HipBackend:
         return [dict(delta_p=np.array(o.delta_p), delta_q=np.array(o.delta_q), delta_v=np.array(o.delta_v), lin_ba=np.array(o.linearized_ba),
                      lin_bg=np.array(o.linearized_bg), sum_dt=float(o.sum_dt), jacobian=np.array(o.jacobian).reshape(15, 15),
                      covariance=np.array(o.covariance).reshape(15, 15)) for o in out]
+
+    def set_map(self, lines3d, Rbw, Tbw):
+        self.map = (np.asarray(lines3d, dtype=float), np.asarray(Rbw, dtype=float), np.asarray(Tbw, dtype=float))
+
+    def match_lines(self, poses, ex, fov, det_frame, det):
+        lines3d, Rbw, Tbw = self.map
+        return self.tcv.match_lines(poses, ex, Rbw, Tbw, synth.K_MAT, int(synth.IMG_W), int(synth.IMG_H), WINDOW_SIZE, lines3d, det_frame, det,
+                                    0.1745, 0.45, in_fov=fov)            # angle_th / overlap_th: sensor.yaml:119-122
 
     def optimize(self, win, marg_flag, num_iterations, fixed_iterations):
         tcv = self.tcv

@@ -143,7 +143,7 @@ def lib():
         L.tcv_batch_gauge_fix.argtypes = [vp, vp]
         L.tcv_batch_marg_status.argtypes = [vp, _ip, C.c_int]
         L.tcv_match_lines.argtypes = [C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_int, _ip, _dp, C.c_double,
-                                      C.c_double, C.POINTER(C.c_ubyte), _ip, C.POINTER(C.c_float), _dp]
+                                      C.c_double, C.c_int, C.POINTER(C.c_ubyte), _ip, C.POINTER(C.c_float), _dp]
         L.tcv_eval_projection_td_factors.argtypes = [C.c_int, _dp, _dp, _dp, C.c_double, C.c_double, C.c_double, _dp, _dp]
         _lib = L
     return _lib
@@ -528,15 +528,16 @@ def gauge_fix(R0, P0, pose, sb):
     return Rs, Ps, Vs, po
 
 
-def match_lines(poses, ex_pose, Rbw, Tbw, K, width, height, window_size, lines3d, det_frame, det_lines, angle_th, overlap_th):
+def match_lines(poses, ex_pose, Rbw, Tbw, K, width, height, window_size, lines3d, det_frame, det_lines, angle_th, overlap_th, in_fov=None):
     """UpdateLinesInFoV + LineCorrespondenceInFrame (estimator.cpp:385-447, :671-885) on the GPU.
     Returns (in_fov bool (n_frames, n_map), match_index (n_det,), err float32 (n_det, 3), projected (n_det, 4))."""
     poses = f64(poses).reshape(-1, 7); lines3d = f64(lines3d).reshape(-1, 6)
     det_frame = i32(det_frame); det_lines = f64(det_lines).reshape(-1, 4)
     nf, nm, nd = poses.shape[0], lines3d.shape[0], det_lines.shape[0]
-    fov = np.zeros((nf, nm), np.uint8); match = np.zeros(max(nd, 1), np.int32); err = np.zeros((max(nd, 1), 3), np.float32); proj = np.zeros((max(nd, 1), 4))
+    fov = np.zeros((nf, nm), np.uint8) if in_fov is None else np.ascontiguousarray(np.asarray(in_fov).reshape(nf, nm), dtype=np.uint8)
+    match = np.zeros(max(nd, 1), np.int32); err = np.zeros((max(nd, 1), 3), np.float32); proj = np.zeros((max(nd, 1), 4))
     ex = f64(ex_pose); R = f64(Rbw).reshape(9); T = f64(Tbw); Kf = f64(K).reshape(9)
     check(lib().tcv_match_lines(nf, dptr(poses), dptr(ex), dptr(R), dptr(T), dptr(Kf), int(width), int(height), int(window_size), nm, dptr(lines3d),
                                 nd, iptr(det_frame) if nd else None, dptr(det_lines) if nd else None, float(angle_th), float(overlap_th),
-                                fov.ctypes.data_as(C.POINTER(C.c_ubyte)), iptr(match), err.ctypes.data_as(C.POINTER(C.c_float)), dptr(proj)))
+                                int(in_fov is not None), fov.ctypes.data_as(C.POINTER(C.c_ubyte)), iptr(match), err.ctypes.data_as(C.POINTER(C.c_float)), dptr(proj)))
     return fov.astype(bool), match[:nd].copy(), err[:nd].copy(), proj[:nd].copy()

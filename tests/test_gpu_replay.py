@@ -24,3 +24,16 @@ def test_replay_hip_vs_oracle_ate(gpu):
     assert d.max() < 1e-3
     i, j = ate.associate(hip["t"], stream["t"])
     assert abs(ate.ate_rmse(hip["p"][i], stream["gt_p"][j]) - ate.ate_rmse(ref["p"][i], stream["gt_p"][j])) < 1e-3
+
+
+def test_replay_with_line_association_hip_vs_oracle(gpu):
+    """the same with the 2D-3D association in the loop (tcv_match_lines vs the NumPy restatement): identical association
+    decisions frame by frame, trajectories within 1 mm."""
+    stream = replay.simulate_stream(1, 30, max_features=30, associate=True)
+    hip = replay.run(stream, replay.HipBackend(), num_iterations=8)
+    ref = replay.run(stream, OracleBackend(), num_iterations=8)
+    assert [l["n_line"] for l in hip["log"]] == [l["n_line"] for l in ref["log"]]
+    assert [l["flag"] for l in hip["log"]] == [l["flag"] for l in ref["log"]]
+    d = np.linalg.norm(hip["p"] - ref["p"], axis=1)
+    print("max |p_hip - p_oracle| per frame [m]:", np.array2string(d, precision=2))
+    assert d.max() < 1e-3

@@ -58,3 +58,14 @@ def test_replay_with_the_oracle_back_end_tracks_the_ground_truth():
     assert len(i) == len(out["t"])
     assert ate.ate_rmse(out["p"][i], stream["gt_p"][j]) < 0.10                    # SE(3)-aligned ATE
     assert ate.ate_rmse(out["p"][i], stream["gt_p"][j], align=False) < 1.0       # no divergence
+
+
+def test_replay_with_line_association_in_the_loop():
+    """N4 in the loop: the stream carries un-associated line tracks + the prior map; every frame runs UpdateLinesInFoV,
+    updateLinePairInWindow / LineCorrespondenceInFrame and removeLineOutlier before the solve (processImagewithLine :328-336)."""
+    stream = replay.simulate_stream(1, 30, max_features=30, associate=True)
+    out = replay.run(stream, OracleBackend(), num_iterations=8)
+    assert all(0 < l["n_line"] <= l["n_line_obs"] for l in out["log"])
+    assert any(l["n_line"] < l["n_line_obs"] for l in out["log"])          # some observations fail the angle / overlap / distance gates
+    i, j = ate.associate(out["t"], stream["t"])
+    assert ate.ate_rmse(out["p"][i], stream["gt_p"][j]) < 0.10
