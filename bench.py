@@ -184,8 +184,8 @@ def main():
     elapsed_max, windows_total = reduce_stats(dist, elapsed, B * args.steps, dev if dist is not None and dist.get_backend() == "nccl" else None)
 
     # parity spot-check of what was just timed is done by tests/ and smoke(); here only sanity of the results
-    s = batch.summaries(4)
-    assert all(np.isfinite(s[k].final_cost) and s[k].final_cost < s[k].initial_cost for k in range(4))
+    s = batch.summaries(min(4, B))
+    assert all(np.isfinite(s[k].final_cost) and s[k].final_cost < s[k].initial_cost for k in range(min(4, B)))
 
     if rank == 0:
         w0 = wins[0]

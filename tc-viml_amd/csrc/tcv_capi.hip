@@ -499,7 +499,7 @@ static void summary_to_public(const DevSummary &s, tcv_solver_summary *o) {
     }
 }
 extern "C" int tcv_batch_get_summaries(tcv_batch *b, tcv_solver_summary *out, int n) {
-    if (!b || !out || n > b->n) return TCV_ERR_INVALID;
+    if (!b || !out || n < 0 || n > b->n) { set_error("batch_get_summaries: n exceeds the batch size"); return TCV_ERR_INVALID; }
     std::vector<DevSummary> h(n);
     HIPCHK(hipMemcpy(h.data(), b->d_summary, sizeof(DevSummary) * n, hipMemcpyDeviceToHost));
     for (int i = 0; i < n; i++) summary_to_public(h[i], out + i);
