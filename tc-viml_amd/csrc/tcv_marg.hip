@@ -29,8 +29,8 @@
 
 namespace tcv {
 
-enum { MARG_MAX_M = 64, MARG_MAX_N = 80, MARG_MAX_POS = MARG_MAX_M + MARG_MAX_N, MARG_MAX_X = 320, MARG_NT = 512 };
-enum { MARG_OUT_J0 = 0, MARG_OUT_R0 = 6400, MARG_OUT_AS = 6480, MARG_OUT_BS = 12880, MARG_OUT_X = 12960, MARG_OUT_STRIDE = 13312 };
+enum { MARG_MAX_M = 64, MARG_MAX_N = 80, MARG_MAX_POS = MARG_MAX_M + MARG_MAX_N, MARG_MAX_X = 1408, MARG_NT = 512 };
+enum { MARG_OUT_J0 = 0, MARG_OUT_R0 = 6400, MARG_OUT_AS = 6480, MARG_OUT_BS = 12880, MARG_OUT_X = 12960, MARG_OUT_STRIDE = 12960 + 1408 + 64 };
 enum { MARG_SCR_Z = 0, MARG_SCR_PR = MARG_MAX_M * MARG_MAX_N, MARG_SCR_SQ = MARG_SCR_PR + 256, MARG_SCR_STRIDE = MARG_SCR_SQ + 16 * 225 + 450 * 16 };
 
 struct MargHdr {
@@ -43,7 +43,11 @@ struct MargHdr {
     int o_pcol;    // prior_n: mloc index of every J0 column (-1 constant)
     int d_x, d_imu, d_proj, d_prior, d_misc;
     long long ibase, dbase;
-    int solve_window, pad;
+    int solve_window;
+    int block_mode;   // 1: the marginalised inverse depths (1 x 1 blocks) are eliminated by scalar pivots while the factors are
+                      // accumulated, only the frame part of the dropped set (m) goes through the eigen pseudo-inverse
+    int o_plast;      // block mode: n_proj flags, 1 = last factor of its landmark (factors sorted by landmark)
+    int pad;
 };
 
 struct MargArgs {
@@ -502,9 +506,11 @@ __global__ void __launch_bounds__(MARG_NT) marg_kernel(MargArgs Aarg) {
         const int r2 = max(2 * me * (me + 1), ne * (ne + 1));
         lds_d *bv = R2 + ((r2 + 1) & ~1);                   // pos
         lds_d *x = bv + MARG_MAX_POS;                       // nx
-        lds_d *rot = x + MARG_MAX_X;                        // 160
+        lds_d *rot = x + ((H.nx + 7) & ~7);                 // 160
         lds_d *lam = rot + 160;                             // MARG_MAX_N
-        lds_d *stage = lam + MARG_MAX_N;                    // 64 proj records or 1 imu record
+        lds_d *cvec = lam + MARG_MAX_N;                     // block mode: the current landmark's coupling to the camera columns
+        lds_d *lmacc = cvec + MARG_MAX_POS;                 // its diagonal and gradient
+        lds_d *stage = lmacc + 8;                           // 64 proj records or 1 imu record
         lds_i *cnt = (lds_i *)(rot + 158);
         gbl_d *out = (gbl_d *)Aarg.out + (size_t)win * MARG_OUT_STRIDE;
         long long t_last = clock64();
@@ -519,7 +525,8 @@ __global__ void __launch_bounds__(MARG_NT) marg_kernel(MargArgs Aarg) {
                                 : dp[H.d_x + go + i];
         }
         for (int i = tid; i < npk; i += MARG_NT) Apk[i] = 0.0;
-        for (int i = tid; i < pos; i += MARG_NT) bv[i] = 0.0;
+        for (int i = tid; i < pos; i += MARG_NT) { bv[i] = 0.0; cvec[i] = 0.0; }
+        if (tid < 8) lmacc[tid] = 0.0;
         cst_d *misc = dp + H.d_misc;
         const double G3[3] = {misc[0], misc[1], misc[2]};
         __syncthreads();
@@ -650,9 +657,16 @@ __global__ void __launch_bounds__(MARG_NT) marg_kernel(MargArgs Aarg) {
                     if (cb < 19 && cb > ca) continue;
                     const int sa = ca == 18 ? 3 : ca / 6;
                     const int la = blk[pf[sa] * 5 + 2];
+                    const double s = rec[ca] * rec[cb] + rec[PROJ_STRIDE + ca] * rec[PROJ_STRIDE + cb];
+                    if (H.block_mode && ca == 18) {
+                        // the landmark's row: coupling to the camera columns, its diagonal and its gradient
+                        if (cb == 18) lmacc[0] += s;
+                        else if (cb == 19) lmacc[1] += s;
+                        else { const int sb = cb / 6, lb = blk[pf[sb] * 5 + 2]; if (lb >= 0) cvec[lb + cb - 6 * sb] += s; }
+                        continue;
+                    }
                     if (la < 0) continue;
                     const int ia = la + (ca == 18 ? 0 : ca - 6 * sa);
-                    const double s = rec[ca] * rec[cb] + rec[PROJ_STRIDE + ca] * rec[PROJ_STRIDE + cb];
                     if (cb == 19) { bv[ia] += s; continue; }
                     const int sb = cb == 18 ? 3 : cb / 6;
                     const int lb = blk[pf[sb] * 5 + 2];
@@ -660,6 +674,21 @@ __global__ void __launch_bounds__(MARG_NT) marg_kernel(MargArgs Aarg) {
                     Apk[pidx(ia, lb + (cb == 18 ? 0 : cb - 6 * sb))] += s;
                 }
                 __syncthreads();
+                if (H.block_mode && ip[H.o_plast + f0 + f]) {
+                    // Schur complement of the 1 x 1 landmark block (pseudo-inverse: a landmark without information contributes nothing)
+                    const double d = lmacc[0], g = lmacc[1], invd = d > 1e-8 ? 1.0 / d : 0.0;
+                    for (int e = tid; e < pos * pos; e += MARG_NT) {
+                        const int i = e / pos, j = e - i * pos;
+                        if (j > i) continue;
+                        const double ci = cvec[i], cj = cvec[j];
+                        if (ci != 0.0 && cj != 0.0) Apk[pidx(i, j)] -= ci * cj * invd;
+                    }
+                    if (tid < pos) bv[tid] -= cvec[tid] * g * invd;
+                    __syncthreads();
+                    for (int i = tid; i < pos; i += MARG_NT) cvec[i] = 0.0;
+                    if (tid == 0) { lmacc[0] = 0.0; lmacc[1] = 0.0; }
+                    __syncthreads();
+                }
             }
         }
         MARG_MARK(3);
@@ -764,6 +793,7 @@ struct MargWindow {
     std::vector<int> keep_block;      // marg-problem block index of every kept block (in mloc order)
     std::vector<int> keep_size, keep_idx, keep_goff;
     std::vector<double *> keep_addr;
+    int m_total = 0;                  // all dropped tangent dims (landmarks included), the reference's m
 };
 struct MargState {
     std::vector<MargWindow> win;
@@ -785,6 +815,15 @@ static void marg_free(tcv_batch *b) {
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     delete s;
     b->marg = nullptr;
+}
+
+// LDS doubles one window needs: [packed A | Amm + V, later A' | b | x | rot | lam | landmark row | staging]; the tridiagonal
+// eigen-solver of A' puts 512 doubles of vectors and an n x (ne + 1) workspace where the staging records were
+static size_t marg_lds_doubles(int pos, int m, int n, int nx) {
+    const int me = m + (m & 1), ne = n + (n & 1);
+    const int r1 = std::max(pos * (pos + 1) / 2, ne * (ne + 1)), r2 = std::max(2 * me * (me + 1), ne * (ne + 1));
+    const size_t before_stage = (size_t)((r1 + 1) & ~1) + ((r2 + 1) & ~1) + MARG_MAX_POS + ((nx + 7) & ~7) + 160 + MARG_MAX_N + MARG_MAX_POS + 8;
+    return before_stage + std::max<size_t>(64 * PROJ_REC, 512 + (size_t)n * (ne + 1));
 }
 
 static int pack_marg(const tcv_problem &p, double *const *drop, int ndrop, const tcv_problem *solve_p, const Packed *solve_pk,
@@ -812,10 +851,38 @@ static int pack_marg(const tcv_problem &p, double *const *drop, int ndrop, const
         nx += p.blocks[b].size;
     }
     const int nblk = (int)gsize.size();
-    int pos = 0;
+    // marginalised inverse depths: size-1 blocks that only ever appear as 4th block of projection factors.  When the dropped
+    // set is too large for the LDS-resident eigen-solver (a 150-feature front end anchors far more than 49 landmarks in the
+    // oldest frame) they are eliminated by scalar pivots (block mode) and only the frame part goes through the eigen step.
+    std::vector<char> is_lm(nb, 0), other_use(nb, 0);
+    for (auto &f : p.proj) { is_lm[f.b[3]] = 1; for (int k = 0; k < 3; k++) other_use[f.b[k]] = 1; }
+    for (auto &f : p.imu) for (int k = 0; k < 4; k++) other_use[f.b[k]] = 1;
+    for (auto &f : p.prior) for (int b : f.b) other_use[b] = 1;
+    int m_all = 0, n_lm_drop = 0;
     for (int c = 0; c < nblk; c++) {
         const ParamBlock &pb = p.blocks[orig[c]];
-        if (dropped[orig[c]] && !pb.constant) { mloc[c] = pos; pos += pb.kind == KIND_POSE ? 6 : pb.size; }
+        if (dropped[orig[c]] && !pb.constant) {
+            m_all += pb.kind == KIND_POSE ? 6 : pb.size;
+            if (is_lm[orig[c]] && !other_use[orig[c]] && pb.size == 1) n_lm_drop++;
+        }
+    }
+    int n_all = 0;
+    for (int c = 0; c < nblk; c++) {
+        const ParamBlock &pb = p.blocks[orig[c]];
+        if (!dropped[orig[c]] && !pb.constant) n_all += pb.kind == KIND_POSE ? 6 : pb.size;
+    }
+    // one-piece eigen-decomposition of A_mm (the reference's) whenever it fits the LDS, block mode otherwise
+    const bool fits = m_all <= MARG_MAX_M && n_all <= MARG_MAX_N && marg_lds_doubles(m_all + n_all, m_all, n_all, nx) <= (size_t)LDS_DOUBLES;
+    const bool block_mode = !fits && n_lm_drop > 0;
+    int pos = 0;
+    std::vector<int> lm_id(nb, -1);
+    int n_lm = 0;
+    for (int c = 0; c < nblk; c++) {
+        const ParamBlock &pb = p.blocks[orig[c]];
+        if (dropped[orig[c]] && !pb.constant) {
+            if (block_mode && is_lm[orig[c]] && !other_use[orig[c]] && pb.size == 1) { lm_id[orig[c]] = n_lm; mloc[c] = -2 - n_lm; n_lm++; continue; }
+            mloc[c] = pos; pos += pb.kind == KIND_POSE ? 6 : pb.size;
+        }
     }
     const int m = pos;
     mw.keep_block.clear(); mw.keep_size.clear(); mw.keep_idx.clear(); mw.keep_addr.clear(); mw.keep_goff.clear();
@@ -829,7 +896,9 @@ static int pack_marg(const tcv_problem &p, double *const *drop, int ndrop, const
         pos += pb.kind == KIND_POSE ? 6 : pb.size;
     }
     const int n = pos - m;
-    if (m < 1 || n < 1) { set_error("marginalize: nothing to drop or nothing to keep"); return TCV_ERR_INVALID; }
+    if (m_all < 1 || n < 1) { set_error("marginalize: nothing to drop or nothing to keep"); return TCV_ERR_INVALID; }
+    if (block_mode && m < 1) { set_error("marginalize: block mode needs a non-landmark block in the dropped set"); return TCV_ERR_UNSUPPORTED; }
+    mw.m_total = m_all;
     if (m > MARG_MAX_M || n > MARG_MAX_N || nx > MARG_MAX_X || p.imu.size() > 16) {
         set_error("marginalisation too large for the LDS-resident kernel (m <= 64, n <= 80)");
         return TCV_ERR_TOO_LARGE;
@@ -854,8 +923,19 @@ static int pack_marg(const tcv_problem &p, double *const *drop, int ndrop, const
     for (int c = 0; c < nblk; c++) { I.push_back(gsize[c]); I.push_back(goff[c]); I.push_back(mloc[c]); I.push_back(kind[c]); I.push_back(xsrc[c]); }
     H.o_imu = imark();
     for (auto &f : p.imu) for (int k = 0; k < 4; k++) I.push_back(id_of[f.b[k]]);
+    std::vector<int> porder(p.proj.size());
+    for (size_t i = 0; i < porder.size(); i++) porder[i] = (int)i;
+    if (block_mode) {
+        for (auto &f : p.proj)
+            if (dropped[f.b[3]] && lm_id[f.b[3]] < 0) { set_error("marginalize: dropped inverse depth shared with a non-projection factor"); return TCV_ERR_UNSUPPORTED; }
+        std::stable_sort(porder.begin(), porder.end(), [&](int a, int b2) { return p.proj[a].b[3] < p.proj[b2].b[3]; });
+    }
+    H.block_mode = block_mode ? 1 : 0;
     H.o_proj = imark();
-    for (auto &f : p.proj) for (int k = 0; k < 4; k++) I.push_back(id_of[f.b[k]]);
+    for (int k2 : porder) for (int k = 0; k < 4; k++) I.push_back(id_of[p.proj[k2].b[k]]);
+    H.o_plast = imark();
+    for (size_t i = 0; i < porder.size(); i++)
+        I.push_back(block_mode && lm_id[p.proj[porder[i]].b[3]] >= 0 && (i + 1 == porder.size() || p.proj[porder[i + 1]].b[3] != p.proj[porder[i]].b[3]) ? 1 : 0);
     H.o_prior = imark();
     std::vector<int> pcol;
     const tcv_prior *pr = p.prior.empty() ? nullptr : p.prior[0].prior;
@@ -887,7 +967,7 @@ static int pack_marg(const tcv_problem &p, double *const *drop, int ndrop, const
     H.d_proj = dmark();
     double psi = 0, pla = 0;
     for (size_t k = 0; k < p.proj.size(); k++) {
-        const ProjFac &f = p.proj[k];
+        const ProjFac &f = p.proj[porder[k]];
         if (k == 0) { psi = f.sqrt_info; pla = f.loss_a; }
         else if (f.sqrt_info != psi || f.loss_a != pla) { set_error("projection factors must share sqrt_info and loss"); return TCV_ERR_UNSUPPORTED; }
         if (p.blocks[f.b[3]].size != 1) { set_error("projection factor: 4th block must be an inverse depth"); return TCV_ERR_UNSUPPORTED; }
@@ -922,9 +1002,7 @@ int tcv_marg_attach(tcv_batch *b, tcv_problem *const *marg_problems, double *con
         s->win[w].hdr.solve_window = w;
         hdrs[w] = s->win[w].hdr;
         const int pos = hdrs[w].pos, m = hdrs[w].m, n = hdrs[w].n;
-        const int me = m + (m & 1), ne = n + (n & 1);
-        const int r1 = std::max(pos * (pos + 1) / 2, ne * (ne + 1)), r2 = std::max(2 * me * (me + 1), ne * (ne + 1));
-        const size_t need = (size_t)(((r1 + 1) & ~1) + ((r2 + 1) & ~1) + MARG_MAX_POS + MARG_MAX_X + 160 + MARG_MAX_N + 64 * PROJ_REC) * 8;
+        const size_t need = marg_lds_doubles(pos, m, n, hdrs[w].nx) * 8;
         if (need > (size_t)LDS_DOUBLES * 8) { set_error("marginalisation does not fit LDS"); return TCV_ERR_TOO_LARGE; }
         lds = std::max(lds, need);
         lds = (size_t)LDS_DOUBLES * 8;      // the eigen-solver's workspace uses everything behind the staging area
@@ -996,7 +1074,7 @@ int tcv_marg_get_prior(tcv_batch *b, int window, tcv_prior **out) {
     MargState *s = (MargState *)b->marg;
     if (!s || !s->ran || window < 0 || window >= b->n) { set_error("no marginalisation result for this window"); return TCV_ERR_INVALID; }
     const MargWindow &mw = s->win[window];
-    const int n = mw.hdr.n, m = mw.hdr.m;
+    const int n = mw.hdr.n, m = mw.hdr.m;      // m: dropped dims that went through the eigen step (all of them unless block mode)
     std::vector<double> o(MARG_OUT_STRIDE);
     int status = -1;
     hipError_t e = hipMemcpy(o.data(), s->d_out + (size_t)window * MARG_OUT_STRIDE, sizeof(double) * MARG_OUT_STRIDE, hipMemcpyDeviceToHost);
@@ -1005,7 +1083,7 @@ int tcv_marg_get_prior(tcv_batch *b, int window, tcv_prior **out) {
     if (e != hipSuccess) return hip_fail(e, "hipMemcpy D2H");
     if (status < 0) { set_error("marginalisation kernel did not complete for this window"); return TCV_ERR_NUMERIC; }
     tcv_prior *pr = new tcv_prior();
-    pr->m = m; pr->n = n;
+    pr->m = mw.m_total; pr->n = n;            // the reference's m counts every marginalised dim (marginalization_factor.cpp:176-186)
     int xo = 0;
     for (size_t k = 0; k < mw.keep_block.size(); k++) {
         pr->size.push_back(mw.keep_size[k]);

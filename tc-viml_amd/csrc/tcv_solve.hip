@@ -200,16 +200,24 @@ __device__ __forceinline__ void copy_doubles(lds_d *dst, cst_d *src, int n, int 
     if ((n & 1) && tid == 0) dst[n - 1] = src[n - 1];
 }
 
-// same without alignment assumptions (8-byte accesses), four loads per thread in flight
+// deep version for data that comes from HBM rather than L2 (the prior's J0, 45 KB per window and linearisation): ten 16-byte
+// loads per thread in flight, so that a 39 KB piece costs ONE memory round trip instead of five
 template <int NT>
-__device__ __forceinline__ void copy_doubles1(lds_d *dst, cst_d *src, int n, int tid) {
-    for (int i = tid; i < n; i += 4 * NT) {
-        double v[4];
+__device__ __forceinline__ void copy_doubles_deep(lds_d *dst, cst_d *src, int n, int tid) {
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    typedef const __attribute__((address_space(4))) v2d cst_v2d;
+    typedef __attribute__((address_space(3))) v2d lds_v2d;
+    const int n2 = n >> 1;                      // src and dst 16-byte aligned
+    cst_v2d *s2 = (cst_v2d *)src;
+    lds_v2d *d2 = (lds_v2d *)dst;
+    for (int i = tid; i < n2; i += 10 * NT) {
+        v2d v[10];
 #pragma unroll
-        for (int k = 0; k < 4; k++) v[k] = src[min(i + k * NT, n - 1)];
+        for (int k = 0; k < 10; k++) v[k] = s2[min(i + k * NT, n2 - 1)];
 #pragma unroll
-        for (int k = 0; k < 4; k++) if (i + k * NT < n) dst[i + k * NT] = v[k];
+        for (int k = 0; k < 10; k++) if (i + k * NT < n2) d2[i + k * NT] = v[k];
     }
+    if ((n & 1) && tid == 0) dst[n - 1] = src[n - 1];
 }
 
 // zero n doubles (n even, 16-byte aligned) with 16-byte LDS stores
@@ -428,14 +436,16 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
             // J0 does not fit the pool in one piece: columns [0, ns) and [ns, n) are staged one after the other.  The big
             // piece comes second and stays resident for the J0' r pass, so only the small one is read twice.
             const int cap = (P.c_pool - 2 * n - 2) / n;
-            const int nb = min(n, cap), ns = n - nb;
+            int nb = min(n, cap);
+            if ((n & 1) && ((n - nb) & 1)) nb--;      // keep the second piece 16-byte aligned: n * (n - nb) even
+            const int ns = n - nb;
             lds_d *Jp = C.stage;
             lds_d *pdx2 = pdx, *pr2 = pr;
             double r = (tid < n) ? r0[tid] : 0.0, r2 = 0.0;
             for (int piece = 0; piece < 2; piece++) {
                 const int c0 = piece == 0 ? 0 : ns, cn = piece == 0 ? ns : nb;
                 if (cn == 0) continue;
-                copy_doubles1<NT>(Jp, J0g + n * c0, n * cn, tid);
+                copy_doubles_deep<NT>(Jp, J0g + n * c0, n * cn, tid);
                 __syncthreads();
                 if (tid < n) {
                     for (int j = 0; j + 1 < cn; j += 2) { r += Jp[tid + n * j] * pdx2[c0 + j]; r2 += Jp[tid + n * (j + 1)] * pdx2[c0 + j + 1]; }
@@ -450,7 +460,7 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
                 for (int piece = 1; piece >= 0; piece--) {
                     const int c0 = piece == 0 ? 0 : ns, cn = piece == 0 ? ns : nb;
                     if (cn == 0) continue;
-                    if (piece == 0) { __syncthreads(); copy_doubles1<NT>(Jp, J0g, n * cn, tid); __syncthreads(); }
+                    if (piece == 0) { __syncthreads(); copy_doubles_deep<NT>(Jp, J0g, n * cn, tid); __syncthreads(); }
                     if (tid < cn) {
                         const int t = pcol[c0 + tid];
                         if (t >= 0) {

@@ -136,6 +136,29 @@ def test_margin_second_new_prior_only(gpu):
     assert got == [tuple(b) for b in po["blocks"]]
 
 
+def test_large_drop_set_uses_landmark_pivots(gpu):
+    """a 150-feature front end anchors far more landmarks in the oldest frame than the LDS-resident eigen-solver takes
+    (m <= 64): the marginalised inverse depths are then eliminated by scalar pivots and only the frame part (15) goes through
+    the eigen pseudo-inverse.  Same A', b' as the reference's one-piece eigen-decomposition of A_mm (oracle) within the
+    reproducibility floor; m keeps the reference's meaning (all marginalised dims)."""
+    batch = synth.make_windows(902, 1, n_landmarks=400, frame_shift=-1)
+    w = synth.window_at(batch, 0)
+    O = orc.Window(w); O.solve(4, True); st = O.states(); po, dbg = O.marginalize_old()
+    assert po["m"] > 64
+    w2 = dict(w, pose=st["pose"], speedbias=st["sb"], ex_pose=st["ex"], lam=st["lam"])
+    mw = gpu.margin_old_window(w2)
+    Wm = gpu.Window(mw)
+    dr = gpu.margin_old_drops(Wm, mw)
+    arr = (gpu._dp * len(dr))(*dr)
+    h = C.c_void_p()
+    gpu.check(gpu.lib().tcv_marginalize(Wm.h, arr, len(dr), C.byref(h)))
+    P = gpu.Prior(h); d = P.export(); As, bs = P.schur()
+    assert (d["m"], d["n"]) == (po["m"], po["n"]) and d["sizes"] == po["sizes"] and d["idx"] == po["idx"]
+    assert fro(As, dbg["A_schur"]) < 1e-5 and fro(bs, dbg["b_schur"]) < 1e-5
+    assert fro(d["J0"].T @ d["J0"], dbg["A_schur"]) < 1e-5
+    assert rel(np.concatenate(d["x0"]), np.concatenate([np.atleast_1d(v) for v in po["x0"]])) == 0.0
+
+
 def test_marginalise_error_paths(gpu):
     batch = synth.make_windows(901, 1)
     w = synth.window_at(batch, 0)

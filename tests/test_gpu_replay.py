@@ -37,3 +37,16 @@ def test_replay_with_line_association_hip_vs_oracle(gpu):
     d = np.linalg.norm(hip["p"] - ref["p"], axis=1)
     print("max |p_hip - p_oracle| per frame [m]:", np.array2string(d, precision=2))
     assert d.max() < 1e-3
+
+
+def test_replay_with_a_dense_front_end(gpu):
+    """90 tracked features per frame: the oldest frame anchors more landmarks than the eigen-solver's m <= 64, so the
+    marginalisation runs in block mode (inverse depths by scalar pivots) and the visual part of the solve is chunked through
+    LDS many times; still within 1 mm of the oracle replay."""
+    stream = replay.simulate_stream(3, 26, max_features=90)
+    hip = replay.run(stream, replay.HipBackend(), num_iterations=8)
+    ref = replay.run(stream, OracleBackend(), num_iterations=8)
+    assert max(l["n_landmarks"] for l in hip["log"]) > 100
+    d = np.linalg.norm(hip["p"] - ref["p"], axis=1)
+    print("max |p_hip - p_oracle| per frame [m]:", np.array2string(d, precision=2), "landmarks", [l["n_landmarks"] for l in hip["log"]][:6])
+    assert d.max() < 1e-3
