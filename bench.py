@@ -220,14 +220,15 @@ def main():
             "config": {"workload": "configs[2]: synthetic 10-kf window, 200 point + 40 2D-3D line residual blocks + marginalisation prior "
                                    "(n=75), 50 landmarks; 8 fixed dogleg iterations + 1 MARGIN_OLD marginalisation per solve",
                        "windows_per_gpu": B, "solver_iterations": SOLVER_ITERATIONS, "parallelism": f"independent windows x{world}",
-                       "threads_per_window": args.threads},
+                       "threads_per_window": args.threads, "layout": "chain" if args.variant == 0 else "dense"},
             "iterations_per_s": windows_total * SOLVER_ITERATIONS / elapsed_max,
             "kernel_ms": {"solve": k_ms, "marginalize": m_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "kernel": "tcv::solve_kernel", "algorithmic_bytes_per_iteration": bpi,
                          "units_per_launch": units,
-                         "note": "fused FP64 solve: latency/issue bound, not HBM bound (DESIGN.md); frac is vs the 8 TB/s HBM3E spec"},
+                         "note": "fused FP64 solve (chain layout, two windows per CU): latency/issue bound, not HBM bound (DESIGN.md 4.1); frac is vs "
+                                 "the 8 TB/s HBM3E spec; traffic = PMC FETCH_SIZE x2 + WRITE_SIZE of profiles/pmc_traffic.json"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(wins, args.cpu_budget)
