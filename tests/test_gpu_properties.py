@@ -57,3 +57,36 @@ def test_restart_from_converged_states_does_not_increase_cost(gpu):
     for k in range(8):
         assert s2[k].final_cost <= s[k].final_cost * (1 + 1e-9)
         assert abs(s2[k].initial_cost - s[k].final_cost) < 1e-9 * s[k].final_cost      # cost(x*) re-evaluated bit-for-bit-ish
+
+
+def test_chain_and_dense_layouts_agree_on_a_large_batch(gpu):
+    """256 cfg-3 windows (200 point + 40 line blocks, GPU-made n = 75 priors): the chain layout (default) and the dense layout
+    must take the same trust-region decisions and end at the same states; also with convergence tests on."""
+    import bench
+    out = {}
+    _b, wins, _keep = bench.build_batches(gpu, synth, 7000, 256)          # identical inputs (incl. the priors) for both layouts
+    del _b, _keep
+    try:
+        for variant in (0, 1):
+            gpu.check(gpu.lib().tcv_set_solver_variant(variant))
+            res = []
+            for fixed, iters in ((True, 8), (False, 30)):
+                W = [gpu.Window(w) for w in wins]
+                batch = gpu.Batch(W)
+                assert batch.plan_stats()["lds_bytes"] == (80 * 1024 if variant == 0 else 160 * 1024)
+                batch.solve(gpu.default_options(iters, fixed)); batch.synchronize(); batch.download_states()
+                s = batch.summaries()
+                res.append(([s[k].final_cost for k in range(256)], [[s[k].dogleg_case[i] for i in range(s[k].num_iterations)] for k in range(256)],
+                            [s[k].termination for k in range(256)], np.stack([w.pose.copy() for w in W])))
+            out[variant] = res
+    finally:
+        gpu.check(gpu.lib().tcv_set_solver_variant(0))
+    for mode in range(2):
+        fc0, dc0, t0, p0 = out[0][mode]; fc1, dc1, t1, p1 = out[1][mode]
+        worst = sorted((abs(a - b) / b, k) for k, (a, b) in enumerate(zip(fc0, fc1)))[-3:]
+        assert worst[-1][0] < 1e-6, (mode, worst, [(dc0[k], dc1[k]) for _, k in worst])
+        same = sum(1 for a, b in zip(dc0, dc1) if a == b)
+        assert same >= 250, same              # a borderline accept / reject may flip between two roundings of the same system
+        assert sum(1 for a, b in zip(t0, t1) if a == b) >= 250
+        if mode == 0:
+            assert rel(p0, p1) < 1e-6
