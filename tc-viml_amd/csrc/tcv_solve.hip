@@ -415,7 +415,9 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
         const int n = P.prior_n;
         cst_d *J0g = dp + C.W->d_prior, *r0 = J0g + n * n, *x0 = r0 + n;
         const bool in_lds = n * n + 2 * n <= C.stage_cap;
-        const bool staged = CHAIN && !in_lds;      // chain mode: J0 goes through the pool in two column pieces
+        // chain mode: J0 goes through the pool in two column pieces (priors too tall for two pieces take the HBM/L2 path below)
+        const int pcap = CHAIN ? (P.c_pool - 2 * n - 2) / n - 1 : 0;
+        const bool staged = CHAIN && !in_lds && n - pcap <= pcap;
         lds_d *J0 = C.stage, *pdx = staged ? C.stage + ((P.c_pool - 2 * n) & ~1) : C.stage + n * n, *pr = pdx + n;
         if (tid < P.prior_nblk) {      // dx of one kept block (marginalization_factor.cpp:348-364); fixed-size, fully unrolled
             cst_i *pb = ip + P.o_prior + tid * 4;
@@ -432,11 +434,10 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
 #pragma unroll
             for (int i = 0; i < 15; i++) if (i < ls) { if (in_lds || staged) pdx[pb[1] + i] = d15[i]; else C.g_pdx[pb[1] + i] = d15[i]; }
         }
-        if (CHAIN && !in_lds) {
+        if (staged) {
             // J0 does not fit the pool in one piece: columns [0, ns) and [ns, n) are staged one after the other.  The big
             // piece comes second and stays resident for the J0' r pass, so only the small one is read twice.
-            const int cap = (P.c_pool - 2 * n - 2) / n;
-            int nb = min(n, cap);
+            int nb = min(n, pcap + 1);
             if ((n & 1) && ((n - nb) & 1)) nb--;      // keep the second piece 16-byte aligned: n * (n - nb) even
             const int ns = n - nb;
             lds_d *Jp = C.stage;
