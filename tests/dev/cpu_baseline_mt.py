@@ -2,7 +2,7 @@
 num_threads = 1) over independent windows of the benchmark workload on N host processes.  Test/measurement infrastructure."""
 import os, sys, time
 import multiprocessing as mp
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tc-viml_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, ROOT)
 
 

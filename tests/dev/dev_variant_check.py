@@ -1,6 +1,6 @@
 """Developer check (GPU): chain layout vs dense layout vs the C oracle on the golden window and a few synthetic ones."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in ("tc-viml_amd", "oracle", "tests"):
     sys.path.insert(0, os.path.join(ROOT, p))
 import numpy as np

@@ -148,3 +148,16 @@ def test_synthetic_generator_is_deterministic_and_batch_independent():
     assert len(w1["proj"]["frame_i"]) == 200 and len(w1["line"]["frame"]) == 40 and len(w1["imu"]["frame_i"]) == 10
     # consecutive tracks starting at the anchor (estimator.cpp:1745-1770), anchors < WINDOW_SIZE - 2 (:1740)
     assert np.all(w1["proj"]["frame_j"] > w1["proj"]["frame_i"]) and w1["proj"]["frame_i"].max() < 8
+
+
+def test_only_tests_smoke_and_cpu_baseline_touch_the_oracle():
+    """the oracle is test infrastructure: nothing under tc-viml_amd/ or tools/ imports it, bench.py only inside cpu_baseline()."""
+    import glob
+    for f in glob.glob(os.path.join(ROOT, "tc-viml_amd", "*.py")) + glob.glob(os.path.join(ROOT, "tools", "*.py")):
+        src = open(f).read()
+        assert "import orc" not in src and "import np_oracle" not in src and "replay_oracle" not in src, f
+    b = open(os.path.join(ROOT, "bench.py")).read()
+    assert b.count("import orc") == 1 and b.index("import orc") > b.index("def cpu_baseline")
+    for f in glob.glob(os.path.join(ROOT, "tc-viml_amd", "csrc", "*")):
+        src = open(f).read()
+        assert "tcv_oracle" not in src and "orc_" not in src and "liborc" not in src, f      # comments may mention the oracle, code may not use it
