@@ -161,3 +161,31 @@ def test_only_tests_smoke_and_cpu_baseline_touch_the_oracle():
     for f in glob.glob(os.path.join(ROOT, "tc-viml_amd", "csrc", "*")):
         src = open(f).read()
         assert "tcv_oracle" not in src and "orc_" not in src and "liborc" not in src, f      # comments may mention the oracle, code may not use it
+
+
+def test_chain_layout_eligibility_is_decided_on_the_host(tcv):
+    """the packer's symbolic elimination (no GPU needed): speed-bias chains get the chain layout; a prior that ties two
+    non-adjacent speed-bias blocks together (more than one later-eliminated neighbour) falls back to the dense layout; a broken
+    IMU chain (sum_dt > 10, estimator.cpp:1726) is still a forest of chains; the chain steps cover every speed-bias block."""
+    pre, main, z = golden_windows()
+    st = tcv.Window(main).plan_stats()
+    assert st["nt"] == 5 and st["n_iunit"] == 11 and st["n_imu_chunk"] == 1 and st["n_vis_chunk"] == 3
+    # prior on sb 0 and sb 5 as well: chain broken -> dense
+    p = main["prior"]
+    n = p["n"] + 9
+    J0 = np.zeros((n, n)); J0[:p["n"], :p["n"]] = p["J0"]; J0[p["n"]:, p["n"]:] = np.eye(9)
+    p2 = dict(p, n=n, J0=J0, r0=np.concatenate([p["r0"], np.zeros(9)]), sizes=list(p["sizes"]) + [9], idx=list(p["idx"]) + [p["n"]],
+              x0=list(p["x0"]) + [np.asarray(main["speedbias"])[5].copy()], blocks=list(p["blocks"]) + [("sb", 5)])
+    st2 = tcv.Window(dict(main, prior=p2)).plan_stats()
+    assert st2["nt"] == 11 and st2["lds_bytes"] > 80 * 1024
+    # ... but sb 0 and sb 1 (neighbours) keep it
+    p3 = dict(p2, blocks=list(p["blocks"]) + [("sb", 1)], x0=list(p["x0"]) + [np.asarray(main["speedbias"])[1].copy()])
+    st3 = tcv.Window(dict(main, prior=p3)).plan_stats()
+    assert st3["nt"] == 5 and st3["n_iunit"] == 11
+    # one IMU factor dropped (sum_dt > 10): two chains
+    w4 = dict(pre); im = dict(pre["imu"]); sd = np.array(im["sum_dt"], dtype=float).copy(); sd[4] = 11.0; im["sum_dt"] = sd; w4["imu"] = im
+    st4 = tcv.Window(w4).plan_stats()
+    assert st4["nt"] == 5 and st4["n_iunit"] == 11
+    # constant extrinsic: 66 pose dims, still 11 chain steps
+    st5 = tcv.Window(main, estimate_extrinsic=False).plan_stats()
+    assert st5["npp"] == 66 and st5["nt"] == 5 and st5["n_iunit"] == 11

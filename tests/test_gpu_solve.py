@@ -188,3 +188,27 @@ def test_chain_layout_matches_dense_layout_and_oracle(gpu):
         for v in (c, d):
             assert abs(v[0] - so.final_cost) < 1e-6 * so.final_cost
             assert rel(v[3], st["pose"]) < 1e-6 and rel(v[4], st["sb"]) < 1e-6
+
+
+def test_chain_layout_variants_vs_oracle(gpu):
+    """graph shapes around the chain layout: a broken IMU chain (sum_dt > 10 drops a factor, estimator.cpp:1726), a prior that
+    also holds the neighbouring speed-bias block (still a chain) and one that ties a distant speed-bias block in (dense fallback)."""
+    pre, main, z = golden_windows()
+    p = main["prior"]
+    n = p["n"] + 9
+    J0 = np.zeros((n, n)); J0[:p["n"], :p["n"]] = p["J0"]; J0[p["n"]:, p["n"]:] = 30.0 * np.eye(9)
+    def with_sb(i):
+        return dict(p, n=n, J0=J0, r0=np.concatenate([p["r0"], 0.01 * np.ones(9)]), sizes=list(p["sizes"]) + [9], idx=list(p["idx"]) + [p["n"]],
+                    x0=list(p["x0"]) + [np.asarray(main["speedbias"])[i].copy()], blocks=list(p["blocks"]) + [("sb", i)])
+    w_broken = dict(pre); im = dict(pre["imu"]); sd = np.array(im["sum_dt"], dtype=float).copy(); sd[4] = 11.0; im["sum_dt"] = sd; w_broken["imu"] = im
+    cases = [("broken chain", w_broken, 80), ("prior on sb0+sb1", dict(main, prior=with_sb(1)), 80), ("prior on sb0+sb5", dict(main, prior=with_sb(5)), 160)]
+    for name, w, lds_kib in cases:
+        W = gpu.Window(w)
+        b = gpu.Batch([W])
+        assert b.plan_stats()["lds_bytes"] == lds_kib * 1024, name
+        b.solve(gpu.default_options(8, True)); b.synchronize(); b.download_states()
+        s = b.summaries()[0]
+        O = orc.Window(w); so = O.solve(8, True); st = O.states()
+        assert abs(s.final_cost - so.final_cost) < 1e-6 * so.final_cost, name
+        assert [s.dogleg_case[i] for i in range(9)] == [so.dogleg_case[i] for i in range(9)], name
+        assert rel(W.pose, st["pose"]) < 1e-6 and rel(W.sb, st["sb"]) < 1e-6, name
