@@ -359,15 +359,19 @@ class Replay:
         win = dict(pose=pose, speedbias=sb, ex_pose=ex, lam=lam, imu=imu, proj=proj, line=line, G=G.copy(), prior=self.prior)
         return win, sel
 
-    def optimize(self):
-        """solveOdometry (:1476-1490) + double2vector + the marginalisation of OptimizationWithLine."""
+    def prepare_window(self):
+        """solveOdometry (:1476-1490) up to the solver call: association, triangulation, vector2double + graph."""
         if self.map_lines is not None:
             self.associate_lines()
         self.triangulate()
-        win, sel = self.build_window()
-        out = self.backend.optimize(win, self.marg_flag, self.num_iterations, self.fixed_iterations)
+        self._win, self._sel = self.build_window()
+        return self._win
+
+    def apply_result(self, out):
+        """double2vector (:1565-1581; the gauge fix itself runs in the back end), setDepth, the new prior."""
+        win, sel = self._win, self._sel
         W = WINDOW_SIZE
-        for i in range(W + 1):       # double2vector (:1565-1581) -- the gauge fix itself runs in the back end
+        for i in range(W + 1):
             self.Ps[i] = out["pose"][i, :3]; self.Rs[i] = q2R(out["pose"][i, 3:])
             self.Vs[i] = out["sb"][i, :3]; self.Bas[i] = out["sb"][i, 3:6]; self.Bgs[i] = out["sb"][i, 6:]
         self.tic = out["ex"][:3].copy(); self.ric = q2R(out["ex"][3:])
@@ -378,6 +382,11 @@ class Replay:
             self.prior = out["prior"]
         self.log.append(dict(flag=self.marg_flag, n_landmarks=len(sel), n_proj=len(win["proj"]["frame_i"]), n_line=len(win["line"]["frame"]), n_line_obs=sum(len(lf["obs"]) for lf in self.linefeatures),
                              iterations=out.get("iterations"), final_cost=out.get("final_cost"), prior_n=None if self.prior is None else self.prior["n"]))
+
+    def optimize(self):
+        """solveOdometry + double2vector + the marginalisation of OptimizationWithLine, one window."""
+        win = self.prepare_window()
+        self.apply_result(self.backend.optimize(win, self.marg_flag, self.num_iterations, self.fixed_iterations))
 
     def failure_detection(self) -> bool:
         W = WINDOW_SIZE
@@ -457,9 +466,9 @@ class Replay:
         self.features = [f for f in self.features if f.solve_flag != 2]          # removeFailures (:399-408)
 
     # ---- one frame ---------------------------------------------------------------------------------------------------
-    def process_frame(self, imu, pts, lines, truth=None):
-        """processIMU for the interval + processImagewithLine.  While the window fills (solver_flag == INITIAL) the states come
-        from `truth` = (P, R, V): initialisation is out of scope."""
+    def begin_frame(self, imu, pts, lines, truth=None) -> bool:
+        """processIMU for the interval + the first half of processImagewithLine; True if the window is full and must be optimised.
+        While the window fills (solver_flag == INITIAL) the states come from `truth` = (P, R, V): initialisation is out of scope."""
         W = WINDOW_SIZE
         if imu is not None:
             self.process_imu(*imu)
@@ -471,14 +480,24 @@ class Replay:
             j = self.frame_count
             self.Bas[j] = self.Bas[j - 1]; self.Bgs[j] = self.Bgs[j - 1]
             self.Ps[j] = self.Ps[j - 1]; self.Rs[j] = self.Rs[j - 1]; self.Vs[j] = self.Vs[j - 1]
-            return None
-        self.optimize()
+            return False
+        return True
+
+    def finish_frame(self):
+        """failureDetection, the published state (pubOdometry) and slideWindow, after the optimisation."""
+        W = WINDOW_SIZE
         if self.failure_detection():
             raise RuntimeError("failure detection (estimator.cpp:1629-1675): the replay diverged")
         res = (self.Ps[W].copy(), R2q(self.Rs[W]), self.Vs[W].copy())
         self.slide_window()
         self.last_P, self.last_R = self.Ps[W].copy(), self.Rs[W].copy()
         return res
+
+    def process_frame(self, imu, pts, lines, truth=None):
+        if not self.begin_frame(imu, pts, lines, truth):
+            return None
+        self.optimize()
+        return self.finish_frame()
 
 
 def run(stream: dict, backend, num_iterations: int = 8, fixed_iterations: bool = False, init_sigma=(0.02, 0.005, 0.05), bias_sigma=(0.005, 0.0005)):
@@ -503,6 +522,50 @@ def run(stream: dict, backend, num_iterations: int = 8, fixed_iterations: bool =
         if r is not None:
             out_t.append(stream["t"][k]); out_p.append(r[0]); out_q.append(r[1]); out_v.append(r[2])
     return dict(t=np.array(out_t), p=np.array(out_p), q=np.array(out_q), v=np.array(out_v), log=rp.log)
+
+
+def run_many(streams, backend, num_iterations: int = 8, fixed_iterations: bool = False, init_sigma=(0.02, 0.005, 0.05), bias_sigma=(0.005, 0.0005)):
+    """several independent sequences in lock step (BASELINE configs[4] in spirit: per-sequence replay, sequences sharded over the
+    GPUs, many per GPU): every frame the full windows of ALL sequences go to the back end as ONE batch (`optimize_many`), and the
+    IMU buffers of all sequences are pre-integrated in one call.  Identical per-sequence results to `run` (the kernels do not
+    couple windows).  Returns one result dict per stream."""
+    S = len(streams)
+    reps, rngs, outs = [], [], []
+    for st in streams:
+        rng = np.random.Generator(np.random.PCG64(0xABCD))
+        rp = Replay(backend, num_iterations, fixed_iterations)
+        if "map_lines" in st:
+            rp.map_lines, rp.Rbw, rp.Tbw = st["map_lines"], st["Rbw"], st["Tbw"]
+            backend.set_map(st["map_lines"], st["Rbw"], st["Tbw"])
+        rp.Bas[:] = st["ba"] + rng.normal(size=3) * bias_sigma[0]; rp.Bgs[:] = st["bg"] + rng.normal(size=3) * bias_sigma[1]
+        reps.append(rp); rngs.append(rng); outs.append(dict(t=[], p=[], q=[], v=[]))
+    for k in range(max(len(st["t"]) for st in streams)):
+        ready = []
+        for si, (st, rp, rng) in enumerate(zip(streams, reps, rngs)):
+            if k >= len(st["t"]):
+                continue
+            truth = None
+            if k <= WINDOW_SIZE:
+                dth = rng.normal(size=3) * init_sigma[1]
+                truth = (st["gt_p"][k] + rng.normal(size=3) * init_sigma[0], st["gt_R"][k] @ deltaQ_R(dth), st["gt_v"][k] + rng.normal(size=3) * init_sigma[2])
+            if rp.begin_frame(st["imu"][k], st["points"][k], st["lines"][k], truth):
+                ready.append(si)
+        if not ready:
+            continue
+        # one pre-integration call for every stale IMU buffer of every sequence
+        need = [(si, j) for si in ready for j in range(1, WINDOW_SIZE + 1) if reps[si].pre[j] is None]
+        if need:
+            res = backend.preintegrate([reps[si].bufs[j] for si, j in need])
+            for (si, j), r in zip(need, res):
+                reps[si].pre[j] = r
+        wins = [reps[si].prepare_window() for si in ready]
+        results = backend.optimize_many(wins, [reps[si].marg_flag for si in ready], num_iterations, fixed_iterations)
+        for si, out in zip(ready, results):
+            reps[si].apply_result(out)
+            r = reps[si].finish_frame()
+            o = outs[si]
+            o["t"].append(streams[si]["t"][k]); o["p"].append(r[0]); o["q"].append(r[1]); o["v"].append(r[2])
+    return [dict(t=np.array(o["t"]), p=np.array(o["p"]), q=np.array(o["q"]), v=np.array(o["v"]), log=rp.log) for o, rp in zip(outs, reps)]
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -544,31 +607,50 @@ class HipBackend:
                                     0.1745, 0.45, in_fov=fov)            # angle_th / overlap_th: sensor.yaml:119-122
 
     def optimize(self, win, marg_flag, num_iterations, fixed_iterations):
+        return self.optimize_many([win], [marg_flag], num_iterations, fixed_iterations)[0]
+
+    def optimize_many(self, wins, marg_flags, num_iterations, fixed_iterations):
+        """all windows in device-resident batches: solve -> gauge fix -> marginalisation, results and priors back to the host.
+        Windows that marginalise (MARGIN_OLD, or MARGIN_SECOND_NEW with para_Pose[WINDOW_SIZE-1] in the prior) and windows that
+        only solve go to separate batches (a batch either carries marginalisation problems for all its windows or for none)."""
         tcv = self.tcv
-        W = tcv.Window(win)
-        Wn = win["pose"].shape[0] - 1
-        prior_blocks = [tuple(b) for b in win["prior"]["blocks"]] if win.get("prior") is not None else []
-        do_marg = marg_flag == MARGIN_OLD or ("pose", Wn - 1) in prior_blocks
-        if do_marg:
-            if marg_flag == MARGIN_OLD:
-                mw = tcv.margin_old_window(win); M = tcv.Window(mw, share=W, prior=W.prior); drops = tcv.margin_old_drops(W, mw)
+        n = len(wins)
+        Ws = [tcv.Window(w) for w in wins]
+        Wn = wins[0]["pose"].shape[0] - 1
+        do_marg = []
+        for w, flag in zip(wins, marg_flags):
+            pb = [tuple(b) for b in w["prior"]["blocks"]] if w.get("prior") is not None else []
+            do_marg.append(flag == MARGIN_OLD or ("pose", Wn - 1) in pb)
+        outs = [None] * n
+        for group in (True, False):
+            idx = [i for i in range(n) if do_marg[i] == group]
+            if not idx:
+                continue
+            if group:
+                Ms, drops = [], []
+                for i in idx:
+                    if marg_flags[i] == MARGIN_OLD:
+                        mw = tcv.margin_old_window(wins[i]); Ms.append(tcv.Window(mw, share=Ws[i], prior=Ws[i].prior)); drops.append(tcv.margin_old_drops(Ws[i], mw))
+                    else:
+                        mw = tcv.margin_second_new_window(wins[i]); Ms.append(tcv.Window(mw, share=Ws[i], prior=Ws[i].prior)); drops.append(tcv.margin_second_new_drops(Ws[i]))
+                b = tcv.Batch([Ws[i] for i in idx], Ms, drops)
             else:
-                mw = tcv.margin_second_new_window(win); M = tcv.Window(mw, share=W, prior=W.prior); drops = tcv.margin_second_new_drops(W)
-            b = tcv.Batch([W], [M], [drops])
-        else:
-            b = tcv.Batch([W])
-        b.solve(tcv.default_options(num_iterations, fixed_iterations))
-        b.gauge_fix()
-        if do_marg:
-            b.marginalize()
-        b.synchronize(); b.download_states()
-        s = b.summaries()[0]
-        out = dict(pose=W.pose.copy(), sb=W.sb.copy(), ex=W.ex.copy(), lam=W.lam.copy(), iterations=s.num_iterations, final_cost=s.final_cost, prior="keep")
-        if do_marg:
-            P = b.prior(0)
-            d = P.export()
-            shift = (lambda nm, i: (nm, i - 1) if nm in ("pose", "sb") else (nm, i)) if marg_flag == MARGIN_OLD else \
-                    (lambda nm, i: (nm, i - 1) if (nm in ("pose", "sb") and i == Wn) else (nm, i))
-            d["blocks"] = tcv.prior_blocks(P, W, shift)
-            out["prior"] = d
-        return out
+                b = tcv.Batch([Ws[i] for i in idx])
+            b.solve(tcv.default_options(num_iterations, fixed_iterations))
+            b.gauge_fix()
+            if group:
+                b.marginalize()
+            b.synchronize(); b.download_states()
+            s = b.summaries()
+            for k, i in enumerate(idx):
+                W = Ws[i]
+                out = dict(pose=W.pose.copy(), sb=W.sb.copy(), ex=W.ex.copy(), lam=W.lam.copy(), iterations=s[k].num_iterations, final_cost=s[k].final_cost, prior="keep")
+                if group:
+                    P = b.prior(k)
+                    d = P.export()
+                    shift = (lambda nm, j: (nm, j - 1) if nm in ("pose", "sb") else (nm, j)) if marg_flags[i] == MARGIN_OLD else \
+                            (lambda nm, j: (nm, j - 1) if (nm in ("pose", "sb") and j == Wn) else (nm, j))
+                    d["blocks"] = tcv.prior_blocks(P, W, shift)
+                    out["prior"] = d
+                outs[i] = out
+        return outs

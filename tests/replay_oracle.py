@@ -33,6 +33,9 @@ class OracleBackend:
             match[q], err[q], proj[q] = c, e, pv
         return np.asarray(fov, dtype=bool), match, err, proj
 
+    def optimize_many(self, wins, marg_flags, num_iterations, fixed_iterations):
+        return [self.optimize(w, f, num_iterations, fixed_iterations) for w, f in zip(wins, marg_flags)]
+
     def optimize(self, win, marg_flag, num_iterations, fixed_iterations):
         O = orc.Window(win)
         s = O.solve(num_iterations, fixed_iterations)

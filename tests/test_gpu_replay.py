@@ -50,3 +50,17 @@ def test_replay_with_a_dense_front_end(gpu):
     d = np.linalg.norm(hip["p"] - ref["p"], axis=1)
     print("max |p_hip - p_oracle| per frame [m]:", np.array2string(d, precision=2), "landmarks", [l["n_landmarks"] for l in hip["log"]][:6])
     assert d.max() < 1e-3
+
+
+def test_lock_step_multi_sequence_replay_on_the_gpu(gpu):
+    """BASELINE configs[4] in spirit: several sequences replayed in lock step, every frame ONE device batch holding the windows of
+    all sequences (heterogeneous graph structures: one plan per distinct structure, both marginalisation modes mixed).  Bit-identical
+    to replaying each sequence alone (no coupling between the windows of a batch) and within 1 mm of the oracle replay."""
+    streams = [replay.simulate_stream(20 + k, 24, max_features=28) for k in range(4)]
+    many = replay.run_many(streams, replay.HipBackend(), num_iterations=8)
+    for k, (st, m) in enumerate(zip(streams, many)):
+        one = replay.run(st, replay.HipBackend(), num_iterations=8)
+        assert np.array_equal(one["p"], m["p"]) and np.array_equal(one["q"], m["q"])
+        if k == 0:
+            ref = replay.run(st, OracleBackend(), num_iterations=8)
+            assert np.linalg.norm(m["p"] - ref["p"], axis=1).max() < 1e-3

@@ -69,3 +69,12 @@ def test_replay_with_line_association_in_the_loop():
     assert any(l["n_line"] < l["n_line_obs"] for l in out["log"])          # some observations fail the angle / overlap / distance gates
     i, j = ate.associate(out["t"], stream["t"])
     assert ate.ate_rmse(out["p"][i], stream["gt_p"][j]) < 0.10
+
+
+def test_lock_step_multi_sequence_replay_equals_individual_replays():
+    """run_many (all sequences' windows as one batch per frame, one pre-integration call) vs run per sequence: same results."""
+    streams = [replay.simulate_stream(10 + k, 22, max_features=24) for k in range(3)]
+    many = replay.run_many(streams, OracleBackend(), num_iterations=4)
+    for st, m in zip(streams, many):
+        one = replay.run(st, OracleBackend(), num_iterations=4)
+        assert np.array_equal(one["p"], m["p"]) and np.array_equal(one["q"], m["q"]) and [l["flag"] for l in one["log"]] == [l["flag"] for l in m["log"]]
