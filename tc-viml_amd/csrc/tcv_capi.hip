@@ -351,7 +351,7 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
         if (mode == 0 && !pk.hdr.chain) {      // a same-shaped window turned out not to be chain-eligible: start over with the dense layout
             mode = 1; b->chain = false; w = -1;
             b->plans.clear(); b->plan_base.clear(); b->wins.clear(); plan_index.clear(); ipool.clear(); dpool.clear();
-            max_state = max_nl = 0; max_lds = 0; b->input_bytes = 0; b->spill_stride = 0;
+            max_state = max_nl = 0; max_lds = 0; b->input_bytes = 0; b->spill_stride = 0; b->hcl_cap = 0;
             continue;
         }
         std::vector<int> key(pk.ints);
@@ -377,6 +377,7 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
                                     : (size_t)(nt * (nt + 1) / 2 * 256 + 2 * ((pk.hdr.nx + pk.hdr.nland + 1) & ~1) + 4 * 176 + 64 + pk.hdr.lds_area) * 8;
         max_lds = std::max(max_lds, lds);
         b->spill_stride = std::max(b->spill_stride, pk.hdr.c_spill);
+        b->hcl_cap = std::max(b->hcl_cap, (pk.hdr.hcl_total + 63) & ~63);
         pk.ints.clear(); pk.ints.shrink_to_fit();
         b->input_bytes += 8.0 * pk.doubles.size();
         pk.doubles.clear(); pk.doubles.shrink_to_fit();
@@ -392,7 +393,7 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
     hipGetDeviceProperties(&prop, dev);
     b->grid = std::min(n, (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256) * (b->chain ? 2 : 1));
     if (const char *eg = getenv("TCV_GRID")) { const int g = atoi(eg); if (g > 0) b->grid = std::min(n, g); }      // tuning experiments
-    const int scr = tcv_solve_scratch_doubles();
+    const int scr = tcv_solve_scratch_doubles() + b->hcl_cap;
 #define UP(dst, src, T, cnt)                                                                          \
     do {                                                                                              \
         hipError_t e_ = hipMalloc((void **)&dst, sizeof(T) * std::max<size_t>(1, (cnt)));             \
@@ -452,7 +453,7 @@ extern "C" int tcv_batch_solve(tcv_batch *b, const tcv_solver_options *o, void *
     a.state_out = b->d_state; a.summary = b->d_summary; a.first_delta = o->record_first_step ? b->d_delta : nullptr;
     a.scratch = b->d_scratch;
     a.prof = b->d_prof;
-    a.nwin = b->n; a.state_stride = b->state_stride; a.delta_stride = b->delta_stride; a.scratch_stride = tcv_solve_scratch_doubles();
+    a.nwin = b->n; a.state_stride = b->state_stride; a.delta_stride = b->delta_stride; a.scratch_stride = tcv_solve_scratch_doubles() + b->hcl_cap;
     a.max_iterations = o->max_num_iterations; a.fixed_iterations = o->fixed_iterations; a.use_mfma = o->use_mfma;
     a.chain = b->chain ? 1 : 0; a.imublk = b->d_imublk; a.spill = b->d_spill; a.spill_stride = b->spill_stride;
     hipStream_t st = (hipStream_t)hip_stream;

@@ -87,6 +87,7 @@ struct tcv_batch {
     bool chain = false;                   // all plans use the chain layout (2 workgroups per CU)
     double *d_imublk = nullptr, *d_spill = nullptr;   // chain mode: per-workgroup IMU J'J blocks and factored fronts
     int spill_stride = 0;
+    int hcl_cap = 0;                      // doubles of the landmark/camera coupling store per workgroup (largest window of the batch)
     // marginalisation
     void *marg = nullptr;                 // tcv_marg.hip state
     void (*marg_free)(tcv_batch *) = nullptr;

@@ -262,11 +262,11 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int 
             }
         }
         if (lm_slots[l].size() > 40) { set_error("landmark observed from more than 40 blocks"); return TCV_ERR_TOO_LARGE; }
-        if (e_off[l] >= (1 << 13)) { set_error("landmark coupling store too large"); return TCV_ERR_TOO_LARGE; }
+        if (e_off[l] >= (1 << 16) - 256) { set_error("landmark coupling store too large"); return TCV_ERR_TOO_LARGE; }
         e_off[l + 1] = e_off[l] + 6 * (int)lm_slots[l].size() + 2;   // + 1/kappa and gl/kappa behind the slice
     }
     H.hcl_total = e_off[L];
-    if (H.hcl_total > 8192) { set_error("landmark coupling store too large"); return TCV_ERR_TOO_LARGE; }
+    if (H.hcl_total > (1 << 16) - 256) { set_error("landmark coupling store too large"); return TCV_ERR_TOO_LARGE; }
     H.o_proj = mark();
     for (size_t k = 0; k < order.size(); k++) {
         const ProjFac &f = p.proj[order[k]];

@@ -73,9 +73,9 @@ struct Ctx {
     int tid;
 };
 
-enum { SCR_HCL = 8192, SCR_HP = 8256, SCR_SQ = 16 * 225, SCR_LM = 1024 };
+enum { SCR_HP = 8256, SCR_SQ = 16 * 225, SCR_LM = 1024 };      // the landmark/camera coupling store comes last: its size is per batch
 enum {
-    SCR_TOTAL = 8 * SCR_NL + 3 * SCR_LM + SCR_HCL + SCR_HP + 2 * 128 + SCR_SQ
+    SCR_TOTAL = 8 * SCR_NL + 3 * SCR_LM + SCR_HP + 2 * 128 + SCR_SQ      // + hcl capacity (tcv_batch_create)
 };
 
 template <int NT>
@@ -1426,8 +1426,9 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CHAIN ?
     C.v_s = scr; C.v_g = scr + SCR_NL; C.v_D = scr + 2 * SCR_NL; C.v_ghat = scr + 3 * SCR_NL; C.v_y = scr + 4 * SCR_NL;
     C.v_p = scr + 5 * SCR_NL; C.v_rc = scr + 6 * SCR_NL; C.v_sd = scr + 7 * SCR_NL;
     C.l_hll = scr + 8 * SCR_NL; C.l_gl = C.l_hll + SCR_LM; C.l_invk = C.l_gl + SCR_LM;
-    C.g_hcl = C.l_invk + SCR_LM; C.g_hp = C.g_hcl + SCR_HCL; C.g_pr = C.g_hp + SCR_HP; C.g_pdx = C.g_pr + 128;
+    C.g_hp = C.l_invk + SCR_LM; C.g_pr = C.g_hp + SCR_HP; C.g_pdx = C.g_pr + 128;
     C.g_sqrt = C.g_pdx + 128;
+    C.g_hcl = C.g_sqrt + SCR_SQ;
     C.prof = A.prof ? (gbl_d *)A.prof + (size_t)blockIdx.x * 32 : nullptr;
     C.t_last = 0;
 #ifdef TCV_PROFILE
