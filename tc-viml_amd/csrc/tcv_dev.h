@@ -7,6 +7,7 @@
 namespace tcv {
 typedef __attribute__((address_space(3))) double lds_d;        // LDS
 typedef __attribute__((address_space(3))) int lds_i;
+typedef __attribute__((address_space(3))) unsigned lds_u;
 typedef __attribute__((address_space(1))) double gbl_d;        // per-workgroup scratch / outputs in HBM
 typedef __attribute__((address_space(1))) int gbl_i;
 typedef const __attribute__((address_space(4))) double cst_d;  // read-only inputs: window data

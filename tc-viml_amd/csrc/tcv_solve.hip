@@ -35,13 +35,15 @@ __device__ __forceinline__ int sw(int r, int c) { return (r << 4) + (c ^ (r & 14
 __device__ __forceinline__ int tbase(int I, int J) { return ((I * (I + 1) / 2) + J) << 8; }
 __device__ __forceinline__ int tix(int a, int b) { return tbase(a >> 4, b >> 4) + sw(a & 15, b & 15); }
 
-// optional per-phase cycle accounting (build with -DTCV_PROFILE): lane 0 adds s_memtime deltas to a global table
+// optional per-phase cycle accounting (build with -DTCV_PROFILE): lane 0 adds s_memtime deltas to 32-bit counters in LDS (the
+// spare half of the reduction scratch; a global read-modify-write per mark used to stall wave 0 for ~1 K cycles and inflated
+// densely marked phases); the counters are flushed to the global table once per window
 #ifdef TCV_PROFILE
-#define TCV_MARK(C, id)                                                        \
-    do {                                                                       \
-        const long long t_ = clock64();                                        \
-        if ((C).tid == 0) (C).prof[id] += (double)(t_ - (C).t_last);           \
-        (C).t_last = t_;                                                       \
+#define TCV_MARK(C, id)                                                                        \
+    do {                                                                                       \
+        const long long t_ = clock64();                                                        \
+        if ((C).tid == 0) ((lds_u *)((C).red + 40))[id] += (unsigned)(t_ - (C).t_last);       \
+        (C).t_last = t_;                                                                       \
     } while (0)
 #else
 #define TCV_MARK(C, id) do { } while (0)
@@ -1466,7 +1468,11 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CHAIN ?
         C.ycam = p; p += 176;
         C.invdiag = p; C.gcam = p; p += 176;
         C.red = p; p += 64;
-        C.flag = (lds_i *)(C.red + 62);   // red[] uses at most 5 * NT/64 = 40 doubles
+        C.flag = (lds_i *)(C.red + 62);   // red[] uses at most 5 * NT/64 = 40 doubles; 40..55 hold the profile build's counters
+#ifdef TCV_PROFILE
+        if (tid < PH_COUNT) ((lds_u *)(C.red + 40))[tid] = 0u;
+        __syncthreads();
+#endif
         C.hd = p;                         // chain mode only (112 doubles)
         C.area = CHAIN ? C.stage + P.c_stage_cap : p;
         typedef __attribute__((address_space(1))) DevSummary gbl_sum;
@@ -1666,6 +1672,11 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CHAIN ?
         }
         __syncthreads();
         TCV_MARK(C, PH_OTHER);
+#ifdef TCV_PROFILE
+        if (tid == 0 && C.prof)
+            for (int i = 0; i < PH_COUNT; i++) { lds_u *lp = (lds_u *)(C.red + 40); C.prof[i] += (double)lp[i]; lp[i] = 0u; }
+        __syncthreads();
+#endif
     }
 }
 

@@ -28,7 +28,9 @@ def test_replay_hip_vs_oracle_ate(gpu):
 
 def test_replay_with_line_association_hip_vs_oracle(gpu):
     """the same with the 2D-3D association in the loop (tcv_match_lines vs the NumPy restatement): identical association
-    decisions frame by frame, trajectories within 1 mm."""
+    decisions frame by frame, trajectories within 1 mm.  (The association is a cascade of threshold tests on the current pose
+    estimate: a different summation order in the solver can flip a borderline match many frames later, after which two replays
+    legitimately diverge -- the reference has the same property.  On this stream no decision is borderline.)"""
     stream = replay.simulate_stream(1, 30, max_features=30, associate=True)
     hip = replay.run(stream, replay.HipBackend(), num_iterations=8)
     ref = replay.run(stream, OracleBackend(), num_iterations=8)
