@@ -189,3 +189,23 @@ def test_chain_layout_eligibility_is_decided_on_the_host(tcv):
     # constant extrinsic: 66 pose dims, still 11 chain steps
     st5 = tcv.Window(main, estimate_extrinsic=False).plan_stats()
     assert st5["npp"] == 66 and st5["nt"] == 5 and st5["n_iunit"] == 11
+
+
+def test_header_is_valid_c99_and_cxx_and_the_example_links(tcv, tmp_path):
+    """include/tcv.h is the drop-in boundary: it must compile as plain C and as C++, and a C++ caller (examples/estimator_shim.cpp,
+    the call sequence of a retargeted estimator.cpp) must link against libtcv_hip.so and fail loudly without a device."""
+    import subprocess
+    c = os.path.join(tmp_path, "t.c")
+    open(c, "w").write('#include "tcv.h"\nint main(void){ tcv_solver_options o; tcv_solver_options_default(&o); return (int)sizeof(tcv_solver_summary) > 0 ? 0 : 1; }\n')
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + inc, "-fsyntax-only", c])
+    subprocess.check_call(["g++", "-std=c++14", "-Wall", "-Werror", "-I" + inc, "-x", "c++", "-fsyntax-only", c])
+    exe = os.path.join(tmp_path, "shim")
+    libdir = os.path.dirname(tcv.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++14", "-Wall", "-I" + inc, os.path.join(ROOT, "examples", "estimator_shim.cpp"), "-L" + libdir, "-ltcv_hip",
+                           "-Wl,-rpath," + libdir, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "6 parameter blocks, 2 residual blocks, 17 residuals" in out.stdout
+    if tcv.lib().tcv_device_count() == 0:
+        assert "no HIP device visible" in out.stdout          # the compute entry points refuse to run instead of falling back
