@@ -209,3 +209,9 @@ def test_header_is_valid_c99_and_cxx_and_the_example_links(tcv, tmp_path):
     assert "6 parameter blocks, 2 residual blocks, 17 residuals" in out.stdout
     if tcv.lib().tcv_device_count() == 0:
         assert "no HIP device visible" in out.stdout          # the compute entry points refuse to run instead of falling back
+    # the Ceres-shaped class veneer (include/tcv_ceres_shim.hpp) and its example
+    exe2 = os.path.join(tmp_path, "shim2")
+    subprocess.check_call(["g++", "-std=c++14", "-Wall", "-Werror", "-I" + inc, os.path.join(ROOT, "examples", "estimator_shim_classes.cpp"), "-L" + libdir,
+                           "-ltcv_hip", "-Wl,-rpath," + libdir, "-o", exe2])
+    out2 = subprocess.run([exe2], capture_output=True, text=True, timeout=120)
+    assert out2.returncode == 0, out2.stdout + out2.stderr

@@ -212,3 +212,23 @@ def test_chain_layout_variants_vs_oracle(gpu):
         assert abs(s.final_cost - so.final_cost) < 1e-6 * so.final_cost, name
         assert [s.dogleg_case[i] for i in range(9)] == [so.dogleg_case[i] for i in range(9)], name
         assert rel(W.pose, st["pose"]) < 1e-6 and rel(W.sb, st["sb"]) < 1e-6, name
+
+
+def test_cxx_examples_run_on_the_device(gpu, tmp_path):
+    """examples/estimator_shim.cpp (plain C-ABI) and estimator_shim_classes.cpp (include/tcv_ceres_shim.hpp, the Ceres-shaped classes
+    estimator.cpp uses) solve the same toy window: same iterations, cost and inverse depth; the class veneer chains the prior."""
+    import os, re, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.dirname(gpu.LIB_PATH)
+    outs = []
+    for src in ("estimator_shim.cpp", "estimator_shim_classes.cpp"):
+        exe = os.path.join(tmp_path, src[:-4])
+        subprocess.check_call(["g++", "-std=c++14", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", src), "-L" + libdir, "-ltcv_hip",
+                               "-Wl,-rpath," + libdir, "-o", exe])
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(r.stdout)
+    a = re.search(r"solve: (\d+) iterations, cost (\S+) -> (\S+), inverse depth (\S+)", outs[0]).groups()
+    b = re.search(r"solve: (\d+) iterations, cost (\S+) -> (\S+), inverse depth (\S+)", outs[1]).groups()
+    assert a == b and float(a[2]) < 1e-12 * float(a[1]) and abs(float(a[3]) - 0.1) < 1e-3
+    assert "prior: m = 16" in outs[0] and "prior: m = 16" in outs[1] and "first -> para_Pose[0]: yes" in outs[1]
