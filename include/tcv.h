@@ -56,7 +56,9 @@ typedef struct {
 /* ceres::Solver::Options fields the reference sets (estimator.cpp:1888-1897) + determinism switch. */
 typedef struct {
     int max_num_iterations;            /* NUM_ITERATIONS                                             */
-    double max_solver_time_in_seconds; /* <= 0: ignore wall clock (deterministic)                    */
+    double max_solver_time_in_seconds; /* <= 0 or fixed_iterations: ignore the clock (deterministic); else
+                                          checked at the start of every iteration like Ceres, on the device
+                                          clock, per window */
     int fixed_iterations;              /* 1: run exactly max_num_iterations, convergence tests off   */
     int compute_sqrt_info_on_device;   /* 1 (default): imu_factor.h:64 evaluated in the kernel        */
     int use_mfma;                      /* 1 (default): trailing Cholesky update on v_mfma_f64_16x16x4_f64; 0: FP64 VALU (debug) */

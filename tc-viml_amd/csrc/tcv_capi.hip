@@ -456,6 +456,14 @@ extern "C" int tcv_batch_solve(tcv_batch *b, const tcv_solver_options *o, void *
     a.nwin = b->n; a.state_stride = b->state_stride; a.delta_stride = b->delta_stride; a.scratch_stride = tcv_solve_scratch_doubles() + b->hcl_cap;
     a.max_iterations = o->max_num_iterations; a.fixed_iterations = o->fixed_iterations; a.use_mfma = o->use_mfma;
     a.chain = b->chain ? 1 : 0; a.imublk = b->d_imublk; a.spill = b->d_spill; a.spill_stride = b->spill_stride;
+    a.max_ticks = 0;
+    if (o->max_solver_time_in_seconds > 0.0 && !o->fixed_iterations) {
+        int dev = 0, khz = 0;
+        hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;      // 100 MHz on CDNA
+        a.max_ticks = (long long)(o->max_solver_time_in_seconds * 1e3 * (double)khz);
+        if (a.max_ticks < 1) a.max_ticks = 1;
+    }
     hipStream_t st = (hipStream_t)hip_stream;
     HIPCHK(hipEventRecord(b->ev0, st));
     const int rc = tcv_launch_solve(&a, b->grid, (!b->chain && o->threads_per_window == 512) ? 512 : 256, b->lds_bytes, hip_stream);

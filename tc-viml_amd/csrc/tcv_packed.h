@@ -137,6 +137,7 @@ struct SolveArgs {
     double *imublk;               // chain mode, per workgroup: 16 x IMU_BLK doubles (per-factor J'J | J'r blocks, 32 x 32 row-major)
     double *spill;                // chain mode, per workgroup: factored fronts (spill_stride doubles)
     int spill_stride, pad2;
+    long long max_ticks;          // max_solver_time_in_seconds in ticks of the constant-rate device clock (wall_clock64); 0: no limit
 };
 
 // chain step record (CH_STRIDE ints per step, copied into LDS by the kernel): a header followed by two ints per front row.

@@ -1515,6 +1515,10 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CHAIN ?
         TCV_MARK(C, PH_SETUP);
 
         const int max_it = A.max_iterations < MAX_TRACE - 1 ? A.max_iterations : MAX_TRACE - 1;
+        // Solver::Options::max_solver_time_in_seconds (estimator.cpp:1892-1897): Ceres checks the wall clock at the start of every
+        // iteration and stops with NO_CONVERGENCE; here the budget runs on the device's constant-rate clock from the moment the
+        // workgroup picks the window up.  Like in the reference this makes the iteration count timing dependent; 0 = no limit.
+        const long long t_window = (A.max_ticks > 0) ? (long long)wall_clock64() : 0;
         const bool fixed = A.fixed_iterations != 0;
         double radius = 1e4, mu = 1e-8, lin_mu = 1e-8;
         bool reuse = false, tiles_valid = true;
@@ -1535,6 +1539,14 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CHAIN ?
         int it = 0;
         while (!done) {
             if (it >= max_it) break;
+            if (A.max_ticks > 0) {      // uniform decision: lane 0 of wave 0 reads the clock, everybody follows
+                if (tid == 0) *C.flag = ((long long)wall_clock64() - t_window > A.max_ticks) ? 7 : 0;
+                __syncthreads();
+                const int over = *C.flag;
+                __syncthreads();
+                if (tid == 0) *C.flag = 0;
+                if (over) break;
+            }
             it++;
             bool ls_ok = true;
             if (!reuse) {

@@ -232,3 +232,22 @@ def test_cxx_examples_run_on_the_device(gpu, tmp_path):
     b = re.search(r"solve: (\d+) iterations, cost (\S+) -> (\S+), inverse depth (\S+)", outs[1]).groups()
     assert a == b and float(a[2]) < 1e-12 * float(a[1]) and abs(float(a[3]) - 0.1) < 1e-3
     assert "prior: m = 16" in outs[0] and "prior: m = 16" in outs[1] and "first -> para_Pose[0]: yes" in outs[1]
+
+
+def test_max_solver_time_stops_the_iteration_loop(gpu):
+    """Solver::Options::max_solver_time_in_seconds (estimator.cpp:1892-1897): checked at the start of every iteration; a budget far
+    below one iteration leaves only the initial evaluation, a generous one changes nothing."""
+    pre, main, z = golden_windows()
+    def run(budget, iters=50):
+        W = gpu.Window(main); b = gpu.Batch([W])
+        o = gpu.default_options(iters, False); o.max_solver_time_in_seconds = budget
+        b.solve(o); b.synchronize()
+        s = b.summaries()[0]
+        return s.num_iterations, s.termination, s.final_cost
+    n_free, t_free, c_free = run(0.0)
+    n_big, t_big, c_big = run(10.0)
+    assert (n_big, t_big, c_big) == (n_free, t_free, c_free) and n_free > 5
+    n0, t0, c0 = run(1e-7)
+    assert n0 == 1 and t0 == 0                       # iteration 0 only (summary.iterations.size() == 1), NO_CONVERGENCE
+    n1, t1, c1 = run(0.0008)                         # ~0.3 ms per iteration for a lone window: a few iterations fit
+    assert 1 < n1 < n_free and c0 > c1 > c_free * (1 - 1e-12)
