@@ -594,12 +594,12 @@ __global__ void __launch_bounds__(MARG_NT) marg_kernel(MargArgs Aarg) {
             cst_i *b = ip + H.o_imu + f * 4;
             lds_d *S = stage + 1500;
             if (tid < 16) (void)imu_sqrt_info_group((const double *)(dp + H.d_imu + f * IMU_CONST + IMU_COV), GEN(S), GEN(stage + 512), GEN(stage + 512 + 225), tid);
-            if (tid == 64) {
+            if ((tid & 63) == 0 && tid >= 64 && tid < 64 * 5) {      // lane 0 of waves 1..4: the four parts of the raw residual / Jacobian
                 double cst[62];
 #pragma unroll
                 for (int i = 0; i < 62; i++) cst[i] = dp[H.d_imu + f * IMU_CONST + i];
-                imu_raw(CGEN(x + blk[b[0] * 5 + 1]), CGEN(x + blk[b[1] * 5 + 1]), CGEN(x + blk[b[2] * 5 + 1]), CGEN(x + blk[b[3] * 5 + 1]),
-                        cst, G3, GEN(stage + 30), IMU_STRIDE_J, GEN(stage), IMU_STRIDE_J);
+                imu_raw_part((tid >> 6) - 1, CGEN(x + blk[b[0] * 5 + 1]), CGEN(x + blk[b[1] * 5 + 1]), CGEN(x + blk[b[2] * 5 + 1]),
+                             CGEN(x + blk[b[3] * 5 + 1]), cst, G3, GEN(stage), IMU_STRIDE_J, true);
             }
             __syncthreads();
             if (tid < 31) {
