@@ -98,8 +98,20 @@ def simulate_stream(seed: int, n_frames: int, max_features: int = 36, max_lines:
         gyr = gyr + rng.normal(size=gyr.shape) * synth.GYR_N * 0.1
     imu = [None] + [(acc[(k - 1) * S:k * S + 1].copy(), gyr[(k - 1) * S:k * S + 1].copy()) for k in range(1, n_frames)]
     Rk = synth.traj_R(tau(t)); pk = synth.traj_p(tau(t)); vk = synth.traj_v(tau(t)) * dtau(t)[:, None]
-    Rwc, twc = synth._cam_pose(Rk, pk)
     ps_pool, pe_pool = synth.line_pool()
+    points, lines = _front_end(rng, Rk, pk, ps_pool, pe_pool, max_features, max_lines, pixel_sigma, associate)
+    out = dict(t=t, gt_p=pk, gt_R=Rk, gt_v=vk, imu=imu, points=points, lines=lines, ba=ba, bg=bg)
+    if associate:
+        out.update(map_lines=np.hstack([(ps_pool - synth.TBW) @ synth.RBW, (pe_pool - synth.TBW) @ synth.RBW]), Rbw=synth.RBW.copy(), Tbw=synth.TBW.copy())
+    return out
+
+
+def _front_end(rng, Rk, pk, ps_pool, pe_pool, max_features, max_lines, pixel_sigma, associate):
+    """what the feature tracker and the line tracker would deliver along the body poses (Rk, pk): per frame {id: (x, y, 1)}
+    tracked points on the normalised plane (a lost track is never re-acquired, new landmarks are spawned in front of the camera
+    when the tracker runs short) and the visible lines of the pool (world-frame end points ps_pool / pe_pool)."""
+    n_frames = len(pk)
+    Rwc, twc = synth._cam_pose(Rk, pk)
     land = []            # world points, spawned in front of the camera when the tracker runs short of features
     alive = []
     points, lines = [], []
@@ -137,9 +149,81 @@ def simulate_stream(seed: int, n_frames: int, max_features: int = 36, max_lines:
             abc = np.array([ye - ys, xs - xe, xe * ys - xs * ye])          # feature_manager.cpp:11-13
             fl.append((int(i), np.array([xs, ys, xe, ye])) if associate else (ps_pool[i].copy(), pe_pool[i].copy(), abc))
         lines.append(fl)
-    out = dict(t=t, gt_p=pk, gt_R=Rk, gt_v=vk, imu=imu, points=points, lines=lines, ba=ba, bg=bg)
+    return points, lines
+
+
+EUROC_SEQUENCES = ("V1_02_medium", "V1_03_difficult", "V2_01_easy", "V2_02_medium", "V2_03_difficult")
+
+
+def load_euroc(seq: str):
+    """the excerpt of benchmark_publisher/config/<seq>/ shipped in data/ (tests/golden/make_euroc_excerpts.py): ground-truth
+    states at 200 Hz in the EuRoC reference frame (p, q wxyz, v, bw, ba: the columns benchmark_publisher_node.cpp:42-62 parses),
+    the prior 3D line map (map frame = ground-truth frame) and initialRotation / initialTranslation (sensor.yaml:40-57), the
+    transform Rbw, Tbw from that frame into the VIO world frame."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "euroc_%s.npz" % seq))
+    st = np.cumsum(d["state_micro_delta"].astype(np.int64), axis=0) * 1e-6
+    for key, ref in (("Ric", synth.RIC), ("Tic", synth.TIC), ("K", np.array([synth.FX, synth.FY, synth.CX, synth.CY])), ("size", np.array([synth.IMG_W, synth.IMG_H])),
+                     ("imu_noise", np.array([synth.ACC_N, synth.GYR_N, synth.ACC_W, synth.GYR_W, synth.G_NORM]))):
+        if not np.array_equal(d[key], ref):
+            raise ValueError("euroc_%s: %s differs from the calibration the kernels' host side is configured with" % (seq, key))
+    return dict(seq=seq, stamp_ns=d["stamp_ns"], t=(d["stamp_ns"] - d["stamp_ns"][0]) * 1e-9, p=st[:, 0:3], q_wxyz=st[:, 3:7], v=st[:, 7:10], bw=st[:, 10:13],
+                ba=st[:, 13:16], lines3d=d["lines3d"], Rbw=d["Rbw"], Tbw=d["Tbw"])
+
+
+def _rotvec(R):
+    """rotation vectors of a stack of rotation matrices (angles well below pi)."""
+    w = np.stack([R[..., 2, 1] - R[..., 1, 2], R[..., 0, 2] - R[..., 2, 0], R[..., 1, 0] - R[..., 0, 1]], axis=-1) * 0.5
+    s = np.linalg.norm(w, axis=-1)
+    c = (np.trace(R, axis1=-2, axis2=-1) - 1.0) * 0.5
+    ang = np.arctan2(s, c)
+    return w * np.where(s > 1e-12, ang / np.where(s > 1e-12, s, 1.0), 1.0)[..., None]
+
+
+def simulate_stream_euroc(seq, n_frames: int, start_s: float = 0.0, seed: int = 0, max_features: int = 36, max_lines: int = 4,
+                          pixel_sigma: float = 1.0, imu_noise: bool = True, associate: bool = False):
+    """Per-frame streams (same dict as `simulate_stream`) of a front end carried along the EuRoC ground-truth trajectory of
+    `seq` (name or a `load_euroc` dict), starting `start_s` seconds into the excerpt: SURVEY.md 8(f) N1's "simulator producing
+    those streams from GT data.csv + line_3d.txt + sensor.yaml".  The bag (images, raw IMU) is not part of the reference, so
+      * the trajectory is the ground truth mapped into the VIO world frame, x_w = Rbw x + Tbw (gravity along -z of that frame);
+      * the 200 Hz IMU samples are what an ideal IMU on that trajectory reads -- body rates from consecutive ground-truth
+        attitudes, specific force from the central difference of the ground-truth velocity -- plus the ground truth's own
+        (slowly varying) gyroscope / accelerometer biases and white noise of the densities in sensor.yaml:90-91;
+      * points are tracked landmarks spawned in view, lines are the sequence's own prior map (891 / 908 segments) seen from the
+        ground-truth camera, with pixel noise -- `associate=True` leaves the 2D-3D association to the replay."""
+    E = load_euroc(seq) if isinstance(seq, str) else seq
+    rng = np.random.Generator(np.random.PCG64(0xE0C0 + seed))
+    S = synth.IMU_RATE_SUB
+    i0 = int(round(start_s / synth.DT_IMU)) + 1                 # one row of margin on both sides for the central differences
+    n_s = (n_frames - 1) * S + 1
+    if i0 + n_s + 1 > len(E["t"]):
+        raise ValueError("euroc excerpt too short: %d frames from %.1f s need %d rows, the excerpt holds %d" % (n_frames, start_s, i0 + n_s + 1, len(E["t"])))
+    U, _, Vt = np.linalg.svd(E["Rbw"])
+    Rbw = U @ Vt                                                 # the 6-digit matrix of the yaml, re-orthonormalised
+    sl = slice(i0 - 1, i0 + n_s + 1)
+    q = E["q_wxyz"][sl] / np.linalg.norm(E["q_wxyz"][sl], axis=1)[:, None]
+    Rg = np.array([q2R(np.array([a[1], a[2], a[3], a[0]])) for a in q])
+    Rw = Rbw @ Rg
+    pw = E["p"][sl] @ Rbw.T + E["Tbw"]
+    vw = E["v"][sl] @ Rbw.T
+    dt = synth.DT_IMU
+    w_half = _rotvec(np.swapaxes(Rw[:-1], -1, -2) @ Rw[1:]) / dt         # mean body rate over [k, k+1]
+    gyr = 0.5 * (w_half[:-1] + w_half[1:]) + E["bw"][sl][1:-1]
+    a_w = (vw[2:] - vw[:-2]) / (2.0 * dt)
+    Rw, pw, vw = Rw[1:-1], pw[1:-1], vw[1:-1]
+    acc = (np.swapaxes(Rw, -1, -2) @ (a_w + G)[..., None])[..., 0] + E["ba"][sl][1:-1]
+    if imu_noise:
+        acc = acc + rng.normal(size=acc.shape) * synth.ACC_N * 0.1
+        gyr = gyr + rng.normal(size=gyr.shape) * synth.GYR_N * 0.1
+    imu = [None] + [(acc[(k - 1) * S:k * S + 1].copy(), gyr[(k - 1) * S:k * S + 1].copy()) for k in range(1, n_frames)]
+    fr = np.arange(n_frames) * S
+    ps_pool = E["lines3d"][:, 0:3] @ E["Rbw"].T + E["Tbw"]        # estimator.cpp:1832-1833 (the yaml's matrix as it is)
+    pe_pool = E["lines3d"][:, 3:6] @ E["Rbw"].T + E["Tbw"]
+    points, lines = _front_end(rng, Rw[fr], pw[fr], ps_pool, pe_pool, max_features, max_lines, pixel_sigma, associate)
+    out = dict(t=E["t"][sl][1:-1][fr], stamp_ns=E["stamp_ns"][sl][1:-1][fr], gt_p=pw[fr], gt_R=Rw[fr], gt_v=vw[fr], imu=imu, points=points, lines=lines,
+               ba=E["ba"][sl][1 + fr[0]].copy(), bg=E["bw"][sl][1 + fr[0]].copy(), seq=E["seq"])
     if associate:
-        out.update(map_lines=np.hstack([(ps_pool - synth.TBW) @ synth.RBW, (pe_pool - synth.TBW) @ synth.RBW]), Rbw=synth.RBW.copy(), Tbw=synth.TBW.copy())
+        out.update(map_lines=E["lines3d"].copy(), Rbw=E["Rbw"].copy(), Tbw=E["Tbw"].copy())
     return out
 
 

@@ -66,3 +66,22 @@ def test_lock_step_multi_sequence_replay_on_the_gpu(gpu):
         if k == 0:
             ref = replay.run(st, OracleBackend(), num_iterations=8)
             assert np.linalg.norm(m["p"] - ref["p"], axis=1).max() < 1e-3
+
+
+@pytest.mark.parametrize("seq,associate", [("V1_02_medium", False), ("V2_03_difficult", True)])
+def test_euroc_trajectory_replay_hip_vs_oracle(gpu, seq, associate):
+    """BASELINE configs[3]: a replay along the EuRoC ground-truth trajectory (the bag itself is not part of the reference: the
+    front-end streams are simulated on the trajectory, replay.simulate_stream_euroc), HIP back end vs the CPU restatement:
+    same keyframe decisions and iteration counts, positions within 1 mm (north-star), the same ATE against the ground truth."""
+    stream = replay.simulate_stream_euroc(seq, 60, start_s=2.0, max_features=40, max_lines=6, associate=associate)
+    hip = replay.run(stream, replay.HipBackend(), num_iterations=8)
+    ref = replay.run(stream, OracleBackend(), num_iterations=8)
+    assert [l["flag"] for l in hip["log"]] == [l["flag"] for l in ref["log"]]
+    assert [l["n_line"] for l in hip["log"]] == [l["n_line"] for l in ref["log"]]
+    assert [l["iterations"] for l in hip["log"]] == [l["iterations"] for l in ref["log"]]
+    d = np.linalg.norm(hip["p"] - ref["p"], axis=1)
+    i, j = ate.associate(hip["t"], stream["t"])
+    a_hip, a_ref = ate.ate_rmse(hip["p"][i], stream["gt_p"][j]), ate.ate_rmse(ref["p"][i], stream["gt_p"][j])
+    print(seq, "max |p_hip - p_oracle| %.2e m, ATE vs ground truth: HIP %.4f m, oracle %.4f m" % (d.max(), a_hip, a_ref))
+    assert d.max() < 1e-3
+    assert abs(a_hip - a_ref) < 1e-3 and a_hip < 0.10

@@ -78,3 +78,46 @@ def test_lock_step_multi_sequence_replay_equals_individual_replays():
     for st, m in zip(streams, many):
         one = replay.run(st, OracleBackend(), num_iterations=4)
         assert np.array_equal(one["p"], m["p"]) and np.array_equal(one["q"], m["q"]) and [l["flag"] for l in one["log"]] == [l["flag"] for l in m["log"]]
+
+
+def test_euroc_excerpts_and_the_synthesised_imu_are_consistent_with_the_ground_truth():
+    """N1's stream simulator on the EuRoC ground truth the reference ships (benchmark_publisher/config/<seq>/data.csv excerpts
+    in tc-viml_amd/data/): every sequence loads, carries its own prior line map and map -> world transform, and the IMU samples
+    synthesised from the ground truth integrate back onto it (mid-point integration as in Estimator::processIMU, open loop, 5 s:
+    a few millimetres)."""
+    assert len(replay.EUROC_SEQUENCES) == 5
+    for seq in replay.EUROC_SEQUENCES:
+        E = replay.load_euroc(seq)
+        assert E["p"].shape == (7200, 3) and E["lines3d"].shape[1] == 6 and E["lines3d"].shape[0] in (891, 908)
+        assert np.abs(np.diff(E["t"]) - 0.005).max() < 1e-6
+        assert np.abs(E["Rbw"] @ E["Rbw"].T - np.eye(3)).max() < 1e-5
+    a = replay.simulate_stream_euroc("V2_02_medium", 51, start_s=3.0, imu_noise=False)
+    assert a["stamp_ns"][0] > 1.4e18 and len(a["points"]) == 51
+    assert np.linalg.norm(a["gt_v"], axis=1).max() > 0.5                   # a flying MAV, not the hovering synthetic platform
+    P, V, R = a["gt_p"][0].copy(), a["gt_v"][0].copy(), a["gt_R"][0].copy()
+    for k in range(1, 51):
+        acc, gyr = a["imu"][k]
+        for i in range(1, len(acc)):
+            a0 = R @ (acc[i - 1] - a["ba"]) - replay.G
+            R = R @ replay.deltaQ_R((0.5 * (gyr[i - 1] + gyr[i]) - a["bg"]) * 0.005)
+            u, _, vt = np.linalg.svd(R); R = u @ vt
+            am = 0.5 * (a0 + R @ (acc[i] - a["ba"]) - replay.G)
+            P = P + 0.005 * V + 0.5 * 0.005 ** 2 * am; V = V + 0.005 * am
+    assert np.linalg.norm(P - a["gt_p"][50]) < 0.01 and np.linalg.norm(V - a["gt_v"][50]) < 0.01
+    assert np.linalg.norm(replay._rotvec(R.T @ a["gt_R"][50])) < 5e-4
+    with np.testing.assert_raises(ValueError):
+        replay.simulate_stream_euroc("V2_02_medium", 400)
+
+
+def test_replay_on_a_euroc_trajectory_with_the_oracle_back_end():
+    """5 s of V1_03_difficult (fast rotations): both marginalisation modes occur, ~60 line factors per window from the sequence's
+    own map; the estimate stays within a few cm of the ground truth (the paper's Table II reports 6.8 cm on a whole sequence)."""
+    stream = replay.simulate_stream_euroc("V1_03_difficult", 50, start_s=1.0, max_features=40, max_lines=6)
+    out = replay.run(stream, OracleBackend(), num_iterations=8)
+    flags = [l["flag"] for l in out["log"]]
+    assert replay.MARGIN_OLD in flags and replay.MARGIN_SECOND_NEW in flags
+    assert min(l["n_line"] for l in out["log"]) >= 30
+    i, j = ate.associate(out["t"], stream["t"])
+    assert len(i) == 40
+    assert ate.ate_rmse(out["p"][i], stream["gt_p"][j]) < 0.08
+    assert ate.ate_rmse(out["p"][i], stream["gt_p"][j], align=False) < 0.25
