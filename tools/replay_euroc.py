@@ -1,7 +1,7 @@
 """BASELINE configs[3] / configs[4]: replay along the EuRoC ground-truth trajectories the reference ships (five sequences,
 36 s excerpts, tc-viml_amd/data/euroc_*.npz) through the HIP back end; the sequences run in lock step, one device batch per frame.
 
-    python tools/replay_euroc.py [--frames 340] [--associate] [--out gpurun_out/euroc]
+    python tools/replay_euroc.py [--frames 340] [--line-mode associate|given|none] [--out gpurun_out/euroc]
     python -m torch.distributed.run --nproc-per-node N ... tools/replay_euroc.py     # sequences sharded rank r -> r::N (configs[4])
 
 Per sequence: `vins_result_<seq>.csv` in the reference's format (visualization.cpp:211-226), the ground truth rows in the format
@@ -19,7 +19,9 @@ ap.add_argument("--frames", type=int, default=340)
 ap.add_argument("--start", type=float, default=0.5)
 ap.add_argument("--features", type=int, default=60)
 ap.add_argument("--lines", type=int, default=8)
-ap.add_argument("--associate", action="store_true", help="run the 2D-3D line association (tcv_match_lines) in the loop")
+ap.add_argument("--line-mode", choices=("associate", "given", "none"), default="associate",
+                help="associate: the 2D-3D association (tcv_match_lines + removeLineOutlier) runs in the loop, as in the reference; "
+                     "given: every line observation arrives with its true 3D partner; none: no line factors")
 ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "euroc"))
 args = ap.parse_args()
 rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -29,7 +31,8 @@ if world > 1:
 seqs = list(replay.EUROC_SEQUENCES)[rank::world]
 os.makedirs(args.out, exist_ok=True)
 t0 = time.perf_counter()
-streams = [replay.simulate_stream_euroc(s, args.frames, start_s=args.start, max_features=args.features, max_lines=args.lines, associate=args.associate) for s in seqs]
+streams = [replay.simulate_stream_euroc(s, args.frames, start_s=args.start, max_features=args.features, max_lines=0 if args.line_mode == "none" else args.lines,
+                                         associate=args.line_mode == "associate") for s in seqs]
 t1 = time.perf_counter()
 outs = replay.run_many(streams, replay.HipBackend(), num_iterations=8) if streams else []
 t2 = time.perf_counter()
@@ -45,8 +48,8 @@ for st, o in zip(streams, outs):
                      margin_old=flags.count(replay.MARGIN_OLD), margin_second_new=flags.count(replay.MARGIN_SECOND_NEW),
                      point_factors_mean=round(float(np.mean([l["n_proj"] for l in o["log"]])), 1), line_factors_mean=round(float(np.mean([l["n_line"] for l in o["log"]])), 1)))
 frames = sum(r["optimised_frames"] for r in rows)
-res = dict(rank=rank, world=world, associate=args.associate, sequences=rows, optimised_frames=frames, simulate_s=round(t1 - t0, 2), replay_s=round(t2 - t1, 2),
+res = dict(rank=rank, world=world, line_mode=args.line_mode, sequences=rows, optimised_frames=frames, simulate_s=round(t1 - t0, 2), replay_s=round(t2 - t1, 2),
            frames_per_s=round(frames / max(t2 - t1, 1e-9), 1))
-with open(os.path.join(args.out, "replay_euroc_rank%d.json" % rank), "w") as f:
+with open(os.path.join(args.out, "replay_euroc_%s_rank%d.json" % (args.line_mode, rank)), "w") as f:
     json.dump(res, f, indent=1)
 print(json.dumps(res))
