@@ -209,7 +209,18 @@ extern "C" int tcv_problem_plan_stats(const tcv_problem *p, int *out) {
 
 // graph construction of estimator.cpp:1683-1846 from frame-indexed arrays
 extern "C" int tcv_problem_from_window(const tcv_window_desc *w, tcv_problem **out) {
-    if (!w || !out || w->n_frames <= 0) return TCV_ERR_INVALID;
+    if (!w || !out || w->n_frames <= 0 || !w->para_pose || !w->para_speedbias || !w->para_ex_pose || (w->n_imu > 0 && (!w->imu || !w->imu_frame_i || !w->imu_frame_j)) ||
+        (w->n_proj > 0 && (!w->proj_pts || !w->proj_frame_i || !w->proj_frame_j || !w->proj_feature || !w->para_feature)) ||
+        (w->n_line > 0 && (!w->line_data || !w->line_frame)) ||
+        (w->prior && (!w->prior_block_kind || !w->prior_block_index)) || w->n_imu < 0 || w->n_proj < 0 || w->n_line < 0) {
+        set_error("problem_from_window: missing array in the window description");
+        return TCV_ERR_INVALID;
+    }
+    auto frame_ok = [&](int f) { return f >= 0 && f < w->n_frames; };
+    for (int k = 0; k < w->n_imu; k++) if (!frame_ok(w->imu_frame_i[k]) || !frame_ok(w->imu_frame_j[k])) { set_error("problem_from_window: IMU frame index out of range"); return TCV_ERR_INVALID; }
+    for (int k = 0; k < w->n_proj; k++)
+        if (!frame_ok(w->proj_frame_i[k]) || !frame_ok(w->proj_frame_j[k]) || w->proj_feature[k] < 0 || w->proj_feature[k] >= w->n_landmarks) { set_error("problem_from_window: projection frame / feature index out of range"); return TCV_ERR_INVALID; }
+    for (int k = 0; k < w->n_line; k++) if (!frame_ok(w->line_frame[k])) { set_error("problem_from_window: line frame index out of range"); return TCV_ERR_INVALID; }
     tcv_problem *p = new tcv_problem();
     int rc = TCV_OK;
     auto chk = [&](int r) { if (rc == TCV_OK && r != TCV_OK) rc = r; };
@@ -226,9 +237,10 @@ extern "C" int tcv_problem_from_window(const tcv_window_desc *w, tcv_problem **o
         std::vector<double *> blocks(nb);
         for (int k = 0; k < nb; k++) {
             const int kind = w->prior_block_kind[k], idx = w->prior_block_index[k];
+            if (kind < 0 || kind > 2 || (kind != 2 && !frame_ok(idx))) { set_error("problem_from_window: prior block kind / index out of range"); rc = TCV_ERR_INVALID; break; }
             blocks[k] = kind == 0 ? w->para_pose + 7 * idx : (kind == 1 ? w->para_speedbias + 9 * idx : w->para_ex_pose);
         }
-        chk(tcv_problem_add_marginalization_factor(p, w->prior, blocks.data(), nb));
+        if (rc == TCV_OK) chk(tcv_problem_add_marginalization_factor(p, w->prior, blocks.data(), nb));
     }
     for (int k = 0; k < w->n_imu; k++) {   // :1723-1732
         if (w->imu[k].sum_dt > 10.0) continue;
@@ -321,7 +333,9 @@ static void batch_free(tcv_batch *b) {
 
 extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, tcv_problem *const *marg_problems,
                                 double *const *const *marg_drop, const int *marg_num_drop, int n) {
-    if (!out || !problems || n <= 0) return TCV_ERR_INVALID;
+    if (!out || !problems || n <= 0) { set_error("batch_create: bad argument"); return TCV_ERR_INVALID; }
+    for (int w = 0; w < n; w++)
+        if (!problems[w] || (marg_problems && (!marg_problems[w] || !marg_drop || !marg_num_drop))) { set_error("batch_create: null problem in the batch"); return TCV_ERR_INVALID; }
     if (int rc = device_ready()) return rc;
     tcv_batch *b = new tcv_batch();
     b->n = n;
@@ -387,10 +401,10 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
     b->delta_stride = (max_nl + 1) & ~1;
     b->lds_bytes = max_lds;
     hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, 0));
     int dev = 0;
-    hipGetDevice(&dev);
-    hipGetDeviceProperties(&prop, dev);
+    hipError_t e0 = hipGetDevice(&dev);
+    if (e0 == hipSuccess) e0 = hipGetDeviceProperties(&prop, dev);
+    if (e0 != hipSuccess) { batch_free(b); return hip_fail(e0, "hipGetDeviceProperties"); }
     b->grid = std::min(n, (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256) * (b->chain ? 2 : 1));
     if (const char *eg = getenv("TCV_GRID")) { const int g = atoi(eg); if (g > 0) b->grid = std::min(n, g); }      // tuning experiments
     const int scr = tcv_solve_scratch_doubles() + b->hcl_cap;
@@ -422,8 +436,9 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
     hipMemset(b->d_scratch, 0, sizeof(double) * (size_t)b->grid * scr);
     hipMemset(b->d_summary, 0, sizeof(DevSummary) * (size_t)n);
     hipMemset(b->d_delta, 0, sizeof(double) * (size_t)n * b->delta_stride);
-    HIPCHK(hipEventCreate(&b->ev0));
-    HIPCHK(hipEventCreate(&b->ev1));
+    e0 = hipEventCreate(&b->ev0);
+    if (e0 == hipSuccess) e0 = hipEventCreate(&b->ev1);
+    if (e0 != hipSuccess) { batch_free(b); return hip_fail(e0, "hipEventCreate"); }
     if (marg_problems) {
         const int rc = tcv_marg_attach(b, marg_problems, marg_drop, marg_num_drop);
         if (rc != TCV_OK) { batch_free(b); return rc; }

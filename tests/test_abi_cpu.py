@@ -106,6 +106,36 @@ def test_error_paths(tcv):
     assert L.tcv_problem_plan_stats(w.h, tcv.iptr(out)) == tcv.TCV_ERR_NUMERIC
 
 
+def test_window_description_is_validated_before_it_is_walked(tcv):
+    """tcv_problem_from_window / tcv_batch_create: missing arrays and out-of-range frame / feature indices are reported as
+    TCV_ERR_INVALID with a message, never dereferenced."""
+    L = tcv.lib()
+    w = tcv.Window(synth.window_at(synth.make_windows(3, 1), 0))
+    h = C.c_void_p()
+
+    def broken(**kw):
+        d = tcv.WindowDesc()
+        C.memmove(C.byref(d), C.byref(w.desc), C.sizeof(d))
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return L.tcv_problem_from_window(C.byref(d), C.byref(h))
+
+    assert broken() == 0
+    L.tcv_problem_destroy(h)
+    assert broken(para_pose=None) == tcv.TCV_ERR_INVALID and b"missing array" in L.tcv_last_error()
+    assert broken(proj_pts=None) == tcv.TCV_ERR_INVALID
+    assert broken(imu=None) == tcv.TCV_ERR_INVALID
+    assert broken(line_data=None) == tcv.TCV_ERR_INVALID
+    assert broken(n_proj=-1) == tcv.TCV_ERR_INVALID
+    bad = tcv.i32(np.full(w.desc.n_proj, 11)); assert broken(proj_frame_j=tcv.iptr(bad)) == tcv.TCV_ERR_INVALID and b"out of range" in L.tcv_last_error()
+    bad = tcv.i32(np.full(w.desc.n_proj, w.desc.n_landmarks)); assert broken(proj_feature=tcv.iptr(bad)) == tcv.TCV_ERR_INVALID
+    bad = tcv.i32(np.full(w.desc.n_line, -1)); assert broken(line_frame=tcv.iptr(bad)) == tcv.TCV_ERR_INVALID
+    bad = tcv.i32(np.full(w.desc.n_imu, 12)); assert broken(imu_frame_i=tcv.iptr(bad)) == tcv.TCV_ERR_INVALID
+    b = C.c_void_p()
+    arr = (C.c_void_p * 2)(w.h, None)
+    assert L.tcv_batch_create(C.byref(b), arr, None, None, None, 2) == tcv.TCV_ERR_INVALID and b"null problem" in L.tcv_last_error()
+
+
 def test_too_many_frames_is_rejected(tcv):
     # 13 frames -> camera tangent dim 201 > 175: the LDS-resident solver refuses instead of truncating
     L = tcv.lib()
