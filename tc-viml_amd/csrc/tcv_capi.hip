@@ -11,6 +11,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <chrono>
 
 #include "tcv_factors.h"
 #include "tcv_host.h"
@@ -337,6 +338,7 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
     for (int w = 0; w < n; w++)
         if (!problems[w] || (marg_problems && (!marg_problems[w] || !marg_drop || !marg_num_drop))) { set_error("batch_create: null problem in the batch"); return TCV_ERR_INVALID; }
     if (int rc = device_ready()) return rc;
+    const auto t_begin = std::chrono::steady_clock::now();
     tcv_batch *b = new tcv_batch();
     b->n = n;
     b->problems.assign(problems, problems + n);
@@ -347,22 +349,14 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
     int max_state = 0, max_nl = 0;
     size_t max_lds = 0;
     int mode = g_solver_variant;
-    if (mode == 0)      // the chain layout is used only if every window of the batch allows it (structure-only question)
-        for (int w = 0; w < n && mode == 0; w++) {
-            if (w > 0 && problems[w]->imu.size() == problems[0]->imu.size() && problems[w]->proj.size() == problems[0]->proj.size() &&
-                problems[w]->prior.size() == problems[0]->prior.size() && problems[w]->blocks.size() == problems[0]->blocks.size())
-                continue;      // same shape as window 0: verified by the packing pass below
-            Packed pk;
-            const int rc = pack_problem(*problems[w], pk, nullptr, 0);
-            if (rc != TCV_OK) { batch_free(b); return rc; }
-            if (!pk.hdr.chain) mode = 1;
-        }
+    // the chain layout is used only if every window of the batch allows it: the packing pass below starts over with the dense layout
+    // at the first window that does not
     b->chain = (mode == 0);
     for (int w = 0; w < n; w++) {
         Packed &pk = b->packed[w];
         const int rc = pack_problem(*problems[w], pk, nullptr, mode);
         if (rc != TCV_OK) { batch_free(b); return rc; }
-        if (mode == 0 && !pk.hdr.chain) {      // a same-shaped window turned out not to be chain-eligible: start over with the dense layout
+        if (mode == 0 && !pk.hdr.chain) {      // not chain-eligible: start over with the dense layout
             mode = 1; b->chain = false; w = -1;
             b->plans.clear(); b->plan_base.clear(); b->wins.clear(); plan_index.clear(); ipool.clear(); dpool.clear();
             max_state = max_nl = 0; max_lds = 0; b->input_bytes = 0; b->spill_stride = 0; b->hcl_cap = 0;
@@ -396,6 +390,7 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
         b->input_bytes += 8.0 * pk.doubles.size();
         pk.doubles.clear(); pk.doubles.shrink_to_fit();
     }
+    const auto t_packed = std::chrono::steady_clock::now();
     b->plan_bytes = 4.0 * ipool.size();
     b->state_stride = (max_state + 1) & ~1;
     b->delta_stride = (max_nl + 1) & ~1;
@@ -439,9 +434,15 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
     e0 = hipEventCreate(&b->ev0);
     if (e0 == hipSuccess) e0 = hipEventCreate(&b->ev1);
     if (e0 != hipSuccess) { batch_free(b); return hip_fail(e0, "hipEventCreate"); }
+    const auto t_up = std::chrono::steady_clock::now();
     if (marg_problems) {
         const int rc = tcv_marg_attach(b, marg_problems, marg_drop, marg_num_drop);
         if (rc != TCV_OK) { batch_free(b); return rc; }
+    }
+    if (getenv("TCV_DEBUG_PACK")) {
+        const auto t_end = std::chrono::steady_clock::now();
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) { return std::chrono::duration<double, std::milli>(c - a).count(); };
+        fprintf(stderr, "[batch_create] n %d: pack %.2f ms, alloc+upload %.2f ms, marg attach %.2f ms\n", n, ms(t_begin, t_packed), ms(t_packed, t_up), ms(t_up, t_end));
     }
     *out = b;
     return TCV_OK;

@@ -414,7 +414,10 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int 
         // smallest number k of chunks whose EXACT programs fit; the line factors are spread over the chunks
         bool found = false;
         const int nline = (int)p.line.size(), nproj = (int)p.proj.size();
-        for (int k = 1; k <= std::max(1, std::min(L, 48)) && !found; k++) {
+        // lower bound on k from the records alone, then jump by the measured overshoot: two exact trials instead of k
+        const int kmax = std::max(1, std::min(L, 48));
+        int k = std::max(1, (nproj * PROJ_REC + nline * LINE_REC + c_pool - 1) / std::max(1, c_pool));
+        for (; k <= kmax && !found;) {
             std::vector<VChunk> cand;
             int l = 0;
             for (int c = 0; c < k; c++) {
@@ -424,9 +427,11 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int 
                 cand.push_back(cur);
             }
             int ms = 0, ma = 0;
-            if (emit_all(cand, -1, -1, vprog, sprog, vchunk_tab, ms, ma) != TCV_OK) continue;
+            if (emit_all(cand, -1, -1, vprog, sprog, vchunk_tab, ms, ma) != TCV_OK) { k++; continue; }
             ma = (ma + 1) & ~1;
+            if (getenv("TCV_DEBUG_PACK")) fprintf(stderr, "[pack] k %d ms %d ma %d pool %d\n", k, ms, ma, c_pool);
             if (ms + ma <= c_pool) { found = true; vch = cand; area_cap = ma; stage_cap = c_pool - ma; }
+            else k = std::max(k + 1, std::min(kmax, (int)(((long long)k * (ms + ma) + c_pool - 1) / c_pool)));      // need(k) ~ a / k + b, b > 0: never overshoots the smallest k
         }
         if (!found) { use_chain = false; chain.clear(); }
     }
