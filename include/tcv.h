@@ -109,7 +109,8 @@ const char *tcv_last_error(void);
 int tcv_device_count(void);            /* 0 when no HIP device is visible */
 int tcv_set_device(int device);
 /* 0 (default): batches whose speed-bias blocks form chains (every window OptimizationWithLine builds) use the chain layout
- * of the fused solver (speed-biases eliminated block by block before the dense pose system, two windows per CU);
+ * of the fused solver (speed-biases eliminated block by block before the dense pose system; two windows per CU when the
+ * batch has more windows than the device has CUs, otherwise one window per CU with the whole LDS);
  * 1: always the dense 171-dim layout (one window per CU; cross-check / arbitrary graphs).  Read at tcv_batch_create. */
 int tcv_set_solver_variant(int variant);
 
@@ -201,6 +202,8 @@ int tcv_batch_marg_status(tcv_batch *b, int *out, int n);
 int tcv_batch_get_first_step(tcv_batch *b, int window, double *out, int cap, int *len);
 /* number of distinct graph structures (plans) in the batch, their bytes, launch grid and LDS bytes */
 int tcv_batch_plan_stats(tcv_batch *b, int *num_plans, double *plan_bytes, int *grid, int *lds_bytes);
+/* layout of the fused solver chosen for this batch: 0 chain (speed-biases eliminated block by block), 1 dense; < 0: error */
+int tcv_batch_layout(const tcv_batch *b);
 /* bytes of window input resident in HBM and elapsed milliseconds of the last solve / marginalise
  * kernels measured with HIP events on the launch stream */
 int tcv_batch_stats(tcv_batch *b, double *input_bytes, double *solve_ms, double *marg_ms);

@@ -348,13 +348,22 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
     std::vector<double> dpool;
     int max_state = 0, max_nl = 0;
     size_t max_lds = 0;
+    int dev = 0, n_cu = 0;
+    hipError_t e0 = hipGetDevice(&dev);
+    if (e0 == hipSuccess) e0 = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e0 != hipSuccess) { batch_free(b); return hip_fail(e0, "hipDeviceGetAttribute"); }
+    if (n_cu <= 0) n_cu = 256;
+    // chain layout: two workgroups share a CU's LDS when the batch is larger than the chip; a batch that leaves CUs idle anyway gives
+    // every workgroup the whole 160 KiB (fewer chunk passes over the visual factors, the prior's J0 staged in one piece)
+    const int chain_lds = (n <= n_cu && !getenv("TCV_CHAIN_LDS_DOUBLES")) ? (int)LDS_DOUBLES : chain_lds_doubles();
+    b->chain_lds = chain_lds;
     int mode = g_solver_variant;
     // the chain layout is used only if every window of the batch allows it: the packing pass below starts over with the dense layout
     // at the first window that does not
     b->chain = (mode == 0);
     for (int w = 0; w < n; w++) {
         Packed &pk = b->packed[w];
-        const int rc = pack_problem(*problems[w], pk, nullptr, mode);
+        const int rc = pack_problem(*problems[w], pk, nullptr, mode, chain_lds);
         if (rc != TCV_OK) { batch_free(b); return rc; }
         if (mode == 0 && !pk.hdr.chain) {      // not chain-eligible: start over with the dense layout
             mode = 1; b->chain = false; w = -1;
@@ -381,7 +390,7 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
         max_state = std::max(max_state, pk.hdr.nx + pk.hdr.nland);
         max_nl = std::max(max_nl, pk.hdr.nc + pk.hdr.nland);
         const int nt = pk.hdr.nt;
-        const size_t lds = b->chain ? (size_t)chain_lds_doubles() * 8
+        const size_t lds = b->chain ? (size_t)chain_lds * 8
                                     : (size_t)(nt * (nt + 1) / 2 * 256 + 2 * ((pk.hdr.nx + pk.hdr.nland + 1) & ~1) + 4 * 176 + 64 + pk.hdr.lds_area) * 8;
         max_lds = std::max(max_lds, lds);
         b->spill_stride = std::max(b->spill_stride, pk.hdr.c_spill);
@@ -395,12 +404,7 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
     b->state_stride = (max_state + 1) & ~1;
     b->delta_stride = (max_nl + 1) & ~1;
     b->lds_bytes = max_lds;
-    hipDeviceProp_t prop;
-    int dev = 0;
-    hipError_t e0 = hipGetDevice(&dev);
-    if (e0 == hipSuccess) e0 = hipGetDeviceProperties(&prop, dev);
-    if (e0 != hipSuccess) { batch_free(b); return hip_fail(e0, "hipGetDeviceProperties"); }
-    b->grid = std::min(n, (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256) * (b->chain ? 2 : 1));
+    b->grid = std::min(n, n_cu * (b->chain ? 2 : 1));
     if (const char *eg = getenv("TCV_GRID")) { const int g = atoi(eg); if (g > 0) b->grid = std::min(n, g); }      // tuning experiments
     const int scr = tcv_solve_scratch_doubles() + b->hcl_cap;
 #define UP(dst, src, T, cnt)                                                                          \
@@ -574,6 +578,7 @@ extern "C" int tcv_batch_profile(tcv_batch *b, double *out32) {
     HIPCHK(hipMemset(b->d_prof, 0, sizeof(double) * h.size()));
     return TCV_OK;
 }
+extern "C" int tcv_batch_layout(const tcv_batch *b) { return b ? (b->chain ? 0 : 1) : TCV_ERR_INVALID; }
 extern "C" int tcv_batch_plan_stats(tcv_batch *b, int *num_plans, double *plan_bytes, int *grid, int *lds_bytes) {
     if (!b) return TCV_ERR_INVALID;
     if (num_plans) *num_plans = (int)b->plans.size();

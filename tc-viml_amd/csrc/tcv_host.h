@@ -85,6 +85,7 @@ struct tcv_batch {
     std::vector<double> h_state;
     bool gauge_fixed = false;
     bool chain = false;                   // all plans use the chain layout (2 workgroups per CU)
+    int chain_lds = 0;                    // LDS doubles per chain-layout workgroup of this batch
     double *d_imublk = nullptr, *d_spill = nullptr;   // chain mode: per-workgroup IMU J'J blocks and factored fronts
     int spill_stride = 0;
     int hcl_cap = 0;                      // doubles of the landmark/camera coupling store per workgroup (largest window of the batch)
@@ -105,5 +106,6 @@ int device_ready();
 void set_error(const std::string &s);
 // returns TCV_OK or a negative status; fills out.  imu_sqrt: optional host-provided sqrt_info (n_imu x 225).
 // mode: 0 = chain layout when the graph allows it (speed-bias blocks form chains), else dense; 1 = dense layout
-int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int mode = 0);
+// chain_lds: LDS doubles of a chain-layout workgroup (0: chain_lds_doubles(), half a CU's LDS so that two workgroups share a CU)
+int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int mode = 0, int chain_lds = 0);
 }  // namespace tcv

@@ -115,7 +115,7 @@ void add_pairs(DestList &dl, const std::vector<Col> &cols, MakeItem mk, int rcol
 
 }  // namespace
 
-int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int mode) {
+int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int mode, int chain_lds) {
     const int nb = (int)p.blocks.size();
     // ---- classify blocks: landmarks = size-1 Euclidean blocks used only as 4th block of projection factors
     std::vector<int> use_lm(nb, 0), use_other(nb, 0);
@@ -225,7 +225,8 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int 
     }
     const int nt_c = (npp + 1 + 15) / 16, ctiles = nt_c * (nt_c + 1) / 2;
     const int c_vec = 2 * nxl + 4 * 176 + 64 + 112;
-    const int c_pool = chain_lds_doubles() - ctiles * 256 - c_vec;
+    const int c_lds = (chain_lds >= 6144 && chain_lds <= LDS_DOUBLES) ? (chain_lds & ~1) : chain_lds_doubles();
+    const int c_pool = c_lds - ctiles * 256 - c_vec;
     if (use_chain && (c_pool < 2 * CH_MAXROWS * CH_W + 16 + 8 * CH_STRIDE + 64 || c_pool < IMU_REC)) use_chain = false;
 
     PlanHdr &H = out.hdr;

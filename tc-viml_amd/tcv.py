@@ -35,7 +35,7 @@ EXPORTS = [
     "tcv_prior_create", "tcv_prior_dims", "tcv_prior_export", "tcv_prior_export_schur", "tcv_prior_keep_block_addresses", "tcv_prior_destroy",
     "tcv_batch_create", "tcv_batch_destroy", "tcv_batch_solve", "tcv_batch_marginalize", "tcv_batch_synchronize",
     "tcv_batch_download_states", "tcv_batch_get_summaries", "tcv_batch_get_prior", "tcv_batch_get_first_step",
-    "tcv_batch_plan_stats", "tcv_batch_stats", "tcv_batch_size",
+    "tcv_batch_plan_stats", "tcv_batch_layout", "tcv_batch_stats", "tcv_batch_size",
     "tcv_eval_imu_factors", "tcv_eval_projection_factors", "tcv_eval_line_factors", "tcv_pose_plus", "tcv_preintegrate",
     "tcv_problem_set_frames", "tcv_gauge_fix", "tcv_batch_gauge_fix", "tcv_set_solver_variant", "tcv_batch_marg_status", "tcv_eval_projection_td_factors", "tcv_match_lines",
 ]
@@ -131,6 +131,7 @@ def lib():
         L.tcv_batch_get_prior.argtypes = [vp, C.c_int, C.POINTER(vp)]
         L.tcv_batch_get_first_step.argtypes = [vp, C.c_int, _dp, C.c_int, _ip]
         L.tcv_batch_plan_stats.argtypes = [vp, _ip, _dp, _ip, _ip]
+        L.tcv_batch_layout.argtypes = [vp]
         L.tcv_batch_stats.argtypes = [vp, _dp, _dp, _dp]
         L.tcv_batch_size.argtypes = [vp]
         L.tcv_eval_imu_factors.argtypes = [C.c_int, C.POINTER(ImuPreintegration), _dp, _dp, C.c_int, _dp, _dp, _dp]
@@ -441,7 +442,7 @@ class Batch:
     def plan_stats(self):
         a, b, c, d = C.c_int(), C.c_double(), C.c_int(), C.c_int()
         check(lib().tcv_batch_plan_stats(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
-        return dict(num_plans=a.value, plan_bytes=b.value, grid=c.value, lds_bytes=d.value)
+        return dict(num_plans=a.value, plan_bytes=b.value, grid=c.value, lds_bytes=d.value, layout=("chain", "dense")[lib().tcv_batch_layout(self.h)])
 
     def __del__(self):
         if getattr(self, "h", None) is not None and _lib is not None:

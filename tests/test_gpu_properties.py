@@ -34,9 +34,14 @@ def test_full_batch_properties(gpu):
     W2, s2 = run(gpu, wins)
     assert all(np.array_equal(W[k].pose, W2[k].pose) and np.array_equal(W[k].lam, W2[k].lam) for k in range(B))
     assert all(s[k].final_cost == s2[k].final_cost for k in range(B))
-    # a window solved alone gives the same bits as inside the batch (no cross-window coupling)
+    # a window gives the same bits whatever its neighbours in the batch are (no cross-window coupling) ...
+    W1, s1 = run(gpu, wins[300:813])
+    assert np.array_equal(W1[213].pose, W[513].pose) and s1[213].final_cost == s[513].final_cost
+    # ... and solved alone -- a batch that does not fill the chip gives every workgroup the whole LDS: other chunking of the
+    # visual factors, another summation order -- the same result to rounding
     W1, s1 = run(gpu, [wins[513]])
-    assert np.array_equal(W1[0].pose, W[513].pose) and s1[0].final_cost == s[513].final_cost
+    assert rel(W1[0].pose, W[513].pose) < 1e-9 and abs(s1[0].final_cost - s[513].final_cost) < 1e-9 * s[513].final_cost
+    assert [s1[0].dogleg_case[i] for i in range(9)] == [s[513].dogleg_case[i] for i in range(9)]
     # matrix-core path vs FP64 VALU path of the trailing update: same algorithm, different rounding
     W3, s3 = run(gpu, wins[:64], mfma=False)
     assert max(rel(W3[k].pose, W[k].pose) for k in range(64)) < 1e-6
@@ -60,11 +65,12 @@ def test_restart_from_converged_states_does_not_increase_cost(gpu):
 
 
 def test_chain_and_dense_layouts_agree_on_a_large_batch(gpu):
-    """256 cfg-3 windows (200 point + 40 line blocks, GPU-made n = 75 priors): the chain layout (default) and the dense layout
+    """320 cfg-3 windows (more than the chip has CUs: two chain-layout workgroups per CU, 80 KiB each) (200 point + 40 line blocks, GPU-made n = 75 priors): the chain layout (default) and the dense layout
     must take the same trust-region decisions and end at the same states; also with convergence tests on."""
     import bench
+    B = 320
     out = {}
-    _b, wins, _keep = bench.build_batches(gpu, synth, 7000, 256)          # identical inputs (incl. the priors) for both layouts
+    _b, wins, _keep = bench.build_batches(gpu, synth, 7000, B)          # identical inputs (incl. the priors) for both layouts
     del _b, _keep
     try:
         for variant in (0, 1):
@@ -73,11 +79,11 @@ def test_chain_and_dense_layouts_agree_on_a_large_batch(gpu):
             for fixed, iters in ((True, 8), (False, 30)):
                 W = [gpu.Window(w) for w in wins]
                 batch = gpu.Batch(W)
-                assert batch.plan_stats()["lds_bytes"] == (80 * 1024 if variant == 0 else 160 * 1024)
+                assert batch.plan_stats()["lds_bytes"] == (80 * 1024 if variant == 0 else 160 * 1024) and batch.plan_stats()["layout"] == ("chain", "dense")[variant]
                 batch.solve(gpu.default_options(iters, fixed)); batch.synchronize(); batch.download_states()
                 s = batch.summaries()
-                res.append(([s[k].final_cost for k in range(256)], [[s[k].dogleg_case[i] for i in range(s[k].num_iterations)] for k in range(256)],
-                            [s[k].termination for k in range(256)], np.stack([w.pose.copy() for w in W])))
+                res.append(([s[k].final_cost for k in range(B)], [[s[k].dogleg_case[i] for i in range(s[k].num_iterations)] for k in range(B)],
+                            [s[k].termination for k in range(B)], np.stack([w.pose.copy() for w in W])))
             out[variant] = res
     finally:
         gpu.check(gpu.lib().tcv_set_solver_variant(0))
@@ -86,7 +92,7 @@ def test_chain_and_dense_layouts_agree_on_a_large_batch(gpu):
         worst = sorted((abs(a - b) / b, k) for k, (a, b) in enumerate(zip(fc0, fc1)))[-3:]
         assert worst[-1][0] < 1e-6, (mode, worst, [(dc0[k], dc1[k]) for _, k in worst])
         same = sum(1 for a, b in zip(dc0, dc1) if a == b)
-        assert same >= 250, same              # a borderline accept / reject may flip between two roundings of the same system
-        assert sum(1 for a, b in zip(t0, t1) if a == b) >= 250
+        assert same >= B - 6, same              # a borderline accept / reject may flip between two roundings of the same system
+        assert sum(1 for a, b in zip(t0, t1) if a == b) >= B - 6
         if mode == 0:
             assert rel(p0, p1) < 1e-6
