@@ -101,6 +101,13 @@ typedef struct {
     const tcv_prior *prior;    /* last_marginalization_info or NULL, estimator.cpp:1714-1720 */
     /* which blocks the prior is attached to, in the prior's keep-block order: kind 0 pose,1 speedbias,2 ex */
     const int *prior_block_kind, *prior_block_index;
+    /* ESTIMATE_TD (estimator.cpp:1703-1707, :1757-1763): para_td != NULL turns every point factor into a ProjectionTdFactor
+     * on the extra 1-dim block para_Td[0].  proj_td_aux: n_proj x 8 = velocity_i xy, velocity_j xy, td_i, td_j, row_i, row_j
+     * (the constructor arguments of projection_td_factor.cpp:6-19); td_TR / td_ROW: the globals TR and ROW (parameters.cpp).
+     * A prior block of kind 3 is para_Td. */
+    double *para_td;
+    const double *proj_td_aux;
+    double td_TR, td_ROW;
 } tcv_window_desc;
 
 /* ---- library ------------------------------------------------------------------------------ */
@@ -129,6 +136,15 @@ int tcv_problem_add_imu_factor(tcv_problem *p, const tcv_imu_preintegration *pre
 int tcv_problem_add_projection_factor(tcv_problem *p, const double pts_i[3], const double pts_j[3],
                                       double sqrt_info, double loss_a, double *pose_i, double *pose_j,
                                       double *ex_pose, double *inv_depth);
+/* AddResidualBlock(new ProjectionTdFactor(pts_i, pts_j, velocity_i, velocity_j, td_i, td_j, row_i, row_j), loss, P_i, P_j, Ex,
+ * Feature, Td)   estimator.cpp:1757-1763 (ESTIMATE_TD).  A problem holds either ProjectionFactors or ProjectionTdFactors, all on
+ * the same Td block; such problems use the dense layout of the fused solver.  TR / ROW (rolling-shutter read-out time and image
+ * rows, globals in the reference) are set once per problem with tcv_problem_set_rolling_shutter (default TR = 0, ROW = 1). */
+int tcv_problem_add_projection_td_factor(tcv_problem *p, const double pts_i[3], const double pts_j[3], const double velocity_i[2],
+                                         const double velocity_j[2], double td_i, double td_j, double row_i, double row_j,
+                                         double sqrt_info, double loss_a, double *pose_i, double *pose_j, double *ex_pose,
+                                         double *inv_depth, double *td);
+int tcv_problem_set_rolling_shutter(tcv_problem *p, double TR, double ROW);
 /* AddResidualBlock(new LineProjectionFactor(ps, pe, abc, K, Ric, Tic), loss, P_f)   estimator.cpp:1834-1840 */
 int tcv_problem_add_line_factor(tcv_problem *p, const double pts_start[3], const double pts_end[3],
                                 const double line_abc[3], const double K[9], const double b_c_R[9],

@@ -378,6 +378,9 @@ class Problem:
         for i in range(F):
             self.blocks.append(("pose", i, 7)); self.blocks.append(("sb", i, 9))
         self.blocks.append(("ex", 0, 7))
+        self.has_td = win.get("td") is not None            # ESTIMATE_TD: para_Td[0], estimator.cpp:1703-1707
+        if self.has_td:
+            self.blocks.append(("td", 0, 1))
         for l in range(L):
             self.blocks.append(("lam", l, 1))
         self.const = set(const_blocks)
@@ -396,13 +399,17 @@ class Problem:
 
     def x0(self):
         w = self.win
-        return dict(pose=w["pose"].copy(), sb=w["speedbias"].copy(), ex=w["ex_pose"].copy(), lam=w["lam"].copy())
+        x = dict(pose=w["pose"].copy(), sb=w["speedbias"].copy(), ex=w["ex_pose"].copy(), lam=w["lam"].copy())
+        if self.has_td:
+            x["td"] = np.array([float(w["td"])])
+        return x
 
     @staticmethod
     def get(x, nm, i):
         if nm == "pose": return x["pose"][i]
         if nm == "sb": return x["sb"][i]
         if nm == "ex": return x["ex"]
+        if nm == "td": return x["td"]
         return x["lam"][i:i + 1]
 
     def factors(self):
@@ -419,8 +426,8 @@ class Problem:
             out.append(("imu", k, [("pose", i), ("sb", i), ("pose", j), ("sb", j)]))
         pr = w["proj"]
         for k in range(len(pr["frame_i"])):
-            out.append(("proj", k, [("pose", int(pr["frame_i"][k])), ("pose", int(pr["frame_j"][k])),
-                                    ("ex", 0), ("lam", int(pr["landmark"][k]))]))
+            blks = [("pose", int(pr["frame_i"][k])), ("pose", int(pr["frame_j"][k])), ("ex", 0), ("lam", int(pr["landmark"][k]))]
+            out.append(("proj_td", k, blks + [("td", 0)]) if self.has_td else ("proj", k, blks))      # estimator.cpp:1757-1768
         ln = w["line"]
         for k in range(len(ln["frame"])):
             out.append(("line", k, [("pose", int(ln["frame"][k]))]))
@@ -442,6 +449,12 @@ class Problem:
             pr = w["proj"]
             r, Js = proj_evaluate(xs[0], xs[1], xs[2], float(xs[3][0]), pr["pts_i"][k], pr["pts_j"][k],
                                   pr["sqrt_info"], want_jac)
+            return loss_correct(r, Js, pr["loss_a"])
+        if kind == "proj_td":
+            pr = w["proj"]
+            r, Js = proj_td_evaluate(xs[0], xs[1], xs[2], float(xs[3][0]), float(xs[4][0]), pr["pts_i"][k], pr["pts_j"][k], pr["vel_i"][k], pr["vel_j"][k],
+                                     float(pr["td_i"][k]), float(pr["td_j"][k]), float(pr["row_i"][k]), float(pr["row_j"][k]), pr["sqrt_info"],
+                                     float(pr["TR"]), float(pr["ROW"]), want_jac)
             return loss_correct(r, Js, pr["loss_a"])
         if kind == "line":
             ln = w["line"]
@@ -478,6 +491,8 @@ class Problem:
 
     def plus(self, x, delta):
         out = dict(pose=x["pose"].copy(), sb=x["sb"].copy(), ex=x["ex"].copy(), lam=x["lam"].copy())
+        if self.has_td:
+            out["td"] = x["td"].copy()
         for (nm, i, g) in self.blocks:
             lo = self.loff[(nm, i)]
             if lo < 0:
@@ -488,6 +503,8 @@ class Problem:
                 out["ex"] = pose_plus(x["ex"], delta[lo:lo + 6])
             elif nm == "sb":
                 out["sb"][i] = x["sb"][i] + delta[lo:lo + 9]
+            elif nm == "td":
+                out["td"] = x["td"] + delta[lo:lo + 1]
             else:
                 out["lam"][i] = x["lam"][i] + delta[lo]
         return out
@@ -673,7 +690,7 @@ def marginalize_old(prob: Problem, x, imu_sqrt=None, eps=1e-8):
         elif kind == "imu" and blks[0] == ("pose", 0):
             if float(w["imu"]["sum_dt"][k]) < 10.0:                                      # :1936
                 facs.append((fac, [0, 1]))
-        elif kind == "proj" and blks[0] == ("pose", 0):                                   # :1957-1986
+        elif kind in ("proj", "proj_td") and blks[0] == ("pose", 0):                      # :1957-1986
             facs.append((fac, [0, 3]))
     # getParameterBlocks with addr_shift pose i -> i-1, sb i -> i-1, ex -> ex (estimator.cpp:2027-2039)
     return _marginalize(prob, x, facs, lambda nm, i: (nm, i - 1) if nm in ("pose", "sb") else (nm, i), imu_sqrt, eps)

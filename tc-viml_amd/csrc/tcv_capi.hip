@@ -139,7 +139,28 @@ extern "C" int tcv_problem_add_projection_factor(tcv_problem *p, const double pt
         f.b[k] = a[k] ? ensure_block(p, a[k], sz[k]) : -1;
         if (f.b[k] < 0) { set_error("add_projection_factor: bad parameter block"); return TCV_ERR_INVALID; }
     }
+    for (int i = 0; i < 8; i++) f.aux[i] = 0.0;
+    f.btd = -1;
     p->proj.push_back(f);
+    return TCV_OK;
+}
+extern "C" int tcv_problem_add_projection_td_factor(tcv_problem *p, const double pts_i[3], const double pts_j[3], const double vel_i[2],
+                                                    const double vel_j[2], double td_i, double td_j, double row_i, double row_j, double sqrt_info,
+                                                    double loss_a, double *pose_i, double *pose_j, double *ex_pose, double *inv_depth, double *td) {
+    if (!p || !vel_i || !vel_j || !td) { set_error("add_projection_td_factor: bad argument"); return TCV_ERR_INVALID; }
+    const int btd = ensure_block(p, td, 1);
+    if (btd < 0) { set_error("add_projection_td_factor: bad td block"); return TCV_ERR_INVALID; }
+    const int rc = tcv_problem_add_projection_factor(p, pts_i, pts_j, sqrt_info, loss_a, pose_i, pose_j, ex_pose, inv_depth);
+    if (rc != TCV_OK) return rc;
+    ProjFac &f = p->proj.back();
+    f.aux[0] = vel_i[0]; f.aux[1] = vel_i[1]; f.aux[2] = vel_j[0]; f.aux[3] = vel_j[1];
+    f.aux[4] = td_i; f.aux[5] = td_j; f.aux[6] = row_i; f.aux[7] = row_j;
+    f.btd = btd;
+    return TCV_OK;
+}
+extern "C" int tcv_problem_set_rolling_shutter(tcv_problem *p, double TR, double ROW) {
+    if (!p || !(ROW > 0.0) || !(TR == TR)) { set_error("set_rolling_shutter: ROW must be positive"); return TCV_ERR_INVALID; }
+    p->td_TR = TR; p->td_ROW = ROW;
     return TCV_OK;
 }
 extern "C" int tcv_problem_add_line_factor(tcv_problem *p, const double ps[3], const double pe[3], const double abc[3],
@@ -213,7 +234,8 @@ extern "C" int tcv_problem_from_window(const tcv_window_desc *w, tcv_problem **o
     if (!w || !out || w->n_frames <= 0 || !w->para_pose || !w->para_speedbias || !w->para_ex_pose || (w->n_imu > 0 && (!w->imu || !w->imu_frame_i || !w->imu_frame_j)) ||
         (w->n_proj > 0 && (!w->proj_pts || !w->proj_frame_i || !w->proj_frame_j || !w->proj_feature || !w->para_feature)) ||
         (w->n_line > 0 && (!w->line_data || !w->line_frame)) ||
-        (w->prior && (!w->prior_block_kind || !w->prior_block_index)) || w->n_imu < 0 || w->n_proj < 0 || w->n_line < 0) {
+        (w->prior && (!w->prior_block_kind || !w->prior_block_index)) || w->n_imu < 0 || w->n_proj < 0 || w->n_line < 0 ||
+        (w->para_td && w->n_proj > 0 && !w->proj_td_aux) || (w->para_td && !(w->td_ROW > 0.0))) {
         set_error("problem_from_window: missing array in the window description");
         return TCV_ERR_INVALID;
     }
@@ -232,14 +254,18 @@ extern "C" int tcv_problem_from_window(const tcv_window_desc *w, tcv_problem **o
     chk(tcv_problem_add_parameter_block(p, w->para_ex_pose, 7, TCV_PARAM_POSE));   // :1689-1701
     if (!w->estimate_extrinsic) chk(tcv_problem_set_parameter_block_constant(p, w->para_ex_pose));
     chk(tcv_problem_set_gravity(p, w->gravity));
+    if (w->para_td) {   // :1703-1707
+        chk(tcv_problem_add_parameter_block(p, w->para_td, 1, TCV_PARAM_EUCLIDEAN));
+        chk(tcv_problem_set_rolling_shutter(p, w->td_TR, w->td_ROW));
+    }
     if (w->prior) {   // :1714-1720
         int m, n, nb, xs;
         tcv_prior_dims(w->prior, &m, &n, &nb, &xs);
         std::vector<double *> blocks(nb);
         for (int k = 0; k < nb; k++) {
             const int kind = w->prior_block_kind[k], idx = w->prior_block_index[k];
-            if (kind < 0 || kind > 2 || (kind != 2 && !frame_ok(idx))) { set_error("problem_from_window: prior block kind / index out of range"); rc = TCV_ERR_INVALID; break; }
-            blocks[k] = kind == 0 ? w->para_pose + 7 * idx : (kind == 1 ? w->para_speedbias + 9 * idx : w->para_ex_pose);
+            if (kind < 0 || kind > 3 || (kind < 2 && !frame_ok(idx)) || (kind == 3 && !w->para_td)) { set_error("problem_from_window: prior block kind / index out of range"); rc = TCV_ERR_INVALID; break; }
+            blocks[k] = kind == 0 ? w->para_pose + 7 * idx : (kind == 1 ? w->para_speedbias + 9 * idx : (kind == 2 ? w->para_ex_pose : w->para_td));
         }
         if (rc == TCV_OK) chk(tcv_problem_add_marginalization_factor(p, w->prior, blocks.data(), nb));
     }
@@ -249,10 +275,17 @@ extern "C" int tcv_problem_from_window(const tcv_window_desc *w, tcv_problem **o
         chk(tcv_problem_add_imu_factor(p, w->imu + k, w->para_pose + 7 * i, w->para_speedbias + 9 * i, w->para_pose + 7 * j,
                                        w->para_speedbias + 9 * j));
     }
-    for (int k = 0; k < w->n_proj; k++)   // :1737-1771
-        chk(tcv_problem_add_projection_factor(p, w->proj_pts + 6 * k, w->proj_pts + 6 * k + 3, w->proj_sqrt_info, w->proj_loss_a,
-                                              w->para_pose + 7 * w->proj_frame_i[k], w->para_pose + 7 * w->proj_frame_j[k],
-                                              w->para_ex_pose, w->para_feature + w->proj_feature[k]));
+    for (int k = 0; k < w->n_proj; k++) {   // :1737-1771
+        if (w->para_td) {
+            const double *a = w->proj_td_aux + 8 * k;
+            chk(tcv_problem_add_projection_td_factor(p, w->proj_pts + 6 * k, w->proj_pts + 6 * k + 3, a, a + 2, a[4], a[5], a[6], a[7], w->proj_sqrt_info,
+                                                     w->proj_loss_a, w->para_pose + 7 * w->proj_frame_i[k], w->para_pose + 7 * w->proj_frame_j[k],
+                                                     w->para_ex_pose, w->para_feature + w->proj_feature[k], w->para_td));
+        } else
+            chk(tcv_problem_add_projection_factor(p, w->proj_pts + 6 * k, w->proj_pts + 6 * k + 3, w->proj_sqrt_info, w->proj_loss_a,
+                                                  w->para_pose + 7 * w->proj_frame_i[k], w->para_pose + 7 * w->proj_frame_j[k],
+                                                  w->para_ex_pose, w->para_feature + w->proj_feature[k]));
+    }
     for (int k = 0; k < w->n_line; k++)   // :1786-1846
         chk(tcv_problem_add_line_factor(p, w->line_data + 9 * k, w->line_data + 9 * k + 3, w->line_data + 9 * k + 6, w->line_K,
                                         w->line_Ric, w->line_Tic, w->line_loss_a, w->para_pose + 7 * w->line_frame[k]));
@@ -543,11 +576,8 @@ extern "C" int tcv_batch_get_first_step(tcv_batch *b, int window, double *out, i
     HIPCHK(hipMemcpy(d.data(), b->d_delta + (size_t)window * b->delta_stride, sizeof(double) * b->delta_stride, hipMemcpyDeviceToHost));
     const tcv_problem &p = *b->problems[window];
     const Packed &pk = b->packed[window];
-    // recompute loff exactly as the packer does
-    int nc = 0, k = 0;
-    std::vector<int> loff(pk.cam_block.size(), -1);
-    for (size_t c = 0; c < pk.cam_block.size(); c++) { const ParamBlock &pb = p.blocks[pk.cam_block[c]]; if (pb.kind == KIND_POSE && !pb.constant) { loff[c] = nc; nc += 6; } }
-    for (size_t c = 0; c < pk.cam_block.size(); c++) { const ParamBlock &pb = p.blocks[pk.cam_block[c]]; if (pb.kind != KIND_POSE && !pb.constant) { loff[c] = nc; nc += pb.size; } }
+    int k = 0;
+    const std::vector<int> &loff = pk.cam_loff;
     for (size_t c = 0; c < pk.cam_block.size(); c++) {
         if (loff[c] < 0) continue;
         const ParamBlock &pb = p.blocks[pk.cam_block[c]];

@@ -32,7 +32,7 @@ struct ParamBlock {
     bool constant;
 };
 struct ImuFac { tcv_imu_preintegration pre; int b[4]; };
-struct ProjFac { double pts[6]; double sqrt_info, loss_a; int b[4]; };
+struct ProjFac { double pts[6]; double sqrt_info, loss_a; int b[4]; double aux[8]; int btd; };   // btd >= 0: ProjectionTdFactor on block btd
 struct LineFac { double d[9]; double K[9], R[9], T[3]; double loss_a; int b; };
 struct PriorFac { const tcv_prior *prior; std::vector<int> b; };
 
@@ -43,6 +43,7 @@ struct Packed {
     WinHdr win;
     // host-side maps for download
     std::vector<int> cam_block;      // problem block index of every camera block
+    std::vector<int> cam_loff;       // tangent offset of every camera block (-1 constant)
     std::vector<int> lm_block;       // problem block index of every landmark
     std::vector<int> proj_order;     // sorted position -> original projection factor index
 };
@@ -57,6 +58,7 @@ struct tcv_problem {
     std::vector<tcv::LineFac> line;
     std::vector<tcv::PriorFac> prior;
     double G[3] = {0, 0, 9.8};
+    double td_TR = 0.0, td_ROW = 1.0;        // rolling-shutter globals of ProjectionTdFactor
     std::vector<int> frame_pose, frame_sb;   // block ids of para_Pose[i] / para_SpeedBias[i] (gauge fix), may be empty
 };
 

@@ -47,7 +47,7 @@ struct MargHdr {
     int block_mode;   // 1: the marginalised inverse depths (1 x 1 blocks) are eliminated by scalar pivots while the factors are
                       // accumulated, only the frame part of the dropped set (m) goes through the eigen pseudo-inverse
     int o_plast;      // block mode: n_proj flags, 1 = last factor of its landmark (factors sorted by landmark)
-    int pad;
+    int td_blk;       // >= 0: the point factors are ProjectionTdFactors on this block (d_proj then holds 14 doubles per factor)
 };
 
 struct MargArgs {
@@ -635,43 +635,68 @@ __global__ void __launch_bounds__(MARG_NT) marg_kernel(MargArgs Aarg) {
         }
         MARG_MARK(2);
         // ---- projection factors in chunks of 64: evaluate in parallel, accumulate one factor at a time
+        // point records: [18 pose columns | inverse depth | r | td (ProjectionTdFactor only)] per residual row
+        const bool with_td = H.td_blk >= 0;
+        const int prs = with_td ? 21 : (int)PROJ_STRIDE, prr = with_td ? 43 : (int)PROJ_REC;
+        const int njc = with_td ? 20 : 19;                    // Jacobian columns; logical column k lives at record column (k == 19 ? 20 : k)
         for (int f0 = 0; f0 < H.n_proj; f0 += 64) {
             const int fn = min(64, H.n_proj - f0);
             if (tid < fn) {
                 cst_i *pf = ip + H.o_proj + (f0 + tid) * 4;
-                lds_d *rec = stage + tid * PROJ_REC;
+                lds_d *rec = stage + tid * prr;
                 double r[2], pts[6];
+                if (with_td) {
+                    double aux[8], Jl[40];
 #pragma unroll
-                for (int i = 0; i < 6; i++) pts[i] = dp[H.d_proj + (f0 + tid) * 6 + i];
-                proj_eval(CGEN(x + blk[pf[0] * 5 + 1]), CGEN(x + blk[pf[1] * 5 + 1]), CGEN(x + blk[pf[2] * 5 + 1]), x[blk[pf[3] * 5 + 1]],
-                          pts, misc[3], r, GEN(rec), PROJ_STRIDE);
-                (void)loss_correct2(r, GEN(rec), 19, PROJ_STRIDE, misc[4]);
-                rec[19] = r[0]; rec[PROJ_STRIDE + 19] = r[1];
+                    for (int i = 0; i < 6; i++) pts[i] = dp[H.d_proj + (f0 + tid) * 14 + i];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) aux[i] = dp[H.d_proj + (f0 + tid) * 14 + 6 + i];
+                    proj_td_eval(CGEN(x + blk[pf[0] * 5 + 1]), CGEN(x + blk[pf[1] * 5 + 1]), CGEN(x + blk[pf[2] * 5 + 1]), x[blk[pf[3] * 5 + 1]],
+                                 x[blk[H.td_blk * 5 + 1]], pts, aux, misc[3], misc[6], misc[7], r, Jl, 20);
+                    (void)loss_correct2(r, Jl, 20, 20, misc[4]);
+                    for (int row = 0; row < 2; row++) {
+                        for (int c2 = 0; c2 < 19; c2++) rec[row * 21 + c2] = Jl[row * 20 + c2];
+                        rec[row * 21 + 19] = r[row]; rec[row * 21 + 20] = Jl[row * 20 + 19];
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 6; i++) pts[i] = dp[H.d_proj + (f0 + tid) * 6 + i];
+                    proj_eval(CGEN(x + blk[pf[0] * 5 + 1]), CGEN(x + blk[pf[1] * 5 + 1]), CGEN(x + blk[pf[2] * 5 + 1]), x[blk[pf[3] * 5 + 1]],
+                              pts, misc[3], r, GEN(rec), PROJ_STRIDE);
+                    (void)loss_correct2(r, GEN(rec), 19, PROJ_STRIDE, misc[4]);
+                    rec[19] = r[0]; rec[PROJ_STRIDE + 19] = r[1];
+                }
             }
             __syncthreads();
             for (int f = 0; f < fn; f++) {
                 cst_i *pf = ip + H.o_proj + (f0 + f) * 4;
-                const lds_d *rec = stage + f * PROJ_REC;
-                for (int e = tid; e < 19 * 20; e += MARG_NT) {
-                    const int ca = e / 20, cb = e - ca * 20;   // cb == 19: residual column
-                    if (cb < 19 && cb > ca) continue;
-                    const int sa = ca == 18 ? 3 : ca / 6;
-                    const int la = blk[pf[sa] * 5 + 2];
-                    const double s = rec[ca] * rec[cb] + rec[PROJ_STRIDE + ca] * rec[PROJ_STRIDE + cb];
+                const lds_d *rec = stage + f * prr;
+                for (int e = tid; e < njc * (njc + 1); e += MARG_NT) {
+                    const int ca = e / (njc + 1), cb = e - ca * (njc + 1);   // cb == njc: residual column
+                    if (cb < njc && cb > ca) continue;
+                    // block and offset of a logical Jacobian column: 0..17 the three poses, 18 the inverse depth, 19 Td
+                    const int ba = ca < 18 ? pf[ca / 6] : (ca == 18 ? pf[3] : H.td_blk), oa = ca < 18 ? ca % 6 : 0;
+                    const int ra = ca == 19 ? 20 : ca, rb = cb == njc ? 19 : (cb == 19 ? 20 : cb);
+                    const int la = blk[ba * 5 + 2];
+                    const double s = rec[ra] * rec[rb] + rec[prs + ra] * rec[prs + rb];
                     if (H.block_mode && ca == 18) {
                         // the landmark's row: coupling to the camera columns, its diagonal and its gradient
                         if (cb == 18) lmacc[0] += s;
-                        else if (cb == 19) lmacc[1] += s;
-                        else { const int sb = cb / 6, lb = blk[pf[sb] * 5 + 2]; if (lb >= 0) cvec[lb + cb - 6 * sb] += s; }
+                        else if (cb == njc) lmacc[1] += s;
+                        else { const int bb = cb < 18 ? pf[cb / 6] : H.td_blk, lb = blk[bb * 5 + 2]; if (lb >= 0) cvec[lb + (cb < 18 ? cb % 6 : 0)] += s; }
+                        continue;
+                    }
+                    if (H.block_mode && ca == 19 && cb == 18) {      // Td row meets the landmark column: same coupling, transposed
+                        if (la >= 0) cvec[la] += s;
                         continue;
                     }
                     if (la < 0) continue;
-                    const int ia = la + (ca == 18 ? 0 : ca - 6 * sa);
-                    if (cb == 19) { bv[ia] += s; continue; }
-                    const int sb = cb == 18 ? 3 : cb / 6;
-                    const int lb = blk[pf[sb] * 5 + 2];
+                    const int ia = la + oa;
+                    if (cb == njc) { bv[ia] += s; continue; }
+                    const int bb = cb < 18 ? pf[cb / 6] : (cb == 18 ? pf[3] : H.td_blk);
+                    const int lb = blk[bb * 5 + 2];
                     if (lb < 0) continue;
-                    Apk[pidx(ia, lb + (cb == 18 ? 0 : cb - 6 * sb))] += s;
+                    Apk[pidx(ia, lb + (cb < 18 ? cb % 6 : 0))] += s;
                 }
                 __syncthreads();
                 if (H.block_mode && ip[H.o_plast + f0 + f]) {
@@ -823,7 +848,7 @@ static size_t marg_lds_doubles(int pos, int m, int n, int nx) {
     const int me = m + (m & 1), ne = n + (n & 1);
     const int r1 = std::max(pos * (pos + 1) / 2, ne * (ne + 1)), r2 = std::max(2 * me * (me + 1), ne * (ne + 1));
     const size_t before_stage = (size_t)((r1 + 1) & ~1) + ((r2 + 1) & ~1) + MARG_MAX_POS + ((nx + 7) & ~7) + 160 + MARG_MAX_N + MARG_MAX_POS + 8;
-    return before_stage + std::max<size_t>(64 * PROJ_REC, 512 + (size_t)n * (ne + 1));
+    return before_stage + std::max<size_t>(64 * 43, 512 + (size_t)n * (ne + 1));      // 43: a ProjectionTdFactor record (2 x 21 + 1)
 }
 
 static int pack_marg(const tcv_problem &p, double *const *drop, int ndrop, const tcv_problem *solve_p, const Packed *solve_pk,
@@ -833,7 +858,7 @@ static int pack_marg(const tcv_problem &p, double *const *drop, int ndrop, const
     if (p.prior.size() > 1) { set_error("more than one marginalisation factor"); return TCV_ERR_UNSUPPORTED; }
     std::vector<char> touched(nb, 0), dropped(nb, 0);
     for (auto &f : p.imu) for (int k = 0; k < 4; k++) touched[f.b[k]] = 1;
-    for (auto &f : p.proj) for (int k = 0; k < 4; k++) touched[f.b[k]] = 1;
+    for (auto &f : p.proj) { for (int k = 0; k < 4; k++) touched[f.b[k]] = 1; if (f.btd >= 0) touched[f.btd] = 1; }
     for (auto &f : p.prior) for (int b : f.b) touched[b] = 1;
     for (int k = 0; k < ndrop; k++) {
         auto it = p.index.find(drop[k]);
@@ -855,7 +880,7 @@ static int pack_marg(const tcv_problem &p, double *const *drop, int ndrop, const
     // set is too large for the LDS-resident eigen-solver (a 150-feature front end anchors far more than 49 landmarks in the
     // oldest frame) they are eliminated by scalar pivots (block mode) and only the frame part goes through the eigen step.
     std::vector<char> is_lm(nb, 0), other_use(nb, 0);
-    for (auto &f : p.proj) { is_lm[f.b[3]] = 1; for (int k = 0; k < 3; k++) other_use[f.b[k]] = 1; }
+    for (auto &f : p.proj) { is_lm[f.b[3]] = 1; for (int k = 0; k < 3; k++) other_use[f.b[k]] = 1; if (f.btd >= 0) other_use[f.btd] = 1; }
     for (auto &f : p.imu) for (int k = 0; k < 4; k++) other_use[f.b[k]] = 1;
     for (auto &f : p.prior) for (int b : f.b) other_use[b] = 1;
     int m_all = 0, n_lm_drop = 0;
@@ -931,6 +956,11 @@ static int pack_marg(const tcv_problem &p, double *const *drop, int ndrop, const
         std::stable_sort(porder.begin(), porder.end(), [&](int a, int b2) { return p.proj[a].b[3] < p.proj[b2].b[3]; });
     }
     H.block_mode = block_mode ? 1 : 0;
+    H.td_blk = -1;
+    for (size_t k = 0; k < p.proj.size(); k++) {
+        if (p.proj[k].btd != p.proj[0].btd) { set_error("projection factors must all be ProjectionTdFactors on one Td block, or none"); return TCV_ERR_UNSUPPORTED; }
+        if (p.proj[k].btd >= 0) H.td_blk = id_of[p.proj[k].btd];
+    }
     H.o_proj = imark();
     for (int k2 : porder) for (int k = 0; k < 4; k++) I.push_back(id_of[p.proj[k2].b[k]]);
     H.o_plast = imark();
@@ -972,11 +1002,12 @@ static int pack_marg(const tcv_problem &p, double *const *drop, int ndrop, const
         else if (f.sqrt_info != psi || f.loss_a != pla) { set_error("projection factors must share sqrt_info and loss"); return TCV_ERR_UNSUPPORTED; }
         if (p.blocks[f.b[3]].size != 1) { set_error("projection factor: 4th block must be an inverse depth"); return TCV_ERR_UNSUPPORTED; }
         D.insert(D.end(), f.pts, f.pts + 6);
+        if (f.btd >= 0) D.insert(D.end(), f.aux, f.aux + 8);
     }
     H.d_prior = dmark();
     if (pr) { D.insert(D.end(), pr->J0.begin(), pr->J0.end()); D.insert(D.end(), pr->r0.begin(), pr->r0.end()); D.insert(D.end(), pr->x0.begin(), pr->x0.end()); }
     H.d_misc = dmark();
-    D.insert(D.end(), p.G, p.G + 3); D.push_back(psi); D.push_back(pla); D.push_back(0.0);
+    D.insert(D.end(), p.G, p.G + 3); D.push_back(psi); D.push_back(pla); D.push_back(0.0); D.push_back(p.td_TR); D.push_back(p.td_ROW);
     if (D.size() & 1) D.push_back(0.0);
     return TCV_OK;
 }

@@ -119,7 +119,19 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int 
     const int nb = (int)p.blocks.size();
     // ---- classify blocks: landmarks = size-1 Euclidean blocks used only as 4th block of projection factors
     std::vector<int> use_lm(nb, 0), use_other(nb, 0);
-    for (auto &f : p.proj) { use_lm[f.b[3]]++; for (int k = 0; k < 3; k++) use_other[f.b[k]]++; }
+    for (auto &f : p.proj) { use_lm[f.b[3]]++; for (int k = 0; k < 3; k++) use_other[f.b[k]]++; if (f.btd >= 0) use_other[f.btd]++; }
+    // ProjectionTdFactor (ESTIMATE_TD): all point factors or none, one shared 1-dim Td block
+    int td_blk = -1;
+    for (size_t k = 0; k < p.proj.size(); k++) {
+        const ProjFac &f = p.proj[k];
+        if (k == 0) td_blk = f.btd;
+        else if (f.btd != td_blk) { set_error("projection factors must all be ProjectionTdFactors on one Td block, or none"); return TCV_ERR_UNSUPPORTED; }
+    }
+    if (td_blk >= 0) {
+        const ParamBlock &pb = p.blocks[td_blk];
+        if (pb.size != 1 || pb.kind != KIND_EUCLID) { set_error("Td must be a size-1 Euclidean block"); return TCV_ERR_UNSUPPORTED; }
+        mode = 1;      // the chain layout has no room for a block that couples with every pose: dense layout
+    }
     for (auto &f : p.imu) for (int k = 0; k < 4; k++) use_other[f.b[k]]++;
     for (auto &f : p.line) use_other[f.b]++;
     for (auto &f : p.prior) for (int b : f.b) use_other[b]++;
@@ -163,12 +175,19 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int 
     }
     for (int c = 0; c < nblk; c++)
         if (kind[c] == KIND_POSE && !p.blocks[out.cam_block[c]].constant) { loff[c] = nc; nc += 6; }
+    // Td comes right behind the poses: its column rides through the 6-wide gather machinery as a pseudo block whose other five
+    // columns are structural zeros, so five more tangent rows must follow it.  It counts as part of the "pose part" npp: the
+    // leading tangent dims the visual factors touch (landmark Schur corrections of the diagonal and the right-hand side).
+    const int td_cam = td_blk >= 0 ? cam_of[td_blk] : -1;
+    if (td_cam >= 0 && !p.blocks[td_blk].constant) { loff[td_cam] = nc; nc += 1; }
     const int npp = nc;
     for (int c = 0; c < nblk; c++)
-        if (kind[c] != KIND_POSE && !p.blocks[out.cam_block[c]].constant) { loff[c] = nc; nc += gsize[c]; }
+        if (kind[c] != KIND_POSE && c != td_cam && !p.blocks[out.cam_block[c]].constant) { loff[c] = nc; nc += gsize[c]; }
     if (nc < 1) { set_error("no free camera-side parameter block"); return TCV_ERR_INVALID; }
+    out.cam_loff = loff;
     const int nt = (nc + 1 + 15) / 16, ntp = (npp + 15) / 16;
     const int ntiles = nt * (nt + 1) / 2, pp_tiles = ntp * (ntp + 1) / 2;
+    if (td_cam >= 0 && loff[td_cam] >= 0 && loff[td_cam] + 6 > nt * 16) { set_error("Td block: no room for its gather slot"); return TCV_ERR_UNSUPPORTED; }
     if (nc > 175 || npp > 88 || nc + L > SCR_NL || L > 1024) { set_error("window too large for the fused solver (camera tangent dim > 175)"); return TCV_ERR_TOO_LARGE; }
     const int nxl = (nx + L + 1) & ~1;
     int area_cap = LDS_DOUBLES - ntiles * 256 - 2 * nxl - 4 * 176 - 64;
@@ -234,6 +253,9 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int 
     H.nblk = nblk; H.nland = L; H.nc = nc; H.nx = nx; H.npp = npp; H.nt = nt; H.ntp = ntp;
     H.n_imu = (int)p.imu.size(); H.n_proj = (int)p.proj.size(); H.n_line = (int)p.line.size();
     H.lds_area = area_cap;
+    H.flags = td_blk >= 0 ? 1 : 0; H.td_cam = td_cam;
+    const int prec = td_blk >= 0 ? (int)PROJ_TD_REC : (int)PROJ_REC;      // doubles per staged point record
+    const int td_t = td_cam >= 0 ? loff[td_cam] : -1;
     std::vector<int> &I = out.ints;
     I.clear();
     auto mark = [&]() { return (int)I.size(); };
@@ -261,6 +283,7 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int 
                 if (t < 0) continue;
                 if (std::find(lm_slots[l].begin(), lm_slots[l].end(), t) == lm_slots[l].end()) lm_slots[l].push_back(t);
             }
+            if (td_t >= 0 && std::find(lm_slots[l].begin(), lm_slots[l].end(), td_t) == lm_slots[l].end()) lm_slots[l].push_back(td_t);
         }
         if (lm_slots[l].size() > 40) { set_error("landmark observed from more than 40 blocks"); return TCV_ERR_TOO_LARGE; }
         if (e_off[l] >= (1 << 16) - 256) { set_error("landmark coupling store too large"); return TCV_ERR_TOO_LARGE; }
@@ -316,9 +339,10 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int 
         vch.clear();
         const int nline = (int)p.line.size();
         const int npose = npp / 6;
-        const int base_prog = 3 * (npose * (npose + 1) / 2 * 6 + npose) ;      // upper bound on tile + gradient units
+        const int npb = npose + (td_t >= 0 ? 1 : 0);
+        const int base_prog = 3 * (npb * (npb + 1) / 2 * 6 + npb);      // upper bound on tile + gradient units
         auto need = [&](int recs, int nf, int nl_, int slots, int nln) {
-            const int ints = base_prog + 3 * (slots + nl_) + 13 * nf + 2 * nln;
+            const int ints = base_prog + 3 * (slots + nl_) + (td_t >= 0 ? 19 : 13) * nf + 2 * nln;      // items per point factor: 6 (10) block pairs + 3 (4) gradients + 3 (4) landmark couplings + 1
             return ((recs + 1) & ~1) + (ints + 1) / 2 + 8;
         };
         if (need(nline * LINE_REC, 0, 0, 0, nline) > stage_cap) { set_error("too many line factors for LDS staging"); return TCV_ERR_TOO_LARGE; }
@@ -327,13 +351,13 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int 
         int recs = 0, hcl = 0, nf_c = 0, slots_c = 0;
         for (int l = 0; l < L; l++) {
             const int nf = lmptr[l + 1] - lmptr[l], ns = (int)lm_slots[l].size(), nh = 6 * ns + 2;
-            if (need(nf * PROJ_REC, nf, 1, ns, 0) > stage_cap || nh + 3 > area_cap) { set_error("landmark track too long for LDS staging"); return TCV_ERR_TOO_LARGE; }
-            if (need(recs + nf * PROJ_REC, nf_c + nf, cur.lmn + 1, slots_c + ns, 0) > stage_cap || hcl + nh + 3 * (cur.lmn + 1) > area_cap) {
+            if (need(nf * prec, nf, 1, ns, 0) > stage_cap || nh + 3 > area_cap) { set_error("landmark track too long for LDS staging"); return TCV_ERR_TOO_LARGE; }
+            if (need(recs + nf * prec, nf_c + nf, cur.lmn + 1, slots_c + ns, 0) > stage_cap || hcl + nh + 3 * (cur.lmn + 1) > area_cap) {
                 vch.push_back(cur);
                 cur = VChunk{lmptr[l], 0, 0, 0, l, 0};
                 recs = 0; hcl = 0; nf_c = 0; slots_c = 0;
             }
-            cur.pn += nf; cur.lmn += 1; recs += nf * PROJ_REC; hcl += nh; nf_c += nf; slots_c += ns;
+            cur.pn += nf; cur.lmn += 1; recs += nf * prec; hcl += nh; nf_c += nf; slots_c += ns;
         }
         if (nline > 0 && need(recs + nline * LINE_REC, nf_c, cur.lmn, slots_c, nline) > stage_cap) {
             vch.push_back(cur);
@@ -352,10 +376,12 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int 
         for (int k = 0; k < c.pn; k++) {
             const ProjFac &f = p.proj[order[c.pb + k]];
             const int l = lm_of[f.b[3]];
-            const int base = k * PROJ_REC;
+            const int base = k * prec;
+            if (base >= (1 << 21)) { set_error("staging offset overflow"); return TCV_ERR_TOO_LARGE; }
             auto mk = [&](int ca, int cb) { return (int)(((unsigned)base << 11) | ((unsigned)ca << 6) | ((unsigned)cb << 1)); };
             std::vector<Col> cols;
             for (int s2 = 0; s2 < 3; s2++) cols.push_back(Col{loff[cam_of[f.b[s2]]], 6 * s2, 6});
+            if (td_t >= 0) cols.push_back(Col{td_t, 20, 6});      // [td | 5 zero columns]
             for (size_t a2 = 0; a2 < cols.size(); a2++)
                 for (size_t b2 = 0; b2 < a2; b2++)
                     if (cols[a2].t >= 0 && cols[a2].t == cols[b2].t) { set_error("projection factor uses one block twice"); return TCV_ERR_UNSUPPORTED; }
@@ -369,7 +395,7 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int 
         }
         for (int k = 0; k < c.ln; k++) {
             const LineFac &f = p.line[c.lb + k];
-            const int base = c.pn * PROJ_REC + k * LINE_REC;
+            const int base = c.pn * prec + k * LINE_REC;
             if (base >= (1 << 21)) { set_error("staging offset overflow"); return TCV_ERR_TOO_LARGE; }
             auto mk = [&](int ca, int cb) { return (int)(((unsigned)base << 11) | ((unsigned)ca << 6) | ((unsigned)cb << 1) | 1u); };
             std::vector<Col> cols{Col{loff[cam_of[f.b]], 0, 6}};
@@ -390,7 +416,7 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int 
         }
         RowProg vp, sp;
         if (!emit_rows(dl, vp, false) || !emit_rows(sl, sp, false)) { set_error("gather program field overflow"); return TCV_ERR_TOO_LARGE; }
-        const int recs = (c.pn * PROJ_REC + c.ln * LINE_REC + 1) & ~1;
+        const int recs = (c.pn * prec + c.ln * LINE_REC + 1) & ~1;
         const int st_need = std::max(recs + ((int)(vp.units.size() + vp.items.size()) + 1) / 2 + 2, ((int)(sp.units.size() + sp.items.size()) + 1) / 2 + 2);
         const int ar_need = (e_off[c.lmb + c.lmn] - e_off[c.lmb]) + 3 * c.lmn + 8;
         max_stage = std::max(max_stage, st_need); max_area = std::max(max_area, ar_need);
@@ -417,7 +443,7 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int 
         const int nline = (int)p.line.size(), nproj = (int)p.proj.size();
         // lower bound on k from the records alone, then jump by the measured overshoot: two exact trials instead of k
         const int kmax = std::max(1, std::min(L, 48));
-        int k = std::max(1, (nproj * PROJ_REC + nline * LINE_REC + c_pool - 1) / std::max(1, c_pool));
+        int k = std::max(1, (nproj * prec + nline * LINE_REC + c_pool - 1) / std::max(1, c_pool));
         for (; k <= kmax && !found;) {
             std::vector<VChunk> cand;
             int l = 0;
@@ -590,6 +616,7 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int 
         if (k == 0) { psi = f.sqrt_info; pla = f.loss_a; }
         else if (f.sqrt_info != psi || f.loss_a != pla) { set_error("projection factors must share sqrt_info and loss"); return TCV_ERR_UNSUPPORTED; }
         D.insert(D.end(), f.pts, f.pts + 6);
+        if (td_blk >= 0) D.insert(D.end(), f.aux, f.aux + 8);
     }
     W.d_line = (int)D.size();
     double lla = 0;
@@ -611,7 +638,7 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int 
     W.d_prior = (int)D.size();
     if (pr) { D.insert(D.end(), pr->J0.begin(), pr->J0.end()); D.insert(D.end(), pr->r0.begin(), pr->r0.end()); D.insert(D.end(), pr->x0.begin(), pr->x0.end()); }
     W.d_misc = (int)D.size();
-    D.insert(D.end(), p.G, p.G + 3); D.push_back(psi); D.push_back(pla); D.push_back(lla);
+    D.insert(D.end(), p.G, p.G + 3); D.push_back(psi); D.push_back(pla); D.push_back(lla); D.push_back(p.td_TR); D.push_back(p.td_ROW);
     W.d_sqrt = -1;
     if (imu_sqrt && H.n_imu) { W.d_sqrt = (int)D.size(); D.insert(D.end(), imu_sqrt, imu_sqrt + 225 * H.n_imu); }
     if (D.size() & 1) D.push_back(0.0);

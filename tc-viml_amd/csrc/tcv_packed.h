@@ -27,6 +27,7 @@ enum { MAX_TRACE = 64 };
 enum {
     PROJ_STRIDE = 20,  // [pose_i 6 | pose_j 6 | ex 6 | inv depth 1 | r]
     PROJ_REC = 41,     // 2 rows x 20 + 1 pad: an odd record stride spreads same-column accesses of different factors over all LDS banks
+    PROJ_TD_STRIDE = 26, PROJ_TD_REC = 53,   // ProjectionTdFactor: [.. | r | td | 0 0 0 0 0]
     LINE_STRIDE = 7,   // [pose 6 | r]
     LINE_REC = 14,
     IMU_STRIDE_J = 31, // [pose_i 6 | sb_i 9 | pose_j 6 | sb_j 9 | r]
@@ -61,7 +62,10 @@ struct PlanHdr {
     int n_imu_chunk;    // IMU factors are staged through LDS in chunks
     int n_vis_chunk;    // point/line factors likewise (1 for the BASELINE configs)
     int lds_area;       // doubles of the time-shared LDS area
-    int flags;
+    int flags;          // bit 0: the point factors are ProjectionTdFactors (dense layout only)
+    int td_cam;         // camera block index of para_Td (-1 none); point records then carry 26 columns per row:
+                        // [.. 19 as below | r | td | 5 zeros] so that Td rides through the 6-wide gather machinery
+    int pad_td;
     // int-pool offsets (relative to the plan base)
     int o_blk;      // nblk x 4 : gsize, goff (ambient), loff (tangent, -1 constant), kind
     int o_imu;      // n_imu x 4 block ids
@@ -101,11 +105,11 @@ struct WinHdr {
     // double-pool offsets (relative to dbase)
     int d_x;        // nx + nland initial state (camera blocks in block order, then landmarks)
     int d_imu;      // n_imu x 287
-    int d_proj;     // n_proj x 6
+    int d_proj;     // n_proj x 6 (ProjectionTdFactor: x 14 = pts_i, pts_j, aux 8)
     int d_line;     // n_line x 9
     int d_linec;    // 21 : K, Ric, Tic (row-major)
     int d_prior;    // J0 (n x n column-major), r0 (n), x0 (prior_xsize)
-    int d_misc;     // G(3), proj sqrt_info, proj loss a, line loss a
+    int d_misc;     // G(3), proj sqrt_info, proj loss a, line loss a, TR, ROW
     int d_sqrt;     // optional host-provided sqrt_info, n_imu x 225 (-1: computed on device)
     int n_doubles;  // doubles of this window
     int pad1;

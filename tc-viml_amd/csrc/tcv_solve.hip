@@ -112,9 +112,9 @@ __device__ __forceinline__ void block_sum_n(double (&v)[N], lds_d *red, int tid)
 }
 
 // ---- row-unit gathers (tcv_packed.h): acc[e] += sum_rows rec[row][colA + ea] * rec[row][colB + e] ------------------
-__device__ __forceinline__ void vis_item1(const lds_d *stage, unsigned it, int ea, double (&acc)[6]) {
+__device__ __forceinline__ void vis_item1(const lds_d *stage, unsigned it, int ea, double (&acc)[6], int pstride) {
     const int type = it & 1, cb = (it >> 1) & 31, ca = (it >> 6) & 31, base = it >> 11;
-    const int ld = type ? LINE_STRIDE : PROJ_STRIDE;
+    const int ld = type ? LINE_STRIDE : pstride;
     const lds_d *rec = stage + base;
     const double a0 = rec[ca + ea], a1 = rec[ld + ca + ea];
     double b0[6], b1[6];
@@ -125,7 +125,7 @@ __device__ __forceinline__ void vis_item1(const lds_d *stage, unsigned it, int e
 }
 // Four items per trip: all item words, then all operands, are in flight before the first FMA (one wave per SIMD
 // cannot hide LDS latency by switching waves, so the loads are batched by hand).
-__device__ __forceinline__ void vis_items(const lds_d *stage, const lds_i *items, int k0, int k1, int kstep, int ea, double (&acc)[6]) {
+__device__ __forceinline__ void vis_items(const lds_d *stage, const lds_i *items, int k0, int k1, int kstep, int ea, double (&acc)[6], int pstride) {
     int k = k0;
     for (; k + 3 * kstep < k1; k += 4 * kstep) {
         unsigned it[4];
@@ -135,7 +135,7 @@ __device__ __forceinline__ void vis_items(const lds_d *stage, const lds_i *items
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int type = it[j] & 1, cb = (it[j] >> 1) & 31, ca = (it[j] >> 6) & 31, base = it[j] >> 11;
-            const int ld = type ? LINE_STRIDE : PROJ_STRIDE;
+            const int ld = type ? LINE_STRIDE : pstride;
             const lds_d *rec = stage + base;
             a0[j] = rec[ca + ea]; a1[j] = rec[ld + ca + ea];
 #pragma unroll
@@ -146,7 +146,7 @@ __device__ __forceinline__ void vis_items(const lds_d *stage, const lds_i *items
 #pragma unroll
             for (int e = 0; e < 6; e++) acc[e] += a0[j] * b0[j][e] + a1[j] * b1[j][e];
     }
-    for (; k < k1; k += kstep) vis_item1(stage, (unsigned)items[k], ea, acc);
+    for (; k < k1; k += kstep) vis_item1(stage, (unsigned)items[k], ea, acc, pstride);
 }
 
 // Schur item: hoff << 18 | nslot << 12 | slotA << 6 | slotB   (slotA = 63: the landmark's gl / kappa instead of Hcl[slotA])
@@ -270,6 +270,9 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
     const double G3[3] = {misc[0], misc[1], misc[2]};
     const double proj_sqrt = misc[3], proj_loss = misc[4], line_loss = misc[5];
     const int pp_elems = CHAIN ? (C.ntiles << 8) : ((P.ntp * (P.ntp + 1) / 2) << 8);
+    // ProjectionTdFactor windows (dense layout only): wider point records, see tcv_packed.h
+    const bool with_td = !CHAIN && (P.flags & 1);
+    const int prec = with_td ? (int)PROJ_TD_REC : (int)PROJ_REC, pstr = with_td ? (int)PROJ_TD_STRIDE : (int)PROJ_STRIDE;
     double cost_acc = 0.0;
 
     if (assemble) {
@@ -286,7 +289,7 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
         const int pb = vc[0], pn = vc[1], lb = vc[2], ln = vc[3], voff = vc[4], vnu = vc[5], vnw = vc[6], vni = vc[7];
         const int lmb = vc[8], lmn = vc[9], ebase = vc[10], esize = vc[11], soff = vc[12], snu = vc[13], snw = vc[14], sni = vc[15];
         lds_d *hcl = C.area, *hll = C.area + esize, *gl = hll + lmn;
-        lds_i *lprog = (lds_i *)(C.stage + ((pn * PROJ_REC + ln * LINE_REC + 1) & ~1));   // gather program behind the records
+        lds_i *lprog = (lds_i *)(C.stage + ((pn * prec + ln * LINE_REC + 1) & ~1));   // gather program behind the records
         if (assemble) {
             for (int i = tid; i < esize + 2 * lmn; i += NT) C.area[i] = 0.0;
             copy_prog<NT>(lprog, ip + P.o_vdest + voff, 3 * vnu + vni, tid);
@@ -296,8 +299,30 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
             cst_i *pf = ip + P.o_proj + (pb + f) * 4;
             const lds_d *xi = x + blk[pf[0] * 4 + 1], *xj = x + blk[pf[1] * 4 + 1], *xe = x + blk[pf[2] * 4 + 1];
             const double lam = x[nx + pf[3]];
-            lds_d *rec = C.stage + f * PROJ_REC;
+            lds_d *rec = C.stage + f * prec;
             double r[2];
+            if (with_td) {      // ProjectionTdFactor (projection_td_factor.cpp:34-140): 20 Jacobian columns, Td last
+                const double tdv = x[blk[P.td_cam * 4 + 1]];
+                double pts[6], aux[8], Jl[40];
+#pragma unroll
+                for (int i = 0; i < 6; i++) pts[i] = dp[C.W->d_proj + (pb + f) * 14 + i];
+#pragma unroll
+                for (int i = 0; i < 8; i++) aux[i] = dp[C.W->d_proj + (pb + f) * 14 + 6 + i];
+                proj_td_eval(CGEN(xi), CGEN(xj), CGEN(xe), lam, tdv, pts, aux, proj_sqrt, misc[6], misc[7], r, assemble ? Jl : nullptr, 20);
+                cost_acc += loss_correct2(r, assemble ? Jl : nullptr, 20, 20, proj_loss);
+                if (assemble) {
+#pragma unroll
+                    for (int row = 0; row < 2; row++) {
+#pragma unroll
+                        for (int c2 = 0; c2 < 19; c2++) rec[row * PROJ_TD_STRIDE + c2] = Jl[row * 20 + c2];
+                        rec[row * PROJ_TD_STRIDE + 19] = r[row];
+                        rec[row * PROJ_TD_STRIDE + 20] = Jl[row * 20 + 19];
+#pragma unroll
+                        for (int c2 = 21; c2 < 26; c2++) rec[row * PROJ_TD_STRIDE + c2] = 0.0;
+                    }
+                }
+                continue;
+            }
             double *J = assemble ? GEN(rec) : nullptr;
             double pts[6];
 #pragma unroll
@@ -309,7 +334,7 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
         for (int f = tid; f < ln; f += NT) {
             const int b = ip[P.o_line + lb + f];
             const lds_d *xp = x + blk[b * 4 + 1];
-            lds_d *rec = C.stage + pn * PROJ_REC + f * LINE_REC;
+            lds_d *rec = C.stage + pn * prec + f * LINE_REC;
             double r[2];
             double *J = assemble ? GEN(rec) : nullptr;
             double ld9[9], lc[21];
@@ -338,8 +363,8 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
                     const int kind = u0 >> 28, ncols = (u0 >> 24) & 15, ea = (u0 >> 20) & 15, n = u0 & 0xfffff;
                     const int o0 = u1 >> 16, o1 = u1 & 0xffff;
                     double acc[6] = {0, 0, 0, 0, 0, 0};
-                    if (wv) { vis_items(C.stage, items, ib + lane, ib + n, 64, ea, acc); wave_sum<6>(acc); if (lane != 0) continue; }
-                    else vis_items(C.stage, items, ib, ib + n, 1, ea, acc);
+                    if (wv) { vis_items(C.stage, items, ib + lane, ib + n, 64, ea, acc, pstr); wave_sum<6>(acc); if (lane != 0) continue; }
+                    else vis_items(C.stage, items, ib, ib + n, 1, ea, acc, pstr);
                     if (kind == DK_TILE) {
 #pragma unroll
                         for (int e = 0; e < 6; e++) if (e < ncols) C.tiles[tix(o0 + ea, o1 + e)] += acc[e];

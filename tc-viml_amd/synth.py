@@ -486,3 +486,22 @@ def window_at(batch: dict, b: int) -> dict:
     out = {k: take(k, v) for k, v in batch.items()}
     out["B"] = 1
     return out
+
+
+def with_time_offset(win: dict, seed: int = 0, td_true: float = 0.004, TR: float = 0.02, ROW: float = IMG_H) -> dict:
+    """ESTIMATE_TD variant of a single window (estimator.cpp:1703-1707, :1757-1763): every point factor becomes a
+    ProjectionTdFactor on the extra block para_Td[0].  Feature velocities on the normalised plane, image rows and the time
+    offsets the observations were stamped with (td_i = td_j = 0, the previous estimate) are drawn at random; the observations
+    are shifted so that they are consistent at td = td_true (rolling-shutter read-out TR over ROW rows).  td starts at 0."""
+    rng = np.random.Generator(np.random.PCG64(0x7D + seed))
+    pr = dict(win["proj"])
+    n = len(pr["frame_i"])
+    vel_i = rng.normal(size=(n, 2)) * 0.4; vel_j = rng.normal(size=(n, 2)) * 0.4
+    row_i = rng.uniform(0.0, ROW, n); row_j = rng.uniform(0.0, ROW, n)
+    td_i = np.zeros(n); td_j = np.zeros(n)
+    pts_i = np.array(pr["pts_i"], dtype=float).copy(); pts_j = np.array(pr["pts_j"], dtype=float).copy()
+    pts_i[:, :2] += (td_true - td_i + TR / ROW * (row_i - ROW / 2))[:, None] * vel_i      # projection_td_factor.cpp:50-51 undone
+    pts_j[:, :2] += (td_true - td_j + TR / ROW * (row_j - ROW / 2))[:, None] * vel_j
+    pr.update(pts_i=pts_i, pts_j=pts_j, vel_i=vel_i, vel_j=vel_j, td_i=td_i, td_j=td_j, row_i=row_i, row_j=row_j, TR=float(TR), ROW=float(ROW))
+    out = dict(win, proj=pr, td=0.0)
+    return out

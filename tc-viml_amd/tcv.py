@@ -29,7 +29,7 @@ EXPORTS = [
     "tcv_version", "tcv_last_error", "tcv_device_count", "tcv_set_device",
     "tcv_problem_create", "tcv_problem_destroy", "tcv_problem_add_parameter_block",
     "tcv_problem_set_parameter_block_constant", "tcv_problem_set_gravity", "tcv_problem_add_imu_factor",
-    "tcv_problem_add_projection_factor", "tcv_problem_add_line_factor", "tcv_problem_add_marginalization_factor",
+    "tcv_problem_add_projection_factor", "tcv_problem_add_projection_td_factor", "tcv_problem_set_rolling_shutter", "tcv_problem_add_line_factor", "tcv_problem_add_marginalization_factor",
     "tcv_problem_from_window", "tcv_problem_num_parameter_blocks", "tcv_problem_num_residual_blocks",
     "tcv_problem_num_residuals", "tcv_problem_plan_stats", "tcv_solver_options_default", "tcv_solve", "tcv_marginalize",
     "tcv_prior_create", "tcv_prior_dims", "tcv_prior_export", "tcv_prior_export_schur", "tcv_prior_keep_block_addresses", "tcv_prior_destroy",
@@ -73,7 +73,8 @@ class WindowDesc(C.Structure):
                 ("line_frame", _ip), ("line_data", _dp),
                 ("line_K", C.c_double * 9), ("line_Ric", C.c_double * 9), ("line_Tic", C.c_double * 3),
                 ("line_loss_a", C.c_double), ("gravity", C.c_double * 3),
-                ("prior", C.c_void_p), ("prior_block_kind", _ip), ("prior_block_index", _ip)]
+                ("prior", C.c_void_p), ("prior_block_kind", _ip), ("prior_block_index", _ip),
+                ("para_td", _dp), ("proj_td_aux", _dp), ("td_TR", C.c_double), ("td_ROW", C.c_double)]
 
 
 _lib = None
@@ -104,6 +105,8 @@ def lib():
         L.tcv_problem_add_imu_factor.argtypes = [vp, C.POINTER(ImuPreintegration), _dp, _dp, _dp, _dp]
         L.tcv_problem_add_projection_factor.argtypes = [vp, _dp, _dp, C.c_double, C.c_double, _dp, _dp, _dp, _dp]
         L.tcv_problem_add_line_factor.argtypes = [vp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_double, _dp]
+        L.tcv_problem_add_projection_td_factor.argtypes = [vp, _dp, _dp, _dp, _dp] + [C.c_double] * 6 + [_dp] * 5
+        L.tcv_problem_set_rolling_shutter.argtypes = [vp, C.c_double, C.c_double]
         L.tcv_problem_add_marginalization_factor.argtypes = [vp, vp, C.POINTER(_dp), C.c_int]
         L.tcv_problem_from_window.argtypes = [C.POINTER(WindowDesc), C.POINTER(vp)]
         for f in ("tcv_problem_num_parameter_blocks", "tcv_problem_num_residual_blocks", "tcv_problem_num_residuals"):
@@ -241,7 +244,7 @@ class Prior:
             self.h = None
 
 
-_KIND = {"pose": 0, "sb": 1, "ex": 2}
+_KIND = {"pose": 0, "sb": 1, "ex": 2, "td": 3}
 
 
 class Window:
@@ -251,8 +254,9 @@ class Window:
     def __init__(self, win: dict, estimate_extrinsic=True, prior: Prior | None = None, share: "Window | None" = None):
         self.win = win
         if share is not None:      # same caller-owned state arrays (parameter blocks are identified by address)
-            self.pose, self.sb, self.ex, self.lam = share.pose, share.sb, share.ex, share.lam
+            self.pose, self.sb, self.ex, self.lam, self.td = share.pose, share.sb, share.ex, share.lam, share.td
         else:
+            self.td = None if win.get("td") is None else f64([float(win["td"])])      # para_Td[0] (ESTIMATE_TD)
             self.pose = f64(win["pose"]).copy(); self.sb = f64(win["speedbias"]).copy()
             self.ex = f64(win["ex_pose"]).copy(); self.lam = f64(win["lam"]).copy()
         im, pr, ln = win["imu"], win["proj"], win["line"]
@@ -274,6 +278,11 @@ class Window:
         d.line_K[:] = list(np.asarray(ln["K"]).reshape(9)); d.line_Ric[:] = list(np.asarray(ln["Ric"]).reshape(9))
         d.line_Tic[:] = list(np.asarray(ln["Tic"]).reshape(3)); d.line_loss_a = float(ln["loss_a"] or 0.0)
         d.gravity[:] = list(np.asarray(win["G"]).reshape(3))
+        if self.td is not None:
+            n = len(self._pi)
+            self._aux = f64(np.concatenate([np.asarray(pr["vel_i"], dtype=float).reshape(n, 2), np.asarray(pr["vel_j"], dtype=float).reshape(n, 2),
+                                            np.stack([np.asarray(pr[k], dtype=float).reshape(n) for k in ("td_i", "td_j", "row_i", "row_j")], -1)], -1)) if n else np.zeros((0, 8))
+            d.para_td = dptr(self.td); d.proj_td_aux = dptr(self._aux); d.td_TR = float(pr["TR"]); d.td_ROW = float(pr["ROW"])
         self.prior = prior
         if prior is None and win.get("prior") is not None:
             self.prior = Prior.from_dict(win["prior"])
@@ -286,7 +295,10 @@ class Window:
         check(lib().tcv_problem_from_window(C.byref(d), C.byref(self.h)))
 
     def states(self):
-        return dict(pose=self.pose.copy(), sb=self.sb.copy(), ex=self.ex.copy(), lam=self.lam.copy())
+        out = dict(pose=self.pose.copy(), sb=self.sb.copy(), ex=self.ex.copy(), lam=self.lam.copy())
+        if self.td is not None:
+            out["td"] = self.td.copy()
+        return out
 
     def plan_stats(self):
         out = np.zeros(16, np.int32)
@@ -302,6 +314,8 @@ class Window:
             return C.cast(C.addressof(self.sb.ctypes.data_as(_dp).contents) + 72 * i, _dp)
         if name == "ex":
             return dptr(self.ex)
+        if name == "td":
+            return dptr(self.td)
         return C.cast(C.addressof(self.lam.ctypes.data_as(_dp).contents) + 8 * i, _dp)
 
     def __del__(self):
@@ -356,6 +370,8 @@ def prior_blocks(prior: "Prior", w: "Window", shift):
     addrs = (_dp * nb)()
     check(lib().tcv_prior_keep_block_addresses(prior.h, addrs))
     base = {"pose": (w.pose.ctypes.data, 56, w.pose.shape[0]), "sb": (w.sb.ctypes.data, 72, w.sb.shape[0]), "ex": (w.ex.ctypes.data, 56, 1)}
+    if getattr(w, "td", None) is not None:
+        base["td"] = (w.td.ctypes.data, 8, 1)
     out = []
     for k in range(nb):
         a = C.cast(addrs[k], C.c_void_p).value
@@ -364,7 +380,7 @@ def prior_blocks(prior: "Prior", w: "Window", shift):
                 out.append(tuple(shift(name, (a - b0) // stride)))
                 break
         else:
-            raise ValueError("kept block is not a pose / speed-bias / extrinsic block")
+            raise ValueError("kept block is not a pose / speed-bias / extrinsic / td block")
     return out
 
 

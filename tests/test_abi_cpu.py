@@ -136,6 +136,23 @@ def test_window_description_is_validated_before_it_is_walked(tcv):
     assert L.tcv_batch_create(C.byref(b), arr, None, None, None, 2) == tcv.TCV_ERR_INVALID and b"null problem" in L.tcv_last_error()
 
 
+def test_time_offset_windows_use_the_dense_layout(tcv):
+    """ESTIMATE_TD: para_Td rides behind the poses in tangent space (nc = 172), the plan is laid out for the dense kernel; mixing
+    ProjectionFactors and ProjectionTdFactors in one problem is refused."""
+    L = tcv.lib()
+    w = synth.with_time_offset(synth.window_at(synth.make_windows(3, 1), 0), 3)
+    W = tcv.Window(w)
+    st = W.plan_stats()
+    assert st["nc"] == 172 and st["npp"] == 73 and st["nt"] == 11 and st["lds_bytes"] == 160 * 1024
+    assert L.tcv_problem_num_parameter_blocks(W.h) == 11 * 2 + 1 + 1 + 50
+    pts = np.array([0.1, 0.2, 1.0])
+    assert L.tcv_problem_add_projection_factor(W.h, tcv.dptr(pts), tcv.dptr(pts), 306.0, 1.0, W.block_ptr("pose", 0), W.block_ptr("pose", 1),
+                                               W.block_ptr("ex", 0), W.block_ptr("lam", 0)) == 0
+    out = np.zeros(16, np.int32)
+    assert L.tcv_problem_plan_stats(W.h, tcv.iptr(out)) == tcv.TCV_ERR_UNSUPPORTED and b"ProjectionTdFactors" in L.tcv_last_error()
+    assert L.tcv_problem_set_rolling_shutter(W.h, 0.02, 0.0) == tcv.TCV_ERR_INVALID
+
+
 def test_too_many_frames_is_rejected(tcv):
     # 13 frames -> camera tangent dim 201 > 175: the LDS-resident solver refuses instead of truncating
     L = tcv.lib()

@@ -1,0 +1,74 @@
+"""T1 in the solver: ESTIMATE_TD windows -- every point factor a ProjectionTdFactor on the extra 1-dim block
+para_Td[0] (estimator.cpp:1703-1707, :1757-1763) -- solved and marginalised by the HIP path (dense layout of the fused solver)
+against the NumPy restatement (oracle/np_oracle.py)."""
+import numpy as np
+import pytest
+
+import np_oracle as NO
+import synth
+from util import fro, rel
+
+pytestmark = pytest.mark.gpu
+
+CASE = {"GAUSS_NEWTON": 1, "CAUCHY": 2, "DOGLEG": 3}
+
+
+def td_window(seed, **kw):
+    return synth.with_time_offset(synth.window_at(synth.make_windows(seed, 1), 0), seed, **kw)
+
+
+@pytest.mark.parametrize("seed,TR", [(21, 0.0), (22, 0.02)])
+def test_td_window_solve_vs_oracle(gpu, seed, TR):
+    w = td_window(seed, TR=TR)
+    W = gpu.Window(w)
+    b = gpu.Batch([W])
+    assert b.plan_stats()["layout"] == "dense"                       # Td couples with every pose: no chain layout
+    b.solve(gpu.default_options(8, True)); b.synchronize(); b.download_states()
+    s = b.summaries()[0]
+    P = NO.Problem(w)
+    x, so = NO.solve(P, 8, True)
+    its = so["iterations"]
+    assert s.num_iterations == len(its)
+    assert abs(s.initial_cost - so["initial_cost"]) < 1e-9 * so["initial_cost"]
+    assert abs(s.final_cost - so["final_cost"]) < 1e-6 * so["final_cost"]
+    assert [s.step_ok[i] for i in range(1, len(its))] == [int(it["step_ok"]) for it in its[1:]]
+    assert rel(W.pose, x["pose"]) < 1e-6 and rel(W.sb, x["sb"]) < 1e-6 and rel(W.lam, x["lam"]) < 1e-5
+    assert abs(W.td[0] - x["td"][0]) < 1e-6 * max(1e-3, abs(x["td"][0]))
+    assert 0.001 < W.td[0] < 0.006                                   # moving from 0 towards the true offset of 4 ms
+    # plain ProjectionFactors on the same data give another answer: the Td column is really in the system
+    w0 = dict(w); w0.pop("td")
+    W0 = gpu.Window(w0); b0 = gpu.Batch([W0]); b0.solve(gpu.default_options(8, True)); b0.synchronize()
+    assert b0.summaries()[0].final_cost > 1.05 * s.final_cost
+
+
+def test_td_window_marginalisation_vs_oracle(gpu):
+    """MARGIN_OLD with ProjectionTdFactors among the marginalised factors (estimator.cpp:1962-1972): para_Td is a kept block, so
+    the new prior has n = 76 and a size-1 block at the end; then the chained window uses that prior (kind 3 = Td)."""
+    w = td_window(23)
+    P = NO.Problem(w)
+    x, _ = NO.solve(P, 8, True)
+    w2 = dict(w, pose=x["pose"], speedbias=x["sb"], ex_pose=x["ex"], lam=x["lam"], td=float(x["td"][0]))
+    po, dbg = NO.marginalize_old(NO.Problem(w2), NO.Problem(w2).x0())
+    mw = gpu.margin_old_window(w2)
+    Wm = gpu.Window(mw)
+    b = gpu.Batch([Wm], [Wm], [gpu.margin_old_drops(Wm, mw)])
+    b.marginalize(); b.synchronize()
+    Pr = b.prior(0); d = Pr.export(); As, bs = Pr.schur()
+    assert (d["m"], d["n"]) == (po["m"], po["n"]) and d["n"] == 76 and d["sizes"] == po["sizes"] and d["sizes"][-1] == 1
+    assert gpu.shifted_prior_blocks(Pr, Wm) == [tuple(bk) for bk in po["blocks"]]
+    assert fro(As, dbg["A_schur"]) < 1e-5 and fro(bs, dbg["b_schur"]) < 1e-6
+    assert fro(d["J0"].T @ d["J0"], dbg["A_schur"]) < 1e-5
+    # the next window with this prior attached: both sides solve it and agree
+    nxt = synth.with_time_offset(synth.window_at(synth.make_windows(24, 1), 0), 24)
+    keep = dict(po, blocks=[tuple(bk) for bk in po["blocks"]])
+    x0 = []
+    for (nm, i), v in zip(keep["blocks"], po["x0"]):
+        cur = {"pose": nxt["pose"], "sb": nxt["speedbias"]}.get(nm)
+        x0.append(np.array(cur[i], dtype=float).copy() if cur is not None else (np.array(nxt["ex_pose"], dtype=float).copy() if nm == "ex" else np.array([0.0])))
+    keep["x0"] = x0                                                   # linearised at the new window's own initial states
+    nxt = dict(nxt, prior=keep)
+    W = gpu.Window(nxt); b2 = gpu.Batch([W]); b2.solve(gpu.default_options(8, True)); b2.synchronize(); b2.download_states()
+    s = b2.summaries()[0]
+    x2, so = NO.solve(NO.Problem(nxt), 8, True)
+    assert abs(s.final_cost - so["final_cost"]) < 1e-6 * so["final_cost"]
+    assert rel(W.pose, x2["pose"]) < 1e-6 and abs(W.td[0] - x2["td"][0]) < 1e-6 * max(1e-3, abs(x2["td"][0]))

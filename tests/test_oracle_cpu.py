@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import np_oracle as npo
+import synth
 import orc
 from util import fro, golden_windows, imu_pre, load, rel
 
@@ -239,3 +240,27 @@ def test_c_oracle_projection_td_matches_golden_and_is_a_true_derivative(lib):
         if k >= 36:
             r0, J0 = NO.proj_evaluate(p[0:7], p[7:14], p[14:21], p[21], pts[:3], pts[3:], float(z["sqrt_info"]))
             assert np.array_equal(r0, z["res"][k]) and np.abs(z["J_td"][k]).max() == 0.0
+
+
+def test_time_offset_window_in_the_numpy_oracle():
+    """ESTIMATE_TD (estimator.cpp:1703-1707, :1757-1763): para_Td[0] is one more camera-side block, every point factor a
+    ProjectionTdFactor.  The Td column of the stacked Jacobian is a true derivative (finite differences), the solve moves Td
+    towards the offset the observations were generated with, and MARGIN_OLD keeps Td (prior n = 76, last block of size 1)."""
+    w = synth.with_time_offset(synth.window_at(synth.make_windows(31, 1), 0), 31, td_true=0.004, TR=0.02)
+    P = npo.Problem(w)
+    assert P.nc == 172 and P.loff[("td", 0)] == 171
+    x = P.x0()
+    J, r, c = P.linearize(x)
+    h = 1e-7
+    xp = dict(x, td=x["td"] + h); xm = dict(x, td=x["td"] - h)
+    # the robust corrector rescales J and r, so the finite difference is taken on the un-robustified residuals
+    w0 = dict(w, proj=dict(w["proj"], loss_a=0.0)); P0 = npo.Problem(w0)
+    J0, r0, _ = P0.linearize(x)
+    fd = (P0.linearize(xp, want_jac=False)[1] - P0.linearize(xm, want_jac=False)[1]) / (2 * h)
+    assert np.abs(J0[:, 171] - fd).max() < 1e-5 * max(1.0, np.abs(fd).max())
+    x8, so = npo.solve(P, 8, True)
+    assert so["final_cost"] < 1e-3 * so["initial_cost"]
+    assert abs(x8["td"][0] - 0.004) < abs(x["td"][0] - 0.004)
+    po, dbg = npo.marginalize_old(P, x8)
+    assert po["n"] == 76 and po["sizes"][-1] == 1 and tuple(po["blocks"][-1]) == ("td", 0)
+    assert np.abs(po["J0"].T @ po["J0"] - dbg["A_schur"]).max() < 1e-6 * np.abs(dbg["A_schur"]).max()
