@@ -60,6 +60,17 @@ struct ProjectionFactor : CostFunction {                                  // pro
     double pts_i[3], pts_j[3];
     static double &sqrt_info() { static double s = 460.0 / 1.5; return s; }      // ProjectionFactor::sqrt_info = FOCAL_LENGTH / 1.5 * I (estimator.cpp:48)
 };
+struct ProjectionTdFactor : CostFunction {                                // projection_td_factor.h:11-30 (ESTIMATE_TD)
+    template <class A, class B, class Cc, class D>
+    ProjectionTdFactor(const A &pts_i_, const B &pts_j_, const Cc &velocity_i_, const D &velocity_j_, double td_i_, double td_j_, double row_i_, double row_j_)
+        : td_i(td_i_), td_j(td_j_), row_i(row_i_), row_j(row_j_) {
+        std::memcpy(pts_i, detail::ptr(pts_i_), 24); std::memcpy(pts_j, detail::ptr(pts_j_), 24);
+        std::memcpy(velocity_i, detail::ptr(velocity_i_), 16); std::memcpy(velocity_j, detail::ptr(velocity_j_), 16);
+    }
+    double pts_i[3], pts_j[3], velocity_i[2], velocity_j[2], td_i, td_j, row_i, row_j;
+    static double &TR() { static double v = 0.0; return v; }                     // the globals TR and ROW (parameters.cpp)
+    static double &ROW() { static double v = 1.0; return v; }
+};
 struct LineProjectionFactor : CostFunction {                              // line_projection_factor.cpp:6-17; K, b_c_R row-major
     template <class A, class B, class Cc, class D, class E, class F>
     LineProjectionFactor(const A &ps, const B &pe, const Cc &abc, const D &K_, const E &R_, const F &T_) {
@@ -99,6 +110,13 @@ class Problem {                                                           // cer
     void AddResidualBlock(ProjectionFactor *f, LossFunction *loss, double *pose_i, double *pose_j, double *ex, double *inv_depth) {
         detail::check(tcv_problem_add_projection_factor(p_, f->pts_i, f->pts_j, ProjectionFactor::sqrt_info(), loss ? loss->scale() : 0.0, pose_i, pose_j, ex,
                                                         inv_depth), "AddResidualBlock(ProjectionFactor)");
+        own(owned_cost_, f); if (loss) own(owned_loss_, loss);
+    }
+    void AddResidualBlock(ProjectionTdFactor *f, LossFunction *loss, double *pose_i, double *pose_j, double *ex, double *inv_depth, double *td) {
+        detail::check(tcv_problem_set_rolling_shutter(p_, ProjectionTdFactor::TR(), ProjectionTdFactor::ROW()), "tcv_problem_set_rolling_shutter");
+        detail::check(tcv_problem_add_projection_td_factor(p_, f->pts_i, f->pts_j, f->velocity_i, f->velocity_j, f->td_i, f->td_j, f->row_i, f->row_j,
+                                                           ProjectionFactor::sqrt_info(), loss ? loss->scale() : 0.0, pose_i, pose_j, ex, inv_depth, td),
+                      "AddResidualBlock(ProjectionTdFactor)");
         own(owned_cost_, f); if (loss) own(owned_loss_, loss);
     }
     void AddResidualBlock(LineProjectionFactor *f, LossFunction *loss, double *pose) {
@@ -210,6 +228,12 @@ inline void MarginalizationInfo::marginalize() {
             for (int k = 0; k < 3; k++) detail::check(tcv_problem_add_parameter_block(mp.handle(), b[k], 7, TCV_PARAM_POSE), "marg pose");
             detail::check(tcv_problem_add_projection_factor(mp.handle(), pf->pts_i, pf->pts_j, ProjectionFactor::sqrt_info(),
                                                             r->loss_function ? r->loss_function->scale() : 0.0, b[0], b[1], b[2], b[3]), "marg projection");
+        } else if (auto *tf = dynamic_cast<ProjectionTdFactor *>(r->cost_function)) {
+            for (int k = 0; k < 3; k++) detail::check(tcv_problem_add_parameter_block(mp.handle(), b[k], 7, TCV_PARAM_POSE), "marg pose");
+            detail::check(tcv_problem_set_rolling_shutter(mp.handle(), ProjectionTdFactor::TR(), ProjectionTdFactor::ROW()), "marg rolling shutter");
+            detail::check(tcv_problem_add_projection_td_factor(mp.handle(), tf->pts_i, tf->pts_j, tf->velocity_i, tf->velocity_j, tf->td_i, tf->td_j, tf->row_i,
+                                                               tf->row_j, ProjectionFactor::sqrt_info(), r->loss_function ? r->loss_function->scale() : 0.0,
+                                                               b[0], b[1], b[2], b[3], b[4]), "marg projection td");
         } else if (auto *mf = dynamic_cast<MarginalizationFactor *>(r->cost_function)) {
             const tcv_prior *pr = mf->marginalization_info->prior();
             int m_, n_, nb, xs;
