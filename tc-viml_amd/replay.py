@@ -368,7 +368,7 @@ class Replay:
         given = None
         if self.fov_ready:
             given = np.array([self.fov[i] if self.fov[i] is not None else np.zeros(len(self.map_lines), bool) for i in range(W + 1)])
-        fov_now, _, _, _ = self.backend.match_lines(pose, ex, None, np.zeros(0, np.int32), np.zeros((0, 4)))
+        fov_now, _, _, _ = self.backend.match_lines(pose, ex, None, np.zeros(0, np.int32), np.zeros((0, 4)), map3d=(self.map_lines, self.Rbw, self.Tbw))
         if not self.fov_ready:
             for i in range(W + 1):
                 self.fov[i] = fov_now[i].copy()          # initialLineFoVWindow (:483-497)
@@ -377,7 +377,7 @@ class Replay:
             self.fov[W] = fov_now[W].copy()              # UpdateLinesInFoV(frame_count) (:385-447)
         given = np.array(self.fov)
         if det:
-            _, match, err, _ = self.backend.match_lines(pose, ex, given, np.array(det_frame, dtype=np.int32), np.array(det))
+            _, match, err, _ = self.backend.match_lines(pose, ex, given, np.array(det_frame, dtype=np.int32), np.array(det), map3d=(self.map_lines, self.Rbw, self.Tbw))
             for ob, f, m, e in zip(where, det_frame, match, err):
                 ob["errA"], ob["errD"], ob["overlap"] = float(e[0]), float(e[1]), float(e[2])
                 idx = np.nonzero(given[f])[0]
@@ -685,8 +685,10 @@ class HipBackend:
     def set_map(self, lines3d, Rbw, Tbw):
         self.map = (np.asarray(lines3d, dtype=float), np.asarray(Rbw, dtype=float), np.asarray(Tbw, dtype=float))
 
-    def match_lines(self, poses, ex, fov, det_frame, det):
-        lines3d, Rbw, Tbw = self.map
+    def match_lines(self, poses, ex, fov, det_frame, det, map3d=None):
+        """map3d = (lines3d, Rbw, Tbw) of the calling sequence (every sequence of a lock-step replay has its own prior map);
+        None: the map of the last set_map call."""
+        lines3d, Rbw, Tbw = [np.asarray(a, dtype=float) for a in map3d] if map3d is not None else self.map
         return self.tcv.match_lines(poses, ex, Rbw, Tbw, synth.K_MAT, int(synth.IMG_W), int(synth.IMG_H), WINDOW_SIZE, lines3d, det_frame, det,
                                     0.1745, 0.45, in_fov=fov)            # angle_th / overlap_th: sensor.yaml:119-122
 

@@ -22,8 +22,8 @@ class OracleBackend:
     def set_map(self, lines3d, Rbw, Tbw):
         self.map = (np.asarray(lines3d, dtype=float), np.asarray(Rbw, dtype=float), np.asarray(Tbw, dtype=float))
 
-    def match_lines(self, poses, ex, fov, det_frame, det):
-        lines3d, Rbw, Tbw = self.map
+    def match_lines(self, poses, ex, fov, det_frame, det, map3d=None):
+        lines3d, Rbw, Tbw = [np.asarray(a, dtype=float) for a in map3d] if map3d is not None else self.map
         W, H = int(synth.IMG_W), int(synth.IMG_H)
         if fov is None:
             fov = np.array([NO.lines_in_fov(poses[k], ex, Rbw, Tbw, synth.K_MAT, W, H, synth.WINDOW_SIZE, lines3d) for k in range(poses.shape[0])])

@@ -121,3 +121,15 @@ def test_replay_on_a_euroc_trajectory_with_the_oracle_back_end():
     assert len(i) == 40
     assert ate.ate_rmse(out["p"][i], stream["gt_p"][j]) < 0.08
     assert ate.ate_rmse(out["p"][i], stream["gt_p"][j], align=False) < 0.25
+
+
+def test_lock_step_replay_keeps_the_prior_maps_of_the_sequences_apart():
+    """two sequences with DIFFERENT prior line maps in one lock-step replay, association in the loop: each is matched against
+    its own map (same result as replayed alone)."""
+    streams = [replay.simulate_stream_euroc(s, 16, start_s=1.0, max_features=30, max_lines=5, associate=True) for s in ("V1_02_medium", "V2_01_easy")]
+    assert streams[0]["map_lines"].shape != streams[1]["map_lines"].shape
+    many = replay.run_many(streams, OracleBackend(), num_iterations=4)
+    for st, m in zip(streams, many):
+        one = replay.run(st, OracleBackend(), num_iterations=4)
+        assert np.array_equal(one["p"], m["p"]) and [l["n_line"] for l in one["log"]] == [l["n_line"] for l in m["log"]]
+        assert all(l["n_line"] > 0 for l in m["log"])
