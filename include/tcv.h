@@ -150,6 +150,8 @@ int tcv_problem_add_line_factor(tcv_problem *p, const double pts_start[3], const
                                 const double line_abc[3], const double K[9], const double b_c_R[9],
                                 const double b_c_T[3], double loss_a, double *pose);
 /* AddResidualBlock(new MarginalizationFactor(info), NULL, last_marginalization_parameter_blocks)  :1717-1719 */
+/* The problem keeps a pointer to `prior` (like MarginalizationFactor keeps its MarginalizationInfo*): the prior must outlive
+ * the problem and every batch created from it. */
 int tcv_problem_add_marginalization_factor(tcv_problem *p, const tcv_prior *prior, double *const *blocks,
                                            int num_blocks);
 /* graph construction of estimator.cpp:1683-1846 from frame-indexed arrays */
