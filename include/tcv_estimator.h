@@ -1,0 +1,77 @@
+/* tcv_estimator.h -- native (C++) mirror of the per-frame window management around the hot path, behind a C-ABI.
+ *
+ * What Estimator / FeatureManager do between two calls of OptimizationWithLine (reference vins_estimator/src):
+ *   processIMU (estimator.cpp:191-228), processImagewithLine (:230-383: addFeaturesCheckParallax feature_manager.cpp:260-334,
+ *   UpdateLinesInFoV / updateLinePairInWindow :385-481, removeLineOutlier feature_manager.cpp:494-534), solveOdometry
+ *   (:1476-1490: triangulate feature_manager.cpp:440-492 + OptimizationWithLine), double2vector / setDepth / removeFailures,
+ *   failureDetection (:1629-1675), slideWindowWithLinesFoV (:2121-2259, removeBackShiftDepth feature_manager.cpp:559-616,
+ *   removeFront :655-696) and the chaining of the marginalisation prior (:2027-2044, :2083-2113).
+ * The solver itself is the C-ABI of tcv.h (device pre-integration, fused solve, gauge fix, marginalisation, line association).
+ * Out of scope as in the rest of this library: image / line front end (the caller delivers tracked points and line tracks),
+ * initialisation (the window is filled from caller-provided states), relocalisation, ESTIMATE_TD.
+ *
+ * Several estimators (one per sequence) are advanced in lock step by tcv_estimators_optimize(): all full windows of a frame form
+ * ONE device batch (BASELINE configs[4]: per-sequence replay, many sequences per GPU).
+ */
+#ifndef TCV_ESTIMATOR_H
+#define TCV_ESTIMATOR_H
+#include "tcv.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tcv_estimator tcv_estimator;
+
+typedef struct {
+    double focal_length;        /* FOCAL_LENGTH (parameters.h:19): ProjectionFactor::sqrt_info = focal_length / 1.5 */
+    double min_parallax;        /* MIN_PARALLAX = keyframe_parallax / FOCAL_LENGTH (parameters.cpp:73-74) */
+    double init_depth;          /* INIT_DEPTH (parameters.cpp:131) */
+    double acc_n, gyr_n, acc_w, gyr_w;   /* sensor.yaml:90-93 */
+    double gravity[3];          /* G */
+    double imu_dt;              /* sample period of the IMU stream */
+    double K[9];                /* camera matrix, row-major */
+    int width, height;          /* image size in pixels */
+    double tic[3], ric[9];      /* camera-IMU extrinsics (row-major rotation) */
+    int estimate_extrinsic;
+    double angle_th, overlap_th, dist_th;   /* line association gates (sensor.yaml:119-122, threshold) */
+    int num_iterations;         /* NUM_ITERATIONS */
+    int fixed_iterations;       /* 1: exactly num_iterations trust-region iterations (deterministic) */
+} tcv_estimator_config;
+
+/* per-frame statistics of the last optimised window */
+typedef struct {
+    int marg_flag;              /* 0 MARGIN_OLD, 1 MARGIN_SECOND_NEW */
+    int n_landmarks, n_proj, n_line, n_line_obs;
+    int iterations, prior_n;
+    double final_cost;
+} tcv_estimator_stats;
+
+int tcv_estimator_create(tcv_estimator **out, const tcv_estimator_config *cfg);
+void tcv_estimator_destroy(tcv_estimator *e);
+/* biases every slot of the window starts from (the reference's initialisation calibrates the gyroscope bias) */
+int tcv_estimator_set_biases(tcv_estimator *e, const double ba[3], const double bg[3]);
+/* prior 3D line map (n x 6, map frame) and the map -> world transform: switches the estimator to association mode, where
+ * lines arrive as (track id, pixel end points) and the 2D-3D association runs every frame */
+int tcv_estimator_set_line_map(tcv_estimator *e, int n, const double *lines3d, const double Rbw[9], const double Tbw[3]);
+
+/* processIMU for the samples since the previous frame + the first half of processImagewithLine.
+ *   acc / gyr: (n_imu + 1) x 3, row 0 = the previous frame's last sample (n_imu = 0 for the very first frame);
+ *   point_ids / points: n_points tracked features, (x, y, 1) on the normalised plane;
+ *   lines: association mode: n_lines x 4 pixel end points with line_ids; otherwise n_lines x 9 = 3D start, 3D end (world frame),
+ *          A B C of the detected line (line_ids ignored);
+ *   truth: 15 doubles P(3) R(9 row-major) V(3) or NULL -- states of the newest slot while the window fills (initialisation is out
+ *          of scope);
+ *   *ready = 1 when the window is full and must be optimised (tcv_estimators_optimize) before tcv_estimator_finish_frame. */
+int tcv_estimator_begin_frame(tcv_estimator *e, int n_imu, const double *acc, const double *gyr, int n_points, const int *point_ids,
+                              const double *points, int n_lines, const int *line_ids, const double *lines, const double *truth, int *ready);
+/* solveOdometry + double2vector + marginalisation for every estimator in the list (all must be ready): one device batch */
+int tcv_estimators_optimize(tcv_estimator *const *e, int n);
+/* failureDetection, the published state (Ps / Rs / Vs[WINDOW_SIZE], quaternion x y z w) and slideWindow.
+ * TCV_ERR_NUMERIC: failure detection fired (the reference would reset the estimator). */
+int tcv_estimator_finish_frame(tcv_estimator *e, double P[3], double q_xyzw[4], double V[3]);
+int tcv_estimator_get_stats(const tcv_estimator *e, tcv_estimator_stats *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

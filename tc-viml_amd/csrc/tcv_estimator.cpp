@@ -1,0 +1,692 @@
+// Native mirror of the estimator's per-frame window management around the hot path (include/tcv_estimator.h).
+// Reference: vins_estimator/src/estimator.cpp (processIMU :191-228, processImagewithLine :230-383, solveOdometry :1476-1490,
+// double2vector :1537-1627, failureDetection :1629-1675, slideWindowWithLinesFoV :2121-2259, prior chaining :2027-2044 / :2083-2113)
+// and feature_manager.cpp (addFeaturesCheckParallax :260-334, setDepth :379-397, removeFailures :399-408, triangulate :440-492,
+// removeLineOutlier :494-534, removeBackShiftDepth :559-616, removeFront :655-696, compensatedParallax2 :698-734).
+// Host code only: every numerical step of the hot path goes through the C-ABI of tcv.h (HIP kernels); there is no CPU solver here.
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/tcv_estimator.h"
+
+namespace tcv { void set_error(const std::string &s); }
+
+namespace {
+
+constexpr int W = 10;                      // WINDOW_SIZE (parameters.h:20)
+enum { MARGIN_OLD = 0, MARGIN_SECOND_NEW = 1 };
+typedef std::array<double, 3> V3;
+typedef std::array<double, 9> M3;          // row-major
+
+inline V3 add(const V3 &a, const V3 &b) { return {a[0] + b[0], a[1] + b[1], a[2] + b[2]}; }
+inline V3 sub(const V3 &a, const V3 &b) { return {a[0] - b[0], a[1] - b[1], a[2] - b[2]}; }
+inline V3 scl(const V3 &a, double s) { return {a[0] * s, a[1] * s, a[2] * s}; }
+inline double nrm(const V3 &a) { return std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); }
+inline V3 mv(const M3 &m, const V3 &v) { return {m[0] * v[0] + m[1] * v[1] + m[2] * v[2], m[3] * v[0] + m[4] * v[1] + m[5] * v[2], m[6] * v[0] + m[7] * v[1] + m[8] * v[2]}; }
+inline M3 mm(const M3 &a, const M3 &b) {
+    M3 c;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) c[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+    return c;
+}
+inline M3 tr(const M3 &a) { return {a[0], a[3], a[6], a[1], a[4], a[7], a[2], a[5], a[8]}; }
+inline M3 eye() { return {1, 0, 0, 0, 1, 0, 0, 0, 1}; }
+// Eigen toRotationMatrix of q = (x y z w), no normalisation
+inline M3 q2R(const double q[4]) {
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    return {1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+            2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)};
+}
+// Eigen `Quaterniond q{R}` (vector2double, estimator.cpp:1499), x y z w
+inline void R2q(const M3 &m, double q[4]) {
+    auto M = [&](int r, int c) { return m[3 * r + c]; };
+    double t = M(0, 0) + M(1, 1) + M(2, 2);
+    if (t > 0) {
+        t = std::sqrt(t + 1.0); q[3] = 0.5 * t; t = 0.5 / t;
+        q[0] = (M(2, 1) - M(1, 2)) * t; q[1] = (M(0, 2) - M(2, 0)) * t; q[2] = (M(1, 0) - M(0, 1)) * t;
+    } else {
+        int i = 0;
+        if (M(1, 1) > M(0, 0)) i = 1;
+        if (M(2, 2) > M(i, i)) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = std::sqrt(M(i, i) - M(j, j) - M(k, k) + 1.0); q[i] = 0.5 * t; t = 0.5 / t;
+        q[3] = (M(k, j) - M(j, k)) * t; q[j] = (M(j, i) + M(i, j)) * t; q[k] = (M(k, i) + M(i, k)) * t;
+    }
+}
+// Utility::deltaQ(theta).toRotationMatrix() (utility.h:15-28; not normalised, like the reference)
+inline M3 deltaQ_R(const V3 &th) { const double q[4] = {th[0] / 2, th[1] / 2, th[2] / 2, 1.0}; return q2R(q); }
+
+// smallest right singular vector of A (rows x 4): one-sided Jacobi on the columns (what JacobiSVD in triangulate() delivers)
+void smallest_right_singular_vector(std::vector<std::array<double, 4>> A, double v_out[4]) {
+    double V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+    const int m = (int)A.size();
+    for (int sweep = 0; sweep < 60; sweep++) {
+        bool rotated = false;
+        for (int p = 0; p < 3; p++)
+            for (int q = p + 1; q < 4; q++) {
+                double a = 0, b = 0, c = 0;
+                for (int i = 0; i < m; i++) { a += A[i][p] * A[i][p]; b += A[i][q] * A[i][q]; c += A[i][p] * A[i][q]; }
+                if (std::fabs(c) <= 1e-300 || std::fabs(c) <= 2.3e-16 * std::sqrt(a * b)) continue;
+                rotated = true;
+                const double zeta = (b - a) / (2.0 * c);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+                const double cs = 1.0 / std::sqrt(1.0 + t * t), sn = cs * t;
+                for (int i = 0; i < m; i++) { const double x = A[i][p], y = A[i][q]; A[i][p] = cs * x - sn * y; A[i][q] = sn * x + cs * y; }
+                for (int i = 0; i < 4; i++) { const double x = V[i][p], y = V[i][q]; V[i][p] = cs * x - sn * y; V[i][q] = sn * x + cs * y; }
+            }
+        if (!rotated) break;
+    }
+    int best = 0;
+    double bn = -1;
+    for (int j = 0; j < 4; j++) {
+        double s = 0;
+        for (int i = 0; i < m; i++) s += A[i][j] * A[i][j];
+        if (bn < 0 || s < bn) { bn = s; best = j; }
+    }
+    for (int i = 0; i < 4; i++) v_out[i] = V[i][best];
+}
+
+struct Feature {
+    int id, start;
+    std::vector<V3> obs;
+    double depth = -1.0;       // FeaturePerId ctor: estimated_depth(-1.0)
+    int solve_flag = 0;
+    int end() const { return start + (int)obs.size() - 1; }
+};
+struct LineObs {
+    double vec[4], abc[3], world[6];
+    double errA = -1, errD = -1, overlap = -1;
+    bool credible_line = true, use_flag = false;
+};
+struct LineFeature { int id, start; std::vector<LineObs> obs; bool credible_matching = true; };
+struct GivenLine { double d[9]; };          // 3D start, 3D end (world), A B C
+struct ImuBuf {
+    bool valid = false;
+    V3 acc0, gyr0, ba, bg;
+    std::vector<V3> acc, gyr;
+};
+
+}  // namespace
+
+struct tcv_estimator {
+    tcv_estimator_config cfg;
+    V3 Ps[W + 1], Vs[W + 1], Bas[W + 1], Bgs[W + 1];
+    M3 Rs[W + 1];
+    V3 tic;
+    M3 ric;
+    ImuBuf bufs[W + 1];
+    tcv_imu_preintegration pre[W + 1];
+    bool pre_valid[W + 1];
+    std::vector<Feature> features;
+    std::vector<GivenLine> line_obs[W + 1];
+    bool assoc = false;
+    std::vector<double> map_lines;           // n x 6
+    int n_map = 0;
+    M3 Rbw;
+    V3 Tbw;
+    std::vector<LineFeature> linefeatures;
+    std::vector<unsigned char> fov[W + 1];   // WorldLinesInFOV[i] as a mask over the map (empty: not set)
+    bool fov_ready = false;
+    tcv_prior *prior = nullptr;
+    std::vector<std::pair<int, int>> prior_blocks;      // (kind 0 pose / 1 sb / 2 ex, index)
+    int frame_count = 0, marg_flag = MARGIN_OLD;
+    bool have_acc0 = false, have_last = false;
+    V3 acc_0, gyr_0, last_P;
+    tcv_estimator_stats stats;
+    // the window handed to the solver (parameter blocks are identified by address: these arrays live as long as the estimator)
+    double para_pose[(W + 1) * 7], para_sb[(W + 1) * 9], para_ex[7];
+    std::vector<double> para_feature;
+    std::vector<int> sel;                    // indices into `features` of the landmarks of the current window
+    // factor lists of the current window
+    std::vector<tcv_imu_preintegration> w_imu;
+    std::vector<int> w_imu_i, w_imu_j, w_pi, w_pj, w_pl, w_lf;
+    std::vector<double> w_pts, w_ld;
+    double w_Ric[9];
+    std::vector<int> w_pk, w_pidx;
+    // marginalisation sub-problem
+    std::vector<tcv_imu_preintegration> m_imu;
+    std::vector<int> m_imu_i, m_imu_j, m_pi, m_pj, m_pl;
+    std::vector<double> m_pts;
+    std::vector<double *> m_drop;
+    int n_line_obs_total = 0;
+};
+
+namespace {
+
+void process_imu(tcv_estimator *e, int n, const double *acc, const double *gyr) {
+    const int j = e->frame_count;
+    auto row = [](const double *a, int i) { return V3{a[3 * i], a[3 * i + 1], a[3 * i + 2]}; };
+    if (!e->have_acc0) { e->acc_0 = row(acc, 0); e->gyr_0 = row(gyr, 0); e->have_acc0 = true; }
+    ImuBuf &b = e->bufs[j];
+    if (!b.valid) { b.valid = true; b.acc0 = e->acc_0; b.gyr0 = e->gyr_0; b.ba = e->Bas[j]; b.bg = e->Bgs[j]; b.acc.clear(); b.gyr.clear(); }
+    const double dt = e->cfg.imu_dt;
+    const V3 G = {e->cfg.gravity[0], e->cfg.gravity[1], e->cfg.gravity[2]};
+    for (int i = 1; i <= n; i++) {
+        const V3 a = row(acc, i), w = row(gyr, i);
+        if (j != 0) {
+            b.acc.push_back(a); b.gyr.push_back(w);
+            const V3 un_acc_0 = sub(mv(e->Rs[j], sub(e->acc_0, e->Bas[j])), G);            // estimator.cpp:217-224
+            const V3 un_gyr = sub(scl(add(e->gyr_0, w), 0.5), e->Bgs[j]);
+            e->Rs[j] = mm(e->Rs[j], deltaQ_R(scl(un_gyr, dt)));
+            const V3 un_acc_1 = sub(mv(e->Rs[j], sub(a, e->Bas[j])), G);
+            const V3 un_acc = scl(add(un_acc_0, un_acc_1), 0.5);
+            e->Ps[j] = add(add(e->Ps[j], scl(e->Vs[j], dt)), scl(un_acc, 0.5 * dt * dt));
+            e->Vs[j] = add(e->Vs[j], scl(un_acc, dt));
+        }
+        e->acc_0 = a; e->gyr_0 = w;
+    }
+    e->pre_valid[j] = false;
+}
+
+bool add_features_check_parallax(tcv_estimator *e, int n_points, const int *ids, const double *pts, int n_lines, const int *line_ids, const double *lines) {
+    const int fc = e->frame_count;
+    std::unordered_map<int, int> by_id;
+    for (size_t k = 0; k < e->features.size(); k++) by_id[e->features[k].id] = (int)k;
+    int last_track_num = 0;
+    for (int k = 0; k < n_points; k++) {
+        auto it = by_id.find(ids[k]);
+        int idx;
+        if (it == by_id.end()) {
+            Feature f; f.id = ids[k]; f.start = fc;
+            e->features.push_back(f); idx = (int)e->features.size() - 1; by_id[ids[k]] = idx;
+        } else { idx = it->second; last_track_num++; }
+        e->features[idx].obs.push_back(V3{pts[3 * k], pts[3 * k + 1], pts[3 * k + 2]});
+    }
+    if (e->assoc) {      // the line tracker's (id, end points): addFeaturesCheckParallax :291-311
+        std::unordered_map<int, int> by_lid;
+        for (size_t k = 0; k < e->linefeatures.size(); k++) by_lid[e->linefeatures[k].id] = (int)k;
+        for (int k = 0; k < n_lines; k++) {
+            auto it = by_lid.find(line_ids[k]);
+            int idx;
+            if (it == by_lid.end()) {
+                LineFeature lf; lf.id = line_ids[k]; lf.start = fc;
+                e->linefeatures.push_back(lf); idx = (int)e->linefeatures.size() - 1; by_lid[line_ids[k]] = idx;
+            } else idx = it->second;
+            LineObs ob;
+            const double *v = lines + 4 * k;
+            for (int i = 0; i < 4; i++) ob.vec[i] = v[i];
+            ob.abc[0] = v[3] - v[1]; ob.abc[1] = v[0] - v[2]; ob.abc[2] = v[2] * v[1] - v[0] * v[3];      // feature_manager.cpp:11-13
+            for (int i = 0; i < 6; i++) ob.world[i] = 0.0;
+            e->linefeatures[idx].obs.push_back(ob);
+        }
+    } else {
+        e->line_obs[fc].clear();
+        for (int k = 0; k < n_lines; k++) { GivenLine g; std::memcpy(g.d, lines + 9 * k, sizeof g.d); e->line_obs[fc].push_back(g); }
+    }
+    if (fc < 2 || last_track_num < 20) return true;
+    double s = 0;
+    int n = 0;
+    for (auto &f : e->features)
+        if (f.start <= fc - 2 && f.end() >= fc - 1) {
+            const V3 &pi = f.obs[fc - 2 - f.start], &pj = f.obs[fc - 1 - f.start];      // compensatedParallax2 (:698-734)
+            const double du = pi[0] / pi[2] - pj[0], dv = pi[1] / pi[2] - pj[1];
+            s += std::sqrt(du * du + dv * dv); n++;
+        }
+    return n == 0 ? true : (s / n >= e->cfg.min_parallax);
+}
+
+bool selected(const Feature &f) { return f.obs.size() >= 2 && f.start < W - 2; }
+
+void triangulate(tcv_estimator *e) {
+    for (auto &f : e->features) {
+        if (!selected(f) || f.depth > 0) continue;
+        const int i = f.start;
+        const V3 t0 = add(e->Ps[i], mv(e->Rs[i], e->tic));
+        const M3 R0 = mm(e->Rs[i], e->ric);
+        std::vector<std::array<double, 4>> A;
+        for (size_t k = 0; k < f.obs.size(); k++) {
+            const int j = i + (int)k;
+            const V3 t1 = add(e->Ps[j], mv(e->Rs[j], e->tic));
+            const M3 R1 = mm(e->Rs[j], e->ric);
+            const V3 t = mv(tr(R0), sub(t1, t0));
+            const M3 R = mm(tr(R0), R1), Rt = tr(R);
+            const V3 mt = scl(mv(Rt, t), -1.0);
+            double P[3][4];
+            for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) P[r][c] = Rt[3 * r + c]; P[r][3] = mt[r]; }
+            const V3 fn = scl(f.obs[k], 1.0 / nrm(f.obs[k]));
+            std::array<double, 4> r0, r1;
+            for (int c = 0; c < 4; c++) { r0[c] = fn[0] * P[2][c] - fn[2] * P[0][c]; r1[c] = fn[1] * P[2][c] - fn[2] * P[1][c]; }
+            A.push_back(r0); A.push_back(r1);
+        }
+        double v[4];
+        smallest_right_singular_vector(A, v);
+        f.depth = v[2] / v[3];
+        if (f.depth < 0.1) f.depth = e->cfg.init_depth;
+    }
+}
+
+void poses_of(const tcv_estimator *e, double pose[(W + 1) * 7], double ex[7]) {
+    for (int i = 0; i <= W; i++) { for (int c = 0; c < 3; c++) pose[7 * i + c] = e->Ps[i][c]; R2q(e->Rs[i], pose + 7 * i + 3); }
+    for (int c = 0; c < 3; c++) ex[c] = e->tic[c];
+    R2q(e->ric, ex + 3);
+}
+
+// UpdateLinesInFoV / initialLineFoVWindow, updateLinePairInWindow and removeLineOutlier, as processImagewithLine runs them before
+// solveOdometry (estimator.cpp:328-336, :385-497; feature_manager.cpp:494-534)
+int associate_lines(tcv_estimator *e) {
+    double pose[(W + 1) * 7], ex[7];
+    poses_of(e, pose, ex);
+    const int nm = e->n_map;
+    std::vector<int> det_frame;
+    std::vector<double> det;
+    std::vector<LineObs *> where;
+    for (auto &lf : e->linefeatures)
+        for (size_t k = 0; k < lf.obs.size(); k++) { det_frame.push_back(lf.start + (int)k); det.insert(det.end(), lf.obs[k].vec, lf.obs[k].vec + 4); where.push_back(&lf.obs[k]); }
+    std::vector<unsigned char> fov_now((size_t)(W + 1) * nm, 0);
+    int rc = tcv_match_lines(W + 1, pose, ex, e->Rbw.data(), e->Tbw.data(), e->cfg.K, e->cfg.width, e->cfg.height, W, nm, e->map_lines.data(), 0, nullptr, nullptr,
+                             e->cfg.angle_th, e->cfg.overlap_th, 0, fov_now.data(), nullptr, nullptr, nullptr);
+    if (rc != TCV_OK) return rc;
+    if (!e->fov_ready) {
+        for (int i = 0; i <= W; i++) e->fov[i].assign(fov_now.begin() + (size_t)i * nm, fov_now.begin() + (size_t)(i + 1) * nm);      // initialLineFoVWindow (:483-497)
+        e->fov_ready = true;
+    } else e->fov[W].assign(fov_now.begin() + (size_t)W * nm, fov_now.begin() + (size_t)(W + 1) * nm);                               // UpdateLinesInFoV(frame_count)
+    std::vector<unsigned char> given((size_t)(W + 1) * nm, 0);
+    for (int i = 0; i <= W; i++) if (!e->fov[i].empty()) std::copy(e->fov[i].begin(), e->fov[i].end(), given.begin() + (size_t)i * nm);
+    const int nd = (int)where.size();
+    if (nd > 0) {
+        std::vector<int> match(nd);
+        std::vector<float> err((size_t)nd * 3);
+        rc = tcv_match_lines(W + 1, pose, ex, e->Rbw.data(), e->Tbw.data(), e->cfg.K, e->cfg.width, e->cfg.height, W, nm, e->map_lines.data(), nd, det_frame.data(),
+                             det.data(), e->cfg.angle_th, e->cfg.overlap_th, 1, given.data(), match.data(), err.data(), nullptr);
+        if (rc != TCV_OK) return rc;
+        for (int q = 0; q < nd; q++) {
+            LineObs &ob = *where[q];
+            ob.errA = (double)err[3 * q]; ob.errD = (double)err[3 * q + 1]; ob.overlap = (double)err[3 * q + 2];
+            const unsigned char *g = given.data() + (size_t)det_frame[q] * nm;
+            int first = -1;
+            for (int i = 0; i < nm && first < 0; i++) if (g[i]) first = i;
+            if (match[q] >= 0) std::memcpy(ob.world, e->map_lines.data() + 6 * match[q], sizeof ob.world);
+            else if (first >= 0) std::memcpy(ob.world, e->map_lines.data() + 6 * first, sizeof ob.world);          // `linesInThisFov[0]` (:871-877)
+            else { const double fake[6] = {ob.vec[0], ob.vec[1], 1.0, ob.vec[0], ob.vec[1], 1.0}; std::memcpy(ob.world, fake, sizeof fake); }      // fake_line (:707-709)
+            ob.use_flag = true;
+            ob.credible_line = err[3 * q] != -1.0f;
+        }
+    }
+    for (auto &lf : e->linefeatures) {                    // removeLineOutlier
+        if (lf.obs.empty()) continue;
+        const double *first = lf.obs[0].world;
+        int count = 0;
+        for (auto &ob : lf.obs) {
+            double d2 = 0;
+            for (int c = 0; c < 3; c++) { const double d = (ob.world[3 + c] - ob.world[c]) - (first[3 + c] - first[c]); d2 += d * d; }
+            ob.credible_line = !((float)std::sqrt(d2) > 0.1f);
+            count += ob.credible_line ? 0 : 1;
+        }
+        lf.credible_matching = !((count / (int)lf.obs.size()) >= 0.5);
+    }
+    return TCV_OK;
+}
+
+// vector2double (estimator.cpp:1492-1535) + the factor lists OptimizationWithLine walks (:1683-1846)
+int build_window(tcv_estimator *e) {
+    poses_of(e, e->para_pose, e->para_ex);
+    for (int i = 0; i <= W; i++) for (int c = 0; c < 3; c++) { e->para_sb[9 * i + c] = e->Vs[i][c]; e->para_sb[9 * i + 3 + c] = e->Bas[i][c]; e->para_sb[9 * i + 6 + c] = e->Bgs[i][c]; }
+    e->sel.clear();
+    for (size_t k = 0; k < e->features.size(); k++) if (selected(e->features[k])) e->sel.push_back((int)k);
+    e->para_feature.resize(std::max<size_t>(1, e->sel.size()));
+    for (size_t l = 0; l < e->sel.size(); l++) e->para_feature[l] = 1.0 / e->features[e->sel[l]].depth;
+    e->w_imu.clear(); e->w_imu_i.clear(); e->w_imu_j.clear();
+    for (int k = 0; k < W; k++)
+        if (e->pre[k + 1].sum_dt <= 10.0) { e->w_imu.push_back(e->pre[k + 1]); e->w_imu_i.push_back(k); e->w_imu_j.push_back(k + 1); }      // estimator.cpp:1726
+    e->w_pi.clear(); e->w_pj.clear(); e->w_pl.clear(); e->w_pts.clear();
+    for (size_t l = 0; l < e->sel.size(); l++) {      // estimator.cpp:1737-1771
+        const Feature &f = e->features[e->sel[l]];
+        for (size_t k = 1; k < f.obs.size(); k++) {
+            e->w_pi.push_back(f.start); e->w_pj.push_back(f.start + (int)k); e->w_pl.push_back((int)l);
+            e->w_pts.insert(e->w_pts.end(), f.obs[0].begin(), f.obs[0].end()); e->w_pts.insert(e->w_pts.end(), f.obs[k].begin(), f.obs[k].end());
+        }
+    }
+    e->w_lf.clear(); e->w_ld.clear();
+    e->n_line_obs_total = 0;
+    if (!e->assoc) {
+        for (int i = 0; i <= W; i++) for (auto &g : e->line_obs[i]) { e->w_lf.push_back(i); e->w_ld.insert(e->w_ld.end(), g.d, g.d + 9); }
+    } else {      // estimator.cpp:1786-1846
+        for (auto &lf : e->linefeatures) {
+            e->n_line_obs_total += (int)lf.obs.size();
+            if (!(lf.obs.size() >= 2 && lf.start < W - 2) || !lf.credible_matching) continue;
+            for (size_t k = 0; k < lf.obs.size(); k++) {
+                const LineObs &ob = lf.obs[k];
+                if (!ob.credible_line || !ob.use_flag || ob.errD > e->cfg.dist_th) continue;
+                e->w_lf.push_back(lf.start + (int)k);
+                const V3 ps = add(mv(e->Rbw, V3{ob.world[0], ob.world[1], ob.world[2]}), e->Tbw), pe = add(mv(e->Rbw, V3{ob.world[3], ob.world[4], ob.world[5]}), e->Tbw);
+                e->w_ld.insert(e->w_ld.end(), ps.begin(), ps.end()); e->w_ld.insert(e->w_ld.end(), pe.begin(), pe.end());
+                e->w_ld.insert(e->w_ld.end(), ob.abc, ob.abc + 3);
+            }
+        }
+    }
+    double qn[4];
+    const double n4 = std::sqrt(e->para_ex[3] * e->para_ex[3] + e->para_ex[4] * e->para_ex[4] + e->para_ex[5] * e->para_ex[5] + e->para_ex[6] * e->para_ex[6]);
+    for (int c = 0; c < 4; c++) qn[c] = e->para_ex[3 + c] / n4;
+    const M3 Ric = q2R(qn);
+    std::memcpy(e->w_Ric, Ric.data(), sizeof e->w_Ric);
+    e->w_pk.clear(); e->w_pidx.clear();
+    for (auto &b : e->prior_blocks) { e->w_pk.push_back(b.first); e->w_pidx.push_back(b.second); }
+    return TCV_OK;
+}
+
+void fill_desc(const tcv_estimator *e, tcv_window_desc &d, bool marg, int flag) {
+    std::memset(&d, 0, sizeof d);
+    tcv_estimator *m = const_cast<tcv_estimator *>(e);
+    d.n_frames = W + 1; d.n_landmarks = (int)e->sel.size(); d.estimate_extrinsic = e->cfg.estimate_extrinsic;
+    d.para_pose = m->para_pose; d.para_speedbias = m->para_sb; d.para_ex_pose = m->para_ex; d.para_feature = m->para_feature.data();
+    d.proj_sqrt_info = e->cfg.focal_length / 1.5; d.proj_loss_a = 1.0; d.line_loss_a = 1.0;
+    std::memcpy(d.line_K, e->cfg.K, sizeof d.line_K); std::memcpy(d.line_Ric, e->w_Ric, sizeof d.line_Ric);
+    for (int c = 0; c < 3; c++) { d.line_Tic[c] = e->tic[c]; d.gravity[c] = e->cfg.gravity[c]; }
+    d.prior = e->prior; d.prior_block_kind = e->w_pk.data(); d.prior_block_index = e->w_pidx.data();
+    if (!marg) {
+        d.n_imu = (int)e->w_imu.size(); d.imu = e->w_imu.data(); d.imu_frame_i = e->w_imu_i.data(); d.imu_frame_j = e->w_imu_j.data();
+        d.n_proj = (int)e->w_pi.size(); d.proj_frame_i = e->w_pi.data(); d.proj_frame_j = e->w_pj.data(); d.proj_feature = e->w_pl.data(); d.proj_pts = e->w_pts.data();
+        d.n_line = (int)e->w_lf.size(); d.line_frame = e->w_lf.data(); d.line_data = e->w_ld.data();
+    } else if (flag == MARGIN_OLD) {
+        d.n_imu = (int)e->m_imu.size(); d.imu = e->m_imu.data(); d.imu_frame_i = e->m_imu_i.data(); d.imu_frame_j = e->m_imu_j.data();
+        d.n_proj = (int)e->m_pi.size(); d.proj_frame_i = e->m_pi.data(); d.proj_frame_j = e->m_pj.data(); d.proj_feature = e->m_pl.data(); d.proj_pts = e->m_pts.data();
+    }
+}
+
+// factor set and drop sets MarginalizationInfo receives: estimator.cpp:1911-1986 (MARGIN_OLD), :2047-2063 (MARGIN_SECOND_NEW)
+void build_marg(tcv_estimator *e, int flag) {
+    e->m_imu.clear(); e->m_imu_i.clear(); e->m_imu_j.clear(); e->m_pi.clear(); e->m_pj.clear(); e->m_pl.clear(); e->m_pts.clear(); e->m_drop.clear();
+    if (flag == MARGIN_OLD) {
+        for (size_t k = 0; k < e->w_imu.size(); k++)
+            if (e->w_imu_i[k] == 0 && e->w_imu[k].sum_dt < 10.0) { e->m_imu.push_back(e->w_imu[k]); e->m_imu_i.push_back(0); e->m_imu_j.push_back(e->w_imu_j[k]); }
+        std::vector<int> lms;
+        for (size_t k = 0; k < e->w_pi.size(); k++)
+            if (e->w_pi[k] == 0) {
+                e->m_pi.push_back(0); e->m_pj.push_back(e->w_pj[k]); e->m_pl.push_back(e->w_pl[k]);
+                e->m_pts.insert(e->m_pts.end(), e->w_pts.begin() + 6 * k, e->w_pts.begin() + 6 * k + 6);
+                lms.push_back(e->w_pl[k]);
+            }
+        std::sort(lms.begin(), lms.end()); lms.erase(std::unique(lms.begin(), lms.end()), lms.end());
+        e->m_drop.push_back(e->para_pose); e->m_drop.push_back(e->para_sb);
+        for (int l : lms) e->m_drop.push_back(e->para_feature.data() + l);
+    } else e->m_drop.push_back(e->para_pose + 7 * (W - 1));
+}
+
+// double2vector (:1565-1581; the gauge fix itself ran on the device), setDepth (feature_manager.cpp:379-397)
+void apply_states(tcv_estimator *e) {
+    for (int i = 0; i <= W; i++) {
+        for (int c = 0; c < 3; c++) { e->Ps[i][c] = e->para_pose[7 * i + c]; e->Vs[i][c] = e->para_sb[9 * i + c]; e->Bas[i][c] = e->para_sb[9 * i + 3 + c]; e->Bgs[i][c] = e->para_sb[9 * i + 6 + c]; }
+        e->Rs[i] = q2R(e->para_pose + 7 * i + 3);
+    }
+    for (int c = 0; c < 3; c++) e->tic[c] = e->para_ex[c];
+    e->ric = q2R(e->para_ex + 3);
+    for (size_t l = 0; l < e->sel.size(); l++) {
+        Feature &f = e->features[e->sel[l]];
+        f.depth = 1.0 / e->para_feature[l];
+        f.solve_flag = f.depth < 0 ? 2 : 1;
+    }
+}
+
+// getParameterBlocks(addr_shift) (marginalization_factor.cpp:301-321; estimator.cpp:2027-2039 / :2084-2104)
+int take_prior(tcv_estimator *e, tcv_prior *np, int flag) {
+    int m, n, nb, xs;
+    int rc = tcv_prior_dims(np, &m, &n, &nb, &xs);
+    if (rc != TCV_OK) return rc;
+    std::vector<double *> addr(nb);
+    rc = tcv_prior_keep_block_addresses(np, addr.data());
+    if (rc != TCV_OK) return rc;
+    std::vector<std::pair<int, int>> blocks;
+    for (int k = 0; k < nb; k++) {
+        int kind = -1, idx = 0;
+        if (addr[k] >= e->para_pose && addr[k] < e->para_pose + (W + 1) * 7) { kind = 0; idx = (int)(addr[k] - e->para_pose) / 7; }
+        else if (addr[k] >= e->para_sb && addr[k] < e->para_sb + (W + 1) * 9) { kind = 1; idx = (int)(addr[k] - e->para_sb) / 9; }
+        else if (addr[k] == e->para_ex) { kind = 2; idx = 0; }
+        else { tcv::set_error("estimator: kept block is not a pose / speed-bias / extrinsic block"); return TCV_ERR_INVALID; }
+        if (kind < 2) {
+            if (flag == MARGIN_OLD) idx -= 1;
+            else if (idx == W) idx -= 1;
+        }
+        blocks.push_back({kind, idx});
+    }
+    if (e->prior) tcv_prior_destroy(e->prior);
+    e->prior = np;
+    e->prior_blocks = blocks;
+    e->stats.prior_n = n;
+    return TCV_OK;
+}
+
+bool failure_detection(const tcv_estimator *e) {
+    if (nrm(e->Bas[W]) > 2.5 || nrm(e->Bgs[W]) > 1.0) return true;
+    if (e->have_last) {
+        if (nrm(sub(e->Ps[W], e->last_P)) > 5 || std::fabs(e->Ps[W][2] - e->last_P[2]) > 1) return true;
+    }
+    return false;
+}
+
+void new_buf(tcv_estimator *e, int j) {
+    ImuBuf &b = e->bufs[j];
+    b.valid = true; b.acc0 = e->acc_0; b.gyr0 = e->gyr_0; b.ba = e->Bas[j]; b.bg = e->Bgs[j]; b.acc.clear(); b.gyr.clear();
+}
+
+void slide_window(tcv_estimator *e) {
+    if (e->frame_count != W) return;
+    if (e->marg_flag == MARGIN_OLD) {
+        const M3 back_R0 = e->Rs[0];
+        const V3 back_P0 = e->Ps[0];
+        for (int i = 0; i < W; i++) {      // the swaps of :2131-2153 followed by the copy of slot W-1 into W
+            e->Ps[i] = e->Ps[i + 1]; e->Rs[i] = e->Rs[i + 1]; e->Vs[i] = e->Vs[i + 1]; e->Bas[i] = e->Bas[i + 1]; e->Bgs[i] = e->Bgs[i + 1];
+            e->bufs[i] = e->bufs[i + 1]; e->pre[i] = e->pre[i + 1]; e->pre_valid[i] = e->pre_valid[i + 1];
+            e->line_obs[i] = e->line_obs[i + 1];                       // WorldLinesInFOV[W] = WorldLinesInFOV[W-1] (:2158): slot W keeps its content
+            e->fov[i] = e->fov[i + 1];
+        }
+        e->pre_valid[W] = false;
+        new_buf(e, W);
+        // slideWindowOld (:2242-2259) -> removeBackShiftDepth (feature_manager.cpp:559-616)
+        const M3 R0 = mm(back_R0, e->ric), R1 = mm(e->Rs[0], e->ric);
+        const V3 P0 = add(back_P0, mv(back_R0, e->tic)), P1 = add(e->Ps[0], mv(e->Rs[0], e->tic));
+        std::vector<Feature> kept;
+        for (auto &f : e->features) {
+            if (f.start != 0) { f.start -= 1; kept.push_back(f); continue; }
+            const V3 uv_i = f.obs.front();
+            f.obs.erase(f.obs.begin());
+            if (f.obs.size() < 2) continue;
+            const V3 pts_j = mv(tr(R1), sub(add(mv(R0, scl(uv_i, f.depth)), P0), P1));
+            f.depth = pts_j[2] > 0 ? pts_j[2] : e->cfg.init_depth;
+            kept.push_back(f);
+        }
+        e->features.swap(kept);
+        std::vector<LineFeature> keptl;                // line features: feature_manager.cpp:598-614
+        for (auto &lf : e->linefeatures) {
+            if (lf.start != 0) { lf.start -= 1; keptl.push_back(lf); continue; }
+            lf.obs.erase(lf.obs.begin());
+            if (!lf.obs.empty()) keptl.push_back(lf);
+        }
+        e->linefeatures.swap(keptl);
+    } else {
+        // MARGIN_SECOND_NEW (:2189-2230): the newest frame replaces the second newest, their IMU buffers are concatenated
+        ImuBuf &a = e->bufs[W - 1], &b = e->bufs[W];
+        a.acc.insert(a.acc.end(), b.acc.begin(), b.acc.end()); a.gyr.insert(a.gyr.end(), b.gyr.begin(), b.gyr.end());
+        e->pre_valid[W - 1] = false;
+        e->Ps[W - 1] = e->Ps[W]; e->Rs[W - 1] = e->Rs[W]; e->Vs[W - 1] = e->Vs[W]; e->Bas[W - 1] = e->Bas[W]; e->Bgs[W - 1] = e->Bgs[W];
+        e->line_obs[W - 1] = e->line_obs[W];
+        new_buf(e, W);
+        e->pre_valid[W] = false;
+        std::vector<Feature> kept;                     // slideWindowNew -> removeFront(frame_count) (feature_manager.cpp:655-675)
+        for (auto &f : e->features) {
+            if (f.start == W) { f.start -= 1; kept.push_back(f); continue; }
+            if (f.end() < W - 1) { kept.push_back(f); continue; }
+            f.obs.erase(f.obs.begin() + (W - 1 - f.start));
+            if (!f.obs.empty()) kept.push_back(f);
+        }
+        e->features.swap(kept);
+        std::vector<LineFeature> keptl;                // feature_manager.cpp:677-695
+        for (auto &lf : e->linefeatures) {
+            if (lf.start == W) { lf.start -= 1; keptl.push_back(lf); continue; }
+            if (lf.start + (int)lf.obs.size() - 1 < W - 1) { keptl.push_back(lf); continue; }
+            lf.obs.erase(lf.obs.begin() + (W - 1 - lf.start));
+            if (!lf.obs.empty()) keptl.push_back(lf);
+        }
+        e->linefeatures.swap(keptl);
+        e->fov[W - 1] = e->fov[W];
+    }
+    std::vector<Feature> ok;                           // removeFailures (:399-408)
+    for (auto &f : e->features) if (f.solve_flag != 2) ok.push_back(f);
+    e->features.swap(ok);
+}
+
+}  // namespace
+
+extern "C" int tcv_estimator_create(tcv_estimator **out, const tcv_estimator_config *cfg) {
+    if (!out || !cfg || !(cfg->imu_dt > 0) || !(cfg->focal_length > 0) || cfg->num_iterations < 1) { tcv::set_error("estimator_create: bad configuration"); return TCV_ERR_INVALID; }
+    tcv_estimator *e = new tcv_estimator();
+    e->cfg = *cfg;
+    for (int i = 0; i <= W; i++) { e->Ps[i] = e->Vs[i] = e->Bas[i] = e->Bgs[i] = V3{0, 0, 0}; e->Rs[i] = eye(); e->pre_valid[i] = false; std::memset(&e->pre[i], 0, sizeof e->pre[i]); }
+    for (int c = 0; c < 3; c++) e->tic[c] = cfg->tic[c];
+    std::memcpy(e->ric.data(), cfg->ric, sizeof(double) * 9);
+    std::memset(&e->stats, 0, sizeof e->stats);
+    *out = e;
+    return TCV_OK;
+}
+extern "C" void tcv_estimator_destroy(tcv_estimator *e) {
+    if (!e) return;
+    if (e->prior) tcv_prior_destroy(e->prior);
+    delete e;
+}
+extern "C" int tcv_estimator_set_biases(tcv_estimator *e, const double ba[3], const double bg[3]) {
+    if (!e || !ba || !bg) return TCV_ERR_INVALID;
+    for (int i = 0; i <= W; i++) for (int c = 0; c < 3; c++) { e->Bas[i][c] = ba[c]; e->Bgs[i][c] = bg[c]; }
+    return TCV_OK;
+}
+extern "C" int tcv_estimator_set_line_map(tcv_estimator *e, int n, const double *lines3d, const double Rbw[9], const double Tbw[3]) {
+    if (!e || n <= 0 || !lines3d || !Rbw || !Tbw) { tcv::set_error("estimator_set_line_map: bad argument"); return TCV_ERR_INVALID; }
+    e->assoc = true; e->n_map = n;
+    e->map_lines.assign(lines3d, lines3d + (size_t)6 * n);
+    std::memcpy(e->Rbw.data(), Rbw, sizeof(double) * 9);
+    for (int c = 0; c < 3; c++) e->Tbw[c] = Tbw[c];
+    return TCV_OK;
+}
+
+extern "C" int tcv_estimator_begin_frame(tcv_estimator *e, int n_imu, const double *acc, const double *gyr, int n_points, const int *point_ids,
+                                         const double *points, int n_lines, const int *line_ids, const double *lines, const double *truth, int *ready) {
+    if (!e || !ready || n_imu < 0 || n_points < 0 || n_lines < 0 || (n_points > 0 && (!point_ids || !points)) || (n_lines > 0 && !lines) ||
+        (n_lines > 0 && e->assoc && !line_ids) || (n_imu > 0 && (!acc || !gyr))) { tcv::set_error("estimator_begin_frame: bad argument"); return TCV_ERR_INVALID; }
+    if (acc && gyr) process_imu(e, n_imu, acc, gyr);
+    e->marg_flag = add_features_check_parallax(e, n_points, point_ids, points, n_lines, line_ids, lines) ? MARGIN_OLD : MARGIN_SECOND_NEW;
+    const int fc = e->frame_count;
+    if (truth) { for (int c = 0; c < 3; c++) { e->Ps[fc][c] = truth[c]; e->Vs[fc][c] = truth[12 + c]; } std::memcpy(e->Rs[fc].data(), truth + 3, sizeof(double) * 9); }
+    if (fc < W) {
+        e->frame_count++;
+        const int j = e->frame_count;
+        e->Bas[j] = e->Bas[j - 1]; e->Bgs[j] = e->Bgs[j - 1]; e->Ps[j] = e->Ps[j - 1]; e->Rs[j] = e->Rs[j - 1]; e->Vs[j] = e->Vs[j - 1];
+        *ready = 0;
+        return TCV_OK;
+    }
+    *ready = 1;
+    return TCV_OK;
+}
+
+extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
+    if (!es || n <= 0) return TCV_ERR_INVALID;
+    for (int i = 0; i < n; i++) if (!es[i] || es[i]->frame_count != W) { tcv::set_error("estimators_optimize: an estimator's window is not full"); return TCV_ERR_INVALID; }
+    // one pre-integration call for every stale IMU buffer of every estimator
+    {
+        std::vector<int> first, count;
+        std::vector<double> samples, init;
+        std::vector<std::pair<int, int>> who;
+        for (int i = 0; i < n; i++)
+            for (int j = 1; j <= W; j++) {
+                tcv_estimator *e = es[i];
+                if (e->pre_valid[j]) continue;
+                const ImuBuf &b = e->bufs[j];
+                if (!b.valid) { tcv::set_error("estimators_optimize: missing IMU buffer"); return TCV_ERR_INVALID; }
+                who.push_back({i, j});
+                first.push_back((int)samples.size() / 7); count.push_back((int)b.acc.size());
+                for (size_t k = 0; k < b.acc.size(); k++) { samples.push_back(e->cfg.imu_dt); samples.insert(samples.end(), b.acc[k].begin(), b.acc[k].end()); samples.insert(samples.end(), b.gyr[k].begin(), b.gyr[k].end()); }
+                init.insert(init.end(), b.acc0.begin(), b.acc0.end()); init.insert(init.end(), b.gyr0.begin(), b.gyr0.end());
+                init.insert(init.end(), b.ba.begin(), b.ba.end()); init.insert(init.end(), b.bg.begin(), b.bg.end());
+            }
+        if (!who.empty()) {
+            const tcv_estimator_config &c = es[0]->cfg;
+            const double noise[4] = {c.acc_n, c.gyr_n, c.acc_w, c.gyr_w};
+            std::vector<tcv_imu_preintegration> out(who.size());
+            if (samples.empty()) samples.push_back(0.0);
+            const int rc = tcv_preintegrate((int)who.size(), first.data(), count.data(), samples.data(), (int)samples.size() / 7, init.data(), noise, out.data());
+            if (rc != TCV_OK) return rc;
+            for (size_t k = 0; k < who.size(); k++) { es[who[k].first]->pre[who[k].second] = out[k]; es[who[k].first]->pre_valid[who[k].second] = true; }
+        }
+    }
+    // solveOdometry up to the solver call: association, triangulation, vector2double + graph
+    for (int i = 0; i < n; i++) {
+        tcv_estimator *e = es[i];
+        if (e->assoc) { const int rc = associate_lines(e); if (rc != TCV_OK) return rc; }
+        triangulate(e);
+        build_window(e);
+    }
+    // windows that marginalise and windows that only solve go to separate batches
+    std::vector<char> do_marg(n);
+    for (int i = 0; i < n; i++) {
+        bool has = false;
+        for (auto &b : es[i]->prior_blocks) if (b.first == 0 && b.second == W - 1) has = true;
+        do_marg[i] = es[i]->marg_flag == MARGIN_OLD || (es[i]->prior && has);
+    }
+    int rc_all = TCV_OK;
+    for (int group = 1; group >= 0 && rc_all == TCV_OK; group--) {
+        std::vector<int> idx;
+        for (int i = 0; i < n; i++) if ((int)do_marg[i] == group) idx.push_back(i);
+        if (idx.empty()) continue;
+        const int nb = (int)idx.size();
+        std::vector<tcv_problem *> P(nb, nullptr), M(nb, nullptr);
+        std::vector<double *const *> drops(nb, nullptr);
+        std::vector<int> ndrop(nb, 0);
+        tcv_batch *b = nullptr;
+        int rc = TCV_OK;
+        for (int k = 0; k < nb && rc == TCV_OK; k++) {
+            tcv_estimator *e = es[idx[k]];
+            tcv_window_desc d;
+            fill_desc(e, d, false, e->marg_flag);
+            rc = tcv_problem_from_window(&d, &P[k]);
+            if (rc == TCV_OK && group) {
+                build_marg(e, e->marg_flag);
+                fill_desc(e, d, true, e->marg_flag);
+                rc = tcv_problem_from_window(&d, &M[k]);
+                drops[k] = e->m_drop.data(); ndrop[k] = (int)e->m_drop.size();
+            }
+        }
+        if (rc == TCV_OK) rc = tcv_batch_create(&b, P.data(), group ? M.data() : nullptr, group ? drops.data() : nullptr, group ? ndrop.data() : nullptr, nb);
+        tcv_solver_options o;
+        tcv_solver_options_default(&o);
+        o.max_num_iterations = es[0]->cfg.num_iterations; o.fixed_iterations = es[0]->cfg.fixed_iterations;
+        if (rc == TCV_OK) rc = tcv_batch_solve(b, &o, nullptr);
+        if (rc == TCV_OK) rc = tcv_batch_gauge_fix(b, nullptr);
+        if (rc == TCV_OK && group) rc = tcv_batch_marginalize(b, nullptr);
+        if (rc == TCV_OK) rc = tcv_batch_synchronize(b);
+        if (rc == TCV_OK) rc = tcv_batch_download_states(b);
+        std::vector<tcv_solver_summary> sum(nb);
+        if (rc == TCV_OK) rc = tcv_batch_get_summaries(b, sum.data(), nb);
+        std::vector<tcv_prior *> newp(nb, nullptr);
+        if (rc == TCV_OK && group)
+            for (int k = 0; k < nb && rc == TCV_OK; k++) rc = tcv_batch_get_prior(b, k, &newp[k]);
+        if (b) tcv_batch_destroy(b);
+        for (int k = 0; k < nb; k++) { if (P[k]) tcv_problem_destroy(P[k]); if (M[k]) tcv_problem_destroy(M[k]); }
+        if (rc != TCV_OK) { for (auto *p : newp) if (p) tcv_prior_destroy(p); rc_all = rc; break; }
+        for (int k = 0; k < nb; k++) {
+            tcv_estimator *e = es[idx[k]];
+            apply_states(e);
+            e->stats.marg_flag = e->marg_flag; e->stats.n_landmarks = (int)e->sel.size(); e->stats.n_proj = (int)e->w_pi.size(); e->stats.n_line = (int)e->w_lf.size();
+            e->stats.n_line_obs = e->n_line_obs_total; e->stats.iterations = sum[k].num_iterations; e->stats.final_cost = sum[k].final_cost;
+            if (group) { rc = take_prior(e, newp[k], e->marg_flag); if (rc != TCV_OK) { rc_all = rc; break; } }
+            else e->stats.prior_n = e->prior ? e->stats.prior_n : 0;
+        }
+    }
+    return rc_all;
+}
+
+extern "C" int tcv_estimator_finish_frame(tcv_estimator *e, double P[3], double q[4], double V[3]) {
+    if (!e || !P || !q || !V) return TCV_ERR_INVALID;
+    if (failure_detection(e)) { tcv::set_error("failure detection (estimator.cpp:1629-1675): the estimator diverged"); return TCV_ERR_NUMERIC; }
+    for (int c = 0; c < 3; c++) { P[c] = e->Ps[W][c]; V[c] = e->Vs[W][c]; }
+    R2q(e->Rs[W], q);
+    slide_window(e);
+    e->last_P = e->Ps[W]; e->have_last = true;
+    return TCV_OK;
+}
+extern "C" int tcv_estimator_get_stats(const tcv_estimator *e, tcv_estimator_stats *out) {
+    if (!e || !out) return TCV_ERR_INVALID;
+    *out = e->stats;
+    return TCV_OK;
+}

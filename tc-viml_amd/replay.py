@@ -740,3 +740,101 @@ class HipBackend:
                     out["prior"] = d
                 outs[i] = out
         return outs
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# the same window management in native code: include/tcv_estimator.h (tc-viml_amd/csrc/tcv_estimator.cpp)
+# ----------------------------------------------------------------------------------------------------------------
+class _EstimatorConfig(C.Structure):
+    _fields_ = [("focal_length", C.c_double), ("min_parallax", C.c_double), ("init_depth", C.c_double),
+                ("acc_n", C.c_double), ("gyr_n", C.c_double), ("acc_w", C.c_double), ("gyr_w", C.c_double),
+                ("gravity", C.c_double * 3), ("imu_dt", C.c_double), ("K", C.c_double * 9), ("width", C.c_int), ("height", C.c_int),
+                ("tic", C.c_double * 3), ("ric", C.c_double * 9), ("estimate_extrinsic", C.c_int),
+                ("angle_th", C.c_double), ("overlap_th", C.c_double), ("dist_th", C.c_double),
+                ("num_iterations", C.c_int), ("fixed_iterations", C.c_int)]
+
+
+class _EstimatorStats(C.Structure):
+    _fields_ = [("marg_flag", C.c_int), ("n_landmarks", C.c_int), ("n_proj", C.c_int), ("n_line", C.c_int), ("n_line_obs", C.c_int),
+                ("iterations", C.c_int), ("prior_n", C.c_int), ("final_cost", C.c_double)]
+
+
+def run_many_native(streams, num_iterations: int = 8, fixed_iterations: bool = False, init_sigma=(0.02, 0.005, 0.05), bias_sigma=(0.005, 0.0005)):
+    """`run_many` with the window management in native code (tcv_estimator_*, one estimator per stream, lock-step
+    tcv_estimators_optimize): Python only feeds the per-frame streams.  Same perturbation draws as `run` / `run_many`."""
+    import tcv
+    L = tcv.lib()
+    vp, dp, ip = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)
+    L.tcv_estimator_create.argtypes = [C.POINTER(vp), C.POINTER(_EstimatorConfig)]
+    L.tcv_estimator_destroy.argtypes = [vp]; L.tcv_estimator_destroy.restype = None
+    L.tcv_estimator_set_biases.argtypes = [vp, dp, dp]
+    L.tcv_estimator_set_line_map.argtypes = [vp, C.c_int, dp, dp, dp]
+    L.tcv_estimator_begin_frame.argtypes = [vp, C.c_int, dp, dp, C.c_int, ip, dp, C.c_int, ip, dp, dp, ip]
+    L.tcv_estimators_optimize.argtypes = [C.POINTER(vp), C.c_int]
+    L.tcv_estimator_finish_frame.argtypes = [vp, dp, dp, dp]
+    L.tcv_estimator_get_stats.argtypes = [vp, C.POINTER(_EstimatorStats)]
+    if L.tcv_device_count() < 1:
+        raise RuntimeError("the native estimator needs a HIP device: the product has no CPU path")
+    cfg = _EstimatorConfig()
+    cfg.focal_length = synth.FOCAL_LENGTH; cfg.min_parallax = MIN_PARALLAX; cfg.init_depth = INIT_DEPTH
+    cfg.acc_n, cfg.gyr_n, cfg.acc_w, cfg.gyr_w = synth.ACC_N, synth.GYR_N, synth.ACC_W, synth.GYR_W
+    cfg.gravity[:] = list(G); cfg.imu_dt = synth.DT_IMU; cfg.K[:] = list(synth.K_MAT.reshape(9)); cfg.width = int(synth.IMG_W); cfg.height = int(synth.IMG_H)
+    cfg.tic[:] = list(synth.TIC); cfg.ric[:] = list(synth.RIC.reshape(9)); cfg.estimate_extrinsic = 1
+    cfg.angle_th, cfg.overlap_th, cfg.dist_th = 0.1745, 0.45, 50.0
+    cfg.num_iterations = num_iterations; cfg.fixed_iterations = int(fixed_iterations)
+    f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    P = lambda a: a.ctypes.data_as(dp)
+    ests, rngs, outs = [], [], []
+    for st in streams:
+        h = vp()
+        tcv.check(L.tcv_estimator_create(C.byref(h), C.byref(cfg)))
+        rng = np.random.Generator(np.random.PCG64(0xABCD))
+        ba = f64(st["ba"] + rng.normal(size=3) * bias_sigma[0]); bg = f64(st["bg"] + rng.normal(size=3) * bias_sigma[1])
+        tcv.check(L.tcv_estimator_set_biases(h, P(ba), P(bg)))
+        if "map_lines" in st:
+            ml = f64(st["map_lines"]); Rb = f64(st["Rbw"]).reshape(9); Tb = f64(st["Tbw"])
+            tcv.check(L.tcv_estimator_set_line_map(h, ml.shape[0], P(ml), P(Rb), P(Tb)))
+        ests.append(h); rngs.append(rng); outs.append(dict(t=[], p=[], q=[], v=[], log=[]))
+    try:
+        for k in range(max(len(st["t"]) for st in streams)):
+            ready = []
+            for si, (st, h, rng) in enumerate(zip(streams, ests, rngs)):
+                if k >= len(st["t"]):
+                    continue
+                truth = None
+                if k <= WINDOW_SIZE:
+                    dth = rng.normal(size=3) * init_sigma[1]
+                    truth = f64(np.concatenate([st["gt_p"][k] + rng.normal(size=3) * init_sigma[0], (st["gt_R"][k] @ deltaQ_R(dth)).reshape(9),
+                                                st["gt_v"][k] + rng.normal(size=3) * init_sigma[2]]))
+                imu = st["imu"][k]
+                acc = f64(imu[0]) if imu is not None else None; gyr = f64(imu[1]) if imu is not None else None
+                pts = st["points"][k]
+                ids = np.ascontiguousarray(list(pts.keys()), dtype=np.int32); pv = f64(np.array(list(pts.values())).reshape(-1, 3))
+                ln = st["lines"][k]
+                if "map_lines" in st:
+                    lid = np.ascontiguousarray([a for a, _ in ln], dtype=np.int32); lv = f64(np.array([v for _, v in ln]).reshape(-1, 4))
+                else:
+                    lid = np.zeros(len(ln), np.int32); lv = f64(np.array([np.concatenate(t3) for t3 in ln]).reshape(-1, 9))
+                rdy = C.c_int()
+                tcv.check(L.tcv_estimator_begin_frame(h, 0 if acc is None else acc.shape[0] - 1, None if acc is None else P(acc), None if gyr is None else P(gyr),
+                                                      len(ids), ids.ctypes.data_as(ip), P(pv), len(ln), lid.ctypes.data_as(ip), P(lv),
+                                                      None if truth is None else P(truth), C.byref(rdy)))
+                if rdy.value:
+                    ready.append(si)
+            if not ready:
+                continue
+            arr = (vp * len(ready))(*[ests[si] for si in ready])
+            tcv.check(L.tcv_estimators_optimize(arr, len(ready)))
+            for si in ready:
+                p3, q4, v3 = np.zeros(3), np.zeros(4), np.zeros(3)
+                s = _EstimatorStats()
+                tcv.check(L.tcv_estimator_get_stats(ests[si], C.byref(s)))
+                tcv.check(L.tcv_estimator_finish_frame(ests[si], P(p3), P(q4), P(v3)))
+                o = outs[si]
+                o["t"].append(streams[si]["t"][k]); o["p"].append(p3); o["q"].append(q4); o["v"].append(v3)
+                o["log"].append(dict(flag=s.marg_flag, n_landmarks=s.n_landmarks, n_proj=s.n_proj, n_line=s.n_line, n_line_obs=s.n_line_obs,
+                                     iterations=s.iterations, final_cost=s.final_cost, prior_n=s.prior_n))
+    finally:
+        for h in ests:
+            L.tcv_estimator_destroy(h)
+    return [dict(t=np.array(o["t"]), p=np.array(o["p"]), q=np.array(o["q"]), v=np.array(o["v"]), log=o["log"]) for o in outs]

@@ -29,6 +29,11 @@ def test_library_exports_every_declared_symbol(tcv):
         assert hasattr(L, name), f"libtcv_hip.so does not export {name}"
     assert declared == set(tcv.EXPORTS)
     assert b"gfx950" in L.tcv_version()
+    # include/tcv_estimator.h: the native window management around the same C-ABI
+    est = set(re.findall(r"\b(tcv_estimators?_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "include", "tcv_estimator.h")).read()))
+    assert len(est) == 8
+    for name in sorted(est):
+        assert hasattr(L, name), f"libtcv_hip.so does not export {name}"
 
 
 def test_product_does_not_link_or_import_the_oracle(tcv):
@@ -243,7 +248,7 @@ def test_header_is_valid_c99_and_cxx_and_the_example_links(tcv, tmp_path):
     the call sequence of a retargeted estimator.cpp) must link against libtcv_hip.so and fail loudly without a device."""
     import subprocess
     c = os.path.join(tmp_path, "t.c")
-    open(c, "w").write('#include "tcv.h"\nint main(void){ tcv_solver_options o; tcv_solver_options_default(&o); return (int)sizeof(tcv_solver_summary) > 0 ? 0 : 1; }\n')
+    open(c, "w").write('#include "tcv.h"\n#include "tcv_estimator.h"\nint main(void){ tcv_solver_options o; tcv_solver_options_default(&o); return (int)sizeof(tcv_solver_summary) > 0 ? 0 : 1; }\n')
     inc = os.path.join(ROOT, "include")
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + inc, "-fsyntax-only", c])
     subprocess.check_call(["g++", "-std=c++14", "-Wall", "-Werror", "-I" + inc, "-x", "c++", "-fsyntax-only", c])

@@ -133,3 +133,47 @@ def test_lock_step_replay_keeps_the_prior_maps_of_the_sequences_apart():
         one = replay.run(st, OracleBackend(), num_iterations=4)
         assert np.array_equal(one["p"], m["p"]) and [l["n_line"] for l in one["log"]] == [l["n_line"] for l in m["log"]]
         assert all(l["n_line"] > 0 for l in m["log"])
+
+
+def test_native_estimator_fails_loudly_without_a_device():
+    """include/tcv_estimator.h on a box without a GPU: the window fills (host logic), the optimisation reports TCV_ERR_NO_DEVICE --
+    no CPU solver hides behind the native window management either."""
+    import ctypes as C
+    import tcv
+    if tcv.lib().tcv_device_count() > 0:
+        return
+    st = replay.simulate_stream(5, 12, max_features=24)
+    try:
+        replay.run_many_native([st], num_iterations=2)
+    except RuntimeError as e:
+        assert "no CPU path" in str(e) or "NO_DEVICE" in str(e) or "no HIP device" in str(e)
+    else:
+        raise AssertionError("the native estimator ran without a device")
+    # the host side alone: ten frames fill the window, the eleventh is ready for the solver, which then refuses
+    L = tcv.lib()
+    cfg = replay._EstimatorConfig()
+    cfg.focal_length = 460.0; cfg.min_parallax = 10.0 / 460.0; cfg.init_depth = 5.0; cfg.imu_dt = 0.005; cfg.num_iterations = 2
+    cfg.gravity[:] = [0.0, 0.0, 9.81]; cfg.ric[:] = [1, 0, 0, 0, 1, 0, 0, 0, 1]; cfg.K[:] = [460, 0, 376, 0, 460, 240, 0, 0, 1]; cfg.width, cfg.height = 752, 480
+    h = C.c_void_p()
+    L.tcv_estimator_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(replay._EstimatorConfig)]
+    assert L.tcv_estimator_create(C.byref(h), C.byref(cfg)) == 0
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    L.tcv_estimator_begin_frame.argtypes = [C.c_void_p, C.c_int, dp, dp, C.c_int, ip, dp, C.c_int, ip, dp, dp, ip]
+    L.tcv_estimators_optimize.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    L.tcv_estimator_destroy.argtypes = [C.c_void_p]; L.tcv_estimator_destroy.restype = None
+    ready = []
+    for k in range(11):
+        imu = st["imu"][k]
+        acc = None if imu is None else np.ascontiguousarray(imu[0]); gyr = None if imu is None else np.ascontiguousarray(imu[1])
+        ids = np.ascontiguousarray(list(st["points"][k].keys()), dtype=np.int32); pv = np.ascontiguousarray(np.array(list(st["points"][k].values())))
+        truth = np.ascontiguousarray(np.concatenate([st["gt_p"][k], st["gt_R"][k].reshape(9), st["gt_v"][k]]))
+        r = C.c_int(-1)
+        assert L.tcv_estimator_begin_frame(h, 0 if acc is None else len(acc) - 1, None if acc is None else acc.ctypes.data_as(dp), None if gyr is None else gyr.ctypes.data_as(dp),
+                                           len(ids), ids.ctypes.data_as(ip), pv.ctypes.data_as(dp), 0, None, None, truth.ctypes.data_as(dp), C.byref(r)) == 0
+        ready.append(r.value)
+    assert ready == [0] * 10 + [1]
+    arr = (C.c_void_p * 1)(h)
+    assert L.tcv_estimators_optimize(arr, 1) == tcv.TCV_ERR_NO_DEVICE
+    bad = C.c_int()
+    assert L.tcv_estimator_begin_frame(h, 3, None, None, 0, None, None, 0, None, None, None, C.byref(bad)) == tcv.TCV_ERR_INVALID
+    L.tcv_estimator_destroy(h)
