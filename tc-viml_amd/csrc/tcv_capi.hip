@@ -12,6 +12,7 @@
 #include <memory>
 #include <string>
 #include <chrono>
+#include <thread>
 
 #include "tcv_factors.h"
 #include "tcv_host.h"
@@ -394,16 +395,40 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
     // the chain layout is used only if every window of the batch allows it: the packing pass below starts over with the dense layout
     // at the first window that does not
     b->chain = (mode == 0);
+    // packing (symbolic elimination, gather programs, data layout) is independent per window: host threads share the work
+    auto pack_all = [&](int md, std::string &msg) -> int {
+        const int nth = std::max(1, std::min({n, 16, (int)std::thread::hardware_concurrency()}));
+        std::vector<int> rcs(n, TCV_OK);
+        std::vector<std::string> msgs(nth);
+        auto work = [&](int t) {
+            for (int w = t; w < n; w += nth) {
+                rcs[w] = pack_problem(*problems[w], b->packed[w], nullptr, md, chain_lds);
+                if (rcs[w] != TCV_OK && msgs[t].empty()) msgs[t] = tcv_last_error();      // the message is thread-local
+            }
+        };
+        if (nth == 1) work(0);
+        else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < nth; t++) th.emplace_back(work, t);
+            for (auto &x : th) x.join();
+        }
+        for (int w = 0; w < n; w++) if (rcs[w] != TCV_OK) { msg = msgs[w % nth]; return rcs[w]; }
+        return TCV_OK;
+    };
+    {
+        std::string msg;
+        int rc = pack_all(mode, msg);
+        if (rc == TCV_OK && mode == 0)
+            for (int w = 0; w < n; w++)
+                if (!b->packed[w].hdr.chain) {      // a window is not chain-eligible: the whole batch uses the dense layout
+                    mode = 1; b->chain = false;
+                    rc = pack_all(mode, msg);
+                    break;
+                }
+        if (rc != TCV_OK) { batch_free(b); if (!msg.empty()) set_error(msg); return rc; }
+    }
     for (int w = 0; w < n; w++) {
         Packed &pk = b->packed[w];
-        const int rc = pack_problem(*problems[w], pk, nullptr, mode, chain_lds);
-        if (rc != TCV_OK) { batch_free(b); return rc; }
-        if (mode == 0 && !pk.hdr.chain) {      // not chain-eligible: start over with the dense layout
-            mode = 1; b->chain = false; w = -1;
-            b->plans.clear(); b->plan_base.clear(); b->wins.clear(); plan_index.clear(); ipool.clear(); dpool.clear();
-            max_state = max_nl = 0; max_lds = 0; b->input_bytes = 0; b->spill_stride = 0; b->hcl_cap = 0;
-            continue;
-        }
         std::vector<int> key(pk.ints);
         const int *hp = reinterpret_cast<const int *>(&pk.hdr);
         key.insert(key.end(), hp, hp + sizeof(PlanHdr) / sizeof(int));
