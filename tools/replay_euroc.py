@@ -29,6 +29,8 @@ rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE",
 if world > 1:
     import torch
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    import tcv
+    tcv.check(tcv.lib().tcv_set_device(int(os.environ.get("LOCAL_RANK", "0"))))
 seqs = list(replay.EUROC_SEQUENCES)[rank::world]
 os.makedirs(args.out, exist_ok=True)
 t0 = time.perf_counter()
