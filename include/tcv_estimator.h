@@ -64,7 +64,8 @@ int tcv_estimator_set_line_map(tcv_estimator *e, int n, const double *lines3d, c
  *   *ready = 1 when the window is full and must be optimised (tcv_estimators_optimize) before tcv_estimator_finish_frame. */
 int tcv_estimator_begin_frame(tcv_estimator *e, int n_imu, const double *acc, const double *gyr, int n_points, const int *point_ids,
                               const double *points, int n_lines, const int *line_ids, const double *lines, const double *truth, int *ready);
-/* solveOdometry + double2vector + marginalisation for every estimator in the list (all must be ready): one device batch */
+/* solveOdometry + double2vector + marginalisation for every estimator in the list (all must be ready): one device batch.
+ * The solver options (num_iterations, fixed_iterations) and the IMU noise are those of the first estimator of the list. */
 int tcv_estimators_optimize(tcv_estimator *const *e, int n);
 /* failureDetection, the published state (Ps / Rs / Vs[WINDOW_SIZE], quaternion x y z w) and slideWindow.
  * TCV_ERR_NUMERIC: failure detection fired (the reference would reset the estimator). */

@@ -154,6 +154,7 @@ struct tcv_estimator {
     std::vector<double> m_pts;
     std::vector<double *> m_drop;
     int n_line_obs_total = 0;
+    int phase = 0;                           // 0: between frames, 1: window full, waiting for the optimisation, 2: optimised, waiting for finish_frame
 };
 
 namespace {
@@ -565,6 +566,7 @@ extern "C" int tcv_estimator_begin_frame(tcv_estimator *e, int n_imu, const doub
                                          const double *points, int n_lines, const int *line_ids, const double *lines, const double *truth, int *ready) {
     if (!e || !ready || n_imu < 0 || n_points < 0 || n_lines < 0 || (n_points > 0 && (!point_ids || !points)) || (n_lines > 0 && !lines) ||
         (n_lines > 0 && e->assoc && !line_ids) || (n_imu > 0 && (!acc || !gyr))) { tcv::set_error("estimator_begin_frame: bad argument"); return TCV_ERR_INVALID; }
+    if (e->phase != 0) { tcv::set_error("estimator_begin_frame: the previous frame has not been optimised and finished"); return TCV_ERR_INVALID; }
     if (acc && gyr) process_imu(e, n_imu, acc, gyr);
     e->marg_flag = add_features_check_parallax(e, n_points, point_ids, points, n_lines, line_ids, lines) ? MARGIN_OLD : MARGIN_SECOND_NEW;
     const int fc = e->frame_count;
@@ -577,12 +579,14 @@ extern "C" int tcv_estimator_begin_frame(tcv_estimator *e, int n_imu, const doub
         return TCV_OK;
     }
     *ready = 1;
+    e->phase = 1;
     return TCV_OK;
 }
 
 extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
     if (!es || n <= 0) return TCV_ERR_INVALID;
-    for (int i = 0; i < n; i++) if (!es[i] || es[i]->frame_count != W) { tcv::set_error("estimators_optimize: an estimator's window is not full"); return TCV_ERR_INVALID; }
+    for (int i = 0; i < n; i++) if (!es[i] || es[i]->phase != 1) { tcv::set_error("estimators_optimize: an estimator has no full window waiting (begin_frame must report ready)"); return TCV_ERR_INVALID; }
+    for (int i = 0; i < n; i++) for (int j = 0; j < i; j++) if (es[i] == es[j]) { tcv::set_error("estimators_optimize: the same estimator twice"); return TCV_ERR_INVALID; }
     // one pre-integration call for every stale IMU buffer of every estimator
     {
         std::vector<int> first, count;
@@ -671,6 +675,7 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
             e->stats.n_line_obs = e->n_line_obs_total; e->stats.iterations = sum[k].num_iterations; e->stats.final_cost = sum[k].final_cost;
             if (group) { rc = take_prior(e, newp[k], e->marg_flag); if (rc != TCV_OK) { rc_all = rc; break; } }
             else e->stats.prior_n = e->prior ? e->stats.prior_n : 0;
+            e->phase = 2;
         }
     }
     return rc_all;
@@ -678,6 +683,8 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
 
 extern "C" int tcv_estimator_finish_frame(tcv_estimator *e, double P[3], double q[4], double V[3]) {
     if (!e || !P || !q || !V) return TCV_ERR_INVALID;
+    if (e->phase != 2) { tcv::set_error("estimator_finish_frame: the window has not been optimised"); return TCV_ERR_INVALID; }
+    e->phase = 0;
     if (failure_detection(e)) { tcv::set_error("failure detection (estimator.cpp:1629-1675): the estimator diverged"); return TCV_ERR_NUMERIC; }
     for (int c = 0; c < 3; c++) { P[c] = e->Ps[W][c]; V[c] = e->Vs[W][c]; }
     R2q(e->Rs[W], q);
