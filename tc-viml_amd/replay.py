@@ -168,7 +168,7 @@ def load_euroc(seq: str):
         if not np.array_equal(d[key], ref):
             raise ValueError("euroc_%s: %s differs from the calibration the kernels' host side is configured with" % (seq, key))
     return dict(seq=seq, stamp_ns=d["stamp_ns"], t=(d["stamp_ns"] - d["stamp_ns"][0]) * 1e-9, p=st[:, 0:3], q_wxyz=st[:, 3:7], v=st[:, 7:10], bw=st[:, 10:13],
-                ba=st[:, 13:16], lines3d=d["lines3d"], Rbw=d["Rbw"], Tbw=d["Tbw"])
+                ba=st[:, 13:16], lines3d=d["lines3d"], Rbw=d["Rbw"], Tbw=d["Tbw"], line_th=d["line_th"])
 
 
 def _rotvec(R):
@@ -223,7 +223,7 @@ def simulate_stream_euroc(seq, n_frames: int, start_s: float = 0.0, seed: int = 
     out = dict(t=E["t"][sl][1:-1][fr], stamp_ns=E["stamp_ns"][sl][1:-1][fr], gt_p=pw[fr], gt_R=Rw[fr], gt_v=vw[fr], imu=imu, points=points, lines=lines,
                ba=E["ba"][sl][1 + fr[0]].copy(), bg=E["bw"][sl][1 + fr[0]].copy(), seq=E["seq"])
     if associate:
-        out.update(map_lines=E["lines3d"].copy(), Rbw=E["Rbw"].copy(), Tbw=E["Tbw"].copy())
+        out.update(map_lines=E["lines3d"].copy(), Rbw=E["Rbw"].copy(), Tbw=E["Tbw"].copy(), line_th=tuple(float(v) for v in E["line_th"]))      # the sequence's own angle_th, overlap_th, dist_th
     return out
 
 
@@ -256,6 +256,7 @@ class Replay:
         self.linefeatures = []             # f_manager.linefeature: dict(id, start_frame, obs=[...], credible_matching)
         self.fov = [None] * (W + 1)        # WorldLinesInFOV[i] as a mask over the map
         self.fov_ready = False
+        self.angle_th, self.overlap_th, self.dist_th = 0.1745, 0.45, 50.0      # sensor.yaml (V1_01_easy): angle_th, overlap_th, dist_th (estimator.cpp:116-119)
         self.prior = None                  # last_marginalization_info + last_marginalization_parameter_blocks
         self.frame_count = 0
         self.marg_flag = MARGIN_OLD
@@ -368,7 +369,7 @@ class Replay:
         given = None
         if self.fov_ready:
             given = np.array([self.fov[i] if self.fov[i] is not None else np.zeros(len(self.map_lines), bool) for i in range(W + 1)])
-        fov_now, _, _, _ = self.backend.match_lines(pose, ex, None, np.zeros(0, np.int32), np.zeros((0, 4)), map3d=(self.map_lines, self.Rbw, self.Tbw))
+        fov_now, _, _, _ = self.backend.match_lines(pose, ex, None, np.zeros(0, np.int32), np.zeros((0, 4)), map3d=(self.map_lines, self.Rbw, self.Tbw), th=(self.angle_th, self.overlap_th))
         if not self.fov_ready:
             for i in range(W + 1):
                 self.fov[i] = fov_now[i].copy()          # initialLineFoVWindow (:483-497)
@@ -377,7 +378,7 @@ class Replay:
             self.fov[W] = fov_now[W].copy()              # UpdateLinesInFoV(frame_count) (:385-447)
         given = np.array(self.fov)
         if det:
-            _, match, err, _ = self.backend.match_lines(pose, ex, given, np.array(det_frame, dtype=np.int32), np.array(det), map3d=(self.map_lines, self.Rbw, self.Tbw))
+            _, match, err, _ = self.backend.match_lines(pose, ex, given, np.array(det_frame, dtype=np.int32), np.array(det), map3d=(self.map_lines, self.Rbw, self.Tbw), th=(self.angle_th, self.overlap_th))
             for ob, f, m, e in zip(where, det_frame, match, err):
                 ob["errA"], ob["errD"], ob["overlap"] = float(e[0]), float(e[1]), float(e[2])
                 idx = np.nonzero(given[f])[0]
@@ -407,7 +408,7 @@ class Replay:
                 for (ps, pe, abc) in self.line_obs[i]:
                     lf_.append(i); lps.append(ps); lpe.append(pe); labc.append(abc)
             return lf_, lps, lpe, labc
-        dist_th = 50.0                                    # sensor.yaml:120
+        dist_th = self.dist_th
         for lf in self.linefeatures:
             if not (len(lf["obs"]) >= 2 and lf["start_frame"] < WINDOW_SIZE - 2) or not lf["credible_matching"]:
                 continue
@@ -591,6 +592,7 @@ def run(stream: dict, backend, num_iterations: int = 8, fixed_iterations: bool =
     rp = Replay(backend, num_iterations, fixed_iterations)
     if "map_lines" in stream:
         rp.map_lines, rp.Rbw, rp.Tbw = stream["map_lines"], stream["Rbw"], stream["Tbw"]
+        rp.angle_th, rp.overlap_th, rp.dist_th = stream.get("line_th", (rp.angle_th, rp.overlap_th, rp.dist_th))
         backend.set_map(stream["map_lines"], stream["Rbw"], stream["Tbw"])
     # the reference's initialisation calibrates the gyroscope bias (initial_aligment.cpp) before the first window; here the
     # biases start near the truth like the other states
@@ -620,6 +622,7 @@ def run_many(streams, backend, num_iterations: int = 8, fixed_iterations: bool =
         rp = Replay(backend, num_iterations, fixed_iterations)
         if "map_lines" in st:
             rp.map_lines, rp.Rbw, rp.Tbw = st["map_lines"], st["Rbw"], st["Tbw"]
+            rp.angle_th, rp.overlap_th, rp.dist_th = st.get("line_th", (rp.angle_th, rp.overlap_th, rp.dist_th))
             backend.set_map(st["map_lines"], st["Rbw"], st["Tbw"])
         rp.Bas[:] = st["ba"] + rng.normal(size=3) * bias_sigma[0]; rp.Bgs[:] = st["bg"] + rng.normal(size=3) * bias_sigma[1]
         reps.append(rp); rngs.append(rng); outs.append(dict(t=[], p=[], q=[], v=[]))
@@ -685,12 +688,12 @@ class HipBackend:
     def set_map(self, lines3d, Rbw, Tbw):
         self.map = (np.asarray(lines3d, dtype=float), np.asarray(Rbw, dtype=float), np.asarray(Tbw, dtype=float))
 
-    def match_lines(self, poses, ex, fov, det_frame, det, map3d=None):
+    def match_lines(self, poses, ex, fov, det_frame, det, map3d=None, th=(0.1745, 0.45)):
         """map3d = (lines3d, Rbw, Tbw) of the calling sequence (every sequence of a lock-step replay has its own prior map);
         None: the map of the last set_map call."""
         lines3d, Rbw, Tbw = [np.asarray(a, dtype=float) for a in map3d] if map3d is not None else self.map
         return self.tcv.match_lines(poses, ex, Rbw, Tbw, synth.K_MAT, int(synth.IMG_W), int(synth.IMG_H), WINDOW_SIZE, lines3d, det_frame, det,
-                                    0.1745, 0.45, in_fov=fov)            # angle_th / overlap_th: sensor.yaml:119-122
+                                    th[0], th[1], in_fov=fov)            # angle_th / overlap_th (estimator.cpp:116-119)
 
     def optimize(self, win, marg_flag, num_iterations, fixed_iterations):
         return self.optimize_many([win], [marg_flag], num_iterations, fixed_iterations)[0]
@@ -787,6 +790,7 @@ def run_many_native(streams, num_iterations: int = 8, fixed_iterations: bool = F
     ests, rngs, outs = [], [], []
     for st in streams:
         h = vp()
+        cfg.angle_th, cfg.overlap_th, cfg.dist_th = st.get("line_th", (0.1745, 0.45, 50.0))
         tcv.check(L.tcv_estimator_create(C.byref(h), C.byref(cfg)))
         rng = np.random.Generator(np.random.PCG64(0xABCD))
         ba = f64(st["ba"] + rng.normal(size=3) * bias_sigma[0]); bg = f64(st["bg"] + rng.normal(size=3) * bias_sigma[1])

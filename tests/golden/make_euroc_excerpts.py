@@ -61,7 +61,8 @@ def main():
             Ric=yaml_matrix(y, "extrinsicRotation", 9).reshape(3, 3), Tic=yaml_matrix(y, "extrinsicTranslation", 3),
             K=np.array([yaml_scalar(y, "fx"), yaml_scalar(y, "fy"), yaml_scalar(y, "cx"), yaml_scalar(y, "cy")]),
             size=np.array([yaml_scalar(y, "width"), yaml_scalar(y, "height")]),
-            imu_noise=np.array([yaml_scalar(y, k) for k in ("acc_n", "gyr_n", "acc_w", "gyr_w", "g_norm")]))
+            imu_noise=np.array([yaml_scalar(y, k) for k in ("acc_n", "gyr_n", "acc_w", "gyr_w", "g_norm")]),
+            line_th=np.array([yaml_scalar(y, k) for k in ("angle_th", "overlap_th", "dist_th")]))      # estimator.cpp:116-119
         p = os.path.join(out_dir, "euroc_%s.npz" % seq)
         print(seq, "rows", len(sel), "lines", lines.shape, "bytes", os.path.getsize(p))
 

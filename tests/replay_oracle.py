@@ -22,14 +22,14 @@ class OracleBackend:
     def set_map(self, lines3d, Rbw, Tbw):
         self.map = (np.asarray(lines3d, dtype=float), np.asarray(Rbw, dtype=float), np.asarray(Tbw, dtype=float))
 
-    def match_lines(self, poses, ex, fov, det_frame, det, map3d=None):
+    def match_lines(self, poses, ex, fov, det_frame, det, map3d=None, th=(0.1745, 0.45)):
         lines3d, Rbw, Tbw = [np.asarray(a, dtype=float) for a in map3d] if map3d is not None else self.map
         W, H = int(synth.IMG_W), int(synth.IMG_H)
         if fov is None:
             fov = np.array([NO.lines_in_fov(poses[k], ex, Rbw, Tbw, synth.K_MAT, W, H, synth.WINDOW_SIZE, lines3d) for k in range(poses.shape[0])])
         match = np.zeros(len(det), np.int32); err = np.zeros((len(det), 3), np.float32); proj = np.zeros((len(det), 4))
         for q, (f, v) in enumerate(zip(det_frame, det)):
-            e, c, pv = NO.line_correspondence_in_frame(poses[f], ex, Rbw, Tbw, synth.K_MAT, W, H, lines3d, fov[f], v, 0.1745, 0.45)
+            e, c, pv = NO.line_correspondence_in_frame(poses[f], ex, Rbw, Tbw, synth.K_MAT, W, H, lines3d, fov[f], v, th[0], th[1])
             match[q], err[q], proj[q] = c, e, pv
         return np.asarray(fov, dtype=bool), match, err, proj
 
