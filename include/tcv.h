@@ -108,6 +108,8 @@ typedef struct {
     double *para_td;
     const double *proj_td_aux;
     double td_TR, td_ROW;
+    int line_exact_jacobian;   /* 0: the reference's line Jacobian; 1: tcv_problem_set_line_jacobian(p, 1) */
+    int pad_;
 } tcv_window_desc;
 
 /* ---- library ------------------------------------------------------------------------------ */
@@ -145,6 +147,11 @@ int tcv_problem_add_projection_td_factor(tcv_problem *p, const double pts_i[3], 
                                          double sqrt_info, double loss_a, double *pose_i, double *pose_j, double *ex_pose,
                                          double *inv_depth, double *td);
 int tcv_problem_set_rolling_shutter(tcv_problem *p, double TR, double ROW);
+/* Opt-in extension, NOT the reference's behaviour.  LineProjectionFactor::Evaluate (line_projection_factor.cpp:73-116) fills its
+ * Jacobian with the derivative of the squared point-line distance chained through [I | skew(p_cam)] -- a camera-frame perturbation --
+ * while the parameter block is the world-frame body pose; exact = 0 (default) reproduces that as written.  exact = 1 uses the
+ * derivative of the same residual with respect to PoseLocalParameterization's (delta p, delta theta); the residual is unchanged. */
+int tcv_problem_set_line_jacobian(tcv_problem *p, int exact);
 /* AddResidualBlock(new LineProjectionFactor(ps, pe, abc, K, Ric, Tic), loss, P_f)   estimator.cpp:1834-1840 */
 int tcv_problem_add_line_factor(tcv_problem *p, const double pts_start[3], const double pts_end[3],
                                 const double line_abc[3], const double K[9], const double b_c_R[9],

@@ -36,6 +36,8 @@ typedef struct {
     double angle_th, overlap_th, dist_th;   /* line association gates (sensor.yaml:119-122, threshold) */
     int num_iterations;         /* NUM_ITERATIONS */
     int fixed_iterations;       /* 1: exactly num_iterations trust-region iterations (deterministic) */
+    int line_exact_jacobian;    /* 0: the reference's line Jacobian (default); 1: tcv_problem_set_line_jacobian(p, 1), see tcv.h */
+    int pad_;
 } tcv_estimator_config;
 
 /* per-frame statistics of the last optimised window */

@@ -268,7 +268,9 @@ def proj_evaluate(pose_i, pose_j, ex, lam, pts_i, pts_j, sqrt_info_scalar, want_
 # L1: LineProjectionFactor::Evaluate   factor/line_projection_factor.cpp:19-120
 # (Jacobian is "as written", NOT the derivative of the residual -- SURVEY.md §8(a) L1)
 # --------------------------------------------------------------------------------------
-def line_evaluate(pose, pts_start, pts_end, abc, K, b_c_R, b_c_T, want_jac=True):
+def line_evaluate(pose, pts_start, pts_end, abc, K, b_c_R, b_c_T, want_jac=True, exact=False):
+    """exact=False: the reference's Jacobian as written (line_projection_factor.cpp:73-116).  exact=True (test oracle of the opt-in
+    extension tcv_problem_set_line_jacobian): the derivative of the same residual w.r.t. PoseLocalParameterization's (dp, dtheta)."""
     T_w = pose[0:3]
     R_w = q2R(qnormalized(pose[3:7]))
     R = b_c_R.T @ R_w.T
@@ -293,6 +295,15 @@ def line_evaluate(pose, pts_start, pts_end, abc, K, b_c_R, b_c_T, want_jac=True)
     ep_ = np.array([[-2 / d * ((mue - u_e) * a * a + a * b * (mve - v_e)),
                      -2 / d * ((mue - u_e) * a * b + b * b * (mve - v_e))]])
     fx, fy = K[0, 0], K[1, 1]
+    if exact:
+        J = np.zeros((2, 7))
+        for e, (pc, P, u, v) in enumerate(((pcs, pts_start, u_s, v_s), (pce, pts_end, u_e, v_e))):
+            L = a * u + b * v + c
+            duv = np.sign(L) / np.sqrt(d) * np.array([a, b])
+            pp = np.array([[fx / pc[2], 0, -fx * pc[0] / (pc[2] * pc[2])], [0, fy / pc[2], -fy * pc[1] / (pc[2] * pc[2])]])
+            y = R_w.T @ (np.asarray(P) - T_w)
+            J[e, :6] = duv @ pp @ np.hstack([-b_c_R.T @ R_w.T, b_c_R.T @ skew(y)])
+        return r, [J]
     pps = np.array([[fx / pcs[2], 0, -fx * pcs[0] / (pcs[2] * pcs[2])],
                     [0, fy / pcs[2], -fy * pcs[1] / (pcs[2] * pcs[2])]])
     ppe = np.array([[fx / pce[2], 0, -fx * pce[0] / (pce[2] * pce[2])],
@@ -459,7 +470,7 @@ class Problem:
         if kind == "line":
             ln = w["line"]
             r, Js = line_evaluate(xs[0], ln["pts_start"][k], ln["pts_end"][k], ln["abc"][k], ln["K"], ln["Ric"],
-                                  ln["Tic"], want_jac)
+                                  ln["Tic"], want_jac, exact=bool(ln.get("exact_jacobian", False)))
             return loss_correct(r, Js, ln["loss_a"])
         if kind == "prior":
             r, Js = prior_evaluate(w["prior"], xs, want_jac)

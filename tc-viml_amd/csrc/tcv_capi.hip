@@ -159,6 +159,11 @@ extern "C" int tcv_problem_add_projection_td_factor(tcv_problem *p, const double
     f.btd = btd;
     return TCV_OK;
 }
+extern "C" int tcv_problem_set_line_jacobian(tcv_problem *p, int exact) {
+    if (!p || (exact != 0 && exact != 1)) { set_error("set_line_jacobian: 0 (reference) or 1 (exact)"); return TCV_ERR_INVALID; }
+    p->line_exact = exact;
+    return TCV_OK;
+}
 extern "C" int tcv_problem_set_rolling_shutter(tcv_problem *p, double TR, double ROW) {
     if (!p || !(ROW > 0.0) || !(TR == TR)) { set_error("set_rolling_shutter: ROW must be positive"); return TCV_ERR_INVALID; }
     p->td_TR = TR; p->td_ROW = ROW;
@@ -255,6 +260,7 @@ extern "C" int tcv_problem_from_window(const tcv_window_desc *w, tcv_problem **o
     chk(tcv_problem_add_parameter_block(p, w->para_ex_pose, 7, TCV_PARAM_POSE));   // :1689-1701
     if (!w->estimate_extrinsic) chk(tcv_problem_set_parameter_block_constant(p, w->para_ex_pose));
     chk(tcv_problem_set_gravity(p, w->gravity));
+    if (w->line_exact_jacobian) chk(tcv_problem_set_line_jacobian(p, 1));
     if (w->para_td) {   // :1703-1707
         chk(tcv_problem_add_parameter_block(p, w->para_td, 1, TCV_PARAM_EUCLIDEAN));
         chk(tcv_problem_set_rolling_shutter(p, w->td_TR, w->td_ROW));

@@ -378,6 +378,7 @@ void fill_desc(const tcv_estimator *e, tcv_window_desc &d, bool marg, int flag) 
     d.proj_sqrt_info = e->cfg.focal_length / 1.5; d.proj_loss_a = 1.0; d.line_loss_a = 1.0;
     std::memcpy(d.line_K, e->cfg.K, sizeof d.line_K); std::memcpy(d.line_Ric, e->w_Ric, sizeof d.line_Ric);
     for (int c = 0; c < 3; c++) { d.line_Tic[c] = e->tic[c]; d.gravity[c] = e->cfg.gravity[c]; }
+    d.line_exact_jacobian = e->cfg.line_exact_jacobian;
     d.prior = e->prior; d.prior_block_kind = e->w_pk.data(); d.prior_block_index = e->w_pidx.data();
     if (!marg) {
         d.n_imu = (int)e->w_imu.size(); d.imu = e->w_imu.data(); d.imu_frame_i = e->w_imu_i.data(); d.imu_frame_j = e->w_imu_j.data();

@@ -59,6 +59,7 @@ struct tcv_problem {
     std::vector<tcv::PriorFac> prior;
     double G[3] = {0, 0, 9.8};
     double td_TR = 0.0, td_ROW = 1.0;        // rolling-shutter globals of ProjectionTdFactor
+    int line_exact = 0;                      // 1: line factors use the exact derivative of their residual (opt-in extension)
     std::vector<int> frame_pose, frame_sb;   // block ids of para_Pose[i] / para_SpeedBias[i] (gauge fix), may be empty
 };
 

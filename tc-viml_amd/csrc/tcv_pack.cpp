@@ -638,7 +638,7 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int 
     W.d_prior = (int)D.size();
     if (pr) { D.insert(D.end(), pr->J0.begin(), pr->J0.end()); D.insert(D.end(), pr->r0.begin(), pr->r0.end()); D.insert(D.end(), pr->x0.begin(), pr->x0.end()); }
     W.d_misc = (int)D.size();
-    D.insert(D.end(), p.G, p.G + 3); D.push_back(psi); D.push_back(pla); D.push_back(lla); D.push_back(p.td_TR); D.push_back(p.td_ROW);
+    D.insert(D.end(), p.G, p.G + 3); D.push_back(psi); D.push_back(pla); D.push_back(lla); D.push_back(p.td_TR); D.push_back(p.td_ROW); D.push_back(p.line_exact ? 1.0 : 0.0);
     W.d_sqrt = -1;
     if (imu_sqrt && H.n_imu) { W.d_sqrt = (int)D.size(); D.insert(D.end(), imu_sqrt, imu_sqrt + 225 * H.n_imu); }
     if (D.size() & 1) D.push_back(0.0);

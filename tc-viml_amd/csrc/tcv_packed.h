@@ -109,7 +109,7 @@ struct WinHdr {
     int d_line;     // n_line x 9
     int d_linec;    // 21 : K, Ric, Tic (row-major)
     int d_prior;    // J0 (n x n column-major), r0 (n), x0 (prior_xsize)
-    int d_misc;     // G(3), proj sqrt_info, proj loss a, line loss a, TR, ROW
+    int d_misc;     // G(3), proj sqrt_info, proj loss a, line loss a, TR, ROW, line Jacobian mode (0 reference, 1 exact)
     int d_sqrt;     // optional host-provided sqrt_info, n_imu x 225 (-1: computed on device)
     int n_doubles;  // doubles of this window
     int pad1;

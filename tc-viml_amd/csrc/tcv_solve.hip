@@ -269,6 +269,7 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
     cst_d *misc = dp + C.W->d_misc;
     const double G3[3] = {misc[0], misc[1], misc[2]};
     const double proj_sqrt = misc[3], proj_loss = misc[4], line_loss = misc[5];
+    const bool line_exact = misc[8] != 0.0;
     const int pp_elems = CHAIN ? (C.ntiles << 8) : ((P.ntp * (P.ntp + 1) / 2) << 8);
     // ProjectionTdFactor windows (dense layout only): wider point records, see tcv_packed.h
     const bool with_td = !CHAIN && (P.flags & 1);
@@ -342,7 +343,7 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
             for (int i = 0; i < 9; i++) ld9[i] = dp[C.W->d_line + (lb + f) * 9 + i];
 #pragma unroll
             for (int i = 0; i < 21; i++) lc[i] = dp[C.W->d_linec + i];
-            line_eval(CGEN(xp), ld9, lc, lc + 9, lc + 18, r, J, LINE_STRIDE);
+            line_eval(CGEN(xp), ld9, lc, lc + 9, lc + 18, r, J, LINE_STRIDE, line_exact);
             cost_acc += loss_correct2(r, J, 6, LINE_STRIDE, line_loss);
             if (assemble) { rec[6] = r[0]; rec[LINE_STRIDE + 6] = r[1]; }
         }

@@ -256,6 +256,7 @@ class Replay:
         self.linefeatures = []             # f_manager.linefeature: dict(id, start_frame, obs=[...], credible_matching)
         self.fov = [None] * (W + 1)        # WorldLinesInFOV[i] as a mask over the map
         self.fov_ready = False
+        self.exact_line_jacobian = False        # True: tcv_problem_set_line_jacobian(p, 1) (opt-in extension, not the reference's behaviour)
         self.angle_th, self.overlap_th, self.dist_th = 0.1745, 0.45, 50.0      # sensor.yaml (V1_01_easy): angle_th, overlap_th, dist_th (estimator.cpp:116-119)
         self.prior = None                  # last_marginalization_info + last_marginalization_parameter_blocks
         self.frame_count = 0
@@ -440,7 +441,8 @@ class Replay:
                     pts_i=np.array(pi).reshape(-1, 3), pts_j=np.array(pj).reshape(-1, 3), sqrt_info=synth.PROJ_SQRT_INFO, loss_a=1.0)
         lf, lps, lpe, labc = self._line_factors()
         line = dict(frame=np.array(lf, dtype=np.int64), pts_start=np.array(lps).reshape(-1, 3), pts_end=np.array(lpe).reshape(-1, 3),
-                    abc=np.array(labc).reshape(-1, 3), K=synth.K_MAT.copy(), Ric=q2R(ex[3:] / np.linalg.norm(ex[3:])), Tic=self.tic.copy(), loss_a=1.0)
+                    abc=np.array(labc).reshape(-1, 3), K=synth.K_MAT.copy(), Ric=q2R(ex[3:] / np.linalg.norm(ex[3:])), Tic=self.tic.copy(), loss_a=1.0,
+                    exact_jacobian=self.exact_line_jacobian)
         win = dict(pose=pose, speedbias=sb, ex_pose=ex, lam=lam, imu=imu, proj=proj, line=line, G=G.copy(), prior=self.prior)
         return win, sel
 
@@ -585,11 +587,13 @@ class Replay:
         return self.finish_frame()
 
 
-def run(stream: dict, backend, num_iterations: int = 8, fixed_iterations: bool = False, init_sigma=(0.02, 0.005, 0.05), bias_sigma=(0.005, 0.0005)):
+def run(stream: dict, backend, num_iterations: int = 8, fixed_iterations: bool = False, init_sigma=(0.02, 0.005, 0.05), bias_sigma=(0.005, 0.0005),
+        exact_line_jacobian: bool = False):
     """replays a simulated stream; returns dict(t, p, q, v) of Ps/Rs/Vs[WINDOW_SIZE] after every optimisation (what pubOdometry
     writes, visualization.cpp:210-226) plus the per-frame log."""
     rng = np.random.Generator(np.random.PCG64(0xABCD))
     rp = Replay(backend, num_iterations, fixed_iterations)
+    rp.exact_line_jacobian = exact_line_jacobian
     if "map_lines" in stream:
         rp.map_lines, rp.Rbw, rp.Tbw = stream["map_lines"], stream["Rbw"], stream["Tbw"]
         rp.angle_th, rp.overlap_th, rp.dist_th = stream.get("line_th", (rp.angle_th, rp.overlap_th, rp.dist_th))
@@ -610,7 +614,8 @@ def run(stream: dict, backend, num_iterations: int = 8, fixed_iterations: bool =
     return dict(t=np.array(out_t), p=np.array(out_p), q=np.array(out_q), v=np.array(out_v), log=rp.log)
 
 
-def run_many(streams, backend, num_iterations: int = 8, fixed_iterations: bool = False, init_sigma=(0.02, 0.005, 0.05), bias_sigma=(0.005, 0.0005)):
+def run_many(streams, backend, num_iterations: int = 8, fixed_iterations: bool = False, init_sigma=(0.02, 0.005, 0.05), bias_sigma=(0.005, 0.0005),
+             exact_line_jacobian: bool = False):
     """several independent sequences in lock step (BASELINE configs[4] in spirit: per-sequence replay, sequences sharded over the
     GPUs, many per GPU): every frame the full windows of ALL sequences go to the back end as ONE batch (`optimize_many`), and the
     IMU buffers of all sequences are pre-integrated in one call.  Identical per-sequence results to `run` (the kernels do not
@@ -620,6 +625,7 @@ def run_many(streams, backend, num_iterations: int = 8, fixed_iterations: bool =
     for st in streams:
         rng = np.random.Generator(np.random.PCG64(0xABCD))
         rp = Replay(backend, num_iterations, fixed_iterations)
+        rp.exact_line_jacobian = exact_line_jacobian
         if "map_lines" in st:
             rp.map_lines, rp.Rbw, rp.Tbw = st["map_lines"], st["Rbw"], st["Tbw"]
             rp.angle_th, rp.overlap_th, rp.dist_th = st.get("line_th", (rp.angle_th, rp.overlap_th, rp.dist_th))
@@ -754,7 +760,7 @@ class _EstimatorConfig(C.Structure):
                 ("gravity", C.c_double * 3), ("imu_dt", C.c_double), ("K", C.c_double * 9), ("width", C.c_int), ("height", C.c_int),
                 ("tic", C.c_double * 3), ("ric", C.c_double * 9), ("estimate_extrinsic", C.c_int),
                 ("angle_th", C.c_double), ("overlap_th", C.c_double), ("dist_th", C.c_double),
-                ("num_iterations", C.c_int), ("fixed_iterations", C.c_int)]
+                ("num_iterations", C.c_int), ("fixed_iterations", C.c_int), ("line_exact_jacobian", C.c_int), ("pad_", C.c_int)]
 
 
 class _EstimatorStats(C.Structure):
@@ -762,7 +768,8 @@ class _EstimatorStats(C.Structure):
                 ("iterations", C.c_int), ("prior_n", C.c_int), ("final_cost", C.c_double)]
 
 
-def run_many_native(streams, num_iterations: int = 8, fixed_iterations: bool = False, init_sigma=(0.02, 0.005, 0.05), bias_sigma=(0.005, 0.0005)):
+def run_many_native(streams, num_iterations: int = 8, fixed_iterations: bool = False, init_sigma=(0.02, 0.005, 0.05), bias_sigma=(0.005, 0.0005),
+                    exact_line_jacobian: bool = False):
     """`run_many` with the window management in native code (tcv_estimator_*, one estimator per stream, lock-step
     tcv_estimators_optimize): Python only feeds the per-frame streams.  Same perturbation draws as `run` / `run_many`."""
     import tcv
@@ -784,7 +791,7 @@ def run_many_native(streams, num_iterations: int = 8, fixed_iterations: bool = F
     cfg.gravity[:] = list(G); cfg.imu_dt = synth.DT_IMU; cfg.K[:] = list(synth.K_MAT.reshape(9)); cfg.width = int(synth.IMG_W); cfg.height = int(synth.IMG_H)
     cfg.tic[:] = list(synth.TIC); cfg.ric[:] = list(synth.RIC.reshape(9)); cfg.estimate_extrinsic = 1
     cfg.angle_th, cfg.overlap_th, cfg.dist_th = 0.1745, 0.45, 50.0
-    cfg.num_iterations = num_iterations; cfg.fixed_iterations = int(fixed_iterations)
+    cfg.num_iterations = num_iterations; cfg.fixed_iterations = int(fixed_iterations); cfg.line_exact_jacobian = int(exact_line_jacobian)
     f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
     P = lambda a: a.ctypes.data_as(dp)
     ests, rngs, outs = [], [], []

@@ -29,7 +29,7 @@ EXPORTS = [
     "tcv_version", "tcv_last_error", "tcv_device_count", "tcv_set_device",
     "tcv_problem_create", "tcv_problem_destroy", "tcv_problem_add_parameter_block",
     "tcv_problem_set_parameter_block_constant", "tcv_problem_set_gravity", "tcv_problem_add_imu_factor",
-    "tcv_problem_add_projection_factor", "tcv_problem_add_projection_td_factor", "tcv_problem_set_rolling_shutter", "tcv_problem_add_line_factor", "tcv_problem_add_marginalization_factor",
+    "tcv_problem_add_projection_factor", "tcv_problem_add_projection_td_factor", "tcv_problem_set_rolling_shutter", "tcv_problem_set_line_jacobian", "tcv_problem_add_line_factor", "tcv_problem_add_marginalization_factor",
     "tcv_problem_from_window", "tcv_problem_num_parameter_blocks", "tcv_problem_num_residual_blocks",
     "tcv_problem_num_residuals", "tcv_problem_plan_stats", "tcv_solver_options_default", "tcv_solve", "tcv_marginalize",
     "tcv_prior_create", "tcv_prior_dims", "tcv_prior_export", "tcv_prior_export_schur", "tcv_prior_keep_block_addresses", "tcv_prior_destroy",
@@ -74,7 +74,8 @@ class WindowDesc(C.Structure):
                 ("line_K", C.c_double * 9), ("line_Ric", C.c_double * 9), ("line_Tic", C.c_double * 3),
                 ("line_loss_a", C.c_double), ("gravity", C.c_double * 3),
                 ("prior", C.c_void_p), ("prior_block_kind", _ip), ("prior_block_index", _ip),
-                ("para_td", _dp), ("proj_td_aux", _dp), ("td_TR", C.c_double), ("td_ROW", C.c_double)]
+                ("para_td", _dp), ("proj_td_aux", _dp), ("td_TR", C.c_double), ("td_ROW", C.c_double),
+                ("line_exact_jacobian", C.c_int), ("pad_", C.c_int)]
 
 
 _lib = None
@@ -107,6 +108,7 @@ def lib():
         L.tcv_problem_add_line_factor.argtypes = [vp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_double, _dp]
         L.tcv_problem_add_projection_td_factor.argtypes = [vp, _dp, _dp, _dp, _dp] + [C.c_double] * 6 + [_dp] * 5
         L.tcv_problem_set_rolling_shutter.argtypes = [vp, C.c_double, C.c_double]
+        L.tcv_problem_set_line_jacobian.argtypes = [vp, C.c_int]
         L.tcv_problem_add_marginalization_factor.argtypes = [vp, vp, C.POINTER(_dp), C.c_int]
         L.tcv_problem_from_window.argtypes = [C.POINTER(WindowDesc), C.POINTER(vp)]
         for f in ("tcv_problem_num_parameter_blocks", "tcv_problem_num_residual_blocks", "tcv_problem_num_residuals"):
@@ -278,6 +280,7 @@ class Window:
         d.line_K[:] = list(np.asarray(ln["K"]).reshape(9)); d.line_Ric[:] = list(np.asarray(ln["Ric"]).reshape(9))
         d.line_Tic[:] = list(np.asarray(ln["Tic"]).reshape(3)); d.line_loss_a = float(ln["loss_a"] or 0.0)
         d.gravity[:] = list(np.asarray(win["G"]).reshape(3))
+        d.line_exact_jacobian = int(bool(ln.get("exact_jacobian", False)))
         if self.td is not None:
             n = len(self._pi)
             self._aux = f64(np.concatenate([np.asarray(pr["vel_i"], dtype=float).reshape(n, 2), np.asarray(pr["vel_j"], dtype=float).reshape(n, 2),

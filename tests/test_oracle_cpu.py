@@ -264,3 +264,24 @@ def test_time_offset_window_in_the_numpy_oracle():
     po, dbg = npo.marginalize_old(P, x8)
     assert po["n"] == 76 and po["sizes"][-1] == 1 and tuple(po["blocks"][-1]) == ("td", 0)
     assert np.abs(po["J0"].T @ po["J0"] - dbg["A_schur"]).max() < 1e-6 * np.abs(dbg["A_schur"]).max()
+
+
+def test_exact_line_jacobian_is_the_derivative_of_the_reference_residual():
+    """the opt-in extension tcv_problem_set_line_jacobian(p, 1): same residual as LineProjectionFactor, Jacobian = its derivative under
+    PoseLocalParameterization::Plus (finite differences); the reference's own Jacobian (default) is not (SURVEY.md 8(a) L1)."""
+    z = load("factors.npz")
+    K, Ric, Tic = z["l1_K"], z["l1_Ric"], z["l1_Tic"]
+    worst_exact, worst_ref = 0.0, 0.0
+    for k in range(8):
+        pose = z["l1_pose"][k]; ps, pe, abc = z["l1_start"][k], z["l1_end"][k], z["l1_abc"][k]
+        r0, Je = npo.line_evaluate(pose, ps, pe, abc, K, Ric, Tic, True, exact=True)
+        r1, Jr = npo.line_evaluate(pose, ps, pe, abc, K, Ric, Tic, True)
+        assert np.array_equal(r0, r1)
+        fd = np.zeros((2, 6)); h = 1e-6
+        for c in range(6):
+            d = np.zeros(6); d[c] = h
+            fd[:, c] = (npo.line_evaluate(npo.pose_plus(pose, d), ps, pe, abc, K, Ric, Tic, False)[0] -
+                        npo.line_evaluate(npo.pose_plus(pose, -d), ps, pe, abc, K, Ric, Tic, False)[0]) / (2 * h)
+        worst_exact = max(worst_exact, np.abs(Je[0][:, :6] - fd).max() / np.abs(fd).max())
+        worst_ref = max(worst_ref, np.abs(Jr[0][:, :6] - fd).max() / np.abs(fd).max())
+    assert worst_exact < 1e-5 and worst_ref > 0.5

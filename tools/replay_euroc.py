@@ -22,6 +22,7 @@ ap.add_argument("--lines", type=int, default=8)
 ap.add_argument("--line-mode", choices=("associate", "given", "none"), default="associate",
                 help="associate: the 2D-3D association (tcv_match_lines + removeLineOutlier) runs in the loop, as in the reference; "
                      "given: every line observation arrives with its true 3D partner; none: no line factors")
+ap.add_argument("--exact-line-jacobian", action="store_true", help="opt-in extension: derivative of the line residual instead of the reference's Jacobian (tcv_problem_set_line_jacobian)")
 ap.add_argument("--native", action="store_true", help="window management in native code (include/tcv_estimator.h) instead of replay.Replay")
 ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "euroc"))
 args = ap.parse_args()
@@ -37,7 +38,7 @@ t0 = time.perf_counter()
 streams = [replay.simulate_stream_euroc(s, args.frames, start_s=args.start, max_features=args.features, max_lines=0 if args.line_mode == "none" else args.lines,
                                          associate=args.line_mode == "associate") for s in seqs]
 t1 = time.perf_counter()
-outs = (replay.run_many_native(streams, num_iterations=8) if args.native else replay.run_many(streams, replay.HipBackend(), num_iterations=8)) if streams else []
+outs = (replay.run_many_native(streams, num_iterations=8, exact_line_jacobian=args.exact_line_jacobian) if args.native else replay.run_many(streams, replay.HipBackend(), num_iterations=8, exact_line_jacobian=args.exact_line_jacobian)) if streams else []
 t2 = time.perf_counter()
 rows = []
 for st, o in zip(streams, outs):
@@ -51,8 +52,8 @@ for st, o in zip(streams, outs):
                      margin_old=flags.count(replay.MARGIN_OLD), margin_second_new=flags.count(replay.MARGIN_SECOND_NEW),
                      point_factors_mean=round(float(np.mean([l["n_proj"] for l in o["log"]])), 1), line_factors_mean=round(float(np.mean([l["n_line"] for l in o["log"]])), 1)))
 frames = sum(r["optimised_frames"] for r in rows)
-res = dict(rank=rank, world=world, line_mode=args.line_mode, window_management="native" if args.native else "python", sequences=rows, optimised_frames=frames, simulate_s=round(t1 - t0, 2), replay_s=round(t2 - t1, 2),
+res = dict(rank=rank, world=world, line_mode=args.line_mode, line_jacobian="exact" if args.exact_line_jacobian else "reference", window_management="native" if args.native else "python", sequences=rows, optimised_frames=frames, simulate_s=round(t1 - t0, 2), replay_s=round(t2 - t1, 2),
            frames_per_s=round(frames / max(t2 - t1, 1e-9), 1))
-with open(os.path.join(args.out, "replay_euroc_%s_rank%d.json" % (args.line_mode, rank)), "w") as f:
+with open(os.path.join(args.out, "replay_euroc_%s%s_rank%d.json" % (args.line_mode, "_exactJ" if args.exact_line_jacobian else "", rank)), "w") as f:
     json.dump(res, f, indent=1)
 print(json.dumps(res))
