@@ -347,6 +347,27 @@ TCV_HD void proj_td_eval(const double *pose_i, const double *pose_j, const doubl
 
 // ---- 2D-3D line factor (prior 3D map line vs detected 2D line) ---------------------------------------
 // lc: pts_start xyz, pts_end xyz, A B C;  K / Ric / Tic row-major constants.  J 2 x 6 row-major local.
+// exact Jacobian of the line residual (opt-in, see line_eval); out of line so that the default path keeps its register allocation
+TCV_HD __attribute__((noinline)) void line_exact_jacobian(const V3 &T_w, const M3 &R_w, const M3 &bcRT, const V3 &pcs, const V3 &pce, double us, double vs,
+                                                          double ue, double ve, const double *lc, double fx, double fy, double *J, int ld) {
+    const double a = lc[6], b = lc[7], c = lc[8], d = a * a + b * b;
+    const double isd = 1.0 / sqrt(d);
+    for (int e = 0; e < 2; e++) {
+        const V3 p = e ? pce : pcs;
+        const double L = a * (e ? ue : us) + b * (e ? ve : vs) + c;          // r = |L| / sqrt(d)
+        const double sg = L > 0.0 ? isd : (L < 0.0 ? -isd : 0.0);
+        const double e1 = sg * a, e2 = sg * b;
+        const V3 ew(e1 * (fx / p.z), e2 * (fy / p.z), e1 * (-fx * p.x / (p.z * p.z)) + e2 * (-fy * p.y / (p.z * p.z)));      // d r / d p_cam
+        // p_cam = Ric' (R_w' (P - T_w) - Tic):  d p_cam / d dp = -Ric' R_w',  d p_cam / d dtheta = Ric' skew(R_w' (P - T_w))
+        const V3 y = transpose(R_w) * (V3(lc + 3 * e) - T_w);
+        const V3 g = vT_mul(ew, bcRT);                 // ew' Ric'
+        const V3 dp = -vT_mul(g, transpose(R_w));
+        const V3 th = vT_mul(g, skew(y));
+        double *o = J + e * ld;
+        o[0] = dp.x; o[1] = dp.y; o[2] = dp.z; o[3] = th.x; o[4] = th.y; o[5] = th.z;
+    }
+}
+
 // exact = false: the reference's Jacobian as written (the derivative of the SQUARED distance chained through [I | skew(p_cam)], a
 // camera-frame perturbation -- not the derivative of r with respect to the world-frame body pose);
 // exact = true (opt-in extension, tcv_problem_set_line_jacobian): d r / d(delta p, delta theta) of the same residual under
@@ -369,21 +390,7 @@ TCV_HD void line_eval(const double *pose, const double *lc, const double *K9, co
     if (!J) return;
     const double fx = K9[0], fy = K9[4];
     if (exact) {
-        const double isd = 1.0 / sqrt(d);
-        for (int e = 0; e < 2; e++) {
-            const V3 p = e ? pce : pcs;
-            const double L = a * (e ? ue : us) + b * (e ? ve : vs) + c;          // r = |L| / sqrt(d)
-            const double sg = L > 0.0 ? isd : (L < 0.0 ? -isd : 0.0);
-            const double e1 = sg * a, e2 = sg * b;
-            const V3 ew(e1 * (fx / p.z), e2 * (fy / p.z), e1 * (-fx * p.x / (p.z * p.z)) + e2 * (-fy * p.y / (p.z * p.z)));      // d r / d p_cam
-            // p_cam = Ric' (R_w' (P - T_w) - Tic):  d p_cam / d dp = -Ric' R_w',  d p_cam / d dtheta = Ric' skew(R_w' (P - T_w))
-            const V3 y = transpose(R_w) * (V3(lc + 3 * e) - T_w);
-            const V3 g = vT_mul(ew, bcRT);                 // ew' Ric'
-            const V3 dp = -vT_mul(g, transpose(R_w));
-            const V3 th = vT_mul(g, skew(y));
-            double *o = J + e * ld;
-            o[0] = dp.x; o[1] = dp.y; o[2] = dp.z; o[3] = th.x; o[4] = th.y; o[5] = th.z;
-        }
+        line_exact_jacobian(T_w, R_w, bcRT, pcs, pce, us, vs, ue, ve, lc, fx, fy, J, ld);
         return;
     }
     for (int e = 0; e < 2; e++) {
