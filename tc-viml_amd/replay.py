@@ -15,8 +15,10 @@ marginalisation kernels).  The tests plug the CPU oracle in through the same int
 
 The image/IMU front end (feature tracker, line detector, ROS) is out of scope; `simulate_stream` produces the per-frame
 streams it would deliver -- IMU samples, tracked point features, matched 2D-3D lines -- from an analytic trajectory with the
-sensor model of benchmark_publisher/config/V1_01_easy/sensor.yaml.  Initialisation (initialStructure, estimator.cpp:1221)
-is out of scope too: the first window starts from perturbed ground truth.
+sensor model of benchmark_publisher/config/V1_01_easy/sensor.yaml, `simulate_stream_euroc` along the EuRoC ground-truth
+trajectories the reference ships (data/euroc_*.npz).  Initialisation (initialStructure, estimator.cpp:1221) is out of scope too:
+the first window starts from perturbed ground truth.  `run_many_native` drives the same logic in native code
+(include/tcv_estimator.h); this module stays the reference for it and the vehicle for the oracle comparison.
 """
 from __future__ import annotations
 
