@@ -565,20 +565,46 @@ __global__ void __launch_bounds__(MARG_NT) marg_kernel(MargArgs Aarg) {
                 }
                 __syncthreads();
             }
-            for (int e = tid; e < np * np; e += MARG_NT) {
-                const int a = e / np, b = e - a * np;
-                if (b > a) continue;
-                const int ia = pcol[a], ib = pcol[b];
-                if (ia < 0 || ib < 0) continue;
-                double s0 = 0, s1 = 0;
-                if (in_lds) {
-                    const lds_d *ca = R2 + np * a, *cb = R2 + np * b;
-                    for (int i = 0; i + 1 < np; i += 2) { s0 += ca[i] * cb[i]; s1 += ca[i + 1] * cb[i + 1]; }
-                    if (np & 1) s0 += ca[np - 1] * cb[np - 1];
-                } else {
-                    for (int i = 0; i < np; i++) s0 += J0[i + np * a] * J0[i + np * b];
+            if (in_lds) {
+                // J0' J0 on the matrix cores: 16 x 16 output tiles of the lower triangle, one per wavefront at a time,
+                // v_mfma_f64_16x16x4 over the rows of J0 (column-major in LDS: J0[i + np a]); rows beyond np contribute zeros
+                typedef double v4f64 __attribute__((ext_vector_type(4)));
+                const int nt16 = (np + 15) >> 4, lane = tid & 63, wave = tid >> 6;
+                const int m16 = lane & 15, k4 = lane >> 4;
+                for (int t = wave; t < nt16 * (nt16 + 1) / 2; t += MARG_NT / 64) {
+                    int ta = 0;
+                    while ((ta + 1) * (ta + 2) / 2 <= t) ta++;
+                    const int tb = t - ta * (ta + 1) / 2;
+                    const int a = 16 * ta + m16, b = 16 * tb + m16;
+                    const lds_d *ca = R2 + np * min(a, np - 1), *cb = R2 + np * min(b, np - 1);
+                    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+                    for (int i0 = 0; i0 < np; i0 += 16) {
+                        double av[4], bv[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const int i = i0 + 4 * u + k4;
+                            const double x = ca[min(i, np - 1)], y = cb[min(i, np - 1)];
+                            av[u] = (i < np && a < np) ? x : 0.0; bv[u] = (i < np && b < np) ? y : 0.0;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {      // acc[i] = G[16 ta + 4 i + k4][16 tb + m16]
+                        const int ga = 16 * ta + 4 * i + k4, gb = 16 * tb + m16;
+                        if (ga < np && gb <= ga) { const int ia = pcol[ga], ib = pcol[gb]; if (ia >= 0 && ib >= 0) Apk[pidx(ia, ib)] += acc[i]; }
+                    }
                 }
-                Apk[pidx(ia, ib)] += s0 + s1;
+            } else {
+                for (int e = tid; e < np * np; e += MARG_NT) {
+                    const int a = e / np, b = e - a * np;
+                    if (b > a) continue;
+                    const int ia = pcol[a], ib = pcol[b];
+                    if (ia < 0 || ib < 0) continue;
+                    double s0 = 0;
+                    for (int i = 0; i < np; i++) s0 += J0[i + np * a] * J0[i + np * b];
+                    Apk[pidx(ia, ib)] += s0;
+                }
             }
             if (tid < np && pcol[tid] >= 0) {
                 double s2 = 0;
