@@ -112,3 +112,38 @@ def test_native_estimator_matches_the_python_window_management(gpu, associate):
         print("native vs python max |dp| %.2e m" % d.max())
         assert d[:m].max() < 1e-4
         assert np.abs(a["q"][:m] - b["q"][:m]).max() < 1e-4 and np.abs(a["v"][:m] - b["v"][:m]).max() < 1e-3
+
+
+def test_windows_of_a_replay_one_by_one_vs_oracle(gpu):
+    """every window a replay hands to the solver (30 different graph structures: growing / sliding feature tracks, both
+    marginalisation modes' priors, ~60 line factors) solved by the HIP path and by the C oracle from identical inputs: same
+    iteration count, accept / reject sequence and dogleg cases, final cost and states to 1e-6 (north-star), run to convergence with
+    the Ceres tolerances."""
+    import orc
+
+    wins = []
+
+    class Spy(OracleBackend):
+        def optimize(self, win, flag, ni, fi):
+            wins.append(win)
+            return super().optimize(win, flag, ni, fi)
+
+    stream = replay.simulate_stream_euroc("V2_02_medium", 40, start_s=3.0, max_features=50, max_lines=6)
+    replay.run(stream, Spy(), num_iterations=8)
+    assert len(wins) == 30 and len({(len(w["proj"]["frame_i"]), len(w["lam"])) for w in wins}) > 20
+    W = [gpu.Window(w) for w in wins]
+    b = gpu.Batch(W)
+    assert b.plan_stats()["num_plans"] > 20 and b.plan_stats()["layout"] == "chain"
+    b.solve(gpu.default_options(20, False)); b.synchronize(); b.download_states()
+    s = b.summaries()
+    worst = 0.0
+    for k, w in enumerate(wins):
+        O = orc.Window(w); so = O.solve(20, False); st = O.states()
+        assert s[k].num_iterations == so.num_iterations and s[k].termination == so.termination, k
+        n = so.num_iterations
+        assert [s[k].step_ok[i] for i in range(n)] == [so.step_ok[i] for i in range(n)], k
+        assert [s[k].dogleg_case[i] for i in range(n)] == [so.dogleg_case[i] for i in range(n)], k
+        worst = max(worst, abs(s[k].final_cost - so.final_cost) / so.final_cost, np.abs(W[k].pose - st["pose"]).max() / np.abs(st["pose"]).max(),
+                    np.abs(W[k].sb - st["sb"]).max() / np.abs(st["sb"]).max())
+    print("worst relative difference over 30 windows: %.2e" % worst)
+    assert worst < 1e-6
