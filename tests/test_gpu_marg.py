@@ -167,3 +167,41 @@ def test_marginalise_error_paths(gpu):
     bogus = np.zeros(7)
     arr = (gpu._dp * 1)(gpu.dptr(bogus))
     assert gpu.lib().tcv_marginalize(W.h, arr, 1, C.byref(h)) in (gpu.TCV_ERR_INVALID, gpu.TCV_ERR_UNSUPPORTED)
+
+
+def test_marginalisation_of_replay_windows_one_by_one_vs_oracle(gpu):
+    """MARGIN_OLD of every keyframe window of a replay (different numbers of landmarks anchored in the oldest frame => different m,
+    incoming priors from the chain) at identical, gauge-fixed states: (m, n), kept blocks, A' and b' against the C oracle."""
+    import np_oracle as NO
+    import replay
+    from replay_oracle import OracleBackend
+
+    got = []
+
+    class Spy(OracleBackend):
+        def optimize(self, win, flag, ni, fi):
+            out = super().optimize(win, flag, ni, fi)
+            if flag == replay.MARGIN_OLD:
+                got.append(dict(win, pose=out["pose"], speedbias=out["sb"], ex_pose=out["ex"], lam=out["lam"]))
+            return out
+
+    stream = replay.simulate_stream_euroc("V1_02_medium", 36, start_s=5.0, max_features=50, max_lines=0)
+    replay.run(stream, Spy(), num_iterations=8)
+    assert len(got) >= 15
+    ms = set()
+    worstA = worstb = 0.0
+    for w2 in got:
+        po, dbg = orc.Window(w2).marginalize_old()
+        mw = gpu.margin_old_window(w2)
+        Wm = gpu.Window(mw)
+        dr = gpu.margin_old_drops(Wm, mw)
+        arr = (gpu._dp * len(dr))(*dr)
+        h = C.c_void_p()
+        gpu.check(gpu.lib().tcv_marginalize(Wm.h, arr, len(dr), C.byref(h)))
+        P = gpu.Prior(h); d = P.export(); As, bs = P.schur()
+        assert (d["m"], d["n"]) == (po["m"], po["n"]) and d["sizes"] == list(po["sizes"])
+        ms.add(d["m"])
+        worstA = max(worstA, fro(As, dbg["A_schur"])); worstb = max(worstb, fro(bs, dbg["b_schur"]))
+        assert fro(d["J0"].T @ d["J0"], dbg["A_schur"]) < 1e-5
+    print("m values", sorted(ms), "worst A' %.2e b' %.2e" % (worstA, worstb))
+    assert len(ms) >= 4 and worstA < 1e-5 and worstb < 1e-6
