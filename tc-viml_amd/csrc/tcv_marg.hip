@@ -268,6 +268,7 @@ __device__ __noinline__ void eig_backtransform(const lds_d *A, lds_d *Z, const l
     }
 }
 
+__device__ __forceinline__ double rank2(double a, double vr, double wc, double wr, double vc) { return a - (vr * wc + wr * vc); }
 __device__ __noinline__ bool sym_eig_tridiag(lds_d *A, lds_d *Z, lds_d *W, lds_d *sm, lds_d *lam, int n, int ld, int tid, gbl_d *dbg) {
     constexpr int NT = MARG_NT, NW = MARG_NT / 64;
     lds_d *dv = sm, *ev = sm + 80, *tauv = sm + 160, *vbuf = sm + 240, *pbuf = sm + 320, *red = sm + 400, *e2 = sm + 416;
@@ -281,31 +282,43 @@ __device__ __noinline__ bool sym_eig_tridiag(lds_d *A, lds_d *Z, lds_d *W, lds_d
 #define EMARK(id) do { } while (0)
 #endif
     if (tid == 0 && dbg) for (int i = 0; i < 6; i++) dbg[8 + i] = 0.0;
+    __syncthreads();
     // ---- (1) tridiagonalisation.  Step i: x = A[i+1:, i] (read as row i: the matrix is kept fully symmetric).  Every
     // 4-lane group owns one row r of A22 and forms u_r = A22[r,:] x together with |x[1:]|^2 in the same sweep, so that
     // beta, tau and v = (x - beta e1) / (alpha - beta) need no extra pass: A22 v = (u - beta A22[:,0]) / (alpha - beta).
-    for (int i = 0; i + 1 < n; i++) {
-        const int m = n - i - 1;
+    // The product u = A22 x of step i + 1 is formed inside the rank-2 update of step i (every thread derives the entries of the next
+    // x -- the updated first row of A22 -- it needs from the old row, v and w), so a step is: scalars + v, p | barrier | update with
+    // the next product | barrier.  Only step 0 runs the product on its own.
+    lds_d *ubuf = W, *xold = W + 96, *xnb = W + 192;      // W (n x ld workspace) is free until the eigenvector stage
+    {
+        const int m = n - 1;
         const int r = tid >> 2, part = tid & 3;
-        const lds_d *xrow = A + i * ld + (i + 1);
+        const lds_d *xrow = A + 1;
         double u = 0, xn2 = 0;
-        {   // m <= 79: at most 20 columns per lane; loads batched five at a time, clamped and masked
-            const lds_d *row = A + (i + 1 + (r < m ? r : 0)) * ld + (i + 1);
+        const lds_d *row = A + (1 + (r < m ? r : 0)) * ld + 1;
 #pragma unroll
-            for (int j0 = 0; j0 < 20; j0 += 5) {
-                if (part + 4 * j0 >= m) break;
-                double rv[5], xv[5];
+        for (int j0 = 0; j0 < 20; j0 += 5) {
+            if (part + 4 * j0 >= m) break;
+            double rv[5], xv[5];
 #pragma unroll
-                for (int j = 0; j < 5; j++) { const int c = min(part + 4 * (j0 + j), m - 1); rv[j] = row[c]; xv[j] = xrow[c]; }
+            for (int j = 0; j < 5; j++) { const int c = min(part + 4 * (j0 + j), m - 1); rv[j] = row[c]; xv[j] = xrow[c]; }
 #pragma unroll
-                for (int j = 0; j < 5; j++) {
-                    const int c = part + 4 * (j0 + j);
-                    if (c < m) { u += rv[j] * xv[j]; if (c > 0) xn2 += xv[j] * xv[j]; }
-                }
+            for (int j = 0; j < 5; j++) {
+                const int c = part + 4 * (j0 + j);
+                if (c < m) { u += rv[j] * xv[j]; if (c > 0) xn2 += xv[j] * xv[j]; }
             }
         }
         u += __shfl_xor(u, 1); u += __shfl_xor(u, 2);
         xn2 += __shfl_xor(xn2, 1); xn2 += __shfl_xor(xn2, 2);
+        if (r < m && part == 0) ubuf[r] = u;
+        if (tid == 0) xnb[0] = xn2;
+        __syncthreads();
+    }
+    for (int i = 0; i + 1 < n; i++) {
+        const int m = n - i - 1;
+        const int r = tid;
+        const lds_d *xrow = A + i * ld + (i + 1);
+        const double xn2 = xnb[i & 1];
         const double alpha = xrow[0];
         double tau = 0.0, beta = alpha, scale = 0.0;
         if (xn2 > 0.0) {
@@ -317,36 +330,62 @@ __device__ __noinline__ bool sym_eig_tridiag(lds_d *A, lds_d *Z, lds_d *W, lds_d
             tau = (beta - alpha) * fast_rcp(beta);
             scale = fast_rcp(alpha - beta);
         }
+#ifdef TCV_FUSE_DEBUG
+        if (r < m && dbg) {
+            double uref = 0, x2ref = 0;
+            for (int c = 0; c < m; c++) { uref += A[(i + 1 + r) * ld + (i + 1 + c)] * xrow[c]; if (c > 0) x2ref += xrow[c] * xrow[c]; }
+            const double du = fabs(uref - ubuf[r]) / (fabs(uref) + 1e-300), dx = fabs(x2ref - xn2) / (x2ref + 1e-300);
+            if (du > 1e-9 && dbg[10] == 0.0) { dbg[10] = 1000.0 * i + r; dbg[8] = du * 1e15; dbg[12] = uref; dbg[13] = ubuf[r]; }
+            if (dx > 1e-9 && dbg[11] == 0.0) { dbg[11] = (double)i + 0.5; dbg[9] = dx * 1e15; }
+        }
+#endif
         double pv = 0;
-        if (r < m && part == 0) {
+        if (r < m) {
+            const double a0 = A[(i + 1 + r) * ld + (i + 1)];
             const double vr = (r == 0) ? 1.0 : xrow[r] * scale;
-            const double pr = tau * scale * (u - beta * A[(i + 1 + r) * ld + (i + 1)]);
+            const double pr = tau * scale * (ubuf[r] - beta * a0);
             vbuf[r] = vr; pbuf[r] = pr;
+            xold[r] = A[(i + 1) * ld + (i + 1 + r)];      // the old first ROW of A22, element r: the fused product must predict exactly the row the
+                                                          // next step reads (the two triangles agree to rounding only, which matters for the small
+                                                          // entries deep in a graded matrix)
             pv = pr * vr;
         }
-        for (int o = 32; o > 0; o >>= 1) pv += __shfl_down(pv, o);
-        if (lane == 0) red[wave] = pv;
+        if (tid < 128) {      // m <= 79: the first two wavefronts hold all the terms
+            for (int o = 32; o > 0; o >>= 1) pv += __shfl_down(pv, o);
+            if (lane == 0) red[wave] = pv;
+        }
         if (tid == 0) { dv[i] = A[i * ld + i]; ev[i] = beta; tauv[i] = tau; }
         __syncthreads();
-        if (tau != 0.0) {
-            double K = 0;
-#pragma unroll
-            for (int w = 0; w < NW; w++) K += red[w];
-            K *= -0.5 * tau;
+        {
+            const double K = -0.5 * tau * (red[0] + red[1]);
+            const double v0 = vbuf[0], w0 = pbuf[0] + K * v0;
             // A22 -= v w' + w v',  w = p + K v ; eight lanes per row.  Column i keeps the reflector for the back-transform.
+            // Next step: x' = new A22[0][1:], u'_(rr-1) = sum_(c >= 1) new A22[rr][c] x'[c], |x'[1:]|^2.
             const int part8 = tid & 7;
-            for (int rr = tid >> 3; rr < m; rr += NT / 8) {
-                const double vr = vbuf[rr], wr = pbuf[rr] + K * vr;
-                lds_d *row = A + (i + 1 + rr) * ld + (i + 1);
-                double vc[10], pc[10], av[10];      // m <= 79: at most 10 columns per lane, every load in flight at once
+            for (int rr = tid >> 3; rr < ((m + 7) & ~7); rr += NT / 8) {
+                const int rc = min(rr, m - 1);
+                const double vr = vbuf[rc], wr = pbuf[rc] + K * vr;
+                lds_d *row = A + (i + 1 + rc) * ld + (i + 1);
+                double vc[10], pc[10], av[10], xo[10];      // m <= 79: at most 10 columns per lane, every load in flight at once
 #pragma unroll
-                for (int j = 0; j < 10; j++) { const int c = min(part8 + 8 * j, m - 1); vc[j] = vbuf[c]; pc[j] = pbuf[c]; av[j] = row[c]; }
+                for (int j = 0; j < 10; j++) { const int c = min(part8 + 8 * j, m - 1); vc[j] = vbuf[c]; pc[j] = pbuf[c]; av[j] = row[c]; xo[j] = xold[c]; }
+                double un = 0, x2 = 0;
 #pragma unroll
                 for (int j = 0; j < 10; j++) {
                     const int c = part8 + 8 * j;
-                    if (c < m) row[c] = av[j] - (vr * (pc[j] + K * vc[j]) + wr * vc[j]);
+                    if (c < m) {
+                        const double wc = pc[j] + K * vc[j];
+                        const double nv = rank2(av[j], vr, wc, wr, vc[j]);
+                        const double xn = rank2(xo[j], v0, wc, w0, vc[j]);      // new A22[0][c], bit for bit what row 0's lanes store
+                        if (rr < m) row[c] = nv;
+                        if (c >= 1) { un += nv * xn; if (c >= 2) x2 += xn * xn; }
+                    }
                 }
-                if (part8 == 0 && rr > 0) A[(i + 1 + rr) * ld + i] = vr;
+                un += __shfl_xor(un, 1); un += __shfl_xor(un, 2); un += __shfl_xor(un, 4);
+                x2 += __shfl_xor(x2, 1); x2 += __shfl_xor(x2, 2); x2 += __shfl_xor(x2, 4);
+                if (part8 == 0 && rr >= 1 && rr < m) ubuf[rr - 1] = un;
+                if (part8 == 0 && rr == 1) xnb[(i + 1) & 1] = x2;
+                if (part8 == 0 && rr > 0 && rr < m) A[(i + 1 + rr) * ld + i] = vr;
             }
         }
         __syncthreads();
