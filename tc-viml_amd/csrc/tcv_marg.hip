@@ -244,24 +244,31 @@ __device__ __noinline__ void eig_backtransform(const lds_d *A, lds_d *Z, const l
     // all LDS loads are unconditional (clamped row) and masked afterwards: a conditional load becomes an exec-mask
     // branch with its own wait, which serialises the loads at full LDS latency
     for (int q = 0; q < 20; q++) { const int R = sub + 4 * q; const double t = Z[min(R, n - 1) * ld + cs]; z[q] = (R < n) ? t : 0.0; }
+    // reflector i is zero above row i + 1: the late reflectors (applied first) only touch the lower rows, so the register slots
+    // q < Q0 (rows < 4 Q0 <= i + 1) are skipped in four static regimes -- same sums, bit for bit (the skipped terms are exact zeros)
+#define TCV_BT_BODY(Q0)                                                                                      \
+    do {                                                                                                     \
+        double v[20], sum = 0;                                                                               \
+        _Pragma("unroll") for (int q = Q0; q < 20; q++) v[q] = A[min(sub + 4 * q, n - 1) * ld + i];         \
+        _Pragma("unroll") for (int q = Q0; q < 20; q++) {                                                    \
+            const int R = sub + 4 * q;                                                                       \
+            v[q] = (R > i + 1 && R < n) ? v[q] : ((R == i + 1) ? 1.0 : 0.0);                                 \
+            sum += v[q] * z[q];                                                                              \
+        }                                                                                                    \
+        sum += __shfl_xor(sum, 1);                                                                           \
+        sum += __shfl_xor(sum, 2);                                                                           \
+        const double w = tau * sum;                                                                          \
+        _Pragma("unroll") for (int q = Q0; q < 20; q++) z[q] -= v[q] * w;                                    \
+    } while (0)
     for (int i = n - 2; i >= 0; i--) {
         const double tau = tauv[i];
         if (tau == 0.0) continue;
-        double v[20], sum = 0;
-#pragma unroll
-        for (int q = 0; q < 20; q++) v[q] = A[min(sub + 4 * q, n - 1) * ld + i];
-#pragma unroll
-        for (int q = 0; q < 20; q++) {
-            const int R = sub + 4 * q;
-            v[q] = (R > i + 1 && R < n) ? v[q] : ((R == i + 1) ? 1.0 : 0.0);
-            sum += v[q] * z[q];
-        }
-        sum += __shfl_xor(sum, 1);
-        sum += __shfl_xor(sum, 2);
-        const double w = tau * sum;
-#pragma unroll
-        for (int q = 0; q < 20; q++) z[q] -= v[q] * w;
+        if (i + 1 >= 60) TCV_BT_BODY(15);
+        else if (i + 1 >= 40) TCV_BT_BODY(10);
+        else if (i + 1 >= 20) TCV_BT_BODY(5);
+        else TCV_BT_BODY(0);
     }
+#undef TCV_BT_BODY
     if (c < n) {
 #pragma unroll
         for (int q = 0; q < 20; q++) { const int R = sub + 4 * q; if (R < n) Z[R * ld + c] = z[q]; }
