@@ -289,7 +289,6 @@ __device__ __noinline__ bool sym_eig_tridiag(lds_d *A, lds_d *Z, lds_d *W, lds_d
 #define EMARK(id) do { } while (0)
 #endif
     if (tid == 0 && dbg) for (int i = 0; i < 6; i++) dbg[8 + i] = 0.0;
-    __syncthreads();
     // ---- (1) tridiagonalisation.  Step i: x = A[i+1:, i] (read as row i: the matrix is kept fully symmetric).  Every
     // 4-lane group owns one row r of A22 and forms u_r = A22[r,:] x together with |x[1:]|^2 in the same sweep, so that
     // beta, tau and v = (x - beta e1) / (alpha - beta) need no extra pass: A22 v = (u - beta A22[:,0]) / (alpha - beta).
@@ -337,15 +336,6 @@ __device__ __noinline__ bool sym_eig_tridiag(lds_d *A, lds_d *Z, lds_d *W, lds_d
             tau = (beta - alpha) * fast_rcp(beta);
             scale = fast_rcp(alpha - beta);
         }
-#ifdef TCV_FUSE_DEBUG
-        if (r < m && dbg) {
-            double uref = 0, x2ref = 0;
-            for (int c = 0; c < m; c++) { uref += A[(i + 1 + r) * ld + (i + 1 + c)] * xrow[c]; if (c > 0) x2ref += xrow[c] * xrow[c]; }
-            const double du = fabs(uref - ubuf[r]) / (fabs(uref) + 1e-300), dx = fabs(x2ref - xn2) / (x2ref + 1e-300);
-            if (du > 1e-9 && dbg[10] == 0.0) { dbg[10] = 1000.0 * i + r; dbg[8] = du * 1e15; dbg[12] = uref; dbg[13] = ubuf[r]; }
-            if (dx > 1e-9 && dbg[11] == 0.0) { dbg[11] = (double)i + 0.5; dbg[9] = dx * 1e15; }
-        }
-#endif
         double pv = 0;
         if (r < m) {
             const double a0 = A[(i + 1 + r) * ld + (i + 1)];
