@@ -581,15 +581,8 @@ __global__ void __launch_bounds__(MARG_NT) marg_kernel(MargArgs Aarg) {
                 prior_block_dx(xv, x0v, gs, dxv);
                 for (int i = 0; i < 16; i++) if (i < ls) pdx[pb[1] + i] = dxv[i];
             }
-            __syncthreads();
-            if (tid < np) {
-                double r = r0[tid];
-                for (int j = 0; j < np; j++) r += J0[tid + np * j] * pdx[j];
-                pr[tid] = r;
-            }
-            __syncthreads();
             cst_i *pcol = ip + H.o_pcol;
-            // J0 (np x np, column-major) staged in R2 (free until Amm is formed): J0' J0 and J0' r run out of LDS
+            // J0 (np x np, column-major) staged in R2 (free until Amm is formed): r = r0 + J0 dx, J0' J0 and J0' r run out of LDS
             const bool in_lds = np * np <= r2;
             if (in_lds) {
                 for (int e = tid; e < np * np; e += 4 * MARG_NT) {
@@ -599,8 +592,15 @@ __global__ void __launch_bounds__(MARG_NT) marg_kernel(MargArgs Aarg) {
 #pragma unroll
                     for (int k = 0; k < 4; k++) if (e + k * MARG_NT < np * np) R2[e + k * MARG_NT] = v4[k];
                 }
-                __syncthreads();
             }
+            __syncthreads();
+            if (tid < np) {
+                double r = r0[tid];
+                if (in_lds) for (int j = 0; j < np; j++) r += R2[tid + np * j] * pdx[j];
+                else for (int j = 0; j < np; j++) r += J0[tid + np * j] * pdx[j];
+                pr[tid] = r;
+            }
+            __syncthreads();
             if (in_lds) {
                 // J0' J0 on the matrix cores: 16 x 16 output tiles of the lower triangle, one per wavefront at a time,
                 // v_mfma_f64_16x16x4 over the rows of J0 (column-major in LDS: J0[i + np a]); rows beyond np contribute zeros
