@@ -9,17 +9,30 @@ estimator.cpp:1888-1897 made deterministic), the double2vector gauge fix (:1905)
 
 Multi-GPU: windows are independent (per-sequence replay shards one sequence per GPU), so every rank owns
 B windows with rank-offset seeds and there is no data-path collective; RCCL is used only for the barrier
-and the MAX-over-ranks time ("scaling": "weak").
+and the MAX-over-ranks time / SUM-over-ranks counts ("scaling": "weak").
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 8 --steps 20 --warmup 3          # starts 8 fresh ranks itself (torch.distributed.run as a child, before any GPU call)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \
-        bench.py --gpus 8 --steps 20 --warmup 3
+        bench.py --gpus 8 --steps 20 --warmup 3             # what the driver runs: same ranks, launched from outside
+
+Modes (`--mode`):
+    solve   (default) the headline above; at N = 1 the line also carries the CPU baseline (all granted host cores + one core),
+            the single-window latency and the PCIe-inclusive streaming rate as extra keys;
+    replay  BASELINE configs[4]: `--streams` (default 8) EuRoC-trajectory streams, stream s on rank s mod N, every rank advances
+            its streams in lock step through the native estimator (include/tcv_estimator.h): value = optimised windows per second;
+            a step is one frame of every stream;
+    stream  only the PCIe-inclusive figures: host-resident problems -> pack + H2D + solve + gauge fix + marginalisation + D2H,
+            double-buffered over two HIP streams, and the end-to-end latency of a single window.
 """
 from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,6 +45,7 @@ HBM_PEAK_GBS = 8000.0                 # /opt/skills/guides/MI355X_MICROARCH.md: 
 SOLVER_ITERATIONS = 8
 # ALGORITHMIC bytes per trust-region iteration per window (cfg 3: 200 pt, 40 line, prior n=75, L=50)
 BYTES_PER_ITERATION_CFG3 = 89056
+DRY = os.environ.get("TCV_BENCH_DRY") == "1"      # tests only: ranks skip the device work (launch / rendezvous / reduction logic runs for real)
 
 
 def algorithmic_bytes_per_iteration(n_imu, n_pt, n_ln, L, prior_n, prior_x0):
@@ -46,31 +60,70 @@ def shard_ids(rank: int, per_gpu: int) -> int:
     return 100000 + rank * per_gpu
 
 
+def shard_streams(n_streams: int, rank: int, world: int):
+    """sequence s -> GPU s mod G."""
+    return [s for s in range(n_streams) if s % world == rank]
+
+
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(n_gpus: int, argv) -> int:
+    """`python bench.py --gpus N` without a launcher: the parent -- which has not touched the GPU -- starts N fresh ranks as a CHILD
+    process (torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1) and returns its exit code.  Never an exec of a
+    process that initialised the GPU."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
 def dist_setup(n_gpus: int, backend: str | None = None):
     """(rank, world, local_rank, dist-or-None).  For N > 1 every rank is one process launched by torch.distributed.run."""
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != n_gpus:
+        raise SystemExit(f"bench.py: --gpus {n_gpus} but WORLD_SIZE={world}: launch exactly one rank per GPU "
+                         f"(python bench.py --gpus {n_gpus} starts them itself)")
     if world == 1:
         return 0, 1, 0, None
     import torch
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+    backend = backend or ("gloo" if DRY or not torch.cuda.is_available() else "nccl")
     if backend == "nccl":
         torch.cuda.set_device(local)
     dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local, dist
 
 
-def reduce_stats(dist, elapsed_s: float, windows: int, device=None):
-    """MAX of the elapsed time and SUM of the windows over ranks (the only collectives of the whole job)."""
+def reduce_stats(dist, elapsed_s: float, windows: int, device=None, extra=()):
+    """MAX of the elapsed time and SUM of the counts over ranks (the only collectives of the whole job; SURVEY.md 8(e):
+    one all-reduce of {solves, iterations, elapsed})."""
     if dist is None:
-        return elapsed_s, windows
+        return (elapsed_s, windows) + tuple(extra) if extra else (elapsed_s, windows)
     import torch
     t = torch.tensor([elapsed_s], dtype=torch.float64, device=device)
-    w = torch.tensor([float(windows)], dtype=torch.float64, device=device)
+    w = torch.tensor([float(windows)] + [float(v) for v in extra], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(w, op=dist.ReduceOp.SUM)
-    return float(t.item()), int(w.item())
+    out = (float(t.item()), int(w[0].item()))
+    return out + tuple(int(v) for v in w[1:].tolist()) if extra else out
+
+
+def ranks_seen(dist, device=None) -> int:
+    """number of ranks the collective backend (RCCL on the GPU box) actually connects: all-reduce of 1."""
+    if dist is None:
+        return 1
+    import torch
+    one = torch.ones(1, dtype=torch.float64, device=device)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    return int(one.item())
 
 
 def build_batches(tcv, synth, first_id: int, B: int):
@@ -84,7 +137,7 @@ def build_batches(tcv, synth, first_id: int, B: int):
     M = [tcv.Window(mw, share=W[k]) for k, mw in enumerate(MW)]
     drops = [tcv.margin_old_drops(W[k], MW[k]) for k in range(B)]
     b0 = tcv.Batch(W, M, drops)
-    b0.solve(opts); b0.marginalize(); b0.synchronize()
+    b0.solve(opts); b0.marginalize(); b0.synchronize(); b0.download_priors()
     main = synth.make_windows(first_id, B)
     wins, keep = [], []
     for k in range(B):
@@ -100,26 +153,67 @@ def build_batches(tcv, synth, first_id: int, B: int):
     return batch, wins, (Wm, Mm, dropsm)
 
 
-def cpu_baseline(wins, budget_s: float = 12.0):
-    """the CPU restatement (oracle/tcv_oracle.c, one thread like Ceres num_threads = 1) on a bounded sample of
-    the SAME windows: solve (8 fixed iterations) + MARGIN_OLD marginalisation per window."""
+# ---- CPU baseline (the ONLY part of this file that touches oracle/) -------------------------------------------------------
+def _cpu_worker(args):
+    """one host process = one window stream, one thread like Ceres num_threads = 1: solve (8 fixed iterations) + MARGIN_OLD
+    marginalisation per window with the C restatement (oracle/tcv_oracle.c)."""
+    wins, budget_s = args
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import orc
     orc.lib()
-    n, t0 = 0, time.perf_counter()
-    ws = [orc.Window(w) for w in wins[:min(len(wins), 4096)]]
+    n, t_solve = 0, 0.0
+    t_end = time.perf_counter() + budget_s
+    while time.perf_counter() < t_end:
+        ws = [orc.Window(w) for w in wins]          # fresh copies (the solve updates the states in place); not timed
+        t0 = time.perf_counter()
+        for O in ws:
+            O.solve(SOLVER_ITERATIONS, True)
+            O.marginalize_old()
+        t_solve += time.perf_counter() - t0
+        n += len(ws)
+    return n, t_solve
+
+
+def _cpu_quota():
+    """cores' worth of CPU time the cgroup grants (cpu.max), or None."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else float(q) / float(p)
+    except (OSError, ValueError):
+        return None
+
+
+def cpu_pool():
+    """worker processes of the all-core CPU baseline, forked BEFORE this process touches the GPU (they idle until the windows
+    exist).  One process per granted core (affinity mask, capped by the cgroup quota rounded up and by 64)."""
+    import multiprocessing as mp
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    q = _cpu_quota()
+    if q:
+        n = min(n, max(1, int(math.ceil(q))))
+    n = max(1, min(n, 64))
+    return mp.get_context("fork").Pool(n), n
+
+
+def cpu_baseline(wins, pool, nproc, budget_s: float = 12.0):
+    """the CPU restatement on a bounded sample of the SAME windows -- on every granted host core (one process
+    per window stream) and on one core."""
+    per = 4
     t0 = time.perf_counter()
-    for O in ws:
-        O.solve(SOLVER_ITERATIONS, True)
-        O.marginalize_old()
-        n += 1
-        if time.perf_counter() - t0 > budget_s and n >= 16:
-            break
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "solves/s", "cores": 1, "kind": "port",
-            "sample": f"{n} of the benchmark's windows, {SOLVER_ITERATIONS} fixed iterations + 1 marginalisation each, "
-                      f"{dt:.1f} s on one host core (oracle/tcv_oracle.c, gcc -O3; dense Schur, not Ceres)",
-            "host_cpu": _cpu_model(), "host_cores_available": os.cpu_count()}
+    res = pool.map(_cpu_worker, [([wins[(i * per + j) % len(wins)] for j in range(per)], budget_s) for i in range(nproc)])
+    wall = time.perf_counter() - t0
+    pool.close(); pool.join()
+    tot = sum(r[0] for r in res); tmax = max(r[1] for r in res)
+    one_n, one_t = _cpu_worker(([wins[j % len(wins)] for j in range(per)], min(4.0, budget_s)))
+    return {"value": tot / tmax, "unit": "solves/s", "cores": nproc, "kind": "port",
+            "sample": f"{tot} solves of the benchmark's windows ({SOLVER_ITERATIONS} fixed iterations + 1 MARGIN_OLD marginalisation each) on {nproc} host "
+                      f"processes for {tmax:.1f} s ({wall:.1f} s wall), one thread per window stream like Ceres num_threads = 1 "
+                      f"(oracle/tcv_oracle.c, gcc -O3; dense Schur, not Ceres)",
+            "single_core_value": one_n / one_t, "single_core_sample": f"{one_n} solves in {one_t:.1f} s on one core",
+            "host_cpu": _cpu_model(), "host_cores_available": os.cpu_count(), "cgroup_cpu_quota_cores": _cpu_quota()}
 
 
 def _cpu_model():
@@ -132,43 +226,107 @@ def _cpu_model():
     return "unknown"
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--windows", type=int, default=1024, help="independent windows per GPU per step")
-    ap.add_argument("--threads", type=int, default=256)
-    ap.add_argument("--variant", type=int, default=0, help="0: chain layout (default, two windows per CU), 1: dense 171-dim layout (cross-check)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=12.0)
-    args = ap.parse_args()
+# ---- PCIe-inclusive figures ---------------------------------------------------------------------------------------------
+def stream_figures(tcv, torch, keep, B_stream: int = 512, rounds: int = 4):
+    """host-resident problems -> tcv_batch_create (pack + H2D) -> solve -> gauge fix -> marginalisation -> D2H of states and
+    priors -> destroy, double-buffered: two host threads, each with its own HIP stream, so that one batch packs / copies while
+    the other computes.  Also the end-to-end and kernel-only latency of ONE window (the real-time single-estimator case)."""
+    import threading
+    Wm, Mm, dropsm = keep
+    B = min(B_stream, len(Wm) // 2)
+    opts = tcv.default_options(SOLVER_ITERATIONS, True)
+    halves = [(Wm[:B], Mm[:B], dropsm[:B]), (Wm[B:2 * B], Mm[B:2 * B], dropsm[B:2 * B])]
+    stage = {"pack_h2d": 0.0, "compute": 0.0, "d2h": 0.0}
 
-    rank, world, local, dist = dist_setup(args.gpus)
-    import torch
-    import synth
-    import tcv
-    if tcv.lib().tcv_device_count() < 1:
-        raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
-    tcv.check(tcv.lib().tcv_set_device(local))
-    tcv.check(tcv.lib().tcv_set_solver_variant(args.variant))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    def one_pass(h, stream_ptr, acc=None):
+        t0 = time.perf_counter()
+        b = tcv.Batch(*h)
+        t1 = time.perf_counter()
+        b.solve(opts, stream_ptr); b.gauge_fix(stream_ptr); b.marginalize(stream_ptr); b.synchronize()
+        t2 = time.perf_counter()
+        b.download_states(); b.download_priors()
+        for k in range(len(h[0])):
+            b.prior(k)
+        t3 = time.perf_counter()
+        del b
+        if acc is not None:
+            acc["pack_h2d"] += t1 - t0; acc["compute"] += t2 - t1; acc["d2h"] += t3 - t2
+
+    def worker(h, st):
+        for _ in range(rounds):
+            one_pass(h, st.cuda_stream)
+
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    one_pass(halves[0], streams[0].cuda_stream)          # warm-up
+    for _ in range(2):
+        one_pass(halves[0], streams[0].cuda_stream, stage)
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=worker, args=(halves[i], streams[i])) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    # one window: kernel-only (resident) and end-to-end (tcv_solve + tcv_marginalize on host blocks)
+    one = ([Wm[0]], [Mm[0]], [dropsm[0]])
+    b1 = tcv.Batch(*one)
+    lat = []
+    for _ in range(12):
+        t1 = time.perf_counter()
+        b1.solve(opts); b1.gauge_fix(); b1.marginalize(); b1.synchronize()
+        lat.append(time.perf_counter() - t1)
+    st1 = b1.stats()
+    e2e = []
+    for _ in range(6):
+        t1 = time.perf_counter()
+        one_pass(one, None)
+        e2e.append(time.perf_counter() - t1)
+    return {"stream_solves_per_s": 2 * rounds * B / dt,
+            "stream_note": f"PCIe-inclusive: 2 host threads x {rounds} passes x {B} windows, per pass pack + H2D (tcv_batch_create), solve + gauge fix + "
+                           f"marginalisation on the thread's own HIP stream, D2H of states and priors; serial stage times per {B}-window pass [ms]: "
+                           + ", ".join(f"{k} {1e3 * v / 2:.1f}" for k, v in stage.items()),
+            "single_window_ms": {"resident_launch_to_sync": 1e3 * float(np.median(lat)), "kernels": st1["solve_ms"] + st1["marg_ms"],
+                                 "host_blocks_end_to_end": 1e3 * float(np.median(e2e))}}
+
+
+# ---- modes ----------------------------------------------------------------------------------------------------------------
+def run_solve(args, rank, world, local, dist):
+    pool = nproc = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not DRY:
+        pool, nproc = cpu_pool()                     # forked before the first GPU call
     B = args.windows
-    batch, wins, _keep = build_batches(tcv, synth, shard_ids(rank, B), B)
-    opts = tcv.default_options(SOLVER_ITERATIONS, True, True, args.threads)
+    if DRY:
+        torch = tcv = None
+        dev = None
+        step = lambda: time.sleep(0.001)
+        sync = (lambda: dist.barrier()) if dist is not None else (lambda: None)
+        wins = None
+    else:
+        import torch
+        import synth
+        import tcv
+        if tcv.lib().tcv_device_count() < 1:
+            raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
+        tcv.check(tcv.lib().tcv_set_device(local))
+        tcv.check(tcv.lib().tcv_set_solver_variant(args.variant))
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        batch, wins, keep = build_batches(tcv, synth, shard_ids(rank, B), B)
+        opts = tcv.default_options(SOLVER_ITERATIONS, True, True, args.threads)
 
-    def step():
-        batch.solve(opts)
-        batch.gauge_fix()          # double2vector(), estimator.cpp:1905: the marginalisation linearises at the gauge-fixed states
-        batch.marginalize()
+        def step():
+            batch.solve(opts)
+            batch.gauge_fix()          # double2vector(), estimator.cpp:1905: the marginalisation linearises at the gauge-fixed states
+            batch.marginalize()
 
-    def sync():
-        batch.synchronize()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        def sync():
+            batch.synchronize()
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
 
+    red_dev = dev if (dist is not None and dist.get_backend() == "nccl") else None
+    n_ranks = ranks_seen(dist, red_dev)
     for _ in range(args.warmup):
         step()
     sync()
@@ -177,66 +335,180 @@ def main():
     sample_every = max(1, (args.steps + 63) // 64)      # HIP-event duration of the launches (events recorded on the launch stream): at most 64 samples
     for k in range(args.steps):
         step()
-        if k % sample_every == 0:
+        if not DRY and k % sample_every == 0:
             batch.synchronize()
             st = batch.stats(); solve_ms.append(st["solve_ms"]); marg_ms.append(st["marg_ms"])
     sync()
     elapsed = time.perf_counter() - t0
-    elapsed_max, windows_total = reduce_stats(dist, elapsed, B * args.steps, dev if dist is not None and dist.get_backend() == "nccl" else None)
+    elapsed_max, windows_total, iters_total = reduce_stats(dist, elapsed, B * args.steps, red_dev, extra=(B * args.steps * SOLVER_ITERATIONS,))
 
-    # parity spot-check of what was just timed is done by tests/ and smoke(); here only sanity of the results
-    s = batch.summaries(min(4, B))
-    assert all(np.isfinite(s[k].final_cost) and s[k].final_cost < s[k].initial_cost for k in range(min(4, B)))
+    if not DRY:
+        # parity of what was just timed is the job of tests/ and smoke(); here only sanity of the results
+        s = batch.summaries(min(4, B))
+        assert all(np.isfinite(s[k].final_cost) and s[k].final_cost < s[k].initial_cost for k in range(min(4, B)))
 
-    if rank == 0:
-        w0 = wins[0]
-        pr = w0["prior"]
-        bpi = algorithmic_bytes_per_iteration(len(w0["imu"]["frame_i"]), len(w0["proj"]["frame_i"]), len(w0["line"]["frame"]),
-                                              len(w0["lam"]), pr["n"], sum(pr["sizes"]))
-        k_ms = float(np.mean(solve_ms)) if solve_ms else None
-        m_ms = float(np.mean(marg_ms)) if marg_ms else None
-        # dominant kernel = the fused solve kernel: B windows x (initial linearisation + 8 iterations) per launch
-        units = B * (SOLVER_ITERATIONS + 1)
-        achieved = (bpi * units) / (k_ms * 1e-3) / 1e9 if k_ms else None
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # written by tools/pmc_traffic.py from a rocprofv3 --pmc run
-        if os.path.exists(tfile):
-            try:
-                traffic = json.load(open(tfile)).get("solve_kernel_hbm_bytes_per_launch")
-            except (OSError, ValueError):
-                traffic = None
-        out = {
-            "metric": "sliding-window solves/sec (10 kf, 200 pt, 40 line)",
-            "value": windows_total / elapsed_max,
-            "unit": "solves/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed_max / args.steps,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": "configs[2]: synthetic 10-kf window, 200 point + 40 2D-3D line residual blocks + marginalisation prior "
-                                   "(n=75), 50 landmarks; 8 fixed dogleg iterations + 1 MARGIN_OLD marginalisation per solve",
-                       "windows_per_gpu": B, "solver_iterations": SOLVER_ITERATIONS, "parallelism": f"independent windows x{world}",
-                       "threads_per_window": args.threads, "layout": "chain" if args.variant == 0 else "dense"},
-            "iterations_per_s": windows_total * SOLVER_ITERATIONS / elapsed_max,
-            "kernel_ms": {"solve": k_ms, "marginalize": m_ms},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "kernel": "tcv::solve_kernel", "algorithmic_bytes_per_iteration": bpi,
-                         "units_per_launch": units,
-                         "note": "fused FP64 solve (chain layout, two windows per CU): latency/issue bound, not HBM bound (DESIGN.md 4.1); frac is vs "
-                                 "the 8 TB/s HBM3E spec; traffic = PMC FETCH_SIZE x2 + WRITE_SIZE of profiles/pmc_traffic.json"},
-        }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(wins, args.cpu_budget)
-            out["gpu_over_cpu_core"] = out["value"] / out["cpu_baseline"]["value"]
+    if rank != 0:
+        return
+    out = {
+        "metric": "sliding-window solves/sec (10 kf, 200 pt, 40 line)",
+        "value": windows_total / elapsed_max,
+        "unit": "solves/s",
+        "n_gpus": n_ranks,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed_max / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "configs[2]: synthetic 10-kf window, 200 point + 40 2D-3D line residual blocks + marginalisation prior "
+                               "(n=75), 50 landmarks; 8 fixed dogleg iterations + 1 MARGIN_OLD marginalisation per solve",
+                   "windows_per_gpu": B, "solver_iterations": SOLVER_ITERATIONS, "parallelism": f"independent windows x{world}",
+                   "threads_per_window": args.threads, "layout": "chain" if args.variant == 0 else "dense"},
+        "iterations_per_s": iters_total / elapsed_max,
+    }
+    if DRY:
+        out["dry_run"] = True
+        out["data"] = "dry run: no device work (launch / reduction logic only)"
         print(json.dumps(out))
+        return
+    w0 = wins[0]
+    pr = w0["prior"]
+    bpi = algorithmic_bytes_per_iteration(len(w0["imu"]["frame_i"]), len(w0["proj"]["frame_i"]), len(w0["line"]["frame"]),
+                                          len(w0["lam"]), pr["n"], sum(pr["sizes"]))
+    k_ms = float(np.mean(solve_ms)) if solve_ms else None
+    m_ms = float(np.mean(marg_ms)) if marg_ms else None
+    # dominant kernel = the fused solve kernel: B windows x (initial linearisation + 8 iterations) per launch
+    units = B * (SOLVER_ITERATIONS + 1)
+    achieved = (bpi * units) / (k_ms * 1e-3) / 1e9 if k_ms else None
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # written by tools/pmc_traffic.py from a rocprofv3 --pmc run
+    if os.path.exists(tfile):
+        try:
+            traffic = json.load(open(tfile)).get("solve_kernel_hbm_bytes_per_launch")
+        except (OSError, ValueError):
+            traffic = None
+    out["kernel_ms"] = {"solve": k_ms, "marginalize": m_ms}
+    out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                       "kernel": "tcv::solve_kernel", "algorithmic_bytes_per_iteration": bpi,
+                       "units_per_launch": units,
+                       "note": "fused FP64 solve: latency/issue bound, not HBM bound (DESIGN.md 4.1); frac is vs "
+                               "the 8 TB/s HBM3E spec; traffic = PMC FETCH_SIZE x2 + WRITE_SIZE of profiles/pmc_traffic.json (static, from the committed profile run)"}
+    if world == 1 and not args.no_extras:
+        out.update(stream_figures(tcv, torch, keep))
+    if pool is not None:
+        out["cpu_baseline"] = cpu_baseline(wins, pool, nproc, args.cpu_budget)
+        out["gpu_over_cpu_all_cores"] = out["value"] / out["cpu_baseline"]["value"]
+        out["gpu_over_cpu_core"] = out["value"] / out["cpu_baseline"]["single_core_value"]
+    print(json.dumps(out))
+
+
+def run_stream(args, rank, world, local, dist):
+    import torch
+    import synth
+    import tcv
+    if tcv.lib().tcv_device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
+    tcv.check(tcv.lib().tcv_set_device(local))
+    torch.cuda.set_device(local)
+    _b, _w, keep = build_batches(tcv, synth, shard_ids(rank, args.windows), args.windows)
+    out = stream_figures(tcv, torch, keep, rounds=max(1, args.steps // 4))
+    if rank == 0:
+        print(json.dumps(dict(metric="PCIe-inclusive streaming solves/sec (10 kf, 200 pt, 40 line)", value=out["stream_solves_per_s"], unit="solves/s",
+                              n_gpus=1, higher_is_better=True, dtype="f64", data="synthetic", **out)))
+
+
+def run_replay(args, rank, world, local, dist):
+    """BASELINE configs[4]: EuRoC-trajectory streams sharded s mod G; every rank advances its streams in lock step."""
+    mine = shard_streams(args.streams, rank, world)
+    if DRY:
+        dev = None
+        warm = lambda k: len(mine)
+        step = lambda k: (time.sleep(0.001), len(mine))[1]
+        k0 = 0
+    else:
+        import torch
+        import replay
+        import tcv
+        if tcv.lib().tcv_device_count() < 1:
+            raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
+        tcv.check(tcv.lib().tcv_set_device(local))
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        n_frames = replay.WINDOW_SIZE + 1 + args.warmup + args.steps
+        seqs = list(replay.EUROC_SEQUENCES)
+        streams = [replay.simulate_stream_euroc(seqs[s % len(seqs)], n_frames, start_s=0.5 + 3.0 * (s // len(seqs)), max_features=args.features,
+                                                max_lines=args.lines, associate=True) for s in mine]
+        ls = replay.NativeLockstep(streams, num_iterations=SOLVER_ITERATIONS) if streams else None
+        step = (lambda k: ls.step(k)) if ls else (lambda k: 0)
+        k0 = 0
+        while ls is not None and k0 < n_frames:      # window fill: frames 0 .. WINDOW_SIZE, the last one triggers the first optimisation
+            r = step(k0)
+            k0 += 1
+            if r:
+                break
+        if ls is None:
+            k0 = replay.WINDOW_SIZE + 1
+    red_dev = dev if (dist is not None and dist.get_backend() == "nccl") else None
+    n_ranks = ranks_seen(dist, red_dev)
+    for k in range(args.warmup):
+        step(k0 + k)
     if dist is not None:
-        dist.destroy_process_group()
+        dist.barrier()
+    n = 0
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        n += step(k0 + args.warmup + k)
+    if not DRY:
+        import torch
+        torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed_max, windows_total, iters_total = reduce_stats(dist, elapsed, n, red_dev, extra=(n * SOLVER_ITERATIONS,))
+    if rank != 0:
+        return
+    out = {"metric": "sliding-window solves/sec, EuRoC-trajectory replay (configs[4])", "value": windows_total / elapsed_max, "unit": "solves/s",
+           "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed_max / args.steps, "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+           "data": "synthetic front-end streams along the EuRoC ground-truth trajectories the reference ships (no bag in the tree)",
+           "config": {"workload": f"configs[4]: {args.streams} EuRoC-trajectory streams (V1_02..V2_03 excerpts, {args.features} tracked features + {args.lines} line "
+                                  f"tracks per frame, 2D-3D association in the loop), stream s on rank s mod {world}, lock-step native estimator, "
+                                  f"{SOLVER_ITERATIONS} iterations (convergence tests on) + marginalisation per frame",
+                      "streams": args.streams, "parallelism": f"streams sharded x{world}"},
+           "frames_per_s_per_stream": windows_total / elapsed_max / max(1, args.streams)}
+    if DRY:
+        out["dry_run"] = True
+    print(json.dumps(out))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mode", choices=("solve", "replay", "stream"), default="solve")
+    ap.add_argument("--windows", type=int, default=1024, help="independent windows per GPU per step")
+    ap.add_argument("--threads", type=int, default=256)
+    ap.add_argument("--variant", type=int, default=0, help="0: chain layout (default), 1: dense 171-dim layout (cross-check)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the PCIe-inclusive / single-window figures")
+    ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--streams", type=int, default=8, help="replay mode: number of EuRoC-trajectory streams of the whole job")
+    ap.add_argument("--features", type=int, default=60)
+    ap.add_argument("--lines", type=int, default=8)
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))       # nothing above touched the GPU
+    rank, world, local, dist = dist_setup(args.gpus)
+    try:
+        {"solve": run_solve, "replay": run_replay, "stream": run_stream}[args.mode](args, rank, world, local, dist)
+    finally:
+        if dist is not None:
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -60,16 +60,20 @@ typedef struct {
                                           checked at the start of every iteration like Ceres, on the device
                                           clock, per window */
     int fixed_iterations;              /* 1: run exactly max_num_iterations, convergence tests off   */
-    int compute_sqrt_info_on_device;   /* 1 (default): imu_factor.h:64 evaluated in the kernel        */
-    int use_mfma;                      /* 1 (default): trailing Cholesky update on v_mfma_f64_16x16x4_f64; 0: FP64 VALU (debug) */
-    int threads_per_window;            /* 256 (default) or 512 threads per workgroup / window          */
+    int compute_sqrt_info_on_device;   /* reserved, ignored: imu_factor.h:64 is always evaluated in the kernel, once per solve */
+    int use_mfma;                      /* dense layout only: 1 (default) trailing Cholesky update on v_mfma_f64_16x16x4_f64,
+                                          0 FP64 VALU (debug).  The chain layout always uses the matrix cores. */
+    int threads_per_window;            /* dense layout only: 256 (default) or 512 threads per workgroup; the chain layout is
+                                          built for 256 */
     int record_first_step;             /* 1: keep the tangent step of iteration 1 (parity tests)      */
 } tcv_solver_options;
 
 #define TCV_MAX_TRACE 64
-/* ceres::Solver::Summary subset (estimator.cpp:1899-1902 reads iterations.size()) + parity trace. */
+/* ceres::Solver::Summary subset (estimator.cpp:1899-1902 reads iterations.size()) + parity trace.
+ * max_num_iterations is honoured whatever its size (sensor.yaml ships 100); the per-iteration arrays below keep the
+ * FIRST TCV_MAX_TRACE entries of the trace, num_iterations keeps counting beyond them. */
 typedef struct {
-    int num_iterations;   /* = summary.iterations.size(): iteration 0 + accepted + rejected steps   */
+    int num_iterations;   /* = summary.iterations.size(): iteration 0 + accepted + rejected steps (may exceed TCV_MAX_TRACE) */
     int termination;      /* 0 NO_CONVERGENCE 1 gradient 2 parameter 3 function 4 radius 5 FAILURE */
     double initial_cost, final_cost;
     double cost[TCV_MAX_TRACE], cost_candidate[TCV_MAX_TRACE], model_cost_change[TCV_MAX_TRACE];
@@ -219,6 +223,9 @@ int tcv_batch_synchronize(tcv_batch *b);
 int tcv_batch_download_states(tcv_batch *b);
 int tcv_batch_get_summaries(tcv_batch *b, tcv_solver_summary *out, int n);
 int tcv_batch_get_prior(tcv_batch *b, int window, tcv_prior **out);
+/* optional: ONE device-to-host copy of every window's marginalisation result; later tcv_batch_get_prior calls are served from it
+ * (until the next tcv_batch_marginalize) */
+int tcv_batch_download_priors(tcv_batch *b);
 /* per-window status of the last marginalisation: 0 ok, 1 an eigen-solver hit its sweep cap, 2 result produced by the
  * cyclic-Jacobi safety net (the tridiagonal eigen-solver failed its orthogonality / trace self-check) */
 int tcv_batch_marg_status(tcv_batch *b, int *out, int n);

@@ -311,12 +311,28 @@ extern "C" int tcv_problem_from_window(const tcv_window_desc *w, tcv_problem **o
 // =====================================================================================================
 extern "C" int tcv_prior_create(tcv_prior **out, int m, int n, int nb, const int *size, const int *idx, const double *x0,
                                 const double *J0, const double *r0) {
-    if (!out || n <= 0 || nb <= 0 || !size || !idx || !x0 || !J0 || !r0) return TCV_ERR_INVALID;
+    if (!out || n <= 0 || nb <= 0 || m < 0 || !size || !idx || !x0 || !J0 || !r0) { set_error("prior_create: bad argument"); return TCV_ERR_INVALID; }
+    // the kernels index fixed-size (128-entry) dx / residual buffers by keep_block_idx: a malformed layout must not reach the device
+    if (n > 128) { set_error("prior_create: more than 128 rows"); return TCV_ERR_TOO_LARGE; }
+    {
+        std::vector<char> used(n, 0);
+        int sum_local = 0;
+        for (int k = 0; k < nb; k++) {
+            if (size[k] <= 0) { set_error("prior_create: keep_block_size must be positive"); return TCV_ERR_INVALID; }
+            const int local = size[k] == 7 ? 6 : size[k];      // MarginalizationInfo::localSize, marginalization_factor.cpp:100-103
+            if (idx[k] < m || idx[k] - m + local > n) { set_error("prior_create: keep_block_idx outside [m, m + n)"); return TCV_ERR_INVALID; }
+            for (int j = 0; j < local; j++) {
+                if (used[idx[k] - m + j]) { set_error("prior_create: kept blocks overlap"); return TCV_ERR_INVALID; }
+                used[idx[k] - m + j] = 1;
+            }
+            sum_local += local;
+        }
+        if (sum_local != n) { set_error("prior_create: local sizes of the kept blocks do not sum to n"); return TCV_ERR_INVALID; }
+    }
     tcv_prior *pr = new tcv_prior();
     pr->m = m; pr->n = n;
     int xs = 0;
     for (int k = 0; k < nb; k++) {   // keep_block_idx counts from the start of the [m | n] ordering (marginalization_factor.cpp:312, :347)
-        if (idx[k] < m) { delete pr; set_error("prior_create: keep_block_idx must be >= m"); return TCV_ERR_INVALID; }
         pr->size.push_back(size[k]); pr->idx.push_back(idx[k] - m); pr->xoff.push_back(xs); xs += size[k];
     }
     pr->x0.assign(x0, x0 + xs);
@@ -549,6 +565,7 @@ extern "C" int tcv_batch_solve(tcv_batch *b, const tcv_solver_options *o, void *
         if (a.max_ticks < 1) a.max_ticks = 1;
     }
     hipStream_t st = (hipStream_t)hip_stream;
+    b->last_stream = st;
     HIPCHK(hipEventRecord(b->ev0, st));
     const int rc = tcv_launch_solve(&a, b->grid, (!b->chain && o->threads_per_window == 512) ? 512 : 256, b->lds_bytes, hip_stream);
     if (rc != 0) return hip_fail((hipError_t)rc, "solve kernel launch");
@@ -558,11 +575,15 @@ extern "C" int tcv_batch_solve(tcv_batch *b, const tcv_solver_options *o, void *
 }
 extern "C" int tcv_batch_marginalize(tcv_batch *b, void *hip_stream) {
     if (!b) return TCV_ERR_INVALID;
+    b->last_stream = (hipStream_t)hip_stream;
     return tcv_marg_run(b, hip_stream);
 }
+// waits for the stream of the last asynchronous call on this batch (the whole device when that was the default stream), so that
+// batches driven from different host threads on different streams overlap (bench.py --mode stream)
 extern "C" int tcv_batch_synchronize(tcv_batch *b) {
     if (!b) return TCV_ERR_INVALID;
-    HIPCHK(hipDeviceSynchronize());
+    if (b->last_stream) HIPCHK(hipStreamSynchronize(b->last_stream));
+    else HIPCHK(hipDeviceSynchronize());
     if (b->solved) hipEventElapsedTime(&b->solve_ms, b->ev0, b->ev1);
     tcv_marg_elapsed(b);
     return TCV_OK;
@@ -622,6 +643,10 @@ extern "C" int tcv_batch_get_first_step(tcv_batch *b, int window, double *out, i
 extern "C" int tcv_batch_get_prior(tcv_batch *b, int window, tcv_prior **out) {
     if (!b || !out) return TCV_ERR_INVALID;
     return tcv_marg_get_prior(b, window, out);
+}
+extern "C" int tcv_batch_download_priors(tcv_batch *b) {
+    if (!b) return TCV_ERR_INVALID;
+    return tcv_marg_download(b);
 }
 extern "C" int tcv_batch_stats(tcv_batch *b, double *input_bytes, double *solve_ms, double *marg_ms) {
     if (!b) return TCV_ERR_INVALID;

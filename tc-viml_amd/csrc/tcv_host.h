@@ -87,6 +87,7 @@ struct tcv_batch {
     bool solved = false;
     std::vector<double> h_state;
     bool gauge_fixed = false;
+    hipStream_t last_stream = nullptr;     // stream of the last asynchronous call (tcv_batch_synchronize waits for it; null: the device)
     bool chain = false;                   // all plans use the chain layout (2 workgroups per CU)
     int chain_lds = 0;                    // LDS doubles per chain-layout workgroup of this batch
     double *d_imublk = nullptr, *d_spill = nullptr;   // chain mode: per-workgroup IMU J'J blocks and factored fronts
@@ -102,6 +103,7 @@ int tcv_marg_attach(tcv_batch *b, tcv_problem *const *marg_problems, double *con
 int tcv_marg_run(tcv_batch *b, void *stream);
 int tcv_marg_get_prior(tcv_batch *b, int window, tcv_prior **out);
 void tcv_marg_elapsed(tcv_batch *b);
+int tcv_marg_download(tcv_batch *b);
 
 namespace tcv {
 int hip_fail(hipError_t e, const char *what);

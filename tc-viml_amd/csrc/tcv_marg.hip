@@ -891,6 +891,9 @@ struct MargState {
     size_t lds_bytes = 0;
     int grid = 0;
     bool ran = false;
+    std::vector<double> h_out;        // host copy of every window's result block (tcv_batch_download_priors), valid until the next run
+    std::vector<int> h_status;
+    bool h_valid = false;
 };
 
 static void marg_free(tcv_batch *b) {
@@ -927,7 +930,9 @@ static int pack_marg(const tcv_problem &p, double *const *drop, int ndrop, const
         if (it == p.index.end()) { set_error("marginalize: dropped block is not part of the problem"); return TCV_ERR_INVALID; }
         if (touched[it->second]) dropped[it->second] = 1;
     }
-    // ambient offsets and [m | n] tangent order
+    // ambient offsets and [m | n] tangent order.  MarginalizationInfo knows nothing about SetParameterBlockConstant: a constant block
+    // (para_Ex_Pose with ESTIMATE_EXTRINSIC = 0, estimator.cpp:1694-1698) is kept / dropped like any other and its Jacobian columns are
+    // accumulated (marginalization_factor.cpp:89-108, :176-194), so the prior of the shipped EuRoC configuration has n = 75 too.
     std::vector<int> id_of(nb, -1), gsize, goff, mloc, kind, xsrc, orig;
     int nx = 0;
     for (int b = 0; b < nb; b++) {
@@ -948,7 +953,7 @@ static int pack_marg(const tcv_problem &p, double *const *drop, int ndrop, const
     int m_all = 0, n_lm_drop = 0;
     for (int c = 0; c < nblk; c++) {
         const ParamBlock &pb = p.blocks[orig[c]];
-        if (dropped[orig[c]] && !pb.constant) {
+        if (dropped[orig[c]]) {
             m_all += pb.kind == KIND_POSE ? 6 : pb.size;
             if (is_lm[orig[c]] && !other_use[orig[c]] && pb.size == 1) n_lm_drop++;
         }
@@ -956,7 +961,7 @@ static int pack_marg(const tcv_problem &p, double *const *drop, int ndrop, const
     int n_all = 0;
     for (int c = 0; c < nblk; c++) {
         const ParamBlock &pb = p.blocks[orig[c]];
-        if (!dropped[orig[c]] && !pb.constant) n_all += pb.kind == KIND_POSE ? 6 : pb.size;
+        if (!dropped[orig[c]]) n_all += pb.kind == KIND_POSE ? 6 : pb.size;
     }
     // one-piece eigen-decomposition of A_mm (the reference's) whenever it fits the LDS, block mode otherwise
     const bool fits = m_all <= MARG_MAX_M && n_all <= MARG_MAX_N && marg_lds_doubles(m_all + n_all, m_all, n_all, nx) <= (size_t)LDS_DOUBLES;
@@ -966,7 +971,7 @@ static int pack_marg(const tcv_problem &p, double *const *drop, int ndrop, const
     int n_lm = 0;
     for (int c = 0; c < nblk; c++) {
         const ParamBlock &pb = p.blocks[orig[c]];
-        if (dropped[orig[c]] && !pb.constant) {
+        if (dropped[orig[c]]) {
             if (block_mode && is_lm[orig[c]] && !other_use[orig[c]] && pb.size == 1) { lm_id[orig[c]] = n_lm; mloc[c] = -2 - n_lm; n_lm++; continue; }
             mloc[c] = pos; pos += pb.kind == KIND_POSE ? 6 : pb.size;
         }
@@ -976,7 +981,6 @@ static int pack_marg(const tcv_problem &p, double *const *drop, int ndrop, const
     for (int c = 0; c < nblk; c++) {
         const ParamBlock &pb = p.blocks[orig[c]];
         if (dropped[orig[c]]) continue;
-        if (pb.constant) continue;   // constant blocks are not part of the linearised prior
         mloc[c] = pos;
         mw.keep_block.push_back(c); mw.keep_size.push_back(pb.size); mw.keep_idx.push_back(pos); mw.keep_addr.push_back(pb.addr);
         mw.keep_goff.push_back(goff[c]);
@@ -1144,6 +1148,20 @@ int tcv_marg_run(tcv_batch *b, void *stream) {
     if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "marg kernel launch");
     if ((e = hipEventRecord(s->ev1, st)) != hipSuccess) return hip_fail(e, "hipEventRecord");
     s->ran = true;
+    s->h_valid = false;
+    return TCV_OK;
+}
+
+// one D2H copy of every window's result block (J0, r0, A', b', x0) and status instead of one copy per tcv_batch_get_prior call
+int tcv_marg_download(tcv_batch *b) {
+    MargState *s = (MargState *)b->marg;
+    if (!s || !s->ran) { set_error("no marginalisation result"); return TCV_ERR_INVALID; }
+    s->h_out.resize((size_t)b->n * MARG_OUT_STRIDE);
+    s->h_status.resize(b->n);
+    hipError_t e = hipMemcpy(s->h_out.data(), s->d_out, sizeof(double) * s->h_out.size(), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(s->h_status.data(), s->d_status, sizeof(int) * b->n, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpy D2H");
+    s->h_valid = true;
     return TCV_OK;
 }
 
@@ -1170,11 +1188,19 @@ int tcv_marg_get_prior(tcv_batch *b, int window, tcv_prior **out) {
     const int n = mw.hdr.n, m = mw.hdr.m;      // m: dropped dims that went through the eigen step (all of them unless block mode)
     std::vector<double> o(MARG_OUT_STRIDE);
     int status = -1;
-    hipError_t e = hipMemcpy(o.data(), s->d_out + (size_t)window * MARG_OUT_STRIDE, sizeof(double) * MARG_OUT_STRIDE, hipMemcpyDeviceToHost);
-    if (e != hipSuccess) return hip_fail(e, "hipMemcpy D2H");
-    e = hipMemcpy(&status, s->d_status + window, sizeof(int), hipMemcpyDeviceToHost);
-    if (e != hipSuccess) return hip_fail(e, "hipMemcpy D2H");
+    if (s->h_valid) {
+        std::copy(s->h_out.begin() + (size_t)window * MARG_OUT_STRIDE, s->h_out.begin() + (size_t)(window + 1) * MARG_OUT_STRIDE, o.begin());
+        status = s->h_status[window];
+    } else {
+        hipError_t e = hipMemcpy(o.data(), s->d_out + (size_t)window * MARG_OUT_STRIDE, sizeof(double) * MARG_OUT_STRIDE, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return hip_fail(e, "hipMemcpy D2H");
+        e = hipMemcpy(&status, s->d_status + window, sizeof(int), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return hip_fail(e, "hipMemcpy D2H");
+    }
     if (status < 0) { set_error("marginalisation kernel did not complete for this window"); return TCV_ERR_NUMERIC; }
+    // status 1: an eigen-solver ran into its sweep cap -- the decomposition is not converged and the prior would silently degrade every
+    // later window (the reference's SelfAdjointEigenSolver has no such exit); status 2 (safety net took over) is a valid result
+    if (status == 1) { set_error("marginalisation: eigen-decomposition did not converge (sweep cap)"); return TCV_ERR_NUMERIC; }
     tcv_prior *pr = new tcv_prior();
     pr->m = mw.m_total; pr->n = n;            // the reference's m counts every marginalised dim (marginalization_factor.cpp:176-186)
     int xo = 0;

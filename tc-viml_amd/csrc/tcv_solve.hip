@@ -1540,7 +1540,9 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CHAIN ?
         __syncthreads();
         TCV_MARK(C, PH_SETUP);
 
-        const int max_it = A.max_iterations < MAX_TRACE - 1 ? A.max_iterations : MAX_TRACE - 1;
+        // Solver::Options::max_num_iterations (estimator.cpp:1890; sensor.yaml ships up to 100): honoured as given.  The per-iteration
+        // trace of DevSummary holds the first MAX_TRACE entries; num_iterations keeps counting beyond it.
+        const int max_it = A.max_iterations;
         // Solver::Options::max_solver_time_in_seconds (estimator.cpp:1892-1897): Ceres checks the wall clock at the start of every
         // iteration and stops with NO_CONVERGENCE; here the budget runs on the device's constant-rate clock from the moment the
         // workgroup picks the window up.  Like in the reference this makes the iteration count timing dependent; 0 = no limit.
@@ -1702,7 +1704,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CHAIN ?
         __syncthreads();
         for (int i = tid; i < P.nx + L; i += NT) A.state_out[(size_t)win * A.state_stride + i] = C.xs[i];
         if (tid == 0) {
-            S->num_iterations = nrec < MAX_TRACE ? nrec : MAX_TRACE;
+            S->num_iterations = nrec;
             S->termination = termination;
             S->status = status;
             S->initial_cost = initial_cost;

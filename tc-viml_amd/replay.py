@@ -770,84 +770,122 @@ class _EstimatorStats(C.Structure):
                 ("iterations", C.c_int), ("prior_n", C.c_int), ("final_cost", C.c_double)]
 
 
+class NativeLockstep:
+    """Several sequences advanced in lock step through the native estimator (include/tcv_estimator.h): one estimator per stream,
+    every frame the full windows of all streams form ONE device batch (tcv_estimators_optimize).  Python only feeds the per-frame
+    streams.  `step(k)` = frame k of every stream: begin_frame for all, one optimize call, finish_frame; returns the number of
+    windows optimised.  Same perturbation draws as `run` / `run_many`."""
+
+    def __init__(self, streams, num_iterations: int = 8, fixed_iterations: bool = False, init_sigma=(0.02, 0.005, 0.05), bias_sigma=(0.005, 0.0005),
+                 exact_line_jacobian: bool = False, estimate_extrinsic: bool = True):
+        import tcv
+        self.tcv = tcv
+        L = self.L = tcv.lib()
+        vp, dp, ip = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)
+        self.vp, self.dp, self.ip = vp, dp, ip
+        L.tcv_estimator_create.argtypes = [C.POINTER(vp), C.POINTER(_EstimatorConfig)]
+        L.tcv_estimator_destroy.argtypes = [vp]; L.tcv_estimator_destroy.restype = None
+        L.tcv_estimator_set_biases.argtypes = [vp, dp, dp]
+        L.tcv_estimator_set_line_map.argtypes = [vp, C.c_int, dp, dp, dp]
+        L.tcv_estimator_begin_frame.argtypes = [vp, C.c_int, dp, dp, C.c_int, ip, dp, C.c_int, ip, dp, dp, ip]
+        L.tcv_estimators_optimize.argtypes = [C.POINTER(vp), C.c_int]
+        L.tcv_estimator_finish_frame.argtypes = [vp, dp, dp, dp]
+        L.tcv_estimator_get_stats.argtypes = [vp, C.POINTER(_EstimatorStats)]
+        if L.tcv_device_count() < 1:
+            raise RuntimeError("the native estimator needs a HIP device: the product has no CPU path")
+        cfg = _EstimatorConfig()
+        cfg.focal_length = synth.FOCAL_LENGTH; cfg.min_parallax = MIN_PARALLAX; cfg.init_depth = INIT_DEPTH
+        cfg.acc_n, cfg.gyr_n, cfg.acc_w, cfg.gyr_w = synth.ACC_N, synth.GYR_N, synth.ACC_W, synth.GYR_W
+        cfg.gravity[:] = list(G); cfg.imu_dt = synth.DT_IMU; cfg.K[:] = list(synth.K_MAT.reshape(9)); cfg.width = int(synth.IMG_W); cfg.height = int(synth.IMG_H)
+        cfg.tic[:] = list(synth.TIC); cfg.ric[:] = list(synth.RIC.reshape(9)); cfg.estimate_extrinsic = int(estimate_extrinsic)
+        cfg.angle_th, cfg.overlap_th, cfg.dist_th = 0.1745, 0.45, 50.0
+        cfg.num_iterations = num_iterations; cfg.fixed_iterations = int(fixed_iterations); cfg.line_exact_jacobian = int(exact_line_jacobian)
+        self.streams, self.init_sigma = streams, init_sigma
+        self.ests, self.rngs, self.outs = [], [], []
+        P = self._P
+        for st in streams:
+            h = vp()
+            cfg.angle_th, cfg.overlap_th, cfg.dist_th = st.get("line_th", (0.1745, 0.45, 50.0))
+            tcv.check(L.tcv_estimator_create(C.byref(h), C.byref(cfg)))
+            self.ests.append(h)
+            rng = np.random.Generator(np.random.PCG64(0xABCD))
+            ba = self._f64(st["ba"] + rng.normal(size=3) * bias_sigma[0]); bg = self._f64(st["bg"] + rng.normal(size=3) * bias_sigma[1])
+            tcv.check(L.tcv_estimator_set_biases(h, P(ba), P(bg)))
+            if "map_lines" in st:
+                ml = self._f64(st["map_lines"]); Rb = self._f64(st["Rbw"]).reshape(9); Tb = self._f64(st["Tbw"])
+                tcv.check(L.tcv_estimator_set_line_map(h, ml.shape[0], P(ml), P(Rb), P(Tb)))
+            self.rngs.append(rng); self.outs.append(dict(t=[], p=[], q=[], v=[], log=[]))
+        self.n_frames = max(len(st["t"]) for st in streams)
+
+    @staticmethod
+    def _f64(a):
+        return np.ascontiguousarray(a, dtype=np.float64)
+
+    def _P(self, a):
+        return a.ctypes.data_as(self.dp)
+
+    def step(self, k: int) -> int:
+        tcv, L, P, f64, ip, vp = self.tcv, self.L, self._P, self._f64, self.ip, self.vp
+        ready = []
+        for si, (st, h, rng) in enumerate(zip(self.streams, self.ests, self.rngs)):
+            if k >= len(st["t"]):
+                continue
+            truth = None
+            if k <= WINDOW_SIZE:
+                dth = rng.normal(size=3) * self.init_sigma[1]
+                truth = f64(np.concatenate([st["gt_p"][k] + rng.normal(size=3) * self.init_sigma[0], (st["gt_R"][k] @ deltaQ_R(dth)).reshape(9),
+                                            st["gt_v"][k] + rng.normal(size=3) * self.init_sigma[2]]))
+            imu = st["imu"][k]
+            acc = f64(imu[0]) if imu is not None else None; gyr = f64(imu[1]) if imu is not None else None
+            pts = st["points"][k]
+            ids = np.ascontiguousarray(list(pts.keys()), dtype=np.int32); pv = f64(np.array(list(pts.values())).reshape(-1, 3))
+            ln = st["lines"][k]
+            if "map_lines" in st:
+                lid = np.ascontiguousarray([a for a, _ in ln], dtype=np.int32); lv = f64(np.array([v for _, v in ln]).reshape(-1, 4))
+            else:
+                lid = np.zeros(len(ln), np.int32); lv = f64(np.array([np.concatenate(t3) for t3 in ln]).reshape(-1, 9))
+            rdy = C.c_int()
+            tcv.check(L.tcv_estimator_begin_frame(h, 0 if acc is None else acc.shape[0] - 1, None if acc is None else P(acc), None if gyr is None else P(gyr),
+                                                  len(ids), ids.ctypes.data_as(ip), P(pv), len(ln), lid.ctypes.data_as(ip), P(lv),
+                                                  None if truth is None else P(truth), C.byref(rdy)))
+            if rdy.value:
+                ready.append(si)
+        if not ready:
+            return 0
+        arr = (vp * len(ready))(*[self.ests[si] for si in ready])
+        tcv.check(L.tcv_estimators_optimize(arr, len(ready)))
+        for si in ready:
+            p3, q4, v3 = np.zeros(3), np.zeros(4), np.zeros(3)
+            s = _EstimatorStats()
+            tcv.check(L.tcv_estimator_get_stats(self.ests[si], C.byref(s)))
+            tcv.check(L.tcv_estimator_finish_frame(self.ests[si], P(p3), P(q4), P(v3)))
+            o = self.outs[si]
+            o["t"].append(self.streams[si]["t"][k]); o["p"].append(p3); o["q"].append(q4); o["v"].append(v3)
+            o["log"].append(dict(flag=s.marg_flag, n_landmarks=s.n_landmarks, n_proj=s.n_proj, n_line=s.n_line, n_line_obs=s.n_line_obs,
+                                 iterations=s.iterations, final_cost=s.final_cost, prior_n=s.prior_n))
+        return len(ready)
+
+    def results(self):
+        return [dict(t=np.array(o["t"]), p=np.array(o["p"]), q=np.array(o["q"]), v=np.array(o["v"]), log=o["log"]) for o in self.outs]
+
+    def close(self):
+        for h in self.ests:
+            self.L.tcv_estimator_destroy(h)
+        self.ests = []
+
+    def __del__(self):
+        if getattr(self, "ests", None):
+            self.close()
+
+
 def run_many_native(streams, num_iterations: int = 8, fixed_iterations: bool = False, init_sigma=(0.02, 0.005, 0.05), bias_sigma=(0.005, 0.0005),
-                    exact_line_jacobian: bool = False):
+                    exact_line_jacobian: bool = False, estimate_extrinsic: bool = True):
     """`run_many` with the window management in native code (tcv_estimator_*, one estimator per stream, lock-step
     tcv_estimators_optimize): Python only feeds the per-frame streams.  Same perturbation draws as `run` / `run_many`."""
-    import tcv
-    L = tcv.lib()
-    vp, dp, ip = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)
-    L.tcv_estimator_create.argtypes = [C.POINTER(vp), C.POINTER(_EstimatorConfig)]
-    L.tcv_estimator_destroy.argtypes = [vp]; L.tcv_estimator_destroy.restype = None
-    L.tcv_estimator_set_biases.argtypes = [vp, dp, dp]
-    L.tcv_estimator_set_line_map.argtypes = [vp, C.c_int, dp, dp, dp]
-    L.tcv_estimator_begin_frame.argtypes = [vp, C.c_int, dp, dp, C.c_int, ip, dp, C.c_int, ip, dp, dp, ip]
-    L.tcv_estimators_optimize.argtypes = [C.POINTER(vp), C.c_int]
-    L.tcv_estimator_finish_frame.argtypes = [vp, dp, dp, dp]
-    L.tcv_estimator_get_stats.argtypes = [vp, C.POINTER(_EstimatorStats)]
-    if L.tcv_device_count() < 1:
-        raise RuntimeError("the native estimator needs a HIP device: the product has no CPU path")
-    cfg = _EstimatorConfig()
-    cfg.focal_length = synth.FOCAL_LENGTH; cfg.min_parallax = MIN_PARALLAX; cfg.init_depth = INIT_DEPTH
-    cfg.acc_n, cfg.gyr_n, cfg.acc_w, cfg.gyr_w = synth.ACC_N, synth.GYR_N, synth.ACC_W, synth.GYR_W
-    cfg.gravity[:] = list(G); cfg.imu_dt = synth.DT_IMU; cfg.K[:] = list(synth.K_MAT.reshape(9)); cfg.width = int(synth.IMG_W); cfg.height = int(synth.IMG_H)
-    cfg.tic[:] = list(synth.TIC); cfg.ric[:] = list(synth.RIC.reshape(9)); cfg.estimate_extrinsic = 1
-    cfg.angle_th, cfg.overlap_th, cfg.dist_th = 0.1745, 0.45, 50.0
-    cfg.num_iterations = num_iterations; cfg.fixed_iterations = int(fixed_iterations); cfg.line_exact_jacobian = int(exact_line_jacobian)
-    f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
-    P = lambda a: a.ctypes.data_as(dp)
-    ests, rngs, outs = [], [], []
-    for st in streams:
-        h = vp()
-        cfg.angle_th, cfg.overlap_th, cfg.dist_th = st.get("line_th", (0.1745, 0.45, 50.0))
-        tcv.check(L.tcv_estimator_create(C.byref(h), C.byref(cfg)))
-        rng = np.random.Generator(np.random.PCG64(0xABCD))
-        ba = f64(st["ba"] + rng.normal(size=3) * bias_sigma[0]); bg = f64(st["bg"] + rng.normal(size=3) * bias_sigma[1])
-        tcv.check(L.tcv_estimator_set_biases(h, P(ba), P(bg)))
-        if "map_lines" in st:
-            ml = f64(st["map_lines"]); Rb = f64(st["Rbw"]).reshape(9); Tb = f64(st["Tbw"])
-            tcv.check(L.tcv_estimator_set_line_map(h, ml.shape[0], P(ml), P(Rb), P(Tb)))
-        ests.append(h); rngs.append(rng); outs.append(dict(t=[], p=[], q=[], v=[], log=[]))
+    ls = NativeLockstep(streams, num_iterations, fixed_iterations, init_sigma, bias_sigma, exact_line_jacobian, estimate_extrinsic)
     try:
-        for k in range(max(len(st["t"]) for st in streams)):
-            ready = []
-            for si, (st, h, rng) in enumerate(zip(streams, ests, rngs)):
-                if k >= len(st["t"]):
-                    continue
-                truth = None
-                if k <= WINDOW_SIZE:
-                    dth = rng.normal(size=3) * init_sigma[1]
-                    truth = f64(np.concatenate([st["gt_p"][k] + rng.normal(size=3) * init_sigma[0], (st["gt_R"][k] @ deltaQ_R(dth)).reshape(9),
-                                                st["gt_v"][k] + rng.normal(size=3) * init_sigma[2]]))
-                imu = st["imu"][k]
-                acc = f64(imu[0]) if imu is not None else None; gyr = f64(imu[1]) if imu is not None else None
-                pts = st["points"][k]
-                ids = np.ascontiguousarray(list(pts.keys()), dtype=np.int32); pv = f64(np.array(list(pts.values())).reshape(-1, 3))
-                ln = st["lines"][k]
-                if "map_lines" in st:
-                    lid = np.ascontiguousarray([a for a, _ in ln], dtype=np.int32); lv = f64(np.array([v for _, v in ln]).reshape(-1, 4))
-                else:
-                    lid = np.zeros(len(ln), np.int32); lv = f64(np.array([np.concatenate(t3) for t3 in ln]).reshape(-1, 9))
-                rdy = C.c_int()
-                tcv.check(L.tcv_estimator_begin_frame(h, 0 if acc is None else acc.shape[0] - 1, None if acc is None else P(acc), None if gyr is None else P(gyr),
-                                                      len(ids), ids.ctypes.data_as(ip), P(pv), len(ln), lid.ctypes.data_as(ip), P(lv),
-                                                      None if truth is None else P(truth), C.byref(rdy)))
-                if rdy.value:
-                    ready.append(si)
-            if not ready:
-                continue
-            arr = (vp * len(ready))(*[ests[si] for si in ready])
-            tcv.check(L.tcv_estimators_optimize(arr, len(ready)))
-            for si in ready:
-                p3, q4, v3 = np.zeros(3), np.zeros(4), np.zeros(3)
-                s = _EstimatorStats()
-                tcv.check(L.tcv_estimator_get_stats(ests[si], C.byref(s)))
-                tcv.check(L.tcv_estimator_finish_frame(ests[si], P(p3), P(q4), P(v3)))
-                o = outs[si]
-                o["t"].append(streams[si]["t"][k]); o["p"].append(p3); o["q"].append(q4); o["v"].append(v3)
-                o["log"].append(dict(flag=s.marg_flag, n_landmarks=s.n_landmarks, n_proj=s.n_proj, n_line=s.n_line, n_line_obs=s.n_line_obs,
-                                     iterations=s.iterations, final_cost=s.final_cost, prior_n=s.prior_n))
+        for k in range(ls.n_frames):
+            ls.step(k)
+        return ls.results()
     finally:
-        for h in ests:
-            L.tcv_estimator_destroy(h)
-    return [dict(t=np.array(o["t"]), p=np.array(o["p"]), q=np.array(o["q"]), v=np.array(o["v"]), log=o["log"]) for o in outs]
+        ls.close()

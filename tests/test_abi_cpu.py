@@ -267,3 +267,39 @@ def test_header_is_valid_c99_and_cxx_and_the_example_links(tcv, tmp_path):
                            "-ltcv_hip", "-Wl,-rpath," + libdir, "-o", exe2])
     out2 = subprocess.run([exe2], capture_output=True, text=True, timeout=120)
     assert out2.returncode == 0, out2.stdout + out2.stderr
+
+
+def test_prior_create_rejects_malformed_layouts(tcv):
+    """keep_block_idx / keep_block_size of a caller-supplied prior index fixed-size device buffers: sizes must be positive, every
+    block must lie in [m, m + n), blocks must not overlap and their local sizes must sum to n (MarginalizationInfo::localSize,
+    marginalization_factor.cpp:100-103: a size-7 block is 6 wide)."""
+    pre, main, z = golden_windows()
+    good = dict(main["prior"])
+    P = tcv.Prior.from_dict(good)
+    assert P.dims()[:2] == (good["m"], good["n"])
+
+    def rc_of(**kw):
+        p = dict(good, **kw)
+        try:
+            tcv.Prior.from_dict(p)
+        except tcv.TcvError as e:
+            return e.status
+        return 0
+
+    sizes, idx = list(good["sizes"]), list(good["idx"])
+    assert rc_of(sizes=[0] + sizes[1:]) == tcv.TCV_ERR_INVALID                        # non-positive size
+    assert rc_of(idx=[idx[0] - 1] + idx[1:]) == tcv.TCV_ERR_INVALID                    # below m
+    assert rc_of(idx=idx[:-1] + [good["n"] - 3]) == tcv.TCV_ERR_INVALID                # runs past n
+    assert rc_of(idx=[idx[1]] + idx[1:]) == tcv.TCV_ERR_INVALID                        # overlap
+    assert rc_of(sizes=sizes[:-1], idx=idx[:-1], x0=good["x0"][:-1]) == tcv.TCV_ERR_INVALID   # local sizes do not sum to n
+    big = dict(m=0, n=130, sizes=[130], idx=[0], x0=[np.zeros(130)], J0=np.zeros((130, 130)), r0=np.zeros(130))
+    try:
+        tcv.Prior.from_dict(big); rc = 0
+    except tcv.TcvError as e:
+        rc = e.status
+    assert rc == tcv.TCV_ERR_TOO_LARGE
+
+
+def test_solver_options_document_the_iteration_limit():
+    hdr = open(os.path.join(ROOT, "include", "tcv.h")).read()
+    assert "may exceed TCV_MAX_TRACE" in hdr and "reserved, ignored" in hdr

@@ -1,10 +1,14 @@
-"""world_size-2 `gloo` test (CPU) of the multi-process logic bench.py uses at N > 1: rank-offset window shards with no
-overlap, a barrier, MAX-over-ranks time and SUM-over-ranks windows.  The data path itself has no collective."""
+"""world_size-2 `gloo` tests (CPU) of the multi-process logic bench.py uses at N > 1: rank-offset window shards with no
+overlap, a barrier, MAX-over-ranks time and SUM-over-ranks windows; the self-launch path of `python bench.py --gpus N` (the parent
+starts N fresh ranks as a child process before any GPU call); stream sharding s mod G of the replay mode.  The data path itself has
+no collective."""
 import json
 import os
 import socket
 import subprocess
 import sys
+
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -16,7 +20,8 @@ rank, world, local, dist = bench.dist_setup(2, backend="gloo")
 first = bench.shard_ids(rank, 64)
 dist.barrier()
 t, w = bench.reduce_stats(dist, 1.0 + 0.5 * rank, 64 * 3)
-print(json.dumps(dict(rank=rank, world=world, first=first, t=t, w=w)))
+t2, w2, it2 = bench.reduce_stats(dist, 1.0, 10, extra=(80,))
+print(json.dumps(dict(rank=rank, world=world, first=first, t=t, w=w, w2=w2, it2=it2, seen=bench.ranks_seen(dist), streams=bench.shard_streams(8, rank, world))))
 dist.destroy_process_group()
 """
 
@@ -39,6 +44,41 @@ def test_two_rank_gloo_reduction(tmp_path):
     assert outs[1]["first"] - outs[0]["first"] == 64                      # disjoint shards, fixed work per rank (weak scaling)
     assert all(abs(d["t"] - 1.5) < 1e-12 for d in outs)                   # MAX over ranks
     assert all(d["w"] == 2 * 64 * 3 for d in outs)                        # whole-job window count
+    assert all(d["w2"] == 20 and d["it2"] == 160 and d["seen"] == 2 for d in outs)
+    assert outs[0]["streams"] == [0, 2, 4, 6] and outs[1]["streams"] == [1, 3, 5, 7]      # sequence s -> GPU s mod G
+
+
+def _bench(args, env_extra, timeout=600):
+    env = dict(os.environ, TCV_BENCH_DRY="1", **env_extra)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        if k not in env_extra:
+            env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    return p.returncode, p.stdout.decode(), p.stderr.decode()
+
+
+@pytest.mark.parametrize("mode", ["solve", "replay"])
+def test_bench_self_launches_one_rank_per_gpu(mode):
+    """`python bench.py --gpus 2` with no launcher around it: the parent spawns torch.distributed.run as a child, two ranks rendezvous
+    (gloo here, RCCL on the GPU box), and rank 0 prints ONE line whose n_gpus is the number of ranks the collective saw.  TCV_BENCH_DRY
+    replaces the device work by a sleep -- the launch, rendezvous and reduction code is the real one."""
+    rc, out, err = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--mode", mode, "--windows", "16"], {})
+    assert rc == 0, err[-3000:]
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dry_run"] is True and d["steps"] == 3
+    if mode == "solve":
+        assert d["config"]["windows_per_gpu"] == 16 and abs(d["value"] * d["ms_per_step"] * 1e-3 - 2 * 16) < 1e-6      # whole-job count / MAX time
+        assert d["scaling"] == "weak"
+    else:
+        assert d["config"]["streams"] == 8 and abs(d["value"] * d["ms_per_step"] * 1e-3 - 8) < 1e-6                    # 8 streams over 2 ranks
+        assert d["scaling"] == "strong"
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    rc, out, err = _bench(["--gpus", "4", "--steps", "1", "--warmup", "0"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert rc != 0 and "WORLD_SIZE=1" in err and not out.strip()
 
 
 def test_algorithmic_bytes_match_the_survey():

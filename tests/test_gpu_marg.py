@@ -205,3 +205,51 @@ def test_marginalisation_of_replay_windows_one_by_one_vs_oracle(gpu):
         assert fro(d["J0"].T @ d["J0"], dbg["A_schur"]) < 1e-5
     print("m values", sorted(ms), "worst A' %.2e b' %.2e" % (worstA, worstb))
     assert len(ms) >= 4 and worstA < 1e-5 and worstb < 1e-6
+
+
+def test_marginalisation_keeps_a_constant_extrinsic(gpu):
+    """ESTIMATE_EXTRINSIC = 0 (what euroc_config.yaml ships): para_Ex_Pose is SetParameterBlockConstant in the solve
+    (estimator.cpp:1694-1698) but MarginalizationInfo knows nothing about constness -- the block stays in keep_block_size / idx / data
+    and its Jacobian columns are accumulated (marginalization_factor.cpp:89-108, :176-194): n = 75, not 69.  MARGIN_OLD and
+    MARGIN_SECOND_NEW against the oracles at bit-identical states, and the chained solve with the extrinsic held constant."""
+    import np_oracle as NO
+    pre, main, z = golden_windows()
+    for w, want_n in ((pre, None), (main, 75)):
+        O = orc.Window(w, ex_constant=True); O.solve(8, True); st = O.states(); po, dbg = O.marginalize_old()
+        assert np.array_equal(st["ex"], w["ex_pose"])                      # constant in the solve
+        w2 = dict(w, pose=st["pose"], speedbias=st["sb"], ex_pose=st["ex"], lam=st["lam"])
+        mw = gpu.margin_old_window(w2)
+        Wm = gpu.Window(mw, estimate_extrinsic=False)
+        dr = gpu.margin_old_drops(Wm, mw)
+        arr = (gpu._dp * len(dr))(*dr)
+        h = C.c_void_p()
+        gpu.check(gpu.lib().tcv_marginalize(Wm.h, arr, len(dr), C.byref(h)))
+        P = gpu.Prior(h); d = P.export(); As, bs = P.schur()
+        assert (d["m"], d["n"]) == (po["m"], po["n"]) and d["sizes"] == list(po["sizes"]) and d["idx"] == list(po["idx"])
+        assert d["sizes"][-1] == 7 and ("ex", 0) in gpu.shifted_prior_blocks(P, Wm)
+        if want_n:
+            assert d["n"] == want_n
+        assert fro(As, dbg["A_schur"]) < 1e-5 and fro(bs, dbg["b_schur"]) < 1e-6
+        assert fro(d["J0"].T @ d["J0"], dbg["A_schur"]) < 1e-5
+    # the solve with the extrinsic constant and a prior that holds it (columns of J0 without a tangent index)
+    Wn = gpu.Window(main, estimate_extrinsic=False)
+    bn = gpu.Batch([Wn]); bn.solve(gpu.default_options(8, True)); bn.synchronize(); bn.download_states()
+    s = bn.summaries()[0]
+    O = orc.Window(main, ex_constant=True); so = O.solve(8, True)
+    assert [s.step_ok[i] for i in range(9)] == [so.step_ok[i] for i in range(9)]
+    assert abs(s.final_cost - so.final_cost) < 1e-6 * so.final_cost
+    assert rel(Wn.pose, O.states()["pose"]) < 1e-6 and np.array_equal(Wn.ex, main["ex_pose"])
+    # MARGIN_SECOND_NEW: the old prior alone, pose WINDOW_SIZE - 1 dropped, the constant extrinsic kept
+    st = O.states()
+    w2 = dict(main, pose=st["pose"], speedbias=st["sb"], ex_pose=st["ex"], lam=st["lam"])
+    prob = NO.Problem(w2, ex_constant=True)
+    po, dbg = NO.marginalize_second_new(prob, prob.x0())
+    mw = gpu.margin_second_new_window(w2)
+    Wm = gpu.Window(mw, estimate_extrinsic=False)
+    dr = gpu.margin_second_new_drops(Wm)
+    arr = (gpu._dp * len(dr))(*dr)
+    h = C.c_void_p()
+    gpu.check(gpu.lib().tcv_marginalize(Wm.h, arr, len(dr), C.byref(h)))
+    P = gpu.Prior(h); d = P.export(); As, bs = P.schur()
+    assert (d["m"], d["n"]) == (6, po["n"]) == (6, main["prior"]["n"] - 6) and d["sizes"] == po["sizes"] and d["idx"] == po["idx"]
+    assert fro(As, dbg["A_schur"]) < 1e-5 and fro(bs, dbg["b_schur"]) < 1e-6

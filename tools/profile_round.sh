@@ -3,17 +3,19 @@
 #   bash tools/profile_round.sh <tag>
 # rocprofv3 --kernel-trace --stats of the benchmark command, separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ counters;
 # kernel-trace only, as gpurun requires), the bench line itself and the per-phase cycle tables of the -DTCV_PROFILE build.
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err
-rocprofv3 --kernel-trace --stats -d $O/stats -o st --output-format csv -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/stats.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o f --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o w --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/write.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU -d $O/sq -o sq --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/sq.log 2>&1
-rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_MFMA -d $O/sq2 -o sq --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/sq2.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/stats -o st --output-format csv -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $O/stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o f --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o w --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU -d $O/sq -o sq --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/sq.log 2>&1
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_MFMA -d $O/sq2 -o sq --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/sq2.log 2>&1
+# north_star's "MFMA-busy": cycles the matrix cores are busy against the cycles the CUs are busy (own pass; SQ_VALU_MFMA_BUSY_CYCLES counts cycles)
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 -d $O/sq3 -o sq --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/sq3.log 2>&1
 cd $R
 python3 tools/pmc_traffic.py $O/fetch $O/write $O/pmc_traffic.json > /dev/null 2>&1
 if [ -f tc-viml_amd/libtcv_hip_prof.so ]; then
@@ -30,7 +32,7 @@ def summarise(d):
         for r in csv.DictReader(open(f)):
             acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items() if "tcv::" in k}
-out = {"sq": summarise("sq"), "sq2": summarise("sq2")}
+out = {"sq": summarise("sq"), "sq2": summarise("sq2"), "mfma": summarise("sq3")}
 json.dump(out, open(f"{O}/sq_counters.json", "w"), indent=1)
 PY
 ls $O
