@@ -73,6 +73,10 @@ int tcv_estimators_optimize(tcv_estimator *const *e, int n);
  * TCV_ERR_NUMERIC: failure detection fired (the reference would reset the estimator). */
 int tcv_estimator_finish_frame(tcv_estimator *e, double P[3], double q_xyzw[4], double V[3]);
 int tcv_estimator_get_stats(const tcv_estimator *e, tcv_estimator_stats *out);
+/* host-side time accounting of tcv_estimators_optimize since the last call (seconds): out8 = pre-integration, association +
+ * triangulation + window, problem construction, batch_create (pack + H2D), kernels (launch to sync), downloads, apply / prior
+ * chaining, number of calls.  Development aid (tools/replay_euroc.py --profile). */
+int tcv_estimators_profile(double *out8);
 
 #ifdef __cplusplus
 }

@@ -449,20 +449,26 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
                 }
         if (rc != TCV_OK) { batch_free(b); if (!msg.empty()) set_error(msg); return rc; }
     }
+    std::map<const PlanTemplate *, int> plan_of_tmpl;   // windows that share a cached plan template share the device plan
     for (int w = 0; w < n; w++) {
         Packed &pk = b->packed[w];
-        std::vector<int> key(pk.ints);
-        const int *hp = reinterpret_cast<const int *>(&pk.hdr);
-        key.insert(key.end(), hp, hp + sizeof(PlanHdr) / sizeof(int));
-        auto it = plan_index.find(key);
-        int pid;
-        if (it == plan_index.end()) {
-            pid = (int)b->plans.size();
-            plan_index[key] = pid;
-            b->plans.push_back(pk.hdr);
-            b->plan_base.push_back((long long)ipool.size());
-            ipool.insert(ipool.end(), pk.ints.begin(), pk.ints.end());
-        } else pid = it->second;
+        const std::vector<int> &pints = pk.tmpl ? pk.tmpl->ints : pk.ints;
+        int pid = -1;
+        if (pk.tmpl) { auto it = plan_of_tmpl.find(pk.tmpl.get()); if (it != plan_of_tmpl.end()) pid = it->second; }
+        if (pid < 0) {
+            std::vector<int> key(pints);
+            const int *hp = reinterpret_cast<const int *>(&pk.hdr);
+            key.insert(key.end(), hp, hp + sizeof(PlanHdr) / sizeof(int));
+            auto it = plan_index.find(key);
+            if (it == plan_index.end()) {
+                pid = (int)b->plans.size();
+                plan_index[key] = pid;
+                b->plans.push_back(pk.hdr);
+                b->plan_base.push_back((long long)ipool.size());
+                ipool.insert(ipool.end(), pints.begin(), pints.end());
+            } else pid = it->second;
+            if (pk.tmpl) plan_of_tmpl[pk.tmpl.get()] = pid;
+        }
         pk.win.plan = pid;
         pk.win.dbase = (long long)dpool.size();
         dpool.insert(dpool.end(), pk.doubles.begin(), pk.doubles.end());

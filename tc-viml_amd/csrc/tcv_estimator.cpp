@@ -6,6 +6,7 @@
 // Host code only: every numerical step of the hot path goes through the C-ABI of tcv.h (HIP kernels); there is no CPU solver here.
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -584,8 +585,22 @@ extern "C" int tcv_estimator_begin_frame(tcv_estimator *e, int n_imu, const doub
     return TCV_OK;
 }
 
+// host-side time accounting of tcv_estimators_optimize (seconds, cumulative; read and cleared by tcv_estimators_profile):
+// 0 pre-integration, 1 association + triangulation + window, 2 problem construction, 3 batch_create (pack + H2D), 4 kernels (launch to
+// sync), 5 downloads (states, summaries, priors), 6 apply / prior chaining, 7 calls
+static double g_prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+extern "C" int tcv_estimators_profile(double *out8) {
+    if (!out8) return TCV_ERR_INVALID;
+    for (int i = 0; i < 8; i++) { out8[i] = g_prof[i]; g_prof[i] = 0; }
+    return TCV_OK;
+}
+
 extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
     if (!es || n <= 0) return TCV_ERR_INVALID;
+    double t_mark = now_s();
+    auto lap = [&](int slot) { const double t = now_s(); g_prof[slot] += t - t_mark; t_mark = t; };
+    g_prof[7] += 1;
     for (int i = 0; i < n; i++) if (!es[i] || es[i]->phase != 1) { tcv::set_error("estimators_optimize: an estimator has no full window waiting (begin_frame must report ready)"); return TCV_ERR_INVALID; }
     for (int i = 0; i < n; i++) for (int j = 0; j < i; j++) if (es[i] == es[j]) { tcv::set_error("estimators_optimize: the same estimator twice"); return TCV_ERR_INVALID; }
     // one pre-integration call for every stale IMU buffer of every estimator
@@ -615,6 +630,7 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
             for (size_t k = 0; k < who.size(); k++) { es[who[k].first]->pre[who[k].second] = out[k]; es[who[k].first]->pre_valid[who[k].second] = true; }
         }
     }
+    lap(0);
     // solveOdometry up to the solver call: association, triangulation, vector2double + graph
     for (int i = 0; i < n; i++) {
         tcv_estimator *e = es[i];
@@ -622,6 +638,7 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
         triangulate(e);
         build_window(e);
     }
+    lap(1);
     // windows that marginalise and windows that only solve go to separate batches
     std::vector<char> do_marg(n);
     for (int i = 0; i < n; i++) {
@@ -652,7 +669,9 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
                 drops[k] = e->m_drop.data(); ndrop[k] = (int)e->m_drop.size();
             }
         }
+        lap(2);
         if (rc == TCV_OK) rc = tcv_batch_create(&b, P.data(), group ? M.data() : nullptr, group ? drops.data() : nullptr, group ? ndrop.data() : nullptr, nb);
+        lap(3);
         tcv_solver_options o;
         tcv_solver_options_default(&o);
         o.max_num_iterations = es[0]->cfg.num_iterations; o.fixed_iterations = es[0]->cfg.fixed_iterations;
@@ -660,13 +679,16 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
         if (rc == TCV_OK) rc = tcv_batch_gauge_fix(b, nullptr);
         if (rc == TCV_OK && group) rc = tcv_batch_marginalize(b, nullptr);
         if (rc == TCV_OK) rc = tcv_batch_synchronize(b);
+        lap(4);
         if (rc == TCV_OK) rc = tcv_batch_download_states(b);
         std::vector<tcv_solver_summary> sum(nb);
         if (rc == TCV_OK) rc = tcv_batch_get_summaries(b, sum.data(), nb);
         std::vector<tcv_prior *> newp(nb, nullptr);
+        if (rc == TCV_OK && group) rc = tcv_batch_download_priors(b);
         if (rc == TCV_OK && group)
             for (int k = 0; k < nb && rc == TCV_OK; k++) rc = tcv_batch_get_prior(b, k, &newp[k]);
         if (b) tcv_batch_destroy(b);
+        lap(5);
         for (int k = 0; k < nb; k++) { if (P[k]) tcv_problem_destroy(P[k]); if (M[k]) tcv_problem_destroy(M[k]); }
         if (rc != TCV_OK) { for (auto *p : newp) if (p) tcv_prior_destroy(p); rc_all = rc; break; }
         for (int k = 0; k < nb; k++) {
@@ -678,6 +700,7 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
             else e->stats.prior_n = e->prior ? e->stats.prior_n : 0;
             e->phase = 2;
         }
+        lap(6);
     }
     return rc_all;
 }

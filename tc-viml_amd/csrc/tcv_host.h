@@ -36,8 +36,17 @@ struct ProjFac { double pts[6]; double sqrt_info, loss_a; int b[4]; double aux[8
 struct LineFac { double d[9]; double K[9], R[9], T[3]; double loss_a; int b; };
 struct PriorFac { const tcv_prior *prior; std::vector<int> b; };
 
+// structural half of a packed window (plan header + int pool + host-side maps): a function of the graph STRUCTURE only, shared by every
+// window with that structure (tcv_pack.cpp keeps a process-wide cache keyed by the structure)
+struct PlanTemplate {
+    PlanHdr hdr;
+    std::vector<int> ints;
+    std::vector<int> cam_block, cam_loff, lm_block, proj_order;
+};
+
 struct Packed {
     PlanHdr hdr;
+    std::shared_ptr<const PlanTemplate> tmpl;   // set when the plan came from / went into the cache: `ints` is then empty and tmpl->ints holds the plan
     std::vector<int> ints;
     std::vector<double> doubles;
     WinHdr win;
@@ -113,4 +122,6 @@ void set_error(const std::string &s);
 // mode: 0 = chain layout when the graph allows it (speed-bias blocks form chains), else dense; 1 = dense layout
 // chain_lds: LDS doubles of a chain-layout workgroup (0: chain_lds_doubles(), half a CU's LDS so that two workgroups share a CU)
 int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int mode = 0, int chain_lds = 0);
+// plan-cache statistics (hits, misses, entries); tcv_pack.cpp
+void plan_cache_stats(long long *hits, long long *misses, long long *entries);
 }  // namespace tcv

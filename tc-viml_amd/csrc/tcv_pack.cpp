@@ -5,7 +5,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <tuple>
+#include <unordered_map>
 
 #include "tcv_host.h"
 
@@ -115,7 +117,8 @@ void add_pairs(DestList &dl, const std::vector<Col> &cols, MakeItem mk, int rcol
 
 }  // namespace
 
-int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int mode, int chain_lds) {
+// structural half: plan header, int pool and the host-side maps (everything that does not depend on the VALUES of the window)
+static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds) {
     const int nb = (int)p.blocks.size();
     // ---- classify blocks: landmarks = size-1 Euclidean blocks used only as 4th block of projection factors
     std::vector<int> use_lm(nb, 0), use_other(nb, 0);
@@ -591,7 +594,16 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int 
     while ((I.size() & 3) != 0) I.push_back(0);          // plans are concatenated: keep every plan 16-byte aligned
     H.plan_ints = (int)I.size();
 
-    // ---- data
+    return TCV_OK;
+}
+
+// data half: the window's doubles in the layout the plan expects (offsets depend on the counts only)
+static int pack_data(const tcv_problem &p, Packed &out, const double *imu_sqrt) {
+    const PlanHdr &H = out.hdr;
+    const int nblk = (int)out.cam_block.size(), L = (int)out.lm_block.size();
+    const std::vector<int> &order = out.proj_order;
+    const bool with_td = (H.flags & 1) != 0;
+    const tcv_prior *pr = p.prior.empty() ? nullptr : p.prior[0].prior;
     std::vector<double> &D = out.doubles;
     D.clear();
     WinHdr &W = out.win;
@@ -616,7 +628,7 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int 
         if (k == 0) { psi = f.sqrt_info; pla = f.loss_a; }
         else if (f.sqrt_info != psi || f.loss_a != pla) { set_error("projection factors must share sqrt_info and loss"); return TCV_ERR_UNSUPPORTED; }
         D.insert(D.end(), f.pts, f.pts + 6);
-        if (td_blk >= 0) D.insert(D.end(), f.aux, f.aux + 8);
+        if (with_td) D.insert(D.end(), f.aux, f.aux + 8);
     }
     W.d_line = (int)D.size();
     double lla = 0;
@@ -645,6 +657,86 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int 
     W.n_doubles = (int)D.size();
     for (double v : D) if (!(v == v) || v > 1e300 || v < -1e300) { set_error("NaN/Inf in window data"); return TCV_ERR_NUMERIC; }
     return TCV_OK;
+}
+
+
+// ---- plan cache ---------------------------------------------------------------------------------------------------------------
+// The plan (symbolic elimination, chunking, gather programs: ~1 ms of host time for a cfg-3 window) is a function of the graph
+// structure alone.  Windows of one batch, the frames of a bench / streaming loop and re-solves of the same window share it: the
+// structure is serialised into an int key (block sizes / kinds / constness, the block indices of every factor, the prior's block
+// layout, the frame table, layout mode and LDS budget), and a process-wide table maps key -> PlanTemplate.
+namespace {
+struct KeyHash {
+    size_t operator()(const std::vector<int> &k) const {
+        unsigned long long h = 1469598103934665603ull;
+        for (int v : k) { h ^= (unsigned)v; h *= 1099511628211ull; }
+        return (size_t)h;
+    }
+};
+std::mutex g_cache_mu;
+std::unordered_map<std::vector<int>, std::shared_ptr<const PlanTemplate>, KeyHash> g_cache;
+long long g_hits = 0, g_misses = 0;
+enum { CACHE_MAX_ENTRIES = 2048 };
+
+void structure_key(const tcv_problem &p, int mode, int chain_lds, std::vector<int> &k) {
+    k.clear();
+    k.reserve(16 + 3 * p.blocks.size() + 4 * p.imu.size() + 5 * p.proj.size() + p.line.size() + 64);
+    k.push_back(mode); k.push_back(chain_lds); k.push_back((int)p.blocks.size());
+    for (auto &b : p.blocks) k.push_back(b.size | (b.kind << 8) | ((int)b.constant << 16));
+    k.push_back((int)p.imu.size());
+    for (auto &f : p.imu) for (int j = 0; j < 4; j++) k.push_back(f.b[j]);
+    k.push_back((int)p.proj.size());
+    for (auto &f : p.proj) { for (int j = 0; j < 4; j++) k.push_back(f.b[j]); k.push_back(f.btd); }
+    k.push_back((int)p.line.size());
+    for (auto &f : p.line) k.push_back(f.b);
+    k.push_back((int)p.prior.size());
+    for (auto &f : p.prior) {
+        const tcv_prior *pr = f.prior;
+        k.push_back(pr->n); k.push_back((int)pr->size.size()); k.push_back((int)pr->x0.size());
+        for (size_t j = 0; j < f.b.size(); j++) { k.push_back(f.b[j]); k.push_back(pr->size[j]); k.push_back(pr->idx[j]); k.push_back(pr->xoff[j]); }
+    }
+    k.push_back((int)p.frame_pose.size());
+    for (int v : p.frame_pose) k.push_back(v);
+    for (int v : p.frame_sb) k.push_back(v);
+}
+}  // namespace
+
+void plan_cache_stats(long long *hits, long long *misses, long long *entries) {
+    std::lock_guard<std::mutex> g(g_cache_mu);
+    if (hits) *hits = g_hits;
+    if (misses) *misses = g_misses;
+    if (entries) *entries = (long long)g_cache.size();
+}
+
+int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int mode, int chain_lds) {
+    static const bool no_cache = getenv("TCV_NO_PLAN_CACHE") != nullptr;
+    const int c_lds = (chain_lds >= 6144 && chain_lds <= LDS_DOUBLES) ? (chain_lds & ~1) : chain_lds_doubles();
+    std::vector<int> key;
+    std::shared_ptr<const PlanTemplate> T;
+    if (!no_cache) {
+        structure_key(p, mode, c_lds, key);
+        std::lock_guard<std::mutex> g(g_cache_mu);
+        auto it = g_cache.find(key);
+        if (it != g_cache.end()) { T = it->second; g_hits++; } else g_misses++;
+    }
+    if (T) {
+        out.hdr = T->hdr; out.tmpl = T; out.ints.clear();
+        out.cam_block = T->cam_block; out.cam_loff = T->cam_loff; out.lm_block = T->lm_block; out.proj_order = T->proj_order;
+    } else {
+        out.tmpl.reset();
+        const int rc = pack_plan(p, out, mode, c_lds);
+        if (rc != TCV_OK) return rc;
+        if (!no_cache) {
+            auto N = std::make_shared<PlanTemplate>();
+            N->hdr = out.hdr; N->ints.swap(out.ints);
+            N->cam_block = out.cam_block; N->cam_loff = out.cam_loff; N->lm_block = out.lm_block; N->proj_order = out.proj_order;
+            out.tmpl = N;
+            std::lock_guard<std::mutex> g(g_cache_mu);
+            if (g_cache.size() >= CACHE_MAX_ENTRIES) g_cache.clear();      // replays produce a new structure every frame: bounded, not LRU
+            g_cache.emplace(std::move(key), N);
+        }
+    }
+    return pack_data(p, out, imu_sqrt);
 }
 
 }  // namespace tcv

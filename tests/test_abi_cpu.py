@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(tcv):
     assert b"gfx950" in L.tcv_version()
     # include/tcv_estimator.h: the native window management around the same C-ABI
     est = set(re.findall(r"\b(tcv_estimators?_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "include", "tcv_estimator.h")).read()))
-    assert len(est) == 8
+    assert len(est) == 9
     for name in sorted(est):
         assert hasattr(L, name), f"libtcv_hip.so does not export {name}"
 
@@ -209,7 +209,9 @@ def test_only_tests_smoke_and_cpu_baseline_touch_the_oracle():
         src = open(f).read()
         assert "import orc" not in src and "import np_oracle" not in src and "replay_oracle" not in src, f
     b = open(os.path.join(ROOT, "bench.py")).read()
-    assert b.count("import orc") == 1 and b.index("import orc") > b.index("def cpu_baseline")
+    # the single import sits in the worker of the CPU baseline, behind the "CPU baseline" banner and before the PCIe / mode sections
+    assert b.count("import orc") == 1 and b.index("# ---- CPU baseline") < b.index("import orc") < b.index("def cpu_baseline") < b.index("# ---- PCIe-inclusive")
+    assert b.count("_cpu_worker") == 3      # its definition and the two calls inside cpu_baseline()
     for f in glob.glob(os.path.join(ROOT, "tc-viml_amd", "csrc", "*")):
         src = open(f).read()
         assert "tcv_oracle" not in src and "orc_" not in src and "liborc" not in src, f      # comments may mention the oracle, code may not use it

@@ -24,6 +24,7 @@ ap.add_argument("--line-mode", choices=("associate", "given", "none"), default="
                      "given: every line observation arrives with its true 3D partner; none: no line factors")
 ap.add_argument("--exact-line-jacobian", action="store_true", help="opt-in extension: derivative of the line residual instead of the reference's Jacobian (tcv_problem_set_line_jacobian)")
 ap.add_argument("--native", action="store_true", help="window management in native code (include/tcv_estimator.h) instead of replay.Replay")
+ap.add_argument("--profile", action="store_true", help="print the host-side time accounting of the native estimator (tcv_estimators_profile)")
 ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "euroc"))
 args = ap.parse_args()
 rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -56,4 +57,10 @@ res = dict(rank=rank, world=world, line_mode=args.line_mode, line_jacobian="exac
            frames_per_s=round(frames / max(t2 - t1, 1e-9), 1))
 with open(os.path.join(args.out, "replay_euroc_%s%s_rank%d.json" % (args.line_mode, "_exactJ" if args.exact_line_jacobian else "", rank)), "w") as f:
     json.dump(res, f, indent=1)
+if args.native and args.profile:
+    import ctypes as C, tcv
+    prof = (C.c_double * 8)()
+    tcv.lib().tcv_estimators_profile(prof)
+    names = ["preintegrate", "assoc+triangulate+window", "problems", "batch_create", "kernels", "downloads", "apply", "calls"]
+    res["native_profile_s"] = {k: round(v, 4) for k, v in zip(names, prof)}
 print(json.dumps(res))
