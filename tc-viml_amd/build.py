@@ -27,10 +27,13 @@ def _stale() -> bool:
     return False
 
 
-def build(force: bool = False, verbose: bool = False, profile: bool = False) -> str:
-    """profile=True builds libtcv_hip_prof.so with per-phase cycle accounting (developer tool)."""
+def build(force: bool = False, verbose: bool = False, profile: bool = False, ablate: bool = False) -> str:
+    """profile=True builds libtcv_hip_prof.so with per-phase cycle accounting, ablate=True libtcv_hip_abl.so whose solve kernel can
+    skip phases (TCV_ABLATE_SKIP bit mask): developer tools."""
     if profile:
         return _compile(os.path.join(HERE, "libtcv_hip_prof.so"), verbose, ["-DTCV_PROFILE=1"])
+    if ablate:
+        return _compile(os.path.join(HERE, "libtcv_hip_abl.so"), verbose, ["-DTCV_ABLATE=1"])
     if not force and not _stale():
         return OUT
     return _compile(OUT, verbose, [])
@@ -66,4 +69,4 @@ def _compile(out: str, verbose: bool, extra) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv, profile="--profile" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv, profile="--profile" in sys.argv, ablate="--ablate" in sys.argv))

@@ -563,6 +563,7 @@ extern "C" int tcv_batch_solve(tcv_batch *b, const tcv_solver_options *o, void *
     a.max_iterations = o->max_num_iterations; a.fixed_iterations = o->fixed_iterations; a.use_mfma = o->use_mfma;
     a.chain = b->chain ? 1 : 0; a.imublk = b->d_imublk; a.spill = b->d_spill; a.spill_stride = b->spill_stride;
     a.max_ticks = 0;
+    if (const char *sk = getenv("TCV_ABLATE_SKIP")) a.pad2 = (int)(unsigned)strtoul(sk, nullptr, 0);      // -DTCV_ABLATE builds only read it
     if (o->max_solver_time_in_seconds > 0.0 && !o->fixed_iterations) {
         int dev = 0, khz = 0;
         hipGetDevice(&dev);

@@ -140,7 +140,7 @@ struct SolveArgs {
     int max_iterations, fixed_iterations, use_mfma, chain;
     double *imublk;               // chain mode, per workgroup: 16 x IMU_BLK doubles (per-factor J'J | J'r blocks, 32 x 32 row-major)
     double *spill;                // chain mode, per workgroup: factored fronts (spill_stride doubles)
-    int spill_stride, pad2;
+    int spill_stride, pad2;       // pad2: phase skip mask of the -DTCV_ABLATE developer build (0 otherwise)
     long long max_ticks;          // max_solver_time_in_seconds in ticks of the constant-rate device clock (wall_clock64); 0: no limit
 };
 

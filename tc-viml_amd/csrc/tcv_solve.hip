@@ -48,6 +48,18 @@ __device__ __forceinline__ int tix(int a, int b) { return tbase(a >> 4, b >> 4) 
 #else
 #define TCV_MARK(C, id) do { } while (0)
 #endif
+// subtractive profiling (build with -DTCV_ABLATE, developer tool): bit k of SolveArgs::skip removes phase k from the kernel (results
+// are garbage, every step is forced to be accepted so that the control flow stays the benchmark's); the time difference to skip = 0
+// is what the phase really costs under the real overlap conditions -- no instrumentation in the timed code
+#ifdef TCV_ABLATE
+#define ABL(C, bit) (!((C).skip & (1u << (bit))))
+#define ABL_FORCE(C) (((C).skip >> 31) != 0)      // bit 31: linear-solver failures are ignored
+#define ABL_ACCEPT(C) ((((C).skip >> 30) & 1u) != 0)      // bit 30: every step is accepted (fixed control flow)
+#else
+#define ABL(C, bit) true
+#endif
+enum { AB_VIS_EVAL = 0, AB_VIS_GATHER, AB_LM, AB_SCHUR, AB_PRIOR_A, AB_IMU_RAW, AB_IMU_WHITEN, AB_IMU_GATHER, AB_PRIOR_B, AB_FIN_SCALE, AB_FIN_PASS,
+       AB_CHAIN_FWD, AB_CHOL, AB_BACK, AB_CHAIN_BWD, AB_LM_BACK, AB_DOGLEG, AB_PLUS, AB_NORMS, AB_SETUP, AB_COPY_PROG };
 enum { PH_SETUP = 0, PH_VIS_EVAL, PH_VIS_GATHER, PH_LM, PH_SCHUR, PH_ZERO, PH_IMU_RAW, PH_IMU_WHITEN, PH_IMU_GATHER, PH_PRIOR,
        PH_COST_RED, PH_FIN_SCALE, PH_FIN_CAUCHY, PH_FIN_PASS, PH_CHOL_DIAG, PH_CHOL_TRSM, PH_CHOL_UPD, PH_BACK, PH_LM_BACK,
        PH_DOGLEG, PH_PLUS, PH_NORMS, PH_OTHER, PH_CHAIN_FWD, PH_CHAIN_BWD, PH_CH_A, PH_CH_B, PH_CH_C, PH_CH_D, PH_COUNT = 32 };
@@ -73,6 +85,7 @@ struct Ctx {
     gbl_d *v_s, *v_g, *v_D, *v_ghat, *v_y, *v_p, *v_rc, *v_sd, *l_hll, *l_gl, *l_invk, *g_hcl, *g_hp, *g_pr, *g_pdx, *g_sqrt;
     int ntiles, stage_cap;
     int tid;
+    unsigned skip;   // TCV_ABLATE builds
 };
 
 enum { SCR_HP = 8256, SCR_SQ = 16 * 225, SCR_LM = 1024 };      // the landmark/camera coupling store comes last: its size is per batch
@@ -296,6 +309,7 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
             copy_prog<NT>(lprog, ip + P.o_vdest + voff, 3 * vnu + vni, tid);
         }
         __syncthreads();
+        if (ABL(C, AB_VIS_EVAL)) {
         for (int f = tid; f < pn; f += NT) {
             cst_i *pf = ip + P.o_proj + (pb + f) * 4;
             const lds_d *xi = x + blk[pf[0] * 4 + 1], *xj = x + blk[pf[1] * 4 + 1], *xe = x + blk[pf[2] * 4 + 1];
@@ -347,11 +361,12 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
             cost_acc += loss_correct2(r, J, 6, LINE_STRIDE, line_loss);
             if (assemble) { rec[6] = r[0]; rec[LINE_STRIDE + 6] = r[1]; }
         }
+        }
         if (!assemble) { TCV_MARK(C, PH_VIS_EVAL); continue; }
         __syncthreads();
         TCV_MARK(C, PH_VIS_EVAL);
         // gather J'J / J'r / landmark couplings: wave units (long item lists) first, then one unit per thread
-        {
+        if (ABL(C, AB_VIS_GATHER)) {
             const lds_i *items = lprog + 3 * vnu;
             const int lane = tid & 63, wave = tid >> 6;
             const int nloop = vnw + ((vnu - vnw + NT - 1) / NT) * 1;   // (only for clarity; loops below are separate)
@@ -385,7 +400,7 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
         // is dead now: the Schur program moves in.
         {
             cst_i *lm = ip + P.o_lm;
-            for (int l = tid; l < lmn; l += NT) {
+            for (int l = tid; l < (ABL(C, AB_LM) ? lmn : 0); l += NT) {
                 const double h = hll[l];
                 double sl;
                 if (first) { sl = 1.0 / (1.0 + sqrt(h)); C.v_s[nc + lmb + l] = sl; }
@@ -405,7 +420,7 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
         for (int i = tid; i < esize; i += NT) C.g_hcl[ebase + i] = hcl[i];
         TCV_MARK(C, PH_LM);
         // Schur complement of the chunk's landmarks
-        {
+        if (ABL(C, AB_SCHUR)) {
             const lds_i *sprog = (const lds_i *)C.stage;
             const lds_i *items = sprog + 3 * snu;
             const int lane = tid & 63, wave = tid >> 6;
@@ -439,7 +454,7 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
     // ---------------- marginalisation prior, part A (marginalization_factor.cpp:335-384): r = r0 + J0 dx, J0' r ------
     // The staging area is free between the Schur phase and the IMU chunks: J0 (n x n, column-major) is staged there
     // once per linearisation so that both products run out of LDS.
-    if (P.prior_n > 0) {
+    if (P.prior_n > 0 && ABL(C, AB_PRIOR_A)) {
         const int n = P.prior_n;
         cst_d *J0g = dp + C.W->d_prior, *r0 = J0g + n * n, *x0 = r0 + n;
         const bool in_lds = n * n + 2 * n <= C.stage_cap;
@@ -567,7 +582,7 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
         lds_d *recs = CHAIN ? C.stage : C.area;      // chain mode: the whole LDS pool holds the records
         const int lane = tid & 63, wave = tid >> 6;
         constexpr int NW = NT / 64;
-        if (wave < 4 && lane < fn) {
+        if (wave < 4 && lane < fn && ABL(C, AB_IMU_RAW)) {
             cst_i *b = ip + P.o_imu + (fb + lane) * 4;
             lds_d *rec = recs + lane * IMU_REC;
             double cst[62];
@@ -578,7 +593,7 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
         }
         __syncthreads();
         TCV_MARK(C, PH_IMU_RAW);
-        {   // whiten: T = S * [J_raw | r_raw]  (S upper triangular 15 x 15, zero padded to 16 x 16)
+        if (ABL(C, AB_IMU_WHITEN)) {   // whiten: T = S * [J_raw | r_raw]  (S upper triangular 15 x 15, zero padded to 16 x 16)
             const int i16 = lane & 15, k4 = lane >> 4;
             for (int f = wave; f < fn; f += NW) {
                 lds_d *rec = recs + f * IMU_REC;
@@ -608,7 +623,7 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
             for (int r = 0; r < 15; r++) s += rec[r * IMU_STRIDE_J] * rec[r * IMU_STRIDE_J];
             cost_acc += 0.5 * s;
         }
-        if (assemble) {
+        if (assemble && ABL(C, AB_IMU_GATHER)) {
             cst_i *imap = ip + P.o_idest;
             const int i16 = lane & 15, k4 = lane >> 4;
             for (int color = 0; color < ncolor; color++) {
@@ -689,7 +704,7 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
         TCV_MARK(C, PH_IMU_GATHER);
     }
     // ---------------- marginalisation prior, part B: the constant J0' J0 (cached per solve) joins the tiles --------------
-    if (P.prior_n > 0 && assemble) {
+    if (P.prior_n > 0 && assemble && ABL(C, AB_PRIOR_B)) {
         const int n = P.prior_n, npk = n * (n + 1) / 2;
         cst_i *pcol = ip + P.o_pcol;
         for (int e0 = tid; e0 < npk; e0 += 4 * NT) {
@@ -850,6 +865,9 @@ __device__ __noinline__ bool chol_tiles(Ctx<NT> &C, int nt, int nc) {
     }
     __syncthreads();
     TCV_MARK(C, PH_CHOL_DIAG);
+#ifdef TCV_ABLATE
+    if (!ABL_FORCE(C))
+#endif
     if (*C.flag) return false;
     for (int K = 0; K + 1 < nt; K++) {
         const int cmax = min(16, nc - 16 * K);
@@ -906,6 +924,9 @@ __device__ __noinline__ bool chol_tiles(Ctx<NT> &C, int nt, int nc) {
         }
         __syncthreads();
         TCV_MARK(C, PH_CHOL_UPD);
+#ifdef TCV_ABLATE
+        if (!ABL_FORCE(C))
+#endif
         if (*C.flag) return false;
     }
     return true;
@@ -1054,6 +1075,9 @@ __device__ __noinline__ bool chain_forward(Ctx<NT> &C, double mu, double &q_out)
 #pragma unroll
                     for (int c = k + 1; c <= r; c++) Ld[r * (r + 1) / 2 + c] -= Ld[r * (r + 1) / 2 + k] * Ld[c * (c + 1) / 2 + k];
             }
+#ifdef TCV_ABLATE
+            if (ABL_FORCE(C)) ok = true;
+#endif
             if (!ok) return false;      // uniform: every thread factored the same block
             for (int r = CH_W + tid; r < nr; r += NT) {
                 double x[CH_W];
@@ -1237,6 +1261,7 @@ __device__ __noinline__ bool finalize_and_solve(Ctx<NT> &C, bool first, double m
     const int tid = C.tid, nc = P.nc, L = P.nland;
     const int nd = C.nd;      // dimension of the dense system in the tiles: nc, or npp in chain mode
     cst_i *ip = C.ip;
+    if (ABL(C, AB_FIN_SCALE)) {
     for (int a = tid; a < nc; a += NT) {
         const double sdv = C.sd[min(a, 87)];
         const double hdv = CHAIN ? C.hd[min(max(a - P.npp, 0), 111)] : 0.0;
@@ -1260,6 +1285,7 @@ __device__ __noinline__ bool finalize_and_solve(Ctx<NT> &C, bool first, double m
         C.v_D[nc + l] = D;
         C.v_ghat[nc + l] = s * C.l_gl[l] / D;
     }
+    }
     __syncthreads();
     TCV_MARK(C, PH_FIN_SCALE);
     // Cauchy point: gg = |ghat|^2, q = |J (ghat / D)|^2 = u' H u with H = [S~ + sum Hcl Hcl'/kappa, Hcl; Hcl', hll].
@@ -1267,7 +1293,7 @@ __device__ __noinline__ bool finalize_and_solve(Ctx<NT> &C, bool first, double m
     // adds mu D^2, writes the rhs row and the identity padding.
     double acc[2] = {0.0, 0.0};
     for (int a = tid; a < nc; a += NT) { const double gh = C.v_ghat[a]; acc[0] += gh * gh; }
-    {
+    if (ABL(C, AB_FIN_SCALE)) {
         cst_i *lm = ip + P.o_lm, *sp = ip + P.o_lmslotptr, *so = ip + P.o_lmslot;
         for (int l = tid; l < L; l += NT) {
             const gbl_d *h = C.g_hcl + lm[2 * l];
@@ -1285,7 +1311,7 @@ __device__ __noinline__ bool finalize_and_solve(Ctx<NT> &C, bool first, double m
         }
     }
     TCV_MARK(C, PH_FIN_CAUCHY);
-    {
+    if (ABL(C, AB_FIN_PASS)) {
         constexpr int NW = NT / 64;
         const int lane = tid & 63, wave = tid >> 6;
         const int r = lane >> 2, c0 = (lane & 3) << 2;
@@ -1335,12 +1361,12 @@ __device__ __noinline__ bool finalize_and_solve(Ctx<NT> &C, bool first, double m
     TCV_MARK(C, PH_FIN_PASS);
     if (CHAIN) {
         double qc = 0.0;
-        if (!chain_forward<NT>(C, mu, qc)) return false;
+        if (ABL(C, AB_CHAIN_FWD) && !chain_forward<NT>(C, mu, qc)) return false;
         q_out += qc;
         TCV_MARK(C, PH_CHAIN_FWD);
     }
-    if (!chol_tiles<NT, MFMA>(C, C.ntd, nd)) return false;
-    back_subst<NT>(C, nd);
+    if (ABL(C, AB_CHOL) && !chol_tiles<NT, MFMA>(C, C.ntd, nd)) return false;
+    if (ABL(C, AB_BACK)) back_subst<NT>(C, nd);
     TCV_MARK(C, PH_BACK);
     // landmarks: y_l = (gl - Hcl' (s o y_c)) / (s_l kappa_l)
     bool bad = false;
@@ -1352,8 +1378,8 @@ __device__ __noinline__ bool finalize_and_solve(Ctx<NT> &C, bool first, double m
     // chain mode: wave 0 walks the chain backwards (Euclidean blocks in reverse elimination order) while the other
     // waves back-substitute the landmarks, which only meet pose-kind blocks
     const int l_first = CHAIN ? tid - 64 : tid, l_step = CHAIN ? NT - 64 : NT;
-    if (CHAIN && tid < 64) { if (!chain_backward<NT>(C)) bad = true; }
-    if (!CHAIN || tid >= 64) {
+    if (CHAIN && tid < 64 && ABL(C, AB_CHAIN_BWD) && ABL(C, AB_CHAIN_FWD)) { if (!chain_backward<NT>(C)) bad = true; }
+    if ((!CHAIN || tid >= 64) && ABL(C, AB_LM_BACK)) {
         cst_i *lm = ip + P.o_lm, *sp = ip + P.o_lmslotptr, *so = ip + P.o_lmslot;
         for (int l = l_first; l < L; l += l_step) {
             const gbl_d *h = C.g_hcl + lm[2 * l];
@@ -1369,11 +1395,17 @@ __device__ __noinline__ bool finalize_and_solve(Ctx<NT> &C, bool first, double m
             if (!(fabs(y) < 1e300)) bad = true;
         }
     }
+#ifdef TCV_ABLATE
+    if (ABL_FORCE(C)) bad = false;
+#endif
     if (bad) *C.flag = 2;
     __syncthreads();
-    const int anybad = *C.flag;
+    int anybad = *C.flag;
     __syncthreads();
     TCV_MARK(C, PH_LM_BACK);
+#ifdef TCV_ABLATE
+    if (ABL_FORCE(C)) anybad = 0;
+#endif
     return anybad == 0;
 }
 
@@ -1459,6 +1491,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CHAIN ?
     C.g_hcl = C.g_sqrt + SCR_SQ;
     C.prof = A.prof ? (gbl_d *)A.prof + (size_t)blockIdx.x * 32 : nullptr;
     C.t_last = 0;
+    C.skip = (unsigned)A.pad2;
 #ifdef TCV_PROFILE
     C.t_last = clock64();
 #endif
@@ -1591,7 +1624,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CHAIN ?
                     if (ok) { ls_ok = true; break; }
                     mu *= 10.0;
                 }
-                if (ls_ok) {
+                if (ls_ok && ABL(C, AB_DOGLEG)) {
                     alpha = gg / q;
                     // dot products for the dogleg interpolation and the model decrease
                     double acc[3] = {0.0, 0.0, 0.0};
@@ -1633,6 +1666,9 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CHAIN ?
                 // sign convention of the minimiser: step = -(...) so that model_cost_change > 0 for descent
                 step_valid = model_cost_change > 0.0;
             }
+#ifdef TCV_ABLATE
+            if (ABL_ACCEPT(C)) step_valid = true;
+#endif
             if (!step_valid) {
                 invalid++;
                 if (tid == 0 && nrec < MAX_TRACE) {
@@ -1650,7 +1686,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CHAIN ?
             TCV_MARK(C, PH_DOGLEG);
             for (int i = tid; i < nl; i += NT) C.v_p[i] = ca * (C.v_ghat[i] / C.v_D[i]) + cb * C.v_y[i];
             __syncthreads();
-            apply_plus<NT>(C, C.xs, C.v_p, C.v_s, C.xc);
+            if (ABL(C, AB_PLUS)) apply_plus<NT>(C, C.xs, C.v_p, C.v_s, C.xc);
             if (A.first_delta && it == 1)
                 for (int i = tid; i < nl; i += NT) A.first_delta[(size_t)win * A.delta_stride + i] = C.v_p[i] * C.v_s[i];
             __syncthreads();
@@ -1660,9 +1696,13 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CHAIN ?
             const double cost_c = linearize<NT, CHAIN>(C, C.xc, false, want_asm, mu_next);
             tiles_valid = want_asm;
             lin_mu = mu_next;
-            ambient_norms<NT>(C, C.xs, C.xc, xn2, dn2);
+            if (ABL(C, AB_NORMS)) ambient_norms<NT>(C, C.xs, C.xc, xn2, dn2);
             TCV_MARK(C, PH_NORMS);
+#ifdef TCV_ABLATE
+            const double rho = ABL_ACCEPT(C) ? 1.0 : (cost - cost_c) / model_cost_change;
+#else
             const double rho = (cost - cost_c) / model_cost_change;
+#endif
             if (tid == 0 && nrec < MAX_TRACE) {
                 S->model_cost_change[nrec] = model_cost_change; S->cost_candidate[nrec] = cost_c;
                 S->radius[nrec] = radius; S->mu[nrec] = mu; S->rho[nrec] = rho; S->step_norm[nrec] = step_norm;
@@ -1679,7 +1719,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CHAIN ?
             }
             if (rho > 1e-3) {
                 for (int i = tid; i < P.nx + L; i += NT) C.xs[i] = C.xc[i];
-                ambient_norms<NT>(C, C.xc, C.xc, xn2, dn2);
+                if (ABL(C, AB_NORMS)) ambient_norms<NT>(C, C.xc, C.xc, xn2, dn2);
                 x_norm = sqrt(xn2);
                 cost = cost_c;
                 if (rho < 0.25) radius *= 0.5;

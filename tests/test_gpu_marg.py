@@ -1,7 +1,12 @@
 """GPU parity of the marginalisation (MarginalizationInfo::marginalize, marginalization_factor.cpp:174-299)
-against the golden vectors and the C oracle.  Gates follow SURVEY.md Appendix B.2: A' is a small difference
-of ~1e14 terms, so ~1e-7 relative is the FP64 reproducibility floor between any two implementations; the
-factors J0, r0 are only defined up to eigenvector sign / rotation, so parity is gated on J0'J0 and J0'r0."""
+against the golden vectors and the C oracle.  A' is a small difference of ~1e14 terms, so ~1e-7 relative is the FP64
+reproducibility floor between any two implementations (SURVEY.md Appendix B.2 measures 4.8e-7 for the same maths with the factors
+accumulated in another order); the factors J0, r0 are only defined up to eigenvector sign / rotation, so parity is gated on J0'J0
+and J0'r0.  Every gate sits about one order of magnitude above the value measured on the MI355X (tests/dev/marg_floor.py,
+profiles/r02_marg_floor.txt; round 1 gated at 1e-5 ... 1e-3 across the board):
+    at bit-identical states      A' 5e-8 ... 1.6e-7   b' 1e-13 ... 4e-13      J0'r0 vs b' 1.6e-6 (35 of 75 eigenvalues of A' are thresholded)
+    after each side's own solve  A' 1.5e-7 ... 5.2e-7 b' 2e-9 ... 5e-8        J0'r0 1.8e-5
+    chained solve on that prior  final cost 1.2e-5, poses 6.5e-7 (the 1e-7 of the prior seen through 8 dogleg iterations)"""
 import ctypes as C
 
 import numpy as np
@@ -36,13 +41,13 @@ def test_golden_marginalisation_after_solve(gpu):
     kinds = {0: "pose", 1: "sb", 2: "ex"}
     want = [(kinds[int(k)], int(i)) for k, i in zip(z["marg_block_kind"], z["marg_block_index"])]
     assert gpu.shifted_prior_blocks(P, W[0]) == want                 # addr_shift of estimator.cpp:2027-2039
-    assert fro(As, z["marg_A_schur"]) < 1e-5 and fro(bs, z["marg_b_schur"]) < 1e-6
+    assert fro(As, z["marg_A_schur"]) < 5e-6 and fro(bs, z["marg_b_schur"]) < 5e-7      # measured 5.2e-7 / 4.7e-8 (each side linearises at its own solve's states)
     JtJ = d["J0"].T @ d["J0"]
-    assert fro(JtJ, z["marg_J0"].T @ z["marg_J0"]) < 1e-5
-    assert fro(d["J0"].T @ d["r0"], z["marg_J0"].T @ z["marg_r0"]) < 1e-3
-    assert rel(np.concatenate(d["x0"]), z["marg_x0"]) < 1e-6          # linearisation point = solved states (preMarginalize :110-129)
-    # reference invariants (marginalization_factor.cpp:297-298) up to the eps = 1e-8 thresholded null space
-    assert fro(JtJ, As) < 1e-5 and fro(d["J0"].T @ d["r0"], bs) < 1e-3
+    assert fro(JtJ, z["marg_J0"].T @ z["marg_J0"]) < 5e-6                                 # measured 5.1e-7
+    assert fro(d["J0"].T @ d["r0"], z["marg_J0"].T @ z["marg_r0"]) < 2e-4                 # measured 1.8e-5
+    assert rel(np.concatenate(d["x0"]), z["marg_x0"]) < 1e-7          # linearisation point = solved states (preMarginalize :110-129); measured 7.5e-9
+    # reference invariants (marginalization_factor.cpp:297-298) up to the eps = 1e-8 thresholded null space (35 of 75 eigenvalues)
+    assert fro(JtJ, As) < 5e-7 and fro(d["J0"].T @ d["r0"], bs) < 2e-4                    # measured 3.7e-8 / 1.5e-5
     # thresholded factor is positive semi-definite and ordered like SelfAdjointEigenSolver (ascending)
     rn = np.linalg.norm(d["J0"], axis=1)
     assert np.all(np.diff(rn) >= -1e-9 * rn.max())
@@ -63,8 +68,9 @@ def test_standalone_marginalise_at_given_state_vs_oracle(gpu):
         gpu.check(gpu.lib().tcv_marginalize(Wm.h, arr, len(dr), C.byref(h)))
         P = gpu.Prior(h); d = P.export(); As, bs = P.schur()
         assert (d["m"], d["n"]) == (po["m"], po["n"])
-        assert fro(As, dbg["A_schur"]) < 1e-5 and fro(bs, dbg["b_schur"]) < 1e-6
-        assert fro(d["J0"].T @ d["J0"], dbg["A_schur"]) < 1e-5
+        assert fro(As, dbg["A_schur"]) < 2e-6 and fro(bs, dbg["b_schur"]) < 1e-11          # measured 1.6e-7 / 1.9e-13 at bit-identical states
+        assert fro(d["J0"].T @ d["J0"], dbg["A_schur"]) < 2e-6
+        assert fro(d["J0"].T @ d["r0"], dbg["b_schur"]) < 2e-5                             # measured 1.8e-6
         assert rel(np.concatenate(d["x0"]), np.concatenate([np.atleast_1d(v) for v in po["x0"]])) == 0.0
 
 
@@ -75,8 +81,8 @@ def test_marginalisation_with_an_incoming_prior(gpu):
     P = b.prior(0); d = P.export(); As, bs = P.schur()
     O = orc.Window(main); O.solve(8, True); po, dbg = O.marginalize_old()
     assert (d["m"], d["n"]) == (po["m"], po["n"]) and d["sizes"] == po["sizes"] and d["idx"] == po["idx"]
-    assert fro(As, dbg["A_schur"]) < 1e-4 and fro(bs, dbg["b_schur"]) < 1e-4
-    assert fro(d["J0"].T @ d["J0"], po["J0"].T @ po["J0"]) < 1e-4
+    assert fro(As, dbg["A_schur"]) < 2e-6 and fro(bs, dbg["b_schur"]) < 5e-8                # measured 1.5e-7 / 2.2e-9 (round 1 gated both at 1e-4)
+    assert fro(d["J0"].T @ d["J0"], po["J0"].T @ po["J0"]) < 2e-6
 
 
 def test_prior_round_trip_and_chained_solve(gpu):
@@ -94,8 +100,10 @@ def test_prior_round_trip_and_chained_solve(gpu):
     bn = gpu.Batch([Wn]); bn.solve(gpu.default_options(8, True)); bn.synchronize(); bn.download_states()
     s = bn.summaries()[0]
     O = orc.Window(main); so = O.solve(8, True)
+    # the prior differs by its reproducibility floor (A' 5e-7); eight dogleg iterations on the ill-conditioned window turn that into
+    # 1.2e-5 on the final cost and 6.5e-7 / 1.2e-6 on poses / speed-biases (measured): the gates sit one order above
     assert abs(s.final_cost - so.final_cost) < 1e-4 * so.final_cost
-    assert rel(Wn.pose, O.states()["pose"]) < 1e-5
+    assert rel(Wn.pose, O.states()["pose"]) < 1e-5 and rel(Wn.sb, O.states()["sb"]) < 2e-5
 
 
 def test_margin_second_new_prior_only(gpu):
@@ -117,9 +125,11 @@ def test_margin_second_new_prior_only(gpu):
     P = gpu.Prior(h); d = P.export(); As, bs = P.schur()
     assert (d["m"], d["n"]) == (6, po["n"]) == (6, main["prior"]["n"] - 6)
     assert d["sizes"] == po["sizes"] and d["idx"] == po["idx"]
-    assert fro(As, dbg["A_schur"]) < 1e-5 and fro(bs, dbg["b_schur"]) < 1e-6
-    assert fro(d["J0"].T @ d["J0"], po["J0"].T @ po["J0"]) < 1e-5
-    assert fro(d["J0"].T @ d["r0"], po["J0"].T @ po["r0"]) < 1e-3
+    print("MARGIN_SECOND_NEW: A' %.2e b' %.2e J0'J0 %.2e J0'r0 %.2e" % (fro(As, dbg["A_schur"]), fro(bs, dbg["b_schur"]), fro(d["J0"].T @ d["J0"], po["J0"].T @ po["J0"]),
+                                                                    fro(d["J0"].T @ d["r0"], po["J0"].T @ po["r0"])))
+    assert fro(As, dbg["A_schur"]) < 2e-6 and fro(bs, dbg["b_schur"]) < 1e-8
+    assert fro(d["J0"].T @ d["J0"], po["J0"].T @ po["J0"]) < 2e-6
+    assert fro(d["J0"].T @ d["r0"], po["J0"].T @ po["r0"]) < 2e-4
     assert rel(np.concatenate(d["x0"]), np.concatenate([np.atleast_1d(v) for v in po["x0"]])) == 0.0
     # kept blocks: every prior block except pose WINDOW_SIZE-1, un-shifted
     W = main["pose"].shape[0] - 1
@@ -154,6 +164,7 @@ def test_large_drop_set_uses_landmark_pivots(gpu):
     gpu.check(gpu.lib().tcv_marginalize(Wm.h, arr, len(dr), C.byref(h)))
     P = gpu.Prior(h); d = P.export(); As, bs = P.schur()
     assert (d["m"], d["n"]) == (po["m"], po["n"]) and d["sizes"] == po["sizes"] and d["idx"] == po["idx"]
+    print("block mode (m = %d): A' %.2e b' %.2e" % (po["m"], fro(As, dbg["A_schur"]), fro(bs, dbg["b_schur"])))
     assert fro(As, dbg["A_schur"]) < 1e-5 and fro(bs, dbg["b_schur"]) < 1e-5
     assert fro(d["J0"].T @ d["J0"], dbg["A_schur"]) < 1e-5
     assert rel(np.concatenate(d["x0"]), np.concatenate([np.atleast_1d(v) for v in po["x0"]])) == 0.0
@@ -204,7 +215,7 @@ def test_marginalisation_of_replay_windows_one_by_one_vs_oracle(gpu):
         worstA = max(worstA, fro(As, dbg["A_schur"])); worstb = max(worstb, fro(bs, dbg["b_schur"]))
         assert fro(d["J0"].T @ d["J0"], dbg["A_schur"]) < 1e-5
     print("m values", sorted(ms), "worst A' %.2e b' %.2e" % (worstA, worstb))
-    assert len(ms) >= 4 and worstA < 1e-5 and worstb < 1e-6
+    assert len(ms) >= 4 and worstA < 5e-6 and worstb < 1e-8
 
 
 def test_marginalisation_keeps_a_constant_extrinsic(gpu):
@@ -229,8 +240,9 @@ def test_marginalisation_keeps_a_constant_extrinsic(gpu):
         assert d["sizes"][-1] == 7 and ("ex", 0) in gpu.shifted_prior_blocks(P, Wm)
         if want_n:
             assert d["n"] == want_n
-        assert fro(As, dbg["A_schur"]) < 1e-5 and fro(bs, dbg["b_schur"]) < 1e-6
-        assert fro(d["J0"].T @ d["J0"], dbg["A_schur"]) < 1e-5
+        print("constant extrinsic MARGIN_OLD: A' %.2e b' %.2e" % (fro(As, dbg["A_schur"]), fro(bs, dbg["b_schur"])))
+        assert fro(As, dbg["A_schur"]) < 2e-6 and fro(bs, dbg["b_schur"]) < 1e-8
+        assert fro(d["J0"].T @ d["J0"], dbg["A_schur"]) < 2e-6
     # the solve with the extrinsic constant and a prior that holds it (columns of J0 without a tangent index)
     Wn = gpu.Window(main, estimate_extrinsic=False)
     bn = gpu.Batch([Wn]); bn.solve(gpu.default_options(8, True)); bn.synchronize(); bn.download_states()
@@ -252,4 +264,4 @@ def test_marginalisation_keeps_a_constant_extrinsic(gpu):
     gpu.check(gpu.lib().tcv_marginalize(Wm.h, arr, len(dr), C.byref(h)))
     P = gpu.Prior(h); d = P.export(); As, bs = P.schur()
     assert (d["m"], d["n"]) == (6, po["n"]) == (6, main["prior"]["n"] - 6) and d["sizes"] == po["sizes"] and d["idx"] == po["idx"]
-    assert fro(As, dbg["A_schur"]) < 1e-5 and fro(bs, dbg["b_schur"]) < 1e-6
+    assert fro(As, dbg["A_schur"]) < 2e-6 and fro(bs, dbg["b_schur"]) < 1e-8
