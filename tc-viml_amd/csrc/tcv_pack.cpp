@@ -56,7 +56,7 @@ struct DestList {
 // unit record (UNIT_INTS ints): u0 = kind << 28 | ncols << 24 | ea << 20 | nitems,  u1 = o0 << 16 | o1,  u2 = item_begin
 // (IMU units carry their <= 2 items inline instead: u2 = item0, u3 = item1).  Units are sorted by descending item
 // count; those with more than WAVE_UNIT_ITEMS items come first and are processed by a whole wavefront each.
-enum { WAVE_UNIT_ITEMS = 128 };
+enum { WAVE_UNIT_ITEMS = 32 };      // longer item lists go to a whole wavefront: a thread unit costs its wavefront ~40 instructions per item while the other lanes idle
 struct RowProg {
     std::vector<int> units, items;
     int n_units = 0, n_wave_units = 0;
@@ -249,7 +249,7 @@ static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds)
     const int c_vec = 2 * nxl + 4 * 176 + 64 + 112;
     const int c_lds = (chain_lds >= 6144 && chain_lds <= LDS_DOUBLES) ? (chain_lds & ~1) : chain_lds_doubles();
     const int c_pool = c_lds - ctiles * 256 - c_vec;
-    if (use_chain && (c_pool < 2 * CH_MAXROWS * CH_W + 16 + 8 * CH_STRIDE + 64 || c_pool < IMU_REC)) use_chain = false;
+    if (use_chain && (c_pool < chain_pool_doubles((int)chain.size(), nt_c) || c_pool < IMU_REC)) use_chain = false;
 
     PlanHdr &H = out.hdr;
     std::memset(&H, 0, sizeof(H));
@@ -419,6 +419,14 @@ static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds)
         }
         RowProg vp, sp;
         if (!emit_rows(dl, vp, false) || !emit_rows(sl, sp, false)) { set_error("gather program field overflow"); return TCV_ERR_TOO_LARGE; }
+        if (getenv("TCV_DEBUG_UNITS")) {
+            auto dump = [](const char *nm, const RowProg &rp) {
+                fprintf(stderr, "[pack] %s: %d units (%d wave units), items per unit (descending):", nm, rp.n_units, rp.n_wave_units);
+                for (int u = 0; u < rp.n_units; u += (u < 16 ? 1 : 16)) fprintf(stderr, " %d", rp.units[3 * u] & 0xfffff);
+                fprintf(stderr, "\n");
+            };
+            dump("visual", vp); dump("schur", sp);
+        }
         const int recs = (c.pn * prec + c.ln * LINE_REC + 1) & ~1;
         const int st_need = std::max(recs + ((int)(vp.units.size() + vp.items.size()) + 1) / 2 + 2, ((int)(sp.units.size() + sp.items.size()) + 1) / 2 + 2);
         const int ar_need = (e_off[c.lmb + c.lmn] - e_off[c.lmb]) + 3 * c.lmn + 8;
@@ -544,7 +552,7 @@ static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds)
         std::vector<int> tab((size_t)ne * CH_STRIDE, 0);
         std::vector<int> pinv(nc + 1, -1);
         for (size_t j = 0; j < pcol.size(); j++) if (pcol[j] >= 0) pinv[pcol[j]] = (int)j;
-        int spill = 0;
+        const int wstride = 16 * nt_c * CH_W;      // W rows of one step in the spill area: 16 nt_c columns (whole tiles) x 9
         std::vector<std::vector<int>> rowt(ne);
         for (int s2 = 0; s2 < ne; s2++) {
             const ChainStep &st = chain[s2];
@@ -561,8 +569,10 @@ static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds)
             int *h = tab.data() + (size_t)s2 * CH_STRIDE;
             h[CH_T0] = st.t0; h[CH_R] = nr - CH_W - 1; h[CH_NEXT] = st.next ? 1 : 0; h[CH_NSRC] = st.nsrc;
             h[CH_F0] = st.f[0]; h[CH_LC0] = st.lc[0]; h[CH_F1] = st.f[1]; h[CH_LC1] = st.lc[1];
-            h[CH_PC0] = pinv[st.t0]; h[CH_SPILL] = spill;
-            spill += nr * CH_W + 16;
+            h[CH_PC0] = pinv[st.t0]; h[CH_SPILL] = s2 * wstride;
+            unsigned char *colrow = reinterpret_cast<unsigned char *>(h + CH_COLROW);
+            for (int c = 0; c < CH_MAXROWS; c++) colrow[c] = 255;
+            int tmask = 0;
             for (int r = 0; r < nr; r++) {
                 int vn = 255;
                 if (st.next) {
@@ -578,8 +588,17 @@ static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds)
                 if (tr > 254 && rt[r] >= 0) { set_error("chain: tangent index overflow"); return TCV_ERR_TOO_LARGE; }
                 h[CH_INTS + 2 * r] = tr | (vn << 8) | (l01[0] << 16) | (l01[1] << 24);
                 h[CH_INTS + 2 * r + 1] = rt[r] >= 0 ? pinv[rt[r]] : -1;
+                // pose rows (tangent index < npp) and the rhs row are the columns of this step's W
+                const int col = rt[r] == -2 ? npp : ((rt[r] >= 0 && rt[r] < npp) ? rt[r] : -1);
+                if (col >= 0) {
+                    if (col >= CH_MAXROWS) { set_error("chain: pose column overflow"); return TCV_ERR_TOO_LARGE; }
+                    colrow[col] = (unsigned char)r;
+                    tmask |= 1 << (col >> 4);
+                }
             }
+            h[CH_TMASK] = tmask;
         }
+        const int spill = ne * wstride;
         H.c_spill = (spill + 1) & ~1;
         I.insert(I.end(), tab.begin(), tab.end());
     }

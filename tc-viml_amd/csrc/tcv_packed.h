@@ -144,23 +144,29 @@ struct SolveArgs {
     long long max_ticks;          // max_solver_time_in_seconds in ticks of the constant-rate device clock (wall_clock64); 0: no limit
 };
 
-// chain step record (CH_STRIDE ints per step, copied into LDS by the kernel): a header followed by two ints per front row.
-// The front of Euclidean block e_s is a (9 + R + 1) x 9 row-major matrix: rows 0..8 the block itself, then the
-// later-eliminated Euclidean block (0 or 9 rows), the pose rows (ascending tangent index), last the rhs.
+// chain step record (CH_STRIDE ints per step, copied into LDS by the kernel): a header, two ints per "front row" and a byte map from
+// pose columns to front rows.  The front rows of Euclidean block e_s: rows 0..8 the block itself, then the later-eliminated
+// Euclidean block (0 or 9 rows), the coupled pose rows (ascending tangent index, fill of earlier steps included), last the rhs.
 enum {
     CH_T0 = 0,      // tangent offset of the block
     CH_R,           // rows between the diagonal block and the rhs row
-    CH_NEXT,        // 1: rows 9..17 are the next step's block (its front receives the Schur update)
+    CH_NEXT,        // 1: rows 9..17 are the next step's block (coupled through an IMU factor / the prior)
     CH_NSRC,        // number of IMU factors touching the block (<= 2)
     CH_F0, CH_LC0,  // factor index and local column of the block in it (6 or 21)
     CH_F1, CH_LC1,
     CH_PC0,         // prior column of the block's first tangent column (-1: not in the prior)
-    CH_SPILL,       // offset of the factored front in the spill area
+    CH_SPILL,       // offset of this step's W rows (9 x (npp + 1), column-major 9-vectors) in the workgroup's spill area
+    CH_TMASK,       // bit I: pose tile row I (16 tangent columns) holds a column coupled to this block (the rhs column counts)
     CH_INTS = 16,   // row r: int 2r   = tangent index (rhs: 255) | row in the next front << 8 (255 none)
                     //                   | local index in factor 0 << 16 (255 none) | local index in factor 1 << 24
                     //        int 2r+1 = prior column of the row (-1 none)
 };
-enum { CH_W = 9, CH_MAXROWS = 96, CH_STRIDE = CH_INTS + 2 * CH_MAXROWS, IMU_BLK = 1024 };   // front rows incl. diagonal block and rhs <= 96; per-factor J'J block 32 x 32
+// CH_COLROW: byte c = front row of pose tangent column c (column npp = the rhs), 255: not coupled
+enum { CH_W = 9, CH_MAXROWS = 96, CH_COLROW = CH_INTS + 2 * CH_MAXROWS, CH_STRIDE = CH_COLROW + CH_MAXROWS / 4, IMU_BLK = 1024 };   // per-factor J'J block 32 x 32
+// LDS pool of the chain phase (doubles): two W buffers (9 x 16 nt_c each), per step L_ee^-1 (9 x 9, offset 0) | L_next,e (9 x 9, offset
+// CH_LN), the T-wave's 18 x 9 workspace, then the step records
+enum { CH_LT = 164, CH_LN = 82, CH_TA = 164 };
+inline int chain_pool_doubles(int n_e, int nt_c) { return 2 * CH_W * 16 * nt_c + n_e * CH_LT + CH_TA + (n_e * CH_STRIDE + 1) / 2 + 8; }
 
 // per-workgroup global scratch layout (doubles)
 enum { SCR_NL = 1280 };  // capacity of an nl-sized vector (nc + nland)

@@ -59,7 +59,7 @@ __device__ __forceinline__ int tix(int a, int b) { return tbase(a >> 4, b >> 4) 
 #define ABL(C, bit) true
 #endif
 enum { AB_VIS_EVAL = 0, AB_VIS_GATHER, AB_LM, AB_SCHUR, AB_PRIOR_A, AB_IMU_RAW, AB_IMU_WHITEN, AB_IMU_GATHER, AB_PRIOR_B, AB_FIN_SCALE, AB_FIN_PASS,
-       AB_CHAIN_FWD, AB_CHOL, AB_BACK, AB_CHAIN_BWD, AB_LM_BACK, AB_DOGLEG, AB_PLUS, AB_NORMS, AB_SETUP, AB_COPY_PROG };
+       AB_CHAIN_FWD, AB_CHOL, AB_BACK, AB_CHAIN_BWD, AB_LM_BACK, AB_DOGLEG, AB_PLUS, AB_NORMS, AB_SETUP, AB_CH_T, AB_CH_W, AB_CH_MFMA, AB_CH_FETCH };
 enum { PH_SETUP = 0, PH_VIS_EVAL, PH_VIS_GATHER, PH_LM, PH_SCHUR, PH_ZERO, PH_IMU_RAW, PH_IMU_WHITEN, PH_IMU_GATHER, PH_PRIOR,
        PH_COST_RED, PH_FIN_SCALE, PH_FIN_CAUCHY, PH_FIN_PASS, PH_CHOL_DIAG, PH_CHOL_TRSM, PH_CHOL_UPD, PH_BACK, PH_LM_BACK,
        PH_DOGLEG, PH_PLUS, PH_NORMS, PH_OTHER, PH_CHAIN_FWD, PH_CHAIN_BWD, PH_CH_A, PH_CH_B, PH_CH_C, PH_CH_D, PH_COUNT = 32 };
@@ -978,279 +978,412 @@ __device__ __noinline__ void back_subst(Ctx<NT> &C, int nc) {
 }
 
 // ---- chain mode: block elimination of the Euclidean camera blocks before the dense pose system ------------------------
-// Step s eliminates block e_s (9 wide).  Its front F is a (9 + R + 1) x 9 row-major matrix in LDS: the block's own rows, the
-// next step's block (if coupled), the coupled pose rows in ascending tangent order and the rhs row.  F = fill left by step
-// s - 1 + the original entries (per-factor IMU J'J blocks parked in HBM/L2 by the linearisation, the cached J0'J0 of the
-// prior), Jacobi-scaled, + mu D^2.  After the 9 x 9 Cholesky and the row solves, the rank-9 Schur update runs on the
-// matrix cores and is scattered into the next front (rows of the next block) and into the pose tiles.  The factored front is
-// spilled to HBM/L2 for the back-substitution.  q accumulates u' H u over the original entries (Cauchy point).
-// LDS layout of the pool during the chain: [front 0 | front 1 | 1/diag (16) | step records (n_e x CH_STRIDE ints)]
-enum { CH_FSZ = CH_MAXROWS * CH_W, CH_TAB_OFF = 2 * CH_FSZ + 16 };
-
-// original (unscaled) entries of front `h` handled by this thread: up to 4 entries (idx = tid + 256 k), three sources each.
-// Issued one step ahead so that the HBM/L2 latency hides behind the previous step's factorisation.
+// The camera system is [E B; B' S]: E the Euclidean (speed-bias) blocks in elimination order -- block tridiagonal, block e_s only
+// meets e_{s+1} -- S the pose system in the LDS tiles (rhs row included), B their coupling plus the rhs of the Euclidean rows as
+// column npp.  With E = L_E L_E' (L_E block lower-bidiagonal) and W = L_E^-1 B the poses see S - W'W.  Three pipelines run side by
+// side, one barrier per step:
+//   T-wave (wave 3)       step s: D_s = E_ss - L_s,s-1 L_s,s-1', L_ss = chol(D_s), L_s+1,s = E_s+1,s L_ss^-T  (serial, 18 x 9 panel in
+//                         registers, one row per lane, pivots broadcast with v_readlane); one step ahead of the others;
+//   column owners         thread c < npp + 1 owns column c of W for the whole elimination: w_s = L_ss^-1 (b_s - L_s,s-1 w_s-1) with
+//   (waves 0, 1)          w_s-1 in registers -- no cross-lane traffic, L blocks read from LDS as broadcasts; w_s goes to an LDS buffer
+//                         for the matrix cores and to the spill area for the back-substitution;
+//   matrix cores          S -= W_s-1' W_s-1 on v_mfma_f64_16x16x4 over the tile pairs that hold coupled columns (waves 0, 1, 2; the
+//                         column owners once their w_s is out).
+// Every quantity is the one the textbook right-looking block Cholesky in this order produces; only the schedule differs.
+// q accumulates u' H u over the original entries of E and B (Cauchy point).
+// LDS pool during the chain: [W buffer 0 | W buffer 1 | per step L_ss, 1/diag, L_next | T workspace | step records]
+struct ChainLds { lds_d *wbuf, *ltab, *ta; lds_i *tab; int wld; };
 template <int NT>
-__device__ __forceinline__ void chain_fetch(const Ctx<NT> &C, const lds_i *h, double (&v)[4][3]) {
-    const int nr = CH_W + h[CH_R] + 1, nsrc = h[CH_NSRC];
-    const int f0 = h[CH_F0], lc0 = h[CH_LC0], f1 = h[CH_F1], lc1 = h[CH_LC1], pc0 = h[CH_PC0];
+__device__ __forceinline__ ChainLds chain_lds(const Ctx<NT> &C) {
+    ChainLds L;
+    L.wld = 16 * C.ntd;
+    L.wbuf = C.stage;
+    L.ltab = C.stage + 2 * CH_W * L.wld;
+    L.ta = L.ltab + C.P->n_e * CH_LT;
+    L.tab = (lds_i *)(L.ta + CH_TA);
+    return L;
+}
+
+// original (unscaled) value of front row r, column i of step h: sum of <= 2 IMU factor blocks (parked in HBM/L2 by the
+// linearisation) and the cached J0'J0 of the prior.  The loads are UNCONDITIONAL (offset 0 when a source is absent) and masked
+// afterwards: a conditional load becomes an exec-mask branch with its own s_waitcnt vmcnt(0), which serialises the loads of a
+// fetch at full memory latency (27 round trips per column owner and step instead of one).
+struct ChainSrc { const gbl_d *imu, *hp; };
+template <int NT>
+__device__ __forceinline__ void chain_entry_fetch(const Ctx<NT> &C, const ChainSrc &G, const lds_i *h, int r, int i, bool valid, double (&v)[3]) {
+    const int nsrc = h[CH_NSRC], f0 = h[CH_F0], lc0 = h[CH_LC0] + i, f1 = h[CH_F1], lc1 = h[CH_LC1] + i, pc = h[CH_PC0] + i;
+    const unsigned w0 = (unsigned)h[CH_INTS + 2 * r];
+    const int pr = h[CH_INTS + 2 * r + 1];
+    const int l0 = (w0 >> 16) & 255, l1 = w0 >> 24;
+    bool u0 = valid && nsrc > 0 && l0 != 255, u1 = valid && nsrc > 1 && l1 != 255, u2 = valid && h[CH_PC0] >= 0 && pr >= 0;
+#ifdef TCV_ABLATE
+    if (!ABL(C, AB_CH_FETCH)) u0 = u1 = u2 = false;
+#endif
+    const int pa = max(pr, pc), pb = min(pr, pc);
+    const int o0 = u0 ? f0 * IMU_BLK + max(l0, lc0) * 32 + min(l0, lc0) : 0;
+    const int o1 = u1 ? f1 * IMU_BLK + max(l1, lc1) * 32 + min(l1, lc1) : 0;
+    const int o2 = u2 ? pa * (pa + 1) / 2 + pb : 0;
+    const double x0 = G.imu[o0], x1 = G.imu[o1], x2 = G.hp[o2];
+    v[0] = u0 ? x0 : 0.0; v[1] = u1 ? x1 : 0.0; v[2] = u2 ? x2 : 0.0;
+}
+
+// T-wave: original entries of the 18 x 9 panel [E_ss; E_s+1,s] of step s, three per lane, fetched one step ahead of their use
+template <int NT>
+__device__ __forceinline__ void chain_t_fetch(const Ctx<NT> &C, const ChainSrc &G, const ChainLds &L, int s, int lane, double (&v)[3][3]) {
+    const lds_i *h = L.tab + s * CH_STRIDE;
+    const int nrow = h[CH_NEXT] ? 2 * CH_W : CH_W;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int idx = C.tid + k * NT;
-        v[k][0] = v[k][1] = v[k][2] = 0.0;
-        if (idx < (nr - 1) * CH_W) {
-            const int r = idx / CH_W, c = idx - r * CH_W;
-            const unsigned w0 = (unsigned)h[CH_INTS + 2 * r];
-            const int pr = h[CH_INTS + 2 * r + 1];
-            const int l0 = (w0 >> 16) & 255, l1 = w0 >> 24;
-            if (nsrc > 0 && l0 != 255) { const int lc = lc0 + c; v[k][0] = C.g_imublk[f0 * IMU_BLK + max(l0, lc) * 32 + min(l0, lc)]; }
-            if (nsrc > 1 && l1 != 255) { const int lc = lc1 + c; v[k][1] = C.g_imublk[f1 * IMU_BLK + max(l1, lc) * 32 + min(l1, lc)]; }
-            if (pc0 >= 0 && pr >= 0) { const int pa = max(pr, pc0 + c), pb = min(pr, pc0 + c); v[k][2] = C.g_hp[pa * (pa + 1) / 2 + pb]; }
-        }
+    for (int k = 0; k < 3; k++) {
+        const int e = min(lane + 64 * k, 2 * CH_W * CH_W - 1), r = e / CH_W;
+        chain_entry_fetch<NT>(C, G, h, r, e - r * CH_W, lane + 64 * k < nrow * CH_W, v[k]);
     }
 }
 
+// T-wave, step s: lanes 0..8 hold the rows of D_s, lanes 9..17 the rows of E_s+1,s, lanes 18..26 the rows of the identity; one panel
+// factorisation (x <- x L_ss^-T for every row x below the block) gives L_ss, L_s+1,s = E_s+1,s L_ss^-T and L_ss^-T, whose transpose
+// the W waves and the back-substitution multiply with.  Returns false (uniform within the wave) on a non-positive pivot.
+template <int NT>
+__device__ __forceinline__ bool chain_t_step(const Ctx<NT> &C, const ChainLds &L, int s, double mu, double &q, int lane, const double (&v)[3][3]) {
+    const lds_i *h = L.tab + s * CH_STRIDE;
+    const int t0 = h[CH_T0], npp = C.P->npp, has_next = h[CH_NEXT];
+    const int nrow = has_next ? 2 * CH_W : CH_W;
+    lds_d *ta = L.ta;
+    // (1) original entries, Jacobi-scaled, + mu D^2 on the diagonal (D exactly as finalize computes it); the entries of the diagonal
+    // block take the fill of the previous step, - L_s,s-1 L_s,s-1' (rows = this block, columns = the previous one), here, one 9-term
+    // product per lane out of LDS, instead of on the row-per-lane layout of the factorisation
+    const bool prev = s > 0 && (L.tab + (s - 1) * CH_STRIDE)[CH_NEXT] != 0;
+    const lds_d *N = L.ltab + (max(s, 1) - 1) * CH_LT + CH_LN;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int e = lane + 64 * k;
+        if (e < nrow * CH_W) {
+            const int r = e / CH_W, c = e - r * CH_W, tc = t0 + c;
+            const int tr = h[CH_INTS + 2 * r] & 255;
+            const double vv = (v[k][0] + v[k][1]) + v[k][2];
+            const double scc = C.sc[tc];
+            const double w = (r < CH_W) ? ((r == c) ? 1.0 : ((r > c) ? 2.0 : 0.0)) : 2.0;
+            q += w * C.ycam[tr] * C.ycam[tc] * vv;
+            double add = C.sc[tr] * scc * vv;
+            if (r == c) add += mu * fmin(fmax(scc * scc * C.hd[tc - npp], 1e-6), 1e32);
+            if (k < 2 && prev && r < CH_W) {
+                const int rr = min(r, CH_W - 1);
+                double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                for (int j = 0; j + 1 < CH_W; j += 2) { a0 += N[rr * CH_W + j] * N[c * CH_W + j]; a1 += N[rr * CH_W + j + 1] * N[c * CH_W + j + 1]; }
+                a0 += N[rr * CH_W + CH_W - 1] * N[c * CH_W + CH_W - 1];
+                add -= a0 + a1;
+            }
+            ta[e] = add;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // (2) one row per lane
+    const int r = min(lane, nrow - 1);
+    double t[CH_W];
+#pragma unroll
+    for (int c = 0; c < CH_W; c++) { const double tv = ta[r * CH_W + c]; t[c] = (lane >= 2 * CH_W) ? ((lane - 2 * CH_W == c) ? 1.0 : 0.0) : tv; }
+    // (3) panel Cholesky: pivot k lives in lane k; column k of every row is scaled, the trailing columns of every row updated
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < CH_W; k++) {
+        const double d = readlane_f64(t[k], k);
+        if (!(d > 0.0) || !(d < 1e300)) ok = false;
+        double l, y;
+        sqrt_rsqrt(ok ? d : 1.0, l, y);
+        const double lk = (lane == k) ? l : t[k] * y;
+        t[k] = lk;
+#pragma unroll
+        for (int c = k + 1; c < CH_W; c++) t[c] -= lk * readlane_f64(lk, c);
+    }
+    lds_d *out = L.ltab + s * CH_LT;
+    if (lane >= 2 * CH_W && lane < 3 * CH_W) {      // row i of L^-T = column i of L^-1
+#pragma unroll
+        for (int c = 0; c < CH_W; c++) out[c * CH_W + (lane - 2 * CH_W)] = t[c];
+    } else if (lane >= CH_W && lane < nrow) {
+#pragma unroll
+        for (int c = 0; c < CH_W; c++) out[CH_LN + (lane - CH_W) * CH_W + c] = t[c];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    return ok;
+}
+
+// W waves: original entries of B_s in the accumulator layout of a 16-column tile -- lane (row0 = lane >> 4, col = lane & 15) holds
+// rows row0, row0 + 4, row0 + 8 of column 16 J + col -- one step ahead of their use.  A pose row never lies inside the local range of
+// the Euclidean block in a factor or in the prior, so each source is base + m * stride (IMU block: stride 32 below the block's
+// columns, 1 above; prior triangle: consecutive entries of row pr above, column entries (pc + m, pr) below).
+template <int NT>
+__device__ __forceinline__ void chain_tile_fetch(const Ctx<NT> &C, const ChainSrc &G, const lds_i *h, int rc, int row0, double (&v)[3][3]) {
+    const bool valid = rc != 255;
+    const int r = min(rc, CH_MAXROWS - 1);
+    const int nsrc = h[CH_NSRC], lc0 = h[CH_LC0], lc1 = h[CH_LC1], pc = h[CH_PC0];
+    const unsigned w0 = (unsigned)h[CH_INTS + 2 * r];
+    const int pr = h[CH_INTS + 2 * r + 1];
+    const int l0 = (w0 >> 16) & 255, l1 = w0 >> 24;
+    bool u0 = valid && nsrc > 0 && l0 != 255, u1 = valid && nsrc > 1 && l1 != 255, u2 = valid && pc >= 0 && pr >= 0;
+#ifdef TCV_ABLATE
+    if (!ABL(C, AB_CH_FETCH)) u0 = u1 = u2 = false;
+#endif
+    const int b0 = u0 ? h[CH_F0] * IMU_BLK + (l0 < lc0 ? lc0 * 32 + l0 : l0 * 32 + lc0) : 0, s0 = (u0 && l0 < lc0) ? 32 : (u0 ? 1 : 0);
+    const int b1 = u1 ? h[CH_F1] * IMU_BLK + (l1 < lc1 ? lc1 * 32 + l1 : l1 * 32 + lc1) : 0, s1 = (u1 && l1 < lc1) ? 32 : (u1 ? 1 : 0);
+    const bool below = pr < pc;
+    double x0[3], x1[3], x2[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const int m = min(row0 + 4 * i, CH_W - 1), pm = pc + m;
+        const int o2 = u2 ? (below ? pm * (pm + 1) / 2 + pr : pr * (pr + 1) / 2 + pm) : 0;
+        x0[i] = G.imu[b0 + m * s0]; x1[i] = G.imu[b1 + m * s1]; x2[i] = G.hp[o2];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) { v[i][0] = u0 ? x0[i] : 0.0; v[i][1] = u1 ? x1[i] : 0.0; v[i][2] = u2 ? x2[i] : 0.0; }
+}
+
+// S -= W' W for the tile pairs (I >= J) whose tile rows hold coupled columns.  A wave runs its pairs two at a time so that the
+// operand loads, the dependent MFMA chains and the read-modify-writes of both overlap.  Everything that depends on the lane only
+// (operand rows, k < 9 masks, swizzled C offsets) is computed once per elimination (ChainMfmaLane): a trip is 12 operand loads,
+// 8 + 8 tile accesses, 6 MFMAs and a handful of address additions.
+struct ChainMfmaLane { int ko[3], co[4]; bool kin[3]; int col; };
+__device__ __forceinline__ ChainMfmaLane chain_mfma_lane(int lane, int wld) {
+    ChainMfmaLane M;
+    const int row0 = lane >> 4;
+    M.col = lane & 15;
+#pragma unroll
+    for (int kk = 0; kk < 3; kk++) { const int k = 4 * kk + row0; M.kin[kk] = k < CH_W; M.ko[kk] = min(k, CH_W - 1) * wld + M.col; }
+#pragma unroll
+    for (int i = 0; i < 4; i++) M.co[i] = sw(row0 + 4 * i, M.col);
+    return M;
+}
+__device__ __forceinline__ void chain_mfma_pair2(lds_d *tiles, const lds_d *W, const ChainMfmaLane &M, int npp, int I0, int J0, int I1, int J1, bool two) {
+    lds_d *C0 = tiles + tbase(I0, J0), *C1 = tiles + tbase(I1, J1);
+    const lds_d *WI0 = W + 16 * I0, *WJ0 = W + 16 * J0, *WI1 = W + 16 * I1, *WJ1 = W + 16 * J1;
+    const bool rhs0 = 16 * J0 + M.col == npp, rhs1 = 16 * J1 + M.col == npp;      // the rhs is a row of the tiles, never a column
+    double a0[3], b0[3], a1[3], b1[3];
+#pragma unroll
+    for (int kk = 0; kk < 3; kk++) {
+        const double ta0 = WI0[M.ko[kk]], tb0 = WJ0[M.ko[kk]], ta1 = WI1[M.ko[kk]], tb1 = WJ1[M.ko[kk]];
+        a0[kk] = M.kin[kk] ? -ta0 : 0.0;
+        b0[kk] = (M.kin[kk] && !rhs0) ? tb0 : 0.0;
+        a1[kk] = M.kin[kk] ? -ta1 : 0.0;
+        b1[kk] = (M.kin[kk] && !rhs1) ? tb1 : 0.0;
+    }
+    v4f64 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { acc0[i] = C0[M.co[i]]; acc1[i] = C1[M.co[i]]; }
+#pragma unroll
+    for (int kk = 0; kk < 3; kk++) {
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[kk], b0[kk], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], b1[kk], acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) { C0[M.co[i]] = acc0[i]; if (two) C1[M.co[i]] = acc1[i]; }
+}
+// pairs first, first + stride, ... of the step's pair list: pair p = (a, b), a >= b, over the ascending list of active tile rows
+template <int NT>
+__device__ __forceinline__ void chain_mfma_update(const Ctx<NT> &C, const lds_d *W, const ChainMfmaLane &M, int tmask, int npp, int first, int stride) {
+    int act = 0, na = 0;      // 4 bits per entry
+    for (int I = 0; I < C.ntd; I++) if ((tmask >> I) & 1) { act |= I << (4 * na); na++; }
+    const int npair = na * (na + 1) / 2;
+    // walk (a, b) along with p instead of inverting the triangular number
+    int a = 0, b = 0, p = 0, pI = -1, pJ = -1;
+    for (int want = first; want < npair; want += stride) {
+        while (p < want) { p++; if (b == a) { a++; b = 0; } else b++; }
+        const int I = (act >> (4 * a)) & 15, J = (act >> (4 * b)) & 15;
+        if (pI < 0) { pI = I; pJ = J; }
+        else { chain_mfma_pair2(C.tiles, W, M, npp, pI, pJ, I, J, true); pI = -1; }
+    }
+    if (pI >= 0) chain_mfma_pair2(C.tiles, W, M, npp, pI, pJ, pI, pJ, false);
+}
+
+#ifdef TCV_PROFILE
+#define CH_TIC() const long long t_role = clock64()
+#define CH_TOC(slot, cond) do { if (cond) ((lds_u *)(C.red + 40))[slot] += (unsigned)(clock64() - t_role); } while (0)
+#else
+#define CH_TIC() do { } while (0)
+#define CH_TOC(slot, cond) do { } while (0)
+#endif
 template <int NT>
 __device__ __noinline__ bool chain_forward(Ctx<NT> &C, double mu, double &q_out) {
+    static_assert(NT >= 256, "chain layout: four wavefronts (column owners on waves 0-1, matrix cores on 0-2, T pipeline on 3)");
     cst_plan &P = *C.P;
-    const int tid = C.tid, lane = tid & 63, wave = tid >> 6, npp = P.npp;
-    constexpr int NW = NT / 64;
-    lds_d *pool = C.stage;
-    lds_d *invd = pool + 2 * CH_FSZ;
-    lds_i *tab = (lds_i *)(pool + CH_TAB_OFF);
+    const int tid = C.tid, lane = tid & 63, wave = tid >> 6, npp = P.npp, ne = P.n_e;
+    const ChainLds L = chain_lds<NT>(C);
+    const int wld = L.wld;
+    const ChainSrc G = {C.g_imublk, C.g_hp};
+    const ChainMfmaLane ML = chain_mfma_lane(lane, wld);
     double q = 0.0;
-    copy_prog<NT>(tab, C.ip + P.o_chain, P.n_e * CH_STRIDE, tid);
-    for (int i = tid; i < CH_FSZ; i += NT) pool[i] = 0.0;
+    copy_prog<NT>(L.tab, C.ip + P.o_chain, ne * CH_STRIDE, tid);
+    for (int i = tid; i < 2 * CH_W * wld; i += NT) L.wbuf[i] = 0.0;
+    if (tid == 0) *C.flag = 0;
     __syncthreads();
-    double v[4][3];
-    chain_fetch<NT>(C, tab, v);
-    for (int s = 0; s < P.n_e; s++) {
-        const lds_i *h = tab + s * CH_STRIDE;
-        const int t0 = h[CH_T0], nr = CH_W + h[CH_R] + 1, has_next = h[CH_NEXT];
-        lds_d *F = pool + (s & 1) * CH_FSZ, *Fn = pool + ((s + 1) & 1) * CH_FSZ;
-        gbl_d *sp = C.g_spill + h[CH_SPILL];
-        // (A) assemble: original entries, Jacobi-scaled, + mu D^2, on top of the fill left by the previous step
+    // W-wave state: wave w < 2 owns the 16-column tiles w, w + 2, w + 4 of W; per tile the previous W rows (accumulator layout: lane
+    // (row0, col) holds rows row0 + 4 i of column 16 J + col) and the prefetched entries of the next B rows
+    constexpr int WT = 3;
+    const int row0 = lane >> 4, col = lane & 15;
+    double wp[WT][4], vb[WT][3][3];
+    int rcs[WT];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int idx = tid + k * NT;
-            if (idx < nr * CH_W) {
-                const int r = idx / CH_W, c = idx - r * CH_W, tc = t0 + c;
-                const int tr = h[CH_INTS + 2 * r] & 255;
-                const double scc = C.sc[tc];
-                double add;
-                if (tr == 255) add = scc * C.gcam[tc];
-                else {
-                    const double vv = (v[k][0] + v[k][1]) + v[k][2];
-                    const double w = (r < CH_W) ? ((r == c) ? 1.0 : ((r > c) ? 2.0 : 0.0)) : 2.0;
-                    q += w * C.ycam[tr] * C.ycam[tc] * vv;
-                    add = C.sc[tr] * scc * vv;
-                    if (r == c) add += mu * fmin(fmax(scc * scc * C.hd[tc - npp], 1e-6), 1e32);      // mu D^2, D exactly as finalize computes it
-                }
-                F[idx] += add;
-            }
+    for (int jt = 0; jt < WT; jt++) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) wp[jt][i] = 0.0;
+        rcs[jt] = 255;
+        if (wave < 2) {
+            const int cc = 16 * (wave + 2 * jt) + col;
+            if (wave + 2 * jt < C.ntd && cc <= npp) rcs[jt] = ((const __attribute__((address_space(3))) unsigned char *)(L.tab + CH_COLROW))[cc];
+            chain_tile_fetch<NT>(C, G, L.tab, rcs[jt], row0, vb[jt]);
         }
-        for (int i = tid; i < CH_FSZ; i += NT) Fn[i] = 0.0;
-        __syncthreads();
-        TCV_MARK(C, PH_CH_A);
-        if (s + 1 < P.n_e) chain_fetch<NT>(C, h + CH_STRIDE, v);      // next step's entries: in flight during (B)-(D)
-        // (B) Cholesky of the 9 x 9 diagonal block: every thread factors it redundantly in registers (no cross-lane traffic, no
-        // barrier before the row solves); (C) row solves X L' = F[rows], one row per thread; the factored front is spilled
-        {
-            double Ld[CH_W * (CH_W + 1) / 2], inv[CH_W];
+    }
+    double vt[3][3], vtn[3][3];      // T-wave: the panel entries of the step being factored / of the one after it
+    if (wave == 3) {
+        chain_t_fetch<NT>(C, G, L, 0, lane, vt);
+        if (ne > 1) chain_t_fetch<NT>(C, G, L, 1, lane, vtn);
+        if (!chain_t_step<NT>(C, L, 0, mu, q, lane, vt) && lane == 0) *C.flag = 1;
+    }
+    __syncthreads();
+    for (int s = 0; s <= ne; s++) {
+        if (*C.flag) return false;      // uniform: read after a barrier, written before it
+        // ---- T pipeline: one step ahead
+        CH_TIC();
+        if (wave == 3 && s + 1 < ne && ABL(C, AB_CH_T)) {
 #pragma unroll
-            for (int r = 0; r < CH_W; r++)
-#pragma unroll
-                for (int c = 0; c <= r; c++) Ld[r * (r + 1) / 2 + c] = F[r * CH_W + c];
-            bool ok = true;
-#pragma unroll
-            for (int k = 0; k < CH_W; k++) {
-                const double d = Ld[k * (k + 1) / 2 + k];
-                if (!(d > 0.0) || !(d < 1e300)) ok = false;
-                double l, y;
-                sqrt_rsqrt(ok ? d : 1.0, l, y);
-                Ld[k * (k + 1) / 2 + k] = l; inv[k] = y;
-#pragma unroll
-                for (int r = k + 1; r < CH_W; r++) Ld[r * (r + 1) / 2 + k] *= y;
-#pragma unroll
-                for (int r = k + 1; r < CH_W; r++)
-#pragma unroll
-                    for (int c = k + 1; c <= r; c++) Ld[r * (r + 1) / 2 + c] -= Ld[r * (r + 1) / 2 + k] * Ld[c * (c + 1) / 2 + k];
-            }
-#ifdef TCV_ABLATE
-            if (ABL_FORCE(C)) ok = true;
-#endif
-            if (!ok) return false;      // uniform: every thread factored the same block
-            for (int r = CH_W + tid; r < nr; r += NT) {
-                double x[CH_W];
-#pragma unroll
-                for (int c = 0; c < CH_W; c++) x[c] = F[r * CH_W + c];
-#pragma unroll
-                for (int c = 0; c < CH_W; c++) {
-                    double a = x[c];
-#pragma unroll
-                    for (int c1 = 0; c1 < c; c1++) a -= x[c1] * Ld[c * (c + 1) / 2 + c1];
-                    x[c] = a * inv[c];
-                }
-#pragma unroll
-                for (int c = 0; c < CH_W; c++) F[r * CH_W + c] = x[c];
-            }
-            if (tid == NT - 1) {      // an otherwise idle thread publishes L_ee and 1/diag for the back-substitution
-#pragma unroll
-                for (int r = 0; r < CH_W; r++)
-#pragma unroll
-                    for (int c = 0; c <= r; c++) sp[r * CH_W + c] = Ld[r * (r + 1) / 2 + c];
-#pragma unroll
-                for (int c = 0; c < CH_W; c++) sp[nr * CH_W + c] = inv[c];
-            }
+            for (int k = 0; k < 3; k++) { vt[k][0] = vtn[k][0]; vt[k][1] = vtn[k][1]; vt[k][2] = vtn[k][2]; }
+            if (s + 2 < ne) chain_t_fetch<NT>(C, G, L, s + 2, lane, vtn);
+            if (!chain_t_step<NT>(C, L, s + 1, mu, q, lane, vt) && lane == 0) *C.flag = 1;
+            CH_TOC(PH_CH_A, tid == 192);
         }
-        __syncthreads();
-        TCV_MARK(C, PH_CH_C);
-        // the solved rows go to the spill area in one coalesced sweep (row-wise stores from the solving threads would touch
-        // every 64-byte granule nine times)
-        for (int i = CH_W * CH_W + tid; i < nr * CH_W; i += NT) sp[i] = F[i];
-        // (D) rank-9 update of everything below: -X X' on the matrix cores, 16 x 16 output tiles over the sub-rows, two tiles
-        // per trip so that their operand loads, MFMA chains and read-modify-writes overlap
-        {
-            const int m = nr - CH_W, mt = (m + 15) >> 4, npair = mt * (mt + 1) / 2;
-            const int i16 = lane & 15, k4 = lane >> 4;
-            for (int p0 = 2 * wave; p0 < npair; p0 += 2 * NW) {
-                int II[2], JJ[2];
+        // ---- W waves: W_s = L_ss^-1 (B_s - L_s,s-1 W_s-1), a 16-column tile at a time on the matrix cores.  The output layout of
+        // v_mfma_f64_16x16x4 (lane holds rows row0 + 4 i of column col) IS its B-operand layout (rows 4 kk + row0), so W_s-1 and the
+        // intermediate product feed the next MFMA straight from the accumulator registers.
+        if (s < ne && wave < 2 && ABL(C, AB_CH_W)) {
+            const lds_i *h = L.tab + s * CH_STRIDE;
+            const int t0 = h[CH_T0], tmask = h[CH_TMASK];
+            const bool prev = s > 0 && (h - CH_STRIDE)[CH_NEXT] != 0;
+            const lds_d *Li = L.ltab + s * CH_LT, *Np = L.ltab + (max(s, 1) - 1) * CH_LT + CH_LN;
+            double aL[3], aN[3];      // A operands: lane holds A[m = col][k = 4 kk + row0]
 #pragma unroll
-                for (int u = 0; u < 2; u++) {      // pair index -> (I, J), J <= I
-                    const int pq = min(p0 + u, npair - 1);
-                    int I = (int)((sqrtf(8.0f * (float)pq + 1.0f) - 1.0f) * 0.5f);
-                    while ((I + 1) * (I + 2) / 2 <= pq) I++;
-                    while (I * (I + 1) / 2 > pq) I--;
-                    II[u] = I; JJ[u] = pq - I * (I + 1) / 2;
-                }
-                const bool two = p0 + 1 < npair;
-                double av[2][3], bv[2][3];
-                int dst[2][4];
-#pragma unroll
-                for (int u = 0; u < 2; u++) {
-                    const int ra = CH_W + 16 * II[u] + i16, rb = CH_W + 16 * JJ[u] + i16;
-#pragma unroll
-                    for (int kk = 0; kk < 3; kk++) {
-                        const int k = 4 * kk + k4;
-                        const double ta = F[min(ra, nr - 1) * CH_W + min(k, CH_W - 1)], tb = F[min(rb, nr - 1) * CH_W + min(k, CH_W - 1)];
-                        av[u][kk] = (ra < nr && k < CH_W) ? -ta : 0.0;
-                        bv[u][kk] = (rb < nr && k < CH_W) ? tb : 0.0;
-                    }
-                    const int R2 = rb;
-                    const int t2 = h[CH_INTS + 2 * min(R2, nr - 1)] & 255;
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const int R1 = CH_W + 16 * II[u] + k4 + 4 * i;
-                        dst[u][i] = -1;
-                        if ((u == 0 || two) && R1 < nr && R2 < nr - 1 && R1 >= R2) {      // lower triangle; the rhs row is never a column
-                            const unsigned w1 = (unsigned)h[CH_INTS + 2 * R1];
-                            if (has_next && R2 < 2 * CH_W) dst[u][i] = -2 - (int)(((w1 >> 8) & 255) * CH_W + (R2 - CH_W));
-                            else dst[u][i] = tix((R1 == nr - 1) ? npp : (int)(w1 & 255), t2);
-                        }
-                    }
-                }
-                v4f64 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int kk = 0; kk < 3; kk++) {
-                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0][kk], bv[0][kk], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1][kk], bv[1][kk], acc1, 0, 0, 0);
-                }
-                double old[2][4];
-#pragma unroll
-                for (int u = 0; u < 2; u++)
-#pragma unroll
-                    for (int i = 0; i < 4; i++) old[u][i] = C.tiles[max(dst[u][i], 0)];
-#pragma unroll
-                for (int u = 0; u < 2; u++)
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const double a = u == 0 ? acc0[i] : acc1[i];
-                        if (dst[u][i] >= 0) C.tiles[dst[u][i]] = old[u][i] + a;
-                        else if (dst[u][i] <= -2) Fn[-2 - dst[u][i]] = a;
-                    }
+            for (int kk = 0; kk < 3; kk++) {
+                const int k = 4 * kk + row0, o = min(col, CH_W - 1) * CH_W + min(k, CH_W - 1);
+                const double tl = Li[o], tn = Np[o];
+                const bool in = col < CH_W && k < CH_W;
+                aL[kk] = in ? tl : 0.0;
+                aN[kk] = (in && prev) ? -tn : 0.0;
             }
+            double scm[3], um[3], gm[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) { const int m = min(row0 + 4 * i, CH_W - 1); scm[i] = C.sc[t0 + m]; um[i] = C.ycam[t0 + m]; gm[i] = C.gcam[t0 + m]; }
+            lds_d *Wb = L.wbuf + (s & 1) * CH_W * wld;
+#pragma unroll
+            for (int jt = 0; jt < WT; jt++) {
+                const int J = wave + 2 * jt;
+                if (J >= C.ntd) continue;
+                const int cc = 16 * J + col;
+                if ((tmask >> J) & 1) {      // else: no coupled column in this tile yet, W stays zero
+                    const bool act = rcs[jt] != 255, rhs = cc == npp;
+                    const double scc = (act && !rhs) ? C.sc[min(cc, 175)] : 0.0, uc = (act && !rhs) ? C.ycam[min(cc, 175)] : 0.0;
+                    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int i = 0; i < 3; i++) {      // branch-free: selects only (rows 9..11 of the accumulator stay zero)
+                        const bool in = act && row0 + 4 * i < CH_W;
+                        const double vv = (vb[jt][i][0] + vb[jt][i][1]) + vb[jt][i][2];
+                        q += in ? 2.0 * uc * um[i] * vv : 0.0;
+                        const double bv = rhs ? scm[i] * gm[i] : scc * scm[i] * vv;
+                        acc[i] = in ? bv : 0.0;
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < 3; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aN[kk], wp[jt][kk], acc, 0, 0, 0);      // aN = 0 without a previous step
+                    v4f64 w4 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int kk = 0; kk < 3; kk++) w4 = __builtin_amdgcn_mfma_f64_16x16x4f64(aL[kk], acc[kk], w4, 0, 0, 0);
+                    // rows row0, row0 + 4 always exist; row0 + 8 only for row0 = 0.  The spill area holds 16 ntd columns per step.
+                    gbl_d *sp = C.g_spill + h[CH_SPILL] + cc * CH_W + row0;
+                    lds_d *wo = Wb + row0 * wld + cc;
+                    wo[0] = w4[0]; wo[4 * wld] = w4[1]; sp[0] = w4[0]; sp[4] = w4[1];
+                    if (row0 == 0) { wo[8 * wld] = w4[2]; sp[8] = w4[2]; }
+#pragma unroll
+                    for (int i = 0; i < 4; i++) wp[jt][i] = w4[i];
+                }
+                if (s + 1 < ne) {      // the next step's entries, whether or not the tile is active yet
+                    rcs[jt] = cc <= npp ? ((const __attribute__((address_space(3))) unsigned char *)(h + CH_STRIDE + CH_COLROW))[cc] : 255;
+                    chain_tile_fetch<NT>(C, G, h + CH_STRIDE, rcs[jt], row0, vb[jt]);
+                }
+            }
+            CH_TOC(PH_CH_B, tid == 0);
+        }
+        // ---- matrix cores: S -= W_s-1' W_s-1
+        if (s > 0 && wave <= 2 && ABL(C, AB_CH_MFMA)) {
+            // wave 2 (no other duty) takes two of every three pairs, wave 1 (nine columns to own) the third; wave 0 owns 64 columns
+            const lds_i *hp = L.tab + (s - 1) * CH_STRIDE;
+            const lds_d *Wp = L.wbuf + ((s - 1) & 1) * CH_W * wld;
+            if (wave == 2) { chain_mfma_update<NT>(C, Wp, ML, hp[CH_TMASK], npp, 0, 3); chain_mfma_update<NT>(C, Wp, ML, hp[CH_TMASK], npp, 1, 3); }
+            else if (wave == 1) chain_mfma_update<NT>(C, Wp, ML, hp[CH_TMASK], npp, 2, 3);
+            CH_TOC(PH_CH_C, tid == 128);
         }
         __syncthreads();
-        TCV_MARK(C, PH_CH_D);
+        CH_TOC(PH_CH_D, tid == 64);      // the whole interval as wave 1 sees it
     }
     q_out = block_sum<NT>(q, C.red, tid);
     __syncthreads();
     return true;
 }
 
-// back-substitution through the chain by ONE wavefront: y_e = L_ee^-T (z_e - sum_rows X[row]' y_row), blocks in reverse
-// elimination order; the rows' solutions (pose part, later blocks) are already in ycam.  The step records are still in LDS
-// (nothing touches the pool between chain_forward and here); every step's loads are issued one step ahead.
-struct ChainCol { double x0[CH_W], x1[CH_W], m0, m1; };
+// back-substitution through the chain: y_s = L_ss^-T (z_s - W_s y_p - L_s+1,s' y_s+1), blocks in reverse elimination order; y_p
+// (poses) is in ycam, z_s is column npp of W_s.  chain_products (all threads): the W_s y_p products of every step at once, two
+// threads per row, W streamed from the spill area with every load in flight together.  chain_backward (ONE wavefront, the other
+// waves back-substitute the landmarks meanwhile): the serial recursion, one lane per row of the block, L_ss^-1 and L_s+1,s still in LDS.
 template <int NT>
-__device__ __forceinline__ void chain_col_fetch(const Ctx<NT> &C, const lds_i *h, int lane, ChainCol &o) {
-    const int nr = CH_W + h[CH_R] + 1;
-    const gbl_d *sp = C.g_spill + h[CH_SPILL];
-    const int r0 = CH_W + lane, r1 = CH_W + lane + 64;
-#pragma unroll
-    for (int c = 0; c < CH_W; c++) {
-        o.x0[c] = (r0 < nr - 1) ? sp[min(r0, nr - 1) * CH_W + c] : 0.0;
-        o.x1[c] = (r1 < nr - 1) ? sp[min(r1, nr - 1) * CH_W + c] : 0.0;
+__device__ __forceinline__ void chain_products(Ctx<NT> &C) {
+    cst_plan &P = *C.P;
+    const int npp = P.npp, ne = P.n_e;
+    const ChainLds L = chain_lds<NT>(C);
+    lds_d *pp = L.wbuf;           // partial products, 2 per row (the W buffers are dead)
+    for (int idx = C.tid; idx < 2 * ne * CH_W; idx += NT) {
+        const int e = idx >> 1, part = idx & 1, s = e / CH_W, i = e - s * CH_W;
+        const gbl_d *sp = C.g_spill + (L.tab + s * CH_STRIDE)[CH_SPILL] + i;
+        const int tm = (L.tab + s * CH_STRIDE)[CH_TMASK];      // tiles without a coupled column were never written: their W is zero
+        double a0 = 0.0, a1 = 0.0;
+        int cc = part;
+#pragma unroll 8
+        for (; cc + 2 < npp; cc += 4) {
+            const double w0 = sp[cc * CH_W], w1 = sp[(cc + 2) * CH_W];
+            a0 += (((tm >> (cc >> 4)) & 1) ? w0 : 0.0) * C.ycam[cc]; a1 += (((tm >> ((cc + 2) >> 4)) & 1) ? w1 : 0.0) * C.ycam[cc + 2];
+        }
+        for (; cc < npp; cc += 2) { const double w0 = sp[cc * CH_W]; a0 += (((tm >> (cc >> 4)) & 1) ? w0 : 0.0) * C.ycam[cc]; }
+        pp[idx] = (part == 0 ? sp[npp * CH_W] : 0.0) - (a0 + a1);
     }
-    // mailbox slots 0..80: L_ee (row-major 9 x 9); 81..89: the rhs row z; 90..98: 1/diag -- two slots per lane
-    const int i1 = 64 + lane;
-    o.m0 = sp[lane];
-    o.m1 = (i1 < 81) ? sp[min(i1, 80)] : ((i1 < 90) ? sp[(nr - 1) * CH_W + min(max(i1 - 81, 0), 8)] : ((i1 < 99) ? sp[nr * CH_W + min(max(i1 - 90, 0), 8)] : 0.0));
+    __syncthreads();
 }
 template <int NT>
 __device__ __noinline__ bool chain_backward(Ctx<NT> &C) {
     cst_plan &P = *C.P;
-    const int lane = C.tid & 63;
-    lds_d *pool = C.stage;
-    const lds_i *tab = (const lds_i *)(pool + CH_TAB_OFF);
-    lds_d *mb = pool;            // 128 doubles of mailbox for L_ee / z / 1/diag (the fronts are dead)
+    const int lane = C.tid & 63, ne = P.n_e;
+    const ChainLds L = chain_lds<NT>(C);
+    const lds_d *pp = L.wbuf;
     bool bad = false;
-    ChainCol cur, nxt;
-    chain_col_fetch<NT>(C, tab + (P.n_e - 1) * CH_STRIDE, lane, cur);
-    for (int s = P.n_e - 1; s >= 0; s--) {
-        const lds_i *h = tab + s * CH_STRIDE;
-        const int t0 = h[CH_T0], nr = CH_W + h[CH_R] + 1;
-        if (s > 0) chain_col_fetch<NT>(C, h - CH_STRIDE, lane, nxt);
-        const int r0 = CH_W + lane, r1 = CH_W + lane + 64;
-        const double y0 = (r0 < nr - 1) ? C.ycam[h[CH_INTS + 2 * min(r0, nr - 1)] & 255] : 0.0;
-        const double y1 = (r1 < nr - 1) ? C.ycam[h[CH_INTS + 2 * min(r1, nr - 1)] & 255] : 0.0;
-        // column sums over the rows through LDS (a shuffle tree on 9 doubles costs 108 ds_bpermutes): lane l adds 16 of the 64
-        // per-lane partial products of column l & 15, two xor-shuffles finish the job
-        lds_d *pp = pool + 128;
+    const int i = min(lane, CH_W - 1);
+    double ynext = 0.0;      // lane j: y_s+1[j]
+    for (int s = ne - 1; s >= 0; s--) {
+        const lds_i *h = L.tab + s * CH_STRIDE;
+        const lds_d *Ls = L.ltab + s * CH_LT;
+        // column i of L_ss^-1 and of L_s+1,s, up front
+        double lc[CH_W], nc[CH_W];
 #pragma unroll
-        for (int c = 0; c < CH_W; c++) pp[c * 64 + lane] = cur.x0[c] * y0 + cur.x1[c] * y1;
-        mb[lane] = cur.m0;
-        mb[64 + lane] = cur.m1;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        {
-            const int c = min(lane & 15, CH_W - 1), g = lane >> 4;
-            double t = 0.0;
+        for (int k = 0; k < CH_W; k++) { lc[k] = Ls[k * CH_W + i]; nc[k] = Ls[CH_LN + k * CH_W + i]; }
+        double r = pp[2 * (s * CH_W + i)] + pp[2 * (s * CH_W + i) + 1];
+        if (h[CH_NEXT]) {      // - L_s+1,s' y_s+1
 #pragma unroll
-            for (int j = 0; j < 16; j++) t += pp[c * 64 + g * 16 + j];
-            t += __shfl_xor(t, 16);
-            t += __shfl_xor(t, 32);
-            if (lane < CH_W) mb[100 + lane] = t;
+            for (int j = 0; j < CH_W; j++) r -= nc[j] * readlane_f64(ynext, j);
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (lane == 0) {
-            double y[CH_W];
+        double y0 = 0.0, y1 = 0.0;      // y = L_ss^-T r
 #pragma unroll
-            for (int c = CH_W - 1; c >= 0; c--) {
-                double a = mb[81 + c] - mb[100 + c];
-#pragma unroll
-                for (int c2 = c + 1; c2 < CH_W; c2++) a -= mb[c2 * CH_W + c] * y[c2];
-                y[c] = a * mb[90 + c];
-            }
-#pragma unroll
-            for (int c = 0; c < CH_W; c++) {
-                C.ycam[t0 + c] = y[c];
-                C.v_y[t0 + c] = y[c];
-                if (!(fabs(y[c]) < 1e300)) bad = true;
-            }
+        for (int k = 0; k + 1 < CH_W; k += 2) { y0 += lc[k] * readlane_f64(r, k); y1 += lc[k + 1] * readlane_f64(r, k + 1); }
+        y0 += lc[CH_W - 1] * readlane_f64(r, CH_W - 1);
+        const double y = y0 + y1;
+        if (lane < CH_W) {
+            C.ycam[h[CH_T0] + lane] = y;
+            C.v_y[h[CH_T0] + lane] = y;
+            if (!(fabs(y) < 1e300)) bad = true;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        cur = nxt;
+        ynext = y;
     }
-    return !bad;
+    return __ballot(bad) == 0ull;
 }
 
 // ---- scale, regularise, factorise and solve (J'J + mu D^2) y = J'r ---------------------------------
@@ -1377,6 +1510,7 @@ __device__ __noinline__ bool finalize_and_solve(Ctx<NT> &C, bool first, double m
     }
     // chain mode: wave 0 walks the chain backwards (Euclidean blocks in reverse elimination order) while the other
     // waves back-substitute the landmarks, which only meet pose-kind blocks
+    if (CHAIN && ABL(C, AB_CHAIN_BWD) && ABL(C, AB_CHAIN_FWD)) chain_products<NT>(C);
     const int l_first = CHAIN ? tid - 64 : tid, l_step = CHAIN ? NT - 64 : NT;
     if (CHAIN && tid < 64 && ABL(C, AB_CHAIN_BWD) && ABL(C, AB_CHAIN_FWD)) { if (!chain_backward<NT>(C)) bad = true; }
     if ((!CHAIN || tid >= 64) && ABL(C, AB_LM_BACK)) {

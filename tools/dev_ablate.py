@@ -12,7 +12,7 @@ import synth, tcv, bench
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 names = ["vis_eval", "vis_gather", "lm", "schur", "prior_A", "imu_raw", "imu_whiten", "imu_gather", "prior_B", "fin_scale", "fin_pass", "chain_fwd", "chol",
-         "back", "chain_bwd", "lm_back", "dogleg", "plus", "norms", "setup", "copy_prog"]
+         "back", "chain_bwd", "lm_back", "dogleg", "plus", "norms", "setup", "ch_T", "ch_owners", "ch_mfma", "ch_fetch"]
 batch, wins, keep = bench.build_batches(tcv, synth, 100000, B)
 opts = tcv.default_options(8, True)
 
@@ -28,14 +28,16 @@ def run(mask, reps=6):
 base = run(0)
 print("B = %d, all phases (every step accepted): %.3f ms" % (B, base), flush=True)
 tot = 0.0
-for b, nm in enumerate(names[:19]):
+for b, nm in enumerate(names):
+    if nm == 'setup':
+        continue
     t = run(1 << b)
     tot += base - t
     print("  without %-11s %.3f ms   -> phase costs %6.3f ms  (%4.1f %%)" % (nm, t, base - t, 100 * (base - t) / base), flush=True)
 print("  sum of the single-phase costs %.3f ms of %.3f" % (tot, base))
 groups = {"visual (eval+gather+lm+schur)": 0b1111, "imu (raw+whiten+gather)": 0b11100000, "prior (A+B)": (1 << 4) | (1 << 8), "linearise (all factor families)": 0b111111111,
           "solve (scale+pass+chain+chol+back+bwd+lm_back)": sum(1 << k for k in range(9, 16)), "chain (fwd+bwd)": (1 << 11) | (1 << 14),
-          "everything": (1 << 19) - 1}
+          "chain pipelines (T + owners + mfma)": (1 << 20) | (1 << 21) | (1 << 22), "everything": (1 << 19) - 1}
 for nm, m in groups.items():
     t = run(m)
     print("  without %-45s %.3f ms  -> %.3f ms (%4.1f %%)" % (nm, t, base - t, 100 * (base - t) / base), flush=True)
