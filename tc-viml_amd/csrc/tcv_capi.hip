@@ -10,6 +10,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <chrono>
 #include <thread>
@@ -34,6 +35,63 @@ int hip_fail(hipError_t e, const char *what) {
         hipError_t e_ = (x);                              \
         if (e_ != hipSuccess) return hip_fail(e_, #x);    \
     } while (0)
+
+// ---- device memory free list -------------------------------------------------------------------------------------------------
+namespace {
+struct DevPool {
+    std::mutex mu;
+    std::multimap<std::pair<int, size_t>, void *> free_list;      // (device, bucket bytes) -> buffer
+    std::map<void *, std::pair<int, size_t>> live;               // buffer -> (device, bucket bytes)
+    size_t cached = 0;
+};
+DevPool &pool() { static DevPool *p = new DevPool(); return *p; }      // leaked on purpose: no hipFree at process exit after the runtime is gone
+size_t bucket_of(size_t n) {
+    if (n <= 256) return 256;
+    if (n > (size_t(2) << 20)) return (n + (size_t(2) << 20) - 1) & ~((size_t(2) << 20) - 1);      // 2 MiB granules above 2 MiB
+    size_t b = 256;
+    while (b < n) b <<= 1;
+    return b;
+}
+constexpr size_t POOL_MAX_CACHED = size_t(3) << 30;
+}  // namespace
+hipError_t dev_malloc(void **p, size_t bytes) {
+    static const bool off = getenv("TCV_NO_DEV_POOL") != nullptr;
+    if (off) return ::hipMalloc(p, bytes);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const size_t b = bucket_of(bytes);
+    DevPool &P = pool();
+    {
+        std::lock_guard<std::mutex> g(P.mu);
+        auto it = P.free_list.find({dev, b});
+        if (it != P.free_list.end()) { *p = it->second; P.free_list.erase(it); P.cached -= b; P.live[*p] = {dev, b}; return hipSuccess; }
+    }
+    hipError_t e = ::hipMalloc(p, b);
+    if (e != hipSuccess) {      // out of memory: give the cached buffers back and retry once
+        std::vector<void *> drop;
+        { std::lock_guard<std::mutex> g(P.mu); for (auto &kv : P.free_list) drop.push_back(kv.second); P.free_list.clear(); P.cached = 0; }
+        for (void *q : drop) (void)::hipFree(q);
+        e = ::hipMalloc(p, b);
+        if (e != hipSuccess) return e;
+    }
+    std::lock_guard<std::mutex> g(P.mu);
+    P.live[*p] = {dev, b};
+    return hipSuccess;
+}
+hipError_t dev_free(void *p) {
+    if (!p) return hipSuccess;
+    DevPool &P = pool();
+    {
+        std::lock_guard<std::mutex> g(P.mu);
+        auto it = P.live.find(p);
+        if (it != P.live.end()) {
+            const auto key = it->second;
+            P.live.erase(it);
+            if (P.cached + key.second <= POOL_MAX_CACHED) { P.free_list.insert({key, p}); P.cached += key.second; return hipSuccess; }
+        }
+    }
+    return ::hipFree(p);
+}
 
 int device_ready() {
     int n = 0;
@@ -378,9 +436,10 @@ extern "C" void tcv_prior_destroy(tcv_prior *pr) { delete pr; }
 // =====================================================================================================
 static void batch_free(tcv_batch *b) {
     if (!b) return;
-    hipFree(b->d_win); hipFree(b->d_plans); hipFree(b->d_plan_base); hipFree(b->d_ipool); hipFree(b->d_dpool);
-    hipFree(b->d_imublk); hipFree(b->d_spill);
-    hipFree(b->d_prof); hipFree(b->d_state); hipFree(b->d_delta); hipFree(b->d_scratch); hipFree(b->d_summary);
+    if (b->pending) { if (b->last_stream) (void)hipStreamSynchronize(b->last_stream); else (void)hipDeviceSynchronize(); }      // the buffers go back to the free list
+    tcv::dev_free(b->d_win); tcv::dev_free(b->d_plans); tcv::dev_free(b->d_plan_base); tcv::dev_free(b->d_ipool); tcv::dev_free(b->d_dpool);
+    tcv::dev_free(b->d_imublk); tcv::dev_free(b->d_spill);
+    tcv::dev_free(b->d_prof); tcv::dev_free(b->d_state); tcv::dev_free(b->d_delta); tcv::dev_free(b->d_scratch); tcv::dev_free(b->d_summary);
     if (b->ev0) hipEventDestroy(b->ev0);
     if (b->ev1) hipEventDestroy(b->ev1);
     if (b->marg_free) b->marg_free(b);
@@ -495,7 +554,7 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
     const int scr = tcv_solve_scratch_doubles() + b->hcl_cap;
 #define UP(dst, src, T, cnt)                                                                          \
     do {                                                                                              \
-        hipError_t e_ = hipMalloc((void **)&dst, sizeof(T) * std::max<size_t>(1, (cnt)));             \
+        hipError_t e_ = tcv::dev_malloc((void **)&dst, sizeof(T) * std::max<size_t>(1, (cnt)));             \
         if (e_ != hipSuccess) { batch_free(b); return hip_fail(e_, "hipMalloc"); }                    \
         if (src) {                                                                                    \
             e_ = hipMemcpy(dst, src, sizeof(T) * (cnt), hipMemcpyHostToDevice);                       \
@@ -572,7 +631,7 @@ extern "C" int tcv_batch_solve(tcv_batch *b, const tcv_solver_options *o, void *
         if (a.max_ticks < 1) a.max_ticks = 1;
     }
     hipStream_t st = (hipStream_t)hip_stream;
-    b->last_stream = st;
+    b->last_stream = st; b->pending = true;
     HIPCHK(hipEventRecord(b->ev0, st));
     const int rc = tcv_launch_solve(&a, b->grid, (!b->chain && o->threads_per_window == 512) ? 512 : 256, b->lds_bytes, hip_stream);
     if (rc != 0) return hip_fail((hipError_t)rc, "solve kernel launch");
@@ -582,7 +641,7 @@ extern "C" int tcv_batch_solve(tcv_batch *b, const tcv_solver_options *o, void *
 }
 extern "C" int tcv_batch_marginalize(tcv_batch *b, void *hip_stream) {
     if (!b) return TCV_ERR_INVALID;
-    b->last_stream = (hipStream_t)hip_stream;
+    b->last_stream = (hipStream_t)hip_stream; b->pending = true;
     return tcv_marg_run(b, hip_stream);
 }
 // waits for the stream of the last asynchronous call on this batch (the whole device when that was the default stream), so that
@@ -591,6 +650,7 @@ extern "C" int tcv_batch_synchronize(tcv_batch *b) {
     if (!b) return TCV_ERR_INVALID;
     if (b->last_stream) HIPCHK(hipStreamSynchronize(b->last_stream));
     else HIPCHK(hipDeviceSynchronize());
+    b->pending = false;
     if (b->solved) hipEventElapsedTime(&b->solve_ms, b->ev0, b->ev1);
     tcv_marg_elapsed(b);
     return TCV_OK;
@@ -804,8 +864,8 @@ __global__ void pose_plus_kernel(int n, const double *x, const double *d, double
 
 struct DevBuf {
     void *p = nullptr;
-    ~DevBuf() { if (p) hipFree(p); }
-    int alloc(size_t bytes) { return hipMalloc(&p, std::max<size_t>(bytes, 8)) == hipSuccess ? 0 : -1; }
+    ~DevBuf() { if (p) tcv::dev_free(p); }
+    int alloc(size_t bytes) { return tcv::dev_malloc(&p, std::max<size_t>(bytes, 8)) == hipSuccess ? 0 : -1; }
     template <class T> T *as() { return (T *)p; }
 };
 }  // namespace tcv

@@ -132,7 +132,7 @@ extern "C" int tcv_gauge_fix(int n, const double *R0, const double *P0, const do
     std::memcpy(h.data(), R0, 72); std::memcpy(h.data() + 9, P0, 24);
     std::memcpy(h.data() + 12, pose, sizeof(double) * 7 * n); std::memcpy(h.data() + 12 + 7 * n, sb, sizeof(double) * 9 * n);
     double *d = nullptr;
-    hipError_t e = hipMalloc((void **)&d, sizeof(double) * (nin + nout));
+    hipError_t e = tcv::dev_malloc((void **)&d, sizeof(double) * (nin + nout));
     if (e != hipSuccess) return hip_fail(e, "hipMalloc");
     int rc = TCV_OK;
     e = hipMemcpy(d, h.data(), sizeof(double) * nin, hipMemcpyHostToDevice);
@@ -151,7 +151,7 @@ extern "C" int tcv_gauge_fix(int n, const double *R0, const double *P0, const do
         }
     }
     if (e != hipSuccess) rc = hip_fail(e, "gauge_fix");
-    hipFree(d);
+    tcv::dev_free(d);
     return rc;
 }
 
@@ -159,7 +159,7 @@ extern "C" int tcv_batch_gauge_fix(tcv_batch *b, void *hip_stream) {
     if (!b || !b->solved) { set_error("batch_gauge_fix: batch has not been solved"); return TCV_ERR_INVALID; }
     for (auto &H : b->plans)
         if (H.n_frames <= 0 || H.n_frames > 64) { set_error("batch_gauge_fix: problem carries no frame table (tcv_problem_set_frames)"); return TCV_ERR_INVALID; }
-    b->last_stream = (hipStream_t)hip_stream;
+    b->last_stream = (hipStream_t)hip_stream; b->pending = true;
     hipLaunchKernelGGL(gauge_batch_kernel, dim3(b->n), dim3(64), 0, (hipStream_t)hip_stream, b->d_win, b->d_plans, b->d_plan_base, b->d_ipool,
                        b->d_dpool, b->d_state, b->state_stride);
     hipError_t e = hipGetLastError();

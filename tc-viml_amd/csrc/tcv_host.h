@@ -97,6 +97,7 @@ struct tcv_batch {
     std::vector<double> h_state;
     bool gauge_fixed = false;
     hipStream_t last_stream = nullptr;     // stream of the last asynchronous call (tcv_batch_synchronize waits for it; null: the device)
+    bool pending = false;                  // asynchronous work issued since the last synchronize (batch_free waits before it recycles the buffers)
     bool chain = false;                   // all plans use the chain layout (2 workgroups per CU)
     int chain_lds = 0;                    // LDS doubles per chain-layout workgroup of this batch
     double *d_imublk = nullptr, *d_spill = nullptr;   // chain mode: per-workgroup IMU J'J blocks and factored fronts
@@ -115,6 +116,10 @@ void tcv_marg_elapsed(tcv_batch *b);
 int tcv_marg_download(tcv_batch *b);
 
 namespace tcv {
+// device allocations go through a per-process free list (size-bucketed, per device): a per-frame estimator creates and destroys a
+// batch every frame, and hipMalloc / hipFree (each a device synchronisation) were a quarter of its host time
+hipError_t dev_malloc(void **p, size_t bytes);
+hipError_t dev_free(void *p);
 int hip_fail(hipError_t e, const char *what);
 int device_ready();
 void set_error(const std::string &s);

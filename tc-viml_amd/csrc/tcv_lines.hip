@@ -212,10 +212,10 @@ extern "C" int tcv_match_lines(int n_frames, const double *poses, const double *
     const size_t o_pose = put(poses, (size_t)7 * n_frames), o_ex = put(ex_pose, 7), o_R = put(Rbw, 9), o_T = put(Tbw, 3), o_K = put(K, 9);
     const size_t o_map = put(lines3d, (size_t)6 * n_map), o_det = n_det ? put(det_lines, (size_t)4 * n_det) : o;
     double *dd = nullptr; int *di = nullptr; float *df = nullptr; unsigned char *db = nullptr;
-    hipError_t e = hipMalloc((void **)&dd, sizeof(double) * (nd_in + nd_out + 1));
-    if (e == hipSuccess) e = hipMalloc((void **)&di, sizeof(int) * (2 * (size_t)n_det + 1));
-    if (e == hipSuccess) e = hipMalloc((void **)&df, sizeof(float) * (3 * (size_t)n_det + 1));
-    if (e == hipSuccess) e = hipMalloc((void **)&db, (size_t)n_frames * n_map);
+    hipError_t e = tcv::dev_malloc((void **)&dd, sizeof(double) * (nd_in + nd_out + 1));
+    if (e == hipSuccess) e = tcv::dev_malloc((void **)&di, sizeof(int) * (2 * (size_t)n_det + 1));
+    if (e == hipSuccess) e = tcv::dev_malloc((void **)&df, sizeof(float) * (3 * (size_t)n_det + 1));
+    if (e == hipSuccess) e = tcv::dev_malloc((void **)&db, (size_t)n_frames * n_map);
     if (e == hipSuccess) e = hipMemcpy(dd, h.data(), sizeof(double) * nd_in, hipMemcpyHostToDevice);
     if (e == hipSuccess && n_det) e = hipMemcpy(di, det_frame, sizeof(int) * n_det, hipMemcpyHostToDevice);
     if (e == hipSuccess && fov_given) e = hipMemcpy(db, in_fov, (size_t)n_frames * n_map, hipMemcpyHostToDevice);
@@ -236,6 +236,6 @@ extern "C" int tcv_match_lines(int n_frames, const double *poses, const double *
         if (e == hipSuccess && n_det && projected) e = hipMemcpy(projected, dd + nd_in, sizeof(double) * 4 * n_det, hipMemcpyDeviceToHost);
     }
     if (e != hipSuccess) rc = hip_fail(e, "match_lines");
-    hipFree(dd); hipFree(di); hipFree(df); hipFree(db);
+    tcv::dev_free(dd); tcv::dev_free(di); tcv::dev_free(df); tcv::dev_free(db);
     return rc;
 }

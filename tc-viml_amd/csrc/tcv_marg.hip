@@ -899,8 +899,8 @@ struct MargState {
 static void marg_free(tcv_batch *b) {
     MargState *s = (MargState *)b->marg;
     if (!s) return;
-    (void)hipFree(s->d_hdr); (void)hipFree(s->d_ipool); (void)hipFree(s->d_status); (void)hipFree(s->d_dpool);
-    (void)hipFree(s->d_out); (void)hipFree(s->d_scratch);
+    (void)tcv::dev_free(s->d_hdr); (void)tcv::dev_free(s->d_ipool); (void)tcv::dev_free(s->d_status); (void)tcv::dev_free(s->d_dpool);
+    (void)tcv::dev_free(s->d_out); (void)tcv::dev_free(s->d_scratch);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     delete s;
@@ -1112,7 +1112,7 @@ int tcv_marg_attach(tcv_batch *b, tcv_problem *const *marg_problems, double *con
     s->grid = std::min(b->n, prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
 #define MUP(dst, src, T, cnt)                                                                    \
     do {                                                                                         \
-        hipError_t e_ = hipMalloc((void **)&dst, sizeof(T) * std::max<size_t>(1, (cnt)));        \
+        hipError_t e_ = tcv::dev_malloc((void **)&dst, sizeof(T) * std::max<size_t>(1, (cnt)));        \
         if (e_ != hipSuccess) return hip_fail(e_, "hipMalloc");                                  \
         if (src) {                                                                               \
             e_ = hipMemcpy(dst, src, sizeof(T) * (cnt), hipMemcpyHostToDevice);                  \

@@ -178,12 +178,12 @@ extern "C" int tcv_preintegrate(int n, const int *first, const int *count, const
     int *d_first = nullptr, *d_count = nullptr;
     double *d_s = nullptr, *d_i = nullptr, *d_o = nullptr;
     hipError_t e = hipSuccess;
-    auto fail = [&](const char *w) { (void)hipFree(d_first); (void)hipFree(d_count); (void)hipFree(d_s); (void)hipFree(d_i); (void)hipFree(d_o); return hip_fail(e, w); };
-    if ((e = hipMalloc((void **)&d_first, sizeof(int) * n)) != hipSuccess) return fail("hipMalloc");
-    if ((e = hipMalloc((void **)&d_count, sizeof(int) * n)) != hipSuccess) return fail("hipMalloc");
-    if ((e = hipMalloc((void **)&d_s, sizeof(double) * 7 * (size_t)std::max(1, num_samples))) != hipSuccess) return fail("hipMalloc");
-    if ((e = hipMalloc((void **)&d_i, sizeof(double) * 12 * (size_t)n)) != hipSuccess) return fail("hipMalloc");
-    if ((e = hipMalloc((void **)&d_o, sizeof(double) * PREINT_OUT * (size_t)n)) != hipSuccess) return fail("hipMalloc");
+    auto fail = [&](const char *w) { (void)tcv::dev_free(d_first); (void)tcv::dev_free(d_count); (void)tcv::dev_free(d_s); (void)tcv::dev_free(d_i); (void)tcv::dev_free(d_o); return hip_fail(e, w); };
+    if ((e = tcv::dev_malloc((void **)&d_first, sizeof(int) * n)) != hipSuccess) return fail("hipMalloc");
+    if ((e = tcv::dev_malloc((void **)&d_count, sizeof(int) * n)) != hipSuccess) return fail("hipMalloc");
+    if ((e = tcv::dev_malloc((void **)&d_s, sizeof(double) * 7 * (size_t)std::max(1, num_samples))) != hipSuccess) return fail("hipMalloc");
+    if ((e = tcv::dev_malloc((void **)&d_i, sizeof(double) * 12 * (size_t)n)) != hipSuccess) return fail("hipMalloc");
+    if ((e = tcv::dev_malloc((void **)&d_o, sizeof(double) * PREINT_OUT * (size_t)n)) != hipSuccess) return fail("hipMalloc");
     if ((e = hipMemcpy(d_first, first, sizeof(int) * n, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy");
     if ((e = hipMemcpy(d_count, count, sizeof(int) * n, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy");
     if (num_samples && (e = hipMemcpy(d_s, samples7, sizeof(double) * 7 * (size_t)num_samples, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy");
@@ -201,6 +201,6 @@ extern "C" int tcv_preintegrate(int n, const int *first, const int *count, const
         std::memcpy(p.linearized_ba, o + 10, 24); std::memcpy(p.linearized_bg, o + 13, 24); p.sum_dt = o[16];
         std::memcpy(p.jacobian, o + 17, 225 * 8); std::memcpy(p.covariance, o + 242, 225 * 8);
     }
-    (void)hipFree(d_first); (void)hipFree(d_count); (void)hipFree(d_s); (void)hipFree(d_i); (void)hipFree(d_o);
+    (void)tcv::dev_free(d_first); (void)tcv::dev_free(d_count); (void)tcv::dev_free(d_s); (void)tcv::dev_free(d_i); (void)tcv::dev_free(d_o);
     return TCV_OK;
 }
