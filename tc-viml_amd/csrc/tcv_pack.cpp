@@ -56,7 +56,10 @@ struct DestList {
 // unit record (UNIT_INTS ints): u0 = kind << 28 | ncols << 24 | ea << 20 | nitems,  u1 = o0 << 16 | o1,  u2 = item_begin
 // (IMU units carry their <= 2 items inline instead: u2 = item0, u3 = item1).  Units are sorted by descending item
 // count; those with more than WAVE_UNIT_ITEMS items come first and are processed by a whole wavefront each.
-enum { WAVE_UNIT_ITEMS = 32 };      // longer item lists go to a whole wavefront: a thread unit costs its wavefront ~40 instructions per item while the other lanes idle
+// A thread unit costs its wavefront ~40 instructions per item while the other lanes idle, a wave unit ~150 instructions whatever its
+// length: the longest lists (above WAVE_UNIT_ITEMS items) go to whole wavefronts, but no more than WAVE_UNIT_MAX of them -- a chunk that
+// holds every factor of a large window has dozens of lists of that length, and turning them all into wave units serialises them.
+enum { WAVE_UNIT_ITEMS = 32, WAVE_UNIT_MAX = 12 };
 struct RowProg {
     std::vector<int> units, items;
     int n_units = 0, n_wave_units = 0;
@@ -92,7 +95,7 @@ static bool emit_rows(const DestList &dl, RowProg &out, bool inline_items) {
     for (auto &u : us) {
         out.units.push_back(u.u0); out.units.push_back(u.u1); out.units.push_back(u.u2);
         if (inline_items) out.units.push_back(u.u3);
-        if (!inline_items && u.n > WAVE_UNIT_ITEMS) out.n_wave_units++;
+        if (!inline_items && u.n > WAVE_UNIT_ITEMS && out.n_wave_units < WAVE_UNIT_MAX) out.n_wave_units++;
     }
     out.n_units = (int)us.size();
     return true;
