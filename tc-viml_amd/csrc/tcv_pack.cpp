@@ -33,16 +33,19 @@ struct DestKey {
 };
 struct DestList {
     std::vector<DestKey> keys;                 // insertion order (deterministic)
-    std::map<DestKey, int> index;
+    std::unordered_map<unsigned long long, int> index;      // kind | o0 | o1 packed (the fields are < 2^20): a hash instead of an ordered map,
+                                                            // the packer spends most of its time here when every frame has a new structure
     std::vector<std::vector<int>> items;
     std::vector<std::pair<int, int>> shape;    // (la, lb); lb = 0: triangle of la
+    DestList() { index.reserve(4096); keys.reserve(2048); items.reserve(2048); shape.reserve(2048); }
     void add(int kind, int o0, int o1, int la, int lb, int item) {
         DestKey k{kind, o0, o1};
-        auto it = index.find(k);
+        const unsigned long long hk = ((unsigned long long)kind << 48) | ((unsigned long long)(unsigned)o0 << 24) | (unsigned long long)(unsigned)o1;
+        auto it = index.find(hk);
         int id;
         if (it == index.end()) {
             id = (int)keys.size();
-            index[k] = id;
+            index.emplace(hk, id);
             keys.push_back(k);
             items.emplace_back();
             shape.emplace_back(la, lb);
