@@ -63,6 +63,7 @@ struct MargArgs {
 
 __device__ __forceinline__ int pidx(int a, int b) { return a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a; }
 
+
 // Parallel cyclic Jacobi eigen-decomposition of the symmetric matrix M (row-major, leading dimension ld, padded to
 // the even size de with a zero row/column), V = eigenvectors.  Round-robin pairing: every round rotates de/2 disjoint
 // index pairs.  Thread (k, part) keeps pair k's (c, s, p, q) in registers and sweeps its share of the rows (column
@@ -189,17 +190,21 @@ __device__ __forceinline__ double fast_rcp(double q) {
     r = fma(fma(-q, r, 1.0), r, r);
     return r;
 }
-// eigenvalue k of the symmetric tridiagonal (dv, e2 = squared off-diagonal) by 4-section on Sturm counts: four lanes per
-// eigenvalue test three interior points per trip (30 trips: 4^-30 of the Gershgorin interval).  Sturm count from the
-// scaled determinant recurrence p_i = (d_i - x) p_{i-1} - e_{i-1}^2 p_{i-2}: a sign change between consecutive p's is a
-// negative pivot; no division on the chain, rescaled every fourth step.
+// eigenvalue k of the symmetric tridiagonal (dv, e2 = squared off-diagonal) by 7-section on Sturm counts: six lanes per
+// eigenvalue test six interior points per trip (ten eigenvalues per wavefront, lanes 60..63 idle; 80 eigenvalues per 512-thread
+// workgroup), 22 trips: 7^-22 < 4^-30 of the Gershgorin interval (round 1 ran 30 trips of 4-section on four lanes: the recurrence
+// is the cost, so fewer trips on more lanes is the same work per trip and 27 % fewer trips).  Sturm count from the scaled
+// determinant recurrence p_i = (d_i - x) p_{i-1} - e_{i-1}^2 p_{i-2}: a sign change between consecutive p's is a negative pivot;
+// no division on the chain, rescaled every fourth step.
 __device__ __noinline__ void eig_multisection(const lds_d *dv, const lds_d *e2, lds_d *lam, int n, double gl, double gu, double pivmin, int tid) {
-    const int k = tid >> 2, sub = tid & 3, lane = tid & 63;
-    if (((tid & ~63) >> 2) >= n) return;          // whole wavefront beyond the last eigenvalue
+    constexpr int LPE = 6, GPW = 10;      // lanes per eigenvalue, eigenvalues per wavefront
+    const int lane = tid & 63, wave = tid >> 6, g = lane / LPE, sub = lane - g * LPE;
+    const int k = wave * GPW + min(g, GPW - 1);
+    if (wave * GPW >= n) return;          // whole wavefront beyond the last eigenvalue
     double lo = gl, hi = gu;
-    for (int it = 0; it < 30; it++) {      // 4^-30: eigenvalues to ~1e-12 abs, close pairs need it for orthogonal twisted vectors
-        const double w4 = (hi - lo) * 0.25;
-        const double x = lo + w4 * (double)(sub + 1);
+    for (int it = 0; it < 22; it++) {
+        const double w7 = (hi - lo) * (1.0 / 7.0);
+        const double x = lo + w7 * (double)(sub + 1);
         double pp = 1.0, pc = dv[0] - x;
         if (pc == 0.0) pc = -pivmin;
         int cnt = (pc < 0.0);
@@ -222,15 +227,14 @@ __device__ __noinline__ void eig_multisection(const lds_d *dv, const lds_d *e2, 
             cnt += (int)(((unsigned)(__double2hiint(pn) ^ __double2hiint(pc))) >> 31);
             pp = pc; pc = pn;
         }
-        const int below = (cnt > k) ? 1 : 0;       // eigenvalue k lies below x
-        const int b0 = __shfl(below, (lane & ~3) + 0), b1 = __shfl(below, (lane & ~3) + 1), b2 = __shfl(below, (lane & ~3) + 2);
-        const double x0 = lo + w4, x1 = lo + 2.0 * w4, x2 = lo + 3.0 * w4;
-        if (b0) hi = x0;
-        else if (b1) { lo = x0; hi = x1; }
-        else if (b2) { lo = x1; hi = x2; }
-        else lo = x2;
+        // eigenvalue k lies below x_sub iff cnt > k; the first such interior point of the group closes the new interval from above
+        const unsigned long long bal = __ballot(cnt > k && g < GPW);
+        const unsigned grp = (unsigned)((bal >> (min(g, GPW - 1) * LPE)) & 0x3full);
+        const int f = grp ? (__ffs((int)grp) - 1) : LPE;      // number of interior points at or below the eigenvalue
+        const double nlo = lo + w7 * (double)f, nhi = (f == LPE) ? hi : lo + w7 * (double)(f + 1);
+        lo = nlo; hi = nhi;
     }
-    if (k < n && sub == 0) lam[k] = 0.5 * (lo + hi);
+    if (k < n && g < GPW && sub == 0) lam[k] = 0.5 * (lo + hi);
 }
 
 // Z <- Q Z, Q = H_0 ... H_{n-2} (reflectors below the sub-diagonal of A): four lanes own a column and keep it in

@@ -88,6 +88,68 @@ struct Ctx {
     unsigned skip;   // TCV_ABLATE builds
 };
 
+// Every pointer and size in Ctx is the same for all lanes of the workgroup, but the phase functions are not inlined (their register
+// budgets would add up) and take the Ctx by reference: the compiler then reloads each field from the kernel's stack frame with FLAT
+// loads into VGPRs, cannot tell that the values are uniform, and ends up with chains scratch load -> wait -> global load of a plan
+// field -> wait -> use all over the phases (and with 64-bit pointers in VGPRs that spill).  uniform_ctx() copies the Ctx once per
+// call through v_readfirstlane: pointers and sizes live in SGPRs from then on, loads through the constant-address-space pointers
+// (plan header, window header, uniform plan ints) become scalar loads, and the per-lane ones take an SGPR base.
+template <class T> __device__ __forceinline__ T *uni_ptr(T *p) {      // 64-bit (generic / global / constant) pointers
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return (T *)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ gbl_d *uni_ptr(gbl_d *p) {
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return (gbl_d *)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ cst_plan *uni_ptr(cst_plan *p) {
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return (cst_plan *)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ cst_win *uni_ptr(cst_win *p) {
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return (cst_win *)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ cst_i *uni_ptr(cst_i *p) {
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return (cst_i *)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ cst_d *uni_ptr(cst_d *p) {
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return (cst_d *)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ lds_d *uni_ptr(lds_d *p) { return (lds_d *)(unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)p); }      // LDS pointers are 32-bit
+__device__ __forceinline__ lds_i *uni_ptr(lds_i *p) { return (lds_i *)(unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)p); }
+template <int NT>
+__device__ __forceinline__ Ctx<NT> uniform_ctx(const Ctx<NT> &R) {
+    Ctx<NT> C;
+    C.prof = uni_ptr(R.prof); C.t_last = R.t_last;
+    C.P = uni_ptr(R.P); C.ip = uni_ptr(R.ip); C.dp = uni_ptr(R.dp); C.W = uni_ptr(R.W);
+    C.tiles = uni_ptr(R.tiles); C.stage = uni_ptr(R.stage); C.xs = uni_ptr(R.xs); C.xc = uni_ptr(R.xc); C.sc = uni_ptr(R.sc);
+    C.ycam = uni_ptr(R.ycam); C.invdiag = uni_ptr(R.invdiag); C.red = uni_ptr(R.red); C.area = uni_ptr(R.area); C.gcam = uni_ptr(R.gcam);
+    C.rc = uni_ptr(R.rc); C.sd = uni_ptr(R.sd); C.flag = uni_ptr(R.flag); C.hd = uni_ptr(R.hd);
+    C.g_imublk = uni_ptr(R.g_imublk); C.g_spill = uni_ptr(R.g_spill);
+    C.nd = __builtin_amdgcn_readfirstlane(R.nd); C.ntd = __builtin_amdgcn_readfirstlane(R.ntd);
+    C.v_s = uni_ptr(R.v_s); C.v_g = uni_ptr(R.v_g); C.v_D = uni_ptr(R.v_D); C.v_ghat = uni_ptr(R.v_ghat); C.v_y = uni_ptr(R.v_y); C.v_p = uni_ptr(R.v_p);
+    C.v_rc = uni_ptr(R.v_rc); C.v_sd = uni_ptr(R.v_sd); C.l_hll = uni_ptr(R.l_hll); C.l_gl = uni_ptr(R.l_gl); C.l_invk = uni_ptr(R.l_invk);
+    C.g_hcl = uni_ptr(R.g_hcl); C.g_hp = uni_ptr(R.g_hp); C.g_pr = uni_ptr(R.g_pr); C.g_pdx = uni_ptr(R.g_pdx); C.g_sqrt = uni_ptr(R.g_sqrt);
+    C.ntiles = __builtin_amdgcn_readfirstlane(R.ntiles); C.stage_cap = __builtin_amdgcn_readfirstlane(R.stage_cap);
+    C.tid = R.tid;
+    C.skip = __builtin_amdgcn_readfirstlane(R.skip);
+    return C;
+}
+#ifdef TCV_PROFILE
+#define TCV_CTX_LEAVE(R, C) do { (R).t_last = (C).t_last; } while (0)
+#else
+#define TCV_CTX_LEAVE(R, C) do { } while (0)
+#endif
+
 enum { SCR_HP = 8256, SCR_SQ = 16 * 225, SCR_LM = 1024 };      // the landmark/camera coupling store comes last: its size is per batch
 enum {
     SCR_TOTAL = 8 * SCR_NL + 3 * SCR_LM + SCR_HP + 2 * 128 + SCR_SQ      // + hcl capacity (tcv_batch_create)
@@ -273,7 +335,8 @@ __device__ __forceinline__ void copy_prog(lds_i *dst, cst_i *src, int n, int tid
 // kappa_l = hll + mu * clamp(s_l^2 hll) / s_l^2 is the landmark pivot of the Jacobi-scaled,
 // mu-regularised system expressed in unscaled units (DoglegStrategy + SchurEliminator restated).
 template <int NT, bool CHAIN>
-__device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first, bool assemble, double mu) {
+__device__ __noinline__ double linearize(Ctx<NT> &Cr, const lds_d *x, bool first, bool assemble, double mu) {
+    Ctx<NT> C = uniform_ctx<NT>(Cr);
     cst_plan &P = *C.P;
     const int tid = C.tid;
     cst_i *ip = C.ip;
@@ -739,6 +802,7 @@ __device__ __noinline__ double linearize(Ctx<NT> &C, const lds_d *x, bool first,
     const double cost = block_sum<NT>(cost_acc, C.red, tid);
     __syncthreads();
     TCV_MARK(C, PH_COST_RED);
+    TCV_CTX_LEAVE(Cr, C);
     return cost;
 }
 
@@ -855,7 +919,8 @@ __device__ __forceinline__ void update_tile2(lds_d *tiles, int I0, int J0, int I
 // wave 0 updates tile (K+1, K+1) first and factorises it, so the serial pivot chain of the next diagonal
 // tile hides behind the matrix-core work.  Two barriers per tile column.
 template <int NT, bool MFMA>
-__device__ __noinline__ bool chol_tiles(Ctx<NT> &C, int nt, int nc) {
+__device__ __noinline__ bool chol_tiles(Ctx<NT> &Cr, int nt, int nc) {
+    Ctx<NT> C = uniform_ctx<NT>(Cr);
     const int tid = C.tid, lane = tid & 63, wave = tid >> 6;
     constexpr int NW = NT / 64, NG = NT / 16;
     lds_d *tiles = C.tiles;
@@ -937,7 +1002,8 @@ __device__ __noinline__ bool chol_tiles(Ctx<NT> &C, int nt, int nc) {
 // 16 lanes that own its columns solve the 16 x 16 triangular system among themselves (v_readlane broadcasts), publish
 // y_K, and after ONE barrier every thread folds tile row K into its own t_c.
 template <int NT>
-__device__ __noinline__ void back_subst(Ctx<NT> &C, int nc) {
+__device__ __noinline__ void back_subst(Ctx<NT> &Cr, int nc) {
+    Ctx<NT> C = uniform_ctx<NT>(Cr);
     const int tid = C.tid, lane = tid & 63;
     lds_d *tiles = C.tiles, *y = C.ycam;
     const int c = tid, Kc = c >> 4, cc = c & 15;
@@ -1201,7 +1267,8 @@ __device__ __forceinline__ void chain_mfma_update(const Ctx<NT> &C, const lds_d 
 #define CH_TOC(slot, cond) do { } while (0)
 #endif
 template <int NT>
-__device__ __noinline__ bool chain_forward(Ctx<NT> &C, double mu, double &q_out) {
+__device__ __noinline__ bool chain_forward(Ctx<NT> &Cr, double mu, double &q_out) {
+    Ctx<NT> C = uniform_ctx<NT>(Cr);
     static_assert(NT >= 256, "chain layout: four wavefronts (column owners on waves 0-1, matrix cores on 0-2, T pipeline on 3)");
     cst_plan &P = *C.P;
     const int tid = C.tid, lane = tid & 63, wave = tid >> 6, npp = P.npp, ne = P.n_e;
@@ -1351,7 +1418,8 @@ __device__ __forceinline__ void chain_products(Ctx<NT> &C) {
     __syncthreads();
 }
 template <int NT>
-__device__ __noinline__ bool chain_backward(Ctx<NT> &C) {
+__device__ __noinline__ bool chain_backward(Ctx<NT> &Cr) {
+    Ctx<NT> C = uniform_ctx<NT>(Cr);
     cst_plan &P = *C.P;
     const int lane = C.tid & 63, ne = P.n_e;
     const ChainLds L = chain_lds<NT>(C);
@@ -1389,7 +1457,8 @@ __device__ __noinline__ bool chain_backward(Ctx<NT> &C) {
 // ---- scale, regularise, factorise and solve (J'J + mu D^2) y = J'r ---------------------------------
 // On return (true): v_y = y (scaled space, camera then landmarks), v_D, v_ghat set, scal = {gg, q}.
 template <int NT, bool MFMA, bool CHAIN>
-__device__ __noinline__ bool finalize_and_solve(Ctx<NT> &C, bool first, double mu, double &gg_out, double &q_out) {
+__device__ __noinline__ bool finalize_and_solve(Ctx<NT> &Cr, bool first, double mu, double &gg_out, double &q_out) {
+    Ctx<NT> C = uniform_ctx<NT>(Cr);
     cst_plan &P = *C.P;
     const int tid = C.tid, nc = P.nc, L = P.nland;
     const int nd = C.nd;      // dimension of the dense system in the tiles: nc, or npp in chain mode
@@ -1540,12 +1609,14 @@ __device__ __noinline__ bool finalize_and_solve(Ctx<NT> &C, bool first, double m
 #ifdef TCV_ABLATE
     if (ABL_FORCE(C)) anybad = 0;
 #endif
+    TCV_CTX_LEAVE(Cr, C);
     return anybad == 0;
 }
 
 // ---- ambient-space helpers ---------------------------------------------------------------------------
 template <int NT>
-__device__ __noinline__ void apply_plus(Ctx<NT> &C, const lds_d *x, const gbl_d *delta_scaled, const gbl_d *s, lds_d *xo) {
+__device__ __noinline__ void apply_plus(Ctx<NT> &Cr, const lds_d *x, const gbl_d *delta_scaled, const gbl_d *s, lds_d *xo) {
+    Ctx<NT> C = uniform_ctx<NT>(Cr);
     // delta = step o scale; per block Plus (pose_local_parameterization.cpp:3-19) or x + delta
     cst_plan &P = *C.P;
     cst_i *blk = C.ip + P.o_blk;
@@ -1570,7 +1641,8 @@ __device__ __noinline__ void apply_plus(Ctx<NT> &C, const lds_d *x, const gbl_d 
 }
 
 template <int NT>
-__device__ __noinline__ void ambient_norms(Ctx<NT> &C, const lds_d *x, const lds_d *xo, double &xn2, double &dn2) {
+__device__ __noinline__ void ambient_norms(Ctx<NT> &Cr, const lds_d *x, const lds_d *xo, double &xn2, double &dn2) {
+    Ctx<NT> C = uniform_ctx<NT>(Cr);
     cst_plan &P = *C.P;
     cst_i *blk = C.ip + P.o_blk;
     double acc[2] = {0.0, 0.0};
@@ -1594,7 +1666,8 @@ __device__ __noinline__ void ambient_norms(Ctx<NT> &C, const lds_d *x, const lds
 }
 
 template <int NT>
-__device__ __noinline__ double grad_max(Ctx<NT> &C) {
+__device__ __noinline__ double grad_max(Ctx<NT> &Cr) {
+    Ctx<NT> C = uniform_ctx<NT>(Cr);
     double m = 0;
     for (int i = C.tid; i < C.P->nc; i += NT) m = fmax(m, fabs(C.gcam[i]));
     for (int i = C.tid; i < C.P->nland; i += NT) m = fmax(m, fabs(C.v_g[C.P->nc + i]));
