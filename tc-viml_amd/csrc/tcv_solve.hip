@@ -126,6 +126,13 @@ __device__ __forceinline__ cst_d *uni_ptr(cst_d *p) {
 }
 __device__ __forceinline__ lds_d *uni_ptr(lds_d *p) { return (lds_d *)(unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)p); }      // LDS pointers are 32-bit
 __device__ __forceinline__ lds_i *uni_ptr(lds_i *p) { return (lds_i *)(unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)p); }
+// a value every lane holds identically (the result of a block reduction, a trust-region scalar): moved to a scalar register pair so that
+// it is kept across the calls of the phase functions by v_writelane / v_readlane instead of a scratch spill
+__device__ __forceinline__ double uni_d(double v) {
+    const unsigned long long u = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
 template <int NT>
 __device__ __forceinline__ Ctx<NT> uniform_ctx(const Ctx<NT> &R) {
     Ctx<NT> C;
@@ -1266,8 +1273,9 @@ __device__ __forceinline__ void chain_mfma_update(const Ctx<NT> &C, const lds_d 
 #define CH_TIC() do { } while (0)
 #define CH_TOC(slot, cond) do { } while (0)
 #endif
+struct ChainOut { double q; bool ok; };
 template <int NT>
-__device__ __noinline__ bool chain_forward(Ctx<NT> &Cr, double mu, double &q_out) {
+__device__ __noinline__ ChainOut chain_forward(Ctx<NT> &Cr, double mu) {
     Ctx<NT> C = uniform_ctx<NT>(Cr);
     static_assert(NT >= 256, "chain layout: four wavefronts (column owners on waves 0-1, matrix cores on 0-2, T pipeline on 3)");
     cst_plan &P = *C.P;
@@ -1306,7 +1314,7 @@ __device__ __noinline__ bool chain_forward(Ctx<NT> &Cr, double mu, double &q_out
     }
     __syncthreads();
     for (int s = 0; s <= ne; s++) {
-        if (*C.flag) return false;      // uniform: read after a barrier, written before it
+        if (*C.flag) { ChainOut bad; bad.q = 0.0; bad.ok = false; return bad; }      // uniform: read after a barrier, written before it
         // ---- T pipeline: one step ahead
         CH_TIC();
         if (wave == 3 && s + 1 < ne && ABL(C, AB_CH_T)) {
@@ -1386,9 +1394,11 @@ __device__ __noinline__ bool chain_forward(Ctx<NT> &Cr, double mu, double &q_out
         __syncthreads();
         CH_TOC(PH_CH_D, tid == 64);      // the whole interval as wave 1 sees it
     }
-    q_out = block_sum<NT>(q, C.red, tid);
+    ChainOut o;
+    o.q = block_sum<NT>(q, C.red, tid);
+    o.ok = true;
     __syncthreads();
-    return true;
+    return o;
 }
 
 // back-substitution through the chain: y_s = L_ss^-T (z_s - W_s y_p - L_s+1,s' y_s+1), blocks in reverse elimination order; y_p
@@ -1456,8 +1466,9 @@ __device__ __noinline__ bool chain_backward(Ctx<NT> &Cr) {
 
 // ---- scale, regularise, factorise and solve (J'J + mu D^2) y = J'r ---------------------------------
 // On return (true): v_y = y (scaled space, camera then landmarks), v_D, v_ghat set, scal = {gg, q}.
+struct FinOut { double gg, q; bool ok; };
 template <int NT, bool MFMA, bool CHAIN>
-__device__ __noinline__ bool finalize_and_solve(Ctx<NT> &Cr, bool first, double mu, double &gg_out, double &q_out) {
+__device__ __noinline__ FinOut finalize_and_solve(Ctx<NT> &Cr, bool first, double mu) {
     Ctx<NT> C = uniform_ctx<NT>(Cr);
     cst_plan &P = *C.P;
     const int tid = C.tid, nc = P.nc, L = P.nland;
@@ -1556,18 +1567,20 @@ __device__ __noinline__ bool finalize_and_solve(Ctx<NT> &Cr, bool first, double 
             }
     }
     block_sum_n<NT, 2>(acc, C.red, tid);
-    gg_out = acc[0];
-    q_out = acc[1];
+    FinOut out;
+    out.gg = acc[0]; out.q = acc[1]; out.ok = false;
     if (tid == 0) *C.flag = 0;
     __syncthreads();
     TCV_MARK(C, PH_FIN_PASS);
     if (CHAIN) {
-        double qc = 0.0;
-        if (ABL(C, AB_CHAIN_FWD) && !chain_forward<NT>(C, mu, qc)) return false;
-        q_out += qc;
+        if (ABL(C, AB_CHAIN_FWD)) {
+            const ChainOut co = chain_forward<NT>(C, mu);
+            if (!co.ok) return out;
+            out.q += co.q;
+        }
         TCV_MARK(C, PH_CHAIN_FWD);
     }
-    if (ABL(C, AB_CHOL) && !chol_tiles<NT, MFMA>(C, C.ntd, nd)) return false;
+    if (ABL(C, AB_CHOL) && !chol_tiles<NT, MFMA>(C, C.ntd, nd)) return out;
     if (ABL(C, AB_BACK)) back_subst<NT>(C, nd);
     TCV_MARK(C, PH_BACK);
     // landmarks: y_l = (gl - Hcl' (s o y_c)) / (s_l kappa_l)
@@ -1610,7 +1623,8 @@ __device__ __noinline__ bool finalize_and_solve(Ctx<NT> &Cr, bool first, double 
     if (ABL_FORCE(C)) anybad = 0;
 #endif
     TCV_CTX_LEAVE(Cr, C);
-    return anybad == 0;
+    out.ok = anybad == 0;
+    return out;
 }
 
 // ---- ambient-space helpers ---------------------------------------------------------------------------
@@ -1640,8 +1654,9 @@ __device__ __noinline__ void apply_plus(Ctx<NT> &Cr, const lds_d *x, const gbl_d
     for (int l = C.tid; l < P.nland; l += NT) xo[P.nx + l] = x[P.nx + l] + delta_scaled[P.nc + l] * s[P.nc + l];
 }
 
+struct Norms2 { double xn2, dn2; };      // returned in registers: reference outputs of a non-inlined function live in scratch memory
 template <int NT>
-__device__ __noinline__ void ambient_norms(Ctx<NT> &Cr, const lds_d *x, const lds_d *xo, double &xn2, double &dn2) {
+__device__ __noinline__ Norms2 ambient_norms(Ctx<NT> &Cr, const lds_d *x, const lds_d *xo) {
     Ctx<NT> C = uniform_ctx<NT>(Cr);
     cst_plan &P = *C.P;
     cst_i *blk = C.ip + P.o_blk;
@@ -1661,8 +1676,9 @@ __device__ __noinline__ void ambient_norms(Ctx<NT> &Cr, const lds_d *x, const ld
         acc[1] += d * d;
     }
     block_sum_n<NT, 2>(acc, C.red, C.tid);
-    xn2 = acc[0];
-    dn2 = acc[1];
+    Norms2 o;
+    o.xn2 = acc[0]; o.dn2 = acc[1];
+    return o;
 }
 
 template <int NT>
@@ -1743,15 +1759,18 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CHAIN ?
         C.area = CHAIN ? C.stage + P.c_stage_cap : p;
         typedef __attribute__((address_space(1))) DevSummary gbl_sum;
         gbl_sum *S = (gbl_sum *)A.summary + win;
+        // C lives in the stack frame (the phase functions take it by reference); the kernel's own accesses go through a copy whose
+        // address never escapes, so that they stay in registers (SGPRs: every field is uniform) across the calls
+        const Ctx<NT> K = uniform_ctx<NT>(C);
 
-        for (int i = tid; i < P.nx + L; i += NT) C.xs[i] = C.dp[W->d_x + i];
+        for (int i = tid; i < P.nx + L; i += NT) K.xs[i] = K.dp[W->d_x + i];
         // sqrt_info = LLT(cov^-1).matrixL()^T once per solve (imu_factor.h:64 recomputes it per Evaluate)
         if (W->d_sqrt >= 0) {
-            for (int i = tid; i < P.n_imu * 225; i += NT) C.g_sqrt[i] = C.dp[W->d_sqrt + i];
+            for (int i = tid; i < P.n_imu * 225; i += NT) C.g_sqrt[i] = K.dp[W->d_sqrt + i];
         } else {
             // one 16-lane group per factor, workspace in the (still unused) tile region
             for (int f = tid >> 4; f < P.n_imu; f += NT / 16)
-                (void)imu_sqrt_info_group((const double *)(C.dp + W->d_imu + f * IMU_CONST + IMU_COV), GEN(C.g_sqrt + f * 225), GEN(lds + f * 450),
+                (void)imu_sqrt_info_group((const double *)(K.dp + W->d_imu + f * IMU_CONST + IMU_COV), GEN(C.g_sqrt + f * 225), GEN(lds + f * 450),
                                           GEN(lds + f * 450 + 225), tid & 15);
         }
         __syncthreads();
@@ -1791,14 +1810,14 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CHAIN ?
         double radius = 1e4, mu = 1e-8, lin_mu = 1e-8;
         bool reuse = false, tiles_valid = true;
         int invalid = 0, termination = 0, nrec = 1, status = 0;
-        double cost = linearize<NT, CHAIN>(C, C.xs, true, true, mu);
+        double cost = uni_d(linearize<NT, CHAIN>(C, K.xs, true, true, mu));
         bool first = true;
         const double initial_cost = cost;
         if (tid == 0) { S->cost[0] = cost; S->step_ok[0] = 1; S->dogleg_case[0] = 0; S->radius[0] = radius; S->mu[0] = mu; }
         double gg = 0, q = 0, alpha = 0, yg = 0, gdy = 0, dy2 = 0;
         double xn2, dn2;
-        ambient_norms<NT>(C, C.xs, C.xs, xn2, dn2);
-        double x_norm = sqrt(xn2);
+        { const Norms2 nn = ambient_norms<NT>(C, K.xs, K.xs); xn2 = uni_d(nn.xn2); dn2 = uni_d(nn.dn2); }
+        double x_norm = uni_d(sqrt(xn2));
         bool done = false;
         if (!fixed) {
             const double gm = grad_max<NT>(C);
@@ -1808,11 +1827,11 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CHAIN ?
         while (!done) {
             if (it >= max_it) break;
             if (A.max_ticks > 0) {      // uniform decision: lane 0 of wave 0 reads the clock, everybody follows
-                if (tid == 0) *C.flag = ((long long)wall_clock64() - t_window > A.max_ticks) ? 7 : 0;
+                if (tid == 0) *K.flag = ((long long)wall_clock64() - t_window > A.max_ticks) ? 7 : 0;
                 __syncthreads();
-                const int over = *C.flag;
+                const int over = *K.flag;
                 __syncthreads();
-                if (tid == 0) *C.flag = 0;
+                if (tid == 0) *K.flag = 0;
                 if (over) break;
             }
             it++;
@@ -1822,27 +1841,29 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CHAIN ?
                 ls_ok = false;
                 while (mu < 1.0) {
                     if (!tiles_valid || lin_mu != mu) {
-                        (void)linearize<NT, CHAIN>(C, C.xs, false, true, mu);
+                        (void)linearize<NT, CHAIN>(C, K.xs, false, true, mu);
                         lin_mu = mu;
                     }
-                    const bool ok = finalize_and_solve<NT, MFMA, CHAIN>(C, first, mu, gg, q);
+                    const FinOut fo = finalize_and_solve<NT, MFMA, CHAIN>(C, first, mu);
+                    const bool ok = fo.ok;
+                    gg = uni_d(fo.gg); q = uni_d(fo.q);
                     first = false;
                     tiles_valid = false;
                     if (ok) { ls_ok = true; break; }
-                    mu *= 10.0;
+                    mu = uni_d(mu * 10.0);
                 }
                 if (ls_ok && ABL(C, AB_DOGLEG)) {
-                    alpha = gg / q;
+                    alpha = uni_d(gg / q);
                     // dot products for the dogleg interpolation and the model decrease
                     double acc[3] = {0.0, 0.0, 0.0};
                     for (int i = tid; i < nl; i += NT) {
-                        const double y = C.v_y[i], D = C.v_D[i], gh = C.v_ghat[i];
+                        const double y = K.v_y[i], D = K.v_D[i], gh = K.v_ghat[i];
                         acc[0] += y * (gh * D);   // y' g_s
                         acc[1] += gh * D * y;     // ghat . (D y) = -ghat . gn
                         acc[2] += (D * y) * (D * y);
                     }
-                    block_sum_n<NT, 3>(acc, C.red, tid);
-                    yg = acc[0]; gdy = acc[1]; dy2 = acc[2];
+                    block_sum_n<NT, 3>(acc, K.red, tid);
+                    yg = uni_d(acc[0]); gdy = uni_d(acc[1]); dy2 = uni_d(acc[2]);
                 }
             }
             TCV_MARK(C, PH_OTHER);
@@ -1869,7 +1890,8 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CHAIN ?
                 const double pg = ca * gg + cb * yg;
                 const double vHy = gg - mu * gdy, yHy = yg - mu * dy2;
                 const double pHp = ca * ca * q + 2.0 * ca * cb * vHy + cb * cb * yHy;
-                model_cost_change = -pg - 0.5 * pHp;
+                model_cost_change = uni_d(-pg - 0.5 * pHp);
+                ca = uni_d(ca); cb = uni_d(cb); step_norm = uni_d(step_norm);
                 // sign convention of the minimiser: step = -(...) so that model_cost_change > 0 for descent
                 step_valid = model_cost_change > 0.0;
             }
@@ -1885,25 +1907,25 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CHAIN ?
                 }
                 nrec++;
                 if (invalid >= 5) { termination = 5; break; }
-                mu *= 10.0;
+                mu = uni_d(mu * 10.0);
                 reuse = false;
                 continue;
             }
             invalid = 0;
             TCV_MARK(C, PH_DOGLEG);
-            for (int i = tid; i < nl; i += NT) C.v_p[i] = ca * (C.v_ghat[i] / C.v_D[i]) + cb * C.v_y[i];
+            for (int i = tid; i < nl; i += NT) K.v_p[i] = ca * (K.v_ghat[i] / K.v_D[i]) + cb * K.v_y[i];
             __syncthreads();
-            if (ABL(C, AB_PLUS)) apply_plus<NT>(C, C.xs, C.v_p, C.v_s, C.xc);
+            if (ABL(C, AB_PLUS)) apply_plus<NT>(C, K.xs, K.v_p, K.v_s, K.xc);
             if (A.first_delta && it == 1)
-                for (int i = tid; i < nl; i += NT) A.first_delta[(size_t)win * A.delta_stride + i] = C.v_p[i] * C.v_s[i];
+                for (int i = tid; i < nl; i += NT) A.first_delta[(size_t)win * A.delta_stride + i] = K.v_p[i] * K.v_s[i];
             __syncthreads();
             TCV_MARK(C, PH_PLUS);
-            const double mu_next = fmax(1e-8, 2.0 * mu / 10.0);
+            const double mu_next = uni_d(fmax(1e-8, 2.0 * mu / 10.0));
             const bool want_asm = (it < max_it) || !fixed;
-            const double cost_c = linearize<NT, CHAIN>(C, C.xc, false, want_asm, mu_next);
+            const double cost_c = uni_d(linearize<NT, CHAIN>(C, K.xc, false, want_asm, mu_next));
             tiles_valid = want_asm;
             lin_mu = mu_next;
-            if (ABL(C, AB_NORMS)) ambient_norms<NT>(C, C.xs, C.xc, xn2, dn2);
+            if (ABL(C, AB_NORMS)) { const Norms2 nn = ambient_norms<NT>(C, K.xs, K.xc); xn2 = uni_d(nn.xn2); dn2 = uni_d(nn.dn2); }
             TCV_MARK(C, PH_NORMS);
 #ifdef TCV_ABLATE
             const double rho = ABL_ACCEPT(C) ? 1.0 : (cost - cost_c) / model_cost_change;
@@ -1925,12 +1947,12 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CHAIN ?
                 nrec++; termination = 3; break;
             }
             if (rho > 1e-3) {
-                for (int i = tid; i < P.nx + L; i += NT) C.xs[i] = C.xc[i];
-                if (ABL(C, AB_NORMS)) ambient_norms<NT>(C, C.xc, C.xc, xn2, dn2);
-                x_norm = sqrt(xn2);
+                for (int i = tid; i < P.nx + L; i += NT) K.xs[i] = K.xc[i];
+                if (ABL(C, AB_NORMS)) { const Norms2 nn = ambient_norms<NT>(C, K.xc, K.xc); xn2 = uni_d(nn.xn2); dn2 = uni_d(nn.dn2); }
+                x_norm = uni_d(sqrt(xn2));
                 cost = cost_c;
-                if (rho < 0.25) radius *= 0.5;
-                if (rho > 0.75) radius = fmax(radius, 3.0 * step_norm);
+                if (rho < 0.25) radius = uni_d(radius * 0.5);
+                if (rho > 0.75) radius = uni_d(fmax(radius, 3.0 * step_norm));
                 mu = mu_next;
                 reuse = false;
                 if (tid == 0 && nrec < MAX_TRACE) { S->cost[nrec] = cost; S->step_ok[nrec] = 1; }
@@ -1940,7 +1962,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CHAIN ?
                     if (gm <= 1e-10) { termination = 1; break; }
                 }
             } else {
-                radius *= 0.5;
+                radius = uni_d(radius * 0.5);
                 reuse = true;
                 tiles_valid = false;
                 if (tid == 0 && nrec < MAX_TRACE) { S->cost[nrec] = cost; S->step_ok[nrec] = 0; }
@@ -1949,7 +1971,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CHAIN ?
             if (radius < 1e-32) { termination = 4; break; }
         }
         __syncthreads();
-        for (int i = tid; i < P.nx + L; i += NT) A.state_out[(size_t)win * A.state_stride + i] = C.xs[i];
+        for (int i = tid; i < P.nx + L; i += NT) A.state_out[(size_t)win * A.state_stride + i] = K.xs[i];
         if (tid == 0) {
             S->num_iterations = nrec;
             S->termination = termination;
@@ -1961,7 +1983,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CHAIN ?
         TCV_MARK(C, PH_OTHER);
 #ifdef TCV_PROFILE
         if (tid == 0 && C.prof)
-            for (int i = 0; i < PH_COUNT; i++) { lds_u *lp = (lds_u *)(C.red + 40); C.prof[i] += (double)lp[i]; lp[i] = 0u; }
+            for (int i = 0; i < PH_COUNT; i++) { lds_u *lp = (lds_u *)(K.red + 40); C.prof[i] += (double)lp[i]; lp[i] = 0u; }
         __syncthreads();
 #endif
     }
