@@ -129,9 +129,12 @@ __device__ __forceinline__ lds_i *uni_ptr(lds_i *p) { return (lds_i *)(unsigned 
 // a value every lane holds identically (the result of a block reduction, a trust-region scalar): moved to a scalar register pair so that
 // it is kept across the calls of the phase functions by v_writelane / v_readlane instead of a scratch spill
 __device__ __forceinline__ double uni_d(double v) {
-    const unsigned long long u = __double_as_longlong(v);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
-    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    const u2 u = __builtin_bit_cast(u2, v);
+    u2 r;
+    r.x = __builtin_amdgcn_readfirstlane(u.x);
+    r.y = __builtin_amdgcn_readfirstlane(u.y);
+    return __builtin_bit_cast(double, r);
 }
 template <int NT>
 __device__ __forceinline__ Ctx<NT> uniform_ctx(const Ctx<NT> &R) {
@@ -826,10 +829,15 @@ __device__ __forceinline__ void sqrt_rsqrt(double d, double &l, double &inv) {
     inv = h + h;
 }
 
+// the two halves go through a 2 x 32-bit vector so that the compiler forms the scalar register PAIR directly (shifting and or-ing
+// them together as a 64-bit integer costs two extra SALU instructions per broadcast, and the factorisations broadcast by the hundred)
+typedef unsigned tcv_u2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ double readlane_f64(double v, int srclane) {
-    const unsigned long long u = __double_as_longlong(v);
-    const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, srclane), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), srclane);
-    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+    const tcv_u2 u = __builtin_bit_cast(tcv_u2, v);
+    tcv_u2 r;
+    r.x = __builtin_amdgcn_readlane(u.x, srclane);
+    r.y = __builtin_amdgcn_readlane(u.y, srclane);
+    return __builtin_bit_cast(double, r);
 }
 
 // Cholesky of one 16x16 diagonal tile by ONE wavefront, one matrix row per lane held in registers
