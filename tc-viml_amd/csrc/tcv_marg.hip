@@ -29,9 +29,15 @@
 
 namespace tcv {
 
-enum { MARG_MAX_M = 64, MARG_MAX_N = 80, MARG_MAX_POS = MARG_MAX_M + MARG_MAX_N, MARG_MAX_X = 1408, MARG_NT = 512 };
+enum { MARG_MAX_M = 64, MARG_MAX_N = 80, MARG_MAX_POS = MARG_MAX_M + MARG_MAX_N, MARG_MAX_X = 1408 };
+// Two launch shapes of the one kernel: 512 threads per window and one workgroup per CU (few windows: shortest time per window), or
+// 256 threads per window and two workgroups per CU when every window of the batch fits 80 KB of LDS (many windows: the barrier and
+// LDS round trips of one window hide behind the other's arithmetic).
+enum { MARG_NT_WIDE = 512, MARG_NT_PAIR = 256, MARG_SM = 720, MARG_STAGE = 64 * 43 };
 enum { MARG_OUT_J0 = 0, MARG_OUT_R0 = 6400, MARG_OUT_AS = 6480, MARG_OUT_BS = 12880, MARG_OUT_X = 12960, MARG_OUT_STRIDE = 12960 + 1408 + 64 };
-enum { MARG_SCR_Z = 0, MARG_SCR_PR = MARG_MAX_M * MARG_MAX_N, MARG_SCR_SQ = MARG_SCR_PR + 256, MARG_SCR_STRIDE = MARG_SCR_SQ + 16 * 225 + 450 * 16 };
+// per-workgroup scratch in HBM (L2-resident): Z = diag(sqrt(lam^+)) V' Amr, its right-hand side, and the eigenvector matrix of the
+// Jacobi safety net for A' (the LDS holds one n x n matrix, not two)
+enum { MARG_SCR_Z = 0, MARG_SCR_PR = MARG_MAX_M * MARG_MAX_N, MARG_SCR_V = MARG_SCR_PR + 256, MARG_SCR_STRIDE = MARG_SCR_V + (MARG_MAX_N + 1) * (MARG_MAX_N + 2) };
 
 struct MargHdr {
     int nblk, pos, m, n, nx;
@@ -79,7 +85,8 @@ __device__ __forceinline__ void jacobi_angle(double app, double aqq, double apq,
         rot = true;
     }
 }
-__device__ __noinline__ int jacobi_eig(lds_d *M, lds_d *V, int d, int ld, lds_d *rot, lds_i *cnt, int tid, double floor_rel, gbl_d *prof = nullptr) {
+template <int MARG_NT, typename VP>
+__device__ __noinline__ int jacobi_eig(lds_d *M, VP *V, int d, int ld, lds_d *rot, lds_i *cnt, int tid, double floor_rel, gbl_d *prof = nullptr) {
     long long t_last = clock64();
 #ifdef TCV_PROFILE
 #define JMARK(id) do { const long long t_ = clock64(); if (tid == 0 && prof) prof[id] += (double)(t_ - t_last); t_last = t_; } while (0)
@@ -174,36 +181,36 @@ __device__ __noinline__ int jacobi_eig(lds_d *M, lds_d *V, int d, int ld, lds_d 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Symmetric eigen-decomposition for the n x n Schur matrix A' (n <= 80), all in LDS, built for one 512-thread
-// workgroup:  (1) Householder tridiagonalisation A = Q T Q' (LAPACK dsytd2 recurrences, the matrix kept full and
-// symmetric so rows are contiguous);  (2) every eigenvalue of T by multisection on Sturm counts, four lanes per
-// eigenvalue (absolute accuracy eps |T|, the class of the tridiagonal QR inside Eigen::SelfAdjointEigenSolver that
-// the reference calls);  (3) every eigenvector of T from the twisted factorisation of T - lambda I (Fernando /
-// Parlett), one lane per eigenvector;  (4) modified Gram-Schmidt inside clusters of close eigenvalues (the
-// near-null gauge directions);  (5) back-transformation by the reflectors, four lanes per column, no barriers.
-// Returns false (caller falls back to the Jacobi sweep) if the result fails the orthogonality / trace checks.
-// A is destroyed (reflectors end up below the sub-diagonal), Z gets the eigenvectors (columns, ascending
-// eigenvalues in lam), W is n*ld doubles of workspace, sm 512 doubles.
+// Symmetric eigen-decomposition for the n x n Schur matrix A' (n <= 80), all in LDS, for one workgroup of NT = 512 or 256
+// threads:  (1) Householder tridiagonalisation A = Q T Q' (LAPACK dsytd2 recurrences, the matrix kept full and
+// symmetric so rows are contiguous; the reflectors are written to a packed side buffer);  (2) every eigenvalue of T by
+// multisection on Sturm counts (absolute accuracy eps |T|, the class of the tridiagonal QR inside
+// Eigen::SelfAdjointEigenSolver that the reference calls);  (3) every eigenvector of T from the twisted factorisation of
+// T - lambda I (Fernando / Parlett), one lane per eigenvector, in the matrix's own storage;  (4) modified Gram-Schmidt inside
+// clusters of close eigenvalues (the near-null gauge directions);  (5) back-transformation by the reflectors, three or four lanes
+// per column, no barriers.  Returns false (caller falls back to the Jacobi sweep) if the result fails the orthogonality / trace
+// checks.  A is overwritten by the eigenvectors (columns, ascending eigenvalues in lam), Hq takes (n - 2)(n - 1) / 2 + 1 doubles
+// of reflectors, sm MARG_SM doubles.  LDS footprint: n (n + 2) + (n - 2)(n - 1) / 2 + MARG_SM doubles (75: 66 KB).
 __device__ __forceinline__ double fast_rcp(double q) {
     double r = __builtin_amdgcn_rcp(q);
     r = fma(fma(-q, r, 1.0), r, r);
     r = fma(fma(-q, r, 1.0), r, r);
     return r;
 }
-// eigenvalue k of the symmetric tridiagonal (dv, e2 = squared off-diagonal) by 7-section on Sturm counts: six lanes per
-// eigenvalue test six interior points per trip (ten eigenvalues per wavefront, lanes 60..63 idle; 80 eigenvalues per 512-thread
-// workgroup), 22 trips: 7^-22 < 4^-30 of the Gershgorin interval (round 1 ran 30 trips of 4-section on four lanes: the recurrence
-// is the cost, so fewer trips on more lanes is the same work per trip and 27 % fewer trips).  Sturm count from the scaled
-// determinant recurrence p_i = (d_i - x) p_{i-1} - e_{i-1}^2 p_{i-2}: a sign change between consecutive p's is a negative pivot;
-// no division on the chain, rescaled every fourth step.
+// eigenvalue k of the symmetric tridiagonal (dv, e2 = squared off-diagonal) by (LPE + 1)-section on Sturm counts: LPE lanes per
+// eigenvalue test LPE interior points per trip, GPW eigenvalues per wavefront.  512 threads: 7-section, ten eigenvalues per wavefront
+// (lanes 60..63 idle), 22 trips: 7^-22 < 4^-30 of the Gershgorin interval (the recurrence is the cost, so fewer trips on more lanes is
+// the same work per trip and fewer trips).  256 threads: 80 eigenvalues need 21 per wavefront, i.e. 4-section on three lanes, 31 trips
+// (4^-31 < 7^-22).  Sturm count from the scaled determinant recurrence p_i = (d_i - x) p_{i-1} - e_{i-1}^2 p_{i-2}: a sign change
+// between consecutive p's is a negative pivot; no division on the chain, rescaled every fourth step.
+template <int LPE, int GPW, int TRIPS>
 __device__ __noinline__ void eig_multisection(const lds_d *dv, const lds_d *e2, lds_d *lam, int n, double gl, double gu, double pivmin, int tid) {
-    constexpr int LPE = 6, GPW = 10;      // lanes per eigenvalue, eigenvalues per wavefront
     const int lane = tid & 63, wave = tid >> 6, g = lane / LPE, sub = lane - g * LPE;
     const int k = wave * GPW + min(g, GPW - 1);
     if (wave * GPW >= n) return;          // whole wavefront beyond the last eigenvalue
     double lo = gl, hi = gu;
-    for (int it = 0; it < 22; it++) {
-        const double w7 = (hi - lo) * (1.0 / 7.0);
+    for (int it = 0; it < TRIPS; it++) {
+        const double w7 = (hi - lo) * (1.0 / (double)(LPE + 1));
         const double x = lo + w7 * (double)(sub + 1);
         double pp = 1.0, pc = dv[0] - x;
         if (pc == 0.0) pc = -pivmin;
@@ -229,7 +236,7 @@ __device__ __noinline__ void eig_multisection(const lds_d *dv, const lds_d *e2, 
         }
         // eigenvalue k lies below x_sub iff cnt > k; the first such interior point of the group closes the new interval from above
         const unsigned long long bal = __ballot(cnt > k && g < GPW);
-        const unsigned grp = (unsigned)((bal >> (min(g, GPW - 1) * LPE)) & 0x3full);
+        const unsigned grp = (unsigned)((bal >> (min(g, GPW - 1) * LPE)) & ((1ull << LPE) - 1ull));
         const int f = grp ? (__ffs((int)grp) - 1) : LPE;      // number of interior points at or below the eigenvalue
         const double nlo = lo + w7 * (double)f, nhi = (f == LPE) ? hi : lo + w7 * (double)(f + 1);
         lo = nlo; hi = nhi;
@@ -237,52 +244,73 @@ __device__ __noinline__ void eig_multisection(const lds_d *dv, const lds_d *e2, 
     if (k < n && g < GPW && sub == 0) lam[k] = 0.5 * (lo + hi);
 }
 
-// Z <- Q Z, Q = H_0 ... H_{n-2} (reflectors below the sub-diagonal of A): four lanes own a column and keep it in
-// registers (rows R = sub + 4 q) for all reflectors, so successive reflectors do not wait on LDS write -> read trips
-__device__ __noinline__ void eig_backtransform(const lds_d *A, lds_d *Z, const lds_d *tauv, int n, int ld, int tid) {
-    const int c = tid >> 2, sub = tid & 3;
-    if (((tid & ~63) >> 2) >= n) return;
-    const int cs = c < n ? c : 0;
-    double z[20];
+// Reflector i of the tridiagonalisation (v[i+1] = 1 implicit, v[i+2 .. n-1] stored) lives packed, reflector after reflector
+__device__ __forceinline__ int refl_off(int i, int n) { return i * (n - 2) - (i * (i - 1)) / 2; }
+
+// Z <- Q Z, Q = H_0 ... H_{n-2}: LPC lanes own a column and keep it in registers (rows R = sub + LPC q) for all reflectors, so
+// successive reflectors do not wait on LDS write -> read trips.  512 threads: four lanes per column, 16 columns per wavefront; 256
+// threads: three lanes per column, 21 columns per wavefront (lane 63 idle).
+template <int LPC>
+__device__ __noinline__ void eig_backtransform(const lds_d *Hq, lds_d *Z, const lds_d *tauv, int n, int ld, int tid) {
+    constexpr int CPW = 64 / LPC, RPL = (MARG_MAX_N + LPC - 1) / LPC;
+    const int lane = tid & 63, wave = tid >> 6, gl = lane / LPC, sub = lane - gl * LPC;
+    if (wave * CPW >= n) return;
+    const int c = wave * CPW + gl;
+    const bool own = gl < CPW && c < n;
+    const int cs = own ? c : 0;
+    const int l0 = min(lane - sub, 63), l1 = min(lane - sub + 1, 63), l2 = min(lane - sub + 2, 63);
+    double z[RPL];
 #pragma unroll
     // all LDS loads are unconditional (clamped row) and masked afterwards: a conditional load becomes an exec-mask
     // branch with its own wait, which serialises the loads at full LDS latency
-    for (int q = 0; q < 20; q++) { const int R = sub + 4 * q; const double t = Z[min(R, n - 1) * ld + cs]; z[q] = (R < n) ? t : 0.0; }
+    for (int q = 0; q < RPL; q++) { const int R = sub + LPC * q; const double t = Z[min(R, n - 1) * ld + cs]; z[q] = (R < n) ? t : 0.0; }
     // reflector i is zero above row i + 1: the late reflectors (applied first) only touch the lower rows, so the register slots
-    // q < Q0 (rows < 4 Q0 <= i + 1) are skipped in four static regimes -- same sums, bit for bit (the skipped terms are exact zeros)
+    // q < Q0 (rows < LPC Q0 <= i + 1) are skipped in four static regimes -- same sums, bit for bit (the skipped terms are exact zeros)
 #define TCV_BT_BODY(Q0)                                                                                      \
     do {                                                                                                     \
-        double v[20], sum = 0;                                                                               \
-        _Pragma("unroll") for (int q = Q0; q < 20; q++) v[q] = A[min(sub + 4 * q, n - 1) * ld + i];         \
-        _Pragma("unroll") for (int q = Q0; q < 20; q++) {                                                    \
-            const int R = sub + 4 * q;                                                                       \
+        double v[RPL], sum = 0;                                                                              \
+        _Pragma("unroll") for (int q = Q0; q < RPL; q++) v[q] = hv[max(0, min(sub + LPC * q - i - 2, len - 1))];   \
+        _Pragma("unroll") for (int q = Q0; q < RPL; q++) {                                                   \
+            const int R = sub + LPC * q;                                                                     \
             v[q] = (R > i + 1 && R < n) ? v[q] : ((R == i + 1) ? 1.0 : 0.0);                                 \
             sum += v[q] * z[q];                                                                              \
         }                                                                                                    \
-        sum += __shfl_xor(sum, 1);                                                                           \
-        sum += __shfl_xor(sum, 2);                                                                           \
+        if (LPC == 4) {                                                                                      \
+            sum += __shfl_xor(sum, 1);                                                                       \
+            sum += __shfl_xor(sum, 2);                                                                       \
+        } else {                                                                                             \
+            const double s0 = __shfl(sum, l0), s1 = __shfl(sum, l1), s2 = __shfl(sum, l2);                   \
+            sum = (s0 + s1) + s2;                                                                            \
+        }                                                                                                    \
         const double w = tau * sum;                                                                          \
-        _Pragma("unroll") for (int q = Q0; q < 20; q++) z[q] -= v[q] * w;                                    \
+        _Pragma("unroll") for (int q = Q0; q < RPL; q++) z[q] -= v[q] * w;                                   \
     } while (0)
+    constexpr int QA = (3 * RPL) / 4, QB = RPL / 2, QC = RPL / 4;
     for (int i = n - 2; i >= 0; i--) {
         const double tau = tauv[i];
         if (tau == 0.0) continue;
-        if (i + 1 >= 60) TCV_BT_BODY(15);
-        else if (i + 1 >= 40) TCV_BT_BODY(10);
-        else if (i + 1 >= 20) TCV_BT_BODY(5);
+        const lds_d *hv = Hq + refl_off(i, n);
+        const int len = n - 2 - i;
+        if (i + 1 >= LPC * QA) TCV_BT_BODY(QA);
+        else if (i + 1 >= LPC * QB) TCV_BT_BODY(QB);
+        else if (i + 1 >= LPC * QC) TCV_BT_BODY(QC);
         else TCV_BT_BODY(0);
     }
 #undef TCV_BT_BODY
-    if (c < n) {
+    if (own) {
 #pragma unroll
-        for (int q = 0; q < 20; q++) { const int R = sub + 4 * q; if (R < n) Z[R * ld + c] = z[q]; }
+        for (int q = 0; q < RPL; q++) { const int R = sub + LPC * q; if (R < n) Z[R * ld + c] = z[q]; }
     }
 }
 
 __device__ __forceinline__ double rank2(double a, double vr, double wc, double wr, double vc) { return a - (vr * wc + wr * vc); }
-__device__ __noinline__ bool sym_eig_tridiag(lds_d *A, lds_d *Z, lds_d *W, lds_d *sm, lds_d *lam, int n, int ld, int tid, gbl_d *dbg) {
-    constexpr int NT = MARG_NT, NW = MARG_NT / 64;
+template <int NT>
+__device__ __noinline__ bool sym_eig_tridiag(lds_d *A, lds_d *Hq, lds_d *sm, lds_d *lam, int n, int ld, int tid, gbl_d *dbg) {
+    constexpr int NW = NT / 64;
+    lds_d *Z = A;                          // the eigenvectors overwrite the matrix: after the tridiagonalisation only T (dv, ev), the
+                                           // reflectors (packed in Hq) and tau are needed
     lds_d *dv = sm, *ev = sm + 80, *tauv = sm + 160, *vbuf = sm + 240, *pbuf = sm + 320, *red = sm + 400, *e2 = sm + 416;
+    lds_d *ubuf = sm + 512, *xold = sm + 608, *xnb = sm + 704;
     const int lane = tid & 63, wave = tid >> 6;
     double trace = 0;
     for (int i = 0; i < n; i++) trace += A[i * ld + i];
@@ -298,30 +326,31 @@ __device__ __noinline__ bool sym_eig_tridiag(lds_d *A, lds_d *Z, lds_d *W, lds_d
     // beta, tau and v = (x - beta e1) / (alpha - beta) need no extra pass: A22 v = (u - beta A22[:,0]) / (alpha - beta).
     // The product u = A22 x of step i + 1 is formed inside the rank-2 update of step i (every thread derives the entries of the next
     // x -- the updated first row of A22 -- it needs from the old row, v and w), so a step is: scalars + v, p | barrier | update with
-    // the next product | barrier.  Only step 0 runs the product on its own.
-    lds_d *ubuf = W, *xold = W + 96, *xnb = W + 192;      // W (n x ld workspace) is free until the eigenvector stage
+    // the next product | barrier.  Only step 0 runs the product on its own.  The reflectors go to Hq (packed) as they are formed.
     {
         const int m = n - 1;
-        const int r = tid >> 2, part = tid & 3;
+        const int part = tid & 3;
         const lds_d *xrow = A + 1;
-        double u = 0, xn2 = 0;
-        const lds_d *row = A + (1 + (r < m ? r : 0)) * ld + 1;
+        for (int r = tid >> 2; r < ((m + 3) & ~3); r += NT / 4) {
+            double u = 0, xn2 = 0;
+            const lds_d *row = A + (1 + (r < m ? r : 0)) * ld + 1;
 #pragma unroll
-        for (int j0 = 0; j0 < 20; j0 += 5) {
-            if (part + 4 * j0 >= m) break;
-            double rv[5], xv[5];
+            for (int j0 = 0; j0 < 20; j0 += 5) {
+                if (part + 4 * j0 >= m) break;
+                double rv[5], xv[5];
 #pragma unroll
-            for (int j = 0; j < 5; j++) { const int c = min(part + 4 * (j0 + j), m - 1); rv[j] = row[c]; xv[j] = xrow[c]; }
+                for (int j = 0; j < 5; j++) { const int c = min(part + 4 * (j0 + j), m - 1); rv[j] = row[c]; xv[j] = xrow[c]; }
 #pragma unroll
-            for (int j = 0; j < 5; j++) {
-                const int c = part + 4 * (j0 + j);
-                if (c < m) { u += rv[j] * xv[j]; if (c > 0) xn2 += xv[j] * xv[j]; }
+                for (int j = 0; j < 5; j++) {
+                    const int c = part + 4 * (j0 + j);
+                    if (c < m) { u += rv[j] * xv[j]; if (c > 0) xn2 += xv[j] * xv[j]; }
+                }
             }
+            u += __shfl_xor(u, 1); u += __shfl_xor(u, 2);
+            xn2 += __shfl_xor(xn2, 1); xn2 += __shfl_xor(xn2, 2);
+            if (r < m && part == 0) ubuf[r] = u;
+            if (tid == 0) xnb[0] = xn2;
         }
-        u += __shfl_xor(u, 1); u += __shfl_xor(u, 2);
-        xn2 += __shfl_xor(xn2, 1); xn2 += __shfl_xor(xn2, 2);
-        if (r < m && part == 0) ubuf[r] = u;
-        if (tid == 0) xnb[0] = xn2;
         __syncthreads();
     }
     for (int i = 0; i + 1 < n; i++) {
@@ -360,7 +389,8 @@ __device__ __noinline__ bool sym_eig_tridiag(lds_d *A, lds_d *Z, lds_d *W, lds_d
         {
             const double K = -0.5 * tau * (red[0] + red[1]);
             const double v0 = vbuf[0], w0 = pbuf[0] + K * v0;
-            // A22 -= v w' + w v',  w = p + K v ; eight lanes per row.  Column i keeps the reflector for the back-transform.
+            lds_d *hq = Hq + refl_off(i, n);
+            // A22 -= v w' + w v',  w = p + K v ; eight lanes per row.  The reflector goes to its packed slot for the back-transform.
             // Next step: x' = new A22[0][1:], u'_(rr-1) = sum_(c >= 1) new A22[rr][c] x'[c], |x'[1:]|^2.
             const int part8 = tid & 7;
             for (int rr = tid >> 3; rr < ((m + 7) & ~7); rr += NT / 8) {
@@ -386,7 +416,7 @@ __device__ __noinline__ bool sym_eig_tridiag(lds_d *A, lds_d *Z, lds_d *W, lds_d
                 x2 += __shfl_xor(x2, 1); x2 += __shfl_xor(x2, 2); x2 += __shfl_xor(x2, 4);
                 if (part8 == 0 && rr >= 1 && rr < m) ubuf[rr - 1] = un;
                 if (part8 == 0 && rr == 1) xnb[(i + 1) & 1] = x2;
-                if (part8 == 0 && rr > 0 && rr < m) A[(i + 1 + rr) * ld + i] = vr;
+                if (part8 == 0 && rr > 0 && rr < m) hq[rr - 1] = vr;
             }
         }
         __syncthreads();
@@ -406,11 +436,12 @@ __device__ __noinline__ bool sym_eig_tridiag(lds_d *A, lds_d *Z, lds_d *W, lds_d
     gl -= 2.2e-16 * tnorm * n + pivmin; gu += 2.2e-16 * tnorm * n + pivmin;
     __syncthreads();
     EMARK(0);
-    // ---- (2) eigenvalues by multisection, four lanes per eigenvalue
-    eig_multisection(dv, e2, lam, n, gl, gu, pivmin, tid);
+    // ---- (2) eigenvalues by multisection
+    if (NT >= 512) eig_multisection<6, 10, 22>(dv, e2, lam, n, gl, gu, pivmin, tid);
+    else eig_multisection<3, 21, 31>(dv, e2, lam, n, gl, gu, pivmin, tid);
     __syncthreads();
     EMARK(1);
-    // ---- (3) eigenvectors of T: twisted factorisation, one lane per eigenvector (column k of Z / W as workspace)
+    // ---- (3) eigenvectors of T: twisted factorisation, one lane per eigenvector (column k of Z as workspace)
     // eigenvalues <= eps are zeroed by the thresholding of marginalization_factor.cpp:284-293: their vectors are never
     // used, and inside that (possibly large, rank-deficient) null cluster they are not even defined -> zero columns
     if (tid < n && !(lam[tid] > 1e-8)) {
@@ -426,17 +457,28 @@ __device__ __noinline__ bool sym_eig_tridiag(lds_d *A, lds_d *Z, lds_d *W, lds_d
             if (fabs(dp) < pivmin) dp = -pivmin;
             Z[(i + 1) * ld + k] = dp;
         }
+        // backward pivots D-: the first pass finds the twist index (smallest |gamma|), the second one -- the same recurrence, bit for
+        // bit -- leaves D-_(rbest+1 .. n-1) in the rows of the column that D+ no longer needs (a second n x n workspace would not fit
+        // an 80 KB workgroup)
         double dm = dv[n - 1] - l;
         if (fabs(dm) < pivmin) dm = -pivmin;
-        W[(n - 1) * ld + k] = dm;
         double gbest = fabs(Z[(n - 1) * ld + k] + dm - (dv[n - 1] - l));
         int rbest = n - 1;
         for (int i = n - 2; i >= 0; i--) {
             dm = fma(-e2[i], fast_rcp(dm), dv[i] - l);
             if (fabs(dm) < pivmin) dm = -pivmin;
-            W[i * ld + k] = dm;
             const double g = fabs(Z[i * ld + k] + dm - (dv[i] - l));
             if (g < gbest) { gbest = g; rbest = i; }
+        }
+        if (rbest < n - 1) {
+            dm = dv[n - 1] - l;
+            if (fabs(dm) < pivmin) dm = -pivmin;
+            Z[(n - 1) * ld + k] = dm;
+            for (int i = n - 2; i > rbest; i--) {
+                dm = fma(-e2[i], fast_rcp(dm), dv[i] - l);
+                if (fabs(dm) < pivmin) dm = -pivmin;
+                Z[i * ld + k] = dm;
+            }
         }
         double z = 1.0, nrm2 = 1.0;
         for (int i = rbest - 1; i >= 0; i--) {          // z_i = -(e_i / D+_i) z_{i+1}
@@ -446,7 +488,7 @@ __device__ __noinline__ bool sym_eig_tridiag(lds_d *A, lds_d *Z, lds_d *W, lds_d
         }
         z = 1.0;
         for (int i = rbest; i + 1 < n; i++) {           // z_{i+1} = -(e_i / D-_{i+1}) z_i
-            z = -ev[i] * fast_rcp(W[(i + 1) * ld + k]) * z;
+            z = -ev[i] * fast_rcp(Z[(i + 1) * ld + k]) * z;
             Z[(i + 1) * ld + k] = z;
             nrm2 += z * z;
         }
@@ -483,7 +525,7 @@ __device__ __noinline__ bool sym_eig_tridiag(lds_d *A, lds_d *Z, lds_d *W, lds_d
     __syncthreads();
     EMARK(3);
     // ---- (5) back-transformation Z <- Q Z
-    eig_backtransform(A, Z, tauv, n, ld, tid);
+    eig_backtransform<(NT >= 512 ? 4 : 3)>(Hq, Z, tauv, n, ld, tid);
     __syncthreads();
     EMARK(4);
     // ---- checks: sum lambda = trace, and (Z_R' Z_R) w = w for two probe vectors w over the retained columns R
@@ -526,7 +568,8 @@ __device__ __noinline__ bool sym_eig_tridiag(lds_d *A, lds_d *Z, lds_d *W, lds_d
 #else
 #define MARG_MARK(id) do { } while (0)
 #endif
-__global__ void __launch_bounds__(MARG_NT) marg_kernel(MargArgs Aarg) {
+template <int MARG_NT>
+__global__ void __launch_bounds__(MARG_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) marg_kernel(MargArgs Aarg) {
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
     lds_d *lds = (lds_d *)lds_raw;
     const int tid = threadIdx.x;
@@ -538,19 +581,22 @@ __global__ void __launch_bounds__(MARG_NT) marg_kernel(MargArgs Aarg) {
         cst_d *dp = (cst_d *)Aarg.dpool + H.dbase;
         const int pos = H.pos, m = H.m, n = H.n;
         const int npk = pos * (pos + 1) / 2;
-        // LDS carve
-        lds_d *Apk = lds;                                   // packed lower triangle of A (later: V2)
+        // LDS carve (marg_lds_doubles() on the host is the same sum).  P: the prior's J0 while J0'J0 is formed, then the packed lower
+        // triangle of A, then A' and finally its eigenvectors V2.  R2: the factor staging records, then Amm + V, then the reflectors of
+        // the tridiagonalisation of A'.
+        lds_d *Apk = lds;
         const int me = m + (m & 1), ne = n + (n & 1);
         const int r1 = max(npk, ne * (ne + 1));
-        lds_d *R2 = lds + ((r1 + 1) & ~1);                  // Amm + V (later A')
-        const int r2 = max(2 * me * (me + 1), ne * (ne + 1));
+        lds_d *R2 = lds + ((r1 + 1) & ~1);
+        const int r2 = max(max((int)MARG_STAGE, 2 * me * (me + 1)), (n - 2) * (n - 1) / 2 + 1);
         lds_d *bv = R2 + ((r2 + 1) & ~1);                   // pos
         lds_d *x = bv + MARG_MAX_POS;                       // nx
         lds_d *rot = x + ((H.nx + 7) & ~7);                 // 160
         lds_d *lam = rot + 160;                             // MARG_MAX_N
         lds_d *cvec = lam + MARG_MAX_N;                     // block mode: the current landmark's coupling to the camera columns
         lds_d *lmacc = cvec + MARG_MAX_POS;                 // its diagonal and gradient
-        lds_d *stage = lmacc + 8;                           // 64 proj records or 1 imu record
+        lds_d *sm = lmacc + 8;                              // MARG_SM: vectors of the eigen-solver; the prior's dx and residual before
+        lds_d *stage = R2;                                  // 64 proj records or 1 imu record
         lds_i *cnt = (lds_i *)(rot + 158);
         gbl_d *out = (gbl_d *)Aarg.out + (size_t)win * MARG_OUT_STRIDE;
         long long t_last = clock64();
@@ -564,7 +610,6 @@ __global__ void __launch_bounds__(MARG_NT) marg_kernel(MargArgs Aarg) {
                                 ? ((const gbl_d *)Aarg.solve_state)[(size_t)H.solve_window * Aarg.state_stride + xs + i]
                                 : dp[H.d_x + go + i];
         }
-        for (int i = tid; i < npk; i += MARG_NT) Apk[i] = 0.0;
         for (int i = tid; i < pos; i += MARG_NT) { bv[i] = 0.0; cvec[i] = 0.0; }
         if (tid < 8) lmacc[tid] = 0.0;
         cst_d *misc = dp + H.d_misc;
@@ -572,11 +617,12 @@ __global__ void __launch_bounds__(MARG_NT) marg_kernel(MargArgs Aarg) {
         __syncthreads();
 
         MARG_MARK(0);
-        // ---- prior factor (MarginalizationFactor::Evaluate, :335-384)
+        // ---- prior factor (MarginalizationFactor::Evaluate, :335-384): the first contribution to A and b
+        bool a_zeroed = false;
         if (H.prior_n > 0) {
             const int np = H.prior_n;
             cst_d *J0 = dp + H.d_prior, *r0 = J0 + np * np, *x0 = r0 + np;
-            gbl_d *pdx = scr + MARG_SCR_PR, *pr = pdx + 128;
+            lds_d *pdx = sm, *pr = sm + 128;
             if (tid < H.prior_nblk) {
                 cst_i *pb = ip + H.o_prior + tid * 4;
                 const int gs = pb[2], ls = gs == 7 ? 6 : gs;
@@ -586,55 +632,84 @@ __global__ void __launch_bounds__(MARG_NT) marg_kernel(MargArgs Aarg) {
                 for (int i = 0; i < 16; i++) if (i < ls) pdx[pb[1] + i] = dxv[i];
             }
             cst_i *pcol = ip + H.o_pcol;
-            // J0 (np x np, column-major) staged in R2 (free until Amm is formed): r = r0 + J0 dx, J0' J0 and J0' r run out of LDS
-            const bool in_lds = np * np <= r2;
+            // J0 (np x np, column-major) staged in P (A is not started yet): r = r0 + J0 dx, J0' J0 and J0' r run out of LDS, the
+            // products wait in registers until the barrier after which P becomes the packed A
+            const bool in_lds = np <= MARG_MAX_N && np * np <= r1;
+            lds_d *Js = Apk;
             if (in_lds) {
                 for (int e = tid; e < np * np; e += 4 * MARG_NT) {
                     double v4[4];
 #pragma unroll
                     for (int k = 0; k < 4; k++) if (e + k * MARG_NT < np * np) v4[k] = J0[e + k * MARG_NT];
 #pragma unroll
-                    for (int k = 0; k < 4; k++) if (e + k * MARG_NT < np * np) R2[e + k * MARG_NT] = v4[k];
+                    for (int k = 0; k < 4; k++) if (e + k * MARG_NT < np * np) Js[e + k * MARG_NT] = v4[k];
                 }
+            } else {
+                for (int i = tid; i < npk; i += MARG_NT) Apk[i] = 0.0;
+                a_zeroed = true;
             }
             __syncthreads();
             if (tid < np) {
                 double r = r0[tid];
-                if (in_lds) for (int j = 0; j < np; j++) r += R2[tid + np * j] * pdx[j];
+                if (in_lds) for (int j = 0; j < np; j++) r += Js[tid + np * j] * pdx[j];
                 else for (int j = 0; j < np; j++) r += J0[tid + np * j] * pdx[j];
                 pr[tid] = r;
             }
             __syncthreads();
             if (in_lds) {
-                // J0' J0 on the matrix cores: 16 x 16 output tiles of the lower triangle, one per wavefront at a time,
-                // v_mfma_f64_16x16x4 over the rows of J0 (column-major in LDS: J0[i + np a]); rows beyond np contribute zeros
+                // J0' J0 on the matrix cores: 16 x 16 output tiles of the lower triangle (at most 15 for np <= 80: four per wavefront
+                // with 256 threads), v_mfma_f64_16x16x4 over the rows of J0 (column-major in LDS: J0[i + np a]); rows beyond np contribute zeros
                 typedef double v4f64 __attribute__((ext_vector_type(4)));
+                constexpr int NWV = MARG_NT / 64;
                 const int nt16 = (np + 15) >> 4, lane = tid & 63, wave = tid >> 6;
                 const int m16 = lane & 15, k4 = lane >> 4;
-                for (int t = wave; t < nt16 * (nt16 + 1) / 2; t += MARG_NT / 64) {
-                    int ta = 0;
-                    while ((ta + 1) * (ta + 2) / 2 <= t) ta++;
-                    const int tb = t - ta * (ta + 1) / 2;
-                    const int a = 16 * ta + m16, b = 16 * tb + m16;
-                    const lds_d *ca = R2 + np * min(a, np - 1), *cb = R2 + np * min(b, np - 1);
+                v4f64 accs[4];
+#pragma unroll
+                for (int slot = 0; slot < 4; slot++) {
+                    const int t = wave + slot * NWV;
                     v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-                    for (int i0 = 0; i0 < np; i0 += 16) {
-                        double av[4], bv[4];
+                    if (t < nt16 * (nt16 + 1) / 2) {
+                        int ta = 0;
+                        while ((ta + 1) * (ta + 2) / 2 <= t) ta++;
+                        const int tb = t - ta * (ta + 1) / 2;
+                        const int a = 16 * ta + m16, b = 16 * tb + m16;
+                        const lds_d *ca = Js + np * min(a, np - 1), *cb = Js + np * min(b, np - 1);
+                        for (int i0 = 0; i0 < np; i0 += 16) {
+                            double av[4], bv4[4];
 #pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            const int i = i0 + 4 * u + k4;
-                            const double x = ca[min(i, np - 1)], y = cb[min(i, np - 1)];
-                            av[u] = (i < np && a < np) ? x : 0.0; bv[u] = (i < np && b < np) ? y : 0.0;
+                            for (int u = 0; u < 4; u++) {
+                                const int i = i0 + 4 * u + k4;
+                                const double xa = ca[min(i, np - 1)], y = cb[min(i, np - 1)];
+                                av[u] = (i < np && a < np) ? xa : 0.0; bv4[u] = (i < np && b < np) ? y : 0.0;
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv4[u], acc, 0, 0, 0);
                         }
-#pragma unroll
-                        for (int u = 0; u < 4; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
                     }
+                    accs[slot] = acc;
+                }
+                double s2 = 0;
+                const bool mine = tid < np && pcol[min(tid, np - 1)] >= 0;
+                if (mine) for (int i = 0; i < np; i++) s2 += Js[i + np * tid] * pr[i];
+                __syncthreads();      // every read of the staged J0 is done: P becomes A
+                for (int i = tid; i < npk; i += MARG_NT) Apk[i] = 0.0;
+                a_zeroed = true;
+                __syncthreads();
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {      // acc[i] = G[16 ta + 4 i + k4][16 tb + m16]
-                        const int ga = 16 * ta + 4 * i + k4, gb = 16 * tb + m16;
-                        if (ga < np && gb <= ga) { const int ia = pcol[ga], ib = pcol[gb]; if (ia >= 0 && ib >= 0) Apk[pidx(ia, ib)] += acc[i]; }
+                for (int slot = 0; slot < 4; slot++) {
+                    const int t = wave + slot * NWV;
+                    if (t < nt16 * (nt16 + 1) / 2) {
+                        int ta = 0;
+                        while ((ta + 1) * (ta + 2) / 2 <= t) ta++;
+                        const int tb = t - ta * (ta + 1) / 2;
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {      // acc[i] = G[16 ta + 4 i + k4][16 tb + m16]
+                            const int ga = 16 * ta + 4 * i + k4, gb = 16 * tb + m16;
+                            if (ga < np && gb <= ga) { const int ia = pcol[ga], ib = pcol[gb]; if (ia >= 0 && ib >= 0) Apk[pidx(ia, ib)] += accs[slot][i]; }
+                        }
                     }
                 }
+                if (mine) bv[pcol[tid]] += s2;
             } else {
                 for (int e = tid; e < np * np; e += MARG_NT) {
                     const int a = e / np, b = e - a * np;
@@ -645,13 +720,16 @@ __global__ void __launch_bounds__(MARG_NT) marg_kernel(MargArgs Aarg) {
                     for (int i = 0; i < np; i++) s0 += J0[i + np * a] * J0[i + np * b];
                     Apk[pidx(ia, ib)] += s0;
                 }
+                if (tid < np && pcol[tid] >= 0) {
+                    double s2 = 0;
+                    for (int i = 0; i < np; i++) s2 += J0[i + np * tid] * pr[i];
+                    bv[pcol[tid]] += s2;
+                }
             }
-            if (tid < np && pcol[tid] >= 0) {
-                double s2 = 0;
-                if (in_lds) for (int i = 0; i < np; i++) s2 += R2[i + np * tid] * pr[i];
-                else for (int i = 0; i < np; i++) s2 += J0[i + np * tid] * pr[i];
-                bv[pcol[tid]] += s2;
-            }
+            __syncthreads();
+        }
+        if (!a_zeroed) {
+            for (int i = tid; i < npk; i += MARG_NT) Apk[i] = 0.0;
             __syncthreads();
         }
         MARG_MARK(1);
@@ -660,11 +738,13 @@ __global__ void __launch_bounds__(MARG_NT) marg_kernel(MargArgs Aarg) {
             cst_i *b = ip + H.o_imu + f * 4;
             lds_d *S = stage + 1500;
             if (tid < 16) (void)imu_sqrt_info_group((const double *)(dp + H.d_imu + f * IMU_CONST + IMU_COV), GEN(S), GEN(stage + 512), GEN(stage + 512 + 225), tid);
-            if ((tid & 63) == 0 && tid >= 64 && tid < 64 * 5) {      // lane 0 of waves 1..4: the four parts of the raw residual / Jacobian
+            // the four parts of the raw residual / Jacobian on four wavefronts: lane 0 of waves 1..4, or (256 threads) lane 32 of waves 0..3
+            constexpr int RW0 = MARG_NT >= 320 ? 1 : 0, RLANE = MARG_NT >= 320 ? 0 : 32;
+            if ((tid & 63) == RLANE && (tid >> 6) >= RW0 && (tid >> 6) < RW0 + 4) {
                 double cst[62];
 #pragma unroll
                 for (int i = 0; i < 62; i++) cst[i] = dp[H.d_imu + f * IMU_CONST + i];
-                imu_raw_part((tid >> 6) - 1, CGEN(x + blk[b[0] * 5 + 1]), CGEN(x + blk[b[1] * 5 + 1]), CGEN(x + blk[b[2] * 5 + 1]),
+                imu_raw_part((tid >> 6) - RW0, CGEN(x + blk[b[0] * 5 + 1]), CGEN(x + blk[b[1] * 5 + 1]), CGEN(x + blk[b[2] * 5 + 1]),
                              CGEN(x + blk[b[3] * 5 + 1]), cst, G3, GEN(stage), IMU_STRIDE_J, true);
             }
             __syncthreads();
@@ -788,7 +868,7 @@ __global__ void __launch_bounds__(MARG_NT) marg_kernel(MargArgs Aarg) {
         lds_d *Mm = R2, *Vm = R2 + me * ldm;
         for (int i = tid; i < m * m; i += MARG_NT) { const int r = i / m, c = i - r * m; Mm[r * ldm + c] = Apk[pidx(r, c)]; }
         __syncthreads();
-        const int sweeps1 = jacobi_eig(Mm, Vm, m, ldm, rot, cnt, tid, 0.0);
+        const int sweeps1 = jacobi_eig<MARG_NT, lds_d>(Mm, Vm, m, ldm, rot, cnt, tid, 0.0);
         MARG_MARK(4);
         if (tid < m) { const double l = Mm[tid * ldm + tid]; lam[tid] = l > 1e-8 ? sqrt(1.0 / l) : 0.0; }
         __syncthreads();
@@ -807,9 +887,9 @@ __global__ void __launch_bounds__(MARG_NT) marg_kernel(MargArgs Aarg) {
         }
         __syncthreads();
         MARG_MARK(5);
-        // A' = Arr - Z'Z, b' = brr - Z' zb
+        // A' = Arr - Z'Z, b' = brr - Z' zb: held in registers until every read of the packed A is done, then written over it
         const int ldn = ne + 1;
-        lds_d *As = R2, *V2 = Apk;
+        lds_d *As = Apk, *V2 = Apk;
         double keepA[ (MARG_MAX_N * MARG_MAX_N + MARG_NT - 1) / MARG_NT ];
         {
             int q = 0;
@@ -825,7 +905,7 @@ __global__ void __launch_bounds__(MARG_NT) marg_kernel(MargArgs Aarg) {
             bprime = bv[m + tid];
             for (int k = 0; k < m; k++) bprime -= Z[k * n + tid] * zb[k];
         }
-        __syncthreads();   // every read of Vm / Apk is done: R2 and Apk can be overwritten
+        __syncthreads();   // every read of Vm / Apk is done: P and R2 can be overwritten
         {
             int q = 0;
             for (int e = tid; e < n * n; e += MARG_NT, q++) {
@@ -837,19 +917,22 @@ __global__ void __launch_bounds__(MARG_NT) marg_kernel(MargArgs Aarg) {
         if (tid < n) { bv[tid] = bprime; out[MARG_OUT_BS + tid] = bprime; }
         __syncthreads();
         MARG_MARK(6);
-        // A' = V2 diag(lam) V2': tridiagonal path first, Jacobi sweep as the safety net
+        // A' = V2 diag(lam) V2': tridiagonal path first, Jacobi sweep as the safety net (its eigenvector matrix in HBM scratch, copied
+        // over the diagonalised A' at the end: the LDS holds one n x n matrix)
         lds_d *evals = lam;
         int sweeps2 = 0;
         {
-            lds_d *sm = stage, *Wk = stage + 512;
-            const bool ok = sym_eig_tridiag(As, V2, Wk, sm, rot, n, ldn, tid, out + MARG_OUT_X + MARG_MAX_X + 14);    // rot: 160 doubles >= n eigenvalues
+            const bool ok = sym_eig_tridiag<MARG_NT>(As, R2, sm, rot, n, ldn, tid, out + MARG_OUT_X + MARG_MAX_X + 14);    // rot: 160 doubles >= n eigenvalues
             if (ok) {
                 if (tid < n) lam[tid] = rot[tid];
             } else {
+                gbl_d *Vg = scr + MARG_SCR_V;
                 for (int e = tid; e < n * n; e += MARG_NT) { const int i2 = e / n, j2 = e - i2 * n; As[i2 * ldn + j2] = out[MARG_OUT_AS + i2 * n + j2]; }
                 __syncthreads();
-                sweeps2 = 100 + jacobi_eig(As, V2, n, ldn, rot, cnt, tid, 2.3e-16, out + MARG_OUT_X + MARG_MAX_X + 2 + 9);
+                sweeps2 = 100 + jacobi_eig<MARG_NT, gbl_d>(As, Vg, n, ldn, rot, cnt, tid, 2.3e-16, out + MARG_OUT_X + MARG_MAX_X + 2 + 9);
                 if (tid < n) lam[tid] = As[tid * ldn + tid];
+                __syncthreads();
+                for (int e = tid; e < n * n; e += MARG_NT) { const int i2 = e / n, j2 = e - i2 * n; V2[i2 * ldn + j2] = Vg[i2 * ldn + j2]; }
             }
         }
         MARG_MARK(7);
@@ -893,7 +976,7 @@ struct MargState {
     double *d_dpool = nullptr, *d_out = nullptr, *d_scratch = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     size_t lds_bytes = 0;
-    int grid = 0;
+    int grid = 0, nt = MARG_NT_WIDE;
     bool ran = false;
     std::vector<double> h_out;        // host copy of every window's result block (tcv_batch_download_priors), valid until the next run
     std::vector<int> h_status;
@@ -911,13 +994,13 @@ static void marg_free(tcv_batch *b) {
     b->marg = nullptr;
 }
 
-// LDS doubles one window needs: [packed A | Amm + V, later A' | b | x | rot | lam | landmark row | staging]; the tridiagonal
-// eigen-solver of A' puts 512 doubles of vectors and an n x (ne + 1) workspace where the staging records were
+// LDS doubles one window needs (the kernel's carve): [P: packed A, later A' and its eigenvectors | R2: staging records (64 x 43: a
+// ProjectionTdFactor record is 2 x 21 + 1), later Amm + V, later the packed reflectors | b | x | rot | lam | landmark row | eigen vectors]
 static size_t marg_lds_doubles(int pos, int m, int n, int nx) {
     const int me = m + (m & 1), ne = n + (n & 1);
-    const int r1 = std::max(pos * (pos + 1) / 2, ne * (ne + 1)), r2 = std::max(2 * me * (me + 1), ne * (ne + 1));
-    const size_t before_stage = (size_t)((r1 + 1) & ~1) + ((r2 + 1) & ~1) + MARG_MAX_POS + ((nx + 7) & ~7) + 160 + MARG_MAX_N + MARG_MAX_POS + 8;
-    return before_stage + std::max<size_t>(64 * 43, 512 + (size_t)n * (ne + 1));      // 43: a ProjectionTdFactor record (2 x 21 + 1)
+    const int r1 = std::max(pos * (pos + 1) / 2, ne * (ne + 1));
+    const int r2 = std::max(std::max((int)MARG_STAGE, 2 * me * (me + 1)), (n - 2) * (n - 1) / 2 + 1);
+    return (size_t)((r1 + 1) & ~1) + ((r2 + 1) & ~1) + MARG_MAX_POS + ((nx + 7) & ~7) + 160 + MARG_MAX_N + MARG_MAX_POS + 8 + MARG_SM;
 }
 
 static int pack_marg(const tcv_problem &p, double *const *drop, int ndrop, const tcv_problem *solve_p, const Packed *solve_pk,
@@ -1106,14 +1189,20 @@ int tcv_marg_attach(tcv_batch *b, tcv_problem *const *marg_problems, double *con
         const size_t need = marg_lds_doubles(pos, m, n, hdrs[w].nx) * 8;
         if (need > (size_t)LDS_DOUBLES * 8) { set_error("marginalisation does not fit LDS"); return TCV_ERR_TOO_LARGE; }
         lds = std::max(lds, need);
-        lds = (size_t)LDS_DOUBLES * 8;      // the eigen-solver's workspace uses everything behind the staging area
     }
     s->lds_bytes = lds;
     hipDeviceProp_t prop;
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return TCV_ERR_HIP;
-    s->grid = std::min(b->n, prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
+    const int n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    // more windows than CUs and every window within half a CU's LDS: two 256-thread workgroups per CU; otherwise one of 512 threads
+    const char *force = getenv("TCV_MARG_NT");
+    const bool pair = force ? atoi(force) == MARG_NT_PAIR : (b->n > n_cu && lds <= (size_t)LDS_DOUBLES * 4);
+    if (pair && lds > (size_t)LDS_DOUBLES * 4) { set_error("TCV_MARG_NT=256: the batch does not fit 80 KB of LDS per window"); return TCV_ERR_TOO_LARGE; }
+    s->nt = pair ? MARG_NT_PAIR : MARG_NT_WIDE;
+    if (pair) s->lds_bytes = (size_t)LDS_DOUBLES * 4;
+    s->grid = std::min(b->n, pair ? 2 * n_cu : n_cu);
 #define MUP(dst, src, T, cnt)                                                                    \
     do {                                                                                         \
         hipError_t e_ = tcv::dev_malloc((void **)&dst, sizeof(T) * std::max<size_t>(1, (cnt)));        \
@@ -1145,10 +1234,12 @@ int tcv_marg_run(tcv_batch *b, void *stream) {
     a.out_status = s->d_status; a.scratch = s->d_scratch; a.nwin = b->n; a.state_stride = b->state_stride;
     a.use_solved_state = b->solved ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipFuncSetAttribute((const void *)marg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes);
+    const void *fn = s->nt == MARG_NT_PAIR ? (const void *)marg_kernel<MARG_NT_PAIR> : (const void *)marg_kernel<MARG_NT_WIDE>;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(marg)");
     if ((e = hipEventRecord(s->ev0, st)) != hipSuccess) return hip_fail(e, "hipEventRecord");
-    hipLaunchKernelGGL(marg_kernel, dim3(s->grid), dim3(MARG_NT), s->lds_bytes, st, a);
+    if (s->nt == MARG_NT_PAIR) hipLaunchKernelGGL(marg_kernel<MARG_NT_PAIR>, dim3(s->grid), dim3(MARG_NT_PAIR), s->lds_bytes, st, a);
+    else hipLaunchKernelGGL(marg_kernel<MARG_NT_WIDE>, dim3(s->grid), dim3(MARG_NT_WIDE), s->lds_bytes, st, a);
     if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "marg kernel launch");
     if ((e = hipEventRecord(s->ev1, st)) != hipSuccess) return hip_fail(e, "hipEventRecord");
     s->ran = true;
