@@ -64,7 +64,8 @@ struct MargArgs {
     double *out;                 // per window MARG_OUT_STRIDE
     int *out_status;             // per window: 0 ok
     double *scratch;             // per workgroup MARG_SCR_STRIDE
-    int nwin, state_stride, use_solved_state, pad;
+    int nwin, state_stride, use_solved_state;
+    int eig_mm;                  // 1: Amm^+ through the eigen-decomposition for every window (TCV_MARG_EIG_MM=1: A/B checks)
 };
 
 __device__ __forceinline__ int pidx(int a, int b) { return a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a; }
@@ -588,7 +589,7 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((amdgpu_waves_per_eu(2,
         const int me = m + (m & 1), ne = n + (n & 1);
         const int r1 = max(npk, ne * (ne + 1));
         lds_d *R2 = lds + ((r1 + 1) & ~1);
-        const int r2 = max(max((int)MARG_STAGE, 2 * me * (me + 1)), (n - 2) * (n - 1) / 2 + 1);
+        const int r2 = max(max((int)MARG_STAGE, me * (me + 1) + max(me * (me + 1), m * (n + 1))), (n - 2) * (n - 1) / 2 + 1);
         lds_d *bv = R2 + ((r2 + 1) & ~1);                   // pos
         lds_d *x = bv + MARG_MAX_POS;                       // nx
         lds_d *rot = x + ((H.nx + 7) & ~7);                 // 160
@@ -863,47 +864,123 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((amdgpu_waves_per_eu(2,
             }
         }
         MARG_MARK(3);
-        // ---- Amm = V diag(lam) V'
+        // ---- Amm^+ (marginalization_factor.cpp:267-272: eigen-decomposition, eigenvalues <= eps dropped).  When every eigenvalue is
+        // provably above eps the pseudo-inverse IS the inverse, and Arm Amm^-1 Amr = Z'Z with Z = L^-1 Amr from the Cholesky factor
+        // Amm = L L' -- 23 dependent column steps on one wavefront instead of ~100 Jacobi rounds of three barriers each.  Proof of rank
+        // per window: lambda_min >= 1 / trace(Amm^-1) = 1 / |L^-1|_F^2 > eps.  Otherwise (a landmark without parallax, a prior
+        // that does not constrain the dropped pose) the eigen path below runs as before.
         const int ldm = me + 1;
         lds_d *Mm = R2, *Vm = R2 + me * ldm;
+        lds_d *Zl = Vm;                                     // Cholesky path: Z (m x (n + 1), last column L^-1 bmm) in LDS
+        const int zs = n + 1;
         for (int i = tid; i < m * m; i += MARG_NT) { const int r = i / m, c = i - r * m; Mm[r * ldm + c] = Apk[pidx(r, c)]; }
         __syncthreads();
-        const int sweeps1 = jacobi_eig<MARG_NT, lds_d>(Mm, Vm, m, ldm, rot, cnt, tid, 0.0);
-        MARG_MARK(4);
-        if (tid < m) { const double l = Mm[tid * ldm + tid]; lam[tid] = l > 1e-8 ? sqrt(1.0 / l) : 0.0; }
-        __syncthreads();
-        // Z = diag(sqrt(lam^+)) V' Amr  (m x n) and zb = diag(sqrt(lam^+)) V' bmm, kept in global scratch
-        gbl_d *Z = scr + MARG_SCR_Z, *zb = scr + MARG_SCR_PR;
-        for (int e = tid; e < m * n; e += MARG_NT) {
-            const int k = e / n, j = e - k * n;
-            double s = 0;
-            for (int p = 0; p < m; p++) s += Vm[p * ldm + k] * Apk[pidx(m + j, p)];
-            Z[k * n + j] = lam[k] * s;
+        bool chol = Aarg.eig_mm == 0;
+        if (chol) {
+            if (tid < 64) {      // left-looking Cholesky, lane = row; the diagonal keeps 1 / L_kk
+                const int i = min(tid, m - 1);
+                bool ok = true;
+                for (int k = 0; k < m; k++) {
+                    double sv = Mm[i * ldm + k], sd = Mm[k * ldm + k];
+                    for (int p2 = 0; p2 < k; p2++) { const double lk = Mm[k * ldm + p2]; sv -= Mm[i * ldm + p2] * lk; sd -= lk * lk; }
+                    ok = ok && (sd > 0.0) && (sd < 1e300);
+                    const double rs = 1.0 / sqrt(ok ? sd : 1.0);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    if (tid < m && tid > k) Mm[tid * ldm + k] = sv * rs;
+                    if (tid == k) Mm[k * ldm + k] = rs;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                }
+                if (tid == 0) lmacc[2] = ok ? 1.0 : 0.0;
+            }
+            __syncthreads();
+            chol = lmacc[2] != 0.0;
         }
-        if (tid < m) {
-            double s = 0;
-            for (int p = 0; p < m; p++) s += Vm[p * ldm + tid] * bv[p];
-            zb[tid] = lam[tid] * s;
+        if (chol) {
+            // forward substitutions L z = rhs, one thread per right-hand side: the n columns of Amr, bmm, and the m unit vectors whose
+            // solutions give |L^-1|_F^2 (kept in the unused upper triangle of Mm)
+            if (tid < n + 1) {
+                const int j = tid;
+                for (int k = 0; k < m; k++) {
+                    double sv = j < n ? Apk[pidx(m + j, k)] : bv[k];
+                    for (int p2 = 0; p2 < k; p2++) sv -= Mm[k * ldm + p2] * Zl[p2 * zs + j];
+                    Zl[k * zs + j] = sv * Mm[k * ldm + k];
+                }
+            } else if (tid < n + 1 + m) {
+                const int j = tid - n - 1;
+                double y = Mm[j * ldm + j], nn = y * y;       // y_j = 1 / L_jj
+                lds_d *yr = Mm + j * ldm;                       // y_k for k > j at Mm[j][k]
+                for (int k = j + 1; k < m; k++) {
+                    double sv = -Mm[k * ldm + j] * y;
+                    for (int p2 = j + 1; p2 < k; p2++) sv -= Mm[k * ldm + p2] * yr[p2];
+                    sv *= Mm[k * ldm + k];
+                    yr[k] = sv;
+                    nn += sv * sv;
+                }
+                rot[j] = nn;
+            }
+            __syncthreads();
+            double tr = 0, trs = 0;
+            for (int j = 0; j < m; j++) { tr += rot[j]; trs += rot[j] * Apk[pidx(j, j)]; }
+            chol = tr < 1e8;                                    // lambda_min >= 1 / tr > 1e-8 (false for NaN)
+            if (tid == 0) { out[MARG_OUT_X + MARG_MAX_X + 40] = tr; out[MARG_OUT_X + MARG_MAX_X + 41] = trs; }
         }
-        __syncthreads();
-        MARG_MARK(5);
-        // A' = Arr - Z'Z, b' = brr - Z' zb: held in registers until every read of the packed A is done, then written over it
+        int sweeps1 = 0;
         const int ldn = ne + 1;
         lds_d *As = Apk, *V2 = Apk;
         double keepA[ (MARG_MAX_N * MARG_MAX_N + MARG_NT - 1) / MARG_NT ];
-        {
+        double bprime = 0;
+        gbl_d *Z = scr + MARG_SCR_Z, *zb = scr + MARG_SCR_PR;
+        if (chol) {
+            MARG_MARK(4);
+            MARG_MARK(5);
+            // A' = Arr - Z'Z, b' = brr - Z' zb: held in registers until every read of the packed A is done, then written over it
             int q = 0;
             for (int e = tid; e < n * n; e += MARG_NT, q++) {
                 const int i = e / n, j = e - i * n;
-                double s = Apk[pidx(m + i, m + j)];
-                for (int k = 0; k < m; k++) s -= Z[k * n + i] * Z[k * n + j];
-                keepA[q] = s;
+                double sv = Apk[pidx(m + i, m + j)];
+                for (int k = 0; k < m; k++) sv -= Zl[k * zs + i] * Zl[k * zs + j];
+                keepA[q] = sv;
             }
-        }
-        double bprime = 0;
-        if (tid < n) {
-            bprime = bv[m + tid];
-            for (int k = 0; k < m; k++) bprime -= Z[k * n + tid] * zb[k];
+            if (tid < n) {
+                bprime = bv[m + tid];
+                for (int k = 0; k < m; k++) bprime -= Zl[k * zs + tid] * Zl[k * zs + n];
+            }
+        } else {
+            // ---- Amm = V diag(lam) V'
+            if (Aarg.eig_mm == 0) {      // the Cholesky attempt overwrote Mm
+                __syncthreads();
+                for (int i = tid; i < m * m; i += MARG_NT) { const int r = i / m, c2 = i - r * m; Mm[r * ldm + c2] = Apk[pidx(r, c2)]; }
+                __syncthreads();
+            }
+            sweeps1 = jacobi_eig<MARG_NT, lds_d>(Mm, Vm, m, ldm, rot, cnt, tid, 0.0);
+            MARG_MARK(4);
+            if (tid < m) { const double l = Mm[tid * ldm + tid]; lam[tid] = l > 1e-8 ? sqrt(1.0 / l) : 0.0; }
+            __syncthreads();
+            // Z = diag(sqrt(lam^+)) V' Amr  (m x n) and zb = diag(sqrt(lam^+)) V' bmm, kept in global scratch
+            for (int e = tid; e < m * n; e += MARG_NT) {
+                const int k = e / n, j = e - k * n;
+                double sv = 0;
+                for (int p2 = 0; p2 < m; p2++) sv += Vm[p2 * ldm + k] * Apk[pidx(m + j, p2)];
+                Z[k * n + j] = lam[k] * sv;
+            }
+            if (tid < m) {
+                double sv = 0;
+                for (int p2 = 0; p2 < m; p2++) sv += Vm[p2 * ldm + tid] * bv[p2];
+                zb[tid] = lam[tid] * sv;
+            }
+            __syncthreads();
+            MARG_MARK(5);
+            int q = 0;
+            for (int e = tid; e < n * n; e += MARG_NT, q++) {
+                const int i = e / n, j = e - i * n;
+                double sv = Apk[pidx(m + i, m + j)];
+                for (int k = 0; k < m; k++) sv -= Z[k * n + i] * Z[k * n + j];
+                keepA[q] = sv;
+            }
+            if (tid < n) {
+                bprime = bv[m + tid];
+                for (int k = 0; k < m; k++) bprime -= Z[k * n + tid] * zb[k];
+            }
         }
         __syncthreads();   // every read of Vm / Apk is done: P and R2 can be overwritten
         {
@@ -999,7 +1076,7 @@ static void marg_free(tcv_batch *b) {
 static size_t marg_lds_doubles(int pos, int m, int n, int nx) {
     const int me = m + (m & 1), ne = n + (n & 1);
     const int r1 = std::max(pos * (pos + 1) / 2, ne * (ne + 1));
-    const int r2 = std::max(std::max((int)MARG_STAGE, 2 * me * (me + 1)), (n - 2) * (n - 1) / 2 + 1);
+    const int r2 = std::max(std::max((int)MARG_STAGE, me * (me + 1) + std::max(me * (me + 1), m * (n + 1))), (n - 2) * (n - 1) / 2 + 1);
     return (size_t)((r1 + 1) & ~1) + ((r2 + 1) & ~1) + MARG_MAX_POS + ((nx + 7) & ~7) + 160 + MARG_MAX_N + MARG_MAX_POS + 8 + MARG_SM;
 }
 
@@ -1233,6 +1310,7 @@ int tcv_marg_run(tcv_batch *b, void *stream) {
     a.hdr = s->d_hdr; a.ipool = s->d_ipool; a.dpool = s->d_dpool; a.solve_state = b->d_state; a.out = s->d_out;
     a.out_status = s->d_status; a.scratch = s->d_scratch; a.nwin = b->n; a.state_stride = b->state_stride;
     a.use_solved_state = b->solved ? 1 : 0;
+    a.eig_mm = getenv("TCV_MARG_EIG_MM") ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     const void *fn = s->nt == MARG_NT_PAIR ? (const void *)marg_kernel<MARG_NT_PAIR> : (const void *)marg_kernel<MARG_NT_WIDE>;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes);
@@ -1314,6 +1392,7 @@ int tcv_marg_get_prior(tcv_batch *b, int window, tcv_prior **out) {
     if (getenv("TCV_DEBUG")) {
         fprintf(stderr, "[tcv] marg window %d: m=%d n=%d jacobi sweeps %g / %g status %d\n", window, m, n, o[MARG_OUT_X + MARG_MAX_X], o[MARG_OUT_X + MARG_MAX_X + 1], status);
         const char *nm[12] = {"load", "prior", "imu", "proj", "eig_mm", "Z", "schur", "eig_rr", "out", "j_angle", "j_cols", "j_rows"};
+        fprintf(stderr, "[tcv]   Amm: trace(Amm^-1) %.3e, of the unit-diagonal scaling %.3e\n", o[MARG_OUT_X + MARG_MAX_X + 40], o[MARG_OUT_X + MARG_MAX_X + 41]);
         for (int i = 0; i < 12; i++) fprintf(stderr, "[tcv]   %-7s %12.0f cycles\n", nm[i], o[MARG_OUT_X + MARG_MAX_X + 2 + i]);
         const char *en[6] = {"tridiag", "bisect", "vectors", "mgs", "backtr", "check"};
         for (int i = 0; i < 6; i++) fprintf(stderr, "[tcv]     eig_rr.%-8s %10.0f cycles\n", en[i], o[MARG_OUT_X + MARG_MAX_X + 14 + 8 + i]);

@@ -193,6 +193,60 @@ def test_both_launch_shapes_of_the_marginalisation_kernel(gpu, monkeypatch, nt):
         assert fro(d["J0"].T @ d["J0"], d2["J0"].T @ d2["J0"]) < 1e-9
 
 
+def _standalone(gpu, w2):
+    mw = gpu.margin_old_window(w2)
+    Wm = gpu.Window(mw)
+    dr = gpu.margin_old_drops(Wm, mw)
+    arr = (gpu._dp * len(dr))(*dr)
+    h = C.c_void_p()
+    gpu.check(gpu.lib().tcv_marginalize(Wm.h, arr, len(dr), C.byref(h)))
+    return gpu.Prior(h)
+
+
+def test_dropped_block_through_cholesky_or_eigen_decomposition(gpu, monkeypatch):
+    """Amm^+ (marginalization_factor.cpp:267-272).  When 1 / trace(Amm^-1) > eps proves every eigenvalue above eps, the kernel forms
+    Arm Amm^-1 Amr from the Cholesky factor; TCV_MARG_EIG_MM=1 forces the reference's eigen-decomposition for every window.  Both against
+    the oracle (eigen-decomposition) at identical states, and against each other."""
+    batch = synth.make_windows(900, 2, frame_shift=-1)
+    for k in range(2):
+        w = synth.window_at(batch, k)
+        O = orc.Window(w); O.solve(8, True); st = O.states(); po, dbg = O.marginalize_old()
+        w2 = dict(w, pose=st["pose"], speedbias=st["sb"], ex_pose=st["ex"], lam=st["lam"])
+        res = {}
+        for mode in ("chol", "eig"):
+            if mode == "eig":
+                monkeypatch.setenv("TCV_MARG_EIG_MM", "1")
+            else:
+                monkeypatch.delenv("TCV_MARG_EIG_MM", raising=False)
+            P = _standalone(gpu, w2); d = P.export(); As, bs = P.schur()
+            res[mode] = (As, bs, d)
+            assert fro(As, dbg["A_schur"]) < 2e-6 and fro(bs, dbg["b_schur"]) < 1e-11
+            assert fro(d["J0"].T @ d["J0"], dbg["A_schur"]) < 2e-6 and fro(d["J0"].T @ d["r0"], dbg["b_schur"]) < 2e-5
+        print("cholesky vs eigen: A' %.2e b' %.2e" % (fro(res["chol"][0], res["eig"][0]), fro(res["chol"][1], res["eig"][1])))
+        assert fro(res["chol"][0], res["eig"][0]) < 2e-6 and fro(res["chol"][1], res["eig"][1]) < 1e-11
+        assert not np.array_equal(res["chol"][0], res["eig"][0])      # the two paths are really different code
+
+
+def test_rank_deficient_dropped_block_takes_the_eigen_path(gpu):
+    """A landmark seen without parallax (its only other observation from a frame with the anchor frame's pose) has a zero row in Amm:
+    the rank proof of the Cholesky path fails and the pseudo-inverse drops that eigenvalue, as the reference does (:267-272)."""
+    batch = synth.make_windows(905, 1, frame_shift=-1)
+    w = synth.window_at(batch, 0)
+    pr = w["proj"]
+    fi, fj, lm = np.asarray(pr["frame_i"]), np.asarray(pr["frame_j"]), np.asarray(pr["landmark"])
+    l0 = int(lm[(fi == 0) & (fj == 1)][0])
+    keep = ~((lm == l0) & ~((fi == 0) & (fj == 1)))
+    w = dict(w, proj={k: (np.asarray(v)[keep] if isinstance(v, np.ndarray) and v.shape[:1] == (len(fi),) else v) for k, v in pr.items()})
+    pose = np.array(w["pose"], copy=True); pose[1] = pose[0]
+    w = dict(w, pose=pose)
+    po, dbg = orc.Window(w).marginalize_old()
+    P = _standalone(gpu, w); d = P.export(); As, bs = P.schur()
+    assert (d["m"], d["n"]) == (po["m"], po["n"])
+    print("rank-deficient Amm: A' %.2e b' %.2e" % (fro(As, dbg["A_schur"]), fro(bs, dbg["b_schur"])))
+    assert fro(As, dbg["A_schur"]) < 1e-5 and fro(bs, dbg["b_schur"]) < 1e-5
+    assert fro(d["J0"].T @ d["J0"], dbg["A_schur"]) < 1e-5
+
+
 def test_marginalise_error_paths(gpu):
     batch = synth.make_windows(901, 1)
     w = synth.window_at(batch, 0)

@@ -30,8 +30,10 @@ def test_replay_with_line_association_hip_vs_oracle(gpu):
     """the same with the 2D-3D association in the loop (tcv_match_lines vs the NumPy restatement): identical association
     decisions frame by frame, trajectories within 1 mm.  (The association is a cascade of threshold tests on the current pose
     estimate: a different summation order in the solver can flip a borderline match many frames later, after which two replays
-    legitimately diverge -- the reference has the same property.  On this stream no decision is borderline.)"""
-    stream = replay.simulate_stream(1, 30, max_features=30, associate=True)
+    legitimately diverge -- the reference has the same property.  tests/dev/replay_seed_sweep.py: of eight such streams two diverge
+    that way whichever of the kernel's two routes to Amm^+ is taken, one more with the Cholesky route only; on this stream no decision
+    is borderline for either, 4e-6 m.)"""
+    stream = replay.simulate_stream(3, 30, max_features=30, associate=True)
     hip = replay.run(stream, replay.HipBackend(), num_iterations=8)
     ref = replay.run(stream, OracleBackend(), num_iterations=8)
     assert [l["n_line"] for l in hip["log"]] == [l["n_line"] for l in ref["log"]]
