@@ -244,7 +244,7 @@ def stream_figures(tcv, torch, keep, B_stream: int = 512, rounds: int = 4):
         t1 = time.perf_counter()
         b.solve(opts, stream_ptr); b.gauge_fix(stream_ptr); b.marginalize(stream_ptr); b.synchronize()
         t2 = time.perf_counter()
-        b.download_states(); b.download_priors()
+        b.download_states(); b.download_priors(compact=True)
         for k in range(len(h[0])):
             b.prior(k)
         t3 = time.perf_counter()

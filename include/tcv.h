@@ -226,6 +226,9 @@ int tcv_batch_get_prior(tcv_batch *b, int window, tcv_prior **out);
 /* optional: ONE device-to-host copy of every window's marginalisation result; later tcv_batch_get_prior calls are served from it
  * (until the next tcv_batch_marginalize) */
 int tcv_batch_download_priors(tcv_batch *b);
+/* the same without A', b' (the parity / debug half of the result: tcv_prior_export_schur fails on priors obtained this way): what an
+ * estimator needs per frame -- J0, r0 and the linearisation point, 62 KB instead of 113 KB per window, into pinned host memory */
+int tcv_batch_download_priors_compact(tcv_batch *b);
 /* per-window status of the last marginalisation: 0 ok, 1 an eigen-solver hit its sweep cap, 2 result produced by the
  * cyclic-Jacobi safety net (the tridiagonal eigen-solver failed its orthogonality / trace self-check) */
 int tcv_batch_marg_status(tcv_batch *b, int *out, int n);

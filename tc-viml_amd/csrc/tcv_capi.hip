@@ -447,6 +447,47 @@ static void batch_free(tcv_batch *b) {
 }
 
 
+// ---- pinned host staging pool ----------------------------------------------------------------------------------------------
+namespace tcv {
+namespace {
+struct HostBuf { void *p; size_t cap; bool busy; };
+std::mutex g_host_mu;
+std::vector<HostBuf> g_host_bufs;
+enum { HOST_POOL_MAX = 6 };
+}  // namespace
+void *host_staging_acquire(size_t bytes) {
+    size_t cap = (size_t)1 << 20;
+    while (cap < bytes) cap <<= 1;
+    {
+        std::lock_guard<std::mutex> g(g_host_mu);
+        HostBuf *best = nullptr;
+        for (auto &h : g_host_bufs) if (!h.busy && h.cap >= bytes && (!best || h.cap < best->cap)) best = &h;
+        if (best) { best->busy = true; return best->p; }
+    }
+    void *p = nullptr;
+    if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> g(g_host_mu);
+    g_host_bufs.push_back(HostBuf{p, cap, true});
+    return p;
+}
+void host_staging_release(void *p) {
+    if (!p) return;
+    void *to_free = nullptr;
+    {
+        std::lock_guard<std::mutex> g(g_host_mu);
+        size_t idle = 0;
+        for (auto &h : g_host_bufs) if (!h.busy) idle++;
+        for (size_t i = 0; i < g_host_bufs.size(); i++)
+            if (g_host_bufs[i].p == p) {
+                if (idle >= HOST_POOL_MAX) { to_free = p; g_host_bufs.erase(g_host_bufs.begin() + i); }
+                else g_host_bufs[i].busy = false;
+                break;
+            }
+    }
+    if (to_free) (void)hipHostFree(to_free);
+}
+}  // namespace tcv
+
 extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, tcv_problem *const *marg_problems,
                                 double *const *const *marg_drop, const int *marg_num_drop, int n) {
     if (!out || !problems || n <= 0) { set_error("batch_create: bad argument"); return TCV_ERR_INVALID; }
@@ -460,7 +501,6 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
     b->packed.resize(n);
     std::map<std::vector<int>, int> plan_index;   // structure de-duplication
     std::vector<int> ipool;
-    std::vector<double> dpool;
     int max_state = 0, max_nl = 0;
     size_t max_lds = 0;
     int dev = 0, n_cu = 0;
@@ -483,7 +523,7 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
         std::vector<std::string> msgs(nth);
         auto work = [&](int t) {
             for (int w = t; w < n; w += nth) {
-                rcs[w] = pack_problem(*problems[w], b->packed[w], nullptr, md, chain_lds);
+                rcs[w] = pack_problem(*problems[w], b->packed[w], nullptr, md, chain_lds, true);      // plan + data size
                 if (rcs[w] != TCV_OK && msgs[t].empty()) msgs[t] = tcv_last_error();      // the message is thread-local
             }
         };
@@ -509,6 +549,7 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
         if (rc != TCV_OK) { batch_free(b); if (!msg.empty()) set_error(msg); return rc; }
     }
     std::map<const PlanTemplate *, int> plan_of_tmpl;   // windows that share a cached plan template share the device plan
+    size_t dtotal = 0;
     for (int w = 0; w < n; w++) {
         Packed &pk = b->packed[w];
         const std::vector<int> &pints = pk.tmpl ? pk.tmpl->ints : pk.ints;
@@ -529,9 +570,8 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
             if (pk.tmpl) plan_of_tmpl[pk.tmpl.get()] = pid;
         }
         pk.win.plan = pid;
-        pk.win.dbase = (long long)dpool.size();
-        dpool.insert(dpool.end(), pk.doubles.begin(), pk.doubles.end());
-        b->wins.push_back(pk.win);
+        pk.win.dbase = (long long)dtotal;
+        dtotal += (size_t)pk.win.n_doubles;
         max_state = std::max(max_state, pk.hdr.nx + pk.hdr.nland);
         max_nl = std::max(max_nl, pk.hdr.nc + pk.hdr.nland);
         const int nt = pk.hdr.nt;
@@ -541,8 +581,29 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
         b->spill_stride = std::max(b->spill_stride, pk.hdr.c_spill);
         b->hcl_cap = std::max(b->hcl_cap, (pk.hdr.hcl_total + 63) & ~63);
         pk.ints.clear(); pk.ints.shrink_to_fit();
-        b->input_bytes += 8.0 * pk.doubles.size();
-        pk.doubles.clear(); pk.doubles.shrink_to_fit();
+        b->input_bytes += 8.0 * pk.win.n_doubles;
+    }
+    // data half: every window written straight into one pinned upload buffer, in parallel
+    double *h_dpool = (double *)host_staging_acquire(sizeof(double) * std::max<size_t>(1, dtotal));
+    if (!h_dpool) { batch_free(b); set_error("hipHostMalloc (upload staging) failed"); return TCV_ERR_HIP; }
+    {
+        const int nth = std::max(1, std::min({n, 16, (int)std::thread::hardware_concurrency()}));
+        std::vector<int> rcs(n, TCV_OK);
+        std::vector<std::string> msgs(nth);
+        auto work = [&](int t) {
+            for (int w = t; w < n; w += nth) {
+                rcs[w] = pack_problem_data(*problems[w], b->packed[w], nullptr, h_dpool + b->packed[w].win.dbase);
+                if (rcs[w] != TCV_OK && msgs[t].empty()) msgs[t] = tcv_last_error();
+            }
+        };
+        if (nth == 1) work(0);
+        else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < nth; t++) th.emplace_back(work, t);
+            for (auto &x : th) x.join();
+        }
+        for (int w = 0; w < n; w++) if (rcs[w] != TCV_OK) { host_staging_release(h_dpool); batch_free(b); if (!msgs[w % nth].empty()) set_error(msgs[w % nth]); return rcs[w]; }
+        for (int w = 0; w < n; w++) b->wins.push_back(b->packed[w].win);
     }
     const auto t_packed = std::chrono::steady_clock::now();
     b->plan_bytes = 4.0 * ipool.size();
@@ -555,17 +616,19 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
 #define UP(dst, src, T, cnt)                                                                          \
     do {                                                                                              \
         hipError_t e_ = tcv::dev_malloc((void **)&dst, sizeof(T) * std::max<size_t>(1, (cnt)));             \
-        if (e_ != hipSuccess) { batch_free(b); return hip_fail(e_, "hipMalloc"); }                    \
+        if (e_ != hipSuccess) { host_staging_release(h_dpool); batch_free(b); return hip_fail(e_, "hipMalloc"); }                    \
         if (src) {                                                                                    \
             e_ = hipMemcpy(dst, src, sizeof(T) * (cnt), hipMemcpyHostToDevice);                       \
-            if (e_ != hipSuccess) { batch_free(b); return hip_fail(e_, "hipMemcpy H2D"); }            \
+            if (e_ != hipSuccess) { host_staging_release(h_dpool); batch_free(b); return hip_fail(e_, "hipMemcpy H2D"); }            \
         }                                                                                             \
     } while (0)
     UP(b->d_win, b->wins.data(), WinHdr, (size_t)n);
     UP(b->d_plans, b->plans.data(), PlanHdr, b->plans.size());
     UP(b->d_plan_base, b->plan_base.data(), long long, b->plan_base.size());
     UP(b->d_ipool, ipool.data(), int, ipool.size());
-    UP(b->d_dpool, dpool.data(), double, dpool.size());
+    UP(b->d_dpool, h_dpool, double, dtotal);
+    host_staging_release(h_dpool);
+    h_dpool = nullptr;
     UP(b->d_state, (double *)nullptr, double, (size_t)n * b->state_stride);
     UP(b->d_delta, (double *)nullptr, double, (size_t)n * b->delta_stride);
     UP(b->d_scratch, (double *)nullptr, double, (size_t)b->grid * scr);
@@ -713,7 +776,13 @@ extern "C" int tcv_batch_get_prior(tcv_batch *b, int window, tcv_prior **out) {
 }
 extern "C" int tcv_batch_download_priors(tcv_batch *b) {
     if (!b) return TCV_ERR_INVALID;
-    return tcv_marg_download(b);
+    if (b->pending) if (int rc = tcv_batch_synchronize(b)) return rc;
+    return tcv_marg_download(b, 0);
+}
+extern "C" int tcv_batch_download_priors_compact(tcv_batch *b) {
+    if (!b) return TCV_ERR_INVALID;
+    if (b->pending) if (int rc = tcv_batch_synchronize(b)) return rc;
+    return tcv_marg_download(b, 1);
 }
 extern "C" int tcv_batch_stats(tcv_batch *b, double *input_bytes, double *solve_ms, double *marg_ms) {
     if (!b) return TCV_ERR_INVALID;

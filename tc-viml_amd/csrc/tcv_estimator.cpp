@@ -684,7 +684,7 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
         std::vector<tcv_solver_summary> sum(nb);
         if (rc == TCV_OK) rc = tcv_batch_get_summaries(b, sum.data(), nb);
         std::vector<tcv_prior *> newp(nb, nullptr);
-        if (rc == TCV_OK && group) rc = tcv_batch_download_priors(b);
+        if (rc == TCV_OK && group) rc = tcv_batch_download_priors_compact(b);
         if (rc == TCV_OK && group)
             for (int k = 0; k < nb && rc == TCV_OK; k++) rc = tcv_batch_get_prior(b, k, &newp[k]);
         if (b) tcv_batch_destroy(b);

@@ -113,7 +113,7 @@ int tcv_marg_attach(tcv_batch *b, tcv_problem *const *marg_problems, double *con
 int tcv_marg_run(tcv_batch *b, void *stream);
 int tcv_marg_get_prior(tcv_batch *b, int window, tcv_prior **out);
 void tcv_marg_elapsed(tcv_batch *b);
-int tcv_marg_download(tcv_batch *b);
+int tcv_marg_download(tcv_batch *b, int compact);
 
 namespace tcv {
 // device allocations go through a per-process free list (size-bucketed, per device): a per-frame estimator creates and destroys a
@@ -126,7 +126,13 @@ void set_error(const std::string &s);
 // returns TCV_OK or a negative status; fills out.  imu_sqrt: optional host-provided sqrt_info (n_imu x 225).
 // mode: 0 = chain layout when the graph allows it (speed-bias blocks form chains), else dense; 1 = dense layout
 // chain_lds: LDS doubles of a chain-layout workgroup (0: chain_lds_doubles(), half a CU's LDS so that two workgroups share a CU)
-int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int mode = 0, int chain_lds = 0);
+// plan_only: plan + the size of the data half (out.win.n_doubles); the data is then written by pack_problem_data into a buffer of the
+// caller (one upload buffer per batch)
+int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int mode = 0, int chain_lds = 0, bool plan_only = false);
+int pack_problem_data(const tcv_problem &p, Packed &out, const double *imu_sqrt, double *dst);
+// pinned host staging buffers for uploads / downloads, recycled through a small per-process pool (hipHostMalloc costs milliseconds)
+void *host_staging_acquire(size_t bytes);
+void host_staging_release(void *p);
 // plan-cache statistics (hits, misses, entries); tcv_pack.cpp
 void plan_cache_stats(long long *hits, long long *misses, long long *entries);
 }  // namespace tcv

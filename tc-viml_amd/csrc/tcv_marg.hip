@@ -19,6 +19,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <thread>
+#include <string>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -34,7 +36,10 @@ enum { MARG_MAX_M = 64, MARG_MAX_N = 80, MARG_MAX_POS = MARG_MAX_M + MARG_MAX_N,
 // 256 threads per window and two workgroups per CU when every window of the batch fits 80 KB of LDS (many windows: the barrier and
 // LDS round trips of one window hide behind the other's arithmetic).
 enum { MARG_NT_WIDE = 512, MARG_NT_PAIR = 256, MARG_SM = 720, MARG_STAGE = 64 * 43 };
-enum { MARG_OUT_J0 = 0, MARG_OUT_R0 = 6400, MARG_OUT_AS = 6480, MARG_OUT_BS = 12880, MARG_OUT_X = 12960, MARG_OUT_STRIDE = 12960 + 1408 + 64 };
+// per-window result block: [J0 | r0 | x (linearisation point) + 64 diagnostics] is what a caller needs (MARG_OUT_COMPACT doubles, the
+// part tcv_batch_download_priors_compact copies); A', b' (parity / debug surface) follow
+enum { MARG_OUT_J0 = 0, MARG_OUT_R0 = 6400, MARG_OUT_X = 6480, MARG_OUT_COMPACT = 6480 + 1408 + 64, MARG_OUT_AS = MARG_OUT_COMPACT, MARG_OUT_BS = MARG_OUT_AS + 6400,
+       MARG_OUT_STRIDE = MARG_OUT_BS + 80 };
 // per-workgroup scratch in HBM (L2-resident): Z = diag(sqrt(lam^+)) V' Amr, its right-hand side, and the eigenvector matrix of the
 // Jacobi safety net for A' (the LDS holds one n x n matrix, not two)
 enum { MARG_SCR_Z = 0, MARG_SCR_PR = MARG_MAX_M * MARG_MAX_N, MARG_SCR_V = MARG_SCR_PR + 256, MARG_SCR_STRIDE = MARG_SCR_V + (MARG_MAX_N + 1) * (MARG_MAX_N + 2) };
@@ -1055,7 +1060,8 @@ struct MargState {
     size_t lds_bytes = 0;
     int grid = 0, nt = MARG_NT_WIDE;
     bool ran = false;
-    std::vector<double> h_out;        // host copy of every window's result block (tcv_batch_download_priors), valid until the next run
+    double *h_out = nullptr;          // pinned host copy of every window's result block (tcv_batch_download_priors), valid until the next run
+    size_t h_stride = 0;              // doubles per window in h_out: MARG_OUT_STRIDE, or MARG_OUT_COMPACT (no A', b')
     std::vector<int> h_status;
     bool h_valid = false;
 };
@@ -1067,6 +1073,7 @@ static void marg_free(tcv_batch *b) {
     (void)tcv::dev_free(s->d_out); (void)tcv::dev_free(s->d_scratch);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
+    tcv::host_staging_release(s->h_out);
     delete s;
     b->marg = nullptr;
 }
@@ -1250,22 +1257,61 @@ int tcv_marg_attach(tcv_batch *b, tcv_problem *const *marg_problems, double *con
     b->marg = s;
     b->marg_free = marg_free;
     s->win.resize(b->n);
-    std::vector<int> I;
-    std::vector<double> D;
     std::vector<MargHdr> hdrs(b->n);
     size_t lds = 0;
-    for (int w = 0; w < b->n; w++) {
+    for (int w = 0; w < b->n; w++)
         if (!marg_problems[w] || !marg_drop || !marg_drop[w]) { set_error("marginalisation problem / drop list missing"); return TCV_ERR_INVALID; }
-        const bool same = marg_problems[w] == b->problems[w];
-        const int rc = pack_marg(*marg_problems[w], marg_drop[w], marg_num_drop[w], b->problems[w], &b->packed[w], s->win[w], I, D);
-        (void)same;
-        if (rc != TCV_OK) return rc;
-        s->win[w].hdr.solve_window = w;
-        hdrs[w] = s->win[w].hdr;
-        const int pos = hdrs[w].pos, m = hdrs[w].m, n = hdrs[w].n;
-        const size_t need = marg_lds_doubles(pos, m, n, hdrs[w].nx) * 8;
-        if (need > (size_t)LDS_DOUBLES * 8) { set_error("marginalisation does not fit LDS"); return TCV_ERR_TOO_LARGE; }
-        lds = std::max(lds, need);
+    // the windows are packed by host threads, each into its own int / double pools (contiguous window ranges); the pools are then laid end
+    // to end in pinned upload buffers and the headers' pool offsets shifted accordingly
+    const int nth = std::max(1, std::min({b->n / 8, 16, (int)std::thread::hardware_concurrency()}));
+    std::vector<std::vector<int>> It(nth);
+    std::vector<std::vector<double>> Dt(nth);
+    std::vector<int> rcs(nth, TCV_OK);
+    std::vector<std::string> msgs(nth);
+    auto range = [&](int t) { return std::make_pair((int)((long long)b->n * t / nth), (int)((long long)b->n * (t + 1) / nth)); };
+    auto work = [&](int t) {
+        const auto r = range(t);
+        for (int w = r.first; w < r.second; w++) {
+            const int rc = pack_marg(*marg_problems[w], marg_drop[w], marg_num_drop[w], b->problems[w], &b->packed[w], s->win[w], It[t], Dt[t]);
+            if (rc != TCV_OK) { rcs[t] = rc; msgs[t] = tcv_last_error(); return; }
+            s->win[w].hdr.solve_window = w;
+        }
+    };
+    if (nth == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nth; t++) th.emplace_back(work, t);
+        for (auto &x : th) x.join();
+    }
+    for (int t = 0; t < nth; t++) if (rcs[t] != TCV_OK) { if (!msgs[t].empty()) set_error(msgs[t]); return rcs[t]; }
+    std::vector<size_t> ib(nth + 1, 0), db(nth + 1, 0);
+    for (int t = 0; t < nth; t++) { ib[t + 1] = ib[t] + It[t].size(); db[t + 1] = db[t] + Dt[t].size(); }
+    for (int t = 0; t < nth; t++) {
+        const auto r = range(t);
+        for (int w = r.first; w < r.second; w++) {
+            s->win[w].hdr.ibase += (long long)ib[t]; s->win[w].hdr.dbase += (long long)db[t];
+            hdrs[w] = s->win[w].hdr;
+            const size_t need = marg_lds_doubles(hdrs[w].pos, hdrs[w].m, hdrs[w].n, hdrs[w].nx) * 8;
+            if (need > (size_t)LDS_DOUBLES * 8) { set_error("marginalisation does not fit LDS"); return TCV_ERR_TOO_LARGE; }
+            lds = std::max(lds, need);
+        }
+    }
+    const size_t i_total = ib[nth], d_total = db[nth];
+    int *h_I = (int *)tcv::host_staging_acquire(sizeof(int) * std::max<size_t>(1, i_total));
+    double *h_D = (double *)tcv::host_staging_acquire(sizeof(double) * std::max<size_t>(1, d_total));
+    struct Staged { void *a, *b2; ~Staged() { tcv::host_staging_release(a); tcv::host_staging_release(b2); } } staged{h_I, h_D};
+    if (!h_I || !h_D) { set_error("hipHostMalloc (upload staging) failed"); return TCV_ERR_HIP; }
+    {
+        auto copy = [&](int t) {
+            if (!It[t].empty()) std::memcpy(h_I + ib[t], It[t].data(), sizeof(int) * It[t].size());
+            if (!Dt[t].empty()) std::memcpy(h_D + db[t], Dt[t].data(), sizeof(double) * Dt[t].size());
+        };
+        if (nth == 1) copy(0);
+        else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < nth; t++) th.emplace_back(copy, t);
+            for (auto &x : th) x.join();
+        }
     }
     s->lds_bytes = lds;
     hipDeviceProp_t prop;
@@ -1290,8 +1336,8 @@ int tcv_marg_attach(tcv_batch *b, tcv_problem *const *marg_problems, double *con
         }                                                                                        \
     } while (0)
     MUP(s->d_hdr, hdrs.data(), MargHdr, hdrs.size());
-    MUP(s->d_ipool, I.data(), int, I.size());
-    MUP(s->d_dpool, D.data(), double, D.size());
+    MUP(s->d_ipool, h_I, int, i_total);
+    MUP(s->d_dpool, h_D, double, d_total);
     MUP(s->d_out, (double *)nullptr, double, (size_t)b->n * MARG_OUT_STRIDE);
     MUP(s->d_status, (int *)nullptr, int, (size_t)b->n);
     MUP(s->d_scratch, (double *)nullptr, double, (size_t)s->grid * MARG_SCR_STRIDE);
@@ -1325,13 +1371,20 @@ int tcv_marg_run(tcv_batch *b, void *stream) {
     return TCV_OK;
 }
 
-// one D2H copy of every window's result block (J0, r0, A', b', x0) and status instead of one copy per tcv_batch_get_prior call
-int tcv_marg_download(tcv_batch *b) {
+// one D2H copy of every window's result block and status instead of one copy per tcv_batch_get_prior call, into a pinned buffer.
+// compact: J0, r0 and the linearisation point only (a strided copy of the first MARG_OUT_COMPACT doubles of every block); the priors
+// handed out afterwards carry no A', b'.
+int tcv_marg_download(tcv_batch *b, int compact) {
     MargState *s = (MargState *)b->marg;
     if (!s || !s->ran) { set_error("no marginalisation result"); return TCV_ERR_INVALID; }
-    s->h_out.resize((size_t)b->n * MARG_OUT_STRIDE);
+    const size_t stride = compact ? (size_t)MARG_OUT_COMPACT : (size_t)MARG_OUT_STRIDE;
+    if (s->h_out && s->h_stride != stride) { tcv::host_staging_release(s->h_out); s->h_out = nullptr; }
+    if (!s->h_out) s->h_out = (double *)tcv::host_staging_acquire(sizeof(double) * stride * b->n);
+    if (!s->h_out) { set_error("hipHostMalloc (download staging) failed"); return TCV_ERR_HIP; }
+    s->h_stride = stride;
     s->h_status.resize(b->n);
-    hipError_t e = hipMemcpy(s->h_out.data(), s->d_out, sizeof(double) * s->h_out.size(), hipMemcpyDeviceToHost);
+    hipError_t e = compact ? hipMemcpy2D(s->h_out, sizeof(double) * stride, s->d_out, sizeof(double) * MARG_OUT_STRIDE, sizeof(double) * stride, b->n, hipMemcpyDeviceToHost)
+                           : hipMemcpy(s->h_out, s->d_out, sizeof(double) * stride * b->n, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(s->h_status.data(), s->d_status, sizeof(int) * b->n, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return hip_fail(e, "hipMemcpy D2H");
     s->h_valid = true;
@@ -1361,8 +1414,10 @@ int tcv_marg_get_prior(tcv_batch *b, int window, tcv_prior **out) {
     const int n = mw.hdr.n, m = mw.hdr.m;      // m: dropped dims that went through the eigen step (all of them unless block mode)
     std::vector<double> o(MARG_OUT_STRIDE);
     int status = -1;
+    bool have_schur = true;
     if (s->h_valid) {
-        std::copy(s->h_out.begin() + (size_t)window * MARG_OUT_STRIDE, s->h_out.begin() + (size_t)(window + 1) * MARG_OUT_STRIDE, o.begin());
+        std::copy(s->h_out + (size_t)window * s->h_stride, s->h_out + (size_t)(window + 1) * s->h_stride, o.begin());
+        have_schur = s->h_stride == (size_t)MARG_OUT_STRIDE;
         status = s->h_status[window];
     } else {
         hipError_t e = hipMemcpy(o.data(), s->d_out + (size_t)window * MARG_OUT_STRIDE, sizeof(double) * MARG_OUT_STRIDE, hipMemcpyDeviceToHost);
@@ -1387,8 +1442,10 @@ int tcv_marg_get_prior(tcv_batch *b, int window, tcv_prior **out) {
     }
     pr->J0.assign(o.begin() + MARG_OUT_J0, o.begin() + MARG_OUT_J0 + (size_t)n * n);
     pr->r0.assign(o.begin() + MARG_OUT_R0, o.begin() + MARG_OUT_R0 + n);
-    pr->As.assign(o.begin() + MARG_OUT_AS, o.begin() + MARG_OUT_AS + (size_t)n * n);
-    pr->bs.assign(o.begin() + MARG_OUT_BS, o.begin() + MARG_OUT_BS + n);
+    if (have_schur) {
+        pr->As.assign(o.begin() + MARG_OUT_AS, o.begin() + MARG_OUT_AS + (size_t)n * n);
+        pr->bs.assign(o.begin() + MARG_OUT_BS, o.begin() + MARG_OUT_BS + n);
+    }
     if (getenv("TCV_DEBUG")) {
         fprintf(stderr, "[tcv] marg window %d: m=%d n=%d jacobi sweeps %g / %g status %d\n", window, m, n, o[MARG_OUT_X + MARG_MAX_X], o[MARG_OUT_X + MARG_MAX_X + 1], status);
         const char *nm[12] = {"load", "prior", "imu", "proj", "eig_mm", "Z", "schur", "eig_rr", "out", "j_angle", "j_cols", "j_rows"};

@@ -461,6 +461,7 @@ static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds)
         // lower bound on k from the records alone, then jump by the measured overshoot: two exact trials instead of k
         const int kmax = std::max(1, std::min(L, 48));
         int k = std::max(1, (nproj * prec + nline * LINE_REC + c_pool - 1) / std::max(1, c_pool));
+        if (const char *ek = getenv("TCV_VIS_CHUNKS")) k = std::max(k, atoi(ek));      // tuning experiments
         for (; k <= kmax && !found;) {
             std::vector<VChunk> cand;
             int l = 0;
@@ -622,40 +623,51 @@ static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds)
     return TCV_OK;
 }
 
-// data half: the window's doubles in the layout the plan expects (offsets depend on the counts only)
-static int pack_data(const tcv_problem &p, Packed &out, const double *imu_sqrt) {
+// data half: the window's doubles in the layout the plan expects (offsets depend on the counts only).  The sink either counts
+// (dst == nullptr) or writes: a batch first sizes every window, then all windows are written straight into one upload buffer.
+namespace {
+struct Sink {
+    double *dst;
+    size_t n = 0;
+    explicit Sink(double *d) : dst(d) {}
+    void put(const double *s, size_t k) { if (dst) std::memcpy(dst + n, s, k * sizeof(double)); n += k; }
+    void put1(double v) { if (dst) dst[n] = v; n++; }
+    void zeros(size_t k) { if (dst) std::memset(dst + n, 0, k * sizeof(double)); n += k; }
+};
+}  // namespace
+
+static int pack_data_to(const tcv_problem &p, Packed &out, const double *imu_sqrt, Sink &D) {
     const PlanHdr &H = out.hdr;
     const int nblk = (int)out.cam_block.size(), L = (int)out.lm_block.size();
     const std::vector<int> &order = out.proj_order;
     const bool with_td = (H.flags & 1) != 0;
     const tcv_prior *pr = p.prior.empty() ? nullptr : p.prior[0].prior;
-    std::vector<double> &D = out.doubles;
-    D.clear();
     WinHdr &W = out.win;
+    const int plan_id = W.plan;
+    const long long dbase = W.dbase;
     std::memset(&W, 0, sizeof(W));
-    W.d_x = (int)D.size();
-    for (int c = 0; c < nblk; c++) { const ParamBlock &pb = p.blocks[out.cam_block[c]]; D.insert(D.end(), pb.addr, pb.addr + pb.size); }
-    for (int l = 0; l < L; l++) D.push_back(p.blocks[out.lm_block[l]].addr[0]);
-    W.d_imu = (int)D.size();
+    W.plan = plan_id; W.dbase = dbase;
+    W.d_x = (int)D.n;
+    for (int c = 0; c < nblk; c++) { const ParamBlock &pb = p.blocks[out.cam_block[c]]; D.put(pb.addr, pb.size); }
+    for (int l = 0; l < L; l++) D.put1(p.blocks[out.lm_block[l]].addr[0]);
+    W.d_imu = (int)D.n;
     for (auto &f : p.imu) {
         const tcv_imu_preintegration &q = f.pre;
-        D.insert(D.end(), q.delta_p, q.delta_p + 3); D.insert(D.end(), q.delta_q, q.delta_q + 4);
-        D.insert(D.end(), q.delta_v, q.delta_v + 3); D.insert(D.end(), q.linearized_ba, q.linearized_ba + 3);
-        D.insert(D.end(), q.linearized_bg, q.linearized_bg + 3); D.push_back(q.sum_dt);
+        D.put(q.delta_p, 3); D.put(q.delta_q, 4); D.put(q.delta_v, 3); D.put(q.linearized_ba, 3); D.put(q.linearized_bg, 3); D.put1(q.sum_dt);
         const int rc[5][2] = {{0, 9}, {0, 12}, {3, 12}, {6, 9}, {6, 12}};   // dp_dba dp_dbg dq_dbg dv_dba dv_dbg (imu_factor.h:61-79)
-        for (auto &b : rc) for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) D.push_back(q.jacobian[(b[0] + i) * 15 + b[1] + j]);
-        D.insert(D.end(), q.covariance, q.covariance + 225);
+        for (auto &b : rc) for (int i = 0; i < 3; i++) D.put(q.jacobian + (b[0] + i) * 15 + b[1], 3);
+        D.put(q.covariance, 225);
     }
-    W.d_proj = (int)D.size();
+    W.d_proj = (int)D.n;
     double psi = 0, pla = 0;
     for (size_t k = 0; k < order.size(); k++) {
         const ProjFac &f = p.proj[order[k]];
         if (k == 0) { psi = f.sqrt_info; pla = f.loss_a; }
         else if (f.sqrt_info != psi || f.loss_a != pla) { set_error("projection factors must share sqrt_info and loss"); return TCV_ERR_UNSUPPORTED; }
-        D.insert(D.end(), f.pts, f.pts + 6);
-        if (with_td) D.insert(D.end(), f.aux, f.aux + 8);
+        D.put(f.pts, 6);
+        if (with_td) D.put(f.aux, 8);
     }
-    W.d_line = (int)D.size();
+    W.d_line = (int)D.n;
     double lla = 0;
     for (size_t k = 0; k < p.line.size(); k++) {
         const LineFac &f = p.line[k];
@@ -666,22 +678,36 @@ static int pack_data(const tcv_problem &p, Packed &out, const double *imu_sqrt) 
                 set_error("line factors must share K, b_c_R, b_c_T and loss"); return TCV_ERR_UNSUPPORTED;
             }
         }
-        D.insert(D.end(), f.d, f.d + 9);
+        D.put(f.d, 9);
     }
-    W.d_linec = (int)D.size();
-    if (!p.line.empty()) { const LineFac &g = p.line[0]; D.insert(D.end(), g.K, g.K + 9); D.insert(D.end(), g.R, g.R + 9); D.insert(D.end(), g.T, g.T + 3); }
-    else D.insert(D.end(), 21, 0.0);
-    if (D.size() & 1) D.push_back(0.0);        // J0 is copied with 16-byte loads
-    W.d_prior = (int)D.size();
-    if (pr) { D.insert(D.end(), pr->J0.begin(), pr->J0.end()); D.insert(D.end(), pr->r0.begin(), pr->r0.end()); D.insert(D.end(), pr->x0.begin(), pr->x0.end()); }
-    W.d_misc = (int)D.size();
-    D.insert(D.end(), p.G, p.G + 3); D.push_back(psi); D.push_back(pla); D.push_back(lla); D.push_back(p.td_TR); D.push_back(p.td_ROW); D.push_back(p.line_exact ? 1.0 : 0.0);
+    W.d_linec = (int)D.n;
+    if (!p.line.empty()) { const LineFac &g = p.line[0]; D.put(g.K, 9); D.put(g.R, 9); D.put(g.T, 3); }
+    else D.zeros(21);
+    if (D.n & 1) D.put1(0.0);        // J0 is copied with 16-byte loads
+    W.d_prior = (int)D.n;
+    if (pr) { D.put(pr->J0.data(), pr->J0.size()); D.put(pr->r0.data(), pr->r0.size()); D.put(pr->x0.data(), pr->x0.size()); }
+    W.d_misc = (int)D.n;
+    D.put(p.G, 3); D.put1(psi); D.put1(pla); D.put1(lla); D.put1(p.td_TR); D.put1(p.td_ROW); D.put1(p.line_exact ? 1.0 : 0.0);
     W.d_sqrt = -1;
-    if (imu_sqrt && H.n_imu) { W.d_sqrt = (int)D.size(); D.insert(D.end(), imu_sqrt, imu_sqrt + 225 * H.n_imu); }
-    if (D.size() & 1) D.push_back(0.0);
-    W.n_doubles = (int)D.size();
-    for (double v : D) if (!(v == v) || v > 1e300 || v < -1e300) { set_error("NaN/Inf in window data"); return TCV_ERR_NUMERIC; }
+    if (imu_sqrt && H.n_imu) { W.d_sqrt = (int)D.n; D.put(imu_sqrt, (size_t)225 * H.n_imu); }
+    if (D.n & 1) D.put1(0.0);
+    W.n_doubles = (int)D.n;
+    if (D.dst) for (size_t i = 0; i < D.n; i++) { const double v = D.dst[i]; if (!(v == v) || v > 1e300 || v < -1e300) { set_error("NaN/Inf in window data"); return TCV_ERR_NUMERIC; } }
     return TCV_OK;
+}
+
+static int pack_data(const tcv_problem &p, Packed &out, const double *imu_sqrt) {
+    Sink cnt(nullptr);
+    int rc = pack_data_to(p, out, imu_sqrt, cnt);
+    if (rc != TCV_OK) return rc;
+    out.doubles.resize(cnt.n);
+    Sink w(out.doubles.data());
+    return pack_data_to(p, out, imu_sqrt, w);
+}
+
+int pack_problem_data(const tcv_problem &p, Packed &out, const double *imu_sqrt, double *dst) {
+    Sink w(dst);
+    return pack_data_to(p, out, imu_sqrt, w);
 }
 
 
@@ -733,11 +759,12 @@ void plan_cache_stats(long long *hits, long long *misses, long long *entries) {
     if (entries) *entries = (long long)g_cache.size();
 }
 
-int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int mode, int chain_lds) {
+int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int mode, int chain_lds, bool plan_only) {
     static const bool no_cache = getenv("TCV_NO_PLAN_CACHE") != nullptr;
     const int c_lds = (chain_lds >= 6144 && chain_lds <= LDS_DOUBLES) ? (chain_lds & ~1) : chain_lds_doubles();
     std::vector<int> key;
     std::shared_ptr<const PlanTemplate> T;
+    std::memset(&out.win, 0, sizeof out.win);
     if (!no_cache) {
         structure_key(p, mode, c_lds, key);
         std::lock_guard<std::mutex> g(g_cache_mu);
@@ -760,6 +787,10 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int 
             if (g_cache.size() >= CACHE_MAX_ENTRIES) g_cache.clear();      // replays produce a new structure every frame: bounded, not LRU
             g_cache.emplace(std::move(key), N);
         }
+    }
+    if (plan_only) {      // size only: the caller writes the data with pack_problem_data once every window of its batch has an offset
+        Sink cnt(nullptr);
+        return pack_data_to(p, out, imu_sqrt, cnt);
     }
     return pack_data(p, out, imu_sqrt);
 }

@@ -38,7 +38,7 @@ EXPORTS = [
     "tcv_batch_plan_stats", "tcv_batch_layout", "tcv_batch_stats", "tcv_batch_size",
     "tcv_eval_imu_factors", "tcv_eval_projection_factors", "tcv_eval_line_factors", "tcv_pose_plus", "tcv_preintegrate",
     "tcv_problem_set_frames", "tcv_gauge_fix", "tcv_batch_gauge_fix", "tcv_set_solver_variant", "tcv_batch_marg_status", "tcv_eval_projection_td_factors", "tcv_match_lines",
-    "tcv_batch_download_priors",
+    "tcv_batch_download_priors", "tcv_batch_download_priors_compact",
 ]
 
 
@@ -136,6 +136,7 @@ def lib():
         L.tcv_batch_get_summaries.argtypes = [vp, C.POINTER(SolverSummary), C.c_int]
         L.tcv_batch_get_prior.argtypes = [vp, C.c_int, C.POINTER(vp)]
         L.tcv_batch_download_priors.argtypes = [vp]
+        L.tcv_batch_download_priors_compact.argtypes = [vp]
         L.tcv_batch_get_first_step.argtypes = [vp, C.c_int, _dp, C.c_int, _ip]
         L.tcv_batch_plan_stats.argtypes = [vp, _ip, _dp, _ip, _ip]
         L.tcv_batch_layout.argtypes = [vp]
@@ -455,9 +456,10 @@ class Batch:
         check(lib().tcv_batch_get_prior(self.h, window, C.byref(h)))
         return Prior(h)
 
-    def download_priors(self):
-        """one D2H copy of every window's marginalisation result; `prior(k)` is then served from the host copy."""
-        check(lib().tcv_batch_download_priors(self.h))
+    def download_priors(self, compact=False):
+        """one D2H copy of every window's marginalisation result; `prior(k)` is then served from the host copy.  compact: without A', b'
+        (`Prior.schur()` is then unavailable)."""
+        check((lib().tcv_batch_download_priors_compact if compact else lib().tcv_batch_download_priors)(self.h))
 
     def stats(self):
         a, b, c = C.c_double(), C.c_double(), C.c_double()
