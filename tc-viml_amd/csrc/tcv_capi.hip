@@ -438,7 +438,7 @@ static void batch_free(tcv_batch *b) {
     if (!b) return;
     if (b->pending) { if (b->last_stream) (void)hipStreamSynchronize(b->last_stream); else (void)hipDeviceSynchronize(); }      // the buffers go back to the free list
     tcv::dev_free(b->d_win); tcv::dev_free(b->d_plans); tcv::dev_free(b->d_plan_base); tcv::dev_free(b->d_ipool); tcv::dev_free(b->d_dpool);
-    tcv::dev_free(b->d_imublk); tcv::dev_free(b->d_spill);
+    tcv::dev_free(b->d_imublk); tcv::dev_free(b->d_spill); tcv::dev_free(b->d_sqrt_out);
     tcv::dev_free(b->d_prof); tcv::dev_free(b->d_state); tcv::dev_free(b->d_delta); tcv::dev_free(b->d_scratch); tcv::dev_free(b->d_summary);
     if (b->ev0) hipEventDestroy(b->ev0);
     if (b->ev1) hipEventDestroy(b->ev1);
@@ -648,8 +648,16 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
     if (e0 != hipSuccess) { batch_free(b); return hip_fail(e0, "hipEventCreate"); }
     const auto t_up = std::chrono::steady_clock::now();
     if (marg_problems) {
+        hipError_t e_ = tcv::dev_malloc((void **)&b->d_sqrt_out, sizeof(double) * (size_t)n * 225);
+        if (e_ != hipSuccess) { batch_free(b); return hip_fail(e_, "hipMalloc"); }
         const int rc = tcv_marg_attach(b, marg_problems, marg_drop, marg_num_drop);
         if (rc != TCV_OK) { batch_free(b); return rc; }
+        bool any = false;
+        for (int w = 0; w < n; w++) { b->wins[w].sqrt_export = tcv_marg_sqrt_source(b, w); any = any || b->wins[w].sqrt_export >= 0; }
+        if (any) {
+            e_ = hipMemcpy(b->d_win, b->wins.data(), sizeof(WinHdr) * (size_t)n, hipMemcpyHostToDevice);
+            if (e_ != hipSuccess) { batch_free(b); return hip_fail(e_, "hipMemcpy H2D"); }
+        }
     }
     if (getenv("TCV_DEBUG_PACK")) {
         const auto t_end = std::chrono::steady_clock::now();
@@ -685,6 +693,8 @@ extern "C" int tcv_batch_solve(tcv_batch *b, const tcv_solver_options *o, void *
     a.max_iterations = o->max_num_iterations; a.fixed_iterations = o->fixed_iterations; a.use_mfma = o->use_mfma;
     a.chain = b->chain ? 1 : 0; a.imublk = b->d_imublk; a.spill = b->d_spill; a.spill_stride = b->spill_stride;
     a.max_ticks = 0;
+    a.sqrt_out = b->d_sqrt_out;
+    b->sqrt_out_valid = b->d_sqrt_out != nullptr;
     if (const char *sk = getenv("TCV_ABLATE_SKIP")) a.pad2 = (int)(unsigned)strtoul(sk, nullptr, 0);      // -DTCV_ABLATE builds only read it
     if (o->max_solver_time_in_seconds > 0.0 && !o->fixed_iterations) {
         int dev = 0, khz = 0;

@@ -101,6 +101,8 @@ struct tcv_batch {
     bool chain = false;                   // all plans use the chain layout (2 workgroups per CU)
     int chain_lds = 0;                    // LDS doubles per chain-layout workgroup of this batch
     double *d_imublk = nullptr, *d_spill = nullptr;   // chain mode: per-workgroup IMU J'J blocks and factored fronts
+    double *d_sqrt_out = nullptr;         // per window 225 doubles: the solve's sqrt_info of the IMU factor the marginalisation needs
+    bool sqrt_out_valid = false;          // the last solve wrote it (device-computed sqrt_info)
     int spill_stride = 0;
     int hcl_cap = 0;                      // doubles of the landmark/camera coupling store per workgroup (largest window of the batch)
     // marginalisation
@@ -109,6 +111,7 @@ struct tcv_batch {
 };
 
 
+int tcv_marg_sqrt_source(const tcv_batch *b, int window);   // index of that factor among the solve problem's IMU factors, -1 none
 int tcv_marg_attach(tcv_batch *b, tcv_problem *const *marg_problems, double *const *const *marg_drop, const int *marg_num_drop);
 int tcv_marg_run(tcv_batch *b, void *stream);
 int tcv_marg_get_prior(tcv_batch *b, int window, tcv_prior **out);

@@ -59,6 +59,9 @@ struct MargHdr {
                       // accumulated, only the frame part of the dropped set (m) goes through the eigen pseudo-inverse
     int o_plast;      // block mode: n_proj flags, 1 = last factor of its landmark (factors sorted by landmark)
     int td_blk;       // >= 0: the point factors are ProjectionTdFactors on this block (d_proj then holds 14 doubles per factor)
+    int sqrt_src;        // >= 0: index of the (single) IMU factor among the solve problem's IMU factors: its sqrt_info was computed by the solve
+    int proj_disjoint;   // 1: no block is the frame-i pose of one point factor and the frame-j pose of another (MARGIN_OLD: every factor is
+                         // anchored in the dropped frame), so one thread can own one entry of the 19 x 20 record across all factors of a chunk
 };
 
 struct MargArgs {
@@ -66,6 +69,7 @@ struct MargArgs {
     const int *ipool;
     const double *dpool;
     const double *solve_state;   // may be null
+    const double *solve_sqrt;    // may be null: per window 225 doubles, the solve's sqrt_info of IMU factor sqrt_src
     double *out;                 // per window MARG_OUT_STRIDE
     int *out_status;             // per window: 0 ok
     double *scratch;             // per workgroup MARG_SCR_STRIDE
@@ -743,7 +747,10 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((amdgpu_waves_per_eu(2,
         for (int f = 0; f < H.n_imu; f++) {
             cst_i *b = ip + H.o_imu + f * 4;
             lds_d *S = stage + 1500;
-            if (tid < 16) (void)imu_sqrt_info_group((const double *)(dp + H.d_imu + f * IMU_CONST + IMU_COV), GEN(S), GEN(stage + 512), GEN(stage + 512 + 225), tid);
+            // sqrt_info: the one the solve of this batch computed from the same covariance with the same code (bit-identical), else here
+            const bool s_given = Aarg.solve_sqrt != nullptr && H.sqrt_src >= 0 && H.n_imu == 1;
+            if (s_given) { for (int i = tid; i < 225; i += MARG_NT) S[i] = ((const gbl_d *)Aarg.solve_sqrt)[(size_t)H.solve_window * 225 + i]; }
+            else if (tid < 16) (void)imu_sqrt_info_group((const double *)(dp + H.d_imu + f * IMU_CONST + IMU_COV), GEN(S), GEN(stage + 512), GEN(stage + 512 + 225), tid);
             // the four parts of the raw residual / Jacobian on four wavefronts: lane 0 of waves 1..4, or (256 threads) lane 32 of waves 0..3
             constexpr int RW0 = MARG_NT >= 320 ? 1 : 0, RLANE = MARG_NT >= 320 ? 0 : 32;
             if ((tid & 63) == RLANE && (tid >> 6) >= RW0 && (tid >> 6) < RW0 + 4) {
@@ -820,6 +827,42 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((amdgpu_waves_per_eu(2,
                 }
             }
             __syncthreads();
+            if (H.proj_disjoint && !H.block_mode) {
+                // thread t owns entry (ca >= cb, or cb = residual) of the factor record for every factor of the chunk, in factor order: the
+                // same sums as the factor-by-factor loop below, bit for bit, without its barrier per factor.  The running destination stays
+                // in a register while consecutive factors hit the same element (the anchor pose, the extrinsics, one landmark's factors).
+                const int ntri = njc * (njc + 1) / 2;
+                for (int t = tid; t < ntri + njc; t += MARG_NT) {
+                    int ca, cb;
+                    if (t < ntri) { ca = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5); while ((ca + 1) * (ca + 2) / 2 <= t) ca++; while (ca * (ca + 1) / 2 > t) ca--; cb = t - ca * (ca + 1) / 2; }
+                    else { ca = t - ntri; cb = njc; }
+                    const int ga = ca < 18 ? ca / 6 : (ca == 18 ? 3 : 4), oa = ca < 18 ? ca % 6 : 0;
+                    const int gb = cb < 18 ? cb / 6 : (cb == 18 ? 3 : 4), ob = cb < 18 ? cb % 6 : 0;
+                    const int ra = ca == 19 ? 20 : ca, rb = cb == njc ? 19 : (cb == 19 ? 20 : cb);
+                    const int ltd = with_td ? blk[H.td_blk * 5 + 2] : -1;
+                    int prev = -1;
+                    double accv = 0.0;
+                    for (int f = 0; f < fn; f++) {
+                        cst_i *pf = ip + H.o_proj + (f0 + f) * 4;
+                        const int l0 = blk[pf[0] * 5 + 2], l1 = blk[pf[1] * 5 + 2], l2 = blk[pf[2] * 5 + 2], l3 = blk[pf[3] * 5 + 2];
+                        const int la = ga == 0 ? l0 : (ga == 1 ? l1 : (ga == 2 ? l2 : (ga == 3 ? l3 : ltd)));
+                        const int lb = gb == 0 ? l0 : (gb == 1 ? l1 : (gb == 2 ? l2 : (gb == 3 ? l3 : ltd)));
+                        const lds_d *rec = stage + f * prr;
+                        const double sv = rec[ra] * rec[rb] + rec[prs + ra] * rec[prs + rb];
+                        const int d = (la < 0 || (cb != njc && lb < 0)) ? -1 : (cb == njc ? MARG_MAX_POS * MARG_MAX_POS + la + oa : pidx(la + oa, lb + ob));
+                        if (d < 0) continue;
+                        if (d != prev) {
+                            if (prev >= 0) { if (prev >= MARG_MAX_POS * MARG_MAX_POS) bv[prev - MARG_MAX_POS * MARG_MAX_POS] = accv; else Apk[prev] = accv; }
+                            accv = d >= MARG_MAX_POS * MARG_MAX_POS ? bv[d - MARG_MAX_POS * MARG_MAX_POS] : Apk[d];
+                            prev = d;
+                        }
+                        accv += sv;
+                    }
+                    if (prev >= 0) { if (prev >= MARG_MAX_POS * MARG_MAX_POS) bv[prev - MARG_MAX_POS * MARG_MAX_POS] = accv; else Apk[prev] = accv; }
+                }
+                __syncthreads();
+                continue;
+            }
             for (int f = 0; f < fn; f++) {
                 cst_i *pf = ip + H.o_proj + (f0 + f) * 4;
                 const lds_d *rec = stage + f * prr;
@@ -1185,6 +1228,10 @@ static int pack_marg(const tcv_problem &p, double *const *drop, int ndrop, const
     for (int c = 0; c < nblk; c++) { I.push_back(gsize[c]); I.push_back(goff[c]); I.push_back(mloc[c]); I.push_back(kind[c]); I.push_back(xsrc[c]); }
     H.o_imu = imark();
     for (auto &f : p.imu) for (int k = 0; k < 4; k++) I.push_back(id_of[f.b[k]]);
+    H.sqrt_src = -1;
+    if (p.imu.size() == 1 && solve_p)      // the same pre-integration among the solve's factors (MARGIN_OLD: the factor between frames 0 and 1)
+        for (size_t g = 0; g < solve_p->imu.size(); g++)
+            if (std::memcmp(&solve_p->imu[g].pre, &p.imu[0].pre, sizeof(tcv_imu_preintegration)) == 0) { H.sqrt_src = (int)g; break; }
     std::vector<int> porder(p.proj.size());
     for (size_t i = 0; i < porder.size(); i++) porder[i] = (int)i;
     if (block_mode) {
@@ -1200,6 +1247,13 @@ static int pack_marg(const tcv_problem &p, double *const *drop, int ndrop, const
     }
     H.o_proj = imark();
     for (int k2 : porder) for (int k = 0; k < 4; k++) I.push_back(id_of[p.proj[k2].b[k]]);
+    {
+        std::vector<char> as_i(nb, 0), as_j(nb, 0);
+        for (auto &f : p.proj) { as_i[f.b[0]] = 1; as_j[f.b[1]] = 1; }
+        H.proj_disjoint = 1;
+        for (int c = 0; c < nb; c++) if (as_i[c] && as_j[c]) H.proj_disjoint = 0;
+        if (getenv("TCV_MARG_PROJ_SERIAL")) H.proj_disjoint = 0;      // A/B checks: the factor-by-factor accumulation
+    }
     H.o_plast = imark();
     for (size_t i = 0; i < porder.size(); i++)
         I.push_back(block_mode && lm_id[p.proj[porder[i]].b[3]] >= 0 && (i + 1 == porder.size() || p.proj[porder[i + 1]].b[3] != p.proj[porder[i]].b[3]) ? 1 : 0);
@@ -1356,6 +1410,7 @@ int tcv_marg_run(tcv_batch *b, void *stream) {
     a.hdr = s->d_hdr; a.ipool = s->d_ipool; a.dpool = s->d_dpool; a.solve_state = b->d_state; a.out = s->d_out;
     a.out_status = s->d_status; a.scratch = s->d_scratch; a.nwin = b->n; a.state_stride = b->state_stride;
     a.use_solved_state = b->solved ? 1 : 0;
+    a.solve_sqrt = (b->solved && b->sqrt_out_valid && !getenv("TCV_MARG_OWN_SQRT")) ? b->d_sqrt_out : nullptr;
     a.eig_mm = getenv("TCV_MARG_EIG_MM") ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     const void *fn = s->nt == MARG_NT_PAIR ? (const void *)marg_kernel<MARG_NT_PAIR> : (const void *)marg_kernel<MARG_NT_WIDE>;
@@ -1369,6 +1424,11 @@ int tcv_marg_run(tcv_batch *b, void *stream) {
     s->ran = true;
     s->h_valid = false;
     return TCV_OK;
+}
+
+int tcv_marg_sqrt_source(const tcv_batch *b, int window) {
+    const MargState *s = (const MargState *)b->marg;
+    return (s && window >= 0 && window < b->n) ? s->win[window].hdr.sqrt_src : -1;
 }
 
 // one D2H copy of every window's result block and status instead of one copy per tcv_batch_get_prior call, into a pinned buffer.

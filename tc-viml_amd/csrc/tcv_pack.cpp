@@ -646,7 +646,7 @@ static int pack_data_to(const tcv_problem &p, Packed &out, const double *imu_sqr
     const int plan_id = W.plan;
     const long long dbase = W.dbase;
     std::memset(&W, 0, sizeof(W));
-    W.plan = plan_id; W.dbase = dbase;
+    W.plan = plan_id; W.dbase = dbase; W.sqrt_export = -1;
     W.d_x = (int)D.n;
     for (int c = 0; c < nblk; c++) { const ParamBlock &pb = p.blocks[out.cam_block[c]]; D.put(pb.addr, pb.size); }
     for (int l = 0; l < L; l++) D.put1(p.blocks[out.lm_block[l]].addr[0]);

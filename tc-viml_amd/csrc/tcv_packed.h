@@ -100,7 +100,7 @@ struct PlanHdr {
 
 struct WinHdr {
     int plan;           // index of the plan
-    int pad;
+    int sqrt_export;    // >= 0: the solve writes this IMU factor's sqrt_info to SolveArgs::sqrt_out (the factor the batch's marginalisation needs)
     long long dbase;    // element offset of this window's doubles in the batch data pool
     // double-pool offsets (relative to dbase)
     int d_x;        // nx + nland initial state (camera blocks in block order, then landmarks)
@@ -142,6 +142,8 @@ struct SolveArgs {
     double *spill;                // chain mode, per workgroup: factored fronts (spill_stride doubles)
     int spill_stride, pad2;       // pad2: phase skip mask of the -DTCV_ABLATE developer build (0 otherwise)
     long long max_ticks;          // max_solver_time_in_seconds in ticks of the constant-rate device clock (wall_clock64); 0: no limit
+    double *sqrt_out;             // optional, per window: 225 doubles -- the sqrt_info of IMU factor WinHdr::sqrt_export as computed by this solve
+                                  // (the marginalisation of the same batch reads it instead of factorising the covariance again)
 };
 
 // chain step record (CH_STRIDE ints per step, copied into LDS by the kernel): a header, two ints per "front row" and a byte map from

@@ -1782,6 +1782,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CHAIN ?
                                           GEN(lds + f * 450 + 225), tid & 15);
         }
         __syncthreads();
+        if (A.sqrt_out && W->d_sqrt < 0 && W->sqrt_export >= 0 && tid < 225) A.sqrt_out[(size_t)win * 225 + tid] = C.g_sqrt[W->sqrt_export * 225 + tid];
         // constant part of the prior: Hp = J0' J0 (packed lower), marginalization_factor.cpp:366,371-380.  The tile
         // region is still unused: J0 is staged there (columns contiguous) and every thread forms 1 x 2 entry pairs.
         if (P.prior_n > 0) {
