@@ -21,7 +21,16 @@ python3 tools/pmc_traffic.py $O/fetch $O/write $O/pmc_traffic.json > /dev/null 2
 if [ -f tc-viml_amd/libtcv_hip_prof.so ]; then
   TCV_LIB=tc-viml_amd/libtcv_hip_prof.so python3 tools/dev_phase_profile.py 512 256 --prior > $O/phase_cycles_solve.txt 2>&1
   TCV_LIB=tc-viml_amd/libtcv_hip_prof.so TCV_DEBUG=1 python3 tools/dev_marg_profile.py > $O/phase_cycles_marg.txt 2>&1
+  TCV_MARG_NT=256 TCV_LIB=tc-viml_amd/libtcv_hip_prof.so TCV_DEBUG=1 python3 tools/dev_marg_profile.py > $O/phase_cycles_marg_256.txt 2>&1
 fi
+if [ -f tc-viml_amd/libtcv_hip_abl.so ]; then
+  TCV_LIB=tc-viml_amd/libtcv_hip_abl.so python3 tools/dev_ablate.py 1024 > $O/ablation_solve_B1024.txt 2>&1
+fi
+python3 tests/dev/stream_breakdown.py > $O/stream_breakdown.txt 2>&1
+python3 tests/dev/parity_sweep.py 1024 > $O/parity_sweep.txt 2>&1
+python3 tests/dev/marg_floor.py > $O/marg_floor.txt 2>&1
+python3 tests/dev/replay_seed_sweep.py > $O/replay_seed_sweep.txt 2>&1
+TCV_MARG_EIG_MM=1 python3 tests/dev/replay_seed_sweep.py > $O/replay_seed_sweep_eig.txt 2>&1
 find $O -name "*_kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
 python3 - <<PY
 import csv, glob, collections, json
