@@ -96,3 +96,65 @@ def test_chain_and_dense_layouts_agree_on_a_large_batch(gpu):
         assert sum(1 for a, b in zip(t0, t1) if a == b) >= B - 6
         if mode == 0:
             assert rel(p0, p1) < 1e-6
+
+
+def _marg_batch(tcv, wins):
+    W = [tcv.Window(w) for w in wins]
+    MW = [tcv.margin_old_window(w) for w in wins]
+    M = [tcv.Window(mw, share=W[k]) for k, mw in enumerate(MW)]
+    drops = [tcv.margin_old_drops(W[k], MW[k]) for k in range(len(wins))]
+    return W, tcv.Batch(W, M, drops)
+
+
+def test_compact_prior_download_and_concurrent_host_threads(gpu):
+    """The PCIe-inclusive path of bench.py --mode stream: two host threads, each creating batches from host-resident problems (windows packed in
+    parallel into a pinned upload buffer from the shared pool), running solve -> gauge fix -> marginalisation on its own HIP stream and bringing
+    the priors back with ONE strided copy (tcv_batch_download_priors_compact: J0, r0, linearisation point; no A', b').  Same bits as a plain
+    sequential pass with the full download; a prior from the compact copy has no Schur system to export."""
+    import ctypes
+    import threading
+    hip = ctypes.CDLL("libamdhip64.so")       # plain HIP streams: the C-ABI takes a hipStream_t, whoever made it
+    B = 300                                   # > 256 CUs: two workgroups per CU in both kernels
+    batch = synth.make_windows(7000, 2 * B, frame_shift=-1)
+    wins = [synth.window_at(batch, k) for k in range(2 * B)]
+    opts = gpu.default_options(8, True)
+    ref = []
+    for h in range(2):                        # reference: sequential, default stream, full download
+        W, b = _marg_batch(gpu, wins[h * B:(h + 1) * B])
+        b.solve(opts); b.gauge_fix(); b.marginalize(); b.synchronize(); b.download_states(); b.download_priors()
+        ref.append(([w.pose.copy() for w in W], [b.prior(k).export() for k in range(0, B, 7)], b.prior(0).schur()))
+        assert list(b.marg_status()) == [0] * B
+    out = [None, None]
+    err = []
+    streams = [ctypes.c_void_p(), ctypes.c_void_p()]
+    for st in streams:
+        assert hip.hipStreamCreateWithFlags(ctypes.byref(st), 1) == 0      # hipStreamNonBlocking
+
+    def worker(h):
+        try:
+            st = streams[h]
+            for rep in range(3):              # the staging buffers go back to the pool and are taken again
+                W, b = _marg_batch(gpu, wins[h * B:(h + 1) * B])
+                b.solve(opts, st); b.gauge_fix(st); b.marginalize(st); b.synchronize()
+                b.download_states(); b.download_priors(compact=True)
+                pr = [b.prior(k) for k in range(0, B, 7)]
+                out[h] = ([w.pose.copy() for w in W], [p.export() for p in pr])
+                with pytest.raises(gpu.TcvError):
+                    pr[0].schur()
+                del b
+        except Exception as e:                # noqa: BLE001 -- reported by the main thread
+            err.append(e)
+
+    th = [threading.Thread(target=worker, args=(h,)) for h in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not err, err
+    for st in streams:
+        hip.hipStreamDestroy(st)
+    for h in range(2):
+        assert all(np.array_equal(a, b2) for a, b2 in zip(ref[h][0], out[h][0]))
+        for d0, d1 in zip(ref[h][1], out[h][1]):
+            assert np.array_equal(d0["J0"], d1["J0"]) and np.array_equal(d0["r0"], d1["r0"]) and d0["idx"] == d1["idx"]
+            assert all(np.array_equal(x0, x1) for x0, x1 in zip(d0["x0"], d1["x0"]))
