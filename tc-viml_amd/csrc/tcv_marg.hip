@@ -772,7 +772,7 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((amdgpu_waves_per_eu(2,
                 }
             }
             __syncthreads();
-            const int colc[4] = {0, 6, 15, 21}, colw[4] = {6, 9, 6, 9};
+            const int colc[4] = {0, 6, 15, 21};
             for (int e = tid; e < 30 * 31; e += MARG_NT) {
                 const int ca = e / 31, cb = e - ca * 31;   // cb == 30: residual column
                 if (cb < 30 && cb > ca) continue;
@@ -789,7 +789,6 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((amdgpu_waves_per_eu(2,
                 if (lb < 0) continue;
                 Apk[pidx(ia, lb + cb - colc[sb])] += s;
             }
-            (void)colw;
             __syncthreads();
         }
         MARG_MARK(2);
@@ -1044,7 +1043,6 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((amdgpu_waves_per_eu(2,
         MARG_MARK(6);
         // A' = V2 diag(lam) V2': tridiagonal path first, Jacobi sweep as the safety net (its eigenvector matrix in HBM scratch, copied
         // over the diagonalised A' at the end: the LDS holds one n x n matrix)
-        lds_d *evals = lam;
         int sweeps2 = 0;
         {
             const bool ok = sym_eig_tridiag<MARG_NT>(As, R2, sm, rot, n, ldn, tid, out + MARG_OUT_X + MARG_MAX_X + 14);    // rot: 160 doubles >= n eigenvalues
@@ -1078,7 +1076,7 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((amdgpu_waves_per_eu(2,
         }
         for (int i = tid; i < H.nx; i += MARG_NT) out[MARG_OUT_X + i] = x[i];
         MARG_MARK(8);
-        if (tid == 0) ((gbl_i *)Aarg.out_status)[win] = (sweeps1 >= 24 || sweeps2 == 124) ? 1 : (sweeps2 >= 100 ? 2 : 0);   // 1: Jacobi hit the sweep cap, 2: fell back to Jacobi   // 1: Jacobi hit the sweep cap
+        if (tid == 0) ((gbl_i *)Aarg.out_status)[win] = (sweeps1 >= 24 || sweeps2 == 124) ? 1 : (sweeps2 >= 100 ? 2 : 0);   // 1: a Jacobi sweep hit its cap, 2: A' went through the Jacobi safety net
         if (tid == 0) { out[MARG_OUT_X + MARG_MAX_X] = sweeps1; out[MARG_OUT_X + MARG_MAX_X + 1] = sweeps2; }
         __syncthreads();
     }
