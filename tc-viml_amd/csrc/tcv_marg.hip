@@ -402,32 +402,35 @@ __device__ __noinline__ bool sym_eig_tridiag(lds_d *A, lds_d *Hq, lds_d *sm, lds
             lds_d *hq = Hq + refl_off(i, n);
             // A22 -= v w' + w v',  w = p + K v ; eight lanes per row.  The reflector goes to its packed slot for the back-transform.
             // Next step: x' = new A22[0][1:], u'_(rr-1) = sum_(c >= 1) new A22[rr][c] x'[c], |x'[1:]|^2.
+            // J column slots per lane (8 J >= m): three static sizes, so that the small trailing blocks of the late steps do not pay for ten
+            // clamped loads and masked updates per lane -- the skipped slots held nothing (c >= m): the same sums, bit for bit
             const int part8 = tid & 7;
-            for (int rr = tid >> 3; rr < ((m + 7) & ~7); rr += NT / 8) {
-                const int rc = min(rr, m - 1);
-                const double vr = vbuf[rc], wr = pbuf[rc] + K * vr;
-                lds_d *row = A + (i + 1 + rc) * ld + (i + 1);
-                double vc[10], pc[10], av[10], xo[10];      // m <= 79: at most 10 columns per lane, every load in flight at once
-#pragma unroll
-                for (int j = 0; j < 10; j++) { const int c = min(part8 + 8 * j, m - 1); vc[j] = vbuf[c]; pc[j] = pbuf[c]; av[j] = row[c]; xo[j] = xold[c]; }
-                double un = 0, x2 = 0;
-#pragma unroll
-                for (int j = 0; j < 10; j++) {
-                    const int c = part8 + 8 * j;
-                    if (c < m) {
-                        const double wc = pc[j] + K * vc[j];
-                        const double nv = rank2(av[j], vr, wc, wr, vc[j]);
-                        const double xn = rank2(xo[j], v0, wc, w0, vc[j]);      // new A22[0][c], bit for bit what row 0's lanes store
-                        if (rr < m) row[c] = nv;
-                        if (c >= 1) { un += nv * xn; if (c >= 2) x2 += xn * xn; }
-                    }
-                }
-                un += __shfl_xor(un, 1); un += __shfl_xor(un, 2); un += __shfl_xor(un, 4);
-                x2 += __shfl_xor(x2, 1); x2 += __shfl_xor(x2, 2); x2 += __shfl_xor(x2, 4);
-                if (part8 == 0 && rr >= 1 && rr < m) ubuf[rr - 1] = un;
-                if (part8 == 0 && rr == 1) xnb[(i + 1) & 1] = x2;
-                if (part8 == 0 && rr > 0 && rr < m) hq[rr - 1] = vr;
+#define TCV_R2_BODY(J)                                                                                                               \
+            for (int rr = tid >> 3; rr < ((m + 7) & ~7); rr += NT / 8) {                                                             \
+                const int rc = min(rr, m - 1);                                                                                       \
+                const double vr = vbuf[rc], wr = pbuf[rc] + K * vr;                                                                  \
+                lds_d *row = A + (i + 1 + rc) * ld + (i + 1);                                                                        \
+                double vc[J], pc[J], av[J], xo[J];      /* every load in flight at once */                                           \
+                _Pragma("unroll") for (int j = 0; j < J; j++) { const int c = min(part8 + 8 * j, m - 1); vc[j] = vbuf[c]; pc[j] = pbuf[c]; av[j] = row[c]; xo[j] = xold[c]; } \
+                double un = 0, x2 = 0;                                                                                               \
+                _Pragma("unroll") for (int j = 0; j < J; j++) {                                                                      \
+                    const int c = part8 + 8 * j;                                                                                     \
+                    if (c < m) {                                                                                                     \
+                        const double wc = pc[j] + K * vc[j];                                                                         \
+                        const double nv = rank2(av[j], vr, wc, wr, vc[j]);                                                           \
+                        const double xn = rank2(xo[j], v0, wc, w0, vc[j]);      /* new A22[0][c], bit for bit what row 0's lanes store */ \
+                        if (rr < m) row[c] = nv;                                                                                     \
+                        if (c >= 1) { un += nv * xn; if (c >= 2) x2 += xn * xn; }                                                    \
+                    }                                                                                                                \
+                }                                                                                                                    \
+                un += __shfl_xor(un, 1); un += __shfl_xor(un, 2); un += __shfl_xor(un, 4);                                           \
+                x2 += __shfl_xor(x2, 1); x2 += __shfl_xor(x2, 2); x2 += __shfl_xor(x2, 4);                                           \
+                if (part8 == 0 && rr >= 1 && rr < m) ubuf[rr - 1] = un;                                                              \
+                if (part8 == 0 && rr == 1) xnb[(i + 1) & 1] = x2;                                                                    \
+                if (part8 == 0 && rr > 0 && rr < m) hq[rr - 1] = vr;                                                                 \
             }
+            if (m > 40) { TCV_R2_BODY(10) } else if (m > 16) { TCV_R2_BODY(5) } else { TCV_R2_BODY(2) }
+#undef TCV_R2_BODY
         }
         __syncthreads();
     }
