@@ -932,7 +932,15 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((amdgpu_waves_per_eu(2,
                 bool ok = true;
                 for (int k = 0; k < m; k++) {
                     double sv = Mm[i * ldm + k], sd = Mm[k * ldm + k];
-                    for (int p2 = 0; p2 < k; p2++) { const double lk = Mm[k * ldm + p2]; sv -= Mm[i * ldm + p2] * lk; sd -= lk * lk; }
+                    int p2 = 0;
+                    for (; p2 + 3 < k; p2 += 4) {      // four steps' loads in flight, the updates in the original order
+                        double lk[4], li[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) { lk[u] = Mm[k * ldm + p2 + u]; li[u] = Mm[i * ldm + p2 + u]; }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) { sv -= li[u] * lk[u]; sd -= lk[u] * lk[u]; }
+                    }
+                    for (; p2 < k; p2++) { const double lk = Mm[k * ldm + p2]; sv -= Mm[i * ldm + p2] * lk; sd -= lk * lk; }
                     ok = ok && (sd > 0.0) && (sd < 1e300);
                     const double rs = 1.0 / sqrt(ok ? sd : 1.0);
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -952,7 +960,15 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((amdgpu_waves_per_eu(2,
                 const int j = tid;
                 for (int k = 0; k < m; k++) {
                     double sv = j < n ? Apk[pidx(m + j, k)] : bv[k];
-                    for (int p2 = 0; p2 < k; p2++) sv -= Mm[k * ldm + p2] * Zl[p2 * zs + j];
+                    int p2 = 0;
+                    for (; p2 + 3 < k; p2 += 4) {
+                        double lk[4], zz[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) { lk[u] = Mm[k * ldm + p2 + u]; zz[u] = Zl[(p2 + u) * zs + j]; }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) sv -= lk[u] * zz[u];
+                    }
+                    for (; p2 < k; p2++) sv -= Mm[k * ldm + p2] * Zl[p2 * zs + j];
                     Zl[k * zs + j] = sv * Mm[k * ldm + k];
                 }
             } else if (tid < n + 1 + m) {
