@@ -664,7 +664,17 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((amdgpu_waves_per_eu(2,
             __syncthreads();
             if (tid < np) {
                 double r = r0[tid];
-                if (in_lds) for (int j = 0; j < np; j++) r += Js[tid + np * j] * pdx[j];
+                if (in_lds) {
+                    int j = 0;
+                    for (; j + 3 < np; j += 4) {
+                        double a4[4], d4[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) { a4[u] = Js[tid + np * (j + u)]; d4[u] = pdx[j + u]; }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) r += a4[u] * d4[u];
+                    }
+                    for (; j < np; j++) r += Js[tid + np * j] * pdx[j];
+                }
                 else for (int j = 0; j < np; j++) r += J0[tid + np * j] * pdx[j];
                 pr[tid] = r;
             }
@@ -703,7 +713,17 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((amdgpu_waves_per_eu(2,
                 }
                 double s2 = 0;
                 const bool mine = tid < np && pcol[min(tid, np - 1)] >= 0;
-                if (mine) for (int i = 0; i < np; i++) s2 += Js[i + np * tid] * pr[i];
+                if (mine) {
+                    int i = 0;
+                    for (; i + 3 < np; i += 4) {
+                        double a4[4], r4[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) { a4[u] = Js[i + u + np * tid]; r4[u] = pr[i + u]; }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) s2 += a4[u] * r4[u];
+                    }
+                    for (; i < np; i++) s2 += Js[i + np * tid] * pr[i];
+                }
                 __syncthreads();      // every read of the staged J0 is done: P becomes A
                 for (int i = tid; i < npk; i += MARG_NT) Apk[i] = 0.0;
                 a_zeroed = true;
@@ -1004,7 +1024,15 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((amdgpu_waves_per_eu(2,
             for (int e = tid; e < n * n; e += MARG_NT, q++) {
                 const int i = e / n, j = e - i * n;
                 double sv = Apk[pidx(m + i, m + j)];
-                for (int k = 0; k < m; k++) sv -= Zl[k * zs + i] * Zl[k * zs + j];
+                int k = 0;
+                for (; k + 3 < m; k += 4) {      // four steps' loads in flight, the updates in the original order
+                    double za[4], zb4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { za[u] = Zl[(k + u) * zs + i]; zb4[u] = Zl[(k + u) * zs + j]; }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) sv -= za[u] * zb4[u];
+                }
+                for (; k < m; k++) sv -= Zl[k * zs + i] * Zl[k * zs + j];
                 keepA[q] = sv;
             }
             if (tid < n) {
