@@ -565,7 +565,15 @@ __device__ __noinline__ double linearize(Ctx<NT> &Cr, const lds_d *x, bool first
                 copy_doubles_deep<NT>(Jp, J0g + n * c0, n * cn, tid);
                 __syncthreads();
                 if (tid < n) {
-                    for (int j = 0; j + 1 < cn; j += 2) { r += Jp[tid + n * j] * pdx2[c0 + j]; r2 += Jp[tid + n * (j + 1)] * pdx2[c0 + j + 1]; }
+                    int j = 0;
+                    for (; j + 7 < cn; j += 8) {      // eight columns' loads in flight, the two accumulators updated in the original order
+                        double a8[8], d8[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) { a8[u] = Jp[tid + n * (j + u)]; d8[u] = pdx2[c0 + j + u]; }
+#pragma unroll
+                        for (int u = 0; u < 8; u += 2) { r += a8[u] * d8[u]; r2 += a8[u + 1] * d8[u + 1]; }
+                    }
+                    for (; j + 1 < cn; j += 2) { r += Jp[tid + n * j] * pdx2[c0 + j]; r2 += Jp[tid + n * (j + 1)] * pdx2[c0 + j + 1]; }
                     if (cn & 1) r += Jp[tid + n * (cn - 1)] * pdx2[c0 + cn - 1];
                 }
                 if (piece == 0) __syncthreads();
@@ -583,7 +591,15 @@ __device__ __noinline__ double linearize(Ctx<NT> &Cr, const lds_d *x, bool first
                         if (t >= 0) {
                             const lds_d *col = Jp + n * tid;
                             double s0 = 0, s1 = 0;
-                            for (int i = 0; i + 1 < n; i += 2) { s0 += col[i] * pr2[i]; s1 += col[i + 1] * pr2[i + 1]; }
+                            int i = 0;
+                            for (; i + 7 < n; i += 8) {
+                                double a8[8], r8[8];
+#pragma unroll
+                                for (int u = 0; u < 8; u++) { a8[u] = col[i + u]; r8[u] = pr2[i + u]; }
+#pragma unroll
+                                for (int u = 0; u < 8; u += 2) { s0 += a8[u] * r8[u]; s1 += a8[u + 1] * r8[u + 1]; }
+                            }
+                            for (; i + 1 < n; i += 2) { s0 += col[i] * pr2[i]; s1 += col[i + 1] * pr2[i + 1]; }
                             if (n & 1) s0 += col[n - 1] * pr2[n - 1];
                             C.gcam[t] += s0 + s1;
                         }
