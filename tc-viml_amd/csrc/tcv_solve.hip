@@ -1807,13 +1807,23 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CHAIN ?
             const bool in_lds = n * n <= (C.ntiles << 8) + (CHAIN ? P.c_pool : 0);
             if (in_lds) copy_doubles<NT>(lds, J0g, n * n, tid);
             __syncthreads();
-            for (int e = tid; e < n * n; e += NT) {
-                const int a = e / n, b = e - a * n;
-                if (b > a) continue;
+            for (int e = tid; e < n * (n + 1) / 2; e += NT) {      // packed index e = a (a + 1) / 2 + b, b <= a: every lane has an entry
+                int a = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+                while ((a + 1) * (a + 2) / 2 <= e) a++;
+                while (a * (a + 1) / 2 > e) a--;
+                const int b = e - a * (a + 1) / 2;
                 double s0 = 0, s1 = 0;
                 if (in_lds) {
                     const lds_d *ca = lds + n * a, *cb = lds + n * b;
-                    for (int i = 0; i + 1 < n; i += 2) { s0 += ca[i] * cb[i]; s1 += ca[i + 1] * cb[i + 1]; }
+                    int i = 0;
+                    for (; i + 7 < n; i += 8) {      // eight rows' loads in flight, the two accumulators updated in the original order
+                        double a8[8], b8[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) { a8[u] = ca[i + u]; b8[u] = cb[i + u]; }
+#pragma unroll
+                        for (int u = 0; u < 8; u += 2) { s0 += a8[u] * b8[u]; s1 += a8[u + 1] * b8[u + 1]; }
+                    }
+                    for (; i + 1 < n; i += 2) { s0 += ca[i] * cb[i]; s1 += ca[i + 1] * cb[i + 1]; }
                     if (n & 1) s0 += ca[n - 1] * cb[n - 1];
                 } else {
                     for (int i = 0; i < n; i++) s0 += J0g[i + n * a] * J0g[i + n * b];
