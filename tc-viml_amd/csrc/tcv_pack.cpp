@@ -548,7 +548,35 @@ static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds)
         H.n_imu_chunk = (int)ichunk.size() / 4;
         H.o_idest = mark(); I.insert(I.end(), imap.begin(), imap.end()); H.n_idest = (int)imap.size();
         H.o_iunit = mark(); I.insert(I.end(), icolor.begin(), icolor.end()); H.n_iunit = (int)icolor.size();
-        H.o_iitem = H.o_iunit; H.n_iitem = 0;
+        // scatter table of the J'J tiles (see IMU_SC_BIAS): what the kernel would derive from the tangent map for every lane and register
+        std::vector<int> sct((size_t)H.n_imu * 1024, 0);
+        for (int f = 0; f < H.n_imu; f++) {
+            const int *tm = imap.data() + (size_t)f * 32;
+            for (int lane = 0; lane < 64; lane++) {
+                const int i16 = lane & 15, k4 = lane >> 4;
+                for (int tile = 0; tile < 4; tile++) {     // (I, J): (0,0) (1,0) (1,1) (0,1)
+                    const int Ir = (tile == 1 || tile == 2) ? 1 : 0, Jc = (tile >= 2) ? 1 : 0;
+                    const int bl = 16 * Jc + i16;
+                    for (int i = 0; i < 4; i++) {
+                        const int al = 16 * Ir + k4 + 4 * i;
+                        const int ta = tm[al], tb = tm[bl];
+                        int d = -1, store = 0;
+                        if (ta >= 0) {
+                            if (bl == 30) d = -2 - ta;
+                            else if (tile != 3 && bl < 30 && al >= bl && tb >= 0) {
+                                store = use_chain ? 1 : 0;
+                                if (use_chain && (ta >= npp || tb >= npp)) d = (al == bl) ? -1000 - (ta - npp) : -1;
+                                else d = ta >= tb ? tix(ta, tb) : tix(tb, ta);
+                            }
+                        }
+                        if (d + IMU_SC_BIAS < 0 || d + IMU_SC_BIAS >= (1 << 16)) { set_error("IMU scatter destination out of range"); return TCV_ERR_TOO_LARGE; }
+                        sct[(size_t)f * 1024 + lane * 16 + tile * 4 + i] = (d + IMU_SC_BIAS) | (store ? IMU_SC_STORE : 0);
+                    }
+                }
+            }
+        }
+        while ((I.size() & 3) != 0) I.push_back(0);      // read with 16-byte loads
+        H.o_iitem = mark(); I.insert(I.end(), sct.begin(), sct.end()); H.n_iitem = (int)sct.size();
         H.o_ichunk = mark(); I.insert(I.end(), ichunk.begin(), ichunk.end());
     }
     // ---- chain step tables

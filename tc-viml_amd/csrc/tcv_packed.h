@@ -35,6 +35,17 @@ enum {
     IMU_CONST = 287    // doubles of pre-integration constants per IMU factor
 };
 
+// 16 x 16 tiles of the reduced camera system in LDS: lower-triangular tile order, XOR-swizzled columns (conflict-free row AND column
+// walks); shared by the kernels and by the packer (which precomputes scatter destinations)
+__host__ __device__ inline int sw(int r, int c) { return (r << 4) + (c ^ (r & 14)); }
+__host__ __device__ inline int tbase(int I, int J) { return ((I * (I + 1) / 2) + J) << 8; }
+__host__ __device__ inline int tix(int a, int b) { return tbase(a >> 4, b >> 4) + sw(a & 15, b & 15); }
+// IMU scatter table (PlanHdr::o_iitem, n_imu x 1024 ints, [factor][lane][16]): per lane and accumulator register q = 4 tile + i of the
+// factor's four 16 x 16 J'J tiles the destination of the value: low 16 bits = d + IMU_SC_BIAS with d >= 0 a tile element, d = -1 nothing,
+// d <= -2 the gradient entry -2 - d, d <= -1000 the diagonal store of a Euclidean block (chain layout); bit 16: the value is also
+// parked in the per-factor J'J block in HBM (chain layout)
+enum { IMU_SC_BIAS = 4096, IMU_SC_STORE = 1 << 16 };
+
 // gather destination kinds
 enum { DK_TILE = 0, DK_G = 1, DK_HCL = 2, DK_HLL = 3, DK_GL = 4, DK_RC = 5 };
 
@@ -83,7 +94,7 @@ struct PlanHdr {
     int o_sdest, o_sunit, o_sitem;   // Schur plan
     int n_sdest, n_sunit, n_sitem;
     int o_ichunk;   // n_imu_chunk x 4 : fac_begin, fac_count, number of colours, 0
-    int o_idest, o_iunit, o_iitem;   // o_idest: n_imu x 32 tangent index of each local column (-1 constant); o_iunit: n_imu colours
+    int o_idest, o_iunit, o_iitem;   // o_idest: n_imu x 32 tangent index of each local column (-1 constant); o_iunit: n_imu colours; o_iitem: scatter table
     int n_idest, n_iunit, n_iitem;
     // chain mode (tcv_solve.hip, CHAIN = true): the Euclidean camera blocks (speed-biases) are eliminated one by one in a
     // fixed order BEFORE the dense pose system; only the pose part (npp + 1 rhs row) lives in LDS tiles

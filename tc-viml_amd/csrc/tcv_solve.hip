@@ -31,9 +31,6 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 // element (r, c) of a 16x16 tile sits at r*16 + (c ^ (r & 14)): conflict-free for the MFMA operand
 // reads (lane -> row l&15, column 4kk + (l>>4)), for the C-layout loads/stores and for row-per-lane
 // column walks.
-__device__ __forceinline__ int sw(int r, int c) { return (r << 4) + (c ^ (r & 14)); }
-__device__ __forceinline__ int tbase(int I, int J) { return ((I * (I + 1) / 2) + J) << 8; }
-__device__ __forceinline__ int tix(int a, int b) { return tbase(a >> 4, b >> 4) + sw(a & 15, b & 15); }
 
 // optional per-phase cycle accounting (build with -DTCV_PROFILE): lane 0 adds s_memtime deltas to 32-bit counters in LDS (the
 // spare half of the reduction scratch; a global read-modify-write per mark used to stall wave 0 for ~1 K cycles and inflated
@@ -721,14 +718,10 @@ __device__ __noinline__ double linearize(Ctx<NT> &Cr, const lds_d *x, bool first
                     if ((int)((colorbits >> (2 * f)) & 3u) != color) continue;
                     if ((slot++ % NW) != wave) continue;
                     const lds_d *rec = recs + f * IMU_REC;
-                    cst_i *tm = imap + (fb + f) * 32;
-                    // tangent indices of this lane's C rows (two row tiles x four registers) and C columns, all loads up front
-                    int trow[2][4], tcol[2];
-#pragma unroll
-                    for (int I = 0; I < 2; I++)
-#pragma unroll
-                        for (int i = 0; i < 4; i++) trow[I][i] = tm[16 * I + k4 + 4 * i];     // entries 30, 31 are -1
-                    tcol[0] = tm[i16]; tcol[1] = tm[16 + i16];
+                    // destinations of this lane's 16 accumulator registers: precomputed by the packer (IMU scatter table), four 16-byte loads
+                    cst_v4i *sct = (cst_v4i *)(ip + P.o_iitem + (fb + f) * 1024) + lane * 4;
+                    const v4i sc0 = sct[0], sc1 = sct[1], sc2 = sct[2], sc3 = sct[3];
+                    const int scv[16] = {sc0.x, sc0.y, sc0.z, sc0.w, sc1.x, sc1.y, sc1.z, sc1.w, sc2.x, sc2.y, sc2.z, sc2.w, sc3.x, sc3.y, sc3.z, sc3.w};
                     double op[2][4];      // operand values of column tiles 0 and 1 (A and B operands coincide: J' J)
 #pragma unroll
                     for (int t = 0; t < 2; t++)
@@ -746,7 +739,10 @@ __device__ __noinline__ double linearize(Ctx<NT> &Cr, const lds_d *x, bool first
 #pragma unroll
                         for (int kk = 0; kk < 4; kk++) acc[tile] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[I][kk], op[J][kk], acc[tile], 0, 0, 0);
                     }
-                    // scatter: all destination reads in flight, then the adds, then the writes (distinct addresses per lane)
+                    // scatter: all destination reads in flight, then the adds, then the writes (distinct addresses per lane).  Chain mode: the
+                    // factor's lower triangle is also parked in HBM/L2 for the chain elimination (whole rows, so that the stores fill their
+                    // 64-byte granules; no other factor writes there); entries of a Euclidean block's row / column go nowhere else, their
+                    // diagonal feeds the Jacobi scaling.
                     int didx[16];
                     double dval[16];
 #pragma unroll
@@ -756,20 +752,9 @@ __device__ __noinline__ double linearize(Ctx<NT> &Cr, const lds_d *x, bool first
 #pragma unroll
                         for (int i = 0; i < 4; i++) {
                             const int al = 16 * I + k4 + 4 * i;  // local row
-                            const int ta = trow[I][i], tb = tcol[J];
-                            int d = -1;                          // >= 0: tile element, -2 - ta: gradient entry, -1: nothing
-                            if (ta >= 0) {
-                                if (bl == 30) d = -2 - ta;
-                                else if (tile != 3 && bl < 30 && al >= bl && tb >= 0) {
-                                    // chain mode: the factor's lower triangle is parked in HBM/L2 for the chain elimination (whole
-                                    // rows, so that the stores fill their 64-byte granules; no other factor writes there).  Entries
-                                    // of a Euclidean block's row / column go nowhere else; their diagonal feeds the Jacobi scaling.
-                                    if (CHAIN) C.g_imublk[(fb + f) * IMU_BLK + al * 32 + bl] = acc[tile][i];
-                                    if (CHAIN && (ta >= P.npp || tb >= P.npp)) d = (al == bl) ? -1000 - (ta - P.npp) : -1;
-                                    else d = ta >= tb ? tix(ta, tb) : tix(tb, ta);
-                                }
-                            }
-                            didx[tile * 4 + i] = d;
+                            const int e = scv[tile * 4 + i];
+                            if (CHAIN && (e & IMU_SC_STORE)) C.g_imublk[(fb + f) * IMU_BLK + al * 32 + bl] = acc[tile][i];
+                            didx[tile * 4 + i] = (e & 0xffff) - IMU_SC_BIAS;      // >= 0: tile element, -2 - ta: gradient entry, -1: nothing
                         }
                     }
 #pragma unroll
