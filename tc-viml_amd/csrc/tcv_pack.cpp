@@ -579,6 +579,21 @@ static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds)
         H.o_iitem = mark(); I.insert(I.end(), sct.begin(), sct.end()); H.n_iitem = (int)sct.size();
         H.o_ichunk = mark(); I.insert(I.end(), ichunk.begin(), ichunk.end());
     }
+    {
+        // destinations of the constant part of the prior (Hp, packed lower triangle): same derivation as the kernel's former inline one
+        H.o_pdest = mark();
+        const int pn = (int)pcol.size();
+        for (int a2 = 0; a2 < pn; a2++)
+            for (int b2 = 0; b2 <= a2; b2++) {
+                const int ta = pcol[a2], tb = pcol[b2];
+                int d = -1;
+                if (ta >= 0 && tb >= 0) {
+                    if (use_chain && (ta >= npp || tb >= npp)) { if (ta == tb) d = -2 - (ta - npp); }
+                    else d = ta >= tb ? tix(ta, tb) : tix(tb, ta);
+                }
+                I.push_back(d);
+            }
+    }
     // ---- chain step tables
     while ((I.size() & 3) != 0) I.push_back(0);
     H.o_chain = mark();

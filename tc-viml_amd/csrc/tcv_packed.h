@@ -84,6 +84,8 @@ struct PlanHdr {
     int o_line;     // n_line
     int o_prior;    // prior_nblk x 4 : blk id, idx (first J0 column), gsize, x0 offset
     int o_pcol;     // prior_n : tangent index of each J0 column (-1 constant)
+    int o_pdest;    // prior_n (prior_n + 1) / 2: where entry e = a (a + 1) / 2 + b of the packed Hp = J0'J0 goes: >= 0 tile element, -1 nowhere,
+                    // <= -2: diagonal store -2 - d of a Euclidean block (chain layout, whose off-diagonal Euclidean entries are read from Hp directly)
     int o_lm;       // nland x 2 : e_off (offset of the landmark's slice in the Hcl store), nslot
     int o_lmslot;   // sum nslot : tangent offset of every slot's block (ordered by landmark)
     int o_lmslotptr;// nland + 1

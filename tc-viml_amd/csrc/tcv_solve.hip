@@ -781,32 +781,24 @@ __device__ __noinline__ double linearize(Ctx<NT> &Cr, const lds_d *x, bool first
     if (P.prior_n > 0 && assemble && ABL(C, AB_PRIOR_B)) {
         const int n = P.prior_n, npk = n * (n + 1) / 2;
         cst_i *pcol = ip + P.o_pcol;
+        cst_i *pdest = ip + P.o_pdest;      // destination of every packed entry, precomputed by the packer
         for (int e0 = tid; e0 < npk; e0 += 4 * NT) {
             double hv[4];
             int di[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const int e = e0 + k * NT;
-                di[k] = -1;
-                if (e < npk) {
-                    hv[k] = C.g_hp[e];
-                    int a2 = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);      // e = a (a + 1) / 2 + b, b <= a
-                    while ((a2 + 1) * (a2 + 2) / 2 <= e) a2++;
-                    while (a2 * (a2 + 1) / 2 > e) a2--;
-                    const int b2 = e - a2 * (a2 + 1) / 2;
-                    const int ta = pcol[a2], tb = pcol[b2];
-                    if (ta >= 0 && tb >= 0) {
-                        if (CHAIN && (ta >= P.npp || tb >= P.npp)) {      // chain mode reads these straight from g_hp; only the diagonal is needed here
-                            if (ta == tb) C.hd[ta - P.npp] += hv[k];
-                        } else di[k] = ta >= tb ? tix(ta, tb) : tix(tb, ta);
-                    }
-                }
+                const int e = min(e0 + k * NT, npk - 1);
+                hv[k] = C.g_hp[e];
+                di[k] = (e0 + k * NT < npk) ? pdest[e] : -1;
             }
             double tv[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) tv[k] = C.tiles[max(di[k], 0)];
+            for (int k = 0; k < 4; k++) tv[k] = (CHAIN && di[k] <= -2) ? C.hd[min(-2 - di[k], 111)] : C.tiles[max(di[k], 0)];
 #pragma unroll
-            for (int k = 0; k < 4; k++) if (di[k] >= 0) C.tiles[di[k]] = tv[k] + hv[k];
+            for (int k = 0; k < 4; k++) {
+                if (di[k] >= 0) C.tiles[di[k]] = tv[k] + hv[k];
+                else if (CHAIN && di[k] <= -2) C.hd[-2 - di[k]] = tv[k] + hv[k];
+            }
         }
     }
     TCV_MARK(C, PH_PRIOR);
