@@ -54,6 +54,8 @@ struct MargHdr {
     int o_pcol;    // prior_n: mloc index of every J0 column (-1 constant)
     int d_x, d_imu, d_proj, d_prior, d_misc;
     long long ibase, dbase;
+    long long prior_abs;   // >= 0: J0 | r0 | x0 of the prior are read from the solve batch's data pool at this offset (the marginalised factor
+                           // set holds the same prior object as the solve problem: no second copy is packed or uploaded)
     int solve_window;
     int block_mode;   // 1: the marginalised inverse depths (1 x 1 blocks) are eliminated by scalar pivots while the factors are
                       // accumulated, only the frame part of the dropped set (m) goes through the eigen pseudo-inverse
@@ -70,6 +72,7 @@ struct MargArgs {
     const double *dpool;
     const double *solve_state;   // may be null
     const double *solve_sqrt;    // may be null: per window 225 doubles, the solve's sqrt_info of IMU factor sqrt_src
+    const double *solve_dpool;   // the solve batch's data pool (MargHdr::prior_abs)
     double *out;                 // per window MARG_OUT_STRIDE
     int *out_status;             // per window: 0 ok
     double *scratch;             // per workgroup MARG_SCR_STRIDE
@@ -634,7 +637,7 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((amdgpu_waves_per_eu(2,
         bool a_zeroed = false;
         if (H.prior_n > 0) {
             const int np = H.prior_n;
-            cst_d *J0 = dp + H.d_prior, *r0 = J0 + np * np, *x0 = r0 + np;
+            cst_d *J0 = H.prior_abs >= 0 ? (cst_d *)Aarg.solve_dpool + H.prior_abs : dp + H.d_prior, *r0 = J0 + np * np, *x0 = r0 + np;
             lds_d *pdx = sm, *pr = sm + 128;
             if (tid < H.prior_nblk) {
                 cst_i *pb = ip + H.o_prior + tid * 4;
@@ -1341,7 +1344,10 @@ static int pack_marg(const tcv_problem &p, double *const *drop, int ndrop, const
         if (f.btd >= 0) D.insert(D.end(), f.aux, f.aux + 8);
     }
     H.d_prior = dmark();
-    if (pr) { D.insert(D.end(), pr->J0.begin(), pr->J0.end()); D.insert(D.end(), pr->r0.begin(), pr->r0.end()); D.insert(D.end(), pr->x0.begin(), pr->x0.end()); }
+    H.prior_abs = -1;
+    if (pr && solve_p && solve_pk && !solve_p->prior.empty() && solve_p->prior[0].prior == pr && solve_pk->hdr.prior_n == pr->n && !getenv("TCV_MARG_OWN_PRIOR"))
+        H.prior_abs = solve_pk->win.dbase + solve_pk->win.d_prior;      // same layout: J0 | r0 | x0 (tcv_pack.cpp)
+    else if (pr) { D.insert(D.end(), pr->J0.begin(), pr->J0.end()); D.insert(D.end(), pr->r0.begin(), pr->r0.end()); D.insert(D.end(), pr->x0.begin(), pr->x0.end()); }
     H.d_misc = dmark();
     D.insert(D.end(), p.G, p.G + 3); D.push_back(psi); D.push_back(pla); D.push_back(0.0); D.push_back(p.td_TR); D.push_back(p.td_ROW);
     if (D.size() & 1) D.push_back(0.0);
@@ -1455,6 +1461,7 @@ int tcv_marg_run(tcv_batch *b, void *stream) {
     a.hdr = s->d_hdr; a.ipool = s->d_ipool; a.dpool = s->d_dpool; a.solve_state = b->d_state; a.out = s->d_out;
     a.out_status = s->d_status; a.scratch = s->d_scratch; a.nwin = b->n; a.state_stride = b->state_stride;
     a.use_solved_state = b->solved ? 1 : 0;
+    a.solve_dpool = b->d_dpool;
     a.solve_sqrt = (b->solved && b->sqrt_out_valid && !getenv("TCV_MARG_OWN_SQRT")) ? b->d_sqrt_out : nullptr;
     a.eig_mm = getenv("TCV_MARG_EIG_MM") ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
