@@ -193,6 +193,29 @@ def test_both_launch_shapes_of_the_marginalisation_kernel(gpu, monkeypatch, nt):
         assert fro(d["J0"].T @ d["J0"], d2["J0"].T @ d2["J0"]) < 1e-9
 
 
+def test_shortcuts_of_the_marginalisation_are_bit_identical_to_the_plain_paths(gpu, monkeypatch):
+    """Three shortcuts of the batch marginalisation reuse what the batch already has: the IMU factor's sqrt_info from the solve kernel
+    (TCV_MARG_OWN_SQRT=1: factorise the covariance again), the prior's J0 | r0 | x0 from the solve batch's data pool (TCV_MARG_OWN_PRIOR=1:
+    an own copy), and the per-entry accumulation of the point factors (TCV_MARG_PROJ_SERIAL=1: factor by factor with a barrier each).
+    Each must leave every bit of the result alone."""
+    pre, main, z = golden_windows()
+    more = synth.make_windows(920, 2, frame_shift=-1)
+    wins = [pre, main, synth.window_at(more, 0), synth.window_at(more, 1)]
+
+    def run():
+        W, b = marg_batch(gpu, wins)
+        return [(b.prior(k).export(), b.prior(k).schur()) for k in range(len(wins))]
+
+    ref = run()
+    for var in ("TCV_MARG_OWN_SQRT", "TCV_MARG_OWN_PRIOR", "TCV_MARG_PROJ_SERIAL"):
+        monkeypatch.setenv(var, "1")
+        got = run()
+        monkeypatch.delenv(var)
+        for (d0, (A0, b0)), (d1, (A1, b1)) in zip(ref, got):
+            assert np.array_equal(A0, A1) and np.array_equal(b0, b1), var
+            assert np.array_equal(d0["J0"], d1["J0"]) and np.array_equal(d0["r0"], d1["r0"]), var
+
+
 def _standalone(gpu, w2):
     mw = gpu.margin_old_window(w2)
     Wm = gpu.Window(mw)
