@@ -416,7 +416,12 @@ __device__ __noinline__ double linearize(Ctx<NT> &Cr, const lds_d *x, bool first
             cost_acc += loss_correct2(r, J, 19, PROJ_STRIDE, proj_loss);
             if (assemble) { rec[19] = r[0]; rec[PROJ_STRIDE + 19] = r[1]; }
         }
-        for (int f = tid; f < ln; f += NT) {
+        // the line factors of the chunk run on the third wavefront while the first two evaluate the point factors; their costs go through
+        // the (idle) reduction scratch back to the threads that used to evaluate them, so that the block sum adds the same numbers in the
+        // same order
+        const bool lines_aside = NT >= 192 && ln <= 40 && pn <= 128;
+        const int lt0 = lines_aside ? 128 : 0;
+        for (int f = tid - lt0; f >= 0 && f < ln; f += NT) {
             const int b = ip[P.o_line + lb + f];
             const lds_d *xp = x + blk[b * 4 + 1];
             lds_d *rec = C.stage + pn * prec + f * LINE_REC;
@@ -428,12 +433,21 @@ __device__ __noinline__ double linearize(Ctx<NT> &Cr, const lds_d *x, bool first
 #pragma unroll
             for (int i = 0; i < 21; i++) lc[i] = dp[C.W->d_linec + i];
             line_eval(CGEN(xp), ld9, lc, lc + 9, lc + 18, r, J, LINE_STRIDE, line_exact);
-            cost_acc += loss_correct2(r, J, 6, LINE_STRIDE, line_loss);
+            const double lcost = loss_correct2(r, J, 6, LINE_STRIDE, line_loss);
+            if (lines_aside) C.red[f] = lcost; else cost_acc += lcost;
             if (assemble) { rec[6] = r[0]; rec[LINE_STRIDE + 6] = r[1]; }
         }
         }
-        if (!assemble) { TCV_MARK(C, PH_VIS_EVAL); continue; }
+        if (!assemble) {
+            if (ABL(C, AB_VIS_EVAL) && NT >= 192 && ln <= 40 && pn <= 128 && ln > 0) {
+                __syncthreads();
+                if (tid < ln) cost_acc += C.red[tid];
+                __syncthreads();
+            }
+            TCV_MARK(C, PH_VIS_EVAL); continue;
+        }
         __syncthreads();
+        if (ABL(C, AB_VIS_EVAL) && NT >= 192 && ln <= 40 && pn <= 128 && tid < ln) cost_acc += C.red[tid];
         TCV_MARK(C, PH_VIS_EVAL);
         // gather J'J / J'r / landmark couplings: wave units (long item lists) first, then one unit per thread
         if (ABL(C, AB_VIS_GATHER)) {
