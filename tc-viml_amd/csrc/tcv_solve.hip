@@ -455,9 +455,12 @@ __device__ __noinline__ double linearize(Ctx<NT> &Cr, const lds_d *x, bool first
             const int lane = tid & 63, wave = tid >> 6;
             const int nloop = vnw + ((vnu - vnw + NT - 1) / NT) * 1;   // (only for clarity; loops below are separate)
             (void)nloop;
+            // wave units (long lists) go to the wavefronts other than the first, which holds the 64 longest thread units of the sorted
+            // list and is the critical one: every unit has its own destination, so who accumulates it does not change a bit
+            constexpr int NWU = NT / 64 > 1 ? NT / 64 - 1 : 1;
             for (int uu = 0; uu < 2; uu++) {
                 const bool wv = (uu == 0);
-                for (int u = wv ? wave : vnw + tid; u < (wv ? vnw : vnu); u += (wv ? NT / 64 : NT)) {
+                for (int u = wv ? (NT / 64 > 1 ? (wave == 0 ? vnw : NT / 64 - 1 - wave) : 0) : vnw + tid; u < (wv ? vnw : vnu); u += (wv ? NWU : NT)) {
                     const unsigned u0 = (unsigned)lprog[3 * u], u1 = (unsigned)lprog[3 * u + 1];
                     const int ib = lprog[3 * u + 2];
                     const int kind = u0 >> 28, ncols = (u0 >> 24) & 15, ea = (u0 >> 20) & 15, n = u0 & 0xfffff;
