@@ -67,7 +67,7 @@ struct RowProg {
     std::vector<int> units, items;
     int n_units = 0, n_wave_units = 0;
 };
-static bool emit_rows(const DestList &dl, RowProg &out, bool inline_items) {
+static bool emit_rows(const DestList &dl, RowProg &out, bool inline_items, int wave_items = WAVE_UNIT_ITEMS, int wave_max = WAVE_UNIT_MAX) {
     struct U { int u0, u1, u2, u3, n; };
     std::vector<U> us;
     for (size_t id = 0; id < dl.keys.size(); id++) {
@@ -98,7 +98,7 @@ static bool emit_rows(const DestList &dl, RowProg &out, bool inline_items) {
     for (auto &u : us) {
         out.units.push_back(u.u0); out.units.push_back(u.u1); out.units.push_back(u.u2);
         if (inline_items) out.units.push_back(u.u3);
-        if (!inline_items && u.n > WAVE_UNIT_ITEMS && out.n_wave_units < WAVE_UNIT_MAX) out.n_wave_units++;
+        if (!inline_items && u.n > wave_items && out.n_wave_units < wave_max) out.n_wave_units++;
     }
     out.n_units = (int)us.size();
     return true;
@@ -424,7 +424,9 @@ static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds)
             }
         }
         RowProg vp, sp;
-        if (!emit_rows(dl, vp, false) || !emit_rows(sl, sp, false)) { set_error("gather program field overflow"); return TCV_ERR_TOO_LARGE; }
+        static const int wu_v = getenv("TCV_WU_V") ? atoi(getenv("TCV_WU_V")) : (int)WAVE_UNIT_ITEMS, wu_s = getenv("TCV_WU_S") ? atoi(getenv("TCV_WU_S")) : (int)WAVE_UNIT_ITEMS,
+                         wu_max = getenv("TCV_WU_MAX") ? atoi(getenv("TCV_WU_MAX")) : (int)WAVE_UNIT_MAX;      // tuning experiments
+        if (!emit_rows(dl, vp, false, wu_v, wu_max) || !emit_rows(sl, sp, false, wu_s, wu_max)) { set_error("gather program field overflow"); return TCV_ERR_TOO_LARGE; }
         if (getenv("TCV_DEBUG_UNITS")) {
             auto dump = [](const char *nm, const RowProg &rp) {
                 fprintf(stderr, "[pack] %s: %d units (%d wave units), items per unit (descending):", nm, rp.n_units, rp.n_wave_units);

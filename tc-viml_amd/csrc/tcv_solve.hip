@@ -511,9 +511,10 @@ __device__ __noinline__ double linearize(Ctx<NT> &Cr, const lds_d *x, bool first
             const lds_i *sprog = (const lds_i *)C.stage;
             const lds_i *items = sprog + 3 * snu;
             const int lane = tid & 63, wave = tid >> 6;
+            constexpr int NWU = NT / 64 > 1 ? NT / 64 - 1 : 1;      // wave units off the first wavefront, as in the visual gather
             for (int uu = 0; uu < 2; uu++) {
                 const bool wv = (uu == 0);
-                for (int u = wv ? wave : snw + tid; u < (wv ? snw : snu); u += (wv ? NT / 64 : NT)) {
+                for (int u = wv ? (NT / 64 > 1 ? (wave == 0 ? snw : NT / 64 - 1 - wave) : 0) : snw + tid; u < (wv ? snw : snu); u += (wv ? NWU : NT)) {
                     const unsigned u0 = (unsigned)sprog[3 * u], u1 = (unsigned)sprog[3 * u + 1];
                     const int ib = sprog[3 * u + 2];
                     const int kind = u0 >> 28, ncols = (u0 >> 24) & 15, ea = (u0 >> 20) & 15, n = u0 & 0xfffff;
