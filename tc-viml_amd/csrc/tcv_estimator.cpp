@@ -4,6 +4,8 @@
 // and feature_manager.cpp (addFeaturesCheckParallax :260-334, setDepth :379-397, removeFailures :399-408, triangulate :440-492,
 // removeLineOutlier :494-534, removeBackShiftDepth :559-616, removeFront :655-696, compensatedParallax2 :698-734).
 // Host code only: every numerical step of the hot path goes through the C-ABI of tcv.h (HIP kernels); there is no CPU solver here.
+#include <hip/hip_runtime.h>
+
 #include <algorithm>
 #include <array>
 #include <chrono>
@@ -646,57 +648,98 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
         for (auto &b : es[i]->prior_blocks) if (b.first == 0 && b.second == W - 1) has = true;
         do_marg[i] = es[i]->marg_flag == MARGIN_OLD || (es[i]->prior && has);
     }
-    int rc_all = TCV_OK;
-    for (int group = 1; group >= 0 && rc_all == TCV_OK; group--) {
+    // The two batches of a frame are independent: both are created first, then their kernels are launched on two HIP streams and run
+    // side by side (a lock-step frame is latency bound: a handful of windows on a handful of CUs), then both are collected.
+    struct Group {
         std::vector<int> idx;
-        for (int i = 0; i < n; i++) if ((int)do_marg[i] == group) idx.push_back(i);
-        if (idx.empty()) continue;
-        const int nb = (int)idx.size();
-        std::vector<tcv_problem *> P(nb, nullptr), M(nb, nullptr);
-        std::vector<double *const *> drops(nb, nullptr);
-        std::vector<int> ndrop(nb, 0);
+        std::vector<tcv_problem *> P, M;
+        std::vector<double *const *> drops;
+        std::vector<int> ndrop;
+        std::vector<tcv_solver_summary> sum;
+        std::vector<tcv_prior *> newp;
         tcv_batch *b = nullptr;
         int rc = TCV_OK;
-        for (int k = 0; k < nb && rc == TCV_OK; k++) {
-            tcv_estimator *e = es[idx[k]];
+    };
+    Group G[2];
+    static hipStream_t g_streams[2] = {nullptr, nullptr};
+    static int g_stream_dev = -1;
+    {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (g_stream_dev != dev) {      // streams belong to a device: made anew if the caller switched devices
+            for (auto &st : g_streams) st = nullptr;
+            if (hipStreamCreateWithFlags(&g_streams[0], hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&g_streams[1], hipStreamNonBlocking) != hipSuccess) {
+                g_streams[0] = g_streams[1] = nullptr;      // fall back to the default stream: sequential, still correct
+            }
+            g_stream_dev = dev;
+        }
+    }
+    int rc_all = TCV_OK;
+    for (int group = 1; group >= 0; group--) {
+        Group &g = G[group];
+        for (int i = 0; i < n; i++) if ((int)do_marg[i] == group) g.idx.push_back(i);
+        if (g.idx.empty()) continue;
+        const int nb = (int)g.idx.size();
+        g.P.assign(nb, nullptr); g.M.assign(nb, nullptr); g.drops.assign(nb, nullptr); g.ndrop.assign(nb, 0);
+        for (int k = 0; k < nb && g.rc == TCV_OK; k++) {
+            tcv_estimator *e = es[g.idx[k]];
             tcv_window_desc d;
             fill_desc(e, d, false, e->marg_flag);
-            rc = tcv_problem_from_window(&d, &P[k]);
-            if (rc == TCV_OK && group) {
+            g.rc = tcv_problem_from_window(&d, &g.P[k]);
+            if (g.rc == TCV_OK && group) {
                 build_marg(e, e->marg_flag);
                 fill_desc(e, d, true, e->marg_flag);
-                rc = tcv_problem_from_window(&d, &M[k]);
-                drops[k] = e->m_drop.data(); ndrop[k] = (int)e->m_drop.size();
+                g.rc = tcv_problem_from_window(&d, &g.M[k]);
+                g.drops[k] = e->m_drop.data(); g.ndrop[k] = (int)e->m_drop.size();
             }
         }
         lap(2);
-        if (rc == TCV_OK) rc = tcv_batch_create(&b, P.data(), group ? M.data() : nullptr, group ? drops.data() : nullptr, group ? ndrop.data() : nullptr, nb);
+        if (g.rc == TCV_OK) g.rc = tcv_batch_create(&g.b, g.P.data(), group ? g.M.data() : nullptr, group ? g.drops.data() : nullptr, group ? g.ndrop.data() : nullptr, nb);
         lap(3);
+    }
+    for (int group = 1; group >= 0; group--) {
+        Group &g = G[group];
+        if (g.idx.empty() || g.rc != TCV_OK) continue;
         tcv_solver_options o;
         tcv_solver_options_default(&o);
         o.max_num_iterations = es[0]->cfg.num_iterations; o.fixed_iterations = es[0]->cfg.fixed_iterations;
-        if (rc == TCV_OK) rc = tcv_batch_solve(b, &o, nullptr);
-        if (rc == TCV_OK) rc = tcv_batch_gauge_fix(b, nullptr);
-        if (rc == TCV_OK && group) rc = tcv_batch_marginalize(b, nullptr);
-        if (rc == TCV_OK) rc = tcv_batch_synchronize(b);
-        lap(4);
-        if (rc == TCV_OK) rc = tcv_batch_download_states(b);
-        std::vector<tcv_solver_summary> sum(nb);
-        if (rc == TCV_OK) rc = tcv_batch_get_summaries(b, sum.data(), nb);
-        std::vector<tcv_prior *> newp(nb, nullptr);
-        if (rc == TCV_OK && group) rc = tcv_batch_download_priors_compact(b);
-        if (rc == TCV_OK && group)
-            for (int k = 0; k < nb && rc == TCV_OK; k++) rc = tcv_batch_get_prior(b, k, &newp[k]);
-        if (b) tcv_batch_destroy(b);
-        lap(5);
-        for (int k = 0; k < nb; k++) { if (P[k]) tcv_problem_destroy(P[k]); if (M[k]) tcv_problem_destroy(M[k]); }
-        if (rc != TCV_OK) { for (auto *p : newp) if (p) tcv_prior_destroy(p); rc_all = rc; break; }
+        void *st = (void *)g_streams[group];
+        g.rc = tcv_batch_solve(g.b, &o, st);
+        if (g.rc == TCV_OK) g.rc = tcv_batch_gauge_fix(g.b, st);
+        if (g.rc == TCV_OK && group) g.rc = tcv_batch_marginalize(g.b, st);
+    }
+    for (int group = 1; group >= 0; group--) {
+        Group &g = G[group];
+        if (g.idx.empty()) continue;
+        if (g.rc == TCV_OK) g.rc = tcv_batch_synchronize(g.b);
+    }
+    lap(4);
+    for (int group = 1; group >= 0; group--) {
+        Group &g = G[group];
+        if (g.idx.empty()) continue;
+        const int nb = (int)g.idx.size();
+        g.sum.resize(nb); g.newp.assign(nb, nullptr);
+        if (g.rc == TCV_OK) g.rc = tcv_batch_download_states(g.b);
+        if (g.rc == TCV_OK) g.rc = tcv_batch_get_summaries(g.b, g.sum.data(), nb);
+        if (g.rc == TCV_OK && group) g.rc = tcv_batch_download_priors_compact(g.b);
+        if (g.rc == TCV_OK && group)
+            for (int k = 0; k < nb && g.rc == TCV_OK; k++) g.rc = tcv_batch_get_prior(g.b, k, &g.newp[k]);
+        if (g.b) tcv_batch_destroy(g.b);
+        for (int k = 0; k < nb; k++) { if (g.P[k]) tcv_problem_destroy(g.P[k]); if (g.M[k]) tcv_problem_destroy(g.M[k]); }
+        if (g.rc != TCV_OK && rc_all == TCV_OK) rc_all = g.rc;
+    }
+    lap(5);
+    for (int group = 1; group >= 0; group--) {
+        Group &g = G[group];
+        if (g.idx.empty()) continue;
+        const int nb = (int)g.idx.size();
+        if (rc_all != TCV_OK) { for (auto *p : g.newp) if (p) tcv_prior_destroy(p); continue; }
         for (int k = 0; k < nb; k++) {
-            tcv_estimator *e = es[idx[k]];
+            tcv_estimator *e = es[g.idx[k]];
             apply_states(e);
             e->stats.marg_flag = e->marg_flag; e->stats.n_landmarks = (int)e->sel.size(); e->stats.n_proj = (int)e->w_pi.size(); e->stats.n_line = (int)e->w_lf.size();
-            e->stats.n_line_obs = e->n_line_obs_total; e->stats.iterations = sum[k].num_iterations; e->stats.final_cost = sum[k].final_cost;
-            if (group) { rc = take_prior(e, newp[k], e->marg_flag); if (rc != TCV_OK) { rc_all = rc; break; } }
+            e->stats.n_line_obs = e->n_line_obs_total; e->stats.iterations = g.sum[k].num_iterations; e->stats.final_cost = g.sum[k].final_cost;
+            if (group) { const int rc = take_prior(e, g.newp[k], e->marg_flag); g.newp[k] = nullptr; if (rc != TCV_OK) { rc_all = rc; break; } }
             else e->stats.prior_n = e->prior ? e->stats.prior_n : 0;
             e->phase = 2;
         }
