@@ -265,7 +265,8 @@ int tcv_gauge_fix(int n_frames, const double origin_R0[9], const double origin_P
  *   det_frame / det_lines n_det x 4: frame index and pixel end points xs ys xe ye of each detected line;
  *   angle_th [rad], overlap_th (sensor.yaml:119-122).
  * fov_given != 0: in_fov is an INPUT (the reference freezes WorldLinesInFOV[i] when frame i enters the window, :328, and re-matches
- * against it with the current poses, updateLinePairInWindow :449-481).
+ * against it with the current poses, updateLinePairInWindow :449-481).  fov_given = 2 + f: the same, except that row f is computed
+ * first (UpdateLinesInFoV(f) for the frame that has just entered) and written back to in_fov: one call per image instead of two.
  * Outputs (any may be NULL): in_fov n_frames x n_map (WorldLinesInFOV membership), match_index n_det (row of lines3d, -1: no
  * credible line), err n_det x 3 = errA, errD, overlap as the reference's Eigen::Vector3f (-1 -1 -1: none), projected n_det x 4
  * (pixel end points of the chosen projected line; the detected line itself when there is no match). */

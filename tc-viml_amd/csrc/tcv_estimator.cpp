@@ -281,23 +281,28 @@ int associate_lines(tcv_estimator *e) {
     std::vector<LineObs *> where;
     for (auto &lf : e->linefeatures)
         for (size_t k = 0; k < lf.obs.size(); k++) { det_frame.push_back(lf.start + (int)k); det.insert(det.end(), lf.obs[k].vec, lf.obs[k].vec + 4); where.push_back(&lf.obs[k]); }
-    std::vector<unsigned char> fov_now((size_t)(W + 1) * nm, 0);
-    int rc = tcv_match_lines(W + 1, pose, ex, e->Rbw.data(), e->Tbw.data(), e->cfg.K, e->cfg.width, e->cfg.height, W, nm, e->map_lines.data(), 0, nullptr, nullptr,
-                             e->cfg.angle_th, e->cfg.overlap_th, 0, fov_now.data(), nullptr, nullptr, nullptr);
-    if (rc != TCV_OK) return rc;
+    int rc = TCV_OK;
+    const bool one_call = e->fov_ready;      // steady state: UpdateLinesInFoV(frame_count) and the matching in ONE device call
     if (!e->fov_ready) {
+        std::vector<unsigned char> fov_now((size_t)(W + 1) * nm, 0);
+        rc = tcv_match_lines(W + 1, pose, ex, e->Rbw.data(), e->Tbw.data(), e->cfg.K, e->cfg.width, e->cfg.height, W, nm, e->map_lines.data(), 0, nullptr, nullptr,
+                             e->cfg.angle_th, e->cfg.overlap_th, 0, fov_now.data(), nullptr, nullptr, nullptr);
+        if (rc != TCV_OK) return rc;
         for (int i = 0; i <= W; i++) e->fov[i].assign(fov_now.begin() + (size_t)i * nm, fov_now.begin() + (size_t)(i + 1) * nm);      // initialLineFoVWindow (:483-497)
         e->fov_ready = true;
-    } else e->fov[W].assign(fov_now.begin() + (size_t)W * nm, fov_now.begin() + (size_t)(W + 1) * nm);                               // UpdateLinesInFoV(frame_count)
+    }
     std::vector<unsigned char> given((size_t)(W + 1) * nm, 0);
     for (int i = 0; i <= W; i++) if (!e->fov[i].empty()) std::copy(e->fov[i].begin(), e->fov[i].end(), given.begin() + (size_t)i * nm);
     const int nd = (int)where.size();
-    if (nd > 0) {
-        std::vector<int> match(nd);
-        std::vector<float> err((size_t)nd * 3);
-        rc = tcv_match_lines(W + 1, pose, ex, e->Rbw.data(), e->Tbw.data(), e->cfg.K, e->cfg.width, e->cfg.height, W, nm, e->map_lines.data(), nd, det_frame.data(),
-                             det.data(), e->cfg.angle_th, e->cfg.overlap_th, 1, given.data(), match.data(), err.data(), nullptr);
+    std::vector<int> match(std::max(nd, 1));
+    std::vector<float> err((size_t)std::max(nd, 1) * 3);
+    if (nd > 0 || one_call) {
+        rc = tcv_match_lines(W + 1, pose, ex, e->Rbw.data(), e->Tbw.data(), e->cfg.K, e->cfg.width, e->cfg.height, W, nm, e->map_lines.data(), nd, nd ? det_frame.data() : nullptr,
+                             nd ? det.data() : nullptr, e->cfg.angle_th, e->cfg.overlap_th, one_call ? 2 + W : 1, given.data(), nd ? match.data() : nullptr, nd ? err.data() : nullptr, nullptr);
         if (rc != TCV_OK) return rc;
+        if (one_call) e->fov[W].assign(given.begin() + (size_t)W * nm, given.begin() + (size_t)(W + 1) * nm);                          // UpdateLinesInFoV(frame_count)
+    }
+    if (nd > 0) {
         for (int q = 0; q < nd; q++) {
             LineObs &ob = *where[q];
             ob.errA = (double)err[3 * q]; ob.errD = (double)err[3 * q + 1]; ob.overlap = (double)err[3 * q + 2];

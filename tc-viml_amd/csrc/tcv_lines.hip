@@ -79,6 +79,7 @@ struct LineArgs {
     const double *poses, *ex, *Rbw, *Tbw, *K, *map, *det;
     const int *det_frame;
     int n_frames, n_map, n_det, width, height, window_size;
+    int only_frame;             // >= 0: the FoV kernel computes this frame's row only (the other rows are given)
     double angle_th, overlap_th;
     unsigned char *in_fov;      // n_frames x n_map
     int *match;                 // n_det
@@ -88,8 +89,9 @@ struct LineArgs {
 
 // UpdateLinesInFoV: one thread per (frame, map line)
 __global__ void lines_fov_kernel(LineArgs A) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= A.n_frames * A.n_map) return;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (A.only_frame >= 0 ? A.n_map : A.n_frames * A.n_map)) return;
+    if (A.only_frame >= 0) i += A.only_frame * A.n_map;
     const int f = i / A.n_map, j = i - f * A.n_map;
     const LineCam c = line_cam(A.poses + 7 * f, A.ex, A.Rbw, A.Tbw);
     const double *l = A.map + 6 * (size_t)j;
@@ -202,6 +204,8 @@ extern "C" int tcv_match_lines(int n_frames, const double *poses, const double *
         set_error("match_lines: bad argument"); return TCV_ERR_INVALID;
     }
     if (fov_given && !in_fov) { set_error("match_lines: fov_given needs in_fov"); return TCV_ERR_INVALID; }
+    const int fov_frame = fov_given >= 2 ? fov_given - 2 : -1;      // this frame's row is computed here, the others are given
+    if (fov_frame >= n_frames) { set_error("match_lines: fov_given names a frame outside the window"); return TCV_ERR_INVALID; }
     for (int i = 0; i < n_det; i++) if (det_frame[i] < 0 || det_frame[i] >= n_frames) { set_error("match_lines: frame index out of range"); return TCV_ERR_INVALID; }
     if (int rc = device_ready()) return rc;
     const size_t nd_in = (size_t)7 * n_frames + 7 + 9 + 3 + 9 + (size_t)6 * n_map + (size_t)4 * n_det;
@@ -226,11 +230,14 @@ extern "C" int tcv_match_lines(int n_frames, const double *poses, const double *
         A.det_frame = di; A.n_frames = n_frames; A.n_map = n_map; A.n_det = n_det; A.width = width; A.height = height; A.window_size = window_size;
         A.angle_th = angle_th; A.overlap_th = overlap_th; A.in_fov = db; A.match = di + n_det; A.err = df; A.proj = dd + nd_in;
         const int tot = n_frames * n_map;
+        A.only_frame = fov_frame;
         if (!fov_given) hipLaunchKernelGGL(lines_fov_kernel, dim3((tot + 255) / 256), dim3(256), 0, 0, A);
+        else if (fov_frame >= 0) hipLaunchKernelGGL(lines_fov_kernel, dim3((n_map + 255) / 256), dim3(256), 0, 0, A);
         if (n_det) hipLaunchKernelGGL(lines_match_kernel, dim3(n_det), dim3(64), 0, 0, A);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipDeviceSynchronize();
         if (e == hipSuccess && in_fov && !fov_given) e = hipMemcpy(in_fov, db, (size_t)tot, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && fov_frame >= 0) e = hipMemcpy(in_fov + (size_t)fov_frame * n_map, db + (size_t)fov_frame * n_map, (size_t)n_map, hipMemcpyDeviceToHost);
         if (e == hipSuccess && n_det && match_index) e = hipMemcpy(match_index, di + n_det, sizeof(int) * n_det, hipMemcpyDeviceToHost);
         if (e == hipSuccess && n_det && err) e = hipMemcpy(err, df, sizeof(float) * 3 * n_det, hipMemcpyDeviceToHost);
         if (e == hipSuccess && n_det && projected) e = hipMemcpy(projected, dd + nd_in, sizeof(double) * 4 * n_det, hipMemcpyDeviceToHost);

@@ -556,8 +556,9 @@ def gauge_fix(R0, P0, pose, sb):
     return Rs, Ps, Vs, po
 
 
-def match_lines(poses, ex_pose, Rbw, Tbw, K, width, height, window_size, lines3d, det_frame, det_lines, angle_th, overlap_th, in_fov=None):
+def match_lines(poses, ex_pose, Rbw, Tbw, K, width, height, window_size, lines3d, det_frame, det_lines, angle_th, overlap_th, in_fov=None, fov_frame=None):
     """UpdateLinesInFoV + LineCorrespondenceInFrame (estimator.cpp:385-447, :671-885) on the GPU.
+    in_fov given: the matching runs against these frozen FoV sets; with fov_frame = f the row of frame f is computed first and returned.
     Returns (in_fov bool (n_frames, n_map), match_index (n_det,), err float32 (n_det, 3), projected (n_det, 4))."""
     poses = f64(poses).reshape(-1, 7); lines3d = f64(lines3d).reshape(-1, 6)
     det_frame = i32(det_frame); det_lines = f64(det_lines).reshape(-1, 4)
@@ -567,5 +568,5 @@ def match_lines(poses, ex_pose, Rbw, Tbw, K, width, height, window_size, lines3d
     ex = f64(ex_pose); R = f64(Rbw).reshape(9); T = f64(Tbw); Kf = f64(K).reshape(9)
     check(lib().tcv_match_lines(nf, dptr(poses), dptr(ex), dptr(R), dptr(T), dptr(Kf), int(width), int(height), int(window_size), nm, dptr(lines3d),
                                 nd, iptr(det_frame) if nd else None, dptr(det_lines) if nd else None, float(angle_th), float(overlap_th),
-                                int(in_fov is not None), fov.ctypes.data_as(C.POINTER(C.c_ubyte)), iptr(match), err.ctypes.data_as(C.POINTER(C.c_float)), dptr(proj)))
+                                (2 + int(fov_frame)) if (in_fov is not None and fov_frame is not None) else int(in_fov is not None), fov.ctypes.data_as(C.POINTER(C.c_ubyte)), iptr(match), err.ctypes.data_as(C.POINTER(C.c_float)), dptr(proj)))
     return fov.astype(bool), match[:nd].copy(), err[:nd].copy(), proj[:nd].copy()

@@ -36,3 +36,24 @@ def test_match_lines_edge_cases(gpu):
     assert match[0] == 0 and abs(err[0, 1] - z["err"][0, 1]) < 1e-5
     with pytest.raises(gpu.TcvError):
         gpu.match_lines(z["poses"], *args, z["lines3d"], [99], z["det"][:1], 0.1745, 0.45)
+
+
+def test_fov_of_the_new_frame_and_matching_in_one_call(gpu):
+    """fov_given = 2 + f (tcv.h): the FoV sets of the frames already in the window are frozen inputs, the row of frame f is computed in
+    the same call and returned -- what the estimator does once per image instead of an FoV call followed by a matching call."""
+    z = load("lines.npz")
+    args = (z["ex"], z["Rbw"], z["Tbw"], z["K"], int(z["width"]), int(z["height"]), int(z["window_size"]))
+    nf = z["poses"].shape[0]
+    f = nf - 1
+    frozen = np.array(z["in_fov"], dtype=np.uint8)
+    rng = np.random.default_rng(5)
+    frozen[:f] ^= (rng.random(frozen[:f].shape) < 0.02).astype(np.uint8)      # frozen sets need not equal what the current poses would give
+    two = frozen.copy()
+    fov_now, _, _, _ = gpu.match_lines(z["poses"], *args, z["lines3d"], np.zeros(0, np.int32), np.zeros((0, 4)), float(z["angle_th"]), float(z["overlap_th"]))
+    two[f] = fov_now[f]
+    _, m2, e2, p2 = gpu.match_lines(z["poses"], *args, z["lines3d"], z["det_frame"], z["det"], float(z["angle_th"]), float(z["overlap_th"]), in_fov=two)
+    one = frozen.copy(); one[f] = 255 - one[f] * 0      # garbage in the row that is to be computed
+    fov1, m1, e1, p1 = gpu.match_lines(z["poses"], *args, z["lines3d"], z["det_frame"], z["det"], float(z["angle_th"]), float(z["overlap_th"]), in_fov=one, fov_frame=f)
+    assert np.array_equal(fov1, two.astype(bool)) and np.array_equal(m1, m2) and np.array_equal(e1, e2) and np.array_equal(p1, p2)
+    with pytest.raises(gpu.TcvError):
+        gpu.match_lines(z["poses"], *args, z["lines3d"], z["det_frame"], z["det"], 0.1745, 0.45, in_fov=one, fov_frame=nf)
