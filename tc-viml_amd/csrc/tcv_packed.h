@@ -96,7 +96,7 @@ struct PlanHdr {
     int o_sdest, o_sunit, o_sitem;   // Schur plan
     int n_sdest, n_sunit, n_sitem;
     int o_ichunk;   // n_imu_chunk x 4 : fac_begin, fac_count, number of colours, 0
-    int o_idest, o_iunit, o_iitem;   // o_idest: n_imu x 32 tangent index of each local column (-1 constant); o_iunit: n_imu colours; o_iitem: scatter table
+    int o_idest, o_iunit, o_iitem;   // o_idest: n_imu x 32 tangent index of each local column (-1 constant; host-side source of the scatter table); o_iunit: n_imu colours; o_iitem: scatter table
     int n_idest, n_iunit, n_iitem;
     // chain mode (tcv_solve.hip, CHAIN = true): the Euclidean camera blocks (speed-biases) are eliminated one by one in a
     // fixed order BEFORE the dense pose system; only the pose part (npp + 1 rhs row) lives in LDS tiles

@@ -728,7 +728,6 @@ __device__ __noinline__ double linearize(Ctx<NT> &Cr, const lds_d *x, bool first
             cost_acc += 0.5 * s;
         }
         if (assemble && ABL(C, AB_IMU_GATHER)) {
-            cst_i *imap = ip + P.o_idest;
             const int i16 = lane & 15, k4 = lane >> 4;
             for (int color = 0; color < ncolor; color++) {
                 // factors of this colour: whole factors go round-robin to the wavefronts; the ones left over when their number is not a
