@@ -229,13 +229,16 @@ def _cpu_model():
 # ---- PCIe-inclusive figures ---------------------------------------------------------------------------------------------
 def stream_figures(tcv, torch, keep, B_stream: int = 512, rounds: int = 4):
     """host-resident problems -> tcv_batch_create (pack + H2D) -> solve -> gauge fix -> marginalisation -> D2H of states and
-    priors -> destroy, double-buffered: two host threads, each with its own HIP stream, so that one batch packs / copies while
-    the other computes.  Also the end-to-end and kernel-only latency of ONE window (the real-time single-estimator case)."""
+    priors -> destroy, overlapped: two to four host threads, each with its own windows and HIP stream, so that one batch packs / copies
+    while another computes.  Also the end-to-end and kernel-only latency of ONE window (the real-time single-estimator case)."""
     import threading
     Wm, Mm, dropsm = keep
-    B = min(B_stream, len(Wm) // 2)
+    # host threads, each with its own windows and HIP stream: as many 512-window sets as the batch holds, between 2 and 4
+    # (`--mode stream --windows 2048`: four)
+    NTH = int(os.environ.get("TCV_STREAM_THREADS", str(max(2, min(4, len(Wm) // B_stream)))))
+    B = min(B_stream, len(Wm) // NTH)
     opts = tcv.default_options(SOLVER_ITERATIONS, True)
-    halves = [(Wm[:B], Mm[:B], dropsm[:B]), (Wm[B:2 * B], Mm[B:2 * B], dropsm[B:2 * B])]
+    halves = [(Wm[i * B:(i + 1) * B], Mm[i * B:(i + 1) * B], dropsm[i * B:(i + 1) * B]) for i in range(NTH)]
     stage = {"pack_h2d": 0.0, "compute": 0.0, "d2h": 0.0}
 
     def one_pass(h, stream_ptr, acc=None):
@@ -256,12 +259,12 @@ def stream_figures(tcv, torch, keep, B_stream: int = 512, rounds: int = 4):
         for _ in range(rounds):
             one_pass(h, st.cuda_stream)
 
-    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    streams = [torch.cuda.Stream() for _ in range(NTH)]
     one_pass(halves[0], streams[0].cuda_stream)          # warm-up
     for _ in range(2):
         one_pass(halves[0], streams[0].cuda_stream, stage)
     t0 = time.perf_counter()
-    th = [threading.Thread(target=worker, args=(halves[i], streams[i])) for i in range(2)]
+    th = [threading.Thread(target=worker, args=(halves[i], streams[i])) for i in range(NTH)]
     for t in th:
         t.start()
     for t in th:
@@ -281,8 +284,8 @@ def stream_figures(tcv, torch, keep, B_stream: int = 512, rounds: int = 4):
         t1 = time.perf_counter()
         one_pass(one, None)
         e2e.append(time.perf_counter() - t1)
-    return {"stream_solves_per_s": 2 * rounds * B / dt,
-            "stream_note": f"PCIe-inclusive: 2 host threads x {rounds} passes x {B} windows, per pass pack + H2D (tcv_batch_create), solve + gauge fix + "
+    return {"stream_solves_per_s": NTH * rounds * B / dt,
+            "stream_note": f"PCIe-inclusive: {NTH} host threads x {rounds} passes x {B} windows, per pass pack + H2D (tcv_batch_create), solve + gauge fix + "
                            f"marginalisation on the thread's own HIP stream, D2H of states and priors; serial stage times per {B}-window pass [ms]: "
                            + ", ".join(f"{k} {1e3 * v / 2:.1f}" for k, v in stage.items()),
             "single_window_ms": {"resident_launch_to_sync": 1e3 * float(np.median(lat)), "kernels": st1["solve_ms"] + st1["marg_ms"],
