@@ -78,3 +78,34 @@ def test_the_scipy_minimiser_is_a_fixed_point_and_a_lower_bound(gpu):
     we2 = dict(we, pose=P["sp_exact_pose"], speedbias=P["sp_exact_sb"], ex_pose=P["sp_exact_ex"], lam=P["sp_exact_lam"])
     W, b, s = _solve(gpu, we2, 50, False)
     assert abs(s.initial_cost - ce) < 1e-9 * ce and abs(s.final_cost - ce) < 1e-8 * ce
+
+
+def test_marginalisation_schur_step_against_50_digits(gpu, monkeypatch):
+    """tests/golden/marg_pin.npz (make_golden_marg_pin.py): A' = Arr - Arm Amm^-1 Amr and b' of the MARGIN_OLD factor set of the two golden
+    windows at their initial states, accumulated and solved with mpmath at 50 digits from binary64 factor Jacobians.  Both routes of the
+    kernel through Amm (Cholesky factor when the rank is proven; TCV_MARG_EIG_MM=1: Jacobi eigen-decomposition) against it.  For scale: the
+    NumPy restatement with LAPACK's eigh -- the accuracy class of the reference's SelfAdjointEigenSolver on this graded matrix (eigenvalues
+    1e1 ... 1e14: absolute accuracy eps |Amm|) -- is 7.4e-6 / 6.2e-7 away from the 50-digit result."""
+    import ctypes as C
+    z = load("marg_pin.npz")
+    pre, main, _ = golden_windows()
+    for w, p in ((pre, "pre_"), (main, "main_")):
+        for mode in ("chol", "eig"):
+            if mode == "eig":
+                monkeypatch.setenv("TCV_MARG_EIG_MM", "1")
+            else:
+                monkeypatch.delenv("TCV_MARG_EIG_MM", raising=False)
+            mw = gpu.margin_old_window(w)
+            Wm = gpu.Window(mw)
+            dr = gpu.margin_old_drops(Wm, mw)
+            arr = (gpu._dp * len(dr))(*dr)
+            h = C.c_void_p()
+            gpu.check(gpu.lib().tcv_marginalize(Wm.h, arr, len(dr), C.byref(h)))
+            P = gpu.Prior(h); As, bs = P.schur(); d = P.export()
+            ea, eb = fro(As, z["mg_" + p + "A"]), fro(bs, z["mg_" + p + "b"])
+            print("50-digit pin %s%s: A' %.2e b' %.2e, J0'J0 vs pin %.2e" % (p, mode, ea, eb, fro(d["J0"].T @ d["J0"], z["mg_" + p + "A"])))
+            # measured: A' 2.2e-6 / 1.9e-6 (pre: Cholesky / eigen route), 2.1e-7 / 3.7e-7 (main) -- the floor set by the rounding of each side's own
+            # Jacobians at these unsolved states; b' 6.9e-12 / 1.7e-8 (pre), 4.7e-13 / 3.5e-10 (main): the Cholesky route is four orders
+            # closer to the exact Schur step than the eigen route, which in turn is three orders closer than LAPACK's eigh (1.6e-5 / 1.4e-6)
+            assert ea < 1e-5 and eb < (1e-10 if mode == "chol" else 1e-6)
+    monkeypatch.delenv("TCV_MARG_EIG_MM", raising=False)
