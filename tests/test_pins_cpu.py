@@ -68,3 +68,20 @@ def test_the_scipy_minimiser_is_a_fixed_point_and_a_lower_bound(lib):
     we2 = dict(we, pose=P["sp_exact_pose"], speedbias=P["sp_exact_sb"], ex_pose=P["sp_exact_ex"], lam=P["sp_exact_lam"])
     prob = npo.Problem(we2)
     assert abs(prob.linearize(prob.x0(), want_jac=False)[2] - ce) < 1e-10 * ce
+
+
+def test_marginalisation_schur_step_of_both_oracles_against_50_digits(lib):
+    """tests/golden/marg_pin.npz: A' and b' of the MARGIN_OLD factor set of the golden windows at their initial states, Schur step at 50
+    digits.  The C oracle (cyclic Jacobi: relative accuracy on the graded Amm) lands at the floor set by FP64 Jacobians; the NumPy
+    oracle (LAPACK eigh, the accuracy class of the reference's SelfAdjointEigenSolver: absolute accuracy eps |Amm|) an order or more away."""
+    z = load("marg_pin.npz")
+    pre, main, _ = golden_windows()
+    for w, p in ((pre, "pre_"), (main, "main_")):
+        po, dbg = orc.Window(w).marginalize_old()
+        ea, eb = fro(dbg["A_schur"], z["mg_" + p + "A"]), fro(dbg["b_schur"], z["mg_" + p + "b"])
+        prob = npo.Problem(w)
+        _, dn = npo.marginalize_old(prob, prob.x0())
+        na, nb = fro(dn["A_schur"], z["mg_" + p + "A"]), fro(dn["b_schur"], z["mg_" + p + "b"])
+        print("%s C oracle A' %.2e b' %.2e | NumPy oracle A' %.2e b' %.2e" % (p, ea, eb, na, nb))
+        assert ea < 1e-5 and eb < 1e-9          # measured 2.5e-6 / 2.6e-7 and 3.6e-11 / 1.9e-12
+        assert na < 5e-5 and nb < 1e-4          # measured 7.4e-6 / 6.2e-7 and 1.6e-5 / 1.4e-6
