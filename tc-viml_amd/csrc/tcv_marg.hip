@@ -394,7 +394,7 @@ __device__ __noinline__ bool sym_eig_tridiag(lds_d *A, lds_d *Hq, lds_d *sm, lds
             pv = pr * vr;
         }
         if (tid < 128) {      // m <= 79: the first two wavefronts hold all the terms
-            for (int o = 32; o > 0; o >>= 1) pv += __shfl_down(pv, o);
+            pv = wave_sum_down(pv);
             if (lane == 0) red[wave] = pv;
         }
         if (tid == 0) { dv[i] = A[i * ld + i]; ev[i] = beta; tauv[i] = tau; }

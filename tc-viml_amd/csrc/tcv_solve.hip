@@ -164,7 +164,7 @@ enum {
 
 template <int NT>
 __device__ __forceinline__ double block_sum(double v, lds_d *red, int tid) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    v = wave_sum_down(v);
     __syncthreads();
     if ((tid & 63) == 0) red[tid >> 6] = v;
     __syncthreads();
@@ -178,7 +178,7 @@ template <int NT, int N>
 __device__ __forceinline__ void block_sum_n(double (&v)[N], lds_d *red, int tid) {
 #pragma unroll
     for (int k = 0; k < N; k++)
-        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_down(v[k], o);
+        v[k] = wave_sum_down(v[k]);
     __syncthreads();
     if ((tid & 63) == 0)
 #pragma unroll
@@ -318,7 +318,7 @@ template <int N>
 __device__ __forceinline__ void wave_sum(double (&acc)[N]) {
 #pragma unroll
     for (int e = 0; e < N; e++)
-        for (int o = 32; o > 0; o >>= 1) acc[e] += __shfl_down(acc[e], o);
+        acc[e] = wave_sum_down(acc[e]);
 }
 
 // global (plan, L2-resident) -> LDS copy of a gather program: 16-byte loads, four in flight per thread
