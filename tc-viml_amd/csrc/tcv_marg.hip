@@ -289,8 +289,8 @@ __device__ __noinline__ void eig_backtransform(const lds_d *Hq, lds_d *Z, const 
             sum += v[q] * z[q];                                                                              \
         }                                                                                                    \
         if (LPC == 4) {                                                                                      \
-            sum += __shfl_xor(sum, 1);                                                                       \
-            sum += __shfl_xor(sum, 2);                                                                       \
+            sum += down_dpp<0xB1>(sum);      /* quad_perm [1,0,3,2]: lane ^ 1 */                              \
+            sum += down_dpp<0x4E>(sum);      /* quad_perm [2,3,0,1]: lane ^ 2 */                              \
         } else {                                                                                             \
             const double s0 = __shfl(sum, l0), s1 = __shfl(sum, l1), s2 = __shfl(sum, l2);                   \
             sum = (s0 + s1) + s2;                                                                            \
@@ -359,8 +359,9 @@ __device__ __noinline__ bool sym_eig_tridiag(lds_d *A, lds_d *Hq, lds_d *sm, lds
                     if (c < m) { u += rv[j] * xv[j]; if (c > 0) xn2 += xv[j] * xv[j]; }
                 }
             }
-            u += __shfl_xor(u, 1); u += __shfl_xor(u, 2);
-            xn2 += __shfl_xor(xn2, 1); xn2 += __shfl_xor(xn2, 2);
+            // (only lane 0 of a 4-lane group uses the sums: the butterfly's pairings on that lane, by DPP row shifts instead of ds_bpermute)
+            u += down_dpp<0x101>(u); u += down_dpp<0x102>(u);
+            xn2 += down_dpp<0x101>(xn2); xn2 += down_dpp<0x102>(xn2);
             if (r < m && part == 0) ubuf[r] = u;
             if (tid == 0) xnb[0] = xn2;
         }
@@ -426,8 +427,8 @@ __device__ __noinline__ bool sym_eig_tridiag(lds_d *A, lds_d *Hq, lds_d *sm, lds
                         if (c >= 1) { un += nv * xn; if (c >= 2) x2 += xn * xn; }                                                    \
                     }                                                                                                                \
                 }                                                                                                                    \
-                un += __shfl_xor(un, 1); un += __shfl_xor(un, 2); un += __shfl_xor(un, 4);                                           \
-                x2 += __shfl_xor(x2, 1); x2 += __shfl_xor(x2, 2); x2 += __shfl_xor(x2, 4);                                           \
+                un += down_dpp<0x101>(un); un += down_dpp<0x102>(un); un += down_dpp<0x104>(un);      /* lane 0 of the 8-lane group */      \
+                x2 += down_dpp<0x101>(x2); x2 += down_dpp<0x102>(x2); x2 += down_dpp<0x104>(x2);                                            \
                 if (part8 == 0 && rr >= 1 && rr < m) ubuf[rr - 1] = un;                                                              \
                 if (part8 == 0 && rr == 1) xnb[(i + 1) & 1] = x2;                                                                    \
                 if (part8 == 0 && rr > 0 && rr < m) hq[rr - 1] = vr;                                                                 \
