@@ -262,16 +262,19 @@ __device__ __forceinline__ int refl_off(int i, int n) { return i * (n - 2) - (i 
 
 // Z <- Q Z, Q = H_0 ... H_{n-2}: LPC lanes own a column and keep it in registers (rows R = sub + LPC q) for all reflectors, so
 // successive reflectors do not wait on LDS write -> read trips.  512 threads: four lanes per column, 16 columns per wavefront; 256
-// threads: three lanes per column, 21 columns per wavefront (lane 63 idle).
+// threads: three lanes per column, five columns per 16-lane row (its last lane idle) = 20 per wavefront, so that a column's three
+// partial sums meet through DPP row shifts.
 template <int LPC>
 __device__ __noinline__ void eig_backtransform(const lds_d *Hq, lds_d *Z, const lds_d *tauv, int n, int ld, int tid) {
-    constexpr int CPW = 64 / LPC, RPL = (MARG_MAX_N + LPC - 1) / LPC;
-    const int lane = tid & 63, wave = tid >> 6, gl = lane / LPC, sub = lane - gl * LPC;
+    constexpr int CPW = LPC == 4 ? 16 : 20, RPL = (MARG_MAX_N + LPC - 1) / LPC;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15;
+    const int gl = LPC == 4 ? lane / 4 : (lane >> 4) * 5 + min(li / 3, 4);
+    const int sub = LPC == 4 ? (lane & 3) : li - 3 * min(li / 3, 4);      // (the idle lane 15 of a row gets sub = 3: it owns nothing)
     if (wave * CPW >= n) return;
     const int c = wave * CPW + gl;
-    const bool own = gl < CPW && c < n;
+    const bool own = sub < LPC && c < n;
     const int cs = own ? c : 0;
-    const int l0 = min(lane - sub, 63), l1 = min(lane - sub + 1, 63), l2 = min(lane - sub + 2, 63);
     double z[RPL];
 #pragma unroll
     // all LDS loads are unconditional (clamped row) and masked afterwards: a conditional load becomes an exec-mask
@@ -291,8 +294,12 @@ __device__ __noinline__ void eig_backtransform(const lds_d *Hq, lds_d *Z, const 
         if (LPC == 4) {                                                                                      \
             sum += down_dpp<0xB1>(sum);      /* quad_perm [1,0,3,2]: lane ^ 1 */                              \
             sum += down_dpp<0x4E>(sum);      /* quad_perm [2,3,0,1]: lane ^ 2 */                              \
-        } else {                                                                                             \
-            const double s0 = __shfl(sum, l0), s1 = __shfl(sum, l1), s2 = __shfl(sum, l2);                   \
+        } else {      /* (s0 + s1) + s2 over the column's three lanes: neighbours through DPP row shifts */          \
+            const double up1 = down_dpp<0x101>(sum), up2 = down_dpp<0x102>(sum);      /* lane + 1, lane + 2 */ \
+            const double dn1 = down_dpp<0x111>(sum), dn2 = down_dpp<0x112>(sum);      /* lane - 1, lane - 2 */ \
+            const double s0 = sub == 0 ? sum : (sub == 1 ? dn1 : dn2);                                       \
+            const double s1 = sub == 0 ? up1 : (sub == 1 ? sum : dn1);                                       \
+            const double s2 = sub == 0 ? up2 : (sub == 1 ? up1 : sum);                                       \
             sum = (s0 + s1) + s2;                                                                            \
         }                                                                                                    \
         const double w = tau * sum;                                                                          \
