@@ -158,3 +158,17 @@ def test_compact_prior_download_and_concurrent_host_threads(gpu):
         for d0, d1 in zip(ref[h][1], out[h][1]):
             assert np.array_equal(d0["J0"], d1["J0"]) and np.array_equal(d0["r0"], d1["r0"]) and d0["idx"] == d1["idx"]
             assert all(np.array_equal(x0, x1) for x0, x1 in zip(d0["x0"], d1["x0"]))
+
+
+def test_valu_wave_sum_reproduces_the_shuffle_tree(gpu, tmp_path):
+    """csrc/tcv_dev.h wave_sum_down: v_permlane32_swap + v_permlane16_swap + DPP row_shl must give lane 0 the bits of the
+    `v += __shfl_down(v, o)` tree it replaced in the gathers, the block sums and the tridiagonalisation (same pairings, same order).
+    tests/dev/hip/wave_sum_check.hip compares 4096 wavefronts of mixed-magnitude doubles; built here with hipcc for gfx950."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(tmp_path, "wave_sum_check")
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", os.path.join(root, "tests", "dev", "hip", "wave_sum_check.hip"), "-o", exe],
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "0 of 4096 sums differ" in r.stdout, r.stdout + r.stderr
