@@ -465,12 +465,19 @@ static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds)
         int k = std::max(1, (nproj * prec + nline * LINE_REC + c_pool - 1) / std::max(1, c_pool));
         if (const char *ek = getenv("TCV_VIS_CHUNKS")) k = std::max(k, atoi(ek));      // tuning experiments
         for (; k <= kmax && !found;) {
+            // point factors: an even split, except that a boundary a few factors above a multiple of 64 is pulled down to it -- one lane
+            // evaluates one factor, so 64 + 68 + 68 factors cost five wavefront passes of the evaluation and 64 + 64 + 72 cost four.  Line
+            // factors: dealt so that the chunks' record volumes even out (the chunk with more point factors gets fewer lines).
             std::vector<VChunk> cand;
-            int l = 0;
+            int l = 0, lines_left = nline, lb_next = 0;
+            const long long rec_even = ((long long)nproj * prec + (long long)nline * LINE_REC) / k;
             for (int c = 0; c < k; c++) {
-                VChunk cur{lmptr[l], 0, c * nline / k, (c + 1) * nline / k - c * nline / k, l, 0};
-                const int target = (int)((long long)(c + 1) * nproj / k);
+                VChunk cur{lmptr[l], 0, lb_next, 0, l, 0};
+                int target = (int)((long long)(c + 1) * nproj / k);
+                if (target % 64 <= 8 && target >= 64) target -= target % 64;
                 while (l < L && (c == k - 1 || lmptr[l + 1] <= target || cur.lmn == 0)) { cur.pn += lmptr[l + 1] - lmptr[l]; cur.lmn++; l++; }
+                int ln_c = c == k - 1 ? lines_left : (int)std::max<long long>(0, std::min<long long>(lines_left, (rec_even - (long long)cur.pn * prec + LINE_REC / 2) / LINE_REC));
+                cur.ln = ln_c; lb_next += ln_c; lines_left -= ln_c;
                 cand.push_back(cur);
             }
             int ms = 0, ma = 0;
