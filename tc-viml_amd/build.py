@@ -27,9 +27,23 @@ def _stale() -> bool:
     return False
 
 
-def build(force: bool = False, verbose: bool = False, profile: bool = False, ablate: bool = False) -> str:
+SANITIZE_FLAGS = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-gline-tables-only", "-shared-libsan"]
+
+
+def asan_runtime() -> str:
+    """the shared AddressSanitizer runtime of the ROCm clang: a process that dlopens the sanitized library must preload it"""
+    import glob
+    hits = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+    return hits[-1] if hits else ""
+
+
+def build(force: bool = False, verbose: bool = False, profile: bool = False, ablate: bool = False, sanitize: bool = False) -> str:
     """profile=True builds libtcv_hip_prof.so with per-phase cycle accounting, ablate=True libtcv_hip_abl.so whose solve kernel can
-    skip phases (TCV_ABLATE_SKIP bit mask): developer tools."""
+    skip phases (TCV_ABLATE_SKIP bit mask): developer tools.  sanitize=True builds libtcv_hip_san.so: the HOST side (packer, C-ABI,
+    native estimator, host halves of the .hip files) under AddressSanitizer + UndefinedBehaviorSanitizer -- the device pass ignores
+    the flags (GPU sanitizers are not available on this pool); tests/test_sanitize_cpu.py drives it without a device."""
+    if sanitize:
+        return _compile(os.path.join(HERE, "libtcv_hip_san.so"), verbose, SANITIZE_FLAGS, opt="-O1", link_extra=["-fsanitize=address,undefined", "-shared-libsan"])
     if profile:
         return _compile(os.path.join(HERE, "libtcv_hip_prof.so"), verbose, ["-DTCV_PROFILE=1"])
     if ablate:
@@ -39,14 +53,14 @@ def build(force: bool = False, verbose: bool = False, profile: bool = False, abl
     return _compile(OUT, verbose, [])
 
 
-def _compile(out: str, verbose: bool, extra) -> str:
+def _compile(out: str, verbose: bool, extra, opt: str = "-O3", link_extra=()) -> str:
     """One object per source (compiled in parallel), then one link.  tcv_solve.hip is compiled twice: the dense kernels, and
     (-DTCV_SOLVE_CHAIN_TU) the chain kernel alone in its own translation unit so that its 2-waves-per-SIMD register budget
     is not widened by the other instantiations' call trees."""
     from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on",
-            "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-value", "-Wno-unused-result", "-x", "hip"]
+    base = [hipcc, "--offload-arch=gfx950", opt, "-std=c++17", "-fPIC", "-ffp-contract=on",
+            "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-value", "-Wno-unused-result", "-Wno-option-ignored", "-x", "hip"]
     if os.path.exists(os.path.join(CSRC, "tcv_marg.hip")):
         base.append("-DTCV_HAVE_MARG=1")
     if verbose:
@@ -64,9 +78,9 @@ def _compile(out: str, verbose: bool, extra) -> str:
 
     with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
         objs = list(ex.map(one, jobs))
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out])
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + list(link_extra) + objs + ["-o", out])
     return out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv, profile="--profile" in sys.argv, ablate="--ablate" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv, profile="--profile" in sys.argv, ablate="--ablate" in sys.argv, sanitize="--sanitize" in sys.argv))

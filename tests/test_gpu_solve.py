@@ -7,7 +7,7 @@ import pytest
 
 import orc
 import synth
-from util import fro, golden_windows, rel
+from util import fro, golden_windows, rel, sub_window
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-6
@@ -93,28 +93,10 @@ def test_constant_extrinsic(gpu):
     check_against_oracle(gpu, w, W[0], b, s[0], 0, 8, True, ex_constant=True)
 
 
-def _sub_window(w, frames, keep_lines=True):
-    """first `frames` frames of a window (ragged case: factors that touch later frames are dropped)."""
-    out = dict(w)
-    out["pose"] = w["pose"][:frames]; out["speedbias"] = w["speedbias"][:frames]
-    im = w["imu"]; ki = [k for k in range(len(im["frame_i"])) if im["frame_j"][k] < frames]
-    out["imu"] = {k: (np.asarray(v)[ki] if isinstance(v, np.ndarray) and v.shape[:1] == (len(im["frame_i"]),) else v) for k, v in im.items()}
-    pr = w["proj"]; kp = [k for k in range(len(pr["frame_i"])) if pr["frame_j"][k] < frames]
-    out["proj"] = {k: (np.asarray(v)[kp] if isinstance(v, np.ndarray) and v.shape[:1] == (len(pr["frame_i"]),) else v) for k, v in pr.items()}
-    used = sorted(set(int(l) for l in out["proj"]["landmark"]))
-    remap = {l: i for i, l in enumerate(used)}
-    out["proj"]["landmark"] = np.array([remap[int(l)] for l in out["proj"]["landmark"]], int)
-    out["lam"] = w["lam"][used]
-    ln = w["line"]; kl = [k for k in range(len(ln["frame"])) if ln["frame"][k] < frames and keep_lines]
-    out["line"] = {k: (np.asarray(v)[kl] if isinstance(v, np.ndarray) and v.shape[:1] == (len(ln["frame"]),) else v) for k, v in ln.items()}
-    out["prior"] = None
-    return out
-
-
 @pytest.mark.parametrize("frames", [3, 6, 9])
 def test_short_and_ragged_windows(gpu, frames):
     batch = synth.make_windows(400, 1)
-    w = _sub_window(synth.window_at(batch, 0), frames)
+    w = sub_window(synth.window_at(batch, 0), frames)
     W, b, s = gpu_solve(gpu, [w])
     check_against_oracle(gpu, w, W[0], b, s[0], 0, 8, True)
 

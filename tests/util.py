@@ -45,3 +45,21 @@ def imu_pre(z, k, prefix="i1_"):
     return dict(delta_p=z[prefix + "delta_p"][k], delta_q=z[prefix + "delta_q"][k], delta_v=z[prefix + "delta_v"][k],
                 lin_ba=z[prefix + "lin_ba"][k], lin_bg=z[prefix + "lin_bg"][k], sum_dt=float(z[prefix + "sum_dt"][k]),
                 jacobian=z[prefix + "jacobian"][k], covariance=z[prefix + "covariance"][k])
+
+
+def sub_window(w, frames, keep_lines=True):
+    """first `frames` frames of a window (ragged case: factors that touch later frames are dropped)."""
+    out = dict(w)
+    out["pose"] = w["pose"][:frames]; out["speedbias"] = w["speedbias"][:frames]
+    im = w["imu"]; ki = [k for k in range(len(im["frame_i"])) if im["frame_j"][k] < frames]
+    out["imu"] = {k: (np.asarray(v)[ki] if isinstance(v, np.ndarray) and v.shape[:1] == (len(im["frame_i"]),) else v) for k, v in im.items()}
+    pr = w["proj"]; kp = [k for k in range(len(pr["frame_i"])) if pr["frame_j"][k] < frames]
+    out["proj"] = {k: (np.asarray(v)[kp] if isinstance(v, np.ndarray) and v.shape[:1] == (len(pr["frame_i"]),) else v) for k, v in pr.items()}
+    used = sorted(set(int(l) for l in out["proj"]["landmark"]))
+    remap = {l: i for i, l in enumerate(used)}
+    out["proj"]["landmark"] = np.array([remap[int(l)] for l in out["proj"]["landmark"]], int)
+    out["lam"] = w["lam"][used]
+    ln = w["line"]; kl = [k for k in range(len(ln["frame"])) if ln["frame"][k] < frames and keep_lines]
+    out["line"] = {k: (np.asarray(v)[kl] if isinstance(v, np.ndarray) and v.shape[:1] == (len(ln["frame"]),) else v) for k, v in ln.items()}
+    out["prior"] = None
+    return out
