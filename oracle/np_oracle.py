@@ -559,20 +559,47 @@ def schur_solve(H, g, nc):
 # Trust-region minimiser with traditional dogleg -- upstream Ceres 2.x defaults, unverified
 # here; options set by the reference: estimator.cpp:1888-1897.
 # --------------------------------------------------------------------------------------
-def solve(prob: Problem, max_num_iterations=8, fixed_iterations=False, imu_sqrt=None, trace=None):
+# Every Ceres default the restatement relies on (Solver::Options / DoglegStrategy constants of upstream Ceres 2.x),
+# by name.  solve() uses exactly these unless `ceres_defaults` overrides some: tools/ceres_logic_sensitivity.py perturbs them ONE at a
+# time so that a maintainer with a real Ceres can falsify the restatement with one number (iterations to converge / final cost).
+CERES_DEFAULTS = dict(
+    jacobi_scaling="1/(1+norm)",          # Solver::Options::jacobi_scaling = true: 1 / (1 + ||column||); alternatives "off", "1/norm"
+    min_lm_diagonal=1e-6, max_lm_diagonal=1e32,
+    initial_trust_region_radius=1e4,
+    min_mu=1e-8, max_mu=1.0, mu_increase_factor=10.0,
+    mu_decrease="max(min_mu, 2 mu / factor)",   # DoglegStrategy::StepAccepted; alternative "keep"
+    decrease_threshold=0.25, increase_threshold=0.75, radius_increase_factor=3.0,
+    min_relative_decrease=1e-3,
+    function_tolerance=1e-6, parameter_tolerance=1e-8, gradient_tolerance=1e-10,
+    min_trust_region_radius=1e-32, max_num_consecutive_invalid_steps=5,
+)
+
+
+def solve(prob: Problem, max_num_iterations=8, fixed_iterations=False, imu_sqrt=None, trace=None, ceres_defaults=None):
+    C = dict(CERES_DEFAULTS)
+    if ceres_defaults:
+        unknown = set(ceres_defaults) - set(C)
+        assert not unknown, unknown
+        C.update(ceres_defaults)
     x = prob.x0()
     nc = prob.nc
     J, r, cost = prob.linearize(x, imu_sqrt)
     # jacobi scaling, computed once at iteration 0
-    scale = 1.0 / (1.0 + np.sqrt((J * J).sum(0)))
+    cn = np.sqrt((J * J).sum(0))
+    if C["jacobi_scaling"] == "1/(1+norm)":
+        scale = 1.0 / (1.0 + cn)
+    elif C["jacobi_scaling"] == "1/norm":
+        scale = 1.0 / np.maximum(cn, 1e-300)
+    else:
+        scale = np.ones_like(cn)
     J = J * scale
     grad_unscaled = (J / scale).T @ r
     summary = dict(initial_cost=cost, iterations=[dict(it=0, cost=cost, step_ok=True)], termination="NO_CONVERGENCE")
-    if not fixed_iterations and np.max(np.abs(grad_unscaled)) <= 1e-10:
+    if not fixed_iterations and np.max(np.abs(grad_unscaled)) <= C["gradient_tolerance"]:
         summary["termination"] = "CONVERGENCE_GRADIENT"; summary["final_cost"] = cost
         return x, summary
-    radius, mu, reuse, invalid = 1e4, 1e-8, False, 0
-    min_mu, max_mu, mu_inc = 1e-8, 1.0, 10.0
+    radius, mu, reuse, invalid = C["initial_trust_region_radius"], C["min_mu"], False, 0
+    min_mu, max_mu, mu_inc = C["min_mu"], C["max_mu"], C["mu_increase_factor"]
     x_norm = np.linalg.norm(prob.ambient(x))
     it = 0
     diag = grad = gn = None
@@ -586,7 +613,7 @@ def solve(prob: Problem, max_num_iterations=8, fixed_iterations=False, imu_sqrt=
         step_valid_ls = True
         if not reuse:
             reuse = True
-            diag = np.sqrt(np.clip((J * J).sum(0), 1e-6, 1e32))
+            diag = np.sqrt(np.clip((J * J).sum(0), C["min_lm_diagonal"], C["max_lm_diagonal"]))
             grad = (J.T @ r) / diag
             Jg = J @ (grad / diag)
             alpha = float(grad @ grad) / float(Jg @ Jg)
@@ -630,7 +657,7 @@ def solve(prob: Problem, max_num_iterations=8, fixed_iterations=False, imu_sqrt=
             invalid += 1
             rec["step_ok"] = False; rec["invalid"] = True; rec["cost"] = cost
             summary["iterations"].append(rec)
-            if invalid >= 5:
+            if invalid >= C["max_num_consecutive_invalid_steps"]:
                 summary["termination"] = "FAILURE"
                 break
             mu *= mu_inc; reuse = False       # DoglegStrategy::StepIsInvalid
@@ -642,33 +669,34 @@ def solve(prob: Problem, max_num_iterations=8, fixed_iterations=False, imu_sqrt=
         rec.update(model_cost_change=model_cost_change, cost_candidate=cost_c, radius=radius,
                    step_norm_dogleg=step_norm, delta=delta.copy())
         dxn = np.linalg.norm(prob.ambient(x) - prob.ambient(x_c))
-        if not fixed_iterations and dxn <= 1e-8 * (x_norm + 1e-8):
+        if not fixed_iterations and dxn <= C["parameter_tolerance"] * (x_norm + C["parameter_tolerance"]):
             rec["cost"] = cost; summary["iterations"].append(rec)
             summary["termination"] = "CONVERGENCE_PARAMETER"
             break
         cost_change = cost - cost_c
-        if not fixed_iterations and abs(cost_change) <= 1e-6 * cost:
+        if not fixed_iterations and abs(cost_change) <= C["function_tolerance"] * cost:
             rec["cost"] = cost; summary["iterations"].append(rec)
             summary["termination"] = "CONVERGENCE_FUNCTION"
             break
         rho = cost_change / model_cost_change
         rec["rho"] = rho
-        if rho > 1e-3:
+        if rho > C["min_relative_decrease"]:
             x = x_c
             x_norm = np.linalg.norm(prob.ambient(x))
             J, r, cost = prob.linearize(x, imu_sqrt)
             grad_unscaled = J.T @ r
             J = J * scale
             rec["step_ok"] = True
-            if rho < 0.25:
+            if rho < C["decrease_threshold"]:
                 radius *= 0.5
-            if rho > 0.75:
-                radius = max(radius, 3.0 * step_norm)
-            mu = max(min_mu, 2.0 * mu / mu_inc)
+            if rho > C["increase_threshold"]:
+                radius = max(radius, C["radius_increase_factor"] * step_norm)
+            if C["mu_decrease"] != "keep":
+                mu = max(min_mu, 2.0 * mu / mu_inc)
             reuse = False
             rec["cost"] = cost
             summary["iterations"].append(rec)
-            if not fixed_iterations and np.max(np.abs(grad_unscaled)) <= 1e-10:
+            if not fixed_iterations and np.max(np.abs(grad_unscaled)) <= C["gradient_tolerance"]:
                 summary["termination"] = "CONVERGENCE_GRADIENT"
                 break
         else:
@@ -677,7 +705,7 @@ def solve(prob: Problem, max_num_iterations=8, fixed_iterations=False, imu_sqrt=
             reuse = True
             rec["cost"] = cost
             summary["iterations"].append(rec)
-        if radius < 1e-32:
+        if radius < C["min_trust_region_radius"]:
             summary["termination"] = "CONVERGENCE_RADIUS"
             break
     summary["final_cost"] = cost
