@@ -44,7 +44,7 @@ typedef struct {
 typedef struct {
     int marg_flag;              /* 0 MARGIN_OLD, 1 MARGIN_SECOND_NEW */
     int n_landmarks, n_proj, n_line, n_line_obs;
-    int iterations, prior_n;
+    int iterations, prior_n;    /* iterations = summary.iterations.size() of the window's solve (what estimator.cpp:1902 logs) */
     double final_cost;
 } tcv_estimator_stats;
 
@@ -67,7 +67,12 @@ int tcv_estimator_set_line_map(tcv_estimator *e, int n, const double *lines3d, c
 int tcv_estimator_begin_frame(tcv_estimator *e, int n_imu, const double *acc, const double *gyr, int n_points, const int *point_ids,
                               const double *points, int n_lines, const int *line_ids, const double *lines, const double *truth, int *ready);
 /* solveOdometry + double2vector + marginalisation for every estimator in the list (all must be ready): one device batch.
- * The solver options (num_iterations, fixed_iterations) and the IMU noise are those of the first estimator of the list. */
+ * The solver options (num_iterations, fixed_iterations) and the IMU noise are those of the first estimator of the list.
+ * A window whose own marginalisation fails numerically (eigen-solver sweep cap) does not fail the batch: the other estimators are
+ * applied, the call returns TCV_OK, and tcv_estimator_finish_frame of THAT estimator returns TCV_ERR_NUMERIC (reset it, like after
+ * failureDetection).  Any other error (HIP, invalid input) fails the whole call and applies nothing.
+ * Thread safety: estimators are independent objects; different host threads may drive different estimator lists, on the same or on
+ * different devices (the launch streams are per device). */
 int tcv_estimators_optimize(tcv_estimator *const *e, int n);
 /* failureDetection, the published state (Ps / Rs / Vs[WINDOW_SIZE], quaternion x y z w) and slideWindow.
  * TCV_ERR_NUMERIC: failure detection fired (the reference would reset the estimator). */

@@ -560,7 +560,7 @@ def schur_solve(H, g, nc):
 # here; options set by the reference: estimator.cpp:1888-1897.
 # --------------------------------------------------------------------------------------
 # Every Ceres default the restatement relies on (Solver::Options / DoglegStrategy constants of upstream Ceres 2.x),
-# by name.  solve() uses exactly these unless `ceres_defaults` overrides some: tools/ceres_logic_sensitivity.py perturbs them ONE at a
+# by name.  solve() uses exactly these unless `ceres_defaults` overrides some: tests/dev/ceres_logic_sensitivity.py perturbs them ONE at a
 # time so that a maintainer with a real Ceres can falsify the restatement with one number (iterations to converge / final cost).
 CERES_DEFAULTS = dict(
     jacobi_scaling="1/(1+norm)",          # Solver::Options::jacobi_scaling = true: 1 / (1 + ||column||); alternatives "off", "1/norm"

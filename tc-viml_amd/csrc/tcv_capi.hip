@@ -436,7 +436,9 @@ extern "C" void tcv_prior_destroy(tcv_prior *pr) { delete pr; }
 // =====================================================================================================
 static void batch_free(tcv_batch *b) {
     if (!b) return;
-    if (b->pending) { if (b->last_stream) (void)hipStreamSynchronize(b->last_stream); else (void)hipDeviceSynchronize(); }      // the buffers go back to the free list
+    if (b->pending)      // the buffers go back to the free list: nothing of this batch may still be running on any stream it used
+        for (hipStream_t st : b->streams) { if (st) (void)hipStreamSynchronize(st); else (void)hipDeviceSynchronize(); }
+    if (b->ev_order) (void)hipEventDestroy(b->ev_order);
     tcv::dev_free(b->d_win); tcv::dev_free(b->d_plans); tcv::dev_free(b->d_plan_base); tcv::dev_free(b->d_ipool); tcv::dev_free(b->d_dpool);
     tcv::dev_free(b->d_imublk); tcv::dev_free(b->d_spill); tcv::dev_free(b->d_sqrt_out);
     tcv::dev_free(b->d_prof); tcv::dev_free(b->d_state); tcv::dev_free(b->d_delta); tcv::dev_free(b->d_scratch); tcv::dev_free(b->d_summary);
@@ -681,6 +683,18 @@ extern "C" void tcv_solver_options_default(tcv_solver_options *o) {
     o->record_first_step = 0;
 }
 
+int tcv_batch_enter_stream(tcv_batch *b, void *hip_stream) {
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (b->pending && b->last_stream != st) {
+        if (!b->ev_order) HIPCHK(hipEventCreateWithFlags(&b->ev_order, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(b->ev_order, b->last_stream));
+        HIPCHK(hipStreamWaitEvent(st, b->ev_order, 0));
+    }
+    if (std::find(b->streams.begin(), b->streams.end(), st) == b->streams.end()) b->streams.push_back(st);
+    b->last_stream = st; b->pending = true;
+    return TCV_OK;
+}
+
 extern "C" int tcv_batch_solve(tcv_batch *b, const tcv_solver_options *o, void *hip_stream) {
     if (!b || !o) return TCV_ERR_INVALID;
     SolveArgs a;
@@ -704,7 +718,7 @@ extern "C" int tcv_batch_solve(tcv_batch *b, const tcv_solver_options *o, void *
         if (a.max_ticks < 1) a.max_ticks = 1;
     }
     hipStream_t st = (hipStream_t)hip_stream;
-    b->last_stream = st; b->pending = true;
+    if (int rc = tcv_batch_enter_stream(b, hip_stream)) return rc;
     HIPCHK(hipEventRecord(b->ev0, st));
     const int rc = tcv_launch_solve(&a, b->grid, (!b->chain && o->threads_per_window == 512) ? 512 : 256, b->lds_bytes, hip_stream);
     if (rc != 0) return hip_fail((hipError_t)rc, "solve kernel launch");
@@ -714,15 +728,15 @@ extern "C" int tcv_batch_solve(tcv_batch *b, const tcv_solver_options *o, void *
 }
 extern "C" int tcv_batch_marginalize(tcv_batch *b, void *hip_stream) {
     if (!b) return TCV_ERR_INVALID;
-    b->last_stream = (hipStream_t)hip_stream; b->pending = true;
+    if (int rc = tcv_batch_enter_stream(b, hip_stream)) return rc;
     return tcv_marg_run(b, hip_stream);
 }
-// waits for the stream of the last asynchronous call on this batch (the whole device when that was the default stream), so that
-// batches driven from different host threads on different streams overlap (bench.py --mode stream)
+// waits for every stream this batch has work in flight on (the whole device when one of them is the default stream), not for the
+// device: batches driven from different host threads on different streams overlap (bench.py --mode stream)
 extern "C" int tcv_batch_synchronize(tcv_batch *b) {
     if (!b) return TCV_ERR_INVALID;
-    if (b->last_stream) HIPCHK(hipStreamSynchronize(b->last_stream));
-    else HIPCHK(hipDeviceSynchronize());
+    for (hipStream_t st : b->streams) { if (st) HIPCHK(hipStreamSynchronize(st)); else HIPCHK(hipDeviceSynchronize()); }
+    b->streams.clear();
     b->pending = false;
     if (b->solved) hipEventElapsedTime(&b->solve_ms, b->ev0, b->ev1);
     tcv_marg_elapsed(b);

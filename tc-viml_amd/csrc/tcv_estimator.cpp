@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -158,6 +159,8 @@ struct tcv_estimator {
     std::vector<double *> m_drop;
     int n_line_obs_total = 0;
     int phase = 0;                           // 0: between frames, 1: window full, waiting for the optimisation, 2: optimised, waiting for finish_frame
+    int opt_failed = 0;                      // != TCV_OK: this estimator's window failed in the last lock-step batch (reported by finish_frame)
+    std::string opt_msg;
 };
 
 namespace {
@@ -595,10 +598,34 @@ extern "C" int tcv_estimator_begin_frame(tcv_estimator *e, int n_imu, const doub
 // host-side time accounting of tcv_estimators_optimize (seconds, cumulative; read and cleared by tcv_estimators_profile):
 // 0 pre-integration, 1 association + triangulation + window, 2 problem construction, 3 batch_create (pack + H2D), 4 kernels (launch to
 // sync), 5 downloads (states, summaries, priors), 6 apply / prior chaining, 7 calls
-static double g_prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+// Process-wide state of tcv_estimators_optimize, shared by host threads that drive estimators on the same or on different GPUs: the
+// profile accumulators and the two launch streams of every device (created once per device, kept for the life of the process).
+namespace {
+std::mutex g_mu;
+double g_prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+std::map<int, std::array<hipStream_t, 2>> g_dev_streams;
+void prof_add(int slot, double v) { std::lock_guard<std::mutex> g(g_mu); g_prof[slot] += v; }
+// the two non-blocking streams of the calling thread's current device; {null, null} (the default stream: sequential, still correct) if
+// they cannot be created
+std::array<hipStream_t, 2> device_streams() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> g(g_mu);
+    auto it = g_dev_streams.find(dev);
+    if (it != g_dev_streams.end()) return it->second;
+    std::array<hipStream_t, 2> st = {nullptr, nullptr};
+    if (hipStreamCreateWithFlags(&st[0], hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&st[1], hipStreamNonBlocking) != hipSuccess) {
+        if (st[0]) (void)hipStreamDestroy(st[0]);
+        st = {nullptr, nullptr};
+    }
+    g_dev_streams.emplace(dev, st);
+    return st;
+}
+}  // namespace
 static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 extern "C" int tcv_estimators_profile(double *out8) {
     if (!out8) return TCV_ERR_INVALID;
+    std::lock_guard<std::mutex> g(g_mu);
     for (int i = 0; i < 8; i++) { out8[i] = g_prof[i]; g_prof[i] = 0; }
     return TCV_OK;
 }
@@ -606,8 +633,8 @@ extern "C" int tcv_estimators_profile(double *out8) {
 extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
     if (!es || n <= 0) return TCV_ERR_INVALID;
     double t_mark = now_s();
-    auto lap = [&](int slot) { const double t = now_s(); g_prof[slot] += t - t_mark; t_mark = t; };
-    g_prof[7] += 1;
+    auto lap = [&](int slot) { const double t = now_s(); prof_add(slot, t - t_mark); t_mark = t; };
+    prof_add(7, 1);
     for (int i = 0; i < n; i++) if (!es[i] || es[i]->phase != 1) { tcv::set_error("estimators_optimize: an estimator has no full window waiting (begin_frame must report ready)"); return TCV_ERR_INVALID; }
     for (int i = 0; i < n; i++) for (int j = 0; j < i; j++) if (es[i] == es[j]) { tcv::set_error("estimators_optimize: the same estimator twice"); return TCV_ERR_INVALID; }
     // one pre-integration call for every stale IMU buffer of every estimator
@@ -662,23 +689,15 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
         std::vector<int> ndrop;
         std::vector<tcv_solver_summary> sum;
         std::vector<tcv_prior *> newp;
+        std::vector<int> est_rc;          // per estimator: TCV_ERR_NUMERIC when its own marginalisation failed
+        std::string est_msg;
         tcv_batch *b = nullptr;
         int rc = TCV_OK;
     };
     Group G[2];
-    static hipStream_t g_streams[2] = {nullptr, nullptr};
-    static int g_stream_dev = -1;
-    {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (g_stream_dev != dev) {      // streams belong to a device: made anew if the caller switched devices
-            for (auto &st : g_streams) st = nullptr;
-            if (hipStreamCreateWithFlags(&g_streams[0], hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&g_streams[1], hipStreamNonBlocking) != hipSuccess) {
-                g_streams[0] = g_streams[1] = nullptr;      // fall back to the default stream: sequential, still correct
-            }
-            g_stream_dev = dev;
-        }
-    }
+    // (the uploads inside tcv_batch_create are host-synchronous hipMemcpy calls: they are complete before any kernel is launched on
+    // these non-blocking streams)
+    const std::array<hipStream_t, 2> g_streams = device_streams();
     int rc_all = TCV_OK;
     for (int group = 1; group >= 0; group--) {
         Group &g = G[group];
@@ -727,8 +746,15 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
         if (g.rc == TCV_OK) g.rc = tcv_batch_download_states(g.b);
         if (g.rc == TCV_OK) g.rc = tcv_batch_get_summaries(g.b, g.sum.data(), nb);
         if (g.rc == TCV_OK && group) g.rc = tcv_batch_download_priors_compact(g.b);
+        g.est_rc.assign(nb, TCV_OK);
         if (g.rc == TCV_OK && group)
-            for (int k = 0; k < nb && g.rc == TCV_OK; k++) g.rc = tcv_batch_get_prior(g.b, k, &g.newp[k]);
+            for (int k = 0; k < nb; k++) {
+                // a window whose marginalisation did not converge (TCV_ERR_NUMERIC) fails alone: the other estimators of the lock-step
+                // batch are applied, this one reports the failure from tcv_estimator_finish_frame
+                g.est_rc[k] = tcv_batch_get_prior(g.b, k, &g.newp[k]);
+                if (g.est_rc[k] != TCV_OK && g.est_rc[k] != TCV_ERR_NUMERIC) { g.rc = g.est_rc[k]; break; }
+                if (g.est_rc[k] != TCV_OK) g.est_msg = tcv_last_error();
+            }
         if (g.b) tcv_batch_destroy(g.b);
         for (int k = 0; k < nb; k++) { if (g.P[k]) tcv_problem_destroy(g.P[k]); if (g.M[k]) tcv_problem_destroy(g.M[k]); }
         if (g.rc != TCV_OK && rc_all == TCV_OK) rc_all = g.rc;
@@ -741,10 +767,22 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
         if (rc_all != TCV_OK) { for (auto *p : g.newp) if (p) tcv_prior_destroy(p); continue; }
         for (int k = 0; k < nb; k++) {
             tcv_estimator *e = es[g.idx[k]];
+            e->opt_failed = TCV_OK;
+            if (g.est_rc[k] != TCV_OK) {      // this estimator's window failed numerically: nothing is applied, finish_frame reports it
+                e->opt_failed = g.est_rc[k]; e->opt_msg = g.est_msg; e->phase = 2;
+                continue;
+            }
             apply_states(e);
             e->stats.marg_flag = e->marg_flag; e->stats.n_landmarks = (int)e->sel.size(); e->stats.n_proj = (int)e->w_pi.size(); e->stats.n_line = (int)e->w_lf.size();
             e->stats.n_line_obs = e->n_line_obs_total; e->stats.iterations = g.sum[k].num_iterations; e->stats.final_cost = g.sum[k].final_cost;
-            if (group) { const int rc = take_prior(e, g.newp[k], e->marg_flag); g.newp[k] = nullptr; if (rc != TCV_OK) { rc_all = rc; break; } }
+            if (group) {
+                const int rc = take_prior(e, g.newp[k], e->marg_flag);
+                if (rc != TCV_OK) {      // (take_prior keeps the old prior on failure: the new one and the ones not handed over yet are released)
+                    for (int k2 = k; k2 < nb; k2++) if (g.newp[k2]) { tcv_prior_destroy(g.newp[k2]); g.newp[k2] = nullptr; }
+                    rc_all = rc; break;
+                }
+                g.newp[k] = nullptr;
+            }
             else e->stats.prior_n = e->prior ? e->stats.prior_n : 0;
             e->phase = 2;
         }
@@ -757,6 +795,11 @@ extern "C" int tcv_estimator_finish_frame(tcv_estimator *e, double P[3], double 
     if (!e || !P || !q || !V) return TCV_ERR_INVALID;
     if (e->phase != 2) { tcv::set_error("estimator_finish_frame: the window has not been optimised"); return TCV_ERR_INVALID; }
     e->phase = 0;
+    if (e->opt_failed != TCV_OK) {      // the window's own solve / marginalisation failed in the lock-step batch: like failureDetection, the caller resets
+        const int rc = e->opt_failed; e->opt_failed = TCV_OK;
+        tcv::set_error("estimator: optimisation of this window failed: " + e->opt_msg);
+        return rc;
+    }
     if (failure_detection(e)) { tcv::set_error("failure detection (estimator.cpp:1629-1675): the estimator diverged"); return TCV_ERR_NUMERIC; }
     for (int c = 0; c < 3; c++) { P[c] = e->Ps[W][c]; V[c] = e->Vs[W][c]; }
     R2q(e->Rs[W], q);

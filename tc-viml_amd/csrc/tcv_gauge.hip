@@ -159,7 +159,7 @@ extern "C" int tcv_batch_gauge_fix(tcv_batch *b, void *hip_stream) {
     if (!b || !b->solved) { set_error("batch_gauge_fix: batch has not been solved"); return TCV_ERR_INVALID; }
     for (auto &H : b->plans)
         if (H.n_frames <= 0 || H.n_frames > 64) { set_error("batch_gauge_fix: problem carries no frame table (tcv_problem_set_frames)"); return TCV_ERR_INVALID; }
-    b->last_stream = (hipStream_t)hip_stream; b->pending = true;
+    if (int rc = tcv_batch_enter_stream(b, hip_stream)) return rc;
     hipLaunchKernelGGL(gauge_batch_kernel, dim3(b->n), dim3(64), 0, (hipStream_t)hip_stream, b->d_win, b->d_plans, b->d_plan_base, b->d_ipool,
                        b->d_dpool, b->d_state, b->state_stride);
     hipError_t e = hipGetLastError();

@@ -96,7 +96,9 @@ struct tcv_batch {
     bool solved = false;
     std::vector<double> h_state;
     bool gauge_fixed = false;
-    hipStream_t last_stream = nullptr;     // stream of the last asynchronous call (tcv_batch_synchronize waits for it; null: the device)
+    hipStream_t last_stream = nullptr;     // stream of the last asynchronous call
+    std::vector<hipStream_t> streams;      // every stream with work of this batch in flight (tcv_batch_synchronize / batch_free wait for all of them; null: the device)
+    hipEvent_t ev_order = nullptr;         // orders a call on a new stream behind the pending work of the previous one (tcv_batch_enter_stream)
     bool pending = false;                  // asynchronous work issued since the last synchronize (batch_free waits before it recycles the buffers)
     bool chain = false;                   // all plans use the chain layout (2 workgroups per CU)
     int chain_lds = 0;                    // LDS doubles per chain-layout workgroup of this batch
@@ -111,6 +113,10 @@ struct tcv_batch {
 };
 
 
+// every asynchronous entry point of a batch passes through here: a call on another stream than the previous one waits (on the device) for
+// the batch's pending work there -- the gauge fix and the marginalisation read what the solve wrote -- and the stream joins the set
+// tcv_batch_synchronize waits for
+int tcv_batch_enter_stream(tcv_batch *b, void *hip_stream);
 int tcv_marg_sqrt_source(const tcv_batch *b, int window);   // index of that factor among the solve problem's IMU factors, -1 none
 int tcv_marg_attach(tcv_batch *b, tcv_problem *const *marg_problems, double *const *const *marg_drop, const int *marg_num_drop);
 int tcv_marg_run(tcv_batch *b, void *stream);

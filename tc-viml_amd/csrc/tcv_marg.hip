@@ -6,13 +6,15 @@
 //      (ResidualBlockInfo::Evaluate, :3-69, loss corrector included), one lane per factor;
 //   2. A = sum J'J and b = sum J'r are accumulated in LDS (packed lower triangle) factor by factor in
 //      a fixed order (the reference deals factors round-robin to 4 pthreads, :232-261);
-//   3. Amm = V diag(lambda) V' by a parallel cyclic Jacobi sweep in LDS, pseudo-inverse with
-//      eigenvalues <= eps zeroed (:267-272);
-//   4. Schur complement A' = Arr - Arm Amm^+ Amr, b' = brr - Arm Amm^+ bmm (:275-282), formed as
-//      Arr - Z'Z with Z = diag(sqrt(lambda^+)) V' Amr;
-//   5. A' = V2 diag(S) V2'  ->  linearized_jacobians = diag(sqrt S) V2', linearized_residuals =
-//      diag(1/sqrt S) V2' b' with S thresholded at eps (:284-293), eigenvalues ascending like
-//      Eigen::SelfAdjointEigenSolver.
+//   3. Amm^+ (:267-272).  Default route: when the rank of Amm is proven per window (lambda_min >= 1 / trace(Amm^-1) > eps from the
+//      Cholesky factor Amm = L L'), the pseudo-inverse is the inverse and Arm Amm^-1 Amr = Z'Z with Z = L^-1 Amr.  Otherwise, and
+//      everywhere with TCV_MARG_EIG_MM=1, the reference's route: Amm = V diag(lambda) V' by a parallel cyclic Jacobi sweep in LDS,
+//      eigenvalues <= eps zeroed, Z = diag(sqrt(lambda^+)) V' Amr.  Both routes against the oracle over 32 association streams and
+//      15 full-length replays: profiles/r03_marg_route_decision.txt (statistically indistinguishable);
+//   4. Schur complement A' = Arr - Arm Amm^+ Amr, b' = brr - Arm Amm^+ bmm (:275-282), formed as Arr - Z'Z;
+//   5. A' = V2 diag(S) V2' by a tridiagonal eigen-solver in LDS (Householder, multisection, twisted factorisation, cyclic Jacobi as
+//      the safety net)  ->  linearized_jacobians = diag(sqrt S) V2', linearized_residuals = diag(1/sqrt S) V2' b' with S thresholded
+//      at eps (:284-293), eigenvalues ascending like Eigen::SelfAdjointEigenSolver.
 //
 // Block order (the reference's is unordered_map / address dependent, :176-194): dropped blocks in the
 // order they were added to the problem, then kept blocks in that order.

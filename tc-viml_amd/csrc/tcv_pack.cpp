@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <list>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -769,19 +770,30 @@ int pack_problem_data(const tcv_problem &p, Packed &out, const double *imu_sqrt,
 // structure is serialised into an int key (block sizes / kinds / constness, the block indices of every factor, the prior's block
 // layout, the frame table, layout mode and LDS budget), and a process-wide table maps key -> PlanTemplate.
 namespace {
-struct KeyHash {
-    size_t operator()(const std::vector<int> &k) const {
-        unsigned long long h = 1469598103934665603ull;
-        for (int v : k) { h ^= (unsigned)v; h *= 1099511628211ull; }
-        return (size_t)h;
+// key = the serialised structure with its hash computed once, outside the cache lock
+struct PlanKey {
+    std::vector<int> k;
+    size_t h = 0;
+    void seal() {
+        unsigned long long x = 1469598103934665603ull;
+        for (int v : k) { x ^= (unsigned)v; x *= 1099511628211ull; }
+        h = (size_t)x;
     }
+    bool operator==(const PlanKey &o) const { return h == o.h && k == o.k; }
 };
+struct KeyHash { size_t operator()(const PlanKey &k) const { return k.h; } };
+// LRU: a live estimator / replay produces a new structure almost every frame (tracks start and end), so most entries never hit again;
+// 256 entries hold the structures a bench / streaming loop cycles through (~27 MB of plans at most) and the cold ones fall off the end
+// one by one instead of the whole table being cleared.
+struct CacheEntry { PlanKey key; std::shared_ptr<const PlanTemplate> tmpl; };
 std::mutex g_cache_mu;
-std::unordered_map<std::vector<int>, std::shared_ptr<const PlanTemplate>, KeyHash> g_cache;
+std::list<CacheEntry> g_lru;
+std::unordered_map<PlanKey, std::list<CacheEntry>::iterator, KeyHash> g_cache;
 long long g_hits = 0, g_misses = 0;
-enum { CACHE_MAX_ENTRIES = 2048 };
+enum { CACHE_MAX_ENTRIES = 256 };
 
-void structure_key(const tcv_problem &p, int mode, int chain_lds, std::vector<int> &k) {
+void structure_key(const tcv_problem &p, int mode, int chain_lds, PlanKey &key) {
+    std::vector<int> &k = key.k;
     k.clear();
     k.reserve(16 + 3 * p.blocks.size() + 4 * p.imu.size() + 5 * p.proj.size() + p.line.size() + 64);
     k.push_back(mode); k.push_back(chain_lds); k.push_back((int)p.blocks.size());
@@ -801,6 +813,7 @@ void structure_key(const tcv_problem &p, int mode, int chain_lds, std::vector<in
     k.push_back((int)p.frame_pose.size());
     for (int v : p.frame_pose) k.push_back(v);
     for (int v : p.frame_sb) k.push_back(v);
+    key.seal();
 }
 }  // namespace
 
@@ -814,14 +827,14 @@ void plan_cache_stats(long long *hits, long long *misses, long long *entries) {
 int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int mode, int chain_lds, bool plan_only) {
     static const bool no_cache = getenv("TCV_NO_PLAN_CACHE") != nullptr;
     const int c_lds = (chain_lds >= 6144 && chain_lds <= LDS_DOUBLES) ? (chain_lds & ~1) : chain_lds_doubles();
-    std::vector<int> key;
+    PlanKey key;
     std::shared_ptr<const PlanTemplate> T;
     std::memset(&out.win, 0, sizeof out.win);
     if (!no_cache) {
         structure_key(p, mode, c_lds, key);
         std::lock_guard<std::mutex> g(g_cache_mu);
         auto it = g_cache.find(key);
-        if (it != g_cache.end()) { T = it->second; g_hits++; } else g_misses++;
+        if (it != g_cache.end()) { g_lru.splice(g_lru.begin(), g_lru, it->second); T = it->second->tmpl; g_hits++; } else g_misses++;
     }
     if (T) {
         out.hdr = T->hdr; out.tmpl = T; out.ints.clear();
@@ -836,8 +849,11 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int 
             N->cam_block = out.cam_block; N->cam_loff = out.cam_loff; N->lm_block = out.lm_block; N->proj_order = out.proj_order;
             out.tmpl = N;
             std::lock_guard<std::mutex> g(g_cache_mu);
-            if (g_cache.size() >= CACHE_MAX_ENTRIES) g_cache.clear();      // replays produce a new structure every frame: bounded, not LRU
-            g_cache.emplace(std::move(key), N);
+            if (g_cache.find(key) == g_cache.end()) {      // (another thread may have packed the same structure meanwhile)
+                while (g_cache.size() >= CACHE_MAX_ENTRIES) { g_cache.erase(g_lru.back().key); g_lru.pop_back(); }
+                g_lru.push_front(CacheEntry{key, N});
+                g_cache.emplace(std::move(key), g_lru.begin());
+            }
         }
     }
     if (plan_only) {      // size only: the caller writes the data with pack_problem_data once every window of its batch has an offset

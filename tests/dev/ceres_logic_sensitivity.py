@@ -8,11 +8,11 @@ cost are tabulated next to the SciPy minimum of the same cost function (tests/go
 has the reference built against a real Ceres needs ONE number to falsify the restatement: `summary.iterations.size()`
 (estimator.cpp:1902 prints it) and `summary.final_cost` on the same window.
 
-    python tools/ceres_logic_sensitivity.py [max_iterations]  > profiles/r03_ceres_logic_sensitivity.txt
+    python tests/dev/ceres_logic_sensitivity.py [max_iterations]  > profiles/r03_ceres_logic_sensitivity.txt
 
 CPU only; imports the oracle (test infrastructure), never the product."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in ("oracle", "tests", os.path.join("tests", "golden")):
     sys.path.insert(0, os.path.join(ROOT, p))
 import numpy as np

@@ -92,8 +92,9 @@ def test_chain_and_dense_layouts_agree_on_a_large_batch(gpu):
         worst = sorted((abs(a - b) / b, k) for k, (a, b) in enumerate(zip(fc0, fc1)))[-3:]
         assert worst[-1][0] < 1e-6, (mode, worst, [(dc0[k], dc1[k]) for _, k in worst])
         same = sum(1 for a, b in zip(dc0, dc1) if a == b)
-        assert same >= B - 6, same              # a borderline accept / reject may flip between two roundings of the same system
-        assert sum(1 for a, b in zip(t0, t1) if a == b) >= B - 6
+        print("mode %s: %d of %d dogleg traces differ between the layouts, %d terminations" % (("8 fixed iterations", "to convergence")[mode], B - same, B, sum(1 for a, b in zip(t0, t1) if a != b)))
+        assert same >= B - 1, same              # measured (round 3, MI355X): 0 of 320 differ in either mode; one borderline accept / reject may flip
+        assert sum(1 for a, b in zip(t0, t1) if a == b) >= B - 1
         if mode == 0:
             assert rel(p0, p1) < 1e-6
 

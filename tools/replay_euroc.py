@@ -55,12 +55,12 @@ for st, o in zip(streams, outs):
 frames = sum(r["optimised_frames"] for r in rows)
 res = dict(rank=rank, world=world, line_mode=args.line_mode, line_jacobian="exact" if args.exact_line_jacobian else "reference", window_management="native" if args.native else "python", sequences=rows, optimised_frames=frames, simulate_s=round(t1 - t0, 2), replay_s=round(t2 - t1, 2),
            frames_per_s=round(frames / max(t2 - t1, 1e-9), 1))
-with open(os.path.join(args.out, "replay_euroc_%s%s_rank%d.json" % (args.line_mode, "_exactJ" if args.exact_line_jacobian else "", rank)), "w") as f:
-    json.dump(res, f, indent=1)
 if args.native and args.profile:
     import ctypes as C, tcv
     prof = (C.c_double * 8)()
     tcv.lib().tcv_estimators_profile(prof)
     names = ["preintegrate", "assoc+triangulate+window", "problems", "batch_create", "kernels", "downloads", "apply", "calls"]
     res["native_profile_s"] = {k: round(v, 4) for k, v in zip(names, prof)}
+with open(os.path.join(args.out, "replay_euroc_%s%s_rank%d.json" % (args.line_mode, "_exactJ" if args.exact_line_jacobian else "", rank)), "w") as f:
+    json.dump(res, f, indent=1)
 print(json.dumps(res))
