@@ -60,7 +60,9 @@ typedef struct {
                                           checked at the start of every iteration like Ceres, on the device
                                           clock, per window */
     int fixed_iterations;              /* 1: run exactly max_num_iterations, convergence tests off   */
-    int compute_sqrt_info_on_device;   /* reserved, ignored: imu_factor.h:64 is always evaluated in the kernel, once per solve */
+    int workgroups_per_window;         /* 0 (default): a batch planned for the cooperative small-batch mode (tcv_set_cooperative) runs each
+                                          window on 1 + H workgroups; 1: one workgroup per window whatever the plan (same chunks, same
+                                          additions: bit-identical results -- the A/B switch of the parity tests) */
     int use_mfma;                      /* dense layout only: 1 (default) trailing Cholesky update on v_mfma_f64_16x16x4_f64,
                                           0 FP64 VALU (debug).  The chain layout always uses the matrix cores. */
     int threads_per_window;            /* dense layout only: 256 (default) or 512 threads per workgroup; the chain layout is
@@ -126,6 +128,13 @@ int tcv_set_device(int device);
  * batch has more windows than the device has CUs, otherwise one window per CU with the whole LDS);
  * 1: always the dense 171-dim layout (one window per CU; cross-check / arbitrary graphs).  Read at tcv_batch_create. */
 int tcv_set_solver_variant(int variant);
+/* Cooperative small-batch mode of the chain layout.  The reference runs ONE estimator at 10 Hz (estimator_node.cpp:282-466); a batch
+ * of a handful of windows leaves 250 of 256 CUs idle, so such a batch gives every window a group of 1 + H workgroups: H helpers
+ * evaluate the point / line factors chunk by chunk, gather J'J and eliminate the landmarks while the master evaluates the prior and
+ * the IMU factors; the master folds their exports into the reduced camera system in a fixed order and runs the chain elimination,
+ * the Cholesky factorisation and the dogleg as before.  helpers = -1 (default): automatic (batches with n (1 + H) <= CUs, H from the
+ * factor count of the largest window); 0: off; 1..7: that many helpers when the batch allows it.  Read at tcv_batch_create. */
+int tcv_set_cooperative(int helpers);
 
 /* ---- ceres::Problem surface (estimator.cpp:1679-1886) ---------------------------------------- */
 int tcv_problem_create(tcv_problem **out);
@@ -237,6 +246,9 @@ int tcv_batch_marg_status(tcv_batch *b, int *out, int n);
 int tcv_batch_get_first_step(tcv_batch *b, int window, double *out, int cap, int *len);
 /* number of distinct graph structures (plans) in the batch, their bytes, launch grid and LDS bytes */
 int tcv_batch_plan_stats(tcv_batch *b, int *num_plans, double *plan_bytes, int *grid, int *lds_bytes);
+/* cooperative mode of this batch (tcv_set_cooperative): helper workgroups per window (0: one workgroup per window), window groups
+ * resident at a time, visual chunks of the largest plan */
+int tcv_batch_cooperative(const tcv_batch *b, int *helpers, int *groups, int *chunks);
 /* layout of the fused solver chosen for this batch: 0 chain (speed-biases eliminated block by block), 1 dense; < 0: error */
 int tcv_batch_layout(const tcv_batch *b);
 /* bytes of window input resident in HBM and elapsed milliseconds of the last solve / marginalise

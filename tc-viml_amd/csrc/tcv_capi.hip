@@ -21,6 +21,7 @@
 extern "C" int tcv_launch_solve(const tcv::SolveArgs *args, int grid, int nthreads, size_t lds_bytes, void *stream);
 extern "C" int tcv_solve_scratch_doubles(void);
 static int g_solver_variant = 0;   // 0: chain layout when the graph allows it, 1: always the dense 171-dim layout
+static int g_coop_helpers = -1;    // cooperative mode of small batches: -1 automatic, 0 off, h >= 1: h helper workgroups per window (when the batch allows it)
 extern "C" int tcv_launch_marg(const void *args, int grid, size_t lds_bytes, void *stream);
 
 namespace tcv {
@@ -117,6 +118,11 @@ extern "C" int tcv_device_count(void) {
 extern "C" int tcv_set_solver_variant(int variant) {
     if (variant != 0 && variant != 1) return TCV_ERR_INVALID;
     g_solver_variant = variant;
+    return TCV_OK;
+}
+extern "C" int tcv_set_cooperative(int helpers) {
+    if (helpers < -1 || helpers > COOP_MAX_H) { set_error("set_cooperative: -1 (automatic), 0 (off) or 1..7 helper workgroups per window"); return TCV_ERR_INVALID; }
+    g_coop_helpers = helpers;
     return TCV_OK;
 }
 extern "C" int tcv_set_device(int device) {
@@ -282,7 +288,8 @@ extern "C" int tcv_problem_num_residuals(const tcv_problem *p) {
 extern "C" int tcv_problem_plan_stats(const tcv_problem *p, int *out) {
     if (!p || !out) return TCV_ERR_INVALID;
     Packed pk;
-    const int rc = pack_problem(*p, pk, nullptr, g_solver_variant);
+    const char *ec = getenv("TCV_PLAN_COOP");      // developer / test switch: the plan the cooperative mode would use with that many helpers
+    const int rc = pack_problem(*p, pk, nullptr, g_solver_variant, 0, false, ec ? atoi(ec) : 0);
     if (rc != TCV_OK) return rc;
     const PlanHdr &H = pk.hdr;
     const int v[16] = {H.nc, H.nx, H.npp, H.nland, H.chain ? H.nt_c : H.nt, H.n_vis_chunk, H.n_imu_chunk, H.n_vunit, H.n_vitem, H.n_sunit, H.n_sitem,
@@ -441,6 +448,7 @@ static void batch_free(tcv_batch *b) {
     if (b->ev_order) (void)hipEventDestroy(b->ev_order);
     tcv::dev_free(b->d_win); tcv::dev_free(b->d_plans); tcv::dev_free(b->d_plan_base); tcv::dev_free(b->d_ipool); tcv::dev_free(b->d_dpool);
     tcv::dev_free(b->d_imublk); tcv::dev_free(b->d_spill); tcv::dev_free(b->d_sqrt_out);
+    tcv::dev_free(b->d_coop_ctl); tcv::dev_free(b->d_coop_x); tcv::dev_free(b->d_coop_exp);
     tcv::dev_free(b->d_prof); tcv::dev_free(b->d_state); tcv::dev_free(b->d_delta); tcv::dev_free(b->d_scratch); tcv::dev_free(b->d_summary);
     if (b->ev0) hipEventDestroy(b->ev0);
     if (b->ev1) hipEventDestroy(b->ev1);
@@ -519,13 +527,27 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
     // at the first window that does not
     b->chain = (mode == 0);
     // packing (symbolic elimination, gather programs, data layout) is independent per window: host threads share the work
+    // Cooperative mode (tcv_packed.h COOP_*): a chain-layout batch that leaves most of the chip idle gives every window 1 + H workgroups.
+    // H: one helper per ~96 point / line factors of the largest window, as many as the CUs allow.  TCV_COOP_H overrides (0: off).
+    int coop_h = 0;
+    if (mode == 0) {
+        int want = g_coop_helpers;
+        if (const char *eh = getenv("TCV_COOP_H")) want = atoi(eh);
+        size_t fmax = 0;
+        for (int w = 0; w < n; w++) fmax = std::max(fmax, problems[w]->proj.size() + problems[w]->line.size());
+        if (want < 0) want = fmax >= 96 ? std::min<int>(COOP_MAX_H, std::max<int>(2, (int)((fmax + 95) / 96))) : 0;
+        want = std::min(want, (int)COOP_MAX_H);
+        while (want > 0 && (long long)n * (1 + want) > n_cu) want--;
+        if (want == 1 && g_coop_helpers < 0 && !getenv("TCV_COOP_H")) want = 0;      // a single helper is not worth the hand-offs
+        coop_h = want;
+    }
     auto pack_all = [&](int md, std::string &msg) -> int {
         const int nth = std::max(1, std::min({n, 16, (int)std::thread::hardware_concurrency()}));
         std::vector<int> rcs(n, TCV_OK);
         std::vector<std::string> msgs(nth);
         auto work = [&](int t) {
             for (int w = t; w < n; w += nth) {
-                rcs[w] = pack_problem(*problems[w], b->packed[w], nullptr, md, chain_lds, true);      // plan + data size
+                rcs[w] = pack_problem(*problems[w], b->packed[w], nullptr, md, chain_lds, true, md == 0 ? coop_h : 0);      // plan + data size
                 if (rcs[w] != TCV_OK && msgs[t].empty()) msgs[t] = tcv_last_error();      // the message is thread-local
             }
         };
@@ -541,10 +563,19 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
     {
         std::string msg;
         int rc = pack_all(mode, msg);
+        if (rc == TCV_OK && mode == 0 && coop_h > 0)
+            for (int w = 0; w < n; w++) {      // what the cooperative master assumes: the prior staged in one piece, one IMU chunk
+                const PlanHdr &H = b->packed[w].hdr;
+                if (!H.chain || H.n_imu_chunk > 1 || (H.prior_n > 0 && H.prior_n * H.prior_n + 2 * H.prior_n > H.c_stage_cap)) {
+                    coop_h = 0;
+                    rc = pack_all(mode, msg);
+                    break;
+                }
+            }
         if (rc == TCV_OK && mode == 0)
             for (int w = 0; w < n; w++)
                 if (!b->packed[w].hdr.chain) {      // a window is not chain-eligible: the whole batch uses the dense layout
-                    mode = 1; b->chain = false;
+                    mode = 1; b->chain = false; coop_h = 0;
                     rc = pack_all(mode, msg);
                     break;
                 }
@@ -614,6 +645,17 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
     b->lds_bytes = max_lds;
     b->grid = std::min(n, n_cu * (b->chain ? 2 : 1));
     if (const char *eg = getenv("TCV_GRID")) { const int g = atoi(eg); if (g > 0) b->grid = std::min(n, g); }      // tuning experiments
+    b->slots = b->grid;
+    if (b->chain && coop_h > 0) {
+        b->coop_h = coop_h;
+        b->coop_groups = std::min(n, n_cu / (1 + coop_h));
+        b->slots = b->coop_groups;
+        b->grid = (1 + coop_h) * ((b->coop_groups + 7) & ~7);
+        b->lds_bytes = (size_t)LDS_DOUBLES * 8;
+        int te_max = 0;
+        for (auto &H : b->plans) { b->coop_exp_chunks = std::max(b->coop_exp_chunks, H.n_vis_chunk); te_max = std::max(te_max, (H.nt_c * (H.nt_c + 1) / 2) << 8); }
+        b->coop_exp_stride = 2 * te_max + COOP_EXP_VEC;
+    }
     const int scr = tcv_solve_scratch_doubles() + b->hcl_cap;
 #define UP(dst, src, T, cnt)                                                                          \
     do {                                                                                              \
@@ -633,16 +675,21 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
     h_dpool = nullptr;
     UP(b->d_state, (double *)nullptr, double, (size_t)n * b->state_stride);
     UP(b->d_delta, (double *)nullptr, double, (size_t)n * b->delta_stride);
-    UP(b->d_scratch, (double *)nullptr, double, (size_t)b->grid * scr);
+    UP(b->d_scratch, (double *)nullptr, double, (size_t)b->slots * scr);
     UP(b->d_summary, (DevSummary *)nullptr, DevSummary, (size_t)n);
-    UP(b->d_prof, (double *)nullptr, double, (size_t)32 * b->grid);
+    UP(b->d_prof, (double *)nullptr, double, (size_t)32 * b->slots);
     if (b->chain) {
-        UP(b->d_imublk, (double *)nullptr, double, (size_t)b->grid * 16 * IMU_BLK);
-        UP(b->d_spill, (double *)nullptr, double, (size_t)b->grid * b->spill_stride);
+        UP(b->d_imublk, (double *)nullptr, double, (size_t)b->slots * 16 * IMU_BLK);
+        UP(b->d_spill, (double *)nullptr, double, (size_t)b->slots * b->spill_stride);
     }
-    hipMemset(b->d_prof, 0, sizeof(double) * 32 * b->grid);
+    if (b->coop_h > 0) {
+        UP(b->d_coop_ctl, (int *)nullptr, int, (size_t)b->coop_groups * COOP_CTL_INTS);
+        UP(b->d_coop_x, (double *)nullptr, double, (size_t)b->coop_groups * COOP_X_DOUBLES);
+        UP(b->d_coop_exp, (double *)nullptr, double, (size_t)b->coop_groups * b->coop_exp_chunks * b->coop_exp_stride);
+    }
+    hipMemset(b->d_prof, 0, sizeof(double) * 32 * b->slots);
 #undef UP
-    hipMemset(b->d_scratch, 0, sizeof(double) * (size_t)b->grid * scr);
+    hipMemset(b->d_scratch, 0, sizeof(double) * (size_t)b->slots * scr);
     hipMemset(b->d_summary, 0, sizeof(DevSummary) * (size_t)n);
     hipMemset(b->d_delta, 0, sizeof(double) * (size_t)n * b->delta_stride);
     e0 = hipEventCreate(&b->ev0);
@@ -677,7 +724,7 @@ extern "C" void tcv_solver_options_default(tcv_solver_options *o) {
     o->max_num_iterations = 8;
     o->max_solver_time_in_seconds = 0.0;
     o->fixed_iterations = 0;
-    o->compute_sqrt_info_on_device = 1;
+    o->workgroups_per_window = 0;
     o->use_mfma = 1;
     o->threads_per_window = 256;
     o->record_first_step = 0;
@@ -708,6 +755,17 @@ extern "C" int tcv_batch_solve(tcv_batch *b, const tcv_solver_options *o, void *
     a.chain = b->chain ? 1 : 0; a.imublk = b->d_imublk; a.spill = b->d_spill; a.spill_stride = b->spill_stride;
     a.max_ticks = 0;
     a.sqrt_out = b->d_sqrt_out;
+    // cooperative plans also run on the single-workgroup kernel (workgroups_per_window = 1): same chunks, same additions, same bits
+    const bool coop = b->coop_h > 0 && o->workgroups_per_window != 1;
+    int grid = b->grid;
+    if (coop) {
+        a.coop_h = b->coop_h; a.coop_groups = b->coop_groups; a.coop_exp_chunks = b->coop_exp_chunks; a.coop_exp_stride = b->coop_exp_stride;
+        a.coop_ctl = b->d_coop_ctl; a.coop_x = b->d_coop_x; a.coop_exp = b->d_coop_exp;
+        int dev = 0, khz = 0;
+        hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;
+        a.coop_timeout = (long long)khz * 2000;      // 2 s
+    } else if (b->coop_h > 0) grid = b->slots;
     b->sqrt_out_valid = b->d_sqrt_out != nullptr;
     if (const char *sk = getenv("TCV_ABLATE_SKIP")) a.pad2 = (int)(unsigned)strtoul(sk, nullptr, 0);      // -DTCV_ABLATE builds only read it
     if (o->max_solver_time_in_seconds > 0.0 && !o->fixed_iterations) {
@@ -719,8 +777,9 @@ extern "C" int tcv_batch_solve(tcv_batch *b, const tcv_solver_options *o, void *
     }
     hipStream_t st = (hipStream_t)hip_stream;
     if (int rc = tcv_batch_enter_stream(b, hip_stream)) return rc;
+    if (coop) HIPCHK(hipMemsetAsync(b->d_coop_ctl, 0, sizeof(int) * (size_t)b->coop_groups * COOP_CTL_INTS, st));
     HIPCHK(hipEventRecord(b->ev0, st));
-    const int rc = tcv_launch_solve(&a, b->grid, (!b->chain && o->threads_per_window == 512) ? 512 : 256, b->lds_bytes, hip_stream);
+    const int rc = tcv_launch_solve(&a, grid, (!b->chain && o->threads_per_window == 512) ? 512 : 256, b->lds_bytes, hip_stream);
     if (rc != 0) return hip_fail((hipError_t)rc, "solve kernel launch");
     HIPCHK(hipEventRecord(b->ev1, st));
     b->solved = true;
@@ -818,10 +877,29 @@ extern "C" int tcv_batch_stats(tcv_batch *b, double *input_bytes, double *solve_
 // TCV_PROFILE builds only: copies (and clears) the 32 per-phase cycle accumulators of the solve kernel
 extern "C" int tcv_batch_profile(tcv_batch *b, double *out32) {
     if (!b || !out32) return TCV_ERR_INVALID;
-    std::vector<double> h((size_t)32 * b->grid);
+    std::vector<double> h((size_t)32 * b->slots);
     HIPCHK(hipMemcpy(h.data(), b->d_prof, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
-    for (int i = 0; i < 32; i++) { out32[i] = 0; for (int g = 0; g < b->grid; g++) out32[i] += h[(size_t)g * 32 + i]; }
+    for (int i = 0; i < 32; i++) { out32[i] = 0; for (int g = 0; g < b->slots; g++) out32[i] += h[(size_t)g * 32 + i]; }
     HIPCHK(hipMemset(b->d_prof, 0, sizeof(double) * h.size()));
+    return TCV_OK;
+}
+extern "C" int tcv_batch_cooperative(const tcv_batch *b, int *helpers, int *groups, int *chunks) {
+    if (!b) return TCV_ERR_INVALID;
+    if (helpers) *helpers = b->coop_h;
+    if (groups) *groups = b->coop_h > 0 ? b->coop_groups : 0;
+    if (chunks) { int c = 0; for (auto &H : b->plans) c = std::max(c, H.n_vis_chunk); *chunks = c; }
+    return TCV_OK;
+}
+// developer diagnostics: the control block of group `group` (COOP_CTL_INTS ints: request / served sequence numbers, abort flag, progress
+// marks), copied on a private stream so that it can be read while a launch is still running
+extern "C" int tcv_batch_debug_coop(tcv_batch *b, int group, int *out64) {
+    if (!b || !out64 || b->coop_h <= 0 || group < 0 || group >= b->coop_groups) { set_error("debug_coop: no cooperative plan / bad group"); return TCV_ERR_INVALID; }
+    hipStream_t st = nullptr;
+    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    hipError_t e = hipMemcpyAsync(out64, b->d_coop_ctl + (size_t)group * COOP_CTL_INTS, sizeof(int) * COOP_CTL_INTS, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipStreamDestroy(st);
+    if (e != hipSuccess) return hip_fail(e, "debug_coop copy");
     return TCV_OK;
 }
 extern "C" int tcv_batch_layout(const tcv_batch *b) { return b ? (b->chain ? 0 : 1) : TCV_ERR_INVALID; }

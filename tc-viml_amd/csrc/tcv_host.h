@@ -107,6 +107,11 @@ struct tcv_batch {
     bool sqrt_out_valid = false;          // the last solve wrote it (device-computed sqrt_info)
     int spill_stride = 0;
     int hcl_cap = 0;                      // doubles of the landmark/camera coupling store per workgroup (largest window of the batch)
+    // cooperative mode (tcv_packed.h COOP_*): helpers per window group (0: off), groups, scratch slots (= grid without it)
+    int coop_h = 0, coop_groups = 0, slots = 0;
+    int coop_exp_chunks = 0, coop_exp_stride = 0;
+    int *d_coop_ctl = nullptr;
+    double *d_coop_x = nullptr, *d_coop_exp = nullptr;
     // marginalisation
     void *marg = nullptr;                 // tcv_marg.hip state
     void (*marg_free)(tcv_batch *) = nullptr;
@@ -137,7 +142,8 @@ void set_error(const std::string &s);
 // chain_lds: LDS doubles of a chain-layout workgroup (0: chain_lds_doubles(), half a CU's LDS so that two workgroups share a CU)
 // plan_only: plan + the size of the data half (out.win.n_doubles); the data is then written by pack_problem_data into a buffer of the
 // caller (one upload buffer per batch)
-int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int mode = 0, int chain_lds = 0, bool plan_only = false);
+// coop_chunks > 0: plan for the cooperative (small-batch) kernel with at least that many visual chunks (tcv_packed.h COOP_*)
+int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int mode = 0, int chain_lds = 0, bool plan_only = false, int coop_chunks = 0);
 int pack_problem_data(const tcv_problem &p, Packed &out, const double *imu_sqrt, double *dst);
 // pinned host staging buffers for uploads / downloads, recycled through a small per-process pool (hipHostMalloc costs milliseconds)
 void *host_staging_acquire(size_t bytes);

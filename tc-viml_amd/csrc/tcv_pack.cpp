@@ -125,7 +125,9 @@ void add_pairs(DestList &dl, const std::vector<Col> &cols, MakeItem mk, int rcol
 }  // namespace
 
 // structural half: plan header, int pool and the host-side maps (everything that does not depend on the VALUES of the window)
-static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds) {
+// coop_chunks > 0: plan for the cooperative kernel (tcv_packed.h COOP_*): at least that many visual chunks of at most 256 point factors
+// each (one helper workgroup per chunk, one lane per factor), and an LDS budget that leaves room for a helper's second tile set
+static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds, int coop_chunks) {
     const int nb = (int)p.blocks.size();
     // ---- classify blocks: landmarks = size-1 Euclidean blocks used only as 4th block of projection factors
     std::vector<int> use_lm(nb, 0), use_other(nb, 0);
@@ -254,7 +256,7 @@ static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds)
     }
     const int nt_c = (npp + 1 + 15) / 16, ctiles = nt_c * (nt_c + 1) / 2;
     const int c_vec = 2 * nxl + 4 * 176 + 64 + 112;
-    const int c_lds = (chain_lds >= 6144 && chain_lds <= LDS_DOUBLES) ? (chain_lds & ~1) : chain_lds_doubles();
+    const int c_lds = coop_chunks > 0 ? (LDS_DOUBLES - ctiles * 256 - 8) : ((chain_lds >= 6144 && chain_lds <= LDS_DOUBLES) ? (chain_lds & ~1) : chain_lds_doubles());
     const int c_pool = c_lds - ctiles * 256 - c_vec;
     if (use_chain && (c_pool < chain_pool_doubles((int)chain.size(), nt_c) || c_pool < IMU_REC)) use_chain = false;
 
@@ -465,6 +467,7 @@ static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds)
         const int kmax = std::max(1, std::min(L, 48));
         int k = std::max(1, (nproj * prec + nline * LINE_REC + c_pool - 1) / std::max(1, c_pool));
         if (const char *ek = getenv("TCV_VIS_CHUNKS")) k = std::max(k, atoi(ek));      // tuning experiments
+        k = std::max(k, std::min(coop_chunks, kmax));
         for (; k <= kmax && !found;) {
             // point factors: an even split, except that a boundary a few factors above a multiple of 64 is pulled down to it -- one lane
             // evaluates one factor, so 64 + 68 + 68 factors cost five wavefront passes of the evaluation and 64 + 64 + 72 cost four.  Line
@@ -482,6 +485,11 @@ static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds)
                 cand.push_back(cur);
             }
             int ms = 0, ma = 0;
+            if (coop_chunks > 0 && k < kmax) {      // one lane per point factor: a cooperative chunk holds at most one pass of a 256-thread helper
+                bool wide = false;
+                for (auto &c : cand) wide = wide || c.pn > 256;
+                if (wide) { k++; continue; }
+            }
             if (emit_all(cand, -1, -1, vprog, sprog, vchunk_tab, ms, ma) != TCV_OK) { k++; continue; }
             ma = (ma + 1) & ~1;
             if (getenv("TCV_DEBUG_PACK")) fprintf(stderr, "[pack] k %d ms %d ma %d pool %d\n", k, ms, ma, c_pool);
@@ -792,11 +800,11 @@ std::unordered_map<PlanKey, std::list<CacheEntry>::iterator, KeyHash> g_cache;
 long long g_hits = 0, g_misses = 0;
 enum { CACHE_MAX_ENTRIES = 256 };
 
-void structure_key(const tcv_problem &p, int mode, int chain_lds, PlanKey &key) {
+void structure_key(const tcv_problem &p, int mode, int chain_lds, int coop_chunks, PlanKey &key) {
     std::vector<int> &k = key.k;
     k.clear();
     k.reserve(16 + 3 * p.blocks.size() + 4 * p.imu.size() + 5 * p.proj.size() + p.line.size() + 64);
-    k.push_back(mode); k.push_back(chain_lds); k.push_back((int)p.blocks.size());
+    k.push_back(mode); k.push_back(chain_lds); k.push_back(coop_chunks); k.push_back((int)p.blocks.size());
     for (auto &b : p.blocks) k.push_back(b.size | (b.kind << 8) | ((int)b.constant << 16));
     k.push_back((int)p.imu.size());
     for (auto &f : p.imu) for (int j = 0; j < 4; j++) k.push_back(f.b[j]);
@@ -824,14 +832,14 @@ void plan_cache_stats(long long *hits, long long *misses, long long *entries) {
     if (entries) *entries = (long long)g_cache.size();
 }
 
-int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int mode, int chain_lds, bool plan_only) {
+int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int mode, int chain_lds, bool plan_only, int coop_chunks) {
     static const bool no_cache = getenv("TCV_NO_PLAN_CACHE") != nullptr;
     const int c_lds = (chain_lds >= 6144 && chain_lds <= LDS_DOUBLES) ? (chain_lds & ~1) : chain_lds_doubles();
     PlanKey key;
     std::shared_ptr<const PlanTemplate> T;
     std::memset(&out.win, 0, sizeof out.win);
     if (!no_cache) {
-        structure_key(p, mode, c_lds, key);
+        structure_key(p, mode, c_lds, coop_chunks, key);
         std::lock_guard<std::mutex> g(g_cache_mu);
         auto it = g_cache.find(key);
         if (it != g_cache.end()) { g_lru.splice(g_lru.begin(), g_lru, it->second); T = it->second->tmpl; g_hits++; } else g_misses++;
@@ -841,7 +849,7 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int 
         out.cam_block = T->cam_block; out.cam_loff = T->cam_loff; out.lm_block = T->lm_block; out.proj_order = T->proj_order;
     } else {
         out.tmpl.reset();
-        const int rc = pack_plan(p, out, mode, c_lds);
+        const int rc = pack_plan(p, out, mode, c_lds, coop_chunks);
         if (rc != TCV_OK) return rc;
         if (!no_cache) {
             auto N = std::make_shared<PlanTemplate>();

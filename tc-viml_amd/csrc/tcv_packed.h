@@ -128,6 +128,9 @@ struct WinHdr {
     int pad1;
 };
 
+// per-workgroup global scratch layout (doubles)
+enum { SCR_NL = 1280 };  // capacity of an nl-sized vector (nc + nland)
+
 // per-window result block written by the solver
 struct DevSummary {
     int num_iterations, termination;
@@ -157,6 +160,31 @@ struct SolveArgs {
     long long max_ticks;          // max_solver_time_in_seconds in ticks of the constant-rate device clock (wall_clock64); 0: no limit
     double *sqrt_out;             // optional, per window: 225 doubles -- the sqrt_info of IMU factor WinHdr::sqrt_export as computed by this solve
                                   // (the marginalisation of the same batch reads it instead of factorising the covariance again)
+    // cooperative (small-batch) mode, see COOP_* below: 0 helpers = off
+    int coop_h, coop_groups;      // helper workgroups per window group, number of groups (persistent: group g owns windows g, g + groups, ...)
+    int coop_exp_chunks, coop_exp_stride;   // per group: chunk slots of the export area and doubles per slot
+    int *coop_ctl;                // per group COOP_CTL_INTS ints
+    double *coop_x;               // per group COOP_X_DOUBLES: the state the master hands to its helpers (+ mu)
+    double *coop_exp;             // per group coop_exp_chunks x coop_exp_stride doubles
+    long long coop_timeout;       // ticks of the constant-rate device clock a workgroup waits for its partners before it gives up (status -9)
+};
+
+// ---- cooperative mode (tcv_solve.hip, solve_kernel<.., COOP = true>) ---------------------------------------------------------------
+// A batch that leaves most of the chip idle (a per-sequence replay, a single estimator: BASELINE configs[3] / [4]) gives every window a
+// GROUP of 1 + H workgroups on 1 + H CUs.  The MASTER runs the trust-region loop, the chain elimination, the Cholesky factorisation
+// and the dogleg exactly as the single-workgroup kernel does; per linearisation it publishes the state, and HELPER h evaluates the
+// point / line factors of visual chunks h, h + H, ... , gathers their J'J / J'r, eliminates the chunk's landmarks and exports, per
+// chunk, [gathered pose tiles | minus the Schur update of the pose tiles | gradient | rhs / diagonal corrections | per-thread costs]
+// to HBM / L2, while the master evaluates the prior and the IMU factors.  The master then folds the chunk exports into its tiles in
+// chunk order -- the additions the single-workgroup kernel performs, in its order: bit-identical results for the same chunking --
+// scatters the IMU blocks and goes on.  Hand-offs are release / acquire flags at agent scope; every wait is bounded by a timeout.
+enum {
+    COOP_MAX_H = 7,
+    COOP_CTL_INTS = 64,           // [0] sequence number of the master's request, [1] command, [2] window, [3] abort; [8 + h] sequence number helper h has served
+    COOP_CTL_SEQ = 0, COOP_CTL_CMD = 1, COOP_CTL_WIN = 2, COOP_CTL_ABORT = 3, COOP_CTL_DONE = 8,
+    COOP_CMD_FIRST = 1, COOP_CMD_ASSEMBLE = 2, COOP_CMD_EXIT = 4,
+    COOP_X_DOUBLES = SCR_NL + 8,  // x (nx + nland) | mu at SCR_NL
+    COOP_EXP_VEC = 176 + 176 + 256 + 256      // behind the two tile sets of a chunk export: gradient | rc, sd | point costs | line costs (one per thread)
 };
 
 // chain step record (CH_STRIDE ints per step, copied into LDS by the kernel): a header, two ints per "front row" and a byte map from
@@ -183,7 +211,5 @@ enum { CH_W = 9, CH_MAXROWS = 96, CH_COLROW = CH_INTS + 2 * CH_MAXROWS, CH_STRID
 enum { CH_LT = 164, CH_LN = 82, CH_TA = 164 };
 inline int chain_pool_doubles(int n_e, int nt_c) { return 2 * CH_W * 16 * nt_c + n_e * CH_LT + CH_TA + (n_e * CH_STRIDE + 1) / 2 + 8; }
 
-// per-workgroup global scratch layout (doubles)
-enum { SCR_NL = 1280 };  // capacity of an nl-sized vector (nc + nland)
 
 }  // namespace tcv

@@ -83,6 +83,11 @@ struct Ctx {
     int ntiles, stage_cap;
     int tid;
     unsigned skip;   // TCV_ABLATE builds
+    // cooperative mode (tcv_packed.h COOP_*): the group's control block, state hand-off and chunk exports; helpers per group
+    gbl_i *cx_ctl;
+    gbl_d *cx_x, *cx_exp;
+    int cx_h, cx_exp_stride, cx_seq;
+    long long cx_timeout;
 };
 
 // Every pointer and size in Ctx is the same for all lanes of the workgroup, but the phase functions are not inlined (their register
@@ -149,6 +154,9 @@ __device__ __forceinline__ Ctx<NT> uniform_ctx(const Ctx<NT> &R) {
     C.ntiles = __builtin_amdgcn_readfirstlane(R.ntiles); C.stage_cap = __builtin_amdgcn_readfirstlane(R.stage_cap);
     C.tid = R.tid;
     C.skip = __builtin_amdgcn_readfirstlane(R.skip);
+    C.cx_ctl = (gbl_i *)uni_ptr((gbl_d *)R.cx_ctl); C.cx_x = uni_ptr(R.cx_x); C.cx_exp = uni_ptr(R.cx_exp);
+    C.cx_h = __builtin_amdgcn_readfirstlane(R.cx_h); C.cx_exp_stride = __builtin_amdgcn_readfirstlane(R.cx_exp_stride);
+    C.cx_seq = __builtin_amdgcn_readfirstlane(R.cx_seq); C.cx_timeout = R.cx_timeout;
     return C;
 }
 #ifdef TCV_PROFILE
@@ -338,37 +346,23 @@ __device__ __forceinline__ void copy_prog(lds_i *dst, cst_i *src, int n, int tid
 }
 
 
-// ---- linearise at x: cost, and (if assemble) S~ = Hcc - sum_l Hcl Hcl'/kappa_l in the tiles --------
-// kappa_l = hll + mu * clamp(s_l^2 hll) / s_l^2 is the landmark pivot of the Jacobi-scaled,
-// mu-regularised system expressed in unscaled units (DoglegStrategy + SchurEliminator restated).
+// ---- one visual chunk (point + line factors whose records fit the LDS staging area together), first half: evaluation into the staging
+// records and the destination-driven gather of J'J / J'r / the landmark couplings.  cost_pt / cost_ln take the chunk's robustified
+// costs of this thread's point and line factor (the single-workgroup kernel passes its one accumulator for both).
 template <int NT, bool CHAIN>
-__device__ __noinline__ double linearize(Ctx<NT> &Cr, const lds_d *x, bool first, bool assemble, double mu) {
-    Ctx<NT> C = uniform_ctx<NT>(Cr);
+__device__ __forceinline__ void vis_part1(Ctx<NT> &C, const lds_d *x, int ch, bool assemble, double &cost_pt, double &cost_ln) {
     cst_plan &P = *C.P;
     const int tid = C.tid;
     cst_i *ip = C.ip;
     cst_d *dp = C.dp;
-    const int nc = P.nc, L = P.nland, nx = P.nx;
+    const int nx = P.nx;
     cst_d *misc = dp + C.W->d_misc;
-    const double G3[3] = {misc[0], misc[1], misc[2]};
     const double proj_sqrt = misc[3], proj_loss = misc[4], line_loss = misc[5];
     const bool line_exact = misc[8] != 0.0;
-    const int pp_elems = CHAIN ? (C.ntiles << 8) : ((P.ntp * (P.ntp + 1) / 2) << 8);
-    // ProjectionTdFactor windows (dense layout only): wider point records, see tcv_packed.h
     const bool with_td = !CHAIN && (P.flags & 1);
     const int prec = with_td ? (int)PROJ_TD_REC : (int)PROJ_REC, pstr = with_td ? (int)PROJ_TD_STRIDE : (int)PROJ_STRIDE;
-    double cost_acc = 0.0;
-
-    if (assemble) {
-        zero_lds<NT>(C.tiles, pp_elems, tid);
-        for (int i = tid; i < nc; i += NT) C.gcam[i] = 0.0;
-        for (int i = tid; i < 176; i += NT) C.rc[i] = 0.0;      // rc | sd
-        if (CHAIN) for (int i = tid; i < 112; i += NT) C.hd[i] = 0.0;
-    }
     cst_i *blk = ip + P.o_blk;
-    TCV_MARK(C, PH_ZERO);
-    // ---------------- point + line factors, chunk by chunk -------------------------------------------
-    for (int ch = 0; ch < P.n_vis_chunk; ch++) {
+    {
         cst_i *vc = ip + P.o_vchunk + ch * 16;
         const int pb = vc[0], pn = vc[1], lb = vc[2], ln = vc[3], voff = vc[4], vnu = vc[5], vnw = vc[6], vni = vc[7];
         const int lmb = vc[8], lmn = vc[9], ebase = vc[10], esize = vc[11], soff = vc[12], snu = vc[13], snw = vc[14], sni = vc[15];
@@ -394,7 +388,7 @@ __device__ __noinline__ double linearize(Ctx<NT> &Cr, const lds_d *x, bool first
 #pragma unroll
                 for (int i = 0; i < 8; i++) aux[i] = dp[C.W->d_proj + (pb + f) * 14 + 6 + i];
                 proj_td_eval(CGEN(xi), CGEN(xj), CGEN(xe), lam, tdv, pts, aux, proj_sqrt, misc[6], misc[7], r, assemble ? Jl : nullptr, 20);
-                cost_acc += loss_correct2(r, assemble ? Jl : nullptr, 20, 20, proj_loss);
+                cost_pt += loss_correct2(r, assemble ? Jl : nullptr, 20, 20, proj_loss);
                 if (assemble) {
 #pragma unroll
                     for (int row = 0; row < 2; row++) {
@@ -413,7 +407,7 @@ __device__ __noinline__ double linearize(Ctx<NT> &Cr, const lds_d *x, bool first
 #pragma unroll
             for (int i = 0; i < 6; i++) pts[i] = dp[C.W->d_proj + (pb + f) * 6 + i];
             proj_eval(CGEN(xi), CGEN(xj), CGEN(xe), lam, pts, proj_sqrt, r, J, PROJ_STRIDE);
-            cost_acc += loss_correct2(r, J, 19, PROJ_STRIDE, proj_loss);
+            cost_pt += loss_correct2(r, J, 19, PROJ_STRIDE, proj_loss);
             if (assemble) { rec[19] = r[0]; rec[PROJ_STRIDE + 19] = r[1]; }
         }
         // the line factors of the chunk run on the third wavefront while the first two evaluate the point factors; their costs go through
@@ -434,20 +428,20 @@ __device__ __noinline__ double linearize(Ctx<NT> &Cr, const lds_d *x, bool first
             for (int i = 0; i < 21; i++) lc[i] = dp[C.W->d_linec + i];
             line_eval(CGEN(xp), ld9, lc, lc + 9, lc + 18, r, J, LINE_STRIDE, line_exact);
             const double lcost = loss_correct2(r, J, 6, LINE_STRIDE, line_loss);
-            if (lines_aside) C.red[f] = lcost; else cost_acc += lcost;
+            if (lines_aside) C.red[f] = lcost; else cost_ln += lcost;
             if (assemble) { rec[6] = r[0]; rec[LINE_STRIDE + 6] = r[1]; }
         }
         }
         if (!assemble) {
             if (ABL(C, AB_VIS_EVAL) && NT >= 192 && ln <= 40 && pn <= 128 && ln > 0) {
                 __syncthreads();
-                if (tid < ln) cost_acc += C.red[tid];
+                if (tid < ln) cost_ln += C.red[tid];
                 __syncthreads();
             }
-            TCV_MARK(C, PH_VIS_EVAL); continue;
+            TCV_MARK(C, PH_VIS_EVAL); return;
         }
         __syncthreads();
-        if (ABL(C, AB_VIS_EVAL) && NT >= 192 && ln <= 40 && pn <= 128 && tid < ln) cost_acc += C.red[tid];
+        if (ABL(C, AB_VIS_EVAL) && NT >= 192 && ln <= 40 && pn <= 128 && tid < ln) cost_ln += C.red[tid];
         TCV_MARK(C, PH_VIS_EVAL);
         // gather J'J / J'r / landmark couplings: wave units (long item lists) first, then one unit per thread
         if (ABL(C, AB_VIS_GATHER)) {
@@ -483,6 +477,20 @@ __device__ __noinline__ double linearize(Ctx<NT> &Cr, const lds_d *x, bool first
         }
         __syncthreads();
         TCV_MARK(C, PH_VIS_GATHER);
+    }
+}
+
+// ---- second half: the chunk's landmark pivots and their Schur complement on the pose tiles (tiles -= ..., sd / rc += ...)
+template <int NT, bool CHAIN>
+__device__ __forceinline__ void vis_part2(Ctx<NT> &C, int ch, bool first, double mu) {
+    cst_plan &P = *C.P;
+    const int tid = C.tid;
+    cst_i *ip = C.ip;
+    const int nc = P.nc;
+    {
+        cst_i *vc = ip + P.o_vchunk + ch * 16;
+        const int lmb = vc[8], lmn = vc[9], ebase = vc[10], esize = vc[11], soff = vc[12], snu = vc[13], snw = vc[14], sni = vc[15];
+        lds_d *hcl = C.area, *hll = C.area + esize, *gl = hll + lmn;
         // landmark pivots of this chunk; keep copies for the Cauchy point and the back-substitution.  The staging area
         // is dead now: the Schur program moves in.
         {
@@ -538,6 +546,272 @@ __device__ __noinline__ double linearize(Ctx<NT> &Cr, const lds_d *x, bool first
         }
         __syncthreads();
         TCV_MARK(C, PH_SCHUR);
+    }
+}
+
+// ---- IMU factors of one chunk, first half: raw residual / Jacobian (lanes = factors, waves 0..3 = the four parts of imu_raw_part), whitening
+// J = sqrt_info * J_raw on the matrix cores (one wavefront per factor), cost of this thread's factor
+template <int NT, bool CHAIN>
+__device__ __forceinline__ void imu_part1(Ctx<NT> &C, const lds_d *x, int ch, bool assemble, double &cost_imu) {
+    cst_plan &P = *C.P;
+    const int tid = C.tid;
+    cst_i *ip = C.ip;
+    cst_d *dp = C.dp;
+    cst_i *blk = ip + P.o_blk;
+    (void)dp; (void)blk;
+    {
+        cst_i *ic = ip + P.o_ichunk + ch * 4;
+        const int fb = ic[0], fn = ic[1], ncolor = ic[2];
+        const unsigned colorbits = (unsigned)ic[3];
+        lds_d *recs = CHAIN ? C.stage : C.area;      // chain mode: the whole LDS pool holds the records
+        const int lane = tid & 63, wave = tid >> 6;
+        constexpr int NW = NT / 64;
+        (void)ncolor; (void)colorbits; (void)NW; (void)lane; (void)wave; (void)fb;
+        cst_d *misc = dp + C.W->d_misc;
+        const double G3[3] = {misc[0], misc[1], misc[2]};
+        if (wave < 4 && lane < fn && ABL(C, AB_IMU_RAW)) {
+            cst_i *b = ip + P.o_imu + (fb + lane) * 4;
+            lds_d *rec = recs + lane * IMU_REC;
+            double cst[62];
+#pragma unroll
+            for (int i = 0; i < 62; i++) cst[i] = dp[C.W->d_imu + (fb + lane) * IMU_CONST + i];
+            imu_raw_part(wave, CGEN(x + blk[b[0] * 4 + 1]), CGEN(x + blk[b[1] * 4 + 1]), CGEN(x + blk[b[2] * 4 + 1]),
+                         CGEN(x + blk[b[3] * 4 + 1]), cst, G3, GEN(rec), IMU_STRIDE_J, assemble);
+        }
+        __syncthreads();
+        TCV_MARK(C, PH_IMU_RAW);
+        if (ABL(C, AB_IMU_WHITEN)) {   // whiten: T = S * [J_raw | r_raw]  (S upper triangular 15 x 15, zero padded to 16 x 16)
+            const int i16 = lane & 15, k4 = lane >> 4;
+            for (int f = wave; f < fn; f += NW) {
+                lds_d *rec = recs + f * IMU_REC;
+                const gbl_d *S = C.g_sqrt + (fb + f) * 225;
+                double sa[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) { const int k = 4 * kk + k4; const double t = S[min(i16, 14) * 15 + min(k, 14)]; sa[kk] = (i16 < 15 && k < 15) ? t : 0.0; }
+                for (int ct = assemble ? 0 : 1; ct < 2; ct++) {
+                    const int col = 16 * ct + i16;
+                    double bb[4];
+#pragma unroll
+                    for (int kk = 0; kk < 4; kk++) { const int k = 4 * kk + k4; const double t = rec[min(k, 14) * IMU_STRIDE_J + min(col, 30)]; bb[kk] = (k < 15 && col < 31) ? t : 0.0; }
+                    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[kk], bb[kk], acc, 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { const int row = k4 + 4 * i; if (row < 15 && col < 31) rec[row * IMU_STRIDE_J + col] = acc[i]; }
+                }
+            }
+        }
+        __syncthreads();
+        TCV_MARK(C, PH_IMU_WHITEN);
+        if (tid < fn) {
+            const lds_d *rec = recs + tid * IMU_REC + 30;
+            double s = 0;
+#pragma unroll
+            for (int r = 0; r < 15; r++) s += rec[r * IMU_STRIDE_J] * rec[r * IMU_STRIDE_J];
+            cost_imu += 0.5 * s;
+        }
+    }
+}
+
+// ---- second half: J'J / J'r per factor on the matrix cores, scattered into the reduced camera system colour by colour (factors of one
+// colour share no block)
+template <int NT, bool CHAIN>
+__device__ __forceinline__ void imu_part2(Ctx<NT> &C, int ch, bool assemble) {
+    cst_plan &P = *C.P;
+    const int tid = C.tid;
+    cst_i *ip = C.ip;
+    cst_d *dp = C.dp;
+    cst_i *blk = ip + P.o_blk;
+    (void)dp; (void)blk;
+    {
+        cst_i *ic = ip + P.o_ichunk + ch * 4;
+        const int fb = ic[0], fn = ic[1], ncolor = ic[2];
+        const unsigned colorbits = (unsigned)ic[3];
+        lds_d *recs = CHAIN ? C.stage : C.area;      // chain mode: the whole LDS pool holds the records
+        const int lane = tid & 63, wave = tid >> 6;
+        constexpr int NW = NT / 64;
+        (void)ncolor; (void)colorbits; (void)NW; (void)lane; (void)wave; (void)fb;
+        if (assemble && ABL(C, AB_IMU_GATHER)) {
+            const int i16 = lane & 15, k4 = lane >> 4;
+            for (int color = 0; color < ncolor; color++) {
+                // factors of this colour: whole factors go round-robin to the wavefronts; the ones left over when their number is not a
+                // multiple of the wavefront count are split by J'J tile (the four tiles of a factor have disjoint destinations), one tile per
+                // wavefront -- five factors on four wavefronts take 1.25 factor times instead of 2.  Same values, same additions.
+                int ncf = 0;
+                for (int f = 0; f < fn; f++) ncf += ((int)((colorbits >> (2 * f)) & 3u) == color) ? 1 : 0;
+                const int nfull = (ncf / NW) * NW;
+                int slot = 0;
+                for (int f = 0; f < fn; f++) {
+                    if ((int)((colorbits >> (2 * f)) & 3u) != color) continue;
+                    const int sl = slot++;
+                    const lds_d *rec = recs + f * IMU_REC;
+                    if (sl >= nfull) {      // split factor: this wavefront's tile
+                        if (wave >= 4) continue;
+                        const int tile = (wave + (sl - nfull)) & 3;
+                        const int I = (tile == 1 || tile == 2) ? 1 : 0, J = (tile >= 2) ? 1 : 0;
+                        const v4i scq = ((cst_v4i *)(ip + P.o_iitem + (fb + f) * 1024) + lane * 4)[tile];
+                        const int sce[4] = {scq.x, scq.y, scq.z, scq.w};
+                        double oa[4], ob[4];
+#pragma unroll
+                        for (int kk = 0; kk < 4; kk++) {
+                            const int k = 4 * kk + k4, ca = 16 * I + i16, cb = 16 * J + i16;
+                            const double ta = rec[min(k, 14) * IMU_STRIDE_J + min(ca, 30)], tb = rec[min(k, 14) * IMU_STRIDE_J + min(cb, 30)];
+                            oa[kk] = (k < 15 && ca < 31) ? ta : 0.0; ob[kk] = (k < 15 && cb < 31) ? tb : 0.0;
+                        }
+                        v4f64 acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int kk = 0; kk < 4; kk++) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(oa[kk], ob[kk], acc1, 0, 0, 0);
+                        const int bl = 16 * J + i16;
+                        int d4[4];
+                        double v4[4];
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const int al = 16 * I + k4 + 4 * i;
+                            if (CHAIN && (sce[i] & IMU_SC_STORE)) C.g_imublk[(fb + f) * IMU_BLK + al * 32 + bl] = acc1[i];
+                            d4[i] = (sce[i] & 0xffff) - IMU_SC_BIAS;
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const double tv = C.tiles[max(d4[i], 0)], gv = C.gcam[min(max(-2 - d4[i], 0), 175)];
+                            v4[i] = d4[i] >= 0 ? tv : gv;
+                            if (CHAIN && d4[i] <= -1000) v4[i] = C.hd[-1000 - d4[i]];
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const double v = v4[i] + acc1[i];
+                            if (d4[i] >= 0) C.tiles[d4[i]] = v;
+                            else if (CHAIN && d4[i] <= -1000) C.hd[-1000 - d4[i]] = v;
+                            else if (d4[i] <= -2) C.gcam[-2 - d4[i]] = v;
+                        }
+                        continue;
+                    }
+                    if ((sl % NW) != wave) continue;
+                    // destinations of this lane's 16 accumulator registers: precomputed by the packer (IMU scatter table), four 16-byte loads
+                    cst_v4i *sct = (cst_v4i *)(ip + P.o_iitem + (fb + f) * 1024) + lane * 4;
+                    const v4i sc0 = sct[0], sc1 = sct[1], sc2 = sct[2], sc3 = sct[3];
+                    const int scv[16] = {sc0.x, sc0.y, sc0.z, sc0.w, sc1.x, sc1.y, sc1.z, sc1.w, sc2.x, sc2.y, sc2.z, sc2.w, sc3.x, sc3.y, sc3.z, sc3.w};
+                    double op[2][4];      // operand values of column tiles 0 and 1 (A and B operands coincide: J' J)
+#pragma unroll
+                    for (int t = 0; t < 2; t++)
+#pragma unroll
+                        for (int kk = 0; kk < 4; kk++) {
+                            const int k = 4 * kk + k4, col = 16 * t + i16;
+                            const double tv = rec[min(k, 14) * IMU_STRIDE_J + min(col, 30)];      // unconditional load, masked after
+                            op[t][kk] = (k < 15 && col < 31) ? tv : 0.0;
+                        }
+                    v4f64 acc[4];
+#pragma unroll
+                    for (int tile = 0; tile < 4; tile++) {     // (I, J): (0,0) (1,0) (1,1) (0,1)
+                        const int I = (tile == 1 || tile == 2) ? 1 : 0, J = (tile >= 2) ? 1 : 0;
+                        acc[tile] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int kk = 0; kk < 4; kk++) acc[tile] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[I][kk], op[J][kk], acc[tile], 0, 0, 0);
+                    }
+                    // scatter: all destination reads in flight, then the adds, then the writes (distinct addresses per lane).  Chain mode: the
+                    // factor's lower triangle is also parked in HBM/L2 for the chain elimination (whole rows, so that the stores fill their
+                    // 64-byte granules; no other factor writes there); entries of a Euclidean block's row / column go nowhere else, their
+                    // diagonal feeds the Jacobi scaling.
+                    int didx[16];
+                    double dval[16];
+#pragma unroll
+                    for (int tile = 0; tile < 4; tile++) {
+                        const int I = (tile == 1 || tile == 2) ? 1 : 0, J = (tile >= 2) ? 1 : 0;
+                        const int bl = 16 * J + i16;            // local column of C held by this lane
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const int al = 16 * I + k4 + 4 * i;  // local row
+                            const int e = scv[tile * 4 + i];
+                            if (CHAIN && (e & IMU_SC_STORE)) C.g_imublk[(fb + f) * IMU_BLK + al * 32 + bl] = acc[tile][i];
+                            didx[tile * 4 + i] = (e & 0xffff) - IMU_SC_BIAS;      // >= 0: tile element, -2 - ta: gradient entry, -1: nothing
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 16; q++) {      // both candidate loads unconditional, selected afterwards
+                        const double tv = C.tiles[max(didx[q], 0)], gv = C.gcam[min(max(-2 - didx[q], 0), 175)];
+                        dval[q] = didx[q] >= 0 ? tv : gv;
+                        if (CHAIN && didx[q] <= -1000) dval[q] = C.hd[-1000 - didx[q]];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 16; q++) {
+                        const double v = dval[q] + acc[q >> 2][q & 3];
+                        if (didx[q] >= 0) C.tiles[didx[q]] = v;
+                        else if (CHAIN && didx[q] <= -1000) C.hd[-1000 - didx[q]] = v;
+                        else if (didx[q] <= -2) C.gcam[-2 - didx[q]] = v;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+        TCV_MARK(C, PH_IMU_GATHER);
+    }
+}
+
+// ---- marginalisation prior, part B: the constant J0' J0 (cached per solve) joins the tiles
+template <int NT, bool CHAIN>
+__device__ __forceinline__ void prior_part_b(Ctx<NT> &C, bool assemble) {
+    cst_plan &P = *C.P;
+    const int tid = C.tid;
+    cst_i *ip = C.ip;
+    if (P.prior_n > 0 && assemble && ABL(C, AB_PRIOR_B)) {
+        const int n = P.prior_n, npk = n * (n + 1) / 2;
+        cst_i *pcol = ip + P.o_pcol;
+        cst_i *pdest = ip + P.o_pdest;      // destination of every packed entry, precomputed by the packer
+        for (int e0 = tid; e0 < npk; e0 += 4 * NT) {
+            double hv[4];
+            int di[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int e = min(e0 + k * NT, npk - 1);
+                hv[k] = C.g_hp[e];
+                di[k] = (e0 + k * NT < npk) ? pdest[e] : -1;
+            }
+            double tv[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) tv[k] = (CHAIN && di[k] <= -2) ? C.hd[min(-2 - di[k], 111)] : C.tiles[max(di[k], 0)];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (di[k] >= 0) C.tiles[di[k]] = tv[k] + hv[k];
+                else if (CHAIN && di[k] <= -2) C.hd[-2 - di[k]] = tv[k] + hv[k];
+            }
+        }
+    }
+}
+
+// ---- linearise at x: cost, and (if assemble) S~ = Hcc - sum_l Hcl Hcl'/kappa_l in the tiles --------
+// kappa_l = hll + mu * clamp(s_l^2 hll) / s_l^2 is the landmark pivot of the Jacobi-scaled,
+// mu-regularised system expressed in unscaled units (DoglegStrategy + SchurEliminator restated).
+template <int NT, bool CHAIN>
+__device__ __noinline__ double linearize(Ctx<NT> &Cr, const lds_d *x, bool first, bool assemble, double mu) {
+    Ctx<NT> C = uniform_ctx<NT>(Cr);
+    cst_plan &P = *C.P;
+    const int tid = C.tid;
+    cst_i *ip = C.ip;
+    cst_d *dp = C.dp;
+    const int nc = P.nc, L = P.nland, nx = P.nx;
+    cst_d *misc = dp + C.W->d_misc;
+    const double G3[3] = {misc[0], misc[1], misc[2]};
+    const double proj_sqrt = misc[3], proj_loss = misc[4], line_loss = misc[5];
+    const bool line_exact = misc[8] != 0.0;
+    const int pp_elems = CHAIN ? (C.ntiles << 8) : ((P.ntp * (P.ntp + 1) / 2) << 8);
+    // ProjectionTdFactor windows (dense layout only): wider point records, see tcv_packed.h
+    const bool with_td = !CHAIN && (P.flags & 1);
+    const int prec = with_td ? (int)PROJ_TD_REC : (int)PROJ_REC, pstr = with_td ? (int)PROJ_TD_STRIDE : (int)PROJ_STRIDE;
+    double cost_acc = 0.0;
+
+    if (assemble) {
+        zero_lds<NT>(C.tiles, pp_elems, tid);
+        for (int i = tid; i < nc; i += NT) C.gcam[i] = 0.0;
+        for (int i = tid; i < 176; i += NT) C.rc[i] = 0.0;      // rc | sd
+        if (CHAIN) for (int i = tid; i < 112; i += NT) C.hd[i] = 0.0;
+    }
+    cst_i *blk = ip + P.o_blk;
+    TCV_MARK(C, PH_ZERO);
+    // ---------------- point + line factors, chunk by chunk -------------------------------------------
+    for (int ch = 0; ch < P.n_vis_chunk; ch++) {
+        vis_part1<NT, CHAIN>(C, x, ch, assemble, cost_acc, cost_acc);
+        if (!assemble) continue;
+        vis_part2<NT, CHAIN>(C, ch, first, mu);
     }
     // ---------------- marginalisation prior, part A (marginalization_factor.cpp:335-384): r = r0 + J0 dx, J0' r ------
     // The staging area is free between the Schur phase and the IMU chunks: J0 (n x n, column-major) is staged there
@@ -680,197 +954,297 @@ __device__ __noinline__ double linearize(Ctx<NT> &Cr, const lds_d *x, bool first
     // and J'J / J'r per factor on the matrix cores (one wavefront per factor); the 30 x 31 result is scattered into the
     // reduced camera system colour by colour (factors of one colour share no block).
     for (int ch = 0; ch < P.n_imu_chunk; ch++) {
-        cst_i *ic = ip + P.o_ichunk + ch * 4;
-        const int fb = ic[0], fn = ic[1], ncolor = ic[2];
-        const unsigned colorbits = (unsigned)ic[3];
-        lds_d *recs = CHAIN ? C.stage : C.area;      // chain mode: the whole LDS pool holds the records
-        const int lane = tid & 63, wave = tid >> 6;
-        constexpr int NW = NT / 64;
-        if (wave < 4 && lane < fn && ABL(C, AB_IMU_RAW)) {
-            cst_i *b = ip + P.o_imu + (fb + lane) * 4;
-            lds_d *rec = recs + lane * IMU_REC;
-            double cst[62];
-#pragma unroll
-            for (int i = 0; i < 62; i++) cst[i] = dp[C.W->d_imu + (fb + lane) * IMU_CONST + i];
-            imu_raw_part(wave, CGEN(x + blk[b[0] * 4 + 1]), CGEN(x + blk[b[1] * 4 + 1]), CGEN(x + blk[b[2] * 4 + 1]),
-                         CGEN(x + blk[b[3] * 4 + 1]), cst, G3, GEN(rec), IMU_STRIDE_J, assemble);
-        }
-        __syncthreads();
-        TCV_MARK(C, PH_IMU_RAW);
-        if (ABL(C, AB_IMU_WHITEN)) {   // whiten: T = S * [J_raw | r_raw]  (S upper triangular 15 x 15, zero padded to 16 x 16)
-            const int i16 = lane & 15, k4 = lane >> 4;
-            for (int f = wave; f < fn; f += NW) {
-                lds_d *rec = recs + f * IMU_REC;
-                const gbl_d *S = C.g_sqrt + (fb + f) * 225;
-                double sa[4];
-#pragma unroll
-                for (int kk = 0; kk < 4; kk++) { const int k = 4 * kk + k4; const double t = S[min(i16, 14) * 15 + min(k, 14)]; sa[kk] = (i16 < 15 && k < 15) ? t : 0.0; }
-                for (int ct = assemble ? 0 : 1; ct < 2; ct++) {
-                    const int col = 16 * ct + i16;
-                    double bb[4];
-#pragma unroll
-                    for (int kk = 0; kk < 4; kk++) { const int k = 4 * kk + k4; const double t = rec[min(k, 14) * IMU_STRIDE_J + min(col, 30)]; bb[kk] = (k < 15 && col < 31) ? t : 0.0; }
-                    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                    for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[kk], bb[kk], acc, 0, 0, 0);
-#pragma unroll
-                    for (int i = 0; i < 4; i++) { const int row = k4 + 4 * i; if (row < 15 && col < 31) rec[row * IMU_STRIDE_J + col] = acc[i]; }
-                }
-            }
-        }
-        __syncthreads();
-        TCV_MARK(C, PH_IMU_WHITEN);
-        if (tid < fn) {
-            const lds_d *rec = recs + tid * IMU_REC + 30;
-            double s = 0;
-#pragma unroll
-            for (int r = 0; r < 15; r++) s += rec[r * IMU_STRIDE_J] * rec[r * IMU_STRIDE_J];
-            cost_acc += 0.5 * s;
-        }
-        if (assemble && ABL(C, AB_IMU_GATHER)) {
-            const int i16 = lane & 15, k4 = lane >> 4;
-            for (int color = 0; color < ncolor; color++) {
-                // factors of this colour: whole factors go round-robin to the wavefronts; the ones left over when their number is not a
-                // multiple of the wavefront count are split by J'J tile (the four tiles of a factor have disjoint destinations), one tile per
-                // wavefront -- five factors on four wavefronts take 1.25 factor times instead of 2.  Same values, same additions.
-                int ncf = 0;
-                for (int f = 0; f < fn; f++) ncf += ((int)((colorbits >> (2 * f)) & 3u) == color) ? 1 : 0;
-                const int nfull = (ncf / NW) * NW;
-                int slot = 0;
-                for (int f = 0; f < fn; f++) {
-                    if ((int)((colorbits >> (2 * f)) & 3u) != color) continue;
-                    const int sl = slot++;
-                    const lds_d *rec = recs + f * IMU_REC;
-                    if (sl >= nfull) {      // split factor: this wavefront's tile
-                        if (wave >= 4) continue;
-                        const int tile = (wave + (sl - nfull)) & 3;
-                        const int I = (tile == 1 || tile == 2) ? 1 : 0, J = (tile >= 2) ? 1 : 0;
-                        const v4i scq = ((cst_v4i *)(ip + P.o_iitem + (fb + f) * 1024) + lane * 4)[tile];
-                        const int sce[4] = {scq.x, scq.y, scq.z, scq.w};
-                        double oa[4], ob[4];
-#pragma unroll
-                        for (int kk = 0; kk < 4; kk++) {
-                            const int k = 4 * kk + k4, ca = 16 * I + i16, cb = 16 * J + i16;
-                            const double ta = rec[min(k, 14) * IMU_STRIDE_J + min(ca, 30)], tb = rec[min(k, 14) * IMU_STRIDE_J + min(cb, 30)];
-                            oa[kk] = (k < 15 && ca < 31) ? ta : 0.0; ob[kk] = (k < 15 && cb < 31) ? tb : 0.0;
-                        }
-                        v4f64 acc1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                        for (int kk = 0; kk < 4; kk++) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(oa[kk], ob[kk], acc1, 0, 0, 0);
-                        const int bl = 16 * J + i16;
-                        int d4[4];
-                        double v4[4];
-#pragma unroll
-                        for (int i = 0; i < 4; i++) {
-                            const int al = 16 * I + k4 + 4 * i;
-                            if (CHAIN && (sce[i] & IMU_SC_STORE)) C.g_imublk[(fb + f) * IMU_BLK + al * 32 + bl] = acc1[i];
-                            d4[i] = (sce[i] & 0xffff) - IMU_SC_BIAS;
-                        }
-#pragma unroll
-                        for (int i = 0; i < 4; i++) {
-                            const double tv = C.tiles[max(d4[i], 0)], gv = C.gcam[min(max(-2 - d4[i], 0), 175)];
-                            v4[i] = d4[i] >= 0 ? tv : gv;
-                            if (CHAIN && d4[i] <= -1000) v4[i] = C.hd[-1000 - d4[i]];
-                        }
-#pragma unroll
-                        for (int i = 0; i < 4; i++) {
-                            const double v = v4[i] + acc1[i];
-                            if (d4[i] >= 0) C.tiles[d4[i]] = v;
-                            else if (CHAIN && d4[i] <= -1000) C.hd[-1000 - d4[i]] = v;
-                            else if (d4[i] <= -2) C.gcam[-2 - d4[i]] = v;
-                        }
-                        continue;
-                    }
-                    if ((sl % NW) != wave) continue;
-                    // destinations of this lane's 16 accumulator registers: precomputed by the packer (IMU scatter table), four 16-byte loads
-                    cst_v4i *sct = (cst_v4i *)(ip + P.o_iitem + (fb + f) * 1024) + lane * 4;
-                    const v4i sc0 = sct[0], sc1 = sct[1], sc2 = sct[2], sc3 = sct[3];
-                    const int scv[16] = {sc0.x, sc0.y, sc0.z, sc0.w, sc1.x, sc1.y, sc1.z, sc1.w, sc2.x, sc2.y, sc2.z, sc2.w, sc3.x, sc3.y, sc3.z, sc3.w};
-                    double op[2][4];      // operand values of column tiles 0 and 1 (A and B operands coincide: J' J)
-#pragma unroll
-                    for (int t = 0; t < 2; t++)
-#pragma unroll
-                        for (int kk = 0; kk < 4; kk++) {
-                            const int k = 4 * kk + k4, col = 16 * t + i16;
-                            const double tv = rec[min(k, 14) * IMU_STRIDE_J + min(col, 30)];      // unconditional load, masked after
-                            op[t][kk] = (k < 15 && col < 31) ? tv : 0.0;
-                        }
-                    v4f64 acc[4];
-#pragma unroll
-                    for (int tile = 0; tile < 4; tile++) {     // (I, J): (0,0) (1,0) (1,1) (0,1)
-                        const int I = (tile == 1 || tile == 2) ? 1 : 0, J = (tile >= 2) ? 1 : 0;
-                        acc[tile] = (v4f64){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                        for (int kk = 0; kk < 4; kk++) acc[tile] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[I][kk], op[J][kk], acc[tile], 0, 0, 0);
-                    }
-                    // scatter: all destination reads in flight, then the adds, then the writes (distinct addresses per lane).  Chain mode: the
-                    // factor's lower triangle is also parked in HBM/L2 for the chain elimination (whole rows, so that the stores fill their
-                    // 64-byte granules; no other factor writes there); entries of a Euclidean block's row / column go nowhere else, their
-                    // diagonal feeds the Jacobi scaling.
-                    int didx[16];
-                    double dval[16];
-#pragma unroll
-                    for (int tile = 0; tile < 4; tile++) {
-                        const int I = (tile == 1 || tile == 2) ? 1 : 0, J = (tile >= 2) ? 1 : 0;
-                        const int bl = 16 * J + i16;            // local column of C held by this lane
-#pragma unroll
-                        for (int i = 0; i < 4; i++) {
-                            const int al = 16 * I + k4 + 4 * i;  // local row
-                            const int e = scv[tile * 4 + i];
-                            if (CHAIN && (e & IMU_SC_STORE)) C.g_imublk[(fb + f) * IMU_BLK + al * 32 + bl] = acc[tile][i];
-                            didx[tile * 4 + i] = (e & 0xffff) - IMU_SC_BIAS;      // >= 0: tile element, -2 - ta: gradient entry, -1: nothing
-                        }
-                    }
-#pragma unroll
-                    for (int q = 0; q < 16; q++) {      // both candidate loads unconditional, selected afterwards
-                        const double tv = C.tiles[max(didx[q], 0)], gv = C.gcam[min(max(-2 - didx[q], 0), 175)];
-                        dval[q] = didx[q] >= 0 ? tv : gv;
-                        if (CHAIN && didx[q] <= -1000) dval[q] = C.hd[-1000 - didx[q]];
-                    }
-#pragma unroll
-                    for (int q = 0; q < 16; q++) {
-                        const double v = dval[q] + acc[q >> 2][q & 3];
-                        if (didx[q] >= 0) C.tiles[didx[q]] = v;
-                        else if (CHAIN && didx[q] <= -1000) C.hd[-1000 - didx[q]] = v;
-                        else if (didx[q] <= -2) C.gcam[-2 - didx[q]] = v;
-                    }
-                }
-                __syncthreads();
-            }
-        }
-        __syncthreads();
-        TCV_MARK(C, PH_IMU_GATHER);
+        imu_part1<NT, CHAIN>(C, x, ch, assemble, cost_acc);
+        imu_part2<NT, CHAIN>(C, ch, assemble);
     }
     // ---------------- marginalisation prior, part B: the constant J0' J0 (cached per solve) joins the tiles --------------
-    if (P.prior_n > 0 && assemble && ABL(C, AB_PRIOR_B)) {
-        const int n = P.prior_n, npk = n * (n + 1) / 2;
-        cst_i *pcol = ip + P.o_pcol;
-        cst_i *pdest = ip + P.o_pdest;      // destination of every packed entry, precomputed by the packer
-        for (int e0 = tid; e0 < npk; e0 += 4 * NT) {
-            double hv[4];
-            int di[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int e = min(e0 + k * NT, npk - 1);
-                hv[k] = C.g_hp[e];
-                di[k] = (e0 + k * NT < npk) ? pdest[e] : -1;
-            }
-            double tv[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) tv[k] = (CHAIN && di[k] <= -2) ? C.hd[min(-2 - di[k], 111)] : C.tiles[max(di[k], 0)];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (di[k] >= 0) C.tiles[di[k]] = tv[k] + hv[k];
-                else if (CHAIN && di[k] <= -2) C.hd[-2 - di[k]] = tv[k] + hv[k];
-            }
-        }
-    }
+    prior_part_b<NT, CHAIN>(C, assemble);
     TCV_MARK(C, PH_PRIOR);
     const double cost = block_sum<NT>(cost_acc, C.red, tid);
     __syncthreads();
     TCV_MARK(C, PH_COST_RED);
     TCV_CTX_LEAVE(Cr, C);
     return cost;
+}
+
+// ---- cooperative mode (tcv_packed.h COOP_*): a window on 1 + H workgroups ----------------------------------------------------------
+// Hand-off flags live in HBM / L2 and are written with release, read with acquire semantics at agent scope (the workgroups of a group
+// normally share an XCD and its L2 -- see the launch mapping in solve_kernel -- but nothing depends on it).  Every wait is bounded:
+// a partner that never answers (a group that was not co-resident, a fault) ends the window with status -9 instead of hanging the queue.
+// polling loads are RELAXED (a coherent load, no cache invalidation per trip: an acquire in the loop floods the L2 the partner is trying to
+// write its exports through); the waiting workgroup issues one acquire fence once the flag has flipped
+__device__ __forceinline__ int coop_load(gbl_i *p) { return __hip_atomic_load((int *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void coop_store(gbl_i *p, int v) { __hip_atomic_store((int *)p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+// progress marks of a group in its control block (ints 16 .. 31: master, 32 + 4 h + w: wavefront w of helper h), read by tcv_batch_debug_coop when a launch
+// has to be diagnosed; relaxed stores of one lane
+#define COOP_MARKW(C, h, v) do { if (((C).tid & 63) == 0) __hip_atomic_store((int *)((C).cx_ctl + 32 + 4 * (h) + ((C).tid >> 6)), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
+#define COOP_MARK(C, slot, v) do { if ((C).tid == 0) __hip_atomic_store((int *)((C).cx_ctl + (slot)), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
+
+// master: wait until every helper has served request `seq`; false on timeout / abort (uniform over the workgroup)
+template <int NT>
+__device__ __forceinline__ bool coop_wait_helpers(const Ctx<NT> &C, int seq) {
+    int ok = 1;
+    if (C.tid < C.cx_h) {
+        gbl_i *f = C.cx_ctl + COOP_CTL_DONE + C.tid;
+        const long long t0 = (long long)wall_clock64();
+        while (coop_load(f) != seq) {
+            if (coop_load(C.cx_ctl + COOP_CTL_ABORT) != 0 || (long long)wall_clock64() - t0 > C.cx_timeout) { ok = 0; break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    // (all waiting lanes sit in the first wavefront; __syncthreads_and would add static LDS to a kernel that owns all 160 KiB dynamically)
+    lds_i *slot = (lds_i *)(C.red + 61);
+    if (C.tid < 64) { const bool all = __ballot(ok == 0) == 0ull; if (C.tid == 0) *slot = all ? 1 : 0; }
+    __syncthreads();
+    ok = *slot;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // every wavefront: nothing stale of the helpers' exports in this CU's caches
+    return ok != 0;
+}
+
+// master: publish a request (state, mu, command) to the helpers of the group
+template <int NT>
+__device__ __forceinline__ void coop_publish(const Ctx<NT> &C, const lds_d *x, int n, double mu, int cmd, int win, int seq) {
+    if (x) for (int i = C.tid; i < n; i += NT) C.cx_x[i] = x[i];
+    if (C.tid == 0) { C.cx_x[SCR_NL] = mu; C.cx_ctl[COOP_CTL_CMD] = cmd; C.cx_ctl[COOP_CTL_WIN] = win; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // every wavefront's part of x (the release of lane 0 below covers its own wavefront only)
+    __syncthreads();
+    if (C.tid == 0) coop_store(C.cx_ctl + COOP_CTL_SEQ, seq);
+}
+
+// Linearisation by the master of a group: same result as linearize<NT, true>, bit for bit when the plan's chunks hold at most NT point
+// factors each (the cooperative packer's rule), because every sum is formed by the same additions in the same order:
+//   tiles / gradient / rhs and diagonal corrections: zero, then per chunk c the gathered value a_c (one addition per destination and
+//   chunk), then minus the Schur value s_c (the helper exports -s_c = 0 - s_c exactly), then the prior's J0'r, the IMU blocks colour by
+//   colour, the cached J0'J0;  cost: per thread its point and line costs chunk by chunk, then its prior row, then its IMU factor.
+// Returns NaN with Cr.cx_seq = -1 if the helpers did not answer.
+template <int NT>
+__device__ __noinline__ double linearize_coop(Ctx<NT> &Cr, const lds_d *x, bool first, bool assemble, double mu, int win) {
+    Ctx<NT> C = uniform_ctx<NT>(Cr);
+    cst_plan &P = *C.P;
+    const int tid = C.tid;
+    cst_i *ip = C.ip;
+    cst_d *dp = C.dp;
+    const int L = P.nland, nx = P.nx;
+    const int seq = C.cx_seq + 1;
+    Cr.cx_seq = seq;
+    COOP_MARK(C, 16, 1); COOP_MARK(C, 17, seq);
+    coop_publish<NT>(C, x, nx + L, mu, (first ? COOP_CMD_FIRST : 0) | (assemble ? COOP_CMD_ASSEMBLE : 0), win, seq);
+    COOP_MARK(C, 16, 2);
+    cst_i *blk = ip + P.o_blk;
+    if (assemble) for (int i = tid; i < 112; i += NT) C.hd[i] = 0.0;
+    TCV_MARK(C, PH_ZERO);
+    // ---- own work while the helpers evaluate the visual chunks: prior part A (marginalization_factor.cpp:335-384) with J0 staged in the
+    // (otherwise idle) pool -- its J0'r is kept in a register until the chunks are folded in, the single-workgroup order --, IMU factors
+    double cost_prior = 0.0, cost_imu = 0.0, pg = 0.0;
+    int pt = -1;
+    if (P.prior_n > 0) {
+        const int n = P.prior_n;
+        cst_d *J0g = dp + C.W->d_prior, *r0 = J0g + n * n, *x0 = r0 + n;
+        lds_d *J0 = C.stage, *pdx = C.stage + n * n, *pr = pdx + n;      // n n + 2 n <= stage_cap: checked by tcv_batch_create
+        if (tid < P.prior_nblk) {
+            cst_i *pb = ip + P.o_prior + tid * 4;
+            const int gs = pb[2], xo = blk[pb[0] * 4 + 1], x0o = pb[3], ls = gs == 7 ? 6 : gs;
+            double d15[15];
+#pragma unroll
+            for (int i = 0; i < 15; i++) d15[i] = (i < gs) ? x[xo + (i < gs ? i : 0)] - x0[x0o + (i < gs ? i : 0)] : 0.0;
+            if (gs == 7) {
+                const Quat q0(x0[x0o + 3], x0[x0o + 4], x0[x0o + 5], x0[x0o + 6]), q(x[xo + 3], x[xo + 4], x[xo + 5], x[xo + 6]);
+                const Quat dq = inverse(q0) * q;
+                const double sg = (dq.w >= 0) ? 2.0 : -2.0;
+                d15[3] = sg * dq.x; d15[4] = sg * dq.y; d15[5] = sg * dq.z;
+            }
+#pragma unroll
+            for (int i = 0; i < 15; i++) if (i < ls) pdx[pb[1] + i] = d15[i];
+        }
+        copy_doubles<NT>(J0, J0g, n * n, tid);
+        __syncthreads();
+        if (tid < n) {      // the in_lds branch of linearize(), verbatim
+            double r = r0[tid], r2 = 0.0;
+            for (int j = 0; j + 1 < n; j += 2) { r += J0[tid + n * j] * pdx[j]; r2 += J0[tid + n * (j + 1)] * pdx[j + 1]; }
+            if (n & 1) r += J0[tid + n * (n - 1)] * pdx[n - 1];
+            r += r2;
+            pr[tid] = r;
+            cost_prior = 0.5 * r * r;
+        }
+        __syncthreads();
+        if (assemble && tid < n) {
+            const int t = (ip + P.o_pcol)[tid];
+            if (t >= 0) {
+                const lds_d *col = J0 + n * tid;
+                double s0 = 0, s1 = 0;
+                for (int i = 0; i + 1 < n; i += 2) { s0 += col[i] * pr[i]; s1 += col[i + 1] * pr[i + 1]; }
+                if (n & 1) s0 += col[n - 1] * pr[n - 1];
+                pg = s0 + s1; pt = t;
+            }
+        }
+        __syncthreads();
+    }
+    TCV_MARK(C, PH_PRIOR);
+    COOP_MARK(C, 16, 3);
+    if (P.n_imu_chunk > 0) imu_part1<NT, true>(C, x, 0, assemble, cost_imu);      // (one chunk: checked by tcv_batch_create)
+    COOP_MARK(C, 16, 4);
+    // ---- the helpers' chunks
+    if (!coop_wait_helpers<NT>(C, seq)) {
+        if (tid == 0) coop_store(C.cx_ctl + COOP_CTL_ABORT, 1);
+        COOP_MARK(C, 16, 9);
+        Cr.cx_seq = -1;
+        return __builtin_nan("");
+    }
+    TCV_MARK(C, PH_VIS_GATHER);
+    COOP_MARK(C, 16, 5);
+    const int nch = P.n_vis_chunk, te = C.ntiles << 8;
+    const gbl_d *E = C.cx_exp;
+    const int es = C.cx_exp_stride;
+    double cost_acc = 0.0;
+    for (int c = 0; c < nch; c++) { cost_acc += E[(size_t)c * es + 2 * te + 352 + tid]; cost_acc += E[(size_t)c * es + 2 * te + 352 + 256 + tid]; }
+    cost_acc += cost_prior;
+    cost_acc += cost_imu;
+    if (assemble) {
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        typedef __attribute__((address_space(1))) v2d gbl_v2d;
+        typedef __attribute__((address_space(3))) v2d lds_v2d;
+        // tiles: element pairs; per element t = 0 + a_1 + (-s_1) + a_2 + (-s_2) ...  (all loads of a trip in flight, the additions in order)
+        for (int i = tid; i < (te >> 1); i += NT) {
+            v2d t = {0.0, 0.0};
+            int c = 0;
+            for (; c + 1 < nch; c += 2) {
+                const gbl_v2d *e0 = (const gbl_v2d *)(E + (size_t)c * es), *e1 = (const gbl_v2d *)(E + (size_t)(c + 1) * es);
+                const v2d a0 = e0[i], s0 = e0[(te >> 1) + i], a1 = e1[i], s1 = e1[(te >> 1) + i];
+                t += a0; t += s0; t += a1; t += s1;
+            }
+            if (c < nch) { const gbl_v2d *e0 = (const gbl_v2d *)(E + (size_t)c * es); const v2d a0 = e0[i], s0 = e0[(te >> 1) + i]; t += a0; t += s0; }
+            ((lds_v2d *)C.tiles)[i] = t;
+        }
+        // gradient (176) | rc, sd (176)
+        for (int i = tid; i < 352; i += NT) {
+            double t = 0.0;
+            for (int c = 0; c < nch; c++) t += E[(size_t)c * es + 2 * te + i];
+            if (i < 176) C.gcam[i] = t; else C.rc[i - 176] = t;
+        }
+        __syncthreads();
+        if (pt >= 0) C.gcam[pt] += pg;
+        __syncthreads();
+        TCV_MARK(C, PH_SCHUR);
+        if (P.n_imu_chunk > 0) imu_part2<NT, true>(C, 0, assemble);
+        prior_part_b<NT, true>(C, assemble);
+    }
+    TCV_MARK(C, PH_PRIOR);
+    const double cost = block_sum<NT>(cost_acc, C.red, tid);
+    __syncthreads();
+    COOP_MARK(C, 16, 6);
+    TCV_MARK(C, PH_COST_RED);
+    TCV_CTX_LEAVE(Cr, C);
+    return cost;
+}
+
+// A helper workgroup of group g: serves the master's linearisation requests until it is told to leave.  Its LDS is carved like the
+// master's (pose tiles | pool | vectors) plus a second tile set for the Schur values; its scratch pointers are the MASTER's (landmark
+// pivots, couplings and scales are written where the master's back-substitution reads them).
+template <int NT>
+__device__ __noinline__ void coop_helper(const SolveArgs &A, lds_d *lds, int g_, int h_) {
+    const int tid = threadIdx.x;
+    // arguments of a non-inlined function arrive in vector registers: made uniform by hand, or every loop over them becomes an exec-mask loop
+    const int g = __builtin_amdgcn_readfirstlane(g_), h = __builtin_amdgcn_readfirstlane(h_);
+    Ctx<NT> C;
+    C.tid = tid;
+    gbl_d *scr = (gbl_d *)A.scratch + (size_t)g * A.scratch_stride;
+    C.v_s = scr; C.v_g = scr + SCR_NL; C.v_D = scr + 2 * SCR_NL; C.v_ghat = scr + 3 * SCR_NL; C.v_y = scr + 4 * SCR_NL;
+    C.v_p = scr + 5 * SCR_NL; C.v_rc = scr + 6 * SCR_NL; C.v_sd = scr + 7 * SCR_NL;
+    C.l_hll = scr + 8 * SCR_NL; C.l_gl = C.l_hll + SCR_LM; C.l_invk = C.l_gl + SCR_LM;
+    C.g_hp = C.l_invk + SCR_LM; C.g_pr = C.g_hp + SCR_HP; C.g_pdx = C.g_pr + 128;
+    C.g_sqrt = C.g_pdx + 128;
+    C.g_hcl = C.g_sqrt + SCR_SQ;
+    C.prof = nullptr; C.t_last = 0; C.skip = 0;
+    C.g_imublk = nullptr; C.g_spill = nullptr;
+    C.cx_ctl = (gbl_i *)A.coop_ctl + (size_t)g * COOP_CTL_INTS;
+    C.cx_x = (gbl_d *)A.coop_x + (size_t)g * COOP_X_DOUBLES;
+    C.cx_exp = (gbl_d *)A.coop_exp + (size_t)g * A.coop_exp_chunks * A.coop_exp_stride;
+    C.cx_h = A.coop_h; C.cx_exp_stride = A.coop_exp_stride; C.cx_seq = 0; C.cx_timeout = A.coop_timeout;
+    lds_i *bcast = (lds_i *)(lds + LDS_DOUBLES - 2);      // the last 16 bytes of the workgroup's LDS: outside every window's carve
+    int seen = 0;
+    for (;;) {
+        COOP_MARKW(C, h, 1 + (seen << 4));
+        if (tid == 0) {
+            const long long t0 = (long long)wall_clock64();
+            int s;
+            while ((s = coop_load(C.cx_ctl + COOP_CTL_SEQ)) == seen) {
+                if (coop_load(C.cx_ctl + COOP_CTL_ABORT) != 0 || (long long)wall_clock64() - t0 > C.cx_timeout) { s = -1; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            *bcast = s;
+        }
+        __syncthreads();
+        const int seq = __builtin_amdgcn_readfirstlane(*bcast);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __syncthreads();
+        if (seq < 0) { if (tid == 0) coop_store(C.cx_ctl + COOP_CTL_ABORT, 1); return; }
+        const int cmd = __builtin_amdgcn_readfirstlane(C.cx_ctl[COOP_CTL_CMD]), win = __builtin_amdgcn_readfirstlane(C.cx_ctl[COOP_CTL_WIN]);
+        COOP_MARKW(C, h, 2 + (seq << 4));
+        if (cmd & COOP_CMD_EXIT) return;
+        cst_win *W = (cst_win *)A.win + win;
+        cst_plan &P = ((cst_plan *)A.plans)[W->plan];
+        C.P = &P; C.W = W;
+        C.ip = (cst_i *)A.ipool + A.plan_base[W->plan];
+        C.dp = (cst_d *)A.dpool + W->dbase;
+        const int L = P.nland, nxl = (P.nx + L + 1) & ~1;
+        C.ntd = P.nt_c; C.nd = P.npp;
+        C.ntiles = C.ntd * (C.ntd + 1) / 2;
+        const int te = C.ntiles << 8;
+        C.tiles = lds;
+        C.stage = lds + te;
+        C.stage_cap = P.c_stage_cap;
+        lds_d *p = C.stage + P.c_pool;
+        C.xs = p; p += nxl;
+        C.xc = p; p += nxl;
+        C.sc = p; p += 176;
+        C.rc = p; C.sd = p + 88; p += 176;
+        C.ycam = p; p += 176;
+        C.invdiag = p; C.gcam = p; p += 176;
+        C.red = p; p += 64;
+        C.flag = (lds_i *)(C.red + 62);
+        C.hd = p; p += 112;
+        C.area = C.stage + P.c_stage_cap;
+        lds_d *tiles2 = p;                                   // the cooperative packer leaves room for it (chain_lds = LDS_DOUBLES - te)
+        const Ctx<NT> K = uniform_ctx<NT>(C);
+        for (int i = tid; i < P.nx + L; i += NT) K.xs[i] = K.cx_x[i];
+        const double mu = K.cx_x[SCR_NL];
+        const bool first = (cmd & COOP_CMD_FIRST) != 0, assemble = (cmd & COOP_CMD_ASSEMBLE) != 0;
+        Ctx<NT> K1 = K, K2 = K;
+        K2.tiles = uni_ptr(tiles2);
+        for (int ch = h; ch < P.n_vis_chunk; ch += K.cx_h) {
+            gbl_d *E = K.cx_exp + (size_t)ch * K.cx_exp_stride;
+            if (assemble) {
+                zero_lds<NT>(K.tiles, te, tid);
+                zero_lds<NT>(tiles2, te, tid);
+                for (int i = tid; i < 176; i += NT) { K.gcam[i] = 0.0; K.rc[i] = 0.0; }      // rc | sd
+            }
+            double cost_pt = 0.0, cost_ln = 0.0;
+            COOP_MARKW(C, h, 3 + (seq << 4));
+            vis_part1<NT, true>(K1, K.xs, ch, assemble, cost_pt, cost_ln);      // (starts with a barrier: the zeroing above is ordered before the gathers)
+            COOP_MARKW(C, h, 4 + (seq << 4));
+            if (assemble) {
+                vis_part2<NT, true>(K2, ch, first, mu);
+                COOP_MARKW(C, h, 5 + (seq << 4));
+                typedef double v2d __attribute__((ext_vector_type(2)));
+                typedef __attribute__((address_space(1))) v2d gbl_v2d;
+                typedef __attribute__((address_space(3))) v2d lds_v2d;
+                for (int i = tid; i < (te >> 1); i += NT) { ((gbl_v2d *)E)[i] = ((lds_v2d *)K.tiles)[i]; ((gbl_v2d *)E)[(te >> 1) + i] = ((lds_v2d *)tiles2)[i]; }
+                for (int i = tid; i < 176; i += NT) { E[2 * te + i] = K.gcam[i]; E[2 * te + 176 + i] = K.rc[i]; }
+            }
+            E[2 * te + 352 + tid] = cost_pt;
+            E[2 * te + 352 + 256 + tid] = cost_ln;
+            COOP_MARKW(C, h, 6 + (seq << 4));
+            __syncthreads();
+        }
+        // every wavefront's exports must have left for the L2 / HBM before lane 0 signals: the release of one lane waits for its own
+        // wavefront's stores only
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        COOP_MARKW(C, h, 7 + (seq << 4));
+        if (tid == 0) coop_store(K.cx_ctl + COOP_CTL_DONE + h, seq);
+        COOP_MARKW(C, h, 8 + (seq << 4));
+        seen = seq;
+    }
 }
 
 // ---- tiled Cholesky of the augmented system in LDS -----------------------------------------------
@@ -1763,28 +2137,46 @@ __device__ __noinline__ double grad_max(Ctx<NT> &Cr) {
 }
 
 // ---- the kernel ---------------------------------------------------------------------------------------
-template <int NT, bool MFMA, bool CHAIN>
-__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CHAIN ? 2 : 1, CHAIN ? 2 : 8))) solve_kernel(SolveArgs A) {
+// COOP (cooperative mode, chain layout, tcv_packed.h): the grid holds 1 + coop_h workgroups per window GROUP.  Workgroup b is member
+// b / ng8 of group b % ng8 (ng8 = number of groups rounded up to a multiple of 8, the XCD count): workgroups are dealt to the XCDs
+// round-robin by index, so the master and the helpers of a group land on the same XCD and hand their exports over through its L2.
+template <int NT, bool MFMA, bool CHAIN, bool COOP = false>
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((CHAIN && !COOP) ? 2 : 1, COOP ? 1 : (CHAIN ? 2 : 8)))) solve_kernel(SolveArgs A) {
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
     lds_d *lds = (lds_d *)lds_raw;
     const int tid = threadIdx.x;
+    int slot = blockIdx.x, wstride = gridDim.x;      // scratch slot and first window of this workgroup; window stride
+    if (COOP) {
+        const int ng8 = (int)gridDim.x / (1 + A.coop_h);
+        const int member = (int)blockIdx.x / ng8, g = (int)blockIdx.x - member * ng8;
+        if (g >= A.coop_groups) return;
+        if (member > 0) { coop_helper<NT>(A, lds, g, member - 1); return; }
+        slot = g; wstride = A.coop_groups;
+    }
     Ctx<NT> C;
     C.tid = tid;
-    gbl_d *scr = (gbl_d *)A.scratch + (size_t)blockIdx.x * A.scratch_stride;
+    C.cx_ctl = nullptr; C.cx_x = nullptr; C.cx_exp = nullptr; C.cx_h = 0; C.cx_exp_stride = 0; C.cx_seq = 0; C.cx_timeout = 0;
+    if (COOP) {
+        C.cx_ctl = (gbl_i *)A.coop_ctl + (size_t)slot * COOP_CTL_INTS;
+        C.cx_x = (gbl_d *)A.coop_x + (size_t)slot * COOP_X_DOUBLES;
+        C.cx_exp = (gbl_d *)A.coop_exp + (size_t)slot * A.coop_exp_chunks * A.coop_exp_stride;
+        C.cx_h = A.coop_h; C.cx_exp_stride = A.coop_exp_stride; C.cx_timeout = A.coop_timeout;
+    }
+    gbl_d *scr = (gbl_d *)A.scratch + (size_t)slot * A.scratch_stride;
     C.v_s = scr; C.v_g = scr + SCR_NL; C.v_D = scr + 2 * SCR_NL; C.v_ghat = scr + 3 * SCR_NL; C.v_y = scr + 4 * SCR_NL;
     C.v_p = scr + 5 * SCR_NL; C.v_rc = scr + 6 * SCR_NL; C.v_sd = scr + 7 * SCR_NL;
     C.l_hll = scr + 8 * SCR_NL; C.l_gl = C.l_hll + SCR_LM; C.l_invk = C.l_gl + SCR_LM;
     C.g_hp = C.l_invk + SCR_LM; C.g_pr = C.g_hp + SCR_HP; C.g_pdx = C.g_pr + 128;
     C.g_sqrt = C.g_pdx + 128;
     C.g_hcl = C.g_sqrt + SCR_SQ;
-    C.prof = A.prof ? (gbl_d *)A.prof + (size_t)blockIdx.x * 32 : nullptr;
+    C.prof = A.prof ? (gbl_d *)A.prof + (size_t)slot * 32 : nullptr;
     C.t_last = 0;
     C.skip = (unsigned)A.pad2;
 #ifdef TCV_PROFILE
     C.t_last = clock64();
 #endif
 
-    for (int win = blockIdx.x; win < A.nwin; win += gridDim.x) {
+    for (int win = slot; win < A.nwin; win += wstride) {
         cst_win *W = (cst_win *)A.win + win;
         cst_plan &P = ((cst_plan *)A.plans)[W->plan];
         C.P = &P; C.W = W;
@@ -1801,8 +2193,8 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CHAIN ?
             C.stage = lds + (C.ntiles << 8);
             C.stage_cap = P.c_stage_cap;
             p = C.stage + P.c_pool;
-            C.g_imublk = (gbl_d *)A.imublk + (size_t)blockIdx.x * 16 * IMU_BLK;
-            C.g_spill = (gbl_d *)A.spill + (size_t)blockIdx.x * A.spill_stride;
+            C.g_imublk = (gbl_d *)A.imublk + (size_t)slot * 16 * IMU_BLK;
+            C.g_spill = (gbl_d *)A.spill + (size_t)slot * A.spill_stride;
         } else {
             C.stage = lds + (pp_tiles << 8);
             C.stage_cap = (C.ntiles - pp_tiles) << 8;
@@ -1886,7 +2278,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CHAIN ?
         double radius = 1e4, mu = 1e-8, lin_mu = 1e-8;
         bool reuse = false, tiles_valid = true;
         int invalid = 0, termination = 0, nrec = 1, status = 0;
-        double cost = uni_d(linearize<NT, CHAIN>(C, K.xs, true, true, mu));
+        double cost = uni_d(COOP ? linearize_coop<NT>(C, K.xs, true, true, mu, win) : linearize<NT, CHAIN>(C, K.xs, true, true, mu));
         bool first = true;
         const double initial_cost = cost;
         if (tid == 0) { S->cost[0] = cost; S->step_ok[0] = 1; S->dogleg_case[0] = 0; S->radius[0] = radius; S->mu[0] = mu; }
@@ -1895,7 +2287,8 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CHAIN ?
         { const Norms2 nn = ambient_norms<NT>(C, K.xs, K.xs); xn2 = uni_d(nn.xn2); dn2 = uni_d(nn.dn2); }
         double x_norm = uni_d(sqrt(xn2));
         bool done = false;
-        if (!fixed) {
+        if (COOP && C.cx_seq < 0) { done = true; status = -9; termination = 5; }      // the helpers did not answer (timeout)
+        if (!fixed && !done) {
             const double gm = grad_max<NT>(C);
             if (gm <= 1e-10) { termination = 1; done = true; }
         }
@@ -1917,7 +2310,8 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CHAIN ?
                 ls_ok = false;
                 while (mu < 1.0) {
                     if (!tiles_valid || lin_mu != mu) {
-                        (void)linearize<NT, CHAIN>(C, K.xs, false, true, mu);
+                        if (COOP) (void)linearize_coop<NT>(C, K.xs, false, true, mu, win); else (void)linearize<NT, CHAIN>(C, K.xs, false, true, mu);
+                        if (COOP && C.cx_seq < 0) break;
                         lin_mu = mu;
                     }
                     const FinOut fo = finalize_and_solve<NT, MFMA, CHAIN>(C, first, mu);
@@ -1928,6 +2322,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CHAIN ?
                     if (ok) { ls_ok = true; break; }
                     mu = uni_d(mu * 10.0);
                 }
+                if (COOP && C.cx_seq < 0) { status = -9; termination = 5; break; }
                 if (ls_ok && ABL(C, AB_DOGLEG)) {
                     alpha = uni_d(gg / q);
                     // dot products for the dogleg interpolation and the model decrease
@@ -1998,7 +2393,8 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CHAIN ?
             TCV_MARK(C, PH_PLUS);
             const double mu_next = uni_d(fmax(1e-8, 2.0 * mu / 10.0));
             const bool want_asm = (it < max_it) || !fixed;
-            const double cost_c = uni_d(linearize<NT, CHAIN>(C, K.xc, false, want_asm, mu_next));
+            const double cost_c = uni_d(COOP ? linearize_coop<NT>(C, K.xc, false, want_asm, mu_next, win) : linearize<NT, CHAIN>(C, K.xc, false, want_asm, mu_next));
+            if (COOP && C.cx_seq < 0) { status = -9; termination = 5; break; }
             tiles_valid = want_asm;
             lin_mu = mu_next;
             if (ABL(C, AB_NORMS)) { const Norms2 nn = ambient_norms<NT>(C, K.xs, K.xc); xn2 = uni_d(nn.xn2); dn2 = uni_d(nn.dn2); }
@@ -2063,13 +2459,27 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CHAIN ?
         __syncthreads();
 #endif
     }
+    if (COOP && C.cx_seq >= 0) {      // the helpers of this group leave with the master
+        __syncthreads();
+        coop_publish<NT>(C, nullptr, 0, 0.0, COOP_CMD_EXIT, 0, C.cx_seq + 1);
+    }
 }
 
 }  // namespace tcv
 
 // The chain kernel is built in its own translation unit (-DTCV_SOLVE_CHAIN_TU, every device function inlined so that the
 // 2-waves-per-SIMD register budget covers the whole call tree: the occupancy attribute does not reach non-inlined callees).
-#ifdef TCV_SOLVE_CHAIN_TU
+#ifdef TCV_SOLVE_COOP_TU
+// cooperative chain kernel (own translation unit, like the chain kernel): grid = (1 + coop_h) x (groups rounded up to a multiple of 8)
+extern "C" int tcv_launch_solve_coop(const tcv::SolveArgs *args, int grid, size_t lds_bytes, void *stream) {
+    using namespace tcv;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipFuncSetAttribute((const void *)solve_kernel<256, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((solve_kernel<256, true, true, true>), dim3(grid), dim3(256), lds_bytes, st, *args);
+    return (int)hipGetLastError();
+}
+#elif defined(TCV_SOLVE_CHAIN_TU)
 extern "C" int tcv_launch_solve_chain(const tcv::SolveArgs *args, int grid, size_t lds_bytes, void *stream) {
     using namespace tcv;
     hipStream_t st = (hipStream_t)stream;
@@ -2080,8 +2490,10 @@ extern "C" int tcv_launch_solve_chain(const tcv::SolveArgs *args, int grid, size
 }
 #else
 extern "C" int tcv_launch_solve_chain(const tcv::SolveArgs *args, int grid, size_t lds_bytes, void *stream);
+extern "C" int tcv_launch_solve_coop(const tcv::SolveArgs *args, int grid, size_t lds_bytes, void *stream);
 extern "C" int tcv_launch_solve(const tcv::SolveArgs *args, int grid, int nthreads, size_t lds_bytes, void *stream) {
     using namespace tcv;
+    if (args->chain && args->coop_h > 0) return tcv_launch_solve_coop(args, grid, lds_bytes, stream);
     if (args->chain) return tcv_launch_solve_chain(args, grid, lds_bytes, stream);
     hipStream_t st = (hipStream_t)stream;
     hipError_t e;

@@ -37,7 +37,7 @@ EXPORTS = [
     "tcv_batch_download_states", "tcv_batch_get_summaries", "tcv_batch_get_prior", "tcv_batch_get_first_step",
     "tcv_batch_plan_stats", "tcv_batch_layout", "tcv_batch_stats", "tcv_batch_size",
     "tcv_eval_imu_factors", "tcv_eval_projection_factors", "tcv_eval_line_factors", "tcv_pose_plus", "tcv_preintegrate",
-    "tcv_problem_set_frames", "tcv_gauge_fix", "tcv_batch_gauge_fix", "tcv_set_solver_variant", "tcv_batch_marg_status", "tcv_eval_projection_td_factors", "tcv_match_lines",
+    "tcv_problem_set_frames", "tcv_gauge_fix", "tcv_batch_gauge_fix", "tcv_set_solver_variant", "tcv_set_cooperative", "tcv_batch_cooperative", "tcv_batch_marg_status", "tcv_eval_projection_td_factors", "tcv_match_lines",
     "tcv_batch_download_priors", "tcv_batch_download_priors_compact",
 ]
 
@@ -50,7 +50,7 @@ class ImuPreintegration(C.Structure):
 
 class SolverOptions(C.Structure):
     _fields_ = [("max_num_iterations", C.c_int), ("max_solver_time_in_seconds", C.c_double),
-                ("fixed_iterations", C.c_int), ("compute_sqrt_info_on_device", C.c_int), ("use_mfma", C.c_int),
+                ("fixed_iterations", C.c_int), ("workgroups_per_window", C.c_int), ("use_mfma", C.c_int),
                 ("threads_per_window", C.c_int), ("record_first_step", C.c_int)]
 
 
@@ -179,9 +179,10 @@ def i32(a):
     return np.ascontiguousarray(a, dtype=np.int32)
 
 
-def default_options(max_num_iterations=8, fixed_iterations=True, use_mfma=True, threads=256, record_first_step=False):
+def default_options(max_num_iterations=8, fixed_iterations=True, use_mfma=True, threads=256, record_first_step=False, workgroups_per_window=0):
     o = SolverOptions()
     lib().tcv_solver_options_default(C.byref(o))
+    o.workgroups_per_window = workgroups_per_window
     o.max_num_iterations = max_num_iterations
     o.fixed_iterations = int(fixed_iterations)
     o.use_mfma = int(use_mfma)
@@ -470,6 +471,11 @@ class Batch:
         a, b, c, d = C.c_int(), C.c_double(), C.c_int(), C.c_int()
         check(lib().tcv_batch_plan_stats(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
         return dict(num_plans=a.value, plan_bytes=b.value, grid=c.value, lds_bytes=d.value, layout=("chain", "dense")[lib().tcv_batch_layout(self.h)])
+
+    def cooperative(self):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        check(lib().tcv_batch_cooperative(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(helpers=a.value, groups=b.value, chunks=c.value)
 
     def __del__(self):
         if getattr(self, "h", None) is not None and _lib is not None:

@@ -304,4 +304,4 @@ def test_prior_create_rejects_malformed_layouts(tcv):
 
 def test_solver_options_document_the_iteration_limit():
     hdr = open(os.path.join(ROOT, "include", "tcv.h")).read()
-    assert "may exceed TCV_MAX_TRACE" in hdr and "reserved, ignored" in hdr
+    assert "may exceed TCV_MAX_TRACE" in hdr and "workgroups_per_window" in hdr and "reserved, ignored" not in hdr

@@ -1,0 +1,95 @@
+"""GPU tests of the cooperative small-batch mode of the fused solver (include/tcv.h tcv_set_cooperative; tc-viml_amd/csrc/tcv_solve.hip
+linearize_coop / coop_helper): a window on 1 + H workgroups.  The mode changes WHERE the point / line factors are evaluated and the
+landmarks eliminated, not a single addition: the same batch solved with one workgroup per window (workgroups_per_window = 1) must
+give the same bits; against the oracle the usual gates hold (every other small-batch GPU test runs in this mode by default)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import synth
+from util import golden_windows, rel
+
+pytestmark = pytest.mark.gpu
+
+
+def _solve(gpu, wins, iters, fixed, wg, marg=False):
+    W = [gpu.Window(w) for w in wins]
+    if marg:
+        MW = [gpu.margin_old_window(w) for w in wins]
+        M = [gpu.Window(mw, share=W[k], prior=W[k].prior) for k, mw in enumerate(MW)]
+        drops = [gpu.margin_old_drops(W[k], MW[k]) for k in range(len(wins))]
+        b = gpu.Batch(W, M, drops)
+    else:
+        b = gpu.Batch(W)
+    b.solve(gpu.default_options(iters, fixed, workgroups_per_window=wg))
+    if marg:
+        b.gauge_fix(); b.marginalize()
+    b.synchronize(); b.download_states()
+    return W, b, b.summaries()
+
+
+def _same_bits(sa, sb, Wa, Wb, n):
+    for k in range(n):
+        assert sa[k].num_iterations == sb[k].num_iterations and sa[k].termination == sb[k].termination, k
+        m = min(sa[k].num_iterations, 64)
+        for f in ("cost", "cost_candidate", "model_cost_change", "radius", "rho", "step_norm"):
+            a = np.array([getattr(sa[k], f)[i] for i in range(m)]); c = np.array([getattr(sb[k], f)[i] for i in range(m)])
+            assert np.array_equal(a, c), (k, f, a - c)
+        assert sa[k].final_cost == sb[k].final_cost
+        for f in ("pose", "sb", "ex", "lam"):
+            assert np.array_equal(getattr(Wa[k], f), getattr(Wb[k], f)), (k, f)
+
+
+def test_cooperative_mode_is_bit_identical_to_one_workgroup_per_window(gpu):
+    pre, main, z = golden_windows()
+    wins = [main, pre] + [synth.window_at(synth.make_windows(910, 3), k) for k in range(3)]
+    Wc, bc, sc = _solve(gpu, wins, 8, True, 0)
+    co = bc.cooperative()
+    assert co["helpers"] >= 2 and co["groups"] == len(wins) and co["chunks"] >= co["helpers"], co
+    W1, b1, s1 = _solve(gpu, wins, 8, True, 1)
+    assert b1.cooperative() == co                       # the same plan, run by one workgroup per window
+    _same_bits(sc, s1, Wc, W1, len(wins))
+    # to convergence with the Ceres tolerances (accept / reject and termination decisions included)
+    Wc, bc, sc = _solve(gpu, wins, 40, False, 0)
+    W1, b1, s1 = _solve(gpu, wins, 40, False, 1)
+    _same_bits(sc, s1, Wc, W1, len(wins))
+    assert max(s.num_iterations for s in sc) > 9
+
+
+def test_cooperative_mode_on_a_replay_sized_window_and_more_chunks_than_helpers(gpu):
+    """~560 point + 40 line factors (a front-end-sized window): seven helpers; with two helpers forced every helper serves several
+    chunks.  Both bit-identical to the one-workgroup run of their own plan; the two plans (different chunkings) agree to rounding."""
+    pre, main, z = golden_windows()
+    big = synth.window_at(synth.make_windows(77, 1, n_landmarks=140), 0)
+    w = dict(main)
+    for k in ("proj", "lam"):
+        w[k] = big[k]
+    res = {}
+    try:
+        for h in (-1, 2):
+            gpu.check(gpu.lib().tcv_set_cooperative(h))
+            Wc, bc, sc = _solve(gpu, [w], 8, True, 0, marg=True)
+            co = bc.cooperative()
+            assert co["helpers"] == (7 if h < 0 else 2) and co["chunks"] >= co["helpers"], co
+            W1, b1, s1 = _solve(gpu, [w], 8, True, 1, marg=True)
+            _same_bits(sc, s1, Wc, W1, 1)
+            assert np.array_equal(bc.prior(0).export()["J0"], b1.prior(0).export()["J0"])
+            res[h] = (sc[0].final_cost, Wc[0].pose.copy())
+    finally:
+        gpu.check(gpu.lib().tcv_set_cooperative(-1))
+    assert abs(res[-1][0] - res[2][0]) < 1e-9 * res[2][0] and rel(res[-1][1], res[2][1]) < 1e-9
+
+
+def test_cooperative_mode_off_and_large_batches_keep_one_workgroup_per_window(gpu):
+    wins = [synth.window_at(synth.make_windows(920, 2), k) for k in range(2)]
+    try:
+        gpu.check(gpu.lib().tcv_set_cooperative(0))
+        W, b, s = _solve(gpu, wins, 4, True, 0)
+        assert b.cooperative()["helpers"] == 0
+    finally:
+        gpu.check(gpu.lib().tcv_set_cooperative(-1))
+    assert gpu.lib().tcv_set_cooperative(9) == gpu.TCV_ERR_INVALID
+    many = [synth.window_at(synth.make_windows(930, 130), k) for k in range(130)]      # 130 x (1 + 2) > 256 CUs: no room for helpers
+    W, b, s = _solve(gpu, many, 2, True, 0)
+    assert b.cooperative()["helpers"] <= 0 or 130 * (1 + b.cooperative()["helpers"]) <= 256

@@ -11,8 +11,9 @@ import numpy as np
 import synth, tcv, replay, bench
 from tools_common import PHASE_NAMES
 
-FRAME = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-REPS = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+_pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+FRAME = int(_pos[0]) if len(_pos) > 0 else 60
+REPS = int(_pos[1]) if len(_pos) > 1 else 12
 PROF = "prof" in os.environ.get("TCV_LIB", "")
 
 
@@ -52,17 +53,27 @@ def measure(name, make):
     prof = np.zeros(32)
     b, Ws, keep = make()
     L.tcv_batch_profile.argtypes = [C.c_void_p, tcv._dp]
+    t1 = []
     for rep in range(REPS):
         if PROF and rep == REPS - 1:
             L.tcv_batch_profile(b.h, tcv.dptr(prof))      # clears the accumulators
         b.solve(tcv.default_options(8, True)); b.gauge_fix(); b.marginalize(); b.synchronize()
         s = b.stats(); ts.append(s["solve_ms"]); tm.append(s["marg_ms"])
+    co = b.cooperative()
+    if co["helpers"] > 0:      # the same plan on one workgroup per window
+        for rep in range(REPS):
+            b.solve(tcv.default_options(8, True, workgroups_per_window=1)); b.synchronize()
+            t1.append(b.stats()["solve_ms"])
     if PROF:
         L.tcv_batch_profile(b.h, tcv.dptr(prof))
     ps = b.plan_stats()
     W0 = Ws[0].plan_stats()
-    print("%-44s half-LDS chunks %d, lds %d KB, grid %d | solve %.3f ms (min %.3f)  marg %.3f ms (min %.3f)  sum %.3f ms" % (
-        name, W0["n_vis_chunk"], ps["lds_bytes"] // 1024, ps["grid"], np.median(ts), min(ts), np.median(tm), min(tm), np.median(ts) + np.median(tm)), flush=True)
+    print("%-44s helpers %d, chunks %d, grid %d | solve %.3f ms (min %.3f)  marg %.3f ms (min %.3f)  sum %.3f ms%s" % (
+        name, co["helpers"], co["chunks"], ps["grid"], np.median(ts), min(ts), np.median(tm), min(tm), np.median(ts) + np.median(tm),
+        ("  | same plan, one workgroup per window: solve %.3f ms" % np.median(t1)) if t1 else ""), flush=True)
+    if PROF and os.environ.get("TCV_DEBUG"):
+        print("   marginalisation phases of window 0: see stderr", flush=True)
+        b.prior(0)
     if PROF:
         tot = prof.sum()
         print("   phase cycles of the solve kernel (last repetition, summed over the windows of the batch):")
@@ -72,7 +83,7 @@ def measure(name, make):
 
 
 if __name__ == "__main__":
-    for B in (1, 5):
+    for B in (() if "--replay-only" in sys.argv else (1, 5)):
         def make(B=B):
             batch, wins, keep = bench.build_batches(tcv, synth, 100000, B)
             return batch, keep[0], keep
