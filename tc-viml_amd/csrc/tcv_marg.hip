@@ -37,7 +37,7 @@ enum { MARG_MAX_M = 64, MARG_MAX_N = 80, MARG_MAX_POS = MARG_MAX_M + MARG_MAX_N,
 // Two launch shapes of the one kernel: 512 threads per window and one workgroup per CU (few windows: shortest time per window), or
 // 256 threads per window and two workgroups per CU when every window of the batch fits 80 KB of LDS (many windows: the barrier and
 // LDS round trips of one window hide behind the other's arithmetic).
-enum { MARG_NT_WIDE = 512, MARG_NT_PAIR = 256, MARG_SM = 720, MARG_STAGE = 64 * 43 };
+enum { MARG_NT_WIDE = 512, MARG_NT_PAIR = 256, MARG_SM = 720, MARG_STAGE = 64 * 43, MARG_CB_LM = 16 };
 // per-window result block: [J0 | r0 | x (linearisation point) + 64 diagnostics] is what a caller needs (MARG_OUT_COMPACT doubles, the
 // part tcv_batch_download_priors_compact copies); A', b' (parity / debug surface) follow
 enum { MARG_OUT_J0 = 0, MARG_OUT_R0 = 6400, MARG_OUT_X = 6480, MARG_OUT_COMPACT = 6480 + 1408 + 64, MARG_OUT_AS = MARG_OUT_COMPACT, MARG_OUT_BS = MARG_OUT_AS + 6400,
@@ -62,6 +62,12 @@ struct MargHdr {
     int block_mode;   // 1: the marginalised inverse depths (1 x 1 blocks) are eliminated by scalar pivots while the factors are
                       // accumulated, only the frame part of the dropped set (m) goes through the eigen pseudo-inverse
     int o_plast;      // block mode: n_proj flags, 1 = last factor of its landmark (factors sorted by landmark)
+    // block mode, chunked path (proj_disjoint, no Td): the factors come in chunks of whole landmarks (<= 64 factors, <= MARG_CB_LM eliminated
+    // landmarks); per chunk the landmarks' couplings C (landmark x camera column), diagonals and gradients are accumulated next to the
+    // camera-camera J'J, and A -= C diag(1/hll) C', b -= C diag(1/hll) gl is ONE rank-16 update on the matrix cores
+    int n_pchunk, o_pchunk;   // n_pchunk x 4: first factor, factors, eliminated landmarks, 0
+    int o_plm;                // n_proj: index of the factor's landmark among the chunk's eliminated landmarks (-1: its landmark is a regular column)
+    int cb_off, cb_stride;    // LDS offset (doubles) and row stride of C: [MARG_CB_LM x cb_stride | hll MARG_CB_LM | gl MARG_CB_LM]; cb_off < 0: old path
     int td_blk;       // >= 0: the point factors are ProjectionTdFactors on this block (d_proj then holds 14 doubles per factor)
     int sqrt_src;        // >= 0: index of the (single) IMU factor among the solve problem's IMU factors: its sqrt_info was computed by the solve
     int proj_disjoint;   // 1: no block is the frame-i pose of one point factor and the frame-j pose of another (MARGIN_OLD: every factor is
@@ -614,7 +620,8 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((amdgpu_waves_per_eu(2,
         const int me = m + (m & 1), ne = n + (n & 1);
         const int r1 = max(npk, ne * (ne + 1));
         lds_d *R2 = lds + ((r1 + 1) & ~1);
-        const int r2 = max(max((int)MARG_STAGE, me * (me + 1) + max(me * (me + 1), m * (n + 1))), (n - 2) * (n - 1) / 2 + 1);
+        const int cb_in_r2 = (H.cb_off >= 0 && H.cb_off >= ((r1 + 1) & ~1)) ? MARG_CB_LM * H.cb_stride + 2 * MARG_CB_LM : 0;      // C behind the staging records
+        const int r2 = max(max((int)MARG_STAGE + cb_in_r2, me * (me + 1) + max(me * (me + 1), m * (n + 1))), (n - 2) * (n - 1) / 2 + 1);
         lds_d *bv = R2 + ((r2 + 1) & ~1);                   // pos
         lds_d *x = bv + MARG_MAX_POS;                       // nx
         lds_d *rot = x + ((H.nx + 7) & ~7);                 // 160
@@ -833,7 +840,103 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((amdgpu_waves_per_eu(2,
         const bool with_td = H.td_blk >= 0;
         const int prs = with_td ? 21 : (int)PROJ_STRIDE, prr = with_td ? 43 : (int)PROJ_REC;
         const int njc = with_td ? 20 : 19;                    // Jacobian columns; logical column k lives at record column (k == 19 ? 20 : k)
-        for (int f0 = 0; f0 < H.n_proj; f0 += 64) {
+        const bool cb_path = H.block_mode && H.cb_off >= 0;
+        for (int pc = 0; cb_path && pc < H.n_pchunk; pc++) {
+            cst_i *pch = ip + H.o_pchunk + pc * 4;
+            const int f0 = pch[0], fn = pch[1];
+            lds_d *Cb = lds + H.cb_off, *hl = Cb + MARG_CB_LM * H.cb_stride, *glv = hl + MARG_CB_LM;
+            const int cbs = H.cb_stride;
+            for (int i = tid; i < MARG_CB_LM * cbs + 2 * MARG_CB_LM; i += MARG_NT) Cb[i] = 0.0;
+            if (tid < fn) {
+                cst_i *pf = ip + H.o_proj + (f0 + tid) * 4;
+                lds_d *rec = stage + tid * prr;
+                double r[2], pts[6];
+#pragma unroll
+                for (int i = 0; i < 6; i++) pts[i] = dp[H.d_proj + (f0 + tid) * 6 + i];
+                proj_eval(CGEN(x + blk[pf[0] * 5 + 1]), CGEN(x + blk[pf[1] * 5 + 1]), CGEN(x + blk[pf[2] * 5 + 1]), x[blk[pf[3] * 5 + 1]],
+                          pts, misc[3], r, GEN(rec), PROJ_STRIDE);
+                (void)loss_correct2(r, GEN(rec), 19, PROJ_STRIDE, misc[4]);
+                rec[19] = r[0]; rec[PROJ_STRIDE + 19] = r[1];
+            }
+            __syncthreads();
+            {
+                // one thread per entry (ca >= cb, or cb = residual column) of the 19 x 20 factor record, all factors of the chunk in factor order,
+                // the running destination kept in a register while consecutive factors hit the same element.  Row 18 (the inverse depth) of a
+                // factor whose landmark is eliminated goes to the landmark's row of C / hll / gl instead of A.
+                const int ntri = 19 * 20 / 2;
+                cst_i *plm = ip + H.o_plm + f0;
+                for (int t = tid; t < ntri + 19; t += MARG_NT) {
+                    int ca, cb;
+                    if (t < ntri) { ca = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5); while ((ca + 1) * (ca + 2) / 2 <= t) ca++; while (ca * (ca + 1) / 2 > t) ca--; cb = t - ca * (ca + 1) / 2; }
+                    else { ca = t - ntri; cb = 19; }
+                    const int ga = ca < 18 ? ca / 6 : 3, oa = ca < 18 ? ca % 6 : 0;
+                    const int gb = cb < 18 ? cb / 6 : 3, ob = cb < 18 ? cb % 6 : 0;
+                    const int rb = cb == 19 ? 19 : cb;      // record column of cb (19 = the residual)
+                    // destinations as offsets from the workgroup's LDS base (>= 0; the packed A starts at offset 0, so a null pointer cannot
+                    // stand for "none")
+                    int prev = -1;
+                    double accv = 0.0;
+                    const int o_bv = (int)(bv - lds), o_cb = (int)(Cb - lds), o_hl = (int)(hl - lds), o_gl = (int)(glv - lds);
+                    for (int f = 0; f < fn; f++) {
+                        cst_i *pf = ip + H.o_proj + (f0 + f) * 4;
+                        const int l0 = blk[pf[0] * 5 + 2], l1 = blk[pf[1] * 5 + 2], l2 = blk[pf[2] * 5 + 2], l3 = blk[pf[3] * 5 + 2];
+                        const int lml = plm[f];
+                        const int la = ga == 0 ? l0 : (ga == 1 ? l1 : (ga == 2 ? l2 : l3));
+                        const int lb = gb == 0 ? l0 : (gb == 1 ? l1 : (gb == 2 ? l2 : l3));
+                        const lds_d *rec = stage + f * prr;
+                        const double sv = rec[ca] * rec[rb] + rec[prs + ca] * rec[prs + rb];
+                        int d = -1;
+                        if (ca == 18 && lml >= 0) {      // (18, column of a camera block) -> C, (18, 18) -> hll, (18, residual) -> gl
+                            if (cb < 18) { if (lb >= 0) d = o_cb + lml * cbs + lb + ob; }
+                            else d = (cb == 18 ? o_hl : o_gl) + lml;
+                        } else if (la >= 0 && (cb == 19 || lb >= 0)) d = cb == 19 ? o_bv + la + oa : pidx(la + oa, lb + ob);
+                        if (d < 0) continue;
+                        if (d != prev) {
+                            if (prev >= 0) lds[prev] = accv;
+                            accv = lds[d];
+                            prev = d;
+                        }
+                        accv += sv;
+                    }
+                    if (prev >= 0) lds[prev] = accv;
+                }
+            }
+            __syncthreads();
+            {
+                // A -= C' diag(1 / hll) C over the lower triangle (pseudo-inverse: a landmark without information, hll <= eps, contributes
+                // nothing), 16 x 16 tiles on the matrix cores, K = the chunk's landmarks; b -= C' diag(1 / hll) gl
+                typedef double v4f64 __attribute__((ext_vector_type(4)));
+                constexpr int NWV = MARG_NT / 64;
+                const int lane = tid & 63, wave = tid >> 6, col = lane & 15, row0 = lane >> 4;
+                const int nt16 = (pos + 15) >> 4;
+                double ih[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) { const double h = hl[4 * kk + row0]; ih[kk] = h > 1e-8 ? 1.0 / h : 0.0; }
+                for (int t = wave; t < nt16 * (nt16 + 1) / 2; t += NWV) {
+                    int I = 0;
+                    while ((I + 1) * (I + 2) / 2 <= t) I++;
+                    const int J = t - I * (I + 1) / 2;
+                    double av[4], bw[4];
+#pragma unroll
+                    for (int kk = 0; kk < 4; kk++) { const lds_d *row = Cb + (4 * kk + row0) * cbs; av[kk] = row[16 * I + col] * ih[kk]; bw[kk] = row[16 * J + col]; }
+                    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bw[kk], acc, 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int ra2 = 16 * I + row0 + 4 * i, cc = 16 * J + col;
+                        if (ra2 < pos && cc <= ra2) Apk[pidx(ra2, cc)] -= acc[i];
+                    }
+                }
+                if (tid < pos) {
+                    double sb = 0.0;
+                    for (int l = 0; l < MARG_CB_LM; l++) { const double h = hl[l]; sb += Cb[l * cbs + tid] * (glv[l] * (h > 1e-8 ? 1.0 / h : 0.0)); }
+                    bv[tid] -= sb;
+                }
+            }
+            __syncthreads();
+        }
+        for (int f0 = 0; !cb_path && f0 < H.n_proj; f0 += 64) {
             const int fn = min(64, H.n_proj - f0);
             if (tid < fn) {
                 cst_i *pf = ip + H.o_proj + (f0 + tid) * 4;
@@ -1181,10 +1284,10 @@ static void marg_free(tcv_batch *b) {
 
 // LDS doubles one window needs (the kernel's carve): [P: packed A, later A' and its eigenvectors | R2: staging records (64 x 43: a
 // ProjectionTdFactor record is 2 x 21 + 1), later Amm + V, later the packed reflectors | b | x | rot | lam | landmark row | eigen vectors]
-static size_t marg_lds_doubles(int pos, int m, int n, int nx) {
+static size_t marg_lds_doubles(int pos, int m, int n, int nx, int cb_in_r2 = 0) {
     const int me = m + (m & 1), ne = n + (n & 1);
     const int r1 = std::max(pos * (pos + 1) / 2, ne * (ne + 1));
-    const int r2 = std::max(std::max((int)MARG_STAGE, me * (me + 1) + std::max(me * (me + 1), m * (n + 1))), (n - 2) * (n - 1) / 2 + 1);
+    const int r2 = std::max(std::max((int)MARG_STAGE + cb_in_r2, me * (me + 1) + std::max(me * (me + 1), m * (n + 1))), (n - 2) * (n - 1) / 2 + 1);
     return (size_t)((r1 + 1) & ~1) + ((r2 + 1) & ~1) + MARG_MAX_POS + ((nx + 7) & ~7) + 160 + MARG_MAX_N + MARG_MAX_POS + 8 + MARG_SM;
 }
 
@@ -1315,6 +1418,39 @@ static int pack_marg(const tcv_problem &p, double *const *drop, int ndrop, const
     H.o_plast = imark();
     for (size_t i = 0; i < porder.size(); i++)
         I.push_back(block_mode && lm_id[p.proj[porder[i]].b[3]] >= 0 && (i + 1 == porder.size() || p.proj[porder[i + 1]].b[3] != p.proj[porder[i]].b[3]) ? 1 : 0);
+    // chunked block path: chunks of whole landmarks, the landmarks' couplings eliminated by one rank-16 update per chunk
+    H.cb_off = -1; H.cb_stride = 0; H.n_pchunk = 0; H.o_pchunk = imark(); H.o_plm = imark();
+    if (block_mode && H.proj_disjoint && H.td_blk < 0 && !getenv("TCV_MARG_BLOCK_SERIAL")) {
+        std::vector<int> chunks, plm(porder.size(), -1);
+        size_t i = 0;
+        while (i < porder.size()) {
+            const size_t c0 = i;
+            int nl = 0;
+            while (i < porder.size()) {
+                size_t j = i;      // the factors of one landmark: [i, j)
+                const int lmb = p.proj[porder[i]].b[3];
+                while (j < porder.size() && p.proj[porder[j]].b[3] == lmb) j++;
+                const bool elim = lm_id[lmb] >= 0;
+                if (i > c0 && (j - c0 > 64 || (elim && nl == MARG_CB_LM))) break;
+                if (j - c0 > 64) { j = c0 + 64; if (elim) { chunks.clear(); i = porder.size(); break; } }      // (a landmark with more than 64 factors: old path)
+                for (size_t q = i; q < j; q++) plm[q] = elim ? nl : -1;
+                if (elim) nl++;
+                i = j;
+            }
+            if (i == porder.size() && chunks.empty() && c0 != 0) break;
+            chunks.push_back((int)c0); chunks.push_back((int)(i - c0)); chunks.push_back(nl); chunks.push_back(0);
+        }
+        if (!chunks.empty() || porder.empty()) {
+            H.n_pchunk = (int)chunks.size() / 4;
+            H.o_pchunk = imark(); I.insert(I.end(), chunks.begin(), chunks.end());
+            H.o_plm = imark(); I.insert(I.end(), plm.begin(), plm.end());
+            const int ne = n + (n & 1), npk = pos * (pos + 1) / 2, r1 = std::max(npk, ne * (ne + 1));
+            H.cb_stride = (pos + 15) & ~15;
+            const int need = MARG_CB_LM * H.cb_stride + 2 * MARG_CB_LM;
+            if (r1 - ((npk + 1) & ~1) >= need) H.cb_off = (npk + 1) & ~1;                      // in the part of region P the packed A does not use
+            else H.cb_off = ((r1 + 1) & ~1) + (int)MARG_STAGE;                                 // behind the staging records in region R2
+        }
+    }
     H.o_prior = imark();
     std::vector<int> pcol;
     const tcv_prior *pr = p.prior.empty() ? nullptr : p.prior[0].prior;
@@ -1406,7 +1542,9 @@ int tcv_marg_attach(tcv_batch *b, tcv_problem *const *marg_problems, double *con
         for (int w = r.first; w < r.second; w++) {
             s->win[w].hdr.ibase += (long long)ib[t]; s->win[w].hdr.dbase += (long long)db[t];
             hdrs[w] = s->win[w].hdr;
-            const size_t need = marg_lds_doubles(hdrs[w].pos, hdrs[w].m, hdrs[w].n, hdrs[w].nx) * 8;
+            const int ne_ = hdrs[w].n + (hdrs[w].n & 1), r1_ = std::max(hdrs[w].pos * (hdrs[w].pos + 1) / 2, ne_ * (ne_ + 1));
+            const int cb_r2 = (hdrs[w].cb_off >= 0 && hdrs[w].cb_off >= ((r1_ + 1) & ~1)) ? MARG_CB_LM * hdrs[w].cb_stride + 2 * MARG_CB_LM : 0;
+            const size_t need = marg_lds_doubles(hdrs[w].pos, hdrs[w].m, hdrs[w].n, hdrs[w].nx, cb_r2) * 8;
             if (need > (size_t)LDS_DOUBLES * 8) { set_error("marginalisation does not fit LDS"); return TCV_ERR_TOO_LARGE; }
             lds = std::max(lds, need);
         }
