@@ -227,7 +227,7 @@ def _cpu_model():
 
 
 # ---- PCIe-inclusive figures ---------------------------------------------------------------------------------------------
-def stream_figures(tcv, torch, keep, B_stream: int = 512, rounds: int = 4):
+def stream_figures(tcv, torch, keep, B_stream: int = 512, rounds: int = 4, wins=None, local: int = 0):
     """host-resident problems -> tcv_batch_create (pack + H2D) -> solve -> gauge fix -> marginalisation -> D2H of states and
     priors -> destroy, overlapped: two to four host threads, each with its own windows and HIP stream, so that one batch packs / copies
     while another computes.  Also the end-to-end and kernel-only latency of ONE window (the real-time single-estimator case)."""
@@ -238,24 +238,26 @@ def stream_figures(tcv, torch, keep, B_stream: int = 512, rounds: int = 4):
     NTH = int(os.environ.get("TCV_STREAM_THREADS", str(max(2, min(4, len(Wm) // B_stream)))))
     B = min(B_stream, len(Wm) // NTH)
     opts = tcv.default_options(SOLVER_ITERATIONS, True)
-    halves = [(Wm[i * B:(i + 1) * B], Mm[i * B:(i + 1) * B], dropsm[i * B:(i + 1) * B]) for i in range(NTH)]
+    # (the argument arrays of tcv_batch_create -- handles and drop lists -- are built once per window set: a C++ caller has them at hand)
+    halves = [tcv.BatchSpec(Wm[i * B:(i + 1) * B], Mm[i * B:(i + 1) * B], dropsm[i * B:(i + 1) * B]) for i in range(NTH)]
     stage = {"pack_h2d": 0.0, "compute": 0.0, "d2h": 0.0}
 
     def one_pass(h, stream_ptr, acc=None):
         t0 = time.perf_counter()
-        b = tcv.Batch(*h)
+        b = tcv.Batch(None, spec=h) if isinstance(h, tcv.BatchSpec) else tcv.Batch(*h)
         t1 = time.perf_counter()
         b.solve(opts, stream_ptr); b.gauge_fix(stream_ptr); b.marginalize(stream_ptr); b.synchronize()
         t2 = time.perf_counter()
         b.download_states(); b.download_priors(compact=True)
-        for k in range(len(h[0])):
-            b.prior(k)
+        pri = b.priors()      # host-resident tcv_prior of every window (J0, r0, linearisation point): what the next frame's problem takes
         t3 = time.perf_counter()
+        del pri
         del b
         if acc is not None:
             acc["pack_h2d"] += t1 - t0; acc["compute"] += t2 - t1; acc["d2h"] += t3 - t2
 
     def worker(h, st):
+        tcv.check(tcv.lib().tcv_set_device(local))      # the current HIP device is per host thread
         for _ in range(rounds):
             one_pass(h, st.cuda_stream)
 
@@ -270,17 +272,26 @@ def stream_figures(tcv, torch, keep, B_stream: int = 512, rounds: int = 4):
     for t in th:
         t.join()
     dt = time.perf_counter() - t0
-    # one window: kernel-only (resident) and end-to-end (tcv_solve + tcv_marginalize on host blocks)
-    one = ([Wm[0]], [Mm[0]], [dropsm[0]])
+    # one window: kernel-only (resident) and end-to-end (host blocks -> batch -> solve -> gauge fix -> marginalisation -> states and prior back).
+    # The window is built afresh from its INITIAL states: the passes above left the batch's windows solved (download_states writes into the
+    # caller's blocks, like ceres::Solve), and a converged window rejects its steps, i.e. skips most linearisations (round 2 timed that: 1.18 ms).
+    def fresh_one():
+        if wins is None:
+            return ([Wm[0]], [Mm[0]], [dropsm[0]])
+        W1 = tcv.Window(wins[0]); mw = tcv.margin_old_window(wins[0]); M1 = tcv.Window(mw, share=W1, prior=W1.prior)
+        return ([W1], [M1], [tcv.margin_old_drops(W1, mw)])
+    one = fresh_one()
     b1 = tcv.Batch(*one)
+    co1 = b1.cooperative()
     lat = []
     for _ in range(12):
         t1 = time.perf_counter()
-        b1.solve(opts); b1.gauge_fix(); b1.marginalize(); b1.synchronize()
+        b1.solve(opts); b1.gauge_fix(); b1.marginalize(); b1.synchronize()      # (resident: every repetition starts from the batch's initial states)
         lat.append(time.perf_counter() - t1)
     st1 = b1.stats()
     e2e = []
     for _ in range(6):
+        one = fresh_one()
         t1 = time.perf_counter()
         one_pass(one, None)
         e2e.append(time.perf_counter() - t1)
@@ -289,7 +300,9 @@ def stream_figures(tcv, torch, keep, B_stream: int = 512, rounds: int = 4):
                            f"marginalisation on the thread's own HIP stream, D2H of states and priors; serial stage times per {B}-window pass [ms]: "
                            + ", ".join(f"{k} {1e3 * v / 2:.1f}" for k, v in stage.items()),
             "single_window_ms": {"resident_launch_to_sync": 1e3 * float(np.median(lat)), "kernels": st1["solve_ms"] + st1["marg_ms"],
-                                 "host_blocks_end_to_end": 1e3 * float(np.median(e2e))}}
+                                 "solve_kernel": st1["solve_ms"], "marg_kernel": st1["marg_ms"], "host_blocks_end_to_end": 1e3 * float(np.median(e2e)),
+                                 "workgroups_per_window": 1 + co1["helpers"],
+                                 "note": "one cfg-3 window from its initial states, 8 full iterations (cooperative small-batch kernels)"}}
 
 
 # ---- modes ----------------------------------------------------------------------------------------------------------------
@@ -400,7 +413,8 @@ def run_solve(args, rank, world, local, dist):
                        "note": "fused FP64 solve: latency/issue bound, not HBM bound (DESIGN.md 4.1); frac is vs "
                                "the 8 TB/s HBM3E spec; traffic = PMC FETCH_SIZE x2 + WRITE_SIZE of profiles/pmc_traffic.json (static, from the committed profile run)"}
     if world == 1 and not args.no_extras:
-        out.update(stream_figures(tcv, torch, keep))
+        out.update(stream_figures(tcv, torch, keep, wins=wins, local=local))
+        out.update(replay_figures(tcv, local))
     if pool is not None:
         out["cpu_baseline"] = cpu_baseline(wins, pool, nproc, args.cpu_budget)
         out["gpu_over_cpu_all_cores"] = out["value"] / out["cpu_baseline"]["value"]
@@ -417,20 +431,63 @@ def run_stream(args, rank, world, local, dist):
     tcv.check(tcv.lib().tcv_set_device(local))
     torch.cuda.set_device(local)
     _b, _w, keep = build_batches(tcv, synth, shard_ids(rank, args.windows), args.windows)
-    out = stream_figures(tcv, torch, keep, rounds=max(1, args.steps // 4))
+    out = stream_figures(tcv, torch, keep, rounds=max(1, args.steps // 4), wins=_w, local=local)
     if rank == 0:
         print(json.dumps(dict(metric="PCIe-inclusive streaming solves/sec (10 kf, 200 pt, 40 line)", value=out["stream_solves_per_s"], unit="solves/s",
                               n_gpus=1, higher_is_better=True, dtype="f64", data="synthetic", **out)))
 
 
+class ReplayEngine:
+    """EuRoC-trajectory streams through the native estimator (include/tcv_estimator.h), `groups` host threads each advancing its own
+    share of the streams in lock step (one device batch per frame and group): while one group's kernels run, the others pack and
+    upload.  Frames of ONE stream stay sequential (frame k + 1 needs frame k's states and prior).  A step = one frame of every stream."""
+
+    def __init__(self, tcv, replay, stream_ids, n_frames, features, lines, groups, local):
+        self.tcv, self.local = tcv, local
+        seqs = list(replay.EUROC_SEQUENCES)
+        streams = [replay.simulate_stream_euroc(seqs[s % len(seqs)], n_frames, start_s=0.5 + 3.0 * (s // len(seqs)), max_features=features,
+                                                max_lines=lines, associate=True) for s in stream_ids]
+        G = max(1, min(groups, len(streams)))
+        self.ls = [replay.NativeLockstep(streams[g::G], num_iterations=SOLVER_ITERATIONS) for g in range(G)] if streams else []
+        for ls in self.ls:
+            ls.prepare()
+        self.k = 0
+        while self.ls and self.k < n_frames:      # window fill: frames 0 .. WINDOW_SIZE, the last one triggers the first optimisation
+            r = sum(ls.step(self.k) for ls in self.ls)
+            self.k += 1
+            if r:
+                break
+        if not self.ls:
+            self.k = replay.WINDOW_SIZE + 1
+
+    def run(self, steps: int) -> int:
+        """`steps` frames of every stream; returns the number of windows optimised"""
+        import threading
+        k0, counts = self.k, [0] * len(self.ls)
+
+        def work(g):
+            self.tcv.check(self.tcv.lib().tcv_set_device(self.local))      # the current device is per host thread
+            for k in range(k0, k0 + steps):
+                counts[g] += self.ls[g].step(k)
+
+        if len(self.ls) == 1:
+            work(0)
+        else:
+            th = [threading.Thread(target=work, args=(g,)) for g in range(len(self.ls))]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+        self.k += steps
+        return sum(counts)
+
+
 def run_replay(args, rank, world, local, dist):
-    """BASELINE configs[4]: EuRoC-trajectory streams sharded s mod G; every rank advances its streams in lock step."""
+    """BASELINE configs[4]: EuRoC-trajectory streams sharded s mod G over the ranks; every rank advances its streams frame by frame."""
     mine = shard_streams(args.streams, rank, world)
     if DRY:
         dev = None
-        warm = lambda k: len(mine)
-        step = lambda k: (time.sleep(0.001), len(mine))[1]
-        k0 = 0
+        run = lambda steps: (time.sleep(0.001 * steps), len(mine) * steps)[1]
     else:
         import torch
         import replay
@@ -440,30 +497,18 @@ def run_replay(args, rank, world, local, dist):
         tcv.check(tcv.lib().tcv_set_device(local))
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
-        n_frames = replay.WINDOW_SIZE + 1 + args.warmup + args.steps
-        seqs = list(replay.EUROC_SEQUENCES)
-        streams = [replay.simulate_stream_euroc(seqs[s % len(seqs)], n_frames, start_s=0.5 + 3.0 * (s // len(seqs)), max_features=args.features,
-                                                max_lines=args.lines, associate=True) for s in mine]
-        ls = replay.NativeLockstep(streams, num_iterations=SOLVER_ITERATIONS) if streams else None
-        step = (lambda k: ls.step(k)) if ls else (lambda k: 0)
-        k0 = 0
-        while ls is not None and k0 < n_frames:      # window fill: frames 0 .. WINDOW_SIZE, the last one triggers the first optimisation
-            r = step(k0)
-            k0 += 1
-            if r:
-                break
-        if ls is None:
-            k0 = replay.WINDOW_SIZE + 1
+        eng = ReplayEngine(tcv, replay, mine, replay.WINDOW_SIZE + 1 + args.warmup + args.steps, args.features, args.lines, args.host_threads, local)
+        run = eng.run
     red_dev = dev if (dist is not None and dist.get_backend() == "nccl") else None
     n_ranks = ranks_seen(dist, red_dev)
-    for k in range(args.warmup):
-        step(k0 + k)
+    run(args.warmup)
+    if not DRY:
+        import ctypes as C
+        tcv.lib().tcv_estimators_profile((C.c_double * 8)())      # clears the accounting of the window fill and the warm-up
     if dist is not None:
         dist.barrier()
-    n = 0
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        n += step(k0 + args.warmup + k)
+    n = run(args.steps)
     if not DRY:
         import torch
         torch.cuda.synchronize()
@@ -473,18 +518,43 @@ def run_replay(args, rank, world, local, dist):
     elapsed_max, windows_total, iters_total = reduce_stats(dist, elapsed, n, red_dev, extra=(n * SOLVER_ITERATIONS,))
     if rank != 0:
         return
+    prof = None
+    if not DRY:      # host-side accounting of tcv_estimators_optimize on rank 0 (summed over its host threads), per call
+        import ctypes as C
+        p8 = (C.c_double * 8)()
+        tcv.lib().tcv_estimators_profile(p8)
+        names = ["preintegrate", "assoc+triangulate+window", "problems", "batch_create", "kernels", "downloads", "apply"]
+        prof = {k: round(1e3 * v / max(1.0, p8[7]), 3) for k, v in zip(names, p8)}
+        prof["calls"] = int(p8[7])
     out = {"metric": "sliding-window solves/sec, EuRoC-trajectory replay (configs[4])", "value": windows_total / elapsed_max, "unit": "solves/s",
            "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed_max / args.steps, "higher_is_better": True,
            "scaling": "strong", "vs_baseline": None, "dtype": "f64",
            "data": "synthetic front-end streams along the EuRoC ground-truth trajectories the reference ships (no bag in the tree)",
            "config": {"workload": f"configs[4]: {args.streams} EuRoC-trajectory streams (V1_02..V2_03 excerpts, {args.features} tracked features + {args.lines} line "
-                                  f"tracks per frame, 2D-3D association in the loop), stream s on rank s mod {world}, lock-step native estimator, "
-                                  f"{SOLVER_ITERATIONS} iterations (convergence tests on) + marginalisation per frame",
-                      "streams": args.streams, "parallelism": f"streams sharded x{world}"},
+                                  f"tracks per frame, 2D-3D association in the loop), stream s on rank s mod {world}, native estimator, "
+                                  f"{SOLVER_ITERATIONS} iterations (convergence tests on) + marginalisation per frame; per rank {args.host_threads} host threads, "
+                                  f"each advancing its share of the rank's streams in lock step (cooperative small-batch kernels)",
+                      "streams": args.streams, "host_threads": args.host_threads, "parallelism": f"streams sharded x{world}"},
            "frames_per_s_per_stream": windows_total / elapsed_max / max(1, args.streams)}
     if DRY:
         out["dry_run"] = True
+    if prof:
+        out["native_profile_ms_per_call"] = prof
     print(json.dumps(out))
+
+
+def replay_figures(tcv, local, streams=8, groups=4, steps=60, warmup=10):
+    """the replay number of the default line (one GPU): optimised windows per second of `streams` EuRoC-trajectory streams"""
+    import replay
+    eng = ReplayEngine(tcv, replay, list(range(streams)), replay.WINDOW_SIZE + 1 + warmup + steps, 60, 8, groups, local)
+    eng.run(warmup)
+    t0 = time.perf_counter()
+    n = eng.run(steps)
+    dt = time.perf_counter() - t0
+    return {"replay_windows_per_s": n / dt,
+            "replay_note": f"{streams} EuRoC-trajectory streams (60 features + 8 line tracks per frame, association in the loop) through the native estimator on "
+                           f"this GPU, {groups} host threads x {streams // max(1, groups)} streams in lock step, {steps} frames per stream: {1e3 * dt / steps:.2f} ms per frame of every stream "
+                           f"(bench.py --mode replay prints this as its value)"}
 
 
 def main():
@@ -502,7 +572,10 @@ def main():
     ap.add_argument("--streams", type=int, default=8, help="replay mode: number of EuRoC-trajectory streams of the whole job")
     ap.add_argument("--features", type=int, default=60)
     ap.add_argument("--lines", type=int, default=8)
+    ap.add_argument("--host-threads", type=int, default=4, help="replay mode: host threads per rank, each advancing its share of the rank's streams")
     args = ap.parse_args()
+    if args.mode == "stream" and args.gpus > 1:
+        raise SystemExit("--mode stream measures one GPU (host threads x HIP streams of one device): use --gpus 1")
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus, sys.argv[1:]))       # nothing above touched the GPU

@@ -232,6 +232,9 @@ int tcv_batch_synchronize(tcv_batch *b);
 int tcv_batch_download_states(tcv_batch *b);
 int tcv_batch_get_summaries(tcv_batch *b, tcv_solver_summary *out, int n);
 int tcv_batch_get_prior(tcv_batch *b, int window, tcv_prior **out);
+/* every window's prior in one call (n = the batch size): out[k] as tcv_batch_get_prior(b, k, &out[k]) would return it; the host copies are
+ * made by several host threads.  On an error nothing is returned (out[] is all NULL). */
+int tcv_batch_get_priors(tcv_batch *b, tcv_prior **out, int n);
 /* optional: ONE device-to-host copy of every window's marginalisation result; later tcv_batch_get_prior calls are served from it
  * (until the next tcv_batch_marginalize) */
 int tcv_batch_download_priors(tcv_batch *b);

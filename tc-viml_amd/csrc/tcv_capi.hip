@@ -94,6 +94,18 @@ hipError_t dev_free(void *p) {
     return ::hipFree(p);
 }
 
+hipStream_t util_stream() {
+    thread_local std::map<int, hipStream_t> mine;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    auto it = mine.find(dev);
+    if (it != mine.end()) return it->second;
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = nullptr;      // the default stream: slower, still correct
+    mine.emplace(dev, st);
+    return st;
+}
+
 int device_ready() {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
@@ -446,7 +458,7 @@ static void batch_free(tcv_batch *b) {
     if (b->pending)      // the buffers go back to the free list: nothing of this batch may still be running on any stream it used
         for (hipStream_t st : b->streams) { if (st) (void)hipStreamSynchronize(st); else (void)hipDeviceSynchronize(); }
     if (b->ev_order) (void)hipEventDestroy(b->ev_order);
-    tcv::dev_free(b->d_win); tcv::dev_free(b->d_plans); tcv::dev_free(b->d_plan_base); tcv::dev_free(b->d_ipool); tcv::dev_free(b->d_dpool);
+    tcv::dev_free(b->d_input);      // (d_dpool, d_win, d_plans, d_plan_base, d_ipool point into it)
     tcv::dev_free(b->d_imublk); tcv::dev_free(b->d_spill); tcv::dev_free(b->d_sqrt_out);
     tcv::dev_free(b->d_coop_ctl); tcv::dev_free(b->d_coop_x); tcv::dev_free(b->d_coop_exp);
     tcv::dev_free(b->d_prof); tcv::dev_free(b->d_state); tcv::dev_free(b->d_delta); tcv::dev_free(b->d_scratch); tcv::dev_free(b->d_summary);
@@ -617,7 +629,14 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
         b->input_bytes += 8.0 * pk.win.n_doubles;
     }
     // data half: every window written straight into one pinned upload buffer, in parallel
-    double *h_dpool = (double *)host_staging_acquire(sizeof(double) * std::max<size_t>(1, dtotal));
+    // ONE pinned staging buffer and ONE device blob for everything the kernels read: [data pool | window headers | plan headers | plan
+    // offsets | plan ints], one asynchronous copy on the calling thread's own stream (five synchronous copies through the default stream
+    // used to cost a lock-step frame more than its packing)
+    auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t o_win = up16(sizeof(double) * std::max<size_t>(1, dtotal)), o_plans = up16(o_win + sizeof(WinHdr) * (size_t)n);
+    const size_t o_pbase = up16(o_plans + sizeof(PlanHdr) * b->plans.size()), o_ipool = up16(o_pbase + sizeof(long long) * b->plan_base.size());
+    const size_t in_bytes = up16(o_ipool + sizeof(int) * std::max<size_t>(1, ipool.size()));
+    double *h_dpool = (double *)host_staging_acquire(in_bytes);
     if (!h_dpool) { batch_free(b); set_error("hipHostMalloc (upload staging) failed"); return TCV_ERR_HIP; }
     {
         const int nth = std::max(1, std::min({n, 16, (int)std::thread::hardware_concurrency()}));
@@ -666,13 +685,27 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
             if (e_ != hipSuccess) { host_staging_release(h_dpool); batch_free(b); return hip_fail(e_, "hipMemcpy H2D"); }            \
         }                                                                                             \
     } while (0)
-    UP(b->d_win, b->wins.data(), WinHdr, (size_t)n);
-    UP(b->d_plans, b->plans.data(), PlanHdr, b->plans.size());
-    UP(b->d_plan_base, b->plan_base.data(), long long, b->plan_base.size());
-    UP(b->d_ipool, ipool.data(), int, ipool.size());
-    UP(b->d_dpool, h_dpool, double, dtotal);
-    host_staging_release(h_dpool);
-    h_dpool = nullptr;
+    hipStream_t ust = tcv::util_stream();
+    if (marg_problems) {      // the marginalisation problems first: which IMU factor's sqrt_info the solve exports is part of the window headers
+        hipError_t e_ = tcv::dev_malloc((void **)&b->d_sqrt_out, sizeof(double) * (size_t)n * 225);
+        if (e_ != hipSuccess) { host_staging_release(h_dpool); batch_free(b); return hip_fail(e_, "hipMalloc"); }
+        const int rc = tcv_marg_attach(b, marg_problems, marg_drop, marg_num_drop);
+        if (rc != TCV_OK) { host_staging_release(h_dpool); batch_free(b); return rc; }
+        for (int w = 0; w < n; w++) b->wins[w].sqrt_export = tcv_marg_sqrt_source(b, w);
+    }
+    {
+        char *hb = (char *)h_dpool;
+        std::memcpy(hb + o_win, b->wins.data(), sizeof(WinHdr) * (size_t)n);
+        std::memcpy(hb + o_plans, b->plans.data(), sizeof(PlanHdr) * b->plans.size());
+        std::memcpy(hb + o_pbase, b->plan_base.data(), sizeof(long long) * b->plan_base.size());
+        if (!ipool.empty()) std::memcpy(hb + o_ipool, ipool.data(), sizeof(int) * ipool.size());
+        hipError_t e_ = tcv::dev_malloc(&b->d_input, in_bytes);
+        if (e_ == hipSuccess) e_ = hipMemcpyAsync(b->d_input, hb, in_bytes, hipMemcpyHostToDevice, ust);
+        if (e_ != hipSuccess) { host_staging_release(h_dpool); batch_free(b); return hip_fail(e_, "upload of the batch"); }
+        char *db = (char *)b->d_input;
+        b->d_dpool = (double *)db; b->d_win = (WinHdr *)(db + o_win); b->d_plans = (PlanHdr *)(db + o_plans);
+        b->d_plan_base = (long long *)(db + o_pbase); b->d_ipool = (int *)(db + o_ipool);
+    }
     UP(b->d_state, (double *)nullptr, double, (size_t)n * b->state_stride);
     UP(b->d_delta, (double *)nullptr, double, (size_t)n * b->delta_stride);
     UP(b->d_scratch, (double *)nullptr, double, (size_t)b->slots * scr);
@@ -687,27 +720,19 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
         UP(b->d_coop_x, (double *)nullptr, double, (size_t)b->coop_groups * COOP_X_DOUBLES);
         UP(b->d_coop_exp, (double *)nullptr, double, (size_t)b->coop_groups * b->coop_exp_chunks * b->coop_exp_stride);
     }
-    hipMemset(b->d_prof, 0, sizeof(double) * 32 * b->slots);
 #undef UP
-    hipMemset(b->d_scratch, 0, sizeof(double) * (size_t)b->slots * scr);
-    hipMemset(b->d_summary, 0, sizeof(DevSummary) * (size_t)n);
-    hipMemset(b->d_delta, 0, sizeof(double) * (size_t)n * b->delta_stride);
+    e0 = hipMemsetAsync(b->d_prof, 0, sizeof(double) * 32 * b->slots, ust);
+    if (e0 == hipSuccess) e0 = hipMemsetAsync(b->d_scratch, 0, sizeof(double) * (size_t)b->slots * scr, ust);
+    if (e0 == hipSuccess) e0 = hipMemsetAsync(b->d_summary, 0, sizeof(DevSummary) * (size_t)n, ust);
+    if (e0 == hipSuccess) e0 = hipMemsetAsync(b->d_delta, 0, sizeof(double) * (size_t)n * b->delta_stride, ust);
+    if (e0 == hipSuccess) e0 = ust ? hipStreamSynchronize(ust) : hipDeviceSynchronize();      // the batch is complete on the device before any stream uses it
+    host_staging_release(h_dpool);
+    h_dpool = nullptr;
+    if (e0 != hipSuccess) { batch_free(b); return hip_fail(e0, "upload of the batch"); }
     e0 = hipEventCreate(&b->ev0);
     if (e0 == hipSuccess) e0 = hipEventCreate(&b->ev1);
     if (e0 != hipSuccess) { batch_free(b); return hip_fail(e0, "hipEventCreate"); }
     const auto t_up = std::chrono::steady_clock::now();
-    if (marg_problems) {
-        hipError_t e_ = tcv::dev_malloc((void **)&b->d_sqrt_out, sizeof(double) * (size_t)n * 225);
-        if (e_ != hipSuccess) { batch_free(b); return hip_fail(e_, "hipMalloc"); }
-        const int rc = tcv_marg_attach(b, marg_problems, marg_drop, marg_num_drop);
-        if (rc != TCV_OK) { batch_free(b); return rc; }
-        bool any = false;
-        for (int w = 0; w < n; w++) { b->wins[w].sqrt_export = tcv_marg_sqrt_source(b, w); any = any || b->wins[w].sqrt_export >= 0; }
-        if (any) {
-            e_ = hipMemcpy(b->d_win, b->wins.data(), sizeof(WinHdr) * (size_t)n, hipMemcpyHostToDevice);
-            if (e_ != hipSuccess) { batch_free(b); return hip_fail(e_, "hipMemcpy H2D"); }
-        }
-    }
     if (getenv("TCV_DEBUG_PACK")) {
         const auto t_end = std::chrono::steady_clock::now();
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) { return std::chrono::duration<double, std::milli>(c - a).count(); };
@@ -803,8 +828,19 @@ extern "C" int tcv_batch_synchronize(tcv_batch *b) {
 }
 extern "C" int tcv_batch_download_states(tcv_batch *b) {
     if (!b || !b->solved) return TCV_ERR_INVALID;
+    if (b->pending) if (int rc = tcv_batch_synchronize(b)) return rc;
     b->h_state.resize((size_t)b->n * b->state_stride);
-    HIPCHK(hipMemcpy(b->h_state.data(), b->d_state, sizeof(double) * b->h_state.size(), hipMemcpyDeviceToHost));
+    {      // through pinned staging on the calling thread's own stream (the default stream serialises the host threads of a process)
+        const size_t bytes = sizeof(double) * b->h_state.size();
+        void *hs = host_staging_acquire(bytes);
+        if (!hs) { set_error("hipHostMalloc (download staging) failed"); return TCV_ERR_HIP; }
+        hipStream_t ust = tcv::util_stream();
+        hipError_t e_ = hipMemcpyAsync(hs, b->d_state, bytes, hipMemcpyDeviceToHost, ust);
+        if (e_ == hipSuccess) e_ = ust ? hipStreamSynchronize(ust) : hipDeviceSynchronize();
+        if (e_ == hipSuccess) std::memcpy(b->h_state.data(), hs, bytes);
+        host_staging_release(hs);
+        if (e_ != hipSuccess) return hip_fail(e_, "download of the states");
+    }
     for (int w = 0; w < b->n; w++) {
         const Packed &pk = b->packed[w];
         const tcv_problem &p = *b->problems[w];
@@ -827,9 +863,16 @@ static void summary_to_public(const DevSummary &s, tcv_solver_summary *o) {
 }
 extern "C" int tcv_batch_get_summaries(tcv_batch *b, tcv_solver_summary *out, int n) {
     if (!b || !out || n < 0 || n > b->n) { set_error("batch_get_summaries: n exceeds the batch size"); return TCV_ERR_INVALID; }
-    std::vector<DevSummary> h(n);
-    HIPCHK(hipMemcpy(h.data(), b->d_summary, sizeof(DevSummary) * n, hipMemcpyDeviceToHost));
-    for (int i = 0; i < n; i++) summary_to_public(h[i], out + i);
+    if (b->pending) if (int rc = tcv_batch_synchronize(b)) return rc;
+    const size_t bytes = sizeof(DevSummary) * (size_t)n;
+    DevSummary *h = (DevSummary *)host_staging_acquire(std::max<size_t>(bytes, 16));
+    if (!h) { set_error("hipHostMalloc (download staging) failed"); return TCV_ERR_HIP; }
+    hipStream_t ust = tcv::util_stream();
+    hipError_t e_ = n ? hipMemcpyAsync(h, b->d_summary, bytes, hipMemcpyDeviceToHost, ust) : hipSuccess;
+    if (e_ == hipSuccess) e_ = ust ? hipStreamSynchronize(ust) : hipDeviceSynchronize();
+    if (e_ == hipSuccess) for (int i = 0; i < n; i++) summary_to_public(h[i], out + i);
+    host_staging_release(h);
+    if (e_ != hipSuccess) return hip_fail(e_, "download of the summaries");
     return TCV_OK;
 }
 // tangent step of iteration 1 in problem order: free camera blocks in the order they were added
@@ -856,6 +899,32 @@ extern "C" int tcv_batch_get_first_step(tcv_batch *b, int window, double *out, i
 extern "C" int tcv_batch_get_prior(tcv_batch *b, int window, tcv_prior **out) {
     if (!b || !out) return TCV_ERR_INVALID;
     return tcv_marg_get_prior(b, window, out);
+}
+extern "C" int tcv_batch_get_priors(tcv_batch *b, tcv_prior **out, int n) {
+    if (!b || !out || n != b->n) { set_error("batch_get_priors: n must be the batch size"); return TCV_ERR_INVALID; }
+    for (int k = 0; k < n; k++) out[k] = nullptr;
+    const int nth = std::max(1, std::min({n / 16, 8, (int)std::thread::hardware_concurrency()}));
+    std::vector<int> rcs(nth, TCV_OK);
+    std::vector<std::string> msgs(nth);
+    auto work = [&](int t) {
+        for (int k = t; k < n; k += nth) {
+            const int rc = tcv_marg_get_prior(b, k, &out[k]);
+            if (rc != TCV_OK) { rcs[t] = rc; msgs[t] = tcv_last_error(); return; }
+        }
+    };
+    if (nth == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nth; t++) th.emplace_back(work, t);
+        for (auto &x : th) x.join();
+    }
+    for (int t = 0; t < nth; t++)
+        if (rcs[t] != TCV_OK) {
+            for (int k = 0; k < n; k++) if (out[k]) { tcv_prior_destroy(out[k]); out[k] = nullptr; }
+            set_error(msgs[t]);
+            return rcs[t];
+        }
+    return TCV_OK;
 }
 extern "C" int tcv_batch_download_priors(tcv_batch *b) {
     if (!b) return TCV_ERR_INVALID;

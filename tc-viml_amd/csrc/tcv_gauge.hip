@@ -138,10 +138,11 @@ extern "C" int tcv_gauge_fix(int n, const double *R0, const double *P0, const do
     e = hipMemcpy(d, h.data(), sizeof(double) * nin, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         double *o = d + nin;
-        hipLaunchKernelGGL(gauge_kernel, dim3((n + 63) / 64), dim3(64), 0, 0, n, d, d + 9, d + 12, d + 12 + 7 * n, o, o + 9 * n, o + 12 * n,
+        hipStream_t st = tcv::util_stream();
+        hipLaunchKernelGGL(gauge_kernel, dim3((n + 63) / 64), dim3(64), 0, st, n, d, d + 9, d + 12, d + 12 + 7 * n, o, o + 9 * n, o + 12 * n,
                            o + 15 * n);
         e = hipGetLastError();
-        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = st ? hipStreamSynchronize(st) : hipDeviceSynchronize();
         std::vector<double> ho(nout);
         if (e == hipSuccess) e = hipMemcpy(ho.data(), o, sizeof(double) * nout, hipMemcpyDeviceToHost);
         if (e == hipSuccess) {

@@ -82,6 +82,7 @@ struct tcv_batch {
     int state_stride = 0, delta_stride = 0;
     double input_bytes = 0, plan_bytes = 0;
     // device
+    void *d_input = nullptr;                 // one allocation: [data pool | window headers | plan headers | plan offsets | plan ints]
     tcv::WinHdr *d_win = nullptr;
     tcv::PlanHdr *d_plans = nullptr;
     long long *d_plan_base = nullptr;
@@ -148,6 +149,10 @@ int pack_problem_data(const tcv_problem &p, Packed &out, const double *imu_sqrt,
 // pinned host staging buffers for uploads / downloads, recycled through a small per-process pool (hipHostMalloc costs milliseconds)
 void *host_staging_acquire(size_t bytes);
 void host_staging_release(void *p);
+// a non-blocking stream of the calling thread on its current device, created on first use and kept: the one-shot entry points
+// (pre-integration, line association, gauge fix) launch there and wait for THAT stream, never for the device -- another host thread's
+// batches keep running (several estimator groups per GPU, bench.py --mode replay)
+hipStream_t util_stream();
 // plan-cache statistics (hits, misses, entries); tcv_pack.cpp
 void plan_cache_stats(long long *hits, long long *misses, long long *entries);
 }  // namespace tcv

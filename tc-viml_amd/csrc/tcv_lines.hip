@@ -208,41 +208,57 @@ extern "C" int tcv_match_lines(int n_frames, const double *poses, const double *
     if (fov_frame >= n_frames) { set_error("match_lines: fov_given names a frame outside the window"); return TCV_ERR_INVALID; }
     for (int i = 0; i < n_det; i++) if (det_frame[i] < 0 || det_frame[i] >= n_frames) { set_error("match_lines: frame index out of range"); return TCV_ERR_INVALID; }
     if (int rc = device_ready()) return rc;
+    // one pinned staging buffer, one device blob, one copy in and one copy out on the calling thread's own stream:
+    //   in : [poses, extrinsic, Rbw, Tbw, K, map, detections (doubles) | frame of every detection (ints) | given FoV rows (bytes)]
+    //   out: [projected segments 4 n_det (doubles) | match index n_det (ints) | errA, errD, overlap 3 n_det (floats) | FoV rows (bytes)]
+    auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
     const size_t nd_in = (size_t)7 * n_frames + 7 + 9 + 3 + 9 + (size_t)6 * n_map + (size_t)4 * n_det;
-    const size_t nd_out = (size_t)4 * n_det;
-    std::vector<double> h(nd_in);
+    const size_t tot = (size_t)n_frames * n_map;
+    const size_t o_det = up16(sizeof(double) * nd_in), o_fov = up16(o_det + sizeof(int) * std::max(1, n_det)), in_bytes = up16(o_fov + tot);
+    const size_t o_match = up16(sizeof(double) * 4 * std::max(1, n_det)), o_err = up16(o_match + sizeof(int) * std::max(1, n_det));
+    const size_t out_bytes = up16(o_err + sizeof(float) * 3 * std::max(1, n_det));
+    char *h = (char *)tcv::host_staging_acquire(in_bytes + out_bytes);
+    if (!h) { set_error("hipHostMalloc (staging) failed"); return TCV_ERR_HIP; }
+    char *dv = nullptr;
+    hipError_t e = tcv::dev_malloc((void **)&dv, in_bytes + out_bytes);
+    double *hd = (double *)h;
     size_t o = 0;
-    auto put = [&](const double *p, size_t n) { std::memcpy(h.data() + o, p, sizeof(double) * n); o += n; return o - n; };
+    auto put = [&](const double *p, size_t n) { std::memcpy(hd + o, p, sizeof(double) * n); o += n; return o - n; };
     const size_t o_pose = put(poses, (size_t)7 * n_frames), o_ex = put(ex_pose, 7), o_R = put(Rbw, 9), o_T = put(Tbw, 3), o_K = put(K, 9);
-    const size_t o_map = put(lines3d, (size_t)6 * n_map), o_det = n_det ? put(det_lines, (size_t)4 * n_det) : o;
-    double *dd = nullptr; int *di = nullptr; float *df = nullptr; unsigned char *db = nullptr;
-    hipError_t e = tcv::dev_malloc((void **)&dd, sizeof(double) * (nd_in + nd_out + 1));
-    if (e == hipSuccess) e = tcv::dev_malloc((void **)&di, sizeof(int) * (2 * (size_t)n_det + 1));
-    if (e == hipSuccess) e = tcv::dev_malloc((void **)&df, sizeof(float) * (3 * (size_t)n_det + 1));
-    if (e == hipSuccess) e = tcv::dev_malloc((void **)&db, (size_t)n_frames * n_map);
-    if (e == hipSuccess) e = hipMemcpy(dd, h.data(), sizeof(double) * nd_in, hipMemcpyHostToDevice);
-    if (e == hipSuccess && n_det) e = hipMemcpy(di, det_frame, sizeof(int) * n_det, hipMemcpyHostToDevice);
-    if (e == hipSuccess && fov_given) e = hipMemcpy(db, in_fov, (size_t)n_frames * n_map, hipMemcpyHostToDevice);
+    const size_t o_map = put(lines3d, (size_t)6 * n_map), o_dl = n_det ? put(det_lines, (size_t)4 * n_det) : o;
+    if (n_det) std::memcpy(h + o_det, det_frame, sizeof(int) * n_det);
+    if (fov_given) std::memcpy(h + o_fov, in_fov, tot);
     int rc = TCV_OK;
+    hipStream_t st = tcv::util_stream();
+    if (e == hipSuccess) e = hipMemcpyAsync(dv, h, fov_given ? in_bytes : o_fov, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
+        double *dd = (double *)dv;
+        char *dout = dv + in_bytes;
         LineArgs A;
-        A.poses = dd + o_pose; A.ex = dd + o_ex; A.Rbw = dd + o_R; A.Tbw = dd + o_T; A.K = dd + o_K; A.map = dd + o_map; A.det = dd + o_det;
-        A.det_frame = di; A.n_frames = n_frames; A.n_map = n_map; A.n_det = n_det; A.width = width; A.height = height; A.window_size = window_size;
-        A.angle_th = angle_th; A.overlap_th = overlap_th; A.in_fov = db; A.match = di + n_det; A.err = df; A.proj = dd + nd_in;
-        const int tot = n_frames * n_map;
+        A.poses = dd + o_pose; A.ex = dd + o_ex; A.Rbw = dd + o_R; A.Tbw = dd + o_T; A.K = dd + o_K; A.map = dd + o_map; A.det = dd + o_dl;
+        A.det_frame = (int *)(dv + o_det); A.n_frames = n_frames; A.n_map = n_map; A.n_det = n_det; A.width = width; A.height = height; A.window_size = window_size;
+        A.angle_th = angle_th; A.overlap_th = overlap_th; A.in_fov = (unsigned char *)(dv + o_fov); A.match = (int *)(dout + o_match); A.err = (float *)(dout + o_err);
+        A.proj = (double *)dout;
         A.only_frame = fov_frame;
-        if (!fov_given) hipLaunchKernelGGL(lines_fov_kernel, dim3((tot + 255) / 256), dim3(256), 0, 0, A);
-        else if (fov_frame >= 0) hipLaunchKernelGGL(lines_fov_kernel, dim3((n_map + 255) / 256), dim3(256), 0, 0, A);
-        if (n_det) hipLaunchKernelGGL(lines_match_kernel, dim3(n_det), dim3(64), 0, 0, A);
+        if (!fov_given) hipLaunchKernelGGL(lines_fov_kernel, dim3(((int)tot + 255) / 256), dim3(256), 0, st, A);
+        else if (fov_frame >= 0) hipLaunchKernelGGL(lines_fov_kernel, dim3((n_map + 255) / 256), dim3(256), 0, st, A);
+        if (n_det) hipLaunchKernelGGL(lines_match_kernel, dim3(n_det), dim3(64), 0, st, A);
         e = hipGetLastError();
-        if (e == hipSuccess) e = hipDeviceSynchronize();
-        if (e == hipSuccess && in_fov && !fov_given) e = hipMemcpy(in_fov, db, (size_t)tot, hipMemcpyDeviceToHost);
-        if (e == hipSuccess && fov_frame >= 0) e = hipMemcpy(in_fov + (size_t)fov_frame * n_map, db + (size_t)fov_frame * n_map, (size_t)n_map, hipMemcpyDeviceToHost);
-        if (e == hipSuccess && n_det && match_index) e = hipMemcpy(match_index, di + n_det, sizeof(int) * n_det, hipMemcpyDeviceToHost);
-        if (e == hipSuccess && n_det && err) e = hipMemcpy(err, df, sizeof(float) * 3 * n_det, hipMemcpyDeviceToHost);
-        if (e == hipSuccess && n_det && projected) e = hipMemcpy(projected, dd + nd_in, sizeof(double) * 4 * n_det, hipMemcpyDeviceToHost);
+        char *ho = h + in_bytes;
+        if (e == hipSuccess && n_det) e = hipMemcpyAsync(ho, dout, out_bytes, hipMemcpyDeviceToHost, st);
+        const bool want_fov = in_fov && (!fov_given || fov_frame >= 0);
+        if (e == hipSuccess && want_fov) e = hipMemcpyAsync(h + o_fov, dv + o_fov, tot, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = st ? hipStreamSynchronize(st) : hipDeviceSynchronize();
+        if (e == hipSuccess) {
+            if (in_fov && !fov_given) std::memcpy(in_fov, h + o_fov, tot);
+            else if (fov_frame >= 0) std::memcpy(in_fov + (size_t)fov_frame * n_map, h + o_fov + (size_t)fov_frame * n_map, (size_t)n_map);
+            if (n_det && match_index) std::memcpy(match_index, ho + o_match, sizeof(int) * n_det);
+            if (n_det && err) std::memcpy(err, ho + o_err, sizeof(float) * 3 * n_det);
+            if (n_det && projected) std::memcpy(projected, ho, sizeof(double) * 4 * n_det);
+        }
     }
     if (e != hipSuccess) rc = hip_fail(e, "match_lines");
-    tcv::dev_free(dd); tcv::dev_free(di); tcv::dev_free(df); tcv::dev_free(db);
+    tcv::host_staging_release(h);
+    tcv::dev_free(dv);
     return rc;
 }

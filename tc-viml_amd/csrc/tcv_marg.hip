@@ -1257,6 +1257,7 @@ struct MargWindow {
 };
 struct MargState {
     std::vector<MargWindow> win;
+    void *d_input = nullptr;          // one allocation: [double pool | headers | int pool]
     MargHdr *d_hdr = nullptr;
     int *d_ipool = nullptr, *d_status = nullptr;
     double *d_dpool = nullptr, *d_out = nullptr, *d_scratch = nullptr;
@@ -1273,7 +1274,7 @@ struct MargState {
 static void marg_free(tcv_batch *b) {
     MargState *s = (MargState *)b->marg;
     if (!s) return;
-    (void)tcv::dev_free(s->d_hdr); (void)tcv::dev_free(s->d_ipool); (void)tcv::dev_free(s->d_status); (void)tcv::dev_free(s->d_dpool);
+    (void)tcv::dev_free(s->d_input); (void)tcv::dev_free(s->d_status);      // (d_hdr, d_ipool, d_dpool point into d_input)
     (void)tcv::dev_free(s->d_out); (void)tcv::dev_free(s->d_scratch);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -1549,11 +1550,17 @@ int tcv_marg_attach(tcv_batch *b, tcv_problem *const *marg_problems, double *con
             lds = std::max(lds, need);
         }
     }
+    // one pinned staging buffer, one device blob: [double pool | headers | int pool], one asynchronous copy on the calling thread's stream
     const size_t i_total = ib[nth], d_total = db[nth];
-    int *h_I = (int *)tcv::host_staging_acquire(sizeof(int) * std::max<size_t>(1, i_total));
-    double *h_D = (double *)tcv::host_staging_acquire(sizeof(double) * std::max<size_t>(1, d_total));
-    struct Staged { void *a, *b2; ~Staged() { tcv::host_staging_release(a); tcv::host_staging_release(b2); } } staged{h_I, h_D};
-    if (!h_I || !h_D) { set_error("hipHostMalloc (upload staging) failed"); return TCV_ERR_HIP; }
+    auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t o_hdr = up16(sizeof(double) * std::max<size_t>(1, d_total)), o_int = up16(o_hdr + sizeof(MargHdr) * hdrs.size());
+    const size_t in_bytes = up16(o_int + sizeof(int) * std::max<size_t>(1, i_total));
+    char *h_in = (char *)tcv::host_staging_acquire(in_bytes);
+    struct Staged { void *a; ~Staged() { tcv::host_staging_release(a); } } staged{h_in};
+    if (!h_in) { set_error("hipHostMalloc (upload staging) failed"); return TCV_ERR_HIP; }
+    int *h_I = (int *)(h_in + o_int);
+    double *h_D = (double *)h_in;
+    std::memcpy(h_in + o_hdr, hdrs.data(), sizeof(MargHdr) * hdrs.size());
     {
         auto copy = [&](int t) {
             if (!It[t].empty()) std::memcpy(h_I + ib[t], It[t].data(), sizeof(int) * It[t].size());
@@ -1579,23 +1586,18 @@ int tcv_marg_attach(tcv_batch *b, tcv_problem *const *marg_problems, double *con
     s->nt = pair ? MARG_NT_PAIR : MARG_NT_WIDE;
     if (pair) s->lds_bytes = (size_t)LDS_DOUBLES * 4;
     s->grid = std::min(b->n, pair ? 2 * n_cu : n_cu);
-#define MUP(dst, src, T, cnt)                                                                    \
-    do {                                                                                         \
-        hipError_t e_ = tcv::dev_malloc((void **)&dst, sizeof(T) * std::max<size_t>(1, (cnt)));        \
-        if (e_ != hipSuccess) return hip_fail(e_, "hipMalloc");                                  \
-        if (src) {                                                                               \
-            e_ = hipMemcpy(dst, src, sizeof(T) * (cnt), hipMemcpyHostToDevice);                  \
-            if (e_ != hipSuccess) return hip_fail(e_, "hipMemcpy H2D");                          \
-        }                                                                                        \
-    } while (0)
-    MUP(s->d_hdr, hdrs.data(), MargHdr, hdrs.size());
-    MUP(s->d_ipool, h_I, int, i_total);
-    MUP(s->d_dpool, h_D, double, d_total);
-    MUP(s->d_out, (double *)nullptr, double, (size_t)b->n * MARG_OUT_STRIDE);
-    MUP(s->d_status, (int *)nullptr, int, (size_t)b->n);
-    MUP(s->d_scratch, (double *)nullptr, double, (size_t)s->grid * MARG_SCR_STRIDE);
-#undef MUP
-    (void)hipMemset(s->d_status, 0xff, sizeof(int) * b->n);
+    {
+        hipStream_t ust = tcv::util_stream();
+        hipError_t e_ = tcv::dev_malloc(&s->d_input, in_bytes);
+        if (e_ == hipSuccess) e_ = hipMemcpyAsync(s->d_input, h_in, in_bytes, hipMemcpyHostToDevice, ust);
+        if (e_ == hipSuccess) e_ = tcv::dev_malloc((void **)&s->d_out, sizeof(double) * std::max<size_t>(1, (size_t)b->n * MARG_OUT_STRIDE));
+        if (e_ == hipSuccess) e_ = tcv::dev_malloc((void **)&s->d_status, sizeof(int) * (size_t)b->n);
+        if (e_ == hipSuccess) e_ = tcv::dev_malloc((void **)&s->d_scratch, sizeof(double) * (size_t)s->grid * MARG_SCR_STRIDE);
+        if (e_ == hipSuccess) e_ = hipMemsetAsync(s->d_status, 0xff, sizeof(int) * b->n, ust);
+        if (e_ == hipSuccess) e_ = ust ? hipStreamSynchronize(ust) : hipDeviceSynchronize();
+        if (e_ != hipSuccess) return hip_fail(e_, "upload of the marginalisation problems");
+        s->d_dpool = (double *)s->d_input; s->d_hdr = (MargHdr *)((char *)s->d_input + o_hdr); s->d_ipool = (int *)((char *)s->d_input + o_int);
+    }
     if (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) return TCV_ERR_HIP;
     b->input_bytes += 0;   // marginalisation reads the same resident inputs
     return TCV_OK;
@@ -1643,8 +1645,10 @@ int tcv_marg_download(tcv_batch *b, int compact) {
     if (!s->h_out) { set_error("hipHostMalloc (download staging) failed"); return TCV_ERR_HIP; }
     s->h_stride = stride;
     s->h_status.resize(b->n);
-    hipError_t e = compact ? hipMemcpy2D(s->h_out, sizeof(double) * stride, s->d_out, sizeof(double) * MARG_OUT_STRIDE, sizeof(double) * stride, b->n, hipMemcpyDeviceToHost)
-                           : hipMemcpy(s->h_out, s->d_out, sizeof(double) * stride * b->n, hipMemcpyDeviceToHost);
+    hipStream_t ust = tcv::util_stream();      // (h_out is pinned: asynchronous copies on the calling thread's own stream)
+    hipError_t e = compact ? hipMemcpy2DAsync(s->h_out, sizeof(double) * stride, s->d_out, sizeof(double) * MARG_OUT_STRIDE, sizeof(double) * stride, b->n, hipMemcpyDeviceToHost, ust)
+                           : hipMemcpyAsync(s->h_out, s->d_out, sizeof(double) * stride * b->n, hipMemcpyDeviceToHost, ust);
+    if (e == hipSuccess) e = ust ? hipStreamSynchronize(ust) : hipDeviceSynchronize();
     if (e == hipSuccess) e = hipMemcpy(s->h_status.data(), s->d_status, sizeof(int) * b->n, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return hip_fail(e, "hipMemcpy D2H");
     s->h_valid = true;

@@ -175,32 +175,38 @@ extern "C" int tcv_preintegrate(int n, const int *first, const int *count, const
     PreintArgs a;
     a.n = n;
     for (int i = 0; i < 4; i++) a.noise[i] = noise[i];
-    int *d_first = nullptr, *d_count = nullptr;
-    double *d_s = nullptr, *d_i = nullptr, *d_o = nullptr;
-    hipError_t e = hipSuccess;
-    auto fail = [&](const char *w) { (void)tcv::dev_free(d_first); (void)tcv::dev_free(d_count); (void)tcv::dev_free(d_s); (void)tcv::dev_free(d_i); (void)tcv::dev_free(d_o); return hip_fail(e, w); };
-    if ((e = tcv::dev_malloc((void **)&d_first, sizeof(int) * n)) != hipSuccess) return fail("hipMalloc");
-    if ((e = tcv::dev_malloc((void **)&d_count, sizeof(int) * n)) != hipSuccess) return fail("hipMalloc");
-    if ((e = tcv::dev_malloc((void **)&d_s, sizeof(double) * 7 * (size_t)std::max(1, num_samples))) != hipSuccess) return fail("hipMalloc");
-    if ((e = tcv::dev_malloc((void **)&d_i, sizeof(double) * 12 * (size_t)n)) != hipSuccess) return fail("hipMalloc");
-    if ((e = tcv::dev_malloc((void **)&d_o, sizeof(double) * PREINT_OUT * (size_t)n)) != hipSuccess) return fail("hipMalloc");
-    if ((e = hipMemcpy(d_first, first, sizeof(int) * n, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy");
-    if ((e = hipMemcpy(d_count, count, sizeof(int) * n, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy");
-    if (num_samples && (e = hipMemcpy(d_s, samples7, sizeof(double) * 7 * (size_t)num_samples, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy");
-    if ((e = hipMemcpy(d_i, acc0_gyr0_ba_bg, sizeof(double) * 12 * (size_t)n, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy");
-    a.first = d_first; a.count = d_count; a.samples = d_s; a.init = d_i; a.out = d_o;
-    hipLaunchKernelGGL(preint_kernel, dim3(std::min(n, 4096)), dim3(256), 0, 0, a);
-    if ((e = hipGetLastError()) != hipSuccess) return fail("preint kernel launch");
-    if ((e = hipDeviceSynchronize()) != hipSuccess) return fail("hipDeviceSynchronize");
-    std::vector<double> h((size_t)n * PREINT_OUT);
-    if ((e = hipMemcpy(h.data(), d_o, sizeof(double) * h.size(), hipMemcpyDeviceToHost)) != hipSuccess) return fail("hipMemcpy");
+    // one pinned staging buffer, one copy in, one copy out, everything on the calling thread's own stream:
+    // [init 12 n | samples 7 ns | first n, count n (ints)] -> device; [out PREINT_OUT n] <- device
+    const size_t ns = (size_t)std::max(1, num_samples);
+    const size_t in_d = 12 * (size_t)n + 7 * ns, in_bytes = sizeof(double) * in_d + sizeof(int) * 2 * (size_t)n, out_bytes = sizeof(double) * PREINT_OUT * (size_t)n;
+    char *h = (char *)tcv::host_staging_acquire(in_bytes + out_bytes);
+    if (!h) { set_error("hipHostMalloc (staging) failed"); return TCV_ERR_HIP; }
+    char *d = nullptr;
+    hipError_t e = tcv::dev_malloc((void **)&d, in_bytes + out_bytes + 16);
+    auto done = [&](int rc) { tcv::host_staging_release(h); (void)tcv::dev_free(d); return rc; };
+    if (e != hipSuccess) return done(hip_fail(e, "hipMalloc"));
+    double *hd = (double *)h;
+    std::memcpy(hd, acc0_gyr0_ba_bg, sizeof(double) * 12 * (size_t)n);
+    if (num_samples) std::memcpy(hd + 12 * (size_t)n, samples7, sizeof(double) * 7 * (size_t)num_samples);
+    int *hi = (int *)(hd + in_d);
+    std::memcpy(hi, first, sizeof(int) * n); std::memcpy(hi + n, count, sizeof(int) * n);
+    const size_t out_off = (in_bytes + 15) & ~(size_t)15;
+    hipStream_t st = tcv::util_stream();
+    if ((e = hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, st)) != hipSuccess) return done(hip_fail(e, "hipMemcpyAsync"));
+    a.init = (const double *)d; a.samples = (const double *)d + 12 * (size_t)n; a.first = (const int *)((const double *)d + in_d); a.count = a.first + n;
+    a.out = (double *)(d + out_off);
+    hipLaunchKernelGGL(preint_kernel, dim3(std::min(n, 4096)), dim3(256), 0, st, a);
+    if ((e = hipGetLastError()) != hipSuccess) return done(hip_fail(e, "preint kernel launch"));
+    char *ho = h + in_bytes;
+    if ((e = hipMemcpyAsync(ho, d + out_off, out_bytes, hipMemcpyDeviceToHost, st)) != hipSuccess) return done(hip_fail(e, "hipMemcpyAsync"));
+    if ((e = (st ? hipStreamSynchronize(st) : hipDeviceSynchronize())) != hipSuccess) return done(hip_fail(e, "hipStreamSynchronize"));
     for (int i = 0; i < n; i++) {
-        const double *o = h.data() + (size_t)i * PREINT_OUT;
+        const double *o = (const double *)ho + (size_t)i * PREINT_OUT;
         tcv_imu_preintegration &p = out[i];
         std::memcpy(p.delta_p, o, 24); std::memcpy(p.delta_q, o + 3, 32); std::memcpy(p.delta_v, o + 7, 24);
         std::memcpy(p.linearized_ba, o + 10, 24); std::memcpy(p.linearized_bg, o + 13, 24); p.sum_dt = o[16];
         std::memcpy(p.jacobian, o + 17, 225 * 8); std::memcpy(p.covariance, o + 242, 225 * 8);
     }
-    (void)tcv::dev_free(d_first); (void)tcv::dev_free(d_count); (void)tcv::dev_free(d_s); (void)tcv::dev_free(d_i); (void)tcv::dev_free(d_o);
+    (void)done(TCV_OK);
     return TCV_OK;
 }

@@ -816,6 +816,28 @@ class NativeLockstep:
                 tcv.check(L.tcv_estimator_set_line_map(h, ml.shape[0], P(ml), P(Rb), P(Tb)))
             self.rngs.append(rng); self.outs.append(dict(t=[], p=[], q=[], v=[], log=[]))
         self.n_frames = max(len(st["t"]) for st in streams)
+        self._frames = [dict() for _ in streams]      # per stream: frame -> the begin_frame arguments as C-contiguous arrays (prepare())
+
+    def prepare(self, k0: int = 0, k1: int = None):
+        """converts the per-frame front-end records (dicts / lists of the simulated streams) of frames [k0, k1) into the contiguous arrays
+        tcv_estimator_begin_frame takes, ahead of time: what a front end would hand over anyway, kept out of a timed replay loop"""
+        for si, st in enumerate(self.streams):
+            for k in range(k0, min(len(st["t"]), self.n_frames if k1 is None else k1)):
+                if k not in self._frames[si]:
+                    self._frames[si][k] = self._frame_args(st, k)
+
+    def _frame_args(self, st, k):
+        f64 = self._f64
+        imu = st["imu"][k]
+        acc = f64(imu[0]) if imu is not None else None; gyr = f64(imu[1]) if imu is not None else None
+        pts = st["points"][k]
+        ids = np.ascontiguousarray(list(pts.keys()), dtype=np.int32); pv = f64(np.array(list(pts.values())).reshape(-1, 3))
+        ln = st["lines"][k]
+        if "map_lines" in st:
+            lid = np.ascontiguousarray([a for a, _ in ln], dtype=np.int32); lv = f64(np.array([v for _, v in ln]).reshape(-1, 4))
+        else:
+            lid = np.zeros(len(ln), np.int32); lv = f64(np.array([np.concatenate(t3) for t3 in ln]).reshape(-1, 9))
+        return acc, gyr, ids, pv, len(ln), lid, lv
 
     @staticmethod
     def _f64(a):
@@ -835,18 +857,10 @@ class NativeLockstep:
                 dth = rng.normal(size=3) * self.init_sigma[1]
                 truth = f64(np.concatenate([st["gt_p"][k] + rng.normal(size=3) * self.init_sigma[0], (st["gt_R"][k] @ deltaQ_R(dth)).reshape(9),
                                             st["gt_v"][k] + rng.normal(size=3) * self.init_sigma[2]]))
-            imu = st["imu"][k]
-            acc = f64(imu[0]) if imu is not None else None; gyr = f64(imu[1]) if imu is not None else None
-            pts = st["points"][k]
-            ids = np.ascontiguousarray(list(pts.keys()), dtype=np.int32); pv = f64(np.array(list(pts.values())).reshape(-1, 3))
-            ln = st["lines"][k]
-            if "map_lines" in st:
-                lid = np.ascontiguousarray([a for a, _ in ln], dtype=np.int32); lv = f64(np.array([v for _, v in ln]).reshape(-1, 4))
-            else:
-                lid = np.zeros(len(ln), np.int32); lv = f64(np.array([np.concatenate(t3) for t3 in ln]).reshape(-1, 9))
+            acc, gyr, ids, pv, n_ln, lid, lv = self._frames[si].pop(k, None) or self._frame_args(st, k)
             rdy = C.c_int()
             tcv.check(L.tcv_estimator_begin_frame(h, 0 if acc is None else acc.shape[0] - 1, None if acc is None else P(acc), None if gyr is None else P(gyr),
-                                                  len(ids), ids.ctypes.data_as(ip), P(pv), len(ln), lid.ctypes.data_as(ip), P(lv),
+                                                  len(ids), ids.ctypes.data_as(ip), P(pv), n_ln, lid.ctypes.data_as(ip), P(lv),
                                                   None if truth is None else P(truth), C.byref(rdy)))
             if rdy.value:
                 ready.append(si)

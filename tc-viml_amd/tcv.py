@@ -37,7 +37,7 @@ EXPORTS = [
     "tcv_batch_download_states", "tcv_batch_get_summaries", "tcv_batch_get_prior", "tcv_batch_get_first_step",
     "tcv_batch_plan_stats", "tcv_batch_layout", "tcv_batch_stats", "tcv_batch_size",
     "tcv_eval_imu_factors", "tcv_eval_projection_factors", "tcv_eval_line_factors", "tcv_pose_plus", "tcv_preintegrate",
-    "tcv_problem_set_frames", "tcv_gauge_fix", "tcv_batch_gauge_fix", "tcv_set_solver_variant", "tcv_set_cooperative", "tcv_batch_cooperative", "tcv_batch_marg_status", "tcv_eval_projection_td_factors", "tcv_match_lines",
+    "tcv_problem_set_frames", "tcv_gauge_fix", "tcv_batch_gauge_fix", "tcv_set_solver_variant", "tcv_set_cooperative", "tcv_batch_cooperative", "tcv_batch_get_priors", "tcv_batch_marg_status", "tcv_eval_projection_td_factors", "tcv_match_lines",
     "tcv_batch_download_priors", "tcv_batch_download_priors_compact",
 ]
 
@@ -396,28 +396,47 @@ def shifted_prior_blocks(prior: "Prior", w: "Window"):
     return prior_blocks(prior, w, lambda name, i: (name, i - 1) if name in ("pose", "sb") else (name, 0))
 
 
-class Batch:
-    """Device-resident batch of independent windows (throughput mode)."""
+class BatchSpec:
+    """the argument arrays of tcv_batch_create (problem handles, marginalisation problem handles, drop lists) as C arrays"""
 
     def __init__(self, windows, marg_windows=None, marg_drops=None):
         self.windows = list(windows)
-        n = len(self.windows)
-        arr = (C.c_void_p * n)(*[w.h for w in self.windows])
-        self.h = C.c_void_p()
-        if marg_windows is None:
-            check(lib().tcv_batch_create(C.byref(self.h), arr, None, None, None, n))
-        else:
+        n = self.n = len(self.windows)
+        self.arr = (C.c_void_p * n)(*[w.h for w in self.windows])
+        self.marg_windows, self.marr, self.dd, self.nd = None, None, None, None
+        if marg_windows is not None:
             self.marg_windows = list(marg_windows)
-            marr = (C.c_void_p * n)(*[w.h for w in self.marg_windows])
+            self.marr = (C.c_void_p * n)(*[w.h for w in self.marg_windows])
             self._drop_arrays = []
-            dd = (C.POINTER(_dp) * n)()
-            nd = (C.c_int * n)()
+            self.dd = (C.POINTER(_dp) * n)()
+            self.nd = (C.c_int * n)()
             for k, drops in enumerate(marg_drops):
                 a = (_dp * len(drops))(*drops)
                 self._drop_arrays.append(a)
-                dd[k] = C.cast(a, C.POINTER(_dp))
-                nd[k] = len(drops)
-            check(lib().tcv_batch_create(C.byref(self.h), arr, marr, dd, nd, n))
+                self.dd[k] = C.cast(a, C.POINTER(_dp))
+                self.nd[k] = len(drops)
+
+
+class Batch:
+    """Device-resident batch of independent windows (throughput mode)."""
+
+    def __init__(self, windows, marg_windows=None, marg_drops=None, spec=None):
+        """spec: a BatchSpec (the C arrays of tcv_batch_create, built once) instead of the three lists -- what a C / C++ caller passes anyway"""
+        if spec is None:
+            spec = BatchSpec(windows, marg_windows, marg_drops)
+        self.spec = spec
+        self.windows = spec.windows
+        if spec.marg_windows is not None:
+            self.marg_windows = spec.marg_windows
+        self.h = C.c_void_p()
+        check(lib().tcv_batch_create(C.byref(self.h), spec.arr, spec.marr, spec.dd, spec.nd, spec.n))
+
+    def priors(self):
+        """every window's prior in one call (tcv_batch_get_priors)"""
+        n = len(self.windows)
+        out = (C.c_void_p * n)()
+        check(lib().tcv_batch_get_priors(self.h, out, n))
+        return [Prior(C.c_void_p(h)) for h in out]
 
     def solve(self, opts, stream=None):
         check(lib().tcv_batch_solve(self.h, C.byref(opts), stream))

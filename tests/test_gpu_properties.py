@@ -138,7 +138,10 @@ def test_compact_prior_download_and_concurrent_host_threads(gpu):
                 W, b = _marg_batch(gpu, wins[h * B:(h + 1) * B])
                 b.solve(opts, st); b.gauge_fix(st); b.marginalize(st); b.synchronize()
                 b.download_states(); b.download_priors(compact=True)
-                pr = [b.prior(k) for k in range(0, B, 7)]
+                allp = b.priors()             # tcv_batch_get_priors: every window's prior in one call (host threads inside)
+                pr = [allp[k] for k in range(0, B, 7)]
+                one = b.prior(7).export()
+                assert all(np.array_equal(np.asarray(one[key]), np.asarray(allp[7].export()[key])) for key in ("J0", "r0"))
                 out[h] = ([w.pose.copy() for w in W], [p.export() for p in pr])
                 with pytest.raises(gpu.TcvError):
                     pr[0].schur()
