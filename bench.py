@@ -413,7 +413,10 @@ def run_solve(args, rank, world, local, dist):
                        "note": "fused FP64 solve: latency/issue bound, not HBM bound (DESIGN.md 4.1); frac is vs "
                                "the 8 TB/s HBM3E spec; traffic = PMC FETCH_SIZE x2 + WRITE_SIZE of profiles/pmc_traffic.json (static, from the committed profile run)"}
     if world == 1 and not args.no_extras:
-        out.update(stream_figures(tcv, torch, keep, wins=wins, local=local))
+        # the PCIe-inclusive figure uses four host threads x 512 windows: the benchmark's 1024 windows and 1024 more of the same kind
+        _b2, _w2, keep2 = build_batches(tcv, synth, shard_ids(rank, B) + B, B) if B == 1024 else (None, None, ([], [], []))
+        del _b2
+        out.update(stream_figures(tcv, torch, tuple(a + b for a, b in zip(keep, keep2)), wins=wins, local=local))
         out.update(replay_figures(tcv, local))
     if pool is not None:
         out["cpu_baseline"] = cpu_baseline(wins, pool, nproc, args.cpu_budget)
@@ -543,7 +546,7 @@ def run_replay(args, rank, world, local, dist):
     print(json.dumps(out))
 
 
-def replay_figures(tcv, local, streams=8, groups=4, steps=60, warmup=10):
+def replay_figures(tcv, local, streams=8, groups=2, steps=60, warmup=10):
     """the replay number of the default line (one GPU): optimised windows per second of `streams` EuRoC-trajectory streams"""
     import replay
     eng = ReplayEngine(tcv, replay, list(range(streams)), replay.WINDOW_SIZE + 1 + warmup + steps, 60, 8, groups, local)
@@ -572,7 +575,7 @@ def main():
     ap.add_argument("--streams", type=int, default=8, help="replay mode: number of EuRoC-trajectory streams of the whole job")
     ap.add_argument("--features", type=int, default=60)
     ap.add_argument("--lines", type=int, default=8)
-    ap.add_argument("--host-threads", type=int, default=4, help="replay mode: host threads per rank, each advancing its share of the rank's streams")
+    ap.add_argument("--host-threads", type=int, default=2, help="replay mode: host threads per rank, each advancing its share of the rank's streams")
     args = ap.parse_args()
     if args.mode == "stream" and args.gpus > 1:
         raise SystemExit("--mode stream measures one GPU (host threads x HIP streams of one device): use --gpus 1")

@@ -42,6 +42,8 @@ def build(force: bool = False, verbose: bool = False, profile: bool = False, abl
     skip phases (TCV_ABLATE_SKIP bit mask): developer tools.  sanitize=True builds libtcv_hip_san.so: the HOST side (packer, C-ABI,
     native estimator, host halves of the .hip files) under AddressSanitizer + UndefinedBehaviorSanitizer -- the device pass ignores
     the flags (GPU sanitizers are not available on this pool); tests/test_sanitize_cpu.py drives it without a device."""
+    if "--occ1" in sys.argv:      # developer A/B build: chain kernel at one wavefront per SIMD (no register spills), see tcv_solve.hip
+        return _compile(os.path.join(HERE, "libtcv_hip_occ1.so"), verbose, ["-DTCV_CHAIN_OCC1=1"])
     if sanitize:
         return _compile(os.path.join(HERE, "libtcv_hip_san.so"), verbose, SANITIZE_FLAGS, opt="-O1", link_extra=["-fsanitize=address,undefined", "-shared-libsan"])
     if profile:

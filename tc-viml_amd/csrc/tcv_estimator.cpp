@@ -10,6 +10,7 @@
 #include <array>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -697,7 +698,9 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
     Group G[2];
     // (the uploads inside tcv_batch_create are host-synchronous hipMemcpy calls: they are complete before any kernel is launched on
     // these non-blocking streams)
-    const std::array<hipStream_t, 2> g_streams = device_streams();
+    std::array<hipStream_t, 2> g_streams = device_streams();
+    static const bool one_stream = getenv("TCV_EST_ONE_STREAM") != nullptr;      // tuning experiment: both batches of a frame on one stream
+    if (one_stream) g_streams[1] = g_streams[0];
     int rc_all = TCV_OK;
     for (int group = 1; group >= 0; group--) {
         Group &g = G[group];

@@ -2,6 +2,8 @@
 // (tcv_packed.h).  Everything structural that the reference redoes per frame through
 // AddParameterBlock / AddResidualBlock pointer chasing is resolved here, once, into flat gather lists.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <list>
@@ -32,27 +34,55 @@ struct DestKey {
     int kind, o0, o1;
     bool operator<(const DestKey &o) const { return std::tie(kind, o0, o1) < std::tie(o.kind, o.o0, o.o1); }
 };
+// Destinations of one gather program with their item lists, in insertion order (deterministic).  Flat storage: the packer builds two of
+// these per visual chunk for every cold window, and a hash map plus one vector per destination was most of its time.  Destination ids come
+// from a direct-index table over (kind, o0, o1) -- thread-local, validated by a generation stamp instead of being cleared --, the items are
+// appended as (id, item) pairs and bucketed by a stable counting sort in finish().
 struct DestList {
-    std::vector<DestKey> keys;                 // insertion order (deterministic)
-    std::unordered_map<unsigned long long, int> index;      // kind | o0 | o1 packed (the fields are < 2^20): a hash instead of an ordered map,
-                                                            // the packer spends most of its time here when every frame has a new structure
-    std::vector<std::vector<int>> items;
+    std::vector<DestKey> keys;                 // insertion order
     std::vector<std::pair<int, int>> shape;    // (la, lb); lb = 0: triangle of la
-    DestList() { index.reserve(4096); keys.reserve(2048); items.reserve(2048); shape.reserve(2048); }
-    void add(int kind, int o0, int o1, int la, int lb, int item) {
-        DestKey k{kind, o0, o1};
-        const unsigned long long hk = ((unsigned long long)kind << 48) | ((unsigned long long)(unsigned)o0 << 24) | (unsigned long long)(unsigned)o1;
-        auto it = index.find(hk);
-        int id;
-        if (it == index.end()) {
-            id = (int)keys.size();
-            index.emplace(hk, id);
-            keys.push_back(k);
-            items.emplace_back();
-            shape.emplace_back(la, lb);
-        } else id = it->second;
-        items[id].push_back(item);
+    std::vector<int> pair_id, pair_item;       // every add(), in order
+    std::vector<int> start, items;             // after finish(): items of destination id = items[start[id] .. start[id + 1])
+    enum { T_TILE = 0, T_G = 176 * 176, T_RC = T_G + 256, T_HLL = T_RC + 256, T_HCL = T_HLL + 2048, T_SIZE = T_HCL + 65536 };
+    struct Table { std::vector<unsigned> stamp; std::vector<int> val; unsigned gen = 0; Table() : stamp(T_SIZE, 0u), val(T_SIZE, 0) {} };
+    static Table &table() { thread_local Table t; return t; }
+    unsigned gen;
+    bool overflow = false;                     // a key outside the table (reported by the caller as a field overflow)
+    DestList() {
+        Table &t = table();
+        if (++t.gen == 0) { std::fill(t.stamp.begin(), t.stamp.end(), 0u); t.gen = 1; }
+        gen = t.gen;
+        keys.reserve(2048); shape.reserve(2048); pair_id.reserve(16384); pair_item.reserve(16384);
     }
+    void add(int kind, int o0, int o1, int la, int lb, int item) {
+        int slot = -1;
+        if (kind == DK_TILE) { if (o0 >= 0 && o0 < 176 && o1 >= 0 && o1 < 176) slot = T_TILE + o0 * 176 + o1; }
+        else if (kind == DK_G) { if (o0 >= 0 && o0 < 256) slot = T_G + o0; }
+        else if (kind == DK_RC) { if (o0 >= 0 && o0 < 256) slot = T_RC + o0; }
+        else if (kind == DK_HLL) { if (o0 >= 0 && o0 < 2048) slot = T_HLL + o0; }
+        else if (kind == DK_HCL) { if (o0 >= 0 && o0 < 65536) slot = T_HCL + o0; }
+        if (slot < 0) { overflow = true; return; }
+        Table &t = table();
+        int id;
+        if (t.stamp[slot] != gen) {
+            id = (int)keys.size();
+            t.stamp[slot] = gen; t.val[slot] = id;
+            keys.push_back(DestKey{kind, o0, o1});
+            shape.emplace_back(la, lb);
+        } else id = t.val[slot];
+        pair_id.push_back(id); pair_item.push_back(item);
+    }
+    void finish() {
+        const int nd = (int)keys.size();
+        start.assign(nd + 1, 0);
+        for (int id : pair_id) start[id + 1]++;
+        for (int d = 0; d < nd; d++) start[d + 1] += start[d];
+        items.resize(pair_id.size());
+        std::vector<int> pos(start.begin(), start.end() - 1);
+        for (size_t k = 0; k < pair_id.size(); k++) items[pos[pair_id[k]]++] = pair_item[k];
+    }
+    int count(int id) const { return start[id + 1] - start[id]; }
+    const int *first(int id) const { return items.data() + start[id]; }
 };
 
 // A ROW UNIT is one row of a destination block: up to `ncols` register accumulators
@@ -71,17 +101,20 @@ struct RowProg {
 static bool emit_rows(const DestList &dl, RowProg &out, bool inline_items, int wave_items = WAVE_UNIT_ITEMS, int wave_max = WAVE_UNIT_MAX) {
     struct U { int u0, u1, u2, u3, n; };
     std::vector<U> us;
+    us.reserve(dl.keys.size() * 4);
+    if (!inline_items) out.items.reserve(out.items.size() + dl.items.size());
+    if (dl.overflow) return false;
     for (size_t id = 0; id < dl.keys.size(); id++) {
         const DestKey &k = dl.keys[id];
-        const int n = (int)dl.items[id].size();
+        const int n = dl.count((int)id);
         const int la = dl.shape[id].first, lb = dl.shape[id].second;
         int ib = 0, i0 = 0, i1 = 0;
         if (inline_items) {
             if (n > 2) return false;
-            i0 = dl.items[id][0]; i1 = n > 1 ? dl.items[id][1] : 0;
+            i0 = dl.first((int)id)[0]; i1 = n > 1 ? dl.first((int)id)[1] : 0;
         } else {
             ib = (int)out.items.size();
-            for (int it : dl.items[id]) out.items.push_back(it);
+            out.items.insert(out.items.end(), dl.first((int)id), dl.first((int)id) + n);
             if (ib + n >= (1 << 16) * 16) return false;
         }
         if (k.o0 >= (1 << 16) || k.o1 >= (1 << 16) || n >= (1 << 20)) return false;
@@ -129,6 +162,9 @@ void add_pairs(DestList &dl, const std::vector<Col> &cols, MakeItem mk, int rcol
 // each (one helper workgroup per chunk, one lane per factor), and an LDS budget that leaves room for a helper's second tile set
 static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds, int coop_chunks) {
     const int nb = (int)p.blocks.size();
+    static const bool dbg_t = getenv("TCV_DEBUG_PACK2") != nullptr;      // developer: where the symbolic packing spends its time
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) { if (dbg_t) { const auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[pack_plan] %-28s %7.1f us\n", what, std::chrono::duration<double, std::micro>(t - t_prev).count()); t_prev = t; } };
     // ---- classify blocks: landmarks = size-1 Euclidean blocks used only as 4th block of projection factors
     std::vector<int> use_lm(nb, 0), use_other(nb, 0);
     for (auto &f : p.proj) { use_lm[f.b[3]]++; for (int k = 0; k < 3; k++) use_other[f.b[k]]++; if (f.btd >= 0) use_other[f.btd]++; }
@@ -260,6 +296,7 @@ static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds,
     const int c_pool = c_lds - ctiles * 256 - c_vec;
     if (use_chain && (c_pool < chain_pool_doubles((int)chain.size(), nt_c) || c_pool < IMU_REC)) use_chain = false;
 
+    lap("classification + chain steps");
     PlanHdr &H = out.hdr;
     std::memset(&H, 0, sizeof(H));
     H.nblk = nblk; H.nland = L; H.nc = nc; H.nx = nx; H.npp = npp; H.nt = nt; H.ntp = ntp;
@@ -385,13 +422,15 @@ static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds,
         vprog.clear(); sprog.clear(); vchunk_tab.clear(); max_stage = 0; max_area = 0;
         for (auto &c : vch) {
         DestList dl, sl;
+        std::vector<Col> cols;      // (one allocation per chunk instead of one per factor)
+        cols.reserve(4);
         for (int k = 0; k < c.pn; k++) {
             const ProjFac &f = p.proj[order[c.pb + k]];
             const int l = lm_of[f.b[3]];
             const int base = k * prec;
             if (base >= (1 << 21)) { set_error("staging offset overflow"); return TCV_ERR_TOO_LARGE; }
             auto mk = [&](int ca, int cb) { return (int)(((unsigned)base << 11) | ((unsigned)ca << 6) | ((unsigned)cb << 1)); };
-            std::vector<Col> cols;
+            cols.clear();
             for (int s2 = 0; s2 < 3; s2++) cols.push_back(Col{loff[cam_of[f.b[s2]]], 6 * s2, 6});
             if (td_t >= 0) cols.push_back(Col{td_t, 20, 6});      // [td | 5 zero columns]
             for (size_t a2 = 0; a2 < cols.size(); a2++)
@@ -410,7 +449,8 @@ static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds,
             const int base = c.pn * prec + k * LINE_REC;
             if (base >= (1 << 21)) { set_error("staging offset overflow"); return TCV_ERR_TOO_LARGE; }
             auto mk = [&](int ca, int cb) { return (int)(((unsigned)base << 11) | ((unsigned)ca << 6) | ((unsigned)cb << 1) | 1u); };
-            std::vector<Col> cols{Col{loff[cam_of[f.b]], 0, 6}};
+            cols.clear();
+            cols.push_back(Col{loff[cam_of[f.b]], 0, 6});
             add_pairs(dl, cols, mk, 6);
         }
         for (int l = c.lmb; l < c.lmb + c.lmn; l++) {
@@ -426,6 +466,7 @@ static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds,
                 }
             }
         }
+        dl.finish(); sl.finish();
         RowProg vp, sp;
         static const int wu_v = getenv("TCV_WU_V") ? atoi(getenv("TCV_WU_V")) : (int)WAVE_UNIT_ITEMS, wu_s = getenv("TCV_WU_S") ? atoi(getenv("TCV_WU_S")) : (int)WAVE_UNIT_ITEMS,
                          wu_max = getenv("TCV_WU_MAX") ? atoi(getenv("TCV_WU_MAX")) : (int)WAVE_UNIT_MAX;      // tuning experiments
@@ -457,6 +498,7 @@ static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds,
             }
         return TCV_OK;
     };
+    lap("tables, landmark slots");
     std::vector<int> vprog, sprog, vchunk_tab;
     if (use_chain) {
         // chain layout: the LDS pool (staging | landmark coupling area) is small, so the landmarks are dealt evenly to the
@@ -505,6 +547,7 @@ static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds,
         const int rc = emit_all(vch, stage_cap, area_cap, vprog, sprog, vchunk_tab, ms, ma);
         if (rc != TCV_OK) return rc;
     }
+    lap("chunks + gather programs");
     set_error("");
     H.chain = use_chain ? 1 : 0; H.n_e = (int)chain.size(); H.nt_c = nt_c; H.c_stage_cap = stage_cap; H.c_area_cap = area_cap; H.c_pool = c_pool;
     if (use_chain) H.lds_area = area_cap;
@@ -612,6 +655,7 @@ static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds,
                 I.push_back(d);
             }
     }
+    lap("program copy, IMU tables");
     // ---- chain step tables
     while ((I.size() & 3) != 0) I.push_back(0);
     H.o_chain = mark();
@@ -680,6 +724,7 @@ static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds,
     }
     while ((I.size() & 3) != 0) I.push_back(0);          // plans are concatenated: keep every plan 16-byte aligned
     H.plan_ints = (int)I.size();
+    lap("chain tables, frames");
 
     return TCV_OK;
 }

@@ -2141,7 +2141,14 @@ __device__ __noinline__ double grad_max(Ctx<NT> &Cr) {
 // b / ng8 of group b % ng8 (ng8 = number of groups rounded up to a multiple of 8, the XCD count): workgroups are dealt to the XCDs
 // round-robin by index, so the master and the helpers of a group land on the same XCD and hand their exports over through its L2.
 template <int NT, bool MFMA, bool CHAIN, bool COOP = false>
-__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((CHAIN && !COOP) ? 2 : 1, COOP ? 1 : (CHAIN ? 2 : 8)))) solve_kernel(SolveArgs A) {
+// (-DTCV_CHAIN_OCC1, developer build libtcv_hip_occ1.so: the chain kernel compiled for ONE wavefront per SIMD -- 512 registers, no spills -- to
+// measure what the 156 spilled registers of the production kernel cost at equal occupancy, profiles/r03_spill_ab.txt)
+#ifdef TCV_CHAIN_OCC1
+#define TCV_CHAIN_WAVES 1
+#else
+#define TCV_CHAIN_WAVES 2
+#endif
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((CHAIN && !COOP) ? TCV_CHAIN_WAVES : 1, COOP ? 1 : (CHAIN ? TCV_CHAIN_WAVES : 8)))) solve_kernel(SolveArgs A) {
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
     lds_d *lds = (lds_d *)lds_raw;
     const int tid = threadIdx.x;
