@@ -250,8 +250,10 @@ int tcv_batch_get_first_step(tcv_batch *b, int window, double *out, int cap, int
 /* number of distinct graph structures (plans) in the batch, their bytes, launch grid and LDS bytes */
 int tcv_batch_plan_stats(tcv_batch *b, int *num_plans, double *plan_bytes, int *grid, int *lds_bytes);
 /* cooperative mode of this batch (tcv_set_cooperative): helper workgroups per window (0: one workgroup per window), window groups
- * resident at a time, visual chunks of the largest plan */
-int tcv_batch_cooperative(const tcv_batch *b, int *helpers, int *groups, int *chunks);
+ * resident at a time, visual chunks of the largest plan, and the workgroups per window the LAST tcv_batch_solve actually used: 1 when the
+ * option asked for it or when the cooperative launches already in flight on the device left no room (all cooperative grids in flight
+ * must fit the chip together; the fall-back runs the same plan and returns the same bits) */
+int tcv_batch_cooperative(const tcv_batch *b, int *helpers, int *groups, int *chunks, int *last_solve_workgroups);
 /* layout of the fused solver chosen for this batch: 0 chain (speed-biases eliminated block by block), 1 dense; < 0: error */
 int tcv_batch_layout(const tcv_batch *b);
 /* bytes of window input resident in HBM and elapsed milliseconds of the last solve / marginalise

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -21,6 +22,12 @@
 extern "C" int tcv_launch_solve(const tcv::SolveArgs *args, int grid, int nthreads, size_t lds_bytes, void *stream);
 extern "C" int tcv_solve_scratch_doubles(void);
 static int g_solver_variant = 0;   // 0: chain layout when the graph allows it, 1: always the dense 171-dim layout
+// CUs claimed by cooperative launches in flight, per device: a cooperative kernel spins on its partners, so all cooperative grids in
+// flight together must fit the chip (two half-resident cooperative kernels could wait for each other's CUs until their timeouts)
+static std::atomic<int> g_coop_claimed[64];
+static void coop_release(tcv_batch *b) {
+    if (b->coop_claim > 0) { g_coop_claimed[b->coop_dev & 63].fetch_sub(b->coop_claim); b->coop_claim = 0; }
+}
 static int g_coop_helpers = -1;    // cooperative mode of small batches: -1 automatic, 0 off, h >= 1: h helper workgroups per window (when the batch allows it)
 extern "C" int tcv_launch_marg(const void *args, int grid, size_t lds_bytes, void *stream);
 
@@ -458,6 +465,7 @@ static void batch_free(tcv_batch *b) {
     if (b->pending)      // the buffers go back to the free list: nothing of this batch may still be running on any stream it used
         for (hipStream_t st : b->streams) { if (st) (void)hipStreamSynchronize(st); else (void)hipDeviceSynchronize(); }
     if (b->ev_order) (void)hipEventDestroy(b->ev_order);
+    coop_release(b);
     tcv::dev_free(b->d_input);      // (d_dpool, d_win, d_plans, d_plan_base, d_ipool point into it)
     tcv::dev_free(b->d_imublk); tcv::dev_free(b->d_spill); tcv::dev_free(b->d_sqrt_out);
     tcv::dev_free(b->d_coop_ctl); tcv::dev_free(b->d_coop_x); tcv::dev_free(b->d_coop_exp);
@@ -665,6 +673,7 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
     b->grid = std::min(n, n_cu * (b->chain ? 2 : 1));
     if (const char *eg = getenv("TCV_GRID")) { const int g = atoi(eg); if (g > 0) b->grid = std::min(n, g); }      // tuning experiments
     b->slots = b->grid;
+    b->n_cu = n_cu; b->coop_dev = dev;
     if (b->chain && coop_h > 0) {
         b->coop_h = coop_h;
         b->coop_groups = std::min(n, n_cu / (1 + coop_h));
@@ -781,8 +790,16 @@ extern "C" int tcv_batch_solve(tcv_batch *b, const tcv_solver_options *o, void *
     a.max_ticks = 0;
     a.sqrt_out = b->d_sqrt_out;
     // cooperative plans also run on the single-workgroup kernel (workgroups_per_window = 1): same chunks, same additions, same bits
-    const bool coop = b->coop_h > 0 && o->workgroups_per_window != 1;
+    bool coop = b->coop_h > 0 && o->workgroups_per_window != 1;
+    if (coop && b->coop_claim == 0) {      // (a claim still held: the previous cooperative solve of this batch, same stream order)
+        const int want = (1 + b->coop_h) * b->coop_groups;
+        if (g_coop_claimed[b->coop_dev & 63].fetch_add(want) + want > b->n_cu) {
+            g_coop_claimed[b->coop_dev & 63].fetch_sub(want);
+            coop = false;      // the chip is taken by other cooperative launches: the same plan on one workgroup per window, the same bits
+        } else b->coop_claim = want;
+    }
     int grid = b->grid;
+    b->last_wg = coop ? 1 + b->coop_h : 1;
     if (coop) {
         a.coop_h = b->coop_h; a.coop_groups = b->coop_groups; a.coop_exp_chunks = b->coop_exp_chunks; a.coop_exp_stride = b->coop_exp_stride;
         a.coop_ctl = b->d_coop_ctl; a.coop_x = b->d_coop_x; a.coop_exp = b->d_coop_exp;
@@ -822,6 +839,7 @@ extern "C" int tcv_batch_synchronize(tcv_batch *b) {
     for (hipStream_t st : b->streams) { if (st) HIPCHK(hipStreamSynchronize(st)); else HIPCHK(hipDeviceSynchronize()); }
     b->streams.clear();
     b->pending = false;
+    coop_release(b);
     if (b->solved) hipEventElapsedTime(&b->solve_ms, b->ev0, b->ev1);
     tcv_marg_elapsed(b);
     return TCV_OK;
@@ -952,8 +970,9 @@ extern "C" int tcv_batch_profile(tcv_batch *b, double *out32) {
     HIPCHK(hipMemset(b->d_prof, 0, sizeof(double) * h.size()));
     return TCV_OK;
 }
-extern "C" int tcv_batch_cooperative(const tcv_batch *b, int *helpers, int *groups, int *chunks) {
+extern "C" int tcv_batch_cooperative(const tcv_batch *b, int *helpers, int *groups, int *chunks, int *last_solve_workgroups) {
     if (!b) return TCV_ERR_INVALID;
+    if (last_solve_workgroups) *last_solve_workgroups = b->last_wg;
     if (helpers) *helpers = b->coop_h;
     if (groups) *groups = b->coop_h > 0 ? b->coop_groups : 0;
     if (chunks) { int c = 0; for (auto &H : b->plans) c = std::max(c, H.n_vis_chunk); *chunks = c; }

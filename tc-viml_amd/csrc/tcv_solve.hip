@@ -2137,9 +2137,11 @@ __device__ __noinline__ double grad_max(Ctx<NT> &Cr) {
 }
 
 // ---- the kernel ---------------------------------------------------------------------------------------
-// COOP (cooperative mode, chain layout, tcv_packed.h): the grid holds 1 + coop_h workgroups per window GROUP.  Workgroup b is member
-// b / ng8 of group b % ng8 (ng8 = number of groups rounded up to a multiple of 8, the XCD count): workgroups are dealt to the XCDs
-// round-robin by index, so the master and the helpers of a group land on the same XCD and hand their exports over through its L2.
+// COOP (cooperative mode, chain layout, tcv_packed.h): the grid holds 1 + coop_h workgroups per window GROUP, in blocks of eight groups.
+// Inside a block workgroup r is member r / 8 of group r % 8: workgroups are dealt to the eight XCDs round-robin by index, so the master
+// and the helpers of a group land on the same XCD and hand their exports over through its L2, and the members of a group are close
+// together in dispatch order (a group is resident as a whole or waits as a whole; tcv_batch_solve additionally keeps the cooperative
+// launches in flight within the CU count and runs the same plan with one workgroup per window otherwise).
 template <int NT, bool MFMA, bool CHAIN, bool COOP = false>
 // (-DTCV_CHAIN_OCC1, developer build libtcv_hip_occ1.so: the chain kernel compiled for ONE wavefront per SIMD -- 512 registers, no spills -- to
 // measure what the 156 spilled registers of the production kernel cost at equal occupancy, profiles/r03_spill_ab.txt)
@@ -2154,8 +2156,9 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((CHAIN 
     const int tid = threadIdx.x;
     int slot = blockIdx.x, wstride = gridDim.x;      // scratch slot and first window of this workgroup; window stride
     if (COOP) {
-        const int ng8 = (int)gridDim.x / (1 + A.coop_h);
-        const int member = (int)blockIdx.x / ng8, g = (int)blockIdx.x - member * ng8;
+        const int G8 = 8 * (1 + A.coop_h);      // workgroups of a block of eight groups: contiguous in dispatch order, one group per XCD
+        const int blk8 = (int)blockIdx.x / G8, r8 = (int)blockIdx.x - blk8 * G8;
+        const int member = r8 >> 3, g = blk8 * 8 + (r8 & 7);
         if (g >= A.coop_groups) return;
         if (member > 0) { coop_helper<NT>(A, lds, g, member - 1); return; }
         slot = g; wstride = A.coop_groups;

@@ -492,9 +492,9 @@ class Batch:
         return dict(num_plans=a.value, plan_bytes=b.value, grid=c.value, lds_bytes=d.value, layout=("chain", "dense")[lib().tcv_batch_layout(self.h)])
 
     def cooperative(self):
-        a, b, c = C.c_int(), C.c_int(), C.c_int()
-        check(lib().tcv_batch_cooperative(self.h, C.byref(a), C.byref(b), C.byref(c)))
-        return dict(helpers=a.value, groups=b.value, chunks=c.value)
+        a, b, c, d = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        check(lib().tcv_batch_cooperative(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return dict(helpers=a.value, groups=b.value, chunks=c.value, last_solve_workgroups=d.value)
 
     def __del__(self):
         if getattr(self, "h", None) is not None and _lib is not None:

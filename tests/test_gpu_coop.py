@@ -46,9 +46,9 @@ def test_cooperative_mode_is_bit_identical_to_one_workgroup_per_window(gpu):
     wins = [main, pre] + [synth.window_at(synth.make_windows(910, 3), k) for k in range(3)]
     Wc, bc, sc = _solve(gpu, wins, 8, True, 0)
     co = bc.cooperative()
-    assert co["helpers"] >= 2 and co["groups"] == len(wins) and co["chunks"] >= co["helpers"], co
+    assert co["helpers"] >= 2 and co["groups"] == len(wins) and co["chunks"] >= co["helpers"] and co["last_solve_workgroups"] == 1 + co["helpers"], co
     W1, b1, s1 = _solve(gpu, wins, 8, True, 1)
-    assert b1.cooperative() == co                       # the same plan, run by one workgroup per window
+    assert b1.cooperative() == dict(co, last_solve_workgroups=1)      # the same plan, run by one workgroup per window
     _same_bits(sc, s1, Wc, W1, len(wins))
     # to convergence with the Ceres tolerances (accept / reject and termination decisions included)
     Wc, bc, sc = _solve(gpu, wins, 40, False, 0)
@@ -71,7 +71,7 @@ def test_cooperative_mode_on_a_replay_sized_window_and_more_chunks_than_helpers(
             gpu.check(gpu.lib().tcv_set_cooperative(h))
             Wc, bc, sc = _solve(gpu, [w], 8, True, 0, marg=True)
             co = bc.cooperative()
-            assert co["helpers"] == (7 if h < 0 else 2) and co["chunks"] >= co["helpers"], co
+            assert co["helpers"] == (7 if h < 0 else 2) and co["chunks"] >= co["helpers"] and co["last_solve_workgroups"] == 1 + co["helpers"], co
             W1, b1, s1 = _solve(gpu, [w], 8, True, 1, marg=True)
             _same_bits(sc, s1, Wc, W1, 1)
             assert np.array_equal(bc.prior(0).export()["J0"], b1.prior(0).export()["J0"])
@@ -93,3 +93,27 @@ def test_cooperative_mode_off_and_large_batches_keep_one_workgroup_per_window(gp
     many = [synth.window_at(synth.make_windows(930, 130), k) for k in range(130)]      # 130 x (1 + 2) > 256 CUs: no room for helpers
     W, b, s = _solve(gpu, many, 2, True, 0)
     assert b.cooperative()["helpers"] <= 0 or 130 * (1 + b.cooperative()["helpers"]) <= 256
+
+
+def test_cooperative_launches_in_flight_must_fit_the_chip(gpu):
+    """a cooperative kernel spins on its partner workgroups, so all cooperative grids in flight together must be resident: a second
+    batch whose groups do not fit next to the first one's runs the SAME plan with one workgroup per window (same bits), and gets its
+    groups back once the first batch has been synchronised."""
+    n = 24
+    wins = [synth.window_at(synth.make_windows(940, n), k) for k in range(n)]
+    try:
+        gpu.check(gpu.lib().tcv_set_cooperative(7))      # 24 x 8 = 192 of 256 CUs per batch
+        Wa = [gpu.Window(w) for w in wins]; Wb = [gpu.Window(w) for w in wins]
+        a = gpu.Batch(Wa); b = gpu.Batch(Wb)
+        assert a.cooperative()["helpers"] == 7 and b.cooperative()["helpers"] == 7
+        o = gpu.default_options(8, True)
+        a.solve(o); b.solve(o)                           # a is still in flight (not synchronised) when b is launched
+        assert a.cooperative()["last_solve_workgroups"] == 8 and b.cooperative()["last_solve_workgroups"] == 1
+        a.synchronize(); b.synchronize(); a.download_states(); b.download_states()
+        sa, sb = a.summaries(), b.summaries()
+        _same_bits(sa, sb, Wa, Wb, n)
+        b.solve(o)
+        assert b.cooperative()["last_solve_workgroups"] == 8
+        b.synchronize()
+    finally:
+        gpu.check(gpu.lib().tcv_set_cooperative(-1))
