@@ -750,10 +750,14 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
         if (g.rc == TCV_OK) g.rc = tcv_batch_get_summaries(g.b, g.sum.data(), nb);
         if (g.rc == TCV_OK && group) g.rc = tcv_batch_download_priors_compact(g.b);
         g.est_rc.assign(nb, TCV_OK);
+        if (g.rc == TCV_OK)
+            for (int k = 0; k < nb; k++)      // ceres::Solve's FAILURE (no valid step / a cooperative group that timed out): the window's states are not applied
+                if (g.sum[k].termination == 5 || !(g.sum[k].final_cost == g.sum[k].final_cost)) { g.est_rc[k] = TCV_ERR_NUMERIC; g.est_msg = "solver failure (no valid step, NaN cost or workgroup time-out)"; }
         if (g.rc == TCV_OK && group)
             for (int k = 0; k < nb; k++) {
                 // a window whose marginalisation did not converge (TCV_ERR_NUMERIC) fails alone: the other estimators of the lock-step
                 // batch are applied, this one reports the failure from tcv_estimator_finish_frame
+                if (g.est_rc[k] != TCV_OK) continue;
                 g.est_rc[k] = tcv_batch_get_prior(g.b, k, &g.newp[k]);
                 if (g.est_rc[k] != TCV_OK && g.est_rc[k] != TCV_ERR_NUMERIC) { g.rc = g.est_rc[k]; break; }
                 if (g.est_rc[k] != TCV_OK) g.est_msg = tcv_last_error();

@@ -3,7 +3,7 @@
 #   bash tools/profile_round.sh <tag>
 # rocprofv3 --kernel-trace --stats of the benchmark command, separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ counters;
 # kernel-trace only, as gpurun requires), the bench line itself and the per-phase cycle tables of the -DTCV_PROFILE build.
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
@@ -29,8 +29,15 @@ fi
 python3 tests/dev/stream_breakdown.py > $O/stream_breakdown.txt 2>&1
 python3 tests/dev/parity_sweep.py 1024 > $O/parity_sweep.txt 2>&1
 python3 tests/dev/marg_floor.py > $O/marg_floor.txt 2>&1
-python3 tests/dev/replay_seed_sweep.py > $O/replay_seed_sweep.txt 2>&1
-TCV_MARG_EIG_MM=1 python3 tests/dev/replay_seed_sweep.py > $O/replay_seed_sweep_eig.txt 2>&1
+# round 3: small-batch latency (cooperative mode) with the per-phase table of the -DTCV_PROFILE build, replay and stream modes, replay frame accounting
+python3 tools/dev_small_batch.py 60 12 > $O/small_batch.txt 2>&1
+if [ -f tc-viml_amd/libtcv_hip_prof.so ]; then
+  TCV_DEBUG=1 TCV_LIB=tc-viml_amd/libtcv_hip_prof.so python3 tools/dev_small_batch.py 60 3 > $O/small_batch_prof.txt 2>&1
+fi
+python3 bench.py --mode replay --steps 150 --warmup 10 > $O/bench_replay.json 2> /dev/null
+python3 bench.py --mode replay --steps 150 --warmup 10 --host-threads 1 > $O/bench_replay_1thread.json 2> /dev/null
+python3 bench.py --mode stream --windows 2048 > $O/bench_stream_2048.json 2> /dev/null
+python3 tools/replay_euroc.py --native --profile --frames 340 --out $O/euroc > $O/replay_euroc_native.json 2> /dev/null
 find $O -name "*_kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
 python3 - <<PY
 import csv, glob, collections, json
