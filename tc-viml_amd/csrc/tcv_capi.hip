@@ -809,6 +809,7 @@ extern "C" int tcv_batch_solve(tcv_batch *b, const tcv_solver_options *o, void *
         a.coop_timeout = (long long)khz * 2000;      // 2 s
     } else if (b->coop_h > 0) grid = b->slots;
     b->sqrt_out_valid = b->d_sqrt_out != nullptr;
+    if (const char *rm = getenv("TCV_ROLE_MODE")) a.role_mode = atoi(rm);
     if (const char *sk = getenv("TCV_ABLATE_SKIP")) a.pad2 = (int)(unsigned)strtoul(sk, nullptr, 0);      // -DTCV_ABLATE builds only read it
     if (o->max_solver_time_in_seconds > 0.0 && !o->fixed_iterations) {
         int dev = 0, khz = 0;

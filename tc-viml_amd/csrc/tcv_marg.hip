@@ -86,6 +86,7 @@ struct MargArgs {
     double *scratch;             // per workgroup MARG_SCR_STRIDE
     int nwin, state_stride, use_solved_state;
     int eig_mm;                  // 1: Amm^+ through the eigen-decomposition for every window (TCV_MARG_EIG_MM=1: A/B checks)
+    int eig_flags;               // developer A/B switches of the eigen-solver of A' (TCV_MARG_EIG_FLAGS): 1 = round 2's eigenvalue search (every eigenvalue, 4- / 7-section)
 };
 
 __device__ __forceinline__ int pidx(int a, int b) { return a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a; }
@@ -265,6 +266,102 @@ __device__ __noinline__ void eig_multisection(const lds_d *dv, const lds_d *e2, 
     if (k < n && g < GPW && sub == 0) lam[k] = 0.5 * (lo + hi);
 }
 
+// ---- round 3: the eigenvalue search the marginalisation actually needs -------------------------------------------------------
+// marginalization_factor.cpp:284-293 keeps the eigenvalues above eps = 1e-8 and zeroes the others, and about half of the spectrum of
+// A' is noise around zero (the directions the dropped factors do not constrain): only the eigenvalues above eps are located, the
+// others are reported as 0 (they are thresholded to exactly that).
+//   * Sturm count by the scaled determinant recurrence p_i = (d_i - x) p_i-1 - e_i-1^2 p_i-2 on the matrix scaled by a power of two
+//     (|T| <= 1: exact, and the products cannot overflow within a block of eight steps): four instructions per step -- subtract,
+//     multiply, fused multiply-add, and v_alignbit shifting the sign bit of p_i into a mask; the sign changes of a block are counted
+//     with one popcount, the pair (p_i, p_i-1) is renormalised by an exact power of two per block.  An exact zero p_i counts like a
+//     positive one; the next value -e_i^2 p_i-1 then carries the opposite sign of p_i-1: the same count as the usual "a zero takes the
+//     sign opposite to its predecessor" rule, provided e_i^2 > 0, which a floor far below the rounding level of T guarantees.
+//   * first trip: 256 lanes evaluate the count at eps and at 255 points up to the Gershgorin bound -- k0 = count(eps) eigenvalues are
+//     null, every other one gets a bracket 1/256 of the interval wide from a binary search in the table of counts;
+//   * then (LPE + 1)-section with LPE = 6, 5, 4 or 3 lanes per eigenvalue, whichever fits the n - k0 eigenvalues left, until the
+//     bracket is 2^-62 of the first interval (the width the 31 four-section trips of round 2 ended at).
+__device__ __forceinline__ int sturm_count(const lds_d *de, int n, double x) {
+    typedef double v2f64 __attribute__((ext_vector_type(2)));
+    typedef const __attribute__((address_space(3))) v2f64 lds_v2;
+    double pp = 1.0, pc = de[0] - x;
+    unsigned mask = (unsigned)__double2hiint(pc) >> 31;
+    int cnt = (int)mask;      // p_-1 = 1
+    int i = 1;
+    for (; i + 7 < n; i += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const v2f64 v = *(lds_v2 *)(de + 2 * (i + u));      // {d_i, e_i-1^2}: one 16-byte broadcast load
+            const double pn = fma(v.x - x, pc, -(v.y * pp));
+            mask = __builtin_amdgcn_alignbit(mask, (unsigned)__double2hiint(pn), 31u);
+            pp = pc; pc = pn;
+        }
+        cnt += __builtin_popcount((mask ^ (mask >> 1)) & 0xffu);
+        const int e = max(__builtin_amdgcn_frexp_exp(pc), __builtin_amdgcn_frexp_exp(pp));
+        pc = ldexp(pc, -e); pp = ldexp(pp, -e);
+    }
+    int rem = 0;
+    for (; i < n; i++, rem++) {
+        const v2f64 v = *(lds_v2 *)(de + 2 * i);
+        const double pn = fma(v.x - x, pc, -(v.y * pp));
+        mask = __builtin_amdgcn_alignbit(mask, (unsigned)__double2hiint(pn), 31u);
+        pp = pc; pc = pn;
+    }
+    cnt += __builtin_popcount((mask ^ (mask >> 1)) & ((1u << rem) - 1u));
+    return cnt;
+}
+template <int LPE>
+__device__ __forceinline__ void eig_refine(const lds_d *de, lds_d *lam, int n, int k0, const lds_i *ctab, double xe, double w256, double unscale, int trips, int tid) {
+    constexpr int GPW = 64 / LPE;
+    const int lane = tid & 63, wave = tid >> 6, g = lane / LPE, sub = lane - g * LPE, gc = min(g, GPW - 1);
+    const int k = k0 + wave * GPW + gc;
+    if (k0 + wave * GPW >= n) return;          // whole wavefront beyond the last eigenvalue
+    // bracket from the table of the first trip: ctab[t] = count(x_t), t = 0 .. 255, ctab[256] = n; invariant ctab[a] <= k < ctab[b]
+    const int kk = min(k, n - 1);
+    int a = 0, b = 256;
+#pragma unroll
+    for (int it = 0; it < 8; it++) { const int mid = (a + b) >> 1; const bool up = ctab[mid] > kk; b = up ? mid : b; a = up ? a : mid; }
+    double lo = xe + w256 * (double)a, hi = xe + w256 * (double)b;
+    for (int it = 0; it < trips; it++) {
+        const double ws = (hi - lo) * (1.0 / (double)(LPE + 1));
+        const double x = lo + ws * (double)(sub + 1);
+        const int cnt = sturm_count(de, n, x);
+        // eigenvalue k lies below x_sub iff cnt > k; the first such interior point of the group closes the new interval from above
+        const unsigned long long bal = __ballot(cnt > kk && g < GPW);
+        const unsigned grp = (unsigned)((bal >> (gc * LPE)) & ((1ull << LPE) - 1ull));
+        const int f = grp ? (__ffs((int)grp) - 1) : LPE;      // number of interior points at or below the eigenvalue
+        const double nlo = lo + ws * (double)f, nhi = (f == LPE) ? hi : lo + ws * (double)(f + 1);
+        lo = nlo; hi = nhi;
+    }
+    if (k < n && g < GPW && sub == 0) lam[k] = 0.5 * (lo + hi) * unscale;
+}
+// dv, e2: the tridiagonal; de: 2 n doubles of workspace (16-byte aligned), ctab: 257 ints.  gu: upper Gershgorin bound (widened).
+template <int NT>
+__device__ __noinline__ void eig_values_above_eps(const lds_d *dv, const lds_d *e2, lds_d *de, lds_i *ctab, lds_d *lam, int n, double gu, double tnorm, int tid) {
+    // scale by a power of two so that |T| <= 1
+    const int ex = __builtin_amdgcn_frexp_exp(fmax(tnorm, 1e-300));
+    const double sc = ldexp(1.0, -ex), unscale = ldexp(1.0, ex);
+    for (int i = tid; i < n; i += NT) { de[2 * i] = dv[i] * sc; de[2 * i + 1] = (i > 0) ? fmax(e2[i - 1] * sc * sc, 1e-200) : 0.0; }
+    const double xe = 1e-8 * sc, xu = gu * sc;
+    const double w256 = (xu - xe) * (1.0 / 256.0);
+    __syncthreads();
+    if (!(xu > xe)) {      // nothing above eps
+        for (int i = tid; i < n; i += NT) lam[i] = 0.0;
+        return;
+    }
+    if (tid < 256) ctab[tid] = sturm_count(de, n, xe + w256 * (double)tid);
+    if (tid == 256 % NT) ctab[256] = n;
+    __syncthreads();
+    const int k0 = min(ctab[0], n);
+    for (int i = tid; i < k0; i += NT) lam[i] = 0.0;
+    const int nret = n - k0;
+    constexpr int NW = NT / 64;
+    // trips: (LPE + 1)^-trips <= 2^-54
+    if (nret <= 10 * NW) eig_refine<6>(de, lam, n, k0, ctab, xe, w256, unscale, 20, tid);
+    else if (nret <= 12 * NW) eig_refine<5>(de, lam, n, k0, ctab, xe, w256, unscale, 21, tid);
+    else if (nret <= 16 * NW) eig_refine<4>(de, lam, n, k0, ctab, xe, w256, unscale, 24, tid);
+    else eig_refine<3>(de, lam, n, k0, ctab, xe, w256, unscale, 27, tid);
+}
+
 // Reflector i of the tridiagonalisation (v[i+1] = 1 implicit, v[i+2 .. n-1] stored) lives packed, reflector after reflector
 __device__ __forceinline__ int refl_off(int i, int n) { return i * (n - 2) - (i * (i - 1)) / 2; }
 
@@ -272,15 +369,16 @@ __device__ __forceinline__ int refl_off(int i, int n) { return i * (n - 2) - (i 
 // successive reflectors do not wait on LDS write -> read trips.  512 threads: four lanes per column, 16 columns per wavefront; 256
 // threads: three lanes per column, five columns per 16-lane row (its last lane idle) = 20 per wavefront, so that a column's three
 // partial sums meet through DPP row shifts.
+// c0: first column to transform (the columns of the thresholded eigenvalues in front of it are zero and stay zero).
 template <int LPC>
-__device__ __noinline__ void eig_backtransform(const lds_d *Hq, lds_d *Z, const lds_d *tauv, int n, int ld, int tid) {
+__device__ __noinline__ void eig_backtransform(const lds_d *Hq, lds_d *Z, const lds_d *tauv, int n, int ld, int tid, int c0) {
     constexpr int CPW = LPC == 4 ? 16 : 20, RPL = (MARG_MAX_N + LPC - 1) / LPC;
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15;
     const int gl = LPC == 4 ? lane / 4 : (lane >> 4) * 5 + min(li / 3, 4);
     const int sub = LPC == 4 ? (lane & 3) : li - 3 * min(li / 3, 4);      // (the idle lane 15 of a row gets sub = 3: it owns nothing)
-    if (wave * CPW >= n) return;
-    const int c = wave * CPW + gl;
+    if (c0 + wave * CPW >= n) return;
+    const int c = c0 + wave * CPW + gl;
     const bool own = sub < LPC && c < n;
     const int cs = own ? c : 0;
     double z[RPL];
@@ -333,7 +431,8 @@ __device__ __noinline__ void eig_backtransform(const lds_d *Hq, lds_d *Z, const 
 
 __device__ __forceinline__ double rank2(double a, double vr, double wc, double wr, double vc) { return a - (vr * wc + wr * vc); }
 template <int NT>
-__device__ __noinline__ bool sym_eig_tridiag(lds_d *A, lds_d *Hq, lds_d *sm, lds_d *lam, int n, int ld, int tid, gbl_d *dbg) {
+__device__ __noinline__ bool sym_eig_tridiag(lds_d *A, lds_d *Hq, lds_d *sm, lds_d *lam, int n, int ld, int tid, gbl_d *dbg, int flags) {
+    const bool old_search = (flags & 1) != 0;
     constexpr int NW = NT / 64;
     lds_d *Z = A;                          // the eigenvectors overwrite the matrix: after the tridiagonalisation only T (dv, ev), the
                                            // reflectors (packed in Hq) and tau are needed
@@ -425,28 +524,37 @@ __device__ __noinline__ bool sym_eig_tridiag(lds_d *A, lds_d *Hq, lds_d *sm, lds
             // clamped loads and masked updates per lane -- the skipped slots held nothing (c >= m): the same sums, bit for bit
             const int part8 = tid & 7;
 #define TCV_R2_BODY(J)                                                                                                               \
-            for (int rr = tid >> 3; rr < ((m + 7) & ~7); rr += NT / 8) {                                                             \
-                const int rc = min(rr, m - 1);                                                                                       \
-                const double vr = vbuf[rc], wr = pbuf[rc] + K * vr;                                                                  \
-                lds_d *row = A + (i + 1 + rc) * ld + (i + 1);                                                                        \
-                double vc[J], pc[J], av[J], xo[J];      /* every load in flight at once */                                           \
-                _Pragma("unroll") for (int j = 0; j < J; j++) { const int c = min(part8 + 8 * j, m - 1); vc[j] = vbuf[c]; pc[j] = pbuf[c]; av[j] = row[c]; xo[j] = xold[c]; } \
-                double un = 0, x2 = 0;                                                                                               \
-                _Pragma("unroll") for (int j = 0; j < J; j++) {                                                                      \
-                    const int c = part8 + 8 * j;                                                                                     \
-                    if (c < m) {                                                                                                     \
-                        const double wc = pc[j] + K * vc[j];                                                                         \
-                        const double nv = rank2(av[j], vr, wc, wr, vc[j]);                                                           \
-                        const double xn = rank2(xo[j], v0, wc, w0, vc[j]);      /* new A22[0][c], bit for bit what row 0's lanes store */ \
-                        if (rr < m) row[c] = nv;                                                                                     \
-                        if (c >= 1) { un += nv * xn; if (c >= 2) x2 += xn * xn; }                                                    \
-                    }                                                                                                                \
+            {                                                                                                                        \
+                /* what depends on the column only -- v, w = p + K v and the new first row x' -- once per step, not once per row pass */ \
+                double vc[J], wc[J], xn[J];                                                                                          \
+                {                                                                                                                    \
+                    double pc[J], xo[J];                                                                                             \
+                    _Pragma("unroll") for (int j = 0; j < J; j++) { const int c = min(part8 + 8 * j, m - 1); vc[j] = vbuf[c]; pc[j] = pbuf[c]; xo[j] = xold[c]; } \
+                    _Pragma("unroll") for (int j = 0; j < J; j++) { wc[j] = pc[j] + K * vc[j]; xn[j] = rank2(xo[j], v0, wc[j], w0, vc[j]); }      /* new A22[0][c], bit for bit what row 0's lanes store */ \
                 }                                                                                                                    \
-                un += down_dpp<0x101>(un); un += down_dpp<0x102>(un); un += down_dpp<0x104>(un);      /* lane 0 of the 8-lane group */      \
-                x2 += down_dpp<0x101>(x2); x2 += down_dpp<0x102>(x2); x2 += down_dpp<0x104>(x2);                                            \
-                if (part8 == 0 && rr >= 1 && rr < m) ubuf[rr - 1] = un;                                                              \
-                if (part8 == 0 && rr == 1) xnb[(i + 1) & 1] = x2;                                                                    \
-                if (part8 == 0 && rr > 0 && rr < m) hq[rr - 1] = vr;                                                                 \
+                double x2 = 0;                                                                                                       \
+                _Pragma("unroll") for (int j = 0; j < J; j++) { const int c = part8 + 8 * j; if (c < m && c >= 2) x2 += xn[j] * xn[j]; } \
+                x2 += down_dpp<0x101>(x2); x2 += down_dpp<0x102>(x2); x2 += down_dpp<0x104>(x2);                                     \
+                if (tid == 8) xnb[(i + 1) & 1] = x2;      /* (lane 0 of the group of row 1) */                                       \
+                for (int rr = tid >> 3; rr < ((m + 7) & ~7); rr += NT / 8) {                                                         \
+                    const int rc = min(rr, m - 1);                                                                                   \
+                    const double vr = vbuf[rc], wr = pbuf[rc] + K * vr;                                                              \
+                    lds_d *row = A + (i + 1 + rc) * ld + (i + 1);                                                                    \
+                    double av[J];      /* every load in flight at once */                                                            \
+                    _Pragma("unroll") for (int j = 0; j < J; j++) av[j] = row[min(part8 + 8 * j, m - 1)];                            \
+                    double un = 0;                                                                                                   \
+                    _Pragma("unroll") for (int j = 0; j < J; j++) {                                                                  \
+                        const int c = part8 + 8 * j;                                                                                 \
+                        if (c < m) {                                                                                                 \
+                            const double nv = rank2(av[j], vr, wc[j], wr, vc[j]);                                                    \
+                            if (rr < m) row[c] = nv;                                                                                 \
+                            if (c >= 1) un += nv * xn[j];                                                                            \
+                        }                                                                                                            \
+                    }                                                                                                                \
+                    un += down_dpp<0x101>(un); un += down_dpp<0x102>(un); un += down_dpp<0x104>(un);      /* lane 0 of the 8-lane group */ \
+                    if (part8 == 0 && rr >= 1 && rr < m) ubuf[rr - 1] = un;                                                          \
+                    if (part8 == 0 && rr > 0 && rr < m) hq[rr - 1] = vr;                                                             \
+                }                                                                                                                    \
             }
             if (m > 40) { TCV_R2_BODY(10) } else if (m > 16) { TCV_R2_BODY(5) } else { TCV_R2_BODY(2) }
 #undef TCV_R2_BODY
@@ -469,13 +577,16 @@ __device__ __noinline__ bool sym_eig_tridiag(lds_d *A, lds_d *Hq, lds_d *sm, lds
     __syncthreads();
     EMARK(0);
     // ---- (2) eigenvalues by multisection
-    if (NT >= 512) eig_multisection<6, 10, 22>(dv, e2, lam, n, gl, gu, pivmin, tid);
-    else eig_multisection<3, 21, 31>(dv, e2, lam, n, gl, gu, pivmin, tid);
+    if (old_search) {
+        if (NT >= 512) eig_multisection<6, 10, 22>(dv, e2, lam, n, gl, gu, pivmin, tid);
+        else eig_multisection<3, 21, 31>(dv, e2, lam, n, gl, gu, pivmin, tid);
+    } else eig_values_above_eps<NT>(dv, e2, ubuf, (lds_i *)vbuf, lam, n, gu, tnorm, tid);      // ubuf + xold: 192 doubles >= 2 n; vbuf + pbuf: 160 doubles >= 257 ints
     __syncthreads();
     EMARK(1);
     // ---- (3) eigenvectors of T: twisted factorisation, one lane per eigenvector (column k of Z as workspace)
     // eigenvalues <= eps are zeroed by the thresholding of marginalization_factor.cpp:284-293: their vectors are never
     // used, and inside that (possibly large, rank-deficient) null cluster they are not even defined -> zero columns
+    double resid = 0.0;
     if (tid < n && !(lam[tid] > 1e-8)) {
         for (int i = 0; i < n; i++) Z[i * ld + tid] = 0.0;
     } else if (tid < n) {
@@ -527,6 +638,7 @@ __device__ __noinline__ bool sym_eig_tridiag(lds_d *A, lds_d *Hq, lds_d *sm, lds
         Z[rbest * ld + k] = 1.0;
         const double sc = 1.0 / sqrt(nrm2);
         for (int i = 0; i < n; i++) Z[i * ld + k] *= sc;
+        resid = gbest * sc;      // (T - lambda) z = gamma_r e_r with z_r = 1: the residual of the normalised pair is |gamma_r| / |z|
     }
     __syncthreads();
     EMARK(2);
@@ -557,7 +669,14 @@ __device__ __noinline__ bool sym_eig_tridiag(lds_d *A, lds_d *Hq, lds_d *sm, lds
     __syncthreads();
     EMARK(3);
     // ---- (5) back-transformation Z <- Q Z
-    eig_backtransform<(NT >= 512 ? 4 : 3)>(Hq, Z, tauv, n, ld, tid);
+    // the retained eigenvalues are the last ones (ascending order): with at most 16 columns per wavefront left, four lanes per column
+    // (20 register rows per lane instead of 27) do it in the 256-thread shape too
+    {
+        int c0 = 0;
+        if (!old_search) { while (c0 < n && !(lam[c0] > 1e-8)) c0++; }
+        if (NT >= 512 || n - c0 <= 16 * NW) eig_backtransform<4>(Hq, Z, tauv, n, ld, tid, c0);
+        else eig_backtransform<3>(Hq, Z, tauv, n, ld, tid, c0);
+    }
     __syncthreads();
     EMARK(4);
     // ---- checks: sum lambda = trace, and (Z_R' Z_R) w = w for two probe vectors w over the retained columns R
@@ -577,18 +696,21 @@ __device__ __noinline__ bool sym_eig_tridiag(lds_d *A, lds_d *Hq, lds_d *sm, lds
             dev = fmax(fabs(t1 - 1.0), fabs(t2 - ((tid & 1) ? -1.0 : 1.0)));
         }
     }
-    for (int o = 32; o > 0; o >>= 1) dev = fmax(dev, __shfl_xor(dev, o));
+    for (int o = 32; o > 0; o >>= 1) { dev = fmax(dev, __shfl_xor(dev, o)); resid = fmax(resid, __shfl_xor(resid, o)); }
     __syncthreads();
-    if (lane == 0) red[wave] = dev;
+    if (lane == 0) { red[wave] = dev; red[8 + wave] = resid; }
     __syncthreads();
-    dev = 0;
+    dev = 0; resid = 0;
 #pragma unroll
-    for (int w = 0; w < NW; w++) dev = fmax(dev, red[w]);
+    for (int w = 0; w < NW; w++) { dev = fmax(dev, red[w]); resid = fmax(resid, red[8 + w]); }
     double sl = 0;
     for (int i = 0; i < n; i++) sl += lam[i];
     __syncthreads();
     EMARK(5);
     if (tid == 0 && dbg) { dbg[0] = dev; dbg[1] = sl; dbg[2] = trace; dbg[3] = tnorm; dbg[4] = lam[0]; dbg[5] = lam[n - 1]; }
+    // the null eigenvalues are not located any more (reported as 0), so the trace test of round 2 is replaced by the residual of every
+    // retained eigenpair, |(T - lambda) z| / |z| = |gamma_r| / |z| from its twisted factorisation, against the same 1e-9 |T| n
+    if (!old_search) return (dev < 1e-7) && (resid <= 1e-9 * fmax(tnorm, 1e-300) * n) && (dev == dev) && (resid == resid);
     // Orthogonality defect delta of the retained eigenvectors = relative error of A' = Z S Z'.  1e-7 is below the FP64
     // reproducibility floor of A' itself (4.8e-7 between two summation orders); a tighter gate
     // only sends windows that sit at 1.0e-8..1.3e-8 (1 in 1024 on the benchmark batch) to the 100x slower Jacobi sweep.
@@ -1208,7 +1330,7 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((amdgpu_waves_per_eu(2,
         // over the diagonalised A' at the end: the LDS holds one n x n matrix)
         int sweeps2 = 0;
         {
-            const bool ok = sym_eig_tridiag<MARG_NT>(As, R2, sm, rot, n, ldn, tid, out + MARG_OUT_X + MARG_MAX_X + 14);    // rot: 160 doubles >= n eigenvalues
+            const bool ok = sym_eig_tridiag<MARG_NT>(As, R2, sm, rot, n, ldn, tid, out + MARG_OUT_X + MARG_MAX_X + 14, Aarg.eig_flags);    // rot: 160 doubles >= n eigenvalues
             if (ok) {
                 if (tid < n) lam[tid] = rot[tid];
             } else {
@@ -1614,6 +1736,7 @@ int tcv_marg_run(tcv_batch *b, void *stream) {
     a.solve_dpool = b->d_dpool;
     a.solve_sqrt = (b->solved && b->sqrt_out_valid && !getenv("TCV_MARG_OWN_SQRT")) ? b->d_sqrt_out : nullptr;
     a.eig_mm = getenv("TCV_MARG_EIG_MM") ? 1 : 0;
+    a.eig_flags = getenv("TCV_MARG_EIG_FLAGS") ? atoi(getenv("TCV_MARG_EIG_FLAGS")) : 0;
     hipStream_t st = (hipStream_t)stream;
     const void *fn = s->nt == MARG_NT_PAIR ? (const void *)marg_kernel<MARG_NT_PAIR> : (const void *)marg_kernel<MARG_NT_WIDE>;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes);

@@ -167,6 +167,7 @@ struct SolveArgs {
     double *coop_x;               // per group COOP_X_DOUBLES: the state the master hands to its helpers (+ mu)
     double *coop_exp;             // per group coop_exp_chunks x coop_exp_stride doubles
     long long coop_timeout;       // ticks of the constant-rate device clock a workgroup waits for its partners before it gives up (status -9)
+    int role_mode, pad3;          // chain kernel: placement of the wavefront roles on the SIMDs (tcv_solve.hip, solve_kernel), developer switch TCV_ROLE_MODE
 };
 
 // ---- cooperative mode (tcv_solve.hip, solve_kernel<.., COOP = true>) ---------------------------------------------------------------

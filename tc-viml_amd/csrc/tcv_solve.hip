@@ -2153,8 +2153,35 @@ template <int NT, bool MFMA, bool CHAIN, bool COOP = false>
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((CHAIN && !COOP) ? TCV_CHAIN_WAVES : 1, COOP ? 1 : (CHAIN ? TCV_CHAIN_WAVES : 8)))) solve_kernel(SolveArgs A) {
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
     lds_d *lds = (lds_d *)lds_raw;
-    const int tid = threadIdx.x;
+    int tid = threadIdx.x;
     int slot = blockIdx.x, wstride = gridDim.x;      // scratch slot and first window of this workgroup; window stride
+    if (CHAIN && !COOP && NT == 256 && A.role_mode != 0) {
+        // Role placement experiment.  The phases give the wavefronts different roles (wave 3: T pipeline, waves 0-1: column owners and the
+        // point factors, ...); two workgroups that share a CU and run in step put the same role on the same SIMD.  HW_ID: wave slot
+        // [3:0], SIMD [5:4], CU [11:8].
+        const unsigned hw = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+        const int simd = (int)(hw >> 4) & 3, wslot = (int)hw & 15, pw = tid >> 6;
+        lds_i *ex = (lds_i *)lds;
+        if ((tid & 63) == 0) { ex[pw] = simd; ex[4 + pw] = wslot; }
+        __syncthreads();
+        const int s0 = ex[0], s1 = ex[1], s2 = ex[2], s3 = ex[3], w0 = ex[4];
+        __syncthreads();
+        const bool perm = ((1 << s0) | (1 << s1) | (1 << s2) | (1 << s3)) == 15;
+        const int mode = A.role_mode & 15;
+        int lw = pw;
+        if (mode == 1) lw = (pw + 2 * (w0 & 1)) & 3;
+        else if (mode == 2) lw = (pw + 2 * (((int)blockIdx.x >> 8) & 1)) & 3;
+        else if (mode == 3 && perm) lw = (simd + 2 * (w0 & 1)) & 3;
+        else if (mode == 4 && perm) lw = simd;
+        else if (mode == 5) lw = (pw + (w0 & 1)) & 3;
+        else if (mode == 6 && perm) lw = (simd + (w0 & 3)) & 3;
+        if ((A.role_mode & 16) && A.prof && (tid & 63) == 0) {
+            gbl_d *pr = (gbl_d *)A.prof + (size_t)blockIdx.x * 32;
+            pr[pw * 4 + simd] += 1.0;
+            if (pw == 0) { pr[16 + (w0 & 7)] += 1.0; pr[24 + (perm ? 1 : 0)] += 1.0; }
+        }
+        tid = (tid & 63) | (__builtin_amdgcn_readfirstlane(lw) << 6);      // the wave index stays provably uniform
+    }
     if (COOP) {
         const int G8 = 8 * (1 + A.coop_h);      // workgroups of a block of eight groups: contiguous in dispatch order, one group per XCD
         const int blk8 = (int)blockIdx.x / G8, r8 = (int)blockIdx.x - blk8 * G8;
