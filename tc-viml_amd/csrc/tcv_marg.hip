@@ -86,7 +86,7 @@ struct MargArgs {
     double *scratch;             // per workgroup MARG_SCR_STRIDE
     int nwin, state_stride, use_solved_state;
     int eig_mm;                  // 1: Amm^+ through the eigen-decomposition for every window (TCV_MARG_EIG_MM=1: A/B checks)
-    int eig_flags;               // developer A/B switches of the eigen-solver of A' (TCV_MARG_EIG_FLAGS): 1 = round 2's eigenvalue search (every eigenvalue, 4- / 7-section)
+    int eig_flags;               // developer A/B switches of the eigen-solver of A' (TCV_MARG_EIG_FLAGS): 1 = round 2's eigenvalue search (every eigenvalue, 4- / 7-section), 2 = reflector-by-reflector back-transformation on the VALU
 };
 
 __device__ __forceinline__ int pidx(int a, int b) { return a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a; }
@@ -213,6 +213,20 @@ __device__ __noinline__ int jacobi_eig(lds_d *M, VP *V, int d, int ld, lds_d *ro
 // per column, no barriers.  Returns false (caller falls back to the Jacobi sweep) if the result fails the orthogonality / trace
 // checks.  A is overwritten by the eigenvectors (columns, ascending eigenvalues in lam), Hq takes (n - 2)(n - 1) / 2 + 1 doubles
 // of reflectors, sm MARG_SM doubles.  LDS footprint: n (n + 2) + (n - 2)(n - 1) / 2 + MARG_SM doubles (75: 66 KB).
+// arguments of the non-inlined eigen-solver functions arrive in vector registers: the compiler cannot know that sizes, strides and LDS
+// pointers are wave-uniform and turns every loop bound into an exec-mask loop and every address into vector arithmetic.  One
+// v_readfirstlane each puts them into scalar registers.
+#ifndef TCV_UNI
+#define TCV_UNI 2      // measured: uniformising the tridiagonalisation gains 0.5 %, the small functions lose 1 % (more SGPR spills)
+#endif
+template <int BIT> __device__ __forceinline__ int uni_i(int v) { return (TCV_UNI & BIT) ? __builtin_amdgcn_readfirstlane(v) : v; }
+template <int BIT, class T> __device__ __forceinline__ T *uni_lds(T *p) { return (TCV_UNI & BIT) ? (T *)(unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)p) : p; }
+__device__ __forceinline__ double uni_f64(double v) {
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+    u2v u = __builtin_bit_cast(u2v, v);
+    u.x = __builtin_amdgcn_readfirstlane(u.x); u.y = __builtin_amdgcn_readfirstlane(u.y);
+    return __builtin_bit_cast(double, u);
+}
 __device__ __forceinline__ double fast_rcp(double q) {
     double r = __builtin_amdgcn_rcp(q);
     r = fma(fma(-q, r, 1.0), r, r);
@@ -336,7 +350,12 @@ __device__ __forceinline__ void eig_refine(const lds_d *de, lds_d *lam, int n, i
 }
 // dv, e2: the tridiagonal; de: 2 n doubles of workspace (16-byte aligned), ctab: 257 ints.  gu: upper Gershgorin bound (widened).
 template <int NT>
-__device__ __noinline__ void eig_values_above_eps(const lds_d *dv, const lds_d *e2, lds_d *de, lds_i *ctab, lds_d *lam, int n, double gu, double tnorm, int tid) {
+__device__ __noinline__ void eig_values_above_eps(const lds_d *dv_, const lds_d *e2_, lds_d *de_, lds_i *ctab_, lds_d *lam_, int n_, double gu_, double tnorm_, int tid) {
+    const lds_d *dv = uni_lds<1>(dv_), *e2 = uni_lds<1>(e2_);
+    lds_d *de = uni_lds<1>(de_), *lam = uni_lds<1>(lam_);
+    lds_i *ctab = uni_lds<1>(ctab_);
+    const int n = uni_i<1>(n_);
+    const double gu = uni_f64(gu_), tnorm = uni_f64(tnorm_);
     // scale by a power of two so that |T| <= 1
     const int ex = __builtin_amdgcn_frexp_exp(fmax(tnorm, 1e-300));
     const double sc = ldexp(1.0, -ex), unscale = ldexp(1.0, ex);
@@ -371,7 +390,10 @@ __device__ __forceinline__ int refl_off(int i, int n) { return i * (n - 2) - (i 
 // partial sums meet through DPP row shifts.
 // c0: first column to transform (the columns of the thresholded eigenvalues in front of it are zero and stay zero).
 template <int LPC>
-__device__ __noinline__ void eig_backtransform(const lds_d *Hq, lds_d *Z, const lds_d *tauv, int n, int ld, int tid, int c0) {
+__device__ __noinline__ void eig_backtransform(const lds_d *Hq_, lds_d *Z_, const lds_d *tauv_, int n_, int ld_, int tid, int c0_) {
+    const lds_d *Hq = uni_lds<1>(Hq_), *tauv = uni_lds<1>(tauv_);
+    lds_d *Z = uni_lds<1>(Z_);
+    const int n = uni_i<1>(n_), ld = uni_i<1>(ld_), c0 = uni_i<1>(c0_);
     constexpr int CPW = LPC == 4 ? 16 : 20, RPL = (MARG_MAX_N + LPC - 1) / LPC;
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15;
@@ -429,9 +451,161 @@ __device__ __noinline__ void eig_backtransform(const lds_d *Hq, lds_d *Z, const 
     }
 }
 
+// ---- round 3: the back-transformation as blocked reflectors on the matrix cores -------------------------------------------------
+// Q = H_0 ... H_(n-2) in blocks of sixteen reflectors, B = H_i0 ... H_(i0+15) = I - V T V' (compact WY: T upper triangular with
+// T^-1 = diag(1 / tau) + striu(V'V)), applied last block first:  Z <- Z - V (T (V'Z)).  A wavefront owns sixteen columns of Z at a time
+// for ALL blocks, so the wavefronts never wait for each other.  Everything stays in registers between the matrix instructions because
+// the accumulator layout of v_mfma_f64_16x16x4 (lane (row0, col) holds rows row0 + 4 i of column col) IS its B-operand layout and the
+// A-operand layout of the TRANSPOSED matrix:
+//   G = V'V (K = the rows below the block's first reflector),  N = diag(tau) striu(G)  (nilpotent),
+//   (I + N)^-1 = (I - N)(I + N^2)(I + N^4)(I + N^8) by five 16 x 16 products that carry N^2k and its transpose along, T' = diag(tau) (I + N)^-T,
+//   per column tile: Y = V'Z, W = T Y, Z -= V W.
+// V is read straight from the packed reflectors (zero above the implicit 1, a reflector with tau = 0 dropped).  Replaces ~75 reflector
+// sweeps of ~320 instructions per wavefront.  Columns c0 .. n-1 are transformed (the columns in front of c0 are zero and stay zero).
+struct ReflLane { int base, i1; bool act; };      // reflector i of a lane: entry r lives at Hq[base + r] for r > i1 = i + 1, is 1 at r = i1, 0 above
+__device__ __forceinline__ ReflLane refl_lane(const lds_d *tauv, int n, int i0, int nb, int j) {
+    ReflLane R;
+    const int i = i0 + min(j, nb - 1);
+    R.base = refl_off(i, n) - i - 2; R.i1 = i + 1;
+    R.act = j < nb && tauv[i] != 0.0;
+    return R;
+}
+// the loads are unconditional (clamped address) and pinned in front of the selects, four at a time behind ONE barrier for the
+// compiler: a conditional LDS load becomes an exec-mask branch with its own wait, one full LDS round trip per matrix instruction
+__device__ __forceinline__ double refl_raw(const lds_d *Hq, const ReflLane &R, int n, int r) { return Hq[R.base + max(R.i1 + 1, min(r, n - 1))]; }      // (the last reflector stores nothing: the packed buffer has one spare double)
+__device__ __forceinline__ double refl_sel(double hv, const ReflLane &R, int n, int r) {
+    const double v = (r > R.i1) ? hv : ((r == R.i1) ? 1.0 : 0.0);
+    return (R.act && r < n) ? v : 0.0;
+}
+#define WY_PIN4(a) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]))
+#define WY_PIN8(a, b) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]))
+typedef double wy_v4 __attribute__((ext_vector_type(4)));
+// acc + X' B for X given by its accumulator-layout registers (used as the A operand they are X transposed)
+__device__ __forceinline__ wy_v4 wy_mm(const wy_v4 &xa, const wy_v4 &b, wy_v4 acc) {
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[kk], b[kk], acc, 0, 0, 0);
+    return acc;
+}
+// T of the block of reflectors i0 .. i0 + nb - 1 as the A operand of W = T Y: lane holds T[m = col][k = 4 kk + row0], kk = 0 .. 3
+__device__ __forceinline__ wy_v4 wy_block_t(const lds_d *Hq, const lds_d *tauv, int n, int i0, int nb, int col, int row0) {
+    const wy_v4 zero4 = {0.0, 0.0, 0.0, 0.0};
+    const int k0 = (i0 + 1) >> 2, k1 = (n + 3) >> 2;      // row quads that hold non-zero entries of the block
+    const ReflLane Rc = refl_lane(tauv, n, i0, nb, col);
+    double tk[4];                                          // tau of reflector row0 + 4 i (0: dropped)
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) { const ReflLane R = refl_lane(tauv, n, i0, nb, 4 * kk + row0); tk[kk] = R.act ? tauv[R.i1 - 1] : 0.0; }
+    const double tcol = Rc.act ? tauv[Rc.i1 - 1] : 0.0;
+    // G = V'V
+    wy_v4 g = zero4;
+    for (int kq = k0; kq < k1; kq += 4) {
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = refl_raw(Hq, Rc, n, 4 * (kq + u) + row0);
+        WY_PIN4(v);
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = refl_sel(v[u], Rc, n, 4 * (kq + u) + row0);      // (quads beyond k1 are rows >= n: zeros)
+#pragma unroll
+        for (int u = 0; u < 4; u++) g = __builtin_amdgcn_mfma_f64_16x16x4f64(v[u], v[u], g, 0, 0, 0);      // A[m = col][k = row0] = B[k = row0][n = col] = V[r][col]
+    }
+    // N = diag(tau) striu(G) and N' in accumulator layout (G is symmetric)
+    wy_v4 N, Nt;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const int j = row0 + 4 * i; N[i] = (j < col) ? tk[i] * g[i] : 0.0; Nt[i] = (col < j) ? tcol * g[i] : 0.0; }
+    // P' = (I + N)^-T = (I + N8') (I + N4') (I + N2') (I - N')
+    wy_v4 Pt;
+#pragma unroll
+    for (int i = 0; i < 4; i++) Pt[i] = ((row0 + 4 * i == col) ? 1.0 : 0.0) - Nt[i];
+    const wy_v4 N2 = wy_mm(Nt, N, zero4), N2t = wy_mm(N, Nt, zero4);      // N N and N' N'
+    Pt = wy_mm(N2, Pt, Pt);                                                  // + N2' P'
+    const wy_v4 N4 = wy_mm(N2t, N2, zero4), N4t = wy_mm(N2, N2t, zero4);
+    Pt = wy_mm(N4, Pt, Pt);
+    const wy_v4 N8 = wy_mm(N4t, N4, zero4);
+    Pt = wy_mm(N8, Pt, Pt);
+    // T[m = col][k = 4 kk + row0] = (T')[row0 + 4 kk][col] = tau_(row0 + 4 kk) P'[row0 + 4 kk][col]
+    wy_v4 ta;
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) ta[kk] = tk[kk] * Pt[kk];
+    return ta;
+}
+// tbuf: 256 doubles.  The LAST wavefront forms the T of the next block while the others apply the current one (it takes column tiles
+// too when there are more tiles than other wavefronts); two barriers per block hand the 256 operand values over.
+template <int NT>
+__device__ __noinline__ void eig_backtransform_wy(const lds_d *Hq_, lds_d *Z_, const lds_d *tauv_, lds_d *tbuf_, int n_, int ld_, int tid, int c0_) {
+    constexpr int NW = NT / 64;
+    const lds_d *Hq = uni_lds<2>(Hq_), *tauv = uni_lds<2>(tauv_);
+    lds_d *Z = uni_lds<2>(Z_), *tbuf = uni_lds<2>(tbuf_);
+    const int n = uni_i<2>(n_), ld = uni_i<2>(ld_), c0 = uni_i<2>(c0_);
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), col = lane & 15, row0 = lane >> 4;
+    const int nref = n - 1;                               // reflectors 0 .. n - 2
+    const int ncol = n - c0, ntile = (ncol + 15) >> 4;
+    if (ncol <= 0) return;
+    const wy_v4 zero4 = {0.0, 0.0, 0.0, 0.0};
+    const int i_last = ((nref - 1) >> 4) << 4;
+    if (wave == NW - 1) {
+        const wy_v4 t0 = wy_block_t(Hq, tauv, n, i_last, min(16, nref - i_last), col, row0);
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) tbuf[kk * 64 + lane] = t0[kk];
+    }
+    for (int i0 = i_last; i0 >= 0; i0 -= 16) {
+        const int nb = min(16, nref - i0);
+        const int k0 = (i0 + 1) >> 2, k1 = (n + 3) >> 2;      // row quads that hold non-zero entries of the block
+        __syncthreads();
+        wy_v4 ta;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) ta[kk] = tbuf[kk * 64 + lane];
+        __syncthreads();
+        if (wave == NW - 1 && i0 > 0) {
+            const wy_v4 tn = wy_block_t(Hq, tauv, n, i0 - 16, 16, col, row0);
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) tbuf[kk * 64 + lane] = tn[kk];
+        }
+        const ReflLane Rc = refl_lane(tauv, n, i0, nb, col);      // the reflector of this lane's column (A operand of V'Z)
+        ReflLane Rk[4];                                            // the reflectors 4 kk + row0 (A operand of Z -= V W)
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) Rk[kk] = refl_lane(tauv, n, i0, nb, 4 * kk + row0);
+        for (int t = wave; t < ntile; t += NW) {
+            const int cz = c0 + 16 * t + col, czc = min(cz, n - 1);
+            const bool cok = cz < n;
+            const lds_d *zp = Z + czc;
+            // Y = V'Z over the rows below the block's first reflector
+            wy_v4 y = zero4;
+            for (int kq = k0; kq < k1; kq += 4) {
+                double v[4], zv[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const int r = 4 * (kq + u) + row0; v[u] = refl_raw(Hq, Rc, n, r); zv[u] = zp[min(r, n - 1) * ld]; }
+                WY_PIN8(v, zv);
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const int r = 4 * (kq + u) + row0; v[u] = refl_sel(v[u], Rc, n, r); zv[u] = (r < n && cok) ? zv[u] : 0.0; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) y = __builtin_amdgcn_mfma_f64_16x16x4f64(v[u], zv[u], y, 0, 0, 0);
+            }
+            // W = T Y (Y's accumulator layout is the B-operand layout; ta is the A operand of T itself)
+            wy_v4 w = zero4;
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) w = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[kk], y[kk], w, 0, 0, 0);
+            // Z -= V W, row tile by row tile (the tiles above the block's first reflector are untouched)
+            for (int rt = (i0 + 1) >> 4; 16 * rt < n; rt++) {
+                wy_v4 acc;
+                double va[4], za[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) { va[kk] = refl_raw(Hq, Rk[kk], n, 16 * rt + col); za[kk] = zp[min(16 * rt + row0 + 4 * kk, n - 1) * ld]; }
+                WY_PIN8(va, za);
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) { va[kk] = -refl_sel(va[kk], Rk[kk], n, 16 * rt + col); acc[kk] = za[kk]; }      // A[m = col][k]: row 16 rt + col, reflector k
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[kk], w[kk], acc, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; i++) { const int r = 16 * rt + row0 + 4 * i; if (r < n && cok) Z[r * ld + cz] = acc[i]; }
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ double rank2(double a, double vr, double wc, double wr, double vc) { return a - (vr * wc + wr * vc); }
 template <int NT>
-__device__ __noinline__ bool sym_eig_tridiag(lds_d *A, lds_d *Hq, lds_d *sm, lds_d *lam, int n, int ld, int tid, gbl_d *dbg, int flags) {
+__device__ __noinline__ bool sym_eig_tridiag(lds_d *A_, lds_d *Hq_, lds_d *sm_, lds_d *lam_, int n_, int ld_, int tid, gbl_d *dbg, int flags_) {
+    lds_d *A = uni_lds<2>(A_), *Hq = uni_lds<2>(Hq_), *sm = uni_lds<2>(sm_), *lam = uni_lds<2>(lam_);
+    const int n = uni_i<2>(n_), ld = uni_i<2>(ld_), flags = uni_i<2>(flags_);
     const bool old_search = (flags & 1) != 0;
     constexpr int NW = NT / 64;
     lds_d *Z = A;                          // the eigenvectors overwrite the matrix: after the tridiagonalisation only T (dv, ev), the
@@ -481,6 +655,13 @@ __device__ __noinline__ bool sym_eig_tridiag(lds_d *A, lds_d *Hq, lds_d *sm, lds
         }
         __syncthreads();
     }
+#ifdef TCV_PROFILE
+    if (tid == 0 && dbg) for (int i = 14; i < 26; i++) dbg[i] = 0.0;
+    long long t_step = clock64();
+#define SMARK(id) do { const long long t_ = clock64(); if (tid == 0 && dbg) dbg[14 + (id)] += (double)(t_ - t_step); t_step = t_; } while (0)
+#else
+#define SMARK(id) do { } while (0)
+#endif
     for (int i = 0; i + 1 < n; i++) {
         const int m = n - i - 1;
         const int r = tid;
@@ -513,7 +694,9 @@ __device__ __noinline__ bool sym_eig_tridiag(lds_d *A, lds_d *Hq, lds_d *sm, lds
             if (lane == 0) red[wave] = pv;
         }
         if (tid == 0) { dv[i] = A[i * ld + i]; ev[i] = beta; tauv[i] = tau; }
+        SMARK(0);
         __syncthreads();
+        SMARK(1);
         {
             const double K = -0.5 * tau * (red[0] + red[1]);
             const double v0 = vbuf[0], w0 = pbuf[0] + K * v0;
@@ -559,7 +742,9 @@ __device__ __noinline__ bool sym_eig_tridiag(lds_d *A, lds_d *Hq, lds_d *sm, lds
             if (m > 40) { TCV_R2_BODY(10) } else if (m > 16) { TCV_R2_BODY(5) } else { TCV_R2_BODY(2) }
 #undef TCV_R2_BODY
         }
+        SMARK(m > 40 ? 2 : (m > 16 ? 3 : 4));
         __syncthreads();
+        SMARK(5);
     }
     if (tid == 0) { dv[n - 1] = A[(n - 1) * ld + n - 1]; ev[n - 1] = 0.0; }
     __syncthreads();
@@ -674,7 +859,8 @@ __device__ __noinline__ bool sym_eig_tridiag(lds_d *A, lds_d *Hq, lds_d *sm, lds
     {
         int c0 = 0;
         if (!old_search) { while (c0 < n && !(lam[c0] > 1e-8)) c0++; }
-        if (NT >= 512 || n - c0 <= 16 * NW) eig_backtransform<4>(Hq, Z, tauv, n, ld, tid, c0);
+        if (!(flags & 2)) eig_backtransform_wy<NT>(Hq, Z, tauv, vbuf, n, ld, tid, c0);      // vbuf .. xnb: 480 doubles, all dead by now
+        else if (NT >= 512 || n - c0 <= 16 * NW) eig_backtransform<4>(Hq, Z, tauv, n, ld, tid, c0);
         else eig_backtransform<3>(Hq, Z, tauv, n, ld, tid, c0);
     }
     __syncthreads();
@@ -1840,6 +2026,7 @@ int tcv_marg_get_prior(tcv_batch *b, int window, tcv_prior **out) {
         for (int i = 0; i < 12; i++) fprintf(stderr, "[tcv]   %-7s %12.0f cycles\n", nm[i], o[MARG_OUT_X + MARG_MAX_X + 2 + i]);
         const char *en[6] = {"tridiag", "bisect", "vectors", "mgs", "backtr", "check"};
         for (int i = 0; i < 6; i++) fprintf(stderr, "[tcv]     eig_rr.%-8s %10.0f cycles\n", en[i], o[MARG_OUT_X + MARG_MAX_X + 14 + 8 + i]);
+        fprintf(stderr, "[tcv]     tridiag steps (wave 0): part 1 %.0f | barrier %.0f | update m > 40 %.0f, m > 16 %.0f, m <= 16 %.0f | barrier %.0f cycles\n", o[MARG_OUT_X + MARG_MAX_X + 28], o[MARG_OUT_X + MARG_MAX_X + 29], o[MARG_OUT_X + MARG_MAX_X + 30], o[MARG_OUT_X + MARG_MAX_X + 31], o[MARG_OUT_X + MARG_MAX_X + 32], o[MARG_OUT_X + MARG_MAX_X + 33]);
         fprintf(stderr, "[tcv]   tridiag check: dev %.3e sum(lam) %.10e trace %.10e |T| %.3e lam_min %.3e lam_max %.3e\n", o[MARG_OUT_X + MARG_MAX_X + 14], o[MARG_OUT_X + MARG_MAX_X + 15], o[MARG_OUT_X + MARG_MAX_X + 16], o[MARG_OUT_X + MARG_MAX_X + 17], o[MARG_OUT_X + MARG_MAX_X + 18], o[MARG_OUT_X + MARG_MAX_X + 19]);
     }
     for (double v : pr->J0) if (!(v == v)) { delete pr; set_error("NaN in marginalisation result"); return TCV_ERR_NUMERIC; }
