@@ -56,6 +56,7 @@ struct MargHdr {
     int o_pcol;    // prior_n: mloc index of every J0 column (-1 constant)
     int d_x, d_imu, d_proj, d_prior, d_misc;
     long long ibase, dbase;
+    int prior_k0, pad_k0;  // leading zero rows of the prior's J0 | r0 that are not stored (WinHdr::prior_k0, tcv_packed.h)
     long long prior_abs;   // >= 0: J0 | r0 | x0 of the prior are read from the solve batch's data pool at this offset (the marginalised factor
                            // set holds the same prior object as the solve problem: no second copy is packed or uploaded)
     int solve_window;
@@ -666,39 +667,42 @@ __device__ __noinline__ bool sym_eig_tridiag(lds_d *A_, lds_d *Hq_, lds_d *sm_, 
         const int m = n - i - 1;
         const int r = tid;
         const lds_d *xrow = A + i * ld + (i + 1);
-        const double xn2 = xnb[i & 1];
-        const double alpha = xrow[0];
-        double tau = 0.0, beta = alpha, scale = 0.0;
-        if (xn2 > 0.0) {
-            const double nn = alpha * alpha + xn2;
-            double y = __builtin_amdgcn_rsq(nn);                 // |x| = nn * rsqrt(nn), two Newton steps
-            y = y * fma(-0.5 * nn * y, y, 1.5);
-            y = y * fma(-0.5 * nn * y, y, 1.5);
-            beta = -copysign(nn * y, alpha);
-            tau = (beta - alpha) * fast_rcp(beta);
-            scale = fast_rcp(alpha - beta);
-        }
-        double pv = 0;
-        if (r < m) {
-            const double a0 = A[(i + 1 + r) * ld + (i + 1)];
-            const double vr = (r == 0) ? 1.0 : xrow[r] * scale;
-            const double pr = tau * scale * (ubuf[r] - beta * a0);
-            vbuf[r] = vr; pbuf[r] = pr;
-            xold[r] = A[(i + 1) * ld + (i + 1 + r)];      // the old first ROW of A22, element r: the fused product must predict exactly the row the
-                                                          // next step reads (the two triangles agree to rounding only, which matters for the small
-                                                          // entries deep in a graded matrix)
-            pv = pr * vr;
-        }
-        if (tid < 128) {      // m <= 79: the first two wavefronts hold all the terms
+        // the first half of the step (scalars, v, p, p'v) needs one lane per row: only the wavefronts that hold rows run it (the others would
+        // execute the whole scalar chain for nothing); tau reaches the second half through tauv[i]
+        if (tid < ((m + 63) & ~63)) {
+            const double xn2 = xnb[i & 1];
+            const double alpha = xrow[0];
+            double tau = 0.0, beta = alpha, scale = 0.0;
+            if (xn2 > 0.0) {
+                const double nn = alpha * alpha + xn2;
+                double y = __builtin_amdgcn_rsq(nn);                 // |x| = nn * rsqrt(nn), two Newton steps
+                y = y * fma(-0.5 * nn * y, y, 1.5);
+                y = y * fma(-0.5 * nn * y, y, 1.5);
+                beta = -copysign(nn * y, alpha);
+                tau = (beta - alpha) * fast_rcp(beta);
+                scale = fast_rcp(alpha - beta);
+            }
+            double pv = 0;
+            if (r < m) {
+                const double a0 = A[(i + 1 + r) * ld + (i + 1)];
+                const double vr = (r == 0) ? 1.0 : xrow[r] * scale;
+                const double pr = tau * scale * (ubuf[r] - beta * a0);
+                vbuf[r] = vr; pbuf[r] = pr;
+                xold[r] = A[(i + 1) * ld + (i + 1 + r)];      // the old first ROW of A22, element r: the fused product must predict exactly the row the
+                                                              // next step reads (the two triangles agree to rounding only, which matters for the small
+                                                              // entries deep in a graded matrix)
+                pv = pr * vr;
+            }
             pv = wave_sum_down(pv);
             if (lane == 0) red[wave] = pv;
+            if (tid == 0) { dv[i] = A[i * ld + i]; ev[i] = beta; tauv[i] = tau; }
         }
-        if (tid == 0) { dv[i] = A[i * ld + i]; ev[i] = beta; tauv[i] = tau; }
         SMARK(0);
         __syncthreads();
         SMARK(1);
         {
-            const double K = -0.5 * tau * (red[0] + red[1]);
+            const double tau = tauv[i];
+            const double K = -0.5 * tau * (red[0] + (m > 64 ? red[1] : 0.0));      // (a wavefront without rows would have contributed an exact zero)
             const double v0 = vbuf[0], w0 = pbuf[0] + K * v0;
             lds_d *hq = Hq + refl_off(i, n);
             // A22 -= v w' + w v',  w = p + K v ; eight lanes per row.  The reflector goes to its packed slot for the back-transform.
@@ -707,7 +711,7 @@ __device__ __noinline__ bool sym_eig_tridiag(lds_d *A_, lds_d *Hq_, lds_d *sm_, 
             // clamped loads and masked updates per lane -- the skipped slots held nothing (c >= m): the same sums, bit for bit
             const int part8 = tid & 7;
 #define TCV_R2_BODY(J)                                                                                                               \
-            {                                                                                                                        \
+            if ((tid & ~63) >> 3 < ((m + 7) & ~7)) {      /* a wavefront whose first row lies beyond the block has nothing to update */ \
                 /* what depends on the column only -- v, w = p + K v and the new first row x' -- once per step, not once per row pass */ \
                 double vc[J], wc[J], xn[J];                                                                                          \
                 {                                                                                                                    \
@@ -961,8 +965,8 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((amdgpu_waves_per_eu(2,
         // ---- prior factor (MarginalizationFactor::Evaluate, :335-384): the first contribution to A and b
         bool a_zeroed = false;
         if (H.prior_n > 0) {
-            const int np = H.prior_n;
-            cst_d *J0 = H.prior_abs >= 0 ? (cst_d *)Aarg.solve_dpool + H.prior_abs : dp + H.d_prior, *r0 = J0 + np * np, *x0 = r0 + np;
+            const int np = H.prior_n, k0 = H.prior_k0, nr = np - k0;      // J0 | r0 without their leading zero rows: nr x np, column-major
+            cst_d *J0 = H.prior_abs >= 0 ? (cst_d *)Aarg.solve_dpool + H.prior_abs : dp + H.d_prior, *r0 = J0 + nr * np, *x0 = r0 + nr;
             lds_d *pdx = sm, *pr = sm + 128;
             if (tid < H.prior_nblk) {
                 cst_i *pb = ip + H.o_prior + tid * 4;
@@ -975,35 +979,35 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((amdgpu_waves_per_eu(2,
             cst_i *pcol = ip + H.o_pcol;
             // J0 (np x np, column-major) staged in P (A is not started yet): r = r0 + J0 dx, J0' J0 and J0' r run out of LDS, the
             // products wait in registers until the barrier after which P becomes the packed A
-            const bool in_lds = np <= MARG_MAX_N && np * np <= r1;
+            const bool in_lds = np <= MARG_MAX_N && nr * np <= r1;
             lds_d *Js = Apk;
             if (in_lds) {
-                for (int e = tid; e < np * np; e += 4 * MARG_NT) {
+                for (int e = tid; e < nr * np; e += 4 * MARG_NT) {
                     double v4[4];
 #pragma unroll
-                    for (int k = 0; k < 4; k++) if (e + k * MARG_NT < np * np) v4[k] = J0[e + k * MARG_NT];
+                    for (int k = 0; k < 4; k++) if (e + k * MARG_NT < nr * np) v4[k] = J0[e + k * MARG_NT];
 #pragma unroll
-                    for (int k = 0; k < 4; k++) if (e + k * MARG_NT < np * np) Js[e + k * MARG_NT] = v4[k];
+                    for (int k = 0; k < 4; k++) if (e + k * MARG_NT < nr * np) Js[e + k * MARG_NT] = v4[k];
                 }
             } else {
                 for (int i = tid; i < npk; i += MARG_NT) Apk[i] = 0.0;
                 a_zeroed = true;
             }
             __syncthreads();
-            if (tid < np) {
+            if (tid < nr) {      // (row k0 + tid of the full matrix; the dropped rows have r = 0)
                 double r = r0[tid];
                 if (in_lds) {
                     int j = 0;
                     for (; j + 3 < np; j += 4) {
                         double a4[4], d4[4];
 #pragma unroll
-                        for (int u = 0; u < 4; u++) { a4[u] = Js[tid + np * (j + u)]; d4[u] = pdx[j + u]; }
+                        for (int u = 0; u < 4; u++) { a4[u] = Js[tid + nr * (j + u)]; d4[u] = pdx[j + u]; }
 #pragma unroll
                         for (int u = 0; u < 4; u++) r += a4[u] * d4[u];
                     }
-                    for (; j < np; j++) r += Js[tid + np * j] * pdx[j];
+                    for (; j < np; j++) r += Js[tid + nr * j] * pdx[j];
                 }
-                else for (int j = 0; j < np; j++) r += J0[tid + np * j] * pdx[j];
+                else for (int j = 0; j < np; j++) r += J0[tid + nr * j] * pdx[j];
                 pr[tid] = r;
             }
             __syncthreads();
@@ -1024,14 +1028,16 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((amdgpu_waves_per_eu(2,
                         while ((ta + 1) * (ta + 2) / 2 <= t) ta++;
                         const int tb = t - ta * (ta + 1) / 2;
                         const int a = 16 * ta + m16, b = 16 * tb + m16;
-                        const lds_d *ca = Js + np * min(a, np - 1), *cb = Js + np * min(b, np - 1);
-                        for (int i0 = 0; i0 < np; i0 += 16) {
+                        // (the K steps keep the row quads of the FULL matrix -- i is the original row index, the dropped rows feed zeros and the
+                        // trips that hold nothing else are skipped --, so every sum is accumulated exactly as with the zero rows in place)
+                        const lds_d *ca = Js + nr * min(a, np - 1), *cb = Js + nr * min(b, np - 1);
+                        for (int i0 = k0 & ~15; i0 < np; i0 += 16) {
                             double av[4], bv4[4];
 #pragma unroll
                             for (int u = 0; u < 4; u++) {
-                                const int i = i0 + 4 * u + k4;
-                                const double xa = ca[min(i, np - 1)], y = cb[min(i, np - 1)];
-                                av[u] = (i < np && a < np) ? xa : 0.0; bv4[u] = (i < np && b < np) ? y : 0.0;
+                                const int i = i0 + 4 * u + k4, ic = max(0, min(i, np - 1) - k0);
+                                const double xa = ca[ic], y = cb[ic];
+                                av[u] = (i >= k0 && i < np && a < np) ? xa : 0.0; bv4[u] = (i >= k0 && i < np && b < np) ? y : 0.0;
                             }
 #pragma unroll
                             for (int u = 0; u < 4; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv4[u], acc, 0, 0, 0);
@@ -1043,14 +1049,14 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((amdgpu_waves_per_eu(2,
                 const bool mine = tid < np && pcol[min(tid, np - 1)] >= 0;
                 if (mine) {
                     int i = 0;
-                    for (; i + 3 < np; i += 4) {
+                    for (; i + 3 < nr; i += 4) {
                         double a4[4], r4[4];
 #pragma unroll
-                        for (int u = 0; u < 4; u++) { a4[u] = Js[i + u + np * tid]; r4[u] = pr[i + u]; }
+                        for (int u = 0; u < 4; u++) { a4[u] = Js[i + u + nr * tid]; r4[u] = pr[i + u]; }
 #pragma unroll
                         for (int u = 0; u < 4; u++) s2 += a4[u] * r4[u];
                     }
-                    for (; i < np; i++) s2 += Js[i + np * tid] * pr[i];
+                    for (; i < nr; i++) s2 += Js[i + nr * tid] * pr[i];
                 }
                 __syncthreads();      // every read of the staged J0 is done: P becomes A
                 for (int i = tid; i < npk; i += MARG_NT) Apk[i] = 0.0;
@@ -1078,12 +1084,12 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((amdgpu_waves_per_eu(2,
                     const int ia = pcol[a], ib = pcol[b];
                     if (ia < 0 || ib < 0) continue;
                     double s0 = 0;
-                    for (int i = 0; i < np; i++) s0 += J0[i + np * a] * J0[i + np * b];
+                    for (int i = 0; i < nr; i++) s0 += J0[i + nr * a] * J0[i + nr * b];
                     Apk[pidx(ia, ib)] += s0;
                 }
                 if (tid < np && pcol[tid] >= 0) {
                     double s2 = 0;
-                    for (int i = 0; i < np; i++) s2 += J0[i + np * tid] * pr[i];
+                    for (int i = 0; i < nr; i++) s2 += J0[i + nr * tid] * pr[i];
                     bv[pcol[tid]] += s2;
                 }
             }
@@ -1801,8 +1807,14 @@ static int pack_marg(const tcv_problem &p, double *const *drop, int ndrop, const
     H.d_prior = dmark();
     H.prior_abs = -1;
     if (pr && solve_p && solve_pk && !solve_p->prior.empty() && solve_p->prior[0].prior == pr && solve_pk->hdr.prior_n == pr->n && !getenv("TCV_MARG_OWN_PRIOR"))
-        H.prior_abs = solve_pk->win.dbase + solve_pk->win.d_prior;      // same layout: J0 | r0 | x0 (tcv_pack.cpp)
-    else if (pr) { D.insert(D.end(), pr->J0.begin(), pr->J0.end()); D.insert(D.end(), pr->r0.begin(), pr->r0.end()); D.insert(D.end(), pr->x0.begin(), pr->x0.end()); }
+        { H.prior_abs = solve_pk->win.dbase + solve_pk->win.d_prior; H.prior_k0 = solve_pk->win.prior_k0; }      // same layout: J0 | r0 | x0 without the leading zero rows (tcv_pack.cpp)
+    else if (pr) {
+        static const bool full = getenv("TCV_PRIOR_FULL") != nullptr;
+        const int n0 = pr->n, k0 = full ? 0 : prior_zero_rows(pr->J0.data(), pr->r0.data(), n0);
+        H.prior_k0 = k0;
+        for (int j = 0; j < n0; j++) D.insert(D.end(), pr->J0.begin() + (size_t)n0 * j + k0, pr->J0.begin() + (size_t)n0 * (j + 1));
+        D.insert(D.end(), pr->r0.begin() + k0, pr->r0.end()); D.insert(D.end(), pr->x0.begin(), pr->x0.end());
+    }
     H.d_misc = dmark();
     D.insert(D.end(), p.G, p.G + 3); D.push_back(psi); D.push_back(pla); D.push_back(0.0); D.push_back(p.td_TR); D.push_back(p.td_ROW);
     if (D.size() & 1) D.push_back(0.0);

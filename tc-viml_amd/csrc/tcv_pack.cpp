@@ -791,7 +791,14 @@ static int pack_data_to(const tcv_problem &p, Packed &out, const double *imu_sqr
     else D.zeros(21);
     if (D.n & 1) D.put1(0.0);        // J0 is copied with 16-byte loads
     W.d_prior = (int)D.n;
-    if (pr) { D.put(pr->J0.data(), pr->J0.size()); D.put(pr->r0.data(), pr->r0.size()); D.put(pr->x0.data(), pr->x0.size()); }
+    if (pr) {      // the rows of the thresholded eigenvalues (exact zeros in J0 and r0) are dropped, tcv_packed.h
+        static const bool full = getenv("TCV_PRIOR_FULL") != nullptr;      // developer A/B switch: keep every row
+        const int n = pr->n, k0 = full ? 0 : prior_zero_rows(pr->J0.data(), pr->r0.data(), n), nr = n - k0;
+        W.prior_k0 = k0;
+        for (int j = 0; j < n; j++) D.put(pr->J0.data() + (size_t)n * j + k0, nr);
+        D.put(pr->r0.data() + k0, nr);
+        D.put(pr->x0.data(), pr->x0.size());
+    }
     W.d_misc = (int)D.n;
     D.put(p.G, 3); D.put1(psi); D.put1(pla); D.put1(lla); D.put1(p.td_TR); D.put1(p.td_ROW); D.put1(p.line_exact ? 1.0 : 0.0);
     W.d_sqrt = -1;

@@ -121,12 +121,24 @@ struct WinHdr {
     int d_proj;     // n_proj x 6 (ProjectionTdFactor: x 14 = pts_i, pts_j, aux 8)
     int d_line;     // n_line x 9
     int d_linec;    // 21 : K, Ric, Tic (row-major)
-    int d_prior;    // J0 (n x n column-major), r0 (n), x0 (prior_xsize)
+    int d_prior;    // J0 rows prior_k0 .. n-1 ((n - prior_k0) x n column-major), r0 (n - prior_k0), x0 (prior_xsize)
     int d_misc;     // G(3), proj sqrt_info, proj loss a, line loss a, TR, ROW, line Jacobian mode (0 reference, 1 exact)
     int d_sqrt;     // optional host-provided sqrt_info, n_imu x 225 (-1: computed on device)
     int n_doubles;  // doubles of this window
-    int pad1;
+    int prior_k0;   // leading rows of the prior's J0 | r0 that are exact zeros -- the eigenvalues of A' the marginalisation thresholded
+                    // (marginalization_factor.cpp:284-293; about half of the 75 on the benchmark windows): neither stored, fetched nor multiplied
 };
+// number of leading rows i of the prior with J0[i][:] == 0 and r0[i] == 0 (J0 n x n column-major)
+inline int prior_zero_rows(const double *J0, const double *r0, int n) {
+    int k0 = 0;
+    for (; k0 < n; k0++) {
+        if (r0[k0] != 0.0) break;
+        bool z = true;
+        for (int j = 0; j < n && z; j++) z = J0[k0 + (size_t)n * j] == 0.0;
+        if (!z) break;
+    }
+    return k0 < n ? k0 : (n > 0 ? n - 1 : 0);      // keep one row: the kernels never see an empty prior
+}
 
 // per-workgroup global scratch layout (doubles)
 enum { SCR_NL = 1280 };  // capacity of an nl-sized vector (nc + nland)

@@ -778,6 +778,44 @@ __device__ __forceinline__ void prior_part_b(Ctx<NT> &C, bool assemble) {
     }
 }
 
+// ---- the prior's two products out of LDS (J0 without its leading k0 zero rows: nr x n, column-major) -------------------------------
+// r = r0 + J0 dx: thread k0 + row owns a row (thread = ORIGINAL row index, so that the per-thread costs and their block sum are the ones of
+// the full matrix); two accumulators by column parity, eight columns' loads in flight.  Returns 0.5 r^2 of the thread's row.
+__device__ __forceinline__ double prior_row_lds(const lds_d *J0, cst_d *r0, const lds_d *pdx, lds_d *pr, int n, int nr, int k0, int tid) {
+    if (tid < k0 || tid >= n) return 0.0;
+    const int row = tid - k0;
+    double r = r0[row], r2 = 0.0;
+    int j = 0;
+    for (; j + 7 < n; j += 8) {
+        double a8[8], d8[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { a8[u] = J0[row + nr * (j + u)]; d8[u] = pdx[j + u]; }
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) { r += a8[u] * d8[u]; r2 += a8[u + 1] * d8[u + 1]; }
+    }
+    for (; j + 1 < n; j += 2) { r += J0[row + nr * j] * pdx[j]; r2 += J0[row + nr * (j + 1)] * pdx[j + 1]; }
+    if (n & 1) r += J0[row + nr * (n - 1)] * pdx[n - 1];
+    r += r2;
+    pr[row] = r;
+    return 0.5 * r * r;
+}
+// (J0' r)[col]: two accumulators by row parity (see the note at Hp = J0'J0: the dropped zero rows do not change the bits)
+__device__ __forceinline__ double prior_col_lds(const lds_d *J0, const lds_d *pr, int nr, int col) {
+    const lds_d *c = J0 + nr * col;
+    double s0 = 0, s1 = 0;
+    int i = 0;
+    for (; i + 7 < nr; i += 8) {
+        double a8[8], r8[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { a8[u] = c[i + u]; r8[u] = pr[i + u]; }
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) { s0 += a8[u] * r8[u]; s1 += a8[u + 1] * r8[u + 1]; }
+    }
+    for (; i + 1 < nr; i += 2) { s0 += c[i] * pr[i]; s1 += c[i + 1] * pr[i + 1]; }
+    if (nr & 1) s0 += c[nr - 1] * pr[nr - 1];
+    return s0 + s1;
+}
+
 // ---- linearise at x: cost, and (if assemble) S~ = Hcc - sum_l Hcl Hcl'/kappa_l in the tiles --------
 // kappa_l = hll + mu * clamp(s_l^2 hll) / s_l^2 is the landmark pivot of the Jacobi-scaled,
 // mu-regularised system expressed in unscaled units (DoglegStrategy + SchurEliminator restated).
@@ -817,13 +855,13 @@ __device__ __noinline__ double linearize(Ctx<NT> &Cr, const lds_d *x, bool first
     // The staging area is free between the Schur phase and the IMU chunks: J0 (n x n, column-major) is staged there
     // once per linearisation so that both products run out of LDS.
     if (P.prior_n > 0 && ABL(C, AB_PRIOR_A)) {
-        const int n = P.prior_n;
-        cst_d *J0g = dp + C.W->d_prior, *r0 = J0g + n * n, *x0 = r0 + n;
-        const bool in_lds = n * n + 2 * n <= C.stage_cap;
-        // chain mode: J0 goes through the pool in two column pieces (priors too tall for two pieces take the HBM/L2 path below)
-        const int pcap = CHAIN ? (P.c_pool - 2 * n - 2) / n - 1 : 0;
+        const int n = P.prior_n, k0 = C.W->prior_k0, nr = n - k0;      // J0 | r0 without their leading zero rows (tcv_packed.h)
+        cst_d *J0g = dp + C.W->d_prior, *r0 = J0g + nr * n, *x0 = r0 + nr;
+        const bool in_lds = nr * n + 2 * n <= C.stage_cap;
+        // chain mode: a J0 that does not fit goes through the pool in two column pieces (priors too tall for two pieces take the HBM/L2 path below)
+        const int pcap = CHAIN ? (P.c_pool - 2 * n - 2) / nr - 1 : 0;
         const bool staged = CHAIN && !in_lds && n - pcap <= pcap;
-        lds_d *J0 = C.stage, *pdx = staged ? C.stage + ((P.c_pool - 2 * n) & ~1) : C.stage + n * n, *pr = pdx + n;
+        lds_d *J0 = C.stage, *pdx = staged ? C.stage + ((P.c_pool - 2 * n) & ~1) : C.stage + ((nr * n + 1) & ~1), *pr = pdx + n;
         if (tid < P.prior_nblk) {      // dx of one kept block (marginalization_factor.cpp:348-364); fixed-size, fully unrolled
             cst_i *pb = ip + P.o_prior + tid * 4;
             const int gs = pb[2], xo = blk[pb[0] * 4 + 1], x0o = pb[3], ls = gs == 7 ? 6 : gs;
@@ -843,91 +881,66 @@ __device__ __noinline__ double linearize(Ctx<NT> &Cr, const lds_d *x, bool first
             // J0 does not fit the pool in one piece: columns [0, ns) and [ns, n) are staged one after the other.  The big
             // piece comes second and stays resident for the J0' r pass, so only the small one is read twice.
             int nb = min(n, pcap + 1);
-            if ((n & 1) && ((n - nb) & 1)) nb--;      // keep the second piece 16-byte aligned: n * (n - nb) even
+            if ((nr & 1) && ((n - nb) & 1)) nb--;      // keep the second piece 16-byte aligned: nr * (n - nb) even
             const int ns = n - nb;
             lds_d *Jp = C.stage;
             lds_d *pdx2 = pdx, *pr2 = pr;
-            double r = (tid < n) ? r0[tid] : 0.0, r2 = 0.0;
+            const bool rown = tid >= k0 && tid < n;      // thread = original row index
+            const int row = rown ? tid - k0 : 0;
+            double r = rown ? r0[row] : 0.0, r2 = 0.0;
             for (int piece = 0; piece < 2; piece++) {
                 const int c0 = piece == 0 ? 0 : ns, cn = piece == 0 ? ns : nb;
                 if (cn == 0) continue;
-                copy_doubles_deep<NT>(Jp, J0g + n * c0, n * cn, tid);
+                copy_doubles_deep<NT>(Jp, J0g + nr * c0, nr * cn, tid);
                 __syncthreads();
-                if (tid < n) {
+                if (rown) {
                     int j = 0;
                     for (; j + 7 < cn; j += 8) {      // eight columns' loads in flight, the two accumulators updated in the original order
                         double a8[8], d8[8];
 #pragma unroll
-                        for (int u = 0; u < 8; u++) { a8[u] = Jp[tid + n * (j + u)]; d8[u] = pdx2[c0 + j + u]; }
+                        for (int u = 0; u < 8; u++) { a8[u] = Jp[row + nr * (j + u)]; d8[u] = pdx2[c0 + j + u]; }
 #pragma unroll
                         for (int u = 0; u < 8; u += 2) { r += a8[u] * d8[u]; r2 += a8[u + 1] * d8[u + 1]; }
                     }
-                    for (; j + 1 < cn; j += 2) { r += Jp[tid + n * j] * pdx2[c0 + j]; r2 += Jp[tid + n * (j + 1)] * pdx2[c0 + j + 1]; }
-                    if (cn & 1) r += Jp[tid + n * (cn - 1)] * pdx2[c0 + cn - 1];
+                    for (; j + 1 < cn; j += 2) { r += Jp[row + nr * j] * pdx2[c0 + j]; r2 += Jp[row + nr * (j + 1)] * pdx2[c0 + j + 1]; }
+                    if (cn & 1) r += Jp[row + nr * (cn - 1)] * pdx2[c0 + cn - 1];
                 }
                 if (piece == 0) __syncthreads();
             }
-            if (tid < n) { r += r2; pr2[tid] = r; cost_acc += 0.5 * r * r; }
+            if (rown) { r += r2; pr2[row] = r; cost_acc += 0.5 * r * r; }
             __syncthreads();
             if (assemble) {
                 cst_i *pcol = ip + P.o_pcol;
                 for (int piece = 1; piece >= 0; piece--) {
                     const int c0 = piece == 0 ? 0 : ns, cn = piece == 0 ? ns : nb;
                     if (cn == 0) continue;
-                    if (piece == 0) { __syncthreads(); copy_doubles_deep<NT>(Jp, J0g, n * cn, tid); __syncthreads(); }
+                    if (piece == 0) { __syncthreads(); copy_doubles_deep<NT>(Jp, J0g, nr * cn, tid); __syncthreads(); }
                     if (tid < cn) {
                         const int t = pcol[c0 + tid];
-                        if (t >= 0) {
-                            const lds_d *col = Jp + n * tid;
-                            double s0 = 0, s1 = 0;
-                            int i = 0;
-                            for (; i + 7 < n; i += 8) {
-                                double a8[8], r8[8];
-#pragma unroll
-                                for (int u = 0; u < 8; u++) { a8[u] = col[i + u]; r8[u] = pr2[i + u]; }
-#pragma unroll
-                                for (int u = 0; u < 8; u += 2) { s0 += a8[u] * r8[u]; s1 += a8[u + 1] * r8[u + 1]; }
-                            }
-                            for (; i + 1 < n; i += 2) { s0 += col[i] * pr2[i]; s1 += col[i + 1] * pr2[i + 1]; }
-                            if (n & 1) s0 += col[n - 1] * pr2[n - 1];
-                            C.gcam[t] += s0 + s1;
-                        }
+                        if (t >= 0) C.gcam[t] += prior_col_lds(Jp, pr2, nr, tid);
                     }
                 }
             }
             __syncthreads();
         } else if (in_lds) {
-            copy_doubles<NT>(J0, J0g, n * n, tid);
+            copy_doubles_deep<NT>(J0, J0g, nr * n, tid);      // ONE memory round trip
             __syncthreads();
-            if (tid < n) {      // row tid of J0: stride-n walk, conflict-free across the threads of a wave
-                double r = r0[tid], r2 = 0.0;
-                for (int j = 0; j + 1 < n; j += 2) { r += J0[tid + n * j] * pdx[j]; r2 += J0[tid + n * (j + 1)] * pdx[j + 1]; }
-                if (n & 1) r += J0[tid + n * (n - 1)] * pdx[n - 1];
-                r += r2;
-                pr[tid] = r;
-                cost_acc += 0.5 * r * r;
-            }
+            cost_acc += prior_row_lds(J0, r0, pdx, pr, n, nr, k0, tid);
             __syncthreads();
             if (assemble) {
                 cst_i *pcol = ip + P.o_pcol;
                 if (tid < n) {
                     const int t = pcol[tid];
-                    if (t >= 0) {
-                        const lds_d *col = J0 + n * tid;
-                        double s0 = 0, s1 = 0;
-                        for (int i = 0; i + 1 < n; i += 2) { s0 += col[i] * pr[i]; s1 += col[i + 1] * pr[i + 1]; }
-                        if (n & 1) s0 += col[n - 1] * pr[n - 1];
-                        C.gcam[t] += s0 + s1;
-                    }
+                    if (t >= 0) C.gcam[t] += prior_col_lds(J0, pr, nr, tid);
                 }
             }
             __syncthreads();
         } else {
             __syncthreads();
-            if (tid < n) {
-                double r = r0[tid];
-                for (int j = 0; j < n; j++) r += J0g[tid + n * j] * C.g_pdx[j];
-                C.g_pr[tid] = r;
+            if (tid >= k0 && tid < n) {
+                double r = r0[tid - k0];
+                for (int j = 0; j < n; j++) r += J0g[tid - k0 + nr * j] * C.g_pdx[j];
+                C.g_pr[tid - k0] = r;
                 cost_acc += 0.5 * r * r;
             }
             __syncthreads();
@@ -935,7 +948,7 @@ __device__ __noinline__ double linearize(Ctx<NT> &Cr, const lds_d *x, bool first
                 cst_i *pcol = ip + P.o_pcol;
                 if (tid < n && pcol[tid] >= 0) {
                     double s2 = 0;
-                    for (int i = 0; i < n; i++) s2 += J0g[i + n * tid] * C.g_pr[i];
+                    for (int i = 0; i < nr; i++) s2 += J0g[i + nr * tid] * C.g_pr[i];
                     C.gcam[pcol[tid]] += s2;
                 }
             }
@@ -1038,9 +1051,9 @@ __device__ __noinline__ double linearize_coop(Ctx<NT> &Cr, const lds_d *x, bool 
     double cost_prior = 0.0, cost_imu = 0.0, pg = 0.0;
     int pt = -1;
     if (P.prior_n > 0) {
-        const int n = P.prior_n;
-        cst_d *J0g = dp + C.W->d_prior, *r0 = J0g + n * n, *x0 = r0 + n;
-        lds_d *J0 = C.stage, *pdx = C.stage + n * n, *pr = pdx + n;      // n n + 2 n <= stage_cap: checked by tcv_batch_create
+        const int n = P.prior_n, k0 = C.W->prior_k0, nr = n - k0;      // J0 | r0 without their leading zero rows (tcv_packed.h)
+        cst_d *J0g = dp + C.W->d_prior, *r0 = J0g + nr * n, *x0 = r0 + nr;
+        lds_d *J0 = C.stage, *pdx = C.stage + ((nr * n + 1) & ~1), *pr = pdx + n;      // n n + 2 n <= stage_cap: checked by tcv_batch_create
         if (tid < P.prior_nblk) {
             cst_i *pb = ip + P.o_prior + tid * 4;
             const int gs = pb[2], xo = blk[pb[0] * 4 + 1], x0o = pb[3], ls = gs == 7 ? 6 : gs;
@@ -1056,26 +1069,13 @@ __device__ __noinline__ double linearize_coop(Ctx<NT> &Cr, const lds_d *x, bool 
 #pragma unroll
             for (int i = 0; i < 15; i++) if (i < ls) pdx[pb[1] + i] = d15[i];
         }
-        copy_doubles<NT>(J0, J0g, n * n, tid);
+        copy_doubles_deep<NT>(J0, J0g, nr * n, tid);
         __syncthreads();
-        if (tid < n) {      // the in_lds branch of linearize(), verbatim
-            double r = r0[tid], r2 = 0.0;
-            for (int j = 0; j + 1 < n; j += 2) { r += J0[tid + n * j] * pdx[j]; r2 += J0[tid + n * (j + 1)] * pdx[j + 1]; }
-            if (n & 1) r += J0[tid + n * (n - 1)] * pdx[n - 1];
-            r += r2;
-            pr[tid] = r;
-            cost_prior = 0.5 * r * r;
-        }
+        cost_prior = prior_row_lds(J0, r0, pdx, pr, n, nr, k0, tid);      // the in_lds branch of linearize()
         __syncthreads();
         if (assemble && tid < n) {
             const int t = (ip + P.o_pcol)[tid];
-            if (t >= 0) {
-                const lds_d *col = J0 + n * tid;
-                double s0 = 0, s1 = 0;
-                for (int i = 0; i + 1 < n; i += 2) { s0 += col[i] * pr[i]; s1 += col[i + 1] * pr[i + 1]; }
-                if (n & 1) s0 += col[n - 1] * pr[n - 1];
-                pg = s0 + s1; pt = t;
-            }
+            if (t >= 0) { pg = prior_col_lds(J0, pr, nr, tid); pt = t; }
         }
         __syncthreads();
     }
@@ -2272,10 +2272,10 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((CHAIN 
         // constant part of the prior: Hp = J0' J0 (packed lower), marginalization_factor.cpp:366,371-380.  The tile
         // region is still unused: J0 is staged there (columns contiguous) and every thread forms 1 x 2 entry pairs.
         if (P.prior_n > 0) {
-            const int n = P.prior_n;
+            const int n = P.prior_n, nr = n - W->prior_k0;      // J0 without its leading zero rows: nr x n, column-major (tcv_packed.h)
             cst_d *J0g = C.dp + W->d_prior;
-            const bool in_lds = n * n <= (C.ntiles << 8) + (CHAIN ? P.c_pool : 0);
-            if (in_lds) copy_doubles<NT>(lds, J0g, n * n, tid);
+            const bool in_lds = nr * n <= (C.ntiles << 8) + (CHAIN ? P.c_pool : 0);
+            if (in_lds) copy_doubles<NT>(lds, J0g, nr * n, tid);
             __syncthreads();
             for (int e = tid; e < n * (n + 1) / 2; e += NT) {      // packed index e = a (a + 1) / 2 + b, b <= a: every lane has an entry
                 int a = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
@@ -2284,19 +2284,21 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((CHAIN 
                 const int b = e - a * (a + 1) / 2;
                 double s0 = 0, s1 = 0;
                 if (in_lds) {
-                    const lds_d *ca = lds + n * a, *cb = lds + n * b;
+                    // (two accumulators by row parity, rows ascending: dropping the zero rows leaves each chain's non-zero terms in their
+                    // order -- an odd number of dropped rows only swaps the names of the two chains -- so s0 + s1 keeps its bits)
+                    const lds_d *ca = lds + nr * a, *cb = lds + nr * b;
                     int i = 0;
-                    for (; i + 7 < n; i += 8) {      // eight rows' loads in flight, the two accumulators updated in the original order
+                    for (; i + 7 < nr; i += 8) {      // eight rows' loads in flight, the two accumulators updated in the original order
                         double a8[8], b8[8];
 #pragma unroll
                         for (int u = 0; u < 8; u++) { a8[u] = ca[i + u]; b8[u] = cb[i + u]; }
 #pragma unroll
                         for (int u = 0; u < 8; u += 2) { s0 += a8[u] * b8[u]; s1 += a8[u + 1] * b8[u + 1]; }
                     }
-                    for (; i + 1 < n; i += 2) { s0 += ca[i] * cb[i]; s1 += ca[i + 1] * cb[i + 1]; }
-                    if (n & 1) s0 += ca[n - 1] * cb[n - 1];
+                    for (; i + 1 < nr; i += 2) { s0 += ca[i] * cb[i]; s1 += ca[i + 1] * cb[i + 1]; }
+                    if (nr & 1) s0 += ca[nr - 1] * cb[nr - 1];
                 } else {
-                    for (int i = 0; i < n; i++) s0 += J0g[i + n * a] * J0g[i + n * b];
+                    for (int i = 0; i < nr; i++) s0 += J0g[i + nr * a] * J0g[i + nr * b];
                 }
                 C.g_hp[a * (a + 1) / 2 + b] = s0 + s1;
             }

@@ -71,7 +71,17 @@ def test_prior_and_constant_extrinsic_change_the_plan(tcv):
     pre, main, z = golden_windows()
     w = tcv.Window(main)
     st = w.plan_stats()
-    assert st["window_doubles"] > 10000          # + n^2 + n + x0 of the prior
+    # + the prior: J0 | r0 WITHOUT the leading rows that are exact zeros (the eigenvalues the marginalisation thresholded,
+    # marginalization_factor.cpp:284-293), + x0
+    J0g, r0g = z["marg_J0"], z["marg_r0"]
+    k0 = 0
+    while k0 < J0g.shape[0] - 1 and not J0g[k0].any() and r0g[k0] == 0.0:
+        k0 += 1
+    nfull, nr = J0g.shape[0], J0g.shape[0] - k0
+    assert 10 < k0 < nfull - 10                  # about half of the 75 rows of the golden prior
+    st0 = tcv.Window(pre).plan_stats()
+    extra = st["window_doubles"] - st0["window_doubles"]
+    assert nr * nfull + nr <= extra <= nr * nfull + nr + 200, (extra, nr, nfull)
     w2 = tcv.Window(main, estimate_extrinsic=False)
     st2 = w2.plan_stats()
     assert st2["nc"] == 165 and st2["npp"] == 66
