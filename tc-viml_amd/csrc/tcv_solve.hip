@@ -56,7 +56,8 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 #define ABL(C, bit) true
 #endif
 enum { AB_VIS_EVAL = 0, AB_VIS_GATHER, AB_LM, AB_SCHUR, AB_PRIOR_A, AB_IMU_RAW, AB_IMU_WHITEN, AB_IMU_GATHER, AB_PRIOR_B, AB_FIN_SCALE, AB_FIN_PASS,
-       AB_CHAIN_FWD, AB_CHOL, AB_BACK, AB_CHAIN_BWD, AB_LM_BACK, AB_DOGLEG, AB_PLUS, AB_NORMS, AB_SETUP, AB_CH_T, AB_CH_W, AB_CH_MFMA, AB_CH_FETCH };
+       AB_CHAIN_FWD, AB_CHOL, AB_BACK, AB_CHAIN_BWD, AB_LM_BACK, AB_DOGLEG, AB_PLUS, AB_NORMS, AB_SETUP, AB_CH_T, AB_CH_W, AB_CH_MFMA, AB_CH_FETCH,
+       AB_COPY_PROG /* only together with the gathers */, AB_ZERO };
 enum { PH_SETUP = 0, PH_VIS_EVAL, PH_VIS_GATHER, PH_LM, PH_SCHUR, PH_ZERO, PH_IMU_RAW, PH_IMU_WHITEN, PH_IMU_GATHER, PH_PRIOR,
        PH_COST_RED, PH_FIN_SCALE, PH_FIN_CAUCHY, PH_FIN_PASS, PH_CHOL_DIAG, PH_CHOL_TRSM, PH_CHOL_UPD, PH_BACK, PH_LM_BACK,
        PH_DOGLEG, PH_PLUS, PH_NORMS, PH_OTHER, PH_CHAIN_FWD, PH_CHAIN_BWD, PH_CH_A, PH_CH_B, PH_CH_C, PH_CH_D, PH_COUNT = 32 };
@@ -370,7 +371,7 @@ __device__ __forceinline__ void vis_part1(Ctx<NT> &C, const lds_d *x, int ch, bo
         lds_i *lprog = (lds_i *)(C.stage + ((pn * prec + ln * LINE_REC + 1) & ~1));   // gather program behind the records
         if (assemble) {
             for (int i = tid; i < esize + 2 * lmn; i += NT) C.area[i] = 0.0;
-            copy_prog<NT>(lprog, ip + P.o_vdest + voff, 3 * vnu + vni, tid);
+            if (ABL(C, AB_COPY_PROG)) copy_prog<NT>(lprog, ip + P.o_vdest + voff, 3 * vnu + vni, tid);
         }
         __syncthreads();
         if (ABL(C, AB_VIS_EVAL)) {
@@ -509,7 +510,7 @@ __device__ __forceinline__ void vis_part2(Ctx<NT> &C, int ch, bool first, double
                 C.l_hll[lmb + l] = h; C.l_gl[lmb + l] = gl[l]; C.l_invk[lmb + l] = ik;
                 C.v_g[nc + lmb + l] = gl[l];
             }
-            copy_prog<NT>((lds_i *)C.stage, ip + P.o_sdest + soff, 3 * snu + sni, tid);
+            if (ABL(C, AB_COPY_PROG)) copy_prog<NT>((lds_i *)C.stage, ip + P.o_sdest + soff, 3 * snu + sni, tid);
         }
         __syncthreads();
         for (int i = tid; i < esize; i += NT) C.g_hcl[ebase + i] = hcl[i];
@@ -837,7 +838,7 @@ __device__ __noinline__ double linearize(Ctx<NT> &Cr, const lds_d *x, bool first
     const int prec = with_td ? (int)PROJ_TD_REC : (int)PROJ_REC, pstr = with_td ? (int)PROJ_TD_STRIDE : (int)PROJ_STRIDE;
     double cost_acc = 0.0;
 
-    if (assemble) {
+    if (assemble && ABL(C, AB_ZERO)) {
         zero_lds<NT>(C.tiles, pp_elems, tid);
         for (int i = tid; i < nc; i += NT) C.gcam[i] = 0.0;
         for (int i = tid; i < 176; i += NT) C.rc[i] = 0.0;      // rc | sd
@@ -2271,7 +2272,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((CHAIN 
         if (A.sqrt_out && W->d_sqrt < 0 && W->sqrt_export >= 0 && tid < 225) A.sqrt_out[(size_t)win * 225 + tid] = C.g_sqrt[W->sqrt_export * 225 + tid];
         // constant part of the prior: Hp = J0' J0 (packed lower), marginalization_factor.cpp:366,371-380.  The tile
         // region is still unused: J0 is staged there (columns contiguous) and every thread forms 1 x 2 entry pairs.
-        if (P.prior_n > 0) {
+        if (P.prior_n > 0 && ABL(C, AB_SETUP)) {
             const int n = P.prior_n, nr = n - W->prior_k0;      // J0 without its leading zero rows: nr x n, column-major (tcv_packed.h)
             cst_d *J0g = C.dp + W->d_prior;
             const bool in_lds = nr * n <= (C.ntiles << 8) + (CHAIN ? P.c_pool : 0);
