@@ -525,6 +525,7 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
         if (!problems[w] || (marg_problems && (!marg_problems[w] || !marg_drop || !marg_num_drop))) { set_error("batch_create: null problem in the batch"); return TCV_ERR_INVALID; }
     if (int rc = device_ready()) return rc;
     const auto t_begin = std::chrono::steady_clock::now();
+    tcv::prior_refresh_switch();
     tcv_batch *b = new tcv_batch();
     b->n = n;
     b->problems.assign(problems, problems + n);

@@ -539,7 +539,7 @@ __device__ __noinline__ void eig_backtransform_wy(const lds_d *Hq_, lds_d *Z_, c
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), col = lane & 15, row0 = lane >> 4;
     const int nref = n - 1;                               // reflectors 0 .. n - 2
     const int ncol = n - c0, ntile = (ncol + 15) >> 4;
-    if (ncol <= 0) return;
+    if (ncol <= 0 || nref <= 0) return;
     const wy_v4 zero4 = {0.0, 0.0, 0.0, 0.0};
     const int i_last = ((nref - 1) >> 4) << 4;
     if (wave == NW - 1) {
@@ -1809,8 +1809,7 @@ static int pack_marg(const tcv_problem &p, double *const *drop, int ndrop, const
     if (pr && solve_p && solve_pk && !solve_p->prior.empty() && solve_p->prior[0].prior == pr && solve_pk->hdr.prior_n == pr->n && !getenv("TCV_MARG_OWN_PRIOR"))
         { H.prior_abs = solve_pk->win.dbase + solve_pk->win.d_prior; H.prior_k0 = solve_pk->win.prior_k0; }      // same layout: J0 | r0 | x0 without the leading zero rows (tcv_pack.cpp)
     else if (pr) {
-        static const bool full = getenv("TCV_PRIOR_FULL") != nullptr;
-        const int n0 = pr->n, k0 = full ? 0 : prior_zero_rows(pr->J0.data(), pr->r0.data(), n0);
+        const int n0 = pr->n, k0 = prior_keep_zero_rows() ? 0 : prior_zero_rows(pr->J0.data(), pr->r0.data(), n0);
         H.prior_k0 = k0;
         for (int j = 0; j < n0; j++) D.insert(D.end(), pr->J0.begin() + (size_t)n0 * j + k0, pr->J0.begin() + (size_t)n0 * (j + 1));
         D.insert(D.end(), pr->r0.begin() + k0, pr->r0.end()); D.insert(D.end(), pr->x0.begin(), pr->x0.end());

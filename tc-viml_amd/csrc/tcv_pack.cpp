@@ -2,6 +2,7 @@
 // (tcv_packed.h).  Everything structural that the reference redoes per frame through
 // AddParameterBlock / AddResidualBlock pointer chasing is resolved here, once, into flat gather lists.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -15,6 +16,16 @@
 #include "tcv_host.h"
 
 namespace tcv {
+
+// TCV_PRIOR_FULL: keep the exact-zero rows of the prior (A/B partner of the default).  The environment is read once per batch
+// (prior_refresh_switch), not once per window.
+static std::atomic<int> g_prior_full{-1};
+void prior_refresh_switch() { g_prior_full.store(getenv("TCV_PRIOR_FULL") ? 1 : 0, std::memory_order_relaxed); }
+bool prior_keep_zero_rows() {
+    int v = g_prior_full.load(std::memory_order_relaxed);
+    if (v < 0) { prior_refresh_switch(); v = g_prior_full.load(std::memory_order_relaxed); }
+    return v != 0;
+}
 
 // Two chain-mode workgroups share one CU's 160 KiB of LDS.  TCV_CHAIN_LDS_DOUBLES overrides the per-workgroup size (tuning).
 int chain_lds_doubles() {
@@ -792,8 +803,7 @@ static int pack_data_to(const tcv_problem &p, Packed &out, const double *imu_sqr
     if (D.n & 1) D.put1(0.0);        // J0 is copied with 16-byte loads
     W.d_prior = (int)D.n;
     if (pr) {      // the rows of the thresholded eigenvalues (exact zeros in J0 and r0) are dropped, tcv_packed.h
-        static const bool full = getenv("TCV_PRIOR_FULL") != nullptr;      // developer A/B switch: keep every row
-        const int n = pr->n, k0 = full ? 0 : prior_zero_rows(pr->J0.data(), pr->r0.data(), n), nr = n - k0;
+        const int n = pr->n, k0 = prior_keep_zero_rows() ? 0 : prior_zero_rows(pr->J0.data(), pr->r0.data(), n), nr = n - k0;
         W.prior_k0 = k0;
         for (int j = 0; j < n; j++) D.put(pr->J0.data() + (size_t)n * j + k0, nr);
         D.put(pr->r0.data() + k0, nr);

@@ -21,6 +21,8 @@ enum { KIND_EUCLID = 0, KIND_POSE = 1 };
 enum { TILE = 16, TILE_ELEMS = 256 };
 enum { LDS_DOUBLES = 20480 };  // 160 KiB per workgroup on gfx950
 int chain_lds_doubles();       // LDS doubles of a chain-mode workgroup (two per CU); tcv_pack.cpp
+bool prior_keep_zero_rows();   // developer A/B switch TCV_PRIOR_FULL (re-read by every tcv_batch_create / tcv_solve); tcv_pack.cpp
+void prior_refresh_switch();
 enum { MAX_TRACE = 64 };
 
 // staging record strides (doubles per residual row): Jacobian columns followed by the residual

@@ -2323,8 +2323,10 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((CHAIN 
         const double initial_cost = cost;
         if (tid == 0) { S->cost[0] = cost; S->step_ok[0] = 1; S->dogleg_case[0] = 0; S->radius[0] = radius; S->mu[0] = mu; }
         double gg = 0, q = 0, alpha = 0, yg = 0, gdy = 0, dy2 = 0;
-        double xn2, dn2;
-        { const Norms2 nn = ambient_norms<NT>(C, K.xs, K.xs); xn2 = uni_d(nn.xn2); dn2 = uni_d(nn.dn2); }
+        // |x| and |x+ - x| in ambient space feed the parameter-tolerance test only: with the convergence tests off (fixed iterations) nothing
+        // reads them, and the three reductions per iteration are not run
+        double xn2 = 0.0, dn2 = 0.0;
+        if (!fixed) { const Norms2 nn = ambient_norms<NT>(C, K.xs, K.xs); xn2 = uni_d(nn.xn2); dn2 = uni_d(nn.dn2); }
         double x_norm = uni_d(sqrt(xn2));
         bool done = false;
         if (COOP && C.cx_seq < 0) { done = true; status = -9; termination = 5; }      // the helpers did not answer (timeout)
@@ -2437,7 +2439,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((CHAIN 
             if (COOP && C.cx_seq < 0) { status = -9; termination = 5; break; }
             tiles_valid = want_asm;
             lin_mu = mu_next;
-            if (ABL(C, AB_NORMS)) { const Norms2 nn = ambient_norms<NT>(C, K.xs, K.xc); xn2 = uni_d(nn.xn2); dn2 = uni_d(nn.dn2); }
+            if (!fixed && ABL(C, AB_NORMS)) { const Norms2 nn = ambient_norms<NT>(C, K.xs, K.xc); xn2 = uni_d(nn.xn2); dn2 = uni_d(nn.dn2); }
             TCV_MARK(C, PH_NORMS);
 #ifdef TCV_ABLATE
             const double rho = ABL_ACCEPT(C) ? 1.0 : (cost - cost_c) / model_cost_change;
@@ -2460,7 +2462,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((CHAIN 
             }
             if (rho > 1e-3) {
                 for (int i = tid; i < P.nx + L; i += NT) K.xs[i] = K.xc[i];
-                if (ABL(C, AB_NORMS)) { const Norms2 nn = ambient_norms<NT>(C, K.xc, K.xc); xn2 = uni_d(nn.xn2); dn2 = uni_d(nn.dn2); }
+                if (!fixed && ABL(C, AB_NORMS)) { const Norms2 nn = ambient_norms<NT>(C, K.xc, K.xc); xn2 = uni_d(nn.xn2); dn2 = uni_d(nn.dn2); }
                 x_norm = uni_d(sqrt(xn2));
                 cost = cost_c;
                 if (rho < 0.25) radius = uni_d(radius * 0.5);

@@ -216,6 +216,61 @@ def test_shortcuts_of_the_marginalisation_are_bit_identical_to_the_plain_paths(g
             assert np.array_equal(d0["J0"], d1["J0"]) and np.array_equal(d0["r0"], d1["r0"]), var
 
 
+def test_round3_eigen_solver_against_round2_paths(gpu, monkeypatch):
+    """Round 3 locates only the eigenvalues of A' above eps (they are the only ones marginalization_factor.cpp:284-293 keeps) and applies the
+    reflectors in blocks on the matrix cores.  TCV_MARG_EIG_FLAGS brings round 2's paths back (1: every eigenvalue by 4-section, 2: reflector
+    by reflector on the VALU): A' and b' are formed before the eigen-solver and must not move a bit; the factors agree as far as an
+    eigen-decomposition of A' is defined -- J0'J0, J0'r0, the number of thresholded rows -- to the accuracy of the solver (1e-9 of |A'|)."""
+    pre, main, z = golden_windows()
+    more = synth.make_windows(930, 3, frame_shift=-1)
+    wins = [pre, main] + [synth.window_at(more, k) for k in range(3)]
+
+    def run():
+        W, b = marg_batch(gpu, wins)
+        assert not b.marg_status().any()                 # nobody on the Jacobi safety net
+        return [(b.prior(k).export(), b.prior(k).schur()) for k in range(len(wins))]
+
+    ref = run()
+    for d, (A, bb) in ref:
+        zero = ~d["J0"].any(axis=1)
+        assert zero.sum() >= 4 and not zero[zero.sum():].any()      # the thresholded rows (at least the gauge) lead, ascending eigenvalues follow
+    for flags in ("1", "2", "3"):
+        monkeypatch.setenv("TCV_MARG_EIG_FLAGS", flags)
+        got = run()
+        monkeypatch.delenv("TCV_MARG_EIG_FLAGS")
+        for (d0, (A0, b0)), (d1, (A1, b1)) in zip(ref, got):
+            assert np.array_equal(A0, A1) and np.array_equal(b0, b1), flags
+            assert (~d0["J0"].any(axis=1)).sum() == (~d1["J0"].any(axis=1)).sum(), flags
+            assert fro(d0["J0"].T @ d0["J0"], d1["J0"].T @ d1["J0"]) < 1e-9, flags
+            assert np.linalg.norm(d0["J0"].T @ d0["r0"] - d1["J0"].T @ d1["r0"]) <= 1e-7 * np.linalg.norm(b0), flags
+
+
+def test_prior_without_its_zero_rows_is_bit_identical(gpu, monkeypatch):
+    """The rows of J0 | r0 that the marginalisation thresholded are exact zeros; the packer drops them (WinHdr::prior_k0) and the solve and the
+    marginalisation work on the stored rows with the accumulation chains of the full matrix.  TCV_PRIOR_FULL=1 packs every row: states, costs,
+    traces and the next prior must agree to the bit, with a third less window data."""
+    pre, main, z = golden_windows()
+
+    def run():
+        W, b = marg_batch(gpu, [main])
+        b.download_states()
+        s = b.summaries()[0]
+        P = b.prior(0)
+        return (W[0].pose.copy(), W[0].sb.copy(), [s.cost[i] for i in range(s.num_iterations)], s.final_cost, P.export(), P.schur(), W[0].plan_stats()["window_doubles"])
+
+    ref = run()
+    monkeypatch.setenv("TCV_PRIOR_FULL", "1")
+    full = run()
+    monkeypatch.delenv("TCV_PRIOR_FULL")
+    assert np.array_equal(ref[0], full[0]) and np.array_equal(ref[1], full[1])
+    assert ref[2] == full[2] and ref[3] == full[3]
+    assert np.array_equal(ref[4]["J0"], full[4]["J0"]) and np.array_equal(ref[4]["r0"], full[4]["r0"])
+    assert np.array_equal(ref[5][0], full[5][0]) and np.array_equal(ref[5][1], full[5][1])
+    n = z["marg_J0"].shape[0]
+    k0 = int((~z["marg_J0"].any(axis=1)).sum())
+    assert full[6] - ref[6] == k0 * n + k0 and k0 > 10
+
+
 def _standalone(gpu, w2):
     mw = gpu.margin_old_window(w2)
     Wm = gpu.Window(mw)
