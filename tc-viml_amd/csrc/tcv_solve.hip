@@ -2182,6 +2182,9 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((CHAIN 
             if (pw == 0) { pr[16 + (w0 & 7)] += 1.0; pr[24 + (perm ? 1 : 0)] += 1.0; }
         }
         tid = (tid & 63) | (__builtin_amdgcn_readfirstlane(lw) << 6);      // the wave index stays provably uniform
+        // de-phasing experiment (role_mode bit 5, count in bits 8..): the second workgroup of a CU starts late, so that the two do not walk
+        // through the same phases (and memory bursts) at the same time
+        if ((A.role_mode & 32) && (w0 & 1)) { const int nsl = __builtin_amdgcn_readfirstlane(A.role_mode >> 8); for (int k = 0; k < nsl; k++) __builtin_amdgcn_s_sleep(127); }
     }
     if (COOP) {
         const int G8 = 8 * (1 + A.coop_h);      // workgroups of a block of eight groups: contiguous in dispatch order, one group per XCD
