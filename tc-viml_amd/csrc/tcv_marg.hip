@@ -710,17 +710,26 @@ __device__ __noinline__ bool sym_eig_tridiag(lds_d *A_, lds_d *Hq_, lds_d *sm_, 
             // J column slots per lane (8 J >= m): three static sizes, so that the small trailing blocks of the late steps do not pay for ten
             // clamped loads and masked updates per lane -- the skipped slots held nothing (c >= m): the same sums, bit for bit
             const int part8 = tid & 7;
-#define TCV_R2_BODY(J)                                                                                                               \
+#define TCV_R2_BODY(J, JV)                                                                                                           \
             if ((tid & ~63) >> 3 < ((m + 7) & ~7)) {      /* a wavefront whose first row lies beyond the block has nothing to update */ \
-                /* what depends on the column only -- v, w = p + K v and the new first row x' -- once per step, not once per row pass */ \
+                /* what depends on the column only -- v, w = p + K v and the new first row x' -- once per step, not once per row pass. */ \
+                /* Column slots j < JV lie inside the block for every lane (8 JV <= the smallest m of the regime): no masks.  A slot */ \
+                /* beyond the block (c >= m) and a row beyond it (rr >= m) work on the CLAMPED column / row: they recompute and store */ \
+                /* the value the owner of entry (m - 1) stores -- same wavefront, loads before stores, same bits -- and only their    */ \
+                /* contributions to the sums are masked: no exec-mask branch per entry.                                               */ \
                 double vc[J], wc[J], xn[J];                                                                                          \
+                int cc[J];                                                                                                           \
                 {                                                                                                                    \
                     double pc[J], xo[J];                                                                                             \
-                    _Pragma("unroll") for (int j = 0; j < J; j++) { const int c = min(part8 + 8 * j, m - 1); vc[j] = vbuf[c]; pc[j] = pbuf[c]; xo[j] = xold[c]; } \
+                    _Pragma("unroll") for (int j = 0; j < J; j++) { cc[j] = (j < JV) ? part8 + 8 * j : min(part8 + 8 * j, m - 1); vc[j] = vbuf[cc[j]]; pc[j] = pbuf[cc[j]]; xo[j] = xold[cc[j]]; } \
                     _Pragma("unroll") for (int j = 0; j < J; j++) { wc[j] = pc[j] + K * vc[j]; xn[j] = rank2(xo[j], v0, wc[j], w0, vc[j]); }      /* new A22[0][c], bit for bit what row 0's lanes store */ \
                 }                                                                                                                    \
                 double x2 = 0;                                                                                                       \
-                _Pragma("unroll") for (int j = 0; j < J; j++) { const int c = part8 + 8 * j; if (c < m && c >= 2) x2 += xn[j] * xn[j]; } \
+                _Pragma("unroll") for (int j = 0; j < J; j++) {                                                                      \
+                    const int c = part8 + 8 * j;                                                                                     \
+                    const bool in = (j == 0) ? (c >= 2 && c < m) : ((j < JV) ? true : c < m);                                        \
+                    x2 = in ? fma(xn[j], xn[j], x2) : x2;                                                                            \
+                }                                                                                                                    \
                 x2 += down_dpp<0x101>(x2); x2 += down_dpp<0x102>(x2); x2 += down_dpp<0x104>(x2);                                     \
                 if (tid == 8) xnb[(i + 1) & 1] = x2;      /* (lane 0 of the group of row 1) */                                       \
                 for (int rr = tid >> 3; rr < ((m + 7) & ~7); rr += NT / 8) {                                                         \
@@ -728,22 +737,21 @@ __device__ __noinline__ bool sym_eig_tridiag(lds_d *A_, lds_d *Hq_, lds_d *sm_, 
                     const double vr = vbuf[rc], wr = pbuf[rc] + K * vr;                                                              \
                     lds_d *row = A + (i + 1 + rc) * ld + (i + 1);                                                                    \
                     double av[J];      /* every load in flight at once */                                                            \
-                    _Pragma("unroll") for (int j = 0; j < J; j++) av[j] = row[min(part8 + 8 * j, m - 1)];                            \
+                    _Pragma("unroll") for (int j = 0; j < J; j++) av[j] = row[cc[j]];                                                \
                     double un = 0;                                                                                                   \
                     _Pragma("unroll") for (int j = 0; j < J; j++) {                                                                  \
                         const int c = part8 + 8 * j;                                                                                 \
-                        if (c < m) {                                                                                                 \
-                            const double nv = rank2(av[j], vr, wc[j], wr, vc[j]);                                                    \
-                            if (rr < m) row[c] = nv;                                                                                 \
-                            if (c >= 1) un += nv * xn[j];                                                                            \
-                        }                                                                                                            \
+                        const double nv = rank2(av[j], vr, wc[j], wr, vc[j]);                                                        \
+                        row[cc[j]] = nv;                                                                                             \
+                        const bool in = (j == 0) ? (c >= 1 && c < m) : ((j < JV) ? true : c < m);                                    \
+                        un = in ? fma(nv, xn[j], un) : un;                                                                           \
                     }                                                                                                                \
                     un += down_dpp<0x101>(un); un += down_dpp<0x102>(un); un += down_dpp<0x104>(un);      /* lane 0 of the 8-lane group */ \
                     if (part8 == 0 && rr >= 1 && rr < m) ubuf[rr - 1] = un;                                                          \
                     if (part8 == 0 && rr > 0 && rr < m) hq[rr - 1] = vr;                                                             \
                 }                                                                                                                    \
             }
-            if (m > 40) { TCV_R2_BODY(10) } else if (m > 16) { TCV_R2_BODY(5) } else { TCV_R2_BODY(2) }
+            if (m > 40) { TCV_R2_BODY(10, 5) } else if (m > 16) { TCV_R2_BODY(5, 2) } else { TCV_R2_BODY(2, 0) }
 #undef TCV_R2_BODY
         }
         SMARK(m > 40 ? 2 : (m > 16 ? 3 : 4));
