@@ -37,7 +37,11 @@ for b, nm in enumerate(names):
 print("  sum of the single-phase costs %.3f ms of %.3f" % (tot, base))
 groups = {"visual (eval+gather+lm+schur)": 0b1111, "imu (raw+whiten+gather)": 0b11100000, "prior (A+B)": (1 << 4) | (1 << 8), "linearise (all factor families)": 0b111111111,
           "solve (scale+pass+chain+chol+back+bwd+lm_back)": sum(1 << k for k in range(9, 16)), "chain (fwd+bwd)": (1 << 11) | (1 << 14),
-          "chain pipelines (T + owners + mfma)": (1 << 20) | (1 << 21) | (1 << 22), "everything": (1 << 19) - 1}
+          "chain pipelines (T + owners + mfma)": (1 << 20) | (1 << 21) | (1 << 22), "everything": (1 << 19) - 1,
+          # the skeleton that is left: what of it the per-solve J0'J0 (bit 19), the copies of the gather programs into LDS (bit 24) and the
+          # zeroing of the tiles (bit 25) are
+          "everything + per-solve J0'J0": (1 << 20) - 1, "everything + gather-program copies": ((1 << 19) - 1) | (1 << 24),
+          "everything + tile zeroing": ((1 << 19) - 1) | (1 << 25), "everything + all three": ((1 << 20) - 1) | (1 << 24) | (1 << 25)}
 for nm, m in groups.items():
     t = run(m)
     print("  without %-45s %.3f ms  -> %.3f ms (%4.1f %%)" % (nm, t, base - t, 100 * (base - t) / base), flush=True)

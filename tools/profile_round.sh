@@ -38,6 +38,15 @@ python3 bench.py --mode replay --steps 150 --warmup 10 > $O/bench_replay.json 2>
 python3 bench.py --mode replay --steps 150 --warmup 10 --host-threads 1 > $O/bench_replay_1thread.json 2> /dev/null
 python3 bench.py --mode stream --windows 2048 > $O/bench_stream_2048.json 2> /dev/null
 python3 tools/replay_euroc.py --native --profile --frames 340 --out $O/euroc > $O/replay_euroc_native.json 2> /dev/null
+# round 3: A/B of the round's kernel changes on the final build (developer switches), the experiments of DESIGN 6b
+for spec in "default:" "round-2 eigenvalue search:TCV_MARG_EIG_FLAGS=1" "reflector-by-reflector back-transformation:TCV_MARG_EIG_FLAGS=2" "both round-2 eigen paths:TCV_MARG_EIG_FLAGS=3" "prior with its zero rows:TCV_PRIOR_FULL=1"; do
+  name="${spec%%:*}"; var="${spec#*:}"
+  for rep in 1 2; do
+    env $var python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-45s solve %.3f ms  marginalisation %.3f ms  %.1f K solves/s' % ('$name', d['kernel_ms']['solve'], d['kernel_ms']['marginalize'], d['value'] / 1e3))"
+  done
+done > $O/kernel_ab.txt 2>&1
+python3 tools/dev_role_modes.py > $O/role_modes.txt 2>&1
+python3 tools/dev_split_streams.py > $O/split_streams.txt 2>&1
 find $O -name "*_kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
 python3 - <<PY
 import csv, glob, collections, json
