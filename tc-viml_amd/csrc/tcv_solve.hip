@@ -858,7 +858,7 @@ __device__ __noinline__ double linearize(Ctx<NT> &Cr, const lds_d *x, bool first
     if (P.prior_n > 0 && ABL(C, AB_PRIOR_A)) {
         const int n = P.prior_n, k0 = C.W->prior_k0, nr = n - k0;      // J0 | r0 without their leading zero rows (tcv_packed.h)
         cst_d *J0g = dp + C.W->d_prior, *r0 = J0g + nr * n, *x0 = r0 + nr;
-        const bool in_lds = nr * n + 2 * n <= C.stage_cap;
+        const bool in_lds = ((nr * n + 1) & ~1) + 2 * n <= C.stage_cap;
         // chain mode: a J0 that does not fit goes through the pool in two column pieces (priors too tall for two pieces take the HBM/L2 path below)
         const int pcap = CHAIN ? (P.c_pool - 2 * n - 2) / nr - 1 : 0;
         const bool staged = CHAIN && !in_lds && n - pcap <= pcap;
