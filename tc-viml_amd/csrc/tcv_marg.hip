@@ -1452,15 +1452,20 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((amdgpu_waves_per_eu(2,
         const int ldn = ne + 1;
         lds_d *As = Apk, *V2 = Apk;
         double keepA[ (MARG_MAX_N * MARG_MAX_N + MARG_NT - 1) / MARG_NT ];
+        bool keep_sym = false;      // keepA holds the folded lower triangle (Cholesky route) instead of all n x n entries
         double bprime = 0;
         gbl_d *Z = scr + MARG_SCR_Z, *zb = scr + MARG_SCR_PR;
         if (chol) {
             MARG_MARK(4);
             MARG_MARK(5);
             // A' = Arr - Z'Z, b' = brr - Z' zb: held in registers until every read of the packed A is done, then written over it
+            // (only the lower triangle, folded into an (n + 1)-wide rectangle: rows R and n - 1 - R share a line; entry (j, i) is the same
+            // difference of the same products as (i, j), bit for bit, and is mirrored when the registers are written back)
             int q = 0;
-            for (int e = tid; e < n * n; e += MARG_NT, q++) {
-                const int i = e / n, j = e - i * n;
+            keep_sym = true;
+            for (int e = tid; e < ((n + 1) >> 1) * (n + 1); e += MARG_NT, q++) {
+                const int R = e / (n + 1), Cc = e - R * (n + 1);
+                const int i = (Cc <= R) ? R : n - 1 - R, j = (Cc <= R) ? Cc : Cc - R - 1;
                 double sv = Apk[pidx(m + i, m + j)];
                 int k = 0;
                 for (; k + 3 < m; k += 4) {      // four steps' loads in flight, the updates in the original order
@@ -1471,7 +1476,7 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((amdgpu_waves_per_eu(2,
                     for (int u = 0; u < 4; u++) sv -= za[u] * zb4[u];
                 }
                 for (; k < m; k++) sv -= Zl[k * zs + i] * Zl[k * zs + j];
-                keepA[q] = sv;
+                keepA[q] = sv;      // (the second half of the middle line of an odd n repeats entries of its first half: harmless duplicates)
             }
             if (tid < n) {
                 bprime = bv[m + tid];
@@ -1517,6 +1522,14 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((amdgpu_waves_per_eu(2,
         __syncthreads();   // every read of Vm / Apk is done: P and R2 can be overwritten
         {
             int q = 0;
+            if (keep_sym) {
+                for (int e = tid; e < ((n + 1) >> 1) * (n + 1); e += MARG_NT, q++) {
+                    const int R = e / (n + 1), Cc = e - R * (n + 1);
+                    const int i = (Cc <= R) ? R : n - 1 - R, j = (Cc <= R) ? Cc : Cc - R - 1;
+                    As[i * ldn + j] = keepA[q]; As[j * ldn + i] = keepA[q];
+                    out[MARG_OUT_AS + i * n + j] = keepA[q]; out[MARG_OUT_AS + j * n + i] = keepA[q];
+                }
+            } else
             for (int e = tid; e < n * n; e += MARG_NT, q++) {
                 const int i = e / n, j = e - i * n;
                 As[i * ldn + j] = keepA[q];
