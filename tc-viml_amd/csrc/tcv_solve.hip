@@ -39,8 +39,12 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 #define TCV_MARK(C, id)                                                                        \
     do {                                                                                       \
         const long long t_ = clock64();                                                        \
-        if ((C).tid == 0) ((lds_u *)((C).red + 40))[id] += (unsigned)(t_ - (C).t_last);       \
-        (C).t_last = t_;                                                                       \
+        if ((C).tid == 0) {      /* the previous mark's time stamp lives in LDS (red + 56), wherever that mark was taken */ \
+            typedef __attribute__((address_space(3))) long long lds_ll;                        \
+            lds_ll *last_ = (lds_ll *)((C).red + 56);                                          \
+            ((lds_u *)((C).red + 40))[id] += (unsigned)(t_ - *last_);                          \
+            *last_ = t_;                                                                       \
+        }                                                                                      \
     } while (0)
 #else
 #define TCV_MARK(C, id) do { } while (0)
@@ -160,13 +164,57 @@ __device__ __forceinline__ Ctx<NT> uniform_ctx(const Ctx<NT> &R) {
     C.cx_seq = __builtin_amdgcn_readfirstlane(R.cx_seq); C.cx_timeout = R.cx_timeout;
     return C;
 }
-#ifdef TCV_PROFILE
-#define TCV_CTX_LEAVE(R, C) do { (R).t_last = (C).t_last; } while (0)
-#else
-#define TCV_CTX_LEAVE(R, C) do { } while (0)
-#endif
-
 enum { SCR_HP = 8256, SCR_SQ = 16 * 225, SCR_LM = 1024 };      // the landmark/camera coupling store comes last: its size is per batch
+// The phase functions of the single-workgroup kernels take the context IN REGISTERS: seventeen scalars (25 dwords) as ordinary arguments,
+// from which everything else follows (the scratch vectors sit at fixed offsets behind v_s, the LDS vectors behind xs).  Passed by reference
+// the 79-dword Ctx was re-read from the stack frame at every entry -- 79 per-lane scratch loads per wavefront and call, ~60 calls per window
+// solve: as much L1 / L2 read traffic as everything else the kernel fetches, and a full memory wait in front of every phase.
+#define TCV_CTX_PARAMS cst_plan *aP_, cst_i *aip_, cst_d *adp_, cst_win *aW_, gbl_d *ascr_, gbl_d *aimu_, gbl_d *aspill_, gbl_d *aprof_, \
+                       lds_d *atiles_, lds_d *astage_, lds_d *axs_, int and_, int antd_, int antiles_, int astagecap_, int atid_, unsigned askip_
+#define TCV_CTX_ARGS(K) (K).P, (K).ip, (K).dp, (K).W, (K).v_s, (K).g_imublk, (K).g_spill, (K).prof, (K).tiles, (K).stage, (K).xs, (K).nd, (K).ntd, \
+                        (K).ntiles, (K).stage_cap, (K).tid, (K).skip
+#define TCV_CTX_FORWARD aP_, aip_, adp_, aW_, ascr_, aimu_, aspill_, aprof_, atiles_, astage_, axs_, and_, antd_, antiles_, astagecap_, atid_, askip_
+// global scratch behind v_s, LDS vectors behind xs: the ONE place that knows the layout (the kernels call these too)
+template <int NT>
+__device__ __forceinline__ void ctx_scratch_layout(Ctx<NT> &C, gbl_d *scr) {
+    C.v_s = scr; C.v_g = scr + SCR_NL; C.v_D = scr + 2 * SCR_NL; C.v_ghat = scr + 3 * SCR_NL; C.v_y = scr + 4 * SCR_NL;
+    C.v_p = scr + 5 * SCR_NL; C.v_rc = scr + 6 * SCR_NL; C.v_sd = scr + 7 * SCR_NL;
+    C.l_hll = scr + 8 * SCR_NL; C.l_gl = C.l_hll + SCR_LM; C.l_invk = C.l_gl + SCR_LM;
+    C.g_hp = C.l_invk + SCR_LM; C.g_pr = C.g_hp + SCR_HP; C.g_pdx = C.g_pr + 128;
+    C.g_sqrt = C.g_pdx + 128;
+    C.g_hcl = C.g_sqrt + SCR_SQ;
+}
+template <int NT>
+__device__ __forceinline__ void ctx_lds_layout(Ctx<NT> &C, lds_d *xs, int nxl, bool chain, int c_stage_cap) {
+    lds_d *p = xs;
+    C.xs = p; p += nxl;
+    C.xc = p; p += nxl;
+    C.sc = p; p += 176;
+    C.rc = p; C.sd = p + 88; p += 176;
+    C.ycam = p; p += 176;
+    C.invdiag = p; C.gcam = p; p += 176;
+    C.red = p; p += 64;
+    C.flag = (lds_i *)(C.red + 62);   // red[] uses at most 5 * NT/64 = 40 doubles; 40..55 hold the profile build's counters, 56 its last time stamp
+    C.hd = p;                         // chain mode only (112 doubles)
+    C.area = chain ? C.stage + c_stage_cap : p;
+}
+template <int NT>
+__device__ __forceinline__ Ctx<NT> ctx_from_args(TCV_CTX_PARAMS) {
+    Ctx<NT> C;
+    C.P = uni_ptr(aP_); C.ip = uni_ptr(aip_); C.dp = uni_ptr(adp_); C.W = uni_ptr(aW_);
+    C.g_imublk = uni_ptr(aimu_); C.g_spill = uni_ptr(aspill_); C.prof = uni_ptr(aprof_); C.t_last = 0;
+    C.tiles = uni_ptr(atiles_); C.stage = uni_ptr(astage_);
+    C.nd = __builtin_amdgcn_readfirstlane(and_); C.ntd = __builtin_amdgcn_readfirstlane(antd_);
+    C.ntiles = __builtin_amdgcn_readfirstlane(antiles_); C.stage_cap = __builtin_amdgcn_readfirstlane(astagecap_);
+    C.tid = atid_;
+    C.skip = __builtin_amdgcn_readfirstlane(askip_);
+    ctx_scratch_layout<NT>(C, uni_ptr(ascr_));
+    cst_plan &P = *C.P;
+    ctx_lds_layout<NT>(C, uni_ptr(axs_), (P.nx + P.nland + 1) & ~1, P.chain != 0, P.c_stage_cap);
+    C.cx_ctl = nullptr; C.cx_x = nullptr; C.cx_exp = nullptr; C.cx_h = 0; C.cx_exp_stride = 0; C.cx_seq = 0; C.cx_timeout = 0;
+    return C;
+}
+
 enum {
     SCR_TOTAL = 8 * SCR_NL + 3 * SCR_LM + SCR_HP + 2 * 128 + SCR_SQ      // + hcl capacity (tcv_batch_create)
 };
@@ -821,8 +869,8 @@ __device__ __forceinline__ double prior_col_lds(const lds_d *J0, const lds_d *pr
 // kappa_l = hll + mu * clamp(s_l^2 hll) / s_l^2 is the landmark pivot of the Jacobi-scaled,
 // mu-regularised system expressed in unscaled units (DoglegStrategy + SchurEliminator restated).
 template <int NT, bool CHAIN>
-__device__ __noinline__ double linearize(Ctx<NT> &Cr, const lds_d *x, bool first, bool assemble, double mu) {
-    Ctx<NT> C = uniform_ctx<NT>(Cr);
+__device__ __noinline__ double linearize(TCV_CTX_PARAMS, const lds_d *x, bool first, bool assemble, double mu) {
+    Ctx<NT> C = ctx_from_args<NT>(TCV_CTX_FORWARD);
     cst_plan &P = *C.P;
     const int tid = C.tid;
     cst_i *ip = C.ip;
@@ -977,7 +1025,6 @@ __device__ __noinline__ double linearize(Ctx<NT> &Cr, const lds_d *x, bool first
     const double cost = block_sum<NT>(cost_acc, C.red, tid);
     __syncthreads();
     TCV_MARK(C, PH_COST_RED);
-    TCV_CTX_LEAVE(Cr, C);
     return cost;
 }
 
@@ -1134,7 +1181,6 @@ __device__ __noinline__ double linearize_coop(Ctx<NT> &Cr, const lds_d *x, bool 
     __syncthreads();
     COOP_MARK(C, 16, 6);
     TCV_MARK(C, PH_COST_RED);
-    TCV_CTX_LEAVE(Cr, C);
     return cost;
 }
 
@@ -1366,8 +1412,8 @@ __device__ __forceinline__ void update_tile2(lds_d *tiles, int I0, int J0, int I
 // wave 0 updates tile (K+1, K+1) first and factorises it, so the serial pivot chain of the next diagonal
 // tile hides behind the matrix-core work.  Two barriers per tile column.
 template <int NT, bool MFMA>
-__device__ __noinline__ bool chol_tiles(Ctx<NT> &Cr, int nt, int nc) {
-    Ctx<NT> C = uniform_ctx<NT>(Cr);
+__device__ __noinline__ bool chol_tiles(TCV_CTX_PARAMS, int nt, int nc) {
+    Ctx<NT> C = ctx_from_args<NT>(TCV_CTX_FORWARD);
     const int tid = C.tid, lane = tid & 63, wave = tid >> 6;
     constexpr int NW = NT / 64, NG = NT / 16;
     lds_d *tiles = C.tiles;
@@ -1449,8 +1495,8 @@ __device__ __noinline__ bool chol_tiles(Ctx<NT> &Cr, int nt, int nc) {
 // 16 lanes that own its columns solve the 16 x 16 triangular system among themselves (v_readlane broadcasts), publish
 // y_K, and after ONE barrier every thread folds tile row K into its own t_c.
 template <int NT>
-__device__ __noinline__ void back_subst(Ctx<NT> &Cr, int nc) {
-    Ctx<NT> C = uniform_ctx<NT>(Cr);
+__device__ __noinline__ void back_subst(TCV_CTX_PARAMS, int nc) {
+    Ctx<NT> C = ctx_from_args<NT>(TCV_CTX_FORWARD);
     const int tid = C.tid, lane = tid & 63;
     lds_d *tiles = C.tiles, *y = C.ycam;
     const int c = tid, Kc = c >> 4, cc = c & 15;
@@ -1715,8 +1761,8 @@ __device__ __forceinline__ void chain_mfma_update(const Ctx<NT> &C, const lds_d 
 #endif
 struct ChainOut { double q; bool ok; };
 template <int NT>
-__device__ __noinline__ ChainOut chain_forward(Ctx<NT> &Cr, double mu) {
-    Ctx<NT> C = uniform_ctx<NT>(Cr);
+__device__ __noinline__ ChainOut chain_forward(TCV_CTX_PARAMS, double mu) {
+    Ctx<NT> C = ctx_from_args<NT>(TCV_CTX_FORWARD);
     static_assert(NT >= 256, "chain layout: four wavefronts (column owners on waves 0-1, matrix cores on 0-2, T pipeline on 3)");
     cst_plan &P = *C.P;
     const int tid = C.tid, lane = tid & 63, wave = tid >> 6, npp = P.npp, ne = P.n_e;
@@ -1868,8 +1914,8 @@ __device__ __forceinline__ void chain_products(Ctx<NT> &C) {
     __syncthreads();
 }
 template <int NT>
-__device__ __noinline__ bool chain_backward(Ctx<NT> &Cr) {
-    Ctx<NT> C = uniform_ctx<NT>(Cr);
+__device__ __noinline__ bool chain_backward(TCV_CTX_PARAMS) {
+    Ctx<NT> C = ctx_from_args<NT>(TCV_CTX_FORWARD);
     cst_plan &P = *C.P;
     const int lane = C.tid & 63, ne = P.n_e;
     const ChainLds L = chain_lds<NT>(C);
@@ -1908,8 +1954,8 @@ __device__ __noinline__ bool chain_backward(Ctx<NT> &Cr) {
 // On return (true): v_y = y (scaled space, camera then landmarks), v_D, v_ghat set, scal = {gg, q}.
 struct FinOut { double gg, q; bool ok; };
 template <int NT, bool MFMA, bool CHAIN>
-__device__ __noinline__ FinOut finalize_and_solve(Ctx<NT> &Cr, bool first, double mu) {
-    Ctx<NT> C = uniform_ctx<NT>(Cr);
+__device__ __noinline__ FinOut finalize_and_solve(TCV_CTX_PARAMS, bool first, double mu) {
+    Ctx<NT> C = ctx_from_args<NT>(TCV_CTX_FORWARD);
     cst_plan &P = *C.P;
     const int tid = C.tid, nc = P.nc, L = P.nland;
     const int nd = C.nd;      // dimension of the dense system in the tiles: nc, or npp in chain mode
@@ -2014,14 +2060,14 @@ __device__ __noinline__ FinOut finalize_and_solve(Ctx<NT> &Cr, bool first, doubl
     TCV_MARK(C, PH_FIN_PASS);
     if (CHAIN) {
         if (ABL(C, AB_CHAIN_FWD)) {
-            const ChainOut co = chain_forward<NT>(C, mu);
+            const ChainOut co = chain_forward<NT>(TCV_CTX_ARGS(C), mu);
             if (!co.ok) return out;
             out.q += co.q;
         }
         TCV_MARK(C, PH_CHAIN_FWD);
     }
-    if (ABL(C, AB_CHOL) && !chol_tiles<NT, MFMA>(C, C.ntd, nd)) return out;
-    if (ABL(C, AB_BACK)) back_subst<NT>(C, nd);
+    if (ABL(C, AB_CHOL) && !chol_tiles<NT, MFMA>(TCV_CTX_ARGS(C), C.ntd, nd)) return out;
+    if (ABL(C, AB_BACK)) back_subst<NT>(TCV_CTX_ARGS(C), nd);
     TCV_MARK(C, PH_BACK);
     // landmarks: y_l = (gl - Hcl' (s o y_c)) / (s_l kappa_l)
     bool bad = false;
@@ -2034,7 +2080,7 @@ __device__ __noinline__ FinOut finalize_and_solve(Ctx<NT> &Cr, bool first, doubl
     // waves back-substitute the landmarks, which only meet pose-kind blocks
     if (CHAIN && ABL(C, AB_CHAIN_BWD) && ABL(C, AB_CHAIN_FWD)) chain_products<NT>(C);
     const int l_first = CHAIN ? tid - 64 : tid, l_step = CHAIN ? NT - 64 : NT;
-    if (CHAIN && tid < 64 && ABL(C, AB_CHAIN_BWD) && ABL(C, AB_CHAIN_FWD)) { if (!chain_backward<NT>(C)) bad = true; }
+    if (CHAIN && tid < 64 && ABL(C, AB_CHAIN_BWD) && ABL(C, AB_CHAIN_FWD)) { if (!chain_backward<NT>(TCV_CTX_ARGS(C))) bad = true; }
     if ((!CHAIN || tid >= 64) && ABL(C, AB_LM_BACK)) {
         cst_i *lm = ip + P.o_lm, *sp = ip + P.o_lmslotptr, *so = ip + P.o_lmslot;
         for (int l = l_first; l < L; l += l_step) {
@@ -2062,15 +2108,14 @@ __device__ __noinline__ FinOut finalize_and_solve(Ctx<NT> &Cr, bool first, doubl
 #ifdef TCV_ABLATE
     if (ABL_FORCE(C)) anybad = 0;
 #endif
-    TCV_CTX_LEAVE(Cr, C);
     out.ok = anybad == 0;
     return out;
 }
 
 // ---- ambient-space helpers ---------------------------------------------------------------------------
 template <int NT>
-__device__ __noinline__ void apply_plus(Ctx<NT> &Cr, const lds_d *x, const gbl_d *delta_scaled, const gbl_d *s, lds_d *xo) {
-    Ctx<NT> C = uniform_ctx<NT>(Cr);
+__device__ __noinline__ void apply_plus(TCV_CTX_PARAMS, const lds_d *x, const gbl_d *delta_scaled, const gbl_d *s, lds_d *xo) {
+    Ctx<NT> C = ctx_from_args<NT>(TCV_CTX_FORWARD);
     // delta = step o scale; per block Plus (pose_local_parameterization.cpp:3-19) or x + delta
     cst_plan &P = *C.P;
     cst_i *blk = C.ip + P.o_blk;
@@ -2096,8 +2141,8 @@ __device__ __noinline__ void apply_plus(Ctx<NT> &Cr, const lds_d *x, const gbl_d
 
 struct Norms2 { double xn2, dn2; };      // returned in registers: reference outputs of a non-inlined function live in scratch memory
 template <int NT>
-__device__ __noinline__ Norms2 ambient_norms(Ctx<NT> &Cr, const lds_d *x, const lds_d *xo) {
-    Ctx<NT> C = uniform_ctx<NT>(Cr);
+__device__ __noinline__ Norms2 ambient_norms(TCV_CTX_PARAMS, const lds_d *x, const lds_d *xo) {
+    Ctx<NT> C = ctx_from_args<NT>(TCV_CTX_FORWARD);
     cst_plan &P = *C.P;
     cst_i *blk = C.ip + P.o_blk;
     double acc[2] = {0.0, 0.0};
@@ -2122,8 +2167,8 @@ __device__ __noinline__ Norms2 ambient_norms(Ctx<NT> &Cr, const lds_d *x, const 
 }
 
 template <int NT>
-__device__ __noinline__ double grad_max(Ctx<NT> &Cr) {
-    Ctx<NT> C = uniform_ctx<NT>(Cr);
+__device__ __noinline__ double grad_max(TCV_CTX_PARAMS) {
+    Ctx<NT> C = ctx_from_args<NT>(TCV_CTX_FORWARD);
     double m = 0;
     for (int i = C.tid; i < C.P->nc; i += NT) m = fmax(m, fabs(C.gcam[i]));
     for (int i = C.tid; i < C.P->nland; i += NT) m = fmax(m, fabs(C.v_g[C.P->nc + i]));
@@ -2204,18 +2249,11 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((CHAIN 
         C.cx_h = A.coop_h; C.cx_exp_stride = A.coop_exp_stride; C.cx_timeout = A.coop_timeout;
     }
     gbl_d *scr = (gbl_d *)A.scratch + (size_t)slot * A.scratch_stride;
-    C.v_s = scr; C.v_g = scr + SCR_NL; C.v_D = scr + 2 * SCR_NL; C.v_ghat = scr + 3 * SCR_NL; C.v_y = scr + 4 * SCR_NL;
-    C.v_p = scr + 5 * SCR_NL; C.v_rc = scr + 6 * SCR_NL; C.v_sd = scr + 7 * SCR_NL;
-    C.l_hll = scr + 8 * SCR_NL; C.l_gl = C.l_hll + SCR_LM; C.l_invk = C.l_gl + SCR_LM;
-    C.g_hp = C.l_invk + SCR_LM; C.g_pr = C.g_hp + SCR_HP; C.g_pdx = C.g_pr + 128;
-    C.g_sqrt = C.g_pdx + 128;
-    C.g_hcl = C.g_sqrt + SCR_SQ;
+    ctx_scratch_layout<NT>(C, scr);
     C.prof = A.prof ? (gbl_d *)A.prof + (size_t)slot * 32 : nullptr;
     C.t_last = 0;
     C.skip = (unsigned)A.pad2;
-#ifdef TCV_PROFILE
-    C.t_last = clock64();
-#endif
+    C.g_imublk = nullptr; C.g_spill = nullptr;
 
     for (int win = slot; win < A.nwin; win += wstride) {
         cst_win *W = (cst_win *)A.win + win;
@@ -2241,20 +2279,12 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((CHAIN 
             C.stage_cap = (C.ntiles - pp_tiles) << 8;
             p = lds + (C.ntiles << 8);
         }
-        C.xs = p; p += nxl;
-        C.xc = p; p += nxl;
-        C.sc = p; p += 176;
-        C.rc = p; C.sd = p + 88; p += 176;
-        C.ycam = p; p += 176;
-        C.invdiag = p; C.gcam = p; p += 176;
-        C.red = p; p += 64;
-        C.flag = (lds_i *)(C.red + 62);   // red[] uses at most 5 * NT/64 = 40 doubles; 40..55 hold the profile build's counters
+        ctx_lds_layout<NT>(C, p, nxl, CHAIN, P.c_stage_cap);      // xs, xc, sc, rc | sd, ycam, invdiag = gcam, red, flag, hd, area
 #ifdef TCV_PROFILE
         if (tid < PH_COUNT) ((lds_u *)(C.red + 40))[tid] = 0u;
+        if (tid == 0) { typedef __attribute__((address_space(3))) long long lds_ll; *(lds_ll *)(C.red + 56) = clock64(); }
         __syncthreads();
 #endif
-        C.hd = p;                         // chain mode only (112 doubles)
-        C.area = CHAIN ? C.stage + P.c_stage_cap : p;
         typedef __attribute__((address_space(1))) DevSummary gbl_sum;
         gbl_sum *S = (gbl_sum *)A.summary + win;
         // C lives in the stack frame (the phase functions take it by reference); the kernel's own accesses go through a copy whose
@@ -2321,7 +2351,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((CHAIN 
         double radius = 1e4, mu = 1e-8, lin_mu = 1e-8;
         bool reuse = false, tiles_valid = true;
         int invalid = 0, termination = 0, nrec = 1, status = 0;
-        double cost = uni_d(COOP ? linearize_coop<NT>(C, K.xs, true, true, mu, win) : linearize<NT, CHAIN>(C, K.xs, true, true, mu));
+        double cost = uni_d(COOP ? linearize_coop<NT>(C, K.xs, true, true, mu, win) : linearize<NT, CHAIN>(TCV_CTX_ARGS(K), K.xs, true, true, mu));
         bool first = true;
         const double initial_cost = cost;
         if (tid == 0) { S->cost[0] = cost; S->step_ok[0] = 1; S->dogleg_case[0] = 0; S->radius[0] = radius; S->mu[0] = mu; }
@@ -2329,12 +2359,12 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((CHAIN 
         // |x| and |x+ - x| in ambient space feed the parameter-tolerance test only: with the convergence tests off (fixed iterations) nothing
         // reads them, and the three reductions per iteration are not run
         double xn2 = 0.0, dn2 = 0.0;
-        if (!fixed) { const Norms2 nn = ambient_norms<NT>(C, K.xs, K.xs); xn2 = uni_d(nn.xn2); dn2 = uni_d(nn.dn2); }
+        if (!fixed) { const Norms2 nn = ambient_norms<NT>(TCV_CTX_ARGS(K), K.xs, K.xs); xn2 = uni_d(nn.xn2); dn2 = uni_d(nn.dn2); }
         double x_norm = uni_d(sqrt(xn2));
         bool done = false;
         if (COOP && C.cx_seq < 0) { done = true; status = -9; termination = 5; }      // the helpers did not answer (timeout)
         if (!fixed && !done) {
-            const double gm = grad_max<NT>(C);
+            const double gm = grad_max<NT>(TCV_CTX_ARGS(K));
             if (gm <= 1e-10) { termination = 1; done = true; }
         }
         int it = 0;
@@ -2355,11 +2385,11 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((CHAIN 
                 ls_ok = false;
                 while (mu < 1.0) {
                     if (!tiles_valid || lin_mu != mu) {
-                        if (COOP) (void)linearize_coop<NT>(C, K.xs, false, true, mu, win); else (void)linearize<NT, CHAIN>(C, K.xs, false, true, mu);
+                        if (COOP) (void)linearize_coop<NT>(C, K.xs, false, true, mu, win); else (void)linearize<NT, CHAIN>(TCV_CTX_ARGS(K), K.xs, false, true, mu);
                         if (COOP && C.cx_seq < 0) break;
                         lin_mu = mu;
                     }
-                    const FinOut fo = finalize_and_solve<NT, MFMA, CHAIN>(C, first, mu);
+                    const FinOut fo = finalize_and_solve<NT, MFMA, CHAIN>(TCV_CTX_ARGS(K), first, mu);
                     const bool ok = fo.ok;
                     gg = uni_d(fo.gg); q = uni_d(fo.q);
                     first = false;
@@ -2431,18 +2461,18 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((CHAIN 
             TCV_MARK(C, PH_DOGLEG);
             for (int i = tid; i < nl; i += NT) K.v_p[i] = ca * (K.v_ghat[i] / K.v_D[i]) + cb * K.v_y[i];
             __syncthreads();
-            if (ABL(C, AB_PLUS)) apply_plus<NT>(C, K.xs, K.v_p, K.v_s, K.xc);
+            if (ABL(C, AB_PLUS)) apply_plus<NT>(TCV_CTX_ARGS(K), K.xs, K.v_p, K.v_s, K.xc);
             if (A.first_delta && it == 1)
                 for (int i = tid; i < nl; i += NT) A.first_delta[(size_t)win * A.delta_stride + i] = K.v_p[i] * K.v_s[i];
             __syncthreads();
             TCV_MARK(C, PH_PLUS);
             const double mu_next = uni_d(fmax(1e-8, 2.0 * mu / 10.0));
             const bool want_asm = (it < max_it) || !fixed;
-            const double cost_c = uni_d(COOP ? linearize_coop<NT>(C, K.xc, false, want_asm, mu_next, win) : linearize<NT, CHAIN>(C, K.xc, false, want_asm, mu_next));
+            const double cost_c = uni_d(COOP ? linearize_coop<NT>(C, K.xc, false, want_asm, mu_next, win) : linearize<NT, CHAIN>(TCV_CTX_ARGS(K), K.xc, false, want_asm, mu_next));
             if (COOP && C.cx_seq < 0) { status = -9; termination = 5; break; }
             tiles_valid = want_asm;
             lin_mu = mu_next;
-            if (!fixed && ABL(C, AB_NORMS)) { const Norms2 nn = ambient_norms<NT>(C, K.xs, K.xc); xn2 = uni_d(nn.xn2); dn2 = uni_d(nn.dn2); }
+            if (!fixed && ABL(C, AB_NORMS)) { const Norms2 nn = ambient_norms<NT>(TCV_CTX_ARGS(K), K.xs, K.xc); xn2 = uni_d(nn.xn2); dn2 = uni_d(nn.dn2); }
             TCV_MARK(C, PH_NORMS);
 #ifdef TCV_ABLATE
             const double rho = ABL_ACCEPT(C) ? 1.0 : (cost - cost_c) / model_cost_change;
@@ -2465,7 +2495,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((CHAIN 
             }
             if (rho > 1e-3) {
                 for (int i = tid; i < P.nx + L; i += NT) K.xs[i] = K.xc[i];
-                if (!fixed && ABL(C, AB_NORMS)) { const Norms2 nn = ambient_norms<NT>(C, K.xc, K.xc); xn2 = uni_d(nn.xn2); dn2 = uni_d(nn.dn2); }
+                if (!fixed && ABL(C, AB_NORMS)) { const Norms2 nn = ambient_norms<NT>(TCV_CTX_ARGS(K), K.xc, K.xc); xn2 = uni_d(nn.xn2); dn2 = uni_d(nn.dn2); }
                 x_norm = uni_d(sqrt(xn2));
                 cost = cost_c;
                 if (rho < 0.25) radius = uni_d(radius * 0.5);
@@ -2475,7 +2505,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((CHAIN 
                 if (tid == 0 && nrec < MAX_TRACE) { S->cost[nrec] = cost; S->step_ok[nrec] = 1; }
                 nrec++;
                 if (!fixed) {
-                    const double gm = grad_max<NT>(C);
+                    const double gm = grad_max<NT>(TCV_CTX_ARGS(K));
                     if (gm <= 1e-10) { termination = 1; break; }
                 }
             } else {
