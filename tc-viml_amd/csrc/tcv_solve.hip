@@ -1077,17 +1077,22 @@ __device__ __forceinline__ void coop_publish(const Ctx<NT> &C, const lds_d *x, i
 //   tiles / gradient / rhs and diagonal corrections: zero, then per chunk c the gathered value a_c (one addition per destination and
 //   chunk), then minus the Schur value s_c (the helper exports -s_c = 0 - s_c exactly), then the prior's J0'r, the IMU blocks colour by
 //   colour, the cached J0'J0;  cost: per thread its point and line costs chunk by chunk, then its prior row, then its IMU factor.
-// Returns NaN with Cr.cx_seq = -1 if the helpers did not answer.
+// Returns the cost and the sequence number of the request; cost NaN and seq = -1 if the helpers did not answer.  The context travels in
+// registers like in the other phase functions (TCV_CTX_PARAMS), the group's hand-off block as seven more arguments.
+struct CoopLin { double cost; int seq; };
 template <int NT>
-__device__ __noinline__ double linearize_coop(Ctx<NT> &Cr, const lds_d *x, bool first, bool assemble, double mu, int win) {
-    Ctx<NT> C = uniform_ctx<NT>(Cr);
+__device__ __noinline__ CoopLin linearize_coop(TCV_CTX_PARAMS, gbl_i *cx_ctl_, gbl_d *cx_x_, gbl_d *cx_exp_, int cx_h_, int cx_exp_stride_, int cx_seq_, long long cx_timeout_,
+                                               const lds_d *x, bool first, bool assemble, double mu, int win) {
+    Ctx<NT> C = ctx_from_args<NT>(TCV_CTX_FORWARD);
+    C.cx_ctl = (gbl_i *)uni_ptr((gbl_d *)cx_ctl_); C.cx_x = uni_ptr(cx_x_); C.cx_exp = uni_ptr(cx_exp_);
+    C.cx_h = __builtin_amdgcn_readfirstlane(cx_h_); C.cx_exp_stride = __builtin_amdgcn_readfirstlane(cx_exp_stride_);
+    C.cx_seq = __builtin_amdgcn_readfirstlane(cx_seq_); C.cx_timeout = cx_timeout_;
     cst_plan &P = *C.P;
     const int tid = C.tid;
     cst_i *ip = C.ip;
     cst_d *dp = C.dp;
     const int L = P.nland, nx = P.nx;
     const int seq = C.cx_seq + 1;
-    Cr.cx_seq = seq;
     COOP_MARK(C, 16, 1); COOP_MARK(C, 17, seq);
     coop_publish<NT>(C, x, nx + L, mu, (first ? COOP_CMD_FIRST : 0) | (assemble ? COOP_CMD_ASSEMBLE : 0), win, seq);
     COOP_MARK(C, 16, 2);
@@ -1135,8 +1140,8 @@ __device__ __noinline__ double linearize_coop(Ctx<NT> &Cr, const lds_d *x, bool 
     if (!coop_wait_helpers<NT>(C, seq)) {
         if (tid == 0) coop_store(C.cx_ctl + COOP_CTL_ABORT, 1);
         COOP_MARK(C, 16, 9);
-        Cr.cx_seq = -1;
-        return __builtin_nan("");
+        CoopLin bad; bad.cost = __builtin_nan(""); bad.seq = -1;
+        return bad;
     }
     TCV_MARK(C, PH_VIS_GATHER);
     COOP_MARK(C, 16, 5);
@@ -1181,7 +1186,8 @@ __device__ __noinline__ double linearize_coop(Ctx<NT> &Cr, const lds_d *x, bool 
     __syncthreads();
     COOP_MARK(C, 16, 6);
     TCV_MARK(C, PH_COST_RED);
-    return cost;
+    CoopLin out; out.cost = cost; out.seq = seq;
+    return out;
 }
 
 // A helper workgroup of group g: serves the master's linearisation requests until it is told to leave.  Its LDS is carved like the
@@ -2351,7 +2357,9 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((CHAIN 
         double radius = 1e4, mu = 1e-8, lin_mu = 1e-8;
         bool reuse = false, tiles_valid = true;
         int invalid = 0, termination = 0, nrec = 1, status = 0;
-        double cost = uni_d(COOP ? linearize_coop<NT>(C, K.xs, true, true, mu, win) : linearize<NT, CHAIN>(TCV_CTX_ARGS(K), K.xs, true, true, mu));
+#define TCV_COOP_LIN(X, FIRST, ASM, MU) coop_lin(linearize_coop<NT>(TCV_CTX_ARGS(K), C.cx_ctl, C.cx_x, C.cx_exp, C.cx_h, C.cx_exp_stride, C.cx_seq, C.cx_timeout, X, FIRST, ASM, MU, win))
+        auto coop_lin = [&](const CoopLin &r) -> double { C.cx_seq = __builtin_amdgcn_readfirstlane(r.seq); return r.cost; };      // the master's sequence number lives in the kernel
+        double cost = uni_d(COOP ? TCV_COOP_LIN(K.xs, true, true, mu) : linearize<NT, CHAIN>(TCV_CTX_ARGS(K), K.xs, true, true, mu));
         bool first = true;
         const double initial_cost = cost;
         if (tid == 0) { S->cost[0] = cost; S->step_ok[0] = 1; S->dogleg_case[0] = 0; S->radius[0] = radius; S->mu[0] = mu; }
@@ -2385,7 +2393,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((CHAIN 
                 ls_ok = false;
                 while (mu < 1.0) {
                     if (!tiles_valid || lin_mu != mu) {
-                        if (COOP) (void)linearize_coop<NT>(C, K.xs, false, true, mu, win); else (void)linearize<NT, CHAIN>(TCV_CTX_ARGS(K), K.xs, false, true, mu);
+                        if (COOP) (void)TCV_COOP_LIN(K.xs, false, true, mu); else (void)linearize<NT, CHAIN>(TCV_CTX_ARGS(K), K.xs, false, true, mu);
                         if (COOP && C.cx_seq < 0) break;
                         lin_mu = mu;
                     }
@@ -2468,7 +2476,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((CHAIN 
             TCV_MARK(C, PH_PLUS);
             const double mu_next = uni_d(fmax(1e-8, 2.0 * mu / 10.0));
             const bool want_asm = (it < max_it) || !fixed;
-            const double cost_c = uni_d(COOP ? linearize_coop<NT>(C, K.xc, false, want_asm, mu_next, win) : linearize<NT, CHAIN>(TCV_CTX_ARGS(K), K.xc, false, want_asm, mu_next));
+            const double cost_c = uni_d(COOP ? TCV_COOP_LIN(K.xc, false, want_asm, mu_next) : linearize<NT, CHAIN>(TCV_CTX_ARGS(K), K.xc, false, want_asm, mu_next));
             if (COOP && C.cx_seq < 0) { status = -9; termination = 5; break; }
             tiles_valid = want_asm;
             lin_mu = mu_next;
