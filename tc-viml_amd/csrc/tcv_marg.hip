@@ -351,7 +351,7 @@ __device__ __forceinline__ void eig_refine(const lds_d *de, lds_d *lam, int n, i
 }
 // dv, e2: the tridiagonal; de: 2 n doubles of workspace (16-byte aligned), ctab: 257 ints.  gu: upper Gershgorin bound (widened).
 template <int NT>
-__device__ __noinline__ void eig_values_above_eps(const lds_d *dv_, const lds_d *e2_, lds_d *de_, lds_i *ctab_, lds_d *lam_, int n_, double gu_, double tnorm_, int tid) {
+__device__ __noinline__ __attribute__((disable_tail_calls)) void eig_values_above_eps(const lds_d *dv_, const lds_d *e2_, lds_d *de_, lds_i *ctab_, lds_d *lam_, int n_, double gu_, double tnorm_, int tid) {
     const lds_d *dv = uni_lds<1>(dv_), *e2 = uni_lds<1>(e2_);
     lds_d *de = uni_lds<1>(de_), *lam = uni_lds<1>(lam_);
     lds_i *ctab = uni_lds<1>(ctab_);
@@ -604,7 +604,9 @@ __device__ __noinline__ void eig_backtransform_wy(const lds_d *Hq_, lds_d *Z_, c
 
 __device__ __forceinline__ double rank2(double a, double vr, double wc, double wr, double vc) { return a - (vr * wc + wr * vc); }
 template <int NT>
-__device__ __noinline__ bool sym_eig_tridiag(lds_d *A_, lds_d *Hq_, lds_d *sm_, lds_d *lam_, int n_, int ld_, int tid, gbl_d *dbg, int flags_) {
+// (disable_tail_calls on every function that calls a non-inlined one: with the IR `tail` marker on a call the callee saves and restores
+// every callee-saved VGPR it touches -- up to 112 scratch stores and loads per call; without it the callees save nothing, tcv_solve.hip)
+__device__ __noinline__ __attribute__((disable_tail_calls)) bool sym_eig_tridiag(lds_d *A_, lds_d *Hq_, lds_d *sm_, lds_d *lam_, int n_, int ld_, int tid, gbl_d *dbg, int flags_) {
     lds_d *A = uni_lds<2>(A_), *Hq = uni_lds<2>(Hq_), *sm = uni_lds<2>(sm_), *lam = uni_lds<2>(lam_);
     const int n = uni_i<2>(n_), ld = uni_i<2>(ld_), flags = uni_i<2>(flags_);
     const bool old_search = (flags & 1) != 0;
@@ -921,7 +923,7 @@ __device__ __noinline__ bool sym_eig_tridiag(lds_d *A_, lds_d *Hq_, lds_d *sm_, 
 #define MARG_MARK(id) do { } while (0)
 #endif
 template <int MARG_NT>
-__global__ void __launch_bounds__(MARG_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) marg_kernel(MargArgs Aarg) {
+__global__ void __launch_bounds__(MARG_NT) __attribute__((disable_tail_calls)) __attribute__((amdgpu_waves_per_eu(2, 2))) marg_kernel(MargArgs Aarg) {
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
     lds_d *lds = (lds_d *)lds_raw;
     const int tid = threadIdx.x;

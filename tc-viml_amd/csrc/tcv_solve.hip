@@ -1960,7 +1960,10 @@ __device__ __noinline__ bool chain_backward(TCV_CTX_PARAMS) {
 // On return (true): v_y = y (scaled space, camera then landmarks), v_D, v_ghat set, scal = {gg, q}.
 struct FinOut { double gg, q; bool ok; };
 template <int NT, bool MFMA, bool CHAIN>
-__device__ __noinline__ FinOut finalize_and_solve(TCV_CTX_PARAMS, bool first, double mu) {
+// (disable_tail_calls, here and on the kernels: a call whose arguments are all values gets the IR `tail` marker, and LLVM's inter-procedural
+// register allocation then makes every callee save the callee-saved VGPRs it touches -- 147 scratch stores and 134 loads per call of
+// linearize, +1.2 GB of scratch traffic per launch; without the marker the callees save nothing and the caller keeps what it needs)
+__device__ __noinline__ __attribute__((disable_tail_calls)) FinOut finalize_and_solve(TCV_CTX_PARAMS, bool first, double mu) {
     Ctx<NT> C = ctx_from_args<NT>(TCV_CTX_FORWARD);
     cst_plan &P = *C.P;
     const int tid = C.tid, nc = P.nc, L = P.nland;
@@ -2202,7 +2205,7 @@ template <int NT, bool MFMA, bool CHAIN, bool COOP = false>
 #else
 #define TCV_CHAIN_WAVES 2
 #endif
-__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((CHAIN && !COOP) ? TCV_CHAIN_WAVES : 1, COOP ? 1 : (CHAIN ? TCV_CHAIN_WAVES : 8)))) solve_kernel(SolveArgs A) {
+__global__ void __launch_bounds__(NT) __attribute__((disable_tail_calls)) __attribute__((amdgpu_waves_per_eu((CHAIN && !COOP) ? TCV_CHAIN_WAVES : 1, COOP ? 1 : (CHAIN ? TCV_CHAIN_WAVES : 8)))) solve_kernel(SolveArgs A) {
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
     lds_d *lds = (lds_d *)lds_raw;
     int tid = threadIdx.x;
