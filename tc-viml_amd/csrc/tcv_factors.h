@@ -218,7 +218,10 @@ TCV_HD int imu_sqrt_info(const double *cov, double *S /*225 row-major*/, double 
 // 16-aligned group inside one wavefront; every element goes through the identical sequence of IEEE
 // operations, so the result is bit-identical to the serial routine and to the CPU oracle).
 // a, inv: 225 doubles each in LDS, private to the group.  Returns 0, or -1 if cov^-1 is not positive definite.
-__device__ __forceinline__ int imu_sqrt_info_group(const double *cov, double *S, double *a, double *inv, int lane) {
+// (CP / SP / LP: pointer types of cov, S and of the LDS workspace -- address-space pointers in the kernels: through generic pointers every
+// workspace access was a FLAT instruction with both memory counters to wait for)
+template <class CP, class SP, class LP>
+__device__ __forceinline__ int imu_sqrt_info_group(CP cov, SP S, LP a, LP inv, int lane) {
     TCV_NO_CONTRACT
 #define TCV_GFENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
     int perm = lane;   // lane i holds perm[i]

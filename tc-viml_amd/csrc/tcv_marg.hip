@@ -1117,7 +1117,7 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((disable_tail_calls)) _
             // sqrt_info: the one the solve of this batch computed from the same covariance with the same code (bit-identical), else here
             const bool s_given = Aarg.solve_sqrt != nullptr && H.sqrt_src >= 0 && H.n_imu == 1;
             if (s_given) { for (int i = tid; i < 225; i += MARG_NT) S[i] = ((const gbl_d *)Aarg.solve_sqrt)[(size_t)H.solve_window * 225 + i]; }
-            else if (tid < 16) (void)imu_sqrt_info_group((const double *)(dp + H.d_imu + f * IMU_CONST + IMU_COV), GEN(S), GEN(stage + 512), GEN(stage + 512 + 225), tid);
+            else if (tid < 16) (void)imu_sqrt_info_group(dp + H.d_imu + f * IMU_CONST + IMU_COV, S, stage + 512, stage + 512 + 225, tid);
             // the four parts of the raw residual / Jacobian on four wavefronts: lane 0 of waves 1..4, or (256 threads) lane 32 of waves 0..3
             constexpr int RW0 = MARG_NT >= 320 ? 1 : 0, RLANE = MARG_NT >= 320 ? 0 : 32;
             if ((tid & 63) == RLANE && (tid >> 6) >= RW0 && (tid >> 6) < RW0 + 4) {

@@ -2197,6 +2197,17 @@ __device__ __noinline__ double grad_max(TCV_CTX_PARAMS) {
 // and the helpers of a group land on the same XCD and hand their exports over through its L2, and the members of a group are close
 // together in dispatch order (a group is resident as a whole or waits as a whole; tcv_batch_solve additionally keeps the cooperative
 // launches in flight within the CU count and runs the same plan with one workgroup per window otherwise).
+// sqrt_info = LLT(cov^-1).matrixL()^T of every IMU factor of a window (imu_factor.h:64), one 16-lane group per factor
+template <int NT>
+__device__ __noinline__ void sqrt_info_all(cst_d *imu0_, int n_imu_, gbl_d *g_sqrt_, lds_d *lds_, int tid) {
+    cst_d *imu0 = uni_ptr(imu0_);
+    gbl_d *g_sqrt = uni_ptr(g_sqrt_);
+    lds_d *ws = uni_ptr(lds_);
+    const int n_imu = __builtin_amdgcn_readfirstlane(n_imu_);
+    for (int f = tid >> 4; f < n_imu; f += NT / 16)
+        (void)imu_sqrt_info_group(imu0 + f * IMU_CONST + IMU_COV, g_sqrt + f * 225, ws + f * 450, ws + f * 450 + 225, tid & 15);
+}
+
 template <int NT, bool MFMA, bool CHAIN, bool COOP = false>
 // (-DTCV_CHAIN_OCC1, developer build libtcv_hip_occ1.so: the chain kernel compiled for ONE wavefront per SIMD -- 512 registers, no spills -- to
 // measure what the 156 spilled registers of the production kernel cost at equal occupancy, profiles/r03_spill_ab.txt)
@@ -2305,10 +2316,9 @@ __global__ void __launch_bounds__(NT) __attribute__((disable_tail_calls)) __attr
         if (W->d_sqrt >= 0) {
             for (int i = tid; i < P.n_imu * 225; i += NT) C.g_sqrt[i] = K.dp[W->d_sqrt + i];
         } else {
-            // one 16-lane group per factor, workspace in the (still unused) tile region
-            for (int f = tid >> 4; f < P.n_imu; f += NT / 16)
-                (void)imu_sqrt_info_group((const double *)(K.dp + W->d_imu + f * IMU_CONST + IMU_COV), GEN(C.g_sqrt + f * 225), GEN(lds + f * 450),
-                                          GEN(lds + f * 450 + 225), tid & 15);
+            // one 16-lane group per factor, workspace in the (still unused) tile region; in a function of its own (registers of its own: inlined
+            // into the kernel its loops reloaded spilled values from scratch memory in every step)
+            sqrt_info_all<NT>(K.dp + W->d_imu, P.n_imu, C.g_sqrt, lds, tid);
         }
         __syncthreads();
         if (A.sqrt_out && W->d_sqrt < 0 && W->sqrt_export >= 0 && tid < 225) A.sqrt_out[(size_t)win * 225 + tid] = C.g_sqrt[W->sqrt_export * 225 + tid];
