@@ -526,6 +526,7 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
     if (int rc = device_ready()) return rc;
     const auto t_begin = std::chrono::steady_clock::now();
     tcv::prior_refresh_switch();
+    const tcv::HostOp host_op;      // host threads of this call: the granted cores shared with the batch-level calls running beside it
     tcv_batch *b = new tcv_batch();
     b->n = n;
     b->problems.assign(problems, problems + n);
@@ -563,7 +564,7 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
         coop_h = want;
     }
     auto pack_all = [&](int md, std::string &msg) -> int {
-        const int nth = std::max(1, std::min({n, 16, (int)std::thread::hardware_concurrency()}));
+        const int nth = host_op.threads(std::min(n, 16));
         std::vector<int> rcs(n, TCV_OK);
         std::vector<std::string> msgs(nth);
         auto work = [&](int t) {
@@ -648,7 +649,7 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
     double *h_dpool = (double *)host_staging_acquire(in_bytes);
     if (!h_dpool) { batch_free(b); set_error("hipHostMalloc (upload staging) failed"); return TCV_ERR_HIP; }
     {
-        const int nth = std::max(1, std::min({n, 16, (int)std::thread::hardware_concurrency()}));
+        const int nth = host_op.threads(std::min(n, 16));
         std::vector<int> rcs(n, TCV_OK);
         std::vector<std::string> msgs(nth);
         auto work = [&](int t) {
@@ -923,7 +924,8 @@ extern "C" int tcv_batch_get_prior(tcv_batch *b, int window, tcv_prior **out) {
 extern "C" int tcv_batch_get_priors(tcv_batch *b, tcv_prior **out, int n) {
     if (!b || !out || n != b->n) { set_error("batch_get_priors: n must be the batch size"); return TCV_ERR_INVALID; }
     for (int k = 0; k < n; k++) out[k] = nullptr;
-    const int nth = std::max(1, std::min({n / 16, 8, (int)std::thread::hardware_concurrency()}));
+    const tcv::HostOp host_op;
+    const int nth = host_op.threads(std::max(1, std::min(n / 16, 8)));
     std::vector<int> rcs(nth, TCV_OK);
     std::vector<std::string> msgs(nth);
     auto work = [&](int t) {

@@ -1857,7 +1857,7 @@ int tcv_marg_attach(tcv_batch *b, tcv_problem *const *marg_problems, double *con
         if (!marg_problems[w] || !marg_drop || !marg_drop[w]) { set_error("marginalisation problem / drop list missing"); return TCV_ERR_INVALID; }
     // the windows are packed by host threads, each into its own int / double pools (contiguous window ranges); the pools are then laid end
     // to end in pinned upload buffers and the headers' pool offsets shifted accordingly
-    const int nth = std::max(1, std::min({b->n / 8, 16, (int)std::thread::hardware_concurrency()}));
+    const int nth = tcv::host_threads(std::max(1, std::min(b->n / 8, 16)));      // (inside tcv_batch_create's HostOp)
     std::vector<std::vector<int>> It(nth);
     std::vector<std::vector<double>> Dt(nth);
     std::vector<int> rcs(nth, TCV_OK);

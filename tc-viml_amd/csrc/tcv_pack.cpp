@@ -1,6 +1,7 @@
 // Packer: ceres::Problem-shaped graph (estimator.cpp:1679-1886) -> device plan + window data
 // (tcv_packed.h).  Everything structural that the reference redoes per frame through
 // AddParameterBlock / AddResidualBlock pointer chasing is resolved here, once, into flat gather lists.
+#include <sched.h>
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -10,12 +11,47 @@
 #include <list>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <tuple>
 #include <unordered_map>
 
 #include "tcv_host.h"
 
 namespace tcv {
+
+// ---- host thread budget (HostOp, tcv_packed.h)
+static int host_core_grant() {
+    static int grant = 0;
+    if (grant > 0) return grant;
+    int g = (int)std::thread::hardware_concurrency();
+    if (g <= 0) g = 1;
+#if defined(__linux__)
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) g = std::min(g, c); }
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {      // cgroup v2: "<quota> <period>" or "max <period>"
+        char q[64]; long long per = 0;
+        if (fscanf(f, "%63s %lld", q, &per) == 2 && per > 0 && strcmp(q, "max") != 0) { const long long quota = atoll(q); if (quota > 0) g = std::min<long long>(g, std::max<long long>(1, (quota + per - 1) / per)); }
+        fclose(f);
+    } else if (FILE *f1 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {      // cgroup v1
+        long long quota = -1, per = 0;
+        if (fscanf(f1, "%lld", &quota) != 1) quota = -1;
+        fclose(f1);
+        if (FILE *f2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(f2, "%lld", &per) != 1) per = 0; fclose(f2); }
+        if (quota > 0 && per > 0) g = std::min<long long>(g, std::max<long long>(1, (quota + per - 1) / per));
+    }
+#endif
+    if (const char *e = getenv("TCV_HOST_THREADS")) { const int v = atoi(e); if (v > 0) g = v; }
+    grant = std::max(1, g);
+    return grant;
+}
+static std::atomic<int> g_host_ops{0};
+HostOp::HostOp() { g_host_ops.fetch_add(1, std::memory_order_relaxed); }
+HostOp::~HostOp() { g_host_ops.fetch_sub(1, std::memory_order_relaxed); }
+int host_threads(int want) {
+    const int active = std::max(1, g_host_ops.load(std::memory_order_relaxed));
+    return std::max(1, std::min(want, std::max(1, host_core_grant() / active)));
+}
+int HostOp::threads(int want) const { return host_threads(want); }
 
 // TCV_PRIOR_FULL: keep the exact-zero rows of the prior (A/B partner of the default).  The environment is read once per batch
 // (prior_refresh_switch), not once per window.

@@ -21,6 +21,11 @@ enum { KIND_EUCLID = 0, KIND_POSE = 1 };
 enum { TILE = 16, TILE_ELEMS = 256 };
 enum { LDS_DOUBLES = 20480 };  // 160 KiB per workgroup on gfx950
 int chain_lds_doubles();       // LDS doubles of a chain-mode workgroup (two per CU); tcv_pack.cpp
+// Host threads a batch-level operation may start: min(want, cores the process is GRANTED / batch-level operations running right now).
+// The grant is the cgroup CPU quota (cpu.max) or the affinity mask, not the machine's thread count: four callers packing 512 windows each on
+// sixteen threads under a 16-core quota used to run 64 threads into the scheduler's throttling.  tcv_pack.cpp
+struct HostOp { HostOp(); ~HostOp(); int threads(int want) const; };
+int host_threads(int want);      // the same share for code that runs inside somebody's HostOp (does not count as an operation of its own)
 bool prior_keep_zero_rows();   // developer A/B switch TCV_PRIOR_FULL (re-read by every tcv_batch_create / tcv_solve); tcv_pack.cpp
 void prior_refresh_switch();
 enum { MAX_TRACE = 64 };
