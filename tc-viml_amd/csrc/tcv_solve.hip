@@ -2424,7 +2424,8 @@ __global__ void __launch_bounds__(NT) __attribute__((disable_tail_calls)) __attr
                     // dot products for the dogleg interpolation and the model decrease
                     double acc[3] = {0.0, 0.0, 0.0};
                     for (int i = tid; i < nl; i += NT) {
-                        const double y = K.v_y[i], D = K.v_D[i], gh = K.v_ghat[i];
+                        // (the scratch vectors by their fixed offsets behind v_s: one base pointer live across the calls instead of five)
+                        const double y = (K.v_s + 4 * SCR_NL)[i], D = (K.v_s + 2 * SCR_NL)[i], gh = (K.v_s + 3 * SCR_NL)[i];
                         acc[0] += y * (gh * D);   // y' g_s
                         acc[1] += gh * D * y;     // ghat . (D y) = -ghat . gn
                         acc[2] += (D * y) * (D * y);
@@ -2480,11 +2481,11 @@ __global__ void __launch_bounds__(NT) __attribute__((disable_tail_calls)) __attr
             }
             invalid = 0;
             TCV_MARK(C, PH_DOGLEG);
-            for (int i = tid; i < nl; i += NT) K.v_p[i] = ca * (K.v_ghat[i] / K.v_D[i]) + cb * K.v_y[i];
+            for (int i = tid; i < nl; i += NT) (K.v_s + 5 * SCR_NL)[i] = ca * ((K.v_s + 3 * SCR_NL)[i] / (K.v_s + 2 * SCR_NL)[i]) + cb * (K.v_s + 4 * SCR_NL)[i];
             __syncthreads();
-            if (ABL(C, AB_PLUS)) apply_plus<NT>(TCV_CTX_ARGS(K), K.xs, K.v_p, K.v_s, K.xc);
+            if (ABL(C, AB_PLUS)) apply_plus<NT>(TCV_CTX_ARGS(K), K.xs, K.v_s + 5 * SCR_NL, K.v_s, K.xc);
             if (A.first_delta && it == 1)
-                for (int i = tid; i < nl; i += NT) A.first_delta[(size_t)win * A.delta_stride + i] = K.v_p[i] * K.v_s[i];
+                for (int i = tid; i < nl; i += NT) A.first_delta[(size_t)win * A.delta_stride + i] = (K.v_s + 5 * SCR_NL)[i] * K.v_s[i];
             __syncthreads();
             TCV_MARK(C, PH_PLUS);
             const double mu_next = uni_d(fmax(1e-8, 2.0 * mu / 10.0));
