@@ -1325,14 +1325,18 @@ __device__ __forceinline__ double readlane_f64(double v, int srclane) {
 }
 
 // Cholesky of one 16x16 diagonal tile by ONE wavefront, one matrix row per lane held in registers
-// (lane & 15 = row; the four 16-lane groups compute redundantly, so there is no divergence).  The pivot and the
+// (lane & 15 = row; the 16-lane groups 0, 2, 3 compute redundantly, so there is no divergence).  The pivot and the
 // pivot column are broadcast with v_readlane (SGPR operands of the FMAs): nothing on the pivot chain touches LDS.
 // Only the first cmax columns are pivots (the rest: rhs row / padding).
+// Group 1 (lanes 16..31) carries the rows of the IDENTITY through the same column operations (x <- x L^-T, the trick of the chain's T
+// step): they end as the rows of L^-T, whose strictly upper part goes to the unused upper triangle of the tile (its diagonal is 1 / l_kk =
+// invd) -- for nothing on the pivot chain -- and turns the panel solve below the tile into a product on the matrix cores.
 __device__ __forceinline__ bool diag_tile_wave(lds_d *TK, int cmax, lds_d *invd, int lane) {
     const int r = lane & 15;
+    const bool idrow = (lane >> 4) == 1;
     double t[16];
 #pragma unroll
-    for (int c = 0; c < 16; c++) t[c] = TK[sw(r, c)];
+    for (int c = 0; c < 16; c++) { const double tv = TK[sw(r, c)]; t[c] = idrow ? ((r == c) ? 1.0 : 0.0) : tv; }
     bool ok = true;
     double d = readlane_f64(t[0], 0);
 #pragma unroll
@@ -1342,7 +1346,7 @@ __device__ __forceinline__ bool diag_tile_wave(lds_d *TK, int cmax, lds_d *invd,
             else {
                 double l, y;
                 sqrt_rsqrt(d, l, y);
-                const double lk = (r == k) ? l : t[k] * y;
+                const double lk = (r == k && !idrow) ? l : t[k] * y;
                 t[k] = lk;
                 if (k + 1 < 16) {       // next pivot first: its rsqrt chain overlaps the rest of this column's updates
                     t[k + 1] -= lk * readlane_f64(lk, k + 1);
@@ -1354,11 +1358,29 @@ __device__ __forceinline__ bool diag_tile_wave(lds_d *TK, int cmax, lds_d *invd,
             }
         }
     }
-    if (lane < 16) {
+    if (lane < 32) {      // group 0: L (lower triangle and diagonal); group 1: L^-T above the diagonal
 #pragma unroll
-        for (int c = 0; c < 16; c++) TK[sw(r, c)] = t[c];
+        for (int c = 0; c < 16; c++) if (idrow ? (c > r) : (c <= r)) TK[sw(r, c)] = t[c];
     }
     return ok;
+}
+
+// panel below a factored diagonal tile on the matrix cores: X = A_IK L_KK^-T, L^-T from the tile's upper triangle and invd (diag_tile_wave)
+__device__ __forceinline__ void panel_tile_mfma(lds_d *T, const lds_d *TK, const lds_d *invd, int lane) {
+    const int row0 = lane >> 4, col = lane & 15;
+    double av[4], bv[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+        const int k = 4 * kk + row0;
+        av[kk] = T[sw(col, k)];                                   // A[m = col][k]
+        const double up = TK[sw(min(k, col), max(k, col))], dg = invd[col];      // B[k][n = col] = L^-T[k][col]: upper triangle, diagonal 1 / l_cc
+        bv[kk] = (k < col) ? up : ((k == col) ? dg : 0.0);
+    }
+    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], acc, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; i++) T[sw(row0 + 4 * i, col)] = acc[i];
 }
 
 template <bool MFMA>
@@ -1437,8 +1459,11 @@ __device__ __noinline__ bool chol_tiles(TCV_CTX_PARAMS, int nt, int nc) {
         const int cmax = min(16, nc - 16 * K);
         if (cmax < 16) break;   // partial pivot tile is the last tile row: nothing below / right of it
         const lds_d *TK = tiles + tbase(K, K);
-        // panel: X * L_KK^T = A_IK, one matrix row per lane
-        {
+        // panel: X * L_KK^T = A_IK -- on the matrix cores with the L_KK^-T the diagonal factorisation left behind (one tile per wavefront and
+        // trip), or by forward substitution, one matrix row per lane
+        if (MFMA) {
+            for (int I = K + 1 + wave; I < nt; I += NW) panel_tile_mfma(tiles + tbase(I, K), TK, C.invdiag + 16 * K, lane);
+        } else {
             const int g = tid >> 4, r = tid & 15;
             for (int I = K + 1 + g; I < nt; I += NG) {
                 lds_d *T = tiles + tbase(I, K);
