@@ -153,8 +153,9 @@ int tcv_problem_add_projection_factor(tcv_problem *p, const double pts_i[3], con
                                       double *ex_pose, double *inv_depth);
 /* AddResidualBlock(new ProjectionTdFactor(pts_i, pts_j, velocity_i, velocity_j, td_i, td_j, row_i, row_j), loss, P_i, P_j, Ex,
  * Feature, Td)   estimator.cpp:1757-1763 (ESTIMATE_TD).  A problem holds either ProjectionFactors or ProjectionTdFactors, all on
- * the same Td block; such problems use the dense layout of the fused solver.  TR / ROW (rolling-shutter read-out time and image
- * rows, globals in the reference) are set once per problem with tcv_problem_set_rolling_shutter (default TR = 0, ROW = 1). */
+ * the same Td block (chain layout like every other window: Td is the last column of the pose part; solver variant 1 = dense
+ * layout).  TR / ROW (rolling-shutter read-out time and image rows, globals in the reference) are set once per problem with
+ * tcv_problem_set_rolling_shutter (default TR = 0, ROW = 1). */
 int tcv_problem_add_projection_td_factor(tcv_problem *p, const double pts_i[3], const double pts_j[3], const double velocity_i[2],
                                          const double velocity_j[2], double td_i, double td_j, double row_i, double row_j,
                                          double sqrt_info, double loss_a, double *pose_i, double *pose_j, double *ex_pose,

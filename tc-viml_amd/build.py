@@ -73,13 +73,14 @@ def _compile(out: str, verbose: bool, extra, opt: str = "-O3", link_extra=()) ->
     jobs = [(f, os.path.join(objdir, f + ".o"), []) for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
     jobs.append(("tcv_solve.hip", os.path.join(objdir, "tcv_solve_chain.o"), ["-DTCV_SOLVE_CHAIN_TU=1"]))
     jobs.append(("tcv_solve.hip", os.path.join(objdir, "tcv_solve_coop.o"), ["-DTCV_SOLVE_COOP_TU=1"]))      # the cooperative small-batch kernel
+    jobs.append(("tcv_solve.hip", os.path.join(objdir, "tcv_solve_chain_td.o"), ["-DTCV_SOLVE_CHAIN_TD_TU=1"]))      # the chain kernel with ProjectionTdFactor
 
     def one(job):
         src, obj, flags = job
         subprocess.check_call(base + flags + ["-c", os.path.join(CSRC, src), "-o", obj])
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(7, len(jobs))) as ex:
+    with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
         objs = list(ex.map(one, jobs))
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + list(link_extra) + objs + ["-o", out])
     return out

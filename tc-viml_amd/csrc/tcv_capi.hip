@@ -559,6 +559,7 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
         for (int w = 0; w < n; w++) fmax = std::max(fmax, problems[w]->proj.size() + problems[w]->line.size());
         if (want < 0) want = fmax >= 96 ? std::min<int>(COOP_MAX_H, std::max<int>(2, (int)((fmax + 95) / 96))) : 0;
         want = std::min(want, (int)COOP_MAX_H);
+        for (int w = 0; w < n; w++) for (auto &f : problems[w]->proj) if (f.btd >= 0) { want = 0; break; }      // the cooperative kernel has no ProjectionTdFactor
         while (want > 0 && (long long)n * (1 + want) > n_cu) want--;
         if (want == 1 && g_coop_helpers < 0 && !getenv("TCV_COOP_H")) want = 0;      // a single helper is not worth the hand-offs
         coop_h = want;
@@ -788,7 +789,9 @@ extern "C" int tcv_batch_solve(tcv_batch *b, const tcv_solver_options *o, void *
     a.prof = b->d_prof;
     a.nwin = b->n; a.state_stride = b->state_stride; a.delta_stride = b->delta_stride; a.scratch_stride = tcv_solve_scratch_doubles() + b->hcl_cap;
     a.max_iterations = o->max_num_iterations; a.fixed_iterations = o->fixed_iterations; a.use_mfma = o->use_mfma;
-    a.chain = b->chain ? 1 : 0; a.imublk = b->d_imublk; a.spill = b->d_spill; a.spill_stride = b->spill_stride;
+    a.chain = b->chain ? 1 : 0; a.chain_td = 0;
+    if (b->chain) for (int w = 0; w < b->n; w++) if (b->packed[w].hdr.flags & 1) { a.chain_td = 1; break; }      // ESTIMATE_TD windows: the kernel instance with ProjectionTdFactor
+    a.imublk = b->d_imublk; a.spill = b->d_spill; a.spill_stride = b->spill_stride;
     a.max_ticks = 0;
     a.sqrt_out = b->d_sqrt_out;
     // cooperative plans also run on the single-workgroup kernel (workgroups_per_window = 1): same chunks, same additions, same bits

@@ -225,7 +225,6 @@ static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds,
     if (td_blk >= 0) {
         const ParamBlock &pb = p.blocks[td_blk];
         if (pb.size != 1 || pb.kind != KIND_EUCLID) { set_error("Td must be a size-1 Euclidean block"); return TCV_ERR_UNSUPPORTED; }
-        mode = 1;      // the chain layout has no room for a block that couples with every pose: dense layout
     }
     for (auto &f : p.imu) for (int k = 0; k < 4; k++) use_other[f.b[k]]++;
     for (auto &f : p.line) use_other[f.b]++;
@@ -300,8 +299,9 @@ static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds,
     if (use_chain) {
         std::vector<char> in_prior(nblk, 0);
         if (!p.prior.empty()) for (int b : p.prior[0].b) if (cam_of[b] >= 0) in_prior[cam_of[b]] = 1;
-        for (int c = nblk - 1; c >= 0; c--) if (kind[c] != KIND_POSE && loff[c] >= 0 && !in_prior[c]) eorder.push_back(c);
-        for (int c = nblk - 1; c >= 0; c--) if (kind[c] != KIND_POSE && loff[c] >= 0 && in_prior[c]) eorder.push_back(c);
+        // (Td is no chain block: it belongs to the pose part, one column wide -- every point factor and so every pose meets it)
+        for (int c = nblk - 1; c >= 0; c--) if (kind[c] != KIND_POSE && c != td_cam && loff[c] >= 0 && !in_prior[c]) eorder.push_back(c);
+        for (int c = nblk - 1; c >= 0; c--) if (kind[c] != KIND_POSE && c != td_cam && loff[c] >= 0 && in_prior[c]) eorder.push_back(c);
         for (int c : eorder) if (gsize[c] != CH_W) use_chain = false;
         if (eorder.empty() || eorder.size() > 16 || npp < 1) use_chain = false;
     }
@@ -322,9 +322,9 @@ static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds,
             if (later.size() > 1 || (later.size() == 1 && pos[later[0]] != s2 + 1)) { use_chain = false; break; }
             st.next = !later.empty();
             std::vector<int> prow;
-            for (int x = 0; x < nblk; x++) if (adj[e][x] && kind[x] == KIND_POSE) prow.push_back(x);
+            for (int x = 0; x < nblk; x++) if (adj[e][x] && (kind[x] == KIND_POSE || x == td_cam)) prow.push_back(x);
             std::sort(prow.begin(), prow.end(), [&](int a2, int b2) { return loff[a2] < loff[b2]; });
-            for (int x : prow) for (int j = 0; j < 6; j++) st.prow_t.push_back(loff[x] + j);
+            for (int x : prow) for (int j = 0; j < (x == td_cam ? 1 : 6); j++) st.prow_t.push_back(loff[x] + j);
             // fill: the eliminated block's neighbours become a clique (pose-pose is dense anyway)
             for (int x : later) for (int y : prow) { adj[x][y] = 1; adj[y][x] = 1; }
             for (size_t k = 0; k < p.imu.size(); k++)
@@ -337,7 +337,8 @@ static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds,
             chain.push_back(st);
         }
     }
-    const int nt_c = (npp + 1 + 15) / 16, ctiles = nt_c * (nt_c + 1) / 2;
+    // (Td's gather slot is six columns wide, tcv_packed.h: the pose tiles have to cover the five structural zeros behind its column)
+    const int nt_c = (std::max(npp + 1, (td_cam >= 0 && loff[td_cam] >= 0) ? loff[td_cam] + 6 : 0) + 15) / 16, ctiles = nt_c * (nt_c + 1) / 2;
     const int c_vec = 2 * nxl + 4 * 176 + 64 + 112;
     const int c_lds = coop_chunks > 0 ? (LDS_DOUBLES - ctiles * 256 - 8) : ((chain_lds >= 6144 && chain_lds <= LDS_DOUBLES) ? (chain_lds & ~1) : chain_lds_doubles());
     const int c_pool = c_lds - ctiles * 256 - c_vec;

@@ -80,7 +80,7 @@ struct PlanHdr {
     int n_imu_chunk;    // IMU factors are staged through LDS in chunks
     int n_vis_chunk;    // point/line factors likewise (1 for the BASELINE configs)
     int lds_area;       // doubles of the time-shared LDS area
-    int flags;          // bit 0: the point factors are ProjectionTdFactors (dense layout only)
+    int flags;          // bit 0: the point factors are ProjectionTdFactors (chain layout: the kernel instance with TD = true)
     int td_cam;         // camera block index of para_Td (-1 none); point records then carry 26 columns per row:
                         // [.. 19 as below | r | td | 5 zeros] so that Td rides through the 6-wide gather machinery
     int pad_td;
@@ -186,7 +186,7 @@ struct SolveArgs {
     double *coop_x;               // per group COOP_X_DOUBLES: the state the master hands to its helpers (+ mu)
     double *coop_exp;             // per group coop_exp_chunks x coop_exp_stride doubles
     long long coop_timeout;       // ticks of the constant-rate device clock a workgroup waits for its partners before it gives up (status -9)
-    int role_mode, pad3;          // chain kernel: placement of the wavefront roles on the SIMDs (tcv_solve.hip, solve_kernel), developer switch TCV_ROLE_MODE
+    int role_mode, chain_td;          // chain kernel: placement of the wavefront roles on the SIMDs (tcv_solve.hip, solve_kernel), developer switch TCV_ROLE_MODE
 };
 
 // ---- cooperative mode (tcv_solve.hip, solve_kernel<.., COOP = true>) ---------------------------------------------------------------

@@ -398,7 +398,7 @@ __device__ __forceinline__ void copy_prog(lds_i *dst, cst_i *src, int n, int tid
 // ---- one visual chunk (point + line factors whose records fit the LDS staging area together), first half: evaluation into the staging
 // records and the destination-driven gather of J'J / J'r / the landmark couplings.  cost_pt / cost_ln take the chunk's robustified
 // costs of this thread's point and line factor (the single-workgroup kernel passes its one accumulator for both).
-template <int NT, bool CHAIN>
+template <int NT, bool CHAIN, bool TD = !CHAIN>
 __device__ __forceinline__ void vis_part1(Ctx<NT> &C, const lds_d *x, int ch, bool assemble, double &cost_pt, double &cost_ln) {
     cst_plan &P = *C.P;
     const int tid = C.tid;
@@ -408,7 +408,7 @@ __device__ __forceinline__ void vis_part1(Ctx<NT> &C, const lds_d *x, int ch, bo
     cst_d *misc = dp + C.W->d_misc;
     const double proj_sqrt = misc[3], proj_loss = misc[4], line_loss = misc[5];
     const bool line_exact = misc[8] != 0.0;
-    const bool with_td = !CHAIN && (P.flags & 1);
+    const bool with_td = TD && (P.flags & 1);
     const int prec = with_td ? (int)PROJ_TD_REC : (int)PROJ_REC, pstr = with_td ? (int)PROJ_TD_STRIDE : (int)PROJ_STRIDE;
     cst_i *blk = ip + P.o_blk;
     {
@@ -868,7 +868,7 @@ __device__ __forceinline__ double prior_col_lds(const lds_d *J0, const lds_d *pr
 // ---- linearise at x: cost, and (if assemble) S~ = Hcc - sum_l Hcl Hcl'/kappa_l in the tiles --------
 // kappa_l = hll + mu * clamp(s_l^2 hll) / s_l^2 is the landmark pivot of the Jacobi-scaled,
 // mu-regularised system expressed in unscaled units (DoglegStrategy + SchurEliminator restated).
-template <int NT, bool CHAIN>
+template <int NT, bool CHAIN, bool TD = !CHAIN>
 __device__ __noinline__ double linearize(TCV_CTX_PARAMS, const lds_d *x, bool first, bool assemble, double mu) {
     Ctx<NT> C = ctx_from_args<NT>(TCV_CTX_FORWARD);
     cst_plan &P = *C.P;
@@ -881,8 +881,8 @@ __device__ __noinline__ double linearize(TCV_CTX_PARAMS, const lds_d *x, bool fi
     const double proj_sqrt = misc[3], proj_loss = misc[4], line_loss = misc[5];
     const bool line_exact = misc[8] != 0.0;
     const int pp_elems = CHAIN ? (C.ntiles << 8) : ((P.ntp * (P.ntp + 1) / 2) << 8);
-    // ProjectionTdFactor windows (dense layout only): wider point records, see tcv_packed.h
-    const bool with_td = !CHAIN && (P.flags & 1);
+    // ProjectionTdFactor windows (the dense kernels and the TD instance of the chain kernel): wider point records, see tcv_packed.h
+    const bool with_td = TD && (P.flags & 1);
     const int prec = with_td ? (int)PROJ_TD_REC : (int)PROJ_REC, pstr = with_td ? (int)PROJ_TD_STRIDE : (int)PROJ_STRIDE;
     double cost_acc = 0.0;
 
@@ -896,7 +896,7 @@ __device__ __noinline__ double linearize(TCV_CTX_PARAMS, const lds_d *x, bool fi
     TCV_MARK(C, PH_ZERO);
     // ---------------- point + line factors, chunk by chunk -------------------------------------------
     for (int ch = 0; ch < P.n_vis_chunk; ch++) {
-        vis_part1<NT, CHAIN>(C, x, ch, assemble, cost_acc, cost_acc);
+        vis_part1<NT, CHAIN, TD>(C, x, ch, assemble, cost_acc, cost_acc);
         if (!assemble) continue;
         vis_part2<NT, CHAIN>(C, ch, first, mu);
     }
@@ -2233,7 +2233,7 @@ __device__ __noinline__ void sqrt_info_all(cst_d *imu0_, int n_imu_, gbl_d *g_sq
         (void)imu_sqrt_info_group(imu0 + f * IMU_CONST + IMU_COV, g_sqrt + f * 225, ws + f * 450, ws + f * 450 + 225, tid & 15);
 }
 
-template <int NT, bool MFMA, bool CHAIN, bool COOP = false>
+template <int NT, bool MFMA, bool CHAIN, bool COOP = false, bool TD = !CHAIN>
 // (-DTCV_CHAIN_OCC1, developer build libtcv_hip_occ1.so: the chain kernel compiled for ONE wavefront per SIMD -- 512 registers, no spills -- to
 // measure what the 156 spilled registers of the production kernel cost at equal occupancy, profiles/r03_spill_ab.txt)
 #ifdef TCV_CHAIN_OCC1
@@ -2397,7 +2397,7 @@ __global__ void __launch_bounds__(NT) __attribute__((disable_tail_calls)) __attr
         int invalid = 0, termination = 0, nrec = 1, status = 0;
 #define TCV_COOP_LIN(X, FIRST, ASM, MU) coop_lin(linearize_coop<NT>(TCV_CTX_ARGS(K), C.cx_ctl, C.cx_x, C.cx_exp, C.cx_h, C.cx_exp_stride, C.cx_seq, C.cx_timeout, X, FIRST, ASM, MU, win))
         auto coop_lin = [&](const CoopLin &r) -> double { C.cx_seq = __builtin_amdgcn_readfirstlane(r.seq); return r.cost; };      // the master's sequence number lives in the kernel
-        double cost = uni_d(COOP ? TCV_COOP_LIN(K.xs, true, true, mu) : linearize<NT, CHAIN>(TCV_CTX_ARGS(K), K.xs, true, true, mu));
+        double cost = uni_d(COOP ? TCV_COOP_LIN(K.xs, true, true, mu) : linearize<NT, CHAIN, TD>(TCV_CTX_ARGS(K), K.xs, true, true, mu));
         bool first = true;
         const double initial_cost = cost;
         if (tid == 0) { S->cost[0] = cost; S->step_ok[0] = 1; S->dogleg_case[0] = 0; S->radius[0] = radius; S->mu[0] = mu; }
@@ -2431,7 +2431,7 @@ __global__ void __launch_bounds__(NT) __attribute__((disable_tail_calls)) __attr
                 ls_ok = false;
                 while (mu < 1.0) {
                     if (!tiles_valid || lin_mu != mu) {
-                        if (COOP) (void)TCV_COOP_LIN(K.xs, false, true, mu); else (void)linearize<NT, CHAIN>(TCV_CTX_ARGS(K), K.xs, false, true, mu);
+                        if (COOP) (void)TCV_COOP_LIN(K.xs, false, true, mu); else (void)linearize<NT, CHAIN, TD>(TCV_CTX_ARGS(K), K.xs, false, true, mu);
                         if (COOP && C.cx_seq < 0) break;
                         lin_mu = mu;
                     }
@@ -2515,7 +2515,7 @@ __global__ void __launch_bounds__(NT) __attribute__((disable_tail_calls)) __attr
             TCV_MARK(C, PH_PLUS);
             const double mu_next = uni_d(fmax(1e-8, 2.0 * mu / 10.0));
             const bool want_asm = (it < max_it) || !fixed;
-            const double cost_c = uni_d(COOP ? TCV_COOP_LIN(K.xc, false, want_asm, mu_next) : linearize<NT, CHAIN>(TCV_CTX_ARGS(K), K.xc, false, want_asm, mu_next));
+            const double cost_c = uni_d(COOP ? TCV_COOP_LIN(K.xc, false, want_asm, mu_next) : linearize<NT, CHAIN, TD>(TCV_CTX_ARGS(K), K.xc, false, want_asm, mu_next));
             if (COOP && C.cx_seq < 0) { status = -9; termination = 5; break; }
             tiles_valid = want_asm;
             lin_mu = mu_next;
@@ -2601,6 +2601,17 @@ extern "C" int tcv_launch_solve_coop(const tcv::SolveArgs *args, int grid, size_
     hipLaunchKernelGGL((solve_kernel<256, true, true, true>), dim3(grid), dim3(256), lds_bytes, st, *args);
     return (int)hipGetLastError();
 }
+#elif defined(TCV_SOLVE_CHAIN_TD_TU)
+// chain kernel with ProjectionTdFactor (ESTIMATE_TD windows): its own instantiation and translation unit, so that the factor's code and
+// registers stay out of the kernel every shipped configuration runs
+extern "C" int tcv_launch_solve_chain_td(const tcv::SolveArgs *args, int grid, size_t lds_bytes, void *stream) {
+    using namespace tcv;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipFuncSetAttribute((const void *)solve_kernel<256, true, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((solve_kernel<256, true, true, false, true>), dim3(grid), dim3(256), lds_bytes, st, *args);
+    return (int)hipGetLastError();
+}
 #elif defined(TCV_SOLVE_CHAIN_TU)
 extern "C" int tcv_launch_solve_chain(const tcv::SolveArgs *args, int grid, size_t lds_bytes, void *stream) {
     using namespace tcv;
@@ -2613,8 +2624,10 @@ extern "C" int tcv_launch_solve_chain(const tcv::SolveArgs *args, int grid, size
 #else
 extern "C" int tcv_launch_solve_chain(const tcv::SolveArgs *args, int grid, size_t lds_bytes, void *stream);
 extern "C" int tcv_launch_solve_coop(const tcv::SolveArgs *args, int grid, size_t lds_bytes, void *stream);
+extern "C" int tcv_launch_solve_chain_td(const tcv::SolveArgs *args, int grid, size_t lds_bytes, void *stream);
 extern "C" int tcv_launch_solve(const tcv::SolveArgs *args, int grid, int nthreads, size_t lds_bytes, void *stream) {
     using namespace tcv;
+    if (args->chain && args->chain_td) return tcv_launch_solve_chain_td(args, grid, lds_bytes, stream);
     if (args->chain && args->coop_h > 0) return tcv_launch_solve_coop(args, grid, lds_bytes, stream);
     if (args->chain) return tcv_launch_solve_chain(args, grid, lds_bytes, stream);
     hipStream_t st = (hipStream_t)stream;

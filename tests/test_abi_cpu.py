@@ -151,14 +151,32 @@ def test_window_description_is_validated_before_it_is_walked(tcv):
     assert L.tcv_batch_create(C.byref(b), arr, None, None, None, 2) == tcv.TCV_ERR_INVALID and b"null problem" in L.tcv_last_error()
 
 
-def test_time_offset_windows_use_the_dense_layout(tcv):
-    """ESTIMATE_TD: para_Td rides behind the poses in tangent space (nc = 172), the plan is laid out for the dense kernel; mixing
-    ProjectionFactors and ProjectionTdFactors in one problem is refused."""
+def test_time_offset_windows_in_both_layouts(tcv):
+    """ESTIMATE_TD: para_Td rides behind the poses in tangent space (nc = 172) as the last column of the pose part (npp = 73): the chain
+    layout keeps it with the poses (5 tile rows: 73 columns + rhs, Td's six-wide gather slot inside them), solver variant 1 lays the plan out
+    for the dense kernel (11 tile rows); mixing ProjectionFactors and ProjectionTdFactors in one problem is refused."""
     L = tcv.lib()
     w = synth.with_time_offset(synth.window_at(synth.make_windows(3, 1), 0), 3)
     W = tcv.Window(w)
     st = W.plan_stats()
-    assert st["nc"] == 172 and st["npp"] == 73 and st["nt"] == 11 and st["lds_bytes"] == 160 * 1024
+    assert st["nc"] == 172 and st["npp"] == 73 and st["nt"] == 5 and st["lds_bytes"] == 80 * 1024
+    L.tcv_set_solver_variant(1)
+    try:
+        st = tcv.Window(w).plan_stats()
+        assert st["nc"] == 172 and st["npp"] == 73 and st["nt"] == 11 and st["lds_bytes"] == 160 * 1024
+    finally:
+        L.tcv_set_solver_variant(0)
+    # a prior that holds Td (n = 76, block kind 3) ties it to the first speed-bias block: Td becomes one more column of that chain
+    # step's front, the plan stays a chain plan
+    import np_oracle as NO
+    po, _ = NO.marginalize_old(NO.Problem(w), NO.Problem(w).x0())
+    assert po["n"] == 76 and tuple(po["blocks"][-1]) == ("td", 0)
+    nxt = synth.with_time_offset(synth.window_at(synth.make_windows(4, 1), 0), 4)
+    keep = dict(po, blocks=[tuple(bk) for bk in po["blocks"]])
+    keep["x0"] = [np.array({"pose": nxt["pose"], "sb": nxt["speedbias"]}[nm][i], dtype=float).copy() if nm in ("pose", "sb")
+                  else (np.array(nxt["ex_pose"], dtype=float).copy() if nm == "ex" else np.array([0.0])) for nm, i in keep["blocks"]]
+    st2 = tcv.Window(dict(nxt, prior=keep)).plan_stats()
+    assert st2["nt"] == 5 and st2["lds_bytes"] == 80 * 1024 and st2["window_doubles"] > st["window_doubles"] + 76 * 40      # (the prior without its zero rows)
     assert L.tcv_problem_num_parameter_blocks(W.h) == 11 * 2 + 1 + 1 + 50
     pts = np.array([0.1, 0.2, 1.0])
     assert L.tcv_problem_add_projection_factor(W.h, tcv.dptr(pts), tcv.dptr(pts), 306.0, 1.0, W.block_ptr("pose", 0), W.block_ptr("pose", 1),

@@ -104,6 +104,15 @@ def test_prior_round_trip_and_chained_solve(gpu):
     # 1.2e-5 on the final cost and 6.5e-7 / 1.2e-6 on poses / speed-biases (measured): the gates sit one order above
     assert abs(s.final_cost - so.final_cost) < 1e-4 * so.final_cost
     assert rel(Wn.pose, O.states()["pose"]) < 1e-5 and rel(Wn.sb, O.states()["sb"]) < 2e-5
+    # ... and with the prior's floor taken out -- the oracle solves the window with the SAME (GPU-made) prior -- the two solves agree at the
+    # level of every other solve parity test: identical accept / reject and dogleg sequences, north_star's 1e-6 with margin
+    O2 = orc.Window(w); so2 = O2.solve(8, True)
+    n2 = so2.num_iterations
+    assert s.num_iterations == n2
+    assert [s.step_ok[i] for i in range(1, n2)] == [so2.step_ok[i] for i in range(1, n2)]
+    assert [s.dogleg_case[i] for i in range(1, n2)] == [so2.dogleg_case[i] for i in range(1, n2)]
+    assert abs(s.final_cost - so2.final_cost) < 1e-7 * so2.final_cost
+    assert rel(Wn.pose, O2.states()["pose"]) < 1e-7 and rel(Wn.sb, O2.states()["sb"]) < 1e-6
 
 
 def test_margin_second_new_prior_only(gpu):

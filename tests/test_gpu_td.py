@@ -1,6 +1,6 @@
 """T1 in the solver: ESTIMATE_TD windows -- every point factor a ProjectionTdFactor on the extra 1-dim block
-para_Td[0] (estimator.cpp:1703-1707, :1757-1763) -- solved and marginalised by the HIP path (dense layout of the fused solver)
-against the NumPy restatement (oracle/np_oracle.py)."""
+para_Td[0] (estimator.cpp:1703-1707, :1757-1763) -- solved (chain layout, the default, and dense layout of the fused solver) and
+marginalised by the HIP path against the NumPy restatement (oracle/np_oracle.py)."""
 import numpy as np
 import pytest
 
@@ -17,12 +17,21 @@ def td_window(seed, **kw):
     return synth.with_time_offset(synth.window_at(synth.make_windows(seed, 1), 0), seed, **kw)
 
 
+@pytest.fixture(params=["chain", "dense"])
+def layout(request, gpu):
+    """chain: Td is the last column of the pose part, the speed-bias chain is eliminated in front of it (the default);
+    dense: solver variant 1, one 172-dim system"""
+    gpu.check(gpu.lib().tcv_set_solver_variant(0 if request.param == "chain" else 1))
+    yield request.param
+    gpu.check(gpu.lib().tcv_set_solver_variant(0))
+
+
 @pytest.mark.parametrize("seed,TR", [(21, 0.0), (22, 0.02)])
-def test_td_window_solve_vs_oracle(gpu, seed, TR):
+def test_td_window_solve_vs_oracle(gpu, layout, seed, TR):
     w = td_window(seed, TR=TR)
     W = gpu.Window(w)
     b = gpu.Batch([W])
-    assert b.plan_stats()["layout"] == "dense"                       # Td couples with every pose: no chain layout
+    assert b.plan_stats()["layout"] == layout
     b.solve(gpu.default_options(8, True)); b.synchronize(); b.download_states()
     s = b.summaries()[0]
     P = NO.Problem(w)
@@ -41,7 +50,7 @@ def test_td_window_solve_vs_oracle(gpu, seed, TR):
     assert b0.summaries()[0].final_cost > 1.05 * s.final_cost
 
 
-def test_td_window_marginalisation_vs_oracle(gpu):
+def test_td_window_marginalisation_vs_oracle(gpu, layout):
     """MARGIN_OLD with ProjectionTdFactors among the marginalised factors (estimator.cpp:1962-1972): para_Td is a kept block, so
     the new prior has n = 76 and a size-1 block at the end; then the chained window uses that prior (kind 3 = Td)."""
     w = td_window(23)
@@ -68,7 +77,35 @@ def test_td_window_marginalisation_vs_oracle(gpu):
     keep["x0"] = x0                                                   # linearised at the new window's own initial states
     nxt = dict(nxt, prior=keep)
     W = gpu.Window(nxt); b2 = gpu.Batch([W]); b2.solve(gpu.default_options(8, True)); b2.synchronize(); b2.download_states()
+    assert b2.plan_stats()["layout"] == layout                        # (chain: the prior ties Td to the first speed-bias block)
     s = b2.summaries()[0]
     x2, so = NO.solve(NO.Problem(nxt), 8, True)
     assert abs(s.final_cost - so["final_cost"]) < 1e-6 * so["final_cost"]
     assert rel(W.pose, x2["pose"]) < 1e-6 and abs(W.td[0] - x2["td"][0]) < 1e-6 * max(1e-3, abs(x2["td"][0]))
+
+
+def test_td_batch_chain_and_dense_agree(gpu):
+    """a batch of ESTIMATE_TD windows larger than the chip (two chain-layout workgroups per CU): the chain kernel with ProjectionTdFactor
+    and the dense kernel solve the same systems -- identical accept / reject and dogleg sequences, states within 1e-8"""
+    ws = [td_window(100 + k, TR=0.02 if k % 2 else 0.0) for k in range(8)]
+    out = {}
+    for variant in (0, 1):
+        gpu.check(gpu.lib().tcv_set_solver_variant(variant))
+        try:
+            Ws = [gpu.Window(ws[k % 8]) for k in range(300)]
+            b = gpu.Batch(Ws)
+            assert b.plan_stats()["layout"] == ("chain", "dense")[variant]
+            b.solve(gpu.default_options(8, True)); b.synchronize(); b.download_states()
+            s = b.summaries()
+            out[variant] = [([s[k].step_ok[i] for i in range(9)], [s[k].dogleg_case[i] for i in range(9)], s[k].final_cost,
+                             Ws[k].pose.copy(), Ws[k].sb.copy(), float(Ws[k].td[0])) for k in range(300)]
+        finally:
+            gpu.check(gpu.lib().tcv_set_solver_variant(0))
+    worst = np.zeros(4)
+    for a, d in zip(out[0], out[1]):
+        assert a[0] == d[0] and a[1] == d[1]
+        worst = np.maximum(worst, [abs(a[2] - d[2]) / d[2], rel(a[3], d[3]), rel(a[4], d[4]), abs(a[5] - d[5]) / max(1e-3, abs(d[5]))])
+    print("chain vs dense, ESTIMATE_TD windows: cost %.1e pose %.1e speed-bias %.1e td %.1e" % tuple(worst))
+    assert worst[0] < 1e-7 and worst[1] < 1e-7 and worst[2] < 1e-6 and worst[3] < 1e-6      # measured 2e-9 on the cost
+    for k in range(8, 300):                                           # the same window gives the same bits wherever it runs
+        assert out[0][k][2] == out[0][k % 8][2] and np.array_equal(out[0][k][3], out[0][k % 8][3])
