@@ -228,6 +228,12 @@ __device__ __forceinline__ double uni_f64(double v) {
     u.x = __builtin_amdgcn_readfirstlane(u.x); u.y = __builtin_amdgcn_readfirstlane(u.y);
     return __builtin_bit_cast(double, u);
 }
+__device__ __forceinline__ double lane_f64(double v, int srclane) {      // broadcast of one lane's value (srclane uniform)
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+    u2v u = __builtin_bit_cast(u2v, v);
+    u.x = __builtin_amdgcn_readlane(u.x, srclane); u.y = __builtin_amdgcn_readlane(u.y, srclane);
+    return __builtin_bit_cast(double, u);
+}
 __device__ __forceinline__ double fast_rcp(double q) {
     double r = __builtin_amdgcn_rcp(q);
     r = fma(fma(-q, r, 1.0), r, r);
@@ -1386,6 +1392,35 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((disable_tail_calls)) _
         for (int i = tid; i < m * m; i += MARG_NT) { const int r = i / m, c = i - r * m; Mm[r * ldm + c] = Apk[pidx(r, c)]; }
         __syncthreads();
         bool chol = Aarg.eig_mm == 0;
+        constexpr int MREG = 24;      // dropped sets of at most 24 dims (a pose, a speed-bias and up to nine landmarks; block mode: 15): in registers
+        if (chol && m <= MREG) {
+            // right-looking in registers, lane = row: entry (i, c) takes its subtractions L_ip L_cp in the order p = 0, 1, ... of the left-looking
+            // loop below (same products, same fused operations: the same bits), pivot column broadcast with v_readlane -- no LDS round trip
+            // on the 23 dependent column steps
+            if (tid < 64) {
+                const int i = min(tid, m - 1);
+                double t[MREG];
+#pragma unroll
+                for (int c = 0; c < MREG; c++) { const double a = Mm[i * ldm + min(c, m - 1)]; t[c] = c < m ? a : 0.0; }
+                bool ok = true;
+#pragma unroll
+                for (int k = 0; k < MREG; k++) {
+                    if (k < m) {
+                        const double sd = lane_f64(t[k], k);
+                        ok = ok && (sd > 0.0) && (sd < 1e300);
+                        const double rs = 1.0 / sqrt(ok ? sd : 1.0);
+                        const double lik = t[k] * rs;
+#pragma unroll
+                        for (int c = k + 1; c < MREG; c++) t[c] -= lik * lane_f64(lik, c);
+                        if (tid < m && tid > k) Mm[tid * ldm + k] = lik;
+                        if (tid == k) Mm[k * ldm + k] = rs;
+                    }
+                }
+                if (tid == 0) lmacc[2] = ok ? 1.0 : 0.0;
+            }
+            __syncthreads();
+            chol = lmacc[2] != 0.0;
+        } else
         if (chol) {
             if (tid < 64) {      // left-looking Cholesky, lane = row; the diagonal keeps 1 / L_kk
                 const int i = min(tid, m - 1);
@@ -1413,6 +1448,38 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((disable_tail_calls)) _
             __syncthreads();
             chol = lmacc[2] != 0.0;
         }
+        if (chol && m <= MREG) {
+            // forward substitutions, one thread per right-hand side (the n columns of Amr, bmm, the m unit vectors for |L^-1|_F^2), the
+            // solution in registers: z_k' -= L_k'k z_k as soon as z_k is final -- per entry the subtractions of the loop below in its order --
+            // with L read as broadcasts; nothing waits for its own stores
+            if (tid < n + 1 + m) {
+                const int j = tid, ju = tid - n - 1;
+                double z[MREG];
+#pragma unroll
+                for (int k = 0; k < MREG; k++) {
+                    const int kc = min(k, m - 1);
+                    const double a = Apk[pidx(m + min(j, n - 1), kc)], bb = bv[kc];
+                    z[k] = k < m ? (j < n ? a : (j == n ? bb : (k == ju ? 1.0 : 0.0))) : 0.0;
+                }
+                double nn = 0.0;
+#pragma unroll
+                for (int k = 0; k < MREG; k++) {
+                    if (k < m) {
+                        z[k] *= Mm[k * ldm + k];
+                        if (k >= ju) nn += z[k] * z[k];      // (unit-vector threads: y_j^2 first, then the entries below it)
+#pragma unroll
+                        for (int k2 = k + 1; k2 < MREG; k2++) { const double l = Mm[min(k2, m - 1) * ldm + k]; if (k2 < m) z[k2] -= l * z[k]; }
+                        if (j <= n) Zl[k * zs + j] = z[k];
+                    }
+                }
+                if (j > n) rot[ju] = nn;
+            }
+            __syncthreads();
+            double tr = 0, trs = 0;
+            for (int j = 0; j < m; j++) { tr += rot[j]; trs += rot[j] * Apk[pidx(j, j)]; }
+            chol = tr < 1e8;                                    // lambda_min >= 1 / tr > 1e-8 (false for NaN)
+            if (tid == 0) { out[MARG_OUT_X + MARG_MAX_X + 40] = tr; out[MARG_OUT_X + MARG_MAX_X + 41] = trs; }
+        } else
         if (chol) {
             // forward substitutions L z = rhs, one thread per right-hand side: the n columns of Amr, bmm, and the m unit vectors whose
             // solutions give |L^-1|_F^2 (kept in the unused upper triangle of Mm)
