@@ -234,6 +234,14 @@ __device__ __forceinline__ double lane_f64(double v, int srclane) {      // broa
     u.x = __builtin_amdgcn_readlane(u.x, srclane); u.y = __builtin_amdgcn_readlane(u.y, srclane);
     return __builtin_bit_cast(double, u);
 }
+// an LDS pointer argument made uniform AND opaque: a callee that can see `lds_raw + constant` behind it re-reads the dynamic-LDS base from
+// the offset table in memory wherever it rematerialises the address (s_getpc / s_load / s_waitcnt in front of the access)
+template <class T> __device__ __forceinline__ T *opaque_lds(T *p) {
+    unsigned a = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)p);
+    asm volatile("" : "+s"(a));
+    return (T *)(unsigned long long)a;
+}
+__device__ __forceinline__ double pin_f64(double v) { asm volatile("" : "+v"(v)); return v; }      // keeps a clamped load unconditional
 __device__ __forceinline__ double fast_rcp(double q) {
     double r = __builtin_amdgcn_rcp(q);
     r = fma(fma(-q, r, 1.0), r, r);
@@ -928,6 +936,68 @@ __device__ __noinline__ __attribute__((disable_tail_calls)) bool sym_eig_tridiag
 #else
 #define MARG_MARK(id) do { } while (0)
 #endif
+// Cholesky of a small Amm (m <= MREG) in registers and the forward substitutions behind it (marg_kernel, step 4): functions of their own,
+// so that their register arrays get registers (inlined into the kernel they were spilled: 263 instead of 123 spilled VGPRs, every access a
+// scratch round trip).  The arguments go through v_readfirstlane: uniform values in SGPRs (the k < m guards become scalar branches), and
+// opaque ones -- with the kernel's `lds_raw + offset` propagated into the callee every LDS access looks the dynamic-LDS base up in memory
+template <int MREG>
+__device__ __noinline__ void chol_small_regs(lds_d *Mm_, lds_d *okflag_, int m_, int ldm_, int tid) {
+    lds_d *Mm = opaque_lds(Mm_), *okflag = opaque_lds(okflag_);
+    const int m = uni_i<2>(m_), ldm = uni_i<2>(ldm_);
+    if (tid < 64) {
+        const int i = min(tid, m - 1);
+        double t[MREG];
+#pragma unroll
+        for (int c = 0; c < MREG; c++) { const double a = pin_f64(Mm[i * ldm + min(c, m - 1)]); t[c] = c < m ? a : 0.0; }
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < MREG; k++) {
+            const double sd = lane_f64(t[k], k);
+            ok = ok && (k >= m || ((sd > 0.0) && (sd < 1e300)));
+            const double rs = 1.0 / sqrt((ok && k < m) ? sd : 1.0);
+            const double lik = t[k] * rs;
+#pragma unroll
+            for (int c = k + 1; c < MREG; c++) t[c] -= lik * lane_f64(lik, c);
+            if (tid < m && tid > k) Mm[tid * ldm + k] = lik;
+            if (tid == k && k < m) Mm[k * ldm + k] = rs;
+        }
+        if (tid == 0) *okflag = ok ? 1.0 : 0.0;
+    }
+}
+template <int MREG>
+__device__ __noinline__ void fwd_small_regs(const lds_d *Mm_, const lds_d *Apk_, const lds_d *bv_, lds_d *Zl_, lds_d *rot_, int m_, int n_, int ldm_, int zs_, int tid) {
+    const lds_d *Mm = opaque_lds(Mm_), *Apk = opaque_lds(Apk_), *bv = opaque_lds(bv_);
+    lds_d *Zl = opaque_lds(Zl_), *rot = opaque_lds(rot_);
+    const int m = uni_i<2>(m_), n = uni_i<2>(n_), ldm = uni_i<2>(ldm_), zs = uni_i<2>(zs_);
+    if (tid < n + 1 + m) {
+        const int j = tid, ju = tid - n - 1;
+        double z[MREG];
+#pragma unroll
+        for (int k = 0; k < MREG; k++) {
+            const int kc = min(k, m - 1);
+            const double a = pin_f64(Apk[pidx(m + min(j, n - 1), kc)]), bb = pin_f64(bv[kc]);
+            z[k] = k < m ? (j < n ? a : (j == n ? bb : (k == ju ? 1.0 : 0.0))) : 0.0;
+        }
+        double nn = 0.0;
+#pragma unroll
+        for (int k = 0; k < MREG; k++) {
+            const int kc = min(k, m - 1);
+            double l[MREG];
+            const double lkk = Mm[kc * ldm + kc];
+#pragma unroll
+            for (int k2 = k + 1; k2 < MREG; k2++) l[k2] = Mm[min(k2, m - 1) * ldm + kc];
+            z[k] *= lkk;
+            nn = (k >= ju && k < m) ? fma(z[k], z[k], nn) : nn;      // (unit-vector threads: y_j^2 first, then the entries below it)
+#pragma unroll
+            for (int k2 = k + 1; k2 < MREG; k2++) z[k2] = pin_f64(z[k2] - l[k2] * z[k]);      // (pinned: left alone the compiler sinks every update to its use,
+                                                                                               //  i.e. keeps all of L alive -- in scratch memory)
+            if (j <= n && k < m) Zl[k * zs + j] = z[k];
+            __builtin_amdgcn_sched_barrier(0);      // one step's loads at a time: hoisted all at once, the 276 entries of L do not fit the registers
+        }
+        if (j > n) rot[ju] = nn;
+    }
+}
+
 template <int MARG_NT>
 __global__ void __launch_bounds__(MARG_NT) __attribute__((disable_tail_calls)) __attribute__((amdgpu_waves_per_eu(2, 2))) marg_kernel(MargArgs Aarg) {
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
@@ -1396,29 +1466,12 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((disable_tail_calls)) _
         if (chol && m <= MREG) {
             // right-looking in registers, lane = row: entry (i, c) takes its subtractions L_ip L_cp in the order p = 0, 1, ... of the left-looking
             // loop below (same products, same fused operations: the same bits), pivot column broadcast with v_readlane -- no LDS round trip
-            // on the 23 dependent column steps
-            if (tid < 64) {
-                const int i = min(tid, m - 1);
-                double t[MREG];
-#pragma unroll
-                for (int c = 0; c < MREG; c++) { const double a = Mm[i * ldm + min(c, m - 1)]; t[c] = c < m ? a : 0.0; }
-                bool ok = true;
-#pragma unroll
-                for (int k = 0; k < MREG; k++) {
-                    if (k < m) {
-                        const double sd = lane_f64(t[k], k);
-                        ok = ok && (sd > 0.0) && (sd < 1e300);
-                        const double rs = 1.0 / sqrt(ok ? sd : 1.0);
-                        const double lik = t[k] * rs;
-#pragma unroll
-                        for (int c = k + 1; c < MREG; c++) t[c] -= lik * lane_f64(lik, c);
-                        if (tid < m && tid > k) Mm[tid * ldm + k] = lik;
-                        if (tid == k) Mm[k * ldm + k] = rs;
-                    }
-                }
-                if (tid == 0) lmacc[2] = ok ? 1.0 : 0.0;
-            }
+            // on the 23 dependent column steps.  One basic block (steps k >= m work on zero rows behind selects, only their stores are
+            // guarded), so that the trailing update of a step is scheduled into the 1 / sqrt chain of the next one.
+            chol_small_regs<MREG>(Mm, lmacc + 2, m, ldm, tid);
+            MARG_MARK(9);
             __syncthreads();
+            MARG_MARK(10);
             chol = lmacc[2] != 0.0;
         } else
         if (chol) {
@@ -1451,29 +1504,10 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((disable_tail_calls)) _
         if (chol && m <= MREG) {
             // forward substitutions, one thread per right-hand side (the n columns of Amr, bmm, the m unit vectors for |L^-1|_F^2), the
             // solution in registers: z_k' -= L_k'k z_k as soon as z_k is final -- per entry the subtractions of the loop below in its order --
-            // with L read as broadcasts; nothing waits for its own stores
-            if (tid < n + 1 + m) {
-                const int j = tid, ju = tid - n - 1;
-                double z[MREG];
-#pragma unroll
-                for (int k = 0; k < MREG; k++) {
-                    const int kc = min(k, m - 1);
-                    const double a = Apk[pidx(m + min(j, n - 1), kc)], bb = bv[kc];
-                    z[k] = k < m ? (j < n ? a : (j == n ? bb : (k == ju ? 1.0 : 0.0))) : 0.0;
-                }
-                double nn = 0.0;
-#pragma unroll
-                for (int k = 0; k < MREG; k++) {
-                    if (k < m) {
-                        z[k] *= Mm[k * ldm + k];
-                        if (k >= ju) nn += z[k] * z[k];      // (unit-vector threads: y_j^2 first, then the entries below it)
-#pragma unroll
-                        for (int k2 = k + 1; k2 < MREG; k2++) { const double l = Mm[min(k2, m - 1) * ldm + k]; if (k2 < m) z[k2] -= l * z[k]; }
-                        if (j <= n) Zl[k * zs + j] = z[k];
-                    }
-                }
-                if (j > n) rot[ju] = nn;
-            }
+            // with L read as broadcasts; nothing waits for its own stores.  Branch-free but for the stores: a guard per entry makes every load
+            // of L wait out its own LDS round trip (45 K cycles instead of 8 K); rows k >= m compute on clamped loads and are never stored.
+            fwd_small_regs<MREG>(Mm, Apk, bv, Zl, rot, m, n, ldm, zs, tid);
+            MARG_MARK(11);
             __syncthreads();
             double tr = 0, trs = 0;
             for (int j = 0; j < m; j++) { tr += rot[j]; trs += rot[j] * Apk[pidx(j, j)]; }
@@ -2122,7 +2156,7 @@ int tcv_marg_get_prior(tcv_batch *b, int window, tcv_prior **out) {
     }
     if (getenv("TCV_DEBUG")) {
         fprintf(stderr, "[tcv] marg window %d: m=%d n=%d jacobi sweeps %g / %g status %d\n", window, m, n, o[MARG_OUT_X + MARG_MAX_X], o[MARG_OUT_X + MARG_MAX_X + 1], status);
-        const char *nm[12] = {"load", "prior", "imu", "proj", "eig_mm", "Z", "schur", "eig_rr", "out", "j_angle", "j_cols", "j_rows"};
+        const char *nm[12] = {"load", "prior", "imu", "proj", "eig_mm", "Z", "schur", "eig_rr", "out", "j_angle|chol_mm", "j_cols|barrier", "j_rows|subst_mm"};      // (9..11: Jacobi safety net, or the register Cholesky route of Amm)
         fprintf(stderr, "[tcv]   Amm: trace(Amm^-1) %.3e, of the unit-diagonal scaling %.3e\n", o[MARG_OUT_X + MARG_MAX_X + 40], o[MARG_OUT_X + MARG_MAX_X + 41]);
         for (int i = 0; i < 12; i++) fprintf(stderr, "[tcv]   %-7s %12.0f cycles\n", nm[i], o[MARG_OUT_X + MARG_MAX_X + 2 + i]);
         const char *en[6] = {"tridiag", "bisect", "vectors", "mgs", "backtr", "check"};
