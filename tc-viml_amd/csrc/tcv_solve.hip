@@ -1766,19 +1766,18 @@ __device__ __forceinline__ void chain_mfma_pair2(lds_d *tiles, const lds_d *W, c
 #pragma unroll
     for (int i = 0; i < 4; i++) { C0[M.co[i]] = acc0[i]; if (two) C1[M.co[i]] = acc1[i]; }
 }
-// pairs first, first + stride, ... of the step's pair list: pair p = (a, b), a >= b, over the ascending list of active tile rows
+// every pair (a, b), a >= b, over the ascending list of active tile rows, two at a time
 template <int NT>
-__device__ __forceinline__ void chain_mfma_update(const Ctx<NT> &C, const lds_d *W, const ChainMfmaLane &M, int tmask, int npp, int first, int stride) {
+__device__ __forceinline__ void chain_mfma_update_all(const Ctx<NT> &C, const lds_d *W, const ChainMfmaLane &M, int tmask, int npp) {
     int act = 0, na = 0;      // 4 bits per entry
     for (int I = 0; I < C.ntd; I++) if ((tmask >> I) & 1) { act |= I << (4 * na); na++; }
     const int npair = na * (na + 1) / 2;
-    // walk (a, b) along with p instead of inverting the triangular number
-    int a = 0, b = 0, p = 0, pI = -1, pJ = -1;
-    for (int want = first; want < npair; want += stride) {
-        while (p < want) { p++; if (b == a) { a++; b = 0; } else b++; }
+    int a = 0, b = 0, pI = -1, pJ = -1;
+    for (int p = 0; p < npair; p++) {
         const int I = (act >> (4 * a)) & 15, J = (act >> (4 * b)) & 15;
         if (pI < 0) { pI = I; pJ = J; }
         else { chain_mfma_pair2(C.tiles, W, M, npp, pI, pJ, I, J, true); pI = -1; }
+        if (b == a) { a++; b = 0; } else b++;
     }
     if (pI >= 0) chain_mfma_pair2(C.tiles, W, M, npp, pI, pJ, pI, pJ, false);
 }
@@ -1900,15 +1899,23 @@ __device__ __noinline__ ChainOut chain_forward(TCV_CTX_PARAMS, double mu) {
             CH_TOC(PH_CH_B, tid == 0);
         }
         // ---- matrix cores: S -= W_s-1' W_s-1
-        if (s > 0 && wave <= 2 && ABL(C, AB_CH_MFMA)) {
-            // wave 2 (no other duty) takes two of every three pairs, wave 1 (nine columns to own) the third; wave 0 owns 64 columns
+        if (s > 0 && wave == 2 && ABL(C, AB_CH_MFMA)) {
+            // wave 2 (no other duty) takes every pair.  Which wavefront a step waits for changes along the chain (timers of the -DTCV_PROFILE
+            // build at the step's barrier): the early steps, with two or three active tile rows, wait for the T pipeline, the late ones for
+            // the W tiles; sharing the pairs out to the W wavefronts (thirds, sevenths, ... measured) never shortened a step
             const lds_i *hp = L.tab + (s - 1) * CH_STRIDE;
             const lds_d *Wp = L.wbuf + ((s - 1) & 1) * CH_W * wld;
-            if (wave == 2) { chain_mfma_update<NT>(C, Wp, ML, hp[CH_TMASK], npp, 0, 3); chain_mfma_update<NT>(C, Wp, ML, hp[CH_TMASK], npp, 1, 3); }
-            else if (wave == 1) chain_mfma_update<NT>(C, Wp, ML, hp[CH_TMASK], npp, 2, 3);
+            if (wave == 2) chain_mfma_update_all<NT>(C, Wp, ML, hp[CH_TMASK], npp);
             CH_TOC(PH_CH_C, tid == 128);
         }
+#ifdef TCV_PROFILE
+        const long long t_arrive = clock64();
+#endif
         __syncthreads();
+#ifdef TCV_PROFILE
+        // how long each wavefront waits at the step's barrier: the one that waits least sets the step (slots: chain_bwd's -- unused here -- and 29..31)
+        if (lane == 0) ((lds_u *)(C.red + 40))[wave == 0 ? (int)PH_CHAIN_BWD : 28 + wave] += (unsigned)(clock64() - t_arrive);
+#endif
         CH_TOC(PH_CH_D, tid == 64);      // the whole interval as wave 1 sees it
     }
     ChainOut o;

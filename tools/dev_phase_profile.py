@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tc-viml_amd"))
 import synth, tcv
 NAMES = ["setup", "vis_eval", "vis_gather", "lm", "schur", "zero", "imu_raw", "imu_whiten", "imu_gather", "prior", "cost_red",
-         "fin_scale", "fin_cauchy", "fin_pass", "chol_diag", "chol_trsm", "chol_upd", "back", "lm_back", "dogleg", "plus", "norms", "other", "chain_fwd", "chain_bwd", "ch_T(wave3)", "ch_owner(w0)", "ch_mfma(w2)", "ch_interval"]
+         "fin_scale", "fin_cauchy", "fin_pass", "chol_diag", "chol_trsm", "chol_upd", "back", "lm_back", "dogleg", "plus", "norms", "other", "chain_fwd", "ch_wait(w0)", "ch_T(wave3)", "ch_owner(w0)", "ch_mfma(w2)", "ch_interval", "ch_wait(w1)", "ch_wait(w2)", "ch_wait(w3)"]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 th = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 if "--dense" in sys.argv:
