@@ -109,3 +109,25 @@ def test_td_batch_chain_and_dense_agree(gpu):
     assert worst[0] < 1e-7 and worst[1] < 1e-7 and worst[2] < 1e-6 and worst[3] < 1e-6      # measured 2e-9 on the cost
     for k in range(8, 300):                                           # the same window gives the same bits wherever it runs
         assert out[0][k][2] == out[0][k % 8][2] and np.array_equal(out[0][k][3], out[0][k % 8][3])
+
+
+def test_mixed_batch_td_and_plain_windows(gpu):
+    """one chain-layout batch holding ESTIMATE_TD windows and plain windows (two plans, the kernel instance with ProjectionTdFactor runs
+    both): every window ends where it ends in a batch of its own (to rounding: a plain window alone takes the cooperative plan, whose
+    chunks -- the order of the sums -- differ), and twice the same window in the batch gives twice the same bits"""
+    wt = td_window(31, TR=0.02)
+    wp = dict(td_window(32)); wp.pop("td")
+    def solve(ws):
+        Ws = [gpu.Window(w) for w in ws]
+        b = gpu.Batch(Ws)
+        assert b.plan_stats()["layout"] == "chain"
+        b.solve(gpu.default_options(8, True)); b.synchronize(); b.download_states()
+        return [(s.final_cost, W.pose.copy(), W.sb.copy()) for s, W in zip(b.summaries(), Ws)], b.plan_stats()["num_plans"]
+    mixed, nplans = solve([wt, wp, wt, wp])
+    assert nplans == 2
+    (alone_t,), _ = solve([wt])
+    (alone_p,), _ = solve([wp])
+    for got, want in ((mixed[0], alone_t), (mixed[2], alone_t), (mixed[1], alone_p), (mixed[3], alone_p)):
+        assert abs(got[0] - want[0]) < 1e-11 * want[0] and rel(got[1], want[1]) < 1e-10 and rel(got[2], want[2]) < 1e-10
+    for a, b in ((0, 2), (1, 3)):
+        assert mixed[a][0] == mixed[b][0] and np.array_equal(mixed[a][1], mixed[b][1]) and np.array_equal(mixed[a][2], mixed[b][2])
