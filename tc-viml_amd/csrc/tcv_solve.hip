@@ -1577,8 +1577,8 @@ __device__ __noinline__ void back_subst(TCV_CTX_PARAMS, int nc) {
 //   column owners         thread c < npp + 1 owns column c of W for the whole elimination: w_s = L_ss^-1 (b_s - L_s,s-1 w_s-1) with
 //   (waves 0, 1)          w_s-1 in registers -- no cross-lane traffic, L blocks read from LDS as broadcasts; w_s goes to an LDS buffer
 //                         for the matrix cores and to the spill area for the back-substitution;
-//   matrix cores          S -= W_s-1' W_s-1 on v_mfma_f64_16x16x4 over the tile pairs that hold coupled columns (waves 0, 1, 2; the
-//                         column owners once their w_s is out).
+//   matrix cores          S -= W_s-1' W_s-1 on v_mfma_f64_16x16x4 over the tile pairs that hold coupled columns (wave 2, which has no
+//                         other duty).
 // Every quantity is the one the textbook right-looking block Cholesky in this order produces; only the schedule differs.
 // q accumulates u' H u over the original entries of E and B (Cauchy point).
 // LDS pool during the chain: [W buffer 0 | W buffer 1 | per step L_ss, 1/diag, L_next | T workspace | step records]
