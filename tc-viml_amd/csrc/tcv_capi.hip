@@ -559,7 +559,6 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
         for (int w = 0; w < n; w++) fmax = std::max(fmax, problems[w]->proj.size() + problems[w]->line.size());
         if (want < 0) want = fmax >= 96 ? std::min<int>(COOP_MAX_H, std::max<int>(2, (int)((fmax + 95) / 96))) : 0;
         want = std::min(want, (int)COOP_MAX_H);
-        for (int w = 0; w < n; w++) for (auto &f : problems[w]->proj) if (f.btd >= 0) { want = 0; break; }      // the cooperative kernel has no ProjectionTdFactor
         while (want > 0 && (long long)n * (1 + want) > n_cu) want--;
         if (want == 1 && g_coop_helpers < 0 && !getenv("TCV_COOP_H")) want = 0;      // a single helper is not worth the hand-offs
         coop_h = want;

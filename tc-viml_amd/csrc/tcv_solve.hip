@@ -1193,7 +1193,7 @@ __device__ __noinline__ CoopLin linearize_coop(TCV_CTX_PARAMS, gbl_i *cx_ctl_, g
 // A helper workgroup of group g: serves the master's linearisation requests until it is told to leave.  Its LDS is carved like the
 // master's (pose tiles | pool | vectors) plus a second tile set for the Schur values; its scratch pointers are the MASTER's (landmark
 // pivots, couplings and scales are written where the master's back-substitution reads them).
-template <int NT>
+template <int NT, bool TD = false>
 __device__ __noinline__ void coop_helper(const SolveArgs &A, lds_d *lds, int g_, int h_) {
     const int tid = threadIdx.x;
     // arguments of a non-inlined function arrive in vector registers: made uniform by hand, or every loop over them becomes an exec-mask loop
@@ -1273,7 +1273,7 @@ __device__ __noinline__ void coop_helper(const SolveArgs &A, lds_d *lds, int g_,
             }
             double cost_pt = 0.0, cost_ln = 0.0;
             COOP_MARKW(C, h, 3 + (seq << 4));
-            vis_part1<NT, true>(K1, K.xs, ch, assemble, cost_pt, cost_ln);      // (starts with a barrier: the zeroing above is ordered before the gathers)
+            vis_part1<NT, true, TD>(K1, K.xs, ch, assemble, cost_pt, cost_ln);      // (starts with a barrier: the zeroing above is ordered before the gathers)
             COOP_MARKW(C, h, 4 + (seq << 4));
             if (assemble) {
                 vis_part2<NT, true>(K2, ch, first, mu);
@@ -2288,7 +2288,7 @@ __global__ void __launch_bounds__(NT) __attribute__((disable_tail_calls)) __attr
         const int blk8 = (int)blockIdx.x / G8, r8 = (int)blockIdx.x - blk8 * G8;
         const int member = r8 >> 3, g = blk8 * 8 + (r8 & 7);
         if (g >= A.coop_groups) return;
-        if (member > 0) { coop_helper<NT>(A, lds, g, member - 1); return; }
+        if (member > 0) { coop_helper<NT, TD>(A, lds, g, member - 1); return; }
         slot = g; wstride = A.coop_groups;
     }
     Ctx<NT> C;
@@ -2603,9 +2603,10 @@ __global__ void __launch_bounds__(NT) __attribute__((disable_tail_calls)) __attr
 extern "C" int tcv_launch_solve_coop(const tcv::SolveArgs *args, int grid, size_t lds_bytes, void *stream) {
     using namespace tcv;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipFuncSetAttribute((const void *)solve_kernel<256, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    // (one instance for plain and ESTIMATE_TD windows: the helpers' factor evaluation is the only place that tells them apart)
+    hipError_t e = hipFuncSetAttribute((const void *)solve_kernel<256, true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((solve_kernel<256, true, true, true>), dim3(grid), dim3(256), lds_bytes, st, *args);
+    hipLaunchKernelGGL((solve_kernel<256, true, true, true, true>), dim3(grid), dim3(256), lds_bytes, st, *args);
     return (int)hipGetLastError();
 }
 #elif defined(TCV_SOLVE_CHAIN_TD_TU)
@@ -2634,8 +2635,8 @@ extern "C" int tcv_launch_solve_coop(const tcv::SolveArgs *args, int grid, size_
 extern "C" int tcv_launch_solve_chain_td(const tcv::SolveArgs *args, int grid, size_t lds_bytes, void *stream);
 extern "C" int tcv_launch_solve(const tcv::SolveArgs *args, int grid, int nthreads, size_t lds_bytes, void *stream) {
     using namespace tcv;
-    if (args->chain && args->chain_td) return tcv_launch_solve_chain_td(args, grid, lds_bytes, stream);
     if (args->chain && args->coop_h > 0) return tcv_launch_solve_coop(args, grid, lds_bytes, stream);
+    if (args->chain && args->chain_td) return tcv_launch_solve_chain_td(args, grid, lds_bytes, stream);
     if (args->chain) return tcv_launch_solve_chain(args, grid, lds_bytes, stream);
     hipStream_t st = (hipStream_t)stream;
     hipError_t e;

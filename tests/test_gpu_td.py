@@ -131,3 +131,21 @@ def test_mixed_batch_td_and_plain_windows(gpu):
         assert abs(got[0] - want[0]) < 1e-11 * want[0] and rel(got[1], want[1]) < 1e-10 and rel(got[2], want[2]) < 1e-10
     for a, b in ((0, 2), (1, 3)):
         assert mixed[a][0] == mixed[b][0] and np.array_equal(mixed[a][1], mixed[b][1]) and np.array_equal(mixed[a][2], mixed[b][2])
+
+
+def test_td_window_in_cooperative_mode_gives_the_same_bits(gpu):
+    """a single ESTIMATE_TD window runs on 1 + H workgroups like every other small batch (the helpers evaluate the ProjectionTdFactors);
+    the same plan on one workgroup (the chain kernel instance with ProjectionTdFactor) gives the same bits"""
+    w = td_window(41, TR=0.02)
+    res = {}
+    for wg in (0, 1):
+        W = gpu.Window(w); b = gpu.Batch([W])
+        assert b.plan_stats()["layout"] == "chain"
+        b.solve(gpu.default_options(8, True, workgroups_per_window=wg)); b.synchronize(); b.download_states()
+        s = b.summaries()[0]
+        res[wg] = (b.cooperative(), s.final_cost, [s.cost[i] for i in range(9)], W.pose.copy(), W.sb.copy(), W.lam.copy(), float(W.td[0]))
+    co = res[0][0]
+    assert co["helpers"] >= 2 and co["last_solve_workgroups"] == 1 + co["helpers"] and res[1][0]["last_solve_workgroups"] == 1, co
+    assert res[0][1] == res[1][1] and res[0][2] == res[1][2] and res[0][6] == res[1][6]
+    for k in (3, 4, 5):
+        assert np.array_equal(res[0][k], res[1][k])
