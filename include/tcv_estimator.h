@@ -77,6 +77,10 @@ int tcv_estimators_optimize(tcv_estimator *const *e, int n);
 /* failureDetection, the published state (Ps / Rs / Vs[WINDOW_SIZE], quaternion x y z w) and slideWindow.
  * TCV_ERR_NUMERIC: failure detection fired (the reference would reset the estimator). */
 int tcv_estimator_finish_frame(tcv_estimator *e, double P[3], double q_xyzw[4], double V[3]);
+/* Estimator::clearState() + setParameter() (estimator.cpp:126-189, :39-52; estimator_node.cpp:437-446 after a failure): drops the
+ * window, the IMU buffers, every feature / line track, the marginalisation prior and the biases; configuration and line map stay.
+ * "Reset it" above means this call (or destroy + create). */
+int tcv_estimator_reset(tcv_estimator *e);
 int tcv_estimator_get_stats(const tcv_estimator *e, tcv_estimator_stats *out);
 /* host-side time accounting of tcv_estimators_optimize since the last call (seconds): out8 = pre-integration, association +
  * triangulation + window, problem construction, batch_create (pack + H2D), kernels (launch to sync), downloads, apply / prior

@@ -22,11 +22,38 @@
 extern "C" int tcv_launch_solve(const tcv::SolveArgs *args, int grid, int nthreads, size_t lds_bytes, void *stream);
 extern "C" int tcv_solve_scratch_doubles(void);
 static int g_solver_variant = 0;   // 0: chain layout when the graph allows it, 1: always the dense 171-dim layout
-// CUs claimed by cooperative launches in flight, per device: a cooperative kernel spins on its partners, so all cooperative grids in
-// flight together must fit the chip (two half-resident cooperative kernels could wait for each other's CUs until their timeouts)
-static std::atomic<int> g_coop_claimed[64];
+// CUs claimed by cooperative launches in flight, per device AND per XCD: a cooperative kernel spins on its partners, so all cooperative
+// grids in flight together must be resident (two half-resident cooperative kernels could wait for each other's CUs until their
+// timeouts).  The members of a group share an XCD -- workgroup b of a launch is dispatched to XCD b % 8 and solve_kernel makes the
+// members of group g the workgroups with b % 8 == (g + rot) % 8 -- so the budget that counts is the XCD's (n_cu / 8 CUs), not the
+// chip's: five one-window batches of eight workgroups each, all starting at XCD 0, would pass a chip-wide count (40 of 256) and
+// sit half-resident on that XCD's 32 CUs.  A launch therefore (1) rotates its groups so that its first group lands on the XCD with the
+// fewest claimed CUs (SolveArgs::coop_rot) and (2) is admitted only if every XCD keeps its claims within its CUs.
+static std::mutex g_coop_mu;
+static int g_coop_claimed[64][8];
 static void coop_release(tcv_batch *b) {
-    if (b->coop_claim > 0) { g_coop_claimed[b->coop_dev & 63].fetch_sub(b->coop_claim); b->coop_claim = 0; }
+    if (b->coop_claim > 0) {
+        std::lock_guard<std::mutex> g(g_coop_mu);
+        for (int x = 0; x < 8; x++) g_coop_claimed[b->coop_dev & 63][x] -= b->coop_claim_xcd[x];
+        b->coop_claim = 0;
+    }
+}
+// admission of a cooperative launch of `groups` groups of `wg` workgroups each: fills b->coop_claim_xcd / coop_rot and returns true, or
+// leaves the table untouched and returns false (the caller then runs the same plan on one workgroup per window: same bits)
+static bool coop_admit(tcv_batch *b, int groups, int wg) {
+    std::lock_guard<std::mutex> g(g_coop_mu);
+    int *cl = g_coop_claimed[b->coop_dev & 63];
+    const int per_xcd = std::max(1, b->n_cu / 8);
+    int rot = 0;
+    for (int x = 1; x < 8; x++) if (cl[x] < cl[rot]) rot = x;
+    int need[8];
+    for (int x = 0; x < 8; x++) need[x] = 0;
+    for (int q = 0; q < 8; q++) need[(q + rot) & 7] = wg * ((groups + 7 - q) / 8);      // groups g = q, q + 8, ... land on XCD (q + rot) % 8
+    for (int x = 0; x < 8; x++) if (cl[x] + need[x] > per_xcd) return false;
+    int total = 0;
+    for (int x = 0; x < 8; x++) { cl[x] += need[x]; b->coop_claim_xcd[x] = need[x]; total += need[x]; }
+    b->coop_claim = total; b->coop_rot = rot;
+    return true;
 }
 static int g_coop_helpers = -1;    // cooperative mode of small batches: -1 automatic, 0 off, h >= 1: h helper workgroups per window (when the batch allows it)
 extern "C" int tcv_launch_marg(const void *args, int grid, size_t lds_bytes, void *stream);
@@ -559,7 +586,7 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
         for (int w = 0; w < n; w++) fmax = std::max(fmax, problems[w]->proj.size() + problems[w]->line.size());
         if (want < 0) want = fmax >= 96 ? std::min<int>(COOP_MAX_H, std::max<int>(2, (int)((fmax + 95) / 96))) : 0;
         want = std::min(want, (int)COOP_MAX_H);
-        while (want > 0 && (long long)n * (1 + want) > n_cu) want--;
+        while (want > 0 && (long long)((n + 7) / 8) * (1 + want) > n_cu / 8) want--;      // the groups of a launch are dealt round-robin to the XCDs: per XCD ceil(n / 8) groups on n_cu / 8 CUs
         if (want == 1 && g_coop_helpers < 0 && !getenv("TCV_COOP_H")) want = 0;      // a single helper is not worth the hand-offs
         coop_h = want;
     }
@@ -678,7 +705,7 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
     b->n_cu = n_cu; b->coop_dev = dev;
     if (b->chain && coop_h > 0) {
         b->coop_h = coop_h;
-        b->coop_groups = std::min(n, n_cu / (1 + coop_h));
+        b->coop_groups = std::min(n, 8 * std::max(1, (n_cu / 8) / (1 + coop_h)));      // whole groups per XCD
         b->slots = b->coop_groups;
         b->grid = (1 + coop_h) * ((b->coop_groups + 7) & ~7);
         b->lds_bytes = (size_t)LDS_DOUBLES * 8;
@@ -687,21 +714,24 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
         b->coop_exp_stride = 2 * te_max + COOP_EXP_VEC;
     }
     const int scr = tcv_solve_scratch_doubles() + b->hcl_cap;
+    hipStream_t ust = tcv::util_stream();
+    // error exits from here on: the asynchronous upload below may still be reading the pinned staging buffer and writing the device blob --
+    // both go back to pools another host thread takes from -- so the stream is drained before anything is released
+    auto bail = [&]() { (void)(ust ? hipStreamSynchronize(ust) : hipDeviceSynchronize()); host_staging_release(h_dpool); h_dpool = nullptr; batch_free(b); };
 #define UP(dst, src, T, cnt)                                                                          \
     do {                                                                                              \
         hipError_t e_ = tcv::dev_malloc((void **)&dst, sizeof(T) * std::max<size_t>(1, (cnt)));             \
-        if (e_ != hipSuccess) { host_staging_release(h_dpool); batch_free(b); return hip_fail(e_, "hipMalloc"); }                    \
+        if (e_ != hipSuccess) { bail(); return hip_fail(e_, "hipMalloc"); }                    \
         if (src) {                                                                                    \
             e_ = hipMemcpy(dst, src, sizeof(T) * (cnt), hipMemcpyHostToDevice);                       \
-            if (e_ != hipSuccess) { host_staging_release(h_dpool); batch_free(b); return hip_fail(e_, "hipMemcpy H2D"); }            \
+            if (e_ != hipSuccess) { bail(); return hip_fail(e_, "hipMemcpy H2D"); }            \
         }                                                                                             \
     } while (0)
-    hipStream_t ust = tcv::util_stream();
     if (marg_problems) {      // the marginalisation problems first: which IMU factor's sqrt_info the solve exports is part of the window headers
         hipError_t e_ = tcv::dev_malloc((void **)&b->d_sqrt_out, sizeof(double) * (size_t)n * 225);
-        if (e_ != hipSuccess) { host_staging_release(h_dpool); batch_free(b); return hip_fail(e_, "hipMalloc"); }
+        if (e_ != hipSuccess) { bail(); return hip_fail(e_, "hipMalloc"); }
         const int rc = tcv_marg_attach(b, marg_problems, marg_drop, marg_num_drop);
-        if (rc != TCV_OK) { host_staging_release(h_dpool); batch_free(b); return rc; }
+        if (rc != TCV_OK) { bail(); return rc; }
         for (int w = 0; w < n; w++) b->wins[w].sqrt_export = tcv_marg_sqrt_source(b, w);
     }
     {
@@ -712,7 +742,7 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
         if (!ipool.empty()) std::memcpy(hb + o_ipool, ipool.data(), sizeof(int) * ipool.size());
         hipError_t e_ = tcv::dev_malloc(&b->d_input, in_bytes);
         if (e_ == hipSuccess) e_ = hipMemcpyAsync(b->d_input, hb, in_bytes, hipMemcpyHostToDevice, ust);
-        if (e_ != hipSuccess) { host_staging_release(h_dpool); batch_free(b); return hip_fail(e_, "upload of the batch"); }
+        if (e_ != hipSuccess) { bail(); return hip_fail(e_, "upload of the batch"); }
         char *db = (char *)b->d_input;
         b->d_dpool = (double *)db; b->d_win = (WinHdr *)(db + o_win); b->d_plans = (PlanHdr *)(db + o_plans);
         b->d_plan_base = (long long *)(db + o_pbase); b->d_ipool = (int *)(db + o_ipool);
@@ -736,7 +766,10 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
     if (e0 == hipSuccess) e0 = hipMemsetAsync(b->d_scratch, 0, sizeof(double) * (size_t)b->slots * scr, ust);
     if (e0 == hipSuccess) e0 = hipMemsetAsync(b->d_summary, 0, sizeof(DevSummary) * (size_t)n, ust);
     if (e0 == hipSuccess) e0 = hipMemsetAsync(b->d_delta, 0, sizeof(double) * (size_t)n * b->delta_stride, ust);
-    if (e0 == hipSuccess) e0 = ust ? hipStreamSynchronize(ust) : hipDeviceSynchronize();      // the batch is complete on the device before any stream uses it
+    {      // the batch is complete on the device before any stream uses it (and the upload is drained before its staging buffer is released, whatever the memsets returned)
+        const hipError_t es = ust ? hipStreamSynchronize(ust) : hipDeviceSynchronize();
+        if (e0 == hipSuccess) e0 = es;
+    }
     host_staging_release(h_dpool);
     h_dpool = nullptr;
     if (e0 != hipSuccess) { batch_free(b); return hip_fail(e0, "upload of the batch"); }
@@ -795,18 +828,13 @@ extern "C" int tcv_batch_solve(tcv_batch *b, const tcv_solver_options *o, void *
     a.sqrt_out = b->d_sqrt_out;
     // cooperative plans also run on the single-workgroup kernel (workgroups_per_window = 1): same chunks, same additions, same bits
     bool coop = b->coop_h > 0 && o->workgroups_per_window != 1;
-    if (coop && b->coop_claim == 0) {      // (a claim still held: the previous cooperative solve of this batch, same stream order)
-        const int want = (1 + b->coop_h) * b->coop_groups;
-        if (g_coop_claimed[b->coop_dev & 63].fetch_add(want) + want > b->n_cu) {
-            g_coop_claimed[b->coop_dev & 63].fetch_sub(want);
-            coop = false;      // the chip is taken by other cooperative launches: the same plan on one workgroup per window, the same bits
-        } else b->coop_claim = want;
-    }
+    if (coop && b->coop_claim == 0)      // (a claim still held: the previous cooperative solve of this batch, same stream order, same rotation)
+        if (!coop_admit(b, b->coop_groups, 1 + b->coop_h)) coop = false;      // the XCDs are taken by other cooperative launches: the same plan on one workgroup per window, the same bits
     int grid = b->grid;
     b->last_wg = coop ? 1 + b->coop_h : 1;
     if (coop) {
         a.coop_h = b->coop_h; a.coop_groups = b->coop_groups; a.coop_exp_chunks = b->coop_exp_chunks; a.coop_exp_stride = b->coop_exp_stride;
-        a.coop_ctl = b->d_coop_ctl; a.coop_x = b->d_coop_x; a.coop_exp = b->d_coop_exp;
+        a.coop_ctl = b->d_coop_ctl; a.coop_x = b->d_coop_x; a.coop_exp = b->d_coop_exp; a.coop_rot = b->coop_rot;
         int dev = 0, khz = 0;
         hipGetDevice(&dev);
         if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;
@@ -921,16 +949,21 @@ extern "C" int tcv_batch_get_first_step(tcv_batch *b, int window, double *out, i
 }
 extern "C" int tcv_batch_get_prior(tcv_batch *b, int window, tcv_prior **out) {
     if (!b || !out) return TCV_ERR_INVALID;
+    if (b->pending) if (int rc = tcv_batch_synchronize(b)) return rc;
     return tcv_marg_get_prior(b, window, out);
 }
 extern "C" int tcv_batch_get_priors(tcv_batch *b, tcv_prior **out, int n) {
     if (!b || !out || n != b->n) { set_error("batch_get_priors: n must be the batch size"); return TCV_ERR_INVALID; }
     for (int k = 0; k < n; k++) out[k] = nullptr;
+    // (the per-window fallback of tcv_marg_get_prior copies on the null stream, which is not ordered behind a marginalisation launched on a
+    // non-blocking stream: wait for the batch's own streams first)
+    if (b->pending) if (int rc = tcv_batch_synchronize(b)) return rc;
     const tcv::HostOp host_op;
     const int nth = host_op.threads(std::max(1, std::min(n / 16, 8)));
     std::vector<int> rcs(nth, TCV_OK);
     std::vector<std::string> msgs(nth);
     auto work = [&](int t) {
+        if (nth > 1) (void)hipSetDevice(b->coop_dev);      // a new thread starts on device 0: the batch's buffers live on its own device
         for (int k = t; k < n; k += nth) {
             const int rc = tcv_marg_get_prior(b, k, &out[k]);
             if (rc != TCV_OK) { rcs[t] = rc; msgs[t] = tcv_last_error(); return; }

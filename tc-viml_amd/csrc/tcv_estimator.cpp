@@ -545,15 +545,38 @@ void slide_window(tcv_estimator *e) {
 
 }  // namespace
 
+static void clear_state(tcv_estimator *e) {
+    const tcv_estimator_config *cfg = &e->cfg;
+    for (int i = 0; i <= W; i++) {
+        e->Ps[i] = e->Vs[i] = e->Bas[i] = e->Bgs[i] = V3{0, 0, 0}; e->Rs[i] = eye(); e->pre_valid[i] = false; std::memset(&e->pre[i], 0, sizeof e->pre[i]);
+        e->bufs[i] = ImuBuf(); e->line_obs[i].clear(); e->fov[i].clear();
+    }
+    for (int c = 0; c < 3; c++) e->tic[c] = cfg->tic[c];
+    std::memcpy(e->ric.data(), cfg->ric, sizeof(double) * 9);
+    std::memset(&e->stats, 0, sizeof e->stats);
+    e->features.clear(); e->linefeatures.clear(); e->fov_ready = false;
+    if (e->prior) { tcv_prior_destroy(e->prior); e->prior = nullptr; }
+    e->prior_blocks.clear();
+    e->frame_count = 0; e->marg_flag = MARGIN_OLD;
+    e->have_acc0 = false; e->have_last = false;
+    e->acc_0 = e->gyr_0 = e->last_P = V3{0, 0, 0};
+    e->para_feature.clear(); e->sel.clear();
+    e->n_line_obs_total = 0; e->phase = 0; e->opt_failed = 0; e->opt_msg.clear();
+}
 extern "C" int tcv_estimator_create(tcv_estimator **out, const tcv_estimator_config *cfg) {
     if (!out || !cfg || !(cfg->imu_dt > 0) || !(cfg->focal_length > 0) || cfg->num_iterations < 1) { tcv::set_error("estimator_create: bad configuration"); return TCV_ERR_INVALID; }
     tcv_estimator *e = new tcv_estimator();
     e->cfg = *cfg;
-    for (int i = 0; i <= W; i++) { e->Ps[i] = e->Vs[i] = e->Bas[i] = e->Bgs[i] = V3{0, 0, 0}; e->Rs[i] = eye(); e->pre_valid[i] = false; std::memset(&e->pre[i], 0, sizeof e->pre[i]); }
-    for (int c = 0; c < 3; c++) e->tic[c] = cfg->tic[c];
-    std::memcpy(e->ric.data(), cfg->ric, sizeof(double) * 9);
-    std::memset(&e->stats, 0, sizeof e->stats);
+    clear_state(e);
     *out = e;
+    return TCV_OK;
+}
+// Estimator::clearState() + setParameter() (estimator.cpp:126-189, :39-52): what estimator_node.cpp does after failureDetection fired
+// (:437-446) or on a restart request -- window, IMU buffers, pre-integrations, feature and line tracks, the marginalisation prior and the
+// biases are dropped, the extrinsic goes back to the configured one; the line map (setParameters, :54-124) stays.
+extern "C" int tcv_estimator_reset(tcv_estimator *e) {
+    if (!e) return TCV_ERR_INVALID;
+    clear_state(e);
     return TCV_OK;
 }
 extern "C" void tcv_estimator_destroy(tcv_estimator *e) {
@@ -696,8 +719,8 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
         int rc = TCV_OK;
     };
     Group G[2];
-    // (the uploads inside tcv_batch_create are host-synchronous hipMemcpy calls: they are complete before any kernel is launched on
-    // these non-blocking streams)
+    // (tcv_batch_create uploads asynchronously on the calling thread's utility stream and waits for THAT stream before it returns: the
+    // batch is complete on the device before any kernel is launched on these non-blocking streams)
     std::array<hipStream_t, 2> g_streams = device_streams();
     static const bool one_stream = getenv("TCV_EST_ONE_STREAM") != nullptr;      // tuning experiment: both batches of a frame on one stream
     if (one_stream) g_streams[1] = g_streams[0];

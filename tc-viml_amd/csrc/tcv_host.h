@@ -112,6 +112,7 @@ struct tcv_batch {
     int coop_h = 0, coop_groups = 0, slots = 0;
     int last_wg = 0;                              // workgroups per window of the last solve (1: single-workgroup kernel)
     int n_cu = 0, coop_claim = 0, coop_dev = 0;   // CUs of the device; CUs this batch's cooperative launch in flight has claimed (tcv_batch_solve)
+    int coop_claim_xcd[8] = {0, 0, 0, 0, 0, 0, 0, 0}, coop_rot = 0;   // the claim per XCD; XCD of the launch's first group (tcv_capi.hip coop_admit)
     int coop_exp_chunks = 0, coop_exp_stride = 0;
     int *d_coop_ctl = nullptr;
     double *d_coop_x = nullptr, *d_coop_exp = nullptr;

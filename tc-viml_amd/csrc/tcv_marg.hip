@@ -1999,7 +1999,9 @@ int tcv_marg_attach(tcv_batch *b, tcv_problem *const *marg_problems, double *con
     const size_t o_hdr = up16(sizeof(double) * std::max<size_t>(1, d_total)), o_int = up16(o_hdr + sizeof(MargHdr) * hdrs.size());
     const size_t in_bytes = up16(o_int + sizeof(int) * std::max<size_t>(1, i_total));
     char *h_in = (char *)tcv::host_staging_acquire(in_bytes);
-    struct Staged { void *a; ~Staged() { tcv::host_staging_release(a); } } staged{h_in};
+    // (released at every exit; once the asynchronous upload has been issued the stream is drained first: the pinned buffer goes back to a
+    // pool another host thread takes from)
+    struct Staged { void *a; hipStream_t st; bool in_flight; ~Staged() { if (in_flight) (void)(st ? hipStreamSynchronize(st) : hipDeviceSynchronize()); tcv::host_staging_release(a); } } staged{h_in, nullptr, false};
     if (!h_in) { set_error("hipHostMalloc (upload staging) failed"); return TCV_ERR_HIP; }
     int *h_I = (int *)(h_in + o_int);
     double *h_D = (double *)h_in;
@@ -2032,12 +2034,12 @@ int tcv_marg_attach(tcv_batch *b, tcv_problem *const *marg_problems, double *con
     {
         hipStream_t ust = tcv::util_stream();
         hipError_t e_ = tcv::dev_malloc(&s->d_input, in_bytes);
-        if (e_ == hipSuccess) e_ = hipMemcpyAsync(s->d_input, h_in, in_bytes, hipMemcpyHostToDevice, ust);
+        if (e_ == hipSuccess) { staged.st = ust; staged.in_flight = true; e_ = hipMemcpyAsync(s->d_input, h_in, in_bytes, hipMemcpyHostToDevice, ust); }
         if (e_ == hipSuccess) e_ = tcv::dev_malloc((void **)&s->d_out, sizeof(double) * std::max<size_t>(1, (size_t)b->n * MARG_OUT_STRIDE));
         if (e_ == hipSuccess) e_ = tcv::dev_malloc((void **)&s->d_status, sizeof(int) * (size_t)b->n);
         if (e_ == hipSuccess) e_ = tcv::dev_malloc((void **)&s->d_scratch, sizeof(double) * (size_t)s->grid * MARG_SCR_STRIDE);
         if (e_ == hipSuccess) e_ = hipMemsetAsync(s->d_status, 0xff, sizeof(int) * b->n, ust);
-        if (e_ == hipSuccess) e_ = ust ? hipStreamSynchronize(ust) : hipDeviceSynchronize();
+        if (e_ == hipSuccess) { e_ = ust ? hipStreamSynchronize(ust) : hipDeviceSynchronize(); if (e_ == hipSuccess) staged.in_flight = false; }
         if (e_ != hipSuccess) return hip_fail(e_, "upload of the marginalisation problems");
         s->d_dpool = (double *)s->d_input; s->d_hdr = (MargHdr *)((char *)s->d_input + o_hdr); s->d_ipool = (int *)((char *)s->d_input + o_int);
     }

@@ -83,8 +83,11 @@ struct DestKey {
 };
 // Destinations of one gather program with their item lists, in insertion order (deterministic).  Flat storage: the packer builds two of
 // these per visual chunk for every cold window, and a hash map plus one vector per destination was most of its time.  Destination ids come
-// from a direct-index table over (kind, o0, o1) -- thread-local, validated by a generation stamp instead of being cleared --, the items are
-// appended as (id, item) pairs and bucketed by a stable counting sort in finish().
+// from a direct-index table over (kind, o0, o1) -- validated by a generation stamp instead of being cleared --, the items are appended as
+// (id, item) pairs and bucketed by a stable counting sort in finish().  Every live list owns a table of its own (two lists of one chunk
+// are alive together: with a shared table an add() to the first after the second had stamped the same slot would silently open a duplicate
+// destination); the tables (0.8 MB each) come from a process-wide pool, so the packing threads a tcv_batch_create starts do not allocate
+// and zero them again.
 struct DestList {
     std::vector<DestKey> keys;                 // insertion order
     std::vector<std::pair<int, int>> shape;    // (la, lb); lb = 0: triangle of la
@@ -92,15 +95,32 @@ struct DestList {
     std::vector<int> start, items;             // after finish(): items of destination id = items[start[id] .. start[id + 1])
     enum { T_TILE = 0, T_G = 176 * 176, T_RC = T_G + 256, T_HLL = T_RC + 256, T_HCL = T_HLL + 2048, T_SIZE = T_HCL + 65536 };
     struct Table { std::vector<unsigned> stamp; std::vector<int> val; unsigned gen = 0; Table() : stamp(T_SIZE, 0u), val(T_SIZE, 0) {} };
-    static Table &table() { thread_local Table t; return t; }
+    struct Pool { std::mutex mu; std::vector<Table *> idle; ~Pool() { for (Table *t : idle) delete t; } };
+    static Pool &pool() { static Pool p; return p; }
+    Table *tab;
     unsigned gen;
     bool overflow = false;                     // a key outside the table (reported by the caller as a field overflow)
-    DestList() {
-        Table &t = table();
+    DestList() : tab(nullptr) {
+        {
+            Pool &P = pool();
+            std::lock_guard<std::mutex> g(P.mu);
+            if (!P.idle.empty()) { tab = P.idle.back(); P.idle.pop_back(); }
+        }
+        if (!tab) tab = new Table();
+        Table &t = *tab;
         if (++t.gen == 0) { std::fill(t.stamp.begin(), t.stamp.end(), 0u); t.gen = 1; }
         gen = t.gen;
         keys.reserve(2048); shape.reserve(2048); pair_id.reserve(16384); pair_item.reserve(16384);
     }
+    ~DestList() {
+        Pool &P = pool();
+        std::lock_guard<std::mutex> g(P.mu);
+        if (P.idle.size() < 64) { P.idle.push_back(tab); tab = nullptr; }
+        delete tab;
+    }
+    DestList(const DestList &) = delete;
+    DestList &operator=(const DestList &) = delete;
+    Table &table() { return *tab; }
     void add(int kind, int o0, int o1, int la, int lb, int item) {
         int slot = -1;
         if (kind == DK_TILE) { if (o0 >= 0 && o0 < 176 && o1 >= 0 && o1 < 176) slot = T_TILE + o0 * 176 + o1; }

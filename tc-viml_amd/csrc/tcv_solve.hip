@@ -2286,7 +2286,7 @@ __global__ void __launch_bounds__(NT) __attribute__((disable_tail_calls)) __attr
     if (COOP) {
         const int G8 = 8 * (1 + A.coop_h);      // workgroups of a block of eight groups: contiguous in dispatch order, one group per XCD
         const int blk8 = (int)blockIdx.x / G8, r8 = (int)blockIdx.x - blk8 * G8;
-        const int member = r8 >> 3, g = blk8 * 8 + (r8 & 7);
+        const int member = r8 >> 3, g = blk8 * 8 + ((r8 - A.coop_rot) & 7);      // (workgroup b runs on XCD b % 8: the host picks the rotation, tcv_capi.hip coop_admit)
         if (g >= A.coop_groups) return;
         if (member > 0) { coop_helper<NT, TD>(A, lds, g, member - 1); return; }
         slot = g; wstride = A.coop_groups;

@@ -817,6 +817,21 @@ class NativeLockstep:
             self.rngs.append(rng); self.outs.append(dict(t=[], p=[], q=[], v=[], log=[]))
         self.n_frames = max(len(st["t"]) for st in streams)
         self._frames = [dict() for _ in streams]      # per stream: frame -> the begin_frame arguments as C-contiguous arrays (prepare())
+        self._bias_sigma = bias_sigma
+
+    def reset(self):
+        """tcv_estimator_reset on every estimator (Estimator::clearState + setParameter) and the replay's own bookkeeping back to frame 0:
+        stepping through the streams again must reproduce the first pass bit for bit"""
+        L, P = self.L, self._P
+        L.tcv_estimator_reset.argtypes = [self.vp]
+        self.rngs, self.outs = [], []
+        for st, h in zip(self.streams, self.ests):
+            self.tcv.check(L.tcv_estimator_reset(h))
+            rng = np.random.Generator(np.random.PCG64(0xABCD))
+            ba = self._f64(st["ba"] + rng.normal(size=3) * self._bias_sigma[0]); bg = self._f64(st["bg"] + rng.normal(size=3) * self._bias_sigma[1])
+            self.tcv.check(L.tcv_estimator_set_biases(h, P(ba), P(bg)))
+            self.rngs.append(rng); self.outs.append(dict(t=[], p=[], q=[], v=[], log=[]))
+        self._frames = [dict() for _ in self.streams]
 
     def prepare(self, k0: int = 0, k1: int = None):
         """converts the per-frame front-end records (dicts / lists of the simulated streams) of frames [k0, k1) into the contiguous arrays

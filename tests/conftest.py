@@ -27,8 +27,11 @@ def built():
 
 
 @pytest.fixture(scope="session")
-def gpu(built):
+def gpu(built, request):
     import tcv
+    if any(os.path.basename(str(it.fspath)) in ("test_gpu_replay.py", "test_gpu_teacher.py") for it in request.session.items):
+        import replay_cache
+        replay_cache.prefetch()          # CPU worker processes for the oracle replays, started before this process touches the device
     if tcv.lib().tcv_device_count() < 1:
         pytest.fail("no HIP device visible: GPU tests must run on the GPU box (the product has no CPU fallback)")
     return tcv

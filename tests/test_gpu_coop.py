@@ -117,3 +117,42 @@ def test_cooperative_launches_in_flight_must_fit_the_chip(gpu):
         b.synchronize()
     finally:
         gpu.check(gpu.lib().tcv_set_cooperative(-1))
+
+
+def test_concurrent_one_window_cooperative_launches_spread_over_the_xcds(gpu):
+    """the members of a cooperative group share an XCD (workgroup b of a launch is dispatched to XCD b % 8), so the budget a launch is
+    admitted against is the XCD's 32 CUs, not the chip's 256: one-window batches with seven helpers each (8 workgroups, a whole CU's LDS
+    each) launched on distinct streams without waiting -- the direct batch-API use of many estimators -- are rotated over the XCDs
+    (`SolveArgs::coop_rot`: the first group of a launch goes to the XCD with the fewest claimed CUs), 4 per XCD = 32 fit the chip, the
+    next ones run the same plan on one workgroup per window.  None waits for partners that cannot be dispatched (status -9 /
+    termination FAILURE after the 2 s timeout), all give the bits of the single-workgroup run."""
+    hip = C.CDLL("libamdhip64.so")
+    n = 36
+    win = synth.window_at(synth.make_windows(955, 1), 0)
+    o = gpu.default_options(8, True)
+    streams = [C.c_void_p() for _ in range(n)]
+    try:
+        gpu.check(gpu.lib().tcv_set_cooperative(7))
+        Wr, br, sr = _solve(gpu, [win], 8, True, 1)
+        for st in streams:
+            assert hip.hipStreamCreateWithFlags(C.byref(st), 1) == 0      # hipStreamNonBlocking
+        Ws = [[gpu.Window(win)] for _ in range(n)]
+        bs = [gpu.Batch(w) for w in Ws]
+        assert all(b.cooperative()["helpers"] == 7 for b in bs)
+        for b, st in zip(bs, streams):
+            b.solve(o, st)                                               # nobody is synchronised before everybody is launched
+        wg = [b.cooperative()["last_solve_workgroups"] for b in bs]
+        assert wg[:32] == [8] * 32 and wg[32:] == [1] * (n - 32), wg      # 4 launches per XCD are admitted, the rest fall back
+        for b, W in zip(bs, Ws):
+            b.synchronize(); b.download_states()
+            s = b.summaries()
+            assert s[0].termination != 5
+            _same_bits(s, sr, W, Wr, 1)
+        bs[-1].solve(o, streams[-1])                                     # the claims are back after the synchronisation
+        assert bs[-1].cooperative()["last_solve_workgroups"] == 8
+        bs[-1].synchronize()
+    finally:
+        gpu.check(gpu.lib().tcv_set_cooperative(-1))
+        for st in streams:
+            if st:
+                hip.hipStreamDestroy(st)
