@@ -242,6 +242,22 @@ int tcv_batch_download_priors(tcv_batch *b);
 /* the same without A', b' (the parity / debug half of the result: tcv_prior_export_schur fails on priors obtained this way): what an
  * estimator needs per frame -- J0, r0 and the linearisation point, 62 KB instead of 113 KB per window, into pinned host memory */
 int tcv_batch_download_priors_compact(tcv_batch *b);
+/* DEVICE-RESIDENT frame-to-frame state: what `last_marginalization_info` is between two frames of the reference (estimator.h:176-177,
+ * estimator.cpp:2027-2044).  out[k] is the prior of window k with its LAYOUT on the host (m, n, keep_block_size / idx, the un-shifted block
+ * addresses: everything tcv_prior_dims / tcv_prior_keep_block_addresses and the graph construction of the next window need) and its
+ * NUMBERS -- linearized_jacobians, linearized_residuals, keep_block_data -- left where the marginalisation kernel wrote them, in HBM (the
+ * handle keeps that buffer alive after tcv_batch_destroy).  A problem that holds such a prior (tcv_problem_add_marginalization_factor /
+ * tcv_window_desc::prior as usual) packs and uploads nothing of it: tcv_batch_create copies J0 | r0 | x0 device-to-device into the new
+ * batch's pool, without the rows the marginalisation thresholded, exactly as the host path lays them out -- the next solve reads the same
+ * bits.  Per window only two ints come down (status, number of thresholded rows).  tcv_prior_export materialises the numbers on the host
+ * on demand (export / checkpoint); tcv_prior_export_schur is not available.  n = the batch size; on an error out[] is all NULL. */
+int tcv_batch_get_priors_device(tcv_batch *b, tcv_prior **out, int n);
+/* 1 if the prior's numbers live on the device (tcv_batch_get_priors_device) and have not been materialised on the host, else 0 */
+int tcv_prior_is_device_resident(const tcv_prior *pr);
+/* replaces the prior of the problem's marginalisation factor by one with the SAME layout (n, keep_block_size / idx), keeping the
+ * factor's parameter blocks: a caller whose graph does not change from frame to frame (a benchmark loop; a window in steady state)
+ * re-uses its problem object and only hands over the new last_marginalization_info */
+int tcv_problem_set_marginalization_prior(tcv_problem *p, const tcv_prior *prior);
 /* per-window status of the last marginalisation: 0 ok, 1 an eigen-solver hit its sweep cap, 2 result produced by the
  * cyclic-Jacobi safety net (the tridiagonal eigen-solver failed its orthogonality / trace self-check) */
 int tcv_batch_marg_status(tcv_batch *b, int *out, int n);

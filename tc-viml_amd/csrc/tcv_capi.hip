@@ -447,6 +447,7 @@ extern "C" int tcv_prior_create(tcv_prior **out, int m, int n, int nb, const int
         pr->size.push_back(size[k]); pr->idx.push_back(idx[k] - m); pr->xoff.push_back(xs); xs += size[k];
     }
     pr->x0.assign(x0, x0 + xs);
+    pr->xsize = xs;
     pr->J0.assign(J0, J0 + (size_t)n * n);
     pr->r0.assign(r0, r0 + n);
     pr->addr.assign(nb, nullptr);
@@ -458,11 +459,17 @@ extern "C" int tcv_prior_dims(const tcv_prior *pr, int *m, int *n, int *nb, int 
     if (m) *m = pr->m;
     if (n) *n = pr->n;
     if (nb) *nb = (int)pr->size.size();
-    if (xs) *xs = (int)pr->x0.size();
+    if (xs) *xs = pr->xsize;
     return TCV_OK;
+}
+extern "C" int tcv_prior_is_device_resident(const tcv_prior *pr) {
+    if (!pr) return 0;
+    std::lock_guard<std::mutex> g(pr->mu);
+    return pr->host ? 0 : 1;
 }
 extern "C" int tcv_prior_export(const tcv_prior *pr, int *size, int *idx, double *x0, double *J0, double *r0) {
     if (!pr) return TCV_ERR_INVALID;
+    if (x0 || J0 || r0) if (int rc = tcv_prior_host(pr)) return rc;      // a device-resident prior is materialised on demand
     if (size) std::copy(pr->size.begin(), pr->size.end(), size);
     if (idx) for (size_t k = 0; k < pr->idx.size(); k++) idx[k] = pr->idx[k] + pr->m;
     if (x0) std::copy(pr->x0.begin(), pr->x0.end(), x0);
@@ -672,7 +679,18 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
     auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
     const size_t o_win = up16(sizeof(double) * std::max<size_t>(1, dtotal)), o_plans = up16(o_win + sizeof(WinHdr) * (size_t)n);
     const size_t o_pbase = up16(o_plans + sizeof(PlanHdr) * b->plans.size()), o_ipool = up16(o_pbase + sizeof(long long) * b->plan_base.size());
-    const size_t in_bytes = up16(o_ipool + sizeof(int) * std::max<size_t>(1, ipool.size()));
+    // device-resident priors (tcv_batch_get_priors_device): nothing of them is packed or uploaded.  Their J0 | r0 | x0 regions live in a
+    // device-only tail behind the uploaded blob (WinHdr::d_prior is relative to the window's slice and simply points there), filled by one
+    // splice job per window on the upload's stream
+    std::vector<int> splice_win;
+    std::vector<long long> tail_off(n, -1);
+    size_t tail_doubles = 0;
+    for (int w = 0; w < n; w++)
+        if (b->packed[w].dev_prior_doubles > 0) { splice_win.push_back(w); tail_off[w] = (long long)tail_doubles; tail_doubles += ((size_t)b->packed[w].dev_prior_doubles + 1) & ~(size_t)1; }
+    const size_t o_jobs = up16(o_ipool + sizeof(int) * std::max<size_t>(1, ipool.size()));
+    const size_t in_bytes = up16(o_jobs + sizeof(PriorSplice) * splice_win.size());
+    const size_t dev_bytes = in_bytes + sizeof(double) * tail_doubles;
+    if ((in_bytes + sizeof(double) * tail_doubles) / sizeof(double) >= ((size_t)1 << 31)) { batch_free(b); set_error("batch too large (data pool offsets are 32-bit)"); return TCV_ERR_TOO_LARGE; }
     double *h_dpool = (double *)host_staging_acquire(in_bytes);
     if (!h_dpool) { batch_free(b); set_error("hipHostMalloc (upload staging) failed"); return TCV_ERR_HIP; }
     {
@@ -692,6 +710,10 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
             for (auto &x : th) x.join();
         }
         for (int w = 0; w < n; w++) if (rcs[w] != TCV_OK) { host_staging_release(h_dpool); batch_free(b); if (!msgs[w % nth].empty()) set_error(msgs[w % nth]); return rcs[w]; }
+        for (int w : splice_win) {      // the prior region of the window: in the tail, addressed relative to the window's own slice
+            Packed &pk = b->packed[w];
+            pk.win.d_prior = (int)((long long)(in_bytes / sizeof(double)) + tail_off[w] - pk.win.dbase);
+        }
         for (int w = 0; w < n; w++) b->wins.push_back(b->packed[w].win);
     }
     const auto t_packed = std::chrono::steady_clock::now();
@@ -740,12 +762,26 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
         std::memcpy(hb + o_plans, b->plans.data(), sizeof(PlanHdr) * b->plans.size());
         std::memcpy(hb + o_pbase, b->plan_base.data(), sizeof(long long) * b->plan_base.size());
         if (!ipool.empty()) std::memcpy(hb + o_ipool, ipool.data(), sizeof(int) * ipool.size());
-        hipError_t e_ = tcv::dev_malloc(&b->d_input, in_bytes);
+        PriorSplice *hj = (PriorSplice *)(hb + o_jobs);
+        for (size_t q = 0; q < splice_win.size(); q++) {
+            const int w = splice_win[q];
+            const tcv_prior *pr = problems[w]->prior[0].prior;
+            PriorSplice &J = hj[q];
+            std::memset(&J, 0, sizeof J);
+            J.src = pr->d_block; J.dst = b->packed[w].win.dbase + b->packed[w].win.d_prior;
+            J.n = pr->n; J.k0 = b->packed[w].win.prior_k0; J.nblk = (int)pr->size.size();
+            for (int k = 0; k < J.nblk; k++) { J.goff[k] = pr->x_goff[k]; J.size[k] = pr->size[k]; }
+        }
+        hipError_t e_ = tcv::dev_malloc(&b->d_input, dev_bytes);
         if (e_ == hipSuccess) e_ = hipMemcpyAsync(b->d_input, hb, in_bytes, hipMemcpyHostToDevice, ust);
         if (e_ != hipSuccess) { bail(); return hip_fail(e_, "upload of the batch"); }
         char *db = (char *)b->d_input;
         b->d_dpool = (double *)db; b->d_win = (WinHdr *)(db + o_win); b->d_plans = (PlanHdr *)(db + o_plans);
         b->d_plan_base = (long long *)(db + o_pbase); b->d_ipool = (int *)(db + o_ipool);
+        if (!splice_win.empty()) {      // behind the upload on its stream; the sources are results of batches their handles synchronised
+            const int rcs = tcv::launch_prior_splice((const PriorSplice *)(db + o_jobs), (int)splice_win.size(), b->d_dpool, ust);
+            if (rcs != TCV_OK) { bail(); return rcs; }
+        }
     }
     UP(b->d_state, (double *)nullptr, double, (size_t)n * b->state_stride);
     UP(b->d_delta, (double *)nullptr, double, (size_t)n * b->delta_stride);
@@ -981,6 +1017,19 @@ extern "C" int tcv_batch_get_priors(tcv_batch *b, tcv_prior **out, int n) {
             set_error(msgs[t]);
             return rcs[t];
         }
+    return TCV_OK;
+}
+extern "C" int tcv_batch_get_priors_device(tcv_batch *b, tcv_prior **out, int n) {
+    if (!b || !out || n != b->n) { set_error("batch_get_priors_device: n must be the batch size"); return TCV_ERR_INVALID; }
+    for (int k = 0; k < n; k++) out[k] = nullptr;
+    if (b->pending) if (int rc = tcv_batch_synchronize(b)) return rc;
+    return tcv_marg_get_priors_device(b, out, n);
+}
+extern "C" int tcv_problem_set_marginalization_prior(tcv_problem *p, const tcv_prior *prior) {
+    if (!p || !prior || p->prior.size() != 1) { set_error("set_marginalization_prior: the problem must hold exactly one marginalisation factor"); return TCV_ERR_INVALID; }
+    const tcv_prior *old = p->prior[0].prior;
+    if (old->n != prior->n || old->size != prior->size || old->idx != prior->idx) { set_error("set_marginalization_prior: the new prior has another layout"); return TCV_ERR_INVALID; }
+    p->prior[0].prior = prior;
     return TCV_OK;
 }
 extern "C" int tcv_batch_download_priors(tcv_batch *b) {

@@ -771,7 +771,13 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
         g.sum.resize(nb); g.newp.assign(nb, nullptr);
         if (g.rc == TCV_OK) g.rc = tcv_batch_download_states(g.b);
         if (g.rc == TCV_OK) g.rc = tcv_batch_get_summaries(g.b, g.sum.data(), nb);
-        if (g.rc == TCV_OK && group) g.rc = tcv_batch_download_priors_compact(g.b);
+        // last_marginalization_info stays on the device (estimator.h:176-177: the reference keeps it alive between frames, too): the new
+        // priors are handles on the batch's result buffer, the next frame's tcv_batch_create splices them device-to-device.
+        // TCV_EST_HOST_PRIORS=1: round 3's host round trip (62 KB down, 46 KB up per window), the A/B partner -- same bits
+        const bool host_priors = getenv("TCV_EST_HOST_PRIORS") != nullptr;
+        bool have_dev = false;
+        if (g.rc == TCV_OK && group && !host_priors) have_dev = tcv_batch_get_priors_device(g.b, g.newp.data(), nb) == TCV_OK;      // (a window that failed: the per-window path below says which)
+        if (g.rc == TCV_OK && group && !have_dev) g.rc = tcv_batch_download_priors_compact(g.b);
         g.est_rc.assign(nb, TCV_OK);
         if (g.rc == TCV_OK)
             for (int k = 0; k < nb; k++)      // ceres::Solve's FAILURE (no valid step / a cooperative group that timed out): the window's states are not applied
@@ -780,7 +786,8 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
             for (int k = 0; k < nb; k++) {
                 // a window whose marginalisation did not converge (TCV_ERR_NUMERIC) fails alone: the other estimators of the lock-step
                 // batch are applied, this one reports the failure from tcv_estimator_finish_frame
-                if (g.est_rc[k] != TCV_OK) continue;
+                if (g.est_rc[k] != TCV_OK) { if (g.newp[k]) { tcv_prior_destroy(g.newp[k]); g.newp[k] = nullptr; } continue; }
+                if (have_dev) continue;
                 g.est_rc[k] = tcv_batch_get_prior(g.b, k, &g.newp[k]);
                 if (g.est_rc[k] != TCV_OK && g.est_rc[k] != TCV_ERR_NUMERIC) { g.rc = g.est_rc[k]; break; }
                 if (g.est_rc[k] != TCV_OK) g.est_msg = tcv_last_error();

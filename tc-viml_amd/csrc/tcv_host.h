@@ -7,6 +7,7 @@
 
 #include <cstdint>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -14,15 +15,35 @@
 #include "../../include/tcv.h"
 #include "tcv_packed.h"
 
+namespace tcv {
+// a device allocation shared between its producer (a batch) and the handles that still read it (device-resident priors)
+struct DevBlob {
+    void *p = nullptr;
+    int dev = 0;
+    ~DevBlob();
+};
+}  // namespace tcv
+
 struct tcv_prior {
     int m = 0, n = 0;
     std::vector<int> size, idx;       // keep_block_size / keep_block_idx (idx relative to m, i.e. column of J0)
     std::vector<int> xoff;            // offset of every block in x0
-    std::vector<double> x0;           // keep_block_data, concatenated
-    std::vector<double> J0, r0;       // linearized_jacobians (n x n column-major), linearized_residuals
+    int xsize = 0;                    // doubles of x0 (= keep_block_data, concatenated), whether or not it is on the host
+    mutable std::vector<double> x0;   // keep_block_data, concatenated
+    mutable std::vector<double> J0, r0;   // linearized_jacobians (n x n column-major), linearized_residuals
     std::vector<double *> addr;       // addresses of the kept blocks at marginalisation time (un-shifted)
     std::vector<double> As, bs;       // Schur system A', b' the factors were taken from (parity/debug, may be empty)
+    // device-resident form (tcv_batch_get_priors_device): J0 | r0 | the marginalisation problem's state vector stay in the producing
+    // batch's result buffer; `host` says whether x0 / J0 / r0 above have been materialised (tcv_prior_host)
+    std::shared_ptr<tcv::DevBlob> dev;
+    const double *d_block = nullptr;  // this window's result block in that buffer (layout: tcv_marg.hip MARG_OUT_*)
+    int k0 = 0;                       // leading rows of J0 | r0 that are exact zeros (tcv_packed.h prior_zero_rows, computed on the device)
+    std::vector<int> x_goff;          // per kept block: offset of its values in the result block's state region
+    mutable bool host = true;
+    mutable std::mutex mu;            // materialisation (several packing threads may ask for it at once)
 };
+// the prior's numbers on the host: no-op for a host prior, one device-to-host copy (once) for a device-resident one; TCV_OK or an error
+int tcv_prior_host(const tcv_prior *pr);
 
 namespace tcv {
 
@@ -50,6 +71,8 @@ struct Packed {
     std::vector<int> ints;
     std::vector<double> doubles;
     WinHdr win;
+    int dev_prior_doubles = 0;       // > 0: the window's prior is device-resident: doubles of its J0 | r0 | x0 region, which lives in the batch's
+                                     // device-only tail (not in the uploaded slice) and is filled by the splice kernel of tcv_batch_create
     // host-side maps for download
     std::vector<int> cam_block;      // problem block index of every camera block
     std::vector<int> cam_loff;       // tangent offset of every camera block (-1 constant)
@@ -82,7 +105,7 @@ struct tcv_batch {
     int state_stride = 0, delta_stride = 0;
     double input_bytes = 0, plan_bytes = 0;
     // device
-    void *d_input = nullptr;                 // one allocation: [data pool | window headers | plan headers | plan offsets | plan ints]
+    void *d_input = nullptr;                 // one allocation: [data pool | window headers | plan headers | plan offsets | plan ints | splice jobs | device-only tail: the regions of device-resident priors]
     tcv::WinHdr *d_win = nullptr;
     tcv::PlanHdr *d_plans = nullptr;
     long long *d_plan_base = nullptr;
@@ -132,6 +155,14 @@ int tcv_marg_run(tcv_batch *b, void *stream);
 int tcv_marg_get_prior(tcv_batch *b, int window, tcv_prior **out);
 void tcv_marg_elapsed(tcv_batch *b);
 int tcv_marg_download(tcv_batch *b, int compact);
+int tcv_marg_get_priors_device(tcv_batch *b, tcv_prior **out, int n);
+// copies device-resident priors into a batch's data pool (one job per window that holds one): launched by tcv_batch_create on the stream
+// of its upload, behind it
+namespace tcv {
+struct PriorSplice { const double *src; long long dst; int n, k0, nblk, pad; int goff[32], size[32]; };
+enum { PRIOR_SPLICE_MAX_BLOCKS = 32 };
+int launch_prior_splice(const PriorSplice *d_jobs, int njobs, double *d_dpool, hipStream_t st);
+}  // namespace tcv
 
 namespace tcv {
 // device allocations go through a per-process free list (size-bucketed, per device): a per-frame estimator creates and destroys a

@@ -1697,8 +1697,9 @@ struct MargState {
     std::vector<MargWindow> win;
     void *d_input = nullptr;          // one allocation: [double pool | headers | int pool]
     MargHdr *d_hdr = nullptr;
-    int *d_ipool = nullptr, *d_status = nullptr;
+    int *d_ipool = nullptr, *d_status = nullptr;      // d_status: per window [status | k0] (2 n ints): marginalisation status, leading zero rows of J0 | r0 (-1: NaN)
     double *d_dpool = nullptr, *d_out = nullptr, *d_scratch = nullptr;
+    std::shared_ptr<DevBlob> out_blob;                // owns d_out: device-resident priors (tcv_batch_get_priors_device) keep it alive after the batch
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     size_t lds_bytes = 0;
     int grid = 0, nt = MARG_NT_WIDE;
@@ -1713,7 +1714,8 @@ static void marg_free(tcv_batch *b) {
     MargState *s = (MargState *)b->marg;
     if (!s) return;
     (void)tcv::dev_free(s->d_input); (void)tcv::dev_free(s->d_status);      // (d_hdr, d_ipool, d_dpool point into d_input)
-    (void)tcv::dev_free(s->d_out); (void)tcv::dev_free(s->d_scratch);
+    s->out_blob.reset(); s->d_out = nullptr;      // (freed when the last device-resident prior that reads it is gone)
+    (void)tcv::dev_free(s->d_scratch);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     tcv::host_staging_release(s->h_out);
@@ -1895,7 +1897,7 @@ static int pack_marg(const tcv_problem &p, double *const *drop, int ndrop, const
     const tcv_prior *pr = p.prior.empty() ? nullptr : p.prior[0].prior;
     if (pr) {
         if (pr->n > 128) { set_error("prior with more than 128 rows"); return TCV_ERR_TOO_LARGE; }
-        H.prior_n = pr->n; H.prior_nblk = (int)pr->size.size(); H.prior_xsize = (int)pr->x0.size();
+        H.prior_n = pr->n; H.prior_nblk = (int)pr->size.size(); H.prior_xsize = pr->xsize;
         pcol.assign(pr->n, -1);
         for (int k = 0; k < H.prior_nblk; k++) {
             const int c = id_of[p.prior[0].b[k]];
@@ -1933,6 +1935,7 @@ static int pack_marg(const tcv_problem &p, double *const *drop, int ndrop, const
     if (pr && solve_p && solve_pk && !solve_p->prior.empty() && solve_p->prior[0].prior == pr && solve_pk->hdr.prior_n == pr->n && !getenv("TCV_MARG_OWN_PRIOR"))
         { H.prior_abs = solve_pk->win.dbase + solve_pk->win.d_prior; H.prior_k0 = solve_pk->win.prior_k0; }      // same layout: J0 | r0 | x0 without the leading zero rows (tcv_pack.cpp)
     else if (pr) {
+        if (int rc = tcv_prior_host(pr)) return rc;      // (a device-resident prior that the solve problem does not share: its numbers are needed here)
         const int n0 = pr->n, k0 = prior_keep_zero_rows() ? 0 : prior_zero_rows(pr->J0.data(), pr->r0.data(), n0);
         H.prior_k0 = k0;
         for (int j = 0; j < n0; j++) D.insert(D.end(), pr->J0.begin() + (size_t)n0 * j + k0, pr->J0.begin() + (size_t)n0 * (j + 1));
@@ -1944,8 +1947,91 @@ static int pack_marg(const tcv_problem &p, double *const *drop, int ndrop, const
     return TCV_OK;
 }
 
+// ---- device-resident priors (tcv_batch_get_priors_device) --------------------------------------------------------------------------
+// number of leading rows of J0 | r0 that are exact zeros, per window, as tcv_packed.h prior_zero_rows() counts them on the host (at least
+// one row is kept); -1 when the result holds a NaN (the host path's scan of J0).  One wavefront per window.
+__global__ void __launch_bounds__(64) prior_k0_kernel(const double *out, const MargHdr *hdr, const int *status, int *k0_out, int nwin) {
+    const int w = blockIdx.x, lane = threadIdx.x;
+    if (w >= nwin) return;
+    const int n = hdr[w].n;
+    const double *J0 = out + (size_t)w * MARG_OUT_STRIDE + MARG_OUT_J0, *r0 = out + (size_t)w * MARG_OUT_STRIDE + MARG_OUT_R0;
+    if (status[w] < 0) { if (lane == 0) k0_out[w] = -1; return; }
+    bool nan = false;
+    unsigned long long zero[2] = {0ull, 0ull};      // bit i of zero[q]: row 64 q + i is an exact-zero row
+    for (int q = 0; q < 2; q++) {
+        const int i = lane + 64 * q;
+        bool z = i < n;
+        if (i < n) {
+            const double r = r0[i];
+            if (!(r == r)) nan = true;
+            if (r != 0.0) z = false;
+            for (int j = 0; j < n; j++) { const double v = J0[i + (size_t)n * j]; if (!(v == v)) nan = true; if (v != 0.0) z = false; }
+        }
+        zero[q] = __ballot(z);
+    }
+    const bool any_nan = __ballot(nan) != 0ull;
+    if (lane == 0) {
+        int k0 = 0;
+        while (k0 < n && ((zero[k0 >> 6] >> (k0 & 63)) & 1ull)) k0++;
+        if (k0 >= n) k0 = n > 0 ? n - 1 : 0;
+        k0_out[w] = any_nan ? -1 : k0;
+    }
+}
+// one workgroup per job: rows k0 .. n-1 of J0 (column by column), r0[k0 ..], the kept blocks' linearisation points -> the layout
+// pack_data_to() gives a host prior in the solve batch's data pool (tcv_pack.cpp; WinHdr::d_prior)
+__global__ void __launch_bounds__(256) prior_splice_kernel(const PriorSplice *jobs, double *dpool) {
+    const PriorSplice &J = jobs[blockIdx.x];
+    const int n = J.n, k0 = J.k0, nr = n - k0, tid = threadIdx.x;
+    const double *src = J.src;
+    double *dst = dpool + J.dst;
+    for (int e = tid; e < nr * n; e += 256) { const int j = e / nr, i = e - j * nr; dst[e] = src[MARG_OUT_J0 + (size_t)n * j + k0 + i]; }
+    for (int i = tid; i < nr; i += 256) dst[nr * n + i] = src[MARG_OUT_R0 + k0 + i];
+    int xo = nr * n + nr;
+    for (int k = 0; k < J.nblk; k++) {
+        if (tid < J.size[k]) dst[xo + tid] = src[MARG_OUT_X + J.goff[k] + tid];
+        xo += J.size[k];
+    }
+}
+int launch_prior_splice(const PriorSplice *d_jobs, int njobs, double *d_dpool, hipStream_t st) {
+    if (njobs <= 0) return TCV_OK;
+    hipLaunchKernelGGL(prior_splice_kernel, dim3(njobs), dim3(256), 0, st, d_jobs, d_dpool);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "prior splice kernel launch");
+    return TCV_OK;
+}
+DevBlob::~DevBlob() {
+    if (!p) return;
+    int cur = 0;
+    const bool sw = hipGetDevice(&cur) == hipSuccess && cur != dev;
+    if (sw) (void)hipSetDevice(dev);      // (the free list is per device)
+    (void)dev_free(p);
+    if (sw) (void)hipSetDevice(cur);
+}
+
 }  // namespace tcv
 using namespace tcv;
+
+// materialises a device-resident prior on the host (export / checkpoint, or a consumer that needs the numbers: a marginalisation problem
+// that does not share its prior with the solve problem)
+int tcv_prior_host(const tcv_prior *pr) {
+    if (!pr) return TCV_ERR_INVALID;
+    std::lock_guard<std::mutex> g(pr->mu);
+    if (pr->host) return TCV_OK;
+    const int n = pr->n;
+    std::vector<double> o(MARG_OUT_COMPACT);
+    int cur = 0;
+    const bool sw = hipGetDevice(&cur) == hipSuccess && pr->dev && cur != pr->dev->dev;
+    if (sw) (void)hipSetDevice(pr->dev->dev);
+    const hipError_t e = hipMemcpy(o.data(), pr->d_block, sizeof(double) * MARG_OUT_COMPACT, hipMemcpyDeviceToHost);
+    if (sw) (void)hipSetDevice(cur);
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpy D2H (device-resident prior)");
+    pr->J0.assign(o.begin() + MARG_OUT_J0, o.begin() + MARG_OUT_J0 + (size_t)n * n);
+    pr->r0.assign(o.begin() + MARG_OUT_R0, o.begin() + MARG_OUT_R0 + n);
+    pr->x0.clear();
+    for (size_t k = 0; k < pr->size.size(); k++) for (int i = 0; i < pr->size[k]; i++) pr->x0.push_back(o[MARG_OUT_X + pr->x_goff[k] + i]);
+    pr->host = true;
+    return TCV_OK;
+}
 
 int tcv_marg_attach(tcv_batch *b, tcv_problem *const *marg_problems, double *const *const *marg_drop, const int *marg_num_drop) {
     MargState *s = new MargState();
@@ -2036,9 +2122,10 @@ int tcv_marg_attach(tcv_batch *b, tcv_problem *const *marg_problems, double *con
         hipError_t e_ = tcv::dev_malloc(&s->d_input, in_bytes);
         if (e_ == hipSuccess) { staged.st = ust; staged.in_flight = true; e_ = hipMemcpyAsync(s->d_input, h_in, in_bytes, hipMemcpyHostToDevice, ust); }
         if (e_ == hipSuccess) e_ = tcv::dev_malloc((void **)&s->d_out, sizeof(double) * std::max<size_t>(1, (size_t)b->n * MARG_OUT_STRIDE));
-        if (e_ == hipSuccess) e_ = tcv::dev_malloc((void **)&s->d_status, sizeof(int) * (size_t)b->n);
+        if (e_ == hipSuccess) { s->out_blob = std::make_shared<DevBlob>(); s->out_blob->p = s->d_out; (void)hipGetDevice(&s->out_blob->dev); }
+        if (e_ == hipSuccess) e_ = tcv::dev_malloc((void **)&s->d_status, sizeof(int) * 2 * (size_t)b->n);
         if (e_ == hipSuccess) e_ = tcv::dev_malloc((void **)&s->d_scratch, sizeof(double) * (size_t)s->grid * MARG_SCR_STRIDE);
-        if (e_ == hipSuccess) e_ = hipMemsetAsync(s->d_status, 0xff, sizeof(int) * b->n, ust);
+        if (e_ == hipSuccess) e_ = hipMemsetAsync(s->d_status, 0xff, sizeof(int) * 2 * b->n, ust);
         if (e_ == hipSuccess) { e_ = ust ? hipStreamSynchronize(ust) : hipDeviceSynchronize(); if (e_ == hipSuccess) staged.in_flight = false; }
         if (e_ != hipSuccess) return hip_fail(e_, "upload of the marginalisation problems");
         s->d_dpool = (double *)s->d_input; s->d_hdr = (MargHdr *)((char *)s->d_input + o_hdr); s->d_ipool = (int *)((char *)s->d_input + o_int);
@@ -2069,6 +2156,9 @@ int tcv_marg_run(tcv_batch *b, void *stream) {
     else hipLaunchKernelGGL(marg_kernel<MARG_NT_WIDE>, dim3(s->grid), dim3(MARG_NT_WIDE), s->lds_bytes, st, a);
     if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "marg kernel launch");
     if ((e = hipEventRecord(s->ev1, st)) != hipSuccess) return hip_fail(e, "hipEventRecord");
+    // what a device-resident consumer of the priors needs on the host: the number of thresholded rows per window (one wavefront each)
+    hipLaunchKernelGGL(prior_k0_kernel, dim3(b->n), dim3(64), 0, st, (const double *)s->d_out, (const MargHdr *)s->d_hdr, (const int *)s->d_status, s->d_status + b->n, b->n);
+    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "prior k0 kernel launch");
     s->ran = true;
     s->h_valid = false;
     return TCV_OK;
@@ -2150,6 +2240,7 @@ int tcv_marg_get_prior(tcv_batch *b, int window, tcv_prior **out) {
         xo += mw.keep_size[k];
         pr->addr.push_back(mw.keep_addr[k]);
     }
+    pr->xsize = xo;
     pr->J0.assign(o.begin() + MARG_OUT_J0, o.begin() + MARG_OUT_J0 + (size_t)n * n);
     pr->r0.assign(o.begin() + MARG_OUT_R0, o.begin() + MARG_OUT_R0 + n);
     if (have_schur) {
@@ -2169,4 +2260,44 @@ int tcv_marg_get_prior(tcv_batch *b, int window, tcv_prior **out) {
     for (double v : pr->J0) if (!(v == v)) { delete pr; set_error("NaN in marginalisation result"); return TCV_ERR_NUMERIC; }
     *out = pr;
     return TCV_OK;
+}
+
+// tcv_batch_get_priors_device: layout on the host, numbers left in the batch's result buffer (shared with the handles)
+int tcv_marg_get_priors_device(tcv_batch *b, tcv_prior **out, int n) {
+    MargState *s = (MargState *)b->marg;
+    if (!s || !s->ran || n != b->n) { set_error("no marginalisation result (or n is not the batch size)"); return TCV_ERR_INVALID; }
+    std::vector<int> st(2 * (size_t)n);
+    {
+        hipStream_t ust = tcv::util_stream();
+        int *hs = (int *)tcv::host_staging_acquire(sizeof(int) * st.size());
+        if (!hs) { set_error("hipHostMalloc (download staging) failed"); return TCV_ERR_HIP; }
+        hipError_t e = hipMemcpyAsync(hs, s->d_status, sizeof(int) * st.size(), hipMemcpyDeviceToHost, ust);
+        if (e == hipSuccess) e = ust ? hipStreamSynchronize(ust) : hipDeviceSynchronize();
+        if (e == hipSuccess) std::memcpy(st.data(), hs, sizeof(int) * st.size());
+        tcv::host_staging_release(hs);
+        if (e != hipSuccess) return hip_fail(e, "hipMemcpy D2H (marginalisation status)");
+    }
+    for (int w = 0; w < n; w++) out[w] = nullptr;
+    int rc = TCV_OK;
+    for (int w = 0; w < n && rc == TCV_OK; w++) {
+        const MargWindow &mw = s->win[w];
+        const int status = st[w], k0 = st[n + w];
+        if (status < 0) { set_error("marginalisation kernel did not complete for this window"); rc = TCV_ERR_NUMERIC; break; }
+        if (status == 1) { set_error("marginalisation: eigen-decomposition did not converge (sweep cap)"); rc = TCV_ERR_NUMERIC; break; }
+        if (k0 < 0) { set_error("NaN in marginalisation result"); rc = TCV_ERR_NUMERIC; break; }
+        if ((int)mw.keep_block.size() > PRIOR_SPLICE_MAX_BLOCKS) { set_error("device-resident prior: too many kept blocks"); rc = TCV_ERR_TOO_LARGE; break; }
+        tcv_prior *pr = new tcv_prior();
+        pr->m = mw.m_total; pr->n = mw.hdr.n;
+        int xo = 0;
+        for (size_t k = 0; k < mw.keep_block.size(); k++) {
+            pr->size.push_back(mw.keep_size[k]); pr->idx.push_back(mw.keep_idx[k] - mw.hdr.m); pr->xoff.push_back(xo);
+            pr->x_goff.push_back(mw.keep_goff[k]); pr->addr.push_back(mw.keep_addr[k]);
+            xo += mw.keep_size[k];
+        }
+        pr->xsize = xo;
+        pr->dev = s->out_blob; pr->d_block = s->d_out + (size_t)w * MARG_OUT_STRIDE; pr->k0 = k0; pr->host = false;
+        out[w] = pr;
+    }
+    if (rc != TCV_OK) for (int w = 0; w < n; w++) if (out[w]) { delete out[w]; out[w] = nullptr; }
+    return rc;
 }

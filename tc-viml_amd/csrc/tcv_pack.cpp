@@ -424,7 +424,7 @@ static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds,
     std::vector<int> pcol;
     if (pr) {
         if (pr->n > 128) { set_error("prior with more than 128 rows"); return TCV_ERR_TOO_LARGE; }
-        H.prior_n = pr->n; H.prior_nblk = (int)pr->size.size(); H.prior_xsize = (int)pr->x0.size();
+        H.prior_n = pr->n; H.prior_nblk = (int)pr->size.size(); H.prior_xsize = pr->xsize;
         pcol.assign(pr->n, -1);
         for (int k = 0; k < H.prior_nblk; k++) {
             const int b = p.prior[0].b[k];
@@ -859,7 +859,21 @@ static int pack_data_to(const tcv_problem &p, Packed &out, const double *imu_sqr
     else D.zeros(21);
     if (D.n & 1) D.put1(0.0);        // J0 is copied with 16-byte loads
     W.d_prior = (int)D.n;
-    if (pr) {      // the rows of the thresholded eigenvalues (exact zeros in J0 and r0) are dropped, tcv_packed.h
+    // (decided by the sizing pass and kept for the writing pass: another thread may materialise the prior on the host in between)
+    bool on_device = out.dev_prior_doubles > 0;
+    if (!D.dst) {
+        on_device = false;
+        if (pr) { std::lock_guard<std::mutex> g(pr->mu); on_device = !pr->host && pr->dev && (int)pr->size.size() <= PRIOR_SPLICE_MAX_BLOCKS; }
+    }
+    out.dev_prior_doubles = 0;
+    if (pr && on_device) {
+        // device-resident (tcv_batch_get_priors_device): nothing is written here; tcv_batch_create gives the region a place in the batch's
+        // device-only tail (it patches d_prior) and the splice kernel fills it with the same layout as below
+        const int n = pr->n, k0 = prior_keep_zero_rows() ? 0 : pr->k0, nr = n - k0;
+        W.prior_k0 = k0;
+        out.dev_prior_doubles = nr * n + nr + pr->xsize;
+    } else if (pr) {      // the rows of the thresholded eigenvalues (exact zeros in J0 and r0) are dropped, tcv_packed.h
+        if (int rc = tcv_prior_host(pr)) return rc;
         const int n = pr->n, k0 = prior_keep_zero_rows() ? 0 : prior_zero_rows(pr->J0.data(), pr->r0.data(), n), nr = n - k0;
         W.prior_k0 = k0;
         for (int j = 0; j < n; j++) D.put(pr->J0.data() + (size_t)n * j + k0, nr);
@@ -934,7 +948,7 @@ void structure_key(const tcv_problem &p, int mode, int chain_lds, int coop_chunk
     k.push_back((int)p.prior.size());
     for (auto &f : p.prior) {
         const tcv_prior *pr = f.prior;
-        k.push_back(pr->n); k.push_back((int)pr->size.size()); k.push_back((int)pr->x0.size());
+        k.push_back(pr->n); k.push_back((int)pr->size.size()); k.push_back(pr->xsize);
         for (size_t j = 0; j < f.b.size(); j++) { k.push_back(f.b[j]); k.push_back(pr->size[j]); k.push_back(pr->idx[j]); k.push_back(pr->xoff[j]); }
     }
     k.push_back((int)p.frame_pose.size());

@@ -39,6 +39,7 @@ EXPORTS = [
     "tcv_eval_imu_factors", "tcv_eval_projection_factors", "tcv_eval_line_factors", "tcv_pose_plus", "tcv_preintegrate",
     "tcv_problem_set_frames", "tcv_gauge_fix", "tcv_batch_gauge_fix", "tcv_set_solver_variant", "tcv_set_cooperative", "tcv_batch_cooperative", "tcv_batch_get_priors", "tcv_batch_marg_status", "tcv_eval_projection_td_factors", "tcv_match_lines",
     "tcv_batch_download_priors", "tcv_batch_download_priors_compact",
+    "tcv_batch_get_priors_device", "tcv_prior_is_device_resident", "tcv_problem_set_marginalization_prior",
 ]
 
 
@@ -137,6 +138,9 @@ def lib():
         L.tcv_batch_get_prior.argtypes = [vp, C.c_int, C.POINTER(vp)]
         L.tcv_batch_download_priors.argtypes = [vp]
         L.tcv_batch_download_priors_compact.argtypes = [vp]
+        L.tcv_batch_get_priors_device.argtypes = [vp, C.POINTER(vp), C.c_int]
+        L.tcv_prior_is_device_resident.argtypes = [vp]
+        L.tcv_problem_set_marginalization_prior.argtypes = [vp, vp]
         L.tcv_batch_get_first_step.argtypes = [vp, C.c_int, _dp, C.c_int, _ip]
         L.tcv_batch_plan_stats.argtypes = [vp, _ip, _dp, _ip, _ip]
         L.tcv_batch_layout.argtypes = [vp]
@@ -222,6 +226,9 @@ class Prior:
                                      J0.ctypes.data_as(_dp), dptr(r0)))
         return cls(h)
 
+    def on_device(self):
+        return bool(lib().tcv_prior_is_device_resident(self.h))
+
     def dims(self):
         m, n, nb, xs = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         check(lib().tcv_prior_dims(self.h, C.byref(m), C.byref(n), C.byref(nb), C.byref(xs)))
@@ -300,6 +307,11 @@ class Window:
         self.desc = d
         self.h = C.c_void_p()
         check(lib().tcv_problem_from_window(C.byref(d), C.byref(self.h)))
+
+    def set_prior(self, prior: "Prior"):
+        """tcv_problem_set_marginalization_prior: hand the problem a new prior with the layout of its current one (the same blocks)"""
+        check(lib().tcv_problem_set_marginalization_prior(self.h, prior.h))
+        self.prior = prior
 
     def states(self):
         out = dict(pose=self.pose.copy(), sb=self.sb.copy(), ex=self.ex.copy(), lam=self.lam.copy())
@@ -436,6 +448,14 @@ class Batch:
         n = len(self.windows)
         out = (C.c_void_p * n)()
         check(lib().tcv_batch_get_priors(self.h, out, n))
+        return [Prior(C.c_void_p(h)) for h in out]
+
+    def priors_device(self):
+        """every window's prior as a DEVICE-RESIDENT handle (tcv_batch_get_priors_device): layout on the host, J0 | r0 | x0 left in HBM; a
+        problem that holds one uploads nothing of it"""
+        n = len(self.windows)
+        out = (C.c_void_p * n)()
+        check(lib().tcv_batch_get_priors_device(self.h, out, n))
         return [Prior(C.c_void_p(h)) for h in out]
 
     def solve(self, opts, stream=None):

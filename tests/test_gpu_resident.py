@@ -1,0 +1,147 @@
+"""Device-resident frame-to-frame state (include/tcv.h tcv_batch_get_priors_device): what `last_marginalization_info` is between two frames
+of the reference (estimator.h:176-177, estimator.cpp:2027-2044).  The prior a batch's marginalisation produced stays in HBM; the next
+batch's tcv_batch_create copies J0 | r0 | x0 device-to-device into its pool (without the thresholded rows, the layout of the host path).
+Everything here is gated BIT FOR BIT against the host round trip (download, tcv_prior object, pack, upload) of the same chain."""
+import os
+
+import numpy as np
+import pytest
+
+import replay
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _marg_batch(tcv, wins, Ws):
+    MW = [tcv.margin_old_window(W.win) for W in Ws]      # (the dicts the windows were built from: they carry the prior's block list)
+    M = [tcv.Window(mw, share=Ws[k], prior=Ws[k].prior) for k, mw in enumerate(MW)]
+    drops = [tcv.margin_old_drops(Ws[k], MW[k]) for k in range(len(wins))]
+    return tcv.Batch(Ws, M, drops)
+
+
+def _run(b, tcv):
+    b.solve(tcv.default_options(8, True)); b.gauge_fix(); b.marginalize(); b.synchronize(); b.download_states()
+    return b.summaries()
+
+
+def _same_summary(a, c):
+    assert a.num_iterations == c.num_iterations and a.termination == c.termination and a.final_cost == c.final_cost
+    m = min(a.num_iterations, 64)
+    for f in ("cost", "cost_candidate", "model_cost_change", "radius", "rho", "step_norm"):
+        assert [getattr(a, f)[i] for i in range(m)] == [getattr(c, f)[i] for i in range(m)], f
+
+
+@pytest.mark.parametrize("B", [5, 300])      # cooperative small-batch shape / two workgroups per CU
+def test_device_resident_prior_chain_is_bit_identical_to_the_host_round_trip(gpu, B):
+    tcv = gpu
+    pre = synth.make_windows(8800, B, frame_shift=-1)
+    pw = [synth.window_at(pre, k) for k in range(B)]
+    main = synth.make_windows(8800, B)
+    mw = [synth.window_at(main, k) for k in range(B)]
+    nxt = synth.make_windows(8800, B, frame_shift=1)
+    nw = [synth.window_at(nxt, k) for k in range(B)]
+
+    def chain(device):
+        """three chained frames: no prior -> prior of frame 1 -> prior of frame 2"""
+        W0 = [tcv.Window(w) for w in pw]
+        b0 = _marg_batch(tcv, pw, W0)
+        _run(b0, tcv)
+        out = []
+        prev_b, prev_W = b0, W0
+        for frame in (mw, nw):
+            if device:
+                pri = prev_b.priors_device()
+                assert all(p.on_device() for p in pri)
+                blocks = [tcv.shifted_prior_blocks(pri[k], prev_W[k]) for k in range(B)]
+                del prev_b                                     # the handles keep the batch's result buffer alive
+                Wk = [tcv.Window(dict(frame[k], prior=dict(blocks=blocks[k])), prior=pri[k]) for k in range(B)]
+            else:
+                prev_b.download_priors(compact=True)
+                pri = prev_b.priors()
+                ds = []
+                for k in range(B):
+                    d = pri[k].export(); d["blocks"] = tcv.shifted_prior_blocks(pri[k], prev_W[k]); ds.append(d)
+                del prev_b
+                Wk = [tcv.Window(dict(frame[k], prior=ds[k])) for k in range(B)]
+            bk = _marg_batch(tcv, frame, Wk)
+            s = _run(bk, tcv)
+            assert list(bk.marg_status()) == [0] * B
+            out.append((s, [w.states() for w in Wk]))
+            prev_b, prev_W = bk, Wk
+        last = prev_b.priors_device() if device else (prev_b.download_priors(compact=True), prev_b.priors())[1]
+        fin = [p.export() for p in last]                       # (materialises the device-resident ones)
+        assert not any(p.on_device() for p in last)
+        return out, fin
+
+    host, fin_h = chain(False)
+    dev, fin_d = chain(True)
+    for (sh, xh), (sd, xd) in zip(host, dev):
+        for k in range(B):
+            _same_summary(sh[k], sd[k])
+            for key in ("pose", "sb", "ex", "lam"):
+                assert np.array_equal(xh[k][key], xd[k][key]), (k, key)
+    for k in range(B):
+        for key in ("J0", "r0"):
+            assert np.array_equal(fin_h[k][key], fin_d[k][key]), (k, key)
+        assert fin_h[k]["idx"] == fin_d[k]["idx"] and fin_h[k]["sizes"] == fin_d[k]["sizes"] and (fin_h[k]["m"], fin_h[k]["n"]) == (fin_d[k]["m"], fin_d[k]["n"])
+        assert all(np.array_equal(a, c) for a, c in zip(fin_h[k]["x0"], fin_d[k]["x0"]))
+
+
+def test_device_and_host_priors_mix_in_one_batch_and_rebind(gpu):
+    """a batch whose windows hold device-resident priors, host priors and no prior at all; tcv_problem_set_marginalization_prior hands an
+    existing problem the next prior (same layout) without rebuilding it -- same bits as fresh problems"""
+    tcv = gpu
+    B = 6
+    pre = synth.make_windows(8900, B, frame_shift=-1)
+    pw = [synth.window_at(pre, k) for k in range(B)]
+    mw = [synth.window_at(synth.make_windows(8900, B), k) for k in range(B)]
+    W0 = [tcv.Window(w) for w in pw]
+    b0 = _marg_batch(tcv, pw, W0); _run(b0, tcv)
+    pd = b0.priors_device()
+    b0.download_priors(compact=True); ph = b0.priors()
+    blocks = [tcv.shifted_prior_blocks(pd[k], W0[k]) for k in range(B)]
+    ref = [tcv.Window(dict(mw[k], prior=dict(ph[k].export(), blocks=blocks[k]))) for k in range(B)]
+    sr = _run(_marg_batch(tcv, mw, ref), tcv)
+    mixed = []
+    for k in range(B):
+        if k % 3 == 0:
+            mixed.append(tcv.Window(dict(mw[k], prior=dict(blocks=blocks[k])), prior=pd[k]))           # device-resident
+        elif k % 3 == 1:
+            mixed.append(tcv.Window(dict(mw[k], prior=dict(ph[k].export(), blocks=blocks[k]))))       # host
+        else:
+            mixed.append(tcv.Window(dict(mw[k], prior=None)))                                         # none
+    bm = _marg_batch(tcv, mw, mixed); sm = _run(bm, tcv)
+    for k in range(B):
+        if k % 3 != 2:
+            _same_summary(sr[k], sm[k])
+            assert np.array_equal(ref[k].pose, mixed[k].pose) and np.array_equal(ref[k].lam, mixed[k].lam)
+    # rebind: the problems of `ref` (host priors) take the device-resident priors; a prior with another layout is refused
+    for k in range(B):
+        ref[k].pose[:] = mw[k]["pose"]; ref[k].sb[:] = mw[k]["speedbias"]; ref[k].ex[:] = mw[k]["ex_pose"]; ref[k].lam[:] = mw[k]["lam"]
+        ref[k].set_prior(pd[k])
+    s2 = _run(_marg_batch(tcv, mw, ref), tcv)
+    for k in range(B):
+        _same_summary(sr[k], s2[k])
+    other = bm.priors_device()[2]      # the prior of a window that had none: n = 75 too, but made from other blocks' values -- same layout is accepted
+    ref[0].set_prior(other)
+    with pytest.raises(tcv.TcvError):
+        ref[0].set_prior(tcv.Prior.from_dict(dict(m=0, n=6, sizes=[7], idx=[0], x0=[np.zeros(7)], J0=np.eye(6), r0=np.zeros(6))))
+
+
+def test_native_estimator_with_device_resident_priors_matches_the_host_round_trip(gpu):
+    """include/tcv_estimator.h keeps last_marginalization_info on the device (default); TCV_EST_HOST_PRIORS=1 is round 3's host round trip:
+    the same trajectories bit for bit, both marginalisation modes, association in the loop"""
+    streams = [replay.simulate_stream(44, 30, max_features=30, associate=True),
+               replay.simulate_stream_euroc("V2_02_medium", 30, start_s=1.0, max_features=40, max_lines=5, associate=True)]
+    dev = replay.run_many_native(streams, num_iterations=8)
+    os.environ["TCV_EST_HOST_PRIORS"] = "1"
+    try:
+        host = replay.run_many_native(streams, num_iterations=8)
+    finally:
+        del os.environ["TCV_EST_HOST_PRIORS"]
+    for a, c in zip(dev, host):
+        assert len(a["t"]) == len(c["t"]) == 30 - replay.WINDOW_SIZE
+        assert {l["flag"] for l in a["log"]} == {0, 1}
+        assert np.array_equal(a["p"], c["p"]) and np.array_equal(a["q"], c["q"]) and np.array_equal(a["v"], c["v"])
+        assert [l["iterations"] for l in a["log"]] == [l["iterations"] for l in c["log"]]
