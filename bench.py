@@ -28,6 +28,7 @@ Modes (`--mode`):
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import json
 import math
 import os
@@ -138,6 +139,7 @@ def build_batches(tcv, synth, first_id: int, B: int):
     drops = [tcv.margin_old_drops(W[k], MW[k]) for k in range(B)]
     b0 = tcv.Batch(W, M, drops)
     b0.solve(opts); b0.marginalize(); b0.synchronize(); b0.download_priors()
+    pdev = b0.priors_device()          # the same priors as device-resident handles (their numbers stay in b0's result buffer): --mode stream
     main = synth.make_windows(first_id, B)
     wins, keep = [], []
     for k in range(B):
@@ -150,7 +152,7 @@ def build_batches(tcv, synth, first_id: int, B: int):
     Mm = [tcv.Window(mw, share=Wm[k], prior=Wm[k].prior) for k, mw in enumerate(MWm)]
     dropsm = [tcv.margin_old_drops(Wm[k], MWm[k]) for k in range(B)]
     batch = tcv.Batch(Wm, Mm, dropsm)
-    return batch, wins, (Wm, Mm, dropsm)
+    return batch, wins, (Wm, Mm, dropsm, pdev)
 
 
 # ---- CPU baseline (the ONLY part of this file that touches oracle/) -------------------------------------------------------
@@ -207,12 +209,24 @@ def cpu_baseline(wins, pool, nproc, budget_s: float = 12.0):
     wall = time.perf_counter() - t0
     pool.close(); pool.join()
     tot = sum(r[0] for r in res); tmax = max(r[1] for r in res)
+    rates = sorted(r[0] / r[1] for r in res)          # per process: its solves over ITS time inside the solver
     one_n, one_t = _cpu_worker(([wins[j % len(wins)] for j in range(per)], min(4.0, budget_s)))
-    return {"value": tot / tmax, "unit": "solves/s", "cores": nproc, "kind": "port",
+    flags = "unknown flags"
+    try:
+        for line in open(os.path.join(ROOT, "oracle", "Makefile")):
+            if line.startswith("CFLAGS"):
+                flags = "gcc " + line.split("=", 1)[1].strip()
+    except OSError:
+        pass
+    # value = the sum of the per-process rates (what the box delivers with every granted core busy); single_core_value = the median
+    # per-process rate of THAT run, so that value / cores and single_core_value are the same measurement seen two ways; the rate of one
+    # process alone on the otherwise idle box (higher or lower: boost clocks, the parent's GPU threads) is reported next to it
+    return {"value": sum(rates), "unit": "solves/s", "cores": nproc, "kind": "port",
             "sample": f"{tot} solves of the benchmark's windows ({SOLVER_ITERATIONS} fixed iterations + 1 MARGIN_OLD marginalisation each) on {nproc} host "
                       f"processes for {tmax:.1f} s ({wall:.1f} s wall), one thread per window stream like Ceres num_threads = 1 "
-                      f"(oracle/tcv_oracle.c, gcc -O3; dense Schur, not Ceres)",
-            "single_core_value": one_n / one_t, "single_core_sample": f"{one_n} solves in {one_t:.1f} s on one core",
+                      f"(oracle/tcv_oracle.c, {flags}; dense Schur, not Ceres)",
+            "single_core_value": rates[len(rates) // 2], "single_core_sample": f"median per-process rate of the {nproc}-process run (min {rates[0]:.1f}, max {rates[-1]:.1f})",
+            "one_process_alone_value": one_n / one_t, "one_process_alone_sample": f"{one_n} solves in {one_t:.1f} s, one process after the others have finished",
             "host_cpu": _cpu_model(), "host_cores_available": os.cpu_count(), "cgroup_cpu_quota_cores": _cpu_quota()}
 
 
@@ -232,7 +246,7 @@ def stream_figures(tcv, torch, keep, B_stream: int = 512, rounds: int = 4, wins=
     priors -> destroy, overlapped: two to four host threads, each with its own windows and HIP stream, so that one batch packs / copies
     while another computes.  Also the end-to-end and kernel-only latency of ONE window (the real-time single-estimator case)."""
     import threading
-    Wm, Mm, dropsm = keep
+    Wm, Mm, dropsm, pdev = keep
     # host threads, each with its own windows and HIP stream: as many 512-window sets as the batch holds, between 2 and 4
     # (`--mode stream --windows 2048`: four)
     NTH = int(os.environ.get("TCV_STREAM_THREADS", str(max(2, min(4, len(Wm) // B_stream)))))
@@ -242,16 +256,26 @@ def stream_figures(tcv, torch, keep, B_stream: int = 512, rounds: int = 4, wins=
     halves = [tcv.BatchSpec(Wm[i * B:(i + 1) * B], Mm[i * B:(i + 1) * B], dropsm[i * B:(i + 1) * B]) for i in range(NTH)]
     stage = {"pack_h2d": 0.0, "compute": 0.0, "d2h": 0.0}
 
+    resident = [True]      # priors device-resident (the default path since round 4) or through the host (round 3's path, for comparison)
+
     def one_pass(h, stream_ptr, acc=None):
         t0 = time.perf_counter()
         b = tcv.Batch(None, spec=h) if isinstance(h, tcv.BatchSpec) else tcv.Batch(*h)
         t1 = time.perf_counter()
         b.solve(opts, stream_ptr); b.gauge_fix(stream_ptr); b.marginalize(stream_ptr); b.synchronize()
         t2 = time.perf_counter()
-        b.download_states(); b.download_priors(compact=True)
-        pri = b.priors()      # host-resident tcv_prior of every window (J0, r0, linearisation point): what the next frame's problem takes
-        t3 = time.perf_counter()
-        del pri
+        b.download_states()
+        if resident[0]:
+            # last_marginalization_info stays in HBM: per window a handle (layout on the host) and two ints come down; the next frame's
+            # tcv_batch_create would splice it device-to-device exactly like the priors this pass was created from
+            pri = b.priors_device_raw()
+            t3 = time.perf_counter()
+            tcv.lib().tcv_priors_destroy(pri, len(pri))
+        else:
+            b.download_priors(compact=True)
+            pri = b.priors()      # host-resident tcv_prior of every window (J0, r0, linearisation point): what the next frame's problem takes
+            t3 = time.perf_counter()
+            del pri
         del b
         if acc is not None:
             acc["pack_h2d"] += t1 - t0; acc["compute"] += t2 - t1; acc["d2h"] += t3 - t2
@@ -262,23 +286,38 @@ def stream_figures(tcv, torch, keep, B_stream: int = 512, rounds: int = 4, wins=
             one_pass(h, st.cuda_stream)
 
     streams = [torch.cuda.Stream() for _ in range(NTH)]
-    one_pass(halves[0], streams[0].cuda_stream)          # warm-up
-    for _ in range(2):
-        one_pass(halves[0], streams[0].cuda_stream, stage)
-    t0 = time.perf_counter()
-    th = [threading.Thread(target=worker, args=(halves[i], streams[i])) for i in range(NTH)]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    dt = time.perf_counter() - t0
+
+    def timed():
+        for k in stage:
+            stage[k] = 0.0
+        one_pass(halves[0], streams[0].cuda_stream)          # warm-up
+        for _ in range(2):
+            one_pass(halves[0], streams[0].cuda_stream, stage)
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=worker, args=(halves[i], streams[i])) for i in range(NTH)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        return time.perf_counter() - t0, dict(stage)
+
+    # round 3's path first (host priors: pack + upload 46 KB, download 62 KB per window), then the same windows with their priors as
+    # device-resident handles (same bits in the pool: tests/test_gpu_resident.py)
+    resident[0] = False
+    dt_host, stage_host = timed()
+    nbind = NTH * B
+    tcv.check(tcv.lib().tcv_problems_set_marginalization_prior((C.c_void_p * nbind)(*[w.h for w in Wm[:nbind]]), (C.c_void_p * nbind)(*[p.h for p in pdev[:nbind]]), nbind))
+    tcv.check(tcv.lib().tcv_problems_set_marginalization_prior((C.c_void_p * nbind)(*[w.h for w in Mm[:nbind]]), (C.c_void_p * nbind)(*[p.h for p in pdev[:nbind]]), nbind))
+    resident[0] = True
+    dt, stage = timed()
     # one window: kernel-only (resident) and end-to-end (host blocks -> batch -> solve -> gauge fix -> marginalisation -> states and prior back).
     # The window is built afresh from its INITIAL states: the passes above left the batch's windows solved (download_states writes into the
     # caller's blocks, like ceres::Solve), and a converged window rejects its steps, i.e. skips most linearisations (round 2 timed that: 1.18 ms).
     def fresh_one():
         if wins is None:
             return ([Wm[0]], [Mm[0]], [dropsm[0]])
-        W1 = tcv.Window(wins[0]); mw = tcv.margin_old_window(wins[0]); M1 = tcv.Window(mw, share=W1, prior=W1.prior)
+        # (steady state of an estimator: the incoming prior is the previous frame's device-resident result)
+        W1 = tcv.Window(wins[0], prior=pdev[0]); mw = tcv.margin_old_window(wins[0]); M1 = tcv.Window(mw, share=W1, prior=W1.prior)
         return ([W1], [M1], [tcv.margin_old_drops(W1, mw)])
     one = fresh_one()
     b1 = tcv.Batch(*one)
@@ -296,9 +335,14 @@ def stream_figures(tcv, torch, keep, B_stream: int = 512, rounds: int = 4, wins=
         one_pass(one, None)
         e2e.append(time.perf_counter() - t1)
     return {"stream_solves_per_s": NTH * rounds * B / dt,
+            "stream_host_priors_solves_per_s": NTH * rounds * B / dt_host,
             "stream_note": f"PCIe-inclusive: {NTH} host threads x {rounds} passes x {B} windows, per pass pack + H2D (tcv_batch_create), solve + gauge fix + "
-                           f"marginalisation on the thread's own HIP stream, D2H of states and priors; serial stage times per {B}-window pass [ms]: "
-                           + ", ".join(f"{k} {1e3 * v / 2:.1f}" for k, v in stage.items()),
+                           f"marginalisation on the thread's own HIP stream, D2H of the states; the marginalisation priors are DEVICE-RESIDENT "
+                           f"(tcv_batch_get_priors_device: made on the device, spliced device-to-device into every pass's pool, the pass's own new "
+                           f"priors taken as handles: two ints per window down); serial stage times per {B}-window pass [ms]: "
+                           + ", ".join(f"{k} {1e3 * v / 2:.1f}" for k, v in stage.items())
+                           + "; stream_host_priors_solves_per_s = round 3's path (priors packed + uploaded, downloaded as 62 KB per window and "
+                           "turned into host objects): " + ", ".join(f"{k} {1e3 * v / 2:.1f}" for k, v in stage_host.items()),
             "single_window_ms": {"resident_launch_to_sync": 1e3 * float(np.median(lat)), "kernels": st1["solve_ms"] + st1["marg_ms"],
                                  "solve_kernel": st1["solve_ms"], "marg_kernel": st1["marg_ms"], "host_blocks_end_to_end": 1e3 * float(np.median(e2e)),
                                  "workgroups_per_window": 1 + co1["helpers"],

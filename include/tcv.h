@@ -258,6 +258,10 @@ int tcv_prior_is_device_resident(const tcv_prior *pr);
  * factor's parameter blocks: a caller whose graph does not change from frame to frame (a benchmark loop; a window in steady state)
  * re-uses its problem object and only hands over the new last_marginalization_info */
 int tcv_problem_set_marginalization_prior(tcv_problem *p, const tcv_prior *prior);
+/* the same for n problems at once (problems[k] takes priors[k]), and tcv_prior_destroy for n handles (NULL entries are skipped): a
+ * throughput loop hands a whole batch's priors on with two calls instead of 2 n */
+int tcv_problems_set_marginalization_prior(tcv_problem *const *problems, tcv_prior *const *priors, int n);
+void tcv_priors_destroy(tcv_prior *const *priors, int n);
 /* per-window status of the last marginalisation: 0 ok, 1 an eigen-solver hit its sweep cap, 2 result produced by the
  * cyclic-Jacobi safety net (the tridiagonal eigen-solver failed its orthogonality / trace self-check) */
 int tcv_batch_marg_status(tcv_batch *b, int *out, int n);

@@ -607,12 +607,7 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
                 if (rcs[w] != TCV_OK && msgs[t].empty()) msgs[t] = tcv_last_error();      // the message is thread-local
             }
         };
-        if (nth == 1) work(0);
-        else {
-            std::vector<std::thread> th;
-            for (int t = 0; t < nth; t++) th.emplace_back(work, t);
-            for (auto &x : th) x.join();
-        }
+        tcv::parallel_run(nth, work);
         for (int w = 0; w < n; w++) if (rcs[w] != TCV_OK) { msg = msgs[w % nth]; return rcs[w]; }
         return TCV_OK;
     };
@@ -703,12 +698,7 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
                 if (rcs[w] != TCV_OK && msgs[t].empty()) msgs[t] = tcv_last_error();
             }
         };
-        if (nth == 1) work(0);
-        else {
-            std::vector<std::thread> th;
-            for (int t = 0; t < nth; t++) th.emplace_back(work, t);
-            for (auto &x : th) x.join();
-        }
+        tcv::parallel_run(nth, work);
         for (int w = 0; w < n; w++) if (rcs[w] != TCV_OK) { host_staging_release(h_dpool); batch_free(b); if (!msgs[w % nth].empty()) set_error(msgs[w % nth]); return rcs[w]; }
         for (int w : splice_win) {      // the prior region of the window: in the tail, addressed relative to the window's own slice
             Packed &pk = b->packed[w];
@@ -1005,12 +995,7 @@ extern "C" int tcv_batch_get_priors(tcv_batch *b, tcv_prior **out, int n) {
             if (rc != TCV_OK) { rcs[t] = rc; msgs[t] = tcv_last_error(); return; }
         }
     };
-    if (nth == 1) work(0);
-    else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < nth; t++) th.emplace_back(work, t);
-        for (auto &x : th) x.join();
-    }
+    tcv::parallel_run(nth, work);
     for (int t = 0; t < nth; t++)
         if (rcs[t] != TCV_OK) {
             for (int k = 0; k < n; k++) if (out[k]) { tcv_prior_destroy(out[k]); out[k] = nullptr; }
@@ -1031,6 +1016,14 @@ extern "C" int tcv_problem_set_marginalization_prior(tcv_problem *p, const tcv_p
     if (old->n != prior->n || old->size != prior->size || old->idx != prior->idx) { set_error("set_marginalization_prior: the new prior has another layout"); return TCV_ERR_INVALID; }
     p->prior[0].prior = prior;
     return TCV_OK;
+}
+extern "C" int tcv_problems_set_marginalization_prior(tcv_problem *const *problems, tcv_prior *const *priors, int n) {
+    if (!problems || !priors || n < 0) return TCV_ERR_INVALID;
+    for (int k = 0; k < n; k++) if (int rc = tcv_problem_set_marginalization_prior(problems[k], priors[k])) return rc;
+    return TCV_OK;
+}
+extern "C" void tcv_priors_destroy(tcv_prior *const *priors, int n) {
+    if (priors) for (int k = 0; k < n; k++) delete priors[k];
 }
 extern "C" int tcv_batch_download_priors(tcv_batch *b) {
     if (!b) return TCV_ERR_INVALID;

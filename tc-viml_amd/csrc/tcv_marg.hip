@@ -1661,6 +1661,7 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((disable_tail_calls)) _
         }
         MARG_MARK(7);
         __syncthreads();
+        bool bad = false;      // a NaN in J0 | r0 (the host path scans the downloaded J0 for it)
         if (tid < n) {
             const double l = lam[tid];
             int rank = 0;
@@ -1670,10 +1671,25 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((disable_tail_calls)) _
             double rb = 0;
             for (int j = 0; j < n; j++) {
                 const double v = V2[j * ldn + tid];
-                out[MARG_OUT_J0 + rank + n * j] = ss * v;
+                const double o = ss * v;
+                out[MARG_OUT_J0 + rank + n * j] = o;
+                if (!(o == o)) bad = true;
                 rb += v * bv[j];
             }
             out[MARG_OUT_R0 + rank] = si * rb;
+            if (!(si * rb == si * rb) || !(l == l)) bad = true;
+        }
+        // what a device-resident consumer of this prior needs on the host (tcv_batch_get_priors_device): the number of leading rows of
+        // J0 | r0 that are exact zeros -- the thresholded eigenvalues rank first and their rows are 0 * v --, capped like
+        // tcv_packed.h prior_zero_rows() (one row is kept); -1: the result holds a NaN
+        {
+            const int any_bad = __syncthreads_or(bad ? 1 : 0);
+            if (tid == 0) {
+                int k0 = 0;
+                for (int j = 0; j < n; j++) k0 += (lam[j] > 1e-8) ? 0 : 1;
+                if (k0 >= n) k0 = n > 0 ? n - 1 : 0;
+                ((gbl_i *)Aarg.out_status)[Aarg.nwin + win] = any_bad ? -1 : k0;
+            }
         }
         for (int i = tid; i < H.nx; i += MARG_NT) out[MARG_OUT_X + i] = x[i];
         MARG_MARK(8);
@@ -1948,35 +1964,6 @@ static int pack_marg(const tcv_problem &p, double *const *drop, int ndrop, const
 }
 
 // ---- device-resident priors (tcv_batch_get_priors_device) --------------------------------------------------------------------------
-// number of leading rows of J0 | r0 that are exact zeros, per window, as tcv_packed.h prior_zero_rows() counts them on the host (at least
-// one row is kept); -1 when the result holds a NaN (the host path's scan of J0).  One wavefront per window.
-__global__ void __launch_bounds__(64) prior_k0_kernel(const double *out, const MargHdr *hdr, const int *status, int *k0_out, int nwin) {
-    const int w = blockIdx.x, lane = threadIdx.x;
-    if (w >= nwin) return;
-    const int n = hdr[w].n;
-    const double *J0 = out + (size_t)w * MARG_OUT_STRIDE + MARG_OUT_J0, *r0 = out + (size_t)w * MARG_OUT_STRIDE + MARG_OUT_R0;
-    if (status[w] < 0) { if (lane == 0) k0_out[w] = -1; return; }
-    bool nan = false;
-    unsigned long long zero[2] = {0ull, 0ull};      // bit i of zero[q]: row 64 q + i is an exact-zero row
-    for (int q = 0; q < 2; q++) {
-        const int i = lane + 64 * q;
-        bool z = i < n;
-        if (i < n) {
-            const double r = r0[i];
-            if (!(r == r)) nan = true;
-            if (r != 0.0) z = false;
-            for (int j = 0; j < n; j++) { const double v = J0[i + (size_t)n * j]; if (!(v == v)) nan = true; if (v != 0.0) z = false; }
-        }
-        zero[q] = __ballot(z);
-    }
-    const bool any_nan = __ballot(nan) != 0ull;
-    if (lane == 0) {
-        int k0 = 0;
-        while (k0 < n && ((zero[k0 >> 6] >> (k0 & 63)) & 1ull)) k0++;
-        if (k0 >= n) k0 = n > 0 ? n - 1 : 0;
-        k0_out[w] = any_nan ? -1 : k0;
-    }
-}
 // one workgroup per job: rows k0 .. n-1 of J0 (column by column), r0[k0 ..], the kept blocks' linearisation points -> the layout
 // pack_data_to() gives a host prior in the solve batch's data pool (tcv_pack.cpp; WinHdr::d_prior)
 __global__ void __launch_bounds__(256) prior_splice_kernel(const PriorSplice *jobs, double *dpool) {
@@ -2058,12 +2045,7 @@ int tcv_marg_attach(tcv_batch *b, tcv_problem *const *marg_problems, double *con
             s->win[w].hdr.solve_window = w;
         }
     };
-    if (nth == 1) work(0);
-    else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < nth; t++) th.emplace_back(work, t);
-        for (auto &x : th) x.join();
-    }
+    tcv::parallel_run(nth, work);
     for (int t = 0; t < nth; t++) if (rcs[t] != TCV_OK) { if (!msgs[t].empty()) set_error(msgs[t]); return rcs[t]; }
     std::vector<size_t> ib(nth + 1, 0), db(nth + 1, 0);
     for (int t = 0; t < nth; t++) { ib[t + 1] = ib[t] + It[t].size(); db[t + 1] = db[t] + Dt[t].size(); }
@@ -2097,12 +2079,7 @@ int tcv_marg_attach(tcv_batch *b, tcv_problem *const *marg_problems, double *con
             if (!It[t].empty()) std::memcpy(h_I + ib[t], It[t].data(), sizeof(int) * It[t].size());
             if (!Dt[t].empty()) std::memcpy(h_D + db[t], Dt[t].data(), sizeof(double) * Dt[t].size());
         };
-        if (nth == 1) copy(0);
-        else {
-            std::vector<std::thread> th;
-            for (int t = 0; t < nth; t++) th.emplace_back(copy, t);
-            for (auto &x : th) x.join();
-        }
+        tcv::parallel_run(nth, copy);
     }
     s->lds_bytes = lds;
     hipDeviceProp_t prop;
@@ -2156,9 +2133,6 @@ int tcv_marg_run(tcv_batch *b, void *stream) {
     else hipLaunchKernelGGL(marg_kernel<MARG_NT_WIDE>, dim3(s->grid), dim3(MARG_NT_WIDE), s->lds_bytes, st, a);
     if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "marg kernel launch");
     if ((e = hipEventRecord(s->ev1, st)) != hipSuccess) return hip_fail(e, "hipEventRecord");
-    // what a device-resident consumer of the priors needs on the host: the number of thresholded rows per window (one wavefront each)
-    hipLaunchKernelGGL(prior_k0_kernel, dim3(b->n), dim3(64), 0, st, (const double *)s->d_out, (const MargHdr *)s->d_hdr, (const int *)s->d_status, s->d_status + b->n, b->n);
-    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "prior k0 kernel launch");
     s->ran = true;
     s->h_valid = false;
     return TCV_OK;

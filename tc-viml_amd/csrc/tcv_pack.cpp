@@ -11,6 +11,9 @@
 #include <list>
 #include <map>
 #include <mutex>
+#include <functional>
+#include <deque>
+#include <condition_variable>
 #include <thread>
 #include <tuple>
 #include <unordered_map>
@@ -52,6 +55,75 @@ int host_threads(int want) {
     return std::max(1, std::min(want, std::max(1, host_core_grant() / active)));
 }
 int HostOp::threads(int want) const { return host_threads(want); }
+
+// ---- persistent worker threads (parallel_run, tcv_packed.h) ------------------------------------------------------------------
+// A batch-level call has three or four short parallel sections (plans, data, marginalisation problems, copies): 16 std::thread
+// creations and joins per section were ~2 ms of a 512-window tcv_batch_create.  The workers are created once (up to the core grant
+// minus the caller), sleep on a condition variable and claim task indices of the posted calls; the CALLER claims indices too, so a call
+// makes progress whatever the workers are busy with, and returns when every index has finished.  The pool object is never destroyed
+// (the detached workers may outlive static destruction).
+namespace {
+struct ParCall {
+    const std::function<void(int)> *fn;
+    int n;
+    std::atomic<int> next{0}, done{0};
+    std::mutex mu;
+    std::condition_variable cv;
+};
+struct WorkerPool {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::shared_ptr<ParCall>> q;
+    int nworkers = 0;
+};
+WorkerPool &worker_pool() { static WorkerPool *P = new WorkerPool(); return *P; }
+void run_call(ParCall &c) {
+    for (;;) {
+        const int t = c.next.fetch_add(1, std::memory_order_relaxed);
+        if (t >= c.n) return;
+        (*c.fn)(t);
+        if (c.done.fetch_add(1, std::memory_order_acq_rel) + 1 == c.n) { std::lock_guard<std::mutex> g(c.mu); c.cv.notify_all(); }
+    }
+}
+void worker_main() {
+    WorkerPool &P = worker_pool();
+    for (;;) {
+        std::shared_ptr<ParCall> c;
+        {
+            std::unique_lock<std::mutex> g(P.mu);
+            for (;;) {
+                while (!P.q.empty() && P.q.front()->next.load(std::memory_order_relaxed) >= P.q.front()->n) P.q.pop_front();      // fully claimed
+                if (!P.q.empty()) { c = P.q.front(); break; }
+                P.cv.wait(g);
+            }
+        }
+        run_call(*c);
+    }
+}
+}  // namespace
+void parallel_run(int nth, const std::function<void(int)> &fn) {
+    if (nth <= 1) { fn(0); return; }
+    static const bool off = getenv("TCV_NO_WORKER_POOL") != nullptr;      // A/B: a thread per task, as before
+    if (off) {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nth; t++) th.emplace_back(fn, t);
+        for (auto &x : th) x.join();
+        return;
+    }
+    WorkerPool &P = worker_pool();
+    auto c = std::make_shared<ParCall>();
+    c->fn = &fn; c->n = nth;
+    {
+        std::lock_guard<std::mutex> g(P.mu);
+        const int want = std::min(31, std::max(1, host_core_grant() - 1));
+        while (P.nworkers < std::min(want, nth - 1)) { std::thread(worker_main).detach(); P.nworkers++; }
+        P.q.push_back(c);
+    }
+    P.cv.notify_all();
+    run_call(*c);
+    std::unique_lock<std::mutex> g(c->mu);
+    c->cv.wait(g, [&] { return c->done.load(std::memory_order_acquire) >= c->n; });
+}
 
 // TCV_PRIOR_FULL: keep the exact-zero rows of the prior (A/B partner of the default).  The environment is read once per batch
 // (prior_refresh_switch), not once per window.

@@ -26,6 +26,12 @@ int chain_lds_doubles();       // LDS doubles of a chain-mode workgroup (two per
 // sixteen threads under a 16-core quota used to run 64 threads into the scheduler's throttling.  tcv_pack.cpp
 struct HostOp { HostOp(); ~HostOp(); int threads(int want) const; };
 int host_threads(int want);      // the same share for code that runs inside somebody's HostOp (does not count as an operation of its own)
+}  // namespace tcv
+#include <functional>
+namespace tcv {
+// fn(t) for t in [0, nth): index claiming by the calling thread and by persistent worker threads (created once, tcv_pack.cpp); returns
+// when all have finished.  nth <= 1: plain call.
+void parallel_run(int nth, const std::function<void(int)> &fn);
 bool prior_keep_zero_rows();   // developer A/B switch TCV_PRIOR_FULL (re-read by every tcv_batch_create / tcv_solve); tcv_pack.cpp
 void prior_refresh_switch();
 enum { MAX_TRACE = 64 };

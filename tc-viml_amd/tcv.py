@@ -40,6 +40,7 @@ EXPORTS = [
     "tcv_problem_set_frames", "tcv_gauge_fix", "tcv_batch_gauge_fix", "tcv_set_solver_variant", "tcv_set_cooperative", "tcv_batch_cooperative", "tcv_batch_get_priors", "tcv_batch_marg_status", "tcv_eval_projection_td_factors", "tcv_match_lines",
     "tcv_batch_download_priors", "tcv_batch_download_priors_compact",
     "tcv_batch_get_priors_device", "tcv_prior_is_device_resident", "tcv_problem_set_marginalization_prior",
+    "tcv_problems_set_marginalization_prior", "tcv_priors_destroy",
 ]
 
 
@@ -141,6 +142,9 @@ def lib():
         L.tcv_batch_get_priors_device.argtypes = [vp, C.POINTER(vp), C.c_int]
         L.tcv_prior_is_device_resident.argtypes = [vp]
         L.tcv_problem_set_marginalization_prior.argtypes = [vp, vp]
+        L.tcv_problems_set_marginalization_prior.argtypes = [C.POINTER(vp), C.POINTER(vp), C.c_int]
+        L.tcv_priors_destroy.argtypes = [C.POINTER(vp), C.c_int]
+        L.tcv_priors_destroy.restype = None
         L.tcv_batch_get_first_step.argtypes = [vp, C.c_int, _dp, C.c_int, _ip]
         L.tcv_batch_plan_stats.argtypes = [vp, _ip, _dp, _ip, _ip]
         L.tcv_batch_layout.argtypes = [vp]
@@ -449,6 +453,14 @@ class Batch:
         out = (C.c_void_p * n)()
         check(lib().tcv_batch_get_priors(self.h, out, n))
         return [Prior(C.c_void_p(h)) for h in out]
+
+    def priors_device_raw(self):
+        """tcv_batch_get_priors_device as a C array of handles (owned by the caller: tcv_priors_destroy) -- for loops that hand the priors
+        of a whole batch on with `tcv_problems_set_marginalization_prior` instead of wrapping every handle in a Python object"""
+        n = len(self.windows)
+        out = (C.c_void_p * n)()
+        check(lib().tcv_batch_get_priors_device(self.h, out, n))
+        return out
 
     def priors_device(self):
         """every window's prior as a DEVICE-RESIDENT handle (tcv_batch_get_priors_device): layout on the host, J0 | r0 | x0 left in HBM; a

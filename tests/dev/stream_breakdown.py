@@ -7,7 +7,7 @@ import numpy as np
 import synth, tcv, bench
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 batch, wins, keep = bench.build_batches(tcv, synth, 100000, B)
-Wm, Mm, dropsm = keep
+Wm, Mm, dropsm = keep[:3]
 opts = tcv.default_options(8, True)
 for rep in range(4):
     t0 = time.perf_counter()
