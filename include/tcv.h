@@ -40,6 +40,7 @@ typedef enum { TCV_LOSS_NONE = 0, TCV_LOSS_CAUCHY = 1 } tcv_loss;               
 typedef struct tcv_problem tcv_problem; /* ceres::Problem           estimator.cpp:1679 */
 typedef struct tcv_prior tcv_prior;     /* MarginalizationInfo      marginalization_factor.h:46-72 */
 typedef struct tcv_batch tcv_batch;     /* device-resident batch of independent windows (throughput mode) */
+typedef struct tcv_preint tcv_preint;   /* IntegrationBase whose numbers stay on the device (tcv_preintegrate_device) */
 
 /* IntegrationBase fields read by IMUFactor (imu_factor.h:16,61-79; integration_base.h:188-203). */
 typedef struct {
@@ -116,6 +117,9 @@ typedef struct {
     double td_TR, td_ROW;
     int line_exact_jacobian;   /* 0: the reference's line Jacobian; 1: tcv_problem_set_line_jacobian(p, 1) */
     int pad_;
+    /* optional (NULL: `imu` above): n_imu device-resident pre-integrations (tcv_preintegrate_device); entry k replaces imu[k].  A window
+     * whose IMU factors are all device-resident uploads none of the 287 doubles per factor. */
+    const tcv_preint *const *imu_device;
 } tcv_window_desc;
 
 /* ---- library ------------------------------------------------------------------------------ */
@@ -323,6 +327,21 @@ int tcv_match_lines(int n_frames, const double *poses, const double *ex_pose, co
  *   noise            : ACC_N, GYR_N, ACC_W, GYR_W (parameters.h; noise matrix integration_base.h:21-27) */
 int tcv_preintegrate(int n, const int *first, const int *count, const double *samples7, int num_samples,
                      const double *acc0_gyr0_ba_bg, const double noise[4], tcv_imu_preintegration *out);
+
+/* The same with the results LEFT ON THE DEVICE -- what `pre_integrations[]` are between two frames of the reference (estimator.h:
+ * pre_integrations[WINDOW_SIZE + 1], estimator.cpp:200-206): out[i] is a handle on pre-integration i in HBM.  A problem takes it through
+ * tcv_problem_add_imu_factor_device (or tcv_window_desc::imu_device); tcv_batch_create copies the factor's constants device-to-device.
+ * Only sum_dt -- the one number the window management reads (estimator.cpp:1726 `sum_dt > 10.0`) -- is kept on the host
+ * (tcv_preint_sum_dt: the sum of the dt column, added in the order the kernel adds it); tcv_preint_export materialises everything. */
+int tcv_preintegrate_device(int n, const int *first, const int *count, const double *samples7, int num_samples,
+                            const double *acc0_gyr0_ba_bg, const double noise[4], tcv_preint **out);
+double tcv_preint_sum_dt(const tcv_preint *pre);
+int tcv_preint_export(const tcv_preint *pre, tcv_imu_preintegration *out);
+void tcv_preint_destroy(tcv_preint *pre);
+/* IMUFactor(pre_integrations[j]) on a device-resident pre-integration (estimator.cpp:1723-1732); the handle must outlive the
+ * tcv_batch_create / tcv_solve / tcv_marginalize calls that use the problem */
+int tcv_problem_add_imu_factor_device(tcv_problem *p, const tcv_preint *pre, double *pose_i, double *speedbias_i, double *pose_j,
+                                      double *speedbias_j);
 
 /* ---- batched factor evaluation (parity / debug surface; CostFunction::Evaluate layout) ------- */
 /* All pointers are HOST pointers; the call uploads, evaluates on the GPU, downloads.

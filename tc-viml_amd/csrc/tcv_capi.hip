@@ -237,6 +237,21 @@ extern "C" int tcv_problem_add_imu_factor(tcv_problem *p, const tcv_imu_preinteg
     p->imu.push_back(f);
     return TCV_OK;
 }
+extern "C" int tcv_problem_add_imu_factor_device(tcv_problem *p, const tcv_preint *pre, double *pose_i, double *sb_i, double *pose_j, double *sb_j) {
+    if (!p || !pre) return TCV_ERR_INVALID;
+    ImuFac f;
+    std::memset(&f.pre, 0, sizeof f.pre);
+    f.pre.sum_dt = pre->sum_dt;
+    f.dev = pre;
+    double *a[4] = {pose_i, sb_i, pose_j, sb_j};
+    const int sz[4] = {7, 9, 7, 9};
+    for (int k = 0; k < 4; k++) {
+        f.b[k] = a[k] ? ensure_block(p, a[k], sz[k]) : -1;
+        if (f.b[k] < 0) { set_error("add_imu_factor_device: bad parameter block"); return TCV_ERR_INVALID; }
+    }
+    p->imu.push_back(f);
+    return TCV_OK;
+}
 extern "C" int tcv_problem_add_projection_factor(tcv_problem *p, const double pts_i[3], const double pts_j[3], double sqrt_info,
                                                  double loss_a, double *pose_i, double *pose_j, double *ex_pose,
                                                  double *inv_depth) {
@@ -390,6 +405,10 @@ extern "C" int tcv_problem_from_window(const tcv_window_desc *w, tcv_problem **o
     for (int k = 0; k < w->n_imu; k++) {   // :1723-1732
         if (w->imu[k].sum_dt > 10.0) continue;
         const int i = w->imu_frame_i[k], j = w->imu_frame_j[k];
+        if (w->imu_device && w->imu_device[k])
+            chk(tcv_problem_add_imu_factor_device(p, w->imu_device[k], w->para_pose + 7 * i, w->para_speedbias + 9 * i, w->para_pose + 7 * j,
+                                                  w->para_speedbias + 9 * j));
+        else
         chk(tcv_problem_add_imu_factor(p, w->imu + k, w->para_pose + 7 * i, w->para_speedbias + 9 * i, w->para_pose + 7 * j,
                                        w->para_speedbias + 9 * j));
     }
@@ -677,13 +696,15 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
     // device-resident priors (tcv_batch_get_priors_device): nothing of them is packed or uploaded.  Their J0 | r0 | x0 regions live in a
     // device-only tail behind the uploaded blob (WinHdr::d_prior is relative to the window's slice and simply points there), filled by one
     // splice job per window on the upload's stream
-    std::vector<int> splice_win;
-    std::vector<long long> tail_off(n, -1);
-    size_t tail_doubles = 0;
-    for (int w = 0; w < n; w++)
-        if (b->packed[w].dev_prior_doubles > 0) { splice_win.push_back(w); tail_off[w] = (long long)tail_doubles; tail_doubles += ((size_t)b->packed[w].dev_prior_doubles + 1) & ~(size_t)1; }
+    std::vector<int> splice_win, splice_imu_win;
+    std::vector<long long> tail_off(n, -1), tail_imu(n, -1);
+    size_t tail_doubles = 0, n_jobs = 0;
+    for (int w = 0; w < n; w++) {
+        if (b->packed[w].dev_prior_doubles > 0) { splice_win.push_back(w); tail_off[w] = (long long)tail_doubles; tail_doubles += ((size_t)b->packed[w].dev_prior_doubles + 1) & ~(size_t)1; n_jobs++; }
+        if (b->packed[w].dev_imu_doubles > 0) { splice_imu_win.push_back(w); tail_imu[w] = (long long)tail_doubles; tail_doubles += ((size_t)b->packed[w].dev_imu_doubles + 1) & ~(size_t)1; n_jobs += problems[w]->imu.size(); }
+    }
     const size_t o_jobs = up16(o_ipool + sizeof(int) * std::max<size_t>(1, ipool.size()));
-    const size_t in_bytes = up16(o_jobs + sizeof(PriorSplice) * splice_win.size());
+    const size_t in_bytes = up16(o_jobs + sizeof(PriorSplice) * n_jobs);
     const size_t dev_bytes = in_bytes + sizeof(double) * tail_doubles;
     if ((in_bytes + sizeof(double) * tail_doubles) / sizeof(double) >= ((size_t)1 << 31)) { batch_free(b); set_error("batch too large (data pool offsets are 32-bit)"); return TCV_ERR_TOO_LARGE; }
     double *h_dpool = (double *)host_staging_acquire(in_bytes);
@@ -703,6 +724,10 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
         for (int w : splice_win) {      // the prior region of the window: in the tail, addressed relative to the window's own slice
             Packed &pk = b->packed[w];
             pk.win.d_prior = (int)((long long)(in_bytes / sizeof(double)) + tail_off[w] - pk.win.dbase);
+        }
+        for (int w : splice_imu_win) {  // likewise the constants of its (device-resident) IMU factors
+            Packed &pk = b->packed[w];
+            pk.win.d_imu = (int)((long long)(in_bytes / sizeof(double)) + tail_imu[w] - pk.win.dbase);
         }
         for (int w = 0; w < n; w++) b->wins.push_back(b->packed[w].win);
     }
@@ -739,6 +764,7 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
             if (e_ != hipSuccess) { bail(); return hip_fail(e_, "hipMemcpy H2D"); }            \
         }                                                                                             \
     } while (0)
+    auto t_marg = t_packed, t_issue = t_packed, t_alloc = t_packed;
     if (marg_problems) {      // the marginalisation problems first: which IMU factor's sqrt_info the solve exports is part of the window headers
         hipError_t e_ = tcv::dev_malloc((void **)&b->d_sqrt_out, sizeof(double) * (size_t)n * 225);
         if (e_ != hipSuccess) { bail(); return hip_fail(e_, "hipMalloc"); }
@@ -746,6 +772,7 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
         if (rc != TCV_OK) { bail(); return rc; }
         for (int w = 0; w < n; w++) b->wins[w].sqrt_export = tcv_marg_sqrt_source(b, w);
     }
+    t_marg = std::chrono::steady_clock::now();
     {
         char *hb = (char *)h_dpool;
         std::memcpy(hb + o_win, b->wins.data(), sizeof(WinHdr) * (size_t)n);
@@ -762,17 +789,28 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
             J.n = pr->n; J.k0 = b->packed[w].win.prior_k0; J.nblk = (int)pr->size.size();
             for (int k = 0; k < J.nblk; k++) { J.goff[k] = pr->x_goff[k]; J.size[k] = pr->size[k]; }
         }
+        {
+            size_t q = splice_win.size();
+            for (int w : splice_imu_win)
+                for (size_t f = 0; f < problems[w]->imu.size(); f++, q++) {
+                    PriorSplice &J = hj[q];
+                    std::memset(&J, 0, sizeof J);
+                    J.kind = 1; J.src = problems[w]->imu[f].dev->d_out;
+                    J.dst = b->packed[w].win.dbase + b->packed[w].win.d_imu + (long long)f * IMU_CONST;
+                }
+        }
         hipError_t e_ = tcv::dev_malloc(&b->d_input, dev_bytes);
         if (e_ == hipSuccess) e_ = hipMemcpyAsync(b->d_input, hb, in_bytes, hipMemcpyHostToDevice, ust);
         if (e_ != hipSuccess) { bail(); return hip_fail(e_, "upload of the batch"); }
         char *db = (char *)b->d_input;
         b->d_dpool = (double *)db; b->d_win = (WinHdr *)(db + o_win); b->d_plans = (PlanHdr *)(db + o_plans);
         b->d_plan_base = (long long *)(db + o_pbase); b->d_ipool = (int *)(db + o_ipool);
-        if (!splice_win.empty()) {      // behind the upload on its stream; the sources are results of batches their handles synchronised
-            const int rcs = tcv::launch_prior_splice((const PriorSplice *)(db + o_jobs), (int)splice_win.size(), b->d_dpool, ust);
+        if (n_jobs > 0) {      // behind the upload on its stream; the sources are results of calls their handles synchronised
+            const int rcs = tcv::launch_prior_splice((const PriorSplice *)(db + o_jobs), (int)n_jobs, b->d_dpool, ust);
             if (rcs != TCV_OK) { bail(); return rcs; }
         }
     }
+    t_issue = std::chrono::steady_clock::now();
     UP(b->d_state, (double *)nullptr, double, (size_t)n * b->state_stride);
     UP(b->d_delta, (double *)nullptr, double, (size_t)n * b->delta_stride);
     UP(b->d_scratch, (double *)nullptr, double, (size_t)b->slots * scr);
@@ -788,6 +826,7 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
         UP(b->d_coop_exp, (double *)nullptr, double, (size_t)b->coop_groups * b->coop_exp_chunks * b->coop_exp_stride);
     }
 #undef UP
+    t_alloc = std::chrono::steady_clock::now();
     e0 = hipMemsetAsync(b->d_prof, 0, sizeof(double) * 32 * b->slots, ust);
     if (e0 == hipSuccess) e0 = hipMemsetAsync(b->d_scratch, 0, sizeof(double) * (size_t)b->slots * scr, ust);
     if (e0 == hipSuccess) e0 = hipMemsetAsync(b->d_summary, 0, sizeof(DevSummary) * (size_t)n, ust);
@@ -806,7 +845,9 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
     if (getenv("TCV_DEBUG_PACK")) {
         const auto t_end = std::chrono::steady_clock::now();
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) { return std::chrono::duration<double, std::milli>(c - a).count(); };
-        fprintf(stderr, "[batch_create] n %d: pack %.2f ms, alloc+upload %.2f ms, marg attach %.2f ms\n", n, ms(t_begin, t_packed), ms(t_packed, t_up), ms(t_up, t_end));
+        fprintf(stderr, "[batch_create] n %d: pack %.3f ms, marg attach %.3f ms, blob + upload issue + splice %.3f ms, allocations %.3f ms, memsets + sync %.3f ms (%d splice jobs, %.1f KB up)\n", n,
+                ms(t_begin, t_packed), ms(t_packed, t_marg), ms(t_marg, t_issue), ms(t_issue, t_alloc), ms(t_alloc, t_up), (int)n_jobs, in_bytes / 1024.0);
+        (void)t_end;
     }
     *out = b;
     return TCV_OK;

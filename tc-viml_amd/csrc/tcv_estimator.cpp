@@ -13,12 +13,14 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
 
 #include "../../include/tcv_estimator.h"
+namespace tcv { hipStream_t util_stream(); }      // (tcv_capi.hip: the calling thread's utility stream)
 
 namespace tcv { void set_error(const std::string &s); }
 
@@ -125,7 +127,8 @@ struct tcv_estimator {
     V3 tic;
     M3 ric;
     ImuBuf bufs[W + 1];
-    tcv_imu_preintegration pre[W + 1];
+    tcv_imu_preintegration pre[W + 1];       // host copy (TCV_EST_HOST_PREINT=1), otherwise only sum_dt is filled in
+    std::shared_ptr<tcv_preint> preh[W + 1]; // pre_integrations[] on the device (estimator.h: pre_integrations[WINDOW_SIZE + 1]); slots share a handle while a slide copies them
     bool pre_valid[W + 1];
     std::vector<Feature> features;
     std::vector<GivenLine> line_obs[W + 1];
@@ -149,6 +152,7 @@ struct tcv_estimator {
     std::vector<int> sel;                    // indices into `features` of the landmarks of the current window
     // factor lists of the current window
     std::vector<tcv_imu_preintegration> w_imu;
+    std::vector<const tcv_preint *> w_imu_dev, m_imu_dev;      // the same factors as device-resident handles (empty: host pre-integrations)
     std::vector<int> w_imu_i, w_imu_j, w_pi, w_pj, w_pl, w_lf;
     std::vector<double> w_pts, w_ld;
     double w_Ric[9];
@@ -343,9 +347,12 @@ int build_window(tcv_estimator *e) {
     for (size_t k = 0; k < e->features.size(); k++) if (selected(e->features[k])) e->sel.push_back((int)k);
     e->para_feature.resize(std::max<size_t>(1, e->sel.size()));
     for (size_t l = 0; l < e->sel.size(); l++) e->para_feature[l] = 1.0 / e->features[e->sel[l]].depth;
-    e->w_imu.clear(); e->w_imu_i.clear(); e->w_imu_j.clear();
+    e->w_imu.clear(); e->w_imu_i.clear(); e->w_imu_j.clear(); e->w_imu_dev.clear();
     for (int k = 0; k < W; k++)
-        if (e->pre[k + 1].sum_dt <= 10.0) { e->w_imu.push_back(e->pre[k + 1]); e->w_imu_i.push_back(k); e->w_imu_j.push_back(k + 1); }      // estimator.cpp:1726
+        if (e->pre[k + 1].sum_dt <= 10.0) {      // estimator.cpp:1726
+            e->w_imu.push_back(e->pre[k + 1]); e->w_imu_i.push_back(k); e->w_imu_j.push_back(k + 1);
+            e->w_imu_dev.push_back(e->preh[k + 1].get());
+        }
     e->w_pi.clear(); e->w_pj.clear(); e->w_pl.clear(); e->w_pts.clear();
     for (size_t l = 0; l < e->sel.size(); l++) {      // estimator.cpp:1737-1771
         const Feature &f = e->features[e->sel[l]];
@@ -394,20 +401,22 @@ void fill_desc(const tcv_estimator *e, tcv_window_desc &d, bool marg, int flag) 
     d.prior = e->prior; d.prior_block_kind = e->w_pk.data(); d.prior_block_index = e->w_pidx.data();
     if (!marg) {
         d.n_imu = (int)e->w_imu.size(); d.imu = e->w_imu.data(); d.imu_frame_i = e->w_imu_i.data(); d.imu_frame_j = e->w_imu_j.data();
+        d.imu_device = e->w_imu_dev.empty() ? nullptr : e->w_imu_dev.data();      // (entries may be null: that factor's host copy is used)
         d.n_proj = (int)e->w_pi.size(); d.proj_frame_i = e->w_pi.data(); d.proj_frame_j = e->w_pj.data(); d.proj_feature = e->w_pl.data(); d.proj_pts = e->w_pts.data();
         d.n_line = (int)e->w_lf.size(); d.line_frame = e->w_lf.data(); d.line_data = e->w_ld.data();
     } else if (flag == MARGIN_OLD) {
         d.n_imu = (int)e->m_imu.size(); d.imu = e->m_imu.data(); d.imu_frame_i = e->m_imu_i.data(); d.imu_frame_j = e->m_imu_j.data();
+        d.imu_device = e->m_imu_dev.empty() ? nullptr : e->m_imu_dev.data();
         d.n_proj = (int)e->m_pi.size(); d.proj_frame_i = e->m_pi.data(); d.proj_frame_j = e->m_pj.data(); d.proj_feature = e->m_pl.data(); d.proj_pts = e->m_pts.data();
     }
 }
 
 // factor set and drop sets MarginalizationInfo receives: estimator.cpp:1911-1986 (MARGIN_OLD), :2047-2063 (MARGIN_SECOND_NEW)
 void build_marg(tcv_estimator *e, int flag) {
-    e->m_imu.clear(); e->m_imu_i.clear(); e->m_imu_j.clear(); e->m_pi.clear(); e->m_pj.clear(); e->m_pl.clear(); e->m_pts.clear(); e->m_drop.clear();
+    e->m_imu.clear(); e->m_imu_dev.clear(); e->m_imu_i.clear(); e->m_imu_j.clear(); e->m_pi.clear(); e->m_pj.clear(); e->m_pl.clear(); e->m_pts.clear(); e->m_drop.clear();
     if (flag == MARGIN_OLD) {
         for (size_t k = 0; k < e->w_imu.size(); k++)
-            if (e->w_imu_i[k] == 0 && e->w_imu[k].sum_dt < 10.0) { e->m_imu.push_back(e->w_imu[k]); e->m_imu_i.push_back(0); e->m_imu_j.push_back(e->w_imu_j[k]); }
+            if (e->w_imu_i[k] == 0 && e->w_imu[k].sum_dt < 10.0) { e->m_imu.push_back(e->w_imu[k]); e->m_imu_dev.push_back(e->w_imu_dev[k]); e->m_imu_i.push_back(0); e->m_imu_j.push_back(e->w_imu_j[k]); }
         std::vector<int> lms;
         for (size_t k = 0; k < e->w_pi.size(); k++)
             if (e->w_pi[k] == 0) {
@@ -484,7 +493,7 @@ void slide_window(tcv_estimator *e) {
         const V3 back_P0 = e->Ps[0];
         for (int i = 0; i < W; i++) {      // the swaps of :2131-2153 followed by the copy of slot W-1 into W
             e->Ps[i] = e->Ps[i + 1]; e->Rs[i] = e->Rs[i + 1]; e->Vs[i] = e->Vs[i + 1]; e->Bas[i] = e->Bas[i + 1]; e->Bgs[i] = e->Bgs[i + 1];
-            e->bufs[i] = e->bufs[i + 1]; e->pre[i] = e->pre[i + 1]; e->pre_valid[i] = e->pre_valid[i + 1];
+            e->bufs[i] = e->bufs[i + 1]; e->pre[i] = e->pre[i + 1]; e->preh[i] = e->preh[i + 1]; e->pre_valid[i] = e->pre_valid[i + 1];
             e->line_obs[i] = e->line_obs[i + 1];                       // WorldLinesInFOV[W] = WorldLinesInFOV[W-1] (:2158): slot W keeps its content
             e->fov[i] = e->fov[i + 1];
         }
@@ -548,7 +557,7 @@ void slide_window(tcv_estimator *e) {
 static void clear_state(tcv_estimator *e) {
     const tcv_estimator_config *cfg = &e->cfg;
     for (int i = 0; i <= W; i++) {
-        e->Ps[i] = e->Vs[i] = e->Bas[i] = e->Bgs[i] = V3{0, 0, 0}; e->Rs[i] = eye(); e->pre_valid[i] = false; std::memset(&e->pre[i], 0, sizeof e->pre[i]);
+        e->Ps[i] = e->Vs[i] = e->Bas[i] = e->Bgs[i] = V3{0, 0, 0}; e->Rs[i] = eye(); e->pre_valid[i] = false; std::memset(&e->pre[i], 0, sizeof e->pre[i]); e->preh[i].reset();
         e->bufs[i] = ImuBuf(); e->line_obs[i].clear(); e->fov[i].clear();
     }
     for (int c = 0; c < 3; c++) e->tic[c] = cfg->tic[c];
@@ -654,6 +663,7 @@ extern "C" int tcv_estimators_profile(double *out8) {
     return TCV_OK;
 }
 
+enum { DEVICE_STATE_MIN_WINDOWS = 32 };      // estimators per lock-step call from which priors / pre-integrations stay on the device (see below)
 extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
     if (!es || n <= 0) return TCV_ERR_INVALID;
     double t_mark = now_s();
@@ -681,11 +691,27 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
         if (!who.empty()) {
             const tcv_estimator_config &c = es[0]->cfg;
             const double noise[4] = {c.acc_n, c.gyr_n, c.acc_w, c.gyr_w};
-            std::vector<tcv_imu_preintegration> out(who.size());
             if (samples.empty()) samples.push_back(0.0);
-            const int rc = tcv_preintegrate((int)who.size(), first.data(), count.data(), samples.data(), (int)samples.size() / 7, init.data(), noise, out.data());
-            if (rc != TCV_OK) return rc;
-            for (size_t k = 0; k < who.size(); k++) { es[who[k].first]->pre[who[k].second] = out[k]; es[who[k].first]->pre_valid[who[k].second] = true; }
+            // pre_integrations[] stay on the device (the reference keeps them alive between frames, too): a handle per buffer, sum_dt on the
+            // host.  TCV_EST_HOST_PREINT=1: round 3's round trip (3.7 KB down per buffer, 2.3 KB up per factor and window), same bits
+            if (getenv("TCV_EST_HOST_PREINT") || (n < DEVICE_STATE_MIN_WINDOWS && !getenv("TCV_EST_DEVICE_STATE"))) {
+                std::vector<tcv_imu_preintegration> out(who.size());
+                const int rc = tcv_preintegrate((int)who.size(), first.data(), count.data(), samples.data(), (int)samples.size() / 7, init.data(), noise, out.data());
+                if (rc != TCV_OK) return rc;
+                for (size_t k = 0; k < who.size(); k++) { tcv_estimator *e = es[who[k].first]; e->pre[who[k].second] = out[k]; e->preh[who[k].second].reset(); e->pre_valid[who[k].second] = true; }
+            } else {
+                std::vector<tcv_preint *> hd(who.size(), nullptr);
+                const int rc = tcv_preintegrate_device((int)who.size(), first.data(), count.data(), samples.data(), (int)samples.size() / 7, init.data(), noise, hd.data());
+                if (rc != TCV_OK) return rc;
+                for (size_t k = 0; k < who.size(); k++) {
+                    tcv_estimator *e = es[who[k].first];
+                    const int j = who[k].second;
+                    e->preh[j] = std::shared_ptr<tcv_preint>(hd[k], tcv_preint_destroy);
+                    std::memset(&e->pre[j], 0, sizeof e->pre[j]);
+                    e->pre[j].sum_dt = tcv_preint_sum_dt(hd[k]);
+                    e->pre_valid[j] = true;
+                }
+            }
         }
     }
     lap(0);
@@ -724,6 +750,11 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
     std::array<hipStream_t, 2> g_streams = device_streams();
     static const bool one_stream = getenv("TCV_EST_ONE_STREAM") != nullptr;      // tuning experiment: both batches of a frame on one stream
     if (one_stream) g_streams[1] = g_streams[0];
+    // tuning experiment TCV_EST_STREAM_MODE=2: both batches on the CALLING THREAD's utility stream (the stream its uploads, splices and
+    // downloads use anyway): one stream per host thread instead of two shared ones plus one per thread -- with the runtime's four hardware
+    // queues, five streams share queues, and a small copy of one thread can end up queued behind the other thread's 2 ms solve kernel
+    static const int stream_mode = getenv("TCV_EST_STREAM_MODE") ? atoi(getenv("TCV_EST_STREAM_MODE")) : 0;
+    if (stream_mode == 2) { g_streams[0] = g_streams[1] = tcv::util_stream(); }
     int rc_all = TCV_OK;
     for (int group = 1; group >= 0; group--) {
         Group &g = G[group];
@@ -769,12 +800,21 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
         if (g.idx.empty()) continue;
         const int nb = (int)g.idx.size();
         g.sum.resize(nb); g.newp.assign(nb, nullptr);
+        static const bool dbg_dl = getenv("TCV_DEBUG_EST") != nullptr;      // developer: where the "downloads" lap goes
+        const double td0 = now_s();
         if (g.rc == TCV_OK) g.rc = tcv_batch_download_states(g.b);
+        const double td1 = now_s();
         if (g.rc == TCV_OK) g.rc = tcv_batch_get_summaries(g.b, g.sum.data(), nb);
+        const double td2 = now_s();
         // last_marginalization_info stays on the device (estimator.h:176-177: the reference keeps it alive between frames, too): the new
         // priors are handles on the batch's result buffer, the next frame's tcv_batch_create splices them device-to-device.
         // TCV_EST_HOST_PRIORS=1: round 3's host round trip (62 KB down, 46 KB up per window), the A/B partner -- same bits
-        const bool host_priors = getenv("TCV_EST_HOST_PRIORS") != nullptr;
+        // Which way is faster depends on the batch: from a few dozen windows per frame the device-resident hand-over wins (512-window passes:
+        // 171 K against 117 K windows/s); a handful of windows per frame is latency-bound, and there the extra small commands on the
+        // thread's utility stream end up queued behind the OTHER host thread's 2 ms solve kernel when five streams share the runtime's four
+        // hardware queues (8 streams on 2 host threads: 1 420 against 1 920 windows/s; GPU_MAX_HW_QUEUES=8: 1 740 against 1 710).
+        // TCV_EST_DEVICE_STATE=1 / TCV_EST_HOST_PRIORS=1 force one or the other.
+        const bool host_priors = getenv("TCV_EST_HOST_PRIORS") != nullptr || (n < DEVICE_STATE_MIN_WINDOWS && !getenv("TCV_EST_DEVICE_STATE"));
         bool have_dev = false;
         if (g.rc == TCV_OK && group && !host_priors) have_dev = tcv_batch_get_priors_device(g.b, g.newp.data(), nb) == TCV_OK;      // (a window that failed: the per-window path below says which)
         if (g.rc == TCV_OK && group && !have_dev) g.rc = tcv_batch_download_priors_compact(g.b);
@@ -792,8 +832,12 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
                 if (g.est_rc[k] != TCV_OK && g.est_rc[k] != TCV_ERR_NUMERIC) { g.rc = g.est_rc[k]; break; }
                 if (g.est_rc[k] != TCV_OK) g.est_msg = tcv_last_error();
             }
+        const double td3 = now_s();
         if (g.b) tcv_batch_destroy(g.b);
+        const double td4 = now_s();
         for (int k = 0; k < nb; k++) { if (g.P[k]) tcv_problem_destroy(g.P[k]); if (g.M[k]) tcv_problem_destroy(g.M[k]); }
+        if (dbg_dl) fprintf(stderr, "[est] group %d n %d: states %.3f ms, summaries %.3f ms, priors %.3f ms, batch destroy %.3f ms, problems destroy %.3f ms\n", group, nb,
+                            1e3 * (td1 - td0), 1e3 * (td2 - td1), 1e3 * (td3 - td2), 1e3 * (td4 - td3), 1e3 * (now_s() - td4));
         if (g.rc != TCV_OK && rc_all == TCV_OK) rc_all = g.rc;
     }
     lap(5);

@@ -42,6 +42,17 @@ struct tcv_prior {
     mutable bool host = true;
     mutable std::mutex mu;            // materialisation (several packing threads may ask for it at once)
 };
+// IntegrationBase on the device (tcv_preintegrate_device): the kernel's output record [delta_p 3 | delta_q 4 | delta_v 3 | ba 3 | bg 3 |
+// sum_dt | jacobian 225 | covariance 225] stays in HBM
+struct tcv_preint {
+    std::shared_ptr<tcv::DevBlob> dev;
+    const double *d_out = nullptr;
+    double sum_dt = 0.0;
+    mutable bool host = false;
+    mutable tcv_imu_preintegration pod;
+    mutable std::mutex mu;
+};
+int tcv_preint_host(const tcv_preint *pre);      // materialises `pod` (once); TCV_OK or an error
 // the prior's numbers on the host: no-op for a host prior, one device-to-host copy (once) for a device-resident one; TCV_OK or an error
 int tcv_prior_host(const tcv_prior *pr);
 
@@ -52,7 +63,7 @@ struct ParamBlock {
     int size, kind;
     bool constant;
 };
-struct ImuFac { tcv_imu_preintegration pre; int b[4]; };
+struct ImuFac { tcv_imu_preintegration pre; int b[4]; const tcv_preint *dev = nullptr; };   // dev: the constants live on the device, `pre` holds sum_dt only
 struct ProjFac { double pts[6]; double sqrt_info, loss_a; int b[4]; double aux[8]; int btd; };   // btd >= 0: ProjectionTdFactor on block btd
 struct LineFac { double d[9]; double K[9], R[9], T[3]; double loss_a; int b; };
 struct PriorFac { const tcv_prior *prior; std::vector<int> b; };
@@ -71,6 +82,7 @@ struct Packed {
     std::vector<int> ints;
     std::vector<double> doubles;
     WinHdr win;
+    int dev_imu_doubles = 0;         // > 0: every IMU factor of the window is device-resident: n_imu x 287 doubles in the device-only tail (WinHdr::d_imu points there)
     int dev_prior_doubles = 0;       // > 0: the window's prior is device-resident: doubles of its J0 | r0 | x0 region, which lives in the batch's
                                      // device-only tail (not in the uploaded slice) and is filled by the splice kernel of tcv_batch_create
     // host-side maps for download
@@ -159,7 +171,9 @@ int tcv_marg_get_priors_device(tcv_batch *b, tcv_prior **out, int n);
 // copies device-resident priors into a batch's data pool (one job per window that holds one): launched by tcv_batch_create on the stream
 // of its upload, behind it
 namespace tcv {
-struct PriorSplice { const double *src; long long dst; int n, k0, nblk, pad; int goff[32], size[32]; };
+// kind 0: a prior (src = the result block of its window, tcv_marg.hip MARG_OUT_*); kind 1: an IMU factor's constants (src = the
+// pre-integration kernel's output record; n, k0, nblk unused)
+struct PriorSplice { const double *src; long long dst; int n, k0, nblk, kind; int goff[32], size[32]; };
 enum { PRIOR_SPLICE_MAX_BLOCKS = 32 };
 int launch_prior_splice(const PriorSplice *d_jobs, int njobs, double *d_dpool, hipStream_t st);
 }  // namespace tcv

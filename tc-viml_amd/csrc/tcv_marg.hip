@@ -60,6 +60,8 @@ struct MargHdr {
     long long prior_abs;   // >= 0: J0 | r0 | x0 of the prior are read from the solve batch's data pool at this offset (the marginalised factor
                            // set holds the same prior object as the solve problem: no second copy is packed or uploaded)
     int solve_window;
+    long long imu_abs;     // >= 0: the (single) IMU factor's 287 constants are read from the solve batch's data pool at this offset (the
+                           // factor is one of the solve problem's: no second copy is packed, uploaded or spliced)
     int block_mode;   // 1: the marginalised inverse depths (1 x 1 blocks) are eliminated by scalar pivots while the factors are
                       // accumulated, only the frame part of the dropped set (m) goes through the eigen pseudo-inverse
     int o_plast;      // block mode: n_proj flags, 1 = last factor of its landmark (factors sorted by landmark)
@@ -1187,19 +1189,20 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((disable_tail_calls)) _
         }
         MARG_MARK(1);
         // ---- IMU factors, one at a time (only the factor touching the marginalised frame is passed in)
+        cst_d *imu0 = H.imu_abs >= 0 ? (cst_d *)Aarg.solve_dpool + H.imu_abs : dp + H.d_imu;      // (the factor's constants: this problem's own copy, or the solve batch's)
         for (int f = 0; f < H.n_imu; f++) {
             cst_i *b = ip + H.o_imu + f * 4;
             lds_d *S = stage + 1500;
             // sqrt_info: the one the solve of this batch computed from the same covariance with the same code (bit-identical), else here
             const bool s_given = Aarg.solve_sqrt != nullptr && H.sqrt_src >= 0 && H.n_imu == 1;
             if (s_given) { for (int i = tid; i < 225; i += MARG_NT) S[i] = ((const gbl_d *)Aarg.solve_sqrt)[(size_t)H.solve_window * 225 + i]; }
-            else if (tid < 16) (void)imu_sqrt_info_group(dp + H.d_imu + f * IMU_CONST + IMU_COV, S, stage + 512, stage + 512 + 225, tid);
+            else if (tid < 16) (void)imu_sqrt_info_group(imu0 + f * IMU_CONST + IMU_COV, S, stage + 512, stage + 512 + 225, tid);
             // the four parts of the raw residual / Jacobian on four wavefronts: lane 0 of waves 1..4, or (256 threads) lane 32 of waves 0..3
             constexpr int RW0 = MARG_NT >= 320 ? 1 : 0, RLANE = MARG_NT >= 320 ? 0 : 32;
             if ((tid & 63) == RLANE && (tid >> 6) >= RW0 && (tid >> 6) < RW0 + 4) {
                 double cst[62];
 #pragma unroll
-                for (int i = 0; i < 62; i++) cst[i] = dp[H.d_imu + f * IMU_CONST + i];
+                for (int i = 0; i < 62; i++) cst[i] = imu0[f * IMU_CONST + i];
                 imu_raw_part((tid >> 6) - RW0, CGEN(x + blk[b[0] * 5 + 1]), CGEN(x + blk[b[1] * 5 + 1]), CGEN(x + blk[b[2] * 5 + 1]),
                              CGEN(x + blk[b[3] * 5 + 1]), cst, G3, GEN(stage), IMU_STRIDE_J, true);
             }
@@ -1673,17 +1676,29 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((disable_tail_calls)) _
                 const double v = V2[j * ldn + tid];
                 const double o = ss * v;
                 out[MARG_OUT_J0 + rank + n * j] = o;
+#ifndef TCV_MARG_NO_K0
                 if (!(o == o)) bad = true;
+#endif
                 rb += v * bv[j];
             }
             out[MARG_OUT_R0 + rank] = si * rb;
+#ifndef TCV_MARG_NO_K0
             if (!(si * rb == si * rb) || !(l == l)) bad = true;
+#endif
         }
         // what a device-resident consumer of this prior needs on the host (tcv_batch_get_priors_device): the number of leading rows of
         // J0 | r0 that are exact zeros -- the thresholded eigenvalues rank first and their rows are 0 * v --, capped like
         // tcv_packed.h prior_zero_rows() (one row is kept); -1: the result holds a NaN
+#ifndef TCV_MARG_NO_K0
         {
-            const int any_bad = __syncthreads_or(bad ? 1 : 0);
+            // (NOT __syncthreads_or: its work-group reduction brings a static LDS variable of its own, and 80 KiB + 4 bytes per workgroup is
+            // one workgroup per CU instead of two -- 0.85 -> 1.40 ms per 1024 windows, measured)
+            lds_i *badf = cnt;      // (the Jacobi sweeps' counter: free here)
+            if (tid == 0) *badf = 0;
+            __syncthreads();
+            if (bad) *badf = 1;
+            __syncthreads();
+            const int any_bad = *badf;
             if (tid == 0) {
                 int k0 = 0;
                 for (int j = 0; j < n; j++) k0 += (lam[j] > 1e-8) ? 0 : 1;
@@ -1691,6 +1706,7 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((disable_tail_calls)) _
                 ((gbl_i *)Aarg.out_status)[Aarg.nwin + win] = any_bad ? -1 : k0;
             }
         }
+#endif
         for (int i = tid; i < H.nx; i += MARG_NT) out[MARG_OUT_X + i] = x[i];
         MARG_MARK(8);
         if (tid == 0) ((gbl_i *)Aarg.out_status)[win] = (sweeps1 >= 24 || sweeps2 == 124) ? 1 : (sweeps2 >= 100 ? 2 : 0);   // 1: a Jacobi sweep hit its cap, 2: A' went through the Jacobi safety net
@@ -1848,8 +1864,11 @@ static int pack_marg(const tcv_problem &p, double *const *drop, int ndrop, const
     for (auto &f : p.imu) for (int k = 0; k < 4; k++) I.push_back(id_of[f.b[k]]);
     H.sqrt_src = -1;
     if (p.imu.size() == 1 && solve_p)      // the same pre-integration among the solve's factors (MARGIN_OLD: the factor between frames 0 and 1)
-        for (size_t g = 0; g < solve_p->imu.size(); g++)
-            if (std::memcmp(&solve_p->imu[g].pre, &p.imu[0].pre, sizeof(tcv_imu_preintegration)) == 0) { H.sqrt_src = (int)g; break; }
+        for (size_t g = 0; g < solve_p->imu.size(); g++) {
+            const bool same = p.imu[0].dev ? solve_p->imu[g].dev == p.imu[0].dev
+                                           : (!solve_p->imu[g].dev && std::memcmp(&solve_p->imu[g].pre, &p.imu[0].pre, sizeof(tcv_imu_preintegration)) == 0);
+            if (same) { H.sqrt_src = (int)g; break; }
+        }
     std::vector<int> porder(p.proj.size());
     for (size_t i = 0; i < porder.size(); i++) porder[i] = (int)i;
     if (block_mode) {
@@ -1927,8 +1946,13 @@ static int pack_marg(const tcv_problem &p, double *const *drop, int ndrop, const
     H.d_x = dmark();
     for (int c = 0; c < nblk; c++) { const ParamBlock &pb = p.blocks[orig[c]]; D.insert(D.end(), pb.addr, pb.addr + pb.size); }
     H.d_imu = dmark();
+    // the factor's constants are the solve problem's (same pre-integration): the kernel reads them from the solve batch's pool
+    H.imu_abs = -1;
+    if (H.sqrt_src >= 0 && solve_pk && !getenv("TCV_MARG_OWN_IMU")) H.imu_abs = solve_pk->win.dbase + solve_pk->win.d_imu + (long long)H.sqrt_src * IMU_CONST;
     for (auto &f : p.imu) {
-        const tcv_imu_preintegration &q = f.pre;
+        if (H.imu_abs >= 0) break;
+        if (f.dev) { if (int rc = tcv_preint_host(f.dev)) return rc; }      // (no shared copy to read from: the numbers are needed here)
+        const tcv_imu_preintegration &q = f.dev ? f.dev->pod : f.pre;
         D.insert(D.end(), q.delta_p, q.delta_p + 3); D.insert(D.end(), q.delta_q, q.delta_q + 4);
         D.insert(D.end(), q.delta_v, q.delta_v + 3); D.insert(D.end(), q.linearized_ba, q.linearized_ba + 3);
         D.insert(D.end(), q.linearized_bg, q.linearized_bg + 3); D.push_back(q.sum_dt);
@@ -1971,6 +1995,21 @@ __global__ void __launch_bounds__(256) prior_splice_kernel(const PriorSplice *jo
     const int n = J.n, k0 = J.k0, nr = n - k0, tid = threadIdx.x;
     const double *src = J.src;
     double *dst = dpool + J.dst;
+    if (J.kind == 1) {
+        // pre-integration record -> the 287 doubles of an IMU factor (tcv_pack.cpp pack_data_to): [dp dq dv ba bg sum_dt] as they are, the five
+        // 3 x 3 bias Jacobians dp_dba dp_dbg dq_dbg dv_dba dv_dbg (imu_factor.h:61-79) out of the 15 x 15 jacobian, the covariance
+        for (int i = tid; i < 287; i += 256) {
+            double v;
+            if (i < 17) v = src[i];
+            else if (i < 62) {
+                const int q = i - 17, blk = q / 9, e = q - 9 * blk, r = e / 3, c = e - 3 * r;
+                const int r0 = (blk < 2) ? 0 : (blk == 2 ? 3 : 6), c0 = (blk == 0 || blk == 3) ? 9 : 12;
+                v = src[17 + (r0 + r) * 15 + c0 + c];
+            } else v = src[242 + (i - 62)];
+            dst[i] = v;
+        }
+        return;
+    }
     for (int e = tid; e < nr * n; e += 256) { const int j = e / nr, i = e - j * nr; dst[e] = src[MARG_OUT_J0 + (size_t)n * j + k0 + i]; }
     for (int i = tid; i < nr; i += 256) dst[nr * n + i] = src[MARG_OUT_R0 + k0 + i];
     int xo = nr * n + nr;

@@ -897,8 +897,19 @@ static int pack_data_to(const tcv_problem &p, Packed &out, const double *imu_sqr
     for (int c = 0; c < nblk; c++) { const ParamBlock &pb = p.blocks[out.cam_block[c]]; D.put(pb.addr, pb.size); }
     for (int l = 0; l < L; l++) D.put1(p.blocks[out.lm_block[l]].addr[0]);
     W.d_imu = (int)D.n;
+    // device-resident pre-integrations (tcv_preintegrate_device): when EVERY IMU factor of the window is one, nothing is written here --
+    // tcv_batch_create places the n_imu x 287 region in the batch's device-only tail (it patches d_imu) and a splice job per factor fills it.
+    // Decided by the sizing pass, like the prior's (a mixed window materialises its device-resident ones on the host).
+    bool imu_on_device = out.dev_imu_doubles > 0;
+    if (!D.dst) {
+        imu_on_device = !p.imu.empty();
+        for (auto &f : p.imu) if (!f.dev) imu_on_device = false;
+    }
+    out.dev_imu_doubles = imu_on_device ? (int)p.imu.size() * IMU_CONST : 0;
     for (auto &f : p.imu) {
-        const tcv_imu_preintegration &q = f.pre;
+        if (imu_on_device) break;
+        if (f.dev) { if (int rc = tcv_preint_host(f.dev)) return rc; }
+        const tcv_imu_preintegration &q = f.dev ? f.dev->pod : f.pre;
         D.put(q.delta_p, 3); D.put(q.delta_q, 4); D.put(q.delta_v, 3); D.put(q.linearized_ba, 3); D.put(q.linearized_bg, 3); D.put1(q.sum_dt);
         const int rc[5][2] = {{0, 9}, {0, 12}, {3, 12}, {6, 9}, {6, 12}};   // dp_dba dp_dbg dq_dbg dv_dba dv_dbg (imu_factor.h:61-79)
         for (auto &b : rc) for (int i = 0; i < 3; i++) D.put(q.jacobian + (b[0] + i) * 15 + b[1], 3);

@@ -165,48 +165,108 @@ __global__ void __launch_bounds__(256) preint_kernel(PreintArgs A) {
 }  // namespace tcv
 using namespace tcv;
 
-// IntegrationBase ctor + push_back x count[i] (integration_base.h:13-36, :130-158); repropagate (:38-52) = same call with new biases
-extern "C" int tcv_preintegrate(int n, const int *first, const int *count, const double *samples7, int num_samples,
-                                const double *acc0_gyr0_ba_bg, const double noise[4], tcv_imu_preintegration *out) {
-    if (n <= 0 || !first || !count || !samples7 || num_samples < 0 || !acc0_gyr0_ba_bg || !noise || !out) return TCV_ERR_INVALID;
+// IntegrationBase ctor + push_back x count[i] (integration_base.h:13-36, :130-158); repropagate (:38-52) = same call with new biases.
+// One pinned staging buffer, one copy in, everything on the calling thread's own stream: [init 12 n | samples 7 ns | first n, count n
+// (ints)] -> device; the kernel's output records (PREINT_OUT doubles each) either come back through the same staging buffer
+// (tcv_preintegrate) or stay where they are, in a buffer of their own that the returned handles share (tcv_preintegrate_device).
+static int preintegrate_core(int n, const int *first, const int *count, const double *samples7, int num_samples, const double *acc0_gyr0_ba_bg,
+                             const double noise[4], tcv_imu_preintegration *out, tcv_preint **handles) {
+    if (n <= 0 || !first || !count || !samples7 || num_samples < 0 || !acc0_gyr0_ba_bg || !noise || (!out && !handles)) return TCV_ERR_INVALID;
     for (int i = 0; i < n; i++)
         if (first[i] < 0 || count[i] < 0 || first[i] + count[i] > num_samples) { set_error("preintegrate: sample range out of bounds"); return TCV_ERR_INVALID; }
     if (int rc = device_ready()) return rc;
     PreintArgs a;
     a.n = n;
     for (int i = 0; i < 4; i++) a.noise[i] = noise[i];
-    // one pinned staging buffer, one copy in, one copy out, everything on the calling thread's own stream:
-    // [init 12 n | samples 7 ns | first n, count n (ints)] -> device; [out PREINT_OUT n] <- device
     const size_t ns = (size_t)std::max(1, num_samples);
     const size_t in_d = 12 * (size_t)n + 7 * ns, in_bytes = sizeof(double) * in_d + sizeof(int) * 2 * (size_t)n, out_bytes = sizeof(double) * PREINT_OUT * (size_t)n;
-    char *h = (char *)tcv::host_staging_acquire(in_bytes + out_bytes);
+    char *h = (char *)tcv::host_staging_acquire(in_bytes + (out ? out_bytes : 0));
     if (!h) { set_error("hipHostMalloc (staging) failed"); return TCV_ERR_HIP; }
-    char *d = nullptr;
-    hipError_t e = tcv::dev_malloc((void **)&d, in_bytes + out_bytes + 16);
-    auto done = [&](int rc) { tcv::host_staging_release(h); (void)tcv::dev_free(d); return rc; };
+    char *d = nullptr, *d_res = nullptr;      // inputs (+ outputs of the host variant); the device variant's outputs
+    hipStream_t st = tcv::util_stream();
+    bool in_flight = false;
+    auto done = [&](int rc) {
+        if (in_flight) (void)(st ? hipStreamSynchronize(st) : hipDeviceSynchronize());      // the pinned buffer and the blobs go back to pools
+        tcv::host_staging_release(h); (void)tcv::dev_free(d);
+        if (rc != TCV_OK) (void)tcv::dev_free(d_res);
+        return rc;
+    };
+    const size_t out_off = (in_bytes + 15) & ~(size_t)15;
+    hipError_t e = tcv::dev_malloc((void **)&d, out_off + (handles ? 0 : out_bytes) + 16);
+    if (e == hipSuccess && handles) e = tcv::dev_malloc((void **)&d_res, out_bytes);
     if (e != hipSuccess) return done(hip_fail(e, "hipMalloc"));
     double *hd = (double *)h;
     std::memcpy(hd, acc0_gyr0_ba_bg, sizeof(double) * 12 * (size_t)n);
     if (num_samples) std::memcpy(hd + 12 * (size_t)n, samples7, sizeof(double) * 7 * (size_t)num_samples);
     int *hi = (int *)(hd + in_d);
     std::memcpy(hi, first, sizeof(int) * n); std::memcpy(hi + n, count, sizeof(int) * n);
-    const size_t out_off = (in_bytes + 15) & ~(size_t)15;
-    hipStream_t st = tcv::util_stream();
+    in_flight = true;
     if ((e = hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, st)) != hipSuccess) return done(hip_fail(e, "hipMemcpyAsync"));
     a.init = (const double *)d; a.samples = (const double *)d + 12 * (size_t)n; a.first = (const int *)((const double *)d + in_d); a.count = a.first + n;
-    a.out = (double *)(d + out_off);
+    a.out = handles ? (double *)d_res : (double *)(d + out_off);
     hipLaunchKernelGGL(preint_kernel, dim3(std::min(n, 4096)), dim3(256), 0, st, a);
     if ((e = hipGetLastError()) != hipSuccess) return done(hip_fail(e, "preint kernel launch"));
     char *ho = h + in_bytes;
-    if ((e = hipMemcpyAsync(ho, d + out_off, out_bytes, hipMemcpyDeviceToHost, st)) != hipSuccess) return done(hip_fail(e, "hipMemcpyAsync"));
+    if (out && (e = hipMemcpyAsync(ho, (const char *)a.out, out_bytes, hipMemcpyDeviceToHost, st)) != hipSuccess) return done(hip_fail(e, "hipMemcpyAsync"));
     if ((e = (st ? hipStreamSynchronize(st) : hipDeviceSynchronize())) != hipSuccess) return done(hip_fail(e, "hipStreamSynchronize"));
-    for (int i = 0; i < n; i++) {
-        const double *o = (const double *)ho + (size_t)i * PREINT_OUT;
-        tcv_imu_preintegration &p = out[i];
-        std::memcpy(p.delta_p, o, 24); std::memcpy(p.delta_q, o + 3, 32); std::memcpy(p.delta_v, o + 7, 24);
-        std::memcpy(p.linearized_ba, o + 10, 24); std::memcpy(p.linearized_bg, o + 13, 24); p.sum_dt = o[16];
-        std::memcpy(p.jacobian, o + 17, 225 * 8); std::memcpy(p.covariance, o + 242, 225 * 8);
+    in_flight = false;
+    if (out)
+        for (int i = 0; i < n; i++) {
+            const double *o = (const double *)ho + (size_t)i * PREINT_OUT;
+            tcv_imu_preintegration &p = out[i];
+            std::memcpy(p.delta_p, o, 24); std::memcpy(p.delta_q, o + 3, 32); std::memcpy(p.delta_v, o + 7, 24);
+            std::memcpy(p.linearized_ba, o + 10, 24); std::memcpy(p.linearized_bg, o + 13, 24); p.sum_dt = o[16];
+            std::memcpy(p.jacobian, o + 17, 225 * 8); std::memcpy(p.covariance, o + 242, 225 * 8);
+        }
+    if (handles) {
+        auto blob = std::make_shared<tcv::DevBlob>();
+        blob->p = d_res; (void)hipGetDevice(&blob->dev);
+        for (int i = 0; i < n; i++) {
+            tcv_preint *q = new tcv_preint();
+            q->dev = blob; q->d_out = (const double *)d_res + (size_t)i * PREINT_OUT;
+            double sdt = 0.0;      // IntegrationBase::sum_dt: the kernel starts at 0.0 and adds the dt column row by row -- the same sum, the same bits
+            for (int k = 0; k < count[i]; k++) sdt += samples7[7 * (size_t)(first[i] + k)];
+            q->sum_dt = sdt;
+            handles[i] = q;
+        }
     }
     (void)done(TCV_OK);
     return TCV_OK;
 }
+extern "C" int tcv_preintegrate(int n, const int *first, const int *count, const double *samples7, int num_samples,
+                                const double *acc0_gyr0_ba_bg, const double noise[4], tcv_imu_preintegration *out) {
+    if (!out) return TCV_ERR_INVALID;
+    return preintegrate_core(n, first, count, samples7, num_samples, acc0_gyr0_ba_bg, noise, out, nullptr);
+}
+extern "C" int tcv_preintegrate_device(int n, const int *first, const int *count, const double *samples7, int num_samples,
+                                       const double *acc0_gyr0_ba_bg, const double noise[4], tcv_preint **out) {
+    if (!out) return TCV_ERR_INVALID;
+    for (int i = 0; i < std::max(n, 0); i++) out[i] = nullptr;
+    return preintegrate_core(n, first, count, samples7, num_samples, acc0_gyr0_ba_bg, noise, nullptr, out);
+}
+int tcv_preint_host(const tcv_preint *pre) {
+    if (!pre) return TCV_ERR_INVALID;
+    std::lock_guard<std::mutex> g(pre->mu);
+    if (pre->host) return TCV_OK;
+    double o[PREINT_OUT];
+    int cur = 0;
+    const bool sw = hipGetDevice(&cur) == hipSuccess && pre->dev && cur != pre->dev->dev;
+    if (sw) (void)hipSetDevice(pre->dev->dev);
+    const hipError_t e = hipMemcpy(o, pre->d_out, sizeof o, hipMemcpyDeviceToHost);
+    if (sw) (void)hipSetDevice(cur);
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpy D2H (device-resident pre-integration)");
+    tcv_imu_preintegration &p = pre->pod;
+    std::memcpy(p.delta_p, o, 24); std::memcpy(p.delta_q, o + 3, 32); std::memcpy(p.delta_v, o + 7, 24);
+    std::memcpy(p.linearized_ba, o + 10, 24); std::memcpy(p.linearized_bg, o + 13, 24); p.sum_dt = o[16];
+    std::memcpy(p.jacobian, o + 17, 225 * 8); std::memcpy(p.covariance, o + 242, 225 * 8);
+    pre->host = true;
+    return TCV_OK;
+}
+extern "C" double tcv_preint_sum_dt(const tcv_preint *pre) { return pre ? pre->sum_dt : 0.0; }
+extern "C" int tcv_preint_export(const tcv_preint *pre, tcv_imu_preintegration *out) {
+    if (!pre || !out) return TCV_ERR_INVALID;
+    if (int rc = tcv_preint_host(pre)) return rc;
+    *out = pre->pod;
+    return TCV_OK;
+}
+extern "C" void tcv_preint_destroy(tcv_preint *pre) { delete pre; }

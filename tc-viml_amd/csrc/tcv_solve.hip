@@ -61,7 +61,9 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 #endif
 enum { AB_VIS_EVAL = 0, AB_VIS_GATHER, AB_LM, AB_SCHUR, AB_PRIOR_A, AB_IMU_RAW, AB_IMU_WHITEN, AB_IMU_GATHER, AB_PRIOR_B, AB_FIN_SCALE, AB_FIN_PASS,
        AB_CHAIN_FWD, AB_CHOL, AB_BACK, AB_CHAIN_BWD, AB_LM_BACK, AB_DOGLEG, AB_PLUS, AB_NORMS, AB_SETUP, AB_CH_T, AB_CH_W, AB_CH_MFMA, AB_CH_FETCH,
-       AB_COPY_PROG /* only together with the gathers */, AB_ZERO };
+       AB_COPY_PROG /* only together with the gathers */, AB_ZERO,
+       AB_CH_HALF /* NOT a phase: the chain runs over every second step record only (blocks 0, 2, 4, ... of the elimination order: 6 of 11 steps): what a
+                     cyclic-reduction order could save at most on the sequential part, before its first level is paid for */ };
 enum { PH_SETUP = 0, PH_VIS_EVAL, PH_VIS_GATHER, PH_LM, PH_SCHUR, PH_ZERO, PH_IMU_RAW, PH_IMU_WHITEN, PH_IMU_GATHER, PH_PRIOR,
        PH_COST_RED, PH_FIN_SCALE, PH_FIN_CAUCHY, PH_FIN_PASS, PH_CHOL_DIAG, PH_CHOL_TRSM, PH_CHOL_UPD, PH_BACK, PH_LM_BACK,
        PH_DOGLEG, PH_PLUS, PH_NORMS, PH_OTHER, PH_CHAIN_FWD, PH_CHAIN_BWD, PH_CH_A, PH_CH_B, PH_CH_C, PH_CH_D, PH_COUNT = 32 };
@@ -1795,7 +1797,12 @@ __device__ __noinline__ ChainOut chain_forward(TCV_CTX_PARAMS, double mu) {
     Ctx<NT> C = ctx_from_args<NT>(TCV_CTX_FORWARD);
     static_assert(NT >= 256, "chain layout: four wavefronts (column owners on waves 0-1, matrix cores on 0-2, T pipeline on 3)");
     cst_plan &P = *C.P;
-    const int tid = C.tid, lane = tid & 63, wave = tid >> 6, npp = P.npp, ne = P.n_e;
+    const int tid = C.tid, lane = tid & 63, wave = tid >> 6, npp = P.npp;
+#ifdef TCV_ABLATE
+    int ne = P.n_e;
+#else
+    const int ne = P.n_e;
+#endif
     const ChainLds L = chain_lds<NT>(C);
     const int wld = L.wld;
     const ChainSrc G = {C.g_imublk, C.g_hp};
@@ -1805,6 +1812,21 @@ __device__ __noinline__ ChainOut chain_forward(TCV_CTX_PARAMS, double mu) {
     for (int i = tid; i < 2 * CH_W * wld; i += NT) L.wbuf[i] = 0.0;
     if (tid == 0) *C.flag = 0;
     __syncthreads();
+#ifdef TCV_ABLATE
+    if (!ABL(C, AB_CH_HALF)) {      // timing experiment (results are garbage): records 0, 2, 4, ... compacted to the front, the pipelines run over those only
+        const int nh = (ne + 1) / 2;
+        for (int k = 1; k < nh; k++) {
+            int v[(CH_STRIDE + NT - 1) / NT];
+            for (int q = 0, i = tid; i < CH_STRIDE; i += NT, q++) v[q] = L.tab[2 * k * CH_STRIDE + i];
+            __syncthreads();
+            for (int q = 0, i = tid; i < CH_STRIDE; i += NT, q++) L.tab[k * CH_STRIDE + i] = v[q];
+            __syncthreads();
+        }
+        if (tid == 0) (L.tab + (nh - 1) * CH_STRIDE)[CH_NEXT] = 0;
+        __syncthreads();
+        ne = nh;
+    }
+#endif
     // W-wave state: wave w < 2 owns the 16-column tiles w, w + 2, w + 4 of W; per tile the previous W rows (accumulator layout: lane
     // (row0, col) holds rows row0 + 4 i of column 16 J + col) and the prefetched entries of the next B rows
     constexpr int WT = 3;
@@ -1830,7 +1852,11 @@ __device__ __noinline__ ChainOut chain_forward(TCV_CTX_PARAMS, double mu) {
     }
     __syncthreads();
     for (int s = 0; s <= ne; s++) {
+#ifdef TCV_ABLATE
+        if (*C.flag && !ABL_FORCE(C)) { ChainOut bad; bad.q = 0.0; bad.ok = false; return bad; }
+#else
         if (*C.flag) { ChainOut bad; bad.q = 0.0; bad.ok = false; return bad; }      // uniform: read after a barrier, written before it
+#endif
         // ---- T pipeline: one step ahead
         CH_TIC();
         if (wave == 3 && s + 1 < ne && ABL(C, AB_CH_T)) {

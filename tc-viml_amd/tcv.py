@@ -41,6 +41,7 @@ EXPORTS = [
     "tcv_batch_download_priors", "tcv_batch_download_priors_compact",
     "tcv_batch_get_priors_device", "tcv_prior_is_device_resident", "tcv_problem_set_marginalization_prior",
     "tcv_problems_set_marginalization_prior", "tcv_priors_destroy",
+    "tcv_preintegrate_device", "tcv_preint_sum_dt", "tcv_preint_export", "tcv_preint_destroy", "tcv_problem_add_imu_factor_device",
 ]
 
 
@@ -78,7 +79,8 @@ class WindowDesc(C.Structure):
                 ("line_loss_a", C.c_double), ("gravity", C.c_double * 3),
                 ("prior", C.c_void_p), ("prior_block_kind", _ip), ("prior_block_index", _ip),
                 ("para_td", _dp), ("proj_td_aux", _dp), ("td_TR", C.c_double), ("td_ROW", C.c_double),
-                ("line_exact_jacobian", C.c_int), ("pad_", C.c_int)]
+                ("line_exact_jacobian", C.c_int), ("pad_", C.c_int),
+                ("imu_device", C.POINTER(C.c_void_p))]
 
 
 _lib = None
@@ -155,6 +157,13 @@ def lib():
         L.tcv_eval_line_factors.argtypes = [C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
         L.tcv_pose_plus.argtypes = [C.c_int, _dp, _dp, _dp]
         L.tcv_preintegrate.argtypes = [C.c_int, _ip, _ip, _dp, C.c_int, _dp, _dp, C.POINTER(ImuPreintegration)]
+        L.tcv_preintegrate_device.argtypes = [C.c_int, _ip, _ip, _dp, C.c_int, _dp, _dp, C.POINTER(vp)]
+        L.tcv_preint_sum_dt.argtypes = [vp]
+        L.tcv_preint_sum_dt.restype = C.c_double
+        L.tcv_preint_export.argtypes = [vp, C.POINTER(ImuPreintegration)]
+        L.tcv_preint_destroy.argtypes = [vp]
+        L.tcv_preint_destroy.restype = None
+        L.tcv_problem_add_imu_factor_device.argtypes = [vp, vp, _dp, _dp, _dp, _dp]
         L.tcv_problem_set_frames.argtypes = [vp, C.c_int, C.POINTER(_dp), C.POINTER(_dp)]
         L.tcv_gauge_fix.argtypes = [C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
         L.tcv_batch_gauge_fix.argtypes = [vp, vp]
@@ -268,8 +277,11 @@ class Window:
     """Caller-side state arrays of one sliding window (what Estimator owns, estimator.h:166-172)
     plus the problem handle built from them with tcv_problem_from_window."""
 
-    def __init__(self, win: dict, estimate_extrinsic=True, prior: Prior | None = None, share: "Window | None" = None):
+    def __init__(self, win: dict, estimate_extrinsic=True, prior: Prior | None = None, share: "Window | None" = None, imu_device=None):
+        """imu_device: optional list of `Preint` handles (device-resident pre-integrations, `preintegrate_device`), one per IMU factor of the
+        window (entries may be None): they replace the host constants of win["imu"]"""
         self.win = win
+        self.imu_device = imu_device
         if share is not None:      # same caller-owned state arrays (parameter blocks are identified by address)
             self.pose, self.sb, self.ex, self.lam, self.td = share.pose, share.sb, share.ex, share.lam, share.td
         else:
@@ -301,6 +313,9 @@ class Window:
             self._aux = f64(np.concatenate([np.asarray(pr["vel_i"], dtype=float).reshape(n, 2), np.asarray(pr["vel_j"], dtype=float).reshape(n, 2),
                                             np.stack([np.asarray(pr[k], dtype=float).reshape(n) for k in ("td_i", "td_j", "row_i", "row_j")], -1)], -1)) if n else np.zeros((0, 8))
             d.para_td = dptr(self.td); d.proj_td_aux = dptr(self._aux); d.td_TR = float(pr["TR"]); d.td_ROW = float(pr["ROW"])
+        if imu_device is not None:
+            self._imu_dev = (C.c_void_p * len(self._imu_i))(*[(h.h if h is not None else None) for h in imu_device])
+            d.imu_device = C.cast(self._imu_dev, C.POINTER(C.c_void_p))
         self.prior = prior
         if prior is None and win.get("prior") is not None:
             self.prior = Prior.from_dict(win["prior"])
@@ -601,6 +616,40 @@ def preintegrate(acc, gyr, dt, lin_ba, lin_bg, noise):
                 lin_bg=np.array([list(o.linearized_bg) for o in out]), sum_dt=np.array([o.sum_dt for o in out]),
                 jacobian=np.array([list(o.jacobian) for o in out]).reshape(n, 15, 15),
                 covariance=np.array([list(o.covariance) for o in out]).reshape(n, 15, 15))
+
+
+class Preint:
+    """Owns a tcv_preint handle: an IntegrationBase whose numbers stay on the device."""
+
+    def __init__(self, h):
+        self.h = h
+
+    def sum_dt(self):
+        return float(lib().tcv_preint_sum_dt(self.h))
+
+    def export(self):
+        o = ImuPreintegration()
+        check(lib().tcv_preint_export(self.h, C.byref(o)))
+        return dict(delta_p=np.array(o.delta_p), delta_q=np.array(o.delta_q), delta_v=np.array(o.delta_v), lin_ba=np.array(o.linearized_ba),
+                    lin_bg=np.array(o.linearized_bg), sum_dt=float(o.sum_dt), jacobian=np.array(o.jacobian).reshape(15, 15), covariance=np.array(o.covariance).reshape(15, 15))
+
+    def __del__(self):
+        if self.h is not None and _lib is not None:
+            _lib.tcv_preint_destroy(self.h)
+            self.h = None
+
+
+def preintegrate_device(acc, gyr, dt, lin_ba, lin_bg, noise):
+    """`preintegrate` with the results left on the device: a list of `Preint` handles"""
+    acc = f64(acc); gyr = f64(gyr)
+    n, S = acc.shape[0], acc.shape[1] - 1
+    samples = np.concatenate([np.full((n, S, 1), float(dt)), acc[:, 1:], gyr[:, 1:]], -1).reshape(n * S, 7).copy()
+    first = i32(np.arange(n) * S); count = i32(np.full(n, S))
+    init = f64(np.concatenate([acc[:, 0], gyr[:, 0], f64(lin_ba).reshape(n, 3), f64(lin_bg).reshape(n, 3)], -1))
+    nz = f64(noise)
+    out = (C.c_void_p * n)()
+    check(lib().tcv_preintegrate_device(n, iptr(first), iptr(count), dptr(samples), n * S, dptr(init), dptr(nz), out))
+    return [Preint(C.c_void_p(h)) for h in out]
 
 
 def gauge_fix(R0, P0, pose, sb):

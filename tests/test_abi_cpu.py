@@ -333,3 +333,33 @@ def test_prior_create_rejects_malformed_layouts(tcv):
 def test_solver_options_document_the_iteration_limit():
     hdr = open(os.path.join(ROOT, "include", "tcv.h")).read()
     assert "may exceed TCV_MAX_TRACE" in hdr and "workgroups_per_window" in hdr and "reserved, ignored" not in hdr
+
+
+def test_no_static_lds_in_the_two_per_cu_kernels(tcv, tmp_path):
+    """The chain-layout solve kernel and `marg_kernel<256>` run TWO workgroups per CU on exactly half a CU's LDS each (80 KiB, dynamic): a
+    single static LDS variable -- e.g. the one `__syncthreads_or` brings for its work-group reduction -- makes it one workgroup per CU
+    (round 4 measured that: marginalisation 0.85 -> 1.40 ms per 1024 windows).  The code objects' metadata must say
+    `.group_segment_fixed_size: 0` for every kernel of those translation units."""
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    objdir = os.path.join(ROOT, "tc-viml_amd", "build", "libtcv_hip")
+    seen = {}
+    for obj in ("tcv_marg.hip.o", "tcv_solve_chain.o", "tcv_solve_chain_td.o"):
+        path = os.path.join(objdir, obj)
+        if not os.path.exists(path):
+            pytest.skip("object files of the build are not there (library built elsewhere)")
+        fat = os.path.join(tmp_path, obj + ".fat"); co = os.path.join(tmp_path, obj + ".co")
+        subprocess.check_call([os.path.join(llvm, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, path])
+        subprocess.check_call([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + fat, "--output=" + co])
+        notes = subprocess.check_output([os.path.join(llvm, "llvm-readelf"), "--notes", co]).decode()
+        lds = None
+        for line in notes.splitlines():
+            line = line.strip()
+            if line.startswith(".group_segment_fixed_size:"):
+                lds = int(line.split(":")[1])
+            elif line.startswith(".name:") and lds is not None:
+                seen[line.split(":", 1)[1].strip()] = lds
+                lds = None
+    big = {k: v for k, v in seen.items() if "marg_kernel" in k or "solve_kernel" in k}
+    assert len(big) >= 3, seen
+    assert all(v == 0 for v in big.values()), big

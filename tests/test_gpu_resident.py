@@ -134,14 +134,83 @@ def test_native_estimator_with_device_resident_priors_matches_the_host_round_tri
     the same trajectories bit for bit, both marginalisation modes, association in the loop"""
     streams = [replay.simulate_stream(44, 30, max_features=30, associate=True),
                replay.simulate_stream_euroc("V2_02_medium", 30, start_s=1.0, max_features=40, max_lines=5, associate=True)]
-    dev = replay.run_many_native(streams, num_iterations=8)
-    os.environ["TCV_EST_HOST_PRIORS"] = "1"
+    os.environ["TCV_EST_DEVICE_STATE"] = "1"      # (a handful of estimators per call takes the host round trip by default, tcv_estimator.cpp)
     try:
+        dev = replay.run_many_native(streams, num_iterations=8)
+        os.environ["TCV_EST_HOST_PRIORS"] = "1"
         host = replay.run_many_native(streams, num_iterations=8)
     finally:
-        del os.environ["TCV_EST_HOST_PRIORS"]
+        os.environ.pop("TCV_EST_HOST_PRIORS", None); os.environ.pop("TCV_EST_DEVICE_STATE", None)
     for a, c in zip(dev, host):
         assert len(a["t"]) == len(c["t"]) == 30 - replay.WINDOW_SIZE
         assert {l["flag"] for l in a["log"]} == {0, 1}
         assert np.array_equal(a["p"], c["p"]) and np.array_equal(a["q"], c["q"]) and np.array_equal(a["v"], c["v"])
         assert [l["iterations"] for l in a["log"]] == [l["iterations"] for l in c["log"]]
+
+
+def test_device_resident_preintegrations_are_bit_identical_to_the_host_round_trip(gpu):
+    """tcv_preintegrate_device: `pre_integrations[]` stay in HBM (estimator.cpp:200-206 keeps them alive between frames).  A handle exports the
+    bits of tcv_preintegrate; a window whose IMU factors are ALL handles uploads none of their constants (n_imu x 287 doubles spliced
+    device-to-device), its marginalisation problem reads its factor from the solve batch's pool; a window that mixes handles and host
+    constants materialises the handles -- every variant gives the bits of the all-host window, solve and marginalisation."""
+    tcv = gpu
+    B = 4
+    batch = synth.make_windows(9100, B)
+    wins = [synth.window_at(batch, k) for k in range(B)]
+    acc = batch["imu"]["acc"].reshape(-1, synth.IMU_RATE_SUB + 1, 3); gyr = batch["imu"]["gyr"].reshape(-1, synth.IMU_RATE_SUB + 1, 3)
+    n = acc.shape[0]
+    nper = n // B
+    z = np.zeros((n, 3))
+    noise = (synth.ACC_N, synth.GYR_N, synth.ACC_W, synth.GYR_W)
+    host = tcv.preintegrate(acc, gyr, synth.DT_IMU, z, z, noise)
+    hd = tcv.preintegrate_device(acc, gyr, synth.DT_IMU, z, z, noise)
+    for k in range(0, n, 7):
+        e = hd[k].export()
+        assert hd[k].sum_dt() == host["sum_dt"][k] == e["sum_dt"]
+        for key in ("delta_p", "delta_q", "delta_v", "lin_ba", "lin_bg", "jacobian", "covariance"):
+            assert np.array_equal(e[key], host[key][k]), key
+    # the windows with the device-computed pre-integrations as HOST constants (the reference case) ...
+    keys = ("delta_p", "delta_q", "delta_v", "lin_ba", "lin_bg", "sum_dt", "jacobian", "covariance")
+    hw = []
+    for k in range(B):
+        w = dict(wins[k]); im = dict(w["imu"])
+        for key in keys:
+            im[key] = host[key][k * nper:(k + 1) * nper]
+        w["imu"] = im; hw.append(w)
+
+    def run(imu_dev):
+        W = [tcv.Window(hw[k], imu_device=None if imu_dev is None else imu_dev(k)) for k in range(B)]
+        MW = [tcv.margin_old_window(w) for w in hw]
+        M = [tcv.Window(MW[k], share=W[k], imu_device=None if imu_dev is None else [imu_dev(k)[0]]) for k in range(B)]      # MARGIN_OLD: the factor (0, 1)
+        b = tcv.Batch(W, M, [tcv.margin_old_drops(W[k], MW[k]) for k in range(B)])
+        s = _run(b, tcv)
+        b.download_priors(compact=True)
+        return s, [w.states() for w in W], [p.export() for p in b.priors()], b.stats()["input_bytes"]
+
+    s0, x0, p0, bytes0 = run(None)
+    s1, x1, p1, bytes1 = run(lambda k: hd[k * nper:(k + 1) * nper])                                             # all device-resident
+    s2, x2, p2, bytes2 = run(lambda k: [h if i % 2 else None for i, h in enumerate(hd[k * nper:(k + 1) * nper])])  # mixed
+    assert bytes0 - bytes1 == 8.0 * B * nper * 287 and bytes2 == bytes0      # nothing of the factors' constants is uploaded
+    for s, x, p in ((s1, x1, p1), (s2, x2, p2)):
+        for k in range(B):
+            _same_summary(s0[k], s[k])
+            for key in ("pose", "sb", "ex", "lam"):
+                assert np.array_equal(x0[k][key], x[k][key]), (k, key)
+            assert np.array_equal(p0[k]["J0"], p[k]["J0"]) and np.array_equal(p0[k]["r0"], p[k]["r0"])
+
+
+def test_native_estimator_with_device_resident_preintegrations_matches_the_host_round_trip(gpu):
+    """include/tcv_estimator.h keeps pre_integrations[] on the device (default); TCV_EST_HOST_PREINT=1 brings them to the host and uploads
+    them with every window: the same trajectories bit for bit (MARGIN_OLD shifts the handles, MARGIN_SECOND_NEW re-integrates a merged buffer)"""
+    streams = [replay.simulate_stream(45, 30, max_features=30),
+               replay.simulate_stream_euroc("V1_02_medium", 30, start_s=1.0, max_features=40, max_lines=5, associate=True)]
+    os.environ["TCV_EST_DEVICE_STATE"] = "1"
+    try:
+        dev = replay.run_many_native(streams, num_iterations=8)
+        os.environ["TCV_EST_HOST_PREINT"] = "1"
+        host = replay.run_many_native(streams, num_iterations=8)
+    finally:
+        os.environ.pop("TCV_EST_HOST_PREINT", None); os.environ.pop("TCV_EST_DEVICE_STATE", None)
+    for a, c in zip(dev, host):
+        assert len(a["t"]) == len(c["t"]) == 30 - replay.WINDOW_SIZE and {l["flag"] for l in a["log"]} == {0, 1}
+        assert np.array_equal(a["p"], c["p"]) and np.array_equal(a["q"], c["q"]) and np.array_equal(a["v"], c["v"])

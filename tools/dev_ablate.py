@@ -42,6 +42,7 @@ groups = {"visual (eval+gather+lm+schur)": 0b1111, "imu (raw+whiten+gather)": 0b
           # zeroing of the tiles (bit 25) are
           "everything + per-solve J0'J0": (1 << 20) - 1, "everything + gather-program copies": ((1 << 19) - 1) | (1 << 24),
           "everything + tile zeroing": ((1 << 19) - 1) | (1 << 25), "everything + all three": ((1 << 20) - 1) | (1 << 24) | (1 << 25)}
+groups["[experiment] chain over every second step record (6 of 11 steps)"] = 1 << 26
 for nm, m in groups.items():
     t = run(m)
     print("  without %-45s %.3f ms  -> %.3f ms (%4.1f %%)" % (nm, t, base - t, 100 * (base - t) / base), flush=True)
