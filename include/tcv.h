@@ -218,7 +218,10 @@ void tcv_prior_destroy(tcv_prior *pr);
 
 /* ---- throughput mode: many independent windows resident in HBM ------------------------------ */
 /* marg_problems[i] (optional, may be NULL array) shares parameter-block addresses with problems[i]
- * and holds the marginalisation factor set; drop lists as in tcv_marginalize. */
+ * and holds the marginalisation factor set; drop lists as in tcv_marginalize.  Single entries may be NULL too: window i is then only
+ * solved (a MARGIN_SECOND_NEW frame whose prior does not hold para_Pose[WINDOW_SIZE - 1], estimator.cpp:2049-2050) -- the windows of a
+ * lock-step frame form ONE batch whether or not they marginalise; tcv_batch_get_prior fails for such a window, the get_priors calls leave
+ * its entry NULL. */
 int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, tcv_problem *const *marg_problems,
                      double *const *const *marg_drop, const int *marg_num_drop, int n);
 void tcv_batch_destroy(tcv_batch *b);
@@ -316,6 +319,15 @@ int tcv_match_lines(int n_frames, const double *poses, const double *ex_pose, co
                     int width, int height, int window_size, int n_map, const double *lines3d, int n_det, const int *det_frame,
                     const double *det_lines, double angle_th, double overlap_th, int fov_given, unsigned char *in_fov, int *match_index,
                     float *err, double *projected);
+
+/* the same for n independent calls (one per sequence of a lock-step frame: every sequence has its own map, poses and detections) with ONE
+ * upload, ONE download and ONE synchronisation for all of them; call k behaves exactly like tcv_match_lines(args[k]...) */
+typedef struct tcv_match_lines_args {
+    int n_frames; const double *poses, *ex_pose, *Rbw, *Tbw, *K; int width, height, window_size, n_map; const double *lines3d;
+    int n_det; const int *det_frame; const double *det_lines; double angle_th, overlap_th; int fov_given;
+    unsigned char *in_fov; int *match_index; float *err; double *projected;
+} tcv_match_lines_args;
+int tcv_match_lines_batch(int n, const tcv_match_lines_args *args);
 
 /* ---- IMU pre-integration (the producer of the IMU factor's constants) ------- */
 /* Batched `IntegrationBase(acc_0, gyr_0, linearized_ba, linearized_bg)` followed by `push_back(dt, acc, gyr)` for every

@@ -575,7 +575,7 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
                                 double *const *const *marg_drop, const int *marg_num_drop, int n) {
     if (!out || !problems || n <= 0) { set_error("batch_create: bad argument"); return TCV_ERR_INVALID; }
     for (int w = 0; w < n; w++)
-        if (!problems[w] || (marg_problems && (!marg_problems[w] || !marg_drop || !marg_num_drop))) { set_error("batch_create: null problem in the batch"); return TCV_ERR_INVALID; }
+        if (!problems[w] || (marg_problems && (!marg_drop || !marg_num_drop))) { set_error("batch_create: null problem in the batch"); return TCV_ERR_INVALID; }
     if (int rc = device_ready()) return rc;
     const auto t_begin = std::chrono::steady_clock::now();
     tcv::prior_refresh_switch();
@@ -1032,6 +1032,7 @@ extern "C" int tcv_batch_get_priors(tcv_batch *b, tcv_prior **out, int n) {
     auto work = [&](int t) {
         if (nth > 1) (void)hipSetDevice(b->coop_dev);      // a new thread starts on device 0: the batch's buffers live on its own device
         for (int k = t; k < n; k += nth) {
+            if (!tcv_marg_has_problem(b, k)) continue;      // not marginalised: out[k] stays NULL
             const int rc = tcv_marg_get_prior(b, k, &out[k]);
             if (rc != TCV_OK) { rcs[t] = rc; msgs[t] = tcv_last_error(); return; }
         }

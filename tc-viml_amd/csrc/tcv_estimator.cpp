@@ -280,48 +280,60 @@ void poses_of(const tcv_estimator *e, double pose[(W + 1) * 7], double ex[7]) {
 
 // UpdateLinesInFoV / initialLineFoVWindow, updateLinePairInWindow and removeLineOutlier, as processImagewithLine runs them before
 // solveOdometry (estimator.cpp:328-336, :385-497; feature_manager.cpp:494-534)
-int associate_lines(tcv_estimator *e) {
+// The 2D-3D association of one estimator, in two halves around the device call so that the estimators of a lock-step frame share ONE
+// tcv_match_lines_batch (one upload, one download, one wait for all of them instead of a round trip each).
+struct AssocJob {
     double pose[(W + 1) * 7], ex[7];
-    poses_of(e, pose, ex);
-    const int nm = e->n_map;
-    std::vector<int> det_frame;
+    std::vector<int> det_frame, match;
     std::vector<double> det;
     std::vector<LineObs *> where;
+    std::vector<unsigned char> given;
+    std::vector<float> err;
+    bool one_call = false, call = false;
+    tcv_match_lines_args args;
+};
+int assoc_prepare(tcv_estimator *e, AssocJob &J) {
+    poses_of(e, J.pose, J.ex);
+    const int nm = e->n_map;
     for (auto &lf : e->linefeatures)
-        for (size_t k = 0; k < lf.obs.size(); k++) { det_frame.push_back(lf.start + (int)k); det.insert(det.end(), lf.obs[k].vec, lf.obs[k].vec + 4); where.push_back(&lf.obs[k]); }
-    int rc = TCV_OK;
-    const bool one_call = e->fov_ready;      // steady state: UpdateLinesInFoV(frame_count) and the matching in ONE device call
+        for (size_t k = 0; k < lf.obs.size(); k++) { J.det_frame.push_back(lf.start + (int)k); J.det.insert(J.det.end(), lf.obs[k].vec, lf.obs[k].vec + 4); J.where.push_back(&lf.obs[k]); }
+    J.one_call = e->fov_ready;      // steady state: UpdateLinesInFoV(frame_count) and the matching in ONE device call
     if (!e->fov_ready) {
         std::vector<unsigned char> fov_now((size_t)(W + 1) * nm, 0);
-        rc = tcv_match_lines(W + 1, pose, ex, e->Rbw.data(), e->Tbw.data(), e->cfg.K, e->cfg.width, e->cfg.height, W, nm, e->map_lines.data(), 0, nullptr, nullptr,
-                             e->cfg.angle_th, e->cfg.overlap_th, 0, fov_now.data(), nullptr, nullptr, nullptr);
+        const int rc = tcv_match_lines(W + 1, J.pose, J.ex, e->Rbw.data(), e->Tbw.data(), e->cfg.K, e->cfg.width, e->cfg.height, W, nm, e->map_lines.data(), 0, nullptr, nullptr,
+                                       e->cfg.angle_th, e->cfg.overlap_th, 0, fov_now.data(), nullptr, nullptr, nullptr);
         if (rc != TCV_OK) return rc;
         for (int i = 0; i <= W; i++) e->fov[i].assign(fov_now.begin() + (size_t)i * nm, fov_now.begin() + (size_t)(i + 1) * nm);      // initialLineFoVWindow (:483-497)
         e->fov_ready = true;
     }
-    std::vector<unsigned char> given((size_t)(W + 1) * nm, 0);
-    for (int i = 0; i <= W; i++) if (!e->fov[i].empty()) std::copy(e->fov[i].begin(), e->fov[i].end(), given.begin() + (size_t)i * nm);
-    const int nd = (int)where.size();
-    std::vector<int> match(std::max(nd, 1));
-    std::vector<float> err((size_t)std::max(nd, 1) * 3);
-    if (nd > 0 || one_call) {
-        rc = tcv_match_lines(W + 1, pose, ex, e->Rbw.data(), e->Tbw.data(), e->cfg.K, e->cfg.width, e->cfg.height, W, nm, e->map_lines.data(), nd, nd ? det_frame.data() : nullptr,
-                             nd ? det.data() : nullptr, e->cfg.angle_th, e->cfg.overlap_th, one_call ? 2 + W : 1, given.data(), nd ? match.data() : nullptr, nd ? err.data() : nullptr, nullptr);
-        if (rc != TCV_OK) return rc;
-        if (one_call) e->fov[W].assign(given.begin() + (size_t)W * nm, given.begin() + (size_t)(W + 1) * nm);                          // UpdateLinesInFoV(frame_count)
-    }
+    J.given.assign((size_t)(W + 1) * nm, 0);
+    for (int i = 0; i <= W; i++) if (!e->fov[i].empty()) std::copy(e->fov[i].begin(), e->fov[i].end(), J.given.begin() + (size_t)i * nm);
+    const int nd = (int)J.where.size();
+    J.match.assign(std::max(nd, 1), 0);
+    J.err.assign((size_t)std::max(nd, 1) * 3, 0.0f);
+    J.call = nd > 0 || J.one_call;
+    tcv_match_lines_args &a = J.args;
+    a.n_frames = W + 1; a.poses = J.pose; a.ex_pose = J.ex; a.Rbw = e->Rbw.data(); a.Tbw = e->Tbw.data(); a.K = e->cfg.K; a.width = e->cfg.width; a.height = e->cfg.height;
+    a.window_size = W; a.n_map = nm; a.lines3d = e->map_lines.data(); a.n_det = nd; a.det_frame = nd ? J.det_frame.data() : nullptr; a.det_lines = nd ? J.det.data() : nullptr;
+    a.angle_th = e->cfg.angle_th; a.overlap_th = e->cfg.overlap_th; a.fov_given = J.one_call ? 2 + W : 1; a.in_fov = J.given.data();
+    a.match_index = nd ? J.match.data() : nullptr; a.err = nd ? J.err.data() : nullptr; a.projected = nullptr;
+    return TCV_OK;
+}
+void assoc_finish(tcv_estimator *e, AssocJob &J) {
+    const int nm = e->n_map, nd = (int)J.where.size();
+    if (J.call && J.one_call) e->fov[W].assign(J.given.begin() + (size_t)W * nm, J.given.begin() + (size_t)(W + 1) * nm);                          // UpdateLinesInFoV(frame_count)
     if (nd > 0) {
         for (int q = 0; q < nd; q++) {
-            LineObs &ob = *where[q];
-            ob.errA = (double)err[3 * q]; ob.errD = (double)err[3 * q + 1]; ob.overlap = (double)err[3 * q + 2];
-            const unsigned char *g = given.data() + (size_t)det_frame[q] * nm;
+            LineObs &ob = *J.where[q];
+            ob.errA = (double)J.err[3 * q]; ob.errD = (double)J.err[3 * q + 1]; ob.overlap = (double)J.err[3 * q + 2];
+            const unsigned char *g = J.given.data() + (size_t)J.det_frame[q] * nm;
             int first = -1;
             for (int i = 0; i < nm && first < 0; i++) if (g[i]) first = i;
-            if (match[q] >= 0) std::memcpy(ob.world, e->map_lines.data() + 6 * match[q], sizeof ob.world);
+            if (J.match[q] >= 0) std::memcpy(ob.world, e->map_lines.data() + 6 * J.match[q], sizeof ob.world);
             else if (first >= 0) std::memcpy(ob.world, e->map_lines.data() + 6 * first, sizeof ob.world);          // `linesInThisFov[0]` (:871-877)
             else { const double fake[6] = {ob.vec[0], ob.vec[1], 1.0, ob.vec[0], ob.vec[1], 1.0}; std::memcpy(ob.world, fake, sizeof fake); }      // fake_line (:707-709)
             ob.use_flag = true;
-            ob.credible_line = err[3 * q] != -1.0f;
+            ob.credible_line = J.err[3 * q] != -1.0f;
         }
     }
     for (auto &lf : e->linefeatures) {                    // removeLineOutlier
@@ -336,7 +348,6 @@ int associate_lines(tcv_estimator *e) {
         }
         lf.credible_matching = !((count / (int)lf.obs.size()) >= 0.5);
     }
-    return TCV_OK;
 }
 
 // vector2double (estimator.cpp:1492-1535) + the factor lists OptimizationWithLine walks (:1683-1846)
@@ -716,14 +727,28 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
     }
     lap(0);
     // solveOdometry up to the solver call: association, triangulation, vector2double + graph
-    for (int i = 0; i < n; i++) {
-        tcv_estimator *e = es[i];
-        if (e->assoc) { const int rc = associate_lines(e); if (rc != TCV_OK) return rc; }
-        triangulate(e);
-        build_window(e);
+    {
+        std::vector<AssocJob> jobs(n);
+        std::vector<tcv_match_lines_args> calls;
+        for (int i = 0; i < n; i++)
+            if (es[i]->assoc) {
+                const int rc = assoc_prepare(es[i], jobs[i]);
+                if (rc != TCV_OK) return rc;
+                if (jobs[i].call) calls.push_back(jobs[i].args);
+            }
+        if (!calls.empty()) { const int rc = tcv_match_lines_batch((int)calls.size(), calls.data()); if (rc != TCV_OK) return rc; }
+        for (int i = 0; i < n; i++) {
+            tcv_estimator *e = es[i];
+            if (e->assoc) assoc_finish(e, jobs[i]);
+            triangulate(e);
+            build_window(e);
+        }
     }
     lap(1);
-    // windows that marginalise and windows that only solve go to separate batches
+    // One device batch per frame: the windows that marginalise (MARGIN_OLD, or MARGIN_SECOND_NEW with para_Pose[WINDOW_SIZE - 1] in the prior,
+    // estimator.cpp:2049-2050) carry a marginalisation problem, the others a NULL entry (tcv_batch_create).  TCV_EST_TWO_BATCHES=1: round 3's
+    // split into a batch that marginalises and one that only solves (two tcv_batch_create calls, two launches side by side) -- same bits.
+    static const bool two_batches = getenv("TCV_EST_TWO_BATCHES") != nullptr;
     std::vector<char> do_marg(n);
     for (int i = 0; i < n; i++) {
         bool has = false;
@@ -734,6 +759,8 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
     // side by side (a lock-step frame is latency bound: a handful of windows on a handful of CUs), then both are collected.
     struct Group {
         std::vector<int> idx;
+        std::vector<char> dm;             // per window of the group: it marginalises
+        bool any_marg = false;
         std::vector<tcv_problem *> P, M;
         std::vector<double *const *> drops;
         std::vector<int> ndrop;
@@ -758,7 +785,7 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
     int rc_all = TCV_OK;
     for (int group = 1; group >= 0; group--) {
         Group &g = G[group];
-        for (int i = 0; i < n; i++) if ((int)do_marg[i] == group) g.idx.push_back(i);
+        for (int i = 0; i < n; i++) if ((two_batches ? (int)do_marg[i] : 1) == group) { g.idx.push_back(i); g.dm.push_back(do_marg[i]); g.any_marg = g.any_marg || do_marg[i]; }
         if (g.idx.empty()) continue;
         const int nb = (int)g.idx.size();
         g.P.assign(nb, nullptr); g.M.assign(nb, nullptr); g.drops.assign(nb, nullptr); g.ndrop.assign(nb, 0);
@@ -767,7 +794,7 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
             tcv_window_desc d;
             fill_desc(e, d, false, e->marg_flag);
             g.rc = tcv_problem_from_window(&d, &g.P[k]);
-            if (g.rc == TCV_OK && group) {
+            if (g.rc == TCV_OK && g.dm[k]) {
                 build_marg(e, e->marg_flag);
                 fill_desc(e, d, true, e->marg_flag);
                 g.rc = tcv_problem_from_window(&d, &g.M[k]);
@@ -775,7 +802,7 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
             }
         }
         lap(2);
-        if (g.rc == TCV_OK) g.rc = tcv_batch_create(&g.b, g.P.data(), group ? g.M.data() : nullptr, group ? g.drops.data() : nullptr, group ? g.ndrop.data() : nullptr, nb);
+        if (g.rc == TCV_OK) g.rc = tcv_batch_create(&g.b, g.P.data(), g.any_marg ? g.M.data() : nullptr, g.any_marg ? g.drops.data() : nullptr, g.any_marg ? g.ndrop.data() : nullptr, nb);
         lap(3);
     }
     for (int group = 1; group >= 0; group--) {
@@ -787,7 +814,7 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
         void *st = (void *)g_streams[group];
         g.rc = tcv_batch_solve(g.b, &o, st);
         if (g.rc == TCV_OK) g.rc = tcv_batch_gauge_fix(g.b, st);
-        if (g.rc == TCV_OK && group) g.rc = tcv_batch_marginalize(g.b, st);
+        if (g.rc == TCV_OK && g.any_marg) g.rc = tcv_batch_marginalize(g.b, st);
     }
     for (int group = 1; group >= 0; group--) {
         Group &g = G[group];
@@ -816,18 +843,18 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
         // TCV_EST_DEVICE_STATE=1 / TCV_EST_HOST_PRIORS=1 force one or the other.
         const bool host_priors = getenv("TCV_EST_HOST_PRIORS") != nullptr || (n < DEVICE_STATE_MIN_WINDOWS && !getenv("TCV_EST_DEVICE_STATE"));
         bool have_dev = false;
-        if (g.rc == TCV_OK && group && !host_priors) have_dev = tcv_batch_get_priors_device(g.b, g.newp.data(), nb) == TCV_OK;      // (a window that failed: the per-window path below says which)
-        if (g.rc == TCV_OK && group && !have_dev) g.rc = tcv_batch_download_priors_compact(g.b);
+        if (g.rc == TCV_OK && g.any_marg && !host_priors) have_dev = tcv_batch_get_priors_device(g.b, g.newp.data(), nb) == TCV_OK;      // (a window that failed: the per-window path below says which)
+        if (g.rc == TCV_OK && g.any_marg && !have_dev) g.rc = tcv_batch_download_priors_compact(g.b);
         g.est_rc.assign(nb, TCV_OK);
         if (g.rc == TCV_OK)
             for (int k = 0; k < nb; k++)      // ceres::Solve's FAILURE (no valid step / a cooperative group that timed out): the window's states are not applied
                 if (g.sum[k].termination == 5 || !(g.sum[k].final_cost == g.sum[k].final_cost)) { g.est_rc[k] = TCV_ERR_NUMERIC; g.est_msg = "solver failure (no valid step, NaN cost or workgroup time-out)"; }
-        if (g.rc == TCV_OK && group)
+        if (g.rc == TCV_OK && g.any_marg)
             for (int k = 0; k < nb; k++) {
                 // a window whose marginalisation did not converge (TCV_ERR_NUMERIC) fails alone: the other estimators of the lock-step
                 // batch are applied, this one reports the failure from tcv_estimator_finish_frame
                 if (g.est_rc[k] != TCV_OK) { if (g.newp[k]) { tcv_prior_destroy(g.newp[k]); g.newp[k] = nullptr; } continue; }
-                if (have_dev) continue;
+                if (have_dev || !g.dm[k]) continue;
                 g.est_rc[k] = tcv_batch_get_prior(g.b, k, &g.newp[k]);
                 if (g.est_rc[k] != TCV_OK && g.est_rc[k] != TCV_ERR_NUMERIC) { g.rc = g.est_rc[k]; break; }
                 if (g.est_rc[k] != TCV_OK) g.est_msg = tcv_last_error();
@@ -856,7 +883,7 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
             apply_states(e);
             e->stats.marg_flag = e->marg_flag; e->stats.n_landmarks = (int)e->sel.size(); e->stats.n_proj = (int)e->w_pi.size(); e->stats.n_line = (int)e->w_lf.size();
             e->stats.n_line_obs = e->n_line_obs_total; e->stats.iterations = g.sum[k].num_iterations; e->stats.final_cost = g.sum[k].final_cost;
-            if (group) {
+            if (g.dm[k]) {
                 const int rc = take_prior(e, g.newp[k], e->marg_flag);
                 if (rc != TCV_OK) {      // (take_prior keeps the old prior on failure: the new one and the ones not handed over yet are released)
                     for (int k2 = k; k2 < nb; k2++) if (g.newp[k2]) { tcv_prior_destroy(g.newp[k2]); g.newp[k2] = nullptr; }

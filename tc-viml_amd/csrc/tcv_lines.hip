@@ -196,69 +196,100 @@ __global__ void __launch_bounds__(64) lines_match_kernel(LineArgs A) {
 }  // namespace tcv
 using namespace tcv;
 
-extern "C" int tcv_match_lines(int n_frames, const double *poses, const double *ex_pose, const double *Rbw, const double *Tbw, const double *K,
-                               int width, int height, int window_size, int n_map, const double *lines3d, int n_det, const int *det_frame,
-                               const double *det_lines, double angle_th, double overlap_th, int fov_given, unsigned char *in_fov, int *match_index,
-                               float *err, double *projected) {
-    if (n_frames <= 0 || n_map <= 0 || n_det < 0 || !poses || !ex_pose || !Rbw || !Tbw || !K || !lines3d || (n_det > 0 && (!det_frame || !det_lines))) {
-        set_error("match_lines: bad argument"); return TCV_ERR_INVALID;
-    }
-    if (fov_given && !in_fov) { set_error("match_lines: fov_given needs in_fov"); return TCV_ERR_INVALID; }
-    const int fov_frame = fov_given >= 2 ? fov_given - 2 : -1;      // this frame's row is computed here, the others are given
-    if (fov_frame >= n_frames) { set_error("match_lines: fov_given names a frame outside the window"); return TCV_ERR_INVALID; }
-    for (int i = 0; i < n_det; i++) if (det_frame[i] < 0 || det_frame[i] >= n_frames) { set_error("match_lines: frame index out of range"); return TCV_ERR_INVALID; }
-    if (int rc = device_ready()) return rc;
-    // one pinned staging buffer, one device blob, one copy in and one copy out on the calling thread's own stream:
-    //   in : [poses, extrinsic, Rbw, Tbw, K, map, detections (doubles) | frame of every detection (ints) | given FoV rows (bytes)]
-    //   out: [projected segments 4 n_det (doubles) | match index n_det (ints) | errA, errD, overlap 3 n_det (floats) | FoV rows (bytes)]
+// n independent association problems in one device round trip: one pinned staging buffer and one device blob
+//   [inputs of every call: poses, extrinsic, Rbw, Tbw, K, map, detections (doubles) | frame of every detection (ints)]
+//   [FoV rows of every call (bytes): given rows go up, computed rows come back]
+//   [outputs of every call: projected segments 4 n_det (doubles) | match index n_det (ints) | errA, errD, overlap 3 n_det (floats)]
+// one copy in ([inputs | FoV]), the kernels of all calls back to back on the calling thread's own stream, one copy out ([FoV | outputs]), one wait
+extern "C" int tcv_match_lines_batch(int n, const tcv_match_lines_args *args) {
+    if (n < 0 || (n > 0 && !args)) { set_error("match_lines_batch: bad argument"); return TCV_ERR_INVALID; }
+    if (n == 0) return TCV_OK;
     auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
-    const size_t nd_in = (size_t)7 * n_frames + 7 + 9 + 3 + 9 + (size_t)6 * n_map + (size_t)4 * n_det;
-    const size_t tot = (size_t)n_frames * n_map;
-    const size_t o_det = up16(sizeof(double) * nd_in), o_fov = up16(o_det + sizeof(int) * std::max(1, n_det)), in_bytes = up16(o_fov + tot);
-    const size_t o_match = up16(sizeof(double) * 4 * std::max(1, n_det)), o_err = up16(o_match + sizeof(int) * std::max(1, n_det));
-    const size_t out_bytes = up16(o_err + sizeof(float) * 3 * std::max(1, n_det));
-    char *h = (char *)tcv::host_staging_acquire(in_bytes + out_bytes);
+    struct Lay { size_t o_in, o_det, o_fov, o_out, o_match, o_err, tot; };
+    std::vector<Lay> L(n);
+    size_t in_total = 0, fov_total = 0, out_total = 0;
+    for (int c = 0; c < n; c++) {
+        const tcv_match_lines_args &a = args[c];
+        if (a.n_frames <= 0 || a.n_map <= 0 || a.n_det < 0 || !a.poses || !a.ex_pose || !a.Rbw || !a.Tbw || !a.K || !a.lines3d || (a.n_det > 0 && (!a.det_frame || !a.det_lines))) {
+            set_error("match_lines: bad argument"); return TCV_ERR_INVALID;
+        }
+        if (a.fov_given && !a.in_fov) { set_error("match_lines: fov_given needs in_fov"); return TCV_ERR_INVALID; }
+        if (a.fov_given >= 2 && a.fov_given - 2 >= a.n_frames) { set_error("match_lines: fov_given names a frame outside the window"); return TCV_ERR_INVALID; }
+        for (int i = 0; i < a.n_det; i++) if (a.det_frame[i] < 0 || a.det_frame[i] >= a.n_frames) { set_error("match_lines: frame index out of range"); return TCV_ERR_INVALID; }
+        const size_t nd_in = (size_t)7 * a.n_frames + 7 + 9 + 3 + 9 + (size_t)6 * a.n_map + (size_t)4 * a.n_det;
+        L[c].tot = (size_t)a.n_frames * a.n_map;
+        L[c].o_in = in_total; L[c].o_det = in_total + up16(sizeof(double) * nd_in);
+        in_total = up16(L[c].o_det + sizeof(int) * std::max(1, a.n_det));
+        L[c].o_fov = fov_total; fov_total += up16(L[c].tot);
+        L[c].o_out = out_total; L[c].o_match = out_total + up16(sizeof(double) * 4 * std::max(1, a.n_det));
+        L[c].o_err = up16(L[c].o_match + sizeof(int) * std::max(1, a.n_det));
+        out_total = up16(L[c].o_err + sizeof(float) * 3 * std::max(1, a.n_det));
+    }
+    if (int rc = device_ready()) return rc;
+    const size_t total = in_total + fov_total + out_total;
+    char *h = (char *)tcv::host_staging_acquire(total);
     if (!h) { set_error("hipHostMalloc (staging) failed"); return TCV_ERR_HIP; }
     char *dv = nullptr;
-    hipError_t e = tcv::dev_malloc((void **)&dv, in_bytes + out_bytes);
-    double *hd = (double *)h;
-    size_t o = 0;
-    auto put = [&](const double *p, size_t n) { std::memcpy(hd + o, p, sizeof(double) * n); o += n; return o - n; };
-    const size_t o_pose = put(poses, (size_t)7 * n_frames), o_ex = put(ex_pose, 7), o_R = put(Rbw, 9), o_T = put(Tbw, 3), o_K = put(K, 9);
-    const size_t o_map = put(lines3d, (size_t)6 * n_map), o_dl = n_det ? put(det_lines, (size_t)4 * n_det) : o;
-    if (n_det) std::memcpy(h + o_det, det_frame, sizeof(int) * n_det);
-    if (fov_given) std::memcpy(h + o_fov, in_fov, tot);
-    int rc = TCV_OK;
+    hipError_t e = tcv::dev_malloc((void **)&dv, total);
     hipStream_t st = tcv::util_stream();
-    if (e == hipSuccess) e = hipMemcpyAsync(dv, h, fov_given ? in_bytes : o_fov, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) {
+    bool in_flight = false;
+    std::vector<size_t> o_pose(n), o_ex(n), o_R(n), o_T(n), o_K(n), o_map(n), o_dl(n);
+    for (int c = 0; c < n && e == hipSuccess; c++) {
+        const tcv_match_lines_args &a = args[c];
+        double *hd = (double *)(h + L[c].o_in);
+        size_t o = 0;
+        auto put = [&](const double *p, size_t k) { std::memcpy(hd + o, p, sizeof(double) * k); o += k; return L[c].o_in / sizeof(double) + o - k; };
+        o_pose[c] = put(a.poses, (size_t)7 * a.n_frames); o_ex[c] = put(a.ex_pose, 7); o_R[c] = put(a.Rbw, 9); o_T[c] = put(a.Tbw, 3); o_K[c] = put(a.K, 9);
+        o_map[c] = put(a.lines3d, (size_t)6 * a.n_map); o_dl[c] = a.n_det ? put(a.det_lines, (size_t)4 * a.n_det) : L[c].o_in / sizeof(double) + o;
+        if (a.n_det) std::memcpy(h + L[c].o_det, a.det_frame, sizeof(int) * a.n_det);
+        if (a.fov_given) std::memcpy(h + in_total + L[c].o_fov, a.in_fov, L[c].tot);
+        else std::memset(h + in_total + L[c].o_fov, 0, L[c].tot);
+    }
+    int rc = TCV_OK;
+    if (e == hipSuccess) { in_flight = true; e = hipMemcpyAsync(dv, h, in_total + fov_total, hipMemcpyHostToDevice, st); }
+    for (int c = 0; c < n && e == hipSuccess; c++) {
+        const tcv_match_lines_args &a = args[c];
         double *dd = (double *)dv;
-        char *dout = dv + in_bytes;
+        char *dout = dv + in_total + fov_total + L[c].o_out;
+        const int fov_frame = a.fov_given >= 2 ? a.fov_given - 2 : -1;      // this frame's row is computed here, the others are given
         LineArgs A;
-        A.poses = dd + o_pose; A.ex = dd + o_ex; A.Rbw = dd + o_R; A.Tbw = dd + o_T; A.K = dd + o_K; A.map = dd + o_map; A.det = dd + o_dl;
-        A.det_frame = (int *)(dv + o_det); A.n_frames = n_frames; A.n_map = n_map; A.n_det = n_det; A.width = width; A.height = height; A.window_size = window_size;
-        A.angle_th = angle_th; A.overlap_th = overlap_th; A.in_fov = (unsigned char *)(dv + o_fov); A.match = (int *)(dout + o_match); A.err = (float *)(dout + o_err);
+        A.poses = dd + o_pose[c]; A.ex = dd + o_ex[c]; A.Rbw = dd + o_R[c]; A.Tbw = dd + o_T[c]; A.K = dd + o_K[c]; A.map = dd + o_map[c]; A.det = dd + o_dl[c];
+        A.det_frame = (int *)(dv + L[c].o_det); A.n_frames = a.n_frames; A.n_map = a.n_map; A.n_det = a.n_det; A.width = a.width; A.height = a.height; A.window_size = a.window_size;
+        A.angle_th = a.angle_th; A.overlap_th = a.overlap_th; A.in_fov = (unsigned char *)(dv + in_total + L[c].o_fov);
+        A.match = (int *)(dv + in_total + fov_total + L[c].o_match); A.err = (float *)(dv + in_total + fov_total + L[c].o_err);
         A.proj = (double *)dout;
         A.only_frame = fov_frame;
-        if (!fov_given) hipLaunchKernelGGL(lines_fov_kernel, dim3(((int)tot + 255) / 256), dim3(256), 0, st, A);
-        else if (fov_frame >= 0) hipLaunchKernelGGL(lines_fov_kernel, dim3((n_map + 255) / 256), dim3(256), 0, st, A);
-        if (n_det) hipLaunchKernelGGL(lines_match_kernel, dim3(n_det), dim3(64), 0, st, A);
+        if (!a.fov_given) hipLaunchKernelGGL(lines_fov_kernel, dim3(((int)L[c].tot + 255) / 256), dim3(256), 0, st, A);
+        else if (fov_frame >= 0) hipLaunchKernelGGL(lines_fov_kernel, dim3((a.n_map + 255) / 256), dim3(256), 0, st, A);
+        if (a.n_det) hipLaunchKernelGGL(lines_match_kernel, dim3(a.n_det), dim3(64), 0, st, A);
         e = hipGetLastError();
-        char *ho = h + in_bytes;
-        if (e == hipSuccess && n_det) e = hipMemcpyAsync(ho, dout, out_bytes, hipMemcpyDeviceToHost, st);
-        const bool want_fov = in_fov && (!fov_given || fov_frame >= 0);
-        if (e == hipSuccess && want_fov) e = hipMemcpyAsync(h + o_fov, dv + o_fov, tot, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = st ? hipStreamSynchronize(st) : hipDeviceSynchronize();
-        if (e == hipSuccess) {
-            if (in_fov && !fov_given) std::memcpy(in_fov, h + o_fov, tot);
-            else if (fov_frame >= 0) std::memcpy(in_fov + (size_t)fov_frame * n_map, h + o_fov + (size_t)fov_frame * n_map, (size_t)n_map);
-            if (n_det && match_index) std::memcpy(match_index, ho + o_match, sizeof(int) * n_det);
-            if (n_det && err) std::memcpy(err, ho + o_err, sizeof(float) * 3 * n_det);
-            if (n_det && projected) std::memcpy(projected, ho, sizeof(double) * 4 * n_det);
-        }
     }
+    if (e == hipSuccess) e = hipMemcpyAsync(h + in_total, dv + in_total, fov_total + out_total, hipMemcpyDeviceToHost, st);
+    if (in_flight) { const hipError_t es = st ? hipStreamSynchronize(st) : hipDeviceSynchronize(); if (e == hipSuccess) e = es; }
+    if (e == hipSuccess)
+        for (int c = 0; c < n; c++) {
+            const tcv_match_lines_args &a = args[c];
+            const int fov_frame = a.fov_given >= 2 ? a.fov_given - 2 : -1;
+            const char *hf = h + in_total + L[c].o_fov, *ho = h + in_total + fov_total;
+            if (a.in_fov && !a.fov_given) std::memcpy(a.in_fov, hf, L[c].tot);
+            else if (fov_frame >= 0) std::memcpy(a.in_fov + (size_t)fov_frame * a.n_map, hf + (size_t)fov_frame * a.n_map, (size_t)a.n_map);
+            if (a.n_det && a.match_index) std::memcpy(a.match_index, ho + L[c].o_match, sizeof(int) * a.n_det);
+            if (a.n_det && a.err) std::memcpy(a.err, ho + L[c].o_err, sizeof(float) * 3 * a.n_det);
+            if (a.n_det && a.projected) std::memcpy(a.projected, ho + L[c].o_out, sizeof(double) * 4 * a.n_det);
+        }
     if (e != hipSuccess) rc = hip_fail(e, "match_lines");
     tcv::host_staging_release(h);
     tcv::dev_free(dv);
     return rc;
+}
+
+extern "C" int tcv_match_lines(int n_frames, const double *poses, const double *ex_pose, const double *Rbw, const double *Tbw, const double *K,
+                               int width, int height, int window_size, int n_map, const double *lines3d, int n_det, const int *det_frame,
+                               const double *det_lines, double angle_th, double overlap_th, int fov_given, unsigned char *in_fov, int *match_index,
+                               float *err, double *projected) {
+    tcv_match_lines_args a;
+    a.n_frames = n_frames; a.poses = poses; a.ex_pose = ex_pose; a.Rbw = Rbw; a.Tbw = Tbw; a.K = K; a.width = width; a.height = height; a.window_size = window_size;
+    a.n_map = n_map; a.lines3d = lines3d; a.n_det = n_det; a.det_frame = det_frame; a.det_lines = det_lines; a.angle_th = angle_th; a.overlap_th = overlap_th;
+    a.fov_given = fov_given; a.in_fov = in_fov; a.match_index = match_index; a.err = err; a.projected = projected;
+    return tcv_match_lines_batch(1, &a);
 }

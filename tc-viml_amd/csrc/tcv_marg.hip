@@ -1012,6 +1012,10 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((disable_tail_calls)) _
         cst_i *ip = (cst_i *)Aarg.ipool + H.ibase;
         cst_d *dp = (cst_d *)Aarg.dpool + H.dbase;
         const int pos = H.pos, m = H.m, n = H.n;
+        if (H.nblk == 0) {      // a window of the batch that is not marginalised (tcv_batch_create: marg_problems[w] == NULL): nothing to do
+            if (tid == 0) { ((gbl_i *)Aarg.out_status)[win] = 0; ((gbl_i *)Aarg.out_status)[Aarg.nwin + win] = 0; }
+            continue;
+        }
         const int npk = pos * (pos + 1) / 2;
         // LDS carve (marg_lds_doubles() on the host is the same sum).  P: the prior's J0 while J0'J0 is formed, then the packed lower
         // triangle of A, then A' and finally its eigenvectors V2.  R2: the factor staging records, then Amm + V, then the reflectors of
@@ -1045,6 +1049,7 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((disable_tail_calls)) _
         }
         for (int i = tid; i < pos; i += MARG_NT) { bv[i] = 0.0; cvec[i] = 0.0; }
         if (tid < 8) lmacc[tid] = 0.0;
+        if (tid == 0) rot[156] = 0.0;      // "the result holds a NaN" (set by the output phase, read behind the window's last barrier)
         cst_d *misc = dp + H.d_misc;
         const double G3[3] = {misc[0], misc[1], misc[2]};
         __syncthreads();
@@ -1674,44 +1679,31 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((disable_tail_calls)) _
             double rb = 0;
             for (int j = 0; j < n; j++) {
                 const double v = V2[j * ldn + tid];
-                const double o = ss * v;
-                out[MARG_OUT_J0 + rank + n * j] = o;
-#ifndef TCV_MARG_NO_K0
-                if (!(o == o)) bad = true;
-#endif
+                out[MARG_OUT_J0 + rank + n * j] = ss * v;
                 rb += v * bv[j];
             }
             out[MARG_OUT_R0 + rank] = si * rb;
-#ifndef TCV_MARG_NO_K0
+            // (a NaN or Inf anywhere in the eigenvector reaches rb -- NaN * 0 is NaN -- and from there si * rb, thresholded row or not)
             if (!(si * rb == si * rb) || !(l == l)) bad = true;
-#endif
         }
         // what a device-resident consumer of this prior needs on the host (tcv_batch_get_priors_device): the number of leading rows of
         // J0 | r0 that are exact zeros -- the thresholded eigenvalues rank first and their rows are 0 * v --, capped like
         // tcv_packed.h prior_zero_rows() (one row is kept); -1: the result holds a NaN
-#ifndef TCV_MARG_NO_K0
-        {
-            // (NOT __syncthreads_or: its work-group reduction brings a static LDS variable of its own, and 80 KiB + 4 bytes per workgroup is
-            // one workgroup per CU instead of two -- 0.85 -> 1.40 ms per 1024 windows, measured)
-            lds_i *badf = cnt;      // (the Jacobi sweeps' counter: free here)
-            if (tid == 0) *badf = 0;
-            __syncthreads();
-            if (bad) *badf = 1;
-            __syncthreads();
-            const int any_bad = *badf;
-            if (tid == 0) {
-                int k0 = 0;
-                for (int j = 0; j < n; j++) k0 += (lam[j] > 1e-8) ? 0 : 1;
-                if (k0 >= n) k0 = n > 0 ? n - 1 : 0;
-                ((gbl_i *)Aarg.out_status)[Aarg.nwin + win] = any_bad ? -1 : k0;
-            }
-        }
-#endif
+        // (the flag is a spare LDS double zeroed at the start of the window and read behind the window's last barrier: no barrier of its own,
+        // and NOT __syncthreads_or, whose work-group reduction brings a static LDS variable -- 80 KiB + 4 bytes per workgroup is one
+        // workgroup per CU instead of two: 0.85 -> 1.40 ms per 1024 windows, measured)
+        if (bad) rot[156] = 1.0;
         for (int i = tid; i < H.nx; i += MARG_NT) out[MARG_OUT_X + i] = x[i];
         MARG_MARK(8);
         if (tid == 0) ((gbl_i *)Aarg.out_status)[win] = (sweeps1 >= 24 || sweeps2 == 124) ? 1 : (sweeps2 >= 100 ? 2 : 0);   // 1: a Jacobi sweep hit its cap, 2: A' went through the Jacobi safety net
         if (tid == 0) { out[MARG_OUT_X + MARG_MAX_X] = sweeps1; out[MARG_OUT_X + MARG_MAX_X + 1] = sweeps2; }
         __syncthreads();
+        if (tid == 0) {
+            int k0 = 0;
+            for (int j = 0; j < n; j++) k0 += (lam[j] > 1e-8) ? 0 : 1;
+            if (k0 >= n) k0 = n > 0 ? n - 1 : 0;
+            ((gbl_i *)Aarg.out_status)[Aarg.nwin + win] = (rot[156] != 0.0) ? -1 : k0;
+        }
     }
 }
 
@@ -2067,7 +2059,7 @@ int tcv_marg_attach(tcv_batch *b, tcv_problem *const *marg_problems, double *con
     std::vector<MargHdr> hdrs(b->n);
     size_t lds = 0;
     for (int w = 0; w < b->n; w++)
-        if (!marg_problems[w] || !marg_drop || !marg_drop[w]) { set_error("marginalisation problem / drop list missing"); return TCV_ERR_INVALID; }
+        if (marg_problems[w] && (!marg_drop || !marg_drop[w])) { set_error("marginalisation problem without a drop list"); return TCV_ERR_INVALID; }
     // the windows are packed by host threads, each into its own int / double pools (contiguous window ranges); the pools are then laid end
     // to end in pinned upload buffers and the headers' pool offsets shifted accordingly
     const int nth = tcv::host_threads(std::max(1, std::min(b->n / 8, 16)));      // (inside tcv_batch_create's HostOp)
@@ -2079,6 +2071,13 @@ int tcv_marg_attach(tcv_batch *b, tcv_problem *const *marg_problems, double *con
     auto work = [&](int t) {
         const auto r = range(t);
         for (int w = r.first; w < r.second; w++) {
+            if (!marg_problems[w]) {      // this window is not marginalised: an empty header (nblk = 0), which the kernel skips
+                MargHdr &H = s->win[w].hdr;
+                std::memset(&H, 0, sizeof H);
+                H.ibase = (long long)It[t].size(); H.dbase = (long long)Dt[t].size();
+                H.sqrt_src = -1; H.prior_abs = -1; H.imu_abs = -1; H.cb_off = -1; H.td_blk = -1; H.solve_window = w;
+                continue;
+            }
             const int rc = pack_marg(*marg_problems[w], marg_drop[w], marg_num_drop[w], b->problems[w], &b->packed[w], s->win[w], It[t], Dt[t]);
             if (rc != TCV_OK) { rcs[t] = rc; msgs[t] = tcv_last_error(); return; }
             s->win[w].hdr.solve_window = w;
@@ -2093,6 +2092,7 @@ int tcv_marg_attach(tcv_batch *b, tcv_problem *const *marg_problems, double *con
         for (int w = r.first; w < r.second; w++) {
             s->win[w].hdr.ibase += (long long)ib[t]; s->win[w].hdr.dbase += (long long)db[t];
             hdrs[w] = s->win[w].hdr;
+            if (hdrs[w].nblk == 0) continue;
             const int ne_ = hdrs[w].n + (hdrs[w].n & 1), r1_ = std::max(hdrs[w].pos * (hdrs[w].pos + 1) / 2, ne_ * (ne_ + 1));
             const int cb_r2 = (hdrs[w].cb_off >= 0 && hdrs[w].cb_off >= ((r1_ + 1) & ~1)) ? MARG_CB_LM * hdrs[w].cb_stride + 2 * MARG_CB_LM : 0;
             const size_t need = marg_lds_doubles(hdrs[w].pos, hdrs[w].m, hdrs[w].n, hdrs[w].nx, cb_r2) * 8;
@@ -2177,6 +2177,10 @@ int tcv_marg_run(tcv_batch *b, void *stream) {
     return TCV_OK;
 }
 
+bool tcv_marg_has_problem(const tcv_batch *b, int window) {
+    const MargState *s = (const MargState *)b->marg;
+    return s && window >= 0 && window < b->n && s->win[window].hdr.nblk != 0;
+}
 int tcv_marg_sqrt_source(const tcv_batch *b, int window) {
     const MargState *s = (const MargState *)b->marg;
     return (s && window >= 0 && window < b->n) ? s->win[window].hdr.sqrt_src : -1;
@@ -2224,6 +2228,7 @@ int tcv_marg_get_prior(tcv_batch *b, int window, tcv_prior **out) {
     MargState *s = (MargState *)b->marg;
     if (!s || !s->ran || window < 0 || window >= b->n) { set_error("no marginalisation result for this window"); return TCV_ERR_INVALID; }
     const MargWindow &mw = s->win[window];
+    if (mw.hdr.nblk == 0) { set_error("this window of the batch has no marginalisation problem"); return TCV_ERR_INVALID; }
     const int n = mw.hdr.n, m = mw.hdr.m;      // m: dropped dims that went through the eigen step (all of them unless block mode)
     std::vector<double> o(MARG_OUT_STRIDE);
     int status = -1;
@@ -2294,6 +2299,7 @@ int tcv_marg_get_priors_device(tcv_batch *b, tcv_prior **out, int n) {
     int rc = TCV_OK;
     for (int w = 0; w < n && rc == TCV_OK; w++) {
         const MargWindow &mw = s->win[w];
+        if (mw.hdr.nblk == 0) continue;      // not marginalised: out[w] stays NULL
         const int status = st[w], k0 = st[n + w];
         if (status < 0) { set_error("marginalisation kernel did not complete for this window"); rc = TCV_ERR_NUMERIC; break; }
         if (status == 1) { set_error("marginalisation: eigen-decomposition did not converge (sweep cap)"); rc = TCV_ERR_NUMERIC; break; }

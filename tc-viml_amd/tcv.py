@@ -41,7 +41,7 @@ EXPORTS = [
     "tcv_batch_download_priors", "tcv_batch_download_priors_compact",
     "tcv_batch_get_priors_device", "tcv_prior_is_device_resident", "tcv_problem_set_marginalization_prior",
     "tcv_problems_set_marginalization_prior", "tcv_priors_destroy",
-    "tcv_preintegrate_device", "tcv_preint_sum_dt", "tcv_preint_export", "tcv_preint_destroy", "tcv_problem_add_imu_factor_device",
+    "tcv_match_lines_batch", "tcv_preintegrate_device", "tcv_preint_sum_dt", "tcv_preint_export", "tcv_preint_destroy", "tcv_problem_add_imu_factor_device",
 ]
 
 
@@ -437,12 +437,13 @@ class BatchSpec:
         self.marg_windows, self.marr, self.dd, self.nd = None, None, None, None
         if marg_windows is not None:
             self.marg_windows = list(marg_windows)
-            self.marr = (C.c_void_p * n)(*[w.h for w in self.marg_windows])
+            self.marr = (C.c_void_p * n)(*[(w.h if w is not None else None) for w in self.marg_windows])      # None: that window is only solved
             self._drop_arrays = []
             self.dd = (C.POINTER(_dp) * n)()
             self.nd = (C.c_int * n)()
             for k, drops in enumerate(marg_drops):
-                a = (_dp * len(drops))(*drops)
+                drops = drops or []
+                a = (_dp * max(1, len(drops)))(*drops)
                 self._drop_arrays.append(a)
                 self.dd[k] = C.cast(a, C.POINTER(_dp))
                 self.nd[k] = len(drops)
@@ -467,7 +468,7 @@ class Batch:
         n = len(self.windows)
         out = (C.c_void_p * n)()
         check(lib().tcv_batch_get_priors(self.h, out, n))
-        return [Prior(C.c_void_p(h)) for h in out]
+        return [Prior(C.c_void_p(h)) if h else None for h in out]
 
     def priors_device_raw(self):
         """tcv_batch_get_priors_device as a C array of handles (owned by the caller: tcv_priors_destroy) -- for loops that hand the priors
@@ -483,7 +484,7 @@ class Batch:
         n = len(self.windows)
         out = (C.c_void_p * n)()
         check(lib().tcv_batch_get_priors_device(self.h, out, n))
-        return [Prior(C.c_void_p(h)) for h in out]
+        return [Prior(C.c_void_p(h)) if h else None for h in out]
 
     def solve(self, opts, stream=None):
         check(lib().tcv_batch_solve(self.h, C.byref(opts), stream))
@@ -616,6 +617,41 @@ def preintegrate(acc, gyr, dt, lin_ba, lin_bg, noise):
                 lin_bg=np.array([list(o.linearized_bg) for o in out]), sum_dt=np.array([o.sum_dt for o in out]),
                 jacobian=np.array([list(o.jacobian) for o in out]).reshape(n, 15, 15),
                 covariance=np.array([list(o.covariance) for o in out]).reshape(n, 15, 15))
+
+
+class MatchLinesArgs(C.Structure):
+    _fields_ = [("n_frames", C.c_int), ("poses", _dp), ("ex_pose", _dp), ("Rbw", _dp), ("Tbw", _dp), ("K", _dp), ("width", C.c_int), ("height", C.c_int),
+                ("window_size", C.c_int), ("n_map", C.c_int), ("lines3d", _dp), ("n_det", C.c_int), ("det_frame", _ip), ("det_lines", _dp),
+                ("angle_th", C.c_double), ("overlap_th", C.c_double), ("fov_given", C.c_int), ("in_fov", C.POINTER(C.c_ubyte)),
+                ("match_index", _ip), ("err", C.POINTER(C.c_float)), ("projected", _dp)]
+
+
+def match_lines_batch(calls):
+    """tcv_match_lines_batch: `calls` = list of dicts with the keyword arguments of `match_lines`; ONE device round trip for all of them.
+    Returns a list of (in_fov, match_index, err, projected) tuples."""
+    n = len(calls)
+    arr = (MatchLinesArgs * n)()
+    keep, outs = [], []
+    for k, c in enumerate(calls):
+        poses = f64(c["poses"]).reshape(-1, 7); lines3d = f64(c["lines3d"]).reshape(-1, 6)
+        det_frame = i32(c["det_frame"]); det_lines = f64(c["det_lines"]).reshape(-1, 4)
+        nf, nm, nd = poses.shape[0], lines3d.shape[0], det_lines.shape[0]
+        in_fov, fov_frame = c.get("in_fov"), c.get("fov_frame")
+        fov = np.zeros((nf, nm), np.uint8) if in_fov is None else np.ascontiguousarray(np.asarray(in_fov).reshape(nf, nm), dtype=np.uint8)
+        match = np.zeros(max(nd, 1), np.int32); err = np.zeros((max(nd, 1), 3), np.float32); proj = np.zeros((max(nd, 1), 4))
+        ex = f64(c["ex_pose"]); R = f64(c["Rbw"]).reshape(9); T = f64(c["Tbw"]); Kf = f64(c["K"]).reshape(9)
+        a = arr[k]
+        a.n_frames = nf; a.poses = dptr(poses); a.ex_pose = dptr(ex); a.Rbw = dptr(R); a.Tbw = dptr(T); a.K = dptr(Kf)
+        a.width = int(c["width"]); a.height = int(c["height"]); a.window_size = int(c["window_size"]); a.n_map = nm; a.lines3d = dptr(lines3d)
+        a.n_det = nd; a.det_frame = iptr(det_frame) if nd else None; a.det_lines = dptr(det_lines) if nd else None
+        a.angle_th = float(c["angle_th"]); a.overlap_th = float(c["overlap_th"])
+        a.fov_given = (2 + int(fov_frame)) if (in_fov is not None and fov_frame is not None) else int(in_fov is not None)
+        a.in_fov = fov.ctypes.data_as(C.POINTER(C.c_ubyte)); a.match_index = iptr(match); a.err = err.ctypes.data_as(C.POINTER(C.c_float)); a.projected = dptr(proj)
+        keep.append((poses, lines3d, det_frame, det_lines, ex, R, T, Kf))
+        outs.append((fov, match, err, proj, nd))
+    lib().tcv_match_lines_batch.argtypes = [C.c_int, C.POINTER(MatchLinesArgs)]
+    check(lib().tcv_match_lines_batch(n, arr))
+    return [(fov.astype(bool), match[:nd].copy(), err[:nd].copy(), proj[:nd].copy()) for fov, match, err, proj, nd in outs]
 
 
 class Preint:

@@ -57,3 +57,25 @@ def test_fov_of_the_new_frame_and_matching_in_one_call(gpu):
     assert np.array_equal(fov1, two.astype(bool)) and np.array_equal(m1, m2) and np.array_equal(e1, e2) and np.array_equal(p1, p2)
     with pytest.raises(gpu.TcvError):
         gpu.match_lines(z["poses"], *args, z["lines3d"], z["det_frame"], z["det"], 0.1745, 0.45, in_fov=one, fov_frame=nf)
+
+
+def test_batched_association_equals_the_single_calls(gpu):
+    """tcv_match_lines_batch: the associations of the sequences of a lock-step frame -- each with its own map, poses, detections and FoV
+    mode -- in ONE device round trip; every call gives exactly what tcv_match_lines gives alone"""
+    z = load("lines.npz")
+    base = dict(ex_pose=z["ex"], Rbw=z["Rbw"], Tbw=z["Tbw"], K=z["K"], width=int(z["width"]), height=int(z["height"]), window_size=int(z["window_size"]),
+                angle_th=float(z["angle_th"]), overlap_th=float(z["overlap_th"]))
+    nf = z["poses"].shape[0]
+    frozen = np.array(z["in_fov"], dtype=np.uint8)
+    calls = [dict(base, poses=z["poses"], lines3d=z["lines3d"], det_frame=z["det_frame"], det_lines=z["det"]),                                        # FoV computed
+             dict(base, poses=z["poses"], lines3d=z["lines3d"][::2], det_frame=z["det_frame"][:40], det_lines=z["det"][:40]),                          # another map
+             dict(base, poses=z["poses"], lines3d=z["lines3d"], det_frame=z["det_frame"], det_lines=z["det"], in_fov=frozen, fov_frame=nf - 1),        # steady state
+             dict(base, poses=z["poses"][:3], lines3d=z["lines3d"], det_frame=np.zeros(0, np.int32), det_lines=np.zeros((0, 4))),                      # no detections
+             dict(base, poses=z["poses"], lines3d=z["lines3d"], det_frame=z["det_frame"][5:9], det_lines=z["det"][5:9], in_fov=frozen)]                # every row given
+    got = gpu.match_lines_batch(calls)
+    for c, g in zip(calls, got):
+        ref = gpu.match_lines(c["poses"], c["ex_pose"], c["Rbw"], c["Tbw"], c["K"], c["width"], c["height"], c["window_size"], c["lines3d"], c["det_frame"], c["det_lines"],
+                              c["angle_th"], c["overlap_th"], in_fov=c.get("in_fov"), fov_frame=c.get("fov_frame"))
+        for a, b in zip(g, ref):
+            assert np.array_equal(a, b)
+    assert np.array_equal(got[0][1], z["match"])

@@ -429,3 +429,36 @@ def test_marginalisation_keeps_a_constant_extrinsic(gpu):
     P = gpu.Prior(h); d = P.export(); As, bs = P.schur()
     assert (d["m"], d["n"]) == (6, po["n"]) == (6, main["prior"]["n"] - 6) and d["sizes"] == po["sizes"] and d["idx"] == po["idx"]
     assert fro(As, dbg["A_schur"]) < 2e-6 and fro(bs, dbg["b_schur"]) < 1e-8
+
+
+def test_batch_with_windows_that_are_only_solved(gpu):
+    """tcv_batch_create: single entries of marg_problems may be NULL -- the windows of a lock-step frame form ONE batch whether or not they
+    marginalise (a MARGIN_SECOND_NEW frame whose prior does not hold para_Pose[WINDOW_SIZE - 1] only solves, estimator.cpp:2049-2050).
+    The marginalised windows give the bits of an all-marginalising batch, the others have no prior."""
+    tcv = gpu
+    B = 5
+    wins = [synth.window_at(synth.make_windows(7300, B), k) for k in range(B)]
+
+    def run(skip):
+        W = [tcv.Window(w) for w in wins]
+        MW = [tcv.margin_old_window(w) for w in wins]
+        M = [None if k in skip else tcv.Window(MW[k], share=W[k]) for k in range(B)]
+        drops = [None if k in skip else tcv.margin_old_drops(W[k], MW[k]) for k in range(B)]
+        b = tcv.Batch(W, M, drops)
+        b.solve(tcv.default_options(8, True)); b.gauge_fix(); b.marginalize(); b.synchronize(); b.download_states(); b.download_priors()
+        return W, b, b.summaries()
+
+    W0, b0, s0 = run(set())
+    W1, b1, s1 = run({1, 3})
+    assert list(b1.marg_status()) == [0] * B
+    pd = b1.priors_device(); ph = b1.priors()
+    for k in range(B):
+        assert s0[k].final_cost == s1[k].final_cost and np.array_equal(W0[k].pose, W1[k].pose) and np.array_equal(W0[k].lam, W1[k].lam)
+        if k in (1, 3):
+            assert pd[k] is None and ph[k] is None
+            with pytest.raises(tcv.TcvError):
+                b1.prior(k)
+        else:
+            e0, e1, ed = b0.prior(k).export(), b1.prior(k).export(), pd[k].export()
+            for key in ("J0", "r0"):
+                assert np.array_equal(e0[key], e1[key]) and np.array_equal(e0[key], ed[key]), (k, key)
