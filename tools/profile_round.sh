@@ -3,7 +3,7 @@
 #   bash tools/profile_round.sh <tag>
 # rocprofv3 --kernel-trace --stats of the benchmark command, separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ counters;
 # kernel-trace only, as gpurun requires), the bench line itself and the per-phase cycle tables of the -DTCV_PROFILE build.
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
@@ -45,8 +45,6 @@ for spec in "default:" "round-2 eigenvalue search:TCV_MARG_EIG_FLAGS=1" "reflect
     env $var python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-45s solve %.3f ms  marginalisation %.3f ms  %.1f K solves/s' % ('$name', d['kernel_ms']['solve'], d['kernel_ms']['marginalize'], d['value'] / 1e3))"
   done
 done > $O/kernel_ab.txt 2>&1
-python3 tools/dev_role_modes.py > $O/role_modes.txt 2>&1
-python3 tools/dev_split_streams.py > $O/split_streams.txt 2>&1
 find $O -name "*_kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
 python3 - <<PY
 import csv, glob, collections, json
