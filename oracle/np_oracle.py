@@ -392,6 +392,13 @@ class Problem:
         self.has_td = win.get("td") is not None            # ESTIMATE_TD: para_Td[0], estimator.cpp:1703-1707
         if self.has_td:
             self.blocks.append(("td", 0, 1))
+        # relocalisation (estimator.cpp:1854-1886): `relo_Pose` is one more pose block with a PoseLocalParameterization (:1857-1858), and every
+        # landmark that starts at or before the matched frame and has a match in the loop-closure frame gets one more ProjectionFactor on
+        # (para_Pose[start], relo_Pose, para_Ex_Pose[0], para_Feature[feature_index]) (:1876-1880).  win["relo"] = dict(pose (7), frame_i, landmark,
+        # pts_i, pts_j): the factor list as the reference's loop would build it.
+        self.has_relo = win.get("relo") is not None
+        if self.has_relo:
+            self.blocks.append(("relo", 0, 7))
         for l in range(L):
             self.blocks.append(("lam", l, 1))
         self.const = set(const_blocks)
@@ -413,6 +420,8 @@ class Problem:
         x = dict(pose=w["pose"].copy(), sb=w["speedbias"].copy(), ex=w["ex_pose"].copy(), lam=w["lam"].copy())
         if self.has_td:
             x["td"] = np.array([float(w["td"])])
+        if self.has_relo:
+            x["relo"] = np.asarray(w["relo"]["pose"], dtype=float).copy()
         return x
 
     @staticmethod
@@ -421,6 +430,7 @@ class Problem:
         if nm == "sb": return x["sb"][i]
         if nm == "ex": return x["ex"]
         if nm == "td": return x["td"]
+        if nm == "relo": return x["relo"]
         return x["lam"][i:i + 1]
 
     def factors(self):
@@ -442,6 +452,10 @@ class Problem:
         ln = w["line"]
         for k in range(len(ln["frame"])):
             out.append(("line", k, [("pose", int(ln["frame"][k]))]))
+        if self.has_relo:                           # estimator.cpp:1854-1886, behind the line factors
+            rl = w["relo"]
+            for k in range(len(rl["frame_i"])):
+                out.append(("proj_relo", k, [("pose", int(rl["frame_i"][k])), ("relo", 0), ("ex", 0), ("lam", int(rl["landmark"][k]))]))
         return out
 
     def eval_factor(self, fac, x, want_jac=True, imu_sqrt=None):
@@ -460,6 +474,10 @@ class Problem:
             pr = w["proj"]
             r, Js = proj_evaluate(xs[0], xs[1], xs[2], float(xs[3][0]), pr["pts_i"][k], pr["pts_j"][k],
                                   pr["sqrt_info"], want_jac)
+            return loss_correct(r, Js, pr["loss_a"])
+        if kind == "proj_relo":                     # ProjectionFactor(pts_i, pts_j) with relo_Pose as the second pose, the same CauchyLoss (:1878-1880)
+            pr, rl = w["proj"], w["relo"]
+            r, Js = proj_evaluate(xs[0], xs[1], xs[2], float(xs[3][0]), rl["pts_i"][k], rl["pts_j"][k], pr["sqrt_info"], want_jac)
             return loss_correct(r, Js, pr["loss_a"])
         if kind == "proj_td":
             pr = w["proj"]
@@ -504,6 +522,8 @@ class Problem:
         out = dict(pose=x["pose"].copy(), sb=x["sb"].copy(), ex=x["ex"].copy(), lam=x["lam"].copy())
         if self.has_td:
             out["td"] = x["td"].copy()
+        if self.has_relo:
+            out["relo"] = x["relo"].copy()
         for (nm, i, g) in self.blocks:
             lo = self.loff[(nm, i)]
             if lo < 0:
@@ -512,6 +532,8 @@ class Problem:
                 out["pose"][i] = pose_plus(x["pose"][i], delta[lo:lo + 6])
             elif nm == "ex":
                 out["ex"] = pose_plus(x["ex"], delta[lo:lo + 6])
+            elif nm == "relo":
+                out["relo"] = pose_plus(x["relo"], delta[lo:lo + 6])
             elif nm == "sb":
                 out["sb"][i] = x["sb"][i] + delta[lo:lo + 9]
             elif nm == "td":

@@ -356,7 +356,7 @@ extern "C" int tcv_problem_plan_stats(const tcv_problem *p, int *out) {
     const int v[16] = {H.nc, H.nx, H.npp, H.nland, H.chain ? H.nt_c : H.nt, H.n_vis_chunk, H.n_imu_chunk, H.n_vunit, H.n_vitem, H.n_sunit, H.n_sitem,
                        H.chain ? H.n_e : H.n_iunit, H.n_iitem, H.plan_ints, pk.win.n_doubles,
                        H.chain ? chain_lds_doubles() * 8
-                               : (H.nt * (H.nt + 1) / 2 * 256 + 2 * ((H.nx + H.nland + 1) & ~1) + 4 * 176 + 64 + H.lds_area) * 8};
+                               : (H.nt * (H.nt + 1) / 2 * 256 + 2 * ((H.nx + H.nland + 1) & ~1) + (3 * H.camw + 176) + 64 + H.lds_area) * 8};
     std::memcpy(out, v, sizeof v);
     return TCV_OK;
 }
@@ -636,7 +636,7 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
         if (rc == TCV_OK && mode == 0 && coop_h > 0)
             for (int w = 0; w < n; w++) {      // what the cooperative master assumes: the prior staged in one piece, one IMU chunk
                 const PlanHdr &H = b->packed[w].hdr;
-                if (!H.chain || H.n_imu_chunk > 1 || (H.prior_n > 0 && H.prior_n * H.prior_n + 2 * H.prior_n > H.c_stage_cap)) {
+                if (!H.chain || H.n_imu_chunk > 1 || H.camw != (int)CAM_W || (H.prior_n > 0 && H.prior_n * H.prior_n + 2 * H.prior_n > H.c_stage_cap)) {      // (the export layout of the helpers holds CAM_W-wide vectors)
                     coop_h = 0;
                     rc = pack_all(mode, msg);
                     break;
@@ -679,7 +679,7 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
         max_nl = std::max(max_nl, pk.hdr.nc + pk.hdr.nland);
         const int nt = pk.hdr.nt;
         const size_t lds = b->chain ? (size_t)chain_lds * 8
-                                    : (size_t)(nt * (nt + 1) / 2 * 256 + 2 * ((pk.hdr.nx + pk.hdr.nland + 1) & ~1) + 4 * 176 + 64 + pk.hdr.lds_area) * 8;
+                                    : (size_t)(nt * (nt + 1) / 2 * 256 + 2 * ((pk.hdr.nx + pk.hdr.nland + 1) & ~1) + (3 * pk.hdr.camw + 176) + 64 + pk.hdr.lds_area) * 8;
         max_lds = std::max(max_lds, lds);
         b->spill_stride = std::max(b->spill_stride, pk.hdr.c_spill);
         b->hcl_cap = std::max(b->hcl_cap, (pk.hdr.hcl_total + 63) & ~63);

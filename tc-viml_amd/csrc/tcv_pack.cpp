@@ -165,7 +165,7 @@ struct DestList {
     std::vector<std::pair<int, int>> shape;    // (la, lb); lb = 0: triangle of la
     std::vector<int> pair_id, pair_item;       // every add(), in order
     std::vector<int> start, items;             // after finish(): items of destination id = items[start[id] .. start[id + 1])
-    enum { T_TILE = 0, T_G = 176 * 176, T_RC = T_G + 256, T_HLL = T_RC + 256, T_HCL = T_HLL + 2048, T_SIZE = T_HCL + 65536 };
+    enum { T_TILE = 0, T_G = CAM_MAX * CAM_MAX, T_RC = T_G + 256, T_HLL = T_RC + 256, T_HCL = T_HLL + 2048, T_SIZE = T_HCL + 65536 };
     struct Table { std::vector<unsigned> stamp; std::vector<int> val; unsigned gen = 0; Table() : stamp(T_SIZE, 0u), val(T_SIZE, 0) {} };
     struct Pool { std::mutex mu; std::vector<Table *> idle; ~Pool() { for (Table *t : idle) delete t; } };
     static Pool &pool() { static Pool p; return p; }
@@ -195,7 +195,7 @@ struct DestList {
     Table &table() { return *tab; }
     void add(int kind, int o0, int o1, int la, int lb, int item) {
         int slot = -1;
-        if (kind == DK_TILE) { if (o0 >= 0 && o0 < 176 && o1 >= 0 && o1 < 176) slot = T_TILE + o0 * 176 + o1; }
+        if (kind == DK_TILE) { if (o0 >= 0 && o0 < CAM_MAX && o1 >= 0 && o1 < CAM_MAX) slot = T_TILE + o0 * CAM_MAX + o1; }
         else if (kind == DK_G) { if (o0 >= 0 && o0 < 256) slot = T_G + o0; }
         else if (kind == DK_RC) { if (o0 >= 0 && o0 < 256) slot = T_RC + o0; }
         else if (kind == DK_HLL) { if (o0 >= 0 && o0 < 2048) slot = T_HLL + o0; }
@@ -374,11 +374,16 @@ static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds,
     const int nt = (nc + 1 + 15) / 16, ntp = (npp + 15) / 16;
     const int ntiles = nt * (nt + 1) / 2, pp_tiles = ntp * (ntp + 1) / 2;
     if (td_cam >= 0 && loff[td_cam] >= 0 && loff[td_cam] + 6 > nt * 16) { set_error("Td block: no room for its gather slot"); return TCV_ERR_UNSUPPORTED; }
-    if (nc > 175 || npp > 88 || nc + L > SCR_NL || L > 1024) { set_error("window too large for the fused solver (camera tangent dim > 175)"); return TCV_ERR_TOO_LARGE; }
+    // camera tangent dims: 171 for the 11 frames + extrinsic of OptimizationWithLine (172 with Td), 177 with the relocalisation pose (:1854-1886)
+    if (nc > CAM_MAX - 1 || npp > 88 || nc + L > SCR_NL || L > 1024) { set_error("window too large for the fused solver (camera tangent dim > 183)"); return TCV_ERR_TOO_LARGE; }
+    const int camw = nc <= CAM_W - 1 ? (int)CAM_W : (int)CAM_MAX;
     const int nxl = (nx + L + 1) & ~1;
-    int area_cap = LDS_DOUBLES - ntiles * 256 - 2 * nxl - 4 * 176 - 64;
+    int area_cap = LDS_DOUBLES - ntiles * 256 - 2 * nxl - (3 * camw + 176) - 64;
     int stage_cap = (ntiles - pp_tiles) * 256;
-    if (area_cap < 512) { set_error("window too large for the fused solver (LDS)"); return TCV_ERR_TOO_LARGE; }
+    // (the dense layout holds the whole camera system in LDS tiles: 12 tile rows -- a window with the relocalisation pose -- do not fit; such a
+    // window needs the chain layout, decided below)
+    const bool dense_fits = area_cap >= 512;
+    if (!dense_fits && mode != 0) { set_error("window too large for the fused solver (LDS)"); return TCV_ERR_TOO_LARGE; }
 
     // ---- chain layout: the free Euclidean camera blocks (speed-biases, 9 wide) only meet their IMU neighbours and the
     // prior, so they are eliminated one after the other BEFORE the dense pose system (block-sparse Cholesky with the poses
@@ -431,7 +436,7 @@ static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds,
     }
     // (Td's gather slot is six columns wide, tcv_packed.h: the pose tiles have to cover the five structural zeros behind its column)
     const int nt_c = (std::max(npp + 1, (td_cam >= 0 && loff[td_cam] >= 0) ? loff[td_cam] + 6 : 0) + 15) / 16, ctiles = nt_c * (nt_c + 1) / 2;
-    const int c_vec = 2 * nxl + 4 * 176 + 64 + 112;
+    const int c_vec = 2 * nxl + (3 * camw + 176) + 64 + 112;
     const int c_lds = coop_chunks > 0 ? (LDS_DOUBLES - ctiles * 256 - 8) : ((chain_lds >= 6144 && chain_lds <= LDS_DOUBLES) ? (chain_lds & ~1) : chain_lds_doubles());
     const int c_pool = c_lds - ctiles * 256 - c_vec;
     if (use_chain && (c_pool < chain_pool_doubles((int)chain.size(), nt_c) || c_pool < IMU_REC)) use_chain = false;
@@ -442,7 +447,7 @@ static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds,
     H.nblk = nblk; H.nland = L; H.nc = nc; H.nx = nx; H.npp = npp; H.nt = nt; H.ntp = ntp;
     H.n_imu = (int)p.imu.size(); H.n_proj = (int)p.proj.size(); H.n_line = (int)p.line.size();
     H.lds_area = area_cap;
-    H.flags = td_blk >= 0 ? 1 : 0; H.td_cam = td_cam;
+    H.flags = td_blk >= 0 ? 1 : 0; H.td_cam = td_cam; H.camw = camw;
     const int prec = td_blk >= 0 ? (int)PROJ_TD_REC : (int)PROJ_REC;      // doubles per staged point record
     const int td_t = td_cam >= 0 ? loff[td_cam] : -1;
     std::vector<int> &I = out.ints;
@@ -680,6 +685,7 @@ static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds,
         }
         if (!found) { use_chain = false; chain.clear(); }
     }
+    if (!use_chain && !dense_fits) { set_error("window too large for the fused solver (LDS; its speed-bias blocks do not form a chain either)"); return TCV_ERR_TOO_LARGE; }
     if (!use_chain) {
         chain.clear();
         { const int rc = build_chunks(stage_cap, area_cap, vch); if (rc != TCV_OK) return rc; }

@@ -18,6 +18,7 @@
 namespace tcv {
 
 enum { KIND_EUCLID = 0, KIND_POSE = 1 };
+enum { CAM_W = 176, CAM_MAX = 184 };      // camera tangent dims the fused solver's vectors hold: every window of OptimizationWithLine / with the relocalisation pose
 enum { TILE = 16, TILE_ELEMS = 256 };
 enum { LDS_DOUBLES = 20480 };  // 160 KiB per workgroup on gfx950
 int chain_lds_doubles();       // LDS doubles of a chain-mode workgroup (two per CU); tcv_pack.cpp
@@ -89,7 +90,8 @@ struct PlanHdr {
     int flags;          // bit 0: the point factors are ProjectionTdFactors (chain layout: the kernel instance with TD = true)
     int td_cam;         // camera block index of para_Td (-1 none); point records then carry 26 columns per row:
                         // [.. 19 as below | r | td | 5 zeros] so that Td rides through the 6-wide gather machinery
-    int pad_td;
+    int camw;           // width of the LDS vectors over the camera tangent space (sc, ycam, invdiag / gcam): CAM_W for nc <= CAM_W, else CAM_MAX
+                        // (a 12th pose block -- the relocalisation pose, estimator.cpp:1854-1886 -- takes the camera side to 177 dims)
     // int-pool offsets (relative to the plan base)
     int o_blk;      // nblk x 4 : gsize, goff (ambient), loff (tangent, -1 constant), kind
     int o_imu;      // n_imu x 4 block ids

@@ -68,6 +68,12 @@ enum { PH_SETUP = 0, PH_VIS_EVAL, PH_VIS_GATHER, PH_LM, PH_SCHUR, PH_ZERO, PH_IM
        PH_COST_RED, PH_FIN_SCALE, PH_FIN_CAUCHY, PH_FIN_PASS, PH_CHOL_DIAG, PH_CHOL_TRSM, PH_CHOL_UPD, PH_BACK, PH_LM_BACK,
        PH_DOGLEG, PH_PLUS, PH_NORMS, PH_OTHER, PH_CHAIN_FWD, PH_CHAIN_BWD, PH_CH_A, PH_CH_B, PH_CH_C, PH_CH_D, PH_COUNT = 32 };
 
+// (developer A/B: -DTCV_CAMW_CONST builds the kernels with the camera-vector width as a literal, i.e. without relocalisation windows)
+#ifdef TCV_CAMW_CONST
+#define TCV_CAMW(P) ((int)CAM_W)
+#else
+#define TCV_CAMW(P) ((P).camw)
+#endif
 template <int NT>
 struct Ctx {
     gbl_d *prof;
@@ -187,14 +193,16 @@ __device__ __forceinline__ void ctx_scratch_layout(Ctx<NT> &C, gbl_d *scr) {
     C.g_hcl = C.g_sqrt + SCR_SQ;
 }
 template <int NT>
-__device__ __forceinline__ void ctx_lds_layout(Ctx<NT> &C, lds_d *xs, int nxl, bool chain, int c_stage_cap) {
+__device__ __forceinline__ void ctx_lds_layout(Ctx<NT> &C, lds_d *xs, int nxl, bool chain, int c_stage_cap, int camw) {
+    // camw (PlanHdr::camw): width of the vectors over the camera tangent space -- 176 for every window of OptimizationWithLine, 184 when a 12th
+    // pose block (the relocalisation pose, estimator.cpp:1854-1886) takes the camera side to 177 dims; rc | sd cover the pose part only (< 88 each)
     lds_d *p = xs;
     C.xs = p; p += nxl;
     C.xc = p; p += nxl;
-    C.sc = p; p += 176;
+    C.sc = p; p += camw;
     C.rc = p; C.sd = p + 88; p += 176;
-    C.ycam = p; p += 176;
-    C.invdiag = p; C.gcam = p; p += 176;
+    C.ycam = p; p += camw;
+    C.invdiag = p; C.gcam = p; p += camw;
     C.red = p; p += 64;
     C.flag = (lds_i *)(C.red + 62);   // red[] uses at most 5 * NT/64 = 40 doubles; 40..55 hold the profile build's counters, 56 its last time stamp
     C.hd = p;                         // chain mode only (112 doubles)
@@ -212,7 +220,7 @@ __device__ __forceinline__ Ctx<NT> ctx_from_args(TCV_CTX_PARAMS) {
     C.skip = __builtin_amdgcn_readfirstlane(askip_);
     ctx_scratch_layout<NT>(C, uni_ptr(ascr_));
     cst_plan &P = *C.P;
-    ctx_lds_layout<NT>(C, uni_ptr(axs_), (P.nx + P.nland + 1) & ~1, P.chain != 0, P.c_stage_cap);
+    ctx_lds_layout<NT>(C, uni_ptr(axs_), (P.nx + P.nland + 1) & ~1, P.chain != 0, P.c_stage_cap, TCV_CAMW(P));
     C.cx_ctl = nullptr; C.cx_x = nullptr; C.cx_exp = nullptr; C.cx_h = 0; C.cx_exp_stride = 0; C.cx_seq = 0; C.cx_timeout = 0;
     return C;
 }
@@ -723,7 +731,7 @@ __device__ __forceinline__ void imu_part2(Ctx<NT> &C, int ch, bool assemble) {
                         }
 #pragma unroll
                         for (int i = 0; i < 4; i++) {
-                            const double tv = C.tiles[max(d4[i], 0)], gv = C.gcam[min(max(-2 - d4[i], 0), 175)];
+                            const double tv = C.tiles[max(d4[i], 0)], gv = C.gcam[min(max(-2 - d4[i], 0), CAM_MAX - 1)];
                             v4[i] = d4[i] >= 0 ? tv : gv;
                             if (CHAIN && d4[i] <= -1000) v4[i] = C.hd[-1000 - d4[i]];
                         }
@@ -778,7 +786,7 @@ __device__ __forceinline__ void imu_part2(Ctx<NT> &C, int ch, bool assemble) {
                     }
 #pragma unroll
                     for (int q = 0; q < 16; q++) {      // both candidate loads unconditional, selected afterwards
-                        const double tv = C.tiles[max(didx[q], 0)], gv = C.gcam[min(max(-2 - didx[q], 0), 175)];
+                        const double tv = C.tiles[max(didx[q], 0)], gv = C.gcam[min(max(-2 - didx[q], 0), CAM_MAX - 1)];
                         dval[q] = didx[q] >= 0 ? tv : gv;
                         if (CHAIN && didx[q] <= -1000) dval[q] = C.hd[-1000 - didx[q]];
                     }
@@ -1894,7 +1902,7 @@ __device__ __noinline__ ChainOut chain_forward(TCV_CTX_PARAMS, double mu) {
                 const int cc = 16 * J + col;
                 if ((tmask >> J) & 1) {      // else: no coupled column in this tile yet, W stays zero
                     const bool act = rcs[jt] != 255, rhs = cc == npp;
-                    const double scc = (act && !rhs) ? C.sc[min(cc, 175)] : 0.0, uc = (act && !rhs) ? C.ycam[min(cc, 175)] : 0.0;
+                    const double scc = (act && !rhs) ? C.sc[min(cc, CAM_MAX - 1)] : 0.0, uc = (act && !rhs) ? C.ycam[min(cc, CAM_MAX - 1)] : 0.0;
                     v4f64 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                     for (int i = 0; i < 3; i++) {      // branch-free: selects only (rows 9..11 of the accumulator stay zero)
@@ -2044,7 +2052,7 @@ __device__ __noinline__ __attribute__((disable_tail_calls)) FinOut finalize_and_
         C.v_ghat[a] = gh;
         C.ycam[a] = s * gh / D;  // u = s * (ghat / D): Cauchy direction in unscaled tangent units
     }
-    for (int a = nc + tid; a < 176; a += NT) { C.ycam[a] = 0.0; C.sc[a] = 0.0; }
+    for (int a = nc + tid; a < TCV_CAMW(*C.P); a += NT) { C.ycam[a] = 0.0; C.sc[a] = 0.0; }
     for (int l = tid; l < L; l += NT) {
         const double s = C.v_s[nc + l], h = C.l_hll[l];
         const double d2 = fmin(fmax(s * s * h, 1e-6), 1e32), D = sqrt(d2);
@@ -2360,7 +2368,7 @@ __global__ void __launch_bounds__(NT) __attribute__((disable_tail_calls)) __attr
             C.stage_cap = (C.ntiles - pp_tiles) << 8;
             p = lds + (C.ntiles << 8);
         }
-        ctx_lds_layout<NT>(C, p, nxl, CHAIN, P.c_stage_cap);      // xs, xc, sc, rc | sd, ycam, invdiag = gcam, red, flag, hd, area
+        ctx_lds_layout<NT>(C, p, nxl, CHAIN, P.c_stage_cap, TCV_CAMW(P));      // xs, xc, sc, rc | sd, ycam, invdiag = gcam, red, flag, hd, area
 #ifdef TCV_PROFILE
         if (tid < PH_COUNT) ((lds_u *)(C.red + 40))[tid] = 0u;
         if (tid == 0) { typedef __attribute__((address_space(3))) long long lds_ll; *(lds_ll *)(C.red + 56) = clock64(); }

@@ -285,3 +285,38 @@ def test_exact_line_jacobian_is_the_derivative_of_the_reference_residual():
         worst_exact = max(worst_exact, np.abs(Je[0][:, :6] - fd).max() / np.abs(fd).max())
         worst_ref = max(worst_ref, np.abs(Jr[0][:, :6] - fd).max() / np.abs(fd).max())
     assert worst_exact < 1e-5 and worst_ref > 0.5
+
+
+def test_relocalisation_pose_and_factors_in_the_numpy_oracle():
+    """np_oracle.Problem with win["relo"] (estimator.cpp:1854-1886): relo_Pose is one more pose block, every matched landmark one more
+    ProjectionFactor on (para_Pose[start], relo_Pose, para_Ex_Pose[0], para_Feature[idx]).  The relo columns of the window Jacobian agree with
+    central differences under PoseLocalParameterization::Plus, and the solve lowers the cost and moves the relocalisation pose."""
+    import np_oracle as NO
+    import synth
+    from relo_util import add_relocalisation
+    w = add_relocalisation(dict(synth.window_at(synth.make_windows(9300, 1, with_lines=False), 0), prior=None), f=6, seed=2)
+    prob = NO.Problem(w)
+    assert prob.has_relo and prob.nc == 12 * 6 + 6 + 11 * 9 and len(w["relo"]["frame_i"]) >= 8
+    n_relo = sum(1 for f in prob.factors() if f[0] == "proj_relo")
+    assert n_relo == len(w["relo"]["frame_i"])
+    x = prob.x0()
+    lo = prob.loff[("relo", 0)]
+    facs = [f for f in prob.factors() if f[0] == "proj_relo"]
+    h = 1e-6
+    for fac in facs[:4]:
+        r, Js, _ = prob.eval_factor(fac, x, True)
+        # undo nothing: compare the loss-corrected Jacobian of the relo block with differences of the loss-corrected residual is not meaningful
+        # (the corrector is not a derivative), so difference the RAW residual
+        kind, k, blks = fac
+        xs = [prob.get(x, nm, i) for (nm, i) in blks]
+        rl, pr = w["relo"], w["proj"]
+        r0, J0 = NO.proj_evaluate(xs[0], xs[1], xs[2], float(xs[3][0]), rl["pts_i"][k], rl["pts_j"][k], pr["sqrt_info"], True)
+        for c in range(6):
+            d = np.zeros(6); d[c] = h
+            rp, _ = NO.proj_evaluate(xs[0], NO.pose_plus(xs[1], d), xs[2], float(xs[3][0]), rl["pts_i"][k], rl["pts_j"][k], pr["sqrt_info"], False)
+            rm, _ = NO.proj_evaluate(xs[0], NO.pose_plus(xs[1], -d), xs[2], float(xs[3][0]), rl["pts_i"][k], rl["pts_j"][k], pr["sqrt_info"], False)
+            assert np.abs((rp - rm) / (2 * h) - J0[1][:, c]).max() < 2e-4 * max(1.0, np.abs(J0[1]).max())
+    xs, so = NO.solve(prob, 8, True)
+    assert so["final_cost"] < so["initial_cost"] and np.abs(xs["relo"] - w["relo"]["pose"]).max() > 1e-4
+    J, r, cost = prob.linearize(x)
+    assert np.abs(J[:, lo:lo + 6]).max() > 0 and J.shape[1] == prob.nlocal
