@@ -64,7 +64,7 @@ typedef struct {
     int workgroups_per_window;         /* 0 (default): a batch planned for the cooperative small-batch mode (tcv_set_cooperative) runs each
                                           window on 1 + H workgroups; 1: one workgroup per window whatever the plan (same chunks, same
                                           additions: bit-identical results -- the A/B switch of the parity tests).
-                                          ABI note: until round 2 this slot was `compute_sqrt_info_on_device` (reserved, ignored, default 1);
+                                          ABI note: until round 2 this slot was `compute_sqrt_info_on_device` (a reserved slot nobody read, default 1);
                                           a caller that still writes 1 here by hand switches the cooperative mode off -- fill the struct
                                           with tcv_solver_options_default() and change only what you mean to */
     int use_mfma;                      /* dense layout only: 1 (default) trailing Cholesky update on v_mfma_f64_16x16x4_f64,
