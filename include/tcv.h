@@ -130,6 +130,10 @@ const char *tcv_version(void);
 const char *tcv_last_error(void);
 int tcv_device_count(void);            /* 0 when no HIP device is visible */
 int tcv_set_device(int device);
+/* Device memory this library holds (all devices): bytes in buffers that live objects own (batches, device-resident priors and
+ * pre-integrations, ...), bytes kept in its free list for reuse (at most 3 GiB, released under memory pressure), number of live
+ * buffers.  Every tcv_*_destroy returns its buffers: after destroying everything `live_bytes` is what it was before (leak checks). */
+int tcv_device_memory_stats(unsigned long long *live_bytes, unsigned long long *cached_bytes, int *live_buffers);
 /* 0 (default): batches whose speed-bias blocks form chains (every window OptimizationWithLine builds) use the chain layout
  * of the fused solver (speed-biases eliminated block by block before the dense pose system; two windows per CU when the
  * batch has more windows than the device has CUs, otherwise one window per CU with the whole LDS);

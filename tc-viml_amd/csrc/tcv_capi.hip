@@ -128,6 +128,16 @@ hipError_t dev_free(void *p) {
     return ::hipFree(p);
 }
 
+void dev_pool_stats(unsigned long long *live_bytes, unsigned long long *cached_bytes, int *live_buffers) {
+    DevPool &P = pool();
+    std::lock_guard<std::mutex> g(P.mu);
+    unsigned long long lb = 0;
+    for (auto &kv : P.live) lb += kv.second.second;
+    if (live_bytes) *live_bytes = lb;
+    if (cached_bytes) *cached_bytes = P.cached;
+    if (live_buffers) *live_buffers = (int)P.live.size();
+}
+
 hipStream_t util_stream() {
     thread_local std::map<int, hipStream_t> mine;
     int dev = 0;
@@ -169,6 +179,10 @@ extern "C" int tcv_set_solver_variant(int variant) {
 extern "C" int tcv_set_cooperative(int helpers) {
     if (helpers < -1 || helpers > COOP_MAX_H) { set_error("set_cooperative: -1 (automatic), 0 (off) or 1..7 helper workgroups per window"); return TCV_ERR_INVALID; }
     g_coop_helpers = helpers;
+    return TCV_OK;
+}
+extern "C" int tcv_device_memory_stats(unsigned long long *live_bytes, unsigned long long *cached_bytes, int *live_buffers) {
+    tcv::dev_pool_stats(live_bytes, cached_bytes, live_buffers);
     return TCV_OK;
 }
 extern "C" int tcv_set_device(int device) {

@@ -26,7 +26,7 @@ _ip = C.POINTER(C.c_int)
 
 # every symbol include/tcv.h declares (checked by tests/test_abi.py against the header text)
 EXPORTS = [
-    "tcv_version", "tcv_last_error", "tcv_device_count", "tcv_set_device",
+    "tcv_version", "tcv_last_error", "tcv_device_count", "tcv_set_device", "tcv_device_memory_stats",
     "tcv_problem_create", "tcv_problem_destroy", "tcv_problem_add_parameter_block",
     "tcv_problem_set_parameter_block_constant", "tcv_problem_set_gravity", "tcv_problem_add_imu_factor",
     "tcv_problem_add_projection_factor", "tcv_problem_add_projection_td_factor", "tcv_problem_set_rolling_shutter", "tcv_problem_set_line_jacobian", "tcv_problem_add_line_factor", "tcv_problem_add_marginalization_factor",
@@ -194,6 +194,13 @@ def f64(a):
 
 def i32(a):
     return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def device_memory_stats():
+    """(live_bytes, cached_bytes, live_buffers) of the library's device allocator (tcv_device_memory_stats)"""
+    lb, cb, n = C.c_ulonglong(0), C.c_ulonglong(0), C.c_int(0)
+    check(lib().tcv_device_memory_stats(C.byref(lb), C.byref(cb), C.byref(n)))
+    return int(lb.value), int(cb.value), int(n.value)
 
 
 def default_options(max_num_iterations=8, fixed_iterations=True, use_mfma=True, threads=256, record_first_step=False, workgroups_per_window=0):

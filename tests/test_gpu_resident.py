@@ -214,3 +214,50 @@ def test_native_estimator_with_device_resident_preintegrations_matches_the_host_
     for a, c in zip(dev, host):
         assert len(a["t"]) == len(c["t"]) == 30 - replay.WINDOW_SIZE and {l["flag"] for l in a["log"]} == {0, 1}
         assert np.array_equal(a["p"], c["p"]) and np.array_equal(a["q"], c["q"]) and np.array_equal(a["v"], c["v"])
+
+
+def test_device_memory_returns_to_its_level_after_the_objects_are_gone(gpu):
+    """tcv_device_memory_stats: batches, device-resident priors (they keep a batch's result buffer alive) and pre-integration handles give
+    every byte back when the last owner goes -- chains of frames through the batch API and through the native estimator (device-resident
+    state forced on) leave the allocator's live bytes / buffer count where they were"""
+    import gc
+    tcv = gpu
+    B = 6
+    pre = synth.make_windows(9300, B, frame_shift=-1)
+    pw = [synth.window_at(pre, k) for k in range(B)]
+    mw = [synth.window_at(synth.make_windows(9300, B), k) for k in range(B)]
+    streams = [replay.simulate_stream(46, 24, max_features=30)]
+
+    def cycle():
+        W = [tcv.Window(w) for w in pw]
+        b = _marg_batch(tcv, pw, W); _run(b, tcv)
+        for _ in range(4):      # frame-to-frame hand-over on the device; every batch but the last is dropped while its priors are in use
+            pri = b.priors_device()
+            blocks = [tcv.shifted_prior_blocks(pri[k], W[k]) for k in range(B)]
+            W = [tcv.Window(dict(mw[k], prior=dict(blocks=blocks[k])), prior=pri[k]) for k in range(B)]
+            b = _marg_batch(tcv, mw, W); _run(b, tcv)
+        kept = b.priors_device()[0]
+        del b, W, pri
+        gc.collect()
+        assert kept.on_device() and tcv.device_memory_stats()[0] > 0      # one handle alone keeps its batch's result buffer
+        kept.export()
+        del kept
+        batch = synth.make_windows(9301, 2)
+        acc = batch["imu"]["acc"].reshape(-1, synth.IMU_RATE_SUB + 1, 3); gyr = batch["imu"]["gyr"].reshape(-1, synth.IMU_RATE_SUB + 1, 3)
+        z = np.zeros((acc.shape[0], 3))
+        hd = tcv.preintegrate_device(acc, gyr, synth.DT_IMU, z, z, (synth.ACC_N, synth.GYR_N, synth.ACC_W, synth.GYR_W))
+        del hd
+        os.environ["TCV_EST_DEVICE_STATE"] = "1"
+        try:
+            replay.run_many_native(streams, num_iterations=4)
+        finally:
+            os.environ.pop("TCV_EST_DEVICE_STATE", None)
+        gc.collect()
+
+    cycle()
+    live0, _, n0 = tcv.device_memory_stats()
+    for _ in range(2):
+        cycle()
+    live1, cached1, n1 = tcv.device_memory_stats()
+    assert (live1, n1) == (live0, n0), (live0, n0, live1, n1)
+    assert cached1 <= 3 << 30
