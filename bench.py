@@ -552,6 +552,8 @@ def run_replay(args, rank, world, local, dist):
     if not DRY:
         import ctypes as C
         tcv.lib().tcv_estimators_profile((C.c_double * 8)())      # clears the accounting of the window fill and the warm-up
+        for ls in eng.ls:
+            ls.host_s = [0.0, 0.0, 0.0, 0]
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
@@ -573,6 +575,10 @@ def run_replay(args, rank, world, local, dist):
         names = ["preintegrate", "assoc+triangulate+window", "problems", "batch_create", "kernels", "downloads", "apply"]
         prof = {k: round(1e3 * v / max(1.0, p8[7]), 3) for k, v in zip(names, p8)}
         prof["calls"] = int(p8[7])
+        # around the native call, per call: tcv_estimator_begin_frame (IMU propagation, feature bookkeeping, keyframe test) and
+        # tcv_estimator_get_stats / finish_frame (failure detection, window slide) of the call's streams, Python harness included
+        hs = [sum(ls.host_s[i] for ls in eng.ls) for i in range(4)]
+        prof["begin_frames"] = round(1e3 * hs[0] / max(1, hs[3]), 3); prof["finish_frames"] = round(1e3 * hs[2] / max(1, hs[3]), 3)
     out = {"metric": "sliding-window solves/sec, EuRoC-trajectory replay (configs[4])", "value": windows_total / elapsed_max, "unit": "solves/s",
            "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed_max / args.steps, "higher_is_better": True,
            "scaling": "strong", "vs_baseline": None, "dtype": "f64",

@@ -15,6 +15,10 @@
 #include <string>
 #include <chrono>
 #include <thread>
+#if defined(__linux__)
+#include <sys/syscall.h>
+#include <unistd.h>
+#endif
 
 #include "tcv_factors.h"
 #include "tcv_host.h"
@@ -138,15 +142,58 @@ void dev_pool_stats(unsigned long long *live_bytes, unsigned long long *cached_b
     if (live_buffers) *live_buffers = (int)P.live.size();
 }
 
+// The calling thread's own stream per device.  A host thread that ends gives its streams back: the runtime maps streams onto a handful of
+// hardware queues (GPU_MAX_HW_QUEUES, 4 by default) and a stream that is never destroyed keeps its share of a queue -- after a few
+// generations of short-lived host threads two LIVE threads end up on one queue and the small commands of one (a pre-integration, an
+// upload) wait behind the other's 2 ms solve kernel (lock-step replay on 2 host threads: 1 500 against 2 200 windows/s).  The main thread's
+// streams are left to the runtime's own teardown at process exit.
+namespace {
+struct Deferred { void *h, *d; hipStream_t st; };
+struct ThreadStreams {
+    std::map<int, hipStream_t> m;
+    std::vector<Deferred> deferred;      // buffers of commands still in flight on one of these streams (defer_release)
+    bool main_thread = false;
+    ~ThreadStreams();
+};
+ThreadStreams &thread_streams() { thread_local ThreadStreams mine; return mine; }
+}  // namespace
+// A call that leaves its commands in flight on the calling thread's stream (tcv_preintegrate_device: nobody on the host needs the result)
+// parks the pinned staging buffer and the device input blob here instead of waiting for the stream; they go back to their pools at the
+// thread's next wait on that stream (every tcv_batch_create ends with one).
+void defer_release(void *host_staging, void *dev_buf, hipStream_t st) { thread_streams().deferred.push_back(Deferred{host_staging, dev_buf, st}); }
+void flush_deferred(hipStream_t st) {
+    std::vector<Deferred> &v = thread_streams().deferred;
+    size_t k = 0;
+    for (size_t i = 0; i < v.size(); i++) {
+        if (v[i].st == st) { host_staging_release(v[i].h); (void)dev_free(v[i].d); }
+        else v[k++] = v[i];
+    }
+    v.resize(k);
+}
+namespace {
+ThreadStreams::~ThreadStreams() {
+    for (auto &kv : m) {
+        if (!kv.second) continue;
+        if (!main_thread || !deferred.empty()) (void)hipStreamSynchronize(kv.second);
+        if (!main_thread) (void)hipStreamDestroy(kv.second);
+    }
+    for (auto &x : deferred) { host_staging_release(x.h); (void)dev_free(x.d); }
+}
+}  // namespace
 hipStream_t util_stream() {
-    thread_local std::map<int, hipStream_t> mine;
+    ThreadStreams &mine = thread_streams();
     int dev = 0;
     (void)hipGetDevice(&dev);
-    auto it = mine.find(dev);
-    if (it != mine.end()) return it->second;
+    auto it = mine.m.find(dev);
+    if (it != mine.m.end()) return it->second;
+#if defined(__linux__)
+    mine.main_thread = (long)syscall(SYS_gettid) == (long)getpid();
+#else
+    mine.main_thread = true;
+#endif
     hipStream_t st = nullptr;
     if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = nullptr;      // the default stream: slower, still correct
-    mine.emplace(dev, st);
+    mine.m.emplace(dev, st);
     return st;
 }
 
@@ -598,8 +645,9 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
     b->n = n;
     b->problems.assign(problems, problems + n);
     b->packed.resize(n);
-    std::map<std::vector<int>, int> plan_index;   // structure de-duplication
-    std::vector<int> ipool;
+    std::unordered_map<unsigned long long, std::vector<int>> plan_by_hash;   // structure de-duplication
+    std::vector<std::pair<const int *, size_t>> plan_src;                    // per device plan: its ints on the host
+    size_t ipool_size = 0;
     int max_state = 0, max_nl = 0;
     size_t max_lds = 0;
     int dev = 0, n_cu = 0;
@@ -638,6 +686,19 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
             for (int w = t; w < n; w += nth) {
                 rcs[w] = pack_problem(*problems[w], b->packed[w], nullptr, md, chain_lds, true, md == 0 ? coop_h : 0);      // plan + data size
                 if (rcs[w] != TCV_OK && msgs[t].empty()) msgs[t] = tcv_last_error();      // the message is thread-local
+                if (rcs[w] == TCV_OK) {      // hash of the plan for the structure de-duplication below
+                    const Packed &pk = b->packed[w];
+                    const std::vector<int> &pints = pk.tmpl ? pk.tmpl->ints : pk.ints;
+                    unsigned long long h = 0x9E3779B97F4A7C15ull ^ pints.size();
+                    auto mix = [&](const int *p, size_t cnt) {
+                        size_t i = 0;
+                        for (; i + 1 < cnt; i += 2) { unsigned long long v; std::memcpy(&v, p + i, 8); h = (h ^ v) * 0xFF51AFD7ED558CCDull; h ^= h >> 29; }
+                        if (i < cnt) { h = (h ^ (unsigned)p[i]) * 0xFF51AFD7ED558CCDull; h ^= h >> 29; }
+                    };
+                    mix(pints.data(), pints.size());
+                    mix(reinterpret_cast<const int *>(&pk.hdr), sizeof(PlanHdr) / sizeof(int));
+                    b->packed[w].plan_hash = h;
+                }
             }
         };
         tcv::parallel_run(nth, work);
@@ -665,6 +726,7 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
                 }
         if (rc != TCV_OK) { batch_free(b); if (!msg.empty()) set_error(msg); return rc; }
     }
+    const auto t_plans = std::chrono::steady_clock::now();
     std::map<const PlanTemplate *, int> plan_of_tmpl;   // windows that share a cached plan template share the device plan
     size_t dtotal = 0;
     for (int w = 0; w < n; w++) {
@@ -673,17 +735,20 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
         int pid = -1;
         if (pk.tmpl) { auto it = plan_of_tmpl.find(pk.tmpl.get()); if (it != plan_of_tmpl.end()) pid = it->second; }
         if (pid < 0) {
-            std::vector<int> key(pints);
-            const int *hp = reinterpret_cast<const int *>(&pk.hdr);
-            key.insert(key.end(), hp, hp + sizeof(PlanHdr) / sizeof(int));
-            auto it = plan_index.find(key);
-            if (it == plan_index.end()) {
+            // equal plans share one device copy: candidates by hash (computed with the packing, in parallel), confirmed by comparison -- the
+            // replay's windows are all different (200 KB of plan each), the benchmark's all equal
+            std::vector<int> &cands = plan_by_hash[pk.plan_hash];
+            for (int c : cands)
+                if (plan_src[c].second == pints.size() && std::memcmp(&b->plans[c], &pk.hdr, sizeof(PlanHdr)) == 0 &&
+                    std::memcmp(plan_src[c].first, pints.data(), sizeof(int) * pints.size()) == 0) { pid = c; break; }
+            if (pid < 0) {
                 pid = (int)b->plans.size();
-                plan_index[key] = pid;
+                cands.push_back(pid);
                 b->plans.push_back(pk.hdr);
-                b->plan_base.push_back((long long)ipool.size());
-                ipool.insert(ipool.end(), pints.begin(), pints.end());
-            } else pid = it->second;
+                b->plan_base.push_back((long long)ipool_size);
+                plan_src.push_back({pints.data(), pints.size()});      // (stays valid: pk.ints / the template live until the copy into the staging buffer)
+                ipool_size += pints.size();
+            }
             if (pk.tmpl) plan_of_tmpl[pk.tmpl.get()] = pid;
         }
         pk.win.plan = pid;
@@ -697,7 +762,6 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
         max_lds = std::max(max_lds, lds);
         b->spill_stride = std::max(b->spill_stride, pk.hdr.c_spill);
         b->hcl_cap = std::max(b->hcl_cap, (pk.hdr.hcl_total + 63) & ~63);
-        pk.ints.clear(); pk.ints.shrink_to_fit();
         b->input_bytes += 8.0 * pk.win.n_doubles;
     }
     // data half: every window written straight into one pinned upload buffer, in parallel
@@ -717,12 +781,13 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
         if (b->packed[w].dev_prior_doubles > 0) { splice_win.push_back(w); tail_off[w] = (long long)tail_doubles; tail_doubles += ((size_t)b->packed[w].dev_prior_doubles + 1) & ~(size_t)1; n_jobs++; }
         if (b->packed[w].dev_imu_doubles > 0) { splice_imu_win.push_back(w); tail_imu[w] = (long long)tail_doubles; tail_doubles += ((size_t)b->packed[w].dev_imu_doubles + 1) & ~(size_t)1; n_jobs += problems[w]->imu.size(); }
     }
-    const size_t o_jobs = up16(o_ipool + sizeof(int) * std::max<size_t>(1, ipool.size()));
+    const size_t o_jobs = up16(o_ipool + sizeof(int) * std::max<size_t>(1, ipool_size));
     const size_t in_bytes = up16(o_jobs + sizeof(PriorSplice) * n_jobs);
     const size_t dev_bytes = in_bytes + sizeof(double) * tail_doubles;
     if ((in_bytes + sizeof(double) * tail_doubles) / sizeof(double) >= ((size_t)1 << 31)) { batch_free(b); set_error("batch too large (data pool offsets are 32-bit)"); return TCV_ERR_TOO_LARGE; }
     double *h_dpool = (double *)host_staging_acquire(in_bytes);
     if (!h_dpool) { batch_free(b); set_error("hipHostMalloc (upload staging) failed"); return TCV_ERR_HIP; }
+    const auto t_dedup = std::chrono::steady_clock::now();
     {
         const int nth = host_op.threads(std::min(n, 16));
         std::vector<int> rcs(n, TCV_OK);
@@ -732,8 +797,11 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
                 rcs[w] = pack_problem_data(*problems[w], b->packed[w], nullptr, h_dpool + b->packed[w].win.dbase);
                 if (rcs[w] != TCV_OK && msgs[t].empty()) msgs[t] = tcv_last_error();
             }
+            for (size_t q = (size_t)t; q < plan_src.size(); q += (size_t)nth)      // the plans straight into the upload buffer
+                std::memcpy((char *)h_dpool + o_ipool + sizeof(int) * (size_t)b->plan_base[q], plan_src[q].first, sizeof(int) * plan_src[q].second);
         };
         tcv::parallel_run(nth, work);
+        for (int w = 0; w < n; w++) { b->packed[w].ints.clear(); b->packed[w].ints.shrink_to_fit(); }
         for (int w = 0; w < n; w++) if (rcs[w] != TCV_OK) { host_staging_release(h_dpool); batch_free(b); if (!msgs[w % nth].empty()) set_error(msgs[w % nth]); return rcs[w]; }
         for (int w : splice_win) {      // the prior region of the window: in the tail, addressed relative to the window's own slice
             Packed &pk = b->packed[w];
@@ -746,7 +814,7 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
         for (int w = 0; w < n; w++) b->wins.push_back(b->packed[w].win);
     }
     const auto t_packed = std::chrono::steady_clock::now();
-    b->plan_bytes = 4.0 * ipool.size();
+    b->plan_bytes = 4.0 * ipool_size;
     b->state_stride = (max_state + 1) & ~1;
     b->delta_stride = (max_nl + 1) & ~1;
     b->lds_bytes = max_lds;
@@ -792,7 +860,6 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
         std::memcpy(hb + o_win, b->wins.data(), sizeof(WinHdr) * (size_t)n);
         std::memcpy(hb + o_plans, b->plans.data(), sizeof(PlanHdr) * b->plans.size());
         std::memcpy(hb + o_pbase, b->plan_base.data(), sizeof(long long) * b->plan_base.size());
-        if (!ipool.empty()) std::memcpy(hb + o_ipool, ipool.data(), sizeof(int) * ipool.size());
         PriorSplice *hj = (PriorSplice *)(hb + o_jobs);
         for (size_t q = 0; q < splice_win.size(); q++) {
             const int w = splice_win[q];
@@ -819,7 +886,10 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
         char *db = (char *)b->d_input;
         b->d_dpool = (double *)db; b->d_win = (WinHdr *)(db + o_win); b->d_plans = (PlanHdr *)(db + o_plans);
         b->d_plan_base = (long long *)(db + o_pbase); b->d_ipool = (int *)(db + o_ipool);
-        if (n_jobs > 0) {      // behind the upload on its stream; the sources are results of calls their handles synchronised
+        if (n_jobs > 0) {      // behind the upload on its stream; a source whose producer did not wait for its kernel carries an event
+            for (int w : splice_imu_win)
+                for (size_t f = 0; f < problems[w]->imu.size(); f++)
+                    if (const int rcw = problems[w]->imu[f].dev->dev->wait_ready(ust)) { bail(); return rcw; }
             const int rcs = tcv::launch_prior_splice((const PriorSplice *)(db + o_jobs), (int)n_jobs, b->d_dpool, ust);
             if (rcs != TCV_OK) { bail(); return rcs; }
         }
@@ -851,6 +921,7 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
     }
     host_staging_release(h_dpool);
     h_dpool = nullptr;
+    tcv::flush_deferred(ust);      // (this thread just waited for its stream)
     if (e0 != hipSuccess) { batch_free(b); return hip_fail(e0, "upload of the batch"); }
     e0 = hipEventCreate(&b->ev0);
     if (e0 == hipSuccess) e0 = hipEventCreate(&b->ev1);
@@ -859,6 +930,7 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
     if (getenv("TCV_DEBUG_PACK")) {
         const auto t_end = std::chrono::steady_clock::now();
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) { return std::chrono::duration<double, std::milli>(c - a).count(); };
+        fprintf(stderr, "[batch_create] n %d: plans %.3f ms, plan pool + staging %.3f ms, data %.3f ms\n", n, ms(t_begin, t_plans), ms(t_plans, t_dedup), ms(t_dedup, t_packed));
         fprintf(stderr, "[batch_create] n %d: pack %.3f ms, marg attach %.3f ms, blob + upload issue + splice %.3f ms, allocations %.3f ms, memsets + sync %.3f ms (%d splice jobs, %.1f KB up)\n", n,
                 ms(t_begin, t_packed), ms(t_packed, t_marg), ms(t_marg, t_issue), ms(t_issue, t_alloc), ms(t_alloc, t_up), (int)n_jobs, in_bytes / 1024.0);
         (void)t_end;

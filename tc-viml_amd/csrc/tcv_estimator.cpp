@@ -21,6 +21,8 @@
 
 #include "../../include/tcv_estimator.h"
 namespace tcv { hipStream_t util_stream(); }      // (tcv_capi.hip: the calling thread's utility stream)
+#include <functional>
+#include "tcv_packed.h"      // parallel_run, HostOp: the persistent host worker threads of the packer
 
 namespace tcv { void set_error(const std::string &s); }
 
@@ -643,27 +645,18 @@ extern "C" int tcv_estimator_begin_frame(tcv_estimator *e, int n_imu, const doub
 // 0 pre-integration, 1 association + triangulation + window, 2 problem construction, 3 batch_create (pack + H2D), 4 kernels (launch to
 // sync), 5 downloads (states, summaries, priors), 6 apply / prior chaining, 7 calls
 // Process-wide state of tcv_estimators_optimize, shared by host threads that drive estimators on the same or on different GPUs: the
-// profile accumulators and the two launch streams of every device (created once per device, kept for the life of the process).
+// profile accumulators.
 namespace {
 std::mutex g_mu;
 double g_prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-std::map<int, std::array<hipStream_t, 2>> g_dev_streams;
 void prof_add(int slot, double v) { std::lock_guard<std::mutex> g(g_mu); g_prof[slot] += v; }
-// the two non-blocking streams of the calling thread's current device; {null, null} (the default stream: sequential, still correct) if
-// they cannot be created
-std::array<hipStream_t, 2> device_streams() {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    std::lock_guard<std::mutex> g(g_mu);
-    auto it = g_dev_streams.find(dev);
-    if (it != g_dev_streams.end()) return it->second;
-    std::array<hipStream_t, 2> st = {nullptr, nullptr};
-    if (hipStreamCreateWithFlags(&st[0], hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&st[1], hipStreamNonBlocking) != hipSuccess) {
-        if (st[0]) (void)hipStreamDestroy(st[0]);
-        st = {nullptr, nullptr};
-    }
-    g_dev_streams.emplace(dev, st);
-    return st;
+// per-estimator host work of a lock-step frame (association bookkeeping, triangulation, window and problem construction) on the packer's
+// persistent worker threads: the estimators are independent objects, every task touches its own
+void for_each_estimator(int n, const std::function<void(int)> &fn) {
+    tcv::HostOp op;
+    const int nth = op.threads(n);
+    if (nth <= 1) { for (int i = 0; i < n; i++) fn(i); return; }
+    tcv::parallel_run(nth, [&](int t) { for (int i = t; i < n; i += nth) fn(i); });
 }
 }  // namespace
 static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -674,7 +667,6 @@ extern "C" int tcv_estimators_profile(double *out8) {
     return TCV_OK;
 }
 
-enum { DEVICE_STATE_MIN_WINDOWS = 32 };      // estimators per lock-step call from which priors / pre-integrations stay on the device (see below)
 extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
     if (!es || n <= 0) return TCV_ERR_INVALID;
     double t_mark = now_s();
@@ -704,8 +696,9 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
             const double noise[4] = {c.acc_n, c.gyr_n, c.acc_w, c.gyr_w};
             if (samples.empty()) samples.push_back(0.0);
             // pre_integrations[] stay on the device (the reference keeps them alive between frames, too): a handle per buffer, sum_dt on the
-            // host.  TCV_EST_HOST_PREINT=1: round 3's round trip (3.7 KB down per buffer, 2.3 KB up per factor and window), same bits
-            if (getenv("TCV_EST_HOST_PREINT") || (n < DEVICE_STATE_MIN_WINDOWS && !getenv("TCV_EST_DEVICE_STATE"))) {
+            // host; nobody waits for the kernel (tcv_preintegrate_device).  TCV_EST_HOST_PREINT=1: round 3's round trip (3.7 KB down per buffer,
+            // 2.3 KB up per factor and window), same bits
+            if (getenv("TCV_EST_HOST_PREINT") || getenv("TCV_EST_HOST_STATE")) {
                 std::vector<tcv_imu_preintegration> out(who.size());
                 const int rc = tcv_preintegrate((int)who.size(), first.data(), count.data(), samples.data(), (int)samples.size() / 7, init.data(), noise, out.data());
                 if (rc != TCV_OK) return rc;
@@ -728,6 +721,8 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
     lap(0);
     // solveOdometry up to the solver call: association, triangulation, vector2double + graph
     {
+        static const bool dbg1 = getenv("TCV_DEBUG_EST") != nullptr;      // developer: where this lap goes
+        const double ta0 = now_s();
         std::vector<AssocJob> jobs(n);
         std::vector<tcv_match_lines_args> calls;
         for (int i = 0; i < n; i++)
@@ -736,13 +731,15 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
                 if (rc != TCV_OK) return rc;
                 if (jobs[i].call) calls.push_back(jobs[i].args);
             }
+        const double ta1 = now_s();
         if (!calls.empty()) { const int rc = tcv_match_lines_batch((int)calls.size(), calls.data()); if (rc != TCV_OK) return rc; }
-        for (int i = 0; i < n; i++) {
+        if (dbg1) fprintf(stderr, "[est] n %d: association prepare %.3f ms, device round trip (%d calls) %.3f ms\n", n, 1e3 * (ta1 - ta0), (int)calls.size(), 1e3 * (now_s() - ta1));
+        for_each_estimator(n, [&](int i) {
             tcv_estimator *e = es[i];
             if (e->assoc) assoc_finish(e, jobs[i]);
             triangulate(e);
             build_window(e);
-        }
+        });
     }
     lap(1);
     // One device batch per frame: the windows that marginalise (MARGIN_OLD, or MARGIN_SECOND_NEW with para_Pose[WINDOW_SIZE - 1] in the prior,
@@ -772,16 +769,12 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
         int rc = TCV_OK;
     };
     Group G[2];
-    // (tcv_batch_create uploads asynchronously on the calling thread's utility stream and waits for THAT stream before it returns: the
-    // batch is complete on the device before any kernel is launched on these non-blocking streams)
-    std::array<hipStream_t, 2> g_streams = device_streams();
-    static const bool one_stream = getenv("TCV_EST_ONE_STREAM") != nullptr;      // tuning experiment: both batches of a frame on one stream
-    if (one_stream) g_streams[1] = g_streams[0];
-    // tuning experiment TCV_EST_STREAM_MODE=2: both batches on the CALLING THREAD's utility stream (the stream its uploads, splices and
-    // downloads use anyway): one stream per host thread instead of two shared ones plus one per thread -- with the runtime's four hardware
-    // queues, five streams share queues, and a small copy of one thread can end up queued behind the other thread's 2 ms solve kernel
-    static const int stream_mode = getenv("TCV_EST_STREAM_MODE") ? atoi(getenv("TCV_EST_STREAM_MODE")) : 0;
-    if (stream_mode == 2) { g_streams[0] = g_streams[1] = tcv::util_stream(); }
+    // Every kernel of the frame goes on the CALLING THREAD's utility stream -- the stream tcv_batch_create's uploads, the device-to-device
+    // splices and the downloads of this thread use anyway: host threads that drive their own estimators overlap on the device (a stream pair
+    // shared by the threads of a device, as until round 4, serialises their kernels: 8 streams on 4 host threads 1 000 against 2 400 windows/s),
+    // and with one stream per thread no small copy of one thread waits behind another thread's 2 ms solve kernel on a shared hardware queue.
+    // (TCV_EST_TWO_BATCHES: the two batches of a frame then run one after the other.)
+    hipStream_t g_streams[2] = {tcv::util_stream(), tcv::util_stream()};
     int rc_all = TCV_OK;
     for (int group = 1; group >= 0; group--) {
         Group &g = G[group];
@@ -789,17 +782,23 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
         if (g.idx.empty()) continue;
         const int nb = (int)g.idx.size();
         g.P.assign(nb, nullptr); g.M.assign(nb, nullptr); g.drops.assign(nb, nullptr); g.ndrop.assign(nb, 0);
-        for (int k = 0; k < nb && g.rc == TCV_OK; k++) {
-            tcv_estimator *e = es[g.idx[k]];
-            tcv_window_desc d;
-            fill_desc(e, d, false, e->marg_flag);
-            g.rc = tcv_problem_from_window(&d, &g.P[k]);
-            if (g.rc == TCV_OK && g.dm[k]) {
-                build_marg(e, e->marg_flag);
-                fill_desc(e, d, true, e->marg_flag);
-                g.rc = tcv_problem_from_window(&d, &g.M[k]);
-                g.drops[k] = e->m_drop.data(); g.ndrop[k] = (int)e->m_drop.size();
-            }
+        {
+            std::vector<int> rcs(nb, TCV_OK);
+            std::vector<std::string> msgs(nb);
+            for_each_estimator(nb, [&](int k) {      // (the error text is per thread: a worker's is carried over)
+                tcv_estimator *e = es[g.idx[k]];
+                tcv_window_desc d;
+                fill_desc(e, d, false, e->marg_flag);
+                rcs[k] = tcv_problem_from_window(&d, &g.P[k]);
+                if (rcs[k] == TCV_OK && g.dm[k]) {
+                    build_marg(e, e->marg_flag);
+                    fill_desc(e, d, true, e->marg_flag);
+                    rcs[k] = tcv_problem_from_window(&d, &g.M[k]);
+                    g.drops[k] = e->m_drop.data(); g.ndrop[k] = (int)e->m_drop.size();
+                }
+                if (rcs[k] != TCV_OK) msgs[k] = tcv_last_error();
+            });
+            for (int k = 0; k < nb && g.rc == TCV_OK; k++) if (rcs[k] != TCV_OK) { g.rc = rcs[k]; tcv::set_error(msgs[k]); }
         }
         lap(2);
         if (g.rc == TCV_OK) g.rc = tcv_batch_create(&g.b, g.P.data(), g.any_marg ? g.M.data() : nullptr, g.any_marg ? g.drops.data() : nullptr, g.any_marg ? g.ndrop.data() : nullptr, nb);
@@ -836,12 +835,10 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
         // last_marginalization_info stays on the device (estimator.h:176-177: the reference keeps it alive between frames, too): the new
         // priors are handles on the batch's result buffer, the next frame's tcv_batch_create splices them device-to-device.
         // TCV_EST_HOST_PRIORS=1: round 3's host round trip (62 KB down, 46 KB up per window), the A/B partner -- same bits
-        // Which way is faster depends on the batch: from a few dozen windows per frame the device-resident hand-over wins (512-window passes:
-        // 171 K against 117 K windows/s); a handful of windows per frame is latency-bound, and there the extra small commands on the
-        // thread's utility stream end up queued behind the OTHER host thread's 2 ms solve kernel when five streams share the runtime's four
-        // hardware queues (8 streams on 2 host threads: 1 420 against 1 920 windows/s; GPU_MAX_HW_QUEUES=8: 1 740 against 1 710).
-        // TCV_EST_DEVICE_STATE=1 / TCV_EST_HOST_PRIORS=1 force one or the other.
-        const bool host_priors = getenv("TCV_EST_HOST_PRIORS") != nullptr || (n < DEVICE_STATE_MIN_WINDOWS && !getenv("TCV_EST_DEVICE_STATE"));
+        // Faster at every batch size once every host thread launches on its own stream (512-window passes: 171 K against 117 K windows/s; eight
+        // replay streams on two host threads: 2 370 - 2 480 against 2 250 - 2 280 windows/s).  TCV_EST_HOST_STATE=1 (both) / TCV_EST_HOST_PRIORS=1 /
+        // TCV_EST_HOST_PREINT=1 take the host round trip.
+        const bool host_priors = getenv("TCV_EST_HOST_PRIORS") != nullptr || getenv("TCV_EST_HOST_STATE") != nullptr;
         bool have_dev = false;
         if (g.rc == TCV_OK && g.any_marg && !host_priors) have_dev = tcv_batch_get_priors_device(g.b, g.newp.data(), nb) == TCV_OK;      // (a window that failed: the per-window path below says which)
         if (g.rc == TCV_OK && g.any_marg && !have_dev) g.rc = tcv_batch_download_priors_compact(g.b);
@@ -849,20 +846,29 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
         if (g.rc == TCV_OK)
             for (int k = 0; k < nb; k++)      // ceres::Solve's FAILURE (no valid step / a cooperative group that timed out): the window's states are not applied
                 if (g.sum[k].termination == 5 || !(g.sum[k].final_cost == g.sum[k].final_cost)) { g.est_rc[k] = TCV_ERR_NUMERIC; g.est_msg = "solver failure (no valid step, NaN cost or workgroup time-out)"; }
-        if (g.rc == TCV_OK && g.any_marg)
-            for (int k = 0; k < nb; k++) {
+        if (g.rc == TCV_OK && g.any_marg) {
+            std::vector<std::string> msgs(nb);
+            int cur_dev = 0;
+            (void)hipGetDevice(&cur_dev);
+            for_each_estimator(nb, [&](int k) {
                 // a window whose marginalisation did not converge (TCV_ERR_NUMERIC) fails alone: the other estimators of the lock-step
                 // batch are applied, this one reports the failure from tcv_estimator_finish_frame
-                if (g.est_rc[k] != TCV_OK) { if (g.newp[k]) { tcv_prior_destroy(g.newp[k]); g.newp[k] = nullptr; } continue; }
-                if (have_dev || !g.dm[k]) continue;
-                g.est_rc[k] = tcv_batch_get_prior(g.b, k, &g.newp[k]);
-                if (g.est_rc[k] != TCV_OK && g.est_rc[k] != TCV_ERR_NUMERIC) { g.rc = g.est_rc[k]; break; }
-                if (g.est_rc[k] != TCV_OK) g.est_msg = tcv_last_error();
+                if (g.est_rc[k] != TCV_OK) { if (g.newp[k]) { tcv_prior_destroy(g.newp[k]); g.newp[k] = nullptr; } return; }
+                if (have_dev || !g.dm[k]) return;
+                (void)hipSetDevice(cur_dev);      // (a worker thread's current device is its own: the fallback copy of a window must see the batch's)
+                g.est_rc[k] = tcv_batch_get_prior(g.b, k, &g.newp[k]);      // (host path: the window's prior out of the downloaded blob)
+                if (g.est_rc[k] != TCV_OK) msgs[k] = tcv_last_error();
+            });
+            for (int k = 0; k < nb; k++) {
+                if (g.est_rc[k] == TCV_OK || msgs[k].empty()) continue;
+                if (g.est_rc[k] != TCV_ERR_NUMERIC) { g.rc = g.est_rc[k]; tcv::set_error(msgs[k]); break; }
+                g.est_msg = msgs[k];
             }
+        }
         const double td3 = now_s();
         if (g.b) tcv_batch_destroy(g.b);
         const double td4 = now_s();
-        for (int k = 0; k < nb; k++) { if (g.P[k]) tcv_problem_destroy(g.P[k]); if (g.M[k]) tcv_problem_destroy(g.M[k]); }
+        for_each_estimator(nb, [&](int k) { if (g.P[k]) tcv_problem_destroy(g.P[k]); if (g.M[k]) tcv_problem_destroy(g.M[k]); });
         if (dbg_dl) fprintf(stderr, "[est] group %d n %d: states %.3f ms, summaries %.3f ms, priors %.3f ms, batch destroy %.3f ms, problems destroy %.3f ms\n", group, nb,
                             1e3 * (td1 - td0), 1e3 * (td2 - td1), 1e3 * (td3 - td2), 1e3 * (td4 - td3), 1e3 * (now_s() - td4));
         if (g.rc != TCV_OK && rc_all == TCV_OK) rc_all = g.rc;

@@ -20,6 +20,11 @@ namespace tcv {
 struct DevBlob {
     void *p = nullptr;
     int dev = 0;
+    // non-null: recorded behind the commands that fill the blob, by a producer that did not wait for them (tcv_preintegrate_device): a
+    // consumer on another stream waits for it (wait_ready), a host reader synchronises it
+    hipEvent_t ready = nullptr;
+    int wait_ready(hipStream_t consumer) const;      // TCV_OK or TCV_ERR_HIP
+    int sync_ready() const;
     ~DevBlob();
 };
 }  // namespace tcv
@@ -82,6 +87,7 @@ struct Packed {
     std::vector<int> ints;
     std::vector<double> doubles;
     WinHdr win;
+    unsigned long long plan_hash = 0;   // of hdr + plan ints (tcv_batch_create: structure de-duplication without copying 200 KB keys)
     int dev_imu_doubles = 0;         // > 0: every IMU factor of the window is device-resident: n_imu x 287 doubles in the device-only tail (WinHdr::d_imu points there)
     int dev_prior_doubles = 0;       // > 0: the window's prior is device-resident: doubles of its J0 | r0 | x0 region, which lives in the batch's
                                      // device-only tail (not in the uploaded slice) and is filled by the splice kernel of tcv_batch_create
@@ -198,6 +204,9 @@ int pack_problem_data(const tcv_problem &p, Packed &out, const double *imu_sqrt,
 // pinned host staging buffers for uploads / downloads, recycled through a small per-process pool (hipHostMalloc costs milliseconds)
 void *host_staging_acquire(size_t bytes);
 void host_staging_release(void *p);
+// buffers of commands left in flight on the calling thread's stream `st`: released at the thread's next wait on it (tcv_capi.hip)
+void defer_release(void *host_staging, void *dev_buf, hipStream_t st);
+void flush_deferred(hipStream_t st);
 // a non-blocking stream of the calling thread on its current device, created on first use and kept: the one-shot entry points
 // (pre-integration, line association, gauge fix) launch there and wait for THAT stream, never for the device -- another host thread's
 // batches keep running (several estimator groups per GPU, bench.py --mode replay)

@@ -87,9 +87,20 @@ struct LineArgs {
     double *proj;               // n_det x 4
 };
 
+// The calls of a batch share two launches (FoV rows, then the matching): a table of the calls' arguments and the first block of every call
+// (n + 1 entries, ascending) sit in the uploaded blob; a block looks its call up.  Sixteen tiny launches back to back on one stream cost a
+// lock-step frame of eight estimators 0.58 ms, two cost 0.1.
+__device__ __forceinline__ int call_of_block(const int *first, int n, int blk) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (first[mid] <= blk) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+
 // UpdateLinesInFoV: one thread per (frame, map line)
-__global__ void lines_fov_kernel(LineArgs A) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void lines_fov_kernel(const LineArgs *tab, const int *first, int ncall) {
+    const int cidx = call_of_block(first, ncall, (int)blockIdx.x);
+    const LineArgs A = tab[cidx];
+    int i = ((int)blockIdx.x - first[cidx]) * blockDim.x + threadIdx.x;
     if (i >= (A.only_frame >= 0 ? A.n_map : A.n_frames * A.n_map)) return;
     if (A.only_frame >= 0) i += A.only_frame * A.n_map;
     const int f = i / A.n_map, j = i - f * A.n_map;
@@ -108,8 +119,10 @@ __global__ void lines_fov_kernel(LineArgs A) {
 }
 
 // LineCorrespondenceInFrame: one wavefront per detected line
-__global__ void __launch_bounds__(64) lines_match_kernel(LineArgs A) {
-    const int q = blockIdx.x, lane = threadIdx.x;
+__global__ void __launch_bounds__(64) lines_match_kernel(const LineArgs *tab, const int *first, int ncall) {
+    const int cidx = call_of_block(first, ncall, (int)blockIdx.x);
+    const LineArgs A = tab[cidx];
+    const int q = (int)blockIdx.x - first[cidx], lane = threadIdx.x;
     const int f = A.det_frame[q];
     const double *dv = A.det + 4 * (size_t)q;
     const L2 det = make_l2(dv[0], dv[1], dv[2], dv[3]);
@@ -225,6 +238,9 @@ extern "C" int tcv_match_lines_batch(int n, const tcv_match_lines_args *args) {
         L[c].o_err = up16(L[c].o_match + sizeof(int) * std::max(1, a.n_det));
         out_total = up16(L[c].o_err + sizeof(float) * 3 * std::max(1, a.n_det));
     }
+    // [.. inputs | argument table (LineArgs per call) | first FoV block per call (n + 1) | first matching block per call (n + 1)]
+    const size_t o_tab = in_total, o_ff = up16(o_tab + sizeof(LineArgs) * (size_t)n), o_mf = up16(o_ff + sizeof(int) * (size_t)(n + 1));
+    in_total = up16(o_mf + sizeof(int) * (size_t)(n + 1));
     if (int rc = device_ready()) return rc;
     const size_t total = in_total + fov_total + out_total;
     char *h = (char *)tcv::host_staging_acquire(total);
@@ -246,22 +262,36 @@ extern "C" int tcv_match_lines_batch(int n, const tcv_match_lines_args *args) {
         else std::memset(h + in_total + L[c].o_fov, 0, L[c].tot);
     }
     int rc = TCV_OK;
-    if (e == hipSuccess) { in_flight = true; e = hipMemcpyAsync(dv, h, in_total + fov_total, hipMemcpyHostToDevice, st); }
-    for (int c = 0; c < n && e == hipSuccess; c++) {
-        const tcv_match_lines_args &a = args[c];
-        double *dd = (double *)dv;
-        char *dout = dv + in_total + fov_total + L[c].o_out;
-        const int fov_frame = a.fov_given >= 2 ? a.fov_given - 2 : -1;      // this frame's row is computed here, the others are given
-        LineArgs A;
-        A.poses = dd + o_pose[c]; A.ex = dd + o_ex[c]; A.Rbw = dd + o_R[c]; A.Tbw = dd + o_T[c]; A.K = dd + o_K[c]; A.map = dd + o_map[c]; A.det = dd + o_dl[c];
-        A.det_frame = (int *)(dv + L[c].o_det); A.n_frames = a.n_frames; A.n_map = a.n_map; A.n_det = a.n_det; A.width = a.width; A.height = a.height; A.window_size = a.window_size;
-        A.angle_th = a.angle_th; A.overlap_th = a.overlap_th; A.in_fov = (unsigned char *)(dv + in_total + L[c].o_fov);
-        A.match = (int *)(dv + in_total + fov_total + L[c].o_match); A.err = (float *)(dv + in_total + fov_total + L[c].o_err);
-        A.proj = (double *)dout;
-        A.only_frame = fov_frame;
-        if (!a.fov_given) hipLaunchKernelGGL(lines_fov_kernel, dim3(((int)L[c].tot + 255) / 256), dim3(256), 0, st, A);
-        else if (fov_frame >= 0) hipLaunchKernelGGL(lines_fov_kernel, dim3((a.n_map + 255) / 256), dim3(256), 0, st, A);
-        if (a.n_det) hipLaunchKernelGGL(lines_match_kernel, dim3(a.n_det), dim3(64), 0, st, A);
+    int fov_blocks = 0, det_blocks = 0;
+    if (e == hipSuccess) {
+        LineArgs *tab = (LineArgs *)(h + o_tab);
+        int *ff = (int *)(h + o_ff), *mf = (int *)(h + o_mf);
+        for (int c = 0; c < n; c++) {
+            const tcv_match_lines_args &a = args[c];
+            double *dd = (double *)dv;
+            char *dout = dv + in_total + fov_total + L[c].o_out;
+            const int fov_frame = a.fov_given >= 2 ? a.fov_given - 2 : -1;      // this frame's row is computed here, the others are given
+            LineArgs A;
+            A.poses = dd + o_pose[c]; A.ex = dd + o_ex[c]; A.Rbw = dd + o_R[c]; A.Tbw = dd + o_T[c]; A.K = dd + o_K[c]; A.map = dd + o_map[c]; A.det = dd + o_dl[c];
+            A.det_frame = (int *)(dv + L[c].o_det); A.n_frames = a.n_frames; A.n_map = a.n_map; A.n_det = a.n_det; A.width = a.width; A.height = a.height; A.window_size = a.window_size;
+            A.angle_th = a.angle_th; A.overlap_th = a.overlap_th; A.in_fov = (unsigned char *)(dv + in_total + L[c].o_fov);
+            A.match = (int *)(dv + in_total + fov_total + L[c].o_match); A.err = (float *)(dv + in_total + fov_total + L[c].o_err);
+            A.proj = (double *)dout;
+            A.only_frame = fov_frame;
+            tab[c] = A;
+            ff[c] = fov_blocks; mf[c] = det_blocks;
+            if (!a.fov_given) fov_blocks += ((int)L[c].tot + 255) / 256;
+            else if (fov_frame >= 0) fov_blocks += (a.n_map + 255) / 256;
+            det_blocks += a.n_det;
+        }
+        ff[n] = fov_blocks; mf[n] = det_blocks;
+        in_flight = true;
+        e = hipMemcpyAsync(dv, h, in_total + fov_total, hipMemcpyHostToDevice, st);
+    }
+    if (e == hipSuccess) {
+        // (a call without blocks has first[c] == first[c + 1]: the search returns the LAST call whose first block is <= the block, i.e. the one that owns it)
+        if (fov_blocks > 0) hipLaunchKernelGGL(lines_fov_kernel, dim3(fov_blocks), dim3(256), 0, st, (const LineArgs *)(dv + o_tab), (const int *)(dv + o_ff), n);
+        if (det_blocks > 0) hipLaunchKernelGGL(lines_match_kernel, dim3(det_blocks), dim3(64), 0, st, (const LineArgs *)(dv + o_tab), (const int *)(dv + o_mf), n);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(h + in_total, dv + in_total, fov_total + out_total, hipMemcpyDeviceToHost, st);

@@ -2017,7 +2017,18 @@ int launch_prior_splice(const PriorSplice *d_jobs, int njobs, double *d_dpool, h
     if (e != hipSuccess) return hip_fail(e, "prior splice kernel launch");
     return TCV_OK;
 }
+int DevBlob::wait_ready(hipStream_t consumer) const {
+    if (!ready) return TCV_OK;
+    const hipError_t e = hipStreamWaitEvent(consumer, ready, 0);
+    return e == hipSuccess ? TCV_OK : hip_fail(e, "hipStreamWaitEvent (device-resident input)");
+}
+int DevBlob::sync_ready() const {
+    if (!ready) return TCV_OK;
+    const hipError_t e = hipEventSynchronize(ready);
+    return e == hipSuccess ? TCV_OK : hip_fail(e, "hipEventSynchronize (device-resident input)");
+}
 DevBlob::~DevBlob() {
+    if (ready) { (void)hipEventSynchronize(ready); (void)hipEventDestroy(ready); }      // (the buffer goes back to a pool: its producer must be done)
     if (!p) return;
     int cur = 0;
     const bool sw = hipGetDevice(&cur) == hipSuccess && cur != dev;

@@ -23,6 +23,7 @@ the first window starts from perturbed ground truth.  `run_many_native` drives t
 from __future__ import annotations
 
 import ctypes as C
+import time
 
 import numpy as np
 
@@ -817,6 +818,7 @@ class NativeLockstep:
             self.rngs.append(rng); self.outs.append(dict(t=[], p=[], q=[], v=[], log=[]))
         self.n_frames = max(len(st["t"]) for st in streams)
         self._frames = [dict() for _ in streams]      # per stream: frame -> the begin_frame arguments as C-contiguous arrays (prepare())
+        self.host_s = [0.0, 0.0, 0.0, 0]              # seconds in begin_frame x streams | tcv_estimators_optimize | stats + finish_frame x streams (incl. this harness); calls
         self._bias_sigma = bias_sigma
 
     def reset(self):
@@ -832,6 +834,7 @@ class NativeLockstep:
             self.tcv.check(L.tcv_estimator_set_biases(h, P(ba), P(bg)))
             self.rngs.append(rng); self.outs.append(dict(t=[], p=[], q=[], v=[], log=[]))
         self._frames = [dict() for _ in self.streams]
+        self.host_s = [0.0, 0.0, 0.0, 0]
 
     def prepare(self, k0: int = 0, k1: int = None):
         """converts the per-frame front-end records (dicts / lists of the simulated streams) of frames [k0, k1) into the contiguous arrays
@@ -864,6 +867,7 @@ class NativeLockstep:
     def step(self, k: int) -> int:
         tcv, L, P, f64, ip, vp = self.tcv, self.L, self._P, self._f64, self.ip, self.vp
         ready = []
+        t_a = time.perf_counter()
         for si, (st, h, rng) in enumerate(zip(self.streams, self.ests, self.rngs)):
             if k >= len(st["t"]):
                 continue
@@ -879,10 +883,14 @@ class NativeLockstep:
                                                   None if truth is None else P(truth), C.byref(rdy)))
             if rdy.value:
                 ready.append(si)
+        t_b = time.perf_counter()
+        self.host_s[0] += t_b - t_a
         if not ready:
             return 0
         arr = (vp * len(ready))(*[self.ests[si] for si in ready])
         tcv.check(L.tcv_estimators_optimize(arr, len(ready)))
+        t_c = time.perf_counter()
+        self.host_s[1] += t_c - t_b; self.host_s[3] += 1
         for si in ready:
             p3, q4, v3 = np.zeros(3), np.zeros(4), np.zeros(3)
             s = _EstimatorStats()
@@ -892,6 +900,7 @@ class NativeLockstep:
             o["t"].append(self.streams[si]["t"][k]); o["p"].append(p3); o["q"].append(q4); o["v"].append(v3)
             o["log"].append(dict(flag=s.marg_flag, n_landmarks=s.n_landmarks, n_proj=s.n_proj, n_line=s.n_line, n_line_obs=s.n_line_obs,
                                  iterations=s.iterations, final_cost=s.final_cost, prior_n=s.prior_n))
+        self.host_s[2] += time.perf_counter() - t_c
         return len(ready)
 
     def results(self):

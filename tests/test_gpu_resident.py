@@ -134,13 +134,12 @@ def test_native_estimator_with_device_resident_priors_matches_the_host_round_tri
     the same trajectories bit for bit, both marginalisation modes, association in the loop"""
     streams = [replay.simulate_stream(44, 30, max_features=30, associate=True),
                replay.simulate_stream_euroc("V2_02_medium", 30, start_s=1.0, max_features=40, max_lines=5, associate=True)]
-    os.environ["TCV_EST_DEVICE_STATE"] = "1"      # (a handful of estimators per call takes the host round trip by default, tcv_estimator.cpp)
     try:
         dev = replay.run_many_native(streams, num_iterations=8)
         os.environ["TCV_EST_HOST_PRIORS"] = "1"
         host = replay.run_many_native(streams, num_iterations=8)
     finally:
-        os.environ.pop("TCV_EST_HOST_PRIORS", None); os.environ.pop("TCV_EST_DEVICE_STATE", None)
+        os.environ.pop("TCV_EST_HOST_PRIORS", None)
     for a, c in zip(dev, host):
         assert len(a["t"]) == len(c["t"]) == 30 - replay.WINDOW_SIZE
         assert {l["flag"] for l in a["log"]} == {0, 1}
@@ -204,13 +203,12 @@ def test_native_estimator_with_device_resident_preintegrations_matches_the_host_
     them with every window: the same trajectories bit for bit (MARGIN_OLD shifts the handles, MARGIN_SECOND_NEW re-integrates a merged buffer)"""
     streams = [replay.simulate_stream(45, 30, max_features=30),
                replay.simulate_stream_euroc("V1_02_medium", 30, start_s=1.0, max_features=40, max_lines=5, associate=True)]
-    os.environ["TCV_EST_DEVICE_STATE"] = "1"
     try:
         dev = replay.run_many_native(streams, num_iterations=8)
         os.environ["TCV_EST_HOST_PREINT"] = "1"
         host = replay.run_many_native(streams, num_iterations=8)
     finally:
-        os.environ.pop("TCV_EST_HOST_PREINT", None); os.environ.pop("TCV_EST_DEVICE_STATE", None)
+        os.environ.pop("TCV_EST_HOST_PREINT", None)
     for a, c in zip(dev, host):
         assert len(a["t"]) == len(c["t"]) == 30 - replay.WINDOW_SIZE and {l["flag"] for l in a["log"]} == {0, 1}
         assert np.array_equal(a["p"], c["p"]) and np.array_equal(a["q"], c["q"]) and np.array_equal(a["v"], c["v"])
@@ -218,8 +216,7 @@ def test_native_estimator_with_device_resident_preintegrations_matches_the_host_
 
 def test_device_memory_returns_to_its_level_after_the_objects_are_gone(gpu):
     """tcv_device_memory_stats: batches, device-resident priors (they keep a batch's result buffer alive) and pre-integration handles give
-    every byte back when the last owner goes -- chains of frames through the batch API and through the native estimator (device-resident
-    state forced on) leave the allocator's live bytes / buffer count where they were"""
+    every byte back when the last owner goes -- chains of frames through the batch API and through the native estimator leave the allocator's live bytes / buffer count where they were"""
     import gc
     tcv = gpu
     B = 6
@@ -247,11 +244,7 @@ def test_device_memory_returns_to_its_level_after_the_objects_are_gone(gpu):
         z = np.zeros((acc.shape[0], 3))
         hd = tcv.preintegrate_device(acc, gyr, synth.DT_IMU, z, z, (synth.ACC_N, synth.GYR_N, synth.ACC_W, synth.GYR_W))
         del hd
-        os.environ["TCV_EST_DEVICE_STATE"] = "1"
-        try:
-            replay.run_many_native(streams, num_iterations=4)
-        finally:
-            os.environ.pop("TCV_EST_DEVICE_STATE", None)
+        replay.run_many_native(streams, num_iterations=4)
         gc.collect()
 
     cycle()
