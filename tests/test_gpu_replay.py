@@ -240,3 +240,30 @@ def test_full_length_euroc_replay_with_the_association_in_the_loop(gpu, seq):
     hip, d, a_hip, a_ref = _free_running(seq, "associate")
     assert d.max() < 1e-3
     assert abs(a_hip - a_ref) < 1e-4
+
+
+def test_host_threads_with_their_own_estimators_reproduce_the_single_thread_run(gpu):
+    """Every entry point issues its work on the calling thread's own stream (tcv_capi.hip util_stream; destroyed when the thread ends):
+    three host threads, each driving its own four estimators in lock step, run side by side on the device -- two generations of them, so
+    that the second one's streams are created after the first one's were given back -- and each reproduces the single-thread run bit
+    for bit (same batches, hence same plans and the same additions; only what else is on the device differs)."""
+    import threading
+    streams = [replay.simulate_stream(60 + s, 24, max_features=30) if s % 2 == 0 else
+               replay.simulate_stream_euroc("V1_03_difficult", 24, start_s=1.0 + s, max_features=40, max_lines=5, associate=True) for s in range(4)]
+    ref = replay.run_many_native(streams, num_iterations=6)
+    for generation in range(2):
+        out, err = [None] * 3, []
+
+        def work(i):
+            try:
+                out[i] = replay.run_many_native(streams, num_iterations=6)
+            except Exception as e:      # noqa: BLE001 (reported below, in the test's thread)
+                err.append(repr(e))
+
+        th = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+        [t.start() for t in th]; [t.join() for t in th]
+        assert not err, err
+        for res in out:
+            for a, c in zip(ref, res):
+                assert np.array_equal(a["p"], c["p"]) and np.array_equal(a["q"], c["q"]) and np.array_equal(a["v"], c["v"])
+                assert [l["iterations"] for l in a["log"]] == [l["iterations"] for l in c["log"]]
