@@ -935,8 +935,11 @@ __device__ __noinline__ __attribute__((disable_tail_calls)) bool sym_eig_tridiag
 
 #ifdef TCV_PROFILE
 #define MARG_MARK(id) do { const long long t_ = clock64(); if (tid == 0) out[MARG_OUT_X + MARG_MAX_X + 2 + (id)] += (double)(t_ - t_last); t_last = t_; } while (0)
+// parts of the projection phase on the chunked block path (slots 44..47: - | evaluation and chunk set-up | accumulation | landmark elimination)
+#define MARG_SUB(id) do { const long long t_ = clock64(); if (tid == 0) out[MARG_OUT_X + MARG_MAX_X + 44 + (id)] += (double)(t_ - t_sub); t_sub = t_; } while (0)
 #else
 #define MARG_MARK(id) do { } while (0)
+#define MARG_SUB(id) do { } while (0)
 #endif
 // Cholesky of a small Amm (m <= MREG) in registers and the forward substitutions behind it (marg_kernel, step 4): functions of their own,
 // so that their register arrays get registers (inlined into the kernel they were spilled: 263 instead of 123 spilled VGPRs, every access a
@@ -1249,10 +1252,16 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((disable_tail_calls)) _
         const int prs = with_td ? 21 : (int)PROJ_STRIDE, prr = with_td ? 43 : (int)PROJ_REC;
         const int njc = with_td ? 20 : 19;                    // Jacobian columns; logical column k lives at record column (k == 19 ? 20 : k)
         const bool cb_path = H.block_mode && H.cb_off >= 0;
+#ifdef TCV_PROFILE
+        long long t_sub = clock64();
+        if (tid == 0) for (int i = 0; i < 4; i++) out[MARG_OUT_X + MARG_MAX_X + 44 + i] = 0.0;
+#endif
+        MARG_SUB(0);
         for (int pc = 0; cb_path && pc < H.n_pchunk; pc++) {
             cst_i *pch = ip + H.o_pchunk + pc * 4;
             const int f0 = pch[0], fn = pch[1];
             lds_d *Cb = lds + H.cb_off, *hl = Cb + MARG_CB_LM * H.cb_stride, *glv = hl + MARG_CB_LM;
+            lds_i *ftab = (lds_i *)cvec;      // (the per-landmark vector of the factor-by-factor path below: unused on this path, 144 doubles >= 128 ints)
             const int cbs = H.cb_stride;
             for (int i = tid; i < MARG_CB_LM * cbs + 2 * MARG_CB_LM; i += MARG_NT) Cb[i] = 0.0;
             if (tid < fn) {
@@ -1265,8 +1274,19 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((disable_tail_calls)) _
                           pts, misc[3], r, GEN(rec), PROJ_STRIDE);
                 (void)loss_correct2(r, GEN(rec), 19, PROJ_STRIDE, misc[4]);
                 rec[19] = r[0]; rec[PROJ_STRIDE + 19] = r[1];
+                // where the factor's four blocks and its landmark go, for the accumulation below: one LDS word pair per factor (tangent offset + 1
+                // of the blocks, a byte each -- MARG_MAX_POS < 255 --, 0 = constant / dropped from this matrix; eliminated landmark's row of C + 1)
+                // instead of nine dependent loads from the plan per factor and thread (a 512-factor replay window: accumulation 497 K -> 352 K cycles,
+                // 0.59 -> 0.52 ms per marginalisation; what is left is the per-factor bookkeeping of 209 threads, not the loads: pre-evaluating all
+                // factors in one pass and walking the factors frame by frame were both measured and changed nothing)
+                unsigned wq = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) wq |= (unsigned)((blk[pf[k] * 5 + 2] + 1) & 255) << (8 * k);
+                ftab[2 * tid] = (int)wq;
+                ftab[2 * tid + 1] = ip[H.o_plm + f0 + tid] + 1;
             }
             __syncthreads();
+            MARG_SUB(1);
             {
                 // one thread per entry (ca >= cb, or cb = residual column) of the 19 x 20 factor record, all factors of the chunk in factor order,
                 // the running destination kept in a register while consecutive factors hit the same element.  Row 18 (the inverse depth) of a
@@ -1285,31 +1305,41 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((disable_tail_calls)) _
                     int prev = -1;
                     double accv = 0.0;
                     const int o_bv = (int)(bv - lds), o_cb = (int)(Cb - lds), o_hl = (int)(hl - lds), o_gl = (int)(glv - lds);
-                    for (int f = 0; f < fn; f++) {
-                        cst_i *pf = ip + H.o_proj + (f0 + f) * 4;
-                        const int l0 = blk[pf[0] * 5 + 2], l1 = blk[pf[1] * 5 + 2], l2 = blk[pf[2] * 5 + 2], l3 = blk[pf[3] * 5 + 2];
-                        const int lml = plm[f];
-                        const int la = ga == 0 ? l0 : (ga == 1 ? l1 : (ga == 2 ? l2 : l3));
-                        const int lb = gb == 0 ? l0 : (gb == 1 ? l1 : (gb == 2 ? l2 : l3));
-                        const lds_d *rec = stage + f * prr;
-                        const double sv = rec[ca] * rec[rb] + rec[prs + ca] * rec[prs + rb];
-                        int d = -1;
-                        if (ca == 18 && lml >= 0) {      // (18, column of a camera block) -> C, (18, 18) -> hll, (18, residual) -> gl
-                            if (cb < 18) { if (lb >= 0) d = o_cb + lml * cbs + lb + ob; }
-                            else d = (cb == 18 ? o_hl : o_gl) + lml;
-                        } else if (la >= 0 && (cb == 19 || lb >= 0)) d = cb == 19 ? o_bv + la + oa : pidx(la + oa, lb + ob);
-                        if (d < 0) continue;
-                        if (d != prev) {
-                            if (prev >= 0) lds[prev] = accv;
-                            accv = lds[d];
-                            prev = d;
+                    for (int fb = 0; fb < fn; fb += 4) {      // four factors' table words and record entries in flight, then their additions in factor order
+                        unsigned w4[4];
+                        int m4[4];
+                        double s4[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const int f = min(fb + u, fn - 1);
+                            const lds_d *rec = stage + f * prr;
+                            w4[u] = (unsigned)ftab[2 * f]; m4[u] = ftab[2 * f + 1];
+                            s4[u] = rec[ca] * rec[rb] + rec[prs + ca] * rec[prs + rb];
                         }
-                        accv += sv;
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            if (fb + u >= fn) break;
+                            const int lml = m4[u] - 1;
+                            const int la = (int)((w4[u] >> (8 * ga)) & 255u) - 1, lb = (int)((w4[u] >> (8 * gb)) & 255u) - 1;
+                            int d = -1;
+                            if (ca == 18 && lml >= 0) {      // (18, column of a camera block) -> C, (18, 18) -> hll, (18, residual) -> gl
+                                if (cb < 18) { if (lb >= 0) d = o_cb + lml * cbs + lb + ob; }
+                                else d = (cb == 18 ? o_hl : o_gl) + lml;
+                            } else if (la >= 0 && (cb == 19 || lb >= 0)) d = cb == 19 ? o_bv + la + oa : pidx(la + oa, lb + ob);
+                            if (d < 0) continue;
+                            if (d != prev) {
+                                if (prev >= 0) lds[prev] = accv;
+                                accv = lds[d];
+                                prev = d;
+                            }
+                            accv += s4[u];
+                        }
                     }
                     if (prev >= 0) lds[prev] = accv;
                 }
             }
             __syncthreads();
+            MARG_SUB(2);
             {
                 // A -= C' diag(1 / hll) C over the lower triangle (pseudo-inverse: a landmark without information, hll <= eps, contributes
                 // nothing), 16 x 16 tiles on the matrix cores, K = the chunk's landmarks; b -= C' diag(1 / hll) gl
@@ -1343,6 +1373,7 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((disable_tail_calls)) _
                 }
             }
             __syncthreads();
+            MARG_SUB(3);
         }
         for (int f0 = 0; !cb_path && f0 < H.n_proj; f0 += 64) {
             const int fn = min(64, H.n_proj - f0);
@@ -1910,6 +1941,11 @@ static int pack_marg(const tcv_problem &p, double *const *drop, int ndrop, const
         }
         if (!chunks.empty() || porder.empty()) {
             H.n_pchunk = (int)chunks.size() / 4;
+            if (getenv("TCV_DEBUG")) {
+                fprintf(stderr, "[tcv] marg plan: %d projection factors in %d chunks (factors, eliminated landmarks):", (int)porder.size(), H.n_pchunk);
+                for (size_t c = 0; c + 3 < chunks.size(); c += 4) fprintf(stderr, " (%d, %d)", chunks[c + 1], chunks[c + 2]);
+                fprintf(stderr, "\n");
+            }
             H.o_pchunk = imark(); I.insert(I.end(), chunks.begin(), chunks.end());
             H.o_plm = imark(); I.insert(I.end(), plm.begin(), plm.end());
             const int ne = n + (n & 1), npk = pos * (pos + 1) / 2, r1 = std::max(npk, ne * (ne + 1));
@@ -2281,6 +2317,8 @@ int tcv_marg_get_prior(tcv_batch *b, int window, tcv_prior **out) {
         const char *nm[12] = {"load", "prior", "imu", "proj", "eig_mm", "Z", "schur", "eig_rr", "out", "j_angle|chol_mm", "j_cols|barrier", "j_rows|subst_mm"};      // (9..11: Jacobi safety net, or the register Cholesky route of Amm)
         fprintf(stderr, "[tcv]   Amm: trace(Amm^-1) %.3e, of the unit-diagonal scaling %.3e\n", o[MARG_OUT_X + MARG_MAX_X + 40], o[MARG_OUT_X + MARG_MAX_X + 41]);
         for (int i = 0; i < 12; i++) fprintf(stderr, "[tcv]   %-7s %12.0f cycles\n", nm[i], o[MARG_OUT_X + MARG_MAX_X + 2 + i]);
+        fprintf(stderr, "[tcv]     proj, chunked block path: evaluation + chunk set-up %.0f | accumulation %.0f | landmark elimination %.0f cycles\n",
+                o[MARG_OUT_X + MARG_MAX_X + 45], o[MARG_OUT_X + MARG_MAX_X + 46], o[MARG_OUT_X + MARG_MAX_X + 47]);
         const char *en[6] = {"tridiag", "bisect", "vectors", "mgs", "backtr", "check"};
         for (int i = 0; i < 6; i++) fprintf(stderr, "[tcv]     eig_rr.%-8s %10.0f cycles\n", en[i], o[MARG_OUT_X + MARG_MAX_X + 14 + 8 + i]);
         fprintf(stderr, "[tcv]     tridiag steps (wave 0): part 1 %.0f | barrier %.0f | update m > 40 %.0f, m > 16 %.0f, m <= 16 %.0f | barrier %.0f cycles\n", o[MARG_OUT_X + MARG_MAX_X + 28], o[MARG_OUT_X + MARG_MAX_X + 29], o[MARG_OUT_X + MARG_MAX_X + 30], o[MARG_OUT_X + MARG_MAX_X + 31], o[MARG_OUT_X + MARG_MAX_X + 32], o[MARG_OUT_X + MARG_MAX_X + 33]);
