@@ -72,11 +72,15 @@ int tcv_estimator_begin_frame(tcv_estimator *e, int n_imu, const double *acc, co
  * applied, the call returns TCV_OK, and tcv_estimator_finish_frame of THAT estimator returns TCV_ERR_NUMERIC (reset it, like after
  * failureDetection).  Any other error (HIP, invalid input) fails the whole call and applies nothing.
  * Thread safety: estimators are independent objects; different host threads may drive different estimator lists, on the same or on
- * different devices (the launch streams are per device). */
+ * different devices (every call issues its copies and kernels on the calling thread's own stream: the threads overlap on the device). */
 int tcv_estimators_optimize(tcv_estimator *const *e, int n);
 /* failureDetection, the published state (Ps / Rs / Vs[WINDOW_SIZE], quaternion x y z w) and slideWindow.
  * TCV_ERR_NUMERIC: failure detection fired (the reference would reset the estimator). */
 int tcv_estimator_finish_frame(tcv_estimator *e, double P[3], double q_xyzw[4], double V[3]);
+/* tcv_estimator_finish_frame (and tcv_estimator_get_stats, taken before the window slides) for every estimator of a lock-step list, on
+ * the library's host worker threads: P 3 n, q_xyzw 4 n, V 3 n doubles, rc n ints (per estimator: what its own finish_frame returns),
+ * stats n records or NULL.  Returns TCV_OK when every estimator finished, else the first failure (its text in tcv_last_error). */
+int tcv_estimators_finish_frames(tcv_estimator *const *e, int n, double *P, double *q_xyzw, double *V, int *rc, tcv_estimator_stats *stats);
 /* Estimator::clearState() + setParameter() (estimator.cpp:126-189, :39-52; estimator_node.cpp:437-446 after a failure): drops the
  * window, the IMU buffers, every feature / line track, the marginalisation prior and the biases; configuration and line map stay.
  * "Reset it" above means this call (or destroy + create). */

@@ -921,6 +921,18 @@ extern "C" int tcv_estimator_finish_frame(tcv_estimator *e, double P[3], double 
     e->last_P = e->Ps[W]; e->have_last = true;
     return TCV_OK;
 }
+extern "C" int tcv_estimators_finish_frames(tcv_estimator *const *es, int n, double *P, double *q, double *V, int *rc, tcv_estimator_stats *stats) {
+    if (!es || n <= 0 || !P || !q || !V || !rc) return TCV_ERR_INVALID;
+    for (int i = 0; i < n; i++) for (int j = 0; j < i; j++) if (es[i] == es[j]) { tcv::set_error("estimators_finish_frames: the same estimator twice"); return TCV_ERR_INVALID; }
+    std::vector<std::string> msgs(n);
+    for_each_estimator(n, [&](int i) {
+        if (stats && es[i]) stats[i] = es[i]->stats;
+        rc[i] = tcv_estimator_finish_frame(es[i], P + 3 * i, q + 4 * i, V + 3 * i);
+        if (rc[i] != TCV_OK) msgs[i] = tcv_last_error();      // (the text is per thread)
+    });
+    for (int i = 0; i < n; i++) if (rc[i] != TCV_OK) { tcv::set_error(msgs[i]); return rc[i]; }
+    return TCV_OK;
+}
 extern "C" int tcv_estimator_get_stats(const tcv_estimator *e, tcv_estimator_stats *out) {
     if (!e || !out) return TCV_ERR_INVALID;
     *out = e->stats;

@@ -791,6 +791,7 @@ class NativeLockstep:
         L.tcv_estimator_begin_frame.argtypes = [vp, C.c_int, dp, dp, C.c_int, ip, dp, C.c_int, ip, dp, dp, ip]
         L.tcv_estimators_optimize.argtypes = [C.POINTER(vp), C.c_int]
         L.tcv_estimator_finish_frame.argtypes = [vp, dp, dp, dp]
+        L.tcv_estimators_finish_frames.argtypes = [C.POINTER(vp), C.c_int, dp, dp, dp, C.POINTER(C.c_int), C.POINTER(_EstimatorStats)]
         L.tcv_estimator_get_stats.argtypes = [vp, C.POINTER(_EstimatorStats)]
         if L.tcv_device_count() < 1:
             raise RuntimeError("the native estimator needs a HIP device: the product has no CPU path")
@@ -820,6 +821,8 @@ class NativeLockstep:
         self._frames = [dict() for _ in streams]      # per stream: frame -> the begin_frame arguments as C-contiguous arrays (prepare())
         self.host_s = [0.0, 0.0, 0.0, 0]              # seconds in begin_frame x streams | tcv_estimators_optimize | stats + finish_frame x streams (incl. this harness); calls
         self._bias_sigma = bias_sigma
+        self._raw = []
+        self._rdy = C.c_int()
 
     def reset(self):
         """tcv_estimator_reset on every estimator (Estimator::clearState + setParameter) and the replay's own bookkeeping back to frame 0:
@@ -835,6 +838,7 @@ class NativeLockstep:
             self.rngs.append(rng); self.outs.append(dict(t=[], p=[], q=[], v=[], log=[]))
         self._frames = [dict() for _ in self.streams]
         self.host_s = [0.0, 0.0, 0.0, 0]
+        self._raw = []
 
     def prepare(self, k0: int = 0, k1: int = None):
         """converts the per-frame front-end records (dicts / lists of the simulated streams) of frames [k0, k1) into the contiguous arrays
@@ -855,7 +859,11 @@ class NativeLockstep:
             lid = np.ascontiguousarray([a for a, _ in ln], dtype=np.int32); lv = f64(np.array([v for _, v in ln]).reshape(-1, 4))
         else:
             lid = np.zeros(len(ln), np.int32); lv = f64(np.array([np.concatenate(t3) for t3 in ln]).reshape(-1, 9))
-        return acc, gyr, ids, pv, len(ln), lid, lv
+        # the ctypes arguments of tcv_estimator_begin_frame, made once (the arrays ride along: they own the memory)
+        P, ip = self._P, self.ip
+        args = (0 if acc is None else acc.shape[0] - 1, None if acc is None else P(acc), None if gyr is None else P(gyr), len(ids), ids.ctypes.data_as(ip), P(pv),
+                len(ln), lid.ctypes.data_as(ip), P(lv))
+        return args, (acc, gyr, ids, pv, lid, lv)
 
     @staticmethod
     def _f64(a):
@@ -876,11 +884,9 @@ class NativeLockstep:
                 dth = rng.normal(size=3) * self.init_sigma[1]
                 truth = f64(np.concatenate([st["gt_p"][k] + rng.normal(size=3) * self.init_sigma[0], (st["gt_R"][k] @ deltaQ_R(dth)).reshape(9),
                                             st["gt_v"][k] + rng.normal(size=3) * self.init_sigma[2]]))
-            acc, gyr, ids, pv, n_ln, lid, lv = self._frames[si].pop(k, None) or self._frame_args(st, k)
-            rdy = C.c_int()
-            tcv.check(L.tcv_estimator_begin_frame(h, 0 if acc is None else acc.shape[0] - 1, None if acc is None else P(acc), None if gyr is None else P(gyr),
-                                                  len(ids), ids.ctypes.data_as(ip), P(pv), n_ln, lid.ctypes.data_as(ip), P(lv),
-                                                  None if truth is None else P(truth), C.byref(rdy)))
+            args, keep = self._frames[si].pop(k, None) or self._frame_args(st, k)
+            rdy = self._rdy
+            tcv.check(L.tcv_estimator_begin_frame(h, *args, None if truth is None else P(truth), C.byref(rdy)))
             if rdy.value:
                 ready.append(si)
         t_b = time.perf_counter()
@@ -891,19 +897,27 @@ class NativeLockstep:
         tcv.check(L.tcv_estimators_optimize(arr, len(ready)))
         t_c = time.perf_counter()
         self.host_s[1] += t_c - t_b; self.host_s[3] += 1
-        for si in ready:
-            p3, q4, v3 = np.zeros(3), np.zeros(4), np.zeros(3)
-            s = _EstimatorStats()
-            tcv.check(L.tcv_estimator_get_stats(self.ests[si], C.byref(s)))
-            tcv.check(L.tcv_estimator_finish_frame(self.ests[si], P(p3), P(q4), P(v3)))
-            o = self.outs[si]
-            o["t"].append(self.streams[si]["t"][k]); o["p"].append(p3); o["q"].append(q4); o["v"].append(v3)
-            o["log"].append(dict(flag=s.marg_flag, n_landmarks=s.n_landmarks, n_proj=s.n_proj, n_line=s.n_line, n_line_obs=s.n_line_obs,
-                                 iterations=s.iterations, final_cost=s.final_cost, prior_n=s.prior_n))
+        nr = len(ready)
+        pa, qa, va = np.zeros((nr, 3)), np.zeros((nr, 4)), np.zeros((nr, 3))
+        rcs = (C.c_int * nr)()
+        sts = (_EstimatorStats * nr)()
+        tcv.check(L.tcv_estimators_finish_frames(arr, nr, P(pa), P(qa), P(va), rcs, sts))
+        self._raw.append((k, ready, pa, qa, va, sts))      # (turned into the per-stream records by results(): nothing of that in the frame loop)
         self.host_s[2] += time.perf_counter() - t_c
         return len(ready)
 
+    def _flush_raw(self):
+        for k, ready, pa, qa, va, sts in self._raw:
+            for j, si in enumerate(ready):
+                s = sts[j]
+                o = self.outs[si]
+                o["t"].append(self.streams[si]["t"][k]); o["p"].append(pa[j]); o["q"].append(qa[j]); o["v"].append(va[j])
+                o["log"].append(dict(flag=s.marg_flag, n_landmarks=s.n_landmarks, n_proj=s.n_proj, n_line=s.n_line, n_line_obs=s.n_line_obs,
+                                     iterations=s.iterations, final_cost=s.final_cost, prior_n=s.prior_n))
+        self._raw = []
+
     def results(self):
+        self._flush_raw()
         return [dict(t=np.array(o["t"]), p=np.array(o["p"]), q=np.array(o["q"]), v=np.array(o["v"]), log=o["log"]) for o in self.outs]
 
     def close(self):
