@@ -506,9 +506,11 @@ void slide_window(tcv_estimator *e) {
         const V3 back_P0 = e->Ps[0];
         for (int i = 0; i < W; i++) {      // the swaps of :2131-2153 followed by the copy of slot W-1 into W
             e->Ps[i] = e->Ps[i + 1]; e->Rs[i] = e->Rs[i + 1]; e->Vs[i] = e->Vs[i + 1]; e->Bas[i] = e->Bas[i + 1]; e->Bgs[i] = e->Bgs[i + 1];
-            e->bufs[i] = e->bufs[i + 1]; e->pre[i] = e->pre[i + 1]; e->preh[i] = e->preh[i + 1]; e->pre_valid[i] = e->pre_valid[i + 1];
-            e->line_obs[i] = e->line_obs[i + 1];                       // WorldLinesInFOV[W] = WorldLinesInFOV[W-1] (:2158): slot W keeps its content
-            e->fov[i] = e->fov[i + 1];
+            // (moves, not copies: this runs once per frame and estimator on the host's critical path; slot W is refilled right below --
+            // except the line bookkeeping, whose slot W keeps its content: WorldLinesInFOV[W] = WorldLinesInFOV[W-1], :2158)
+            e->bufs[i] = std::move(e->bufs[i + 1]); e->pre[i] = e->pre[i + 1]; e->preh[i] = std::move(e->preh[i + 1]); e->pre_valid[i] = e->pre_valid[i + 1];
+            if (i + 1 < W) { e->line_obs[i] = std::move(e->line_obs[i + 1]); e->fov[i] = std::move(e->fov[i + 1]); }
+            else { e->line_obs[i] = e->line_obs[i + 1]; e->fov[i] = e->fov[i + 1]; }
         }
         e->pre_valid[W] = false;
         new_buf(e, W);
@@ -517,20 +519,20 @@ void slide_window(tcv_estimator *e) {
         const V3 P0 = add(back_P0, mv(back_R0, e->tic)), P1 = add(e->Ps[0], mv(e->Rs[0], e->tic));
         std::vector<Feature> kept;
         for (auto &f : e->features) {
-            if (f.start != 0) { f.start -= 1; kept.push_back(f); continue; }
+            if (f.start != 0) { f.start -= 1; kept.push_back(std::move(f)); continue; }
             const V3 uv_i = f.obs.front();
             f.obs.erase(f.obs.begin());
             if (f.obs.size() < 2) continue;
             const V3 pts_j = mv(tr(R1), sub(add(mv(R0, scl(uv_i, f.depth)), P0), P1));
             f.depth = pts_j[2] > 0 ? pts_j[2] : e->cfg.init_depth;
-            kept.push_back(f);
+            kept.push_back(std::move(f));
         }
         e->features.swap(kept);
         std::vector<LineFeature> keptl;                // line features: feature_manager.cpp:598-614
         for (auto &lf : e->linefeatures) {
-            if (lf.start != 0) { lf.start -= 1; keptl.push_back(lf); continue; }
+            if (lf.start != 0) { lf.start -= 1; keptl.push_back(std::move(lf)); continue; }
             lf.obs.erase(lf.obs.begin());
-            if (!lf.obs.empty()) keptl.push_back(lf);
+            if (!lf.obs.empty()) keptl.push_back(std::move(lf));
         }
         e->linefeatures.swap(keptl);
     } else {
@@ -544,24 +546,24 @@ void slide_window(tcv_estimator *e) {
         e->pre_valid[W] = false;
         std::vector<Feature> kept;                     // slideWindowNew -> removeFront(frame_count) (feature_manager.cpp:655-675)
         for (auto &f : e->features) {
-            if (f.start == W) { f.start -= 1; kept.push_back(f); continue; }
-            if (f.end() < W - 1) { kept.push_back(f); continue; }
+            if (f.start == W) { f.start -= 1; kept.push_back(std::move(f)); continue; }
+            if (f.end() < W - 1) { kept.push_back(std::move(f)); continue; }
             f.obs.erase(f.obs.begin() + (W - 1 - f.start));
-            if (!f.obs.empty()) kept.push_back(f);
+            if (!f.obs.empty()) kept.push_back(std::move(f));
         }
         e->features.swap(kept);
         std::vector<LineFeature> keptl;                // feature_manager.cpp:677-695
         for (auto &lf : e->linefeatures) {
-            if (lf.start == W) { lf.start -= 1; keptl.push_back(lf); continue; }
-            if (lf.start + (int)lf.obs.size() - 1 < W - 1) { keptl.push_back(lf); continue; }
+            if (lf.start == W) { lf.start -= 1; keptl.push_back(std::move(lf)); continue; }
+            if (lf.start + (int)lf.obs.size() - 1 < W - 1) { keptl.push_back(std::move(lf)); continue; }
             lf.obs.erase(lf.obs.begin() + (W - 1 - lf.start));
-            if (!lf.obs.empty()) keptl.push_back(lf);
+            if (!lf.obs.empty()) keptl.push_back(std::move(lf));
         }
         e->linefeatures.swap(keptl);
         e->fov[W - 1] = e->fov[W];
     }
     std::vector<Feature> ok;                           // removeFailures (:399-408)
-    for (auto &f : e->features) if (f.solve_flag != 2) ok.push_back(f);
+    for (auto &f : e->features) if (f.solve_flag != 2) ok.push_back(std::move(f));
     e->features.swap(ok);
 }
 
