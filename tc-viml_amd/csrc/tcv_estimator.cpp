@@ -676,6 +676,25 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
     prof_add(7, 1);
     for (int i = 0; i < n; i++) if (!es[i] || es[i]->phase != 1) { tcv::set_error("estimators_optimize: an estimator has no full window waiting (begin_frame must report ready)"); return TCV_ERR_INVALID; }
     for (int i = 0; i < n; i++) for (int j = 0; j < i; j++) if (es[i] == es[j]) { tcv::set_error("estimators_optimize: the same estimator twice"); return TCV_ERR_INVALID; }
+    // solveOdometry up to the solver call: association, triangulation, vector2double + graph.  The association's device round trip comes
+    // first and the pre-integration of the new IMU buffers is issued behind it (nobody on the host waits for that kernel: its results are
+    // spliced into the batch on the device), so the kernel runs while the host builds the windows and problems.
+    std::vector<AssocJob> jobs(n);
+    {
+        static const bool dbg1 = getenv("TCV_DEBUG_EST") != nullptr;      // developer: where this lap goes
+        const double ta0 = now_s();
+        std::vector<tcv_match_lines_args> calls;
+        for (int i = 0; i < n; i++)
+            if (es[i]->assoc) {
+                const int rc = assoc_prepare(es[i], jobs[i]);
+                if (rc != TCV_OK) return rc;
+                if (jobs[i].call) calls.push_back(jobs[i].args);
+            }
+        const double ta1 = now_s();
+        if (!calls.empty()) { const int rc = tcv_match_lines_batch((int)calls.size(), calls.data()); if (rc != TCV_OK) return rc; }
+        if (dbg1) fprintf(stderr, "[est] n %d: association prepare %.3f ms, device round trip (%d calls) %.3f ms\n", n, 1e3 * (ta1 - ta0), (int)calls.size(), 1e3 * (now_s() - ta1));
+    }
+    lap(1);
     // one pre-integration call for every stale IMU buffer of every estimator
     {
         std::vector<int> first, count;
@@ -721,21 +740,7 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
         }
     }
     lap(0);
-    // solveOdometry up to the solver call: association, triangulation, vector2double + graph
     {
-        static const bool dbg1 = getenv("TCV_DEBUG_EST") != nullptr;      // developer: where this lap goes
-        const double ta0 = now_s();
-        std::vector<AssocJob> jobs(n);
-        std::vector<tcv_match_lines_args> calls;
-        for (int i = 0; i < n; i++)
-            if (es[i]->assoc) {
-                const int rc = assoc_prepare(es[i], jobs[i]);
-                if (rc != TCV_OK) return rc;
-                if (jobs[i].call) calls.push_back(jobs[i].args);
-            }
-        const double ta1 = now_s();
-        if (!calls.empty()) { const int rc = tcv_match_lines_batch((int)calls.size(), calls.data()); if (rc != TCV_OK) return rc; }
-        if (dbg1) fprintf(stderr, "[est] n %d: association prepare %.3f ms, device round trip (%d calls) %.3f ms\n", n, 1e3 * (ta1 - ta0), (int)calls.size(), 1e3 * (now_s() - ta1));
         for_each_estimator(n, [&](int i) {
             tcv_estimator *e = es[i];
             if (e->assoc) assoc_finish(e, jobs[i]);
