@@ -68,8 +68,11 @@ struct MargHdr {
     // block mode, chunked path (proj_disjoint, no Td): the factors come in chunks of whole landmarks (<= 64 factors, <= MARG_CB_LM eliminated
     // landmarks); per chunk the landmarks' couplings C (landmark x camera column), diagonals and gradients are accumulated next to the
     // camera-camera J'J, and A -= C diag(1/hll) C', b -= C diag(1/hll) gl is ONE rank-16 update on the matrix cores
-    int n_pchunk, o_pchunk;   // n_pchunk x 4: first factor, factors, eliminated landmarks, 0
+    int n_pchunk, o_pchunk;   // n_pchunk x 4: first factor, factors, eliminated landmarks, offset of the chunk's group table behind o_pgrp
     int o_plm;                // n_proj: index of the factor's landmark among the chunk's eliminated landmarks (-1: its landmark is a regular column)
+    int o_pgrp, pad_pgrp;     // per chunk: [frames nfr | landmark runs nlg | 1 if every factor shares its first pose and its extrinsic block | length |
+                              //  (first, count) x nfr into the list at the end | (first factor, count) x nlg | the chunk's factors grouped by their
+                              //  second pose, factor order inside a group]: the task decomposition of the accumulation (marg_kernel)
     int cb_off, cb_stride;    // LDS offset (doubles) and row stride of C: [MARG_CB_LM x cb_stride | hll MARG_CB_LM | gl MARG_CB_LM]; cb_off < 0: old path
     int td_blk;       // >= 0: the point factors are ProjectionTdFactors on this block (d_proj then holds 14 doubles per factor)
     int sqrt_src;        // >= 0: index of the (single) IMU factor among the solve problem's IMU factors: its sqrt_info was computed by the solve
@@ -1257,6 +1260,26 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((disable_tail_calls)) _
         if (tid == 0) for (int i = 0; i < 4; i++) out[MARG_OUT_X + MARG_MAX_X + 44 + i] = 0.0;
 #endif
         MARG_SUB(0);
+        // chunked block path: tables in the eigen-solver's vector area (idle until the eigen-decomposition): the current chunk's group table,
+        // the entries of the factor record by class (see the accumulation below)
+        typedef __attribute__((address_space(3))) unsigned char lds_b;
+        lds_i *gtab = (lds_i *)sm, *ncls = gtab + 336;
+        lds_b *listS = (lds_b *)(gtab + 340), *listJ = listS + 96, *listL = listJ + 104;
+        if (cb_path) {
+            if (tid < 3) ncls[tid] = 0;
+            __syncthreads();
+            const int ntri = 19 * 20 / 2;
+            if (tid < ntri + 19) {
+                int ca, cb;
+                if (tid < ntri) { ca = (int)((sqrt(8.0 * (double)tid + 1.0) - 1.0) * 0.5); while ((ca + 1) * (ca + 2) / 2 <= tid) ca++; while (ca * (ca + 1) / 2 > tid) ca--; cb = tid - ca * (ca + 1) / 2; }
+                else { ca = tid - ntri; cb = 19; }
+                const int ga = ca < 18 ? ca / 6 : 3, gb = cb < 18 ? cb / 6 : 3;
+                const int cls = ca == 18 ? 2 : ((ga == 1 || (cb < 18 && gb == 1)) ? 1 : 0);
+                const int at = atomicAdd((int *)(ncls + cls), 1);      // (which thread later takes which entry does not matter: entries are independent)
+                (cls == 0 ? listS : (cls == 1 ? listJ : listL))[at] = (unsigned char)tid;
+            }
+            __syncthreads();
+        }
         for (int pc = 0; cb_path && pc < H.n_pchunk; pc++) {
             cst_i *pch = ip + H.o_pchunk + pc * 4;
             const int f0 = pch[0], fn = pch[1];
@@ -1264,6 +1287,11 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((disable_tail_calls)) _
             lds_i *ftab = (lds_i *)cvec;      // (the per-landmark vector of the factor-by-factor path below: unused on this path, 144 doubles >= 128 ints)
             const int cbs = H.cb_stride;
             for (int i = tid; i < MARG_CB_LM * cbs + 2 * MARG_CB_LM; i += MARG_NT) Cb[i] = 0.0;
+            {      // the chunk's group table (MargHdr::o_pgrp) into LDS
+                cst_i *gsrc = ip + H.o_pgrp + pch[3];
+                const int glen = gsrc[3];
+                for (int i = tid; i < glen; i += MARG_NT) gtab[i] = gsrc[i];
+            }
             if (tid < fn) {
                 cst_i *pf = ip + H.o_proj + (f0 + tid) * 4;
                 lds_d *rec = stage + tid * prr;
@@ -1288,52 +1316,94 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((disable_tail_calls)) _
             __syncthreads();
             MARG_SUB(1);
             {
-                // one thread per entry (ca >= cb, or cb = residual column) of the 19 x 20 factor record, all factors of the chunk in factor order,
-                // the running destination kept in a register while consecutive factors hit the same element.  Row 18 (the inverse depth) of a
-                // factor whose landmark is eliminated goes to the landmark's row of C / hll / gl instead of A.
-                const int ntri = 19 * 20 / 2;
-                cst_i *plm = ip + H.o_plm + f0;
-                for (int t = tid; t < ntri + 19; t += MARG_NT) {
+                // Accumulation of the chunk's J'J / J'r: every element of A, b, C, hll, gl receives its terms in factor order (the sums of the
+                // factor-by-factor path, bit for bit), but the elements are independent, and which factors reach an element is known from the
+                // plan: entries of the 19 x 20 factor record (ca >= cb, or cb = the residual column) come in three classes --
+                //   S  both columns in the first pose / the extrinsic: one element for every factor of the chunk when they all share those blocks
+                //      (MARGIN_OLD: the host frame is frame 0) -- a plain sum over the chunk;
+                //   J  a column in the second pose: the element depends on that pose only -- one task per (frame, entry) over the frame's factors;
+                //   L  the inverse-depth row: one task per (landmark, entry) over the landmark's factors.
+                // ~1 300 short tasks on all eight wavefronts instead of 209 threads walking every factor (a 512-factor replay window: 352 K ->
+                // ~90 K cycles of the marginalisation's 1.2 M).
+                const int nfr = gtab[0], nlg = gtab[1], uniform = gtab[2];
+                cst_i *dummy_plm = ip + H.o_plm + f0; (void)dummy_plm;
+                const lds_i *fr = gtab + 4, *lg = fr + 2 * nfr, *fl = lg + 2 * nlg;
+                const int nS = ncls[0], nJ = ncls[1], nL = ncls[2];
+                const int secS = (nS + 63) & ~63, secJ = (nfr * nJ + 63) & ~63, secL = nlg * nL;
+                const int o_bv = (int)(bv - lds), o_cb = (int)(Cb - lds), o_hl = (int)(hl - lds), o_gl = (int)(glv - lds);
+                for (int task = tid; task < secS + secJ + secL; task += MARG_NT) {
+                    int t, kind, g0 = 0, cnt = fn;
+                    if (task < secS) { if (task >= nS) continue; kind = 0; t = listS[task]; }
+                    else if (task < secS + secJ) {
+                        const int q = task - secS;
+                        if (q >= nfr * nJ) continue;
+                        const int sfr = q / nJ;
+                        kind = 1; t = listJ[q - sfr * nJ]; g0 = fr[2 * sfr]; cnt = fr[2 * sfr + 1];
+                    } else {
+                        const int q = task - secS - secJ, sl = q / nL;
+                        kind = 2; t = listL[q - sl * nL]; g0 = lg[2 * sl]; cnt = lg[2 * sl + 1];
+                    }
+                    const int ntri = 19 * 20 / 2;
                     int ca, cb;
                     if (t < ntri) { ca = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5); while ((ca + 1) * (ca + 2) / 2 <= t) ca++; while (ca * (ca + 1) / 2 > t) ca--; cb = t - ca * (ca + 1) / 2; }
                     else { ca = t - ntri; cb = 19; }
                     const int ga = ca < 18 ? ca / 6 : 3, oa = ca < 18 ? ca % 6 : 0;
                     const int gb = cb < 18 ? cb / 6 : 3, ob = cb < 18 ? cb % 6 : 0;
                     const int rb = cb == 19 ? 19 : cb;      // record column of cb (19 = the residual)
-                    // destinations as offsets from the workgroup's LDS base (>= 0; the packed A starts at offset 0, so a null pointer cannot
-                    // stand for "none")
+                    // destination of factor f's term as an offset from the workgroup's LDS base (>= 0; -1: a constant / dropped block).  Row 18
+                    // (the inverse depth) of a factor whose landmark is eliminated goes to the landmark's row of C / hll / gl instead of A.
+                    auto dest = [&](int f) -> int {
+                        const unsigned w = (unsigned)ftab[2 * f];
+                        const int lml = ftab[2 * f + 1] - 1;
+                        const int la = (int)((w >> (8 * ga)) & 255u) - 1, lb = (int)((w >> (8 * gb)) & 255u) - 1;
+                        if (ca == 18 && lml >= 0) {      // (18, column of a camera block) -> C, (18, 18) -> hll, (18, residual) -> gl
+                            if (cb < 18) return lb >= 0 ? o_cb + lml * cbs + lb + ob : -1;
+                            return (cb == 18 ? o_hl : o_gl) + lml;
+                        }
+                        if (la >= 0 && (cb == 19 || lb >= 0)) return cb == 19 ? o_bv + la + oa : pidx(la + oa, lb + ob);
+                        return -1;
+                    };
+                    // With the first pose and the extrinsic shared by the chunk's factors a task has ONE element -- the frame's (J), the landmark's
+                    // (L, except its couplings to the second pose: one element per factor) or the chunk's (S): a plain sum, four record
+                    // entries in flight
+                    if (uniform && !(kind == 2 && cb < 18 && gb == 1)) {
+                        const int d = dest(kind == 1 ? fl[g0] : g0);
+                        if (d < 0) continue;
+                        double accv = lds[d];
+                        int k = 0;
+                        for (; k + 3 < cnt; k += 4) {
+                            double s4[4];
+#pragma unroll
+                            for (int u = 0; u < 4; u++) {
+                                const int f = kind == 1 ? fl[g0 + k + u] : g0 + k + u;
+                                const lds_d *rec = stage + f * prr;
+                                s4[u] = rec[ca] * rec[rb] + rec[prs + ca] * rec[prs + rb];
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; u++) accv += s4[u];
+                        }
+                        for (; k < cnt; k++) {
+                            const int f = kind == 1 ? fl[g0 + k] : g0 + k;
+                            const lds_d *rec = stage + f * prr;
+                            accv += rec[ca] * rec[rb] + rec[prs + ca] * rec[prs + rb];
+                        }
+                        lds[d] = accv;
+                        continue;
+                    }
                     int prev = -1;
                     double accv = 0.0;
-                    const int o_bv = (int)(bv - lds), o_cb = (int)(Cb - lds), o_hl = (int)(hl - lds), o_gl = (int)(glv - lds);
-                    for (int fb = 0; fb < fn; fb += 4) {      // four factors' table words and record entries in flight, then their additions in factor order
-                        unsigned w4[4];
-                        int m4[4];
-                        double s4[4];
-#pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            const int f = min(fb + u, fn - 1);
-                            const lds_d *rec = stage + f * prr;
-                            w4[u] = (unsigned)ftab[2 * f]; m4[u] = ftab[2 * f + 1];
-                            s4[u] = rec[ca] * rec[rb] + rec[prs + ca] * rec[prs + rb];
+                    for (int k = 0; k < cnt; k++) {
+                        const int f = kind == 1 ? fl[g0 + k] : g0 + k;
+                        const lds_d *rec = stage + f * prr;
+                        const double sv = rec[ca] * rec[rb] + rec[prs + ca] * rec[prs + rb];
+                        const int d = dest(f);
+                        if (d < 0) continue;
+                        if (d != prev) {
+                            if (prev >= 0) lds[prev] = accv;
+                            accv = lds[d];
+                            prev = d;
                         }
-#pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            if (fb + u >= fn) break;
-                            const int lml = m4[u] - 1;
-                            const int la = (int)((w4[u] >> (8 * ga)) & 255u) - 1, lb = (int)((w4[u] >> (8 * gb)) & 255u) - 1;
-                            int d = -1;
-                            if (ca == 18 && lml >= 0) {      // (18, column of a camera block) -> C, (18, 18) -> hll, (18, residual) -> gl
-                                if (cb < 18) { if (lb >= 0) d = o_cb + lml * cbs + lb + ob; }
-                                else d = (cb == 18 ? o_hl : o_gl) + lml;
-                            } else if (la >= 0 && (cb == 19 || lb >= 0)) d = cb == 19 ? o_bv + la + oa : pidx(la + oa, lb + ob);
-                            if (d < 0) continue;
-                            if (d != prev) {
-                                if (prev >= 0) lds[prev] = accv;
-                                accv = lds[d];
-                                prev = d;
-                            }
-                            accv += s4[u];
-                        }
+                        accv += sv;
                     }
                     if (prev >= 0) lds[prev] = accv;
                 }
@@ -1946,8 +2016,35 @@ static int pack_marg(const tcv_problem &p, double *const *drop, int ndrop, const
                 for (size_t c = 0; c + 3 < chunks.size(); c += 4) fprintf(stderr, " (%d, %d)", chunks[c + 1], chunks[c + 2]);
                 fprintf(stderr, "\n");
             }
+            std::vector<int> pgrp;
+            for (size_t c = 0; c + 3 < chunks.size(); c += 4) {
+                const int c0 = chunks[c], cn = chunks[c + 1];
+                chunks[c + 3] = (int)pgrp.size();
+                std::vector<int> keys;
+                std::vector<std::vector<int>> members;
+                std::vector<int> runs;
+                bool uniform = true;
+                for (int q = 0; q < cn; q++) {
+                    const ProjFac &f = p.proj[porder[c0 + q]];
+                    size_t k = 0;
+                    while (k < keys.size() && keys[k] != f.b[1]) k++;
+                    if (k == keys.size()) { keys.push_back(f.b[1]); members.emplace_back(); }
+                    members[k].push_back(q);
+                    if (q == 0 || p.proj[porder[c0 + q - 1]].b[3] != f.b[3]) { runs.push_back(q); runs.push_back(0); }
+                    runs.back()++;
+                    if (f.b[0] != p.proj[porder[c0]].b[0] || f.b[2] != p.proj[porder[c0]].b[2]) uniform = false;
+                }
+                const size_t h0 = pgrp.size();
+                pgrp.push_back((int)keys.size()); pgrp.push_back((int)runs.size() / 2); pgrp.push_back(uniform ? 1 : 0); pgrp.push_back(0);
+                int off = 0;
+                for (auto &mbr : members) { pgrp.push_back(off); pgrp.push_back((int)mbr.size()); off += (int)mbr.size(); }
+                pgrp.insert(pgrp.end(), runs.begin(), runs.end());
+                for (auto &mbr : members) pgrp.insert(pgrp.end(), mbr.begin(), mbr.end());
+                pgrp[h0 + 3] = (int)(pgrp.size() - h0);
+            }
             H.o_pchunk = imark(); I.insert(I.end(), chunks.begin(), chunks.end());
             H.o_plm = imark(); I.insert(I.end(), plm.begin(), plm.end());
+            H.o_pgrp = imark(); I.insert(I.end(), pgrp.begin(), pgrp.end());
             const int ne = n + (n & 1), npk = pos * (pos + 1) / 2, r1 = std::max(npk, ne * (ne + 1));
             H.cb_stride = (pos + 15) & ~15;
             const int need = MARG_CB_LM * H.cb_stride + 2 * MARG_CB_LM;
