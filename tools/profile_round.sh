@@ -59,3 +59,7 @@ out = {"sq": summarise("sq"), "sq2": summarise("sq2"), "mfma": summarise("sq3")}
 json.dump(out, open(f"{O}/sq_counters.json", "w"), indent=1)
 PY
 ls $O
+# round 4: kernel durations of a lock-step replay frame, thread sweep of the replay
+bash $R/tools/dev_replay_kernel_trace.sh > /dev/null 2>&1; cp $R/gpurun_out/replay_kernel_stats.csv $O/replay_kernel_stats.csv 2>/dev/null
+THREADS="1 2 4" DEVSTATE="1" bash $R/tools/dev_replay_thread_sweep.sh > $O/replay_thread_sweep.txt 2>&1
+GPU_MAX_HW_QUEUES=8 QUEUES=8 THREADS="4" DEVSTATE="1" bash $R/tools/dev_replay_thread_sweep.sh >> $O/replay_thread_sweep.txt 2>&1
