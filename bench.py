@@ -517,14 +517,14 @@ class ReplayEngine:
             for k in range(k0, k0 + steps):
                 counts[g] += self.ls[g].step(k)
 
-        if len(self.ls) == 1:
-            work(0)
-        else:
-            th = [threading.Thread(target=work, args=(g,)) for g in range(len(self.ls))]
-            for t in th:
-                t.start()
-            for t in th:
-                t.join()
+        # group 0 on the calling thread (its stream exists already), the others on threads of their own: one stream fewer on the runtime's
+        # four hardware queues -- two host threads that share a queue wait for each other's solve kernels
+        th = [threading.Thread(target=work, args=(g,)) for g in range(1, len(self.ls))]
+        for t in th:
+            t.start()
+        work(0)
+        for t in th:
+            t.join()
         self.k += steps
         return sum(counts)
 
