@@ -266,6 +266,13 @@ int tcv_batch_download_priors_compact(tcv_batch *b);
  * bits.  Per window only two ints come down (status, number of thresholded rows).  tcv_prior_export materialises the numbers on the host
  * on demand (export / checkpoint); tcv_prior_export_schur is not available.  n = the batch size; on an error out[] is all NULL. */
 int tcv_batch_get_priors_device(tcv_batch *b, tcv_prior **out, int n);
+/* The same without waiting for the marginalisation (tcv_batch_marginalize may still be running): takes the marginalisation off the host's
+ * critical path -- estimator.cpp publishes the frame's pose after it (:2027-2044 run inside optimization()), here the next frame's host work
+ * overlaps it.  The handles are ordered behind the producing kernel on the device (an event the next tcv_batch_create waits for on its
+ * stream); the number of thresholded rows, which sizes the host layout of a prior, is read on the device.  What the host does not know
+ * yet is whether the marginalisation succeeded: ask tcv_batch_marg_status (it waits) before trusting anything computed on such a prior --
+ * a failed one (status != 0, or a NaN) poisons the consumer's window, it does not crash it.  Keep the batch alive until then. */
+int tcv_batch_get_priors_device_async(tcv_batch *b, tcv_prior **out, int n);
 /* 1 if the prior's numbers live on the device (tcv_batch_get_priors_device) and have not been materialised on the host, else 0 */
 int tcv_prior_is_device_resident(const tcv_prior *pr);
 /* replaces the prior of the problem's marginalisation factor by one with the SAME layout (n, keep_block_size / idx), keeping the
@@ -277,7 +284,8 @@ int tcv_problem_set_marginalization_prior(tcv_problem *p, const tcv_prior *prior
 int tcv_problems_set_marginalization_prior(tcv_problem *const *problems, tcv_prior *const *priors, int n);
 void tcv_priors_destroy(tcv_prior *const *priors, int n);
 /* per-window status of the last marginalisation: 0 ok, 1 an eigen-solver hit its sweep cap, 2 result produced by the
- * cyclic-Jacobi safety net (the tridiagonal eigen-solver failed its orthogonality / trace self-check) */
+ * cyclic-Jacobi safety net (the tridiagonal eigen-solver failed its orthogonality / trace self-check), -1 not run, -2 a NaN in the
+ * result (a prior made from it is unusable).  Waits for the batch's work in flight. */
 int tcv_batch_marg_status(tcv_batch *b, int *out, int n);
 /* tangent step of iteration 1 (needs record_first_step): free camera blocks in the order they were
  * added (local size each), then the inverse depths in order of first use.  Parity/debug surface. */

@@ -868,6 +868,7 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
             std::memset(&J, 0, sizeof J);
             J.src = pr->d_block; J.dst = b->packed[w].win.dbase + b->packed[w].win.d_prior;
             J.n = pr->n; J.k0 = b->packed[w].win.prior_k0; J.nblk = (int)pr->size.size();
+            J.k0_src = b->packed[w].prior_k0_deferred ? pr->d_k0 : nullptr; J.win = w;
             for (int k = 0; k < J.nblk; k++) { J.goff[k] = pr->x_goff[k]; J.size[k] = pr->size[k]; }
         }
         {
@@ -890,7 +891,9 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
             for (int w : splice_imu_win)
                 for (size_t f = 0; f < problems[w]->imu.size(); f++)
                     if (const int rcw = problems[w]->imu[f].dev->dev->wait_ready(ust)) { bail(); return rcw; }
-            const int rcs = tcv::launch_prior_splice((const PriorSplice *)(db + o_jobs), (int)n_jobs, b->d_dpool, ust);
+            for (int w : splice_win)
+                if (const int rcw = problems[w]->prior[0].prior->dev->wait_ready(ust)) { bail(); return rcw; }
+            const int rcs = tcv::launch_prior_splice((const PriorSplice *)(db + o_jobs), (int)n_jobs, b->d_dpool, (void *)b->d_win, ust);
             if (rcs != TCV_OK) { bail(); return rcs; }
         }
     }
@@ -1132,11 +1135,16 @@ extern "C" int tcv_batch_get_priors(tcv_batch *b, tcv_prior **out, int n) {
         }
     return TCV_OK;
 }
+extern "C" int tcv_batch_get_priors_device_async(tcv_batch *b, tcv_prior **out, int n) {
+    if (!b || !out || n != b->n) { set_error("batch_get_priors_device_async: n must be the batch size"); return TCV_ERR_INVALID; }
+    for (int k = 0; k < n; k++) out[k] = nullptr;
+    return tcv_marg_get_priors_device(b, out, n, true);      // (no wait: the marginalisation may still be running)
+}
 extern "C" int tcv_batch_get_priors_device(tcv_batch *b, tcv_prior **out, int n) {
     if (!b || !out || n != b->n) { set_error("batch_get_priors_device: n must be the batch size"); return TCV_ERR_INVALID; }
     for (int k = 0; k < n; k++) out[k] = nullptr;
     if (b->pending) if (int rc = tcv_batch_synchronize(b)) return rc;
-    return tcv_marg_get_priors_device(b, out, n);
+    return tcv_marg_get_priors_device(b, out, n, false);
 }
 extern "C" int tcv_problem_set_marginalization_prior(tcv_problem *p, const tcv_prior *prior) {
     if (!p || !prior || p->prior.size() != 1) { set_error("set_marginalization_prior: the problem must hold exactly one marginalisation factor"); return TCV_ERR_INVALID; }

@@ -43,6 +43,9 @@ struct tcv_prior {
     std::shared_ptr<tcv::DevBlob> dev;
     const double *d_block = nullptr;  // this window's result block in that buffer (layout: tcv_marg.hip MARG_OUT_*)
     int k0 = 0;                       // leading rows of J0 | r0 that are exact zeros (tcv_packed.h prior_zero_rows, computed on the device)
+                                      // -1: not known on the host (tcv_batch_get_priors_device_async: the marginalisation may still be running) --
+    const int *d_k0 = nullptr;        //     the consumer reads it on the device, behind the producer's event (dev->ready): [status | k0] of this window
+    const int *d_status = nullptr;
     std::vector<int> x_goff;          // per kept block: offset of its values in the result block's state region
     mutable bool host = true;
     mutable std::mutex mu;            // materialisation (several packing threads may ask for it at once)
@@ -89,6 +92,7 @@ struct Packed {
     WinHdr win;
     unsigned long long plan_hash = 0;   // of hdr + plan ints (tcv_batch_create: structure de-duplication without copying 200 KB keys)
     int dev_imu_doubles = 0;         // > 0: every IMU factor of the window is device-resident: n_imu x 287 doubles in the device-only tail (WinHdr::d_imu points there)
+    bool prior_k0_deferred = false;  // the prior's zero-row count is read on the device (tcv_prior::k0 < 0): WinHdr::prior_k0 is patched by the splice kernel
     int dev_prior_doubles = 0;       // > 0: the window's prior is device-resident: doubles of its J0 | r0 | x0 region, which lives in the batch's
                                      // device-only tail (not in the uploaded slice) and is filled by the splice kernel of tcv_batch_create
     // host-side maps for download
@@ -173,16 +177,20 @@ int tcv_marg_run(tcv_batch *b, void *stream);
 int tcv_marg_get_prior(tcv_batch *b, int window, tcv_prior **out);
 void tcv_marg_elapsed(tcv_batch *b);
 int tcv_marg_download(tcv_batch *b, int compact);
-int tcv_marg_get_priors_device(tcv_batch *b, tcv_prior **out, int n);
+int tcv_marg_get_priors_device(tcv_batch *b, tcv_prior **out, int n, bool nowait);
 bool tcv_marg_has_problem(const tcv_batch *b, int window);      // false: marg_problems[window] was NULL
 // copies device-resident priors into a batch's data pool (one job per window that holds one): launched by tcv_batch_create on the stream
 // of its upload, behind it
 namespace tcv {
 // kind 0: a prior (src = the result block of its window, tcv_marg.hip MARG_OUT_*); kind 1: an IMU factor's constants (src = the
 // pre-integration kernel's output record; n, k0, nblk unused)
-struct PriorSplice { const double *src; long long dst; int n, k0, nblk, kind; int goff[32], size[32]; };
+struct PriorSplice {
+    const double *src; long long dst; int n, k0, nblk, kind; int goff[32], size[32];
+    const int *k0_src;      // non-null: k0 is read here, on the device ([status | k0] of the producing marginalisation), and written to the window header `win`
+    int win, pad;
+};
 enum { PRIOR_SPLICE_MAX_BLOCKS = 32 };
-int launch_prior_splice(const PriorSplice *d_jobs, int njobs, double *d_dpool, hipStream_t st);
+int launch_prior_splice(const PriorSplice *d_jobs, int njobs, double *d_dpool, void *d_win_headers, hipStream_t st);
 }  // namespace tcv
 
 namespace tcv {

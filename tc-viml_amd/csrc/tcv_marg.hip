@@ -87,6 +87,7 @@ struct MargArgs {
     const double *solve_state;   // may be null
     const double *solve_sqrt;    // may be null: per window 225 doubles, the solve's sqrt_info of IMU factor sqrt_src
     const double *solve_dpool;   // the solve batch's data pool (MargHdr::prior_abs)
+    const void *solve_win;       // its window headers (WinHdr): prior_k0 of a prior whose zero-row count was only known on the device (MargHdr::prior_k0 < 0)
     double *out;                 // per window MARG_OUT_STRIDE
     int *out_status;             // per window: 0 ok
     double *scratch;             // per workgroup MARG_SCR_STRIDE
@@ -1064,7 +1065,7 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((disable_tail_calls)) _
         // ---- prior factor (MarginalizationFactor::Evaluate, :335-384): the first contribution to A and b
         bool a_zeroed = false;
         if (H.prior_n > 0) {
-            const int np = H.prior_n, k0 = H.prior_k0, nr = np - k0;      // J0 | r0 without their leading zero rows: nr x np, column-major
+            const int np = H.prior_n, k0 = H.prior_k0 >= 0 ? H.prior_k0 : ((cst_win *)Aarg.solve_win)[H.solve_window].prior_k0, nr = np - k0;      // J0 | r0 without their leading zero rows: nr x np, column-major
             cst_d *J0 = H.prior_abs >= 0 ? (cst_d *)Aarg.solve_dpool + H.prior_abs : dp + H.d_prior, *r0 = J0 + nr * np, *x0 = r0 + nr;
             lds_d *pdx = sm, *pr = sm + 128;
             if (tid < H.prior_nblk) {
@@ -1838,7 +1839,7 @@ struct MargState {
 static void marg_free(tcv_batch *b) {
     MargState *s = (MargState *)b->marg;
     if (!s) return;
-    (void)tcv::dev_free(s->d_input); (void)tcv::dev_free(s->d_status);      // (d_hdr, d_ipool, d_dpool point into d_input)
+    (void)tcv::dev_free(s->d_input);      // (d_hdr, d_ipool, d_dpool point into d_input; d_status lives behind d_out in the result blob)
     s->out_blob.reset(); s->d_out = nullptr;      // (freed when the last device-resident prior that reads it is gone)
     (void)tcv::dev_free(s->d_scratch);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -2098,7 +2099,7 @@ static int pack_marg(const tcv_problem &p, double *const *drop, int ndrop, const
     H.d_prior = dmark();
     H.prior_abs = -1;
     if (pr && solve_p && solve_pk && !solve_p->prior.empty() && solve_p->prior[0].prior == pr && solve_pk->hdr.prior_n == pr->n && !getenv("TCV_MARG_OWN_PRIOR"))
-        { H.prior_abs = solve_pk->win.dbase + solve_pk->win.d_prior; H.prior_k0 = solve_pk->win.prior_k0; }      // same layout: J0 | r0 | x0 without the leading zero rows (tcv_pack.cpp)
+        { H.prior_abs = solve_pk->win.dbase + solve_pk->win.d_prior; H.prior_k0 = solve_pk->prior_k0_deferred ? -1 : solve_pk->win.prior_k0; }      // same layout: J0 | r0 | x0 without the leading zero rows (tcv_pack.cpp)
     else if (pr) {
         if (int rc = tcv_prior_host(pr)) return rc;      // (a device-resident prior that the solve problem does not share: its numbers are needed here)
         const int n0 = pr->n, k0 = prior_keep_zero_rows() ? 0 : prior_zero_rows(pr->J0.data(), pr->r0.data(), n0);
@@ -2115,9 +2116,15 @@ static int pack_marg(const tcv_problem &p, double *const *drop, int ndrop, const
 // ---- device-resident priors (tcv_batch_get_priors_device) --------------------------------------------------------------------------
 // one workgroup per job: rows k0 .. n-1 of J0 (column by column), r0[k0 ..], the kept blocks' linearisation points -> the layout
 // pack_data_to() gives a host prior in the solve batch's data pool (tcv_pack.cpp; WinHdr::d_prior)
-__global__ void __launch_bounds__(256) prior_splice_kernel(const PriorSplice *jobs, double *dpool) {
+__global__ void __launch_bounds__(256) prior_splice_kernel(const PriorSplice *jobs, double *dpool, WinHdr *wins) {
     const PriorSplice &J = jobs[blockIdx.x];
-    const int n = J.n, k0 = J.k0, nr = n - k0, tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    int k0 = J.k0;
+    if (J.kind == 0 && J.k0_src) {      // the count the producing marginalisation left on the device (-1 = NaN in its result: the consumer's window is lost anyway)
+        k0 = max(0, min(J.n - 1, *J.k0_src));
+        if (tid == 0) wins[J.win].prior_k0 = k0;
+    }
+    const int n = J.n, nr = n - k0;
     const double *src = J.src;
     double *dst = dpool + J.dst;
     if (J.kind == 1) {
@@ -2143,9 +2150,9 @@ __global__ void __launch_bounds__(256) prior_splice_kernel(const PriorSplice *jo
         xo += J.size[k];
     }
 }
-int launch_prior_splice(const PriorSplice *d_jobs, int njobs, double *d_dpool, hipStream_t st) {
+int launch_prior_splice(const PriorSplice *d_jobs, int njobs, double *d_dpool, void *d_win_headers, hipStream_t st) {
     if (njobs <= 0) return TCV_OK;
-    hipLaunchKernelGGL(prior_splice_kernel, dim3(njobs), dim3(256), 0, st, d_jobs, d_dpool);
+    hipLaunchKernelGGL(prior_splice_kernel, dim3(njobs), dim3(256), 0, st, d_jobs, d_dpool, (WinHdr *)d_win_headers);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "prior splice kernel launch");
     return TCV_OK;
@@ -2184,6 +2191,7 @@ int tcv_prior_host(const tcv_prior *pr) {
     int cur = 0;
     const bool sw = hipGetDevice(&cur) == hipSuccess && pr->dev && cur != pr->dev->dev;
     if (sw) (void)hipSetDevice(pr->dev->dev);
+    if (pr->dev) if (const int rcw = pr->dev->sync_ready()) { if (sw) (void)hipSetDevice(cur); return rcw; }
     const hipError_t e = hipMemcpy(o.data(), pr->d_block, sizeof(double) * MARG_OUT_COMPACT, hipMemcpyDeviceToHost);
     if (sw) (void)hipSetDevice(cur);
     if (e != hipSuccess) return hip_fail(e, "hipMemcpy D2H (device-resident prior)");
@@ -2281,9 +2289,9 @@ int tcv_marg_attach(tcv_batch *b, tcv_problem *const *marg_problems, double *con
         hipStream_t ust = tcv::util_stream();
         hipError_t e_ = tcv::dev_malloc(&s->d_input, in_bytes);
         if (e_ == hipSuccess) { staged.st = ust; staged.in_flight = true; e_ = hipMemcpyAsync(s->d_input, h_in, in_bytes, hipMemcpyHostToDevice, ust); }
-        if (e_ == hipSuccess) e_ = tcv::dev_malloc((void **)&s->d_out, sizeof(double) * std::max<size_t>(1, (size_t)b->n * MARG_OUT_STRIDE));
-        if (e_ == hipSuccess) { s->out_blob = std::make_shared<DevBlob>(); s->out_blob->p = s->d_out; (void)hipGetDevice(&s->out_blob->dev); }
-        if (e_ == hipSuccess) e_ = tcv::dev_malloc((void **)&s->d_status, sizeof(int) * 2 * (size_t)b->n);
+        // result blocks and, behind them, [status | k0] of every window: one buffer, kept alive by the device-resident priors that read it
+        if (e_ == hipSuccess) e_ = tcv::dev_malloc((void **)&s->d_out, sizeof(double) * std::max<size_t>(1, (size_t)b->n * MARG_OUT_STRIDE) + sizeof(int) * 2 * (size_t)b->n);
+        if (e_ == hipSuccess) { s->out_blob = std::make_shared<DevBlob>(); s->out_blob->p = s->d_out; (void)hipGetDevice(&s->out_blob->dev); s->d_status = (int *)(s->d_out + std::max<size_t>(1, (size_t)b->n * MARG_OUT_STRIDE)); }
         if (e_ == hipSuccess) e_ = tcv::dev_malloc((void **)&s->d_scratch, sizeof(double) * (size_t)s->grid * MARG_SCR_STRIDE);
         if (e_ == hipSuccess) e_ = hipMemsetAsync(s->d_status, 0xff, sizeof(int) * 2 * b->n, ust);
         if (e_ == hipSuccess) { e_ = ust ? hipStreamSynchronize(ust) : hipDeviceSynchronize(); if (e_ == hipSuccess) staged.in_flight = false; }
@@ -2303,7 +2311,7 @@ int tcv_marg_run(tcv_batch *b, void *stream) {
     a.hdr = s->d_hdr; a.ipool = s->d_ipool; a.dpool = s->d_dpool; a.solve_state = b->d_state; a.out = s->d_out;
     a.out_status = s->d_status; a.scratch = s->d_scratch; a.nwin = b->n; a.state_stride = b->state_stride;
     a.use_solved_state = b->solved ? 1 : 0;
-    a.solve_dpool = b->d_dpool;
+    a.solve_dpool = b->d_dpool; a.solve_win = (const void *)b->d_win;
     a.solve_sqrt = (b->solved && b->sqrt_out_valid && !getenv("TCV_MARG_OWN_SQRT")) ? b->d_sqrt_out : nullptr;
     a.eig_mm = getenv("TCV_MARG_EIG_MM") ? 1 : 0;
     a.eig_flags = getenv("TCV_MARG_EIG_FLAGS") ? atoi(getenv("TCV_MARG_EIG_FLAGS")) : 0;
@@ -2316,6 +2324,12 @@ int tcv_marg_run(tcv_batch *b, void *stream) {
     else hipLaunchKernelGGL(marg_kernel<MARG_NT_WIDE>, dim3(s->grid), dim3(MARG_NT_WIDE), s->lds_bytes, st, a);
     if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "marg kernel launch");
     if ((e = hipEventRecord(s->ev1, st)) != hipSuccess) return hip_fail(e, "hipEventRecord");
+    // what consumers of device-resident priors on other streams (and host readers) wait for: tcv_batch_get_priors_device_async hands the
+    // results out while this kernel may still be running
+    if (s->out_blob) {
+        if (!s->out_blob->ready && hipEventCreateWithFlags(&s->out_blob->ready, hipEventDisableTiming) != hipSuccess) s->out_blob->ready = nullptr;
+        if (s->out_blob->ready && (e = hipEventRecord(s->out_blob->ready, st)) != hipSuccess) return hip_fail(e, "hipEventRecord");
+    }
     s->ran = true;
     s->h_valid = false;
     return TCV_OK;
@@ -2363,8 +2377,11 @@ void tcv_marg_elapsed(tcv_batch *b) {
 extern "C" int tcv_batch_marg_status(tcv_batch *b, int *out, int n) {
     MargState *s = b ? (MargState *)b->marg : nullptr;
     if (!s || !s->ran || !out || n > b->n) { set_error("no marginalisation result"); return TCV_ERR_INVALID; }
-    hipError_t e = hipMemcpy(out, s->d_status, sizeof(int) * n, hipMemcpyDeviceToHost);
+    if (b->pending) if (int rc = tcv_batch_synchronize(b)) return rc;      // (a copy on the null stream is not ordered behind a non-blocking stream)
+    std::vector<int> st(2 * (size_t)b->n);
+    hipError_t e = hipMemcpy(st.data(), s->d_status, sizeof(int) * st.size(), hipMemcpyDeviceToHost);
     if (e != hipSuccess) return hip_fail(e, "hipMemcpy D2H");
+    for (int w = 0; w < n; w++) out[w] = (st[w] == 0 && st[b->n + w] < 0 && s->win[w].hdr.nblk != 0) ? -2 : st[w];      // -2: a NaN in the result
     return TCV_OK;
 }
 
@@ -2427,11 +2444,13 @@ int tcv_marg_get_prior(tcv_batch *b, int window, tcv_prior **out) {
 }
 
 // tcv_batch_get_priors_device: layout on the host, numbers left in the batch's result buffer (shared with the handles)
-int tcv_marg_get_priors_device(tcv_batch *b, tcv_prior **out, int n) {
+int tcv_marg_get_priors_device(tcv_batch *b, tcv_prior **out, int n, bool nowait) {
     MargState *s = (MargState *)b->marg;
     if (!s || !s->ran || n != b->n) { set_error("no marginalisation result (or n is not the batch size)"); return TCV_ERR_INVALID; }
-    std::vector<int> st(2 * (size_t)n);
-    {
+    if (nowait && !(s->out_blob && s->out_blob->ready)) nowait = false;      // (no event to order consumers by: wait as usual)
+    std::vector<int> st(2 * (size_t)n, 0);
+    if (nowait) { for (int w = 0; w < n; w++) st[n + w] = -1; }      // status unknown here (tcv_batch_marg_status later), k0 read on the device
+    else {
         hipStream_t ust = tcv::util_stream();
         int *hs = (int *)tcv::host_staging_acquire(sizeof(int) * st.size());
         if (!hs) { set_error("hipHostMalloc (download staging) failed"); return TCV_ERR_HIP; }
@@ -2449,7 +2468,7 @@ int tcv_marg_get_priors_device(tcv_batch *b, tcv_prior **out, int n) {
         const int status = st[w], k0 = st[n + w];
         if (status < 0) { set_error("marginalisation kernel did not complete for this window"); rc = TCV_ERR_NUMERIC; break; }
         if (status == 1) { set_error("marginalisation: eigen-decomposition did not converge (sweep cap)"); rc = TCV_ERR_NUMERIC; break; }
-        if (k0 < 0) { set_error("NaN in marginalisation result"); rc = TCV_ERR_NUMERIC; break; }
+        if (k0 < 0 && !nowait) { set_error("NaN in marginalisation result"); rc = TCV_ERR_NUMERIC; break; }
         if ((int)mw.keep_block.size() > PRIOR_SPLICE_MAX_BLOCKS) { set_error("device-resident prior: too many kept blocks"); rc = TCV_ERR_TOO_LARGE; break; }
         tcv_prior *pr = new tcv_prior();
         pr->m = mw.m_total; pr->n = mw.hdr.n;
@@ -2461,6 +2480,7 @@ int tcv_marg_get_priors_device(tcv_batch *b, tcv_prior **out, int n) {
         }
         pr->xsize = xo;
         pr->dev = s->out_blob; pr->d_block = s->d_out + (size_t)w * MARG_OUT_STRIDE; pr->k0 = k0; pr->host = false;
+        pr->d_status = s->d_status + w; pr->d_k0 = s->d_status + n + w;
         out[w] = pr;
     }
     if (rc != TCV_OK) for (int w = 0; w < n; w++) if (out[w]) { delete out[w]; out[w] = nullptr; }

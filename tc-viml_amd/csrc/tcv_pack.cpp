@@ -955,10 +955,14 @@ static int pack_data_to(const tcv_problem &p, Packed &out, const double *imu_sqr
         if (pr) { std::lock_guard<std::mutex> g(pr->mu); on_device = !pr->host && pr->dev && (int)pr->size.size() <= PRIOR_SPLICE_MAX_BLOCKS; }
     }
     out.dev_prior_doubles = 0;
+    out.prior_k0_deferred = false;
     if (pr && on_device) {
         // device-resident (tcv_batch_get_priors_device): nothing is written here; tcv_batch_create gives the region a place in the batch's
         // device-only tail (it patches d_prior) and the splice kernel fills it with the same layout as below
-        const int n = pr->n, k0 = prior_keep_zero_rows() ? 0 : pr->k0, nr = n - k0;
+        // (k0 not known on the host yet -- tcv_batch_get_priors_device_async --: room for every row, the splice kernel compacts by the
+        // count it reads on the device and writes it into the window header)
+        out.prior_k0_deferred = pr->k0 < 0 && !prior_keep_zero_rows();
+        const int n = pr->n, k0 = (prior_keep_zero_rows() || pr->k0 < 0) ? 0 : pr->k0, nr = n - k0;
         W.prior_k0 = k0;
         out.dev_prior_doubles = nr * n + nr + pr->xsize;
     } else if (pr) {      // the rows of the thresholded eigenvalues (exact zeros in J0 and r0) are dropped, tcv_packed.h

@@ -39,7 +39,7 @@ EXPORTS = [
     "tcv_eval_imu_factors", "tcv_eval_projection_factors", "tcv_eval_line_factors", "tcv_pose_plus", "tcv_preintegrate",
     "tcv_problem_set_frames", "tcv_gauge_fix", "tcv_batch_gauge_fix", "tcv_set_solver_variant", "tcv_set_cooperative", "tcv_batch_cooperative", "tcv_batch_get_priors", "tcv_batch_marg_status", "tcv_eval_projection_td_factors", "tcv_match_lines",
     "tcv_batch_download_priors", "tcv_batch_download_priors_compact",
-    "tcv_batch_get_priors_device", "tcv_prior_is_device_resident", "tcv_problem_set_marginalization_prior",
+    "tcv_batch_get_priors_device", "tcv_batch_get_priors_device_async", "tcv_prior_is_device_resident", "tcv_problem_set_marginalization_prior",
     "tcv_problems_set_marginalization_prior", "tcv_priors_destroy",
     "tcv_match_lines_batch", "tcv_preintegrate_device", "tcv_preint_sum_dt", "tcv_preint_export", "tcv_preint_destroy", "tcv_problem_add_imu_factor_device",
 ]
@@ -142,6 +142,7 @@ def lib():
         L.tcv_batch_download_priors.argtypes = [vp]
         L.tcv_batch_download_priors_compact.argtypes = [vp]
         L.tcv_batch_get_priors_device.argtypes = [vp, C.POINTER(vp), C.c_int]
+        L.tcv_batch_get_priors_device_async.argtypes = [vp, C.POINTER(vp), C.c_int]
         L.tcv_prior_is_device_resident.argtypes = [vp]
         L.tcv_problem_set_marginalization_prior.argtypes = [vp, vp]
         L.tcv_problems_set_marginalization_prior.argtypes = [C.POINTER(vp), C.POINTER(vp), C.c_int]
@@ -485,12 +486,13 @@ class Batch:
         check(lib().tcv_batch_get_priors_device(self.h, out, n))
         return out
 
-    def priors_device(self):
+    def priors_device(self, nowait=False):
         """every window's prior as a DEVICE-RESIDENT handle (tcv_batch_get_priors_device): layout on the host, J0 | r0 | x0 left in HBM; a
-        problem that holds one uploads nothing of it"""
+        problem that holds one uploads nothing of it.  nowait: tcv_batch_get_priors_device_async -- the marginalisation may still be running,
+        consumers are ordered behind it on the device, its status is asked for later (marg_status)"""
         n = len(self.windows)
         out = (C.c_void_p * n)()
-        check(lib().tcv_batch_get_priors_device(self.h, out, n))
+        check((lib().tcv_batch_get_priors_device_async if nowait else lib().tcv_batch_get_priors_device)(self.h, out, n))
         return [Prior(C.c_void_p(h)) if h else None for h in out]
 
     def solve(self, opts, stream=None):

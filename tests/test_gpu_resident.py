@@ -254,3 +254,48 @@ def test_device_memory_returns_to_its_level_after_the_objects_are_gone(gpu):
     live1, cached1, n1 = tcv.device_memory_stats()
     assert (live1, n1) == (live0, n0), (live0, n0, live1, n1)
     assert cached1 <= 3 << 30
+
+
+@pytest.mark.parametrize("B", [4, 300])
+def test_priors_handed_on_without_waiting_for_the_marginalisation_give_the_same_bits(gpu, B):
+    """tcv_batch_get_priors_device_async: the handles are taken while the marginalisation may still be running; the next tcv_batch_create is
+    ordered behind it by the result buffer's event (the batch calls below run on the default stream, the upload and the splice on the
+    calling thread's own stream: the cross-stream case), the number of thresholded rows is read on the device -- the chain of frames gives
+    the bits of the chain that waits (tcv_batch_get_priors_device); the statuses are asked for afterwards"""
+    tcv = gpu
+    pre = synth.make_windows(9400, B, frame_shift=-1)
+    pw = [synth.window_at(pre, k) for k in range(B)]
+    main = synth.make_windows(9400, B)
+    mw = [synth.window_at(main, k) for k in range(B)]
+    opts = tcv.default_options(8, True)
+
+    def chain(nowait):
+        W = [tcv.Window(w) for w in pw]
+        b = _marg_batch(tcv, pw, W)
+        out, old = [], []
+        for frame in range(3):
+            b.solve(opts); b.gauge_fix(); b.download_states(); s = b.summaries()      # (waits for the solve: the frame's result)
+            b.marginalize()
+            pri = b.priors_device(nowait=nowait)
+            if nowait:
+                assert all(p.on_device() for p in pri)
+            out.append((s, [w.states() for w in W]))
+            blocks = [tcv.shifted_prior_blocks(pri[k], W[k]) for k in range(B)]
+            old.append(b)                                     # (kept until its status has been read)
+            W = [tcv.Window(dict(mw[k], prior=dict(blocks=blocks[k])), prior=pri[k]) for k in range(B)]
+            b = _marg_batch(tcv, mw, W)
+        for ob in old:
+            assert list(ob.marg_status()) == [0] * B
+        b.solve(opts); b.synchronize(); b.download_states()
+        out.append((b.summaries(), [w.states() for w in W]))
+        return out, [p.export() for p in pri]
+
+    ref, fin_r = chain(False)
+    got, fin_g = chain(True)
+    for (sr, xr), (sg, xg) in zip(ref, got):
+        for k in range(B):
+            _same_summary(sr[k], sg[k])
+            for key in ("pose", "sb", "ex", "lam"):
+                assert np.array_equal(xr[k][key], xg[k][key]), (k, key)
+    for k in range(B):
+        assert np.array_equal(fin_r[k]["J0"], fin_g[k]["J0"]) and np.array_equal(fin_r[k]["r0"], fin_g[k]["r0"])
