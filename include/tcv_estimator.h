@@ -71,6 +71,11 @@ int tcv_estimator_begin_frame(tcv_estimator *e, int n_imu, const double *acc, co
  * A window whose own marginalisation fails numerically (eigen-solver sweep cap) does not fail the batch: the other estimators are
  * applied, the call returns TCV_OK, and tcv_estimator_finish_frame of THAT estimator returns TCV_ERR_NUMERIC (reset it, like after
  * failureDetection).  Any other error (HIP, invalid input) fails the whole call and applies nothing.
+ * The marginalisation is off the caller's critical path: the call returns when the solve and the gauge fix are done and the new states
+ * are applied; the marginalisation (whose result, the next prior, never leaves the device) is launched behind them and runs while the
+ * caller finishes this frame and starts the next.  Its status is read at the estimator's NEXT tcv_estimators_optimize: a window that was
+ * solved on the prior of a failed marginalisation is not applied and reports TCV_ERR_NUMERIC from tcv_estimator_finish_frame -- one frame
+ * later than a failure of the solve itself.  (TCV_EST_MARG_WAIT=1 in the environment: wait for it inside the call, as until round 4.)
  * Thread safety: estimators are independent objects; different host threads may drive different estimator lists, on the same or on
  * different devices (every call issues its copies and kernels on the calling thread's own stream: the threads overlap on the device). */
 int tcv_estimators_optimize(tcv_estimator *const *e, int n);

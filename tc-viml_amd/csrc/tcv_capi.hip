@@ -151,6 +151,7 @@ namespace {
 struct Deferred { void *h, *d; hipStream_t st; };
 struct ThreadStreams {
     std::map<int, hipStream_t> m;
+    std::map<int, hipStream_t> aux;      // a second stream per device for work that runs beside the thread's main sequence (aux_stream)
     std::vector<Deferred> deferred;      // buffers of commands still in flight on one of these streams (defer_release)
     bool main_thread = false;
     ~ThreadStreams();
@@ -178,8 +179,23 @@ ThreadStreams::~ThreadStreams() {
         if (!main_thread) (void)hipStreamDestroy(kv.second);
     }
     for (auto &x : deferred) { host_staging_release(x.h); (void)dev_free(x.d); }
+    if (!main_thread) for (auto &kv : aux) if (kv.second) { (void)hipStreamSynchronize(kv.second); (void)hipStreamDestroy(kv.second); }
 }
 }  // namespace
+// the calling thread's second stream (created at first use): the native estimator runs a frame's marginalisation there, beside the next
+// frame's association and upload on the thread's main stream
+hipStream_t aux_stream() {
+    ThreadStreams &mine = thread_streams();
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    auto it = mine.aux.find(dev);
+    if (it != mine.aux.end()) return it->second;
+    (void)util_stream();      // (sets main_thread)
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = util_stream();
+    mine.aux.emplace(dev, st);
+    return st;
+}
 hipStream_t util_stream() {
     ThreadStreams &mine = thread_streams();
     int dev = 0;
@@ -576,9 +592,11 @@ extern "C" void tcv_prior_destroy(tcv_prior *pr) { delete pr; }
 // =====================================================================================================
 static void batch_free(tcv_batch *b) {
     if (!b) return;
+    if (b->wait_inflight) (void)hipEventSynchronize(b->ev_inflight);
     if (b->pending)      // the buffers go back to the free list: nothing of this batch may still be running on any stream it used
         for (hipStream_t st : b->streams) { if (st) (void)hipStreamSynchronize(st); else (void)hipDeviceSynchronize(); }
     if (b->ev_order) (void)hipEventDestroy(b->ev_order);
+    if (b->ev_inflight) (void)hipEventDestroy(b->ev_inflight);
     coop_release(b);
     tcv::dev_free(b->d_input);      // (d_dpool, d_win, d_plans, d_plan_base, d_ipool point into it)
     tcv::dev_free(b->d_imublk); tcv::dev_free(b->d_spill); tcv::dev_free(b->d_sqrt_out);
@@ -957,7 +975,8 @@ extern "C" void tcv_solver_options_default(tcv_solver_options *o) {
 
 int tcv_batch_enter_stream(tcv_batch *b, void *hip_stream) {
     hipStream_t st = (hipStream_t)hip_stream;
-    if (b->pending && b->last_stream != st) {
+    if (b->wait_inflight) HIPCHK(hipStreamWaitEvent(st, b->ev_inflight, 0));      // (the stream that work ran on may be gone: its event orders the new call)
+    else if (b->pending && b->last_stream != st) {
         if (!b->ev_order) HIPCHK(hipEventCreateWithFlags(&b->ev_order, hipEventDisableTiming));
         HIPCHK(hipEventRecord(b->ev_order, b->last_stream));
         HIPCHK(hipStreamWaitEvent(st, b->ev_order, 0));
@@ -1025,6 +1044,7 @@ extern "C" int tcv_batch_marginalize(tcv_batch *b, void *hip_stream) {
 // device: batches driven from different host threads on different streams overlap (bench.py --mode stream)
 extern "C" int tcv_batch_synchronize(tcv_batch *b) {
     if (!b) return TCV_ERR_INVALID;
+    if (b->wait_inflight) { HIPCHK(hipEventSynchronize(b->ev_inflight)); b->wait_inflight = false; }
     for (hipStream_t st : b->streams) { if (st) HIPCHK(hipStreamSynchronize(st)); else HIPCHK(hipDeviceSynchronize()); }
     b->streams.clear();
     b->pending = false;
@@ -1138,7 +1158,16 @@ extern "C" int tcv_batch_get_priors(tcv_batch *b, tcv_prior **out, int n) {
 extern "C" int tcv_batch_get_priors_device_async(tcv_batch *b, tcv_prior **out, int n) {
     if (!b || !out || n != b->n) { set_error("batch_get_priors_device_async: n must be the batch size"); return TCV_ERR_INVALID; }
     for (int k = 0; k < n; k++) out[k] = nullptr;
-    return tcv_marg_get_priors_device(b, out, n, true);      // (no wait: the marginalisation may still be running)
+    const int rc = tcv_marg_get_priors_device(b, out, n, true);      // (no wait: the marginalisation may still be running)
+    if (rc == TCV_OK && b->pending && !b->streams.empty()) {
+        // the batch outlives this call with work in flight: from here on that work is an event, not the streams it runs on -- the calling
+        // thread may end (its stream goes with it) before somebody asks for the status or destroys the batch
+        if (!b->ev_inflight) HIPCHK(hipEventCreateWithFlags(&b->ev_inflight, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(b->ev_inflight, b->last_stream));
+        b->streams.clear();
+        b->wait_inflight = true;
+    }
+    return rc;
 }
 extern "C" int tcv_batch_get_priors_device(tcv_batch *b, tcv_prior **out, int n) {
     if (!b || !out || n != b->n) { set_error("batch_get_priors_device: n must be the batch size"); return TCV_ERR_INVALID; }

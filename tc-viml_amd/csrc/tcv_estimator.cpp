@@ -20,7 +20,7 @@
 #include <vector>
 
 #include "../../include/tcv_estimator.h"
-namespace tcv { hipStream_t util_stream(); }      // (tcv_capi.hip: the calling thread's utility stream)
+namespace tcv { hipStream_t util_stream(); hipStream_t aux_stream(); }      // (tcv_capi.hip: the calling thread's utility stream and its second stream)
 #include <functional>
 #include "tcv_packed.h"      // parallel_run, HostOp: the persistent host worker threads of the packer
 
@@ -122,8 +122,36 @@ struct ImuBuf {
 
 }  // namespace
 
+// A lock-step frame whose marginalisation was left running when tcv_estimators_optimize returned (device-resident state): the batch and
+// its problems, shared by the estimators of the frame; each asks for the status of its own window at its next frame (or lets go of it when
+// it is reset / destroyed), the last one to let go destroys the batch.
+struct EstInflight {
+    tcv_batch *b = nullptr;
+    std::vector<tcv_problem *> P, M;
+    std::vector<int> status;
+    bool have_status = false;
+    std::mutex mu;
+    int status_of(int k) {
+        std::lock_guard<std::mutex> g(mu);
+        if (!have_status) {
+            const int n = tcv_batch_size(b);
+            status.assign(n, -9);
+            if (tcv_batch_marg_status(b, status.data(), n) != TCV_OK) status.assign(n, -9);      // (waits for the batch; -9: the question itself failed)
+            have_status = true;
+        }
+        return (k >= 0 && k < (int)status.size()) ? status[k] : -9;
+    }
+    ~EstInflight() {
+        if (b) tcv_batch_destroy(b);      // (waits for work in flight)
+        for (auto *p : P) if (p) tcv_problem_destroy(p);
+        for (auto *p : M) if (p) tcv_problem_destroy(p);
+    }
+};
+
 struct tcv_estimator {
     tcv_estimator_config cfg;
+    std::shared_ptr<EstInflight> prev;       // the frame whose marginalisation produced `prior` and may still be running; prev_k: this estimator's window in it
+    int prev_k = -1;
     V3 Ps[W + 1], Vs[W + 1], Bas[W + 1], Bgs[W + 1];
     M3 Rs[W + 1];
     V3 tic;
@@ -580,6 +608,7 @@ static void clear_state(tcv_estimator *e) {
     std::memset(&e->stats, 0, sizeof e->stats);
     e->features.clear(); e->linefeatures.clear(); e->fov_ready = false;
     if (e->prior) { tcv_prior_destroy(e->prior); e->prior = nullptr; }
+    e->prev.reset(); e->prev_k = -1;
     e->prior_blocks.clear();
     e->frame_count = 0; e->marg_flag = MARGIN_OLD;
     e->have_acc0 = false; e->have_last = false;
@@ -782,6 +811,19 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
     // and with one stream per thread no small copy of one thread waits behind another thread's 2 ms solve kernel on a shared hardware queue.
     // (TCV_EST_TWO_BATCHES: the two batches of a frame then run one after the other.)
     hipStream_t g_streams[2] = {tcv::util_stream(), tcv::util_stream()};
+    // last_marginalization_info stays on the device (estimator.h:176-177: the reference keeps it alive between frames, too): the new
+    // priors are handles on the batch's result buffer, the next frame's tcv_batch_create splices them device-to-device.
+    // TCV_EST_HOST_PRIORS=1: round 3's host round trip (62 KB down, 46 KB up per window), the A/B partner -- same bits.
+    // Faster at every batch size once every host thread launches on its own stream (512-window passes: 171 K against 117 K windows/s; eight
+    // replay streams on two host threads: 2 370 - 2 480 against 2 250 - 2 280 windows/s).  TCV_EST_HOST_STATE=1 (both) / TCV_EST_HOST_PRIORS=1 /
+    // TCV_EST_HOST_PREINT=1 take the host round trip.
+    const bool host_priors = getenv("TCV_EST_HOST_PRIORS") != nullptr || getenv("TCV_EST_HOST_STATE") != nullptr;
+    // With the priors on the device the host needs nothing of the marginalisation but its status: the call returns once the solve and the
+    // gauge fix are done and the states are applied; the marginalisation is launched behind them and runs while the caller finishes the
+    // frame and starts the next one (tcv_batch_get_priors_device_async).  Its status is read at each estimator's NEXT frame, after that
+    // frame's solve: a window solved on a prior whose marginalisation failed is not applied and reports the failure (finish_frame), one
+    // frame late.  TCV_EST_MARG_WAIT=1: wait for it as before (same bits).
+    const bool marg_off_path = !host_priors && !two_batches && getenv("TCV_EST_MARG_WAIT") == nullptr;
     int rc_all = TCV_OK;
     for (int group = 1; group >= 0; group--) {
         Group &g = G[group];
@@ -820,7 +862,7 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
         void *st = (void *)g_streams[group];
         g.rc = tcv_batch_solve(g.b, &o, st);
         if (g.rc == TCV_OK) g.rc = tcv_batch_gauge_fix(g.b, st);
-        if (g.rc == TCV_OK && g.any_marg) g.rc = tcv_batch_marginalize(g.b, st);
+        if (g.rc == TCV_OK && g.any_marg && !marg_off_path) g.rc = tcv_batch_marginalize(g.b, st);
     }
     for (int group = 1; group >= 0; group--) {
         Group &g = G[group];
@@ -839,20 +881,31 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
         const double td1 = now_s();
         if (g.rc == TCV_OK) g.rc = tcv_batch_get_summaries(g.b, g.sum.data(), nb);
         const double td2 = now_s();
-        // last_marginalization_info stays on the device (estimator.h:176-177: the reference keeps it alive between frames, too): the new
-        // priors are handles on the batch's result buffer, the next frame's tcv_batch_create splices them device-to-device.
-        // TCV_EST_HOST_PRIORS=1: round 3's host round trip (62 KB down, 46 KB up per window), the A/B partner -- same bits
-        // Faster at every batch size once every host thread launches on its own stream (512-window passes: 171 K against 117 K windows/s; eight
-        // replay streams on two host threads: 2 370 - 2 480 against 2 250 - 2 280 windows/s).  TCV_EST_HOST_STATE=1 (both) / TCV_EST_HOST_PRIORS=1 /
-        // TCV_EST_HOST_PREINT=1 take the host round trip.
-        const bool host_priors = getenv("TCV_EST_HOST_PRIORS") != nullptr || getenv("TCV_EST_HOST_STATE") != nullptr;
         bool have_dev = false;
-        if (g.rc == TCV_OK && g.any_marg && !host_priors) have_dev = tcv_batch_get_priors_device(g.b, g.newp.data(), nb) == TCV_OK;      // (a window that failed: the per-window path below says which)
+        if (g.rc == TCV_OK && g.any_marg && marg_off_path) {      // the states are on the host: now the marginalisation, and its results as handles without a wait
+            // (on the thread's main stream: the next frame's association round trip queues behind it, ~0.1 ms of a frame.  TCV_EST_MARG_AUX=1: on the
+            // thread's second stream -- one host thread 2 570 - 2 720 against 2 590 windows/s, two host threads 2 490 - 2 550 against 2 940: two
+            // streams per thread share the runtime's four hardware queues again)
+            static const bool marg_aux = getenv("TCV_EST_MARG_AUX") && atoi(getenv("TCV_EST_MARG_AUX")) != 0;
+            g.rc = tcv_batch_marginalize(g.b, marg_aux ? (void *)tcv::aux_stream() : (void *)g_streams[group]);
+            if (g.rc == TCV_OK) g.rc = tcv_batch_get_priors_device_async(g.b, g.newp.data(), nb);
+            have_dev = g.rc == TCV_OK;
+        }
+        if (g.rc == TCV_OK && g.any_marg && !host_priors && !marg_off_path) have_dev = tcv_batch_get_priors_device(g.b, g.newp.data(), nb) == TCV_OK;      // (a window that failed: the per-window path below says which)
         if (g.rc == TCV_OK && g.any_marg && !have_dev) g.rc = tcv_batch_download_priors_compact(g.b);
         g.est_rc.assign(nb, TCV_OK);
         if (g.rc == TCV_OK)
-            for (int k = 0; k < nb; k++)      // ceres::Solve's FAILURE (no valid step / a cooperative group that timed out): the window's states are not applied
+            for (int k = 0; k < nb; k++) {     // ceres::Solve's FAILURE (no valid step / a cooperative group that timed out): the window's states are not applied
                 if (g.sum[k].termination == 5 || !(g.sum[k].final_cost == g.sum[k].final_cost)) { g.est_rc[k] = TCV_ERR_NUMERIC; g.est_msg = "solver failure (no valid step, NaN cost or workgroup time-out)"; }
+                // the marginalisation that made this window's prior was still running when the previous frame returned: its verdict now (it
+                // finished before this frame's solve started)
+                tcv_estimator *e = es[g.idx[k]];
+                if (e->prev) {
+                    const int stp = e->prev->status_of(e->prev_k);
+                    if (stp != 0 && stp != 2) { g.est_rc[k] = TCV_ERR_NUMERIC; g.est_msg = "the previous frame's marginalisation failed (eigen-solver sweep cap or NaN): this window was solved on an invalid prior"; }
+                    e->prev.reset(); e->prev_k = -1;
+                }
+            }
         if (g.rc == TCV_OK && g.any_marg) {
             std::vector<std::string> msgs(nb);
             int cur_dev = 0;
@@ -873,6 +926,12 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
             }
         }
         const double td3 = now_s();
+        if (g.rc == TCV_OK && g.any_marg && marg_off_path && have_dev) {      // the batch lives on until its marginalisation has been asked about
+            auto fl = std::make_shared<EstInflight>();
+            fl->b = g.b; fl->P = g.P; fl->M = g.M;
+            g.b = nullptr; g.P.assign(nb, nullptr); g.M.assign(nb, nullptr);
+            for (int k = 0; k < nb; k++) if (g.dm[k] && g.est_rc[k] == TCV_OK) { es[g.idx[k]]->prev = fl; es[g.idx[k]]->prev_k = k; }
+        }
         if (g.b) tcv_batch_destroy(g.b);
         const double td4 = now_s();
         for_each_estimator(nb, [&](int k) { if (g.P[k]) tcv_problem_destroy(g.P[k]); if (g.M[k]) tcv_problem_destroy(g.M[k]); });

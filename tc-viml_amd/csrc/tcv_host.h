@@ -145,6 +145,8 @@ struct tcv_batch {
     hipStream_t last_stream = nullptr;     // stream of the last asynchronous call
     std::vector<hipStream_t> streams;      // every stream with work of this batch in flight (tcv_batch_synchronize / batch_free wait for all of them; null: the device)
     hipEvent_t ev_order = nullptr;         // orders a call on a new stream behind the pending work of the previous one (tcv_batch_enter_stream)
+    hipEvent_t ev_inflight = nullptr;      // tcv_batch_get_priors_device_async: the work in flight is tracked by this event from then on, not by the streams it runs
+    bool wait_inflight = false;            // on (the batch outlives the call, a stream may go with its host thread); waited for by synchronize / destroy / the next call
     bool pending = false;                  // asynchronous work issued since the last synchronize (batch_free waits before it recycles the buffers)
     bool chain = false;                   // all plans use the chain layout (2 workgroups per CU)
     int chain_lds = 0;                    // LDS doubles per chain-layout workgroup of this batch
