@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -139,6 +140,10 @@ struct EstInflight {
             if (tcv_batch_marg_status(b, status.data(), n) != TCV_OK) status.assign(n, -9);      // (waits for the batch; -9: the question itself failed)
             have_status = true;
         }
+        // (test hook: TCV_EST_INJECT_MARG_FAIL=q reports the q-th status asked for in the process as a sweep-cap failure)
+        static std::atomic<int> asked{0};
+        static const int inject = getenv("TCV_EST_INJECT_MARG_FAIL") ? atoi(getenv("TCV_EST_INJECT_MARG_FAIL")) : -1;
+        if (inject >= 0 && asked.fetch_add(1) == inject) return 1;
         return (k >= 0 && k < (int)status.size()) ? status[k] : -9;
     }
     ~EstInflight() {

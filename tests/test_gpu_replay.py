@@ -267,3 +267,32 @@ def test_host_threads_with_their_own_estimators_reproduce_the_single_thread_run(
             for a, c in zip(ref, res):
                 assert np.array_equal(a["p"], c["p"]) and np.array_equal(a["q"], c["q"]) and np.array_equal(a["v"], c["v"])
                 assert [l["iterations"] for l in a["log"]] == [l["iterations"] for l in c["log"]]
+
+
+def test_a_failed_marginalisation_is_reported_at_the_estimators_next_frame():
+    """The marginalisation runs off the caller's critical path (include/tcv_estimator.h): its status is read at the estimator's next frame.  A
+    failure (injected: the library has no natural one to offer) keeps that frame's window from being applied and comes back from
+    finish_frame as TCV_ERR_NUMERIC -- for that estimator only.  Own process: the hook is read once."""
+    import subprocess, sys, os
+    code = r'''
+import sys, os
+sys.path.insert(0, os.path.join(%r, "tc-viml_amd"))
+import numpy as np, replay, tcv
+streams = [replay.simulate_stream(70 + s, 22, max_features=30) for s in range(3)]
+ls = replay.NativeLockstep(streams, num_iterations=4)
+failed = None
+for k in range(ls.n_frames):
+    try:
+        ls.step(k)
+    except tcv.TcvError as e:
+        failed = (k, str(e)); break
+assert failed is not None, "no failure reported"
+k, msg = failed
+assert "previous frame's marginalisation failed" in msg, msg
+assert replay.WINDOW_SIZE + 2 <= k <= replay.WINDOW_SIZE + 4, k          # statuses are asked for one frame after a marginalisation: ids 0..2 at frame W+1 if all three marginalised at frame W, the injected id 4 a frame or two later
+print("ok", k)
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    env = dict(os.environ, TCV_EST_INJECT_MARG_FAIL="4")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+test_a_failed_marginalisation_is_reported_at_the_estimators_next_frame = pytest.mark.gpu(test_a_failed_marginalisation_is_reported_at_the_estimators_next_frame)
