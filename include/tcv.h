@@ -231,6 +231,11 @@ void tcv_prior_destroy(tcv_prior *pr);
  * its entry NULL. */
 int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, tcv_problem *const *marg_problems,
                      double *const *const *marg_drop, const int *marg_num_drop, int n);
+/* The marginalisation problems of a batch created with marg_problems == NULL, attached afterwards (same arguments as tcv_batch_create):
+ * their packing and upload may run while tcv_batch_solve of the same batch is on the device -- the native estimator overlaps them
+ * with the solve.  (The solve of such a batch does not hand its IMU factor's sqrt_info to the marginalisation, which forms its own:
+ * same bits.)  Once per batch, before tcv_batch_marginalize. */
+int tcv_batch_attach_marginalization(tcv_batch *b, tcv_problem *const *marg_problems, double *const *const *marg_drop, const int *marg_num_drop);
 void tcv_batch_destroy(tcv_batch *b);
 /* one pass of the hot path over the batch: solve every window from its uploaded initial state
  * (and, if marg problems were given, marginalise at the solution).  Asynchronous on `hip_stream`

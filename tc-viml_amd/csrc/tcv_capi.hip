@@ -959,6 +959,17 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
     *out = b;
     return TCV_OK;
 }
+// The marginalisation problems of a batch that was created without them: their packing and upload can then run while the batch's solve
+// is on the device (the native estimator does: ~0.3 ms of a lock-step frame).  The solve of such a batch does not export an IMU factor's
+// sqrt_info (which factor is part of the window headers, uploaded before): the marginalisation kernel forms its own -- same function, same bits.
+extern "C" int tcv_batch_attach_marginalization(tcv_batch *b, tcv_problem *const *marg_problems, double *const *const *marg_drop, const int *marg_num_drop) {
+    if (!b || !marg_problems || !marg_drop || !marg_num_drop) { set_error("batch_attach_marginalization: bad argument"); return TCV_ERR_INVALID; }
+    if (b->marg) { set_error("batch_attach_marginalization: the batch has marginalisation problems already"); return TCV_ERR_INVALID; }
+    const tcv::HostOp host_op;
+    const int rc = tcv_marg_attach(b, marg_problems, marg_drop, marg_num_drop);
+    if (rc != TCV_OK && b->marg && b->marg_free) b->marg_free(b);      // (nothing half-attached stays behind)
+    return rc;
+}
 extern "C" void tcv_batch_destroy(tcv_batch *b) { batch_free(b); }
 extern "C" int tcv_batch_size(const tcv_batch *b) { return b ? b->n : 0; }
 

@@ -844,7 +844,7 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
                 tcv_window_desc d;
                 fill_desc(e, d, false, e->marg_flag);
                 rcs[k] = tcv_problem_from_window(&d, &g.P[k]);
-                if (rcs[k] == TCV_OK && g.dm[k]) {
+                if (rcs[k] == TCV_OK && g.dm[k] && !marg_off_path) {
                     build_marg(e, e->marg_flag);
                     fill_desc(e, d, true, e->marg_flag);
                     rcs[k] = tcv_problem_from_window(&d, &g.M[k]);
@@ -855,7 +855,9 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
             for (int k = 0; k < nb && g.rc == TCV_OK; k++) if (rcs[k] != TCV_OK) { g.rc = rcs[k]; tcv::set_error(msgs[k]); }
         }
         lap(2);
-        if (g.rc == TCV_OK) g.rc = tcv_batch_create(&g.b, g.P.data(), g.any_marg ? g.M.data() : nullptr, g.any_marg ? g.drops.data() : nullptr, g.any_marg ? g.ndrop.data() : nullptr, nb);
+        // (marg_off_path: the batch is created without its marginalisation problems -- they are built and attached below, while the solve runs)
+        const bool with_marg = g.any_marg && !marg_off_path;
+        if (g.rc == TCV_OK) g.rc = tcv_batch_create(&g.b, g.P.data(), with_marg ? g.M.data() : nullptr, with_marg ? g.drops.data() : nullptr, with_marg ? g.ndrop.data() : nullptr, nb);
         lap(3);
     }
     for (int group = 1; group >= 0; group--) {
@@ -868,6 +870,27 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
         g.rc = tcv_batch_solve(g.b, &o, st);
         if (g.rc == TCV_OK) g.rc = tcv_batch_gauge_fix(g.b, st);
         if (g.rc == TCV_OK && g.any_marg && !marg_off_path) g.rc = tcv_batch_marginalize(g.b, st);
+    }
+    if (marg_off_path) {      // the solve is on the device: the marginalisation problems of the frame, their packing and upload meanwhile
+        for (int group = 1; group >= 0; group--) {
+            Group &g = G[group];
+            if (g.idx.empty() || g.rc != TCV_OK || !g.any_marg) continue;
+            const int nb = (int)g.idx.size();
+            std::vector<int> rcs(nb, TCV_OK);
+            std::vector<std::string> msgs(nb);
+            for_each_estimator(nb, [&](int k) {
+                if (!g.dm[k]) return;
+                tcv_estimator *e = es[g.idx[k]];
+                tcv_window_desc d;
+                build_marg(e, e->marg_flag);
+                fill_desc(e, d, true, e->marg_flag);
+                rcs[k] = tcv_problem_from_window(&d, &g.M[k]);
+                g.drops[k] = e->m_drop.data(); g.ndrop[k] = (int)e->m_drop.size();
+                if (rcs[k] != TCV_OK) msgs[k] = tcv_last_error();
+            });
+            for (int k = 0; k < nb && g.rc == TCV_OK; k++) if (rcs[k] != TCV_OK) { g.rc = rcs[k]; tcv::set_error(msgs[k]); }
+            if (g.rc == TCV_OK) g.rc = tcv_batch_attach_marginalization(g.b, g.M.data(), g.drops.data(), g.ndrop.data());
+        }
     }
     for (int group = 1; group >= 0; group--) {
         Group &g = G[group];

@@ -2214,7 +2214,7 @@ int tcv_marg_attach(tcv_batch *b, tcv_problem *const *marg_problems, double *con
         if (marg_problems[w] && (!marg_drop || !marg_drop[w])) { set_error("marginalisation problem without a drop list"); return TCV_ERR_INVALID; }
     // the windows are packed by host threads, each into its own int / double pools (contiguous window ranges); the pools are then laid end
     // to end in pinned upload buffers and the headers' pool offsets shifted accordingly
-    const int nth = tcv::host_threads(std::max(1, std::min(b->n / 8, 16)));      // (inside tcv_batch_create's HostOp)
+    const int nth = tcv::host_threads(std::max(1, std::min(b->n <= 16 ? b->n : b->n / 8, 16)));      // (inside tcv_batch_create's HostOp; a lock-step frame's handful of windows: one each)
     std::vector<std::vector<int>> It(nth);
     std::vector<std::vector<double>> Dt(nth);
     std::vector<int> rcs(nth, TCV_OK);

@@ -33,7 +33,7 @@ EXPORTS = [
     "tcv_problem_from_window", "tcv_problem_num_parameter_blocks", "tcv_problem_num_residual_blocks",
     "tcv_problem_num_residuals", "tcv_problem_plan_stats", "tcv_solver_options_default", "tcv_solve", "tcv_marginalize",
     "tcv_prior_create", "tcv_prior_dims", "tcv_prior_export", "tcv_prior_export_schur", "tcv_prior_keep_block_addresses", "tcv_prior_destroy",
-    "tcv_batch_create", "tcv_batch_destroy", "tcv_batch_solve", "tcv_batch_marginalize", "tcv_batch_synchronize",
+    "tcv_batch_create", "tcv_batch_attach_marginalization", "tcv_batch_destroy", "tcv_batch_solve", "tcv_batch_marginalize", "tcv_batch_synchronize",
     "tcv_batch_download_states", "tcv_batch_get_summaries", "tcv_batch_get_prior", "tcv_batch_get_first_step",
     "tcv_batch_plan_stats", "tcv_batch_layout", "tcv_batch_stats", "tcv_batch_size",
     "tcv_eval_imu_factors", "tcv_eval_projection_factors", "tcv_eval_line_factors", "tcv_pose_plus", "tcv_preintegrate",
@@ -131,6 +131,7 @@ def lib():
         L.tcv_prior_destroy.argtypes = [vp]
         L.tcv_prior_destroy.restype = None
         L.tcv_batch_create.argtypes = [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.POINTER(_dp)), _ip, C.c_int]
+        L.tcv_batch_attach_marginalization.argtypes = [vp, C.POINTER(vp), C.POINTER(C.POINTER(_dp)), _ip]
         L.tcv_batch_destroy.argtypes = [vp]
         L.tcv_batch_destroy.restype = None
         L.tcv_batch_solve.argtypes = [vp, C.POINTER(SolverOptions), vp]
@@ -470,6 +471,13 @@ class Batch:
             self.marg_windows = spec.marg_windows
         self.h = C.c_void_p()
         check(lib().tcv_batch_create(C.byref(self.h), spec.arr, spec.marr, spec.dd, spec.nd, spec.n))
+
+    def attach_marginalization(self, marg_windows, marg_drops):
+        """tcv_batch_attach_marginalization: the marginalisation problems of a batch created without them (may overlap the batch's solve)"""
+        sp = BatchSpec(self.windows, marg_windows, marg_drops)
+        self._attached = sp
+        self.marg_windows = sp.marg_windows
+        check(lib().tcv_batch_attach_marginalization(self.h, sp.marr, sp.dd, sp.nd))
 
     def priors(self):
         """every window's prior in one call (tcv_batch_get_priors)"""

@@ -462,3 +462,41 @@ def test_batch_with_windows_that_are_only_solved(gpu):
             e0, e1, ed = b0.prior(k).export(), b1.prior(k).export(), pd[k].export()
             for key in ("J0", "r0"):
                 assert np.array_equal(e0[key], e1[key]) and np.array_equal(e0[key], ed[key]), (k, key)
+
+
+def test_marginalisation_problems_attached_while_the_solve_runs_give_the_same_priors(gpu):
+    """tcv_batch_attach_marginalization: a batch created without marginalisation problems takes them after its solve has been launched (their
+    packing and upload overlap the solve; the marginalisation then forms the IMU factor's sqrt_info itself instead of taking the solve's
+    export) -- states and priors bit for bit those of the batch that was created with them"""
+    tcv = gpu
+    B = 6
+    batch = synth.make_windows(9500, B)
+    wins = [synth.window_at(batch, k) for k in range(B)]
+    opts = tcv.default_options(8, True)
+
+    def run(attach_late):
+        W = [tcv.Window(w) for w in wins]
+        MW = [tcv.margin_old_window(w) for w in wins]
+        M = [tcv.Window(MW[k], share=W[k]) for k in range(B)]
+        drops = [tcv.margin_old_drops(W[k], MW[k]) for k in range(B)]
+        if attach_late:
+            b = tcv.Batch(W)
+            b.solve(opts); b.gauge_fix()
+            b.attach_marginalization(M, drops)
+            with pytest.raises(tcv.TcvError):
+                b.attach_marginalization(M, drops)      # once per batch
+        else:
+            b = tcv.Batch(W, M, drops)
+            b.solve(opts); b.gauge_fix()
+        b.marginalize(); b.synchronize(); b.download_states()
+        assert list(b.marg_status()) == [0] * B
+        b.download_priors(compact=True)
+        return [w.states() for w in W], [p.export() for p in b.priors()]
+
+    x0, p0 = run(False)
+    x1, p1 = run(True)
+    for k in range(B):
+        for key in ("pose", "sb", "ex", "lam"):
+            assert np.array_equal(x0[k][key], x1[k][key]), (k, key)
+        assert np.array_equal(p0[k]["J0"], p1[k]["J0"]) and np.array_equal(p0[k]["r0"], p1[k]["r0"])
+        assert all(np.array_equal(a, c) for a, c in zip(p0[k]["x0"], p1[k]["x0"]))
