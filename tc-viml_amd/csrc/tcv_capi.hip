@@ -1173,6 +1173,7 @@ extern "C" int tcv_batch_get_priors_device_async(tcv_batch *b, tcv_prior **out, 
     if (rc == TCV_OK && b->pending && !b->streams.empty()) {
         // the batch outlives this call with work in flight: from here on that work is an event, not the streams it runs on -- the calling
         // thread may end (its stream goes with it) before somebody asks for the status or destroys the batch
+        (void)tcv_marg_status_prefetch(b, (void *)b->last_stream);
         if (!b->ev_inflight) HIPCHK(hipEventCreateWithFlags(&b->ev_inflight, hipEventDisableTiming));
         HIPCHK(hipEventRecord(b->ev_inflight, b->last_stream));
         b->streams.clear();

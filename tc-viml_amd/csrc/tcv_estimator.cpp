@@ -910,6 +910,7 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
         if (g.rc == TCV_OK) g.rc = tcv_batch_get_summaries(g.b, g.sum.data(), nb);
         const double td2 = now_s();
         bool have_dev = false;
+        std::vector<std::shared_ptr<EstInflight>> retired;
         if (g.rc == TCV_OK && g.any_marg && marg_off_path) {      // the states are on the host: now the marginalisation, and its results as handles without a wait
             // (on the thread's main stream: the next frame's association round trip queues behind it, ~0.1 ms of a frame.  TCV_EST_MARG_AUX=1: on the
             // thread's second stream -- one host thread 2 570 - 2 720 against 2 590 windows/s, two host threads 2 490 - 2 550 against 2 940: two
@@ -931,9 +932,20 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
                 if (e->prev) {
                     const int stp = e->prev->status_of(e->prev_k);
                     if (stp != 0 && stp != 2) { g.est_rc[k] = TCV_ERR_NUMERIC; g.est_msg = "the previous frame's marginalisation failed (eigen-solver sweep cap or NaN): this window was solved on an invalid prior"; }
-                    e->prev.reset(); e->prev_k = -1;
+                    retired.push_back(std::move(e->prev)); e->prev.reset(); e->prev_k = -1;
                 }
             }
+        // the frames let go of above: their problems are destroyed on the worker threads (16 of them per frame of eight estimators: 0.16 ms
+        // one after the other), the batch by the last owner as usual
+        std::sort(retired.begin(), retired.end());
+        retired.erase(std::unique(retired.begin(), retired.end()), retired.end());      // (one reference per frame left: the estimators' went with their copies)
+        for (auto &fl : retired)
+            if (fl && fl.use_count() == 1) {
+                std::vector<tcv_problem *> all(fl->P); all.insert(all.end(), fl->M.begin(), fl->M.end());
+                fl->P.clear(); fl->M.clear();
+                for_each_estimator((int)all.size(), [&](int q) { if (all[q]) tcv_problem_destroy(all[q]); });
+            }
+        retired.clear();
         if (g.rc == TCV_OK && g.any_marg) {
             std::vector<std::string> msgs(nb);
             int cur_dev = 0;

@@ -1829,6 +1829,8 @@ struct MargState {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     size_t lds_bytes = 0;
     int grid = 0, nt = MARG_NT_WIDE;
+    int *h_status_pre = nullptr;      // pinned: [status | k0] copied behind the kernel by tcv_marg_status_prefetch (valid once the batch's work is waited for)
+    bool status_prefetched = false;
     bool ran = false;
     double *h_out = nullptr;          // pinned host copy of every window's result block (tcv_batch_download_priors), valid until the next run
     size_t h_stride = 0;              // doubles per window in h_out: MARG_OUT_STRIDE, or MARG_OUT_COMPACT (no A', b')
@@ -1845,6 +1847,7 @@ static void marg_free(tcv_batch *b) {
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     tcv::host_staging_release(s->h_out);
+    tcv::host_staging_release(s->h_status_pre);
     delete s;
     b->marg = nullptr;
 }
@@ -2332,6 +2335,19 @@ int tcv_marg_run(tcv_batch *b, void *stream) {
     }
     s->ran = true;
     s->h_valid = false;
+    s->status_prefetched = false;
+    return TCV_OK;
+}
+
+// the statuses on their way to the host behind the marginalisation kernel (tcv_batch_get_priors_device_async): whoever asks later, after
+// waiting for the batch, finds them in pinned memory instead of paying a blocking copy
+int tcv_marg_status_prefetch(tcv_batch *b, void *stream) {
+    MargState *s = (MargState *)b->marg;
+    if (!s || !s->ran) return TCV_OK;
+    if (!s->h_status_pre) s->h_status_pre = (int *)tcv::host_staging_acquire(sizeof(int) * 2 * (size_t)b->n);
+    if (!s->h_status_pre) return TCV_OK;      // (the blocking copy later)
+    const hipError_t e = hipMemcpyAsync(s->h_status_pre, s->d_status, sizeof(int) * 2 * (size_t)b->n, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    s->status_prefetched = e == hipSuccess;
     return TCV_OK;
 }
 
@@ -2379,8 +2395,11 @@ extern "C" int tcv_batch_marg_status(tcv_batch *b, int *out, int n) {
     if (!s || !s->ran || !out || n > b->n) { set_error("no marginalisation result"); return TCV_ERR_INVALID; }
     if (b->pending) if (int rc = tcv_batch_synchronize(b)) return rc;      // (a copy on the null stream is not ordered behind a non-blocking stream)
     std::vector<int> st(2 * (size_t)b->n);
-    hipError_t e = hipMemcpy(st.data(), s->d_status, sizeof(int) * st.size(), hipMemcpyDeviceToHost);
-    if (e != hipSuccess) return hip_fail(e, "hipMemcpy D2H");
+    if (s->status_prefetched) std::memcpy(st.data(), s->h_status_pre, sizeof(int) * st.size());      // (came down behind the kernel; the wait above covers it)
+    else {
+        const hipError_t e = hipMemcpy(st.data(), s->d_status, sizeof(int) * st.size(), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return hip_fail(e, "hipMemcpy D2H");
+    }
     for (int w = 0; w < n; w++) out[w] = (st[w] == 0 && st[b->n + w] < 0 && s->win[w].hdr.nblk != 0) ? -2 : st[w];      // -2: a NaN in the result
     return TCV_OK;
 }
