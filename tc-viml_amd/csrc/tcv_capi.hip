@@ -696,6 +696,18 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
         if (want == 1 && g_coop_helpers < 0 && !getenv("TCV_COOP_H")) want = 0;      // a single helper is not worth the hand-offs
         coop_h = want;
     }
+    auto plan_hash_of = [](const Packed &pk) -> unsigned long long {
+        const std::vector<int> &pints = pk.tmpl ? pk.tmpl->ints : pk.ints;
+        unsigned long long h = 0x9E3779B97F4A7C15ull ^ pints.size();
+        auto mix = [&](const int *p, size_t cnt) {
+            size_t i = 0;
+            for (; i + 1 < cnt; i += 2) { unsigned long long v; std::memcpy(&v, p + i, 8); h = (h ^ v) * 0xFF51AFD7ED558CCDull; h ^= h >> 29; }
+            if (i < cnt) { h = (h ^ (unsigned)p[i]) * 0xFF51AFD7ED558CCDull; h ^= h >> 29; }
+        };
+        mix(pints.data(), pints.size());
+        mix(reinterpret_cast<const int *>(&pk.hdr), sizeof(PlanHdr) / sizeof(int));
+        return h;
+    };
     auto pack_all = [&](int md, std::string &msg) -> int {
         const int nth = host_op.threads(std::min(n, 16));
         std::vector<int> rcs(n, TCV_OK);
@@ -704,19 +716,9 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
             for (int w = t; w < n; w += nth) {
                 rcs[w] = pack_problem(*problems[w], b->packed[w], nullptr, md, chain_lds, true, md == 0 ? coop_h : 0);      // plan + data size
                 if (rcs[w] != TCV_OK && msgs[t].empty()) msgs[t] = tcv_last_error();      // the message is thread-local
-                if (rcs[w] == TCV_OK) {      // hash of the plan for the structure de-duplication below
-                    const Packed &pk = b->packed[w];
-                    const std::vector<int> &pints = pk.tmpl ? pk.tmpl->ints : pk.ints;
-                    unsigned long long h = 0x9E3779B97F4A7C15ull ^ pints.size();
-                    auto mix = [&](const int *p, size_t cnt) {
-                        size_t i = 0;
-                        for (; i + 1 < cnt; i += 2) { unsigned long long v; std::memcpy(&v, p + i, 8); h = (h ^ v) * 0xFF51AFD7ED558CCDull; h ^= h >> 29; }
-                        if (i < cnt) { h = (h ^ (unsigned)p[i]) * 0xFF51AFD7ED558CCDull; h ^= h >> 29; }
-                    };
-                    mix(pints.data(), pints.size());
-                    mix(reinterpret_cast<const int *>(&pk.hdr), sizeof(PlanHdr) / sizeof(int));
-                    b->packed[w].plan_hash = h;
-                }
+                // hash of the plan for the structure de-duplication below (a plan out of the cache is de-duplicated by its template: hashed
+                // there, once per template, not once per window)
+                if (rcs[w] == TCV_OK && !b->packed[w].tmpl) b->packed[w].plan_hash = plan_hash_of(b->packed[w]);
             }
         };
         tcv::parallel_run(nth, work);
@@ -755,6 +757,7 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
         if (pid < 0) {
             // equal plans share one device copy: candidates by hash (computed with the packing, in parallel), confirmed by comparison -- the
             // replay's windows are all different (200 KB of plan each), the benchmark's all equal
+            if (pk.tmpl) pk.plan_hash = plan_hash_of(pk);
             std::vector<int> &cands = plan_by_hash[pk.plan_hash];
             for (int c : cands)
                 if (plan_src[c].second == pints.size() && std::memcmp(&b->plans[c], &pk.hdr, sizeof(PlanHdr)) == 0 &&
