@@ -363,3 +363,9 @@ def test_no_static_lds_in_the_two_per_cu_kernels(tcv, tmp_path):
     big = {k: v for k, v in seen.items() if "marg_kernel" in k or "solve_kernel" in k}
     assert len(big) >= 3, seen
     assert all(v == 0 for v in big.values()), big
+
+
+def test_device_memory_stats_without_a_device(tcv):
+    """tcv_device_memory_stats is plain bookkeeping of the library's allocator: callable without a device, all zeros before any allocation"""
+    live, cached, n = tcv.device_memory_stats()
+    assert (live, cached, n) == (0, 0, 0)
