@@ -69,6 +69,29 @@ int main() {
     CHECK(tcv_prior_keep_block_addresses(prior, keep.data()));                       // the caller applies addr_shift (estimator.cpp:2027-2039)
     std::printf("prior: m = %d, n = %d, %d kept blocks\n", m, n, nb);
     tcv_prior_destroy(prior);
+
+    // The same frame through the batched entry points, in the order a per-frame loop uses them with the marginalisation OFF the caller's
+    // path: the solve problems alone make the batch; the marginalisation problems are attached while the solve runs;
+    // the states come back as soon as solve + gauge fix are done; the marginalisation is launched behind them and its prior is handed on
+    // as a device-resident handle without a wait; its status is asked for later.
+    tcv_batch *batch = nullptr;
+    tcv_problem *solve_problems[1] = {problem}, *marg_problems[1] = {problem};      // (this toy marginalises with every factor of the window)
+    double *const *drops[1] = {drop};
+    const int ndrops[1] = {3};
+    CHECK(tcv_batch_create(&batch, solve_problems, nullptr, nullptr, nullptr, 1));
+    CHECK(tcv_batch_solve(batch, &opt, nullptr));
+    CHECK(tcv_batch_gauge_fix(batch, nullptr));
+    CHECK(tcv_batch_attach_marginalization(batch, marg_problems, drops, ndrops));
+    CHECK(tcv_batch_download_states(batch));                                         // the frame's result: publish the pose here
+    CHECK(tcv_batch_marginalize(batch, nullptr));
+    tcv_prior *next_prior[1] = {nullptr};
+    CHECK(tcv_batch_get_priors_device_async(batch, next_prior, 1));                  // no wait; the next tcv_batch_create is ordered behind the kernel
+    int status[1] = {-1};
+    CHECK(tcv_batch_marg_status(batch, status, 1));                                  // (waits) 0: the prior is good
+    CHECK(tcv_prior_dims(next_prior[0], &m, &n, &nb, &xs));
+    std::printf("batched frame: marginalisation status %d, prior m = %d, n = %d, device-resident %d\n", status[0], m, n, tcv_prior_is_device_resident(next_prior[0]));
+    tcv_prior_destroy(next_prior[0]);
+    tcv_batch_destroy(batch);
     tcv_problem_destroy(problem);
     return 0;
 }

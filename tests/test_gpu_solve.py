@@ -214,6 +214,7 @@ def test_cxx_examples_run_on_the_device(gpu, tmp_path):
     b = re.search(r"solve: (\d+) iterations, cost (\S+) -> (\S+), inverse depth (\S+)", outs[1]).groups()
     assert a == b and float(a[2]) < 1e-12 * float(a[1]) and abs(float(a[3]) - 0.1) < 1e-3
     assert "prior: m = 16" in outs[0] and "prior: m = 16" in outs[1] and "first -> para_Pose[0]: yes" in outs[1]
+    assert "batched frame: marginalisation status 0, prior m = 16" in outs[0] and "device-resident 1" in outs[0]      # (the no-wait frame loop of INTEGRATION.md 3a)
 
 
 def test_max_solver_time_stops_the_iteration_loop(gpu):
