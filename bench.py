@@ -283,16 +283,18 @@ def stream_figures(tcv, torch, keep, B_stream: int = 512, rounds: int = 4, wins=
     def worker(h, st):
         tcv.check(tcv.lib().tcv_set_device(local))      # the current HIP device is per host thread
         for _ in range(rounds):
-            one_pass(h, st.cuda_stream)
+            one_pass(h, st)
 
-    streams = [torch.cuda.Stream() for _ in range(NTH)]
+    # (TCV_STREAM_THREAD: every host thread launches on its own library stream, the one its uploads and downloads use anyway -- one stream
+    # per thread instead of two on the runtime's four hardware queues)
+    streams = [tcv.STREAM_THREAD for _ in range(NTH)]
 
     def timed():
         for k in stage:
             stage[k] = 0.0
-        one_pass(halves[0], streams[0].cuda_stream)          # warm-up
+        one_pass(halves[0], streams[0])          # warm-up
         for _ in range(2):
-            one_pass(halves[0], streams[0].cuda_stream, stage)
+            one_pass(halves[0], streams[0], stage)
         t0 = time.perf_counter()
         th = [threading.Thread(target=worker, args=(halves[i], streams[i])) for i in range(NTH)]
         for t in th:

@@ -20,6 +20,7 @@
 #ifndef TCV_H
 #define TCV_H
 
+#include <stddef.h>
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -239,7 +240,10 @@ int tcv_batch_attach_marginalization(tcv_batch *b, tcv_problem *const *marg_prob
 void tcv_batch_destroy(tcv_batch *b);
 /* one pass of the hot path over the batch: solve every window from its uploaded initial state
  * (and, if marg problems were given, marginalise at the solution).  Asynchronous on `hip_stream`
- * (a hipStream_t cast to void*, NULL = default stream); inputs and outputs stay in HBM. */
+ * (a hipStream_t cast to void*, NULL = default stream, TCV_STREAM_THREAD = the calling thread's own stream, on which this library
+ * issues its uploads, splices and downloads anyway: host threads that each drive their own batches then use one stream each -- the
+ * runtime maps streams onto a handful of hardware queues, fewer streams collide less); inputs and outputs stay in HBM. */
+#define TCV_STREAM_THREAD ((void *)(~(size_t)0))
 int tcv_batch_solve(tcv_batch *b, const tcv_solver_options *o, void *hip_stream);
 int tcv_batch_marginalize(tcv_batch *b, void *hip_stream);
 /* Estimator::double2vector() gauge fix (estimator.cpp:1537-1581) followed by vector2double() (:1492-1512), in place

@@ -1002,6 +1002,7 @@ int tcv_batch_enter_stream(tcv_batch *b, void *hip_stream) {
 
 extern "C" int tcv_batch_solve(tcv_batch *b, const tcv_solver_options *o, void *hip_stream) {
     if (!b || !o) return TCV_ERR_INVALID;
+    if (hip_stream == TCV_STREAM_THREAD) hip_stream = (void *)tcv::util_stream();
     SolveArgs a;
     std::memset(&a, 0, sizeof a);
     a.win = b->d_win; a.plans = b->d_plans; a.plan_base = b->d_plan_base; a.ipool = b->d_ipool; a.dpool = b->d_dpool;
@@ -1051,6 +1052,7 @@ extern "C" int tcv_batch_solve(tcv_batch *b, const tcv_solver_options *o, void *
 }
 extern "C" int tcv_batch_marginalize(tcv_batch *b, void *hip_stream) {
     if (!b) return TCV_ERR_INVALID;
+    if (hip_stream == TCV_STREAM_THREAD) hip_stream = (void *)tcv::util_stream();
     if (int rc = tcv_batch_enter_stream(b, hip_stream)) return rc;
     return tcv_marg_run(b, hip_stream);
 }

@@ -158,6 +158,7 @@ extern "C" int tcv_gauge_fix(int n, const double *R0, const double *P0, const do
 
 extern "C" int tcv_batch_gauge_fix(tcv_batch *b, void *hip_stream) {
     if (!b || !b->solved) { set_error("batch_gauge_fix: batch has not been solved"); return TCV_ERR_INVALID; }
+    if (hip_stream == TCV_STREAM_THREAD) hip_stream = (void *)tcv::util_stream();
     for (auto &H : b->plans)
         if (H.n_frames <= 0 || H.n_frames > 64) { set_error("batch_gauge_fix: problem carries no frame table (tcv_problem_set_frames)"); return TCV_ERR_INVALID; }
     if (int rc = tcv_batch_enter_stream(b, hip_stream)) return rc;

@@ -45,6 +45,9 @@ EXPORTS = [
 ]
 
 
+STREAM_THREAD = C.c_void_p(2 ** (8 * C.sizeof(C.c_void_p)) - 1)      # TCV_STREAM_THREAD: the calling thread's own stream
+
+
 class ImuPreintegration(C.Structure):
     _fields_ = [("delta_p", C.c_double * 3), ("delta_q", C.c_double * 4), ("delta_v", C.c_double * 3),
                 ("linearized_ba", C.c_double * 3), ("linearized_bg", C.c_double * 3), ("sum_dt", C.c_double),

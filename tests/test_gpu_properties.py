@@ -176,3 +176,29 @@ def test_valu_wave_sum_reproduces_the_shuffle_tree(gpu, tmp_path):
                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "0 of 4096 sums differ" in r.stdout, r.stdout + r.stderr
+
+
+def test_the_calling_threads_own_stream_gives_the_same_bits(gpu):
+    """TCV_STREAM_THREAD (include/tcv.h): solve / gauge fix / marginalise on the calling thread's own library stream -- the results of the
+    default stream, bit for bit"""
+    tcv = gpu
+    B = 6
+    batch = synth.make_windows(9600, B)
+    wins = [synth.window_at(batch, k) for k in range(B)]
+    opts = tcv.default_options(8, True)
+
+    def run(stream):
+        W = [tcv.Window(w) for w in wins]
+        MW = [tcv.margin_old_window(w) for w in wins]
+        M = [tcv.Window(MW[k], share=W[k]) for k in range(B)]
+        b = tcv.Batch(W, M, [tcv.margin_old_drops(W[k], MW[k]) for k in range(B)])
+        b.solve(opts, stream); b.gauge_fix(stream); b.marginalize(stream); b.synchronize(); b.download_states()
+        b.download_priors(compact=True)
+        return [w.states() for w in W], [p.export() for p in b.priors()]
+
+    x0, p0 = run(None)
+    x1, p1 = run(tcv.STREAM_THREAD)
+    for k in range(B):
+        for key in ("pose", "sb", "ex", "lam"):
+            assert np.array_equal(x0[k][key], x1[k][key])
+        assert np.array_equal(p0[k]["J0"], p1[k]["J0"]) and np.array_equal(p0[k]["r0"], p1[k]["r0"])
