@@ -123,12 +123,11 @@ struct ImuBuf {
 
 }  // namespace
 
-// A lock-step frame whose marginalisation was left running when tcv_estimators_optimize returned (device-resident state): the batch and
-// its problems, shared by the estimators of the frame; each asks for the status of its own window at its next frame (or lets go of it when
+// A lock-step frame whose marginalisation was left running when tcv_estimators_optimize returned (device-resident state): its batch,
+// shared by the estimators of the frame; each asks for the status of its own window at its next frame (or lets go of it when
 // it is reset / destroyed), the last one to let go destroys the batch.
 struct EstInflight {
     tcv_batch *b = nullptr;
-    std::vector<tcv_problem *> P, M;
     std::vector<int> status;
     bool have_status = false;
     std::mutex mu;
@@ -148,8 +147,6 @@ struct EstInflight {
     }
     ~EstInflight() {
         if (b) tcv_batch_destroy(b);      // (waits for work in flight)
-        for (auto *p : P) if (p) tcv_problem_destroy(p);
-        for (auto *p : M) if (p) tcv_problem_destroy(p);
     }
 };
 
@@ -910,7 +907,6 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
         if (g.rc == TCV_OK) g.rc = tcv_batch_get_summaries(g.b, g.sum.data(), nb);
         const double td2 = now_s();
         bool have_dev = false;
-        std::vector<std::shared_ptr<EstInflight>> retired;
         if (g.rc == TCV_OK && g.any_marg && marg_off_path) {      // the states are on the host: now the marginalisation, and its results as handles without a wait
             // (on the thread's main stream: the next frame's association round trip queues behind it, ~0.1 ms of a frame.  TCV_EST_MARG_AUX=1: on the
             // thread's second stream -- one host thread 2 570 - 2 720 against 2 590 windows/s, two host threads 2 490 - 2 550 against 2 940: two
@@ -932,20 +928,9 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
                 if (e->prev) {
                     const int stp = e->prev->status_of(e->prev_k);
                     if (stp != 0 && stp != 2) { g.est_rc[k] = TCV_ERR_NUMERIC; g.est_msg = "the previous frame's marginalisation failed (eigen-solver sweep cap or NaN): this window was solved on an invalid prior"; }
-                    retired.push_back(std::move(e->prev)); e->prev.reset(); e->prev_k = -1;
+                    e->prev.reset(); e->prev_k = -1;      // (the last estimator of that frame to let go destroys its batch)
                 }
             }
-        // the frames let go of above: their problems are destroyed on the worker threads (16 of them per frame of eight estimators: 0.16 ms
-        // one after the other), the batch by the last owner as usual
-        std::sort(retired.begin(), retired.end());
-        retired.erase(std::unique(retired.begin(), retired.end()), retired.end());      // (one reference per frame left: the estimators' went with their copies)
-        for (auto &fl : retired)
-            if (fl && fl.use_count() == 1) {
-                std::vector<tcv_problem *> all(fl->P); all.insert(all.end(), fl->M.begin(), fl->M.end());
-                fl->P.clear(); fl->M.clear();
-                for_each_estimator((int)all.size(), [&](int q) { if (all[q]) tcv_problem_destroy(all[q]); });
-            }
-        retired.clear();
         if (g.rc == TCV_OK && g.any_marg) {
             std::vector<std::string> msgs(nb);
             int cur_dev = 0;
@@ -967,9 +952,11 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
         }
         const double td3 = now_s();
         if (g.rc == TCV_OK && g.any_marg && marg_off_path && have_dev) {      // the batch lives on until its marginalisation has been asked about
+            // (the batch alone: its problems were read for the last time by tcv_batch_download_states / tcv_batch_attach_marginalization and
+            // go now, like the old prior they point to)
             auto fl = std::make_shared<EstInflight>();
-            fl->b = g.b; fl->P = g.P; fl->M = g.M;
-            g.b = nullptr; g.P.assign(nb, nullptr); g.M.assign(nb, nullptr);
+            fl->b = g.b;
+            g.b = nullptr;
             for (int k = 0; k < nb; k++) if (g.dm[k] && g.est_rc[k] == TCV_OK) { es[g.idx[k]]->prev = fl; es[g.idx[k]]->prev_k = k; }
         }
         if (g.b) tcv_batch_destroy(g.b);
