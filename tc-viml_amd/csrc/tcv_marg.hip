@@ -2466,7 +2466,10 @@ int tcv_marg_get_prior(tcv_batch *b, int window, tcv_prior **out) {
 int tcv_marg_get_priors_device(tcv_batch *b, tcv_prior **out, int n, bool nowait) {
     MargState *s = (MargState *)b->marg;
     if (!s || !s->ran || n != b->n) { set_error("no marginalisation result (or n is not the batch size)"); return TCV_ERR_INVALID; }
-    if (nowait && !(s->out_blob && s->out_blob->ready)) nowait = false;      // (no event to order consumers by: wait as usual)
+    if (nowait && !(s->out_blob && s->out_blob->ready)) {      // (no event to order consumers by: wait as usual)
+        nowait = false;
+        if (b->pending) if (int rcs = tcv_batch_synchronize(b)) return rcs;
+    }
     std::vector<int> st(2 * (size_t)n, 0);
     if (nowait) { for (int w = 0; w < n; w++) st[n + w] = -1; }      // status unknown here (tcv_batch_marg_status later), k0 read on the device
     else {
