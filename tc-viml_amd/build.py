@@ -73,8 +73,10 @@ def _compile(out: str, verbose: bool, extra, opt: str = "-O3", link_extra=()) ->
     objdir = os.path.join(HERE, "build", os.path.basename(out).replace(".so", ""))
     os.makedirs(objdir, exist_ok=True)
     jobs = [(f, os.path.join(objdir, f + ".o"), []) for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
-    jobs.append(("tcv_solve.hip", os.path.join(objdir, "tcv_solve_chain.o"), ["-DTCV_SOLVE_CHAIN_TU=1"]))
-    jobs.append(("tcv_solve.hip", os.path.join(objdir, "tcv_solve_coop.o"), ["-DTCV_SOLVE_COOP_TU=1"]))      # the cooperative small-batch kernel
+    # (-DTCV_CAMW_CONST: the width of the camera-space vectors as a literal -- windows with a relocalisation pose, whose vectors are wider,
+    # run on the ProjectionTdFactor instance below, tcv_capi.hip tcv_batch_solve; the cooperative mode does not take them)
+    jobs.append(("tcv_solve.hip", os.path.join(objdir, "tcv_solve_chain.o"), ["-DTCV_SOLVE_CHAIN_TU=1", "-DTCV_CAMW_CONST=1"]))
+    jobs.append(("tcv_solve.hip", os.path.join(objdir, "tcv_solve_coop.o"), ["-DTCV_SOLVE_COOP_TU=1", "-DTCV_CAMW_CONST=1"]))      # the cooperative small-batch kernel
     jobs.append(("tcv_solve.hip", os.path.join(objdir, "tcv_solve_chain_td.o"), ["-DTCV_SOLVE_CHAIN_TD_TU=1"]))      # the chain kernel with ProjectionTdFactor
 
     def one(job):

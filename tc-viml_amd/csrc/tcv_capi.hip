@@ -1012,7 +1012,10 @@ extern "C" int tcv_batch_solve(tcv_batch *b, const tcv_solver_options *o, void *
     a.nwin = b->n; a.state_stride = b->state_stride; a.delta_stride = b->delta_stride; a.scratch_stride = tcv_solve_scratch_doubles() + b->hcl_cap;
     a.max_iterations = o->max_num_iterations; a.fixed_iterations = o->fixed_iterations; a.use_mfma = o->use_mfma;
     a.chain = b->chain ? 1 : 0; a.chain_td = 0;
-    if (b->chain) for (int w = 0; w < b->n; w++) if (b->packed[w].hdr.flags & 1) { a.chain_td = 1; break; }      // ESTIMATE_TD windows: the kernel instance with ProjectionTdFactor
+    // ESTIMATE_TD windows: the kernel instance with ProjectionTdFactor.  It also takes the windows with a relocalisation pose (camera vectors 184
+    // wide, PlanHdr::camw): the width is a literal in the instance every shipped configuration runs (build.py: -DTCV_CAMW_CONST for that
+    // translation unit; read from the plan it cost the benchmark 0.3 %), a plan field in this one
+    if (b->chain) for (int w = 0; w < b->n; w++) if ((b->packed[w].hdr.flags & 1) || b->packed[w].hdr.camw != (int)CAM_W) { a.chain_td = 1; break; }
     a.imublk = b->d_imublk; a.spill = b->d_spill; a.spill_stride = b->spill_stride;
     a.max_ticks = 0;
     a.sqrt_out = b->d_sqrt_out;

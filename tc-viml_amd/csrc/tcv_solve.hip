@@ -68,7 +68,8 @@ enum { PH_SETUP = 0, PH_VIS_EVAL, PH_VIS_GATHER, PH_LM, PH_SCHUR, PH_ZERO, PH_IM
        PH_COST_RED, PH_FIN_SCALE, PH_FIN_CAUCHY, PH_FIN_PASS, PH_CHOL_DIAG, PH_CHOL_TRSM, PH_CHOL_UPD, PH_BACK, PH_LM_BACK,
        PH_DOGLEG, PH_PLUS, PH_NORMS, PH_OTHER, PH_CHAIN_FWD, PH_CHAIN_BWD, PH_CH_A, PH_CH_B, PH_CH_C, PH_CH_D, PH_COUNT = 32 };
 
-// (developer A/B: -DTCV_CAMW_CONST builds the kernels with the camera-vector width as a literal, i.e. without relocalisation windows)
+// (-DTCV_CAMW_CONST: the camera-vector width as a literal -- the chain and cooperative translation units, build.py; windows with a relocalisation
+// pose go to the ProjectionTdFactor instance, which reads the width from the plan)
 #ifdef TCV_CAMW_CONST
 #define TCV_CAMW(P) ((int)CAM_W)
 #else
