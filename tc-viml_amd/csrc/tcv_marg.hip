@@ -1800,11 +1800,11 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((disable_tail_calls)) _
         if (tid == 0) ((gbl_i *)Aarg.out_status)[win] = (sweeps1 >= 24 || sweeps2 == 124) ? 1 : (sweeps2 >= 100 ? 2 : 0);   // 1: a Jacobi sweep hit its cap, 2: A' went through the Jacobi safety net
         if (tid == 0) { out[MARG_OUT_X + MARG_MAX_X] = sweeps1; out[MARG_OUT_X + MARG_MAX_X + 1] = sweeps2; }
         __syncthreads();
-        if (tid == 0) {
-            int k0 = 0;
-            for (int j = 0; j < n; j++) k0 += (lam[j] > 1e-8) ? 0 : 1;
+        if (tid < 64) {      // (the first wavefront counts, two eigenvalues per lane: n <= 80; one lane walking them held its wavefront back at the next window's first barrier)
+            const bool z0 = tid < n && !(lam[tid] > 1e-8), z1 = tid + 64 < n && !(lam[tid + 64] > 1e-8);
+            int k0 = __popcll(__ballot(z0)) + __popcll(__ballot(z1));
             if (k0 >= n) k0 = n > 0 ? n - 1 : 0;
-            ((gbl_i *)Aarg.out_status)[Aarg.nwin + win] = (rot[156] != 0.0) ? -1 : k0;
+            if (tid == 0) ((gbl_i *)Aarg.out_status)[Aarg.nwin + win] = (rot[156] != 0.0) ? -1 : k0;
         }
     }
 }
