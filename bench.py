@@ -509,7 +509,7 @@ class ReplayEngine:
     def __init__(self, tcv, replay, stream_ids, n_frames, features, lines, groups, local):
         self.tcv, self.local = tcv, local
         seqs = list(replay.EUROC_SEQUENCES)
-        streams = [replay.simulate_stream_euroc(seqs[s % len(seqs)], n_frames, start_s=0.5 + 3.0 * (s // len(seqs)), max_features=features,
+        streams = [replay.simulate_stream_euroc(seqs[s % len(seqs)], n_frames, start_s=(0.5 + 3.0 * (s // len(seqs))) % max(3.0, 33.0 - 0.1 * n_frames), max_features=features,
                                                 max_lines=lines, associate=True) for s in stream_ids]
         G = max(1, min(groups, len(streams)))
         self.ls = [replay.NativeLockstep(streams[g::G], num_iterations=SOLVER_ITERATIONS) for g in range(G)] if streams else []
