@@ -617,9 +617,12 @@ def replay_figures(tcv, local, streams=8, groups=2, steps=60, warmup=10):
     """the replay number of the default line (one GPU): optimised windows per second of `streams` EuRoC-trajectory streams"""
     import replay
     eng = ReplayEngine(tcv, replay, list(range(streams)), replay.WINDOW_SIZE + 1 + warmup + steps, 60, 8, groups, local)
+    import torch
     eng.run(warmup)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     n = eng.run(steps)
+    torch.cuda.synchronize()      # (the last frame's marginalisation is launched behind the states the call returns with)
     dt = time.perf_counter() - t0
     return {"replay_windows_per_s": n / dt,
             "replay_note": f"{streams} EuRoC-trajectory streams (60 features + 8 line tracks per frame, association in the loop) through the native estimator on "
