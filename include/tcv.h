@@ -402,6 +402,11 @@ int tcv_eval_line_factors(int n, const double *line_data, const double K[9], con
 /* PoseLocalParameterization::Plus pose_local_parameterization.cpp:3-19: x n x 7, delta n x 6 */
 int tcv_pose_plus(int n, const double *x, const double *delta, double *x_plus_delta);
 
+/* Measurement aid (no reference counterpart; SURVEY.md 8(d) "FP64 peak ... microbench it"): the FP64 rate of the current device,
+ * measured with dependence-free chains of v_fma_f64 and of v_mfma_f64_16x16x4_f64 on every CU.
+ * out4 = { vector FMA TFLOP/s, MFMA TFLOP/s, compute units, shader clock reported by the runtime [MHz] }. */
+int tcv_microbench_fp64(double *out4);
+
 #ifdef __cplusplus
 }
 #endif

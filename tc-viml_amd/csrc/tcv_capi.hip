@@ -161,7 +161,15 @@ ThreadStreams &thread_streams() { thread_local ThreadStreams mine; return mine; 
 // A call that leaves its commands in flight on the calling thread's stream (tcv_preintegrate_device: nobody on the host needs the result)
 // parks the pinned staging buffer and the device input blob here instead of waiting for the stream; they go back to their pools at the
 // thread's next wait on that stream (every tcv_batch_create ends with one).
-void defer_release(void *host_staging, void *dev_buf, hipStream_t st) { thread_streams().deferred.push_back(Deferred{host_staging, dev_buf, st}); }
+// The list is bounded: a thread that pre-integrates and never creates a batch (or whose frames keep failing before tcv_batch_create) would
+// otherwise pin host and device memory until it ends -- at DEFER_MAX parked commands the stream is drained and its buffers released.
+enum { DEFER_MAX = 32 };
+void flush_deferred(hipStream_t st);
+void defer_release(void *host_staging, void *dev_buf, hipStream_t st) {
+    std::vector<Deferred> &v = thread_streams().deferred;
+    if (v.size() >= DEFER_MAX) { (void)(st ? hipStreamSynchronize(st) : hipDeviceSynchronize()); flush_deferred(st); }
+    v.push_back(Deferred{host_staging, dev_buf, st});
+}
 void flush_deferred(hipStream_t st) {
     std::vector<Deferred> &v = thread_streams().deferred;
     size_t k = 0;
@@ -172,14 +180,34 @@ void flush_deferred(hipStream_t st) {
     v.resize(k);
 }
 namespace {
+// Streams of host threads that have ended, per device.  A thread's stream is drained and parked here instead of being destroyed: a batch
+// that ran on it (TCV_STREAM_THREAD, the native estimator) may still hold the handle in tcv_batch::streams / last_stream, and a
+// hipStreamSynchronize / hipEventRecord on a destroyed stream is an error (round-4 advisor finding).  The next new thread takes a parked
+// stream over, so the process never holds more streams than it had live threads at once -- which is what keeps two LIVE threads off one
+// hardware queue (see above).  Leaked on purpose, like the device pool.
+struct StreamPark { std::mutex mu; std::multimap<int, hipStream_t> idle; };
+StreamPark &stream_park() { static StreamPark *p = new StreamPark(); return *p; }
+hipStream_t take_parked_stream(int dev) {
+    StreamPark &P = stream_park();
+    std::lock_guard<std::mutex> g(P.mu);
+    auto it = P.idle.find(dev);
+    if (it == P.idle.end()) return nullptr;
+    hipStream_t st = it->second;
+    P.idle.erase(it);
+    return st;
+}
 ThreadStreams::~ThreadStreams() {
     for (auto &kv : m) {
         if (!kv.second) continue;
         if (!main_thread || !deferred.empty()) (void)hipStreamSynchronize(kv.second);
-        if (!main_thread) (void)hipStreamDestroy(kv.second);
     }
     for (auto &x : deferred) { host_staging_release(x.h); (void)dev_free(x.d); }
-    if (!main_thread) for (auto &kv : aux) if (kv.second) { (void)hipStreamSynchronize(kv.second); (void)hipStreamDestroy(kv.second); }
+    if (main_thread) return;      // (the main thread's streams are left to the runtime's own teardown at process exit)
+    for (auto &kv : aux) if (kv.second) (void)hipStreamSynchronize(kv.second);
+    StreamPark &P = stream_park();
+    std::lock_guard<std::mutex> g(P.mu);
+    for (auto &kv : m) if (kv.second) P.idle.emplace(kv.first, kv.second);
+    for (auto &kv : aux) if (kv.second) { bool own = true; for (auto &k2 : m) if (k2.second == kv.second) own = false; if (own) P.idle.emplace(kv.first, kv.second); }
 }
 }  // namespace
 // the calling thread's second stream (created at first use): the native estimator runs a frame's marginalisation there, beside the next
@@ -191,8 +219,8 @@ hipStream_t aux_stream() {
     auto it = mine.aux.find(dev);
     if (it != mine.aux.end()) return it->second;
     (void)util_stream();      // (sets main_thread)
-    hipStream_t st = nullptr;
-    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = util_stream();
+    hipStream_t st = take_parked_stream(dev);
+    if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = util_stream();
     mine.aux.emplace(dev, st);
     return st;
 }
@@ -207,8 +235,8 @@ hipStream_t util_stream() {
 #else
     mine.main_thread = true;
 #endif
-    hipStream_t st = nullptr;
-    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = nullptr;      // the default stream: slower, still correct
+    hipStream_t st = take_parked_stream(dev);
+    if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = nullptr;      // the default stream: slower, still correct
     mine.m.emplace(dev, st);
     return st;
 }
@@ -663,6 +691,7 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
     b->n = n;
     b->problems.assign(problems, problems + n);
     b->packed.resize(n);
+    { int cur = -1; if (hipGetDevice(&cur) != hipSuccess) cur = -1; for (auto &pk : b->packed) pk.batch_dev = cur; }
     std::unordered_map<unsigned long long, std::vector<int>> plan_by_hash;   // structure de-duplication
     std::vector<std::pair<const int *, size_t>> plan_src;                    // per device plan: its ints on the host
     size_t ipool_size = 0;
@@ -1158,12 +1187,16 @@ extern "C" int tcv_batch_get_priors(tcv_batch *b, tcv_prior **out, int n) {
     std::vector<int> rcs(nth, TCV_OK);
     std::vector<std::string> msgs(nth);
     auto work = [&](int t) {
-        if (nth > 1) (void)hipSetDevice(b->coop_dev);      // a new thread starts on device 0: the batch's buffers live on its own device
+        // a worker thread starts on device 0: the batch's buffers live on its own device.  The CALLER runs this lambda too (parallel_run):
+        // whatever thread it is, its current device is put back
+        int prev = -1;
+        if (nth > 1 && hipGetDevice(&prev) == hipSuccess && prev != b->coop_dev) (void)hipSetDevice(b->coop_dev); else prev = -1;
         for (int k = t; k < n; k += nth) {
             if (!tcv_marg_has_problem(b, k)) continue;      // not marginalised: out[k] stays NULL
             const int rc = tcv_marg_get_prior(b, k, &out[k]);
-            if (rc != TCV_OK) { rcs[t] = rc; msgs[t] = tcv_last_error(); return; }
+            if (rc != TCV_OK) { rcs[t] = rc; msgs[t] = tcv_last_error(); break; }
         }
+        if (prev >= 0) (void)hipSetDevice(prev);
     };
     tcv::parallel_run(nth, work);
     for (int t = 0; t < nth; t++)
@@ -1182,8 +1215,16 @@ extern "C" int tcv_batch_get_priors_device_async(tcv_batch *b, tcv_prior **out, 
         // the batch outlives this call with work in flight: from here on that work is an event, not the streams it runs on -- the calling
         // thread may end (its stream goes with it) before somebody asks for the status or destroys the batch
         (void)tcv_marg_status_prefetch(b, (void *)b->last_stream);
-        if (!b->ev_inflight) HIPCHK(hipEventCreateWithFlags(&b->ev_inflight, hipEventDisableTiming));
-        HIPCHK(hipEventRecord(b->ev_inflight, b->last_stream));
+        hipError_t e = hipSuccess;
+        if (!b->ev_inflight) e = hipEventCreateWithFlags(&b->ev_inflight, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventRecord(b->ev_inflight, b->last_stream);
+        if (e != hipSuccess) {
+            // no event to track the work by: wait for it here (the streams are still this batch's) -- the handles stay valid, the call merely
+            // was not asynchronous; if even that fails the handles are destroyed: "on an error out[] is all NULL" (include/tcv.h)
+            const int rcs = tcv_batch_synchronize(b);
+            if (rcs != TCV_OK) { for (int k = 0; k < n; k++) if (out[k]) { tcv_prior_destroy(out[k]); out[k] = nullptr; } return rcs; }
+            return TCV_OK;
+        }
         b->streams.clear();
         b->wait_inflight = true;
     }

@@ -93,6 +93,8 @@ struct Packed {
     unsigned long long plan_hash = 0;   // of hdr + plan ints (tcv_batch_create: structure de-duplication without copying 200 KB keys)
     int dev_imu_doubles = 0;         // > 0: every IMU factor of the window is device-resident: n_imu x 287 doubles in the device-only tail (WinHdr::d_imu points there)
     bool prior_k0_deferred = false;  // the prior's zero-row count is read on the device (tcv_prior::k0 < 0): WinHdr::prior_k0 is patched by the splice kernel
+    int batch_dev = -1;              // device the batch is created on (tcv_batch_create; -1: no device-resident input is spliced): a prior / pre-integration
+                                     // resident on ANOTHER device goes through the host (peer access is never enabled)
     int dev_prior_doubles = 0;       // > 0: the window's prior is device-resident: doubles of its J0 | r0 | x0 region, which lives in the batch's
                                      // device-only tail (not in the uploaded slice) and is filled by the splice kernel of tcv_batch_create
     // host-side maps for download

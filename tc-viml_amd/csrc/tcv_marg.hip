@@ -1056,7 +1056,6 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((disable_tail_calls)) _
         }
         for (int i = tid; i < pos; i += MARG_NT) { bv[i] = 0.0; cvec[i] = 0.0; }
         if (tid < 8) lmacc[tid] = 0.0;
-        if (tid == 0) rot[156] = 0.0;      // "the result holds a NaN" (set by the output phase, read behind the window's last barrier)
         cst_d *misc = dp + H.d_misc;
         const double G3[3] = {misc[0], misc[1], misc[2]};
         __syncthreads();
@@ -1790,22 +1789,25 @@ __global__ void __launch_bounds__(MARG_NT) __attribute__((disable_tail_calls)) _
         }
         // what a device-resident consumer of this prior needs on the host (tcv_batch_get_priors_device): the number of leading rows of
         // J0 | r0 that are exact zeros -- the thresholded eigenvalues rank first and their rows are 0 * v --, capped like
-        // tcv_packed.h prior_zero_rows() (one row is kept); -1: the result holds a NaN
-        // (the flag is a spare LDS double zeroed at the start of the window and read behind the window's last barrier: no barrier of its own,
-        // and NOT __syncthreads_or, whose work-group reduction brings a static LDS variable -- 80 KiB + 4 bytes per workgroup is one
-        // workgroup per CU instead of two: 0.85 -> 1.40 ms per 1024 windows, measured)
-        if (bad) rot[156] = 1.0;
+        // tcv_packed.h prior_zero_rows() (one row is kept); -1: the result holds a NaN.
+        // Nothing of the window's LDS is read behind its last barrier: the other wavefronts are in the next window of the loop by then,
+        // whose carve-up of the LDS (r1 / r2 / nx differ between MARGIN_OLD and SECOND_NEW windows) puts x[] / bv[] / cvec[] over this
+        // window's lam[] (round-4 advisor finding).  The count is taken here -- lam[] is final since the barrier above --, stored by lane 0
+        // BEFORE the barrier, and a thread that saw a NaN overwrites it with -1 BEHIND the barrier from its register (no LDS flag, and NOT
+        // __syncthreads_or, whose work-group reduction brings a static LDS variable -- 80 KiB + 4 bytes per workgroup is one workgroup per
+        // CU instead of two: 0.85 -> 1.40 ms per 1024 windows, measured).
+        if (tid < 64) {      // (the first wavefront counts, two eigenvalues per lane: n <= 80)
+            const bool z0 = tid < n && !(lam[tid] > 1e-8), z1 = tid + 64 < n && !(lam[tid + 64] > 1e-8);
+            int k0 = __popcll(__ballot(z0)) + __popcll(__ballot(z1));
+            if (k0 >= n) k0 = n > 0 ? n - 1 : 0;
+            if (tid == 0) ((gbl_i *)Aarg.out_status)[Aarg.nwin + win] = k0;
+        }
         for (int i = tid; i < H.nx; i += MARG_NT) out[MARG_OUT_X + i] = x[i];
         MARG_MARK(8);
         if (tid == 0) ((gbl_i *)Aarg.out_status)[win] = (sweeps1 >= 24 || sweeps2 == 124) ? 1 : (sweeps2 >= 100 ? 2 : 0);   // 1: a Jacobi sweep hit its cap, 2: A' went through the Jacobi safety net
         if (tid == 0) { out[MARG_OUT_X + MARG_MAX_X] = sweeps1; out[MARG_OUT_X + MARG_MAX_X + 1] = sweeps2; }
         __syncthreads();
-        if (tid < 64) {      // (the first wavefront counts, two eigenvalues per lane: n <= 80; one lane walking them held its wavefront back at the next window's first barrier)
-            const bool z0 = tid < n && !(lam[tid] > 1e-8), z1 = tid + 64 < n && !(lam[tid + 64] > 1e-8);
-            int k0 = __popcll(__ballot(z0)) + __popcll(__ballot(z1));
-            if (k0 >= n) k0 = n > 0 ? n - 1 : 0;
-            if (tid == 0) ((gbl_i *)Aarg.out_status)[Aarg.nwin + win] = (rot[156] != 0.0) ? -1 : k0;
-        }
+        if (bad) ((gbl_i *)Aarg.out_status)[Aarg.nwin + win] = -1;      // (ordered behind lane 0's store by the barrier)
     }
 }
 

@@ -909,7 +909,7 @@ static int pack_data_to(const tcv_problem &p, Packed &out, const double *imu_sqr
     bool imu_on_device = out.dev_imu_doubles > 0;
     if (!D.dst) {
         imu_on_device = !p.imu.empty();
-        for (auto &f : p.imu) if (!f.dev) imu_on_device = false;
+        for (auto &f : p.imu) if (!f.dev || !f.dev->dev || f.dev->dev->dev != out.batch_dev) imu_on_device = false;      // (a blob of another device: host path)
     }
     out.dev_imu_doubles = imu_on_device ? (int)p.imu.size() * IMU_CONST : 0;
     for (auto &f : p.imu) {
@@ -952,7 +952,7 @@ static int pack_data_to(const tcv_problem &p, Packed &out, const double *imu_sqr
     bool on_device = out.dev_prior_doubles > 0;
     if (!D.dst) {
         on_device = false;
-        if (pr) { std::lock_guard<std::mutex> g(pr->mu); on_device = !pr->host && pr->dev && (int)pr->size.size() <= PRIOR_SPLICE_MAX_BLOCKS; }
+        if (pr) { std::lock_guard<std::mutex> g(pr->mu); on_device = !pr->host && pr->dev && pr->dev->dev == out.batch_dev && (int)pr->size.size() <= PRIOR_SPLICE_MAX_BLOCKS; }
     }
     out.dev_prior_doubles = 0;
     out.prior_k0_deferred = false;
