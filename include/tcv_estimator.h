@@ -66,6 +66,15 @@ int tcv_estimator_set_line_map(tcv_estimator *e, int n, const double *lines3d, c
  *   *ready = 1 when the window is full and must be optimised (tcv_estimators_optimize) before tcv_estimator_finish_frame. */
 int tcv_estimator_begin_frame(tcv_estimator *e, int n_imu, const double *acc, const double *gyr, int n_points, const int *point_ids,
                               const double *points, int n_lines, const int *line_ids, const double *lines, const double *truth, int *ready);
+/* tcv_estimator_begin_frame for the estimators of a lock-step frame (one input record each), on the library's host worker threads.
+ * ready[i] as above; returns TCV_OK or the first failure (rc[i], when given, holds every estimator's own status). */
+typedef struct tcv_frame_input {
+    int n_imu; const double *acc, *gyr;
+    int n_points; const int *point_ids; const double *points;
+    int n_lines; const int *line_ids; const double *lines;
+    const double *truth;
+} tcv_frame_input;
+int tcv_estimators_begin_frames(tcv_estimator *const *e, int n, const tcv_frame_input *in, int *ready, int *rc);
 /* solveOdometry + double2vector + marginalisation for every estimator in the list (all must be ready): one device batch.
  * The solver options (num_iterations, fixed_iterations) and the IMU noise are those of the first estimator of the list.
  * A window whose own marginalisation fails numerically (eigen-solver sweep cap) does not fail the batch: the other estimators are

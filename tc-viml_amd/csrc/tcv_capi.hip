@@ -466,6 +466,43 @@ extern "C" int tcv_problem_plan_stats(const tcv_problem *p, int *out) {
     return TCV_OK;
 }
 
+// diagnostics of the packer (tests/test_pack_cpu.py): the plan of a problem as the device would get it -- header (as ints) followed by the
+// int pool -- and the switch between the fast gather-program builder with its caches and the generic reference builder
+extern "C" int tcv_problem_plan_ints(const tcv_problem *p, int *out, int cap, int *len) {
+    if (!p || !len) return TCV_ERR_INVALID;
+    Packed pk;
+    const char *ec = getenv("TCV_PLAN_COOP");
+    const int rc = pack_problem(*p, pk, nullptr, g_solver_variant, 0, true, ec ? atoi(ec) : 0);
+    if (rc != TCV_OK) return rc;
+    const PlanInts &pints = pk.tmpl ? pk.tmpl->ints : pk.ints;
+    const int nh = (int)(sizeof(PlanHdr) / sizeof(int));
+    *len = nh + (int)pints.size();
+    if (out && cap >= *len) { std::memcpy(out, &pk.hdr, sizeof(PlanHdr)); std::memcpy(out + nh, pints.data(), sizeof(int) * pints.size()); }
+    return TCV_OK;
+}
+extern "C" int tcv_set_packer_reference(int on) { tcv::set_pack_reference(on); return TCV_OK; }
+// the packing pass of tcv_batch_create (plans + data sizes of n problems on `threads` host threads of the library's worker pool) without
+// a device: seconds of wall time in *seconds
+extern "C" int tcv_problems_pack_bench(tcv_problem *const *problems, int n, int threads, int coop_chunks, double *seconds) {
+    if (!problems || n <= 0 || !seconds) return TCV_ERR_INVALID;
+    std::vector<Packed> packed(n);
+    std::vector<int> rcs(n, TCV_OK);
+    const int nth = std::max(1, std::min(threads, n));
+    const auto t0 = std::chrono::steady_clock::now();
+    tcv::parallel_run(nth, [&](int t) { for (int w = t; w < n; w += nth) rcs[w] = pack_problem(*problems[w], packed[w], nullptr, g_solver_variant, coop_chunks > 0 ? (int)LDS_DOUBLES : 0, true, coop_chunks); });
+    *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (getenv("TCV_DEBUG_PACK2")) tcv::pack_laps_print();
+    for (int w = 0; w < n; w++) if (rcs[w] != TCV_OK) return rcs[w];
+    return TCV_OK;
+}
+extern "C" int tcv_plan_cache_stats(long long *out4) {
+    if (!out4) return TCV_ERR_INVALID;
+    long long e = 0;
+    tcv::plan_cache_stats(&out4[0], &out4[1], &e);
+    tcv::cam_cache_stats(&out4[2], &out4[3]);
+    return TCV_OK;
+}
+
 // graph construction of estimator.cpp:1683-1846 from frame-indexed arrays
 extern "C" int tcv_problem_from_window(const tcv_window_desc *w, tcv_problem **out) {
     if (!w || !out || w->n_frames <= 0 || !w->para_pose || !w->para_speedbias || !w->para_ex_pose || (w->n_imu > 0 && (!w->imu || !w->imu_frame_i || !w->imu_frame_j)) ||
@@ -725,18 +762,8 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
         if (want == 1 && g_coop_helpers < 0 && !getenv("TCV_COOP_H")) want = 0;      // a single helper is not worth the hand-offs
         coop_h = want;
     }
-    auto plan_hash_of = [](const Packed &pk) -> unsigned long long {
-        const std::vector<int> &pints = pk.tmpl ? pk.tmpl->ints : pk.ints;
-        unsigned long long h = 0x9E3779B97F4A7C15ull ^ pints.size();
-        auto mix = [&](const int *p, size_t cnt) {
-            size_t i = 0;
-            for (; i + 1 < cnt; i += 2) { unsigned long long v; std::memcpy(&v, p + i, 8); h = (h ^ v) * 0xFF51AFD7ED558CCDull; h ^= h >> 29; }
-            if (i < cnt) { h = (h ^ (unsigned)p[i]) * 0xFF51AFD7ED558CCDull; h ^= h >> 29; }
-        };
-        mix(pints.data(), pints.size());
-        mix(reinterpret_cast<const int *>(&pk.hdr), sizeof(PlanHdr) / sizeof(int));
-        return h;
-    };
+    // (a plan out of the cache carries the hash of its template, computed once by the thread that built it)
+    auto plan_hash_of = [](const Packed &pk) -> unsigned long long { return pk.tmpl ? pk.tmpl->hash : tcv::plan_content_hash(pk.hdr, pk.ints); };
     auto pack_all = [&](int md, std::string &msg) -> int {
         const int nth = host_op.threads(std::min(n, 16));
         std::vector<int> rcs(n, TCV_OK);
@@ -780,7 +807,7 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
     size_t dtotal = 0;
     for (int w = 0; w < n; w++) {
         Packed &pk = b->packed[w];
-        const std::vector<int> &pints = pk.tmpl ? pk.tmpl->ints : pk.ints;
+        const PlanInts &pints = pk.tmpl ? pk.tmpl->ints : pk.ints;
         int pid = -1;
         if (pk.tmpl) { auto it = plan_of_tmpl.find(pk.tmpl.get()); if (it != plan_of_tmpl.end()) pid = it->second; }
         if (pid < 0) {

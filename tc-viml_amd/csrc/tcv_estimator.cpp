@@ -693,6 +693,21 @@ void for_each_estimator(int n, const std::function<void(int)> &fn) {
 }
 }  // namespace
 static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+extern "C" int tcv_estimators_begin_frames(tcv_estimator *const *es, int n, const tcv_frame_input *in, int *ready, int *rc_out) {
+    if (!es || n <= 0 || !in || !ready) { tcv::set_error("estimators_begin_frames: bad argument"); return TCV_ERR_INVALID; }
+    for (int i = 0; i < n; i++) for (int j = 0; j < i; j++) if (es[i] == es[j]) { tcv::set_error("estimators_begin_frames: the same estimator twice"); return TCV_ERR_INVALID; }
+    std::vector<int> rcs(n, TCV_OK);
+    std::vector<std::string> msgs(n);
+    for_each_estimator(n, [&](int i) {
+        const tcv_frame_input &f = in[i];
+        ready[i] = 0;
+        rcs[i] = tcv_estimator_begin_frame(es[i], f.n_imu, f.acc, f.gyr, f.n_points, f.point_ids, f.points, f.n_lines, f.line_ids, f.lines, f.truth, &ready[i]);
+        if (rcs[i] != TCV_OK) msgs[i] = tcv_last_error();      // (the text is per thread)
+    });
+    if (rc_out) for (int i = 0; i < n; i++) rc_out[i] = rcs[i];
+    for (int i = 0; i < n; i++) if (rcs[i] != TCV_OK) { tcv::set_error(msgs[i]); return rcs[i]; }
+    return TCV_OK;
+}
 extern "C" int tcv_estimators_profile(double *out8) {
     if (!out8) return TCV_ERR_INVALID;
     std::lock_guard<std::mutex> g(g_mu);

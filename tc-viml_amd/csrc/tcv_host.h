@@ -76,18 +76,34 @@ struct ProjFac { double pts[6]; double sqrt_info, loss_a; int b[4]; double aux[8
 struct LineFac { double d[9]; double K[9], R[9], T[3]; double loss_a; int b; };
 struct PriorFac { const tcv_prior *prior; std::vector<int> b; };
 
+// Int pools of the plans (~170 KB per window) come from a process-wide free list of power-of-two blocks: a malloc of that size is a fresh
+// mmap whose pages fault in on first touch (~100 us per plan, as much as building it); a live estimator makes and drops one per frame.
+void *plan_block_alloc(size_t bytes);
+void plan_block_free(void *p, size_t bytes);
+template <class T> struct PlanAlloc {
+    typedef T value_type;
+    PlanAlloc() = default;
+    template <class U> PlanAlloc(const PlanAlloc<U> &) {}
+    T *allocate(size_t n) { return static_cast<T *>(plan_block_alloc(n * sizeof(T))); }
+    void deallocate(T *p, size_t n) { plan_block_free(p, n * sizeof(T)); }
+    template <class U> bool operator==(const PlanAlloc<U> &) const { return true; }
+    template <class U> bool operator!=(const PlanAlloc<U> &) const { return false; }
+};
+typedef std::vector<int, PlanAlloc<int>> PlanInts;
+
 // structural half of a packed window (plan header + int pool + host-side maps): a function of the graph STRUCTURE only, shared by every
 // window with that structure (tcv_pack.cpp keeps a process-wide cache keyed by the structure)
 struct PlanTemplate {
     PlanHdr hdr;
-    std::vector<int> ints;
+    PlanInts ints;
+    unsigned long long hash = 0;      // plan_content_hash(hdr, ints), computed once by the packing thread that made the template
     std::vector<int> cam_block, cam_loff, lm_block, proj_order;
 };
 
 struct Packed {
     PlanHdr hdr;
     std::shared_ptr<const PlanTemplate> tmpl;   // set when the plan came from / went into the cache: `ints` is then empty and tmpl->ints holds the plan
-    std::vector<int> ints;
+    PlanInts ints;
     std::vector<double> doubles;
     WinHdr win;
     unsigned long long plan_hash = 0;   // of hdr + plan ints (tcv_batch_create: structure de-duplication without copying 200 KB keys)
@@ -226,4 +242,9 @@ void flush_deferred(hipStream_t st);
 hipStream_t util_stream();
 // plan-cache statistics (hits, misses, entries); tcv_pack.cpp
 void plan_cache_stats(long long *hits, long long *misses, long long *entries);
+void set_pack_reference(int on);
+void pack_laps_print();      // TCV_DEBUG_PACK2=1: per-phase times of the packer since the last call, on stderr
+bool pack_reference();
+void cam_cache_stats(long long *hits, long long *misses);      // the camera halves of the plans (tcv_pack.cpp)
+unsigned long long plan_content_hash(const PlanHdr &hdr, const PlanInts &ints);
 }  // namespace tcv

@@ -125,6 +125,36 @@ void parallel_run(int nth, const std::function<void(int)> &fn) {
     c->cv.wait(g, [&] { return c->done.load(std::memory_order_acquire) >= c->n; });
 }
 
+// ---- blocks of the plans' int pools (PlanAlloc, tcv_host.h): power-of-two size classes from 16 KB, a bounded free list per class
+namespace {
+struct BlockPool { std::mutex mu; std::vector<void *> idle[12]; };      // 16 KB .. 32 MB
+BlockPool &block_pool() { static BlockPool *p = new BlockPool(); return *p; }
+inline int block_class(size_t bytes, size_t &cap) { int c = 0; cap = (size_t)16 << 10; while (cap < bytes) { cap <<= 1; c++; } return c; }
+}  // namespace
+void *plan_block_alloc(size_t bytes) {
+    if (bytes < ((size_t)16 << 10)) return ::operator new(bytes);
+    size_t cap;
+    const int c = block_class(bytes, cap);
+    if (c < 12) {
+        BlockPool &P = block_pool();
+        std::lock_guard<std::mutex> g(P.mu);
+        if (!P.idle[c].empty()) { void *p = P.idle[c].back(); P.idle[c].pop_back(); return p; }
+    }
+    return ::operator new(cap);
+}
+void plan_block_free(void *p, size_t bytes) {
+    if (!p) return;
+    if (bytes < ((size_t)16 << 10)) { ::operator delete(p); return; }
+    size_t cap;
+    const int c = block_class(bytes, cap);
+    if (c < 12) {
+        BlockPool &P = block_pool();
+        std::lock_guard<std::mutex> g(P.mu);
+        if (P.idle[c].size() < (size_t)(c <= 5 ? 192 : 8)) { P.idle[c].push_back(p); return; }      // (<= 512 KB: the plans of a lock-step frame; larger blocks: a handful)
+    }
+    ::operator delete(p);
+}
+
 // TCV_PRIOR_FULL: keep the exact-zero rows of the prior (A/B partner of the default).  The environment is read once per batch
 // (prior_refresh_switch), not once per window.
 static std::atomic<int> g_prior_full{-1};
@@ -296,17 +326,476 @@ void add_pairs(DestList &dl, const std::vector<Col> &cols, MakeItem mk, int rcol
 
 }  // namespace
 
+// ---- camera half of a plan -------------------------------------------------------------------------------------------------------
+// Everything of a plan that is a function of the CAMERA-side structure alone -- block table, IMU factor tables (colours, tangent maps,
+// the 40 KB scatter table of the J'J tiles), the prior's column and destination tables, the chain elimination's step records, the
+// frame table: a live estimator keeps that structure from frame to frame (11 poses + 11 speed-biases + extrinsic, ten IMU factors, the
+// previous frame's prior layout), while its visual half -- which landmark is seen from which frames -- changes with every frame.
+// The camera half is the PREFIX of the plan's int pool (so its offsets do not depend on the visual half) and is cached process-wide
+// by its structure; a window whose camera structure is known copies 65 KB instead of rebuilding it (symbolic elimination included).
+namespace {
+struct ChainStep { int cam, t0; std::vector<int> prow_t; bool next; int nsrc, f[2], lc[2]; };
+struct CamPlan {
+    bool eligible = true;        // want_chain: the speed-bias blocks form a chain (false: the caller asks again for the dense layout)
+    PlanHdr hdr;                 // the camera fields: nblk, nc, nx, npp, nt, ntp, n_imu, prior_*, n_imu_chunk, flags, td_cam, camw, chain, n_e, nt_c, c_spill,
+                                 // n_frames and the o_* / n_* of the tables below
+    std::vector<int> ints;       // [blk | imu | prior | pcol | idest | iunit | iitem | ichunk | pdest | chain | frames], a multiple of 4 ints
+    std::vector<int> loff;       // tangent offset of every camera block (-1 constant)
+    std::vector<int> goff;
+};
+struct CamKey {
+    std::vector<int> k;
+    size_t h = 0;
+    void seal() { unsigned long long x = 1469598103934665603ull; for (int v : k) { x ^= (unsigned)v; x *= 1099511628211ull; } h = (size_t)x; }
+    bool operator==(const CamKey &o) const { return h == o.h && k == o.k; }
+};
+struct CamKeyHash { size_t operator()(const CamKey &k) const { return k.h; } };
+std::mutex g_cam_mu;
+std::unordered_map<CamKey, std::shared_ptr<const CamPlan>, CamKeyHash> g_cam_cache;
+long long g_cam_hits = 0, g_cam_misses = 0;
+enum { CAM_CACHE_MAX = 512 };
+
+// what the camera half is built from (filled by pack_plan's classification)
+struct CamIn {
+    const tcv_problem *p;
+    const std::vector<int> *cam_block, *cam_of;
+    int td_blk;
+    bool want_chain;
+    int per_imu;                 // IMU factors per staging chunk (a function of the LDS pool the visual half leaves: part of the key)
+};
+
+int build_cam(const CamIn &in, CamPlan &out) {
+    const tcv_problem &p = *in.p;
+    const std::vector<int> &cam_block = *in.cam_block, &cam_of = *in.cam_of;
+    const int nblk = (int)cam_block.size();
+    const int td_blk = in.td_blk;
+    std::vector<int> gsize(nblk), goff(nblk), loff(nblk, -1), kind(nblk);
+    int nx = 0, nc = 0;
+    for (int c = 0; c < nblk; c++) {
+        const ParamBlock &pb = p.blocks[cam_block[c]];
+        gsize[c] = pb.size; kind[c] = pb.kind; goff[c] = nx; nx += pb.size;
+        if (pb.kind == KIND_EUCLID && pb.size > 15) { set_error("Euclidean block wider than 15"); return TCV_ERR_UNSUPPORTED; }
+    }
+    for (int c = 0; c < nblk; c++)
+        if (kind[c] == KIND_POSE && !p.blocks[cam_block[c]].constant) { loff[c] = nc; nc += 6; }
+    // Td comes right behind the poses: its column rides through the 6-wide gather machinery as a pseudo block whose other five
+    // columns are structural zeros, so five more tangent rows must follow it.  It counts as part of the "pose part" npp: the
+    // leading tangent dims the visual factors touch (landmark Schur corrections of the diagonal and the right-hand side).
+    const int td_cam = td_blk >= 0 ? cam_of[td_blk] : -1;
+    if (td_cam >= 0 && !p.blocks[td_blk].constant) { loff[td_cam] = nc; nc += 1; }
+    const int npp = nc;
+    for (int c = 0; c < nblk; c++)
+        if (kind[c] != KIND_POSE && c != td_cam && !p.blocks[cam_block[c]].constant) { loff[c] = nc; nc += gsize[c]; }
+    if (nc < 1) { set_error("no free camera-side parameter block"); return TCV_ERR_INVALID; }
+    const int nt = (nc + 1 + 15) / 16, ntp = (npp + 15) / 16;
+    if (td_cam >= 0 && loff[td_cam] >= 0 && loff[td_cam] + 6 > nt * 16) { set_error("Td block: no room for its gather slot"); return TCV_ERR_UNSUPPORTED; }
+    // camera tangent dims: 171 for the 11 frames + extrinsic of OptimizationWithLine (172 with Td), 177 with the relocalisation pose (:1854-1886)
+    if (nc > CAM_MAX - 1 || npp > 88) { set_error("window too large for the fused solver (camera tangent dim > 183)"); return TCV_ERR_TOO_LARGE; }
+    const int camw = nc <= CAM_W - 1 ? (int)CAM_W : (int)CAM_MAX;
+    out.loff = loff; out.goff = goff;
+
+    // ---- chain layout: the free Euclidean camera blocks (speed-biases, 9 wide) only meet their IMU neighbours and the
+    // prior, so they are eliminated one after the other BEFORE the dense pose system (block-sparse Cholesky with the poses
+    // ordered last, what SPARSE_SCHUR's reduced-camera factorisation exploits too).  Symbolic elimination at block level:
+    // eligible iff every Euclidean block has at most one later-eliminated Euclidean neighbour and that one is next in order.
+    std::vector<ChainStep> chain;
+    bool use_chain = in.want_chain;
+    std::vector<int> eorder;
+    if (use_chain) {
+        std::vector<char> in_prior(nblk, 0);
+        if (!p.prior.empty()) for (int b : p.prior[0].b) if (cam_of[b] >= 0) in_prior[cam_of[b]] = 1;
+        // (Td is no chain block: it belongs to the pose part, one column wide -- every point factor and so every pose meets it)
+        for (int c = nblk - 1; c >= 0; c--) if (kind[c] != KIND_POSE && c != td_cam && loff[c] >= 0 && !in_prior[c]) eorder.push_back(c);
+        for (int c = nblk - 1; c >= 0; c--) if (kind[c] != KIND_POSE && c != td_cam && loff[c] >= 0 && in_prior[c]) eorder.push_back(c);
+        for (int c : eorder) if (gsize[c] != CH_W) use_chain = false;
+        if (eorder.empty() || eorder.size() > 16 || npp < 1) use_chain = false;
+    }
+    if (use_chain) {
+        const int ne = (int)eorder.size();
+        std::vector<int> pos(nblk, -1);
+        for (int s2 = 0; s2 < ne; s2++) pos[eorder[s2]] = s2;
+        std::vector<char> adj((size_t)nblk * nblk, 0);
+        auto link = [&](const int *bs, int nb2) { for (int i = 0; i < nb2; i++) for (int j = 0; j < nb2; j++) { const int a2 = bs[i], b2 = bs[j]; if (a2 != b2 && a2 >= 0 && b2 >= 0 && loff[a2] >= 0 && loff[b2] >= 0) adj[(size_t)a2 * nblk + b2] = 1; } };
+        for (auto &f : p.imu) { const int bs[4] = {cam_of[f.b[0]], cam_of[f.b[1]], cam_of[f.b[2]], cam_of[f.b[3]]}; link(bs, 4); }
+        if (!p.prior.empty()) { std::vector<int> bs; for (int b : p.prior[0].b) bs.push_back(cam_of[b]); link(bs.data(), (int)bs.size()); }
+        for (int s2 = 0; s2 < ne && use_chain; s2++) {
+            const int e = eorder[s2];
+            ChainStep st;
+            st.cam = e; st.t0 = loff[e]; st.next = false; st.nsrc = 0; st.f[0] = st.f[1] = 0; st.lc[0] = st.lc[1] = 0;
+            std::vector<int> later;
+            for (int x = 0; x < nblk; x++) if (adj[(size_t)e * nblk + x] && pos[x] > s2) later.push_back(x);
+            if (later.size() > 1 || (later.size() == 1 && pos[later[0]] != s2 + 1)) { use_chain = false; break; }
+            st.next = !later.empty();
+            std::vector<int> prow;
+            for (int x = 0; x < nblk; x++) if (adj[(size_t)e * nblk + x] && (kind[x] == KIND_POSE || x == td_cam)) prow.push_back(x);
+            std::sort(prow.begin(), prow.end(), [&](int a2, int b2) { return loff[a2] < loff[b2]; });
+            for (int x : prow) for (int j = 0; j < (x == td_cam ? 1 : 6); j++) st.prow_t.push_back(loff[x] + j);
+            // fill: the eliminated block's neighbours become a clique (pose-pose is dense anyway)
+            for (int x : later) for (int y : prow) { adj[(size_t)x * nblk + y] = 1; adj[(size_t)y * nblk + x] = 1; }
+            for (size_t k = 0; k < p.imu.size(); k++)
+                for (int sl = 1; sl < 4; sl += 2)
+                    if (cam_of[p.imu[k].b[sl]] == e) {
+                        if (st.nsrc >= 2) { use_chain = false; break; }
+                        st.f[st.nsrc] = (int)k; st.lc[st.nsrc] = sl == 1 ? 6 : 21; st.nsrc++;
+                    }
+            if (CH_W + (st.next ? CH_W : 0) + (int)st.prow_t.size() + 1 > CH_MAXROWS) use_chain = false;
+            chain.push_back(st);
+        }
+    }
+    if (in.want_chain && !use_chain) { out.eligible = false; return TCV_OK; }
+    // (Td's gather slot is six columns wide, tcv_packed.h: the pose tiles have to cover the five structural zeros behind its column)
+    const int nt_c = (std::max(npp + 1, (td_cam >= 0 && loff[td_cam] >= 0) ? loff[td_cam] + 6 : 0) + 15) / 16;
+
+    PlanHdr &H = out.hdr;
+    std::memset(&H, 0, sizeof(H));
+    H.nblk = nblk; H.nc = nc; H.nx = nx; H.npp = npp; H.nt = nt; H.ntp = ntp;
+    H.n_imu = (int)p.imu.size();
+    H.flags = td_blk >= 0 ? 1 : 0; H.td_cam = td_cam; H.camw = camw;
+    H.chain = use_chain ? 1 : 0; H.n_e = (int)chain.size(); H.nt_c = nt_c;
+    std::vector<int> &I = out.ints;
+    I.clear();
+    auto mark = [&]() { return (int)I.size(); };
+    H.o_blk = mark();
+    for (int c = 0; c < nblk; c++) { I.push_back(gsize[c]); I.push_back(goff[c]); I.push_back(loff[c]); I.push_back(kind[c]); }
+    H.o_imu = mark();
+    for (auto &f : p.imu) for (int k = 0; k < 4; k++) I.push_back(cam_of[f.b[k]]);
+
+    // ---- prior
+    if (p.prior.size() > 1) { set_error("more than one marginalisation factor"); return TCV_ERR_UNSUPPORTED; }
+    const tcv_prior *pr = p.prior.empty() ? nullptr : p.prior[0].prior;
+    H.o_prior = mark();
+    std::vector<int> pcol;
+    if (pr) {
+        if (pr->n > 128) { set_error("prior with more than 128 rows"); return TCV_ERR_TOO_LARGE; }
+        H.prior_n = pr->n; H.prior_nblk = (int)pr->size.size(); H.prior_xsize = pr->xsize;
+        pcol.assign(pr->n, -1);
+        for (int k = 0; k < H.prior_nblk; k++) {
+            const int b = p.prior[0].b[k];
+            if (cam_of[b] < 0) { set_error("prior attached to a landmark block"); return TCV_ERR_UNSUPPORTED; }
+            const ParamBlock &pb = p.blocks[b];
+            if (pb.size != pr->size[k]) { set_error("prior block size mismatch"); return TCV_ERR_INVALID; }
+            I.push_back(cam_of[b]); I.push_back(pr->idx[k]); I.push_back(pr->size[k]); I.push_back(pr->xoff[k]);
+            const int local = pr->size[k] == 7 ? 6 : pr->size[k];
+            const int t = loff[cam_of[b]];
+            for (int j = 0; j < local; j++)
+                if (pr->idx[k] + j < pr->n) pcol[pr->idx[k] + j] = t < 0 ? -1 : t + j;
+        }
+    }
+    H.o_pcol = mark();
+    for (int v : pcol) I.push_back(v);
+
+    std::vector<int> imap;
+    // ---- IMU chunks.  Per factor: the tangent index of each of its 30 local Jacobian columns (-1 for a constant
+    // block) and a colour; factors of one colour share no parameter block, so their J'J tiles can be scattered into the
+    // reduced camera system concurrently (the frame chain needs two colours).
+    {
+        const int per = std::max(1, std::min(H.n_imu, in.per_imu));
+        if (H.n_imu > 16) { set_error("more than 16 IMU factors"); return TCV_ERR_TOO_LARGE; }
+        std::vector<int> icolor(H.n_imu, 0), ichunk;
+        for (int fb = 0; fb < H.n_imu; fb += per) {
+            const int fn = std::min(per, H.n_imu - fb);
+            int ncol = 0;
+            for (int k = 0; k < fn; k++) {       // greedy colouring inside the chunk
+                const ImuFac &f = p.imu[fb + k];
+                for (int a2 = 0; a2 < 4; a2++)
+                    for (int b2 = 0; b2 < a2; b2++)
+                        if (f.b[a2] == f.b[b2]) { set_error("IMU factor uses one block twice"); return TCV_ERR_UNSUPPORTED; }
+                int col = 0;
+                for (;; col++) {
+                    bool clash = false;
+                    for (int j = 0; j < k && !clash; j++) {
+                        if (icolor[fb + j] != col) continue;
+                        for (int a2 = 0; a2 < 4; a2++) for (int b2 = 0; b2 < 4; b2++) if (p.imu[fb + j].b[a2] == f.b[b2]) clash = true;
+                    }
+                    if (!clash) break;
+                }
+                icolor[fb + k] = col;
+                ncol = std::max(ncol, col + 1);
+            }
+            if (ncol > 4) { set_error("IMU factors of one chunk need more than 4 colours"); return TCV_ERR_UNSUPPORTED; }
+            unsigned bits = 0;
+            for (int k = 0; k < fn; k++) bits |= (unsigned)icolor[fb + k] << (2 * k);      // 2 bits per factor
+            ichunk.push_back(fb); ichunk.push_back(fn); ichunk.push_back(ncol); ichunk.push_back((int)bits);
+        }
+        for (auto &f : p.imu) {
+            const int colc[4] = {0, 6, 15, 21}, colw[4] = {6, 9, 6, 9};
+            int m[32];
+            for (int i = 0; i < 32; i++) m[i] = -1;
+            for (int s2 = 0; s2 < 4; s2++) {
+                const int t = loff[cam_of[f.b[s2]]];
+                for (int j = 0; j < colw[s2]; j++) m[colc[s2] + j] = t < 0 ? -1 : t + j;
+            }
+            imap.insert(imap.end(), m, m + 32);
+        }
+        H.n_imu_chunk = (int)ichunk.size() / 4;
+        H.o_idest = mark(); I.insert(I.end(), imap.begin(), imap.end()); H.n_idest = (int)imap.size();
+        H.o_iunit = mark(); I.insert(I.end(), icolor.begin(), icolor.end()); H.n_iunit = (int)icolor.size();
+        // scatter table of the J'J tiles (see IMU_SC_BIAS): what the kernel would derive from the tangent map for every lane and register
+        while ((I.size() & 3) != 0) I.push_back(0);      // read with 16-byte loads
+        H.o_iitem = mark(); H.n_iitem = H.n_imu * 1024;
+        I.resize(I.size() + (size_t)H.n_imu * 1024, 0);
+        int *sct = I.data() + H.o_iitem;
+        for (int f = 0; f < H.n_imu; f++) {
+            const int *tm = imap.data() + (size_t)f * 32;
+            for (int lane = 0; lane < 64; lane++) {
+                const int i16 = lane & 15, k4 = lane >> 4;
+                for (int tile = 0; tile < 4; tile++) {     // (I, J): (0,0) (1,0) (1,1) (0,1)
+                    const int Ir = (tile == 1 || tile == 2) ? 1 : 0, Jc = (tile >= 2) ? 1 : 0;
+                    const int bl = 16 * Jc + i16;
+                    for (int i = 0; i < 4; i++) {
+                        const int al = 16 * Ir + k4 + 4 * i;
+                        const int ta = tm[al], tb = tm[bl];
+                        int d = -1, store = 0;
+                        if (ta >= 0) {
+                            if (bl == 30) d = -2 - ta;
+                            else if (tile != 3 && bl < 30 && al >= bl && tb >= 0) {
+                                store = use_chain ? 1 : 0;
+                                if (use_chain && (ta >= npp || tb >= npp)) d = (al == bl) ? -1000 - (ta - npp) : -1;
+                                else d = ta >= tb ? tix(ta, tb) : tix(tb, ta);
+                            }
+                        }
+                        if (d + IMU_SC_BIAS < 0 || d + IMU_SC_BIAS >= (1 << 16)) { set_error("IMU scatter destination out of range"); return TCV_ERR_TOO_LARGE; }
+                        sct[(size_t)f * 1024 + lane * 16 + tile * 4 + i] = (d + IMU_SC_BIAS) | (store ? IMU_SC_STORE : 0);
+                    }
+                }
+            }
+        }
+        H.o_ichunk = mark(); I.insert(I.end(), ichunk.begin(), ichunk.end());
+    }
+    {
+        // destinations of the constant part of the prior (Hp, packed lower triangle): same derivation as the kernel's former inline one
+        H.o_pdest = mark();
+        const int pn = (int)pcol.size();
+        I.reserve(I.size() + (size_t)pn * (pn + 1) / 2 + 4096);
+        for (int a2 = 0; a2 < pn; a2++)
+            for (int b2 = 0; b2 <= a2; b2++) {
+                const int ta = pcol[a2], tb = pcol[b2];
+                int d = -1;
+                if (ta >= 0 && tb >= 0) {
+                    if (use_chain && (ta >= npp || tb >= npp)) { if (ta == tb) d = -2 - (ta - npp); }
+                    else d = ta >= tb ? tix(ta, tb) : tix(tb, ta);
+                }
+                I.push_back(d);
+            }
+    }
+    // ---- chain step tables
+    while ((I.size() & 3) != 0) I.push_back(0);
+    H.o_chain = mark();
+    if (use_chain) {
+        const int ne = (int)chain.size();
+        std::vector<int> tab((size_t)ne * CH_STRIDE, 0);
+        std::vector<int> pinv(nc + 1, -1);
+        for (size_t j = 0; j < pcol.size(); j++) if (pcol[j] >= 0) pinv[pcol[j]] = (int)j;
+        const int wstride = 16 * nt_c * CH_W;      // W rows of one step in the spill area: 16 nt_c columns (whole tiles) x 9
+        std::vector<std::vector<int>> rowt(ne);
+        for (int s2 = 0; s2 < ne; s2++) {
+            const ChainStep &st = chain[s2];
+            std::vector<int> &rt = rowt[s2];
+            for (int j = 0; j < CH_W; j++) rt.push_back(st.t0 + j);
+            if (st.next) for (int j = 0; j < CH_W; j++) rt.push_back(chain[s2 + 1].t0 + j);
+            for (int t : st.prow_t) rt.push_back(t);
+            rt.push_back(-2);
+        }
+        for (int s2 = 0; s2 < ne; s2++) {
+            const ChainStep &st = chain[s2];
+            const std::vector<int> &rt = rowt[s2];
+            const int nr = (int)rt.size();
+            int *h = tab.data() + (size_t)s2 * CH_STRIDE;
+            h[CH_T0] = st.t0; h[CH_R] = nr - CH_W - 1; h[CH_NEXT] = st.next ? 1 : 0; h[CH_NSRC] = st.nsrc;
+            h[CH_F0] = st.f[0]; h[CH_LC0] = st.lc[0]; h[CH_F1] = st.f[1]; h[CH_LC1] = st.lc[1];
+            h[CH_PC0] = pinv[st.t0]; h[CH_SPILL] = s2 * wstride;
+            unsigned char *colrow = reinterpret_cast<unsigned char *>(h + CH_COLROW);
+            for (int c = 0; c < CH_MAXROWS; c++) colrow[c] = 255;
+            int tmask = 0;
+            for (int r = 0; r < nr; r++) {
+                int vn = 255;
+                if (st.next) {
+                    const std::vector<int> &nx2 = rowt[s2 + 1];
+                    for (size_t q = 0; q < nx2.size(); q++) if (nx2[q] == rt[r]) vn = (int)q;
+                    if (r >= CH_W && vn == 255) { set_error("chain: fill row missing in the next front"); return TCV_ERR_INVALID; }
+                }
+                int l01[2] = {255, 255};
+                for (int src = 0; src < st.nsrc; src++)
+                    if (rt[r] >= 0)
+                        for (int l = 0; l < 30; l++) if (imap[(size_t)st.f[src] * 32 + l] == rt[r]) l01[src] = l;
+                const int tr = rt[r] >= 0 ? rt[r] : 255;
+                if (tr > 254 && rt[r] >= 0) { set_error("chain: tangent index overflow"); return TCV_ERR_TOO_LARGE; }
+                h[CH_INTS + 2 * r] = tr | (vn << 8) | (l01[0] << 16) | (l01[1] << 24);
+                h[CH_INTS + 2 * r + 1] = rt[r] >= 0 ? pinv[rt[r]] : -1;
+                // pose rows (tangent index < npp) and the rhs row are the columns of this step's W
+                const int col = rt[r] == -2 ? npp : ((rt[r] >= 0 && rt[r] < npp) ? rt[r] : -1);
+                if (col >= 0) {
+                    if (col >= CH_MAXROWS) { set_error("chain: pose column overflow"); return TCV_ERR_TOO_LARGE; }
+                    colrow[col] = (unsigned char)r;
+                    tmask |= 1 << (col >> 4);
+                }
+            }
+            h[CH_TMASK] = tmask;
+        }
+        const int spill = ne * wstride;
+        H.c_spill = (spill + 1) & ~1;
+        I.insert(I.end(), tab.begin(), tab.end());
+    }
+    // ---- frame table (gauge fix, estimator.cpp:1537-1581)
+    H.n_frames = (int)p.frame_pose.size();
+    H.o_frames = mark();
+    for (int i = 0; i < H.n_frames; i++) {
+        const int bp = p.frame_pose[i], bs = i < (int)p.frame_sb.size() ? p.frame_sb[i] : -1;
+        I.push_back(bp >= 0 && cam_of[bp] >= 0 ? goff[cam_of[bp]] : -1);
+        I.push_back(bs >= 0 && cam_of[bs] >= 0 ? goff[cam_of[bs]] : -1);
+    }
+    while ((I.size() & 3) != 0) I.push_back(0);
+    return TCV_OK;
+}
+
+void cam_key(const CamIn &in, CamKey &key) {
+    const tcv_problem &p = *in.p;
+    const std::vector<int> &cam_block = *in.cam_block, &cam_of = *in.cam_of;
+    std::vector<int> &k = key.k;
+    k.clear();
+    k.reserve(64 + cam_block.size() + 4 * p.imu.size());
+    k.push_back(in.want_chain ? 1 : 0); k.push_back(in.per_imu); k.push_back(in.td_blk >= 0 ? cam_of[in.td_blk] : -1); k.push_back((int)cam_block.size());
+    for (int b : cam_block) { const ParamBlock &pb = p.blocks[b]; k.push_back(pb.size | (pb.kind << 8) | ((int)pb.constant << 16)); }
+    k.push_back((int)p.imu.size());
+    for (auto &f : p.imu) for (int j = 0; j < 4; j++) k.push_back(cam_of[f.b[j]]);
+    k.push_back((int)p.prior.size());
+    for (auto &f : p.prior) {
+        const tcv_prior *pr = f.prior;
+        k.push_back(pr->n); k.push_back((int)pr->size.size()); k.push_back(pr->xsize);
+        for (size_t j = 0; j < f.b.size(); j++) { k.push_back(cam_of[f.b[j]]); k.push_back(pr->size[j]); k.push_back(pr->idx[j]); k.push_back(pr->xoff[j]); }
+    }
+    k.push_back((int)p.frame_pose.size());
+    for (int v : p.frame_pose) k.push_back(v >= 0 ? cam_of[v] : -1);
+    k.push_back((int)p.frame_sb.size());
+    for (int v : p.frame_sb) k.push_back(v >= 0 ? cam_of[v] : -1);
+    key.seal();
+}
+
+// the camera half for this structure: out of the cache, or built and put there
+int get_cam(const CamIn &in, std::shared_ptr<const CamPlan> &out, bool use_cache) {
+    CamKey key;
+    if (use_cache) {
+        cam_key(in, key);
+        std::lock_guard<std::mutex> g(g_cam_mu);
+        auto it = g_cam_cache.find(key);
+        if (it != g_cam_cache.end()) { out = it->second; g_cam_hits++; return TCV_OK; }
+        g_cam_misses++;
+    }
+    auto N = std::make_shared<CamPlan>();
+    const int rc = build_cam(in, *N);
+    if (rc != TCV_OK) return rc;
+    out = N;
+    if (use_cache) {
+        std::lock_guard<std::mutex> g(g_cam_mu);
+        if (g_cam_cache.size() >= CAM_CACHE_MAX) g_cam_cache.clear();
+        g_cam_cache.emplace(std::move(key), N);
+    }
+    return TCV_OK;
+}
+
+// ---- gather program of one visual chunk, fast path -----------------------------------------------------------------------------------
+// Same program as DestList + emit_rows above produce (the reference path, TCV_PACK_REF=1; tests/test_pack_cpu.py compares the two int by
+// int): destinations in order of first appearance, the items of a destination in factor order, units sorted by descending item count
+// (stable).  Two passes over the factors with a direct-index table of a few hundred slots (block ORDINALS instead of tangent offsets:
+// every pose-kind block is 6 wide) -- a count pass that also records the order of first appearance, and a fill pass --, then a
+// counting sort of the units.  ~8x faster than the generic path on a replay window (500 point factors, 90 landmarks).
+struct ProgScratch { std::vector<int> cnt, start, order, ukey; };
+ProgScratch &prog_scratch() { thread_local ProgScratch s; return s; }
+
+// slots of the table: [TILE 16 x 16 ordinals | G / RC 16 | per landmark (HLL) | per landmark slot (HCL)]
+enum { PS_TILE = 0, PS_G = 256, PS_LM = 272 };
+
+// writes [units (3 ints each) | items] behind `prog` (which the caller has aligned); n_units / n_wave_units / n_items describe them
+struct ProgOut { int n_units = 0, n_wave_units = 0, n_items = 0; };
+template <class Walk, class DestOf>
+bool fast_prog(int nslot, Walk &&walk, DestOf &&dest_of, std::vector<int> &prog, ProgOut &po, int wave_items, int wave_max) {
+    ProgScratch &S = prog_scratch();
+    S.cnt.assign(nslot, 0); S.order.clear();
+    // pass A: counts + order of first appearance
+    walk([&](int slot, int) { if (S.cnt[slot]++ == 0) S.order.push_back(slot); });
+    const int nd = (int)S.order.size();
+    S.start.resize(nslot);
+    int total = 0, nu = 0, nmax = 0;
+    struct D { int kind, o0, o1, la, lb; };
+    static thread_local std::vector<D> ds;
+    ds.resize(nd);
+    for (int d = 0; d < nd; d++) {
+        const int sl = S.order[d];
+        S.start[sl] = total; total += S.cnt[sl];
+        D &q = ds[d];
+        dest_of(sl, q.kind, q.o0, q.o1, q.la, q.lb);
+        if (q.o0 >= (1 << 16) || q.o1 >= (1 << 16) || S.cnt[sl] >= (1 << 20)) return false;
+        nu += (q.kind == DK_TILE) ? q.la : 1;
+        nmax = std::max(nmax, S.cnt[sl]);
+    }
+    if ((size_t)total >= (size_t)(1 << 16) * 16) return false;
+    const size_t off = prog.size();
+    prog.resize(off + 3 * (size_t)nu + total);
+    int *un = prog.data() + off, *items = un + 3 * (size_t)nu;
+    // pass B: fill (the count doubles as the cursor: start[slot] advances, the unit records below use start - cnt)
+    walk([&](int slot, int item) { items[S.start[slot]++] = item; });
+    // units in destination order, placed by a stable counting sort on descending item count
+    std::vector<int> &bk = S.ukey;
+    bk.assign(nmax + 2, 0);
+    for (int d = 0; d < nd; d++) bk[nmax - S.cnt[S.order[d]] + 1] += (ds[d].kind == DK_TILE) ? ds[d].la : 1;
+    for (int b = 0; b <= nmax; b++) bk[b + 1] += bk[b];
+    int nw = 0;
+    for (int d = 0; d < nd; d++) {
+        const int sl = S.order[d], n = S.cnt[sl], ib = S.start[sl] - n;
+        const D &q = ds[d];
+        const int nrow = (q.kind == DK_TILE) ? q.la : 1;
+        const int u1 = (int)(((unsigned)q.o0 << 16) | (unsigned)q.o1);
+        int pos = bk[nmax - n];
+        bk[nmax - n] += nrow;
+        for (int ea = 0; ea < nrow; ea++, pos++) {
+            const int ncols = (q.kind == DK_TILE) ? (q.lb == 0 ? ea + 1 : q.lb) : q.la;
+            un[3 * pos] = (int)(((unsigned)q.kind << 28) | ((unsigned)ncols << 24) | ((unsigned)ea << 20) | (unsigned)n);
+            un[3 * pos + 1] = u1; un[3 * pos + 2] = ib;
+        }
+        if (n > wave_items) nw += nrow;
+    }
+    po.n_units = nu; po.n_wave_units = std::min(nw, wave_max); po.n_items = total;
+    return true;
+}
+
+}  // namespace
+
+void cam_cache_stats(long long *hits, long long *misses) {
+    std::lock_guard<std::mutex> g(g_cam_mu);
+    if (hits) *hits = g_cam_hits;
+    if (misses) *misses = g_cam_misses;
+}
+
+// developer profile of the packer (TCV_DEBUG_PACK2=1): time per phase, summed over all threads; printed and cleared by pack_laps_print()
+namespace {
+std::mutex g_lap_mu;
+std::map<std::string, std::pair<double, long long>> g_laps;
+void pack_lap_add(const char *what, double us) { std::lock_guard<std::mutex> g(g_lap_mu); auto &e = g_laps[what]; e.first += us; e.second++; }
+}  // namespace
+void pack_laps_print() {
+    std::lock_guard<std::mutex> g(g_lap_mu);
+    for (auto &kv : g_laps) fprintf(stderr, "[pack] %-32s %8.1f us avg over %lld\n", kv.first.c_str(), kv.second.first / std::max<long long>(1, kv.second.second), kv.second.second);
+    g_laps.clear();
+}
+
+// tcv_set_packer_reference (diagnostics): 1 = every plan is built by the generic path and nothing is cached
+static std::atomic<int> g_pack_reference{getenv("TCV_PACK_REF") ? 1 : 0};
+void set_pack_reference(int on) { g_pack_reference.store(on ? 1 : 0, std::memory_order_relaxed); }
+bool pack_reference() { return g_pack_reference.load(std::memory_order_relaxed) != 0; }
+
 // structural half: plan header, int pool and the host-side maps (everything that does not depend on the VALUES of the window)
 // coop_chunks > 0: plan for the cooperative kernel (tcv_packed.h COOP_*): at least that many visual chunks of at most 256 point factors
 // each (one helper workgroup per chunk, one lane per factor), and an LDS budget that leaves room for a helper's second tile set
 static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds, int coop_chunks) {
     const int nb = (int)p.blocks.size();
     static const bool dbg_t = getenv("TCV_DEBUG_PACK2") != nullptr;      // developer: where the symbolic packing spends its time
+    const bool ref_path = g_pack_reference.load(std::memory_order_relaxed) != 0;      // the generic gather-program builder (DestList + emit_rows) and no camera-half cache: the reference of tests/test_pack_cpu.py
+    static const bool no_cache = getenv("TCV_NO_CAM_CACHE") != nullptr;      // (TCV_NO_PLAN_CACHE switches the whole-plan cache off, this one the camera halves')
     auto t_prev = std::chrono::steady_clock::now();
-    auto lap = [&](const char *what) { if (dbg_t) { const auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[pack_plan] %-28s %7.1f us\n", what, std::chrono::duration<double, std::micro>(t - t_prev).count()); t_prev = t; } };
+    auto lap = [&](const char *what) { if (dbg_t) { const auto t = std::chrono::steady_clock::now(); pack_lap_add(what, std::chrono::duration<double, std::micro>(t - t_prev).count()); t_prev = std::chrono::steady_clock::now(); } };
     // ---- classify blocks: landmarks = size-1 Euclidean blocks used only as 4th block of projection factors
-    std::vector<int> use_lm(nb, 0), use_other(nb, 0);
-    for (auto &f : p.proj) { use_lm[f.b[3]]++; for (int k = 0; k < 3; k++) use_other[f.b[k]]++; if (f.btd >= 0) use_other[f.btd]++; }
+    std::vector<int> use_other(nb, 0);
+    for (auto &f : p.proj) { for (int k = 0; k < 3; k++) use_other[f.b[k]]++; if (f.btd >= 0) use_other[f.btd]++; }
     // ProjectionTdFactor (ESTIMATE_TD): all point factors or none, one shared 1-dim Td block
     int td_blk = -1;
     for (size_t k = 0; k < p.proj.size(); k++) {
@@ -351,30 +840,21 @@ static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds,
     for (auto &f : p.line)
         if (p.blocks[f.b].kind != KIND_POSE) { set_error("line factor: block must be a pose"); return TCV_ERR_UNSUPPORTED; }
 
-    // ---- ambient / tangent offsets: pose-kind blocks first in tangent space
-    std::vector<int> gsize(nblk), goff(nblk), loff(nblk, -1), kind(nblk);
-    int nx = 0, nc = 0;
+    // ---- sizes of the camera side (the tables themselves come from the camera half below)
+    int nx = 0, nc = 0, npose_free = 0;
     for (int c = 0; c < nblk; c++) {
         const ParamBlock &pb = p.blocks[out.cam_block[c]];
-        gsize[c] = pb.size; kind[c] = pb.kind; goff[c] = nx; nx += pb.size;
-        if (pb.kind == KIND_EUCLID && pb.size > 15) { set_error("Euclidean block wider than 15"); return TCV_ERR_UNSUPPORTED; }
+        nx += pb.size;
+        if (pb.kind == KIND_POSE && !pb.constant) npose_free++;
     }
-    for (int c = 0; c < nblk; c++)
-        if (kind[c] == KIND_POSE && !p.blocks[out.cam_block[c]].constant) { loff[c] = nc; nc += 6; }
-    // Td comes right behind the poses: its column rides through the 6-wide gather machinery as a pseudo block whose other five
-    // columns are structural zeros, so five more tangent rows must follow it.  It counts as part of the "pose part" npp: the
-    // leading tangent dims the visual factors touch (landmark Schur corrections of the diagonal and the right-hand side).
     const int td_cam = td_blk >= 0 ? cam_of[td_blk] : -1;
-    if (td_cam >= 0 && !p.blocks[td_blk].constant) { loff[td_cam] = nc; nc += 1; }
-    const int npp = nc;
-    for (int c = 0; c < nblk; c++)
-        if (kind[c] != KIND_POSE && c != td_cam && !p.blocks[out.cam_block[c]].constant) { loff[c] = nc; nc += gsize[c]; }
+    const int td_free = (td_cam >= 0 && !p.blocks[td_blk].constant) ? 1 : 0;
+    const int npp = 6 * npose_free + td_free;
+    nc = npp;
+    for (int c = 0; c < nblk; c++) { const ParamBlock &pb = p.blocks[out.cam_block[c]]; if (pb.kind != KIND_POSE && c != td_cam && !pb.constant) nc += pb.size; }
     if (nc < 1) { set_error("no free camera-side parameter block"); return TCV_ERR_INVALID; }
-    out.cam_loff = loff;
     const int nt = (nc + 1 + 15) / 16, ntp = (npp + 15) / 16;
     const int ntiles = nt * (nt + 1) / 2, pp_tiles = ntp * (ntp + 1) / 2;
-    if (td_cam >= 0 && loff[td_cam] >= 0 && loff[td_cam] + 6 > nt * 16) { set_error("Td block: no room for its gather slot"); return TCV_ERR_UNSUPPORTED; }
-    // camera tangent dims: 171 for the 11 frames + extrinsic of OptimizationWithLine (172 with Td), 177 with the relocalisation pose (:1854-1886)
     if (nc > CAM_MAX - 1 || npp > 88 || nc + L > SCR_NL || L > 1024) { set_error("window too large for the fused solver (camera tangent dim > 183)"); return TCV_ERR_TOO_LARGE; }
     const int camw = nc <= CAM_W - 1 ? (int)CAM_W : (int)CAM_MAX;
     const int nxl = (nx + L + 1) & ~1;
@@ -384,146 +864,90 @@ static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds,
     // window needs the chain layout, decided below)
     const bool dense_fits = area_cap >= 512;
     if (!dense_fits && mode != 0) { set_error("window too large for the fused solver (LDS)"); return TCV_ERR_TOO_LARGE; }
-
-    // ---- chain layout: the free Euclidean camera blocks (speed-biases, 9 wide) only meet their IMU neighbours and the
-    // prior, so they are eliminated one after the other BEFORE the dense pose system (block-sparse Cholesky with the poses
-    // ordered last, what SPARSE_SCHUR's reduced-camera factorisation exploits too).  Symbolic elimination at block level:
-    // eligible iff every Euclidean block has at most one later-eliminated Euclidean neighbour and that one is next in order.
-    struct ChainStep { int cam, t0; std::vector<int> prow_t; bool next; int nsrc, f[2], lc[2]; };
-    std::vector<ChainStep> chain;
-    bool use_chain = (mode == 0);
-    std::vector<int> eorder;
-    if (use_chain) {
-        std::vector<char> in_prior(nblk, 0);
-        if (!p.prior.empty()) for (int b : p.prior[0].b) if (cam_of[b] >= 0) in_prior[cam_of[b]] = 1;
-        // (Td is no chain block: it belongs to the pose part, one column wide -- every point factor and so every pose meets it)
-        for (int c = nblk - 1; c >= 0; c--) if (kind[c] != KIND_POSE && c != td_cam && loff[c] >= 0 && !in_prior[c]) eorder.push_back(c);
-        for (int c = nblk - 1; c >= 0; c--) if (kind[c] != KIND_POSE && c != td_cam && loff[c] >= 0 && in_prior[c]) eorder.push_back(c);
-        for (int c : eorder) if (gsize[c] != CH_W) use_chain = false;
-        if (eorder.empty() || eorder.size() > 16 || npp < 1) use_chain = false;
-    }
-    if (use_chain) {
-        const int ne = (int)eorder.size();
-        std::vector<int> pos(nblk, -1);
-        for (int s2 = 0; s2 < ne; s2++) pos[eorder[s2]] = s2;
-        std::vector<std::vector<char>> adj(nblk, std::vector<char>(nblk, 0));
-        auto link = [&](const std::vector<int> &bs) { for (int a2 : bs) for (int b2 : bs) if (a2 != b2 && loff[a2] >= 0 && loff[b2] >= 0) adj[a2][b2] = 1; };
-        for (auto &f : p.imu) link({cam_of[f.b[0]], cam_of[f.b[1]], cam_of[f.b[2]], cam_of[f.b[3]]});
-        if (!p.prior.empty()) { std::vector<int> bs; for (int b : p.prior[0].b) bs.push_back(cam_of[b]); link(bs); }
-        for (int s2 = 0; s2 < ne && use_chain; s2++) {
-            const int e = eorder[s2];
-            ChainStep st;
-            st.cam = e; st.t0 = loff[e]; st.next = false; st.nsrc = 0; st.f[0] = st.f[1] = 0; st.lc[0] = st.lc[1] = 0;
-            std::vector<int> later;
-            for (int x = 0; x < nblk; x++) if (adj[e][x] && pos[x] > s2) later.push_back(x);
-            if (later.size() > 1 || (later.size() == 1 && pos[later[0]] != s2 + 1)) { use_chain = false; break; }
-            st.next = !later.empty();
-            std::vector<int> prow;
-            for (int x = 0; x < nblk; x++) if (adj[e][x] && (kind[x] == KIND_POSE || x == td_cam)) prow.push_back(x);
-            std::sort(prow.begin(), prow.end(), [&](int a2, int b2) { return loff[a2] < loff[b2]; });
-            for (int x : prow) for (int j = 0; j < (x == td_cam ? 1 : 6); j++) st.prow_t.push_back(loff[x] + j);
-            // fill: the eliminated block's neighbours become a clique (pose-pose is dense anyway)
-            for (int x : later) for (int y : prow) { adj[x][y] = 1; adj[y][x] = 1; }
-            for (size_t k = 0; k < p.imu.size(); k++)
-                for (int sl = 1; sl < 4; sl += 2)
-                    if (cam_of[p.imu[k].b[sl]] == e) {
-                        if (st.nsrc >= 2) { use_chain = false; break; }
-                        st.f[st.nsrc] = (int)k; st.lc[st.nsrc] = sl == 1 ? 6 : 21; st.nsrc++;
-                    }
-            if (CH_W + (st.next ? CH_W : 0) + (int)st.prow_t.size() + 1 > CH_MAXROWS) use_chain = false;
-            chain.push_back(st);
-        }
-    }
-    // (Td's gather slot is six columns wide, tcv_packed.h: the pose tiles have to cover the five structural zeros behind its column)
-    const int nt_c = (std::max(npp + 1, (td_cam >= 0 && loff[td_cam] >= 0) ? loff[td_cam] + 6 : 0) + 15) / 16, ctiles = nt_c * (nt_c + 1) / 2;
+    const int td_t_pre = td_free ? 6 * npose_free : -1;
+    const int nt_c = (std::max(npp + 1, td_t_pre >= 0 ? td_t_pre + 6 : 0) + 15) / 16, ctiles = nt_c * (nt_c + 1) / 2;
     const int c_vec = 2 * nxl + (3 * camw + 176) + 64 + 112;
     const int c_lds = coop_chunks > 0 ? (LDS_DOUBLES - ctiles * 256 - 8) : ((chain_lds >= 6144 && chain_lds <= LDS_DOUBLES) ? (chain_lds & ~1) : chain_lds_doubles());
     const int c_pool = c_lds - ctiles * 256 - c_vec;
-    if (use_chain && (c_pool < chain_pool_doubles((int)chain.size(), nt_c) || c_pool < IMU_REC)) use_chain = false;
+    const int n_imu = (int)p.imu.size();
 
-    lap("classification + chain steps");
-    PlanHdr &H = out.hdr;
-    std::memset(&H, 0, sizeof(H));
-    H.nblk = nblk; H.nland = L; H.nc = nc; H.nx = nx; H.npp = npp; H.nt = nt; H.ntp = ntp;
-    H.n_imu = (int)p.imu.size(); H.n_proj = (int)p.proj.size(); H.n_line = (int)p.line.size();
-    H.lds_area = area_cap;
-    H.flags = td_blk >= 0 ? 1 : 0; H.td_cam = td_cam; H.camw = camw;
+    // ---- the camera half: chain layout if the graph allows it and its LDS pool holds the chain's working set
+    CamIn cin;
+    cin.p = &p; cin.cam_block = &out.cam_block; cin.cam_of = &cam_of; cin.td_blk = td_blk;
+    std::shared_ptr<const CamPlan> cam;
+    bool use_chain = (mode == 0);
+    auto cam_for = [&](bool chain) -> int {
+        const int imu_cap = chain ? c_pool : area_cap;       // chain mode: the whole pool holds IMU records
+        if (n_imu > 0 && imu_cap < IMU_REC) { if (chain) return 1; set_error("no LDS room for IMU staging"); return TCV_ERR_TOO_LARGE; }
+        cin.want_chain = chain; cin.per_imu = std::max(1, std::min(n_imu, imu_cap / IMU_REC));
+        return get_cam(cin, cam, !ref_path && !no_cache);
+    };
+    if (use_chain) {
+        const int rc = cam_for(true);
+        if (rc < 0) return rc;
+        if (rc == 1 || !cam->eligible || c_pool < chain_pool_doubles(cam->hdr.n_e, nt_c) || c_pool < IMU_REC) use_chain = false;
+    }
+    if (!use_chain) {
+        if (!dense_fits) { set_error("window too large for the fused solver (LDS; its speed-bias blocks do not form a chain either)"); return TCV_ERR_TOO_LARGE; }
+        const int rc = cam_for(false);
+        if (rc != TCV_OK) return rc;
+    }
+    const std::vector<int> *loffp = &cam->loff;
+    lap("classification + camera half");
+
     const int prec = td_blk >= 0 ? (int)PROJ_TD_REC : (int)PROJ_REC;      // doubles per staged point record
-    const int td_t = td_cam >= 0 ? loff[td_cam] : -1;
-    std::vector<int> &I = out.ints;
-    I.clear();
-    auto mark = [&]() { return (int)I.size(); };
-
-    H.o_blk = mark();
-    for (int c = 0; c < nblk; c++) { I.push_back(gsize[c]); I.push_back(goff[c]); I.push_back(loff[c]); I.push_back(kind[c]); }
-    H.o_imu = mark();
-    for (auto &f : p.imu) for (int k = 0; k < 4; k++) I.push_back(cam_of[f.b[k]]);
+    const int td_t = td_cam >= 0 ? (*loffp)[td_cam] : -1;
 
     // ---- projection factors sorted by landmark (stable), landmark slots
+    const int nproj = (int)p.proj.size(), nline = (int)p.line.size();
     std::vector<int> &order = out.proj_order;
-    order.resize(p.proj.size());
-    for (size_t i = 0; i < order.size(); i++) order[i] = (int)i;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lm_of[p.proj[a].b[3]] < lm_of[p.proj[b].b[3]]; });
+    order.resize(nproj);
     std::vector<int> lmptr(L + 1, 0);
     for (auto &f : p.proj) lmptr[lm_of[f.b[3]] + 1]++;
     for (int l = 0; l < L; l++) lmptr[l + 1] += lmptr[l];
-    std::vector<std::vector<int>> lm_slots(L);   // tangent offsets of the distinct free pose blocks
+    {      // stable counting sort by landmark
+        std::vector<int> pos(lmptr.begin(), lmptr.end() - 1);
+        for (int i = 0; i < nproj; i++) order[pos[lm_of[p.proj[i].b[3]]]++] = i;
+    }
+    // slots of a landmark = the distinct free pose-kind blocks (and Td) it is seen from, in order of first appearance: flat arrays, and per
+    // sorted factor the slot of each of its columns (-1: constant block)
+    const int ncol_f = td_t >= 0 ? 4 : 3;
+    std::vector<int> slotptr(L + 1, 0), slot_t;
+    std::vector<signed char> fslot((size_t)nproj * 4, -1);
+    std::vector<int> ft((size_t)nproj * 4, -1);      // per sorted factor: tangent offset of each column group (-1 constant)
+    slot_t.reserve((size_t)L * 8);
     std::vector<int> e_off(L + 1, 0);
     for (int l = 0; l < L; l++) {
+        const int s0 = (int)slot_t.size();
+        slotptr[l] = s0;
         for (int k = lmptr[l]; k < lmptr[l + 1]; k++) {
             const ProjFac &f = p.proj[order[k]];
-            for (int s = 0; s < 3; s++) {
-                const int t = loff[cam_of[f.b[s]]];
+            for (int s = 0; s < ncol_f; s++) {
+                const int t = s < 3 ? (*loffp)[cam_of[f.b[s]]] : td_t;
+                ft[(size_t)k * 4 + s] = t;
                 if (t < 0) continue;
-                if (std::find(lm_slots[l].begin(), lm_slots[l].end(), t) == lm_slots[l].end()) lm_slots[l].push_back(t);
+                int q = s0;
+                const int s1 = (int)slot_t.size();
+                while (q < s1 && slot_t[q] != t) q++;
+                if (q == s1) slot_t.push_back(t);
+                fslot[(size_t)k * 4 + s] = (signed char)(q - s0);
             }
-            if (td_t >= 0 && std::find(lm_slots[l].begin(), lm_slots[l].end(), td_t) == lm_slots[l].end()) lm_slots[l].push_back(td_t);
         }
-        if (lm_slots[l].size() > 40) { set_error("landmark observed from more than 40 blocks"); return TCV_ERR_TOO_LARGE; }
+        const int ns = (int)slot_t.size() - s0;
+        if (ns > 40) { set_error("landmark observed from more than 40 blocks"); return TCV_ERR_TOO_LARGE; }
         if (e_off[l] >= (1 << 16) - 256) { set_error("landmark coupling store too large"); return TCV_ERR_TOO_LARGE; }
-        e_off[l + 1] = e_off[l] + 6 * (int)lm_slots[l].size() + 2;   // + 1/kappa and gl/kappa behind the slice
+        e_off[l + 1] = e_off[l] + 6 * ns + 2;   // + 1/kappa and gl/kappa behind the slice
     }
-    H.hcl_total = e_off[L];
-    if (H.hcl_total > (1 << 16) - 256) { set_error("landmark coupling store too large"); return TCV_ERR_TOO_LARGE; }
-    H.o_proj = mark();
-    for (size_t k = 0; k < order.size(); k++) {
-        const ProjFac &f = p.proj[order[k]];
-        for (int s = 0; s < 3; s++) I.push_back(cam_of[f.b[s]]);
-        I.push_back(lm_of[f.b[3]]);
+    slotptr[L] = (int)slot_t.size();
+    // (the reference order of the slots: Td is appended behind the three pose slots of every factor, as above)
+    if (e_off[L] > (1 << 16) - 256) { set_error("landmark coupling store too large"); return TCV_ERR_TOO_LARGE; }
+    for (int k = 0; k < nproj; k++) {
+        const int *t4 = ft.data() + (size_t)k * 4;
+        for (int a2 = 0; a2 < ncol_f; a2++) for (int b2 = 0; b2 < a2; b2++)
+            if (t4[a2] >= 0 && t4[a2] == t4[b2]) { set_error("projection factor uses one block twice"); return TCV_ERR_UNSUPPORTED; }
     }
-    H.o_line = mark();
-    for (auto &f : p.line) I.push_back(cam_of[f.b]);
-
-    // ---- prior
-    if (p.prior.size() > 1) { set_error("more than one marginalisation factor"); return TCV_ERR_UNSUPPORTED; }
-    const tcv_prior *pr = p.prior.empty() ? nullptr : p.prior[0].prior;
-    H.o_prior = mark();
-    std::vector<int> pcol;
-    if (pr) {
-        if (pr->n > 128) { set_error("prior with more than 128 rows"); return TCV_ERR_TOO_LARGE; }
-        H.prior_n = pr->n; H.prior_nblk = (int)pr->size.size(); H.prior_xsize = pr->xsize;
-        pcol.assign(pr->n, -1);
-        for (int k = 0; k < H.prior_nblk; k++) {
-            const int b = p.prior[0].b[k];
-            if (cam_of[b] < 0) { set_error("prior attached to a landmark block"); return TCV_ERR_UNSUPPORTED; }
-            const ParamBlock &pb = p.blocks[b];
-            if (pb.size != pr->size[k]) { set_error("prior block size mismatch"); return TCV_ERR_INVALID; }
-            I.push_back(cam_of[b]); I.push_back(pr->idx[k]); I.push_back(pr->size[k]); I.push_back(pr->xoff[k]);
-            const int local = pr->size[k] == 7 ? 6 : pr->size[k];
-            const int t = loff[cam_of[b]];
-            for (int j = 0; j < local; j++)
-                if (pr->idx[k] + j < pr->n) pcol[pr->idx[k] + j] = t < 0 ? -1 : t + j;
-        }
-    }
-    H.o_pcol = mark();
-    for (int v : pcol) I.push_back(v);
-
-    H.o_lm = mark();
-    for (int l = 0; l < L; l++) { I.push_back(e_off[l]); I.push_back((int)lm_slots[l].size()); }
-    H.o_lmslotptr = mark();
-    { int acc = 0; for (int l = 0; l < L; l++) { I.push_back(acc); acc += (int)lm_slots[l].size(); } I.push_back(acc); }
-    H.o_lmslot = mark();
-    for (int l = 0; l < L; l++) for (int t : lm_slots[l]) I.push_back(t);
+    std::vector<int> line_t(nline);
+    for (int k = 0; k < nline; k++) line_t[k] = (*loffp)[cam_of[p.line[k].b]];
 
     // ---- visual chunks (whole landmarks; lines ride in chunk 0).  Staging holds the factor records AND the chunk's
     // gather program (units + items), so both count against the capacity.
@@ -531,7 +955,6 @@ static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds,
     std::vector<VChunk> vch;
     auto build_chunks = [&](int stage_cap, int area_cap, std::vector<VChunk> &vch) -> int {
         vch.clear();
-        const int nline = (int)p.line.size();
         const int npose = npp / 6;
         const int npb = npose + (td_t >= 0 ? 1 : 0);
         const int base_prog = 3 * (npb * (npb + 1) / 2 * 6 + npb);      // upper bound on tile + gradient units
@@ -544,7 +967,7 @@ static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds,
         VChunk cur{0, 0, 0, 0, 0, 0};
         int recs = 0, hcl = 0, nf_c = 0, slots_c = 0;
         for (int l = 0; l < L; l++) {
-            const int nf = lmptr[l + 1] - lmptr[l], ns = (int)lm_slots[l].size(), nh = 6 * ns + 2;
+            const int nf = lmptr[l + 1] - lmptr[l], ns = slotptr[l + 1] - slotptr[l], nh = 6 * ns + 2;
             if (need(nf * prec, nf, 1, ns, 0) > stage_cap || nh + 3 > area_cap) { set_error("landmark track too long for LDS staging"); return TCV_ERR_TOO_LARGE; }
             if (need(recs + nf * prec, nf_c + nf, cur.lmn + 1, slots_c + ns, 0) > stage_cap || hcl + nh + 3 * (cur.lmn + 1) > area_cap) {
                 vch.push_back(cur);
@@ -561,13 +984,12 @@ static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds,
         vch.push_back(cur);
         return TCV_OK;
     };
-    // gather programs of a chunk list; measures the staging / area doubles the largest chunk needs
-    auto emit_all = [&](const std::vector<VChunk> &vch, int stage_chk, int area_chk, std::vector<int> &vprog, std::vector<int> &sprog,
-                        std::vector<int> &vchunk_tab, int &max_stage, int &max_area) -> int {
-        vprog.clear(); sprog.clear(); vchunk_tab.clear(); max_stage = 0; max_area = 0;
-        for (auto &c : vch) {
+    static const int wu_v = getenv("TCV_WU_V") ? atoi(getenv("TCV_WU_V")) : (int)WAVE_UNIT_ITEMS, wu_s = getenv("TCV_WU_S") ? atoi(getenv("TCV_WU_S")) : (int)WAVE_UNIT_ITEMS,
+                     wu_max = getenv("TCV_WU_MAX") ? atoi(getenv("TCV_WU_MAX")) : (int)WAVE_UNIT_MAX;      // tuning experiments
+    // the two gather programs of one chunk: the generic builder (reference) ...
+    auto chunk_progs_ref = [&](const VChunk &c, RowProg &vp, RowProg &sp) -> int {
         DestList dl, sl;
-        std::vector<Col> cols;      // (one allocation per chunk instead of one per factor)
+        std::vector<Col> cols;
         cols.reserve(4);
         for (int k = 0; k < c.pn; k++) {
             const ProjFac &f = p.proj[order[c.pb + k]];
@@ -576,15 +998,13 @@ static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds,
             if (base >= (1 << 21)) { set_error("staging offset overflow"); return TCV_ERR_TOO_LARGE; }
             auto mk = [&](int ca, int cb) { return (int)(((unsigned)base << 11) | ((unsigned)ca << 6) | ((unsigned)cb << 1)); };
             cols.clear();
-            for (int s2 = 0; s2 < 3; s2++) cols.push_back(Col{loff[cam_of[f.b[s2]]], 6 * s2, 6});
+            for (int s2 = 0; s2 < 3; s2++) cols.push_back(Col{(*loffp)[cam_of[f.b[s2]]], 6 * s2, 6});
             if (td_t >= 0) cols.push_back(Col{td_t, 20, 6});      // [td | 5 zero columns]
-            for (size_t a2 = 0; a2 < cols.size(); a2++)
-                for (size_t b2 = 0; b2 < a2; b2++)
-                    if (cols[a2].t >= 0 && cols[a2].t == cols[b2].t) { set_error("projection factor uses one block twice"); return TCV_ERR_UNSUPPORTED; }
             add_pairs(dl, cols, mk, 19);
             for (auto &cc : cols) {
                 if (cc.t < 0) continue;
-                const int slot = (int)(std::find(lm_slots[l].begin(), lm_slots[l].end(), cc.t) - lm_slots[l].begin());
+                const int *sb = slot_t.data() + slotptr[l], *se = slot_t.data() + slotptr[l + 1];
+                const int slot = (int)(std::find(sb, se, cc.t) - sb);
                 dl.add(DK_HCL, e_off[l] + 6 * slot, 0, 6, 1, mk(18, cc.c));      // Hcl[e] += sum J[:,18] * J[:, c + e]
             }
             dl.add(DK_HLL, l, 0, 2, 1, mk(18, 18));                              // acc[0] = hll, acc[1] = gl (columns 18, 19)
@@ -595,61 +1015,151 @@ static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds,
             if (base >= (1 << 21)) { set_error("staging offset overflow"); return TCV_ERR_TOO_LARGE; }
             auto mk = [&](int ca, int cb) { return (int)(((unsigned)base << 11) | ((unsigned)ca << 6) | ((unsigned)cb << 1) | 1u); };
             cols.clear();
-            cols.push_back(Col{loff[cam_of[f.b]], 0, 6});
+            cols.push_back(Col{(*loffp)[cam_of[f.b]], 0, 6});
             add_pairs(dl, cols, mk, 6);
         }
         for (int l = c.lmb; l < c.lmb + c.lmn; l++) {
-            const auto &sl_t = lm_slots[l];
-            for (size_t a2 = 0; a2 < sl_t.size(); a2++) {
-                const unsigned hoff = (unsigned)(e_off[l] - e_off[c.lmb]), ns = (unsigned)sl_t.size();
+            const int *sl_t = slot_t.data() + slotptr[l];
+            const int nsl = slotptr[l + 1] - slotptr[l];
+            for (int a2 = 0; a2 < nsl; a2++) {
+                const unsigned hoff = (unsigned)(e_off[l] - e_off[c.lmb]), ns = (unsigned)nsl;
                 auto mk = [&](int sa, int sb) { return (int)((hoff << 18) | (ns << 12) | ((unsigned)sa << 6) | (unsigned)sb); };
-                sl.add(DK_TILE, sl_t[a2], sl_t[a2], 6, 0, mk((int)a2, (int)a2));
-                sl.add(DK_RC, sl_t[a2], 0, 6, 1, mk(63, (int)a2));                // rc[t + e] += gl/kappa * Hcl[slot][e]
-                for (size_t b2 = 0; b2 < a2; b2++) {
-                    if (sl_t[a2] > sl_t[b2]) sl.add(DK_TILE, sl_t[a2], sl_t[b2], 6, 6, mk((int)a2, (int)b2));
-                    else sl.add(DK_TILE, sl_t[b2], sl_t[a2], 6, 6, mk((int)b2, (int)a2));
+                sl.add(DK_TILE, sl_t[a2], sl_t[a2], 6, 0, mk(a2, a2));
+                sl.add(DK_RC, sl_t[a2], 0, 6, 1, mk(63, a2));                // rc[t + e] += gl/kappa * Hcl[slot][e]
+                for (int b2 = 0; b2 < a2; b2++) {
+                    if (sl_t[a2] > sl_t[b2]) sl.add(DK_TILE, sl_t[a2], sl_t[b2], 6, 6, mk(a2, b2));
+                    else sl.add(DK_TILE, sl_t[b2], sl_t[a2], 6, 6, mk(b2, a2));
                 }
             }
         }
         dl.finish(); sl.finish();
-        RowProg vp, sp;
-        static const int wu_v = getenv("TCV_WU_V") ? atoi(getenv("TCV_WU_V")) : (int)WAVE_UNIT_ITEMS, wu_s = getenv("TCV_WU_S") ? atoi(getenv("TCV_WU_S")) : (int)WAVE_UNIT_ITEMS,
-                         wu_max = getenv("TCV_WU_MAX") ? atoi(getenv("TCV_WU_MAX")) : (int)WAVE_UNIT_MAX;      // tuning experiments
         if (!emit_rows(dl, vp, false, wu_v, wu_max) || !emit_rows(sl, sp, false, wu_s, wu_max)) { set_error("gather program field overflow"); return TCV_ERR_TOO_LARGE; }
-        if (getenv("TCV_DEBUG_UNITS")) {
-            auto dump = [](const char *nm, const RowProg &rp) {
-                fprintf(stderr, "[pack] %s: %d units (%d wave units), items per unit (descending):", nm, rp.n_units, rp.n_wave_units);
-                for (int u = 0; u < rp.n_units; u += (u < 16 ? 1 : 16)) fprintf(stderr, " %d", rp.units[3 * u] & 0xfffff);
-                fprintf(stderr, "\n");
-            };
-            dump("visual", vp); dump("schur", sp);
-        }
-        const int recs = (c.pn * prec + c.ln * LINE_REC + 1) & ~1;
-        const int st_need = std::max(recs + ((int)(vp.units.size() + vp.items.size()) + 1) / 2 + 2, ((int)(sp.units.size() + sp.items.size()) + 1) / 2 + 2);
-        const int ar_need = (e_off[c.lmb + c.lmn] - e_off[c.lmb]) + 3 * c.lmn + 8;
-        max_stage = std::max(max_stage, st_need); max_area = std::max(max_area, ar_need);
-        if (stage_chk >= 0 && (st_need > stage_chk || ar_need > area_chk)) {
-            set_error("gather program does not fit the LDS staging area"); return TCV_ERR_TOO_LARGE;
-        }
-        while (vprog.size() & 3) vprog.push_back(0);        // every program starts 16-byte aligned (vector loads on the device)
-        while (sprog.size() & 3) sprog.push_back(0);
-        const int voff = (int)vprog.size(), soff = (int)sprog.size();
-        vprog.insert(vprog.end(), vp.units.begin(), vp.units.end()); vprog.insert(vprog.end(), vp.items.begin(), vp.items.end());
-        sprog.insert(sprog.end(), sp.units.begin(), sp.units.end()); sprog.insert(sprog.end(), sp.items.begin(), sp.items.end());
-        const int tab[16] = {c.pb, c.pn, c.lb, c.ln, voff, vp.n_units, vp.n_wave_units, (int)vp.items.size(),
-                             c.lmb, c.lmn, e_off[c.lmb], e_off[c.lmb + c.lmn] - e_off[c.lmb],
-                             soff, sp.n_units, sp.n_wave_units, (int)sp.items.size()};
-        vchunk_tab.insert(vchunk_tab.end(), tab, tab + 16);
-            }
         return TCV_OK;
     };
-    lap("tables, landmark slots");
-    std::vector<int> vprog, sprog, vchunk_tab;
+    // ... and the fast one (same programs, int by int)
+    auto chunk_progs_fast = [&](const VChunk &c, std::vector<int> &vprog, std::vector<int> &sprog, ProgOut &vp, ProgOut &sp) -> int {
+        if ((c.pn > 0 && (long long)(c.pn - 1) * prec >= (1 << 21)) || (c.ln > 0 && (long long)c.pn * prec + (long long)(c.ln - 1) * LINE_REC >= (1 << 21))) { set_error("staging offset overflow"); return TCV_ERR_TOO_LARGE; }
+        const int sp0 = slotptr[c.lmb];
+        const int PS_HCL = PS_LM + c.lmn, nslot = PS_HCL + (slotptr[c.lmb + c.lmn] - sp0);
+        const int colc[4] = {0, 6, 12, 20};
+        auto vis_walk = [&](auto add) {
+            for (int k = 0; k < c.pn; k++) {
+                const int kk = c.pb + k;
+                const int l = lm_of[p.proj[order[kk]].b[3]];
+                const int *t4 = ft.data() + (size_t)kk * 4;
+                const unsigned base = (unsigned)(k * prec) << 11;
+                for (int a2 = 0; a2 < ncol_f; a2++) {
+                    if (t4[a2] < 0) continue;
+                    const int oa = t4[a2] / 6, ca = colc[a2];
+                    add(PS_TILE + oa * 16 + oa, (int)(base | ((unsigned)ca << 6) | ((unsigned)ca << 1)));
+                    add(PS_G + oa, (int)(base | (19u << 6) | ((unsigned)ca << 1)));
+                    for (int b2 = 0; b2 < a2; b2++) {
+                        if (t4[b2] < 0) continue;
+                        const int ob = t4[b2] / 6, cb = colc[b2];
+                        if (t4[a2] > t4[b2]) add(PS_TILE + oa * 16 + ob, (int)(base | ((unsigned)ca << 6) | ((unsigned)cb << 1)));
+                        else add(PS_TILE + ob * 16 + oa, (int)(base | ((unsigned)cb << 6) | ((unsigned)ca << 1)));
+                    }
+                }
+                for (int a2 = 0; a2 < ncol_f; a2++) {
+                    if (t4[a2] < 0) continue;
+                    add(PS_HCL + (slotptr[l] - sp0) + fslot[(size_t)kk * 4 + a2], (int)(base | (18u << 6) | ((unsigned)colc[a2] << 1)));
+                }
+                add(PS_LM + (l - c.lmb), (int)(base | (18u << 6) | (18u << 1)));
+            }
+            for (int k = 0; k < c.ln; k++) {
+                const int t = line_t[c.lb + k];
+                if (t < 0) continue;
+                const unsigned base = (unsigned)(c.pn * prec + k * LINE_REC) << 11;
+                const int o = t / 6;
+                add(PS_TILE + o * 16 + o, (int)(base | 1u));
+                add(PS_G + o, (int)(base | (6u << 6) | 1u));
+            }
+        };
+        auto vis_dest = [&](int sl, int &kind, int &o0, int &o1, int &la, int &lb) {
+            if (sl < PS_G) { const int oa = sl >> 4, ob = sl & 15; kind = DK_TILE; o0 = 6 * oa; o1 = 6 * ob; la = 6; lb = oa == ob ? 0 : 6; }
+            else if (sl < PS_LM) { kind = DK_G; o0 = 6 * (sl - PS_G); o1 = 0; la = 6; lb = 1; }
+            else if (sl < PS_HCL) { kind = DK_HLL; o0 = c.lmb + (sl - PS_LM); o1 = 0; la = 2; lb = 1; }
+            else {
+                const int q = sp0 + (sl - PS_HCL);      // global slot index: its landmark by binary search in slotptr
+                const int l = (int)(std::upper_bound(slotptr.begin() + c.lmb, slotptr.begin() + c.lmb + c.lmn + 1, q) - slotptr.begin()) - 1;
+                kind = DK_HCL; o0 = e_off[l] + 6 * (q - slotptr[l]); o1 = 0; la = 6; lb = 1;
+            }
+        };
+        if (!fast_prog(nslot, vis_walk, vis_dest, vprog, vp, wu_v, wu_max)) { set_error("gather program field overflow"); return TCV_ERR_TOO_LARGE; }
+        auto sch_walk = [&](auto add) {
+            for (int l = c.lmb; l < c.lmb + c.lmn; l++) {
+                const int *sl_t = slot_t.data() + slotptr[l];
+                const int nsl = slotptr[l + 1] - slotptr[l];
+                const unsigned hdr = ((unsigned)(e_off[l] - e_off[c.lmb]) << 18) | ((unsigned)nsl << 12);
+                for (int a2 = 0; a2 < nsl; a2++) {
+                    const int oa = sl_t[a2] / 6;
+                    add(PS_TILE + oa * 16 + oa, (int)(hdr | ((unsigned)a2 << 6) | (unsigned)a2));
+                    add(PS_G + oa, (int)(hdr | (63u << 6) | (unsigned)a2));
+                    for (int b2 = 0; b2 < a2; b2++) {
+                        const int ob = sl_t[b2] / 6;
+                        if (sl_t[a2] > sl_t[b2]) add(PS_TILE + oa * 16 + ob, (int)(hdr | ((unsigned)a2 << 6) | (unsigned)b2));
+                        else add(PS_TILE + ob * 16 + oa, (int)(hdr | ((unsigned)b2 << 6) | (unsigned)a2));
+                    }
+                }
+            }
+        };
+        auto sch_dest = [&](int sl, int &kind, int &o0, int &o1, int &la, int &lb) {
+            if (sl < PS_G) { const int oa = sl >> 4, ob = sl & 15; kind = DK_TILE; o0 = 6 * oa; o1 = 6 * ob; la = 6; lb = oa == ob ? 0 : 6; }
+            else { kind = DK_RC; o0 = 6 * (sl - PS_G); o1 = 0; la = 6; lb = 1; }
+        };
+        if (!fast_prog(PS_LM, sch_walk, sch_dest, sprog, sp, wu_s, wu_max)) { set_error("gather program field overflow"); return TCV_ERR_TOO_LARGE; }
+        return TCV_OK;
+    };
+    // the fast path indexes blocks by ordinal = tangent offset / 6: every slot of the pose part is 6 wide (Td: its 6-wide gather slot) and
+    // there are at most 16 of them (npp <= 88); anything else takes the generic path
+    const bool fast_ok = !ref_path && npp <= 90;
+    // gather programs of a chunk list; measures the staging / area doubles the largest chunk needs
+    auto emit_all = [&](const std::vector<VChunk> &vch, int stage_chk, int area_chk, std::vector<int> &vprog, std::vector<int> &sprog,
+                        std::vector<int> &vchunk_tab, int &max_stage, int &max_area) -> int {
+        vprog.clear(); sprog.clear(); vchunk_tab.clear(); max_stage = 0; max_area = 0;
+        for (auto &c : vch) {
+            while (vprog.size() & 3) vprog.push_back(0);        // every program starts 16-byte aligned (vector loads on the device)
+            while (sprog.size() & 3) sprog.push_back(0);
+            const int voff = (int)vprog.size(), soff = (int)sprog.size();
+            ProgOut vp, sp;
+            if (fast_ok) { const int rcp = chunk_progs_fast(c, vprog, sprog, vp, sp); if (rcp != TCV_OK) return rcp; }
+            else {
+                RowProg rv, rs;
+                const int rcp = chunk_progs_ref(c, rv, rs);
+                if (rcp != TCV_OK) return rcp;
+                vprog.insert(vprog.end(), rv.units.begin(), rv.units.end()); vprog.insert(vprog.end(), rv.items.begin(), rv.items.end());
+                sprog.insert(sprog.end(), rs.units.begin(), rs.units.end()); sprog.insert(sprog.end(), rs.items.begin(), rs.items.end());
+                vp.n_units = rv.n_units; vp.n_wave_units = rv.n_wave_units; vp.n_items = (int)rv.items.size();
+                sp.n_units = rs.n_units; sp.n_wave_units = rs.n_wave_units; sp.n_items = (int)rs.items.size();
+            }
+            if (getenv("TCV_DEBUG_UNITS")) {
+                auto dump = [](const char *nm, const ProgOut &rp, const int *un) {
+                    fprintf(stderr, "[pack] %s: %d units (%d wave units), items per unit (descending):", nm, rp.n_units, rp.n_wave_units);
+                    for (int u = 0; u < rp.n_units; u += (u < 16 ? 1 : 16)) fprintf(stderr, " %d", un[3 * u] & 0xfffff);
+                    fprintf(stderr, "\n");
+                };
+                dump("visual", vp, vprog.data() + voff); dump("schur", sp, sprog.data() + soff);
+            }
+            const int recs = (c.pn * prec + c.ln * LINE_REC + 1) & ~1;
+            const int st_need = std::max(recs + (3 * vp.n_units + vp.n_items + 1) / 2 + 2, (3 * sp.n_units + sp.n_items + 1) / 2 + 2);
+            const int ar_need = (e_off[c.lmb + c.lmn] - e_off[c.lmb]) + 3 * c.lmn + 8;
+            max_stage = std::max(max_stage, st_need); max_area = std::max(max_area, ar_need);
+            if (stage_chk >= 0 && (st_need > stage_chk || ar_need > area_chk)) {
+                set_error("gather program does not fit the LDS staging area"); return TCV_ERR_TOO_LARGE;
+            }
+            const int tab[16] = {c.pb, c.pn, c.lb, c.ln, voff, vp.n_units, vp.n_wave_units, vp.n_items,
+                                 c.lmb, c.lmn, e_off[c.lmb], e_off[c.lmb + c.lmn] - e_off[c.lmb],
+                                 soff, sp.n_units, sp.n_wave_units, sp.n_items};
+            vchunk_tab.insert(vchunk_tab.end(), tab, tab + 16);
+        }
+        return TCV_OK;
+    };
+    lap("landmark slots");
+    static thread_local std::vector<int> vprog, sprog, vchunk_tab;      // (reused: a plan per window per frame)
     if (use_chain) {
         // chain layout: the LDS pool (staging | landmark coupling area) is small, so the landmarks are dealt evenly to the
         // smallest number k of chunks whose EXACT programs fit; the line factors are spread over the chunks
         bool found = false;
-        const int nline = (int)p.line.size(), nproj = (int)p.proj.size();
         // lower bound on k from the records alone, then jump by the measured overshoot: two exact trials instead of k
         const int kmax = std::max(1, std::min(L, 48));
         int k = std::max(1, (nproj * prec + nline * LINE_REC + c_pool - 1) / std::max(1, c_pool));
@@ -683,11 +1193,16 @@ static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds,
             if (ms + ma <= c_pool) { found = true; vch = cand; area_cap = ma; stage_cap = c_pool - ma; }
             else k = std::max(k + 1, std::min(kmax, (int)(((long long)k * (ms + ma) + c_pool - 1) / c_pool)));      // need(k) ~ a / k + b, b > 0: never overshoots the smallest k
         }
-        if (!found) { use_chain = false; chain.clear(); }
+        if (!found) {      // the visual half does not fit the chain layout's pool: the dense layout (its camera half, its slot offsets are the same)
+            use_chain = false;
+            if (!dense_fits) { set_error("window too large for the fused solver (LDS; its speed-bias blocks do not form a chain either)"); return TCV_ERR_TOO_LARGE; }
+            const int rc = cam_for(false);
+            if (rc != TCV_OK) return rc;
+            area_cap = LDS_DOUBLES - ntiles * 256 - 2 * nxl - (3 * camw + 176) - 64;
+            stage_cap = (ntiles - pp_tiles) * 256;
+        }
     }
-    if (!use_chain && !dense_fits) { set_error("window too large for the fused solver (LDS; its speed-bias blocks do not form a chain either)"); return TCV_ERR_TOO_LARGE; }
     if (!use_chain) {
-        chain.clear();
         { const int rc = build_chunks(stage_cap, area_cap, vch); if (rc != TCV_OK) return rc; }
         int ms = 0, ma = 0;
         const int rc = emit_all(vch, stage_cap, area_cap, vprog, sprog, vchunk_tab, ms, ma);
@@ -695,9 +1210,34 @@ static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds,
     }
     lap("chunks + gather programs");
     set_error("");
-    H.chain = use_chain ? 1 : 0; H.n_e = (int)chain.size(); H.nt_c = nt_c; H.c_stage_cap = stage_cap; H.c_area_cap = area_cap; H.c_pool = c_pool;
-    if (use_chain) H.lds_area = area_cap;
+
+    // ---- the plan: header = the camera half's fields + the window's own, int pool = [camera half | visual half]
+    PlanHdr &H = out.hdr;
+    H = cam->hdr;
+    H.nland = L; H.n_proj = nproj; H.n_line = nline;
+    H.hcl_total = e_off[L];
+    H.lds_area = area_cap;
+    H.c_stage_cap = stage_cap; H.c_area_cap = area_cap; H.c_pool = c_pool;
     H.n_vis_chunk = (int)vch.size();
+    PlanInts &I = out.ints;
+    I.clear();
+    I.reserve(cam->ints.size() + 4 * (size_t)nproj + nline + 3 * (size_t)L + slot_t.size() + vchunk_tab.size() + vprog.size() + sprog.size() + 32);
+    I.insert(I.end(), cam->ints.begin(), cam->ints.end());
+    auto mark = [&]() { return (int)I.size(); };
+    H.o_proj = mark();
+    for (int k = 0; k < nproj; k++) {
+        const ProjFac &f = p.proj[order[k]];
+        for (int s = 0; s < 3; s++) I.push_back(cam_of[f.b[s]]);
+        I.push_back(lm_of[f.b[3]]);
+    }
+    H.o_line = mark();
+    for (auto &f : p.line) I.push_back(cam_of[f.b]);
+    H.o_lm = mark();
+    for (int l = 0; l < L; l++) { I.push_back(e_off[l]); I.push_back(slotptr[l + 1] - slotptr[l]); }
+    H.o_lmslotptr = mark();
+    for (int l = 0; l <= L; l++) I.push_back(slotptr[l]);
+    H.o_lmslot = mark();
+    I.insert(I.end(), slot_t.begin(), slot_t.end());
     H.o_vchunk = mark(); I.insert(I.end(), vchunk_tab.begin(), vchunk_tab.end());
     while ((I.size() & 3) != 0) I.push_back(0);
     H.o_vdest = mark(); I.insert(I.end(), vprog.begin(), vprog.end()); H.n_vdest = 0;
@@ -705,173 +1245,10 @@ static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds,
     while ((I.size() & 3) != 0) I.push_back(0);
     H.o_sdest = mark(); I.insert(I.end(), sprog.begin(), sprog.end()); H.n_sdest = 0;
     H.o_sunit = H.o_sdest; H.n_sunit = (int)sprog.size(); H.o_sitem = H.o_sdest; H.n_sitem = 0;
-
-    std::vector<int> imap_all;
-    // ---- IMU chunks.  Per factor: the tangent index of each of its 30 local Jacobian columns (-1 for a constant
-    // block) and a colour; factors of one colour share no parameter block, so their J'J tiles can be scattered into the
-    // reduced camera system concurrently (the frame chain needs two colours).
-    {
-        const int imu_cap = use_chain ? c_pool : area_cap;       // chain mode: the whole pool holds IMU records
-        const int per = std::max(1, std::min(H.n_imu, imu_cap / IMU_REC));
-        if (H.n_imu > 0 && imu_cap < IMU_REC) { set_error("no LDS room for IMU staging"); return TCV_ERR_TOO_LARGE; }
-        if (H.n_imu > 16) { set_error("more than 16 IMU factors"); return TCV_ERR_TOO_LARGE; }
-        std::vector<int> &imap = imap_all;
-        std::vector<int> icolor(H.n_imu, 0), ichunk;
-        for (int fb = 0; fb < H.n_imu; fb += per) {
-            const int fn = std::min(per, H.n_imu - fb);
-            int ncol = 0;
-            for (int k = 0; k < fn; k++) {       // greedy colouring inside the chunk
-                const ImuFac &f = p.imu[fb + k];
-                for (int a2 = 0; a2 < 4; a2++)
-                    for (int b2 = 0; b2 < a2; b2++)
-                        if (f.b[a2] == f.b[b2]) { set_error("IMU factor uses one block twice"); return TCV_ERR_UNSUPPORTED; }
-                int col = 0;
-                for (;; col++) {
-                    bool clash = false;
-                    for (int j = 0; j < k && !clash; j++) {
-                        if (icolor[fb + j] != col) continue;
-                        for (int a2 = 0; a2 < 4; a2++) for (int b2 = 0; b2 < 4; b2++) if (p.imu[fb + j].b[a2] == f.b[b2]) clash = true;
-                    }
-                    if (!clash) break;
-                }
-                icolor[fb + k] = col;
-                ncol = std::max(ncol, col + 1);
-            }
-            if (ncol > 4) { set_error("IMU factors of one chunk need more than 4 colours"); return TCV_ERR_UNSUPPORTED; }
-            unsigned bits = 0;
-            for (int k = 0; k < fn; k++) bits |= (unsigned)icolor[fb + k] << (2 * k);      // 2 bits per factor
-            ichunk.push_back(fb); ichunk.push_back(fn); ichunk.push_back(ncol); ichunk.push_back((int)bits);
-        }
-        for (auto &f : p.imu) {
-            const int colc[4] = {0, 6, 15, 21}, colw[4] = {6, 9, 6, 9};
-            int m[32];
-            for (int i = 0; i < 32; i++) m[i] = -1;
-            for (int s2 = 0; s2 < 4; s2++) {
-                const int t = loff[cam_of[f.b[s2]]];
-                for (int j = 0; j < colw[s2]; j++) m[colc[s2] + j] = t < 0 ? -1 : t + j;
-            }
-            imap.insert(imap.end(), m, m + 32);
-        }
-        H.n_imu_chunk = (int)ichunk.size() / 4;
-        H.o_idest = mark(); I.insert(I.end(), imap.begin(), imap.end()); H.n_idest = (int)imap.size();
-        H.o_iunit = mark(); I.insert(I.end(), icolor.begin(), icolor.end()); H.n_iunit = (int)icolor.size();
-        // scatter table of the J'J tiles (see IMU_SC_BIAS): what the kernel would derive from the tangent map for every lane and register
-        std::vector<int> sct((size_t)H.n_imu * 1024, 0);
-        for (int f = 0; f < H.n_imu; f++) {
-            const int *tm = imap.data() + (size_t)f * 32;
-            for (int lane = 0; lane < 64; lane++) {
-                const int i16 = lane & 15, k4 = lane >> 4;
-                for (int tile = 0; tile < 4; tile++) {     // (I, J): (0,0) (1,0) (1,1) (0,1)
-                    const int Ir = (tile == 1 || tile == 2) ? 1 : 0, Jc = (tile >= 2) ? 1 : 0;
-                    const int bl = 16 * Jc + i16;
-                    for (int i = 0; i < 4; i++) {
-                        const int al = 16 * Ir + k4 + 4 * i;
-                        const int ta = tm[al], tb = tm[bl];
-                        int d = -1, store = 0;
-                        if (ta >= 0) {
-                            if (bl == 30) d = -2 - ta;
-                            else if (tile != 3 && bl < 30 && al >= bl && tb >= 0) {
-                                store = use_chain ? 1 : 0;
-                                if (use_chain && (ta >= npp || tb >= npp)) d = (al == bl) ? -1000 - (ta - npp) : -1;
-                                else d = ta >= tb ? tix(ta, tb) : tix(tb, ta);
-                            }
-                        }
-                        if (d + IMU_SC_BIAS < 0 || d + IMU_SC_BIAS >= (1 << 16)) { set_error("IMU scatter destination out of range"); return TCV_ERR_TOO_LARGE; }
-                        sct[(size_t)f * 1024 + lane * 16 + tile * 4 + i] = (d + IMU_SC_BIAS) | (store ? IMU_SC_STORE : 0);
-                    }
-                }
-            }
-        }
-        while ((I.size() & 3) != 0) I.push_back(0);      // read with 16-byte loads
-        H.o_iitem = mark(); I.insert(I.end(), sct.begin(), sct.end()); H.n_iitem = (int)sct.size();
-        H.o_ichunk = mark(); I.insert(I.end(), ichunk.begin(), ichunk.end());
-    }
-    {
-        // destinations of the constant part of the prior (Hp, packed lower triangle): same derivation as the kernel's former inline one
-        H.o_pdest = mark();
-        const int pn = (int)pcol.size();
-        for (int a2 = 0; a2 < pn; a2++)
-            for (int b2 = 0; b2 <= a2; b2++) {
-                const int ta = pcol[a2], tb = pcol[b2];
-                int d = -1;
-                if (ta >= 0 && tb >= 0) {
-                    if (use_chain && (ta >= npp || tb >= npp)) { if (ta == tb) d = -2 - (ta - npp); }
-                    else d = ta >= tb ? tix(ta, tb) : tix(tb, ta);
-                }
-                I.push_back(d);
-            }
-    }
-    lap("program copy, IMU tables");
-    // ---- chain step tables
-    while ((I.size() & 3) != 0) I.push_back(0);
-    H.o_chain = mark();
-    if (use_chain) {
-        const int ne = (int)chain.size();
-        std::vector<int> tab((size_t)ne * CH_STRIDE, 0);
-        std::vector<int> pinv(nc + 1, -1);
-        for (size_t j = 0; j < pcol.size(); j++) if (pcol[j] >= 0) pinv[pcol[j]] = (int)j;
-        const int wstride = 16 * nt_c * CH_W;      // W rows of one step in the spill area: 16 nt_c columns (whole tiles) x 9
-        std::vector<std::vector<int>> rowt(ne);
-        for (int s2 = 0; s2 < ne; s2++) {
-            const ChainStep &st = chain[s2];
-            std::vector<int> &rt = rowt[s2];
-            for (int j = 0; j < CH_W; j++) rt.push_back(st.t0 + j);
-            if (st.next) for (int j = 0; j < CH_W; j++) rt.push_back(chain[s2 + 1].t0 + j);
-            for (int t : st.prow_t) rt.push_back(t);
-            rt.push_back(-2);
-        }
-        for (int s2 = 0; s2 < ne; s2++) {
-            const ChainStep &st = chain[s2];
-            const std::vector<int> &rt = rowt[s2];
-            const int nr = (int)rt.size();
-            int *h = tab.data() + (size_t)s2 * CH_STRIDE;
-            h[CH_T0] = st.t0; h[CH_R] = nr - CH_W - 1; h[CH_NEXT] = st.next ? 1 : 0; h[CH_NSRC] = st.nsrc;
-            h[CH_F0] = st.f[0]; h[CH_LC0] = st.lc[0]; h[CH_F1] = st.f[1]; h[CH_LC1] = st.lc[1];
-            h[CH_PC0] = pinv[st.t0]; h[CH_SPILL] = s2 * wstride;
-            unsigned char *colrow = reinterpret_cast<unsigned char *>(h + CH_COLROW);
-            for (int c = 0; c < CH_MAXROWS; c++) colrow[c] = 255;
-            int tmask = 0;
-            for (int r = 0; r < nr; r++) {
-                int vn = 255;
-                if (st.next) {
-                    const std::vector<int> &nx2 = rowt[s2 + 1];
-                    for (size_t q = 0; q < nx2.size(); q++) if (nx2[q] == rt[r]) vn = (int)q;
-                    if (r >= CH_W && vn == 255) { set_error("chain: fill row missing in the next front"); return TCV_ERR_INVALID; }
-                }
-                int l01[2] = {255, 255};
-                for (int src = 0; src < st.nsrc; src++)
-                    if (rt[r] >= 0)
-                        for (int l = 0; l < 30; l++) if (imap_all[(size_t)st.f[src] * 32 + l] == rt[r]) l01[src] = l;
-                const int tr = rt[r] >= 0 ? rt[r] : 255;
-                if (tr > 254 && rt[r] >= 0) { set_error("chain: tangent index overflow"); return TCV_ERR_TOO_LARGE; }
-                h[CH_INTS + 2 * r] = tr | (vn << 8) | (l01[0] << 16) | (l01[1] << 24);
-                h[CH_INTS + 2 * r + 1] = rt[r] >= 0 ? pinv[rt[r]] : -1;
-                // pose rows (tangent index < npp) and the rhs row are the columns of this step's W
-                const int col = rt[r] == -2 ? npp : ((rt[r] >= 0 && rt[r] < npp) ? rt[r] : -1);
-                if (col >= 0) {
-                    if (col >= CH_MAXROWS) { set_error("chain: pose column overflow"); return TCV_ERR_TOO_LARGE; }
-                    colrow[col] = (unsigned char)r;
-                    tmask |= 1 << (col >> 4);
-                }
-            }
-            h[CH_TMASK] = tmask;
-        }
-        const int spill = ne * wstride;
-        H.c_spill = (spill + 1) & ~1;
-        I.insert(I.end(), tab.begin(), tab.end());
-    }
-    // ---- frame table (gauge fix, estimator.cpp:1537-1581)
-    H.n_frames = (int)p.frame_pose.size();
-    H.o_frames = mark();
-    for (int i = 0; i < H.n_frames; i++) {
-        const int bp = p.frame_pose[i], bs = i < (int)p.frame_sb.size() ? p.frame_sb[i] : -1;
-        I.push_back(bp >= 0 && cam_of[bp] >= 0 ? goff[cam_of[bp]] : -1);
-        I.push_back(bs >= 0 && cam_of[bs] >= 0 ? goff[cam_of[bs]] : -1);
-    }
     while ((I.size() & 3) != 0) I.push_back(0);          // plans are concatenated: keep every plan 16-byte aligned
     H.plan_ints = (int)I.size();
-    lap("chain tables, frames");
-
+    out.cam_loff = cam->loff;
+    lap("plan assembly");
     return TCV_OK;
 }
 
@@ -1008,10 +1385,16 @@ namespace {
 struct PlanKey {
     std::vector<int> k;
     size_t h = 0;
-    void seal() {
-        unsigned long long x = 1469598103934665603ull;
-        for (int v : k) { x ^= (unsigned)v; x *= 1099511628211ull; }
-        h = (size_t)x;
+    void seal() {      // four independent multiply chains over 8-byte words (one chain per int was a third of a cache lookup)
+        unsigned long long x[4] = {1469598103934665603ull, 0x9E3779B97F4A7C15ull, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull};
+        const size_t n = k.size();
+        size_t i = 0;
+        for (; i + 8 <= n; i += 8)
+            for (int c = 0; c < 4; c++) { unsigned long long v; std::memcpy(&v, k.data() + i + 2 * c, 8); x[c] = (x[c] ^ v) * 0xFF51AFD7ED558CCDull; x[c] ^= x[c] >> 32; }
+        for (; i < n; i++) { x[0] = (x[0] ^ (unsigned)k[i]) * 1099511628211ull; }
+        unsigned long long r = x[0];
+        for (int c = 1; c < 4; c++) { r = (r ^ x[c]) * 0xFF51AFD7ED558CCDull; r ^= r >> 29; }
+        h = (size_t)(r ^ n);
     }
     bool operator==(const PlanKey &o) const { return h == o.h && k == o.k; }
 };
@@ -1028,28 +1411,44 @@ enum { CACHE_MAX_ENTRIES = 256 };
 
 void structure_key(const tcv_problem &p, int mode, int chain_lds, int coop_chunks, PlanKey &key) {
     std::vector<int> &k = key.k;
-    k.clear();
-    k.reserve(16 + 3 * p.blocks.size() + 4 * p.imu.size() + 5 * p.proj.size() + p.line.size() + 64);
-    k.push_back(mode); k.push_back(chain_lds); k.push_back(coop_chunks); k.push_back((int)p.blocks.size());
-    for (auto &b : p.blocks) k.push_back(b.size | (b.kind << 8) | ((int)b.constant << 16));
-    k.push_back((int)p.imu.size());
-    for (auto &f : p.imu) for (int j = 0; j < 4; j++) k.push_back(f.b[j]);
-    k.push_back((int)p.proj.size());
-    for (auto &f : p.proj) { for (int j = 0; j < 4; j++) k.push_back(f.b[j]); k.push_back(f.btd); }
-    k.push_back((int)p.line.size());
-    for (auto &f : p.line) k.push_back(f.b);
-    k.push_back((int)p.prior.size());
+    size_t n = 16 + p.blocks.size() + 4 * p.imu.size() + 5 * p.proj.size() + p.line.size() + p.frame_pose.size() + p.frame_sb.size();
+    for (auto &f : p.prior) n += 3 + 4 * f.b.size();
+    k.resize(n);
+    int *q = k.data();
+    *q++ = mode; *q++ = chain_lds; *q++ = coop_chunks; *q++ = (int)p.blocks.size();
+    for (auto &b : p.blocks) *q++ = b.size | (b.kind << 8) | ((int)b.constant << 16);
+    *q++ = (int)p.imu.size();
+    for (auto &f : p.imu) { q[0] = f.b[0]; q[1] = f.b[1]; q[2] = f.b[2]; q[3] = f.b[3]; q += 4; }
+    *q++ = (int)p.proj.size();
+    for (auto &f : p.proj) { q[0] = f.b[0]; q[1] = f.b[1]; q[2] = f.b[2]; q[3] = f.b[3]; q[4] = f.btd; q += 5; }
+    *q++ = (int)p.line.size();
+    for (auto &f : p.line) *q++ = f.b;
+    *q++ = (int)p.prior.size();
     for (auto &f : p.prior) {
         const tcv_prior *pr = f.prior;
-        k.push_back(pr->n); k.push_back((int)pr->size.size()); k.push_back(pr->xsize);
-        for (size_t j = 0; j < f.b.size(); j++) { k.push_back(f.b[j]); k.push_back(pr->size[j]); k.push_back(pr->idx[j]); k.push_back(pr->xoff[j]); }
+        *q++ = pr->n; *q++ = (int)pr->size.size(); *q++ = pr->xsize;
+        for (size_t j = 0; j < f.b.size(); j++) { *q++ = f.b[j]; *q++ = pr->size[j]; *q++ = pr->idx[j]; *q++ = pr->xoff[j]; }
     }
-    k.push_back((int)p.frame_pose.size());
-    for (int v : p.frame_pose) k.push_back(v);
-    for (int v : p.frame_sb) k.push_back(v);
+    *q++ = (int)p.frame_pose.size();
+    for (int v : p.frame_pose) *q++ = v;
+    for (int v : p.frame_sb) *q++ = v;
+    k.resize((size_t)(q - k.data()));
     key.seal();
 }
 }  // namespace
+
+// content hash of a plan (header + int pool): tcv_batch_create gives equal plans of a batch one device copy
+unsigned long long plan_content_hash(const PlanHdr &hdr, const PlanInts &pints) {
+    unsigned long long h = 0x9E3779B97F4A7C15ull ^ pints.size();
+    auto mix = [&](const int *p, size_t cnt) {
+        size_t i = 0;
+        for (; i + 1 < cnt; i += 2) { unsigned long long v; std::memcpy(&v, p + i, 8); h = (h ^ v) * 0xFF51AFD7ED558CCDull; h ^= h >> 29; }
+        if (i < cnt) { h = (h ^ (unsigned)p[i]) * 0xFF51AFD7ED558CCDull; h ^= h >> 29; }
+    };
+    mix(pints.data(), pints.size());
+    mix(reinterpret_cast<const int *>(&hdr), sizeof(PlanHdr) / sizeof(int));
+    return h;
+}
 
 void plan_cache_stats(long long *hits, long long *misses, long long *entries) {
     std::lock_guard<std::mutex> g(g_cache_mu);
@@ -1059,17 +1458,22 @@ void plan_cache_stats(long long *hits, long long *misses, long long *entries) {
 }
 
 int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int mode, int chain_lds, bool plan_only, int coop_chunks) {
-    static const bool no_cache = getenv("TCV_NO_PLAN_CACHE") != nullptr;
+    static const bool no_cache_env = getenv("TCV_NO_PLAN_CACHE") != nullptr;
+    const bool no_cache = no_cache_env || pack_reference();
     const int c_lds = (chain_lds >= 6144 && chain_lds <= LDS_DOUBLES) ? (chain_lds & ~1) : chain_lds_doubles();
     PlanKey key;
     std::shared_ptr<const PlanTemplate> T;
     std::memset(&out.win, 0, sizeof out.win);
+    static const bool dbg_t = getenv("TCV_DEBUG_PACK2") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) { if (dbg_t) { const auto t = std::chrono::steady_clock::now(); pack_lap_add(what, std::chrono::duration<double, std::micro>(t - t_prev).count()); t_prev = std::chrono::steady_clock::now(); } };
     if (!no_cache) {
         structure_key(p, mode, c_lds, coop_chunks, key);
         std::lock_guard<std::mutex> g(g_cache_mu);
         auto it = g_cache.find(key);
         if (it != g_cache.end()) { g_lru.splice(g_lru.begin(), g_lru, it->second); T = it->second->tmpl; g_hits++; } else g_misses++;
     }
+    lap("key + lookup");
     if (T) {
         out.hdr = T->hdr; out.tmpl = T; out.ints.clear();
         out.cam_block = T->cam_block; out.cam_loff = T->cam_loff; out.lm_block = T->lm_block; out.proj_order = T->proj_order;
@@ -1077,10 +1481,14 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int 
         out.tmpl.reset();
         const int rc = pack_plan(p, out, mode, c_lds, coop_chunks);
         if (rc != TCV_OK) return rc;
+        lap("pack_plan");
         if (!no_cache) {
             auto N = std::make_shared<PlanTemplate>();
             N->hdr = out.hdr; N->ints.swap(out.ints);
             N->cam_block = out.cam_block; N->cam_loff = out.cam_loff; N->lm_block = out.lm_block; N->proj_order = out.proj_order;
+            // identity for the de-duplication of equal plans inside a batch (tcv_batch_create compares the contents of candidates): equal
+            // structure keys give equal plans, so the key's hash serves -- hashing the 170 KB of content cost as much as a third of the build
+            N->hash = (unsigned long long)key.h * 0x9E3779B97F4A7C15ull + (unsigned long long)N->ints.size();
             out.tmpl = N;
             std::lock_guard<std::mutex> g(g_cache_mu);
             if (g_cache.find(key) == g_cache.end()) {      // (another thread may have packed the same structure meanwhile)
@@ -1090,9 +1498,12 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int 
             }
         }
     }
+    lap("template + cache insert");
     if (plan_only) {      // size only: the caller writes the data with pack_problem_data once every window of its batch has an offset
         Sink cnt(nullptr);
-        return pack_data_to(p, out, imu_sqrt, cnt);
+        const int rcd = pack_data_to(p, out, imu_sqrt, cnt);
+        lap("data size");
+        return rcd;
     }
     return pack_data(p, out, imu_sqrt);
 }

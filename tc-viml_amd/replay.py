@@ -771,6 +771,13 @@ class _EstimatorStats(C.Structure):
                 ("iterations", C.c_int), ("prior_n", C.c_int), ("final_cost", C.c_double)]
 
 
+class _FrameInput(C.Structure):
+    _fields_ = [("n_imu", C.c_int), ("acc", C.POINTER(C.c_double)), ("gyr", C.POINTER(C.c_double)),
+                ("n_points", C.c_int), ("point_ids", C.POINTER(C.c_int)), ("points", C.POINTER(C.c_double)),
+                ("n_lines", C.c_int), ("line_ids", C.POINTER(C.c_int)), ("lines", C.POINTER(C.c_double)),
+                ("truth", C.POINTER(C.c_double))]
+
+
 class NativeLockstep:
     """Several sequences advanced in lock step through the native estimator (include/tcv_estimator.h): one estimator per stream,
     every frame the full windows of all streams form ONE device batch (tcv_estimators_optimize).  Python only feeds the per-frame
@@ -789,6 +796,7 @@ class NativeLockstep:
         L.tcv_estimator_set_biases.argtypes = [vp, dp, dp]
         L.tcv_estimator_set_line_map.argtypes = [vp, C.c_int, dp, dp, dp]
         L.tcv_estimator_begin_frame.argtypes = [vp, C.c_int, dp, dp, C.c_int, ip, dp, C.c_int, ip, dp, dp, ip]
+        L.tcv_estimators_begin_frames.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(_FrameInput), ip, ip]
         L.tcv_estimators_optimize.argtypes = [C.POINTER(vp), C.c_int]
         L.tcv_estimator_finish_frame.argtypes = [vp, dp, dp, dp]
         L.tcv_estimators_finish_frames.argtypes = [C.POINTER(vp), C.c_int, dp, dp, dp, C.POINTER(C.c_int), C.POINTER(_EstimatorStats)]
@@ -822,7 +830,7 @@ class NativeLockstep:
         self.host_s = [0.0, 0.0, 0.0, 0]              # seconds in begin_frame x streams | tcv_estimators_optimize | stats + finish_frame x streams (incl. this harness); calls
         self._bias_sigma = bias_sigma
         self._raw = []
-        self._rdy = C.c_int()
+        self._batches = {}
 
     def reset(self):
         """tcv_estimator_reset on every estimator (Estimator::clearState + setParameter) and the replay's own bookkeeping back to frame 0:
@@ -839,6 +847,7 @@ class NativeLockstep:
         self._frames = [dict() for _ in self.streams]
         self.host_s = [0.0, 0.0, 0.0, 0]
         self._raw = []
+        self._batches = {}
 
     def prepare(self, k0: int = 0, k1: int = None):
         """converts the per-frame front-end records (dicts / lists of the simulated streams) of frames [k0, k1) into the contiguous arrays
@@ -872,11 +881,12 @@ class NativeLockstep:
     def _P(self, a):
         return a.ctypes.data_as(self.dp)
 
-    def step(self, k: int) -> int:
-        tcv, L, P, f64, ip, vp = self.tcv, self.L, self._P, self._f64, self.ip, self.vp
-        ready = []
-        t_a = time.perf_counter()
-        for si, (st, h, rng) in enumerate(zip(self.streams, self.ests, self.rngs)):
+    def _frame_batch(self, k: int):
+        """the input records of frame k for every stream that has one: (stream indices, estimator array, tcv_frame_input array, ready array,
+        the objects that own the memory)"""
+        f64, P, vp = self._f64, self._P, self.vp
+        live, keep = [], []
+        for si, (st, rng) in enumerate(zip(self.streams, self.rngs)):
             if k >= len(st["t"]):
                 continue
             truth = None
@@ -884,16 +894,44 @@ class NativeLockstep:
                 dth = rng.normal(size=3) * self.init_sigma[1]
                 truth = f64(np.concatenate([st["gt_p"][k] + rng.normal(size=3) * self.init_sigma[0], (st["gt_R"][k] @ deltaQ_R(dth)).reshape(9),
                                             st["gt_v"][k] + rng.normal(size=3) * self.init_sigma[2]]))
-            args, keep = self._frames[si].pop(k, None) or self._frame_args(st, k)
-            rdy = self._rdy
-            tcv.check(L.tcv_estimator_begin_frame(h, *args, None if truth is None else P(truth), C.byref(rdy)))
-            if rdy.value:
-                ready.append(si)
+            args, own = self._frames[si].pop(k, None) or self._frame_args(st, k)
+            live.append((si, args, truth)); keep.append((own, truth))
+        n = len(live)
+        rec = (_FrameInput * max(1, n))()
+        for j, (si, a, truth) in enumerate(live):
+            r = rec[j]
+            r.n_imu = a[0]
+            if a[1] is not None:
+                r.acc, r.gyr = a[1], a[2]
+            r.n_points, r.point_ids, r.points = a[3], a[4], a[5]
+            r.n_lines, r.line_ids, r.lines = a[6], a[7], a[8]
+            if truth is not None:
+                r.truth = P(truth)
+        arr = (vp * max(1, n))(*[self.ests[si] for si, _, _ in live])
+        return [si for si, _, _ in live], arr, rec, (C.c_int * max(1, n))(), keep
+
+    def prepare_batches(self, k0: int, k1: int):
+        """the tcv_frame_input records of frames [k0, k1) ahead of time (what a front end hands over anyway), kept out of a timed loop.
+        Only valid behind the window fill: the initial-pose draws of frames <= WINDOW_SIZE come from the streams' generators in frame order."""
+        assert k0 > WINDOW_SIZE
+        self.prepare(k0, k1)
+        for k in range(k0, k1):
+            if k not in self._batches:
+                self._batches[k] = self._frame_batch(k)
+
+    def step(self, k: int) -> int:
+        tcv, L, P, f64, ip, vp = self.tcv, self.L, self._P, self._f64, self.ip, self.vp
+        t_a = time.perf_counter()
+        live, arr_all, rec, rdy, keep = self._batches.pop(k, None) or self._frame_batch(k)
+        if not live:
+            return 0
+        tcv.check(L.tcv_estimators_begin_frames(arr_all, len(live), rec, rdy, None))
+        ready = [si for j, si in enumerate(live) if rdy[j]]
         t_b = time.perf_counter()
         self.host_s[0] += t_b - t_a
         if not ready:
             return 0
-        arr = (vp * len(ready))(*[self.ests[si] for si in ready])
+        arr = arr_all if len(ready) == len(live) else (vp * len(ready))(*[self.ests[si] for si in ready])
         tcv.check(L.tcv_estimators_optimize(arr, len(ready)))
         t_c = time.perf_counter()
         self.host_s[1] += t_c - t_b; self.host_s[3] += 1

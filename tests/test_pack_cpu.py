@@ -53,3 +53,98 @@ def test_replay_sized_window_with_prior(tcv):
         w[k] = big[k]
     st = tcv.Window(w).plan_stats()
     assert st["nland"] == 140 and st["n_vis_chunk"] >= 3 and st["window_doubles"] > 10000
+
+
+def _plan_ints(tcv, W):
+    import ctypes as C
+    L = tcv.lib()
+    L.tcv_problem_plan_ints.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]
+    n = C.c_int()
+    tcv.check(L.tcv_problem_plan_ints(W.h, None, 0, C.byref(n)))
+    out = np.zeros(n.value, np.int32)
+    tcv.check(L.tcv_problem_plan_ints(W.h, out.ctypes.data_as(C.POINTER(C.c_int)), n.value, C.byref(n)))
+    return out
+
+
+def _replay_like_windows():
+    """window structures as a live estimator produces them: tracks of different lengths starting in different frames, a few line
+    factors per frame, with and without a prior, ragged frame counts"""
+    pre, main, z = golden_windows()
+    rng = np.random.Generator(np.random.PCG64(5))
+    wins = []
+    for n_land in (3, 40, 90, 140):
+        big = synth.window_at(synth.make_windows(900 + n_land, 1, n_landmarks=n_land), 0)
+        w = dict(main)
+        for k in ("proj", "lam"):
+            w[k] = big[k]
+        # ragged tracks: drop a random tail of every landmark's observations (keeps at least one factor per landmark)
+        pr = {k: np.asarray(v) for k, v in w["proj"].items()}
+        keep = np.ones(len(pr["landmark"]), bool)
+        for l in range(n_land):
+            idx = np.nonzero(pr["landmark"] == l)[0]
+            cut = rng.integers(1, len(idx) + 1)
+            keep[idx[cut:]] = False
+        w["proj"] = {k: (v[keep] if isinstance(v, np.ndarray) and v.shape[:1] == keep.shape else v) for k, v in pr.items()}
+        wins.append(w)
+        wins.append({k: v for k, v in w.items() if k != "prior"})
+    wins.append(synth.window_at(synth.make_windows(600, 1, n_landmarks=200), 0))
+    wins += [sub_window(synth.window_at(synth.make_windows(400, 1), 0), f) for f in (3, 6)]
+    return wins
+
+
+def test_fast_packer_builds_the_reference_plans_int_by_int(tcv):
+    """the fast gather-program builder with the cached camera half (tcv_pack.cpp fast_prog / get_cam) against the generic builder
+    (DestList + emit_rows, nothing cached): identical plans -- header and int pool -- for the chain and the dense layout, single-workgroup and
+    cooperative chunking, first build and cache hit"""
+    import os
+    L = tcv.lib()
+    wins = _replay_like_windows()
+    old = os.environ.get("TCV_PLAN_COOP")
+    built = 0
+    try:
+        for coop in ("0", "4"):
+            os.environ["TCV_PLAN_COOP"] = coop
+            for variant in (0, 1):
+                L.tcv_set_solver_variant(variant)
+                for i, w in enumerate(wins):
+                    W = tcv.Window(w)
+
+                    def plan():      # (a window that does not fit a layout must fail the same way on both paths)
+                        try:
+                            return _plan_ints(tcv, W)
+                        except tcv.TcvError as e:
+                            return np.frombuffer(str(e).encode(), np.uint8).astype(np.int32)
+                    L.tcv_set_packer_reference(1)
+                    ref = plan()
+                    L.tcv_set_packer_reference(0)
+                    fast, again = plan(), plan()
+                    built += ref.size > 1000
+                    assert ref.shape == fast.shape and (ref == fast).all() and (fast == again).all(), (coop, variant, i)
+    finally:
+        L.tcv_set_packer_reference(0)
+        L.tcv_set_solver_variant(0)
+        if old is None:
+            os.environ.pop("TCV_PLAN_COOP", None)
+        else:
+            os.environ["TCV_PLAN_COOP"] = old
+    assert built >= 30
+
+
+def test_camera_half_is_cached_across_visual_structures(tcv):
+    """windows that differ in their landmark tracks only share the camera half of their plans (IMU tables, chain records, prior tables)"""
+    import ctypes as C
+    L = tcv.lib()
+    pre, main, z = golden_windows()
+    st0 = (C.c_longlong * 4)()
+    tcv.check(L.tcv_plan_cache_stats(st0))
+    for n_land in (31, 32, 33, 34):
+        big = synth.window_at(synth.make_windows(1200 + n_land, 1, n_landmarks=n_land), 0)
+        w = dict(main)
+        for k in ("proj", "lam"):
+            w[k] = big[k]
+        tcv.Window(w).plan_stats()
+    st1 = (C.c_longlong * 4)()
+    tcv.check(L.tcv_plan_cache_stats(st1))
+    assert st1[1] - st0[1] == 4          # four new whole-plan structures ...
+    assert st1[3] - st0[3] <= 1          # ... on at most one new camera half
+    assert st1[2] - st0[2] >= 3
