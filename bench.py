@@ -46,6 +46,10 @@ HBM_PEAK_GBS = 8000.0                 # /opt/skills/guides/MI355X_MICROARCH.md: 
 SOLVER_ITERATIONS = 8
 # ALGORITHMIC bytes per trust-region iteration per window (cfg 3: 200 pt, 40 line, prior n=75, L=50)
 BYTES_PER_ITERATION_CFG3 = 89056
+# ALGORITHMIC FP64 flops per trust-region iteration per window (cfg 3: assembly 1.41 M + landmark Schur 0.13 M + Cholesky and
+# substitutions of the 171-dim system 1.73 M; the fused kernel does less -- chain elimination instead of the dense factorisation -- the figure
+# prices the WORK of an iteration, like the bytes do)
+FLOPS_PER_ITERATION_CFG3 = 3.3e6
 DRY = os.environ.get("TCV_BENCH_DRY") == "1"      # tests only: ranks skip the device work (launch / rendezvous / reduction logic runs for real)
 
 
@@ -93,6 +97,8 @@ def dist_setup(n_gpus: int, backend: str | None = None):
                          f"(python bench.py --gpus {n_gpus} starts them itself)")
     if world == 1:
         return 0, 1, 0, None
+    if not os.environ.get("TCV_BENCH_NO_PIN"):
+        cpu_share(local, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))      # (before torch / the library start their threads)
     import torch
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -115,6 +121,36 @@ def reduce_stats(dist, elapsed_s: float, windows: int, device=None, extra=()):
     dist.all_reduce(w, op=dist.ReduceOp.SUM)
     out = (float(t.item()), int(w[0].item()))
     return out + tuple(int(v) for v in w[1:].tolist()) if extra else out
+
+
+def gather_rank_rates(dist, elapsed_s: float, windows: int, device=None):
+    """per-rank windows/s as every rank measured it (rank order): a straggler is visible on the line"""
+    if dist is None:
+        return [windows / elapsed_s if elapsed_s > 0 else 0.0]
+    import torch
+    mine = torch.tensor([float(windows), float(elapsed_s)], dtype=torch.float64, device=device)
+    got = [torch.zeros(2, dtype=torch.float64, device=device) for _ in range(dist.get_world_size())]
+    dist.all_gather(got, mine)
+    return [float(g[0].item()) / float(g[1].item()) if float(g[1].item()) > 0 else 0.0 for g in got]
+
+
+def cpu_share(local: int, n_local: int):
+    """the host cores of one rank when several ranks share a node: the process's affinity mask cut into n_local contiguous pieces.  Set
+    before anything starts a thread (the library's worker threads inherit it, and size their pool by it), so the ranks' host sides do not
+    migrate over each other's cores.  Returns the share, or None when there is nothing to cut."""
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return None
+    if n_local <= 1 or len(cores) < n_local:
+        return None
+    per = len(cores) // n_local
+    share = cores[local * per:(local + 1) * per]
+    try:
+        os.sched_setaffinity(0, share)
+    except OSError:
+        return None
+    return share
 
 
 def ranks_seen(dist, device=None) -> int:
@@ -227,6 +263,63 @@ def cpu_baseline(wins, pool, nproc, budget_s: float = 12.0):
                       f"(oracle/tcv_oracle.c, {flags}; dense Schur, not Ceres)",
             "single_core_value": rates[len(rates) // 2], "single_core_sample": f"median per-process rate of the {nproc}-process run (min {rates[0]:.1f}, max {rates[-1]:.1f})",
             "one_process_alone_value": one_n / one_t, "one_process_alone_sample": f"{one_n} solves in {one_t:.1f} s, one process after the others have finished",
+            "host_cpu": _cpu_model(), "host_cores_available": os.cpu_count(), "cgroup_cpu_quota_cores": _cpu_quota()}
+
+
+def _cpu_replay_worker(args):
+    """one host process = one EuRoC-trajectory stream replayed through the Python window management with the CPU ORACLE back end
+    (tests/replay_oracle.py: the C restatement solves and marginalises every window, one thread like Ceres num_threads = 1).  Timed: the
+    back end's optimize() calls only (solve + gauge fix + marginalisation of a window) -- NOT the Python window management, the NumPy
+    pre-integration or the NumPy 2D-3D association around them, which the reference does in C++."""
+    stream_id, n_frames, features, lines, budget_s = args
+    for d in ("oracle", "tests", "tc-viml_amd"):
+        sys.path.insert(0, os.path.join(ROOT, d))
+    import replay
+    from replay_oracle import OracleBackend
+
+    class Timed(OracleBackend):
+        t = 0.0
+        n = 0
+        t_end = None
+
+        def optimize(self, win, marg_flag, num_iterations, fixed_iterations):
+            if self.t_end is not None and time.perf_counter() > self.t_end:
+                raise TimeoutError
+            t0 = time.perf_counter()
+            r = OracleBackend.optimize(self, win, marg_flag, num_iterations, fixed_iterations)
+            self.t += time.perf_counter() - t0
+            self.n += 1
+            return r
+
+    seqs = list(replay.EUROC_SEQUENCES)
+    st = replay.simulate_stream_euroc(seqs[stream_id % len(seqs)], n_frames, start_s=(0.5 + 3.0 * (stream_id // len(seqs))) % max(3.0, 33.0 - 0.1 * n_frames),
+                                      max_features=features, max_lines=lines, associate=True)
+    be = Timed()
+    be.t_end = time.perf_counter() + budget_s
+    try:
+        replay.run(st, be, num_iterations=SOLVER_ITERATIONS)
+    except TimeoutError:
+        pass
+    return be.n, be.t
+
+
+def cpu_replay_baseline(pool, nproc, n_frames, features, lines, budget_s, close=True):
+    """the replay workload's CPU figure: every granted core replays one of the SAME streams (stream i on process i) for a bounded time"""
+    t0 = time.perf_counter()
+    res = pool.map(_cpu_replay_worker, [(i, n_frames, features, lines, budget_s) for i in range(nproc)], chunksize=1)
+    wall = time.perf_counter() - t0
+    if close:
+        pool.close(); pool.join()
+    res = [r for r in res if r[0] > 0 and r[1] > 0]
+    if not res:
+        return None
+    rates = sorted(n / t for n, t in res)
+    return {"value": sum(rates), "unit": "solves/s", "cores": len(rates), "kind": "port",
+            "sample": f"{sum(n for n, _ in res)} windows of the replay's own streams (stream i on process i, {features} features + {lines} line tracks per frame, association "
+                      f"in the loop) solved and marginalised by the C restatement (oracle/tcv_oracle.c, one thread per stream like Ceres num_threads = 1; dense Schur, "
+                      f"not Ceres) in {max(t for _, t in res):.1f} s of back-end time per process ({wall:.1f} s wall: the Python window management, NumPy pre-integration "
+                      f"and NumPy association around the back end are NOT in the rate)",
+            "single_core_value": rates[len(rates) // 2], "single_core_sample": f"median per-process rate (min {rates[0]:.1f}, max {rates[-1]:.1f})",
             "host_cpu": _cpu_model(), "host_cores_available": os.cpu_count(), "cgroup_cpu_quota_cores": _cpu_quota()}
 
 
@@ -366,6 +459,45 @@ def stream_figures(tcv, torch, keep, B_stream: int = 512, rounds: int = 4, wins=
                                          "(tcv_batch_get_priors_device_async), as in the native estimator"}}
 
 
+def sweep_figures(tcv, keep, opts):
+    """B in {256, 1024, 4096} windows per launch and the run-to-convergence rate -- kernel-side (solve + gauge fix +
+    marginalisation launches, launch to sync), three launches each.  The 4096-window batch holds the benchmark's 1024 windows four times
+    (every entry is packed into its own slice of the pool: the same traffic as 4096 different windows of this shape)."""
+    Wm, Mm, dropsm, _pdev = keep
+    n0 = len(Wm)
+    res = {}
+    for B in (256, 1024, 4096):
+        if n0 < min(B, 1024):
+            continue
+        idx = [k % n0 for k in range(B)]
+        b = tcv.Batch([Wm[k] for k in idx], [Mm[k] for k in idx], [dropsm[k] for k in idx])
+        b.solve(opts); b.gauge_fix(); b.marginalize(); b.synchronize()          # warm-up
+        t0 = time.perf_counter()
+        for _ in range(3):
+            b.solve(opts); b.gauge_fix(); b.marginalize()
+        b.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+        st = b.stats()
+        res[str(B)] = {"solves_per_s": B / dt, "ms_per_launch_set": 1e3 * dt, "solve_kernel_ms": st["solve_ms"], "marg_kernel_ms": st["marg_ms"]}
+        if B == min(1024, n0):
+            # run to convergence: Ceres' tolerances decide (function 1e-6, gradient 1e-10, parameter 1e-8), at most 50 iterations (Ceres' default cap)
+            oc = tcv.default_options(50, False)
+            b.solve(oc); b.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                b.solve(oc); b.gauge_fix(); b.marginalize()
+            b.synchronize()
+            dtc = (time.perf_counter() - t0) / 3
+            sm = b.summaries()
+            its = np.array([sm[k].num_iterations for k in range(B)])
+            res_conv = {"solves_per_s": B / dtc, "ms_per_launch_set": 1e3 * dtc, "windows": B, "max_num_iterations": 50,
+                        "iterations_mean": float(its.mean()), "iterations_median": float(np.median(its)), "iterations_max": int(its.max()),
+                        "note": "the same windows solved until Ceres' convergence tests fire (estimator.cpp:1888-1897 sets only the iteration cap and the time budget; "
+                                "tolerances are Ceres' defaults) + gauge fix + marginalisation; a launch lasts as long as its slowest window"}
+        del b
+    return {"batch_sweep": res, "run_to_convergence": res_conv if res else None}
+
+
 # ---- modes ----------------------------------------------------------------------------------------------------------------
 def run_solve(args, rank, world, local, dist):
     pool = nproc = None
@@ -418,6 +550,7 @@ def run_solve(args, rank, world, local, dist):
     sync()
     elapsed = time.perf_counter() - t0
     elapsed_max, windows_total, iters_total = reduce_stats(dist, elapsed, B * args.steps, red_dev, extra=(B * args.steps * SOLVER_ITERATIONS,))
+    rank_rates = gather_rank_rates(dist, elapsed, B * args.steps, red_dev)
 
     if not DRY:
         # parity of what was just timed is the job of tests/ and smoke(); here only sanity of the results
@@ -444,6 +577,8 @@ def run_solve(args, rank, world, local, dist):
                    "windows_per_gpu": B, "solver_iterations": SOLVER_ITERATIONS, "parallelism": f"independent windows x{world}",
                    "threads_per_window": args.threads, "layout": "chain" if args.variant == 0 else "dense"},
         "iterations_per_s": iters_total / elapsed_max,
+        "ranks_seen": n_ranks,
+        "per_rank_solves_per_s": rank_rates,
     }
     if DRY:
         out["dry_run"] = True
@@ -473,6 +608,33 @@ def run_solve(args, rank, world, local, dist):
                        "units_per_launch": units,
                        "note": "fused FP64 solve: latency/issue bound, not HBM bound (DESIGN.md 4.1); frac is vs "
                                "the 8 TB/s HBM3E spec; traffic = PMC FETCH_SIZE x2 + WRITE_SIZE of profiles/pmc_traffic.json (static, from the committed profile run)"}
+    # the same launches against the FP64 roof -- peak MEASURED on this device (tcv_microbench_fp64: dependence-free
+    # v_fma_f64 / v_mfma_f64_16x16x4 chains on every CU), not quoted
+    mb = (C.c_double * 4)()
+    if tcv.lib().tcv_microbench_fp64(mb) == 0 and k_ms:
+        peak = max(mb[0], mb[1])
+        ach = FLOPS_PER_ITERATION_CFG3 * units / (k_ms * 1e-3) / 1e12
+        out["roofline_fp64"] = {"bound": "fp64", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                                "peak_vector_fma": mb[0], "peak_mfma_f64_16x16x4": mb[1], "compute_units": int(mb[2]), "shader_clock_mhz": mb[3],
+                                "flops_per_iteration": FLOPS_PER_ITERATION_CFG3,
+                                "note": "peak = the better of the two micro-benchmarks run by this process on this device just now; flops = SURVEY.md 8(d)'s "
+                                        "algorithmic 3.3 MFLOP per iteration and window (dense reduced-camera solve), not the instructions the fused kernel issues"}
+    # hardware counters of the same launch shape, from the committed profile run (tools/profile_round.sh): static, so they carry the commit
+    # they were taken at -- a stale figure is detectable
+    cfile = os.path.join(ROOT, "profiles", "counters.json")
+    if os.path.exists(cfile):
+        try:
+            cj = json.load(open(cfile))
+            out["counters"] = {k: cj.get(k) for k in ("commit", "valu_active", "mfma_busy", "salu_per_valu", "waiting", "solve_kernel_hbm_bytes_per_launch",
+                                                      "solve_kernel_write_bytes_per_launch", "marg_kernel_hbm_bytes_per_launch", "source")}
+            out["mfma_busy"] = cj.get("mfma_busy"); out["valu_active"] = cj.get("valu_active")
+            if traffic is None:
+                out["roofline"]["traffic"] = cj.get("solve_kernel_hbm_bytes_per_launch")
+            out["roofline"]["traffic_commit"] = cj.get("commit")
+        except (OSError, ValueError):
+            pass
+    if world == 1 and not args.no_extras:
+        out.update(sweep_figures(tcv, keep, opts))
     if world == 1 and not args.no_extras:
         # the PCIe-inclusive figure uses four host threads x 512 windows: the benchmark's 1024 windows and 1024 more of the same kind
         _b2, _w2, keep2 = build_batches(tcv, synth, shard_ids(rank, B) + B, B) if B == 1024 else (None, None, ([], [], []))
@@ -480,6 +642,13 @@ def run_solve(args, rank, world, local, dist):
         out.update(stream_figures(tcv, torch, tuple(a + b for a, b in zip(keep, keep2)), wins=wins, local=local))
         out.update(replay_figures(tcv, local))
     if pool is not None:
+        if "replay_windows_per_s" in out:      # the replay figure's own CPU baseline: the same eight streams through the oracle back end, one process each
+            import replay
+            rb = cpu_replay_baseline(pool, min(nproc, 8), replay.WINDOW_SIZE + 1 + 10 + 60, 60, 8, min(8.0, args.cpu_budget), close=False)      # (replay_figures' streams: 10 + 60 frames)
+            if rb:
+                out["replay_cpu_baseline"] = rb
+                out["replay_over_cpu_all_cores"] = out["replay_windows_per_s"] / rb["value"]
+                out["replay_over_cpu_core"] = out["replay_windows_per_s"] / rb["single_core_value"]
         out["cpu_baseline"] = cpu_baseline(wins, pool, nproc, args.cpu_budget)
         out["gpu_over_cpu_all_cores"] = out["value"] / out["cpu_baseline"]["value"]
         out["gpu_over_cpu_core"] = out["value"] / out["cpu_baseline"]["single_core_value"]
@@ -552,6 +721,9 @@ class ReplayEngine:
 def run_replay(args, rank, world, local, dist):
     """BASELINE configs[4]: EuRoC-trajectory streams sharded s mod G over the ranks; every rank advances its streams frame by frame."""
     mine = shard_streams(args.streams, rank, world)
+    pool = nproc = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not DRY:
+        pool, nproc = cpu_pool()                     # forked before the first GPU call
     if DRY:
         dev = None
         run = lambda steps: (time.sleep(0.001 * steps), len(mine) * steps)[1]
@@ -572,6 +744,7 @@ def run_replay(args, rank, world, local, dist):
     if not DRY:
         import ctypes as C
         tcv.lib().tcv_estimators_profile((C.c_double * 8)())      # clears the accounting of the window fill and the warm-up
+        tcv.lib().tcv_estimators_kernel_profile((C.c_double * 8)())
         for ls in eng.ls:
             ls.host_s = [0.0, 0.0, 0.0, 0]
     if dist is not None:
@@ -585,6 +758,7 @@ def run_replay(args, rank, world, local, dist):
         dist.barrier()
     elapsed = time.perf_counter() - t0
     elapsed_max, windows_total, iters_total = reduce_stats(dist, elapsed, n, red_dev, extra=(n * SOLVER_ITERATIONS,))
+    rank_rates = gather_rank_rates(dist, elapsed, n, red_dev)
     if rank != 0:
         return
     prof = None
@@ -608,11 +782,40 @@ def run_replay(args, rank, world, local, dist):
                                   f"{SOLVER_ITERATIONS} iterations (convergence tests on) + marginalisation per frame; per rank {args.host_threads} host threads, "
                                   f"each advancing its share of the rank's streams in lock step (cooperative small-batch kernels)",
                       "streams": args.streams, "host_threads": args.host_threads, "parallelism": f"streams sharded x{world}"},
-           "frames_per_s_per_stream": windows_total / elapsed_max / max(1, args.streams)}
+           "frames_per_s_per_stream": windows_total / elapsed_max / max(1, args.streams),
+           "ranks_seen": n_ranks, "per_rank_solves_per_s": rank_rates, "streams_per_rank": [len(shard_streams(args.streams, r, world)) for r in range(world)]}
     if DRY:
         out["dry_run"] = True
     if prof:
         out["native_profile_ms_per_call"] = prof
+    if not DRY:
+        # the kernels this path runs, live: HIP-event durations of every solve / marginalisation launch of the timed frames (rank 0) and the
+        # ALGORITHMIC bytes of the windows they held (SURVEY.md 8(d) formula on every window's own factor counts x its linearisations)
+        k8 = (C.c_double * 8)()
+        tcv.lib().tcv_estimators_kernel_profile(k8)
+        if k8[0] > 0 and k8[1] > 0:
+            ach = k8[5] / (k8[0] * 1e-3) / 1e9
+            out["kernel_ms"] = {"solve": k8[0] / k8[1], "solve_launches": int(k8[1]), "windows_per_solve_launch": k8[4] / k8[1],
+                                "marginalize": (k8[2] / k8[3]) if k8[3] > 0 else None, "marginalize_launches": int(k8[3]),
+                                "windows_per_marginalize_launch": (k8[7] / k8[3]) if k8[3] > 0 else None}
+            out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                               "kernel": "tcv::solve_kernel<256, true, true, true, false> (cooperative: 1 + H workgroups per window)",
+                               "algorithmic_bytes_per_linearisation_mean": k8[5] / max(1.0, k8[6]), "linearisations_per_window_mean": k8[6] / max(1.0, k8[4]),
+                               "note": "achieved = algorithmic bytes of the windows of all launches (each window's own factor counts, x its linearisations) / summed HIP-event "
+                                       "duration of the launches; launches of different host threads overlap on the device, so the sum of durations exceeds the wall time "
+                                       "they occupy.  A lock-step frame of a few windows is LATENCY bound (a window's trust-region iterations are sequential; the chip is "
+                                       "mostly idle): the fraction says how far from a bandwidth problem this workload is, not how good the kernel is"}
+    if pool is not None:
+        # (the generator is called with the GPU run's own frame count: identical streams)
+        try:
+            cb = cpu_replay_baseline(pool, min(nproc, max(1, args.streams)), replay.WINDOW_SIZE + 1 + args.warmup + args.steps, args.features, args.lines, args.cpu_budget)
+        except Exception as e:      # the GPU line stands on its own
+            cb = None
+            out["cpu_baseline_error"] = repr(e)[:300]
+        if cb:
+            out["cpu_baseline"] = cb
+            out["gpu_over_cpu_all_cores"] = out["value"] / cb["value"]
+            out["gpu_over_cpu_core"] = out["value"] / cb["single_core_value"]
     print(json.dumps(out))
 
 

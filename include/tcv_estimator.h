@@ -100,10 +100,36 @@ int tcv_estimators_finish_frames(tcv_estimator *const *e, int n, double *P, doub
  * "Reset it" above means this call (or destroy + create). */
 int tcv_estimator_reset(tcv_estimator *e);
 int tcv_estimator_get_stats(const tcv_estimator *e, tcv_estimator_stats *out);
+/* Window tap (test / checkpoint aid, no reference counterpart): with the tap on, every tcv_estimators_optimize keeps a snapshot of the
+ * window this estimator handed to the solver -- what OptimizationWithLine sees after vector2double and the graph construction
+ * (estimator.cpp:1492-1535, :1683-1846): parameter arrays before and after the solve, factor lists, pre-integrations, the incoming prior.
+ * tests/test_gpu_teacher.py re-solves every tapped window of a native replay with the CPU oracle.  The arrays of a snapshot belong to the
+ * estimator and stay valid until its next tcv_estimators_optimize / reset / destroy.  The tap waits for device-resident inputs (prior,
+ * pre-integrations) to copy them: it costs a frame its overlap, never its results. */
+typedef struct tcv_window_snapshot {
+    int n_frames, n_landmarks, n_imu, n_proj, n_line, marg_flag, estimate_extrinsic, line_exact_jacobian;
+    const double *pose_in, *speedbias_in, *ex_pose_in, *feature_in;        /* before the solve: n_frames x 7, n_frames x 9, 7, n_landmarks */
+    const double *pose_out, *speedbias_out, *ex_pose_out, *feature_out;    /* after the solve and the gauge fix (zeros when the window failed) */
+    const tcv_imu_preintegration *imu; const int *imu_frame_i, *imu_frame_j;
+    const int *proj_frame_i, *proj_frame_j, *proj_feature; const double *proj_pts;      /* n_proj x 6 */
+    const int *line_frame; const double *line_data;                                      /* n_line x 9 */
+    double line_K[9], line_Ric[9], line_Tic[3], gravity[3], proj_sqrt_info;
+    int prior_m, prior_n, prior_nblk;                                                    /* prior_n = 0: no prior */
+    const int *prior_block_kind, *prior_block_index, *prior_block_size, *prior_block_idx;
+    const double *prior_x0, *prior_J0, *prior_r0;                                        /* concatenated blocks, n x n column-major, n */
+    int iterations, applied; double final_cost;
+} tcv_window_snapshot;
+int tcv_estimator_set_window_tap(tcv_estimator *e, int on);
+int tcv_estimator_get_window_snapshot(const tcv_estimator *e, tcv_window_snapshot *out);
 /* host-side time accounting of tcv_estimators_optimize since the last call (seconds): out8 = pre-integration, association +
  * triangulation + window, problem construction, batch_create (pack + H2D), kernels (launch to sync), downloads, apply / prior
  * chaining, number of calls.  Development aid (tools/replay_euroc.py --profile). */
 int tcv_estimators_profile(double *out8);
+/* kernel-side accounting of the lock-step frames since the last call: out8 = { solve-kernel ms (HIP events around every launch, summed),
+ * solve launches, marginalisation-kernel ms, marginalisation launches whose batch has been retired, windows solved, sum over those windows
+ * of their ALGORITHMIC bytes per linearisation (SURVEY.md 8(d) formula on the window's own factor counts) x linearisations, linearisations,
+ * windows marginalised by the retired launches }.  bench.py --mode replay prices the solve kernel against the HBM roofline with it. */
+int tcv_estimators_kernel_profile(double *out8);
 
 #ifdef __cplusplus
 }

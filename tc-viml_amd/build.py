@@ -44,6 +44,8 @@ def build(force: bool = False, verbose: bool = False, profile: bool = False, abl
     the flags (GPU sanitizers are not available on this pool); tests/test_sanitize_cpu.py drives it without a device."""
     if "--occ1" in sys.argv:      # developer A/B build: chain kernel at one wavefront per SIMD (no register spills), see tcv_solve.hip
         return _compile(os.path.join(HERE, "libtcv_hip_occ1.so"), verbose, ["-DTCV_CHAIN_OCC1=1"])
+    if "--margocc1" in sys.argv:  # developer A/B build: marginalisation kernel at one wavefront per SIMD (no register spills), tools/r05_marg_spill_ab.sh
+        return _compile(os.path.join(HERE, "libtcv_hip_margocc1.so"), verbose, ["-DTCV_MARG_OCC1=1"])
     if "--occ3" in sys.argv:      # developer A/B build: chain kernel at three wavefronts per SIMD (168 registers), tools/dev_occupancy3.py
         return _compile(os.path.join(HERE, "libtcv_hip_occ3.so"), verbose, ["-DTCV_CHAIN_OCC3=1"])
     if sanitize:

@@ -554,20 +554,42 @@ extern "C" int tcv_problem_from_window(const tcv_window_desc *w, tcv_problem **o
         chk(tcv_problem_add_imu_factor(p, w->imu + k, w->para_pose + 7 * i, w->para_speedbias + 9 * i, w->para_pose + 7 * j,
                                        w->para_speedbias + 9 * j));
     }
-    for (int k = 0; k < w->n_proj; k++) {   // :1737-1771
-        if (w->para_td) {
-            const double *a = w->proj_td_aux + 8 * k;
-            chk(tcv_problem_add_projection_td_factor(p, w->proj_pts + 6 * k, w->proj_pts + 6 * k + 3, a, a + 2, a[4], a[5], a[6], a[7], w->proj_sqrt_info,
-                                                     w->proj_loss_a, w->para_pose + 7 * w->proj_frame_i[k], w->para_pose + 7 * w->proj_frame_j[k],
-                                                     w->para_ex_pose, w->para_feature + w->proj_feature[k], w->para_td));
-        } else
-            chk(tcv_problem_add_projection_factor(p, w->proj_pts + 6 * k, w->proj_pts + 6 * k + 3, w->proj_sqrt_info, w->proj_loss_a,
-                                                  w->para_pose + 7 * w->proj_frame_i[k], w->para_pose + 7 * w->proj_frame_j[k],
-                                                  w->para_ex_pose, w->para_feature + w->proj_feature[k]));
+    // The point and line factors: same result as tcv_problem_add_projection[_td]_factor / tcv_problem_add_line_factor per factor (blocks the
+    // factors introduce are added in order of first appearance, like ceres::Problem::AddResidualBlock does for unknown pointers), but the
+    // block indices of the frame-indexed arrays are known here -- no address lookup per pointer (four per point factor: a third of a
+    // lock-step frame's problem construction)
+    if (rc == TCV_OK) {
+        const int b_ex = block_of(p, w->para_ex_pose), b_td = w->para_td ? block_of(p, w->para_td) : -1;
+        std::vector<int> b_pose(w->n_frames), b_feat(std::max(1, w->n_landmarks), -1);
+        for (int i = 0; i < w->n_frames; i++) b_pose[i] = block_of(p, w->para_pose + 7 * i);
+        p->proj.reserve((size_t)w->n_proj); p->line.reserve((size_t)w->n_line);
+        p->blocks.reserve(p->blocks.size() + (size_t)w->n_landmarks);
+        for (int k = 0; k < w->n_proj && rc == TCV_OK; k++) {   // :1737-1771
+            const int l = w->proj_feature[k];
+            if (b_feat[l] < 0) {
+                double *addr = w->para_feature + l;
+                b_feat[l] = ensure_block(p, addr, 1);      // (an address that is a block already must be a size-1 block)
+                if (b_feat[l] < 0) { set_error("add_projection_factor: bad parameter block"); rc = TCV_ERR_INVALID; break; }
+            }
+            p->proj.emplace_back();
+            ProjFac &f = p->proj.back();
+            const double *pt = w->proj_pts + 6 * k;
+            for (int i = 0; i < 6; i++) f.pts[i] = pt[i];
+            f.sqrt_info = w->proj_sqrt_info; f.loss_a = w->proj_loss_a;
+            f.b[0] = b_pose[w->proj_frame_i[k]]; f.b[1] = b_pose[w->proj_frame_j[k]]; f.b[2] = b_ex; f.b[3] = b_feat[l];
+            if (w->para_td) { const double *a = w->proj_td_aux + 8 * k; for (int i = 0; i < 8; i++) f.aux[i] = a[i]; f.btd = b_td; }
+            else { for (int i = 0; i < 8; i++) f.aux[i] = 0.0; f.btd = -1; }
+        }
+        for (int k = 0; k < w->n_line && rc == TCV_OK; k++) {   // :1786-1846
+            p->line.emplace_back();
+            LineFac &f = p->line.back();
+            const double *d = w->line_data + 9 * k;
+            for (int i = 0; i < 9; i++) { f.d[i] = d[i]; f.K[i] = w->line_K[i]; f.R[i] = w->line_Ric[i]; }
+            for (int i = 0; i < 3; i++) f.T[i] = w->line_Tic[i];
+            f.loss_a = w->line_loss_a;
+            f.b = b_pose[w->line_frame[k]];
+        }
     }
-    for (int k = 0; k < w->n_line; k++)   // :1786-1846
-        chk(tcv_problem_add_line_factor(p, w->line_data + 9 * k, w->line_data + 9 * k + 3, w->line_data + 9 * k + 6, w->line_K,
-                                        w->line_Ric, w->line_Tic, w->line_loss_a, w->para_pose + 7 * w->line_frame[k]));
     {
         std::vector<double *> fp(w->n_frames), fs(w->n_frames);
         for (int i = 0; i < w->n_frames; i++) { fp[i] = w->para_pose + 7 * i; fs[i] = w->para_speedbias + 9 * i; }

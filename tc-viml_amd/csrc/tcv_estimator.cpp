@@ -126,8 +126,36 @@ struct ImuBuf {
 // A lock-step frame whose marginalisation was left running when tcv_estimators_optimize returned (device-resident state): its batch,
 // shared by the estimators of the frame; each asks for the status of its own window at its next frame (or lets go of it when
 // it is reset / destroyed), the last one to let go destroys the batch.
+// kernel-time accounting of the lock-step frames (tcv_estimators_kernel_profile): HIP-event durations of the solve and marginalisation
+// launches, the windows they held and those windows' ALGORITHMIC bytes x linearisations -- what bench.py --mode replay
+// prices against the HBM roofline
+std::mutex g_kmu;
+double g_kern[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // solve ms, solve launches, marginalisation ms, marginalisation launches, windows, bytes x linearisations, linearisations, marginalised windows
+void kern_add(int slot, double v) { std::lock_guard<std::mutex> g(g_kmu); g_kern[slot] += v; }
+
 struct EstInflight {
     tcv_batch *b = nullptr;
+    int n_marg = 0;
+    // deferred launch (the default): the frame that solved the batch returns WITHOUT launching its marginalisation; the first of its
+    // estimators to come back for its next frame launches it -- behind that frame's 2D-3D association, whose device round trip would
+    // otherwise queue behind the marginalisation kernel on the thread's stream (0.3 - 0.5 ms of a lock-step frame, whatever the number
+    // of windows) -- and every estimator takes its own prior handle.  The kernel then runs while the host builds that frame's windows.
+    bool deferred = false, launched = false;
+    int launch_rc = TCV_OK;
+    std::string launch_msg;
+    std::vector<tcv_prior *> handles;      // per window of the batch: the new prior, until its estimator takes it
+    int launch(void *stream) {      // (any estimator of the batch, any thread: once)
+        std::lock_guard<std::mutex> g(mu);
+        if (launched) return launch_rc;
+        launched = true;
+        const int n = tcv_batch_size(b);
+        handles.assign(n, nullptr);
+        launch_rc = tcv_batch_marginalize(b, stream);
+        if (launch_rc == TCV_OK) launch_rc = tcv_batch_get_priors_device_async(b, handles.data(), n);
+        if (launch_rc != TCV_OK) launch_msg = tcv_last_error();
+        return launch_rc;
+    }
+    tcv_prior *take(int k) { std::lock_guard<std::mutex> g(mu); tcv_prior *p = (k >= 0 && k < (int)handles.size()) ? handles[k] : nullptr; if (p) handles[k] = nullptr; return p; }
     std::vector<int> status;
     bool have_status = false;
     std::mutex mu;
@@ -146,14 +174,32 @@ struct EstInflight {
         return (k >= 0 && k < (int)status.size()) ? status[k] : -9;
     }
     ~EstInflight() {
-        if (b) tcv_batch_destroy(b);      // (waits for work in flight)
+        for (tcv_prior *p : handles) if (p) tcv_prior_destroy(p);
+        if (!b) return;
+        double ms = 0;
+        if (tcv_batch_synchronize(b) == TCV_OK && tcv_batch_stats(b, nullptr, nullptr, &ms) == TCV_OK && ms > 0) { kern_add(2, ms); kern_add(3, 1); kern_add(7, n_marg); }
+        tcv_batch_destroy(b);      // (waits for work in flight)
     }
+};
+
+// snapshot of the window an estimator handed to the solver (tcv_estimator_set_window_tap)
+struct WindowTap {
+    bool on = false, have = false;
+    std::vector<double> pose_in, sb_in, ex_in, feat_in, pose_out, sb_out, ex_out, feat_out, pts, ld, x0, J0, r0;
+    std::vector<tcv_imu_preintegration> imu;
+    std::vector<int> imu_i, imu_j, pi, pj, pl, lf, pk, pidx, psize, pcol;
+    double Ric[9];
+    int marg_flag = 0, prior_m = 0, prior_n = 0, iterations = 0, applied = 0;
+    double final_cost = 0;
 };
 
 struct tcv_estimator {
     tcv_estimator_config cfg;
+    WindowTap tap;
     std::shared_ptr<EstInflight> prev;       // the frame whose marginalisation produced `prior` and may still be running; prev_k: this estimator's window in it
     int prev_k = -1;
+    std::shared_ptr<EstInflight> pend;       // the frame whose marginalisation has not been launched yet (EstInflight::deferred): its prior is taken at the start of the next tcv_estimators_optimize
+    int pend_k = -1, pend_flag = MARGIN_OLD;
     V3 Ps[W + 1], Vs[W + 1], Bas[W + 1], Bgs[W + 1];
     M3 Rs[W + 1];
     V3 tic;
@@ -516,6 +562,34 @@ int take_prior(tcv_estimator *e, tcv_prior *np, int flag) {
     return TCV_OK;
 }
 
+// the window build_window() just made, copied for the tap (device-resident inputs are materialised: tcv_preint_export / tcv_prior_export)
+int tap_window(tcv_estimator *e) {
+    WindowTap &T = e->tap;
+    T.have = false; T.applied = 0; T.iterations = 0; T.final_cost = 0;
+    T.pose_in.assign(e->para_pose, e->para_pose + (W + 1) * 7); T.sb_in.assign(e->para_sb, e->para_sb + (W + 1) * 9);
+    T.ex_in.assign(e->para_ex, e->para_ex + 7); T.feat_in.assign(e->para_feature.begin(), e->para_feature.begin() + e->sel.size());
+    T.pose_out.assign((W + 1) * 7, 0.0); T.sb_out.assign((W + 1) * 9, 0.0); T.ex_out.assign(7, 0.0); T.feat_out.assign(e->sel.size(), 0.0);
+    T.imu = e->w_imu; T.imu_i = e->w_imu_i; T.imu_j = e->w_imu_j;
+    for (size_t k = 0; k < T.imu.size(); k++)
+        if (k < e->w_imu_dev.size() && e->w_imu_dev[k]) { const int rc = tcv_preint_export(e->w_imu_dev[k], &T.imu[k]); if (rc != TCV_OK) return rc; }
+    T.pi = e->w_pi; T.pj = e->w_pj; T.pl = e->w_pl; T.pts = e->w_pts; T.lf = e->w_lf; T.ld = e->w_ld;
+    std::memcpy(T.Ric, e->w_Ric, sizeof T.Ric);
+    T.marg_flag = e->marg_flag;
+    T.pk = e->w_pk; T.pidx = e->w_pidx; T.psize.clear(); T.pcol.clear(); T.x0.clear(); T.J0.clear(); T.r0.clear();
+    T.prior_m = T.prior_n = 0;
+    if (e->prior) {
+        int m, nn, nb, xs;
+        int rc = tcv_prior_dims(e->prior, &m, &nn, &nb, &xs);
+        if (rc != TCV_OK) return rc;
+        T.psize.resize(nb); T.pcol.resize(nb); T.x0.resize(xs); T.J0.resize((size_t)nn * nn); T.r0.resize(nn);
+        rc = tcv_prior_export(e->prior, T.psize.data(), T.pcol.data(), T.x0.data(), T.J0.data(), T.r0.data());
+        if (rc != TCV_OK) return rc;
+        T.prior_m = m; T.prior_n = nn;
+    }
+    T.have = true;
+    return TCV_OK;
+}
+
 bool failure_detection(const tcv_estimator *e) {
     if (nrm(e->Bas[W]) > 2.5 || nrm(e->Bgs[W]) > 1.0) return true;
     if (e->have_last) {
@@ -611,6 +685,7 @@ static void clear_state(tcv_estimator *e) {
     e->features.clear(); e->linefeatures.clear(); e->fov_ready = false;
     if (e->prior) { tcv_prior_destroy(e->prior); e->prior = nullptr; }
     e->prev.reset(); e->prev_k = -1;
+    e->pend.reset(); e->pend_k = -1;
     e->prior_blocks.clear();
     e->frame_count = 0; e->marg_flag = MARGIN_OLD;
     e->have_acc0 = false; e->have_last = false;
@@ -708,6 +783,12 @@ extern "C" int tcv_estimators_begin_frames(tcv_estimator *const *es, int n, cons
     for (int i = 0; i < n; i++) if (rcs[i] != TCV_OK) { tcv::set_error(msgs[i]); return rcs[i]; }
     return TCV_OK;
 }
+extern "C" int tcv_estimators_kernel_profile(double *out8) {
+    if (!out8) return TCV_ERR_INVALID;
+    std::lock_guard<std::mutex> g(g_kmu);
+    for (int i = 0; i < 8; i++) { out8[i] = g_kern[i]; g_kern[i] = 0; }
+    return TCV_OK;
+}
 extern "C" int tcv_estimators_profile(double *out8) {
     if (!out8) return TCV_ERR_INVALID;
     std::lock_guard<std::mutex> g(g_mu);
@@ -730,17 +811,36 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
         static const bool dbg1 = getenv("TCV_DEBUG_EST") != nullptr;      // developer: where this lap goes
         const double ta0 = now_s();
         std::vector<tcv_match_lines_args> calls;
-        for (int i = 0; i < n; i++)
-            if (es[i]->assoc) {
-                const int rc = assoc_prepare(es[i], jobs[i]);
-                if (rc != TCV_OK) return rc;
-                if (jobs[i].call) calls.push_back(jobs[i].args);
-            }
+        {      // (per estimator: poses, the detections of its line tracks, its field-of-view sets -- independent objects, the worker threads share them)
+            std::vector<int> rcs(n, TCV_OK);
+            std::vector<std::string> msgs(n);
+            bool warm = true;
+            for (int i = 0; i < n; i++) if (es[i]->assoc && !es[i]->fov_ready) warm = false;      // (the first frame's own device call per estimator stays on this thread)
+            auto one = [&](int i) { if (es[i]->assoc) { rcs[i] = assoc_prepare(es[i], jobs[i]); if (rcs[i] != TCV_OK) msgs[i] = tcv_last_error(); } };
+            if (warm) for_each_estimator(n, one); else for (int i = 0; i < n; i++) one(i);
+            for (int i = 0; i < n; i++) if (rcs[i] != TCV_OK) { tcv::set_error(msgs[i]); return rcs[i]; }
+            for (int i = 0; i < n; i++) if (es[i]->assoc && jobs[i].call) calls.push_back(jobs[i].args);
+        }
         const double ta1 = now_s();
         if (!calls.empty()) { const int rc = tcv_match_lines_batch((int)calls.size(), calls.data()); if (rc != TCV_OK) return rc; }
         if (dbg1) fprintf(stderr, "[est] n %d: association prepare %.3f ms, device round trip (%d calls) %.3f ms\n", n, 1e3 * (ta1 - ta0), (int)calls.size(), 1e3 * (now_s() - ta1));
     }
     lap(1);
+    // the previous frame's marginalisations (deferred: see EstInflight) go on the device NOW, behind the association's round trip, and every
+    // estimator takes the prior it will build this frame's window on (getParameterBlocks, marginalization_factor.cpp:301-321)
+    for (int i = 0; i < n; i++) {
+        tcv_estimator *e = es[i];
+        if (!e->pend) continue;
+        std::shared_ptr<EstInflight> fl = e->pend;
+        const int rcl = fl->launch((void *)tcv::util_stream());
+        if (rcl != TCV_OK) { tcv::set_error(fl->launch_msg); return rcl; }
+        tcv_prior *np = fl->take(e->pend_k);
+        if (!np) { tcv::set_error("estimators_optimize: the previous frame's marginalisation left no prior for this estimator"); return TCV_ERR_INVALID; }
+        const int rct = take_prior(e, np, e->pend_flag);
+        if (rct != TCV_OK) { tcv_prior_destroy(np); return rct; }
+        e->prev = fl; e->prev_k = e->pend_k;
+        e->pend.reset(); e->pend_k = -1;
+    }
     // one pre-integration call for every stale IMU buffer of every estimator
     {
         std::vector<int> first, count;
@@ -793,6 +893,7 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
             triangulate(e);
             build_window(e);
         });
+        for (int i = 0; i < n; i++) if (es[i]->tap.on) { const int rc = tap_window(es[i]); if (rc != TCV_OK) return rc; }
     }
     lap(1);
     // One device batch per frame: the windows that marginalise (MARGIN_OLD, or MARGIN_SECOND_NEW with para_Pose[WINDOW_SIZE - 1] in the prior,
@@ -820,6 +921,7 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
         std::string est_msg;
         tcv_batch *b = nullptr;
         int rc = TCV_OK;
+        bool deferred = false;            // the marginalisation of this frame is launched by its estimators' next frame (EstInflight)
     };
     Group G[2];
     // Every kernel of the frame goes on the CALLING THREAD's utility stream -- the stream tcv_batch_create's uploads, the device-to-device
@@ -908,6 +1010,8 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
         Group &g = G[group];
         if (g.idx.empty()) continue;
         if (g.rc == TCV_OK) g.rc = tcv_batch_synchronize(g.b);
+        double ms = 0;
+        if (g.rc == TCV_OK && tcv_batch_stats(g.b, nullptr, &ms, nullptr) == TCV_OK && ms > 0) { kern_add(0, ms); kern_add(1, 1); }
     }
     lap(4);
     for (int group = 1; group >= 0; group--) {
@@ -922,7 +1026,10 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
         if (g.rc == TCV_OK) g.rc = tcv_batch_get_summaries(g.b, g.sum.data(), nb);
         const double td2 = now_s();
         bool have_dev = false;
-        if (g.rc == TCV_OK && g.any_marg && marg_off_path) {      // the states are on the host: now the marginalisation, and its results as handles without a wait
+        static const bool marg_eager = getenv("TCV_EST_MARG_EAGER") != nullptr;      // A/B partner: launch the marginalisation at the end of its own frame (round 4)
+        const bool defer_marg = g.rc == TCV_OK && g.any_marg && marg_off_path && !marg_eager;
+        if (defer_marg) have_dev = true;      // (nothing to fetch now: EstInflight::launch at the estimators' next frame)
+        if (g.rc == TCV_OK && g.any_marg && marg_off_path && marg_eager) {      // the states are on the host: now the marginalisation, and its results as handles without a wait
             // (on the thread's main stream: the next frame's association round trip queues behind it, ~0.1 ms of a frame.  TCV_EST_MARG_AUX=1: on the
             // thread's second stream -- one host thread 2 570 - 2 720 against 2 590 windows/s, two host threads 2 490 - 2 550 against 2 940: two
             // streams per thread share the runtime's four hardware queues again)
@@ -934,6 +1041,17 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
         if (g.rc == TCV_OK && g.any_marg && !host_priors && !marg_off_path) have_dev = tcv_batch_get_priors_device(g.b, g.newp.data(), nb) == TCV_OK;      // (a window that failed: the per-window path below says which)
         if (g.rc == TCV_OK && g.any_marg && !have_dev) g.rc = tcv_batch_download_priors_compact(g.b);
         g.est_rc.assign(nb, TCV_OK);
+        if (g.rc == TCV_OK) {      // algorithmic bytes of the frame's windows x linearisations (the initial one + one per iteration)
+            double bytes = 0, lin = 0;
+            for (int k = 0; k < nb; k++) {
+                const tcv_estimator *e = es[g.idx[k]];
+                const double L = (double)e->sel.size(), n = e->prior ? (double)e->stats.prior_n : 0.0, nl = (double)std::max(1, g.sum[k].num_iterations);      // (ceres numbering: iteration 0 is the initial linearisation)
+                const double per = 8.0 * ((77 + 99 + 7 + L) + 287.0 * e->w_imu.size() + 6.0 * e->w_pi.size() + 9.0 * e->w_lf.size() + 21 + (n > 0 ? n * n + n + 86 : 0))
+                                   + 4.0 * (4.0 * e->w_imu.size() + 4.0 * e->w_pi.size() + e->w_lf.size()) + 8.0 * ((171 + L) + 1);
+                bytes += per * nl; lin += nl;
+            }
+            kern_add(4, nb); kern_add(5, bytes); kern_add(6, lin);
+        }
         if (g.rc == TCV_OK)
             for (int k = 0; k < nb; k++) {     // ceres::Solve's FAILURE (no valid step / a cooperative group that timed out): the window's states are not applied
                 if (g.sum[k].termination == 5 || !(g.sum[k].final_cost == g.sum[k].final_cost)) { g.est_rc[k] = TCV_ERR_NUMERIC; g.est_msg = "solver failure (no valid step, NaN cost or workgroup time-out)"; }
@@ -971,12 +1089,25 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
             // go now, like the old prior they point to)
             auto fl = std::make_shared<EstInflight>();
             fl->b = g.b;
+            fl->deferred = defer_marg;
+            for (int k = 0; k < nb; k++) fl->n_marg += g.dm[k] ? 1 : 0;
             g.b = nullptr;
-            for (int k = 0; k < nb; k++) if (g.dm[k] && g.est_rc[k] == TCV_OK) { es[g.idx[k]]->prev = fl; es[g.idx[k]]->prev_k = k; }
+            for (int k = 0; k < nb; k++)
+                if (g.dm[k] && g.est_rc[k] == TCV_OK) {
+                    tcv_estimator *e = es[g.idx[k]];
+                    if (defer_marg) { e->pend = fl; e->pend_k = k; e->pend_flag = e->marg_flag; }
+                    else { e->prev = fl; e->prev_k = k; }
+                }
+            g.deferred = defer_marg;
         }
         if (g.b) tcv_batch_destroy(g.b);
         const double td4 = now_s();
-        for_each_estimator(nb, [&](int k) { if (g.P[k]) tcv_problem_destroy(g.P[k]); if (g.M[k]) tcv_problem_destroy(g.M[k]); });
+        {      // the frame's problems have been read for the last time: destroyed on a worker thread, behind the caller's back
+            auto dead = std::make_shared<std::vector<tcv_problem *>>();
+            dead->reserve(2 * (size_t)nb);
+            for (int k = 0; k < nb; k++) { if (g.P[k]) dead->push_back(g.P[k]); if (g.M[k]) dead->push_back(g.M[k]); g.P[k] = g.M[k] = nullptr; }
+            tcv::async_run([dead] { for (tcv_problem *q : *dead) tcv_problem_destroy(q); });
+        }
         if (dbg_dl) fprintf(stderr, "[est] group %d n %d: states %.3f ms, summaries %.3f ms, priors %.3f ms, batch destroy %.3f ms, problems destroy %.3f ms\n", group, nb,
                             1e3 * (td1 - td0), 1e3 * (td2 - td1), 1e3 * (td3 - td2), 1e3 * (td4 - td3), 1e3 * (now_s() - td4));
         if (g.rc != TCV_OK && rc_all == TCV_OK) rc_all = g.rc;
@@ -995,9 +1126,16 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
                 continue;
             }
             apply_states(e);
+            if (e->tap.on && e->tap.have) {
+                WindowTap &T = e->tap;
+                T.pose_out.assign(e->para_pose, e->para_pose + (W + 1) * 7); T.sb_out.assign(e->para_sb, e->para_sb + (W + 1) * 9);
+                T.ex_out.assign(e->para_ex, e->para_ex + 7); T.feat_out = e->para_feature;
+                T.iterations = g.sum[k].num_iterations; T.final_cost = g.sum[k].final_cost; T.applied = 1;
+            }
             e->stats.marg_flag = e->marg_flag; e->stats.n_landmarks = (int)e->sel.size(); e->stats.n_proj = (int)e->w_pi.size(); e->stats.n_line = (int)e->w_lf.size();
             e->stats.n_line_obs = e->n_line_obs_total; e->stats.iterations = g.sum[k].num_iterations; e->stats.final_cost = g.sum[k].final_cost;
-            if (g.dm[k]) {
+            if (g.dm[k] && g.deferred) e->stats.prior_n = e->stats.prior_n;      // (the new prior is taken at the start of the next frame)
+            else if (g.dm[k]) {
                 const int rc = take_prior(e, g.newp[k], e->marg_flag);
                 if (rc != TCV_OK) {      // (take_prior keeps the old prior on failure: the new one and the ones not handed over yet are released)
                     for (int k2 = k; k2 < nb; k2++) if (g.newp[k2]) { tcv_prior_destroy(g.newp[k2]); g.newp[k2] = nullptr; }
@@ -1039,6 +1177,33 @@ extern "C" int tcv_estimators_finish_frames(tcv_estimator *const *es, int n, dou
         if (rc[i] != TCV_OK) msgs[i] = tcv_last_error();      // (the text is per thread)
     });
     for (int i = 0; i < n; i++) if (rc[i] != TCV_OK) { tcv::set_error(msgs[i]); return rc[i]; }
+    return TCV_OK;
+}
+extern "C" int tcv_estimator_set_window_tap(tcv_estimator *e, int on) {
+    if (!e) return TCV_ERR_INVALID;
+    e->tap.on = on != 0;
+    if (!on) e->tap = WindowTap();
+    return TCV_OK;
+}
+extern "C" int tcv_estimator_get_window_snapshot(const tcv_estimator *e, tcv_window_snapshot *o) {
+    if (!e || !o) return TCV_ERR_INVALID;
+    const WindowTap &T = e->tap;
+    if (!T.on || !T.have) { tcv::set_error("estimator_get_window_snapshot: no snapshot (tap off, or no window optimised since it was switched on)"); return TCV_ERR_INVALID; }
+    std::memset(o, 0, sizeof *o);
+    o->n_frames = W + 1; o->n_landmarks = (int)T.feat_in.size(); o->n_imu = (int)T.imu.size(); o->n_proj = (int)T.pi.size(); o->n_line = (int)T.lf.size();
+    o->marg_flag = T.marg_flag; o->estimate_extrinsic = e->cfg.estimate_extrinsic; o->line_exact_jacobian = e->cfg.line_exact_jacobian;
+    o->pose_in = T.pose_in.data(); o->speedbias_in = T.sb_in.data(); o->ex_pose_in = T.ex_in.data(); o->feature_in = T.feat_in.data();
+    o->pose_out = T.pose_out.data(); o->speedbias_out = T.sb_out.data(); o->ex_pose_out = T.ex_out.data(); o->feature_out = T.feat_out.data();
+    o->imu = T.imu.data(); o->imu_frame_i = T.imu_i.data(); o->imu_frame_j = T.imu_j.data();
+    o->proj_frame_i = T.pi.data(); o->proj_frame_j = T.pj.data(); o->proj_feature = T.pl.data(); o->proj_pts = T.pts.data();
+    o->line_frame = T.lf.data(); o->line_data = T.ld.data();
+    std::memcpy(o->line_K, e->cfg.K, sizeof o->line_K); std::memcpy(o->line_Ric, T.Ric, sizeof o->line_Ric);
+    for (int c = 0; c < 3; c++) { o->line_Tic[c] = T.ex_in[c]; o->gravity[c] = e->cfg.gravity[c]; }
+    o->proj_sqrt_info = e->cfg.focal_length / 1.5;
+    o->prior_m = T.prior_m; o->prior_n = T.prior_n; o->prior_nblk = (int)T.psize.size();
+    o->prior_block_kind = T.pk.data(); o->prior_block_index = T.pidx.data(); o->prior_block_size = T.psize.data(); o->prior_block_idx = T.pcol.data();
+    o->prior_x0 = T.x0.data(); o->prior_J0 = T.J0.data(); o->prior_r0 = T.r0.data();
+    o->iterations = T.iterations; o->applied = T.applied; o->final_cost = T.final_cost;
     return TCV_OK;
 }
 extern "C" int tcv_estimator_get_stats(const tcv_estimator *e, tcv_estimator_stats *out) {

@@ -1007,8 +1007,13 @@ __device__ __noinline__ void fwd_small_regs(const lds_d *Mm_, const lds_d *Apk_,
     }
 }
 
+#ifdef TCV_MARG_OCC1      // developer A/B build (build.py --margocc1): one wavefront per SIMD, 512 registers -- what the spills of the production build cost (tools/r05_marg_spill_ab.sh)
+#define TCV_MARG_WAVES 1
+#else
+#define TCV_MARG_WAVES 2
+#endif
 template <int MARG_NT>
-__global__ void __launch_bounds__(MARG_NT) __attribute__((disable_tail_calls)) __attribute__((amdgpu_waves_per_eu(2, 2))) marg_kernel(MargArgs Aarg) {
+__global__ void __launch_bounds__(MARG_NT) __attribute__((disable_tail_calls)) __attribute__((amdgpu_waves_per_eu(TCV_MARG_WAVES, TCV_MARG_WAVES))) marg_kernel(MargArgs Aarg) {
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
     lds_d *lds = (lds_d *)lds_raw;
     const int tid = threadIdx.x;
@@ -2290,6 +2295,7 @@ int tcv_marg_attach(tcv_batch *b, tcv_problem *const *marg_problems, double *con
     s->nt = pair ? MARG_NT_PAIR : MARG_NT_WIDE;
     if (pair) s->lds_bytes = (size_t)LDS_DOUBLES * 4;
     s->grid = std::min(b->n, pair ? 2 * n_cu : n_cu);
+    if (const char *eg = getenv("TCV_MARG_GRID")) { const int g = atoi(eg); if (g > 0) s->grid = std::min(s->grid, g); }      // tuning experiments (one workgroup per CU: TCV_MARG_GRID=256)
     {
         hipStream_t ust = tcv::util_stream();
         hipError_t e_ = tcv::dev_malloc(&s->d_input, in_bytes);

@@ -65,6 +65,7 @@ int HostOp::threads(int want) const { return host_threads(want); }
 namespace {
 struct ParCall {
     const std::function<void(int)> *fn;
+    std::function<void(int)> own;      // async_run: the call owns its function (nobody waits for it)
     int n;
     std::atomic<int> next{0}, done{0};
     std::mutex mu;
@@ -153,6 +154,25 @@ void plan_block_free(void *p, size_t bytes) {
         if (P.idle[c].size() < (size_t)(c <= 5 ? 192 : 8)) { P.idle[c].push_back(p); return; }      // (<= 512 KB: the plans of a lock-step frame; larger blocks: a handful)
     }
     ::operator delete(p);
+}
+
+// fire and forget on the worker pool (the retired problems of a lock-step frame are destroyed this way: 0.3 ms of the caller's frame
+// at 64 windows).  Without workers -- a one-core grant -- the function runs here.
+void async_run(std::function<void()> fn) {
+    WorkerPool &P = worker_pool();
+    bool have_worker;
+    {
+        std::lock_guard<std::mutex> g(P.mu);
+        if (P.nworkers == 0 && host_core_grant() > 1) { std::thread(worker_main).detach(); P.nworkers++; }
+        have_worker = P.nworkers > 0;
+    }
+    if (!have_worker) { fn(); return; }
+    auto c = std::make_shared<ParCall>();
+    auto sp = std::make_shared<std::function<void()>>(std::move(fn));
+    c->own = [sp](int) { (*sp)(); };
+    c->fn = &c->own; c->n = 1;
+    { std::lock_guard<std::mutex> g(P.mu); P.q.push_back(c); }
+    P.cv.notify_one();
 }
 
 // TCV_PRIOR_FULL: keep the exact-zero rows of the prior (A/B partner of the default).  The environment is read once per batch

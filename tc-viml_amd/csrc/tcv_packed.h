@@ -33,6 +33,7 @@ namespace tcv {
 // fn(t) for t in [0, nth): index claiming by the calling thread and by persistent worker threads (created once, tcv_pack.cpp); returns
 // when all have finished.  nth <= 1: plain call.
 void parallel_run(int nth, const std::function<void(int)> &fn);
+void async_run(std::function<void()> fn);      // fn() on a worker thread, some time later; nobody waits (here and now if the process has no worker)
 bool prior_keep_zero_rows();   // developer A/B switch TCV_PRIOR_FULL (re-read by every tcv_batch_create / tcv_solve); tcv_pack.cpp
 void prior_refresh_switch();
 enum { MAX_TRACE = 64 };

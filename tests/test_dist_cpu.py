@@ -76,6 +76,49 @@ def test_bench_self_launches_one_rank_per_gpu(mode):
         assert d["scaling"] == "strong"
 
 
+def test_replay_shards_an_odd_stream_count_over_two_ranks():
+    """7 streams over 2 ranks (stream s -> rank s mod G): rank 0 advances 4, rank 1 advances 3, the line counts all 7, names
+    the ranks the collective saw and carries every rank's own rate (a straggler is visible)"""
+    rc, out, err = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--mode", "replay", "--streams", "7"], {})
+    assert rc == 0, err[-3000:]
+    d = json.loads([l for l in out.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["streams_per_rank"] == [4, 3]
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 7) < 1e-6
+    assert len(d["per_rank_solves_per_s"]) == 2 and all(v > 0 for v in d["per_rank_solves_per_s"])
+    assert d["per_rank_solves_per_s"][0] > d["per_rank_solves_per_s"][1]          # 4 against 3 windows per (equally long) dry step
+
+
+def test_default_line_key_set():
+    """the keys the default line promises beyond the contract's: present in the source of the line and, for the ones the dry
+    run can produce, on the dry line"""
+    rc, out, err = _bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--windows", "16"], {})
+    assert rc == 0, err[-3000:]
+    d = json.loads([l for l in out.splitlines() if l.startswith("{")][0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "ranks_seen", "per_rank_solves_per_s"):
+        assert k in d, k
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for k in ("roofline_fp64", "batch_sweep", "run_to_convergence", "mfma_busy", "valu_active", "replay_cpu_baseline", "cpu_baseline", "traffic_commit"):
+        assert f'"{k}"' in src, k
+
+
+def test_cpu_share_cuts_the_affinity_mask():
+    sys.path.insert(0, ROOT)
+    import bench
+    cores = sorted(os.sched_getaffinity(0))
+    if len(cores) < 2:
+        pytest.skip("one core")
+    pid = os.fork()
+    if pid == 0:      # (in a child: the mask of the test process stays)
+        try:
+            a = bench.cpu_share(1, 2)
+            ok = a == cores[len(cores) // 2: 2 * (len(cores) // 2)] and sorted(os.sched_getaffinity(0)) == a
+            os._exit(0 if ok else 1)
+        except BaseException:
+            os._exit(2)
+    assert os.waitpid(pid, 0)[1] == 0
+
+
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
     rc, out, err = _bench(["--gpus", "4", "--steps", "1", "--warmup", "0"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert rc != 0 and "WORLD_SIZE=1" in err and not out.strip()
