@@ -26,6 +26,7 @@ namespace tcv { hipStream_t util_stream(); hipStream_t aux_stream(); }      // (
 #include "tcv_packed.h"      // parallel_run, HostOp: the persistent host worker threads of the packer
 
 namespace tcv { void set_error(const std::string &s); }
+int tcv_marg_layout_n(const tcv_batch *b, int window);      // (tcv_marg.hip: n of the prior a window's attached marginalisation problem makes, known before the kernel runs)
 
 namespace {
 
@@ -1026,7 +1027,12 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
         if (g.rc == TCV_OK) g.rc = tcv_batch_get_summaries(g.b, g.sum.data(), nb);
         const double td2 = now_s();
         bool have_dev = false;
-        static const bool marg_eager = getenv("TCV_EST_MARG_EAGER") != nullptr;      // A/B partner: launch the marginalisation at the end of its own frame (round 4)
+        // Deferred (EstInflight::launch) for frames of many windows, whose host side is long enough to hide the kernel behind the NEXT frame's window
+        // construction: 128 streams on two host threads 17.4 K against 15.7 K windows/s.  A frame of a few windows launches it here, behind its
+        // own downloads -- deferred, its 0.45 ms would end up in front of the next frame's upload (8 streams: 3 050 against 3 250 windows/s).
+        // TCV_EST_MARG_DEFER=n: defer from n windows per call on (0: never, 1: always).
+        static const int defer_from = getenv("TCV_EST_MARG_DEFER") ? atoi(getenv("TCV_EST_MARG_DEFER")) : 12;
+        const bool marg_eager = defer_from <= 0 || nb < defer_from;
         const bool defer_marg = g.rc == TCV_OK && g.any_marg && marg_off_path && !marg_eager;
         if (defer_marg) have_dev = true;      // (nothing to fetch now: EstInflight::launch at the estimators' next frame)
         if (g.rc == TCV_OK && g.any_marg && marg_off_path && marg_eager) {      // the states are on the host: now the marginalisation, and its results as handles without a wait
@@ -1095,7 +1101,7 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
             for (int k = 0; k < nb; k++)
                 if (g.dm[k] && g.est_rc[k] == TCV_OK) {
                     tcv_estimator *e = es[g.idx[k]];
-                    if (defer_marg) { e->pend = fl; e->pend_k = k; e->pend_flag = e->marg_flag; }
+                    if (defer_marg) { e->pend = fl; e->pend_k = k; e->pend_flag = e->marg_flag; const int pn = tcv_marg_layout_n(fl->b, k); if (pn >= 0) e->stats.prior_n = pn; }      // (the new prior's n is part of the attached problem's layout)
                     else { e->prev = fl; e->prev_k = k; }
                 }
             g.deferred = defer_marg;
@@ -1134,7 +1140,7 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
             }
             e->stats.marg_flag = e->marg_flag; e->stats.n_landmarks = (int)e->sel.size(); e->stats.n_proj = (int)e->w_pi.size(); e->stats.n_line = (int)e->w_lf.size();
             e->stats.n_line_obs = e->n_line_obs_total; e->stats.iterations = g.sum[k].num_iterations; e->stats.final_cost = g.sum[k].final_cost;
-            if (g.dm[k] && g.deferred) e->stats.prior_n = e->stats.prior_n;      // (the new prior is taken at the start of the next frame)
+            if (g.dm[k] && g.deferred) { }      // (the new prior is taken at the start of the next frame; stats.prior_n was set with the hand-over above)
             else if (g.dm[k]) {
                 const int rc = take_prior(e, g.newp[k], e->marg_flag);
                 if (rc != TCV_OK) {      // (take_prior keeps the old prior on failure: the new one and the ones not handed over yet are released)

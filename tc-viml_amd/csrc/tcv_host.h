@@ -200,6 +200,7 @@ int tcv_marg_download(tcv_batch *b, int compact);
 int tcv_marg_get_priors_device(tcv_batch *b, tcv_prior **out, int n, bool nowait);
 int tcv_marg_status_prefetch(tcv_batch *b, void *stream);
 bool tcv_marg_has_problem(const tcv_batch *b, int window);      // false: marg_problems[window] was NULL
+int tcv_marg_layout_n(const tcv_batch *b, int window);          // n of the prior this window's marginalisation makes (known from the attached problem, before the kernel runs); -1: none
 // copies device-resident priors into a batch's data pool (one job per window that holds one): launched by tcv_batch_create on the stream
 // of its upload, behind it
 namespace tcv {

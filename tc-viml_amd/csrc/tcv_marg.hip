@@ -2359,6 +2359,11 @@ int tcv_marg_status_prefetch(tcv_batch *b, void *stream) {
     return TCV_OK;
 }
 
+int tcv_marg_layout_n(const tcv_batch *b, int window) {
+    const MargState *s = (const MargState *)b->marg;
+    if (!s || window < 0 || window >= (int)s->win.size() || s->win[window].hdr.nblk == 0) return -1;
+    return s->win[window].hdr.n;
+}
 bool tcv_marg_has_problem(const tcv_batch *b, int window) {
     const MargState *s = (const MargState *)b->marg;
     return s && window >= 0 && window < b->n && s->win[window].hdr.nblk != 0;

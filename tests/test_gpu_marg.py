@@ -44,10 +44,10 @@ def test_golden_marginalisation_after_solve(gpu):
     assert fro(As, z["marg_A_schur"]) < 5e-6 and fro(bs, z["marg_b_schur"]) < 5e-7      # measured 5.2e-7 / 4.7e-8 (each side linearises at its own solve's states)
     JtJ = d["J0"].T @ d["J0"]
     assert fro(JtJ, z["marg_J0"].T @ z["marg_J0"]) < 5e-6                                 # measured 5.1e-7
-    assert fro(d["J0"].T @ d["r0"], z["marg_J0"].T @ z["marg_r0"]) < 2e-4                 # measured 1.8e-5
+    assert fro(d["J0"].T @ d["r0"], z["marg_J0"].T @ z["marg_r0"]) < 1e-4                 # measured 1.8e-5
     assert rel(np.concatenate(d["x0"]), z["marg_x0"]) < 1e-7          # linearisation point = solved states (preMarginalize :110-129); measured 7.5e-9
     # reference invariants (marginalization_factor.cpp:297-298) up to the eps = 1e-8 thresholded null space (35 of 75 eigenvalues)
-    assert fro(JtJ, As) < 5e-7 and fro(d["J0"].T @ d["r0"], bs) < 2e-4                    # measured 3.7e-8 / 1.5e-5
+    assert fro(JtJ, As) < 5e-7 and fro(d["J0"].T @ d["r0"], bs) < 1e-4                    # measured 3.7e-8 / 1.5e-5
     # thresholded factor is positive semi-definite and ordered like SelfAdjointEigenSolver (ascending)
     rn = np.linalg.norm(d["J0"], axis=1)
     assert np.all(np.diff(rn) >= -1e-9 * rn.max())
@@ -100,10 +100,24 @@ def test_prior_round_trip_and_chained_solve(gpu):
     bn = gpu.Batch([Wn]); bn.solve(gpu.default_options(8, True)); bn.synchronize(); bn.download_states()
     s = bn.summaries()[0]
     O = orc.Window(main); so = O.solve(8, True)
-    # the prior differs by its reproducibility floor (A' 5e-7); eight dogleg iterations on the ill-conditioned window turn that into
-    # 1.2e-5 on the final cost and 6.5e-7 / 1.2e-6 on poses / speed-biases (measured): the gates sit one order above
-    assert abs(s.final_cost - so.final_cost) < 1e-4 * so.final_cost
-    assert rel(Wn.pose, O.states()["pose"]) < 1e-5 and rel(Wn.sb, O.states()["sb"]) < 2e-5
+    # Two correct priors (HIP-made and oracle-made: A' 4.7e-7, J0'r0 1.7e-5 apart -- r0 = S^-1/2 V'b' amplifies the small retained
+    # eigenvalues) are two slightly different cost functions, so the two chains are gated on what is well-posed, not on the end state of
+    # eight dogleg iterations on an ill-conditioned window (round-4 review, item 5a; profiles/r05_chained_prior_invariants.txt):
+    # (1) the first trust-region step from the same states: cost at the start, model-cost decrease, step norm (measured 2.5e-10 / 7.4e-8 / 5e-16);
+    r = lambda a, c: abs(a - c) / abs(c)
+    assert r(s.initial_cost, so.initial_cost) < 1e-8
+    assert r(s.model_cost_change[1], so.model_cost_change[1]) < 1e-6 and r(s.step_norm[1], so.step_norm[1]) < 1e-9
+    # (2) the same accept / reject and dogleg-case sequence through all eight iterations;
+    n1 = so.num_iterations
+    assert s.num_iterations == n1
+    assert [s.step_ok[i] for i in range(1, n1)] == [so.step_ok[i] for i in range(1, n1)]
+    assert [s.dogleg_case[i] for i in range(1, n1)] == [so.dogleg_case[i] for i in range(1, n1)]
+    # (3) the end states by the north_star's trajectory criterion -- positions within 1 mm (measured 1.2 um) --, and the final cost within
+    # the difference of the two priors' own linear terms (first order: d cost ~ dx' d(J0'r0); measured 2.0e-5 against 1.7e-5)
+    jtr = fro(d["J0"].T @ d["r0"], main["prior"]["J0"].T @ main["prior"]["r0"])
+    assert np.abs(Wn.pose[:, :3] - O.states()["pose"][:, :3]).max() < 1e-5
+    assert r(s.final_cost, so.final_cost) < 2.0 * jtr + 1e-7, (r(s.final_cost, so.final_cost), jtr)
+    assert rel(Wn.pose, O.states()["pose"]) < 1e-5 and rel(Wn.sb, O.states()["sb"]) < 2e-5          # (regression bound, not a parity criterion: measured 6.4e-7 / 1.6e-6)
     # ... and with the prior's floor taken out -- the oracle solves the window with the SAME (GPU-made) prior -- the two solves agree at the
     # level of every other solve parity test: identical accept / reject and dogleg sequences, north_star's 1e-6 with margin
     O2 = orc.Window(w); so2 = O2.solve(8, True)
@@ -198,7 +212,7 @@ def test_both_launch_shapes_of_the_marginalisation_kernel(gpu, monkeypatch, nt):
         As2, bs2 = b2.prior(k).schur(); d2 = b2.prior(k).export()
         assert np.array_equal(As, As2) and np.array_equal(bs, bs2)
         # measured (both shapes alike: the defect is the thresholded noise eigenvalue, -4e-2 against |A'| = 3e5): 1.3e-7 / 1.4e-5
-        assert fro(d["J0"].T @ d["J0"], As) < 2e-6 and fro(d["J0"].T @ d["r0"], bs) < 2e-4
+        assert fro(d["J0"].T @ d["J0"], As) < 2e-6 and fro(d["J0"].T @ d["r0"], bs) < 1e-4
         assert fro(d["J0"].T @ d["J0"], d2["J0"].T @ d2["J0"]) < 1e-9
 
 

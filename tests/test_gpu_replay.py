@@ -117,7 +117,7 @@ def test_native_estimator_matches_the_python_window_management(gpu, associate):
         # carry eigenvalues that are rounding noise of either sign (|lambda| ~ 1e-2 against |A'| ~ 1e6), so a 1e-13 difference in the
         # triangulated depths decides whether such a direction enters J0 with weight 1 / sqrt(lambda) -- in the reference as well.  The
         # python path stays within 3e-5 of the oracle on that excerpt (tests/dev/replay_three_way.py).
-        assert d[:10].max() < 1e-3 and d.max() < 8e-3      # (measured 6.4e-3 at frame 15 of the V2_02 excerpt + margin; per-window parity of the kernels is gated teacher-forced, tests/test_gpu_teacher.py)
+        assert d[:10].max() < 1e-3 and d.max() < 8e-3      # (measured 6.4e-3 at frame 15 of the V2_02 excerpt + margin.  This free-running allowance is NOT the native path's parity gate: every window the native estimator hands to the solver is re-solved by the oracle within 1e-6 in tests/test_gpu_teacher.py::test_native_estimator_windows_resolved_by_the_oracle)
         assert np.abs(a["q"][:10] - b["q"][:10]).max() < 1e-4 and np.abs(a["v"][:10] - b["v"][:10]).max() < 1e-3
 
 

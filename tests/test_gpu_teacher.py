@@ -212,8 +212,10 @@ def test_teacher_forced_full_length_replay(gpu, seq, mode):
 # full-length replay, because one rounding-level difference is amplified by the window dynamics.  Here every window the native estimator
 # hands to the solver is tapped (tcv_estimator_set_window_tap: parameter arrays, factor lists, pre-integrations, the device-made prior it
 # carries from the previous frame) and re-solved by the CPU oracle from those identical inputs: per window, whatever the trajectory did.
+_dp, _ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+
+
 class _Snapshot(C.Structure):
-    _dp, _ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
     _fields_ = [(k, C.c_int) for k in ("n_frames", "n_landmarks", "n_imu", "n_proj", "n_line", "marg_flag", "estimate_extrinsic", "line_exact_jacobian")] + \
                [(k, _dp) for k in ("pose_in", "speedbias_in", "ex_pose_in", "feature_in", "pose_out", "speedbias_out", "ex_pose_out", "feature_out")] + \
                [("imu", C.c_void_p), ("imu_frame_i", _ip), ("imu_frame_j", _ip), ("proj_frame_i", _ip), ("proj_frame_j", _ip), ("proj_feature", _ip), ("proj_pts", _dp),

@@ -57,6 +57,30 @@ def summarise(d):
     return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items() if "tcv::" in k}
 out = {"sq": summarise("sq"), "sq2": summarise("sq2"), "mfma": summarise("sq3")}
 json.dump(out, open(f"{O}/sq_counters.json", "w"), indent=1)
+# the figures bench.py copies onto its default line (profiles/counters.json), with the commit they were taken at
+import os
+def pick(d, pat):
+    for k, v in d.items():
+        if pat in k:
+            return v
+    return {}
+sk = "solve_kernel<256, true, true, false, false>"
+a, b2, c = pick(out["sq"], sk), pick(out["sq2"], sk), pick(out["mfma"], sk)
+tr = {}
+try:
+    tr = json.load(open(f"{O}/pmc_traffic.json"))
+except (OSError, ValueError):
+    pass
+trk = pick(tr.get("kernels", {}), sk)
+cnt = {"commit": os.environ.get("COMMIT", "unknown"), "source": "tools/profile_round.sh: rocprofv3 --kernel-trace --pmc passes of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras` (B = 1024)",
+       "kernel": sk,
+       "valu_active": (a.get("SQ_ACTIVE_INST_VALU", 0) / a["SQ_WAVE_CYCLES"]) if a.get("SQ_WAVE_CYCLES") else None,
+       "waiting": (a.get("SQ_WAIT_ANY", 0) / a["SQ_WAVE_CYCLES"]) if a.get("SQ_WAVE_CYCLES") else None,
+       "mfma_busy": (c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / c["SQ_BUSY_CU_CYCLES"]) if c.get("SQ_BUSY_CU_CYCLES") else None,
+       "salu_per_valu": (b2.get("SQ_INSTS_SALU", 0) / a["SQ_INSTS_VALU"]) if a.get("SQ_INSTS_VALU") else None,
+       "solve_kernel_hbm_bytes_per_launch": tr.get("solve_kernel_hbm_bytes_per_launch"), "marg_kernel_hbm_bytes_per_launch": tr.get("marg_kernel_hbm_bytes_per_launch"),
+       "solve_kernel_write_bytes_per_launch": trk.get("write_bytes_per_launch_raw"), "solve_kernel_fetch_bytes_per_launch_raw": trk.get("fetch_bytes_per_launch_raw")}
+json.dump(cnt, open(f"{O}/counters.json", "w"), indent=1)
 PY
 ls $O
 # round 4: kernel durations of a lock-step replay frame, thread sweep of the replay
