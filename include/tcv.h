@@ -361,8 +361,14 @@ typedef struct tcv_match_lines_args {
     int n_frames; const double *poses, *ex_pose, *Rbw, *Tbw, *K; int width, height, window_size, n_map; const double *lines3d;
     int n_det; const int *det_frame; const double *det_lines; double angle_th, overlap_th; int fov_given;
     unsigned char *in_fov; int *match_index; float *err; double *projected;
+    const struct tcv_line_map *map_device;      /* NULL, or the same n_map lines resident on the device (tcv_line_map_create): nothing of the map is uploaded */
 } tcv_match_lines_args;
 int tcv_match_lines_batch(int n, const tcv_match_lines_args *args);
+/* The 3D line map of a sequence (`lines_3d`, n x 6: what setParameters reads from line_3d.txt once, estimator.cpp:54-124) resident in HBM for
+ * the life of the handle: the per-frame association then uploads poses and detections only (the map is 43 KB per call otherwise). */
+typedef struct tcv_line_map tcv_line_map;
+int tcv_line_map_create(tcv_line_map **out, int n_map, const double *lines3d);
+void tcv_line_map_destroy(tcv_line_map *m);
 
 /* ---- IMU pre-integration (the producer of the IMU factor's constants) ------- */
 /* Batched `IntegrationBase(acc_0, gyr_0, linearized_ba, linearized_bg)` followed by `push_back(dt, acc, gyr)` for every

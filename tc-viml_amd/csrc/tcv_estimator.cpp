@@ -213,6 +213,7 @@ struct tcv_estimator {
     std::vector<GivenLine> line_obs[W + 1];
     bool assoc = false;
     std::vector<double> map_lines;           // n x 6
+    std::shared_ptr<tcv_line_map> map_dev;   // the same lines resident on the device (created with set_line_map; null: uploaded per call)
     int n_map = 0;
     M3 Rbw;
     V3 Tbw;
@@ -393,7 +394,7 @@ int assoc_prepare(tcv_estimator *e, AssocJob &J) {
     J.call = nd > 0 || J.one_call;
     tcv_match_lines_args &a = J.args;
     a.n_frames = W + 1; a.poses = J.pose; a.ex_pose = J.ex; a.Rbw = e->Rbw.data(); a.Tbw = e->Tbw.data(); a.K = e->cfg.K; a.width = e->cfg.width; a.height = e->cfg.height;
-    a.window_size = W; a.n_map = nm; a.lines3d = e->map_lines.data(); a.n_det = nd; a.det_frame = nd ? J.det_frame.data() : nullptr; a.det_lines = nd ? J.det.data() : nullptr;
+    a.window_size = W; a.n_map = nm; a.lines3d = e->map_lines.data(); a.map_device = e->map_dev.get(); a.n_det = nd; a.det_frame = nd ? J.det_frame.data() : nullptr; a.det_lines = nd ? J.det.data() : nullptr;
     a.angle_th = e->cfg.angle_th; a.overlap_th = e->cfg.overlap_th; a.fov_given = J.one_call ? 2 + W : 1; a.in_fov = J.given.data();
     a.match_index = nd ? J.match.data() : nullptr; a.err = nd ? J.err.data() : nullptr; a.projected = nullptr;
     return TCV_OK;
@@ -724,6 +725,11 @@ extern "C" int tcv_estimator_set_line_map(tcv_estimator *e, int n, const double 
     if (!e || n <= 0 || !lines3d || !Rbw || !Tbw) { tcv::set_error("estimator_set_line_map: bad argument"); return TCV_ERR_INVALID; }
     e->assoc = true; e->n_map = n;
     e->map_lines.assign(lines3d, lines3d + (size_t)6 * n);
+    {      // (best effort: without the handle the association uploads the map per call, same results)
+        tcv_line_map *md = nullptr;
+        e->map_dev.reset();
+        if (!getenv("TCV_EST_HOST_MAP") && tcv_line_map_create(&md, n, lines3d) == TCV_OK) e->map_dev = std::shared_ptr<tcv_line_map>(md, tcv_line_map_destroy);
+    }
     std::memcpy(e->Rbw.data(), Rbw, sizeof(double) * 9);
     for (int c = 0; c < 3; c++) e->Tbw[c] = Tbw[c];
     return TCV_OK;

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "tcv_host.h"
+#include "tcv_packed.h"      // parallel_run, host_threads
 #include "tcv_math.h"
 
 namespace tcv {
@@ -214,6 +215,26 @@ using namespace tcv;
 //   [FoV rows of every call (bytes): given rows go up, computed rows come back]
 //   [outputs of every call: projected segments 4 n_det (doubles) | match index n_det (ints) | errA, errD, overlap 3 n_det (floats)]
 // one copy in ([inputs | FoV]), the kernels of all calls back to back on the calling thread's own stream, one copy out ([FoV | outputs]), one wait
+struct tcv_line_map { double *d = nullptr; int n = 0, dev = 0; };
+extern "C" int tcv_line_map_create(tcv_line_map **out, int n_map, const double *lines3d) {
+    if (!out || n_map <= 0 || !lines3d) { set_error("line_map_create: bad argument"); return TCV_ERR_INVALID; }
+    if (int rc = device_ready()) return rc;
+    tcv_line_map *m = new tcv_line_map();
+    m->n = n_map;
+    (void)hipGetDevice(&m->dev);
+    hipError_t e = tcv::dev_malloc((void **)&m->d, sizeof(double) * 6 * (size_t)n_map);
+    if (e == hipSuccess) e = hipMemcpy(m->d, lines3d, sizeof(double) * 6 * (size_t)n_map, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { tcv::dev_free(m->d); delete m; return hip_fail(e, "line_map_create"); }
+    *out = m;
+    return TCV_OK;
+}
+extern "C" void tcv_line_map_destroy(tcv_line_map *m) {
+    if (!m) return;
+    (void)hipDeviceSynchronize();      // (an association that reads it may be in flight on another thread's stream)
+    tcv::dev_free(m->d);
+    delete m;
+}
+
 extern "C" int tcv_match_lines_batch(int n, const tcv_match_lines_args *args) {
     if (n < 0 || (n > 0 && !args)) { set_error("match_lines_batch: bad argument"); return TCV_ERR_INVALID; }
     if (n == 0) return TCV_OK;
@@ -229,7 +250,8 @@ extern "C" int tcv_match_lines_batch(int n, const tcv_match_lines_args *args) {
         if (a.fov_given && !a.in_fov) { set_error("match_lines: fov_given needs in_fov"); return TCV_ERR_INVALID; }
         if (a.fov_given >= 2 && a.fov_given - 2 >= a.n_frames) { set_error("match_lines: fov_given names a frame outside the window"); return TCV_ERR_INVALID; }
         for (int i = 0; i < a.n_det; i++) if (a.det_frame[i] < 0 || a.det_frame[i] >= a.n_frames) { set_error("match_lines: frame index out of range"); return TCV_ERR_INVALID; }
-        const size_t nd_in = (size_t)7 * a.n_frames + 7 + 9 + 3 + 9 + (size_t)6 * a.n_map + (size_t)4 * a.n_det;
+        if (a.map_device && a.map_device->n != a.n_map) { set_error("match_lines: map_device holds another number of lines"); return TCV_ERR_INVALID; }
+        const size_t nd_in = (size_t)7 * a.n_frames + 7 + 9 + 3 + 9 + (a.map_device ? 0 : (size_t)6 * a.n_map) + (size_t)4 * a.n_det;
         L[c].tot = (size_t)a.n_frames * a.n_map;
         L[c].o_in = in_total; L[c].o_det = in_total + up16(sizeof(double) * nd_in);
         in_total = up16(L[c].o_det + sizeof(int) * std::max(1, a.n_det));
@@ -250,16 +272,26 @@ extern "C" int tcv_match_lines_batch(int n, const tcv_match_lines_args *args) {
     hipStream_t st = tcv::util_stream();
     bool in_flight = false;
     std::vector<size_t> o_pose(n), o_ex(n), o_R(n), o_T(n), o_K(n), o_map(n), o_dl(n);
-    for (int c = 0; c < n && e == hipSuccess; c++) {
-        const tcv_match_lines_args &a = args[c];
-        double *hd = (double *)(h + L[c].o_in);
-        size_t o = 0;
-        auto put = [&](const double *p, size_t k) { std::memcpy(hd + o, p, sizeof(double) * k); o += k; return L[c].o_in / sizeof(double) + o - k; };
-        o_pose[c] = put(a.poses, (size_t)7 * a.n_frames); o_ex[c] = put(a.ex_pose, 7); o_R[c] = put(a.Rbw, 9); o_T[c] = put(a.Tbw, 3); o_K[c] = put(a.K, 9);
-        o_map[c] = put(a.lines3d, (size_t)6 * a.n_map); o_dl[c] = a.n_det ? put(a.det_lines, (size_t)4 * a.n_det) : L[c].o_in / sizeof(double) + o;
-        if (a.n_det) std::memcpy(h + L[c].o_det, a.det_frame, sizeof(int) * a.n_det);
-        if (a.fov_given) std::memcpy(h + in_total + L[c].o_fov, a.in_fov, L[c].tot);
-        else std::memset(h + in_total + L[c].o_fov, 0, L[c].tot);
+    int cur_dev = 0;
+    (void)hipGetDevice(&cur_dev);
+    for (int c = 0; c < n && e == hipSuccess; c++) if (args[c].map_device && args[c].map_device->dev != cur_dev) { tcv::host_staging_release(h); tcv::dev_free(dv); set_error("match_lines: map_device lives on another device"); return TCV_ERR_INVALID; }
+    if (e == hipSuccess) {
+        // the staging buffer is filled by the worker threads (the calls' slices are disjoint): 64 calls with their maps are 3.4 MB of memcpy
+        auto fill = [&](int c) {
+            const tcv_match_lines_args &a = args[c];
+            double *hd = (double *)(h + L[c].o_in);
+            size_t o = 0;
+            auto put = [&](const double *p, size_t k) { std::memcpy(hd + o, p, sizeof(double) * k); o += k; return L[c].o_in / sizeof(double) + o - k; };
+            o_pose[c] = put(a.poses, (size_t)7 * a.n_frames); o_ex[c] = put(a.ex_pose, 7); o_R[c] = put(a.Rbw, 9); o_T[c] = put(a.Tbw, 3); o_K[c] = put(a.K, 9);
+            o_map[c] = a.map_device ? 0 : put(a.lines3d, (size_t)6 * a.n_map);
+            o_dl[c] = a.n_det ? put(a.det_lines, (size_t)4 * a.n_det) : L[c].o_in / sizeof(double) + o;
+            if (a.n_det) std::memcpy(h + L[c].o_det, a.det_frame, sizeof(int) * a.n_det);
+            if (a.fov_given) std::memcpy(h + in_total + L[c].o_fov, a.in_fov, L[c].tot);
+            else std::memset(h + in_total + L[c].o_fov, 0, L[c].tot);
+        };
+        const int nth = n >= 8 ? tcv::host_threads(std::min(n / 4, 8)) : 1;
+        if (nth > 1) tcv::parallel_run(nth, [&](int t) { for (int c = t; c < n; c += nth) fill(c); });
+        else for (int c = 0; c < n; c++) fill(c);
     }
     int rc = TCV_OK;
     int fov_blocks = 0, det_blocks = 0;
@@ -272,7 +304,7 @@ extern "C" int tcv_match_lines_batch(int n, const tcv_match_lines_args *args) {
             char *dout = dv + in_total + fov_total + L[c].o_out;
             const int fov_frame = a.fov_given >= 2 ? a.fov_given - 2 : -1;      // this frame's row is computed here, the others are given
             LineArgs A;
-            A.poses = dd + o_pose[c]; A.ex = dd + o_ex[c]; A.Rbw = dd + o_R[c]; A.Tbw = dd + o_T[c]; A.K = dd + o_K[c]; A.map = dd + o_map[c]; A.det = dd + o_dl[c];
+            A.poses = dd + o_pose[c]; A.ex = dd + o_ex[c]; A.Rbw = dd + o_R[c]; A.Tbw = dd + o_T[c]; A.K = dd + o_K[c]; A.map = a.map_device ? a.map_device->d : dd + o_map[c]; A.det = dd + o_dl[c];
             A.det_frame = (int *)(dv + L[c].o_det); A.n_frames = a.n_frames; A.n_map = a.n_map; A.n_det = a.n_det; A.width = a.width; A.height = a.height; A.window_size = a.window_size;
             A.angle_th = a.angle_th; A.overlap_th = a.overlap_th; A.in_fov = (unsigned char *)(dv + in_total + L[c].o_fov);
             A.match = (int *)(dv + in_total + fov_total + L[c].o_match); A.err = (float *)(dv + in_total + fov_total + L[c].o_err);
@@ -320,6 +352,6 @@ extern "C" int tcv_match_lines(int n_frames, const double *poses, const double *
     tcv_match_lines_args a;
     a.n_frames = n_frames; a.poses = poses; a.ex_pose = ex_pose; a.Rbw = Rbw; a.Tbw = Tbw; a.K = K; a.width = width; a.height = height; a.window_size = window_size;
     a.n_map = n_map; a.lines3d = lines3d; a.n_det = n_det; a.det_frame = det_frame; a.det_lines = det_lines; a.angle_th = angle_th; a.overlap_th = overlap_th;
-    a.fov_given = fov_given; a.in_fov = in_fov; a.match_index = match_index; a.err = err; a.projected = projected;
+    a.fov_given = fov_given; a.in_fov = in_fov; a.match_index = match_index; a.err = err; a.projected = projected; a.map_device = nullptr;
     return tcv_match_lines_batch(1, &a);
 }

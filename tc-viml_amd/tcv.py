@@ -42,7 +42,7 @@ EXPORTS = [
     "tcv_batch_get_priors_device", "tcv_batch_get_priors_device_async", "tcv_prior_is_device_resident", "tcv_problem_set_marginalization_prior",
     "tcv_problems_set_marginalization_prior", "tcv_priors_destroy",
     "tcv_match_lines_batch", "tcv_preintegrate_device", "tcv_preint_sum_dt", "tcv_preint_export", "tcv_preint_destroy", "tcv_problem_add_imu_factor_device",
-    "tcv_microbench_fp64", "tcv_problem_plan_ints", "tcv_set_packer_reference", "tcv_plan_cache_stats", "tcv_problems_pack_bench",
+    "tcv_microbench_fp64", "tcv_problem_plan_ints", "tcv_set_packer_reference", "tcv_plan_cache_stats", "tcv_problems_pack_bench", "tcv_line_map_create", "tcv_line_map_destroy",
 ]
 
 
@@ -644,7 +644,7 @@ class MatchLinesArgs(C.Structure):
     _fields_ = [("n_frames", C.c_int), ("poses", _dp), ("ex_pose", _dp), ("Rbw", _dp), ("Tbw", _dp), ("K", _dp), ("width", C.c_int), ("height", C.c_int),
                 ("window_size", C.c_int), ("n_map", C.c_int), ("lines3d", _dp), ("n_det", C.c_int), ("det_frame", _ip), ("det_lines", _dp),
                 ("angle_th", C.c_double), ("overlap_th", C.c_double), ("fov_given", C.c_int), ("in_fov", C.POINTER(C.c_ubyte)),
-                ("match_index", _ip), ("err", C.POINTER(C.c_float)), ("projected", _dp)]
+                ("match_index", _ip), ("err", C.POINTER(C.c_float)), ("projected", _dp), ("map_device", C.c_void_p)]
 
 
 def match_lines_batch(calls):
