@@ -230,7 +230,11 @@ extern "C" int tcv_line_map_create(tcv_line_map **out, int n_map, const double *
 }
 extern "C" void tcv_line_map_destroy(tcv_line_map *m) {
     if (!m) return;
+    int cur = -1;
+    const bool sw = hipGetDevice(&cur) == hipSuccess && cur != m->dev;
+    if (sw) (void)hipSetDevice(m->dev);
     (void)hipDeviceSynchronize();      // (an association that reads it may be in flight on another thread's stream)
+    if (sw) (void)hipSetDevice(cur);
     tcv::dev_free(m->d);
     delete m;
 }
