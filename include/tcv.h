@@ -266,6 +266,14 @@ int tcv_batch_synchronize(tcv_batch *b);
 /* copy results back: states into the callers' parameter blocks, summaries, priors */
 int tcv_batch_download_states(tcv_batch *b);
 int tcv_batch_get_summaries(tcv_batch *b, tcv_solver_summary *out, int n);
+/* tcv_batch_download_states plus, per window, the three summary numbers a per-frame caller reads -- Summary::iterations.size() (the one the
+ * reference reads, estimator.cpp:1902), termination type, final cost -- in ONE device round trip (any of the arrays may be NULL; n = batch size) */
+int tcv_batch_download_states_brief(tcv_batch *b, int *num_iterations, int *termination, double *final_cost);
+/* the same in two halves, for callers that enqueue more work behind the solve: _begin puts the copies on `hip_stream` (behind the batch's
+ * work in flight) and returns; _end waits for the copies only -- not for what the caller enqueued behind them, e.g. tcv_batch_marginalize --
+ * and writes the states into the callers' blocks.  Between the two calls the parameter blocks must not be read. */
+int tcv_batch_download_states_begin(tcv_batch *b, void *hip_stream);
+int tcv_batch_download_states_end(tcv_batch *b, int *num_iterations, int *termination, double *final_cost);
 int tcv_batch_get_prior(tcv_batch *b, int window, tcv_prior **out);
 /* every window's prior in one call (n = the batch size): out[k] as tcv_batch_get_prior(b, k, &out[k]) would return it; the host copies are
  * made by several host threads.  On an error nothing is returned (out[] is all NULL). */

@@ -293,8 +293,7 @@ extern "C" int tcv_problem_create(tcv_problem **out) {
 extern "C" void tcv_problem_destroy(tcv_problem *p) { delete p; }
 
 static int block_of(tcv_problem *p, double *addr) {
-    auto it = p->index.find(addr);
-    return it == p->index.end() ? -1 : it->second;
+    return p->index.find(addr);
 }
 
 extern "C" int tcv_problem_add_parameter_block(tcv_problem *p, double *values, int size, int parameterization) {
@@ -306,7 +305,7 @@ extern "C" int tcv_problem_add_parameter_block(tcv_problem *p, double *values, i
         p->blocks[b].kind = parameterization == TCV_PARAM_POSE ? KIND_POSE : p->blocks[b].kind;
         return TCV_OK;
     }
-    p->index[values] = (int)p->blocks.size();
+    p->index.put(values, (int)p->blocks.size());
     p->blocks.push_back(ParamBlock{values, size, parameterization == TCV_PARAM_POSE ? KIND_POSE : KIND_EUCLID, false});
     return TCV_OK;
 }
@@ -682,6 +681,8 @@ static void batch_free(tcv_batch *b) {
     if (b->wait_inflight) (void)hipEventSynchronize(b->ev_inflight);
     if (b->pending)      // the buffers go back to the free list: nothing of this batch may still be running on any stream it used
         for (hipStream_t st : b->streams) { if (st) (void)hipStreamSynchronize(st); else (void)hipDeviceSynchronize(); }
+    if (b->dl_staging) { if (b->ev_dl) (void)hipEventSynchronize(b->ev_dl); tcv::host_staging_release(b->dl_staging); b->dl_staging = nullptr; }
+    if (b->ev_dl) (void)hipEventDestroy(b->ev_dl);
     if (b->ev_order) (void)hipEventDestroy(b->ev_order);
     if (b->ev_inflight) (void)hipEventDestroy(b->ev_inflight);
     coop_release(b);
@@ -1174,6 +1175,73 @@ extern "C" int tcv_batch_download_states(tcv_batch *b) {
         for (int blk : pk.lm_block) p.blocks[blk].addr[0] = x[off++];
     }
     return TCV_OK;
+}
+// Split form for callers that enqueue more work behind the solve: _begin puts the copy of the states (and of the summary heads) on `hip_stream`
+// behind whatever the batch has in flight there and returns; the caller may launch the marginalisation right behind it; _end waits for the
+// COPY only (an event), not for the stream, and hands the results out.  The native estimator does: the marginalisation starts the moment the
+// states have left, not a host round trip later.
+extern "C" int tcv_batch_download_states_begin(tcv_batch *b, void *hip_stream) {
+    if (!b || !b->solved) return TCV_ERR_INVALID;
+    if (b->dl_staging) { set_error("batch_download_states_begin: a download is in flight already"); return TCV_ERR_INVALID; }
+    if (hip_stream == TCV_STREAM_THREAD) hip_stream = (void *)tcv::util_stream();
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (int rc = tcv_batch_enter_stream(b, hip_stream)) return rc;
+    b->h_state.resize((size_t)b->n * b->state_stride);
+    const size_t sbytes = sizeof(double) * b->h_state.size(), hbytes = (size_t)32 * b->n;
+    static_assert(offsetof(DevSummary, final_cost) == 24 && offsetof(DevSummary, num_iterations) == 0 && offsetof(DevSummary, termination) == 4, "head of DevSummary");
+    char *hs = (char *)host_staging_acquire(sbytes + hbytes);
+    if (!hs) { set_error("hipHostMalloc (download staging) failed"); return TCV_ERR_HIP; }
+    hipError_t e_ = hipSuccess;
+    if (!b->ev_dl) e_ = hipEventCreateWithFlags(&b->ev_dl, hipEventDisableTiming);
+    if (e_ == hipSuccess) e_ = hipMemcpyAsync(hs, b->d_state, sbytes, hipMemcpyDeviceToHost, st);
+    if (e_ == hipSuccess) e_ = hipMemcpy2DAsync(hs + sbytes, 32, b->d_summary, sizeof(DevSummary), 32, (size_t)b->n, hipMemcpyDeviceToHost, st);
+    if (e_ == hipSuccess) e_ = hipEventRecord(b->ev_dl, st);
+    if (e_ != hipSuccess) { (void)(st ? hipStreamSynchronize(st) : hipDeviceSynchronize()); host_staging_release(hs); return hip_fail(e_, "download of the states"); }
+    b->dl_staging = hs;
+    return TCV_OK;
+}
+extern "C" int tcv_batch_download_states_end(tcv_batch *b, int *num_iterations, int *termination, double *final_cost) {
+    if (!b || !b->dl_staging || !b->ev_dl) { set_error("batch_download_states_end: no download in flight"); return TCV_ERR_INVALID; }
+    char *hs = (char *)b->dl_staging;
+    const size_t sbytes = sizeof(double) * b->h_state.size();
+    const hipError_t e_ = hipEventSynchronize(b->ev_dl);
+    if (e_ == hipSuccess) {
+        std::memcpy(b->h_state.data(), hs, sbytes);
+        for (int w = 0; w < b->n; w++) {
+            const char *q = hs + sbytes + (size_t)32 * w;
+            int it, tm; double fc;
+            std::memcpy(&it, q, 4); std::memcpy(&tm, q + 4, 4); std::memcpy(&fc, q + 24, 8);
+            if (num_iterations) num_iterations[w] = it;
+            if (termination) termination[w] = tm;
+            if (final_cost) final_cost[w] = fc;
+        }
+    }
+    host_staging_release(hs);
+    b->dl_staging = nullptr;
+    if (e_ != hipSuccess) return hip_fail(e_, "download of the states");
+    // the solve (and the gauge fix) lie behind the copy on the stream: they have finished -- its duration and the CUs its cooperative launch held
+    coop_release(b);
+    if (b->solved) (void)hipEventElapsedTime(&b->solve_ms, b->ev0, b->ev1);
+    for (int w = 0; w < b->n; w++) {
+        const Packed &pk = b->packed[w];
+        const tcv_problem &p = *b->problems[w];
+        const double *x = b->h_state.data() + (size_t)w * b->state_stride;
+        int off = 0;
+        for (int blk : pk.cam_block) { std::memcpy(p.blocks[blk].addr, x + off, sizeof(double) * p.blocks[blk].size); off += p.blocks[blk].size; }
+        for (int blk : pk.lm_block) p.blocks[blk].addr[0] = x[off++];
+    }
+    return TCV_OK;
+}
+// States into the callers' blocks AND the three numbers of the summary a per-frame caller reads (the reference reads one:
+// summary.iterations.size(), estimator.cpp:1902) in ONE device round trip: the states and the heads of the summary records (32 of their
+// 4 136 bytes, a pitched copy) on the calling thread's stream, one wait.
+extern "C" int tcv_batch_download_states_brief(tcv_batch *b, int *num_iterations, int *termination, double *final_cost) {
+    if (!b || !b->solved) return TCV_ERR_INVALID;
+    if (b->pending) if (int rc = tcv_batch_synchronize(b)) return rc;
+    if (int rc = tcv_batch_download_states_begin(b, (void *)tcv::util_stream())) return rc;
+    const int rc = tcv_batch_download_states_end(b, num_iterations, termination, final_cost);
+    if (rc == TCV_OK) { if (int rcs = tcv_batch_synchronize(b)) return rcs; }      // (nothing of this call stays in flight)
+    return rc;
 }
 static void summary_to_public(const DevSummary &s, tcv_solver_summary *o) {
     std::memset(o, 0, sizeof *o);

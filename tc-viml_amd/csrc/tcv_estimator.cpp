@@ -929,6 +929,7 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
         tcv_batch *b = nullptr;
         int rc = TCV_OK;
         bool deferred = false;            // the marginalisation of this frame is launched by its estimators' next frame (EstInflight)
+        bool dl_begun = false, marg_launched = false;      // the copy of the states / the marginalisation were enqueued behind the solve (marg_off_path)
     };
     Group G[2];
     // Every kernel of the frame goes on the CALLING THREAD's utility stream -- the stream tcv_batch_create's uploads, the device-to-device
@@ -1013,10 +1014,44 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
             if (g.rc == TCV_OK) g.rc = tcv_batch_attach_marginalization(g.b, g.M.data(), g.drops.data(), g.ndrop.data());
         }
     }
+    // Deferred marginalisation (EstInflight::launch) for frames of many windows, whose host side is long enough to hide the kernel behind the NEXT
+    // frame's window construction: 128 streams on two host threads 17.4 K against 15.7 K windows/s.  A frame of a few windows enqueues it here,
+    // right behind the copy of its states -- deferred, its 0.45 ms would end up in front of the next frame's upload (8 streams: 3 050 against
+    // 3 250 windows/s).  TCV_EST_MARG_DEFER=n: defer from n windows per call on (0: never, 1: always).
+    static const int defer_from = getenv("TCV_EST_MARG_DEFER") ? atoi(getenv("TCV_EST_MARG_DEFER")) : 12;
+    static const bool marg_aux = getenv("TCV_EST_MARG_AUX") && atoi(getenv("TCV_EST_MARG_AUX")) != 0;
+    if (marg_off_path) {
+        // everything the frame still needs from the device goes on the stream NOW, while the solve runs: the copy of the states (and of the
+        // summary heads), and behind it the marginalisation with its no-wait prior handles -- the kernel starts the moment the states have
+        // left instead of a host round trip (wake-up, unpacking, launch) later, which the next frame's association would wait out
+        for (int group = 1; group >= 0; group--) {
+            Group &g = G[group];
+            if (g.idx.empty() || g.rc != TCV_OK) continue;
+            const int nb = (int)g.idx.size();
+            void *st = (void *)g_streams[group];
+            g.rc = tcv_batch_download_states_begin(g.b, st);
+            g.dl_begun = g.rc == TCV_OK;
+            g.newp.assign(nb, nullptr);
+            const bool eager = defer_from <= 0 || nb < defer_from;
+            if (g.rc == TCV_OK && g.any_marg && eager && !marg_aux) {
+                g.rc = tcv_batch_marginalize(g.b, st);
+                if (g.rc == TCV_OK) g.rc = tcv_batch_get_priors_device_async(g.b, g.newp.data(), nb);
+                g.marg_launched = g.rc == TCV_OK;
+            }
+        }
+    }
     for (int group = 1; group >= 0; group--) {
         Group &g = G[group];
         if (g.idx.empty()) continue;
-        if (g.rc == TCV_OK) g.rc = tcv_batch_synchronize(g.b);
+        const int nb = (int)g.idx.size();
+        g.sum.resize(nb);
+        if (g.dl_begun) {      // waits for the copy (an event behind the solve and the gauge fix), not for the marginalisation behind it
+            std::vector<int> its(nb, 0), tms(nb, 0);
+            std::vector<double> fcs(nb, 0.0);
+            const int rcd = tcv_batch_download_states_end(g.b, its.data(), tms.data(), fcs.data());
+            if (g.rc == TCV_OK) g.rc = rcd;
+            for (int k = 0; k < nb; k++) { std::memset(&g.sum[k], 0, sizeof g.sum[k]); g.sum[k].num_iterations = its[k]; g.sum[k].termination = tms[k]; g.sum[k].final_cost = fcs[k]; }
+        } else if (g.rc == TCV_OK) g.rc = tcv_batch_synchronize(g.b);
         double ms = 0;
         if (g.rc == TCV_OK && tcv_batch_stats(g.b, nullptr, &ms, nullptr) == TCV_OK && ms > 0) { kern_add(0, ms); kern_add(1, 1); }
     }
@@ -1025,27 +1060,25 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
         Group &g = G[group];
         if (g.idx.empty()) continue;
         const int nb = (int)g.idx.size();
-        g.sum.resize(nb); g.newp.assign(nb, nullptr);
+        if ((int)g.newp.size() != nb) g.newp.assign(nb, nullptr);
         static const bool dbg_dl = getenv("TCV_DEBUG_EST") != nullptr;      // developer: where the "downloads" lap goes
         const double td0 = now_s();
-        if (g.rc == TCV_OK) g.rc = tcv_batch_download_states(g.b);
+        if (!g.dl_begun) {      // (the variants that wait for the marginalisation inside the call: states + the three summary numbers, one device round trip)
+            std::vector<int> its(nb, 0), tms(nb, 0);
+            std::vector<double> fcs(nb, 0.0);
+            if (g.rc == TCV_OK) g.rc = tcv_batch_download_states_brief(g.b, its.data(), tms.data(), fcs.data());
+            for (int k = 0; k < nb; k++) { std::memset(&g.sum[k], 0, sizeof g.sum[k]); g.sum[k].num_iterations = its[k]; g.sum[k].termination = tms[k]; g.sum[k].final_cost = fcs[k]; }
+        }
         const double td1 = now_s();
-        if (g.rc == TCV_OK) g.rc = tcv_batch_get_summaries(g.b, g.sum.data(), nb);
-        const double td2 = now_s();
+        const double td2 = td1;
         bool have_dev = false;
-        // Deferred (EstInflight::launch) for frames of many windows, whose host side is long enough to hide the kernel behind the NEXT frame's window
-        // construction: 128 streams on two host threads 17.4 K against 15.7 K windows/s.  A frame of a few windows launches it here, behind its
-        // own downloads -- deferred, its 0.45 ms would end up in front of the next frame's upload (8 streams: 3 050 against 3 250 windows/s).
-        // TCV_EST_MARG_DEFER=n: defer from n windows per call on (0: never, 1: always).
-        static const int defer_from = getenv("TCV_EST_MARG_DEFER") ? atoi(getenv("TCV_EST_MARG_DEFER")) : 12;
         const bool marg_eager = defer_from <= 0 || nb < defer_from;
         const bool defer_marg = g.rc == TCV_OK && g.any_marg && marg_off_path && !marg_eager;
         if (defer_marg) have_dev = true;      // (nothing to fetch now: EstInflight::launch at the estimators' next frame)
-        if (g.rc == TCV_OK && g.any_marg && marg_off_path && marg_eager) {      // the states are on the host: now the marginalisation, and its results as handles without a wait
-            // (on the thread's main stream: the next frame's association round trip queues behind it, ~0.1 ms of a frame.  TCV_EST_MARG_AUX=1: on the
-            // thread's second stream -- one host thread 2 570 - 2 720 against 2 590 windows/s, two host threads 2 490 - 2 550 against 2 940: two
-            // streams per thread share the runtime's four hardware queues again)
-            static const bool marg_aux = getenv("TCV_EST_MARG_AUX") && atoi(getenv("TCV_EST_MARG_AUX")) != 0;
+        if (g.marg_launched) have_dev = true; // (enqueued behind the copy of the states, above; the handles are in g.newp)
+        else if (g.rc == TCV_OK && g.any_marg && marg_off_path && marg_eager) {      // TCV_EST_MARG_AUX=1: on the thread's second stream, now that the states are on the host
+            // (one host thread 2 570 - 2 720 against 2 590 windows/s, two host threads 2 490 - 2 550 against 2 940: two streams per thread share
+            // the runtime's four hardware queues again)
             g.rc = tcv_batch_marginalize(g.b, marg_aux ? (void *)tcv::aux_stream() : (void *)g_streams[group]);
             if (g.rc == TCV_OK) g.rc = tcv_batch_get_priors_device_async(g.b, g.newp.data(), nb);
             have_dev = g.rc == TCV_OK;

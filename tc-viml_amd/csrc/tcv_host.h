@@ -122,9 +122,36 @@ struct Packed {
 
 }  // namespace tcv
 
+namespace tcv {
+// address -> block index of a problem: open addressing in one flat array (a node-based map cost a live estimator 200 small allocations and
+// frees per window and frame)
+struct AddrIndex {
+    std::vector<std::pair<double *, int>> tab;      // power-of-two size; first == nullptr: empty
+    size_t used = 0;
+    static size_t h(const double *a) { size_t x = (size_t)a >> 3; x *= 0x9E3779B97F4A7C15ull; return x >> 17; }
+    int find(double *a) const {
+        if (tab.empty()) return -1;
+        const size_t m = tab.size() - 1;
+        for (size_t i = h(a) & m;; i = (i + 1) & m) { if (tab[i].first == a) return tab[i].second; if (!tab[i].first) return -1; }
+    }
+    void put(double *a, int v) {
+        if (2 * (used + 1) > tab.size()) grow();
+        const size_t m = tab.size() - 1;
+        for (size_t i = h(a) & m;; i = (i + 1) & m) { if (tab[i].first == a) { tab[i].second = v; return; } if (!tab[i].first) { tab[i] = {a, v}; used++; return; } }
+    }
+    void grow() {
+        std::vector<std::pair<double *, int>> old;
+        old.swap(tab);
+        tab.assign(old.empty() ? 512 : 2 * old.size(), {nullptr, 0});
+        used = 0;
+        for (auto &kv : old) if (kv.first) put(kv.first, kv.second);
+    }
+};
+}  // namespace tcv
+
 struct tcv_problem {
     std::vector<tcv::ParamBlock> blocks;
-    std::unordered_map<double *, int> index;
+    tcv::AddrIndex index;
     std::vector<tcv::ImuFac> imu;
     std::vector<tcv::ProjFac> proj;
     std::vector<tcv::LineFac> line;
@@ -162,6 +189,8 @@ struct tcv_batch {
     bool gauge_fixed = false;
     hipStream_t last_stream = nullptr;     // stream of the last asynchronous call
     std::vector<hipStream_t> streams;      // every stream with work of this batch in flight (tcv_batch_synchronize / batch_free wait for all of them; null: the device)
+    hipEvent_t ev_dl = nullptr;            // tcv_batch_download_states_begin: recorded behind the enqueued copy of the states
+    void *dl_staging = nullptr;            // its pinned buffer, until tcv_batch_download_states_end
     hipEvent_t ev_order = nullptr;         // orders a call on a new stream behind the pending work of the previous one (tcv_batch_enter_stream)
     hipEvent_t ev_inflight = nullptr;      // tcv_batch_get_priors_device_async: the work in flight is tracked by this event from then on, not by the streams it runs
     bool wait_inflight = false;            // on (the batch outlives the call, a stream may go with its host thread); waited for by synchronize / destroy / the next call

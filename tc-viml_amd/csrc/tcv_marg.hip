@@ -1878,9 +1878,9 @@ static int pack_marg(const tcv_problem &p, double *const *drop, int ndrop, const
     for (auto &f : p.proj) { for (int k = 0; k < 4; k++) touched[f.b[k]] = 1; if (f.btd >= 0) touched[f.btd] = 1; }
     for (auto &f : p.prior) for (int b : f.b) touched[b] = 1;
     for (int k = 0; k < ndrop; k++) {
-        auto it = p.index.find(drop[k]);
-        if (it == p.index.end()) { set_error("marginalize: dropped block is not part of the problem"); return TCV_ERR_INVALID; }
-        if (touched[it->second]) dropped[it->second] = 1;
+        const int bd = p.index.find(drop[k]);
+        if (bd < 0) { set_error("marginalize: dropped block is not part of the problem"); return TCV_ERR_INVALID; }
+        if (touched[bd]) dropped[bd] = 1;
     }
     // ambient offsets and [m | n] tangent order.  MarginalizationInfo knows nothing about SetParameterBlockConstant: a constant block
     // (para_Ex_Pose with ESTIMATE_EXTRINSIC = 0, estimator.cpp:1694-1698) is kept / dropped like any other and its Jacobian columns are

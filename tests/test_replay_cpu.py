@@ -177,3 +177,58 @@ def test_native_estimator_fails_loudly_without_a_device():
     bad = C.c_int()
     assert L.tcv_estimator_begin_frame(h, 3, None, None, 0, None, None, 0, None, None, None, C.byref(bad)) == tcv.TCV_ERR_INVALID
     L.tcv_estimator_destroy(h)
+
+
+def test_bench_cpu_leg_of_the_replay_mode_runs_the_same_streams():
+    """bench.py --mode replay, CPU baseline leg: a worker process replays stream i with the oracle back end and times the back end's calls only
+    (no device involved); the generator arguments are the GPU run's, so the frame count must fit the 36 s ground-truth excerpts"""
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, ROOT)
+    import bench
+    n, t = bench._cpu_replay_worker((1, replay.WINDOW_SIZE + 1 + 10 + 100, 60, 8, 3.0))      # the default replay line: warm-up 10 + 100 steps
+    assert n >= 3 and 0.0 < t < 3.5
+    # the default line's replay figure (10 + 60 frames) and a stream of the second lap over the sequences (start offset 3 s)
+    n2, t2 = bench._cpu_replay_worker((6, replay.WINDOW_SIZE + 1 + 10 + 60, 60, 8, 1.0))
+    assert n2 >= 1 and t2 > 0.0
+
+
+def test_native_estimator_host_side_entry_points_without_a_device():
+    """tcv_estimators_begin_frames (one call per lock-step frame) and the window tap's error path are host code: they run without a GPU"""
+    import ctypes as C
+    import tcv
+    L = tcv.lib()
+    st = replay.simulate_stream(5, 6, max_features=20)
+    cfg = replay._EstimatorConfig()
+    cfg.focal_length = 460.0; cfg.min_parallax = replay.MIN_PARALLAX; cfg.init_depth = replay.INIT_DEPTH
+    cfg.acc_n = cfg.gyr_n = cfg.acc_w = cfg.gyr_w = 1e-3
+    cfg.gravity[:] = [0.0, 0.0, 9.81]; cfg.imu_dt = 0.005; cfg.K[:] = [460.0, 0, 376.0, 0, 460.0, 240.0, 0, 0, 1.0]; cfg.width = 752; cfg.height = 480
+    cfg.tic[:] = [0.0, 0.0, 0.0]; cfg.ric[:] = [1.0, 0, 0, 0, 1.0, 0, 0, 0, 1.0]; cfg.estimate_extrinsic = 1
+    cfg.angle_th, cfg.overlap_th, cfg.dist_th = 0.17, 0.45, 50.0
+    cfg.num_iterations = 8; cfg.fixed_iterations = 0; cfg.line_exact_jacobian = 0
+    vp = C.c_void_p
+    L.tcv_estimator_create.argtypes = [C.POINTER(vp), C.POINTER(replay._EstimatorConfig)]
+    L.tcv_estimator_destroy.argtypes = [vp]; L.tcv_estimator_destroy.restype = None
+    L.tcv_estimators_begin_frames.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(replay._FrameInput), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.tcv_estimator_set_window_tap.argtypes = [vp, C.c_int]
+    hs = [vp(), vp()]
+    for h in hs:
+        tcv.check(L.tcv_estimator_create(C.byref(h), C.byref(cfg)))
+    try:
+        arr = (vp * 2)(*hs)
+        rec = (replay._FrameInput * 2)()
+        pts = np.ascontiguousarray(np.array([[0.1, 0.2, 1.0], [-0.1, 0.05, 1.0]])); ids = np.ascontiguousarray([7, 9], dtype=np.int32)
+        for r in rec:
+            r.n_imu = 0; r.n_points = 2; r.point_ids = ids.ctypes.data_as(C.POINTER(C.c_int)); r.points = pts.ctypes.data_as(C.POINTER(C.c_double)); r.n_lines = 0
+        ready = (C.c_int * 2)(5, 5); rcs = (C.c_int * 2)(9, 9)
+        tcv.check(L.tcv_estimators_begin_frames(arr, 2, rec, ready, rcs))
+        assert list(ready) == [0, 0] and list(rcs) == [0, 0]                      # the window is not full after one frame
+        assert L.tcv_estimators_begin_frames((vp * 2)(hs[0], hs[0]), 2, rec, ready, rcs) != 0      # the same estimator twice
+        tcv.check(L.tcv_estimator_set_window_tap(hs[0], 1))
+        snap = (C.c_char * 1024)()
+        L.tcv_estimator_get_window_snapshot.argtypes = [vp, C.c_void_p]
+        assert L.tcv_estimator_get_window_snapshot(hs[0], C.cast(snap, C.c_void_p)) != 0            # no window optimised yet
+        assert b"no snapshot" in L.tcv_last_error()
+    finally:
+        for h in hs:
+            L.tcv_estimator_destroy(h)

@@ -72,7 +72,7 @@ try:
 except (OSError, ValueError):
     pass
 trk = pick(tr.get("kernels", {}), sk)
-cnt = {"commit": os.environ.get("COMMIT", "unknown"), "source": "tools/profile_round.sh: rocprofv3 --kernel-trace --pmc passes of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras` (B = 1024)",
+cnt = {"commit": os.environ.get("COMMIT", "unknown"), "source": "tools/profile_round.sh: rocprofv3 --kernel-trace --pmc passes of python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras (B = 1024)",
        "kernel": sk,
        "valu_active": (a.get("SQ_ACTIVE_INST_VALU", 0) / a["SQ_WAVE_CYCLES"]) if a.get("SQ_WAVE_CYCLES") else None,
        "waiting": (a.get("SQ_WAIT_ANY", 0) / a["SQ_WAVE_CYCLES"]) if a.get("SQ_WAVE_CYCLES") else None,
