@@ -764,7 +764,7 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
     if (n_cu <= 0) n_cu = 256;
     // chain layout: two workgroups share a CU's LDS when the batch is larger than the chip; a batch that leaves CUs idle anyway gives
     // every workgroup the whole 160 KiB (fewer chunk passes over the visual factors, the prior's J0 staged in one piece)
-    const int chain_lds = (n <= n_cu && !getenv("TCV_CHAIN_LDS_DOUBLES")) ? (int)LDS_DOUBLES : chain_lds_doubles();
+    int chain_lds = (n <= n_cu && !getenv("TCV_CHAIN_LDS_DOUBLES")) ? (int)LDS_DOUBLES : chain_lds_doubles();
     b->chain_lds = chain_lds;
     int mode = g_solver_variant;
     // the chain layout is used only if every window of the batch allows it: the packing pass below starts over with the dense layout
@@ -807,6 +807,14 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
     {
         std::string msg;
         int rc = pack_all(mode, msg);
+        // a window that does not fit half a CU's LDS (more than ~280 landmarks: its vectors over the unknowns and the chain's working set leave no
+        // pool for the visual chunks) gives the WHOLE batch one workgroup per CU with all 160 KiB -- up to 1024 landmarks / 4096 point factors --
+        // instead of failing; such a batch runs at 1 / 1.7 of the two-per-CU rate
+        if (rc == TCV_ERR_TOO_LARGE && mode == 0 && chain_lds < (int)LDS_DOUBLES && !getenv("TCV_CHAIN_LDS_DOUBLES")) {
+            chain_lds = (int)LDS_DOUBLES; b->chain_lds = chain_lds;
+            msg.clear();
+            rc = pack_all(mode, msg);
+        }
         if (rc == TCV_OK && mode == 0 && coop_h > 0)
             for (int w = 0; w < n; w++) {      // what the cooperative master assumes: the prior staged in one piece, one IMU chunk
                 const PlanHdr &H = b->packed[w].hdr;
@@ -918,7 +926,7 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
     b->state_stride = (max_state + 1) & ~1;
     b->delta_stride = (max_nl + 1) & ~1;
     b->lds_bytes = max_lds;
-    b->grid = std::min(n, n_cu * (b->chain ? 2 : 1));
+    b->grid = std::min(n, n_cu * ((b->chain && chain_lds < (int)LDS_DOUBLES) ? 2 : 1));      // (two workgroups per CU only when each takes half its LDS)
     if (const char *eg = getenv("TCV_GRID")) { const int g = atoi(eg); if (g > 0) b->grid = std::min(n, g); }      // tuning experiments
     b->slots = b->grid;
     b->n_cu = n_cu; b->coop_dev = dev;

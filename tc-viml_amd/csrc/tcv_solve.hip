@@ -1925,6 +1925,13 @@ __device__ __noinline__ ChainOut chain_forward(TCV_CTX_PARAMS, double mu) {
                     if (row0 == 0) { wo[8 * wld] = w4[2]; sp[8] = w4[2]; }
 #pragma unroll
                     for (int i = 0; i < 4; i++) wp[jt][i] = w4[i];
+                } else {
+                    // W_s of a tile without a coupled column IS zero -- and must be in the registers the next step multiplies with: along
+                    // one chain the active tiles only grow, so an inactive tile had never been written, but a window whose IMU chain is
+                    // broken (a pre-integration over 10 s is left out, estimator.cpp:1726) starts a second chain with fewer active tiles,
+                    // and the block the prior couples to every pose (para_SpeedBias[0]) then picked up the FIRST chain's rows here
+#pragma unroll
+                    for (int i = 0; i < 4; i++) wp[jt][i] = 0.0;
                 }
                 if (s + 1 < ne) {      // the next step's entries, whether or not the tile is active yet
                     rcs[jt] = cc <= npp ? ((const __attribute__((address_space(3))) unsigned char *)(h + CH_STRIDE + CH_COLROW))[cc] : 255;

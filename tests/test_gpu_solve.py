@@ -234,3 +234,55 @@ def test_max_solver_time_stops_the_iteration_loop(gpu):
     assert n0 == 1 and t0 == 0                       # iteration 0 only (summary.iterations.size() == 1), NO_CONVERGENCE
     n1, t1, c1 = run(0.0008)                         # ~0.3 ms per iteration for a lone window: a few iterations fit
     assert 1 < n1 < n_free and c0 > c1 > c_free * (1 - 1e-12)
+
+
+@pytest.mark.parametrize("window", ["prior", "no prior"])
+@pytest.mark.parametrize("gone", [(0,), (4,), (7,), (2, 6)])
+def test_imu_factor_over_ten_seconds_is_left_out(gpu, gone, window):
+    """estimator.cpp:1726: `if (pre_integrations[j]->sum_dt > 10.0) continue;` (a platform that stood still: MARGIN_SECOND_NEW keeps merging
+    the IMU buffers of the newest interval) -- the window is then two or three IMU chains (the chain layout's steps cover them,
+    tests/test_abi_cpu.py).  The HIP side gets the window WITH the long pre-integration and must drop it itself (tcv_problem_from_window);
+    the oracle gets the graph without that factor.  With the prior -- which couples para_SpeedBias[0] to every pose -- this caught the
+    chain elimination carrying the first chain's W rows into the second one (round 5)."""
+    pre, main0, z = golden_windows()
+    main = main0 if window == "prior" else pre
+    im = dict(main["imu"])
+    sd = np.array(im["sum_dt"], dtype=float).copy(); sd[list(gone)] = 11.0; im["sum_dt"] = sd
+    w_hip = dict(main, imu=im)
+    keep = ~np.isin(np.arange(len(sd)), gone)
+    w_orc = dict(main, imu={k: (np.asarray(v)[keep] if isinstance(v, np.ndarray) and np.asarray(v).shape[:1] == keep.shape else v) for k, v in main["imu"].items()})
+    W, b, s = gpu_solve(gpu, [w_hip])
+    assert gpu.lib().tcv_problem_num_residual_blocks(W[0].h) == len(main["imu"]["sum_dt"]) - len(gone) + len(main["proj"]["frame_i"]) + len(main["line"]["frame"]) + (1 if main.get("prior") is not None else 0)
+    assert b.plan_stats()["layout"] == "chain"
+    O = orc.Window(w_orc); so = O.solve(8, True)
+    n = so.num_iterations
+    assert s[0].num_iterations == n and [s[0].step_ok[i] for i in range(1, n)] == [so.step_ok[i] for i in range(1, n)]
+    assert [s[0].dogleg_case[i] for i in range(1, n)] == [so.dogleg_case[i] for i in range(1, n)]
+    assert abs(s[0].final_cost - so.final_cost) < TOL * so.final_cost
+    st, sg = O.states(), W[0].states()
+    for key in ("pose", "sb", "ex", "lam"):
+        assert rel(sg[key], st[key]) < TOL, key
+
+
+def test_a_window_beyond_half_a_cu_moves_its_batch_to_one_workgroup_per_cu(gpu):
+    """Maximum sizes.  A batch larger than the chip runs two workgroups per CU on 80 KiB of LDS each, which holds windows of up to ~280
+    landmarks; ONE larger window (here 600 landmarks x 4 observations = 2400 point factors, twelve staging chunks) used to fail the whole
+    tcv_batch_create with TCV_ERR_TOO_LARGE -- the batch now takes one workgroup per CU with all 160 KiB (up to 1024 landmarks).  Both the
+    large window and its small neighbours must come out as the oracle solves them."""
+    small = synth.make_windows(5200, 300)
+    wins = [synth.window_at(small, k) for k in range(300)]
+    wins[137] = synth.window_at(synth.make_windows(5600, 1, n_landmarks=600), 0)
+    W = [gpu.Window(w) for w in wins]
+    b = gpu.Batch(W)
+    num, pbytes, grid, lds = b.plan_stats()["num_plans"], b.plan_stats()["plan_bytes"], b.plan_stats()["grid"], b.plan_stats()["lds_bytes"]
+    assert lds == 160 * 1024 and grid <= 256 and num == 2
+    b.solve(gpu.default_options(8, True, True, 256, True)); b.synchronize(); b.download_states()
+    s = b.summaries()
+    for k in (137, 0, 299):
+        check_against_oracle(gpu, wins[k], W[k], b, s[k], k, 8, True)
+    # the limit itself: 1024 landmarks pack, 1025 are refused with a clear error
+    big = gpu.Window(synth.window_at(synth.make_windows(5700, 1, n_landmarks=1024), 0))
+    b1 = gpu.Batch([big]); b1.solve(gpu.default_options(2, True)); b1.synchronize()
+    assert np.isfinite(b1.summaries()[0].final_cost)
+    with pytest.raises(gpu.TcvError):
+        gpu.Batch([gpu.Window(synth.window_at(synth.make_windows(5800, 1, n_landmarks=1025), 0))])
