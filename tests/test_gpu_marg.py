@@ -514,3 +514,65 @@ def test_marginalisation_problems_attached_while_the_solve_runs_give_the_same_pr
             assert np.array_equal(x0[k][key], x1[k][key]), (k, key)
         assert np.array_equal(p0[k]["J0"], p1[k]["J0"]) and np.array_equal(p0[k]["r0"], p1[k]["r0"])
         assert all(np.array_equal(a, c) for a, c in zip(p0[k]["x0"], p1[k]["x0"]))
+
+
+def test_margin_old_without_the_long_imu_factor(gpu):
+    """estimator.cpp:1933: the IMU factor (0, 1) joins the marginalisation only `if (pre_integrations[1]->sum_dt < 10.0)`.  A window whose first
+    interval is longer marginalises frame 0 from the prior and the point factors anchored there alone: same layout (m = 15 + landmarks of frame
+    0, kept blocks), same A', b' as the oracle at bit-identical states."""
+    pre, main, z = golden_windows()
+    im = dict(main["imu"]); sd = np.array(im["sum_dt"], dtype=float).copy(); sd[0] = 11.0; im["sum_dt"] = sd
+    w = dict(main, imu=im)
+    O = orc.Window(w); O.solve(8, True); st = O.states(); po, dbg = O.marginalize_old()
+    w2 = dict(w, pose=st["pose"], speedbias=st["sb"], ex_pose=st["ex"], lam=st["lam"])
+    mw = gpu.margin_old_window(w2)
+    assert len(mw["imu"]["frame_i"]) == 0
+    Wm = gpu.Window(mw)
+    dr = gpu.margin_old_drops(Wm, mw)
+    arr = (gpu._dp * len(dr))(*dr)
+    h = C.c_void_p()
+    gpu.check(gpu.lib().tcv_marginalize(Wm.h, arr, len(dr), C.byref(h)))
+    P = gpu.Prior(h); d = P.export(); As, bs = P.schur()
+    assert (d["m"], d["n"]) == (po["m"], po["n"]) and d["sizes"] == po["sizes"] and d["idx"] == po["idx"]
+    print("MARGIN_OLD without the IMU factor: A' %.2e b' %.2e J0'J0 %.2e" % (fro(As, dbg["A_schur"]), fro(bs, dbg["b_schur"]), fro(d["J0"].T @ d["J0"], dbg["A_schur"])))
+    assert fro(As, dbg["A_schur"]) < 2e-6 and fro(bs, dbg["b_schur"]) < 1e-8
+    assert fro(d["J0"].T @ d["J0"], dbg["A_schur"]) < 2e-6
+    # ... and in a batch behind its own solve (the solve drops the factor from the chain, the marginalisation from its factor set)
+    W, b = marg_batch(gpu, [w])
+    P2 = b.prior(0); d2 = P2.export(); As2, bs2 = P2.schur()
+    assert (d2["m"], d2["n"]) == (po["m"], po["n"])
+    assert fro(As2, dbg["A_schur"]) < 5e-6 and fro(bs2, dbg["b_schur"]) < 5e-7
+
+
+def test_margin_old_with_no_landmark_anchored_in_the_oldest_frame(gpu):
+    """m = 15: every feature of the window started after frame 0, so MARGIN_OLD drops para_Pose[0] and para_SpeedBias[0] alone
+    (the prior and the IMU factor are the only residual blocks MarginalizationInfo receives, estimator.cpp:1913-1947)"""
+    pre, main, z = golden_windows()
+    pr = {k: np.asarray(v) for k, v in main["proj"].items()}
+    keep = pr["frame_i"] != 0
+    # landmarks are renumbered in order of first appearance among the kept factors
+    order, remap = [], {}
+    for l in pr["landmark"][keep]:
+        if int(l) not in remap:
+            remap[int(l)] = len(order); order.append(int(l))
+    proj = {k: (v[keep] if isinstance(v, np.ndarray) and v.shape[:1] == keep.shape else v) for k, v in pr.items()}
+    proj["landmark"] = np.array([remap[int(l)] for l in proj["landmark"]], dtype=np.int64)
+    w = dict(main, proj=proj, lam=np.asarray(main["lam"])[order])
+    O = orc.Window(w); O.solve(8, True); st = O.states(); po, dbg = O.marginalize_old()
+    assert po["m"] == 15
+    w2 = dict(w, pose=st["pose"], speedbias=st["sb"], ex_pose=st["ex"], lam=st["lam"])
+    mw = gpu.margin_old_window(w2)
+    assert len(mw["proj"]["frame_i"]) == 0 and len(mw["imu"]["frame_i"]) == 1
+    Wm = gpu.Window(mw)
+    dr = gpu.margin_old_drops(Wm, mw)
+    arr = (gpu._dp * len(dr))(*dr)
+    h = C.c_void_p()
+    gpu.check(gpu.lib().tcv_marginalize(Wm.h, arr, len(dr), C.byref(h)))
+    P = gpu.Prior(h); d = P.export(); As, bs = P.schur()
+    assert (d["m"], d["n"]) == (15, po["n"]) and d["sizes"] == po["sizes"] and d["idx"] == po["idx"]
+    print("MARGIN_OLD, m = 15: A' %.2e b' %.2e" % (fro(As, dbg["A_schur"]), fro(bs, dbg["b_schur"])))
+    assert fro(As, dbg["A_schur"]) < 2e-6 and fro(bs, dbg["b_schur"]) < 1e-8
+    assert fro(d["J0"].T @ d["J0"], dbg["A_schur"]) < 2e-6
+    W, b = marg_batch(gpu, [w])
+    As2, bs2 = b.prior(0).schur()
+    assert b.prior(0).dims()[:2] == (15, po["n"]) and fro(As2, dbg["A_schur"]) < 5e-6 and fro(bs2, dbg["b_schur"]) < 5e-7

@@ -237,7 +237,7 @@ def test_max_solver_time_stops_the_iteration_loop(gpu):
 
 
 @pytest.mark.parametrize("window", ["prior", "no prior"])
-@pytest.mark.parametrize("gone", [(0,), (4,), (7,), (2, 6)])
+@pytest.mark.parametrize("gone", [(0,), (4,), (7,), (2, 6), (9,)])      # (9,): para_SpeedBias[10] is left without any factor
 def test_imu_factor_over_ten_seconds_is_left_out(gpu, gone, window):
     """estimator.cpp:1726: `if (pre_integrations[j]->sum_dt > 10.0) continue;` (a platform that stood still: MARGIN_SECOND_NEW keeps merging
     the IMU buffers of the newest interval) -- the window is then two or three IMU chains (the chain layout's steps cover them,
