@@ -1018,7 +1018,8 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
     // frame's window construction: 128 streams on two host threads 17.4 K against 15.7 K windows/s.  A frame of a few windows enqueues it here,
     // right behind the copy of its states -- deferred, its 0.45 ms would end up in front of the next frame's upload (8 streams: 3 050 against
     // 3 250 windows/s).  TCV_EST_MARG_DEFER=n: defer from n windows per call on (0: never, 1: always).
-    static const int defer_from = getenv("TCV_EST_MARG_DEFER") ? atoi(getenv("TCV_EST_MARG_DEFER")) : 12;
+    const char *e_defer = getenv("TCV_EST_MARG_DEFER");      // (read per call: the tests switch it)
+    const int defer_from = e_defer ? atoi(e_defer) : 12;
     static const bool marg_aux = getenv("TCV_EST_MARG_AUX") && atoi(getenv("TCV_EST_MARG_AUX")) != 0;
     if (marg_off_path) {
         // everything the frame still needs from the device goes on the stream NOW, while the solve runs: the copy of the states (and of the

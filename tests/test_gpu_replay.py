@@ -296,3 +296,68 @@ print("ok", k)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
 test_a_failed_marginalisation_is_reported_at_the_estimators_next_frame = pytest.mark.gpu(test_a_failed_marginalisation_is_reported_at_the_estimators_next_frame)
+
+
+def _drive_grouped(gpu, streams, n_frames, groups_of_frame, threads=False):
+    """lock-step frames through tcv_estimators_begin_frames / optimize / finish_frames with the estimators of a frame split into the groups
+    `groups_of_frame(k)` names (lists of stream indices): one tcv_estimators_optimize per group, one after the other or on threads of their own.
+    Returns per stream the positions after every optimised frame."""
+    import ctypes as C
+    import threading
+    ls = replay.NativeLockstep(streams, num_iterations=5)
+    L, vp = ls.L, ls.vp
+    out = [[] for _ in streams]
+    try:
+        for k in range(n_frames):
+            live, arr_all, rec, rdy, keep = ls._frame_batch(k)
+            gpu.check(L.tcv_estimators_begin_frames(arr_all, len(live), rec, rdy, None))
+            ready = [si for j, si in enumerate(live) if rdy[j]]
+            if not ready:
+                continue
+            groups = [[si for si in g if si in ready] for g in groups_of_frame(k)]
+            groups = [g for g in groups if g]
+            errs = []
+
+            def opt(g):
+                try:
+                    gpu.check(L.tcv_set_device(0))
+                    gpu.check(L.tcv_estimators_optimize((vp * len(g))(*[ls.ests[si] for si in g]), len(g)))
+                except Exception as e:      # noqa: BLE001
+                    errs.append(repr(e))
+            if threads:
+                th = [threading.Thread(target=opt, args=(g,)) for g in groups]
+                [t.start() for t in th]; [t.join() for t in th]
+            else:
+                for g in groups:
+                    opt(g)
+            assert not errs, errs
+            nr = len(ready)
+            pa, qa, va = np.zeros((nr, 3)), np.zeros((nr, 4)), np.zeros((nr, 3))
+            rcs = (C.c_int * nr)()
+            gpu.check(L.tcv_estimators_finish_frames((vp * nr)(*[ls.ests[si] for si in ready]), nr, ls._P(pa), ls._P(qa), ls._P(va), rcs, None))
+            for j, si in enumerate(ready):
+                out[si].append(pa[j].copy())
+    finally:
+        ls.close()
+    return [np.array(o) for o in out]
+
+
+def test_deferred_marginalisation_is_launched_by_whichever_group_comes_back_first(gpu, monkeypatch):
+    """Frames of many windows launch their marginalisation with the estimators' NEXT tcv_estimators_optimize (include/tcv_estimator.h,
+    TCV_EST_MARG_DEFER).  The estimators of one frame's batch need not come back together: regrouped between frames -- and the groups on host
+    threads of their own, so that two threads ask the same retired batch for its launch at once -- every estimator still gets the prior its own
+    window's marginalisation made: the trajectories are those of the eager launch, bit for bit."""
+    streams = [replay.simulate_stream(80 + s, 26, max_features=30) for s in range(4)]
+    pairs = lambda k: [[0, 1], [2, 3]] if k % 2 == 0 else [[0, 2], [1, 3]]
+    monkeypatch.setenv("TCV_EST_MARG_DEFER", "0")
+    eager = _drive_grouped(gpu, streams, 26, lambda k: [[0, 1, 2, 3]])
+    eager_pairs = _drive_grouped(gpu, streams, 26, pairs)
+    monkeypatch.setenv("TCV_EST_MARG_DEFER", "1")
+    one = _drive_grouped(gpu, streams, 26, lambda k: [[0, 1, 2, 3]])
+    regrouped = _drive_grouped(gpu, streams, 26, pairs)
+    threaded = _drive_grouped(gpu, streams, 26, pairs, threads=True)
+    assert all(len(a) == 26 - replay.WINDOW_SIZE for a in eager)
+    for a, b in zip(eager, one):
+        assert np.array_equal(a, b)                      # the same batches: only the launch time of the marginalisation differs
+    for a, b, c in zip(eager_pairs, regrouped, threaded):
+        assert np.array_equal(a, b) and np.array_equal(a, c)
