@@ -74,13 +74,16 @@ def deltaQ_R(theta):
 # simulated front-end streams
 # ----------------------------------------------------------------------------------------------------------------
 def simulate_stream(seed: int, n_frames: int, max_features: int = 36, max_lines: int = 4, pixel_sigma: float = 1.0,
-                    t0: float = 0.0, imu_noise: bool = True, pace: float = 0.85, associate: bool = False):
+                    t0: float = 0.0, imu_noise: bool = True, pace: float = 0.85, associate: bool = False, hold=None):
     """Per-frame streams of a front end following the analytic trajectory of synth.py at 10 Hz / 200 Hz IMU.
     Returns dict(t, gt_p, gt_R, gt_v, imu=[(acc (S+1,3), gyr (S+1,3))] per frame (sample 0 = the previous frame's last
     sample), points=[{id: (x, y, 1)}], lines=[[(pts_start, pts_end, abc)]], ba, bg).
     associate=True: the lines come as the line tracker delivers them -- [(track id, pixel end points xs ys xe ye)] without their
     3D partner -- together with the prior map (`map_lines` n x 6 in the map frame, `Rbw`, `Tbw`); the replay then runs the
-    reference's 2D-3D association (UpdateLinesInFoV / LineCorrespondenceInFrame / removeLineOutlier) every frame."""
+    reference's 2D-3D association (UpdateLinesInFoV / LineCorrespondenceInFrame / removeLineOutlier) every frame.
+    hold=(t_stop, seconds): the platform comes to rest at t_stop (over 0.5 s), stands still for `seconds` and moves on -- every frame of the
+    rest is a non-keyframe (MARGIN_SECOND_NEW), the newest interval's IMU buffers are merged frame after frame, and beyond 10 s the window's
+    last IMU factor is left out (estimator.cpp:1726) and so is MARGIN_OLD's (:1933) when the rest ends."""
     rng = np.random.Generator(np.random.PCG64(0xFEED + seed))
     S = synth.IMU_RATE_SUB
     t = t0 + synth.DT_KF * np.arange(n_frames)
@@ -89,9 +92,31 @@ def simulate_stream(seed: int, n_frames: int, max_features: int = 36, max_lines:
     # smooth time warp tau(t): the platform alternates between fast and almost-hovering phases, so that both keyframe
     # decisions of addFeaturesCheckParallax (MARGIN_OLD / MARGIN_SECOND_NEW) occur
     wa, ww = pace, 2.0 * np.pi / 3.0
-    tau = lambda x: x + wa / ww * np.sin(ww * x)
-    dtau = lambda x: 1.0 + wa * np.cos(ww * x)
-    ddtau = lambda x: -wa * ww * np.sin(ww * x)
+    tau0 = lambda x: x + wa / ww * np.sin(ww * x)
+    dtau0 = lambda x: 1.0 + wa * np.cos(ww * x)
+    ddtau0 = lambda x: -wa * ww * np.sin(ww * x)
+    if hold is None:
+        tau, dtau, ddtau = tau0, dtau0, ddtau0
+    else:
+        # clock of the platform c(x): runs with the wall clock, slows to a stop over `w` seconds at t_stop (C2 smoothstep), rests, speeds up again
+        ts0, rest = float(hold[0]), float(hold[1])
+        w = 0.5
+        sm = lambda u: ((6.0 * u - 15.0) * u + 10.0) * u ** 3                       # smoothstep and its integral / derivative
+        ism = lambda u: ((u - 3.0) * u + 2.5) * u ** 4
+        dsm = lambda u: ((30.0 * u - 60.0) * u + 30.0) * u ** 2
+
+        def bump(x):      # 1 while at rest, 0 while moving; (integral from -inf, value, derivative)
+            x = np.asarray(x, dtype=float)
+            a, b = ts0, ts0 + w + rest
+            u1 = np.clip((x - a) / w, 0.0, 1.0); u2 = np.clip((x - b) / w, 0.0, 1.0)
+            val = sm(u1) - sm(u2)
+            integ = w * ism(u1) + np.clip(x - (a + w), 0.0, None) - (w * ism(u2) + np.clip(x - (b + w), 0.0, None))
+            der = (dsm(u1) * ((x > a) & (x < a + w)) - dsm(u2) * ((x > b) & (x < b + w))) / w
+            return integ, val, der
+        cl = lambda x: np.asarray(x, dtype=float) - bump(x)[0]
+        tau = lambda x: tau0(cl(x))
+        dtau = lambda x: dtau0(cl(x)) * (1.0 - bump(x)[1])
+        ddtau = lambda x: ddtau0(cl(x)) * (1.0 - bump(x)[1]) ** 2 - dtau0(cl(x)) * bump(x)[2]
     Rw = synth.traj_R(tau(ts))
     a_w = synth.traj_a(tau(ts)) * dtau(ts)[:, None] ** 2 + synth.traj_v(tau(ts)) * ddtau(ts)[:, None]
     acc = (np.swapaxes(Rw, -1, -2) @ (a_w + G)[..., None])[..., 0] + ba

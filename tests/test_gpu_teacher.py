@@ -303,3 +303,68 @@ def test_native_estimator_windows_resolved_by_the_oracle(gpu, seq, mode):
     assert n_win >= 100 and n_prior >= 95
     assert not bad_it, bad_it
     assert all(v < 1e-6 for v in worst.values()), worst
+
+
+def test_teacher_forced_replay_through_a_standstill(gpu):
+    """A platform at rest for 11.5 s (tests/replay_cache.py STANDSTILL): 115 MARGIN_SECOND_NEW frames in a row, then windows whose newest IMU
+    factor is left out (sum_dt > 10, estimator.cpp:1726), then ten keyframes with the gap in the MIDDLE of the window -- two IMU chains next to a
+    prior, the case that caught the chain elimination in round 5 -- and a MARGIN_OLD without its IMU factor (:1933).  Every window the oracle
+    replay solved goes through the HIP path from identical inputs: identical traces and prior layouts, states within 1e-6."""
+    from replay_cache import STANDSTILL, teacher_replay
+    T = teacher_replay(STANDSTILL, "given")
+    rec = T["rec"]
+    n_imu = [len(r["win"]["imu"]["sum_dt"]) for r in rec]
+    flags = [r["flag"] for r in rec]
+    gap_inside = [k for k, r in enumerate(rec) if len(r["win"]["imu"]["sum_dt"]) == 9 and list(np.asarray(r["win"]["imu"]["frame_i"])) != list(range(9))]
+    print("standstill: %d windows, %d without one IMU factor (%d of them with the gap inside the window), %d MARGIN_SECOND_NEW"
+          % (len(rec), sum(v == 9 for v in n_imu), len(gap_inside), flags.count(replay.MARGIN_SECOND_NEW)))
+    assert len(rec) >= 170 and sum(v == 9 for v in n_imu) >= 15 and len(gap_inside) >= 8 and flags.count(replay.MARGIN_SECOND_NEW) >= 100
+    hip = hip_windows(gpu, rec, 8, False)
+    worst, bad_trace, bad_layout, rows, n_marg = compare(rec, hip)
+    print("standstill: traces differ on %s, layouts on %s; worst %s; thresholded rows differ on %d windows" % (bad_trace, bad_layout, {k: float("%.3g" % v) for k, v in worst.items()}, len(rows)))
+    T["rec"] = None
+    assert not bad_trace and not bad_layout, (bad_trace, bad_layout)
+    assert worst["cost"] < 1e-6 and worst["pose"] < 1e-6 and worst["sb"] < 1e-6 and worst["lam"] < 1e-6, worst
+    assert worst["A"] < 2e-6 and worst["b"] < 2e-6 and worst["JtJ"] < 2e-6, worst
+    assert worst["flip"] < 1e-8, rows
+
+
+def test_native_estimator_through_a_standstill(gpu):
+    """the same stream through the native window management (include/tcv_estimator.h): every window it builds while the platform rests and
+    after it moves on -- IMU buffers merged frame after frame, the long pre-integration left out, the gap travelling through the window -- is
+    re-solved by the oracle from the tapped inputs"""
+    import np_oracle as NO
+    import orc
+    from replay_cache import STANDSTILL, stream_of
+    tcv = gpu
+    st = stream_of(STANDSTILL, "given")
+    ls = replay.NativeLockstep([st], num_iterations=8)
+    L = tcv.lib()
+    L.tcv_estimator_set_window_tap.argtypes = [C.c_void_p, C.c_int]
+    L.tcv_estimator_get_window_snapshot.argtypes = [C.c_void_p, C.POINTER(_Snapshot)]
+    tcv.check(L.tcv_estimator_set_window_tap(ls.ests[0], 1))
+    worst = dict(cost=0.0, pose=0.0, sb=0.0, lam=0.0, ex=0.0)
+    n_win, n_gap, bad_it = 0, 0, []
+    try:
+        for k in range(ls.n_frames):
+            if not ls.step(k):
+                continue
+            S = _Snapshot()
+            tcv.check(L.tcv_estimator_get_window_snapshot(ls.ests[0], C.byref(S)))
+            win, res = _snapshot_window(tcv, S)
+            assert res["applied"] == 1
+            O = orc.Window(win); so = O.solve(8, False); sto = O.states()
+            Rs, Ps, Vs, po = orc.gauge_fix(NO.q2R(win["pose"][0, 3:]), win["pose"][0, :3], sto["pose"], sto["sb"])
+            sbo = sto["sb"].copy(); sbo[:, :3] = Vs
+            n_win += 1; n_gap += int(len(win["imu"]["sum_dt"]) < replay.WINDOW_SIZE)      # (the window holds the factors that passed the 10 s rule)
+            if so.num_iterations != res["iterations"]:
+                bad_it.append((k, res["iterations"], so.num_iterations))
+                continue
+            worst["cost"] = max(worst["cost"], abs(res["cost"] - so.final_cost) / abs(so.final_cost))
+            worst["pose"] = max(worst["pose"], rel(res["pose"], po)); worst["sb"] = max(worst["sb"], rel(res["sb"], sbo))
+            worst["lam"] = max(worst["lam"], rel(res["lam"], sto["lam"])); worst["ex"] = max(worst["ex"], rel(res["ex"], sto["ex"]))
+    finally:
+        ls.close()
+    print("standstill, native: %d windows (%d without the IMU factor of an interval over 10 s), iteration counts differ on %s; worst %s" % (n_win, n_gap, bad_it, {k: float("%.3g" % v) for k, v in worst.items()}))
+    assert n_win >= 170 and n_gap >= 15 and not bad_it, (n_win, n_gap, bad_it)
+    assert all(v < 1e-6 for v in worst.values()), worst
