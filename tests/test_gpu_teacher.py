@@ -259,8 +259,9 @@ def _snapshot_window(tcv, S):
     return win, res
 
 
-@pytest.mark.parametrize("seq,mode", [("V1_02_medium", "associate"), ("V2_01_easy", "given"), ("V2_03_difficult", "none")])
-def test_native_estimator_windows_resolved_by_the_oracle(gpu, seq, mode):
+@pytest.mark.parametrize("seq,mode,extrinsic", [("V1_02_medium", "associate", True), ("V2_01_easy", "given", True), ("V2_03_difficult", "none", True),
+                                                 ("V1_03_difficult", "given", False)])      # False: ESTIMATE_EXTRINSIC = 0 (config/*/…_config.yaml of several rigs): para_Ex_Pose constant in the solve, kept in the prior
+def test_native_estimator_windows_resolved_by_the_oracle(gpu, seq, mode, extrinsic):
     """120 frames of a native lock-step replay; every window it optimises -- from its own states, its own device-resident pre-integrations and the
     device-made prior of its previous frame -- is solved again by the C oracle: iterations, final cost and the gauge-fixed states within the
     north_star's 1e-6, window by window"""
@@ -268,7 +269,7 @@ def test_native_estimator_windows_resolved_by_the_oracle(gpu, seq, mode):
     import orc
     tcv = gpu
     st = replay.simulate_stream_euroc(seq, 120, start_s=0.5, max_features=60, **MODES[mode])
-    ls = replay.NativeLockstep([st], num_iterations=8)
+    ls = replay.NativeLockstep([st], num_iterations=8, estimate_extrinsic=extrinsic)
     L = tcv.lib()
     L.tcv_estimator_set_window_tap.argtypes = [C.c_void_p, C.c_int]
     L.tcv_estimator_get_window_snapshot.argtypes = [C.c_void_p, C.POINTER(_Snapshot)]
@@ -282,8 +283,8 @@ def test_native_estimator_windows_resolved_by_the_oracle(gpu, seq, mode):
             S = _Snapshot()
             tcv.check(L.tcv_estimator_get_window_snapshot(ls.ests[0], C.byref(S)))
             win, res = _snapshot_window(tcv, S)
-            assert res["applied"] == 1
-            O = orc.Window(win)
+            assert res["applied"] == 1 and bool(S.estimate_extrinsic) == extrinsic
+            O = orc.Window(win, ex_constant=not extrinsic)
             so = O.solve(8, False)
             sto = O.states()
             R0 = NO.q2R(win["pose"][0, 3:]); P0 = win["pose"][0, :3]
