@@ -789,6 +789,12 @@ def run_replay(args, rank, world, local, dist):
     if prof:
         out["native_profile_ms_per_call"] = prof
     if not DRY:
+        # every replay window has a structure of its own: the whole-plan cache misses, the camera half of the plan (IMU tables, chain records,
+        # prior tables -- tcv_pack.cpp) is found; the visual half is built per window and frame
+        pc = (C.c_longlong * 4)()
+        if tcv.lib().tcv_plan_cache_stats(pc) == 0:
+            out["plan_cache"] = {"whole_plan_hits": int(pc[0]), "whole_plan_misses": int(pc[1]), "camera_half_hits": int(pc[2]), "camera_half_misses": int(pc[3]),
+                                 "camera_half_hit_rate": pc[2] / max(1, pc[2] + pc[3]), "note": "since the process started (window fill and warm-up included)"}
         # the kernels this path runs, live: HIP-event durations of every solve / marginalisation launch of the timed frames (rank 0) and the
         # ALGORITHMIC bytes of the windows they held (SURVEY.md 8(d) formula on every window's own factor counts x its linearisations)
         k8 = (C.c_double * 8)()
