@@ -782,6 +782,16 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
         if (want < 0) want = fmax >= 96 ? std::min<int>(COOP_MAX_H, std::max<int>(2, (int)((fmax + 95) / 96))) : 0;
         want = std::min(want, (int)COOP_MAX_H);
         while (want > 0 && (long long)((n + 7) / 8) * (1 + want) > n_cu / 8) want--;      // the groups of a launch are dealt round-robin to the XCDs: per XCD ceil(n / 8) groups on n_cu / 8 CUs
+        // A large batch seldom has the device to itself -- a lock-step replay drives it from two host threads, and a launch that fills the chip with
+        // helpers makes the other thread's launch queue behind it (64 streams: 10.8 K windows/s with seven helpers per window against 12.1 K with
+        // two; 128 streams: 15.5 K with three against 17.7 K with two; profiles/r05_replay_coop_helpers.txt).  From 24 windows on a launch takes
+        // half the chip -- three quarters if that is what two helpers per window need; TCV_COOP_H / tcv_set_cooperative still decide otherwise.
+        if (n >= 24 && g_coop_helpers < 0 && !getenv("TCV_COOP_H")) {
+            int w2 = want;
+            while (w2 > 0 && (long long)n * (1 + w2) > n_cu / 2) w2--;
+            if (w2 < 2 && want >= 2 && (long long)n * 3 <= (long long)n_cu * 3 / 4) w2 = 2;
+            want = std::min(want, w2);
+        }
         if (want == 1 && g_coop_helpers < 0 && !getenv("TCV_COOP_H")) want = 0;      // a single helper is not worth the hand-offs
         coop_h = want;
     }
