@@ -681,7 +681,17 @@ class ReplayEngine:
         streams = [replay.simulate_stream_euroc(seqs[s % len(seqs)], n_frames, start_s=(0.5 + 3.0 * (s // len(seqs))) % max(3.0, 33.0 - 0.1 * n_frames), max_features=features,
                                                 max_lines=lines, associate=True) for s in stream_ids]
         G = max(1, min(groups, len(streams)))
-        self.ls = [replay.NativeLockstep(streams[g::G], num_iterations=SOLVER_ITERATIONS) for g in range(G)] if streams else []
+        # TCV_BENCH_PIPELINE=1 (experiment, NOT the default): every host thread drives TWO lock-step objects, each with half of the thread's
+        # streams and its own library stream (slot 0 / 1), and alternates between them -- the host side of one half's frame against the kernels
+        # of the other half's (tcv_estimators_optimize_begin / _end).  Measured slower than one object per thread at every stream count
+        # (profiles/r05_replay_pipeline.txt): a group's own cycle -- its host side, then its solve -- is not shortened by halving the group, the
+        # per-call fixed costs double, and four cooperative launches in flight crowd the chip
+        self.pipelined = bool(os.environ.get("TCV_BENCH_PIPELINE")) and len(streams) >= 2 * G
+        self.G = G
+        H = 2 * G if self.pipelined else G
+        self.ls = [replay.NativeLockstep(streams[h::H], num_iterations=SOLVER_ITERATIONS) for h in range(H)] if streams else []
+        for h, ls in enumerate(self.ls):
+            ls.slot = (h // G) if self.pipelined else 0
         for ls in self.ls:
             ls.prepare()
         self.k = 0
@@ -700,15 +710,28 @@ class ReplayEngine:
         """`steps` frames of every stream; returns the number of windows optimised"""
         import threading
         k0, counts = self.k, [0] * len(self.ls)
+        G = self.G
 
         def work(g):
             self.tcv.check(self.tcv.lib().tcv_set_device(self.local))      # the current device is per host thread
+            if not self.pipelined:
+                for k in range(k0, k0 + steps):
+                    counts[g] += self.ls[g].step(k)
+                return
+            A, B = self.ls[g], self.ls[g + G]      # (slots 0 and 1 of this thread)
+            if steps <= 0:
+                return
+            A.step_begin(k0)
             for k in range(k0, k0 + steps):
-                counts[g] += self.ls[g].step(k)
+                B.step_begin(k)
+                counts[g] += A.step_end()
+                if k + 1 < k0 + steps:
+                    A.step_begin(k + 1)
+                counts[g + G] += B.step_end()
 
         # group 0 on the calling thread (its stream exists already), the others on threads of their own: one stream fewer on the runtime's
         # four hardware queues -- two host threads that share a queue wait for each other's solve kernels
-        th = [threading.Thread(target=work, args=(g,)) for g in range(1, len(self.ls))]
+        th = [threading.Thread(target=work, args=(g,)) for g in range(1, G)]
         for t in th:
             t.start()
         work(0)
@@ -749,8 +772,15 @@ def run_replay(args, rank, world, local, dist):
             ls.host_s = [0.0, 0.0, 0.0, 0]
     if dist is not None:
         dist.barrier()
+    dbg0 = None
+    if not DRY and os.environ.get("TCV_BENCH_DEBUG_POOLS"):
+        Lb = tcv.lib(); Lb.tcv_debug_host_pool_allocs.restype = C.c_longlong; Lb.tcv_debug_dev_pool_misses.restype = C.c_longlong
+        dbg0 = (Lb.tcv_debug_host_pool_allocs(), Lb.tcv_debug_dev_pool_misses())
     t0 = time.perf_counter()
     n = run(args.steps)
+    if dbg0 is not None:
+        a, b = Lb.tcv_debug_host_pool_allocs(), Lb.tcv_debug_dev_pool_misses()
+        print("[bench] timed region: hipHostMalloc %d, hipHostFree %d, hipMalloc %d" % (a // 1000000 - dbg0[0] // 1000000, a % 1000000 - dbg0[0] % 1000000, b - dbg0[1]), file=sys.stderr)
     if not DRY:
         import torch
         torch.cuda.synchronize()

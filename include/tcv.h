@@ -255,6 +255,10 @@ void tcv_batch_destroy(tcv_batch *b);
  * issues its uploads, splices and downloads anyway: host threads that each drive their own batches then use one stream each -- the
  * runtime maps streams onto a handful of hardware queues, fewer streams collide less); inputs and outputs stay in HBM. */
 #define TCV_STREAM_THREAD ((void *)(~(size_t)0))
+/* Which of the calling thread's two library streams "its own stream" means from now on (0, the default, or 1; created at first use): a host
+ * thread that drives two independent groups of work -- one's host side against the other's kernels -- gives each group a stream of its own
+ * by selecting the slot before every call it makes for that group.  Returns the previous slot. */
+int tcv_thread_stream_slot(int slot);
 int tcv_batch_solve(tcv_batch *b, const tcv_solver_options *o, void *hip_stream);
 int tcv_batch_marginalize(tcv_batch *b, void *hip_stream);
 /* Estimator::double2vector() gauge fix (estimator.cpp:1537-1581) followed by vector2double() (:1492-1512), in place

@@ -88,6 +88,15 @@ int tcv_estimators_begin_frames(tcv_estimator *const *e, int n, const tcv_frame_
  * Thread safety: estimators are independent objects; different host threads may drive different estimator lists, on the same or on
  * different devices (every call issues its copies and kernels on the calling thread's own stream: the threads overlap on the device). */
 int tcv_estimators_optimize(tcv_estimator *const *e, int n);
+/* The same frame in two calls, for a host thread that overlaps the host side of one group of estimators with the device side of another:
+ * _begin returns when the frame's last command is on the device (association, windows, upload, solve, gauge fix, the copy of the states and --
+ * frames of few windows -- the marginalisation), _end waits for the states, applies them and consumes the ticket (also on failure).
+ * tcv_estimators_optimize = _begin + _end.  Between the two calls the estimators of the ticket must not be touched.  A thread that keeps two
+ * tickets in flight puts them on different library streams (tcv_thread_stream_slot(0 / 1) around each group's calls, include/tcv.h):
+ * on one stream the second group's association round trip would queue behind the first group's solve. */
+typedef struct tcv_opt_ticket tcv_opt_ticket;
+int tcv_estimators_optimize_begin(tcv_estimator *const *e, int n, tcv_opt_ticket **ticket);
+int tcv_estimators_optimize_end(tcv_opt_ticket *ticket);
 /* failureDetection, the published state (Ps / Rs / Vs[WINDOW_SIZE], quaternion x y z w) and slideWindow.
  * TCV_ERR_NUMERIC: failure detection fired (the reference would reset the estimator). */
 int tcv_estimator_finish_frame(tcv_estimator *e, double P[3], double q_xyzw[4], double V[3]);

@@ -93,6 +93,8 @@ size_t bucket_of(size_t n) {
 }
 constexpr size_t POOL_MAX_CACHED = size_t(3) << 30;
 }  // namespace
+static std::atomic<long long> g_dev_misses{0};
+long long dev_pool_misses() { return g_dev_misses.load(); }
 hipError_t dev_malloc(void **p, size_t bytes) {
     static const bool off = getenv("TCV_NO_DEV_POOL") != nullptr;
     if (off) return ::hipMalloc(p, bytes);
@@ -105,6 +107,7 @@ hipError_t dev_malloc(void **p, size_t bytes) {
         auto it = P.free_list.find({dev, b});
         if (it != P.free_list.end()) { *p = it->second; P.free_list.erase(it); P.cached -= b; P.live[*p] = {dev, b}; return hipSuccess; }
     }
+    g_dev_misses++;
     hipError_t e = ::hipMalloc(p, b);
     if (e != hipSuccess) {      // out of memory: give the cached buffers back and retry once
         std::vector<void *> drop;
@@ -224,7 +227,10 @@ hipStream_t aux_stream() {
     mine.aux.emplace(dev, st);
     return st;
 }
+namespace { thread_local int g_stream_slot = 0; }
+hipStream_t aux_stream();
 hipStream_t util_stream() {
+    if (g_stream_slot == 1) { const int keep = g_stream_slot; g_stream_slot = 0; hipStream_t a = aux_stream(); g_stream_slot = keep; return a; }      // (aux_stream asks for the main one once, to learn whether this is the main thread)
     ThreadStreams &mine = thread_streams();
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -275,6 +281,11 @@ extern "C" int tcv_set_cooperative(int helpers) {
 extern "C" int tcv_device_memory_stats(unsigned long long *live_bytes, unsigned long long *cached_bytes, int *live_buffers) {
     tcv::dev_pool_stats(live_bytes, cached_bytes, live_buffers);
     return TCV_OK;
+}
+extern "C" int tcv_thread_stream_slot(int slot) {
+    const int prev = g_stream_slot;
+    g_stream_slot = slot == 1 ? 1 : 0;
+    return prev;
 }
 extern "C" int tcv_set_device(int device) {
     if (int rc = device_ready()) return rc;
@@ -703,8 +714,11 @@ namespace {
 struct HostBuf { void *p; size_t cap; bool busy; };
 std::mutex g_host_mu;
 std::vector<HostBuf> g_host_bufs;
-enum { HOST_POOL_MAX = 6 };
+enum { HOST_POOL_MAX = 24 };      // idle pinned buffers kept (a host thread that keeps two lock-step groups in flight holds four to six at a time; releasing one to the runtime costs a device-wide wait)
 }  // namespace
+static std::atomic<long long> g_host_allocs{0}, g_host_frees{0};
+extern "C" long long tcv_debug_host_pool_allocs(void) { return g_host_allocs.load() * 1000000 + g_host_frees.load(); }
+extern "C" long long tcv_debug_dev_pool_misses(void) { return tcv::dev_pool_misses(); }
 void *host_staging_acquire(size_t bytes) {
     size_t cap = (size_t)1 << 20;
     while (cap < bytes) cap <<= 1;
@@ -715,6 +729,7 @@ void *host_staging_acquire(size_t bytes) {
         if (best) { best->busy = true; return best->p; }
     }
     void *p = nullptr;
+    g_host_allocs++;
     if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> g(g_host_mu);
     g_host_bufs.push_back(HostBuf{p, cap, true});
@@ -734,7 +749,7 @@ void host_staging_release(void *p) {
                 break;
             }
     }
-    if (to_free) (void)hipHostFree(to_free);
+    if (to_free) { g_host_frees++; (void)hipHostFree(to_free); }
 }
 }  // namespace tcv
 

@@ -803,9 +803,42 @@ extern "C" int tcv_estimators_profile(double *out8) {
     return TCV_OK;
 }
 
-extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
-    if (!es || n <= 0) return TCV_ERR_INVALID;
-    double t_mark = now_s();
+struct OptGroup {
+    std::vector<int> idx;
+    std::vector<char> dm;             // per window of the group: it marginalises
+    bool any_marg = false;
+    std::vector<tcv_problem *> P, M;
+    std::vector<double *const *> drops;
+    std::vector<int> ndrop;
+    std::vector<tcv_solver_summary> sum;
+    std::vector<tcv_prior *> newp;
+    std::vector<int> est_rc;          // per estimator: TCV_ERR_NUMERIC when its own marginalisation failed
+    std::string est_msg;
+    tcv_batch *b = nullptr;
+    int rc = TCV_OK;
+    bool deferred = false;            // the marginalisation of this frame is launched by its estimators' next frame (EstInflight)
+    bool dl_begun = false, marg_launched = false;      // the copy of the states / the marginalisation were enqueued behind the solve (marg_off_path)
+};
+
+struct OptRun {
+    std::vector<tcv_estimator *> esv;
+    int n = 0;
+    OptGroup G[2];
+    hipStream_t g_streams[2] = {nullptr, nullptr};
+    bool host_priors = false, marg_off_path = false, marg_aux = false;
+    int defer_from = 12, rc_all = TCV_OK;
+    double t_mark = 0.0, t_begin0 = 0.0, t_end0 = 0.0;
+    ~OptRun() { for (auto &g : G) { if (g.b) tcv_batch_destroy(g.b); for (auto *p : g.P) if (p) tcv_problem_destroy(p); for (auto *p : g.M) if (p) tcv_problem_destroy(p); for (auto *p : g.newp) if (p) tcv_prior_destroy(p); } }
+};
+// ---- a lock-step frame in two halves (tcv_estimators_optimize_begin / _end): everything up to the last command on the device, and the wait for the
+// states with what follows.  OptRun carries what the second half needs.
+static int optimize_begin(OptRun &R) {
+    tcv_estimator *const *es = R.esv.data();
+    const int n = R.n;
+    typedef OptGroup Group;
+    double &t_mark = R.t_mark;
+    t_mark = now_s();
+    R.t_begin0 = t_mark;
     auto lap = [&](int slot) { const double t = now_s(); prof_add(slot, t - t_mark); t_mark = t; };
     prof_add(7, 1);
     for (int i = 0; i < n; i++) if (!es[i] || es[i]->phase != 1) { tcv::set_error("estimators_optimize: an estimator has no full window waiting (begin_frame must report ready)"); return TCV_ERR_INVALID; }
@@ -915,29 +948,14 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
     }
     // The two batches of a frame are independent: both are created first, then their kernels are launched on two HIP streams and run
     // side by side (a lock-step frame is latency bound: a handful of windows on a handful of CUs), then both are collected.
-    struct Group {
-        std::vector<int> idx;
-        std::vector<char> dm;             // per window of the group: it marginalises
-        bool any_marg = false;
-        std::vector<tcv_problem *> P, M;
-        std::vector<double *const *> drops;
-        std::vector<int> ndrop;
-        std::vector<tcv_solver_summary> sum;
-        std::vector<tcv_prior *> newp;
-        std::vector<int> est_rc;          // per estimator: TCV_ERR_NUMERIC when its own marginalisation failed
-        std::string est_msg;
-        tcv_batch *b = nullptr;
-        int rc = TCV_OK;
-        bool deferred = false;            // the marginalisation of this frame is launched by its estimators' next frame (EstInflight)
-        bool dl_begun = false, marg_launched = false;      // the copy of the states / the marginalisation were enqueued behind the solve (marg_off_path)
-    };
-    Group G[2];
+    OptGroup (&G)[2] = R.G;
     // Every kernel of the frame goes on the CALLING THREAD's utility stream -- the stream tcv_batch_create's uploads, the device-to-device
     // splices and the downloads of this thread use anyway: host threads that drive their own estimators overlap on the device (a stream pair
     // shared by the threads of a device, as until round 4, serialises their kernels: 8 streams on 4 host threads 1 000 against 2 400 windows/s),
     // and with one stream per thread no small copy of one thread waits behind another thread's 2 ms solve kernel on a shared hardware queue.
     // (TCV_EST_TWO_BATCHES: the two batches of a frame then run one after the other.)
-    hipStream_t g_streams[2] = {tcv::util_stream(), tcv::util_stream()};
+    hipStream_t (&g_streams)[2] = R.g_streams;
+    g_streams[0] = g_streams[1] = tcv::util_stream();
     // last_marginalization_info stays on the device (estimator.h:176-177: the reference keeps it alive between frames, too): the new
     // priors are handles on the batch's result buffer, the next frame's tcv_batch_create splices them device-to-device.
     // TCV_EST_HOST_PRIORS=1: round 3's host round trip (62 KB down, 46 KB up per window), the A/B partner -- same bits.
@@ -951,7 +969,8 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
     // frame's solve: a window solved on a prior whose marginalisation failed is not applied and reports the failure (finish_frame), one
     // frame late.  TCV_EST_MARG_WAIT=1: wait for it as before (same bits).
     const bool marg_off_path = !host_priors && !two_batches && getenv("TCV_EST_MARG_WAIT") == nullptr;
-    int rc_all = TCV_OK;
+    int &rc_all = R.rc_all;
+    rc_all = TCV_OK;
     for (int group = 1; group >= 0; group--) {
         Group &g = G[group];
         for (int i = 0; i < n; i++) if ((two_batches ? (int)do_marg[i] : 1) == group) { g.idx.push_back(i); g.dm.push_back(do_marg[i]); g.any_marg = g.any_marg || do_marg[i]; }
@@ -1041,6 +1060,22 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
             }
         }
     }
+    R.host_priors = host_priors; R.marg_off_path = marg_off_path; R.defer_from = defer_from; R.marg_aux = marg_aux;
+    if (getenv("TCV_DEBUG_PIPE")) fprintf(stderr, "[pipe] %p begin  n %d  %.3f -> %.3f ms\n", (void *)tcv::util_stream(), n, 1e3 * (R.t_begin0 - 1.7e9 * 0), 1e3 * now_s());
+    return TCV_OK;
+}
+
+static int optimize_end(OptRun &R) {
+    R.t_end0 = now_s();
+    tcv_estimator *const *es = R.esv.data();
+    typedef OptGroup Group;
+    double &t_mark = R.t_mark;
+    auto lap = [&](int slot) { const double t = now_s(); prof_add(slot, t - t_mark); t_mark = t; };
+    OptGroup (&G)[2] = R.G;
+    hipStream_t (&g_streams)[2] = R.g_streams;
+    int &rc_all = R.rc_all;
+    const bool host_priors = R.host_priors, marg_off_path = R.marg_off_path, marg_aux = R.marg_aux;
+    const int defer_from = R.defer_from;
     for (int group = 1; group >= 0; group--) {
         Group &g = G[group];
         if (g.idx.empty()) continue;
@@ -1055,6 +1090,7 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
         } else if (g.rc == TCV_OK) g.rc = tcv_batch_synchronize(g.b);
         double ms = 0;
         if (g.rc == TCV_OK && tcv_batch_stats(g.b, nullptr, &ms, nullptr) == TCV_OK && ms > 0) { kern_add(0, ms); kern_add(1, 1); }
+        if (getenv("TCV_DEBUG_PIPE")) fprintf(stderr, "[pipe] %p end    n %d  entered %.3f  states at %.3f ms (solve kernel %.3f ms)\n", (void *)tcv::util_stream(), nb, 1e3 * R.t_end0, 1e3 * now_s(), ms);
     }
     lap(4);
     for (int group = 1; group >= 0; group--) {
@@ -1146,7 +1182,7 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
                 }
             g.deferred = defer_marg;
         }
-        if (g.b) tcv_batch_destroy(g.b);
+        if (g.b) { tcv_batch_destroy(g.b); g.b = nullptr; }      // (the ticket destroys what is left in it)
         const double td4 = now_s();
         {      // the frame's problems have been read for the last time: destroyed on a worker thread, behind the caller's back
             auto dead = std::make_shared<std::vector<tcv_problem *>>();
@@ -1163,7 +1199,7 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
         Group &g = G[group];
         if (g.idx.empty()) continue;
         const int nb = (int)g.idx.size();
-        if (rc_all != TCV_OK) { for (auto *p : g.newp) if (p) tcv_prior_destroy(p); continue; }
+        if (rc_all != TCV_OK) { for (auto *&p : g.newp) if (p) { tcv_prior_destroy(p); p = nullptr; } continue; }
         for (int k = 0; k < nb; k++) {
             tcv_estimator *e = es[g.idx[k]];
             e->opt_failed = TCV_OK;
@@ -1195,6 +1231,34 @@ extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
         lap(6);
     }
     return rc_all;
+}
+
+
+// The frame in two calls, for callers that overlap the host side of one group of estimators with the device side of another (bench.py --mode
+// replay: every host thread alternates between two halves of its streams): _begin returns when the frame's last command is on the device,
+// _end waits for the states and applies them.  tcv_estimators_optimize = _begin + _end.  Between the two calls the estimators of the ticket
+// must not be touched; the ticket is consumed by _end (also on failure).
+extern "C" int tcv_estimators_optimize_begin(tcv_estimator *const *es, int n, tcv_opt_ticket **out) {
+    if (!es || n <= 0 || !out) return TCV_ERR_INVALID;
+    OptRun *R = new OptRun();
+    R->esv.assign(es, es + n); R->n = n;
+    const int rc = optimize_begin(*R);
+    if (rc != TCV_OK) { delete R; *out = nullptr; return rc; }
+    *out = reinterpret_cast<tcv_opt_ticket *>(R);
+    return TCV_OK;
+}
+extern "C" int tcv_estimators_optimize_end(tcv_opt_ticket *t) {
+    if (!t) return TCV_ERR_INVALID;
+    OptRun *R = reinterpret_cast<OptRun *>(t);
+    const int rc = optimize_end(*R);
+    delete R;
+    return rc;
+}
+extern "C" int tcv_estimators_optimize(tcv_estimator *const *es, int n) {
+    tcv_opt_ticket *t = nullptr;
+    const int rc = tcv_estimators_optimize_begin(es, n, &t);
+    if (rc != TCV_OK) return rc;
+    return tcv_estimators_optimize_end(t);
 }
 
 extern "C" int tcv_estimator_finish_frame(tcv_estimator *e, double P[3], double q[4], double V[3]) {

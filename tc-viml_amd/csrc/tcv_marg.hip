@@ -2305,7 +2305,15 @@ int tcv_marg_attach(tcv_batch *b, tcv_problem *const *marg_problems, double *con
         if (e_ == hipSuccess) { s->out_blob = std::make_shared<DevBlob>(); s->out_blob->p = s->d_out; (void)hipGetDevice(&s->out_blob->dev); s->d_status = (int *)(s->d_out + std::max<size_t>(1, (size_t)b->n * MARG_OUT_STRIDE)); }
         if (e_ == hipSuccess) e_ = tcv::dev_malloc((void **)&s->d_scratch, sizeof(double) * (size_t)s->grid * MARG_SCR_STRIDE);
         if (e_ == hipSuccess) e_ = hipMemsetAsync(s->d_status, 0xff, sizeof(int) * 2 * b->n, ust);
-        if (e_ == hipSuccess) { e_ = ust ? hipStreamSynchronize(ust) : hipDeviceSynchronize(); if (e_ == hipSuccess) staged.in_flight = false; }
+        // No wait for the upload: the native estimator attaches the problems while the batch's SOLVE runs on this very stream, and a wait here
+        // is a wait for that kernel (a caller that overlaps another group's host work with it -- tcv_estimators_optimize_begin -- lost the whole
+        // overlap to it).  The batch notes the stream (a later launch on another stream is ordered behind the upload by an event,
+        // tcv_batch_enter_stream); the pinned staging buffer is parked until this thread's next wait on the stream.
+        if (e_ == hipSuccess && ust != nullptr) {
+            if (int rce = tcv_batch_enter_stream(b, (void *)ust)) return rce;
+            tcv::defer_release(h_in, nullptr, ust);
+            staged.in_flight = false; staged.a = nullptr;
+        } else if (e_ == hipSuccess) { e_ = hipDeviceSynchronize(); if (e_ == hipSuccess) staged.in_flight = false; }
         if (e_ != hipSuccess) return hip_fail(e_, "upload of the marginalisation problems");
         s->d_dpool = (double *)s->d_input; s->d_hdr = (MargHdr *)((char *)s->d_input + o_hdr); s->d_ipool = (int *)((char *)s->d_input + o_int);
     }

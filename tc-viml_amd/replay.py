@@ -823,6 +823,11 @@ class NativeLockstep:
         L.tcv_estimator_begin_frame.argtypes = [vp, C.c_int, dp, dp, C.c_int, ip, dp, C.c_int, ip, dp, dp, ip]
         L.tcv_estimators_begin_frames.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(_FrameInput), ip, ip]
         L.tcv_estimators_optimize.argtypes = [C.POINTER(vp), C.c_int]
+        L.tcv_estimators_optimize_begin.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(vp)]
+        L.tcv_estimators_optimize_end.argtypes = [vp]
+        L.tcv_thread_stream_slot.argtypes = [C.c_int]
+        self.slot = 0                # which of the calling thread's two library streams this object's frames use (tcv_thread_stream_slot)
+        self._pending = None
         L.tcv_estimator_finish_frame.argtypes = [vp, dp, dp, dp]
         L.tcv_estimators_finish_frames.argtypes = [C.POINTER(vp), C.c_int, dp, dp, dp, C.POINTER(C.c_int), C.POINTER(_EstimatorStats)]
         L.tcv_estimator_get_stats.argtypes = [vp, C.POINTER(_EstimatorStats)]
@@ -945,19 +950,42 @@ class NativeLockstep:
                 self._batches[k] = self._frame_batch(k)
 
     def step(self, k: int) -> int:
-        tcv, L, P, f64, ip, vp = self.tcv, self.L, self._P, self._f64, self.ip, self.vp
+        self.step_begin(k)
+        return self.step_end()
+
+    def step_begin(self, k: int):
+        """first half of frame k: begin_frame of every stream and everything of tcv_estimators_optimize up to the last command on the device
+        (tcv_estimators_optimize_begin).  A host thread that alternates between two NativeLockstep objects (slot 0 / 1) overlaps the host side
+        of one with the kernels of the other."""
+        tcv, L, vp = self.tcv, self.L, self.vp
+        assert self._pending is None
+        L.tcv_thread_stream_slot(self.slot)
         t_a = time.perf_counter()
         live, arr_all, rec, rdy, keep = self._batches.pop(k, None) or self._frame_batch(k)
         if not live:
-            return 0
+            return
         tcv.check(L.tcv_estimators_begin_frames(arr_all, len(live), rec, rdy, None))
         ready = [si for j, si in enumerate(live) if rdy[j]]
         t_b = time.perf_counter()
         self.host_s[0] += t_b - t_a
         if not ready:
-            return 0
+            return
         arr = arr_all if len(ready) == len(live) else (vp * len(ready))(*[self.ests[si] for si in ready])
-        tcv.check(L.tcv_estimators_optimize(arr, len(ready)))
+        ticket = vp()
+        tcv.check(L.tcv_estimators_optimize_begin(arr, len(ready), C.byref(ticket)))
+        self.host_s[1] += time.perf_counter() - t_b
+        self._pending = (k, ready, arr, ticket, keep)
+
+    def step_end(self) -> int:
+        """second half: waits for the states, applies them (tcv_estimators_optimize_end), finish_frame of every stream; returns the number of windows"""
+        tcv, L, P, vp = self.tcv, self.L, self._P, self.vp
+        if self._pending is None:
+            return 0
+        k, ready, arr, ticket, keep = self._pending
+        self._pending = None
+        L.tcv_thread_stream_slot(self.slot)
+        t_b = time.perf_counter()
+        tcv.check(L.tcv_estimators_optimize_end(ticket))
         t_c = time.perf_counter()
         self.host_s[1] += t_c - t_b; self.host_s[3] += 1
         nr = len(ready)

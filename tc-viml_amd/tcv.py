@@ -42,7 +42,7 @@ EXPORTS = [
     "tcv_batch_get_priors_device", "tcv_batch_get_priors_device_async", "tcv_prior_is_device_resident", "tcv_problem_set_marginalization_prior",
     "tcv_problems_set_marginalization_prior", "tcv_priors_destroy",
     "tcv_match_lines_batch", "tcv_preintegrate_device", "tcv_preint_sum_dt", "tcv_preint_export", "tcv_preint_destroy", "tcv_problem_add_imu_factor_device",
-    "tcv_microbench_fp64", "tcv_problem_plan_ints", "tcv_set_packer_reference", "tcv_plan_cache_stats", "tcv_problems_pack_bench", "tcv_line_map_create", "tcv_line_map_destroy", "tcv_batch_download_states_brief", "tcv_batch_download_states_begin", "tcv_batch_download_states_end",
+    "tcv_microbench_fp64", "tcv_problem_plan_ints", "tcv_set_packer_reference", "tcv_plan_cache_stats", "tcv_problems_pack_bench", "tcv_line_map_create", "tcv_line_map_destroy", "tcv_batch_download_states_brief", "tcv_thread_stream_slot", "tcv_batch_download_states_begin", "tcv_batch_download_states_end",
 ]
 
 
