@@ -361,3 +361,35 @@ def test_deferred_marginalisation_is_launched_by_whichever_group_comes_back_firs
         assert np.array_equal(a, b)                      # the same batches: only the launch time of the marginalisation differs
     for a, b, c in zip(eager_pairs, regrouped, threaded):
         assert np.array_equal(a, b) and np.array_equal(a, c)
+
+
+def test_two_frames_in_flight_on_one_host_thread(gpu):
+    """tcv_estimators_optimize_begin / _end with the calling thread's two library streams (tcv_thread_stream_slot): a thread that alternates
+    between two groups of estimators -- the second group's frame begun before the first one's is collected -- gets the results of the plain
+    begin-and-collect loop, bit for bit (same batches; only what overlaps on the device and the host differs)."""
+    streams = [replay.simulate_stream(90 + s, 40, max_features=30) for s in range(4)]
+
+    def run(pipelined):
+        A = replay.NativeLockstep(streams[:2], num_iterations=5); B = replay.NativeLockstep(streams[2:], num_iterations=5)
+        A.slot, B.slot = 0, 1
+        try:
+            if not pipelined:
+                for k in range(40):
+                    A.step(k); B.step(k)
+            else:
+                A.step_begin(0)
+                for k in range(40):
+                    B.step_begin(k)
+                    A.step_end()
+                    if k + 1 < 40:
+                        A.step_begin(k + 1)
+                    B.step_end()
+            return A.results() + B.results()
+        finally:
+            gpu.lib().tcv_thread_stream_slot(0)
+            A.close(); B.close()
+    plain, piped = run(False), run(True)
+    assert all(len(r["t"]) == 40 - replay.WINDOW_SIZE for r in plain)
+    for a, b in zip(plain, piped):
+        assert np.array_equal(a["p"], b["p"]) and np.array_equal(a["q"], b["q"]) and np.array_equal(a["v"], b["v"])
+        assert [l["iterations"] for l in a["log"]] == [l["iterations"] for l in b["log"]]
