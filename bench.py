@@ -41,6 +41,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "tc-viml_amd"))
+# HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default).  The lock-step replay uses two library streams per host thread (the
+# marginalisation of a frame runs beside the next frame's association): with two host threads that is four streams next to the null stream,
+# and two of them on one queue wait for each other's kernels.  Read by the runtime at its first call; an explicit setting wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0                 # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 SOLVER_ITERATIONS = 8
@@ -811,7 +815,8 @@ def run_replay(args, rank, world, local, dist):
                                   f"tracks per frame, 2D-3D association in the loop), stream s on rank s mod {world}, native estimator, "
                                   f"{SOLVER_ITERATIONS} iterations (convergence tests on) + marginalisation per frame; per rank {args.host_threads} host threads, "
                                   f"each advancing its share of the rank's streams in lock step (cooperative small-batch kernels)",
-                      "streams": args.streams, "host_threads": args.host_threads, "parallelism": f"streams sharded x{world}"},
+                      "streams": args.streams, "host_threads": args.host_threads, "parallelism": f"streams sharded x{world}",
+                      "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")},
            "frames_per_s_per_stream": windows_total / elapsed_max / max(1, args.streams),
            "ranks_seen": n_ranks, "per_rank_solves_per_s": rank_rates, "streams_per_rank": [len(shard_streams(args.streams, r, world)) for r in range(world)]}
     if DRY:

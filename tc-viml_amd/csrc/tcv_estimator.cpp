@@ -1039,7 +1039,11 @@ static int optimize_begin(OptRun &R) {
     // 3 250 windows/s).  TCV_EST_MARG_DEFER=n: defer from n windows per call on (0: never, 1: always).
     const char *e_defer = getenv("TCV_EST_MARG_DEFER");      // (read per call: the tests switch it)
     const int defer_from = e_defer ? atoi(e_defer) : 12;
-    static const bool marg_aux = getenv("TCV_EST_MARG_AUX") && atoi(getenv("TCV_EST_MARG_AUX")) != 0;
+    // the marginalisation of a frame of few windows runs on the thread's SECOND stream (ordered behind the copy of the states by an event): the next
+    // frame's association round trip on the main stream then does not queue behind the kernel (0.45 -> 0.2 ms of a 2.4 ms frame: 8 streams on one
+    // host thread 3 200 -> 3 700 windows/s; on two host threads only if the runtime has a hardware queue per stream, GPU_MAX_HW_QUEUES >= 8:
+    // 3 400 -> 3 750; otherwise no change).  TCV_EST_MARG_AUX=0: on the main stream, as until round 5.
+    static const bool marg_aux = !(getenv("TCV_EST_MARG_AUX") && atoi(getenv("TCV_EST_MARG_AUX")) == 0);
     if (marg_off_path) {
         // everything the frame still needs from the device goes on the stream NOW, while the solve runs: the copy of the states (and of the
         // summary heads), and behind it the marginalisation with its no-wait prior handles -- the kernel starts the moment the states have
@@ -1053,8 +1057,10 @@ static int optimize_begin(OptRun &R) {
             g.dl_begun = g.rc == TCV_OK;
             g.newp.assign(nb, nullptr);
             const bool eager = defer_from <= 0 || nb < defer_from;
-            if (g.rc == TCV_OK && g.any_marg && eager && !marg_aux) {
-                g.rc = tcv_batch_marginalize(g.b, st);
+            if (g.rc == TCV_OK && g.any_marg && eager) {
+                // (TCV_EST_MARG_AUX=1: on the thread's SECOND stream, ordered behind the copy of the states by an event -- the next frame's
+                // association round trip on the main stream then does not queue behind the kernel)
+                g.rc = tcv_batch_marginalize(g.b, marg_aux ? (void *)tcv::aux_stream() : st);
                 if (g.rc == TCV_OK) g.rc = tcv_batch_get_priors_device_async(g.b, g.newp.data(), nb);
                 g.marg_launched = g.rc == TCV_OK;
             }
