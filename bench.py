@@ -748,6 +748,8 @@ class ReplayEngine:
 def run_replay(args, rank, world, local, dist):
     """BASELINE configs[4]: EuRoC-trajectory streams sharded s mod G over the ranks; every rank advances its streams frame by frame."""
     mine = shard_streams(args.streams, rank, world)
+    if args.host_threads <= 0:
+        args.host_threads = 4 if len(mine) >= 96 else 2
     pool = nproc = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not DRY:
         pool, nproc = cpu_pool()                     # forked before the first GPU call
@@ -780,8 +782,10 @@ def run_replay(args, rank, world, local, dist):
     if not DRY and os.environ.get("TCV_BENCH_DEBUG_POOLS"):
         Lb = tcv.lib(); Lb.tcv_debug_host_pool_allocs.restype = C.c_longlong; Lb.tcv_debug_dev_pool_misses.restype = C.c_longlong
         dbg0 = (Lb.tcv_debug_host_pool_allocs(), Lb.tcv_debug_dev_pool_misses())
+    cpu0 = time.process_time()
     t0 = time.perf_counter()
     n = run(args.steps)
+    cpu_s = time.process_time() - cpu0               # every thread of this process: host threads, packer workers, HIP runtime threads
     if dbg0 is not None:
         a, b = Lb.tcv_debug_host_pool_allocs(), Lb.tcv_debug_dev_pool_misses()
         print("[bench] timed region: hipHostMalloc %d, hipHostFree %d, hipMalloc %d" % (a // 1000000 - dbg0[0] // 1000000, a % 1000000 - dbg0[0] % 1000000, b - dbg0[1]), file=sys.stderr)
@@ -821,6 +825,8 @@ def run_replay(args, rank, world, local, dist):
            "ranks_seen": n_ranks, "per_rank_solves_per_s": rank_rates, "streams_per_rank": [len(shard_streams(args.streams, r, world)) for r in range(world)]}
     if DRY:
         out["dry_run"] = True
+    out["host_cpu"] = {"cores_busy_mean": cpu_s / max(elapsed, 1e-9), "cpu_us_per_window": 1e6 * cpu_s / max(1, n), "cgroup_cpu_quota_cores": _cpu_quota(),
+                       "note": "rank 0's process CPU time over the timed frames / their wall time: how much of the granted cores the host side of the replay keeps busy"}
     if prof:
         out["native_profile_ms_per_call"] = prof
     if not DRY:
@@ -892,7 +898,8 @@ def main():
     ap.add_argument("--streams", type=int, default=8, help="replay mode: number of EuRoC-trajectory streams of the whole job")
     ap.add_argument("--features", type=int, default=60)
     ap.add_argument("--lines", type=int, default=8)
-    ap.add_argument("--host-threads", type=int, default=2, help="replay mode: host threads per rank, each advancing its share of the rank's streams")
+    ap.add_argument("--host-threads", type=int, default=0, help="replay mode: host threads per rank, each advancing its share of the rank's streams "
+                    "(default: 2, and 4 from 96 streams per rank on -- profiles/r05_replay_host_workers.txt)")
     args = ap.parse_args()
     if args.mode == "stream" and args.gpus > 1:
         raise SystemExit("--mode stream measures one GPU (host threads x HIP streams of one device): use --gpus 1")

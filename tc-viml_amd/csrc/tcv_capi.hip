@@ -495,11 +495,19 @@ extern "C" int tcv_set_packer_reference(int on) { tcv::set_pack_reference(on); r
 // a device: seconds of wall time in *seconds
 extern "C" int tcv_problems_pack_bench(tcv_problem *const *problems, int n, int threads, int coop_chunks, double *seconds) {
     if (!problems || n <= 0 || !seconds) return TCV_ERR_INVALID;
-    std::vector<Packed> packed(n);
+    // TCV_PACK_BENCH_FRAME = f: the problems are packed f at a time and every group's plans are released before the next group starts --
+    // the life cycle of a lock-step frame's batch (the int pools come back from the block pool) instead of n plans alive at once
+    int frame = n;
+    if (const char *e = getenv("TCV_PACK_BENCH_FRAME")) { const int v = atoi(e); if (v > 0) frame = std::min(n, v); }
     std::vector<int> rcs(n, TCV_OK);
-    const int nth = std::max(1, std::min(threads, n));
     const auto t0 = std::chrono::steady_clock::now();
-    tcv::parallel_run(nth, [&](int t) { for (int w = t; w < n; w += nth) rcs[w] = pack_problem(*problems[w], packed[w], nullptr, g_solver_variant, coop_chunks > 0 ? (int)LDS_DOUBLES : 0, true, coop_chunks); });
+    for (int b = 0; b < n; b += frame) {
+        const int m = std::min(frame, n - b), nth = std::max(1, std::min(threads, m));
+        std::vector<Packed> packed(m);
+        auto one = [&](int w) { rcs[b + w] = pack_problem(*problems[b + w], packed[w], nullptr, g_solver_variant, coop_chunks > 0 ? (int)LDS_DOUBLES : 0, true, coop_chunks); };
+        if (getenv("TCV_PACK_BENCH_STRIDED")) tcv::parallel_run(nth, [&](int t) { for (int w = t; w < m; w += nth) one(w); });      // (a fixed share per thread: up to round 5)
+        else tcv::parallel_items(m, nth, [&](int w, int) { one(w); });
+    }
     *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (getenv("TCV_DEBUG_PACK2")) tcv::pack_laps_print();
     for (int w = 0; w < n; w++) if (rcs[w] != TCV_OK) return rcs[w];
@@ -816,17 +824,16 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
         const int nth = host_op.threads(std::min(n, 16));
         std::vector<int> rcs(n, TCV_OK);
         std::vector<std::string> msgs(nth);
-        auto work = [&](int t) {
-            for (int w = t; w < n; w += nth) {
-                rcs[w] = pack_problem(*problems[w], b->packed[w], nullptr, md, chain_lds, true, md == 0 ? coop_h : 0);      // plan + data size
-                if (rcs[w] != TCV_OK && msgs[t].empty()) msgs[t] = tcv_last_error();      // the message is thread-local
-                // hash of the plan for the structure de-duplication below (a plan out of the cache is de-duplicated by its template: hashed
-                // there, once per template, not once per window)
-                if (rcs[w] == TCV_OK && !b->packed[w].tmpl) b->packed[w].plan_hash = plan_hash_of(b->packed[w]);
-            }
-        };
-        tcv::parallel_run(nth, work);
-        for (int w = 0; w < n; w++) if (rcs[w] != TCV_OK) { msg = msgs[w % nth]; return rcs[w]; }
+        std::vector<int> who(n, 0);
+        tcv::parallel_items(n, nth, [&](int w, int t) {
+            rcs[w] = pack_problem(*problems[w], b->packed[w], nullptr, md, chain_lds, true, md == 0 ? coop_h : 0);      // plan + data size
+            who[w] = t;
+            if (rcs[w] != TCV_OK && msgs[t].empty()) msgs[t] = tcv_last_error();      // the message is thread-local
+            // hash of the plan for the structure de-duplication below (a plan out of the cache is de-duplicated by its template: hashed
+            // there, once per template, not once per window)
+            if (rcs[w] == TCV_OK && !b->packed[w].tmpl && !b->packed[w].key_hashed) b->packed[w].plan_hash = plan_hash_of(b->packed[w]);
+        });
+        for (int w = 0; w < n; w++) if (rcs[w] != TCV_OK) { msg = msgs[who[w]]; return rcs[w]; }
         return TCV_OK;
     };
     {
@@ -925,17 +932,20 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
         const int nth = host_op.threads(std::min(n, 16));
         std::vector<int> rcs(n, TCV_OK);
         std::vector<std::string> msgs(nth);
-        auto work = [&](int t) {
-            for (int w = t; w < n; w += nth) {
-                rcs[w] = pack_problem_data(*problems[w], b->packed[w], nullptr, h_dpool + b->packed[w].win.dbase);
-                if (rcs[w] != TCV_OK && msgs[t].empty()) msgs[t] = tcv_last_error();
+        std::vector<int> who(n, 0);
+        const int n_plans = (int)plan_src.size();
+        tcv::parallel_items(n + n_plans, nth, [&](int i, int t) {
+            if (i < n_plans) {      // the plans straight into the upload buffer (the larger items first)
+                std::memcpy((char *)h_dpool + o_ipool + sizeof(int) * (size_t)b->plan_base[i], plan_src[i].first, sizeof(int) * plan_src[i].second);
+                return;
             }
-            for (size_t q = (size_t)t; q < plan_src.size(); q += (size_t)nth)      // the plans straight into the upload buffer
-                std::memcpy((char *)h_dpool + o_ipool + sizeof(int) * (size_t)b->plan_base[q], plan_src[q].first, sizeof(int) * plan_src[q].second);
-        };
-        tcv::parallel_run(nth, work);
+            const int w = i - n_plans;
+            rcs[w] = pack_problem_data(*problems[w], b->packed[w], nullptr, h_dpool + b->packed[w].win.dbase);
+            who[w] = t;
+            if (rcs[w] != TCV_OK && msgs[t].empty()) msgs[t] = tcv_last_error();
+        });
         for (int w = 0; w < n; w++) { b->packed[w].ints.clear(); b->packed[w].ints.shrink_to_fit(); }
-        for (int w = 0; w < n; w++) if (rcs[w] != TCV_OK) { host_staging_release(h_dpool); batch_free(b); if (!msgs[w % nth].empty()) set_error(msgs[w % nth]); return rcs[w]; }
+        for (int w = 0; w < n; w++) if (rcs[w] != TCV_OK) { host_staging_release(h_dpool); batch_free(b); if (!msgs[who[w]].empty()) set_error(msgs[who[w]]); return rcs[w]; }
         for (int w : splice_win) {      // the prior region of the window: in the tail, addressed relative to the window's own slice
             Packed &pk = b->packed[w];
             pk.win.d_prior = (int)((long long)(in_bytes / sizeof(double)) + tail_off[w] - pk.win.dbase);

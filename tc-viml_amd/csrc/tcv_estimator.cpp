@@ -12,6 +12,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <ctime>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -765,13 +766,19 @@ namespace {
 std::mutex g_mu;
 double g_prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 void prof_add(int slot, double v) { std::lock_guard<std::mutex> g(g_mu); g_prof[slot] += v; }
+// TCV_DEBUG_EST_CPU=1 (developer): CPU time of the whole process (caller, worker threads, runtime threads) between the laps of the same slots,
+// printed by tcv_estimators_profile -- drive the estimators from ONE host thread to read it
+double g_prof_cpu[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+bool prof_cpu_on() { static const bool on = getenv("TCV_DEBUG_EST_CPU") != nullptr; return on; }
+double cpu_now_s() { timespec ts; clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+void prof_cpu_add(int slot, double v) { std::lock_guard<std::mutex> g(g_mu); g_prof_cpu[slot] += v; }
 // per-estimator host work of a lock-step frame (association bookkeeping, triangulation, window and problem construction) on the packer's
 // persistent worker threads: the estimators are independent objects, every task touches its own
 void for_each_estimator(int n, const std::function<void(int)> &fn) {
     tcv::HostOp op;
     const int nth = op.threads(n);
     if (nth <= 1) { for (int i = 0; i < n; i++) fn(i); return; }
-    tcv::parallel_run(nth, [&](int t) { for (int i = t; i < n; i += nth) fn(i); });
+    tcv::parallel_items(n, nth, [&](int i, int) { fn(i); });
 }
 }  // namespace
 static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -799,7 +806,11 @@ extern "C" int tcv_estimators_kernel_profile(double *out8) {
 extern "C" int tcv_estimators_profile(double *out8) {
     if (!out8) return TCV_ERR_INVALID;
     std::lock_guard<std::mutex> g(g_mu);
-    for (int i = 0; i < 8; i++) { out8[i] = g_prof[i]; g_prof[i] = 0; }
+    if (prof_cpu_on() && g_prof[7] > 0) {
+        static const char *nm[7] = {"preintegrate", "assoc+triangulate+window", "problems", "batch_create", "kernels", "downloads", "apply"};
+        for (int i = 0; i < 7; i++) fprintf(stderr, "[est cpu] %-26s wall %8.3f ms  process cpu %8.3f ms per call (%.0f calls)\n", nm[i], 1e3 * g_prof[i] / g_prof[7], 1e3 * g_prof_cpu[i] / g_prof[7], g_prof[7]);
+    }
+    for (int i = 0; i < 8; i++) { out8[i] = g_prof[i]; g_prof[i] = 0; g_prof_cpu[i] = 0; }
     return TCV_OK;
 }
 
@@ -839,7 +850,8 @@ static int optimize_begin(OptRun &R) {
     double &t_mark = R.t_mark;
     t_mark = now_s();
     R.t_begin0 = t_mark;
-    auto lap = [&](int slot) { const double t = now_s(); prof_add(slot, t - t_mark); t_mark = t; };
+    double c_mark = prof_cpu_on() ? cpu_now_s() : 0.0;
+    auto lap = [&](int slot) { const double t = now_s(); prof_add(slot, t - t_mark); t_mark = t; if (prof_cpu_on()) { const double c = cpu_now_s(); prof_cpu_add(slot, c - c_mark); c_mark = c; } };
     prof_add(7, 1);
     for (int i = 0; i < n; i++) if (!es[i] || es[i]->phase != 1) { tcv::set_error("estimators_optimize: an estimator has no full window waiting (begin_frame must report ready)"); return TCV_ERR_INVALID; }
     for (int i = 0; i < n; i++) for (int j = 0; j < i; j++) if (es[i] == es[j]) { tcv::set_error("estimators_optimize: the same estimator twice"); return TCV_ERR_INVALID; }
@@ -1076,7 +1088,8 @@ static int optimize_end(OptRun &R) {
     tcv_estimator *const *es = R.esv.data();
     typedef OptGroup Group;
     double &t_mark = R.t_mark;
-    auto lap = [&](int slot) { const double t = now_s(); prof_add(slot, t - t_mark); t_mark = t; };
+    double c_mark = prof_cpu_on() ? cpu_now_s() : 0.0;
+    auto lap = [&](int slot) { const double t = now_s(); prof_add(slot, t - t_mark); t_mark = t; if (prof_cpu_on()) { const double c = cpu_now_s(); prof_cpu_add(slot, c - c_mark); c_mark = c; } };
     OptGroup (&G)[2] = R.G;
     hipStream_t (&g_streams)[2] = R.g_streams;
     int &rc_all = R.rc_all;

@@ -107,6 +107,7 @@ struct Packed {
     std::vector<double> doubles;
     WinHdr win;
     unsigned long long plan_hash = 0;   // of hdr + plan ints (tcv_batch_create: structure de-duplication without copying 200 KB keys)
+    bool key_hashed = false;            // plan_hash was set by the packer from the structure key (a plan built for this window alone: tcv_pack.cpp)
     int dev_imu_doubles = 0;         // > 0: every IMU factor of the window is device-resident: n_imu x 287 doubles in the device-only tail (WinHdr::d_imu points there)
     bool prior_k0_deferred = false;  // the prior's zero-row count is read on the device (tcv_prior::k0 < 0): WinHdr::prior_k0 is patched by the splice kernel
     int batch_dev = -1;              // device the batch is created on (tcv_batch_create; -1: no device-resident input is spliced): a prior / pre-integration

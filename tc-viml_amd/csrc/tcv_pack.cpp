@@ -76,8 +76,25 @@ struct WorkerPool {
     std::condition_variable cv;
     std::deque<std::shared_ptr<ParCall>> q;
     int nworkers = 0;
+    std::atomic<unsigned> posted{0};      // calls pushed so far: what a worker polls before it goes to sleep
+    std::atomic<int> sleepers{0};         // workers inside cv.wait: a post with nobody asleep skips the futex
 };
 WorkerPool &worker_pool() { static WorkerPool *P = new WorkerPool(); return *P; }
+// TCV_WORKER_SPIN_US = t > 0: a worker that has just finished a section polls for the next one for t microseconds before it sleeps on the
+// condition variable, and the caller polls for its last task the same way (a lock-step frame is a burst of short parallel sections a few
+// microseconds apart).  Measured on the 2 x 64-core host at 8 / 64 / 128 replay streams with t = 40 and 150: the same windows/s within the
+// run-to-run spread and 15 - 40 % more CPU time (profiles/r05_replay_host_workers.txt) -- so the default is 0: sleep at once.
+int worker_spin_us() {
+    static const int us = [] { const char *e = getenv("TCV_WORKER_SPIN_US"); const int v = e ? atoi(e) : 0; return std::max(0, std::min(v, 2000)); }();
+    return us;
+}
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
+}
 void run_call(ParCall &c) {
     for (;;) {
         const int t = c.next.fetch_add(1, std::memory_order_relaxed);
@@ -88,6 +105,7 @@ void run_call(ParCall &c) {
 }
 void worker_main() {
     WorkerPool &P = worker_pool();
+    unsigned seen = P.posted.load(std::memory_order_acquire);
     for (;;) {
         std::shared_ptr<ParCall> c;
         {
@@ -95,11 +113,41 @@ void worker_main() {
             for (;;) {
                 while (!P.q.empty() && P.q.front()->next.load(std::memory_order_relaxed) >= P.q.front()->n) P.q.pop_front();      // fully claimed
                 if (!P.q.empty()) { c = P.q.front(); break; }
+                seen = P.posted.load(std::memory_order_acquire);
+                const int spin = worker_spin_us();
+                if (spin > 0) {      // poll outside the lock, then look again
+                    g.unlock();
+                    const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(spin);
+                    bool news = false;
+                    for (int it = 0;; it++) {
+                        if (P.posted.load(std::memory_order_acquire) != seen) { news = true; break; }
+                        cpu_relax();
+                        if ((it & 63) == 63 && std::chrono::steady_clock::now() >= t_end) break;
+                    }
+                    g.lock();
+                    if (news) continue;
+                    if (P.posted.load(std::memory_order_acquire) != seen) continue;
+                }
+                P.sleepers.fetch_add(1, std::memory_order_relaxed);
                 P.cv.wait(g);
+                P.sleepers.fetch_sub(1, std::memory_order_relaxed);
             }
         }
         run_call(*c);
     }
+}
+void wait_call(ParCall &c) {
+    const int spin = worker_spin_us();
+    if (spin > 0) {
+        const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(spin);
+        for (int it = 0;; it++) {
+            if (c.done.load(std::memory_order_acquire) >= c.n) return;
+            cpu_relax();
+            if ((it & 63) == 63 && std::chrono::steady_clock::now() >= t_end) break;
+        }
+    }
+    std::unique_lock<std::mutex> g(c.mu);
+    c.cv.wait(g, [&] { return c.done.load(std::memory_order_acquire) >= c.n; });
 }
 }  // namespace
 void parallel_run(int nth, const std::function<void(int)> &fn) {
@@ -114,16 +162,26 @@ void parallel_run(int nth, const std::function<void(int)> &fn) {
     WorkerPool &P = worker_pool();
     auto c = std::make_shared<ParCall>();
     c->fn = &fn; c->n = nth;
+    bool wake;
     {
         std::lock_guard<std::mutex> g(P.mu);
         const int want = std::min(31, std::max(1, host_core_grant() - 1));
         while (P.nworkers < std::min(want, nth - 1)) { std::thread(worker_main).detach(); P.nworkers++; }
         P.q.push_back(c);
+        P.posted.fetch_add(1, std::memory_order_release);
+        wake = P.sleepers.load(std::memory_order_relaxed) > 0;
     }
-    P.cv.notify_all();
+    if (wake) P.cv.notify_all();
     run_call(*c);
-    std::unique_lock<std::mutex> g(c->mu);
-    c->cv.wait(g, [&] { return c->done.load(std::memory_order_acquire) >= c->n; });
+    wait_call(*c);
+}
+
+void parallel_items(int n, int nth, const std::function<void(int, int)> &fn) {
+    if (n <= 0) return;
+    nth = std::min(nth, n);
+    if (nth <= 1) { for (int i = 0; i < n; i++) fn(i, 0); return; }
+    std::atomic<int> next{0};
+    parallel_run(nth, [&](int t) { for (;;) { const int i = next.fetch_add(1, std::memory_order_relaxed); if (i >= n) return; fn(i, t); } });
 }
 
 // ---- blocks of the plans' int pools (PlanAlloc, tcv_host.h): power-of-two size classes from 16 KB, a bounded free list per class
@@ -171,7 +229,7 @@ void async_run(std::function<void()> fn) {
     auto sp = std::make_shared<std::function<void()>>(std::move(fn));
     c->own = [sp](int) { (*sp)(); };
     c->fn = &c->own; c->n = 1;
-    { std::lock_guard<std::mutex> g(P.mu); P.q.push_back(c); }
+    { std::lock_guard<std::mutex> g(P.mu); P.q.push_back(c); P.posted.fetch_add(1, std::memory_order_release); }
     P.cv.notify_one();
 }
 
@@ -1419,15 +1477,26 @@ struct PlanKey {
     bool operator==(const PlanKey &o) const { return h == o.h && k == o.k; }
 };
 struct KeyHash { size_t operator()(const PlanKey &k) const { return k.h; } };
-// LRU: a live estimator / replay produces a new structure almost every frame (tracks start and end), so most entries never hit again;
-// 256 entries hold the structures a bench / streaming loop cycles through (~27 MB of plans at most) and the cold ones fall off the end
-// one by one instead of the whole table being cleared.
+// LRU: a live estimator / replay produces a new structure almost every frame (tracks start and end), so most structures are seen once.
+//  * The table is cut into 16 shards by the key's hash, each with its own lock, list and 24 entries (384 plans at most): 8 - 16 packer
+//    threads looked up and inserted under ONE lock before, 20 + 12 us per window at 16 threads against 3.5 + 1 us alone.
+//  * A structure enters the cache at its SECOND appearance: every shard remembers the hashes of its last 64 misses; a miss whose hash is
+//    not among them builds its plan for the caller alone (no template, no eviction, the int pool goes back to the block pool with the
+//    batch, still warm), a miss that is builds it again and keeps it.  A bench / streaming loop pays one extra build per structure, a live
+//    estimator none of the bookkeeping.  TCV_PLAN_CACHE_EAGER=1: insert at first sight (the behaviour up to round 5).
 struct CacheEntry { PlanKey key; std::shared_ptr<const PlanTemplate> tmpl; };
-std::mutex g_cache_mu;
-std::list<CacheEntry> g_lru;
-std::unordered_map<PlanKey, std::list<CacheEntry>::iterator, KeyHash> g_cache;
-long long g_hits = 0, g_misses = 0;
-enum { CACHE_MAX_ENTRIES = 256 };
+enum { CACHE_SHARDS = 16, CACHE_SHARD_ENTRIES = 24, CACHE_RECENT = 64 };
+struct CacheShard {
+    std::mutex mu;
+    std::list<CacheEntry> lru;
+    std::unordered_map<PlanKey, std::list<CacheEntry>::iterator, KeyHash> map;
+    size_t recent[CACHE_RECENT] = {0};
+    unsigned recent_next = 0;
+    char pad[64];
+};
+CacheShard *g_shards() { static CacheShard *s = new CacheShard[CACHE_SHARDS]; return s; }
+inline CacheShard &shard_of(const PlanKey &k) { return g_shards()[(k.h >> 7) & (CACHE_SHARDS - 1)]; }
+std::atomic<long long> g_hits{0}, g_misses{0};
 
 void structure_key(const tcv_problem &p, int mode, int chain_lds, int coop_chunks, PlanKey &key) {
     std::vector<int> &k = key.k;
@@ -1471,10 +1540,13 @@ unsigned long long plan_content_hash(const PlanHdr &hdr, const PlanInts &pints) 
 }
 
 void plan_cache_stats(long long *hits, long long *misses, long long *entries) {
-    std::lock_guard<std::mutex> g(g_cache_mu);
-    if (hits) *hits = g_hits;
-    if (misses) *misses = g_misses;
-    if (entries) *entries = (long long)g_cache.size();
+    if (hits) *hits = g_hits.load();
+    if (misses) *misses = g_misses.load();
+    if (entries) {
+        long long e = 0;
+        for (int i = 0; i < CACHE_SHARDS; i++) { CacheShard &S = g_shards()[i]; std::lock_guard<std::mutex> g(S.mu); e += (long long)S.map.size(); }
+        *entries = e;
+    }
 }
 
 int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int mode, int chain_lds, bool plan_only, int coop_chunks) {
@@ -1487,13 +1559,23 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int 
     static const bool dbg_t = getenv("TCV_DEBUG_PACK2") != nullptr;
     auto t_prev = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) { if (dbg_t) { const auto t = std::chrono::steady_clock::now(); pack_lap_add(what, std::chrono::duration<double, std::micro>(t - t_prev).count()); t_prev = std::chrono::steady_clock::now(); } };
+    bool keep = false;      // the structure has been seen before (or TCV_PLAN_CACHE_EAGER): its plan goes into the cache
     if (!no_cache) {
+        static const bool eager = getenv("TCV_PLAN_CACHE_EAGER") != nullptr;
         structure_key(p, mode, c_lds, coop_chunks, key);
-        std::lock_guard<std::mutex> g(g_cache_mu);
-        auto it = g_cache.find(key);
-        if (it != g_cache.end()) { g_lru.splice(g_lru.begin(), g_lru, it->second); T = it->second->tmpl; g_hits++; } else g_misses++;
+        CacheShard &S = shard_of(key);
+        std::lock_guard<std::mutex> g(S.mu);
+        auto it = S.map.find(key);
+        if (it != S.map.end()) { S.lru.splice(S.lru.begin(), S.lru, it->second); T = it->second->tmpl; g_hits.fetch_add(1, std::memory_order_relaxed); }
+        else {
+            g_misses.fetch_add(1, std::memory_order_relaxed);
+            keep = eager;
+            for (int i = 0; i < CACHE_RECENT && !keep; i++) keep = S.recent[i] == key.h;
+            if (!keep) { S.recent[S.recent_next] = key.h; S.recent_next = (S.recent_next + 1) % CACHE_RECENT; }
+        }
     }
     lap("key + lookup");
+    out.key_hashed = false;
     if (T) {
         out.hdr = T->hdr; out.tmpl = T; out.ints.clear();
         out.cam_block = T->cam_block; out.cam_loff = T->cam_loff; out.lm_block = T->lm_block; out.proj_order = T->proj_order;
@@ -1502,19 +1584,23 @@ int pack_problem(const tcv_problem &p, Packed &out, const double *imu_sqrt, int 
         const int rc = pack_plan(p, out, mode, c_lds, coop_chunks);
         if (rc != TCV_OK) return rc;
         lap("pack_plan");
-        if (!no_cache) {
+        // identity for the de-duplication of equal plans inside a batch (tcv_batch_create compares the contents of candidates): equal
+        // structure keys give equal plans, so the key's hash serves -- hashing the 170 KB of content cost as much as a third of the build
+        const unsigned long long id = (unsigned long long)key.h * 0x9E3779B97F4A7C15ull + (unsigned long long)out.ints.size();
+        if (!no_cache && !keep) { out.plan_hash = id; out.key_hashed = true; }
+        if (!no_cache && keep) {
             auto N = std::make_shared<PlanTemplate>();
             N->hdr = out.hdr; N->ints.swap(out.ints);
             N->cam_block = out.cam_block; N->cam_loff = out.cam_loff; N->lm_block = out.lm_block; N->proj_order = out.proj_order;
-            // identity for the de-duplication of equal plans inside a batch (tcv_batch_create compares the contents of candidates): equal
-            // structure keys give equal plans, so the key's hash serves -- hashing the 170 KB of content cost as much as a third of the build
-            N->hash = (unsigned long long)key.h * 0x9E3779B97F4A7C15ull + (unsigned long long)N->ints.size();
+            N->hash = id;
             out.tmpl = N;
-            std::lock_guard<std::mutex> g(g_cache_mu);
-            if (g_cache.find(key) == g_cache.end()) {      // (another thread may have packed the same structure meanwhile)
-                while (g_cache.size() >= CACHE_MAX_ENTRIES) { g_cache.erase(g_lru.back().key); g_lru.pop_back(); }
-                g_lru.push_front(CacheEntry{key, N});
-                g_cache.emplace(std::move(key), g_lru.begin());
+            std::shared_ptr<const PlanTemplate> victim;      // (released outside the lock)
+            CacheShard &S = shard_of(key);
+            std::lock_guard<std::mutex> g(S.mu);
+            if (S.map.find(key) == S.map.end()) {      // (another thread may have packed the same structure meanwhile)
+                if (S.map.size() >= CACHE_SHARD_ENTRIES) { victim = S.lru.back().tmpl; S.map.erase(S.lru.back().key); S.lru.pop_back(); }
+                S.lru.push_front(CacheEntry{key, N});
+                S.map.emplace(std::move(key), S.lru.begin());
             }
         }
     }

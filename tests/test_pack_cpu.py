@@ -148,3 +148,55 @@ def test_camera_half_is_cached_across_visual_structures(tcv):
     assert st1[1] - st0[1] == 4          # four new whole-plan structures ...
     assert st1[3] - st0[3] <= 1          # ... on at most one new camera half
     assert st1[2] - st0[2] >= 3
+
+
+def test_a_structure_enters_the_plan_cache_at_its_second_appearance(tcv):
+    """one-off structures (a live estimator's windows) are built for their caller alone; a structure that comes back is kept from then on;
+    the plan is the same ints whichever of the three ways it came about"""
+    import ctypes as C
+    L = tcv.lib()
+    pre, main, z = golden_windows()
+    big = synth.window_at(synth.make_windows(90417, 1, n_landmarks=37), 0)
+    w = dict(main)
+    for k in ("proj", "lam"):
+        w[k] = big[k]
+    st = [(C.c_longlong * 4)() for _ in range(4)]
+    tcv.check(L.tcv_plan_cache_stats(st[0]))
+    for i in range(3):
+        tcv.Window(w).plan_stats()                    # (packs the window once)
+        tcv.check(L.tcv_plan_cache_stats(st[i + 1]))
+    hits = [st[i + 1][0] - st[i][0] for i in range(3)]
+    misses = [st[i + 1][1] - st[i][1] for i in range(3)]
+    assert (misses[0], hits[0]) == (1, 0)             # first sight: built, not kept
+    assert (misses[1], hits[1]) == (1, 0)             # second sight: built again, kept
+    assert (misses[2], hits[2]) == (0, 1)             # from the cache
+    cached = _plan_ints(tcv, tcv.Window(w))
+    L.tcv_set_packer_reference(1)                     # (the reference builder bypasses the cache)
+    try:
+        fresh = _plan_ints(tcv, tcv.Window(w))
+    finally:
+        L.tcv_set_packer_reference(0)
+    assert np.array_equal(cached, fresh)
+
+
+def test_items_of_a_parallel_section_are_each_run_once(tcv):
+    """tcv_problems_pack_bench packs its windows through the worker pool's one-at-a-time claim (parallel_items) and through the fixed-share
+    split: every window ends up packed (a return code per window), on 1 .. 8 threads, frames of 5"""
+    import ctypes as C
+    import os
+    L = tcv.lib()
+    L.tcv_problems_pack_bench.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    Ws = [tcv.Window(w) for w in _replay_like_windows()[:12]]
+    arr = (C.c_void_p * len(Ws))(*[w.h for w in Ws])
+    s = C.c_double()
+    old = os.environ.get("TCV_PACK_BENCH_FRAME")
+    os.environ["TCV_PACK_BENCH_FRAME"] = "5"
+    try:
+        for nt in (1, 3, 8):
+            tcv.check(L.tcv_problems_pack_bench(arr, len(Ws), nt, 0, C.byref(s)))
+            assert s.value > 0
+    finally:
+        if old is None:
+            os.environ.pop("TCV_PACK_BENCH_FRAME", None)
+        else:
+            os.environ["TCV_PACK_BENCH_FRAME"] = old

@@ -39,7 +39,7 @@ def main():
     L = tcv.lib()
     L.tcv_problems_pack_bench.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
     for nt in threads:
-        Ws = [tcv.Window(w) for w in windows(reps=320)]      # fresh structures per measurement: every plan is built
+        Ws = [tcv.Window(w) for w in windows(reps=int(os.environ.get("PACK_BENCH_WINDOWS", "320")))]      # fresh structures per measurement: every plan is built
         arr = (C.c_void_p * len(Ws))(*[w.h for w in Ws])
         s = C.c_double()
         tcv.check(L.tcv_problems_pack_bench(arr, len(Ws), nt, 4, C.byref(s)))
