@@ -4,6 +4,7 @@ like a live estimator's -- no device needed.  Replays a short EuRoC-trajectory s
 that only records the windows, then packs variants of them on 1 .. N host threads (tcv_problems_pack_bench).
 
     python tools/dev_pack_bench.py [threads ...]          TCV_DEBUG_PACK2=1: per-phase times
+    PACK_BENCH_LAND=150 PACK_BENCH_LINES=88 PACK_BENCH_DROP=1: ~560 point + 88 line factors per window, like a 60-feature replay frame
 """
 import ctypes as C
 import os
@@ -18,17 +19,17 @@ import synth    # noqa: E402
 import tcv      # noqa: E402
 
 
-def windows(n_land=90, reps=160):
+def windows(n_land=int(os.environ.get("PACK_BENCH_LAND", "90")), reps=160):
     """replay-sized windows with distinct structures: ragged tracks drawn per window"""
     rng = np.random.Generator(np.random.PCG64(11))
     out = []
     for r in range(reps):
-        w = dict(synth.window_at(synth.make_windows(7000 + r, 1, n_landmarks=n_land + int(rng.integers(-10, 10))), 0))
+        w = dict(synth.window_at(synth.make_windows(7000 + r, 1, n_landmarks=n_land + int(rng.integers(-10, 10)), n_lines=int(os.environ.get("PACK_BENCH_LINES", "40"))), 0))
         pr = {k: np.asarray(v) for k, v in w["proj"].items()}
         keep = np.ones(len(pr["landmark"]), bool)
         for l in range(int(pr["landmark"].max()) + 1):
             idx = np.nonzero(pr["landmark"] == l)[0]
-            keep[idx[int(rng.integers(1, len(idx) + 1)):]] = False
+            keep[idx[int(rng.integers(max(1, len(idx) - int(os.environ.get("PACK_BENCH_DROP", "99"))), len(idx) + 1)):]] = False
         w["proj"] = {k: (v[keep] if isinstance(v, np.ndarray) and v.shape[:1] == keep.shape else v) for k, v in pr.items()}
         out.append(w)
     return out
