@@ -1281,10 +1281,20 @@ static int pack_plan(const tcv_problem &p, Packed &out, int mode, int chain_lds,
         }
     }
     if (!use_chain) {
-        { const int rc = build_chunks(stage_cap, area_cap, vch); if (rc != TCV_OK) return rc; }
-        int ms = 0, ma = 0;
-        const int rc = emit_all(vch, stage_cap, area_cap, vprog, sprog, vchunk_tab, ms, ma);
-        if (rc != TCV_OK) return rc;
+        // build_chunks sizes the chunks by an estimate of the VISUAL program; the exact programs (emit_all) may need more -- the Schur program of
+        // ragged tracks (many camera-block pairs per landmark) does: the chunks are then cut for a smaller budget until the exact programs fit
+        int cap_try = stage_cap, rc = TCV_OK;
+        std::string first_msg;
+        for (int attempt = 0; attempt < 12; attempt++) {
+            const int rcb = build_chunks(cap_try, area_cap, vch);
+            if (rcb != TCV_OK) { if (attempt == 0) return rcb; rc = TCV_ERR_TOO_LARGE; break; }      // (a single landmark no longer fits the reduced budget)
+            int ms = 0, ma = 0;
+            rc = emit_all(vch, stage_cap, area_cap, vprog, sprog, vchunk_tab, ms, ma);
+            if (rc != TCV_ERR_TOO_LARGE) break;
+            if (first_msg.empty()) first_msg = tcv_last_error();
+            cap_try = cap_try * 4 / 5;
+        }
+        if (rc != TCV_OK) { if (!first_msg.empty()) set_error(first_msg); return rc; }
     }
     lap("chunks + gather programs");
     set_error("");

@@ -1376,22 +1376,36 @@ __device__ __forceinline__ bool diag_tile_wave(lds_d *TK, int cmax, lds_d *invd,
     return ok;
 }
 
-// panel below a factored diagonal tile on the matrix cores: X = A_IK L_KK^-T, L^-T from the tile's upper triangle and invd (diag_tile_wave)
+// panel below a factored diagonal tile on the matrix cores: X L_KK' = A_IK, with the L_KK^-T the diagonal factorisation left behind in the
+// tile's upper triangle and invd (diag_tile_wave).  A product with an explicit inverse is not backward stable: its residual A - X L' is
+// cond(L_KK) eps |A|, and a camera system that is rank deficient beyond the gauge (a pose held by one observation and no IMU factor, a two-frame
+// window: only the trust region's mu D^2 holds those directions, cond(L_KK) ~ 1e4) then loses that factor in the solution -- first steps off by
+// 1e-3 where substitution gives 1e-7 (tests/dev/fuzz_solve.py).  One refinement step on the matrix cores restores the residual to eps |A|:
+//   Y1 = Linv A',  R = A' - L Y1,  Y = Y1 + Linv R,  X = Y'
+// in the transposed form because the accumulator layout of v_mfma_f64_16x16x4 IS its B-operand layout (a product can be multiplied from the
+// LEFT straight out of the registers): 12 MFMAs per tile instead of 4, in a phase that is 1 % of the kernel.
 __device__ __forceinline__ void panel_tile_mfma(lds_d *T, const lds_d *TK, const lds_d *invd, int lane) {
     const int row0 = lane >> 4, col = lane & 15;
-    double av[4], bv[4];
+    double li[4], ll[4], at[4];      // A operands: Linv[m = col][k], L[m = col][k] (both lower triangular); B operand: A'[k][n = col] = A[col][k]
 #pragma unroll
     for (int kk = 0; kk < 4; kk++) {
         const int k = 4 * kk + row0;
-        av[kk] = T[sw(col, k)];                                   // A[m = col][k]
-        const double up = TK[sw(min(k, col), max(k, col))], dg = invd[col];      // B[k][n = col] = L^-T[k][col]: upper triangle, diagonal 1 / l_cc
-        bv[kk] = (k < col) ? up : ((k == col) ? dg : 0.0);
+        const double up = TK[sw(min(k, col), max(k, col))], lo = TK[sw(max(k, col), min(k, col))], dg = invd[col];
+        li[kk] = (k < col) ? up : ((k == col) ? dg : 0.0);           // Linv[col][k] = L^-T[k][col]
+        ll[kk] = (k <= col) ? -lo : 0.0;                             // -L[col][k]
+        at[kk] = T[sw(col, k)];
     }
-    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+    v4f64 y1 = {0.0, 0.0, 0.0, 0.0}, r;
 #pragma unroll
-    for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], acc, 0, 0, 0);
+    for (int i = 0; i < 4; i++) r[i] = T[sw(col, row0 + 4 * i)];     // A' in the accumulator layout: rows row0 + 4 i of column col
 #pragma unroll
-    for (int i = 0; i < 4; i++) T[sw(row0 + 4 * i, col)] = acc[i];
+    for (int kk = 0; kk < 4; kk++) y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(li[kk], at[kk], y1, 0, 0, 0);
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) r = __builtin_amdgcn_mfma_f64_16x16x4f64(ll[kk], y1[kk], r, 0, 0, 0);
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(li[kk], r[kk], y1, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; i++) T[sw(col, row0 + 4 * i)] = y1[i];    // X = Y'
 }
 
 template <bool MFMA>

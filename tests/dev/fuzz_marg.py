@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Developer checker (GPU): the marginalisation (MARGIN_OLD, marginalization_factor.cpp:174-299) on the randomised window structures of
+tests/dev/fuzz_solve.py against the C oracle, both sides linearising at bit-identical states (tcv_marginalize on host-resident states).
+Compared: layout (m, n, block sizes), the Schur complement A', b' and the factor's J0'J0, J0'r0 (J0 itself is defined up to eigenvector
+signs).  A' is a small difference of large terms: ~1e-7 relative is the FP64 floor between two summation orders (tests/test_gpu_marg.py);
+the mutations make it far worse (every landmark seen once: A' has rank 8 of 21; IMU factor only: A' = 0 in exact arithmetic), so the checker
+measures the floor of each case on the ORACLE ALONE -- the same window with its states moved by 1e-13 relative, three draws -- and allows the
+device 10x that (measured: 3.1x at most, median 0.9x) where it exceeds the well-posed gates (`ok~`).
+
+    python tests/dev/fuzz_marg.py [cases] [first seed]
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import fuzz_solve as fz      # noqa: E402
+from util import fro      # noqa: E402
+
+tcv, orc = fz.tcv, fz.orc
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    tally, bad = {}, []
+    worst = dict(A=0.0, b=0.0, JtJ=0.0, Jtr=0.0)
+    for c in range(cases):
+        seed = seed0 + c
+        rng = np.random.Generator(np.random.PCG64(seed))
+        w_hip, w_orc, exc, note = fz.make_case(rng, seed)
+        if len(w_hip["pose"]) < 3:
+            continue
+        try:
+            O = orc.Window(w_orc, ex_constant=exc)
+            po, dbg = O.marginalize_old()
+        except Exception as e:      # noqa: BLE001
+            print(f"case {seed} [{note}]: oracle refused: {str(e)[:100]}")
+            tally["oracle refused"] = tally.get("oracle refused", 0) + 1
+            continue
+        sens = dict(A=0.0, b=0.0)
+        for rep in range(3):
+            r2 = np.random.Generator(np.random.PCG64(733 + rep))
+            w2 = dict(w_orc)
+            for key in ("lam", "pose", "speedbias"):
+                a = np.asarray(w_orc[key], dtype=float)
+                w2[key] = a * (1 + 1e-13 * r2.standard_normal(a.shape))
+            try:
+                po2, dbg2 = orc.Window(w2, ex_constant=exc).marginalize_old()
+                if (po2["m"], po2["n"]) == (po["m"], po["n"]):
+                    sens["A"] = max(sens["A"], fro(dbg2["A_schur"], dbg["A_schur"])); sens["b"] = max(sens["b"], fro(dbg2["b_schur"], dbg["b_schur"]))
+            except Exception:      # noqa: BLE001
+                pass
+        try:
+            mw = tcv.margin_old_window(w_hip)
+            Wm = tcv.Window(mw, estimate_extrinsic=not exc)
+            dr = tcv.margin_old_drops(Wm, mw)
+            arr = (tcv._dp * len(dr))(*dr)
+            h = C.c_void_p()
+            tcv.check(tcv.lib().tcv_marginalize(Wm.h, arr, len(dr), C.byref(h)))
+            P = tcv.Prior(h); d = P.export(); As, bs = P.schur()
+        except Exception as e:      # noqa: BLE001
+            verdict, detail = "ERROR", str(e)[:140]
+        else:
+            if (d["m"], d["n"]) != (po["m"], po["n"]):
+                verdict, detail = "LAYOUT", f"m, n {d['m']}, {d['n']} vs {po['m']}, {po['n']}"
+            else:
+                eA, eb = fro(As, dbg["A_schur"]), fro(bs, dbg["b_schur"])
+                eJ, er = fro(d["J0"].T @ d["J0"], dbg["A_schur"]), fro(d["J0"].T @ d["r0"], dbg["b_schur"])
+                worst = dict(A=max(worst["A"], eA), b=max(worst["b"], eb), JtJ=max(worst["JtJ"], eJ), Jtr=max(worst["Jtr"], er))
+                detail = f"A' {eA:.1e} b' {eb:.1e} J0'J0 {eJ:.1e} J0'r0 {er:.1e} (m {d['m']}, n {d['n']})"
+                gA, gb = max(2e-6, 10 * sens["A"]), max(1e-9, 10 * sens["b"])
+                well = eA < 2e-6 and eb < 1e-9 and eJ < 2e-6 and er < 1e-4
+                soft = eA < gA and eb < gb and eJ < 2 * gA      # (J0'r0 against b' is gated by the thresholded eigenvalues, not by the conditioning: reported only)
+                verdict = "ok" if well else ("ok~" if soft else "DIFF")
+                detail += f" | oracle moves A' {sens['A']:.1e} b' {sens['b']:.1e}"
+        tally[verdict] = tally.get(verdict, 0) + 1
+        if verdict not in ("ok", "ok~"):
+            bad.append((seed, note, verdict, detail))
+        print(f"case {seed} [{note}; {len(w_hip['proj']['landmark'])} point, {len(w_hip['line']['frame'])} line factors, {len(w_hip['lam'])} landmarks, prior {'yes' if w_hip.get('prior') is not None else 'no'}]: {verdict} {detail}", flush=True)
+    print("\ntally:", tally, "worst", {k: f"{v:.1e}" for k, v in worst.items()})
+    print("flagged:", len(bad))
+    for x in bad:
+        print("  ", x)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
