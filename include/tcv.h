@@ -68,8 +68,10 @@ typedef struct {
                                           ABI note: until round 2 this slot was `compute_sqrt_info_on_device` (a reserved slot nobody read, default 1);
                                           a caller that still writes 1 here by hand switches the cooperative mode off -- fill the struct
                                           with tcv_solver_options_default() and change only what you mean to */
-    int use_mfma;                      /* dense layout only: 1 (default) trailing Cholesky update on v_mfma_f64_16x16x4_f64,
-                                          0 FP64 VALU (debug).  The chain layout always uses the matrix cores. */
+    int use_mfma;                      /* dense layout only: 1 (default) panel solve and trailing Cholesky update on v_mfma_f64_16x16x4_f64
+                                          (the panel is a product with the diagonal tile's inverse plus one refinement step: residual
+                                          eps |A|, like substitution), 0 FP64 VALU with forward substitution (debug).  The chain layout
+                                          always uses the matrix cores. */
     int threads_per_window;            /* dense layout only: 256 (default) or 512 threads per workgroup; the chain layout is
                                           built for 256 */
     int record_first_step;             /* 1: keep the tangent step of iteration 1 (parity tests)      */
