@@ -202,6 +202,7 @@ def main():
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     tally = {}
     bad = []
+    kept = []
     for c in range(cases):
         seed = seed0 + c
         rng = np.random.Generator(np.random.PCG64(seed))
@@ -213,6 +214,7 @@ def main():
         except Exception as e:      # noqa: BLE001
             print(f"case {seed} [{note}]: oracle refused: {e}")
             continue
+        kept.append((seed, note, w_hip, exc, O, so, sens))
         row = []
         for name, kw in (("lone", dict(copies=1)), ("single", dict(copies=1, coop_off=True)), ("packed", dict(copies=257)), ("dense", dict(copies=1, dense=True))):
             try:
@@ -228,6 +230,24 @@ def main():
                 bad.append((seed, note, name, verdict, detail))
         np_, nl_, nlm = len(w_hip["proj"]["landmark"]), len(w_hip["line"]["frame"]), len(w_hip["lam"])
         print(f"case {seed} [{note}; {np_} point, {nl_} line factors, {nlm} landmarks, prior {'yes' if w_hip.get('prior') is not None else 'no'}]: " + "  ".join(row), flush=True)
+    # the same windows six at a time in ONE batch (a lock-step frame: different structures side by side, the helpers sized by the largest
+    # window, groups rotated over the XCDs), each against its own oracle solve
+    for g0 in range(0, len(kept), 6):
+        grp = kept[g0:g0 + 6]
+        try:
+            Ws = [tcv.Window(w, estimate_extrinsic=not exc) for (_, _, w, exc, _, _, _) in grp]
+            b = tcv.Batch(Ws)
+            b.solve(tcv.default_options(8, True, True, 256, True)); b.synchronize(); b.download_states()
+            ss = b.summaries()
+            for k, (seed, note, w, exc, O, so, sens) in enumerate(grp):
+                verdict, detail = compare(Ws[k], b, ss[k], k, O, so, sens)
+                tally[("mixed", verdict)] = tally.get(("mixed", verdict), 0) + 1
+                if verdict in ("FIRST STEP", "STATE", "ERROR"):
+                    bad.append((seed, note, "mixed", verdict, detail))
+            print(f"mixed batch of seeds {[g[0] for g in grp]}: layout {b.plan_stats()['layout']}, plans {b.plan_stats()['num_plans']}, cooperative {b.cooperative()}", flush=True)
+        except Exception as e:      # noqa: BLE001
+            tally[("mixed", "ERROR")] = tally.get(("mixed", "ERROR"), 0) + 1
+            bad.append((grp[0][0], "batch", "mixed", "ERROR", str(e)[:160]))
     print("\ntally:", {f"{a}/{b}": n for (a, b), n in sorted(tally.items())})
     print("mismatches:", len(bad))
     for x in bad:
