@@ -100,7 +100,9 @@ def preintegrate(acc, gyr, dt, lin_ba, lin_bg, acc_n, gyr_n, acc_w, gyr_w):
     delta_p = np.zeros(3); delta_v = np.zeros(3); delta_q = np.array([0.0, 0, 0, 1])
     jacobian = np.eye(15); covariance = np.zeros((15, 15)); sum_dt = 0.0
     I3 = np.eye(3)
+    dts = np.broadcast_to(np.asarray(dt, dtype=float), (acc.shape[0] - 1,))      # push_back(dt, acc, gyr) carries its own dt (:29-36): a scalar or one per sample
     for k in range(acc.shape[0] - 1):
+        dt = float(dts[k])
         a0, g0, a1, g1 = acc[k], gyr[k], acc[k + 1], gyr[k + 1]
         # midPointIntegration :54-128
         un_acc_0 = qrot(delta_q, a0 - lin_ba)
