@@ -53,3 +53,7 @@ def test_gauge_fix_on_random_windows(gpu):
 
 def test_factor_evaluators_on_random_inputs(gpu):
     assert run("fuzz_factors", 500, 0) == 0
+
+
+def test_native_estimator_on_stress_streams(gpu):
+    assert run("fuzz_estimator", 6, 0, 40) == 0
