@@ -1,0 +1,3 @@
+#!/bin/bash
+O=gpurun_out/r05z31; mkdir -p $O
+python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log; tail -4 $O/pytest.log
