@@ -30,6 +30,16 @@ def _stale() -> bool:
 SANITIZE_FLAGS = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-gline-tables-only", "-shared-libsan"]
 
 
+TSAN_FLAGS = ["-fsanitize=thread", "-fno-omit-frame-pointer", "-gline-tables-only", "-shared-libsan"]
+
+
+def tsan_runtime() -> str:
+    """the shared ThreadSanitizer runtime of the ROCm clang (preloaded by tests/test_sanitize_cpu.py, like the ASan one)"""
+    import glob
+    hits = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.tsan-x86_64.so"))
+    return hits[-1] if hits else ""
+
+
 def asan_runtime() -> str:
     """the shared AddressSanitizer runtime of the ROCm clang: a process that dlopens the sanitized library must preload it"""
     import glob
@@ -48,6 +58,8 @@ def build(force: bool = False, verbose: bool = False, profile: bool = False, abl
         return _compile(os.path.join(HERE, "libtcv_hip_margocc1.so"), verbose, ["-DTCV_MARG_OCC1=1"])
     if "--occ3" in sys.argv:      # developer A/B build: chain kernel at three wavefronts per SIMD (168 registers), tools/dev_occupancy3.py
         return _compile(os.path.join(HERE, "libtcv_hip_occ3.so"), verbose, ["-DTCV_CHAIN_OCC3=1"])
+    if "--tsan" in sys.argv or os.environ.get("TCV_BUILD_TSAN") == "1":      # ThreadSanitizer over the host side: worker pool, plan caches, block pool
+        return _compile(os.path.join(HERE, "libtcv_hip_tsan.so"), verbose, TSAN_FLAGS, opt="-O1", link_extra=["-fsanitize=thread", "-shared-libsan"])
     if sanitize:
         return _compile(os.path.join(HERE, "libtcv_hip_san.so"), verbose, SANITIZE_FLAGS, opt="-O1", link_extra=["-fsanitize=address,undefined", "-shared-libsan"])
     if profile:

@@ -23,9 +23,7 @@
 namespace tcv {
 
 // ---- host thread budget (HostOp, tcv_packed.h)
-static int host_core_grant() {
-    static int grant = 0;
-    if (grant > 0) return grant;
+static int host_core_grant_probe() {
     int g = (int)std::thread::hardware_concurrency();
     if (g <= 0) g = 1;
 #if defined(__linux__)
@@ -44,7 +42,10 @@ static int host_core_grant() {
     }
 #endif
     if (const char *e = getenv("TCV_HOST_THREADS")) { const int v = atoi(e); if (v > 0) g = v; }
-    grant = std::max(1, g);
+    return std::max(1, g);
+}
+static int host_core_grant() {
+    static const int grant = host_core_grant_probe();      // (once: several host threads ask at the same time)
     return grant;
 }
 static std::atomic<int> g_host_ops{0};
@@ -245,13 +246,12 @@ bool prior_keep_zero_rows() {
 
 // Two chain-mode workgroups share one CU's 160 KiB of LDS.  TCV_CHAIN_LDS_DOUBLES overrides the per-workgroup size (tuning).
 int chain_lds_doubles() {
-    static int v = 0;
-    if (v == 0) {
+    static const int v = [] {      // (initialised once, by whichever packer thread comes first: a plain static written by all of them was a data race, found by the ThreadSanitizer build)
         const char *e = getenv("TCV_CHAIN_LDS_DOUBLES");
-        v = e ? atoi(e) : LDS_DOUBLES / 2;
-        if (v < 6144 || v > LDS_DOUBLES) v = LDS_DOUBLES / 2;
-        v &= ~1;
-    }
+        int x = e ? atoi(e) : LDS_DOUBLES / 2;
+        if (x < 6144 || x > LDS_DOUBLES) x = LDS_DOUBLES / 2;
+        return x & ~1;
+    }();
     return v;
 }
 

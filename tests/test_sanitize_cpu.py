@@ -42,3 +42,57 @@ def test_host_side_is_clean_under_asan_and_ubsan(built):
     probe = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, 'tc-viml_amd'); import tcv; tcv.lib(); print(open('/proc/self/maps').read().count('libtcv_hip_san.so') > 0)"],
                            capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert probe.stdout.strip().endswith("True"), probe.stdout + probe.stderr
+
+
+def test_host_side_is_clean_under_tsan(built, tmp_path):
+    """ThreadSanitizer over the same host code (`build.py --tsan`): the persistent worker pool, the one-at-a-time item claim, the sharded plan
+    cache, the camera-half cache and the block pool, driven by THREE host threads that post 8-thread parallel sections at once over the
+    same 48 structures (first sight: built, second: built and kept, third: cache hit), then the CPU suites of the packer and the ABI.
+    Round 5: this found the lazily initialised `static int` of chain_lds_doubles() / host_core_grant() written by every packer thread."""
+    mod = _build_mod()
+    rt = mod.tsan_runtime()
+    assert rt, "ROCm clang's shared TSan runtime not found"
+    old = os.environ.get("TCV_BUILD_TSAN")
+    os.environ["TCV_BUILD_TSAN"] = "1"
+    try:
+        lib = mod.build()
+    finally:
+        if old is None:
+            os.environ.pop("TCV_BUILD_TSAN", None)
+        else:
+            os.environ["TCV_BUILD_TSAN"] = old
+    assert lib.endswith("libtcv_hip_tsan.so")
+    drive = tmp_path / "drive.py"
+    drive.write_text('''
+import ctypes as C, sys, threading
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import tcv
+import dev_pack_bench as d
+L = tcv.lib()
+L.tcv_problems_pack_bench.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+Ws = [tcv.Window(w) for w in d.windows(reps=48)]
+arr = (C.c_void_p * len(Ws))(*[w.h for w in Ws])
+def run(coop):
+    s = C.c_double()
+    for rep in range(3):
+        tcv.check(L.tcv_problems_pack_bench(arr, len(Ws), 8, coop, C.byref(s)))
+ts = [threading.Thread(target=run, args=(c,)) for c in (0, 4, 0)]
+for t in ts: t.start()
+for t in ts: t.join()
+st = (C.c_longlong * 4)(); L.tcv_plan_cache_stats(st)
+assert st[0] > 0 and st[1] > 0, list(st)
+print("driven", list(st))
+''' % (os.path.join(ROOT, "tc-viml_amd"), os.path.join(ROOT, "tools")))
+    env = dict(os.environ, TCV_LIB=lib, LD_PRELOAD=rt, TCV_PACK_BENCH_FRAME="16", TSAN_OPTIONS="halt_on_error=0:exitcode=66:report_signal_unsafe=0")
+    out = subprocess.run([sys.executable, str(drive)], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    text = out.stdout + out.stderr
+    assert out.returncode == 0 and "driven" in text, text[-4000:]
+    assert "ThreadSanitizer" not in text, text[-6000:]
+    cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider",
+           os.path.join(ROOT, "tests", "test_pack_cpu.py"), os.path.join(ROOT, "tests", "test_replay_cpu.py"), os.path.join(ROOT, "tests", "test_abi_cpu.py"),
+           "--deselect", os.path.join(ROOT, "tests", "test_abi_cpu.py") + "::test_header_is_valid_c99_and_cxx_and_the_example_links"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env, cwd=ROOT)
+    text = out.stdout + out.stderr
+    assert out.returncode == 0, text[-4000:]
+    assert "ThreadSanitizer" not in text, text[-6000:]
+    assert " passed" in text and "failed" not in text
