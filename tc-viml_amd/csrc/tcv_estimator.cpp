@@ -775,6 +775,12 @@ void prof_cpu_add(int slot, double v) { std::lock_guard<std::mutex> g(g_mu); g_p
 // per-estimator host work of a lock-step frame (association bookkeeping, triangulation, window and problem construction) on the packer's
 // persistent worker threads: the estimators are independent objects, every task touches its own
 void for_each_estimator(int n, const std::function<void(int)> &fn) {
+    // TCV_EST_SERIAL_MAX = m (experiment, default 0): up to m estimators per call the tasks run on the caller.  A task is 10 - 20 us and a fork / join
+    // ~50 us, so at four windows per call the association sections are faster alone (0.18 against 0.22 ms) -- but the problems then all come
+    // out of the CALLER's malloc arena while the worker threads free last frame's behind its back, and their construction goes from 0.06 to
+    // 0.13 ms (0.07 -> 0.3 ms at eight per call): 8 streams the same, 16 streams 6.4 K -> 5.6 K windows/s (profiles/r05_replay_host_workers.txt)
+    static const int serial_max = [] { const char *e = getenv("TCV_EST_SERIAL_MAX"); return e ? atoi(e) : 0; }();
+    if (n <= serial_max) { for (int i = 0; i < n; i++) fn(i); return; }
     tcv::HostOp op;
     const int nth = op.threads(n);
     if (nth <= 1) { for (int i = 0; i < n; i++) fn(i); return; }
