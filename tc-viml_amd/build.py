@@ -56,6 +56,8 @@ def build(force: bool = False, verbose: bool = False, profile: bool = False, abl
         return _compile(os.path.join(HERE, "libtcv_hip_occ1.so"), verbose, ["-DTCV_CHAIN_OCC1=1"])
     if "--margocc1" in sys.argv:  # developer A/B build: marginalisation kernel at one wavefront per SIMD (no register spills), tools/r05_marg_spill_ab.sh
         return _compile(os.path.join(HERE, "libtcv_hip_margocc1.so"), verbose, ["-DTCV_MARG_OCC1=1"])
+    if "--norefine" in sys.argv:  # developer A/B build: the Cholesky's panel solve without its refinement step (what it costs: profiles/r05_panel_refine_ab.txt)
+        return _compile(os.path.join(HERE, "libtcv_hip_norefine.so"), verbose, ["-DTCV_PANEL_NOREFINE=1"])
     if "--occ3" in sys.argv:      # developer A/B build: chain kernel at three wavefronts per SIMD (168 registers), tools/dev_occupancy3.py
         return _compile(os.path.join(HERE, "libtcv_hip_occ3.so"), verbose, ["-DTCV_CHAIN_OCC3=1"])
     if "--tsan" in sys.argv or os.environ.get("TCV_BUILD_TSAN") == "1":      # ThreadSanitizer over the host side: worker pool, plan caches, block pool

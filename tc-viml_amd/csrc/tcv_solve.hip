@@ -1397,13 +1397,15 @@ __device__ __forceinline__ void panel_tile_mfma(lds_d *T, const lds_d *TK, const
     }
     v4f64 y1 = {0.0, 0.0, 0.0, 0.0}, r;
 #pragma unroll
-    for (int i = 0; i < 4; i++) r[i] = T[sw(col, row0 + 4 * i)];     // A' in the accumulator layout: rows row0 + 4 i of column col
+    for (int i = 0; i < 4; i++) r[i] = at[i];                        // A' in the accumulator layout (rows row0 + 4 i of column col) IS the B operand just loaded
 #pragma unroll
     for (int kk = 0; kk < 4; kk++) y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(li[kk], at[kk], y1, 0, 0, 0);
+#ifndef TCV_PANEL_NOREFINE      // (A/B build `build.py --norefine`: the product with the explicit inverse alone, as up to round 5)
 #pragma unroll
     for (int kk = 0; kk < 4; kk++) r = __builtin_amdgcn_mfma_f64_16x16x4f64(ll[kk], y1[kk], r, 0, 0, 0);
 #pragma unroll
     for (int kk = 0; kk < 4; kk++) y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(li[kk], r[kk], y1, 0, 0, 0);
+#endif
 #pragma unroll
     for (int i = 0; i < 4; i++) T[sw(col, row0 + 4 * i)] = y1[i];    // X = Y'
 }
