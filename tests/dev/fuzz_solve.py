@@ -79,12 +79,22 @@ def thin_lines(rng, w, frac):
 
 def make_case(rng, seed):
     pre, main, z = golden_windows()
-    kind = rng.choice(["main", "pre", "synth", "synth", "short"])
+    # (seeds from 100000 on also draw `chained`: a synthetic window on the prior the ORACLE makes from the window one frame earlier -- priors of
+    # many layouts next to every mutation; the list below 100000 is unchanged so that the recorded seed ranges keep their cases)
+    kind = rng.choice(["main", "pre", "synth", "synth", "short"] + (["chained", "chained", "chained"] if seed >= 100000 else []))
     notes = [str(kind)]
     if kind == "main":
         w = dict(main)
     elif kind == "pre":
         w = dict(pre)
+    elif kind == "chained":
+        nl = int(rng.choice([3, 17, 50, 120, 200])); nn = int(rng.choice([1, 7, 40, 100]))
+        before = dict(synth.window_at(synth.make_windows(40000 + seed, 1, n_landmarks=nl, n_lines=nn, frame_shift=-1), 0), prior=None)
+        Op = orc.Window(before); Op.solve(8, True); st = Op.states()
+        before = dict(before, pose=st["pose"], speedbias=st["sb"], ex_pose=st["ex"], lam=st["lam"])
+        po, _ = orc.Window(before).marginalize_old()
+        w = dict(synth.window_at(synth.make_windows(40000 + seed, 1, n_landmarks=nl, n_lines=nn), 0), prior=po)
+        notes.append(f"L{nl} n{nn} prior n={po['n']}")
     else:
         nl = int(rng.choice([1, 3, 17, 50, 120, 200, 290]))
         nn = int(rng.choice([0, 1, 7, 40, 100]))
