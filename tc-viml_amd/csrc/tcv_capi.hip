@@ -708,7 +708,8 @@ static void batch_free(tcv_batch *b) {
     tcv::dev_free(b->d_input);      // (d_dpool, d_win, d_plans, d_plan_base, d_ipool point into it)
     tcv::dev_free(b->d_imublk); tcv::dev_free(b->d_spill); tcv::dev_free(b->d_sqrt_out);
     tcv::dev_free(b->d_coop_ctl); tcv::dev_free(b->d_coop_x); tcv::dev_free(b->d_coop_exp);
-    tcv::dev_free(b->d_prof); tcv::dev_free(b->d_state); tcv::dev_free(b->d_delta); tcv::dev_free(b->d_scratch); tcv::dev_free(b->d_summary);
+    tcv::dev_free(b->d_zero); tcv::dev_free(b->d_state);      // (d_delta, d_scratch, d_summary, d_prof live inside d_zero)
+    b->d_zero = nullptr; b->d_prof = nullptr; b->d_delta = nullptr; b->d_scratch = nullptr; b->d_summary = nullptr;
     if (b->ev0) hipEventDestroy(b->ev0);
     if (b->ev1) hipEventDestroy(b->ev1);
     if (b->marg_free) b->marg_free(b);
@@ -1042,10 +1043,20 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
     }
     t_issue = std::chrono::steady_clock::now();
     UP(b->d_state, (double *)nullptr, double, (size_t)n * b->state_stride);
-    UP(b->d_delta, (double *)nullptr, double, (size_t)n * b->delta_stride);
-    UP(b->d_scratch, (double *)nullptr, double, (size_t)b->slots * scr);
-    UP(b->d_summary, (DevSummary *)nullptr, DevSummary, (size_t)n);
-    UP(b->d_prof, (double *)nullptr, double, (size_t)32 * b->slots);
+    // the four buffers that start as zeros share ONE allocation and one memset: four fill kernels of 4 - 5 us with their launch gaps sat between
+    // the upload and the frame's solve (a lock-step frame's GPU timeline, tools/r05_gpu_z43.sh: ~50 us of a 2.1 ms frame)
+    size_t zero_bytes = 0;
+    {
+        auto up256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
+        const size_t o_delta = 0, o_scr = up256(o_delta + sizeof(double) * std::max<size_t>(1, (size_t)n * b->delta_stride));
+        const size_t o_sum = up256(o_scr + sizeof(double) * std::max<size_t>(1, (size_t)b->slots * scr));
+        const size_t o_prof = up256(o_sum + sizeof(DevSummary) * std::max<size_t>(1, (size_t)n));
+        zero_bytes = up256(o_prof + sizeof(double) * std::max<size_t>(1, (size_t)32 * b->slots));
+        hipError_t e_ = tcv::dev_malloc(&b->d_zero, zero_bytes);
+        if (e_ != hipSuccess) { bail(); return hip_fail(e_, "hipMalloc"); }
+        char *z = (char *)b->d_zero;
+        b->d_delta = (double *)(z + o_delta); b->d_scratch = (double *)(z + o_scr); b->d_summary = (DevSummary *)(z + o_sum); b->d_prof = (double *)(z + o_prof);
+    }
     if (b->chain) {
         UP(b->d_imublk, (double *)nullptr, double, (size_t)b->slots * 16 * IMU_BLK);
         UP(b->d_spill, (double *)nullptr, double, (size_t)b->slots * b->spill_stride);
@@ -1057,10 +1068,7 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
     }
 #undef UP
     t_alloc = std::chrono::steady_clock::now();
-    e0 = hipMemsetAsync(b->d_prof, 0, sizeof(double) * 32 * b->slots, ust);
-    if (e0 == hipSuccess) e0 = hipMemsetAsync(b->d_scratch, 0, sizeof(double) * (size_t)b->slots * scr, ust);
-    if (e0 == hipSuccess) e0 = hipMemsetAsync(b->d_summary, 0, sizeof(DevSummary) * (size_t)n, ust);
-    if (e0 == hipSuccess) e0 = hipMemsetAsync(b->d_delta, 0, sizeof(double) * (size_t)n * b->delta_stride, ust);
+    e0 = hipMemsetAsync(b->d_zero, 0, zero_bytes, ust);
     {      // the batch is complete on the device before any stream uses it (and the upload is drained before its staging buffer is released, whatever the memsets returned)
         const hipError_t es = ust ? hipStreamSynchronize(ust) : hipDeviceSynchronize();
         if (e0 == hipSuccess) e0 = es;

@@ -1029,6 +1029,10 @@ static int optimize_begin(OptRun &R) {
         g.rc = tcv_batch_solve(g.b, &o, st);
         if (g.rc == TCV_OK) g.rc = tcv_batch_gauge_fix(g.b, st);
         if (g.rc == TCV_OK && g.any_marg && !marg_off_path) g.rc = tcv_batch_marginalize(g.b, st);
+        // the copy of the states (and of the summary heads) goes on the stream right behind the gauge fix -- BEFORE the upload of the marginalisation
+        // problems attached below, which used to sit between them (a lock-step frame's GPU timeline: 10 us of upload, a fill and their launch gaps,
+        // ~35 us before the states left; tools/r05_gpu_z43.sh)
+        if (g.rc == TCV_OK && marg_off_path) { g.rc = tcv_batch_download_states_begin(g.b, st); g.dl_begun = g.rc == TCV_OK; }
     }
     if (marg_off_path) {      // the solve is on the device: the marginalisation problems of the frame, their packing and upload meanwhile
         for (int group = 1; group >= 0; group--) {
@@ -1071,8 +1075,7 @@ static int optimize_begin(OptRun &R) {
             if (g.idx.empty() || g.rc != TCV_OK) continue;
             const int nb = (int)g.idx.size();
             void *st = (void *)g_streams[group];
-            g.rc = tcv_batch_download_states_begin(g.b, st);
-            g.dl_begun = g.rc == TCV_OK;
+            if (!g.dl_begun) { g.rc = tcv_batch_download_states_begin(g.b, st); g.dl_begun = g.rc == TCV_OK; }
             g.newp.assign(nb, nullptr);
             const bool eager = defer_from <= 0 || nb < defer_from;
             if (g.rc == TCV_OK && g.any_marg && eager) {

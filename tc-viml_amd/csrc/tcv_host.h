@@ -178,6 +178,7 @@ struct tcv_batch {
     tcv::PlanHdr *d_plans = nullptr;
     long long *d_plan_base = nullptr;
     int *d_ipool = nullptr;
+    void *d_zero = nullptr;                  // one allocation, zeroed by one memset: [d_delta | d_scratch | d_summary | d_prof]
     double *d_dpool = nullptr, *d_state = nullptr, *d_delta = nullptr, *d_scratch = nullptr;
     tcv::DevSummary *d_summary = nullptr;
     double *d_prof = nullptr;
