@@ -188,7 +188,11 @@ namespace {
 // hipStreamSynchronize / hipEventRecord on a destroyed stream is an error (round-4 advisor finding).  The next new thread takes a parked
 // stream over, so the process never holds more streams than it had live threads at once -- which is what keeps two LIVE threads off one
 // hardware queue (see above).  Leaked on purpose, like the device pool.
-struct StreamPark { std::mutex mu; std::multimap<int, hipStream_t> idle; };
+// `orphans`: the buffers of commands a thread left in flight when it ended (defer_release), per stream; whoever takes the stream over waits
+// for it once and releases them.  The destructor below makes NO HIP call: it runs among the thread's TLS destructors,
+// where a profiler's own thread state may be gone already (rocprofv3 aborted in hipStreamSynchronize there -- "must be non nullptr" -- as soon
+// as a replay or the stream mode ran on more than one host thread; round 5).
+struct StreamPark { std::mutex mu; std::multimap<int, hipStream_t> idle; std::map<hipStream_t, std::vector<Deferred>> orphans; };
 StreamPark &stream_park() { static StreamPark *p = new StreamPark(); return *p; }
 hipStream_t take_parked_stream(int dev) {
     StreamPark &P = stream_park();
@@ -197,18 +201,20 @@ hipStream_t take_parked_stream(int dev) {
     if (it == P.idle.end()) return nullptr;
     hipStream_t st = it->second;
     P.idle.erase(it);
+    auto oi = P.orphans.find(st);
+    if (oi != P.orphans.end()) {      // what the stream's previous thread left in flight has long finished, as a rule: wait (here a HIP call is fine) and release
+        (void)hipStreamSynchronize(st);
+        for (auto &x : oi->second) { host_staging_release(x.h); (void)dev_free(x.d); }
+        P.orphans.erase(oi);
+    }
     return st;
 }
 ThreadStreams::~ThreadStreams() {
-    for (auto &kv : m) {
-        if (!kv.second) continue;
-        if (!main_thread || !deferred.empty()) (void)hipStreamSynchronize(kv.second);
-    }
-    for (auto &x : deferred) { host_staging_release(x.h); (void)dev_free(x.d); }
-    if (main_thread) return;      // (the main thread's streams are left to the runtime's own teardown at process exit)
-    for (auto &kv : aux) if (kv.second) (void)hipStreamSynchronize(kv.second);
+    if (main_thread) return;      // (the main thread's streams and whatever it left in flight go with the runtime's own teardown at process exit)
     StreamPark &P = stream_park();
     std::lock_guard<std::mutex> g(P.mu);
+    for (auto &x : deferred) P.orphans[x.st].push_back(x);      // still in flight, possibly: released by the stream's next owner after its first wait
+    deferred.clear();
     for (auto &kv : m) if (kv.second) P.idle.emplace(kv.first, kv.second);
     for (auto &kv : aux) if (kv.second) { bool own = true; for (auto &k2 : m) if (k2.second == kv.second) own = false; if (own) P.idle.emplace(kv.first, kv.second); }
 }
