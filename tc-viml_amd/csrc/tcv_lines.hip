@@ -119,11 +119,18 @@ __global__ void lines_fov_kernel(const LineArgs *tab, const int *first, int ncal
     A.in_fov[i] = (s || e) ? 1 : 0;
 }
 
-// LineCorrespondenceInFrame: one wavefront per detected line
-__global__ void __launch_bounds__(64) lines_match_kernel(const LineArgs *tab, const int *first, int ncall) {
+// LineCorrespondenceInFrame: four wavefronts per detected line (a map of ~900 segments: 3 - 4 per lane instead of 14 -- the association is
+// a host round trip of every frame, and its kernel was 60 us alone, 270 us beside the solves of a 128-stream replay).  Each lane keeps the first
+// minimum of its own ascending walk; lanes, then wavefronts, are merged by (smallest distance, then smallest map index) = the first hit of the
+// reference's sequential scan, whatever the partition.
+enum { MATCH_NT = 256 };
+__global__ void __launch_bounds__(MATCH_NT) lines_match_kernel(const LineArgs *tab, const int *first, int ncall) {
     const int cidx = call_of_block(first, ncall, (int)blockIdx.x);
     const LineArgs A = tab[cidx];
-    const int q = (int)blockIdx.x - first[cidx], lane = threadIdx.x;
+    const int q = (int)blockIdx.x - first[cidx], lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ float s_best[MATCH_NT / 64], s_angle[MATCH_NT / 64], s_ov[MATCH_NT / 64];
+    __shared__ int s_j[MATCH_NT / 64];
+    __shared__ double s_p[MATCH_NT / 64][4];
     const int f = A.det_frame[q];
     const double *dv = A.det + 4 * (size_t)q;
     const L2 det = make_l2(dv[0], dv[1], dv[2], dv[3]);
@@ -134,7 +141,7 @@ __global__ void __launch_bounds__(64) lines_match_kernel(const LineArgs *tab, co
     int best_j = 0x7fffffff;
     double bp[4] = {dv[0], dv[1], dv[2], dv[3]};
     int any_fov = 0;
-    for (int j = lane; j < A.n_map; j += 64) {
+    for (int j = (int)threadIdx.x; j < A.n_map; j += MATCH_NT) {
         if (!A.in_fov[(size_t)f * A.n_map + j]) continue;
         any_fov = 1;
         const double *l = A.map + 6 * (size_t)j;
@@ -198,7 +205,16 @@ __global__ void __launch_bounds__(64) lines_match_kernel(const LineArgs *tab, co
             for (int k = 0; k < 4; k++) bp[k] = op[k];
         }
     }
-    if (lane == 0) {
+    if (lane == 0) { s_best[wave] = best; s_j[wave] = best_j; s_angle[wave] = b_angle; s_ov[wave] = b_ov; for (int k = 0; k < 4; k++) s_p[wave][k] = bp[k]; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < MATCH_NT / 64; w++) {
+            const float ob = s_best[w]; const int oj = s_j[w];
+            if (oj != 0x7fffffff && (best_j == 0x7fffffff || ob < best || (ob == best && oj < best_j))) {
+                best = ob; best_j = oj; b_angle = s_angle[w]; b_ov = s_ov[w];
+                for (int k = 0; k < 4; k++) bp[k] = s_p[w][k];
+            }
+        }
         const bool hit = best_j != 0x7fffffff;
         A.match[q] = hit ? best_j : -1;
         A.err[3 * q] = hit ? b_angle : -1.0f; A.err[3 * q + 1] = hit ? best : -1.0f; A.err[3 * q + 2] = hit ? b_ov : -1.0f;
@@ -327,7 +343,7 @@ extern "C" int tcv_match_lines_batch(int n, const tcv_match_lines_args *args) {
     if (e == hipSuccess) {
         // (a call without blocks has first[c] == first[c + 1]: the search returns the LAST call whose first block is <= the block, i.e. the one that owns it)
         if (fov_blocks > 0) hipLaunchKernelGGL(lines_fov_kernel, dim3(fov_blocks), dim3(256), 0, st, (const LineArgs *)(dv + o_tab), (const int *)(dv + o_ff), n);
-        if (det_blocks > 0) hipLaunchKernelGGL(lines_match_kernel, dim3(det_blocks), dim3(64), 0, st, (const LineArgs *)(dv + o_tab), (const int *)(dv + o_mf), n);
+        if (det_blocks > 0) hipLaunchKernelGGL(lines_match_kernel, dim3(det_blocks), dim3(MATCH_NT), 0, st, (const LineArgs *)(dv + o_tab), (const int *)(dv + o_mf), n);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(h + in_total, dv + in_total, fov_total + out_total, hipMemcpyDeviceToHost, st);
