@@ -220,7 +220,10 @@ int tcv_solve(const tcv_solver_options *o, tcv_problem *p, tcv_solver_summary *s
 /* ---- MarginalizationInfo surface (marginalization_factor.cpp:89-321, estimator.cpp:1913-2044) -- */
 /* `p` holds exactly the factors the reference would wrap in ResidualBlockInfo; `drop` lists the
  * parameter blocks of the drop_sets.  Equivalent to addResidualBlockInfo* + preMarginalize +
- * marginalize.  The new prior keeps the current values of the kept blocks as linearisation point. */
+ * marginalize.  The new prior keeps the current values of the kept blocks as linearisation point.
+ * A marginalisation that keeps nothing (every block its factors touch is dropped) returns a prior with n = 0 and no blocks, like the
+ * reference's empty MarginalizationInfo (marginalization_factor.cpp:174-194); tcv_problem_add_marginalization_factor accepts it as a
+ * factor without residuals (estimator.cpp:1714-1720), tcv_prior_create builds one from n = 0, num_blocks = 0. */
 int tcv_marginalize(tcv_problem *p, double *const *drop, int num_drop, tcv_prior **out);
 /* MarginalizationInfo fields: m, n, keep_block_size/idx/data, linearized_jacobians (n x n,
  * column-major like Eigen::MatrixXd), linearized_residuals (marginalization_factor.h:57-70).
@@ -421,7 +424,8 @@ int tcv_eval_imu_factors(int n, const tcv_imu_preintegration *pre, const double 
 int tcv_eval_projection_factors(int n, const double *pts, const double *params, double sqrt_info,
                                 double *residuals, double *jacobians);
 /* ProjectionTdFactor::Evaluate projection_td_factor.cpp:34-140 (camera-IMU time offset + rolling shutter; selected by ESTIMATE_TD,
- * estimator.cpp:1757, which is 0 in every shipped configuration -- the fused solver does not take this factor yet):
+ * estimator.cpp:1757, which is 0 in every shipped configuration; the fused solver takes it through tcv_problem_add_projection_td_factor /
+ * tcv_window::para_td above -- this entry point is the per-factor parity check):
  * params n x (7+7+7+1+1) = pose_i, pose_j, ex_pose, inverse depth, td; pts n x 6; aux n x 8 = velocity_i xy, velocity_j xy, td_i,
  * td_j, row_i, row_j (constructor arguments, :6-18); TR / ROW = rolling-shutter read-out time / image height (parameters.cpp:92,145);
  * residuals n x 2, jacobians n x (14+14+14+2+2) */

@@ -428,7 +428,10 @@ extern "C" int tcv_problem_add_line_factor(tcv_problem *p, const double ps[3], c
     return TCV_OK;
 }
 extern "C" int tcv_problem_add_marginalization_factor(tcv_problem *p, const tcv_prior *prior, double *const *blocks, int n) {
-    if (!p || !prior || !blocks || n != (int)prior->size.size()) { set_error("add_marginalization_factor: block count mismatch"); return TCV_ERR_INVALID; }
+    if (!p || !prior || n != (int)prior->size.size() || (n > 0 && !blocks)) { set_error("add_marginalization_factor: block count mismatch"); return TCV_ERR_INVALID; }
+    // the prior of a marginalisation that kept nothing (n = 0): the reference adds a MarginalizationFactor with no residuals over no blocks
+    // (estimator.cpp:1714-1720 on the empty MarginalizationInfo of marginalization_factor.cpp:174-194) -- accepted, contributes nothing
+    if (prior->n == 0) return TCV_OK;
     PriorFac f;
     f.prior = prior;
     for (int k = 0; k < n; k++) {
@@ -506,17 +509,21 @@ extern "C" int tcv_problems_pack_bench(tcv_problem *const *problems, int n, int 
     int frame = n;
     if (const char *e = getenv("TCV_PACK_BENCH_FRAME")) { const int v = atoi(e); if (v > 0) frame = std::min(n, v); }
     std::vector<int> rcs(n, TCV_OK);
+    std::vector<std::string> msgs(n);
     const auto t0 = std::chrono::steady_clock::now();
     for (int b = 0; b < n; b += frame) {
         const int m = std::min(frame, n - b), nth = std::max(1, std::min(threads, m));
         std::vector<Packed> packed(m);
-        auto one = [&](int w) { rcs[b + w] = pack_problem(*problems[b + w], packed[w], nullptr, g_solver_variant, coop_chunks > 0 ? (int)LDS_DOUBLES : 0, true, coop_chunks); };
+        auto one = [&](int w) {
+            rcs[b + w] = pack_problem(*problems[b + w], packed[w], nullptr, g_solver_variant, coop_chunks > 0 ? (int)LDS_DOUBLES : 0, true, coop_chunks);
+            if (rcs[b + w] != TCV_OK) msgs[b + w] = tcv_last_error();      // (the text is per thread: a worker's is carried over to the caller below)
+        };
         if (getenv("TCV_PACK_BENCH_STRIDED")) tcv::parallel_run(nth, [&](int t) { for (int w = t; w < m; w += nth) one(w); });      // (a fixed share per thread: up to round 5)
         else tcv::parallel_items(m, nth, [&](int w, int) { one(w); });
     }
     *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (getenv("TCV_DEBUG_PACK2")) tcv::pack_laps_print();
-    for (int w = 0; w < n; w++) if (rcs[w] != TCV_OK) return rcs[w];
+    for (int w = 0; w < n; w++) if (rcs[w] != TCV_OK) { set_error(msgs[w]); return rcs[w]; }
     return TCV_OK;
 }
 extern "C" int tcv_plan_cache_stats(long long *out4) {
@@ -532,7 +539,7 @@ extern "C" int tcv_problem_from_window(const tcv_window_desc *w, tcv_problem **o
     if (!w || !out || w->n_frames <= 0 || !w->para_pose || !w->para_speedbias || !w->para_ex_pose || (w->n_imu > 0 && (!w->imu || !w->imu_frame_i || !w->imu_frame_j)) ||
         (w->n_proj > 0 && (!w->proj_pts || !w->proj_frame_i || !w->proj_frame_j || !w->proj_feature || !w->para_feature)) ||
         (w->n_line > 0 && (!w->line_data || !w->line_frame)) ||
-        (w->prior && (!w->prior_block_kind || !w->prior_block_index)) || w->n_imu < 0 || w->n_proj < 0 || w->n_line < 0 ||
+        (w->prior && w->prior->n > 0 && (!w->prior_block_kind || !w->prior_block_index)) || w->n_imu < 0 || w->n_proj < 0 || w->n_line < 0 ||
         (w->para_td && w->n_proj > 0 && !w->proj_td_aux) || (w->para_td && !(w->td_ROW > 0.0))) {
         set_error("problem_from_window: missing array in the window description");
         return TCV_ERR_INVALID;
@@ -629,6 +636,12 @@ extern "C" int tcv_problem_from_window(const tcv_window_desc *w, tcv_problem **o
 // =====================================================================================================
 extern "C" int tcv_prior_create(tcv_prior **out, int m, int n, int nb, const int *size, const int *idx, const double *x0,
                                 const double *J0, const double *r0) {
+    if (out && n == 0 && nb == 0 && m >= 0) {      // the empty MarginalizationInfo of a marginalisation that kept nothing (tcv_marginalize can return one)
+        tcv_prior *pr = new tcv_prior();
+        pr->m = m;
+        *out = pr;
+        return TCV_OK;
+    }
     if (!out || n <= 0 || nb <= 0 || m < 0 || !size || !idx || !x0 || !J0 || !r0) { set_error("prior_create: bad argument"); return TCV_ERR_INVALID; }
     // the kernels index fixed-size (128-entry) dx / residual buffers by keep_block_idx: a malformed layout must not reach the device
     if (n > 128) { set_error("prior_create: more than 128 rows"); return TCV_ERR_TOO_LARGE; }

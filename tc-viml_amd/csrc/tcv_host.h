@@ -131,11 +131,12 @@ struct AddrIndex {
     size_t used = 0;
     static size_t h(const double *a) { size_t x = (size_t)a >> 3; x *= 0x9E3779B97F4A7C15ull; return x >> 17; }
     int find(double *a) const {
-        if (tab.empty()) return -1;
+        if (!a || tab.empty()) return -1;      // nullptr marks an empty slot: a NULL key must never match one
         const size_t m = tab.size() - 1;
         for (size_t i = h(a) & m;; i = (i + 1) & m) { if (tab[i].first == a) return tab[i].second; if (!tab[i].first) return -1; }
     }
     void put(double *a, int v) {
+        if (!a) return;                          // callers reject NULL addresses before they get here (tcv_problem_add_parameter_block)
         if (2 * (used + 1) > tab.size()) grow();
         const size_t m = tab.size() - 1;
         for (size_t i = h(a) & m;; i = (i + 1) & m) { if (tab[i].first == a) { tab[i].second = v; return; } if (!tab[i].first) { tab[i] = {a, v}; used++; return; } }

@@ -1825,6 +1825,9 @@ struct MargWindow {
     std::vector<int> keep_size, keep_idx, keep_goff;
     std::vector<double *> keep_addr;
     int m_total = 0;                  // all dropped tangent dims (landmarks included), the reference's m
+    bool empty_keep = false;          // every block the factors touch is dropped (n = 0): nothing runs on the device, the result is the reference's
+                                      // empty MarginalizationInfo (marginalization_factor.cpp:174-194 with n = pos - m = 0; carried into the next frame
+                                      // by estimator.cpp:2040-2043, where its factor has no residuals and no blocks)
 };
 struct MargState {
     std::vector<MargWindow> win;
@@ -1868,6 +1871,7 @@ static size_t marg_lds_doubles(int pos, int m, int n, int nx, int cb_in_r2 = 0) 
     return (size_t)((r1 + 1) & ~1) + ((r2 + 1) & ~1) + MARG_MAX_POS + ((nx + 7) & ~7) + 160 + MARG_MAX_N + MARG_MAX_POS + 8 + MARG_SM;
 }
 
+enum { MARG_PACK_EMPTY_KEEP = 1 };      // pack_marg: the marginalisation keeps nothing (MargWindow::empty_keep); not an error
 static int pack_marg(const tcv_problem &p, double *const *drop, int ndrop, const tcv_problem *solve_p, const Packed *solve_pk,
                      MargWindow &mw, std::vector<int> &I, std::vector<double> &D) {
     const int nb = (int)p.blocks.size();
@@ -1939,7 +1943,8 @@ static int pack_marg(const tcv_problem &p, double *const *drop, int ndrop, const
         pos += pb.kind == KIND_POSE ? 6 : pb.size;
     }
     const int n = pos - m;
-    if (m_all < 1 || n < 1) { set_error("marginalize: nothing to drop or nothing to keep"); return TCV_ERR_INVALID; }
+    if (m_all < 1) { set_error("marginalize: nothing to drop"); return TCV_ERR_INVALID; }
+    if (n < 1) { mw.m_total = m_all; mw.empty_keep = true; return MARG_PACK_EMPTY_KEEP; }      // (the caller writes a header the kernel skips)
     if (block_mode && m < 1) { set_error("marginalize: block mode needs a non-landmark block in the dropped set"); return TCV_ERR_UNSUPPORTED; }
     mw.m_total = m_all;
     if (m > MARG_MAX_M || n > MARG_MAX_N || nx > MARG_MAX_X || p.imu.size() > 16) {
@@ -2233,14 +2238,16 @@ int tcv_marg_attach(tcv_batch *b, tcv_problem *const *marg_problems, double *con
     auto work = [&](int t) {
         const auto r = range(t);
         for (int w = r.first; w < r.second; w++) {
-            if (!marg_problems[w]) {      // this window is not marginalised: an empty header (nblk = 0), which the kernel skips
+            auto skip_header = [&]() {      // an empty header (nblk = 0), which the kernel skips
                 MargHdr &H = s->win[w].hdr;
                 std::memset(&H, 0, sizeof H);
                 H.ibase = (long long)It[t].size(); H.dbase = (long long)Dt[t].size();
                 H.sqrt_src = -1; H.prior_abs = -1; H.imu_abs = -1; H.cb_off = -1; H.td_blk = -1; H.solve_window = w;
-                continue;
-            }
+            };
+            if (!marg_problems[w]) { skip_header(); continue; }      // this window is not marginalised
+            const size_t i0 = It[t].size(), d0 = Dt[t].size();
             const int rc = pack_marg(*marg_problems[w], marg_drop[w], marg_num_drop[w], b->problems[w], &b->packed[w], s->win[w], It[t], Dt[t]);
+            if (rc == MARG_PACK_EMPTY_KEEP) { It[t].resize(i0); Dt[t].resize(d0); skip_header(); continue; }      // keeps nothing: an empty prior comes back
             if (rc != TCV_OK) { rcs[t] = rc; msgs[t] = tcv_last_error(); return; }
             s->win[w].hdr.solve_window = w;
         }
@@ -2374,7 +2381,7 @@ int tcv_marg_layout_n(const tcv_batch *b, int window) {
 }
 bool tcv_marg_has_problem(const tcv_batch *b, int window) {
     const MargState *s = (const MargState *)b->marg;
-    return s && window >= 0 && window < b->n && s->win[window].hdr.nblk != 0;
+    return s && window >= 0 && window < b->n && (s->win[window].hdr.nblk != 0 || s->win[window].empty_keep);
 }
 int tcv_marg_sqrt_source(const tcv_batch *b, int window) {
     const MargState *s = (const MargState *)b->marg;
@@ -2421,7 +2428,8 @@ extern "C" int tcv_batch_marg_status(tcv_batch *b, int *out, int n) {
         const hipError_t e = hipMemcpy(st.data(), s->d_status, sizeof(int) * st.size(), hipMemcpyDeviceToHost);
         if (e != hipSuccess) return hip_fail(e, "hipMemcpy D2H");
     }
-    for (int w = 0; w < n; w++) out[w] = (st[w] == 0 && st[b->n + w] < 0 && s->win[w].hdr.nblk != 0) ? -2 : st[w];      // -2: a NaN in the result
+    for (int w = 0; w < n; w++)      // -2: a NaN in the result; a marginalisation that keeps nothing has nothing to run: 0
+        out[w] = s->win[w].empty_keep ? 0 : ((st[w] == 0 && st[b->n + w] < 0 && s->win[w].hdr.nblk != 0) ? -2 : st[w]);
     return TCV_OK;
 }
 
@@ -2429,6 +2437,7 @@ int tcv_marg_get_prior(tcv_batch *b, int window, tcv_prior **out) {
     MargState *s = (MargState *)b->marg;
     if (!s || !s->ran || window < 0 || window >= b->n) { set_error("no marginalisation result for this window"); return TCV_ERR_INVALID; }
     const MargWindow &mw = s->win[window];
+    if (mw.empty_keep) { tcv_prior *pr = new tcv_prior(); pr->m = mw.m_total; pr->n = 0; *out = pr; return TCV_OK; }      // the reference's empty MarginalizationInfo
     if (mw.hdr.nblk == 0) { set_error("this window of the batch has no marginalisation problem"); return TCV_ERR_INVALID; }
     const int n = mw.hdr.n, m = mw.hdr.m;      // m: dropped dims that went through the eigen step (all of them unless block mode)
     std::vector<double> o(MARG_OUT_STRIDE);
@@ -2507,6 +2516,7 @@ int tcv_marg_get_priors_device(tcv_batch *b, tcv_prior **out, int n, bool nowait
     int rc = TCV_OK;
     for (int w = 0; w < n && rc == TCV_OK; w++) {
         const MargWindow &mw = s->win[w];
+        if (mw.empty_keep) { tcv_prior *pr = new tcv_prior(); pr->m = mw.m_total; pr->n = 0; out[w] = pr; continue; }      // empty prior: host-resident, nothing to splice
         if (mw.hdr.nblk == 0) continue;      // not marginalised: out[w] stays NULL
         const int status = st[w], k0 = st[n + w];
         if (status < 0) { set_error("marginalisation kernel did not complete for this window"); rc = TCV_ERR_NUMERIC; break; }

@@ -333,7 +333,7 @@ class Window:
         if prior is None and win.get("prior") is not None:
             self.prior = Prior.from_dict(win["prior"])
         if self.prior is not None:
-            blocks = win["prior"]["blocks"] if win.get("prior") is not None else self.prior_blocks
+            blocks = win["prior"]["blocks"] if win.get("prior") is not None else getattr(self, "prior_blocks", [])      # (an empty prior, n = 0, has none)
             self._pk = i32([_KIND[b[0]] for b in blocks]); self._pidx = i32([b[1] for b in blocks])
             d.prior = self.prior.h; d.prior_block_kind = iptr(self._pk); d.prior_block_index = iptr(self._pidx)
         self.desc = d

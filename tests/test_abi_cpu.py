@@ -121,6 +121,32 @@ def test_error_paths(tcv):
     assert L.tcv_problem_plan_stats(w.h, tcv.iptr(out)) == tcv.TCV_ERR_NUMERIC
 
 
+def test_null_addresses_are_rejected_not_resolved_to_block_zero(tcv):
+    """A NULL parameter-block address never names a block (ceres::Problem CHECKs on it): the open-addressing index marks empty slots with
+    nullptr, so a NULL key used to match the first empty slot and come back as block 0 (round-5 advisor finding)."""
+    L = tcv.lib()
+    w = tcv.Window(synth.window_at(synth.make_windows(3, 1), 0))
+    null = C.POINTER(C.c_double)()
+    assert L.tcv_problem_set_parameter_block_constant(w.h, null) == tcv.TCV_ERR_INVALID
+    assert b"unknown block" in L.tcv_last_error()
+    assert L.tcv_problem_add_parameter_block(w.h, null, 7, tcv.TCV_PARAM_POSE) == tcv.TCV_ERR_INVALID
+    nf = w.desc.n_frames
+    PP = C.POINTER(C.c_double) * nf
+    pose_rows = [tcv.dptr(w.pose[i]) for i in range(nf)]
+    good = PP(*pose_rows)
+    assert L.tcv_problem_set_frames(w.h, nf, good, None) == 0
+    rows = list(pose_rows); rows[3] = null
+    assert L.tcv_problem_set_frames(w.h, nf, PP(*rows), None) == tcv.TCV_ERR_INVALID and b"unknown pose block" in L.tcv_last_error()
+    # a marginalisation factor over a NULL block
+    n = 6
+    pr = C.c_void_p()
+    size = tcv.i32(np.array([7])); idx = tcv.i32(np.array([0]))
+    assert L.tcv_prior_create(C.byref(pr), 0, n, 1, tcv.iptr(size), tcv.iptr(idx), tcv.dptr(np.zeros(7)), tcv.dptr(np.eye(n)), tcv.dptr(np.zeros(n))) == 0
+    blocks = (C.POINTER(C.c_double) * 1)(null)
+    assert L.tcv_problem_add_marginalization_factor(w.h, pr, blocks, 1) == tcv.TCV_ERR_INVALID
+    L.tcv_prior_destroy(pr)
+
+
 def test_window_description_is_validated_before_it_is_walked(tcv):
     """tcv_problem_from_window / tcv_batch_create: missing arrays and out-of-range frame / feature indices are reported as
     TCV_ERR_INVALID with a message, never dereferenced."""

@@ -576,3 +576,52 @@ def test_margin_old_with_no_landmark_anchored_in_the_oldest_frame(gpu):
     W, b = marg_batch(gpu, [w])
     As2, bs2 = b.prior(0).schur()
     assert b.prior(0).dims()[:2] == (15, po["n"]) and fro(As2, dbg["A_schur"]) < 5e-6 and fro(bs2, dbg["b_schur"]) < 5e-7
+
+
+def test_marginalisation_that_keeps_nothing_returns_the_references_empty_prior(gpu):
+    """Every block the factors touch is dropped: the reference's marginalize() runs with n = pos - m = 0 (marginalization_factor.cpp:174-194)
+    and the estimator carries the empty MarginalizationInfo into the next frame, where its factor has no residuals over no blocks
+    (estimator.cpp:2040-2043, :1714-1720).  Found by fuzz seed 1306 (frame 0 seen by line factors alone, its IMU factor left out); here: the
+    IMU factor (0, 1) alone, all four of its blocks dropped -- standalone, inside a batch next to ordinary windows, and the solve on it."""
+    L = gpu.lib()
+    w = {k: v for k, v in synth.window_at(synth.make_windows(905, 1), 0).items() if k != "prior"}
+    mw = gpu.margin_old_window(w)
+    none = np.zeros(0, int)
+    npj = len(mw["proj"]["frame_i"])
+    mw["proj"] = {k: (np.asarray(v)[none] if isinstance(v, np.ndarray) and v.shape[:1] == (npj,) else v) for k, v in mw["proj"].items()}
+    Wm = gpu.Window(mw)
+    dr = [Wm.block_ptr("pose", 0), Wm.block_ptr("sb", 0), Wm.block_ptr("pose", 1), Wm.block_ptr("sb", 1)]
+    arr = (gpu._dp * len(dr))(*dr)
+    h = C.c_void_p()
+    gpu.check(L.tcv_marginalize(Wm.h, arr, len(dr), C.byref(h)))
+    P = gpu.Prior(h)
+    assert P.dims() == (30, 0, 0, 0)                      # m = 6 + 9 + 6 + 9 dropped tangent dims, nothing kept
+    d = P.export()
+    assert d["sizes"] == [] and d["J0"].shape == (0, 0) and d["r0"].shape == (0,)
+    # the next frame's problem takes it as a factor without residuals: same solve as without a prior
+    W0 = gpu.Window(w); n_res0 = L.tcv_problem_num_residual_blocks(W0.h)
+    W1 = gpu.Window(w, prior=P)
+    assert L.tcv_problem_num_residual_blocks(W1.h) == n_res0
+    b = gpu.Batch([W0, W1]); b.solve(gpu.default_options(8, True)); b.synchronize(); b.download_states()
+    s = b.summaries()
+    assert s[0].final_cost == s[1].final_cost and np.array_equal(W0.pose, W1.pose)
+    # inside a batch: window 0 marginalises as usual, window 1 keeps nothing
+    w_ok = synth.window_at(synth.make_windows(906, 1, frame_shift=-1), 0)
+    Wk = gpu.Window(w_ok); mk = gpu.margin_old_window(w_ok); Mk = gpu.Window(mk, share=Wk)
+    We = gpu.Window(w); Me = gpu.Window(mw, share=We)
+    dre = [Me.block_ptr("pose", 0), Me.block_ptr("sb", 0), Me.block_ptr("pose", 1), Me.block_ptr("sb", 1)]
+    b2 = gpu.Batch([Wk, We], [Mk, Me], [gpu.margin_old_drops(Wk, mk), dre])
+    b2.solve(gpu.default_options(8, True)); b2.marginalize(); b2.synchronize()
+    st = np.zeros(2, np.int32)
+    gpu.check(L.tcv_batch_marg_status(b2.h, gpu.iptr(st), 2))
+    assert list(st) == [0, 0]
+    p0, p1 = b2.prior(0), b2.prior(1)
+    assert p0.dims()[1] > 0 and p1.dims() == (30, 0, 0, 0)
+    Wr = gpu.Window(w_ok); Mr = gpu.Window(mk, share=Wr)
+    b3 = gpu.Batch([Wr], [Mr], [gpu.margin_old_drops(Wr, mk)])
+    b3.solve(gpu.default_options(8, True)); b3.marginalize(); b3.synchronize()
+    assert np.array_equal(p0.export()["J0"], b3.prior(0).export()["J0"])      # the empty neighbour changes nothing for the others
+    # a prior built by hand with n = 0 (checkpoint of such a state)
+    h2 = C.c_void_p()
+    gpu.check(L.tcv_prior_create(C.byref(h2), 30, 0, 0, None, None, None, None, None))
+    assert gpu.Prior(h2).dims() == (30, 0, 0, 0)

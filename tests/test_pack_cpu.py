@@ -200,3 +200,35 @@ def test_items_of_a_parallel_section_are_each_run_once(tcv):
             os.environ.pop("TCV_PACK_BENCH_FRAME", None)
         else:
             os.environ["TCV_PACK_BENCH_FRAME"] = old
+
+
+def test_a_worker_threads_error_text_reaches_the_caller(tcv):
+    """tcv_last_error() is per thread: an error raised inside a parallel section (on one of the library's worker threads) has to be carried
+    over to the thread that made the call.  Twelve windows on eight threads, one of them too large for the LDS-resident solver."""
+    import ctypes as C
+    import threading
+    L = tcv.lib()
+    L.tcv_problems_pack_bench.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    Ws = [tcv.Window(w) for w in _replay_like_windows()[:12]]
+    # 13 frames: camera tangent dim 201 > 175, refused at the plan stage with a message (tests/test_abi_cpu.py)
+    bad = C.c_void_p(); L.tcv_problem_create(C.byref(bad))
+    poses = np.zeros((13, 7)); poses[:, 6] = 1; sbs = np.zeros((13, 9))
+    for i in range(13):
+        L.tcv_problem_add_parameter_block(bad, tcv.dptr(poses[i]), 7, tcv.TCV_PARAM_POSE)
+        L.tcv_problem_add_parameter_block(bad, tcv.dptr(sbs[i]), 9, tcv.TCV_PARAM_EUCLIDEAN)
+    hs = [w.h for w in Ws]; hs[7] = bad
+    arr = (C.c_void_p * len(hs))(*hs)
+    s = C.c_double()
+    res = {}
+
+    def call():      # from a fresh thread: its own error text starts empty, so whatever it reads afterwards was carried over
+        res["before"] = L.tcv_last_error()
+        res["rc"] = L.tcv_problems_pack_bench(arr, len(hs), 8, 0, C.byref(s))
+        res["msg"] = L.tcv_last_error()
+
+    for _ in range(4):      # (which thread claims window 7 is a race: a few rounds)
+        t = threading.Thread(target=call); t.start(); t.join()
+        assert res["before"] == b""
+        assert res["rc"] == tcv.TCV_ERR_TOO_LARGE
+        assert res["msg"] != b"", res
+    L.tcv_problem_destroy(bad)
