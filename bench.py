@@ -64,6 +64,17 @@ def algorithmic_bytes_per_iteration(n_imu, n_pt, n_ln, L, prior_n, prior_x0):
     return 8 * (S + n_imu * 287 + n_pt * 6 + n_ln * 9 + 21 + prior) + 4 * (4 * n_imu + 4 * n_pt + n_ln) + 8 * ((171 + L) + 1)
 
 
+def csrc_sha16() -> str:
+    """hash of the kernel sources (tools/profile_round.sh stores the same in profiles/counters.json): static counter figures are printed only
+    next to the sources they were measured on (the GPU box has no .git to ask)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "tc-viml_amd", "csrc", "*"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def shard_ids(rank: int, per_gpu: int) -> int:
     """first synthetic window id of a rank: disjoint seeds per rank, fixed work per GPU (weak scaling)."""
     return 100000 + rank * per_gpu
@@ -595,9 +606,13 @@ def run_solve(args, rank, world, local, dist):
                                           len(w0["lam"]), pr["n"], sum(pr["sizes"]))
     k_ms = float(np.mean(solve_ms)) if solve_ms else None
     m_ms = float(np.mean(marg_ms)) if marg_ms else None
-    # dominant kernel = the fused solve kernel: B windows x (initial linearisation + 8 iterations) per launch
-    units = B * (SOLVER_ITERATIONS + 1)
+    # dominant kernel = the fused solve kernel.  SURVEY.md 8(d)'s unit of work is ONE trust-region iteration (B x 8 per launch, the same unit
+    # as `iterations_per_s`): `achieved` / `frac` are quoted on it.  The kernel runs B x 9 linearisations for them (Ceres' iteration 0 is the
+    # initial linearisation; each reads the window's algorithmic bytes): the per-linearisation figure stands beside it.
+    units = B * SOLVER_ITERATIONS
+    lins = B * (SOLVER_ITERATIONS + 1)
     achieved = (bpi * units) / (k_ms * 1e-3) / 1e9 if k_ms else None
+    achieved_lin = (bpi * lins) / (k_ms * 1e-3) / 1e9 if k_ms else None
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # written by tools/pmc_traffic.py from a rocprofv3 --pmc run
     if os.path.exists(tfile):
@@ -609,7 +624,9 @@ def run_solve(args, rank, world, local, dist):
     out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                        "kernel": "tcv::solve_kernel", "algorithmic_bytes_per_iteration": bpi,
-                       "units_per_launch": units,
+                       "unit_of_work": "trust-region iteration (SURVEY.md 8(d)); same unit as iterations_per_s",
+                       "units_per_launch": units, "linearisations_per_launch": lins,
+                       "achieved_per_linearisation": achieved_lin, "frac_per_linearisation": (achieved_lin / HBM_PEAK_GBS) if achieved_lin else None,
                        "note": "fused FP64 solve: latency/issue bound, not HBM bound (DESIGN.md 4.1); frac is vs "
                                "the 8 TB/s HBM3E spec; traffic = PMC FETCH_SIZE x2 + WRITE_SIZE of profiles/pmc_traffic.json (static, from the committed profile run)"}
     # the same launches against the FP64 roof -- peak MEASURED on this device (tcv_microbench_fp64: dependence-free
@@ -620,21 +637,38 @@ def run_solve(args, rank, world, local, dist):
         ach = FLOPS_PER_ITERATION_CFG3 * units / (k_ms * 1e-3) / 1e12
         out["roofline_fp64"] = {"bound": "fp64", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                                 "peak_vector_fma": mb[0], "peak_mfma_f64_16x16x4": mb[1], "compute_units": int(mb[2]), "shader_clock_mhz": mb[3],
-                                "flops_per_iteration": FLOPS_PER_ITERATION_CFG3,
+                                "flops_per_iteration": FLOPS_PER_ITERATION_CFG3, "units_per_launch": units,
                                 "note": "peak = the better of the two micro-benchmarks run by this process on this device just now; flops = SURVEY.md 8(d)'s "
-                                        "algorithmic 3.3 MFLOP per iteration and window (dense reduced-camera solve), not the instructions the fused kernel issues"}
+                                        "algorithmic 3.3 MFLOP per iteration and window (dense reduced-camera solve), not the instructions the fused kernel issues "
+                                        "(those: `executed`, from the hardware counters of the committed profile run)"}
     # hardware counters of the same launch shape, from the committed profile run (tools/profile_round.sh): static, so they carry the commit
-    # they were taken at -- a stale figure is detectable
+    # AND a hash of the kernel sources they were taken at -- when tc-viml_amd/csrc/ has changed since, they are not printed (`"stale": true`)
     cfile = os.path.join(ROOT, "profiles", "counters.json")
     if os.path.exists(cfile):
         try:
             cj = json.load(open(cfile))
-            out["counters"] = {k: cj.get(k) for k in ("commit", "valu_active", "mfma_busy", "salu_per_valu", "waiting", "solve_kernel_hbm_bytes_per_launch",
-                                                      "solve_kernel_write_bytes_per_launch", "marg_kernel_hbm_bytes_per_launch", "source")}
-            out["mfma_busy"] = cj.get("mfma_busy"); out["valu_active"] = cj.get("valu_active")
-            if traffic is None:
-                out["roofline"]["traffic"] = cj.get("solve_kernel_hbm_bytes_per_launch")
-            out["roofline"]["traffic_commit"] = cj.get("commit")
+            stale = cj.get("csrc_sha16") != csrc_sha16()
+            if stale:
+                out["counters"] = {"stale": True, "commit": cj.get("commit"), "csrc_sha16": cj.get("csrc_sha16"), "csrc_sha16_now": csrc_sha16(),
+                                   "note": "profiles/counters.json was taken at other kernel sources than the ones this run was built from: figures withheld"}
+                out["roofline"]["traffic"] = None
+                out["roofline"]["traffic_stale"] = True
+            else:
+                out["counters"] = {k: cj.get(k) for k in ("commit", "csrc_sha16", "valu_active", "mfma_busy", "salu_per_valu", "waiting", "solve_kernel_hbm_bytes_per_launch",
+                                                          "solve_kernel_write_bytes_per_launch", "marg_kernel_hbm_bytes_per_launch", "wait_split", "mean_latency_cycles",
+                                                          "insts_per_launch", "l2_hit_rate", "source")}
+                out["counters"]["stale"] = False
+                out["mfma_busy"] = cj.get("mfma_busy"); out["valu_active"] = cj.get("valu_active")
+                if traffic is None:
+                    out["roofline"]["traffic"] = cj.get("solve_kernel_hbm_bytes_per_launch")
+                out["roofline"]["traffic_commit"] = cj.get("commit")
+                if "roofline_fp64" in out and cj.get("mfma_mops_f64_per_launch") and k_ms:
+                    mf = cj["mfma_mops_f64_per_launch"] * 512.0      # one MOPS unit = 512 flops (SQ_INSTS_VALU_MFMA_MOPS_F64)
+                    vu = (cj.get("valu_insts_per_launch") or 0.0) * 64 * 2
+                    out["roofline_fp64"]["executed"] = {"mfma_flops_per_launch": mf, "mfma_tflops": mf / (k_ms * 1e-3) / 1e12, "mfma_frac_of_peak": mf / (k_ms * 1e-3) / 1e12 / mb[1] if mb[1] else None,
+                                                        "valu_flops_per_launch_upper_bound": vu, "valu_tflops_upper_bound": vu / (k_ms * 1e-3) / 1e12,
+                                                        "note": "counters of the committed profile run over THIS run's kernel time; the matrix-core figure counts the zero padding of the 9- and 15-wide "
+                                                                "blocks in 16x16x4 tiles; the vector figure prices every VALU instruction as a 64-lane FMA (upper bound)"}
         except (OSError, ValueError):
             pass
     if world == 1 and not args.no_extras:
@@ -679,7 +713,7 @@ class ReplayEngine:
     share of the streams in lock step (one device batch per frame and group): while one group's kernels run, the others pack and
     upload.  Frames of ONE stream stay sequential (frame k + 1 needs frame k's states and prior).  A step = one frame of every stream."""
 
-    def __init__(self, tcv, replay, stream_ids, n_frames, features, lines, groups, local):
+    def __init__(self, tcv, replay, stream_ids, n_frames, features, lines, groups, local, num_iterations=SOLVER_ITERATIONS, solver_time=0.0):
         self.tcv, self.local = tcv, local
         seqs = list(replay.EUROC_SEQUENCES)
         streams = [replay.simulate_stream_euroc(seqs[s % len(seqs)], n_frames, start_s=(0.5 + 3.0 * (s // len(seqs))) % max(3.0, 33.0 - 0.1 * n_frames), max_features=features,
@@ -693,7 +727,7 @@ class ReplayEngine:
         self.pipelined = bool(os.environ.get("TCV_BENCH_PIPELINE")) and len(streams) >= 2 * G
         self.G = G
         H = 2 * G if self.pipelined else G
-        self.ls = [replay.NativeLockstep(streams[h::H], num_iterations=SOLVER_ITERATIONS) for h in range(H)] if streams else []
+        self.ls = [replay.NativeLockstep(streams[h::H], num_iterations=num_iterations, solver_time=solver_time) for h in range(H)] if streams else []
         for h, ls in enumerate(self.ls):
             ls.slot = (h // G) if self.pipelined else 0
         for ls in self.ls:
@@ -877,10 +911,43 @@ def replay_figures(tcv, local, streams=8, groups=2, steps=60, warmup=10):
     n = eng.run(steps)
     torch.cuda.synchronize()      # (the last frame's marginalisation is launched behind the states the call returns with)
     dt = time.perf_counter() - t0
-    return {"replay_windows_per_s": n / dt,
-            "replay_note": f"{streams} EuRoC-trajectory streams (60 features + 8 line tracks per frame, association in the loop) through the native estimator on "
-                           f"this GPU, {groups} host threads x {streams // max(1, groups)} streams in lock step, {steps} frames per stream: {1e3 * dt / steps:.2f} ms per frame of every stream "
-                           f"(bench.py --mode replay prints this as its value)"}
+    out = {"replay_windows_per_s": n / dt,
+           "replay_note": f"{streams} EuRoC-trajectory streams (60 features + 8 line tracks per frame, association in the loop) through the native estimator on "
+                          f"this GPU, {groups} host threads x {streams // max(1, groups)} streams in lock step, {steps} frames per stream: {1e3 * dt / steps:.2f} ms per frame of every stream "
+                          f"(bench.py --mode replay prints this as its value)"}
+    del eng
+    out["deployed_budget"] = deployed_budget_figures(tcv, replay, local, streams, groups, steps=max(20, steps // 2), warmup=warmup)
+    return out
+
+
+def deployed_budget_figures(tcv, replay, local, streams=8, groups=2, steps=30, warmup=10):
+    """The same replay on the solver budget the reference SHIPS (benchmark_publisher/config/V1_01_easy/sensor.yaml:85-86, estimator.cpp:1892-1897):
+    max_num_iterations 100, convergence tests on, max_solver_time 0.04 s (x 4/5 on frames that marginalise the oldest keyframe) -- every other
+    replay figure of this file uses 8 iterations.  Reports how the solves ended: a GPU window that needs its ~26 iterations is done long before
+    the 32 ms wall budget that cuts the reference's CPU solve short."""
+    import torch
+    eng = ReplayEngine(tcv, replay, list(range(streams)), replay.WINDOW_SIZE + 1 + warmup + steps, 60, 8, groups, local, num_iterations=100, solver_time=0.04)
+    eng.run(warmup)
+    torch.cuda.synchronize()
+    for ls in eng.ls:      # (only the timed frames are counted below)
+        ls._flush_raw()
+        for o in ls.outs:
+            o["log"].clear()
+    t0 = time.perf_counter()
+    n = eng.run(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    its, term = [], []
+    for ls in eng.ls:
+        for r in ls.results():
+            its += [e["iterations"] for e in r["log"]]; term += [e["termination"] for e in r["log"]]
+    its = np.array(its if its else [0]); term = np.array(term if term else [0])
+    names = {0: "no_convergence_cap_or_clock", 1: "gradient_tolerance", 2: "parameter_tolerance", 3: "function_tolerance", 4: "radius", 5: "failure"}
+    return {"windows_per_s": n / dt, "ms_per_frame": 1e3 * dt / steps, "max_num_iterations": 100, "max_solver_time_in_seconds": 0.04,
+            "max_solver_time_margin_old": 0.032, "iterations_mean": float(its.mean()), "iterations_max": int(its.max()),
+            "terminations": {names.get(int(k), str(int(k))): int((term == k).sum()) for k in np.unique(term)}, "windows": int(len(its)),
+            "note": f"{streams} streams / {groups} host threads as replay_windows_per_s; iterations = summary.iterations.size() (iteration 0 included); a lock-step frame "
+                    "is one batch with one budget: 0.032 s as soon as one of its windows is MARGIN_OLD (include/tcv_estimator.h)"}
 
 
 def main():

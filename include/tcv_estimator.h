@@ -38,6 +38,10 @@ typedef struct {
     int fixed_iterations;       /* 1: exactly num_iterations trust-region iterations (deterministic) */
     int line_exact_jacobian;    /* 0: the reference's line Jacobian (default); 1: tcv_problem_set_line_jacobian(p, 1), see tcv.h */
     int pad_;
+    double solver_time;         /* SOLVER_TIME (sensor.yaml:85 max_solver_time, 0.04 s shipped): the wall budget of a window's solve,
+                                   options.max_solver_time_in_seconds of estimator.cpp:1894-1897 -- x 4/5 when the frame marginalises the oldest
+                                   frame.  A lock-step frame is ONE batch with ONE budget: as soon as any of its windows is MARGIN_OLD the
+                                   whole frame runs on the tighter 4/5 budget.  <= 0 (default) or fixed_iterations: no clock (deterministic) */
 } tcv_estimator_config;
 
 /* per-frame statistics of the last optimised window */
@@ -45,6 +49,8 @@ typedef struct {
     int marg_flag;              /* 0 MARGIN_OLD, 1 MARGIN_SECOND_NEW */
     int n_landmarks, n_proj, n_line, n_line_obs;
     int iterations, prior_n;    /* iterations = summary.iterations.size() of the window's solve (what estimator.cpp:1902 logs) */
+    int termination;            /* tcv_solver_summary::termination of that solve: 0 NO_CONVERGENCE (iteration cap or the solver_time budget), 1 gradient,
+                                   2 parameter, 3 function tolerance, 4 radius, 5 FAILURE (this slot was padding until round 5: same size and offsets) */
     double final_cost;
 } tcv_estimator_stats;
 

@@ -52,6 +52,10 @@ def build(force: bool = False, verbose: bool = False, profile: bool = False, abl
     skip phases (TCV_ABLATE_SKIP bit mask): developer tools.  sanitize=True builds libtcv_hip_san.so: the HOST side (packer, C-ABI,
     native estimator, host halves of the .hip files) under AddressSanitizer + UndefinedBehaviorSanitizer -- the device pass ignores
     the flags (GPU sanitizers are not available on this pool); tests/test_sanitize_cpu.py drives it without a device."""
+    # developer builds with arbitrary switches: python tc-viml_amd/build.py --suffix=lin3 -DTCV_ABLATE_CONST=0x... -DTCV_CHAIN_OCC=3  ->  libtcv_hip_lin3.so
+    sfx = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--suffix=")]
+    if sfx:
+        return _compile(os.path.join(HERE, "libtcv_hip_%s.so" % sfx[0]), verbose, [a for a in sys.argv if a.startswith("-D")])
     if "--occ1" in sys.argv:      # developer A/B build: chain kernel at one wavefront per SIMD (no register spills), see tcv_solve.hip
         return _compile(os.path.join(HERE, "libtcv_hip_occ1.so"), verbose, ["-DTCV_CHAIN_OCC1=1"])
     if "--margocc1" in sys.argv:  # developer A/B build: marginalisation kernel at one wavefront per SIMD (no register spills), tools/r05_marg_spill_ab.sh

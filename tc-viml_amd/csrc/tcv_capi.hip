@@ -1063,7 +1063,7 @@ extern "C" int tcv_batch_create(tcv_batch **out, tcv_problem *const *problems, t
     t_issue = std::chrono::steady_clock::now();
     UP(b->d_state, (double *)nullptr, double, (size_t)n * b->state_stride);
     // the four buffers that start as zeros share ONE allocation and one memset: four fill kernels of 4 - 5 us with their launch gaps sat between
-    // the upload and the frame's solve (a lock-step frame's GPU timeline, tools/r05_gpu_z43.sh: ~50 us of a 2.1 ms frame)
+    // the upload and the frame's solve (a lock-step frame's GPU timeline, tools/gpu_calls.md#r05_gpu_z43: ~50 us of a 2.1 ms frame)
     size_t zero_bytes = 0;
     {
         auto up256 = [](size_t v) { return (v + 255) & ~(size_t)255; };

@@ -1025,13 +1025,18 @@ static int optimize_begin(OptRun &R) {
         tcv_solver_options o;
         tcv_solver_options_default(&o);
         o.max_num_iterations = es[0]->cfg.num_iterations; o.fixed_iterations = es[0]->cfg.fixed_iterations;
+        if (es[0]->cfg.solver_time > 0.0 && !o.fixed_iterations) {      // estimator.cpp:1894-1897 (one budget per batch: include/tcv_estimator.h)
+            bool any_old = false;
+            for (int i : g.idx) any_old = any_old || es[i]->marg_flag == MARGIN_OLD;
+            o.max_solver_time_in_seconds = es[0]->cfg.solver_time * (any_old ? 4.0 / 5.0 : 1.0);
+        }
         void *st = (void *)g_streams[group];
         g.rc = tcv_batch_solve(g.b, &o, st);
         if (g.rc == TCV_OK) g.rc = tcv_batch_gauge_fix(g.b, st);
         if (g.rc == TCV_OK && g.any_marg && !marg_off_path) g.rc = tcv_batch_marginalize(g.b, st);
         // the copy of the states (and of the summary heads) goes on the stream right behind the gauge fix -- BEFORE the upload of the marginalisation
         // problems attached below, which used to sit between them (a lock-step frame's GPU timeline: 10 us of upload, a fill and their launch gaps,
-        // ~35 us before the states left; tools/r05_gpu_z43.sh)
+        // ~35 us before the states left; tools/gpu_calls.md#r05_gpu_z43)
         if (g.rc == TCV_OK && marg_off_path) { g.rc = tcv_batch_download_states_begin(g.b, st); g.dl_begun = g.rc == TCV_OK; }
     }
     if (marg_off_path) {      // the solve is on the device: the marginalisation problems of the frame, their packing and upload meanwhile
@@ -1243,7 +1248,7 @@ static int optimize_end(OptRun &R) {
                 T.iterations = g.sum[k].num_iterations; T.final_cost = g.sum[k].final_cost; T.applied = 1;
             }
             e->stats.marg_flag = e->marg_flag; e->stats.n_landmarks = (int)e->sel.size(); e->stats.n_proj = (int)e->w_pi.size(); e->stats.n_line = (int)e->w_lf.size();
-            e->stats.n_line_obs = e->n_line_obs_total; e->stats.iterations = g.sum[k].num_iterations; e->stats.final_cost = g.sum[k].final_cost;
+            e->stats.n_line_obs = e->n_line_obs_total; e->stats.iterations = g.sum[k].num_iterations; e->stats.termination = g.sum[k].termination; e->stats.final_cost = g.sum[k].final_cost;
             if (g.dm[k] && g.deferred) { }      // (the new prior is taken at the start of the next frame; stats.prior_n was set with the hand-over above)
             else if (g.dm[k]) {
                 const int rc = take_prior(e, g.newp[k], e->marg_flag);

@@ -93,7 +93,7 @@ struct MargArgs {
     double *scratch;             // per workgroup MARG_SCR_STRIDE
     int nwin, state_stride, use_solved_state;
     int eig_mm;                  // 1: Amm^+ through the eigen-decomposition for every window (TCV_MARG_EIG_MM=1: A/B checks)
-    int eig_flags;               // developer A/B switches of the eigen-solver of A' (TCV_MARG_EIG_FLAGS): 1 = round 2's eigenvalue search (every eigenvalue, 4- / 7-section), 2 = reflector-by-reflector back-transformation on the VALU
+    int eig_flags;               // developer A/B switches of the eigen-solver of A' (TCV_MARG_EIG_FLAGS): 1 = round 2's eigenvalue search (every eigenvalue, 4- / 7-section), 2 = reflector-by-reflector back-transformation on the VALU, 4 = round 5's LDS-resident tridiagonalisation
 };
 
 __device__ __forceinline__ int pidx(int a, int b) { return a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a; }
@@ -622,6 +622,164 @@ __device__ __noinline__ void eig_backtransform_wy(const lds_d *Hq_, lds_d *Z_, c
     }
 }
 
+// ---- round 6: the tridiagonalisation with the matrix in REGISTERS, one column per lane -------------------------------------------------
+// The 256-thread shape above spends ~4 900 cycles per Householder step on a 75 x 75 matrix (LDS-bandwidth bound rank-2 update over eight
+// lanes per row, a product pass, two workgroup barriers; profiles/r05_phase_cycles_marg_256.txt: 353 K of a window's 760 K cycles).  Here
+// lane c of the first two wavefronts OWNS column c of the (fully symmetric) matrix: 80 doubles = 160 VGPRs.  A step is then
+//     u_c = sum_r a_c[r] x_r                  one FMA per row, x broadcast out of LDS (16-byte reads, two rows each)
+//     p_c = tau scale (u_c - beta a_c[i+1]),  v_c, p'v by a wavefront reduction                                   | barrier
+//     a_c[r] -= v_r w_c + w_r v_c,  w = p + K v     three FMAs per row, (v_r, p_r) broadcast out of LDS (one 16-byte read)  | barrier
+// with no LDS traffic for the matrix itself.  Row i (the next Householder vector, by symmetry), the next diagonal entry and row i + 1 are
+// taken out of the registers right behind the update (a uniform switch over the 8-row block that holds them -- register arrays cannot be
+// indexed by a run-time value), so the next step starts with x, |x[1:]|^2 and A22[:,0] in place.  Rows and columns that are finished (or
+// lie beyond n) take part with v = p = x = 0: their entries stay what they are.  Same algorithm as above (LAPACK dsytd2, lower), another
+// summation order: T, the reflectors (packed in Hq) and tau agree to rounding (gated on J0'J0 and J0'r0 like every eigen path: the
+// eigenvectors' signs and the rotation inside the null cluster are not defined).  Waves 2.. only keep the barriers company.
+__device__ __forceinline__ double sel8(const double (&a)[MARG_MAX_N], int b, int k) {      // a[b + k], k uniform in 0..7, b a literal
+    // (all eight entries are read first and the choice is made among VALUES: a choice among conditional reads is folded into one read at a
+    // run-time offset, which takes the array out of the registers)
+    const double v0 = a[b], v1 = a[b + 1], v2 = a[b + 2], v3 = a[b + 3], v4 = a[b + 4], v5 = a[b + 5], v6 = a[b + 6], v7 = a[b + 7];
+    double r = v0;
+    r = (k == 1) ? v1 : r; r = (k == 2) ? v2 : r; r = (k == 3) ? v3 : r; r = (k == 4) ? v4 : r;
+    r = (k == 5) ? v5 : r; r = (k == 6) ? v6 : r; r = (k == 7) ? v7 : r;
+    return r;
+}
+__device__ __forceinline__ double row_of(const double (&a)[MARG_MAX_N], int r) {      // a[r], r uniform: a real branch per block, selects inside
+    const int k = r & 7;
+    double v;
+    // (every case ends in an asm statement of its own: identical cases would be merged into ONE select chain behind a phi of base pointers,
+    // i.e. a run-time index into the array, and the whole array would live in scratch memory instead of registers)
+#define TCV_ROW_CASE(B) case B: v = sel8(a, 8 * B, k); asm volatile("; row block " #B : "+v"(v)); break;
+    switch (r >> 3) {
+        TCV_ROW_CASE(0) TCV_ROW_CASE(1) TCV_ROW_CASE(2) TCV_ROW_CASE(3) TCV_ROW_CASE(4) TCV_ROW_CASE(5) TCV_ROW_CASE(6) TCV_ROW_CASE(7) TCV_ROW_CASE(8)
+        default: v = sel8(a, 72, k); asm volatile("; row block 9" : "+v"(v)); break;
+    }
+#undef TCV_ROW_CASE
+    return v;
+}
+template <int NT>
+__device__ __noinline__ void tridiag_cols(lds_d *A_, lds_d *Hq_, lds_d *sm_, int n_, int ld_, int tid) {
+    static_assert(MARG_MAX_N == 80 && NT >= 128, "one column per lane of two wavefronts, ten blocks of eight rows");
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) v2d lds_v2d;
+    lds_d *A = uni_lds<2>(A_), *Hq = uni_lds<2>(Hq_), *sm = uni_lds<2>(sm_);
+    const int n = uni_i<2>(n_), ld = uni_i<2>(ld_);
+    constexpr int NR = MARG_MAX_N;
+    lds_d *dv = sm, *ev = sm + 80, *tauv = sm + 160, *xbuf = sm + 240, *red = sm + 400;      // red: [0..1] |x[1:]|^2 per wave, [2..3] p'v per wave, [4] the next diagonal entry
+    lds_v2d *vw = (lds_v2d *)(sm + 512);                                                     // (v_r, p_r), 16-byte aligned (sm is an even offset, tcv_marg.hip LDS carve)
+    const lds_v2d *x2 = (const lds_v2d *)xbuf;
+    const bool owner = tid < 128;      // uniform per wavefront
+    const int c = tid, lane = tid & 63, wave = tid >> 6;
+    double a[NR];
+    double xc = 0.0, a0 = 0.0;
+    if (owner) {
+        const int cl = min(c, n - 1);
+#pragma unroll
+        for (int r = 0; r < NR; r++) a[r] = 0.0;
+#pragma unroll
+        for (int blk = 0; blk < NR / 8; blk++)
+            if (8 * blk < n) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) { const int r = 8 * blk + k; const double t = A[min(r, n - 1) * ld + cl]; a[r] = (r < n && c < n) ? t : 0.0; }
+            }
+        xc = (c >= 1) ? a[0] : 0.0;
+        a0 = a[1];
+        if (c < NR) xbuf[c] = xc;
+        if (c == 0) red[4] = a[0];
+        double s2 = (c >= 2) ? xc * xc : 0.0;
+        s2 = wave_sum_down(s2);
+        if (lane == 0) red[wave] = s2;
+    }
+    __syncthreads();
+    for (int i = 0; i + 1 < n; i++) {
+        double vc = 0.0, pc = 0.0, tau = 0.0;
+        if (owner) {
+            const double xn2 = red[0] + red[1];
+            const double alpha = xbuf[i + 1];
+            double beta = alpha, scale = 0.0;
+            if (xn2 > 0.0) {
+                const double nn = alpha * alpha + xn2;
+                double y = __builtin_amdgcn_rsq(nn);                 // |x| = nn * rsqrt(nn), two Newton steps
+                y = y * fma(-0.5 * nn * y, y, 1.5);
+                y = y * fma(-0.5 * nn * y, y, 1.5);
+                beta = -copysign(nn * y, alpha);
+                tau = (beta - alpha) * fast_rcp(beta);
+                scale = fast_rcp(alpha - beta);
+            }
+            double u0 = 0.0, u1 = 0.0;      // two chains (even / odd rows): the FMA latency is not hidden by a second wavefront here
+            const int bfirst = (i + 1) >> 3;      // the first block with a live row; the live blocks are contiguous from there
+            {
+                v2d xx[4], xnx[4];      // this block's x and the next block's, read one block ahead (the LDS latency of a block is longer than its eight FMAs)
+#pragma unroll
+                for (int blk = 0; blk < NR / 8; blk++)
+                    if (8 * blk + 7 > i && 8 * blk < n) {
+                        if (blk == bfirst) {
+#pragma unroll
+                            for (int k = 0; k < 4; k++) xx[k] = x2[4 * blk + k];
+                        }
+                        if (blk + 1 < NR / 8) {
+#pragma unroll
+                            for (int k = 0; k < 4; k++) xnx[k] = x2[4 * (blk + 1) + k];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; k++) { u0 = fma(a[8 * blk + 2 * k], xx[k].x, u0); u1 = fma(a[8 * blk + 2 * k + 1], xx[k].y, u1); }
+#pragma unroll
+                        for (int k = 0; k < 4; k++) xx[k] = xnx[k];
+                    }
+            }
+            if (c > i) { vc = (c == i + 1) ? 1.0 : xc * scale; pc = tau * scale * ((u0 + u1) - beta * a0); }
+            if (c < NR) { v2d t; t.x = vc; t.y = pc; vw[c] = t; }
+            double pv = pc * vc;
+            pv = wave_sum_down(pv);
+            if (lane == 0) red[2 + wave] = pv;
+            if (c >= i + 2 && c < n) Hq[refl_off(i, n) + c - i - 2] = vc;
+            if (tid == 0) { dv[i] = red[4]; ev[i] = beta; tauv[i] = tau; }
+        }
+        __syncthreads();
+        if (owner) {
+            const double K = -0.5 * tau * (red[2] + red[3]);
+            const double wc = fma(K, vc, pc);
+            {
+                const int bfirst = (i + 1) >> 3;
+                v2d t[4], tn[4];      // (v_r, p_r) of four rows and of the next four, read half a block ahead
+#pragma unroll
+                for (int blk = 0; blk < NR / 8; blk++)
+                    if (8 * blk + 7 > i && 8 * blk < n) {
+                        if (blk == bfirst) {
+#pragma unroll
+                            for (int k = 0; k < 4; k++) t[k] = vw[8 * blk + k];
+                        }
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            if (8 * blk + 4 * h + 4 < NR) {
+#pragma unroll
+                                for (int k = 0; k < 4; k++) tn[k] = vw[8 * blk + 4 * h + 4 + k];
+                            }
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                const double wr = fma(K, t[k].x, t[k].y);
+                                a[8 * blk + 4 * h + k] = fma(-wr, vc, fma(-t[k].x, wc, a[8 * blk + 4 * h + k]));
+                            }
+#pragma unroll
+                            for (int k = 0; k < 4; k++) t[k] = tn[k];
+                        }
+                    }
+            }
+            // the next step's inputs: row i + 1 of every column (diagonal entry on lane i + 1, x on the lanes behind it), row i + 2
+            const double xnew = row_of(a, i + 1);
+            a0 = row_of(a, min(i + 2, NR - 1));
+            if (c == i + 1) red[4] = xnew;
+            xc = (c >= i + 2) ? xnew : 0.0;
+            if (c < NR) xbuf[c] = xc;
+            double s2 = (c >= i + 3) ? xc * xc : 0.0;
+            s2 = wave_sum_down(s2);
+            if (lane == 0) red[wave] = s2;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) { dv[n - 1] = red[4]; ev[n - 1] = 0.0; }
+}
+
 __device__ __forceinline__ double rank2(double a, double vr, double wc, double wr, double vc) { return a - (vr * wc + wr * vc); }
 template <int NT>
 // (disable_tail_calls on every function that calls a non-inlined one: with the IR `tail` marker on a call the callee saves and restores
@@ -645,6 +803,9 @@ __device__ __noinline__ __attribute__((disable_tail_calls)) bool sym_eig_tridiag
 #define EMARK(id) do { } while (0)
 #endif
     if (tid == 0 && dbg) for (int i = 0; i < 6; i++) dbg[8 + i] = 0.0;
+    if (!(flags & 4)) {      // round 6: the matrix in registers, one column per lane of the first two wavefronts (flags bit 2: the LDS-resident path below, A/B)
+        tridiag_cols<NT>(A, Hq, sm, n, ld, tid);
+    } else {
     // ---- (1) tridiagonalisation.  Step i: x = A[i+1:, i] (read as row i: the matrix is kept fully symmetric).  Every
     // 4-lane group owns one row r of A22 and forms u_r = A22[r,:] x together with |x[1:]|^2 in the same sweep, so that
     // beta, tau and v = (x - beta e1) / (alpha - beta) need no extra pass: A22 v = (u - beta A22[:,0]) / (alpha - beta).
@@ -781,6 +942,7 @@ __device__ __noinline__ __attribute__((disable_tail_calls)) bool sym_eig_tridiag
         SMARK(5);
     }
     if (tid == 0) { dv[n - 1] = A[(n - 1) * ld + n - 1]; ev[n - 1] = 0.0; }
+    }
     __syncthreads();
     for (int i = tid; i < n; i += NT) e2[i] = ev[i] * ev[i];
     // Gershgorin interval, |T| and the pivot floor (every thread, redundantly)

@@ -52,7 +52,14 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 // subtractive profiling (build with -DTCV_ABLATE, developer tool): bit k of SolveArgs::skip removes phase k from the kernel (results
 // are garbage, every step is forced to be accepted so that the control flow stays the benchmark's); the time difference to skip = 0
 // is what the phase really costs under the real overlap conditions -- no instrumentation in the timed code
-#ifdef TCV_ABLATE
+// (-DTCV_ABLATE_CONST=mask, round 6: the same mask as a COMPILE-TIME constant -- the removed phases' code and registers are really gone, which is
+// what a phase-split pipeline's kernels would look like to the register allocator: tools/r06_phase_split_bound.sh)
+#if defined(TCV_ABLATE_CONST)
+#define TCV_ABLATE 1
+#define ABL(C, bit) (!((unsigned)(TCV_ABLATE_CONST) & (1u << (bit))))
+#define ABL_FORCE(C) ((((unsigned)(TCV_ABLATE_CONST)) >> 31) != 0)
+#define ABL_ACCEPT(C) (((((unsigned)(TCV_ABLATE_CONST)) >> 30) & 1u) != 0)
+#elif defined(TCV_ABLATE)
 #define ABL(C, bit) (!((C).skip & (1u << (bit))))
 #define ABL_FORCE(C) (((C).skip >> 31) != 0)      // bit 31: linear-solver failures are ignored
 #define ABL_ACCEPT(C) ((((C).skip >> 30) & 1u) != 0)      // bit 30: every step is accepted (fixed control flow)
@@ -2302,7 +2309,9 @@ template <int NT, bool MFMA, bool CHAIN, bool COOP = false, bool TD = !CHAIN>
 // (-DTCV_CHAIN_OCC1, developer build libtcv_hip_occ1.so: the chain kernel compiled for ONE wavefront per SIMD -- 512 registers, no spills -- to
 // measure what the 156 spilled registers of the production kernel cost at equal occupancy, profiles/r03_spill_ab.txt)
 // (-DTCV_CHAIN_OCC3, libtcv_hip_occ3.so: THREE wavefronts per SIMD -- 168 registers -- for the occupancy experiment of tools/dev_occupancy3.py)
-#if defined(TCV_CHAIN_OCC1)
+#if defined(TCV_CHAIN_OCC)      // (round 6: any occupancy, -DTCV_CHAIN_OCC=4 -> 128 registers)
+#define TCV_CHAIN_WAVES TCV_CHAIN_OCC
+#elif defined(TCV_CHAIN_OCC1)
 #define TCV_CHAIN_WAVES 1
 #elif defined(TCV_CHAIN_OCC3)
 #define TCV_CHAIN_WAVES 3

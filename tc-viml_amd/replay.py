@@ -788,12 +788,13 @@ class _EstimatorConfig(C.Structure):
                 ("gravity", C.c_double * 3), ("imu_dt", C.c_double), ("K", C.c_double * 9), ("width", C.c_int), ("height", C.c_int),
                 ("tic", C.c_double * 3), ("ric", C.c_double * 9), ("estimate_extrinsic", C.c_int),
                 ("angle_th", C.c_double), ("overlap_th", C.c_double), ("dist_th", C.c_double),
-                ("num_iterations", C.c_int), ("fixed_iterations", C.c_int), ("line_exact_jacobian", C.c_int), ("pad_", C.c_int)]
+                ("num_iterations", C.c_int), ("fixed_iterations", C.c_int), ("line_exact_jacobian", C.c_int), ("pad_", C.c_int),
+                ("solver_time", C.c_double)]
 
 
 class _EstimatorStats(C.Structure):
     _fields_ = [("marg_flag", C.c_int), ("n_landmarks", C.c_int), ("n_proj", C.c_int), ("n_line", C.c_int), ("n_line_obs", C.c_int),
-                ("iterations", C.c_int), ("prior_n", C.c_int), ("final_cost", C.c_double)]
+                ("iterations", C.c_int), ("prior_n", C.c_int), ("termination", C.c_int), ("final_cost", C.c_double)]
 
 
 class _FrameInput(C.Structure):
@@ -810,7 +811,8 @@ class NativeLockstep:
     windows optimised.  Same perturbation draws as `run` / `run_many`."""
 
     def __init__(self, streams, num_iterations: int = 8, fixed_iterations: bool = False, init_sigma=(0.02, 0.005, 0.05), bias_sigma=(0.005, 0.0005),
-                 exact_line_jacobian: bool = False, estimate_extrinsic: bool = True):
+                 exact_line_jacobian: bool = False, estimate_extrinsic: bool = True, solver_time: float = 0.0):
+        """solver_time: SOLVER_TIME of the reference's configuration (sensor.yaml:85; 0: no clock)"""
         import tcv
         self.tcv = tcv
         L = self.L = tcv.lib()
@@ -840,6 +842,7 @@ class NativeLockstep:
         cfg.tic[:] = list(synth.TIC); cfg.ric[:] = list(synth.RIC.reshape(9)); cfg.estimate_extrinsic = int(estimate_extrinsic)
         cfg.angle_th, cfg.overlap_th, cfg.dist_th = 0.1745, 0.45, 50.0
         cfg.num_iterations = num_iterations; cfg.fixed_iterations = int(fixed_iterations); cfg.line_exact_jacobian = int(exact_line_jacobian)
+        cfg.solver_time = float(solver_time)
         self.streams, self.init_sigma = streams, init_sigma
         self.ests, self.rngs, self.outs = [], [], []
         P = self._P
@@ -957,9 +960,15 @@ class NativeLockstep:
         """first half of frame k: begin_frame of every stream and everything of tcv_estimators_optimize up to the last command on the device
         (tcv_estimators_optimize_begin).  A host thread that alternates between two NativeLockstep objects (slot 0 / 1) overlaps the host side
         of one with the kernels of the other."""
+        prev = self.L.tcv_thread_stream_slot(self.slot)      # (the slot is per-thread state of the library: put back what the thread had)
+        try:
+            self._step_begin(k)
+        finally:
+            self.L.tcv_thread_stream_slot(prev)
+
+    def _step_begin(self, k: int):
         tcv, L, vp = self.tcv, self.L, self.vp
         assert self._pending is None
-        L.tcv_thread_stream_slot(self.slot)
         t_a = time.perf_counter()
         live, arr_all, rec, rdy, keep = self._batches.pop(k, None) or self._frame_batch(k)
         if not live:
@@ -978,12 +987,18 @@ class NativeLockstep:
 
     def step_end(self) -> int:
         """second half: waits for the states, applies them (tcv_estimators_optimize_end), finish_frame of every stream; returns the number of windows"""
-        tcv, L, P, vp = self.tcv, self.L, self._P, self.vp
         if self._pending is None:
             return 0
+        prev = self.L.tcv_thread_stream_slot(self.slot)
+        try:
+            return self._step_end()
+        finally:
+            self.L.tcv_thread_stream_slot(prev)
+
+    def _step_end(self) -> int:
+        tcv, L, P, vp = self.tcv, self.L, self._P, self.vp
         k, ready, arr, ticket, keep = self._pending
         self._pending = None
-        L.tcv_thread_stream_slot(self.slot)
         t_b = time.perf_counter()
         tcv.check(L.tcv_estimators_optimize_end(ticket))
         t_c = time.perf_counter()
@@ -1004,7 +1019,7 @@ class NativeLockstep:
                 o = self.outs[si]
                 o["t"].append(self.streams[si]["t"][k]); o["p"].append(pa[j]); o["q"].append(qa[j]); o["v"].append(va[j])
                 o["log"].append(dict(flag=s.marg_flag, n_landmarks=s.n_landmarks, n_proj=s.n_proj, n_line=s.n_line, n_line_obs=s.n_line_obs,
-                                     iterations=s.iterations, final_cost=s.final_cost, prior_n=s.prior_n))
+                                     iterations=s.iterations, termination=s.termination, final_cost=s.final_cost, prior_n=s.prior_n))
         self._raw = []
 
     def results(self):

@@ -98,8 +98,19 @@ def test_default_line_key_set():
               "ranks_seen", "per_rank_solves_per_s"):
         assert k in d, k
     src = open(os.path.join(ROOT, "bench.py")).read()
-    for k in ("roofline_fp64", "batch_sweep", "run_to_convergence", "mfma_busy", "valu_active", "replay_cpu_baseline", "cpu_baseline", "traffic_commit"):
+    for k in ("roofline_fp64", "batch_sweep", "run_to_convergence", "mfma_busy", "valu_active", "replay_cpu_baseline", "cpu_baseline", "traffic_commit",
+              # round 6: the roofline on SURVEY 8(d)'s unit (iteration) with the per-linearisation figure beside it, executed flops from the counters,
+              # the wait split, and the staleness guard of the static counter figures
+              "unit_of_work", "linearisations_per_launch", "frac_per_linearisation", "executed", "wait_split", "mean_latency_cycles", "stale", "csrc_sha16",
+              "deployed_budget"):
         assert f'"{k}"' in src, k
+    # the static counters belong to the kernel sources they were measured on: the guard's hash moves with any file under csrc/
+    sys.path.insert(0, ROOT)
+    import bench
+    h = bench.csrc_sha16()
+    assert len(h) == 16 and h == bench.csrc_sha16()
+    cj = json.load(open(os.path.join(ROOT, "profiles", "counters.json")))
+    assert "commit" in cj and "kernel" in cj
 
 
 def test_cpu_share_cuts_the_affinity_mask():

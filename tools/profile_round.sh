@@ -16,6 +16,13 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_AN
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_MFMA -d $O/sq2 -o sq --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/sq2.log 2>&1
 # north_star's "MFMA-busy": cycles the matrix cores are busy against the cycles the CUs are busy (own pass; SQ_VALU_MFMA_BUSY_CYCLES counts cycles)
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 -d $O/sq3 -o sq --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/sq3.log 2>&1
+# round 6: where the wavefronts wait -- the split of SQ_WAVE_CYCLES, and mean latencies by Little's law (rocprofv3's accumulate() derived counters; one per pass)
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM SQ_INSTS_SMEM -d $O/sq4 -o sq --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/sq4.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_FLAT SQ_ACTIVE_INST_MISC SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES -d $O/sq5 -o sq --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/sq5.log 2>&1
+for LC in VmemLatency LdsLatency SmemLatency; do
+  rocprofv3 --kernel-trace --pmc $LC -d $O/lat_$LC -o l --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/lat_$LC.log 2>&1
+done
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum -d $O/tcc -o t --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/tcc.log 2>&1
 cd $R
 python3 tools/pmc_traffic.py $O/fetch $O/write $O/pmc_traffic.json > /dev/null 2>&1
 if [ -f tc-viml_amd/libtcv_hip_prof.so ]; then
@@ -55,7 +62,15 @@ def summarise(d):
         for r in csv.DictReader(open(f)):
             acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items() if "tcv::" in k}
-out = {"sq": summarise("sq"), "sq2": summarise("sq2"), "mfma": summarise("sq3")}
+out = {"sq": summarise("sq"), "sq2": summarise("sq2"), "mfma": summarise("sq3"), "wait": summarise("sq4"), "active": summarise("sq5"), "tcc": summarise("tcc"),
+       "latency": {k: v for d in ("lat_VmemLatency", "lat_LdsLatency", "lat_SmemLatency") for k, v in summarise(d).items()}}
+def merged(*ds):
+    m = {}
+    for d in ds:
+        for k, v in d.items():
+            m.setdefault(k, {}).update(v)
+    return m
+out["latency"] = merged(summarise("lat_VmemLatency"), summarise("lat_LdsLatency"), summarise("lat_SmemLatency"))
 json.dump(out, open(f"{O}/sq_counters.json", "w"), indent=1)
 # the figures bench.py copies onto its default line (profiles/counters.json), with the commit they were taken at
 import os
@@ -66,6 +81,15 @@ def pick(d, pat):
     return {}
 sk = "solve_kernel<256, true, true, false, false>"
 a, b2, c = pick(out["sq"], sk), pick(out["sq2"], sk), pick(out["mfma"], sk)
+wt, ac, lt, tc = pick(out["wait"], sk), pick(out["active"], sk), pick(out["latency"], sk), pick(out["tcc"], sk)
+import hashlib, glob as _g
+def csrc_sha16(root):      # what bench.py compares with: the counters belong to THESE kernel sources
+    h = hashlib.sha256()
+    for f in sorted(_g.glob(os.path.join(root, "tc-viml_amd", "csrc", "*"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+def frac(x, k, d):
+    return (x.get(k, 0) / x[d]) if x.get(d) else None
 tr = {}
 try:
     tr = json.load(open(f"{O}/pmc_traffic.json"))
@@ -79,7 +103,19 @@ cnt = {"commit": os.environ.get("COMMIT", "unknown"), "source": "tools/profile_r
        "mfma_busy": (c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / c["SQ_BUSY_CU_CYCLES"]) if c.get("SQ_BUSY_CU_CYCLES") else None,
        "salu_per_valu": (b2.get("SQ_INSTS_SALU", 0) / a["SQ_INSTS_VALU"]) if a.get("SQ_INSTS_VALU") else None,
        "solve_kernel_hbm_bytes_per_launch": tr.get("solve_kernel_hbm_bytes_per_launch"), "marg_kernel_hbm_bytes_per_launch": tr.get("marg_kernel_hbm_bytes_per_launch"),
-       "solve_kernel_write_bytes_per_launch": trk.get("write_bytes_per_launch_raw"), "solve_kernel_fetch_bytes_per_launch_raw": trk.get("fetch_bytes_per_launch_raw")}
+       "solve_kernel_write_bytes_per_launch": trk.get("write_bytes_per_launch_raw"), "solve_kernel_fetch_bytes_per_launch_raw": trk.get("fetch_bytes_per_launch_raw"),
+       "csrc_sha16": csrc_sha16("$R"),
+       # executed FP64 work of one launch: matrix-core ops x 512 flops (SQ_INSTS_VALU_MFMA_MOPS_F64), and an UPPER bound of the vector part
+       # (every VALU instruction priced as a 64-lane FMA)
+       "mfma_mops_f64_per_launch": c.get("SQ_INSTS_VALU_MFMA_MOPS_F64"), "valu_insts_per_launch": a.get("SQ_INSTS_VALU"),
+       # where the wavefronts' cycles go (disjoint: waiting at s_waitcnt / barrier | issue stalls | issuing) and what they issue
+       "wait_split": {"wait_any": frac(wt, "SQ_WAIT_ANY", "SQ_WAVE_CYCLES"), "wait_inst_any": frac(wt, "SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES"),
+                      "wait_inst_lds": frac(wt, "SQ_WAIT_INST_LDS", "SQ_WAVE_CYCLES"), "active_inst_any": frac(wt, "SQ_ACTIVE_INST_ANY", "SQ_WAVE_CYCLES"),
+                      "active_valu": frac(ac, "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES"), "active_scalar": frac(ac, "SQ_ACTIVE_INST_SCA", "SQ_WAVE_CYCLES"),
+                      "active_lds": frac(ac, "SQ_ACTIVE_INST_LDS", "SQ_WAVE_CYCLES"), "active_flat": frac(ac, "SQ_ACTIVE_INST_FLAT", "SQ_WAVE_CYCLES")},
+       "mean_latency_cycles": {"vmem": lt.get("VmemLatency"), "lds": lt.get("LdsLatency"), "smem": lt.get("SmemLatency")},
+       "insts_per_launch": {"vmem": wt.get("SQ_INSTS_VMEM"), "lds": b2.get("SQ_INSTS_LDS"), "smem": wt.get("SQ_INSTS_SMEM"), "waves": wt.get("SQ_WAVES")},
+       "l2_hit_rate": (tc.get("TCC_HIT_sum", 0) / (tc.get("TCC_HIT_sum", 0) + tc.get("TCC_MISS_sum", 0))) if (tc.get("TCC_HIT_sum", 0) + tc.get("TCC_MISS_sum", 0)) else None}
 json.dump(cnt, open(f"{O}/counters.json", "w"), indent=1)
 PY
 ls $O
