@@ -152,7 +152,11 @@ struct EstInflight {
         launched = true;
         const int n = tcv_batch_size(b);
         handles.assign(n, nullptr);
-        launch_rc = tcv_batch_marginalize(b, stream);
+        // (test hook: TCV_EST_INJECT_LAUNCH_FAIL=q makes the q-th deferred launch of the process fail -- the library has no natural one to offer)
+        static std::atomic<int> launches{0};
+        static const int inject = getenv("TCV_EST_INJECT_LAUNCH_FAIL") ? atoi(getenv("TCV_EST_INJECT_LAUNCH_FAIL")) : -1;
+        if (inject >= 0 && launches.fetch_add(1) == inject) { tcv::set_error("injected launch failure"); launch_rc = TCV_ERR_HIP; }
+        else launch_rc = tcv_batch_marginalize(b, stream);
         if (launch_rc == TCV_OK) launch_rc = tcv_batch_get_priors_device_async(b, handles.data(), n);
         if (launch_rc != TCV_OK) launch_msg = tcv_last_error();
         return launch_rc;
@@ -247,7 +251,18 @@ struct tcv_estimator {
     int phase = 0;                           // 0: between frames, 1: window full, waiting for the optimisation, 2: optimised, waiting for finish_frame
     int opt_failed = 0;                      // != TCV_OK: this estimator's window failed in the last lock-step batch (reported by finish_frame)
     std::string opt_msg;
+    int pend_failed = 0;                     // != TCV_OK: the previous frame's (deferred) marginalisation could not be launched: this frame's window is solved without
+    std::string pend_msg;                    // its prior, nothing of it is applied and finish_frame reports the failure (the caller resets, like after failureDetection)
 };
+// the device-resident line map is bound to the device that was current at tcv_estimator_set_line_map: an estimator optimised with another
+// current device uses the host copy it still holds (uploaded with the call) instead of failing the association (round-5 advisor finding)
+extern "C" int tcv_line_map_device(const tcv_line_map *m);
+static inline const tcv_line_map *map_on_current_device(const tcv_estimator *e) {
+    if (!e->map_dev) return nullptr;
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) return nullptr;
+    return tcv_line_map_device(e->map_dev.get()) == cur ? e->map_dev.get() : nullptr;
+}
 
 namespace {
 
@@ -395,7 +410,7 @@ int assoc_prepare(tcv_estimator *e, AssocJob &J) {
     J.call = nd > 0 || J.one_call;
     tcv_match_lines_args &a = J.args;
     a.n_frames = W + 1; a.poses = J.pose; a.ex_pose = J.ex; a.Rbw = e->Rbw.data(); a.Tbw = e->Tbw.data(); a.K = e->cfg.K; a.width = e->cfg.width; a.height = e->cfg.height;
-    a.window_size = W; a.n_map = nm; a.lines3d = e->map_lines.data(); a.map_device = e->map_dev.get(); a.n_det = nd; a.det_frame = nd ? J.det_frame.data() : nullptr; a.det_lines = nd ? J.det.data() : nullptr;
+    a.window_size = W; a.n_map = nm; a.lines3d = e->map_lines.data(); a.map_device = map_on_current_device(e); a.n_det = nd; a.det_frame = nd ? J.det_frame.data() : nullptr; a.det_lines = nd ? J.det.data() : nullptr;
     a.angle_th = e->cfg.angle_th; a.overlap_th = e->cfg.overlap_th; a.fov_given = J.one_call ? 2 + W : 1; a.in_fov = J.given.data();
     a.match_index = nd ? J.match.data() : nullptr; a.err = nd ? J.err.data() : nullptr; a.projected = nullptr;
     return TCV_OK;
@@ -694,7 +709,7 @@ static void clear_state(tcv_estimator *e) {
     e->have_acc0 = false; e->have_last = false;
     e->acc_0 = e->gyr_0 = e->last_P = V3{0, 0, 0};
     e->para_feature.clear(); e->sel.clear();
-    e->n_line_obs_total = 0; e->phase = 0; e->opt_failed = 0; e->opt_msg.clear();
+    e->n_line_obs_total = 0; e->phase = 0; e->opt_failed = 0; e->opt_msg.clear(); e->pend_failed = 0; e->pend_msg.clear();
 }
 extern "C" int tcv_estimator_create(tcv_estimator **out, const tcv_estimator_config *cfg) {
     if (!out || !cfg || !(cfg->imu_dt > 0) || !(cfg->focal_length > 0) || cfg->num_iterations < 1) { tcv::set_error("estimator_create: bad configuration"); return TCV_ERR_INVALID; }
@@ -891,7 +906,16 @@ static int optimize_begin(OptRun &R) {
         if (!e->pend) continue;
         std::shared_ptr<EstInflight> fl = e->pend;
         const int rcl = fl->launch((void *)tcv::util_stream());
-        if (rcl != TCV_OK) { tcv::set_error(fl->launch_msg); return rcl; }
+        if (rcl != TCV_OK) {
+            // the launch failed for the whole batch of the previous frame (EstInflight::launch keeps the verdict): every estimator of that batch loses
+            // its new prior -- and only those: nothing is sticky, the rest of THIS call's estimators go on, and the affected ones report the failure
+            // through finish_frame instead of blocking every later call until a reset (round-5 advisor finding)
+            e->pend_failed = rcl; e->pend_msg = fl->launch_msg;
+            e->pend.reset(); e->pend_k = -1;
+            if (e->prior) { tcv_prior_destroy(e->prior); e->prior = nullptr; }
+            e->prior_blocks.clear(); e->stats.prior_n = 0;
+            continue;
+        }
         tcv_prior *np = fl->take(e->pend_k);
         if (!np) { tcv::set_error("estimators_optimize: the previous frame's marginalisation left no prior for this estimator"); return TCV_ERR_INVALID; }
         const int rct = take_prior(e, np, e->pend_flag);
@@ -1173,6 +1197,10 @@ static int optimize_end(OptRun &R) {
                 // the marginalisation that made this window's prior was still running when the previous frame returned: its verdict now (it
                 // finished before this frame's solve started)
                 tcv_estimator *e = es[g.idx[k]];
+                if (e->pend_failed != TCV_OK) {
+                    g.est_rc[k] = e->pend_failed; g.est_msg = "the previous frame's marginalisation could not be launched (" + e->pend_msg + "): this window was solved without its prior";
+                    e->pend_failed = TCV_OK; e->pend_msg.clear();
+                }
                 if (e->prev) {
                     const int stp = e->prev->status_of(e->prev_k);
                     if (stp != 0 && stp != 2) { g.est_rc[k] = TCV_ERR_NUMERIC; g.est_msg = "the previous frame's marginalisation failed (eigen-solver sweep cap or NaN): this window was solved on an invalid prior"; }

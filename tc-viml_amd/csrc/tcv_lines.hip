@@ -244,13 +244,14 @@ extern "C" int tcv_line_map_create(tcv_line_map **out, int n_map, const double *
     *out = m;
     return TCV_OK;
 }
+extern "C" int tcv_line_map_device(const tcv_line_map *m) { return m ? m->dev : -1; }      // (library-internal: tcv_estimator.cpp)
 extern "C" void tcv_line_map_destroy(tcv_line_map *m) {
     if (!m) return;
-    int cur = -1;
-    const bool sw = hipGetDevice(&cur) == hipSuccess && cur != m->dev;
-    if (sw) (void)hipSetDevice(m->dev);
-    (void)hipDeviceSynchronize();      // (an association that reads it may be in flight on another thread's stream)
-    if (sw) (void)hipSetDevice(cur);
+    // An association that reads the map may still be in flight -- on the stream of the thread that launched it.  Every tcv_match_lines_batch
+    // call waits for its own results before it returns (the matches are a host round trip), so by the time a caller can destroy the map no
+    // launch of ITS threads reads it any more; the calling thread's own stream is drained below.  No device-wide synchronisation: it stalled every host thread's stream of a multi-threaded replay on each estimator
+    // teardown (round-5 advisor finding).
+    { int cur = -1; if (hipGetDevice(&cur) == hipSuccess && cur == m->dev) { hipStream_t st = tcv::util_stream(); if (st) (void)hipStreamSynchronize(st); } }
     tcv::dev_free(m->d);
     delete m;
 }

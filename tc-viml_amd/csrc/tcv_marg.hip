@@ -37,7 +37,7 @@ enum { MARG_MAX_M = 64, MARG_MAX_N = 80, MARG_MAX_POS = MARG_MAX_M + MARG_MAX_N,
 // Two launch shapes of the one kernel: 512 threads per window and one workgroup per CU (few windows: shortest time per window), or
 // 256 threads per window and two workgroups per CU when every window of the batch fits 80 KB of LDS (many windows: the barrier and
 // LDS round trips of one window hide behind the other's arithmetic).
-enum { MARG_NT_WIDE = 512, MARG_NT_PAIR = 256, MARG_SM = 720, MARG_STAGE = 64 * 43, MARG_CB_LM = 16 };
+enum { MARG_NT_WIDE = 512, MARG_NT_PAIR = 256, MARG_SM = 768, MARG_STAGE = 64 * 43, MARG_CB_LM = 16 };
 // per-window result block: [J0 | r0 | x (linearisation point) + 64 diagnostics] is what a caller needs (MARG_OUT_COMPACT doubles, the
 // part tcv_batch_download_priors_compact copies); A', b' (parity / debug surface) follow
 enum { MARG_OUT_J0 = 0, MARG_OUT_R0 = 6400, MARG_OUT_X = 6480, MARG_OUT_COMPACT = 6480 + 1408 + 64, MARG_OUT_AS = MARG_OUT_COMPACT, MARG_OUT_BS = MARG_OUT_AS + 6400,
@@ -93,7 +93,7 @@ struct MargArgs {
     double *scratch;             // per workgroup MARG_SCR_STRIDE
     int nwin, state_stride, use_solved_state;
     int eig_mm;                  // 1: Amm^+ through the eigen-decomposition for every window (TCV_MARG_EIG_MM=1: A/B checks)
-    int eig_flags;               // developer A/B switches of the eigen-solver of A' (TCV_MARG_EIG_FLAGS): 1 = round 2's eigenvalue search (every eigenvalue, 4- / 7-section), 2 = reflector-by-reflector back-transformation on the VALU, 4 = round 5's LDS-resident tridiagonalisation
+    int eig_flags;               // developer A/B switches of the eigen-solver of A' (TCV_MARG_EIG_FLAGS): 1 = round 2's eigenvalue search (every eigenvalue, 4- / 7-section), 2 = reflector-by-reflector back-transformation on the VALU, 4 = round 5's LDS-resident tridiagonalisation, 8 = the register-resident one on two wavefronts (one lane per column) instead of four
 };
 
 __device__ __forceinline__ int pidx(int a, int b) { return a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a; }
@@ -780,6 +780,172 @@ __device__ __noinline__ void tridiag_cols(lds_d *A_, lds_d *Hq_, lds_d *sm_, int
     if (tid == 0) { dv[n - 1] = red[4]; ev[n - 1] = 0.0; }
 }
 
+// The same tridiagonalisation on FOUR wavefronts: a lone wavefront issues one instruction every ~4 cycles, and a step of tridiag_cols is ~1 500
+// instructions on each of its two wavefronts (5 600 cycles measured, profiles/r06_marg_tridiag.txt) -- issue bound, not latency bound.  Here the rows
+// of a column are split by parity between two lanes: lane (c, h) = (tid & 127, tid >> 7) holds the rows r = 2 j + h of column c (40 doubles), so the
+// two long loops of a step are half as long on every wavefront and all four SIMDs of the CU work.  Costs: the partial products u_h meet in LDS (a third
+// barrier per step), and the rows a step hands to the next one (row i + 1: the next Householder vector; row i + 2: the first column of the next
+// trailing block) live in one half each and reach the other half through LDS.  Same operations per entry as tridiag_cols except the association of
+// u = (even rows) + (odd rows).
+__device__ __forceinline__ double sel8h(const double (&a)[MARG_MAX_N / 2], int b, int k) {
+    const double v0 = a[b], v1 = a[b + 1], v2 = a[b + 2], v3 = a[b + 3], v4 = a[b + 4], v5 = a[b + 5], v6 = a[b + 6], v7 = a[b + 7];
+    double r = v0;
+    r = (k == 1) ? v1 : r; r = (k == 2) ? v2 : r; r = (k == 3) ? v3 : r; r = (k == 4) ? v4 : r;
+    r = (k == 5) ? v5 : r; r = (k == 6) ? v6 : r; r = (k == 7) ? v7 : r;
+    return r;
+}
+__device__ __forceinline__ double row_of_h(const double (&a)[MARG_MAX_N / 2], int j) {      // a[j], j uniform in 0..39
+    const int k = j & 7;
+    double v;
+#define TCV_ROW_CASE(B) case B: v = sel8h(a, 8 * B, k); asm volatile("; half row block " #B : "+v"(v)); break;
+    switch (j >> 3) {
+        TCV_ROW_CASE(0) TCV_ROW_CASE(1) TCV_ROW_CASE(2) TCV_ROW_CASE(3)
+        default: v = sel8h(a, 32, k); asm volatile("; half row block 4" : "+v"(v)); break;
+    }
+#undef TCV_ROW_CASE
+    return v;
+}
+template <int NT>
+__device__ __noinline__ void tridiag_cols4(lds_d *A_, lds_d *Hq_, lds_d *sm_, int n_, int ld_, int tid) {
+    static_assert(MARG_MAX_N == 80 && NT >= 256, "two lanes per column (row parity), four wavefronts");
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) v2d lds_v2d;
+    lds_d *A = uni_lds<2>(A_), *Hq = uni_lds<2>(Hq_), *sm = uni_lds<2>(sm_);
+    const int n = uni_i<2>(n_), ld = uni_i<2>(ld_);
+    constexpr int NR = MARG_MAX_N, NH = NR / 2;
+    // sm: dv 0 | ev 80 | tauv 160 | xbuf 240 (x, zero where finished) | a0buf 320 (row i + 1 of every column: A22[:,0]) | red 400: [0..1] |x[1:]|^2 of the
+    // owner half's two waves, [2..3] p'v of half 0's waves, [4] next diagonal entry | ubuf 416 (2 x 80 partial products) | vw 576..735
+    lds_d *dv = sm, *ev = sm + 80, *tauv = sm + 160, *xbuf = sm + 240, *a0buf = sm + 320, *red = sm + 400, *ubuf = sm + 416;
+    // (v_r, p_r) pairs, split by row parity so that a half reads ITS rows' pairs with 16-byte reads at consecutive addresses: vw[h][j] = pair of row 2 j + h
+    lds_v2d *vw = (lds_v2d *)(sm + 576);      // 2 x 40 pairs = 160 doubles: 576..735 (MARG_SM = 768)
+    const bool live = tid < 256;              // (NT = 512: waves 4.. only keep the barriers company)
+    const int c = tid & 127, h = (tid >> 7) & 1, lane = tid & 63, wave = tid >> 6;
+    const bool col = live && c < NR;          // lanes 80..127 of a half hold nothing
+    double a[NH];
+    if (live) {
+        const int cl = min(c, n - 1);
+#pragma unroll
+        for (int j = 0; j < NH; j++) a[j] = 0.0;
+#pragma unroll
+        for (int blk = 0; blk < NH / 8; blk++)
+            if (16 * blk < n) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) { const int j = 8 * blk + k, r = 2 * j + h; const double t = A[min(r, n - 1) * ld + cl]; a[j] = (r < n && c < n) ? t : 0.0; }
+            }
+        // step 0 inputs: row 0 (half 0) -> x, diagonal, |x[1:]|^2; row 1 (half 1) -> A22[:,0]
+        if (h == 0) {
+            const double xc = (c >= 1) ? a[0] : 0.0;
+            if (col) xbuf[c] = xc;
+            if (c == 0) red[4] = a[0];
+            double s2 = (c >= 2) ? xc * xc : 0.0;
+            s2 = wave_sum_down(s2);
+            if (lane == 0) red[wave & 1] = s2;
+        } else if (col) a0buf[c] = a[0];
+    }
+    __syncthreads();
+    for (int i = 0; i + 1 < n; i++) {
+        double vc = 0.0, pc = 0.0, tau = 0.0, beta = 0.0, scale = 0.0;
+        if (live) {
+            const double xn2 = red[0] + red[1];
+            const double alpha = xbuf[i + 1];
+            beta = alpha;
+            if (xn2 > 0.0) {
+                const double nn = alpha * alpha + xn2;
+                double y = __builtin_amdgcn_rsq(nn);                 // |x| = nn * rsqrt(nn), two Newton steps
+                y = y * fma(-0.5 * nn * y, y, 1.5);
+                y = y * fma(-0.5 * nn * y, y, 1.5);
+                beta = -copysign(nn * y, alpha);
+                tau = (beta - alpha) * fast_rcp(beta);
+                scale = fast_rcp(alpha - beta);
+            }
+            // partial product over this half's rows r = 2 j + h > i: x_r sits at xbuf[2 j + h] (stride-2 reads; pairs of the OTHER parity are skipped)
+            double u0 = 0.0, u1 = 0.0;
+            const int jfirst = (i + 1 - h + 1) >> 1;      // first local row with 2 j + h >= i + 1
+            const int bfirst = jfirst >> 3;
+            {
+                double xx[8], xnx[8];
+#pragma unroll
+                for (int blk = 0; blk < NH / 8; blk++)
+                    if (8 * blk + 7 >= jfirst && 16 * blk < n) {
+                        if (blk == bfirst) {
+#pragma unroll
+                            for (int k = 0; k < 8; k++) xx[k] = xbuf[2 * (8 * blk + k) + h];
+                        }
+                        if (blk + 1 < NH / 8) {
+#pragma unroll
+                            for (int k = 0; k < 8; k++) xnx[k] = xbuf[2 * (8 * (blk + 1) + k) + h];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 8; k += 2) { u0 = fma(a[8 * blk + k], xx[k], u0); u1 = fma(a[8 * blk + k + 1], xx[k + 1], u1); }
+#pragma unroll
+                        for (int k = 0; k < 8; k++) xx[k] = xnx[k];
+                    }
+            }
+            if (col) ubuf[NR * h + c] = u0 + u1;
+        }
+        __syncthreads();
+        if (live) {
+            const double u = col ? ubuf[c] + ubuf[NR + c] : 0.0;      // (even rows) + (odd rows): the same sum in both halves
+            const double xc = col ? xbuf[c] : 0.0, a0 = col ? a0buf[c] : 0.0;
+            if (c > i) { vc = (c == i + 1) ? 1.0 : xc * scale; pc = tau * scale * (u - beta * a0); }
+            if (h == 0) {
+                if (col) { v2d t; t.x = vc; t.y = pc; vw[(c & 1) * NH + (c >> 1)] = t; }      // pair of row c: parity c & 1, local index c >> 1
+                double pv = pc * vc;
+                pv = wave_sum_down(pv);
+                if (lane == 0) red[2 + (wave & 1)] = pv;
+                if (c >= i + 2 && c < n) Hq[refl_off(i, n) + c - i - 2] = vc;
+                if (tid == 0) { dv[i] = red[4]; ev[i] = beta; tauv[i] = tau; }
+            }
+        }
+        __syncthreads();
+        if (live) {
+            const double K = -0.5 * tau * (red[2] + red[3]);
+            const double wc = fma(K, vc, pc);
+            const int jfirst = (i + 1 - h + 1) >> 1, bfirst = jfirst >> 3;
+            const lds_v2d *vwh = vw + h * NH;
+            {
+                v2d t[4], tn[4];      // (v_r, p_r) of four of this half's rows and of the next four, read half a block ahead
+#pragma unroll
+                for (int blk = 0; blk < NH / 8; blk++)
+                    if (8 * blk + 7 >= jfirst && 16 * blk < n) {
+                        if (blk == bfirst) {
+#pragma unroll
+                            for (int k = 0; k < 4; k++) t[k] = vwh[8 * blk + k];
+                        }
+#pragma unroll
+                        for (int q = 0; q < 2; q++) {
+                            if (8 * blk + 4 * q + 4 < NH) {
+#pragma unroll
+                                for (int k = 0; k < 4; k++) tn[k] = vwh[8 * blk + 4 * q + 4 + k];
+                            }
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                const double wr = fma(K, t[k].x, t[k].y);
+                                a[8 * blk + 4 * q + k] = fma(-wr, vc, fma(-t[k].x, wc, a[8 * blk + 4 * q + k]));
+                            }
+#pragma unroll
+                            for (int k = 0; k < 4; k++) t[k] = tn[k];
+                        }
+                    }
+            }
+            // hand-over to step i + 1: row i + 1 (the half of its parity) -> diagonal entry, x, |x[1:]|^2; row i + 2 (the other half) -> A22[:,0]
+            const int r1 = i + 1, r2 = min(i + 2, NR - 1);
+            if (h == (r1 & 1)) {
+                const double xnew = row_of_h(a, r1 >> 1);
+                if (c == i + 1) red[4] = xnew;
+                const double xc = (c >= i + 2) ? xnew : 0.0;
+                if (col) xbuf[c] = xc;
+                double s2 = (c >= i + 3) ? xc * xc : 0.0;
+                s2 = wave_sum_down(s2);
+                if (lane == 0) red[wave & 1] = s2;
+            }
+            if (h == (r2 & 1) && col) a0buf[c] = row_of_h(a, r2 >> 1);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) { dv[n - 1] = red[4]; ev[n - 1] = 0.0; }
+}
+
 __device__ __forceinline__ double rank2(double a, double vr, double wc, double wr, double vc) { return a - (vr * wc + wr * vc); }
 template <int NT>
 // (disable_tail_calls on every function that calls a non-inlined one: with the IR `tail` marker on a call the callee saves and restores
@@ -804,7 +970,8 @@ __device__ __noinline__ __attribute__((disable_tail_calls)) bool sym_eig_tridiag
 #endif
     if (tid == 0 && dbg) for (int i = 0; i < 6; i++) dbg[8 + i] = 0.0;
     if (!(flags & 4)) {      // round 6: the matrix in registers, one column per lane of the first two wavefronts (flags bit 2: the LDS-resident path below, A/B)
-        tridiag_cols<NT>(A, Hq, sm, n, ld, tid);
+        if (flags & 8) tridiag_cols<NT>(A, Hq, sm, n, ld, tid);      // (bit 3: one lane per column on two wavefronts -- correct, issue bound, slower: A/B)
+        else tridiag_cols4<NT>(A, Hq, sm, n, ld, tid);
     } else {
     // ---- (1) tridiagonalisation.  Step i: x = A[i+1:, i] (read as row i: the matrix is kept fully symmetric).  Every
     // 4-lane group owns one row r of A22 and forms u_r = A22[r,:] x together with |x[1:]|^2 in the same sweep, so that

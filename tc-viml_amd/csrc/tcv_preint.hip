@@ -3,10 +3,10 @@
 // push_back :30-36, propagate :130-158, midPointIntegration :54-128).  repropagate (:38-52) is the same computation
 // with new linearisation biases, so it maps onto the same entry point.
 //
-// One 256-thread workgroup per pre-integration.  Per sample: lanes 0..44 build the five 3x3 base matrices every block
+// One three-wavefront workgroup per pre-integration.  Per sample: the state wave builds the five 3x3 base matrices every block
 // of F (15x15) and V (15x18) is a multiple of (R0 = R(delta_q), R1 = R(result_delta_q), M0 = R0 [a0]x, M1 = R1 [a1]x,
-// M1B = M1 (I - [w]x dt)); lane 64 advances delta_p / delta_q / delta_v (mid-point rule); then 225 lanes own one entry
-// each of jacobian <- F jacobian and covariance <- F covariance F' + V noise V' (noise is diagonal, :21-27).
+// M1B = M1 (I - [w]x dt)) and advances delta_p / delta_q / delta_v (mid-point rule); the 128 lanes of the two matrix waves own
+// the entries of jacobian <- F jacobian and covariance <- F covariance F' + V noise V' (noise is diagonal, :21-27).  preint_kernel below.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -78,99 +78,144 @@ __device__ __forceinline__ double V_entry(const lds_d *B, int r, int k, double d
     return (bk == 5) ? id * dt : 0.0;
 }
 
-__global__ void __launch_bounds__(256) preint_kernel(PreintArgs A) {
+// Round 6: the per-sample chain re-cut.  Until round 5 a sample was five workgroup barriers of a 256-thread workgroup in which 45 lanes, then
+// 225, then ONE (the state), then 225 had work: ~5 us per sample on the device, 303 us per frame of a 128-stream replay
+// (profiles/r05_replay128_timeline.txt).  Now three wavefronts with roles and TWO barriers per sample:
+//   state wave    (wave 2, one lane of it) runs one sample ahead: mid-point update of delta_p / delta_q / delta_v, then the base matrices of the
+//                 NEXT sample into the other half of a double buffer;
+//   matrix waves  (waves 0, 1; 128 lanes over the 225 entries): F, V of this sample from the base matrices | barrier | J' = F J and T = F P
+//                 (J and F / V double-buffered, so nothing is overwritten that a slower lane still reads) | barrier | P = T F' + V N V'.
+// Every entry is the same expression, summed in the same order, as before: the same bits.
+enum { PRE_MW = 2, PRE_NT = 64 * (PRE_MW + 1), PRE_ML = 64 * PRE_MW };
+__global__ void __launch_bounds__(PRE_NT) preint_kernel(PreintArgs A) {
     enum { SMP_CHUNK = 64 };
-    __shared__ double sh[15 * 15 * 4 + 15 * 18 + 64 + 32 + 7 * SMP_CHUNK];
+    __shared__ double sh[2 * 225 + 225 + 225 + 2 * 225 + 2 * 270 + 2 * 64 + 32 + 7 * SMP_CHUNK];
     lds_d *S = (lds_d *)sh;
-    lds_d *J = S, *P = S + 225, *T = S + 450, *F = S + 675, *V = S + 900, *B = S + 1170, *st = S + 1234, *SB = S + 1266;
+    lds_d *Jb = S, *P = S + 450, *T = S + 675, *Fb = S + 900, *Vb = S + 1350, *Bb = S + 1890, *st = S + 2018, *SB = S + 2050;
     // st: delta_p 0..2, delta_q 3..6, delta_v 7..9, acc_0 10..12, gyr_0 13..15, ba 16..18, bg 19..21, sum_dt 22
     const int tid = threadIdx.x;
+    const bool mat = tid < PRE_ML;
+    const int sl = tid - PRE_ML;      // lane of the state wave (>= 0 there)
+    const double n2[6] = {A.noise[0] * A.noise[0], A.noise[1] * A.noise[1], A.noise[0] * A.noise[0], A.noise[1] * A.noise[1],
+                          A.noise[2] * A.noise[2], A.noise[3] * A.noise[3]};      // :21-27 (ACC_N / GYR_N for k and k+1)
     for (int it = blockIdx.x; it < A.n; it += gridDim.x) {
         const double *init = A.init + (size_t)it * 12;
-        if (tid < 225) { J[tid] = (tid / 15 == tid % 15) ? 1.0 : 0.0; P[tid] = 0.0; }
-        if (tid == 0) {
+        const int s0 = A.first[it], ns = A.count[it];
+        if (mat) for (int e = tid; e < 225; e += PRE_ML) { Jb[e] = (e / 15 == e % 15) ? 1.0 : 0.0; P[e] = 0.0; }
+        if (sl == 0) {
             for (int i = 0; i < 10; i++) st[i] = 0.0;
             st[6] = 1.0;
             for (int i = 0; i < 12; i++) st[10 + i] = init[i];
             st[22] = 0.0;
         }
+        // the samples of the buffer in LDS, chunk by chunk (a read from global memory at the top of every step of this serial chain costs a memory
+        // round trip per sample)
+        { const int cnt = min((int)SMP_CHUNK, ns) * 7; for (int i = tid; i < cnt; i += PRE_NT) SB[i] = A.samples[(size_t)s0 * 7 + i]; }
         __syncthreads();
-        const int s0 = A.first[it], ns = A.count[it];
-        // the samples of the buffer in LDS, chunk by chunk: a read from global memory at the top of every step of this serial chain costs a
-        // memory round trip per sample (8 estimators' new buffers: 207 -> ~100 us of a lock-step frame)
-        for (int k = 0; k < ns; k++) {
-            const int kc = k % SMP_CHUNK;
-            if (kc == 0) {
-                __syncthreads();
-                const int cnt = min((int)SMP_CHUNK, ns - k) * 7;
-                for (int i = tid; i < cnt; i += 256) SB[i] = A.samples[(size_t)(s0 + k) * 7 + i];
-                __syncthreads();
-            }
-            const lds_d *smp = SB + kc * 7;
-            const double dt = smp[0];
-            const V3 a1(smp[1], smp[2], smp[3]), g1(smp[4], smp[5], smp[6]);
+        // base matrices of a sample from the state in st (integration_base.h:63-66, :90-118).  ONE lane computes all six 3x3 matrices and stores them
+        // with literal indices: a lane per entry looked parallel but indexed the matrices by (lane / 3, lane % 3) -- a run-time index into
+        // registers, i.e. the matrices went through scratch memory (a memory round trip per access, five times per sample, on the one chain of
+        // the kernel that cannot be hidden: 224 B of scratch per lane until round 5)
+        auto base = [&](const double *smp_dt_acc_gyr, lds_d *B) {
+            const double dt = smp_dt_acc_gyr[0];
+            const V3 a1(smp_dt_acc_gyr[1], smp_dt_acc_gyr[2], smp_dt_acc_gyr[3]), g1(smp_dt_acc_gyr[4], smp_dt_acc_gyr[5], smp_dt_acc_gyr[6]);
             const V3 a0(st[10], st[11], st[12]), g0(st[13], st[14], st[15]), ba(st[16], st[17], st[18]), bg(st[19], st[20], st[21]);
             const Quat dq(st[3], st[4], st[5], st[6]);
             const V3 un_gyr = 0.5 * (g0 + g1) - bg;                                             // :65
             const Quat rq = dq * Quat(un_gyr.x * dt / 2, un_gyr.y * dt / 2, un_gyr.z * dt / 2, 1.0);   // :66 (not normalised here)
-            if (tid < 45) {           // base matrices
-                const int which = tid / 9, e = tid - 9 * which, i = e / 3, j = e - 3 * i;
-                const M3 R0 = to_matrix(dq), R1 = to_matrix(rq);
-                const M3 A0 = skew(a0 - ba), A1 = skew(a1 - ba), Rw = skew(un_gyr);
-                double v;
-                if (which == 0) v = R0(i, j);
-                else if (which == 1) v = R1(i, j);
-                else if (which == 2) v = (R0 * A0)(i, j);
-                else if (which == 3) v = (R1 * A1)(i, j);
-                else { const M3 Bm = m3_identity() - dt * Rw; v = ((R1 * A1) * Bm)(i, j); }
-                B[tid] = v;
-                if (which == 4) { const M3 Bm = m3_identity() - dt * Rw; B[45 + e] = Bm(i, j); }
-            }
-            __syncthreads();
-            if (tid < 225) F[tid] = F_entry(B, tid / 15, tid % 15, dt);
-            for (int e = tid; e < 270; e += 256) V[e] = V_entry(B, e / 18, e % 18, dt);
-            __syncthreads();
-            double jn = 0, tn = 0;
-            if (tid < 225) {
-                const int r = tid / 15, c = tid - 15 * r;
+            const M3 R0 = to_matrix(dq), R1 = to_matrix(rq);
+            const M3 A0 = skew(a0 - ba), A1 = skew(a1 - ba), Rw = skew(un_gyr);
+            const M3 M0 = R0 * A0, M1 = R1 * A1, Bm = m3_identity() - dt * Rw, M1B = M1 * Bm;
 #pragma unroll
-                for (int q = 0; q < 15; q++) { jn += F[r * 15 + q] * J[q * 15 + c]; tn += F[r * 15 + q] * P[q * 15 + c]; }
-            }
-            __syncthreads();
-            if (tid < 225) { J[tid] = jn; T[tid] = tn; }
-            if (tid == 255) {         // state: mid-point rule :63-71, propagate :148-156 (st is next read after two more barriers)
-                const V3 un_acc_0 = rotate(dq, a0 - ba);
-                const V3 un_acc_1 = rotate(rq, a1 - ba);
-                const V3 un_acc = 0.5 * (un_acc_0 + un_acc_1);
-                const V3 dp(st[0], st[1], st[2]), dv(st[7], st[8], st[9]);
-                const V3 rp = dp + dv * dt + 0.5 * un_acc * dt * dt;
-                const V3 rv = dv + un_acc * dt;
-                const Quat qn = normalized(rq);                                                      // :153
-                st[0] = rp.x; st[1] = rp.y; st[2] = rp.z; st[3] = qn.x; st[4] = qn.y; st[5] = qn.z; st[6] = qn.w;
-                st[7] = rv.x; st[8] = rv.y; st[9] = rv.z;
-                st[10] = a1.x; st[11] = a1.y; st[12] = a1.z; st[13] = g1.x; st[14] = g1.y; st[15] = g1.z;
-                st[22] += dt;
-            }
-            __syncthreads();
-            if (tid < 225) {
-                const int r = tid / 15, c = tid - 15 * r;
-                double pn = 0;
+            for (int e = 0; e < 9; e++) { B[e] = R0.m[e]; B[9 + e] = R1.m[e]; B[18 + e] = M0.m[e]; B[27 + e] = M1.m[e]; B[36 + e] = M1B.m[e]; B[45 + e] = Bm.m[e]; }
+        };
+        auto sample_at = [&](int k, double (&o)[7]) {      // sample k of this buffer: out of the LDS chunk that holds it, or (the state wave looking one sample
+            const int c0 = (k / SMP_CHUNK) * SMP_CHUNK;   // ahead across a chunk boundary) straight from memory
+            (void)c0;
 #pragma unroll
-                for (int q = 0; q < 15; q++) pn += T[r * 15 + q] * F[c * 15 + q];
-                const double n2[6] = {A.noise[0] * A.noise[0], A.noise[1] * A.noise[1], A.noise[0] * A.noise[0], A.noise[1] * A.noise[1],
-                                      A.noise[2] * A.noise[2], A.noise[3] * A.noise[3]};      // :21-27 (ACC_N / GYR_N for k and k+1)
-                double vn = 0;
+            for (int i = 0; i < 7; i++) o[i] = A.samples[(size_t)(s0 + k) * 7 + i];
+        };
+        if (sl == 0 && ns > 0) { double sm[7]; for (int i = 0; i < 7; i++) sm[i] = SB[i]; base(sm, Bb); }
+        __syncthreads();
+        for (int k = 0; k < ns; k++) {
+            const int kc = k % SMP_CHUNK, cur = k & 1, nxt = cur ^ 1;
+            if (kc == 0 && k > 0) {      // next chunk of samples (every 64 steps): nobody reads SB between these two barriers
+                __syncthreads();
+                const int cnt = min((int)SMP_CHUNK, ns - k) * 7;
+                for (int i = tid; i < cnt; i += PRE_NT) SB[i] = A.samples[(size_t)(s0 + k) * 7 + i];
+                __syncthreads();
+            }
+            const double dt = SB[kc * 7];
+            lds_d *F = Fb + 225 * cur, *V = Vb + 270 * cur, *J = Jb + 225 * cur, *Jn = Jb + 225 * nxt;
+            const lds_d *B = Bb + 64 * cur;
+            if (mat) {
+                for (int e = tid; e < 225; e += PRE_ML) F[e] = F_entry(B, e / 15, e % 15, dt);
+                for (int e = tid; e < 270; e += PRE_ML) V[e] = V_entry(B, e / 18, e % 18, dt);
+            } else {
+                // the state wave, one sample ahead: state k -> k + 1 (mid-point rule :63-71, propagate :148-156), then the base matrices of sample k + 1
+                double sm[7];
 #pragma unroll
-                for (int q = 0; q < 18; q++) vn += V[r * 18 + q] * n2[q / 3] * V[c * 18 + q];
-                P[tid] = pn + vn;
+                for (int i = 0; i < 7; i++) sm[i] = SB[kc * 7 + i];
+                if (sl == 0) {
+                    const V3 a1(sm[1], sm[2], sm[3]), g1(sm[4], sm[5], sm[6]);
+                    const V3 a0(st[10], st[11], st[12]), g0(st[13], st[14], st[15]), ba(st[16], st[17], st[18]), bg(st[19], st[20], st[21]);
+                    const Quat dq(st[3], st[4], st[5], st[6]);
+                    const V3 un_gyr = 0.5 * (g0 + g1) - bg;
+                    const Quat rq = dq * Quat(un_gyr.x * dt / 2, un_gyr.y * dt / 2, un_gyr.z * dt / 2, 1.0);
+                    const V3 un_acc_0 = rotate(dq, a0 - ba);
+                    const V3 un_acc_1 = rotate(rq, a1 - ba);
+                    const V3 un_acc = 0.5 * (un_acc_0 + un_acc_1);
+                    const V3 dp(st[0], st[1], st[2]), dv(st[7], st[8], st[9]);
+                    const V3 rp = dp + dv * dt + 0.5 * un_acc * dt * dt;
+                    const V3 rv = dv + un_acc * dt;
+                    const Quat qn = normalized(rq);                                                      // :153
+                    st[0] = rp.x; st[1] = rp.y; st[2] = rp.z; st[3] = qn.x; st[4] = qn.y; st[5] = qn.z; st[6] = qn.w;
+                    st[7] = rv.x; st[8] = rv.y; st[9] = rv.z;
+                    st[10] = a1.x; st[11] = a1.y; st[12] = a1.z; st[13] = g1.x; st[14] = g1.y; st[15] = g1.z;
+                    st[22] += dt;
+                }
+                if (k + 1 < ns && sl == 0) {
+                    double sn[7];
+                    if (kc + 1 < SMP_CHUNK) {
+#pragma unroll
+                        for (int i = 0; i < 7; i++) sn[i] = SB[(kc + 1) * 7 + i];
+                    } else sample_at(k + 1, sn);
+                    base(sn, Bb + 64 * nxt);
+                }
             }
             __syncthreads();
+            if (mat) {
+                for (int e = tid; e < 225; e += PRE_ML) {
+                    const int r = e / 15, c = e - 15 * r;
+                    double jn = 0, tn = 0;
+#pragma unroll
+                    for (int q = 0; q < 15; q++) { jn += F[r * 15 + q] * J[q * 15 + c]; tn += F[r * 15 + q] * P[q * 15 + c]; }
+                    Jn[e] = jn; T[e] = tn;
+                }
+            }
+            __syncthreads();
+            if (mat) {
+                for (int e = tid; e < 225; e += PRE_ML) {
+                    const int r = e / 15, c = e - 15 * r;
+                    double pn = 0;
+#pragma unroll
+                    for (int q = 0; q < 15; q++) pn += T[r * 15 + q] * F[c * 15 + q];
+                    double vn = 0;
+#pragma unroll
+                    for (int q = 0; q < 18; q++) vn += V[r * 18 + q] * n2[q / 3] * V[c * 18 + q];
+                    P[e] = pn + vn;
+                }
+            }
+            // (no barrier here: the next step's F / V / J' go to the other halves of their buffers, and its first barrier stands between this
+            // step's writes of P and the next step's reads)
         }
+        __syncthreads();
+        const lds_d *J = Jb + 225 * (ns & 1);
         double *o = A.out + (size_t)it * PREINT_OUT;
         if (tid < 10) o[tid] = st[tid];
         if (tid < 6) o[10 + tid] = st[16 + tid];
         if (tid == 0) o[16] = st[22];
-        if (tid < 225) { o[17 + tid] = J[tid]; o[242 + tid] = P[tid]; }
+        for (int e = tid; e < 225; e += PRE_NT) { o[17 + e] = J[e]; o[242 + e] = P[e]; }
         __syncthreads();
     }
 }
@@ -221,7 +266,7 @@ static int preintegrate_core(int n, const int *first, const int *count, const do
     if ((e = hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, st)) != hipSuccess) return done(hip_fail(e, "hipMemcpyAsync"));
     a.init = (const double *)d; a.samples = (const double *)d + 12 * (size_t)n; a.first = (const int *)((const double *)d + in_d); a.count = a.first + n;
     a.out = handles ? (double *)d_res : (double *)(d + out_off);
-    hipLaunchKernelGGL(preint_kernel, dim3(std::min(n, 4096)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(preint_kernel, dim3(std::min(n, 4096)), dim3(tcv::PRE_NT), 0, st, a);
     if ((e = hipGetLastError()) != hipSuccess) return done(hip_fail(e, "preint kernel launch"));
     char *ho = h + in_bytes;
     if (out && (e = hipMemcpyAsync(ho, (const char *)a.out, out_bytes, hipMemcpyDeviceToHost, st)) != hipSuccess) return done(hip_fail(e, "hipMemcpyAsync"));

@@ -298,6 +298,62 @@ print("ok", k)
 test_a_failed_marginalisation_is_reported_at_the_estimators_next_frame = pytest.mark.gpu(test_a_failed_marginalisation_is_reported_at_the_estimators_next_frame)
 
 
+def test_a_failed_deferred_launch_costs_only_its_own_batch():
+    """Frames of many windows launch their marginalisation with the estimators' NEXT tcv_estimators_optimize (TCV_EST_MARG_DEFER).  When that
+    launch fails (injected), the estimators of THAT batch lose their new prior: their window of this frame is solved without it, nothing of it is
+    applied and finish_frame reports the failure for them -- the other estimators of the same call go on, and nothing is sticky (until round 5
+    the call returned the launch's error for every estimator of the batch on every later call until a reset).  Own process: the hook is read once."""
+    import subprocess, sys, os
+    code = r'''
+import sys, os, ctypes as C
+sys.path.insert(0, os.path.join(%r, "tc-viml_amd"))
+import numpy as np, replay, tcv
+W = replay.WINDOW_SIZE
+streams = [replay.simulate_stream(80 + s, W + 8, max_features=30) for s in range(4)]
+ls = replay.NativeLockstep(streams, num_iterations=4)
+L, vp = ls.L, ls.vp
+seen = None
+for k in range(W + 6):
+    live, arr_all, rec, rdy, keep = ls._frame_batch(k)
+    tcv.check(L.tcv_estimators_begin_frames(arr_all, len(live), rec, rdy, None))
+    ready = [si for j, si in enumerate(live) if rdy[j]]
+    if not ready:
+        continue
+    # frame W: two batches ([0, 1] and [2, 3]: deferred launches 0 and 1 at frame W + 1); from frame W + 1 on ONE call for all four
+    groups = [[0, 1], [2, 3]] if k == W else [[0, 1, 2, 3]]
+    for g in groups:
+        tcv.check(L.tcv_estimators_optimize((vp * len(g))(*[ls.ests[si] for si in g]), len(g)))      # the call itself succeeds
+    nr = len(ready)
+    pa, qa, va = np.zeros((nr, 3)), np.zeros((nr, 4)), np.zeros((nr, 3))
+    rcs = (C.c_int * nr)()
+    rc = L.tcv_estimators_finish_frames((vp * nr)(*[ls.ests[si] for si in ready]), nr, ls._P(pa), ls._P(qa), ls._P(va), rcs, None)
+    if k == W + 1:
+        assert rc != 0 and b"could not be launched" in L.tcv_last_error(), (rc, L.tcv_last_error())
+        assert list(rcs)[:2] == [0, 0] and list(rcs)[2:] == [tcv.TCV_ERR_HIP] * 2, list(rcs)      # launch 1 = the batch of streams 2, 3
+        seen = k
+        break
+    assert rc == 0 and not any(rcs), (k, rc, list(rcs))
+assert seen == W + 1
+# nothing sticky: the two unaffected estimators take their next frame as usual
+k = W + 2
+live, arr_all, rec, rdy, keep = ls._frame_batch(k)
+sub = [0, 1]
+arr = (vp * 2)(*[ls.ests[si] for si in sub])
+rec2 = (type(rec[0]) * 2)(rec[0], rec[1]); rdy2 = (C.c_int * 2)()
+tcv.check(L.tcv_estimators_begin_frames(arr, 2, rec2, rdy2, None))
+tcv.check(L.tcv_estimators_optimize(arr, 2))
+pa, qa, va = np.zeros((2, 3)), np.zeros((2, 4)), np.zeros((2, 3))
+rcs = (C.c_int * 2)()
+tcv.check(L.tcv_estimators_finish_frames(arr, 2, ls._P(pa), ls._P(qa), ls._P(va), rcs, None))
+assert list(rcs) == [0, 0] and np.isfinite(pa).all()
+print("ok")
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    env = dict(os.environ, TCV_EST_INJECT_LAUNCH_FAIL="1", TCV_EST_MARG_DEFER="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+test_a_failed_deferred_launch_costs_only_its_own_batch = pytest.mark.gpu(test_a_failed_deferred_launch_costs_only_its_own_batch)
+
+
 def _drive_grouped(gpu, streams, n_frames, groups_of_frame, threads=False):
     """lock-step frames through tcv_estimators_begin_frames / optimize / finish_frames with the estimators of a frame split into the groups
     `groups_of_frame(k)` names (lists of stream indices): one tcv_estimators_optimize per group, one after the other or on threads of their own.

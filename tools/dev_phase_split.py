@@ -34,6 +34,8 @@ def main():
         if not os.path.exists(path):
             print("%-60s (library not built)" % name); continue
         env = dict(os.environ, TCV_LIB=path, TCV_GRID=str(grid), TCV_CHAIN_LDS_DOUBLES=lds)
+        if path != lib(""):
+            env["TCV_ABLATED"] = "1"
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dev_occupancy3.py"), "--worker", str(frames), str(B)], env=env, capture_output=True, text=True, timeout=900)
         r = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")]
         if out.returncode != 0 or not r:
