@@ -93,7 +93,7 @@ struct MargArgs {
     double *scratch;             // per workgroup MARG_SCR_STRIDE
     int nwin, state_stride, use_solved_state;
     int eig_mm;                  // 1: Amm^+ through the eigen-decomposition for every window (TCV_MARG_EIG_MM=1: A/B checks)
-    int eig_flags;               // developer A/B switches of the eigen-solver of A' (TCV_MARG_EIG_FLAGS): 1 = round 2's eigenvalue search (every eigenvalue, 4- / 7-section), 2 = reflector-by-reflector back-transformation on the VALU, 4 = round 5's LDS-resident tridiagonalisation, 8 = the register-resident one on two wavefronts (one lane per column) instead of four
+    int eig_flags;               // developer A/B switches of the eigen-solver of A' (TCV_MARG_EIG_FLAGS): 1 = round 2's eigenvalue search (every eigenvalue, 4- / 7-section), 2 = reflector-by-reflector back-transformation on the VALU, 4 / 8 = round 6's register-resident tridiagonalisations on four / two wavefronts (measured slower: profiles/r06_marg_tridiag.txt)
 };
 
 __device__ __forceinline__ int pidx(int a, int b) { return a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a; }
@@ -806,7 +806,14 @@ __device__ __forceinline__ double row_of_h(const double (&a)[MARG_MAX_N / 2], in
     return v;
 }
 template <int NT>
-__device__ __noinline__ void tridiag_cols4(lds_d *A_, lds_d *Hq_, lds_d *sm_, int n_, int ld_, int tid) {
+__device__ __noinline__ void tridiag_cols4(lds_d *A_, lds_d *Hq_, lds_d *sm_, int n_, int ld_, int tid, gbl_d *dbg) {
+#ifdef TCV_PROFILE      // per-part cycles of wave 0 (slots 14..: scalars + product | barrier | p, v, reduction | barrier | update | hand-over | barrier)
+    long long t_c4 = clock64();
+    if (tid == 0 && dbg) for (int i = 14; i < 26; i++) dbg[i] = 0.0;
+#define C4MARK(id) do { const long long t_ = clock64(); if (tid == 0 && dbg) dbg[14 + (id)] += (double)(t_ - t_c4); t_c4 = t_; } while (0)
+#else
+#define C4MARK(id) do { } while (0)
+#endif
     static_assert(MARG_MAX_N == 80 && NT >= 256, "two lanes per column (row parity), four wavefronts");
     typedef double v2d __attribute__((ext_vector_type(2)));
     typedef __attribute__((address_space(3))) v2d lds_v2d;
@@ -883,7 +890,9 @@ __device__ __noinline__ void tridiag_cols4(lds_d *A_, lds_d *Hq_, lds_d *sm_, in
             }
             if (col) ubuf[NR * h + c] = u0 + u1;
         }
+        C4MARK(0);
         __syncthreads();
+        C4MARK(1);
         if (live) {
             const double u = col ? ubuf[c] + ubuf[NR + c] : 0.0;      // (even rows) + (odd rows): the same sum in both halves
             const double xc = col ? xbuf[c] : 0.0, a0 = col ? a0buf[c] : 0.0;
@@ -897,7 +906,9 @@ __device__ __noinline__ void tridiag_cols4(lds_d *A_, lds_d *Hq_, lds_d *sm_, in
                 if (tid == 0) { dv[i] = red[4]; ev[i] = beta; tauv[i] = tau; }
             }
         }
+        C4MARK(2);
         __syncthreads();
+        C4MARK(3);
         if (live) {
             const double K = -0.5 * tau * (red[2] + red[3]);
             const double wc = fma(K, vc, pc);
@@ -928,6 +939,7 @@ __device__ __noinline__ void tridiag_cols4(lds_d *A_, lds_d *Hq_, lds_d *sm_, in
                         }
                     }
             }
+            C4MARK(4);
             // hand-over to step i + 1: row i + 1 (the half of its parity) -> diagonal entry, x, |x[1:]|^2; row i + 2 (the other half) -> A22[:,0]
             const int r1 = i + 1, r2 = min(i + 2, NR - 1);
             if (h == (r1 & 1)) {
@@ -941,9 +953,12 @@ __device__ __noinline__ void tridiag_cols4(lds_d *A_, lds_d *Hq_, lds_d *sm_, in
             }
             if (h == (r2 & 1) && col) a0buf[c] = row_of_h(a, r2 >> 1);
         }
+        C4MARK(5);
         __syncthreads();
+        C4MARK(6);
     }
     if (tid == 0) { dv[n - 1] = red[4]; ev[n - 1] = 0.0; }
+#undef C4MARK
 }
 
 __device__ __forceinline__ double rank2(double a, double vr, double wc, double wr, double vc) { return a - (vr * wc + wr * vc); }
@@ -969,9 +984,9 @@ __device__ __noinline__ __attribute__((disable_tail_calls)) bool sym_eig_tridiag
 #define EMARK(id) do { } while (0)
 #endif
     if (tid == 0 && dbg) for (int i = 0; i < 6; i++) dbg[8 + i] = 0.0;
-    if (!(flags & 4)) {      // round 6: the matrix in registers, one column per lane of the first two wavefronts (flags bit 2: the LDS-resident path below, A/B)
-        if (flags & 8) tridiag_cols<NT>(A, Hq, sm, n, ld, tid);      // (bit 3: one lane per column on two wavefronts -- correct, issue bound, slower: A/B)
-        else tridiag_cols4<NT>(A, Hq, sm, n, ld, tid);
+    if (flags & 12) {      // round 6 experiments, both measured SLOWER than the LDS-resident path below (profiles/r06_marg_tridiag.txt): the matrix in registers,
+        if (flags & 8) tridiag_cols<NT>(A, Hq, sm, n, ld, tid);      // bit 3: one lane per column on two wavefronts
+        else tridiag_cols4<NT>(A, Hq, sm, n, ld, tid, dbg);          // bit 2: two lanes per column (row parity) on four wavefronts
     } else {
     // ---- (1) tridiagonalisation.  Step i: x = A[i+1:, i] (read as row i: the matrix is kept fully symmetric).  Every
     // 4-lane group owns one row r of A22 and forms u_r = A22[r,:] x together with |x[1:]|^2 in the same sweep, so that
@@ -2814,6 +2829,9 @@ int tcv_marg_get_prior(tcv_batch *b, int window, tcv_prior **out) {
         const char *en[6] = {"tridiag", "bisect", "vectors", "mgs", "backtr", "check"};
         for (int i = 0; i < 6; i++) fprintf(stderr, "[tcv]     eig_rr.%-8s %10.0f cycles\n", en[i], o[MARG_OUT_X + MARG_MAX_X + 14 + 8 + i]);
         fprintf(stderr, "[tcv]     tridiag steps (wave 0): part 1 %.0f | barrier %.0f | update m > 40 %.0f, m > 16 %.0f, m <= 16 %.0f | barrier %.0f cycles\n", o[MARG_OUT_X + MARG_MAX_X + 28], o[MARG_OUT_X + MARG_MAX_X + 29], o[MARG_OUT_X + MARG_MAX_X + 30], o[MARG_OUT_X + MARG_MAX_X + 31], o[MARG_OUT_X + MARG_MAX_X + 32], o[MARG_OUT_X + MARG_MAX_X + 33]);
+        if (getenv("TCV_MARG_EIG_FLAGS") && (atoi(getenv("TCV_MARG_EIG_FLAGS")) & 4))      // the four-wavefront register variant's own parts (same slots)
+            fprintf(stderr, "[tcv]     tridiag_cols4 (wave 0): scalars + product %.0f | barrier %.0f | p, v, reduction %.0f | barrier %.0f | update %.0f | hand-over %.0f | barrier %.0f cycles\n",
+                    o[MARG_OUT_X + MARG_MAX_X + 28], o[MARG_OUT_X + MARG_MAX_X + 29], o[MARG_OUT_X + MARG_MAX_X + 30], o[MARG_OUT_X + MARG_MAX_X + 31], o[MARG_OUT_X + MARG_MAX_X + 32], o[MARG_OUT_X + MARG_MAX_X + 33], o[MARG_OUT_X + MARG_MAX_X + 34]);
         fprintf(stderr, "[tcv]   tridiag check: dev %.3e sum(lam) %.10e trace %.10e |T| %.3e lam_min %.3e lam_max %.3e\n", o[MARG_OUT_X + MARG_MAX_X + 14], o[MARG_OUT_X + MARG_MAX_X + 15], o[MARG_OUT_X + MARG_MAX_X + 16], o[MARG_OUT_X + MARG_MAX_X + 17], o[MARG_OUT_X + MARG_MAX_X + 18], o[MARG_OUT_X + MARG_MAX_X + 19]);
     }
     for (double v : pr->J0) if (!(v == v)) { delete pr; set_error("NaN in marginalisation result"); return TCV_ERR_NUMERIC; }
