@@ -470,3 +470,32 @@ def test_host_threads_end_cleanly_under_the_profiler(gpu, tmp_path):
                          capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
     text = out.stdout + out.stderr
     assert out.returncode == 0 and "windows optimised" in text, text[-3000:]
+
+
+@pytest.mark.gpu
+def test_the_shipped_solver_budget_runs_through_the_native_estimator():
+    """sensor.yaml:85-86 / estimator.cpp:1890-1897: max_num_iterations 100 with the convergence tests on and SOLVER_TIME 0.04 s (x 4/5 on frames that
+    marginalise the oldest keyframe) -- tcv_estimator_config::solver_time.  On the device a window converges long before the wall budget: every
+    solve ends by a tolerance (or, rarely, the iteration cap), none by the clock, and the per-frame statistics say how (tcv_estimator_stats::termination)."""
+    streams = [replay.simulate_stream(60 + s, replay.WINDOW_SIZE + 8, max_features=40) for s in range(3)]
+    ls = replay.NativeLockstep(streams, num_iterations=100, fixed_iterations=False, solver_time=0.04)
+    try:
+        for k in range(ls.n_frames):
+            ls.step(k)
+        res = ls.results()
+    finally:
+        ls.close()
+    its = [e["iterations"] for r in res for e in r["log"]]
+    term = [e["termination"] for r in res for e in r["log"]]
+    assert len(its) == 3 * 8
+    assert all(2 <= i <= 101 for i in its) and all(0 <= t <= 4 for t in term), (its, term)
+    assert sum(1 for t in term if t in (1, 2, 3)) >= len(term) - 2          # tolerances end the solves, not the budget
+    # same streams, 8 fixed iterations: the converged solves cost at least as many iterations and end lower or equal in cost
+    ls8 = replay.NativeLockstep(streams, num_iterations=8, fixed_iterations=True)
+    try:
+        for k in range(ls8.n_frames):
+            ls8.step(k)
+        res8 = ls8.results()
+    finally:
+        ls8.close()
+    assert all(e["termination"] == 0 and e["iterations"] == 9 for r in res8 for e in r["log"])      # the cap: NO_CONVERGENCE, iteration 0 + 8
