@@ -44,10 +44,10 @@ def test_golden_marginalisation_after_solve(gpu):
     assert fro(As, z["marg_A_schur"]) < 5e-6 and fro(bs, z["marg_b_schur"]) < 5e-7      # measured 5.2e-7 / 4.7e-8 (each side linearises at its own solve's states)
     JtJ = d["J0"].T @ d["J0"]
     assert fro(JtJ, z["marg_J0"].T @ z["marg_J0"]) < 5e-6                                 # measured 5.1e-7
-    assert fro(d["J0"].T @ d["r0"], z["marg_J0"].T @ z["marg_r0"]) < 1e-4                 # measured 1.8e-5
+    assert fro(d["J0"].T @ d["r0"], z["marg_J0"].T @ z["marg_r0"]) < 6e-5                 # measured 1.8e-5 (gate = 3 x: r0 = S^-1/2 V' b' amplifies the eigenvectors' rounding)
     assert rel(np.concatenate(d["x0"]), z["marg_x0"]) < 1e-7          # linearisation point = solved states (preMarginalize :110-129); measured 7.5e-9
     # reference invariants (marginalization_factor.cpp:297-298) up to the eps = 1e-8 thresholded null space (35 of 75 eigenvalues)
-    assert fro(JtJ, As) < 5e-7 and fro(d["J0"].T @ d["r0"], bs) < 1e-4                    # measured 3.7e-8 / 1.5e-5
+    assert fro(JtJ, As) < 5e-7 and fro(d["J0"].T @ d["r0"], bs) < 5e-5                    # measured 3.7e-8 / 1.5e-5 (3 x)
     # thresholded factor is positive semi-definite and ordered like SelfAdjointEigenSolver (ascending)
     rn = np.linalg.norm(d["J0"], axis=1)
     assert np.all(np.diff(rn) >= -1e-9 * rn.max())
@@ -152,7 +152,7 @@ def test_margin_second_new_prior_only(gpu):
                                                                     fro(d["J0"].T @ d["r0"], po["J0"].T @ po["r0"])))
     assert fro(As, dbg["A_schur"]) < 2e-6 and fro(bs, dbg["b_schur"]) < 1e-8
     assert fro(d["J0"].T @ d["J0"], po["J0"].T @ po["J0"]) < 2e-6
-    assert fro(d["J0"].T @ d["r0"], po["J0"].T @ po["r0"]) < 2e-4
+    assert fro(d["J0"].T @ d["r0"], po["J0"].T @ po["r0"]) < 1e-10      # measured 1.8e-13 (MARGIN_SECOND_NEW of a full-rank prior: no thresholded noise directions)
     assert rel(np.concatenate(d["x0"]), np.concatenate([np.atleast_1d(v) for v in po["x0"]])) == 0.0
     # kept blocks: every prior block except pose WINDOW_SIZE-1, un-shifted
     W = main["pose"].shape[0] - 1
@@ -212,7 +212,7 @@ def test_both_launch_shapes_of_the_marginalisation_kernel(gpu, monkeypatch, nt):
         As2, bs2 = b2.prior(k).schur(); d2 = b2.prior(k).export()
         assert np.array_equal(As, As2) and np.array_equal(bs, bs2)
         # measured (both shapes alike: the defect is the thresholded noise eigenvalue, -4e-2 against |A'| = 3e5): 1.3e-7 / 1.4e-5
-        assert fro(d["J0"].T @ d["J0"], As) < 2e-6 and fro(d["J0"].T @ d["r0"], bs) < 1e-4
+        assert fro(d["J0"].T @ d["J0"], As) < 2e-6 and fro(d["J0"].T @ d["r0"], bs) < 5e-5
         assert fro(d["J0"].T @ d["J0"], d2["J0"].T @ d2["J0"]) < 1e-9
 
 
