@@ -37,7 +37,12 @@ enum { MARG_MAX_M = 64, MARG_MAX_N = 80, MARG_MAX_POS = MARG_MAX_M + MARG_MAX_N,
 // Two launch shapes of the one kernel: 512 threads per window and one workgroup per CU (few windows: shortest time per window), or
 // 256 threads per window and two workgroups per CU when every window of the batch fits 80 KB of LDS (many windows: the barrier and
 // LDS round trips of one window hide behind the other's arithmetic).
-enum { MARG_NT_WIDE = 512, MARG_NT_PAIR = 256, MARG_SM = 768, MARG_STAGE = 64 * 43, MARG_CB_LM = 16 };
+#ifdef TCV_MARG_REG_TRIDIAG
+enum { MARG_SM_DOUBLES = 768 };      // (tridiag_cols4's exchange buffers)
+#else
+enum { MARG_SM_DOUBLES = 720 };
+#endif
+enum { MARG_NT_WIDE = 512, MARG_NT_PAIR = 256, MARG_SM = MARG_SM_DOUBLES, MARG_STAGE = 64 * 43, MARG_CB_LM = 16 };
 // per-window result block: [J0 | r0 | x (linearisation point) + 64 diagnostics] is what a caller needs (MARG_OUT_COMPACT doubles, the
 // part tcv_batch_download_priors_compact copies); A', b' (parity / debug surface) follow
 enum { MARG_OUT_J0 = 0, MARG_OUT_R0 = 6400, MARG_OUT_X = 6480, MARG_OUT_COMPACT = 6480 + 1408 + 64, MARG_OUT_AS = MARG_OUT_COMPACT, MARG_OUT_BS = MARG_OUT_AS + 6400,
@@ -622,6 +627,11 @@ __device__ __noinline__ void eig_backtransform_wy(const lds_d *Hq_, lds_d *Z_, c
     }
 }
 
+// (-DTCV_MARG_REG_TRIDIAG=1, `python tc-viml_amd/build.py --suffix=regtri -DTCV_MARG_REG_TRIDIAG=1`: the two register-resident tridiagonalisations of
+// round 6 below are compiled in and selected by TCV_MARG_EIG_FLAGS bits 2 / 3.  Both were measured SLOWER than the LDS-resident path
+// (profiles/r06_marg_tridiag.txt), and their mere presence costs the production kernel 2 - 3 % (call frames, another register allocation of
+// sym_eig_tridiag): the default build leaves them out.)
+#ifdef TCV_MARG_REG_TRIDIAG
 // ---- round 6: the tridiagonalisation with the matrix in REGISTERS, one column per lane -------------------------------------------------
 // The 256-thread shape above spends ~4 900 cycles per Householder step on a 75 x 75 matrix (LDS-bandwidth bound rank-2 update over eight
 // lanes per row, a product pass, two workgroup barriers; profiles/r05_phase_cycles_marg_256.txt: 353 K of a window's 760 K cycles).  Here
@@ -961,6 +971,8 @@ __device__ __noinline__ void tridiag_cols4(lds_d *A_, lds_d *Hq_, lds_d *sm_, in
 #undef C4MARK
 }
 
+#endif      // TCV_MARG_REG_TRIDIAG
+
 __device__ __forceinline__ double rank2(double a, double vr, double wc, double wr, double vc) { return a - (vr * wc + wr * vc); }
 template <int NT>
 // (disable_tail_calls on every function that calls a non-inlined one: with the IR `tail` marker on a call the callee saves and restores
@@ -984,10 +996,13 @@ __device__ __noinline__ __attribute__((disable_tail_calls)) bool sym_eig_tridiag
 #define EMARK(id) do { } while (0)
 #endif
     if (tid == 0 && dbg) for (int i = 0; i < 6; i++) dbg[8 + i] = 0.0;
+#ifdef TCV_MARG_REG_TRIDIAG
     if (flags & 12) {      // round 6 experiments, both measured SLOWER than the LDS-resident path below (profiles/r06_marg_tridiag.txt): the matrix in registers,
         if (flags & 8) tridiag_cols<NT>(A, Hq, sm, n, ld, tid);      // bit 3: one lane per column on two wavefronts
         else tridiag_cols4<NT>(A, Hq, sm, n, ld, tid, dbg);          // bit 2: two lanes per column (row parity) on four wavefronts
-    } else {
+    } else
+#endif
+    {
     // ---- (1) tridiagonalisation.  Step i: x = A[i+1:, i] (read as row i: the matrix is kept fully symmetric).  Every
     // 4-lane group owns one row r of A22 and forms u_r = A22[r,:] x together with |x[1:]|^2 in the same sweep, so that
     // beta, tau and v = (x - beta e1) / (alpha - beta) need no extra pass: A22 v = (u - beta A22[:,0]) / (alpha - beta).

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the register variants need the -DTCV_MARG_REG_TRIDIAG build since the end of the round: TCV_LIB=tc-viml_amd/libtcv_hip_regtri.so)
 # round 6, GPU call d: four-wave register-resident tridiagonalisation (parity + A/B + phase cycles), the re-cut pre-integration kernel, the
 # boundary tests of the round, the phase-split bound with the fixed tool
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r06d; mkdir -p $O; cd $R
