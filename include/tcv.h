@@ -271,6 +271,10 @@ int tcv_batch_marginalize(tcv_batch *b, void *hip_stream);
  * reference does (double2vector :1905, vector2double :1915).  The origin (Rs[0], Ps[0]) is the uploaded initial
  * pose of frame 0.  Needs the frame table (tcv_problem_set_frames / tcv_problem_from_window). */
 int tcv_batch_gauge_fix(tcv_batch *b, void *hip_stream);
+/* The same fix in the solve kernel's epilogue, where the solved states are still on chip: from the next tcv_batch_solve on the batch's states come out
+ * gauge-fixed (one kernel launch and its gap less per frame) and tcv_batch_gauge_fix behind such a solve is a no-op.  Same arithmetic, same bits
+ * (tests/test_gpu_gauge.py).  Needs the frame tables, like tcv_batch_gauge_fix. */
+int tcv_batch_set_fused_gauge_fix(tcv_batch *b, int on);
 int tcv_batch_synchronize(tcv_batch *b);
 /* copy results back: states into the callers' parameter blocks, summaries, priors */
 int tcv_batch_download_states(tcv_batch *b);

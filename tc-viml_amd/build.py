@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libtcv_hip.so")
 SOURCES = ["tcv_capi.hip", "tcv_solve.hip", "tcv_marg.hip", "tcv_preint.hip", "tcv_gauge.hip", "tcv_lines.hip", "tcv_microbench.hip", "tcv_pack.cpp", "tcv_estimator.cpp"]
-HEADERS = ["tcv_math.h", "tcv_factors.h", "tcv_packed.h", "tcv_host.h", "tcv_dev.h", os.path.join("..", "..", "include", "tcv.h"), os.path.join("..", "..", "include", "tcv_estimator.h")]
+HEADERS = ["tcv_math.h", "tcv_gauge.h", "tcv_factors.h", "tcv_packed.h", "tcv_host.h", "tcv_dev.h", os.path.join("..", "..", "include", "tcv.h"), os.path.join("..", "..", "include", "tcv_estimator.h")]
 
 
 def _stale() -> bool:

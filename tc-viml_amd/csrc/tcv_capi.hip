@@ -1168,6 +1168,7 @@ extern "C" int tcv_batch_solve(tcv_batch *b, const tcv_solver_options *o, void *
     a.imublk = b->d_imublk; a.spill = b->d_spill; a.spill_stride = b->spill_stride;
     a.max_ticks = 0;
     a.sqrt_out = b->d_sqrt_out;
+    a.gauge_fix = b->fuse_gauge ? 1 : 0;
     // cooperative plans also run on the single-workgroup kernel (workgroups_per_window = 1): same chunks, same additions, same bits
     bool coop = b->coop_h > 0 && o->workgroups_per_window != 1;
     if (coop && b->coop_claim == 0)      // (a claim still held: the previous cooperative solve of this batch, same stream order, same rotation)
@@ -1200,6 +1201,8 @@ extern "C" int tcv_batch_solve(tcv_batch *b, const tcv_solver_options *o, void *
     if (rc != 0) return hip_fail((hipError_t)rc, "solve kernel launch");
     HIPCHK(hipEventRecord(b->ev1, st));
     b->solved = true;
+    b->gauge_in_solve = a.gauge_fix != 0;
+    if (a.gauge_fix) b->gauge_fixed = true;
     return TCV_OK;
 }
 extern "C" int tcv_batch_marginalize(tcv_batch *b, void *hip_stream) {

@@ -1055,7 +1055,11 @@ static int optimize_begin(OptRun &R) {
             o.max_solver_time_in_seconds = es[0]->cfg.solver_time * (any_old ? 4.0 / 5.0 : 1.0);
         }
         void *st = (void *)g_streams[group];
-        g.rc = tcv_batch_solve(g.b, &o, st);
+        // double2vector() in the solve kernel's epilogue (the tcv_batch_gauge_fix below is then a no-op): one launch and its gap less per frame.
+        // TCV_EST_SEPARATE_GAUGE=1: the stand-alone kernel, as up to round 5 (same bits)
+        static const bool separate_gauge = getenv("TCV_EST_SEPARATE_GAUGE") != nullptr;
+        if (!separate_gauge) g.rc = tcv_batch_set_fused_gauge_fix(g.b, 1);
+        if (g.rc == TCV_OK) g.rc = tcv_batch_solve(g.b, &o, st);
         if (g.rc == TCV_OK) g.rc = tcv_batch_gauge_fix(g.b, st);
         if (g.rc == TCV_OK && g.any_marg && !marg_off_path) g.rc = tcv_batch_marginalize(g.b, st);
         // the copy of the states (and of the summary heads) goes on the stream right behind the gauge fix -- BEFORE the upload of the marginalisation

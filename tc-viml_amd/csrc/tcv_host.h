@@ -190,6 +190,7 @@ struct tcv_batch {
     bool solved = false;
     std::vector<double> h_state;
     bool gauge_fixed = false;
+    bool fuse_gauge = false, gauge_in_solve = false;      // tcv_batch_set_fused_gauge_fix: the fix in the solve kernel's epilogue; whether the LAST solve applied it
     hipStream_t last_stream = nullptr;     // stream of the last asynchronous call
     std::vector<hipStream_t> streams;      // every stream with work of this batch in flight (tcv_batch_synchronize / batch_free wait for all of them; null: the device)
     hipEvent_t ev_dl = nullptr;            // tcv_batch_download_states_begin: recorded behind the enqueued copy of the states

@@ -200,7 +200,8 @@ struct SolveArgs {
     double *coop_exp;             // per group coop_exp_chunks x coop_exp_stride doubles
     long long coop_timeout;       // ticks of the constant-rate device clock a workgroup waits for its partners before it gives up (status -9)
     int role_mode, chain_td;          // chain kernel: placement of the wavefront roles on the SIMDs (tcv_solve.hip, solve_kernel), developer switch TCV_ROLE_MODE
-    int coop_rot, pad3;               // cooperative mode: group g runs on the workgroups b with b % 8 == (g + coop_rot) % 8, i.e. on XCD (g + coop_rot) % 8
+    int coop_rot, gauge_fix;          // cooperative mode: group g runs on the workgroups b with b % 8 == (g + coop_rot) % 8, i.e. on XCD (g + coop_rot) % 8;
+                                      // gauge_fix: double2vector() in the kernel's epilogue (tcv_batch_set_fused_gauge_fix)
 };
 
 // ---- cooperative mode (tcv_solve.hip, solve_kernel<.., COOP = true>) ---------------------------------------------------------------

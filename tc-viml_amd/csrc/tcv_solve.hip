@@ -22,6 +22,7 @@
 #include "tcv_factors.h"
 #include "tcv_packed.h"
 #include "tcv_dev.h"
+#include "tcv_gauge.h"
 
 namespace tcv {
 
@@ -2305,6 +2306,38 @@ __device__ __noinline__ void sqrt_info_all(cst_d *imu0_, int n_imu_, gbl_d *g_sq
         (void)imu_sqrt_info_group(imu0 + f * IMU_CONST + IMU_COV, g_sqrt + f * 225, ws + f * 450, ws + f * 450 + 225, tid & 15);
 }
 
+// double2vector() (estimator.cpp:1537-1581) on the solved states while they are still in LDS (SolveArgs::gauge_fix): thread i < n_frames takes frame i, every
+// thread recomputes rot_diff from the un-fixed pose 0, which is overwritten behind the barrier -- the arithmetic of tcv::gauge_batch_kernel (tcv_gauge.hip),
+// the same bits.  A function of its own: atan2 / sin / cos in FP64 would otherwise sit in the kernel's register allocation.
+template <int NT>
+__device__ __noinline__ void gauge_epilogue(lds_d *xs_, cst_d *x_init_, cst_i *ft_, int n_frames_, int tid) {
+    lds_d *xs = uni_ptr(xs_);
+    cst_d *x_init = uni_ptr(x_init_);
+    cst_i *ft = uni_ptr(ft_);
+    const int n_frames = __builtin_amdgcn_readfirstlane(n_frames_);
+    const bool act = tid < n_frames && n_frames > 0 && ft[0] >= 0 && ft[2 * min(tid, max(n_frames - 1, 0))] >= 0;
+    M3 R; V3 Pn, V;
+    int go = 0, so = -1;
+    if (act) {
+        const int g0 = ft[0];
+        go = ft[2 * tid]; so = ft[2 * tid + 1];
+        double p0i[7], p0[7], pi[7], vi[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < 7; k++) { p0i[k] = x_init[g0 + k]; p0[k] = xs[g0 + k]; pi[k] = xs[go + k]; }
+        if (so >= 0) { vi[0] = xs[so]; vi[1] = xs[so + 1]; vi[2] = xs[so + 2]; }
+        const M3 R0 = to_matrix(Quat(p0i + 3));      // Rs[0] before the solve: what vector2double() turned into para_Pose[0]
+        const M3 rot = gauge_rot_diff(R0, p0);
+        gauge_frame(rot, p0i, p0, pi, so >= 0 ? vi : nullptr, R, Pn, V);
+    }
+    __syncthreads();
+    if (act) {
+        const Quat q = r2q(R);
+        xs[go] = Pn.x; xs[go + 1] = Pn.y; xs[go + 2] = Pn.z; xs[go + 3] = q.x; xs[go + 4] = q.y; xs[go + 5] = q.z; xs[go + 6] = q.w;
+        if (so >= 0) { xs[so] = V.x; xs[so + 1] = V.y; xs[so + 2] = V.z; }
+    }
+    __syncthreads();
+}
+
 template <int NT, bool MFMA, bool CHAIN, bool COOP = false, bool TD = !CHAIN>
 // (-DTCV_CHAIN_OCC1, developer build libtcv_hip_occ1.so: the chain kernel compiled for ONE wavefront per SIMD -- 512 registers, no spills -- to
 // measure what the 156 spilled registers of the production kernel cost at equal occupancy, profiles/r03_spill_ab.txt)
@@ -2642,6 +2675,7 @@ __global__ void __launch_bounds__(NT) __attribute__((disable_tail_calls)) __attr
             if (radius < 1e-32) { termination = 4; break; }
         }
         __syncthreads();
+        if (A.gauge_fix) gauge_epilogue<NT>(K.xs, K.dp + W->d_x, K.ip + P.o_frames, P.n_frames, tid);
         for (int i = tid; i < P.nx + L; i += NT) A.state_out[(size_t)win * A.state_stride + i] = K.xs[i];
         if (tid == 0) {
             S->num_iterations = nrec;

@@ -37,7 +37,7 @@ EXPORTS = [
     "tcv_batch_download_states", "tcv_batch_get_summaries", "tcv_batch_get_prior", "tcv_batch_get_first_step",
     "tcv_batch_plan_stats", "tcv_batch_layout", "tcv_batch_stats", "tcv_batch_size",
     "tcv_eval_imu_factors", "tcv_eval_projection_factors", "tcv_eval_line_factors", "tcv_pose_plus", "tcv_preintegrate",
-    "tcv_problem_set_frames", "tcv_gauge_fix", "tcv_batch_gauge_fix", "tcv_set_solver_variant", "tcv_set_cooperative", "tcv_batch_cooperative", "tcv_batch_get_priors", "tcv_batch_marg_status", "tcv_eval_projection_td_factors", "tcv_match_lines",
+    "tcv_problem_set_frames", "tcv_gauge_fix", "tcv_batch_gauge_fix", "tcv_batch_set_fused_gauge_fix", "tcv_set_solver_variant", "tcv_set_cooperative", "tcv_batch_cooperative", "tcv_batch_get_priors", "tcv_batch_marg_status", "tcv_eval_projection_td_factors", "tcv_match_lines",
     "tcv_batch_download_priors", "tcv_batch_download_priors_compact",
     "tcv_batch_get_priors_device", "tcv_batch_get_priors_device_async", "tcv_prior_is_device_resident", "tcv_problem_set_marginalization_prior",
     "tcv_problems_set_marginalization_prior", "tcv_priors_destroy",
@@ -173,6 +173,7 @@ def lib():
         L.tcv_problem_set_frames.argtypes = [vp, C.c_int, C.POINTER(_dp), C.POINTER(_dp)]
         L.tcv_gauge_fix.argtypes = [C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
         L.tcv_batch_gauge_fix.argtypes = [vp, vp]
+        L.tcv_batch_set_fused_gauge_fix.argtypes = [vp, C.c_int]
         L.tcv_batch_marg_status.argtypes = [vp, _ip, C.c_int]
         L.tcv_match_lines.argtypes = [C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_int, _ip, _dp, C.c_double,
                                       C.c_double, C.c_int, C.POINTER(C.c_ubyte), _ip, C.POINTER(C.c_float), _dp]
@@ -521,6 +522,10 @@ class Batch:
     def gauge_fix(self, stream=None):
         """Estimator::double2vector() + vector2double() in place on the solved states in HBM (estimator.cpp:1537-1581)."""
         check(lib().tcv_batch_gauge_fix(self.h, stream))
+
+    def fuse_gauge_fix(self, on=True):
+        """tcv_batch_set_fused_gauge_fix: the same fix in the solve kernel's epilogue; `gauge_fix()` behind such a solve is a no-op."""
+        check(lib().tcv_batch_set_fused_gauge_fix(self.h, int(on)))
 
     def synchronize(self):
         check(lib().tcv_batch_synchronize(self.h))

@@ -62,3 +62,36 @@ def test_batch_gauge_fix_in_place_after_solve(gpu):
             cur = {"pose": W[k].pose, "sb": W[k].sb}.get(name)
             if cur is not None:
                 assert np.array_equal(x0, cur[idx + 1]), (name, idx)
+
+
+def test_gauge_fix_in_the_solve_kernels_epilogue_is_the_stand_alone_kernel_bit_for_bit(gpu):
+    """tcv_batch_set_fused_gauge_fix: double2vector() applied to the solved states while they are still in LDS (one launch less per frame).  Same
+    arithmetic as tcv_batch_gauge_fix's kernel -- states, the marginalisation that linearises at them, and a later stand-alone call (a no-op) all
+    agree bit for bit; in the packed two-per-CU shape, one workgroup per window, the cooperative mode and the dense layout."""
+    L = gpu.lib()
+
+    def run(B, seed, fused, variant=0, wg=0):
+        L.tcv_set_solver_variant(variant)
+        try:
+            batch = synth.make_windows(seed, B, frame_shift=-1)
+            wins = [synth.window_at(batch, k) for k in range(B)]
+            W = [gpu.Window(w) for w in wins]
+            MW = [gpu.margin_old_window(w) for w in wins]
+            M = [gpu.Window(mw, share=W[k]) for k, mw in enumerate(MW)]
+            drops = [gpu.margin_old_drops(W[k], MW[k]) for k in range(B)]
+            b = gpu.Batch(W, M, drops)
+            if fused:
+                b.fuse_gauge_fix()
+            o = gpu.default_options(8, True)
+            o.workgroups_per_window = wg
+            b.solve(o); b.gauge_fix(); b.marginalize(); b.synchronize(); b.download_states()
+            pri = [b.prior(k).export() for k in range(B)]
+            return [(W[k].pose.copy(), W[k].sb.copy(), W[k].ex.copy(), W[k].lam.copy(), pri[k]["J0"], pri[k]["r0"]) for k in range(B)]
+        finally:
+            L.tcv_set_solver_variant(0)
+
+    for B, seed, variant, wg in ((3, 4300, 0, 0), (3, 4300, 0, 1), (300, 4400, 0, 0), (3, 4300, 1, 0)):      # cooperative | one workgroup | two per CU | dense
+        a, f = run(B, seed, False, variant, wg), run(B, seed, True, variant, wg)
+        for x, y in zip(a, f):
+            for u, v in zip(x, y):
+                assert np.array_equal(u, v)
