@@ -699,6 +699,7 @@ extern "C" int tcv_prior_export(const tcv_prior *pr, int *size, int *idx, double
 }
 // parity/debug: the Schur system (A' n x n row-major, b') the prior was factored from; TCV_ERR_INVALID if not recorded
 extern "C" int tcv_prior_export_schur(const tcv_prior *pr, double *As, double *bs) {
+    if (pr && pr->n == 0) return TCV_OK;      // (the empty prior of a marginalisation that kept nothing: nothing to copy)
     if (!pr || pr->As.empty()) { set_error("prior carries no Schur system"); return TCV_ERR_INVALID; }
     if (As) std::copy(pr->As.begin(), pr->As.end(), As);
     if (bs) std::copy(pr->bs.begin(), pr->bs.end(), bs);

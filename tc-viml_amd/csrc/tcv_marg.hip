@@ -2302,8 +2302,10 @@ static int pack_marg(const tcv_problem &p, double *const *drop, int ndrop, const
         pos += pb.kind == KIND_POSE ? 6 : pb.size;
     }
     const int n = pos - m;
-    if (m_all < 1) { set_error("marginalize: nothing to drop"); return TCV_ERR_INVALID; }
+    // nothing kept -- every touched block is dropped, or the problem holds no factor at all (frame 0 without a prior, its IMU factor left out,
+    // nothing anchored in it): the reference's marginalize() runs with n = 0 (and m = 0 in the second case) and leaves an empty MarginalizationInfo
     if (n < 1) { mw.m_total = m_all; mw.empty_keep = true; return MARG_PACK_EMPTY_KEEP; }      // (the caller writes a header the kernel skips)
+    if (m_all < 1) { set_error("marginalize: none of the dropped blocks is touched by a factor (m = 0, n > 0: the kernel has no path without a dropped block)"); return TCV_ERR_INVALID; }
     if (block_mode && m < 1) { set_error("marginalize: block mode needs a non-landmark block in the dropped set"); return TCV_ERR_UNSUPPORTED; }
     mw.m_total = m_all;
     if (m > MARG_MAX_M || n > MARG_MAX_N || nx > MARG_MAX_X || p.imu.size() > 16) {

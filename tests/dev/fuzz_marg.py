@@ -67,6 +67,8 @@ def main():
         else:
             if (d["m"], d["n"]) != (po["m"], po["n"]):
                 verdict, detail = "LAYOUT", f"m, n {d['m']}, {d['n']} vs {po['m']}, {po['n']}"
+            elif d["n"] == 0:      # a marginalisation that keeps nothing: the reference's empty MarginalizationInfo on both sides
+                verdict, detail = "ok", f"empty prior (m {d['m']}, n 0)"
             else:
                 eA, eb = fro(As, dbg["A_schur"]), fro(bs, dbg["b_schur"])
                 eJ, er = fro(d["J0"].T @ d["J0"], dbg["A_schur"]), fro(d["J0"].T @ d["r0"], dbg["b_schur"])

@@ -621,6 +621,17 @@ def test_marginalisation_that_keeps_nothing_returns_the_references_empty_prior(g
     b3 = gpu.Batch([Wr], [Mr], [gpu.margin_old_drops(Wr, mk)])
     b3.solve(gpu.default_options(8, True)); b3.marginalize(); b3.synchronize()
     assert np.array_equal(p0.export()["J0"], b3.prior(0).export()["J0"])      # the empty neighbour changes nothing for the others
+    # no factor at all (frame 0 without a prior, its IMU factor left out, nothing anchored in it -- fuzz seed 6139): m = 0 and n = 0 in the reference, too
+    nimu = len(mw["imu"]["frame_i"])
+    mw0 = dict(mw, imu={k: (np.asarray(v)[none] if isinstance(v, np.ndarray) and v.shape[:1] == (nimu,) else v) for k, v in mw["imu"].items()})
+    W0m = gpu.Window(mw0)
+    dr0 = [W0m.block_ptr("pose", 0), W0m.block_ptr("sb", 0)]
+    h0 = C.c_void_p()
+    gpu.check(L.tcv_marginalize(W0m.h, (gpu._dp * 2)(*dr0), 2, C.byref(h0)))
+    P0 = gpu.Prior(h0)
+    assert P0.dims() == (0, 0, 0, 0)
+    As0, bs0 = P0.schur()
+    assert As0.shape == (0, 0)
     # a prior built by hand with n = 0 (checkpoint of such a state)
     h2 = C.c_void_p()
     gpu.check(L.tcv_prior_create(C.byref(h2), 30, 0, 0, None, None, None, None, None))
