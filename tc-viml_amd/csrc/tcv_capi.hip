@@ -196,16 +196,29 @@ struct StreamPark { std::mutex mu; std::multimap<int, hipStream_t> idle; std::ma
 StreamPark &stream_park() { static StreamPark *p = new StreamPark(); return *p; }
 hipStream_t take_parked_stream(int dev) {
     StreamPark &P = stream_park();
-    std::lock_guard<std::mutex> g(P.mu);
-    auto it = P.idle.find(dev);
-    if (it == P.idle.end()) return nullptr;
-    hipStream_t st = it->second;
-    P.idle.erase(it);
-    auto oi = P.orphans.find(st);
-    if (oi != P.orphans.end()) {      // what the stream's previous thread left in flight has long finished, as a rule: wait (here a HIP call is fine) and release
-        (void)hipStreamSynchronize(st);
-        for (auto &x : oi->second) { host_staging_release(x.h); (void)dev_free(x.d); }
-        P.orphans.erase(oi);
+    hipStream_t st = nullptr;
+    std::vector<std::pair<hipStream_t, std::vector<Deferred>>> drain;      // waited for and released OUTSIDE the lock: every ending thread's destructor needs it
+    {
+        std::lock_guard<std::mutex> g(P.mu);
+        auto it = P.idle.find(dev);
+        if (it != P.idle.end()) {
+            st = it->second;
+            P.idle.erase(it);
+            auto oi = P.orphans.find(st);
+            if (oi != P.orphans.end()) { drain.emplace_back(st, std::move(oi->second)); P.orphans.erase(oi); }
+        }
+        // orphans nobody will ever adopt -- commands a thread left on the NULL stream (its stream creation had failed), or on a stream that is not
+        // parked (the ending thread's aux stream was its main stream) -- would keep their pinned staging and device memory for the life of the
+        // process: whoever comes by for a stream takes them along
+        for (auto oi = P.orphans.begin(); oi != P.orphans.end();) {
+            bool parked = false;
+            for (auto &kv : P.idle) if (kv.second == oi->first) { parked = true; break; }
+            if (!parked) { drain.emplace_back(oi->first, std::move(oi->second)); oi = P.orphans.erase(oi); } else ++oi;
+        }
+    }
+    for (auto &d : drain) {      // what a stream's previous thread left in flight has long finished, as a rule: wait (here a HIP call is fine) and release
+        (void)(d.first ? hipStreamSynchronize(d.first) : hipDeviceSynchronize());
+        for (auto &x : d.second) { host_staging_release(x.h); (void)dev_free(x.d); }
     }
     return st;
 }

@@ -129,9 +129,7 @@ __global__ void __launch_bounds__(PRE_NT) preint_kernel(PreintArgs A) {
 #pragma unroll
             for (int e = 0; e < 9; e++) { B[e] = R0.m[e]; B[9 + e] = R1.m[e]; B[18 + e] = M0.m[e]; B[27 + e] = M1.m[e]; B[36 + e] = M1B.m[e]; B[45 + e] = Bm.m[e]; }
         };
-        auto sample_at = [&](int k, double (&o)[7]) {      // sample k of this buffer: out of the LDS chunk that holds it, or (the state wave looking one sample
-            const int c0 = (k / SMP_CHUNK) * SMP_CHUNK;   // ahead across a chunk boundary) straight from memory
-            (void)c0;
+        auto sample_at = [&](int k, double (&o)[7]) {      // sample k straight from memory: the state wave looking one sample ahead across a chunk boundary
 #pragma unroll
             for (int i = 0; i < 7; i++) o[i] = A.samples[(size_t)(s0 + k) * 7 + i];
         };
