@@ -1,4 +1,5 @@
 #!/bin/bash
+# (provenance of profiles/r06_preint_scan.txt: preint_scan_kernel and its TCV_PREINT_SEQ switch were removed again after this measurement)
 # round 6, GPU call m: pre-integration as a scan over the samples (preint_scan_kernel) against the sample-by-sample kernel (TCV_PREINT_SEQ=1): parity, kernel
 # durations in a replay, throughput
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r06m; mkdir -p $O; cd $R
